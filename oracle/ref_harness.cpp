@@ -1,0 +1,574 @@
+// ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (parity oracle), never shipped, never on the product path.
+//
+// Our own driver around the *reference's* CPU alignment path, linked against the reference's
+// objects compiled where they lie (see oracle/ref.mk).  It stands in for main()/alignment.cu
+// (CUDA translation units that cannot be built here) and routes every read through the
+// reference's CPU twin of the GPU kernel:
+//      ProcessReadDoubleStrand2            CPUfunctions.cpp:555
+//      BWTModelSwitch*2 / *_Lookup2 / _CE2 BGS-HostAlgnmtAlgo2.cpp:36-1728
+//      hostKernelThreadWrapper             CPUfunctions.cpp:3022   (mode "sam")
+//
+// Modes
+//   models <out>                                  dump SRAModel case/step tables (SRA2BWTMdl.c:1171,4411)
+//   search <ini> <index> <reads> <L> <mm> <out>   per read / per case SA ranges + CE hits, reference order
+//   sam    <ini> single <index> <reads> [soap3-dp options]   all-best / all-valid single-end SAM
+//          (mirrors all_best_single_alignment, alignment.cu:1422-1465, and all_valid_alignment,
+//           alignment.cu:534-1115, with every (read,case) answer marked "resolve on CPU")
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+#include <zlib.h>
+#include <vector>
+
+#include "CPUfunctions.h"
+#include "QueryParser.h"
+#include "IndexHandler.h"
+#include "SAM.h"
+#include "2bwt-lib/Timing.h"
+
+// defined (non-static) in CPUfunctions.cpp but not declared in its header
+unsigned long long ProcessReadDoubleStrand2 ( SRAQueryInput * qInput, SRAQueryInput * qInput_neg, SRAModel * aModel, SRAModel * aModel_neg,
+        int whichCase, SAList * sa_list, OCCList * occ_list );
+
+static void dumpModels ( const char * outName )
+{
+    FILE * f = fopen ( outName, "w" );
+    SRASetting st;
+    memset ( &st, 0, sizeof ( st ) );
+    st.ErrorType = SRA_STEP_ERROR_TYPE_MISMATCH_ONLY;
+    st.OutputType = SRA_REPORT_ALL;
+    st.MaxNBMismatch = 0;
+    SRAIndex idx;
+    memset ( &idx, 0, sizeof ( idx ) );
+    SRAModel * m = ( SRAModel * ) malloc ( sizeof ( SRAModel ) );
+
+    for ( int L = 25; L <= 1024; L++ )
+    {
+        for ( int e = 0; e <= 4; e++ )
+        {
+            st.MaxError = e;
+            SRAModelPopulate ( m, L, QUERY_POS_STRAND, &st, &idx, SRA_MODEL_16G );
+
+            for ( int c = 0; c < MAX_NUM_OF_SRA_CASES; c++ )
+            {
+                if ( m->cases[c].type != SRA_CASE_TYPE_ALIGNMENT ) { break; }
+
+                fprintf ( f, "L %d E %d C %d id %d :", L, e, c, m->cases[c].id );
+
+                for ( int s = 0; s < MAX_NUM_OF_SRA_STEPS; s++ )
+                {
+                    SRAStep * p = &m->cases[c].steps[s];
+
+                    if ( p->type == SRA_STEP_TYPE_COMPLETE ) { break; }
+
+                    fprintf ( f, " [%d %d %d ce %d %d %d err %d %d %d]", ( int ) p->type, p->start, p->end, p->ceThreshold, p->ceStart, p->ceEnd,
+                              ( int ) p->ErrorType, ( int ) p->MinError, ( int ) p->MaxError );
+                }
+
+                // leftMostAligned is derived data; a checksum over the positions the case visits pins it
+                unsigned long long h = 1469598103934665603ULL;
+
+                for ( int s = 0; s < MAX_NUM_OF_SRA_STEPS; s++ )
+                {
+                    SRAStep * p = &m->cases[c].steps[s];
+
+                    if ( p->type == SRA_STEP_TYPE_COMPLETE ) { break; }
+
+                    for ( int q = 0; q < p->len; q++ )
+                    {
+                        int pos = p->start + p->step * q;
+                        h = ( h ^ ( unsigned long long ) ( unsigned int ) m->cases[c].leftMostAligned[pos] ) * 1099511628211ULL;
+                    }
+                }
+
+                fprintf ( f, " lma %016llx\n", h );
+            }
+        }
+    }
+
+    free ( m );
+    fclose ( f );
+}
+
+struct Reads
+{
+    uint * queries;
+    uint * readLengths;
+    uint * readIDs;
+    char * upkdQualities;
+    char * upkdQueryNames;
+    uint numQueries;
+    uint wordPerQuery;
+    uint maxReadLength;
+    char isFastq;
+};
+
+static Reads loadReads ( const char * fileName, unsigned char * charMap, uint maxReadLength, int maxLenReadName, uint maxNumQueries )
+{
+    Reads R;
+    R.maxReadLength = maxReadLength;
+    uint wpq = 1;
+
+    while ( wpq < maxReadLength ) { wpq *= 2; }
+
+    R.wordPerQuery = wpq / CHAR_PER_WORD;
+    size_t roundUp = ( ( size_t ) maxNumQueries + 31 ) / 32 * 32;
+    R.queries = ( uint * ) calloc ( roundUp * R.wordPerQuery, sizeof ( uint ) );
+    R.readLengths = ( uint * ) calloc ( roundUp, sizeof ( uint ) );
+    R.readIDs = ( uint * ) calloc ( roundUp, sizeof ( uint ) );
+    R.upkdQualities = ( char * ) calloc ( roundUp * maxReadLength, 1 );
+    R.upkdQueryNames = ( char * ) calloc ( roundUp * maxLenReadName, 1 );
+    gzFile gz = gzopen ( fileName, "r" );
+
+    if ( gz == NULL ) { fprintf ( stderr, "cannot open %s\n", fileName ); exit ( 1 ); }
+
+    char * buf = ( char * ) malloc ( INPUT_BUFFER_SIZE );
+    size_t bufferSize = gzread ( gz, buf, INPUT_BUFFER_SIZE );
+    uint bufferIndex = 0;
+    char queryChar = buf[bufferIndex++];
+    R.isFastq = 0;
+    R.numQueries = loadSingleReadsGz ( gz, buf, charMap, R.queries, R.readLengths, R.readIDs, R.upkdQualities, R.upkdQueryNames,
+                                       maxReadLength, maxNumQueries, bufferSize, queryChar, bufferIndex, 0, R.wordPerQuery,
+                                       DEFAULT_QUAL_CONST, R.isFastq, maxLenReadName );
+    gzclose ( gz );
+    free ( buf );
+    return R;
+}
+
+static void initHspAux ( Soap3Index * index, IniParams & ini, InputOptions & opt, size_t roundUp )
+{
+    HSPAux * hspaux = index->sraIndex->hspaux;
+    memset ( hspaux, 0, sizeof ( HSPAux ) );
+    hspaux->dpMatchScore = ini.Ini_MatchScore;
+    hspaux->dpMisMatchScore = ini.Ini_MismatchScore;
+    hspaux->alignmentType = opt.alignmentType;
+    hspaux->readType = opt.readType;
+    hspaux->peMaxOutputPerRead = ini.Ini_PEMaxOutputPerPair;
+    hspaux->ProceedDPForTooManyHits = ini.Ini_proceedDPForTooManyHits;
+    hspaux->x0_array = ( int * ) malloc ( roundUp * sizeof ( int ) );
+    hspaux->x1_array = ( int * ) malloc ( roundUp * sizeof ( int ) );
+    hspaux->mismatch_array = ( int * ) malloc ( roundUp * sizeof ( int ) );
+    hspaux->minMAPQ = ini.Ini_minMAPQ;
+    hspaux->maxMAPQ = ini.Ini_maxMAPQ;
+    hspaux->bwaLikeScore = ini.Ini_bwaLikeScore;
+    hspaux->maxLenReadName = ini.Ini_maxReadNameLen;
+
+    if ( hspaux->bwaLikeScore ) { bwase_initialize ( hspaux->g_log_n ); }
+
+    hspaux->soap3AnsArray = malloc ( roundUp * sizeof ( void * ) );
+    hspaux->sa_start = ( unsigned int * ) malloc ( roundUp * sizeof ( unsigned int ) );
+    hspaux->occ_start = ( unsigned int * ) malloc ( roundUp * sizeof ( unsigned int ) );
+    hspaux->sa_num = ( unsigned int * ) malloc ( roundUp * sizeof ( unsigned int ) );
+    hspaux->occ_num = ( unsigned int * ) malloc ( roundUp * sizeof ( unsigned int ) );
+    hspaux->isPrintMDNM = opt.isPrintMDNM;
+    hspaux->readGroup = opt.readGroup;
+
+    if ( hspaux->readGroup == NULL || strlen ( hspaux->readGroup ) == 0 ) { hspaux->readGroup = opt.queryFileName; }
+
+    hspaux->sampleName = opt.sampleName;
+
+    if ( hspaux->sampleName == NULL || strlen ( hspaux->sampleName ) == 0 ) { hspaux->sampleName = ( char * ) DEFAULT_SAMPLE_NAME; }
+
+    hspaux->readGrpOption = opt.readGrpOption;
+    hspaux->readsIDForSingleDP = ( BothUnalignedPairsArrays * ) constructBothUnalignedPairsArrays ( 1 );
+    hspaux->allHits = ( AllHits * ) constructAllHits ();
+}
+
+// ---------------------------------------------------------------------------------------------
+// mode "search": dump what the CPU twin finds, case by case, in its own emission order
+static int modeSearch ( int argc, char ** argv )
+{
+    if ( argc < 8 ) { fprintf ( stderr, "search <ini> <index> <reads> <L> <mm> <out>\n" ); return 1; }
+
+    IniParams ini;
+
+    if ( ParseIniFile ( argv[2], ini ) != 0 ) { fprintf ( stderr, "bad ini\n" ); return 1; }
+
+    char * indexName = argv[3];
+    uint maxReadLength = atoi ( argv[5] );
+    int mm = atoi ( argv[6] );
+    Soap3Index * index = INDEXLoad ( &ini, indexName, 0 );
+    InputOptions opt;
+    memset ( &opt, 0, sizeof ( opt ) );
+    opt.alignmentType = OUTPUT_ALL_VALID;
+    opt.readType = SINGLE_READ;
+    opt.queryFileName = argv[4];
+    initHspAux ( index, ini, opt, 1024 );
+    Reads R = loadReads ( argv[4], index->charMap, maxReadLength, ini.Ini_maxReadNameLen, 1 << 22 );
+    fprintf ( stderr, "[harness] %u reads loaded\n", R.numQueries );
+    SRASetting st;
+    memset ( &st, 0, sizeof ( st ) );
+    st.occ = OCCConstruct ();
+    st.OutFileFormat = SRA_OUTPUT_FORMAT_SAM_API;
+    st.MaxOutputPerRead = ini.Ini_MaxOutputPerRead;
+    st.ReadStrand = QUERY_BOTH_STRAND;
+    st.ErrorType = SRA_STEP_ERROR_TYPE_MISMATCH_ONLY;
+    st.OutputType = SRA_REPORT_ALL;
+    st.MaxError = mm;
+    st.MaxNBMismatch = 0;
+    SRAQueryResultCount rOut;
+    memset ( &rOut, 0, sizeof ( rOut ) );
+    SRAModel * models[MAX_READ_LENGTH + 1];
+    memset ( models, 0, sizeof ( models ) );
+    int numCases = GetNumCases ( mm );
+    char dummyQuality[MAX_READ_LENGTH];
+    memset ( dummyQuality, 1, sizeof ( dummyQuality ) );
+    SRAQueryInfo qiP, qiN;
+    SRAQueryInput qP, qN;
+    memset ( &qiP, 0, sizeof ( qiP ) );
+    memset ( &qiN, 0, sizeof ( qiN ) );
+    qiP.ReadStrand = QUERY_POS_STRAND;
+    qiP.ReadQuality = dummyQuality;
+    qiN.ReadStrand = QUERY_NEG_STRAND;
+    qiN.ReadQuality = dummyQuality;
+    qP.QueryInfo = &qiP; qP.QuerySetting = &st; qP.AlgnmtIndex = index->sraIndex; qP.QueryOutput = &rOut;
+    qN.QueryInfo = &qiN; qN.QuerySetting = &st; qN.AlgnmtIndex = index->sraIndex; qN.QueryOutput = &rOut;
+    SAList * sa_list = SAListConstruct ();
+    OCCList * occ_list = OCCListConstruct ();
+    FILE * f = fopen ( argv[7], "w" );
+    unsigned char fwd[MAX_READ_LENGTH], rev[MAX_READ_LENGTH];
+    double t0 = setStartTime ();
+
+    for ( uint r = 0; r < R.numQueries; r++ )
+    {
+        int L = R.readLengths[r];
+
+        if ( models[L] == NULL ) { models[L] = SRAModelConstruct ( L, QUERY_POS_STRAND, &st, index->sraIndex, ini.Ini_HostAlignmentModel ); }
+
+        retrieve2BWTQueryFormat ( R.queries, r, R.wordPerQuery, fwd );
+
+        for ( int i = 0; i < L; i++ ) { rev[i] = soap3DnaComplement[fwd[L - i - 1]]; }
+
+        qiP.ReadCode = fwd; qiP.ReadLength = L; qiP.ReadId = r + 1;
+        qiN.ReadCode = rev; qiN.ReadLength = L; qiN.ReadId = r + 1;
+        // per read reset, as collect_all_answers does (CPUfunctions.cpp:1246-1247)
+        rOut.TotalOccurrences = 0;
+        memset ( rOut.WithError, 0, sizeof ( rOut.WithError ) );
+        SAListReset ( sa_list );
+        OCCListReset ( occ_list );
+
+        for ( int c = 0; c < numCases; c++ )
+        {
+            unsigned int sa0 = sa_list->curr_size, oc0 = occ_list->curr_size;
+            ProcessReadDoubleStrand2 ( &qP, &qN, models[L], models[L], c, sa_list, occ_list );
+
+            for ( unsigned int k = sa0; k < sa_list->curr_size; k++ )
+            {
+                fprintf ( f, "%u %d S %u %u %d %d\n", r, c, sa_list->sa[k].saIndexLeft, sa_list->sa[k].saIndexRight,
+                          ( int ) sa_list->sa[k].strand, ( int ) sa_list->sa[k].mismatchCount );
+            }
+
+            for ( unsigned int k = oc0; k < occ_list->curr_size; k++ )
+            {
+                fprintf ( f, "%u %d O %u %u %d %d\n", r, c, ( unsigned int ) occ_list->occ[k].ambPosition, ( unsigned int ) occ_list->occ[k].ambPosition,
+                          ( int ) occ_list->occ[k].strand, ( int ) occ_list->occ[k].mismatchCount );
+            }
+        }
+
+        fprintf ( f, "%u T %u", r, rOut.TotalOccurrences );
+
+        for ( int e = 0; e <= 4; e++ ) { fprintf ( f, " %u", rOut.WithError[e] ); }
+
+        fprintf ( f, "\n" );
+    }
+
+    double dt = getElapsedTime ( t0 );
+    fprintf ( stderr, "[harness] search mm=%d: %u reads in %.3f s (%.1f reads/s, 1 thread)\n", mm, R.numQueries, dt, R.numQueries / dt );
+    fclose ( f );
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mode "sam": reference host pipeline, single-end, with every answer resolved by the CPU twin
+struct Ctx
+{
+    Soap3Index * index;
+    IniParams ini;
+    InputOptions opt;
+    samfile_t * samOut;
+    char * outName;
+};
+
+static void allValid ( Ctx & C, Reads & R, uint * queries, uint * readLengths, uint * seedLengths, uint * readIDs, uint numQueries, uint numMismatch,
+                       uint * unAlignedReads, uint & numOfUnAligned, unsigned long long & numOfAnswer, uint & numOfAlignedRead,
+                       uint8_t isTerminalCase )
+{
+    // mirrors all_valid_alignment (alignment.cu:534-1115) with one CPU thread and one batch
+    uint numCases, sa1, sa2, wpa, wpa2;
+    char skip2;
+    getParametersForThisMismatch ( numMismatch, numCases, sa1, sa2, skip2, wpa, wpa2 );
+    bool needOutputMAPQ = ( C.opt.alignmentType == OUTPUT_ALL_VALID || C.opt.alignmentType == OUTPUT_ALL_BEST ) &&
+                          ( C.opt.outputFormat == SRA_OUTPUT_FORMAT_SAM_API );
+    HostKernelArguements * hk = ( HostKernelArguements * ) calloc ( MAX_NUM_CPU_THREADS, sizeof ( HostKernelArguements ) );
+    pthread_t threads[MAX_NUM_CPU_THREADS];
+    IniParams ini1 = C.ini;
+    ini1.Ini_NumOfCpuThreads = 1;
+    setHostKernelArguments ( hk, threads, ini1, C.index, R.maxReadLength, R.wordPerQuery, wpa, &C.opt );
+    static SRAModel * M[MAX_READ_LENGTH + 1], * M2[MAX_READ_LENGTH + 1], * Mn[MAX_READ_LENGTH + 1], * M2n[MAX_READ_LENGTH + 1];
+    memset ( M, 0, sizeof ( M ) ); memset ( M2, 0, sizeof ( M2 ) ); memset ( Mn, 0, sizeof ( Mn ) ); memset ( M2n, 0, sizeof ( M2n ) );
+    hk[0].upkdQualities = R.upkdQualities;
+    hk[0].upkdQueryNames = R.upkdQueryNames;
+    hk[0].SRAMismatchModel = M; hk[0].SRAMismatchModel2 = M2; hk[0].SRAMismatchModel_neg = Mn; hk[0].SRAMismatchModel2_neg = M2n;
+    hk[0].outputFileName = C.outName;
+    hk[0].readLengths = readLengths;
+    hk[0].seedLengths = seedLengths;
+    hk[0].readIDs = readIDs;
+    hk[0].accumReadNum = 0;
+    uint * unAlignedId = ( uint * ) malloc ( ( ( size_t ) numQueries + 32 ) * sizeof ( uint ) );
+    hk[0].unAlignedIDs = unAlignedId;
+    hk[0].unAlignedOcc = 0;
+    hk[0].sraQuerySettings.MaxError = numMismatch;
+    hk[0].sraQuerySettings.MaxNBMismatch = 0;
+    hk[0].numCases = numCases;
+    hk[0].numCases2 = GetNumCases ( numMismatch + 1 );
+    hk[0].sa_range_allowed_1 = sa1;
+    hk[0].sa_range_allowed_2 = sa2;
+    hk[0].maxNumMismatch = numMismatch;
+    hk[0].bothUnalignedPairs = ( ( BothUnalignedPairsArrays * ) C.index->sraIndex->hspaux->readsIDForSingleDP )->array[0];
+    hk[0].sraQuerySettings.SAMOutFilePtr = C.samOut;
+    uint * lens = seedLengths ? seedLengths : readLengths;
+
+    for ( uint r = 0; r < numQueries; r++ )
+    {
+        uint L = lens[r];
+
+        if ( M[L] == NULL )
+        {
+            M[L] = SRAModelConstruct ( L, QUERY_POS_STRAND, &hk[0].sraQuerySettings, C.index->sraIndex, C.ini.Ini_HostAlignmentModel );
+            Mn[L] = SRAModelConstruct ( L, QUERY_NEG_STRAND, &hk[0].sraQuerySettings, C.index->sraIndex, C.ini.Ini_HostAlignmentModel );
+        }
+    }
+
+    if ( needOutputMAPQ && numMismatch < 4 )
+    {
+        SRASetting tmp;
+        memcpy ( &tmp, &hk[0].sraQuerySettings, sizeof ( SRASetting ) );
+        tmp.MaxError = numMismatch + 1;
+
+        for ( uint r = 0; r < numQueries; r++ )
+        {
+            uint L = lens[r];
+
+            if ( M2[L] == NULL )
+            {
+                M2[L] = SRAModelConstruct ( L, QUERY_POS_STRAND, &tmp, C.index->sraIndex, C.ini.Ini_HostAlignmentModel );
+                M2n[L] = SRAModelConstruct ( L, QUERY_NEG_STRAND, &tmp, C.index->sraIndex, C.ini.Ini_HostAlignmentModel );
+            }
+        }
+    }
+
+    // answers: every (read, case) is "too many SA ranges => resolve on CPU" (0xFFFFFFFE), except
+    // that a case with no hit must say 0xFFFFFFFD so that `nohit` stays honest (CPUfunctions.cpp:1750-1752)
+    size_t roundUp = ( ( size_t ) numQueries + 31 ) / 32 * 32;
+    uint * answers[MAX_NUM_CASES];
+    {
+        SRAQueryResultCount rOut;
+        memset ( &rOut, 0, sizeof ( rOut ) );
+        char dummyQuality[MAX_READ_LENGTH];
+        memset ( dummyQuality, 1, sizeof ( dummyQuality ) );
+        SRAQueryInfo qiP, qiN;
+        SRAQueryInput qP, qN;
+        memset ( &qiP, 0, sizeof ( qiP ) ); memset ( &qiN, 0, sizeof ( qiN ) );
+        qiP.ReadStrand = QUERY_POS_STRAND; qiP.ReadQuality = dummyQuality;
+        qiN.ReadStrand = QUERY_NEG_STRAND; qiN.ReadQuality = dummyQuality;
+        qP.QueryInfo = &qiP; qP.QuerySetting = &hk[0].sraQuerySettings; qP.AlgnmtIndex = &hk[0].sraIndex; qP.QueryOutput = &rOut;
+        qN.QueryInfo = &qiN; qN.QuerySetting = &hk[0].sraQuerySettings; qN.AlgnmtIndex = &hk[0].sraIndex; qN.QueryOutput = &rOut;
+        SAList * sl = SAListConstruct ();
+        OCCList * ol = OCCListConstruct ();
+        unsigned char fwd[MAX_READ_LENGTH], rev[MAX_READ_LENGTH];
+
+        for ( uint c = 0; c < numCases; c++ )
+        {
+            answers[c] = ( uint * ) malloc ( roundUp * wpa * sizeof ( uint ) );
+            memset ( answers[c], 0xFF, roundUp * wpa * sizeof ( uint ) );
+        }
+
+        for ( uint r = 0; r < numQueries; r++ )
+        {
+            int L = lens[r];
+            retrieve2BWTQueryFormat ( queries, r, R.wordPerQuery, fwd );
+
+            for ( int i = 0; i < L; i++ ) { rev[i] = soap3DnaComplement[fwd[L - i - 1]]; }
+
+            qiP.ReadCode = fwd; qiP.ReadLength = L;
+            qiN.ReadCode = rev; qiN.ReadLength = L;
+
+            for ( uint c = 0; c < numCases; c++ )
+            {
+                rOut.TotalOccurrences = 0;
+                SAListReset ( sl );
+                OCCListReset ( ol );
+                ProcessReadDoubleStrand2 ( &qP, &qN, M[L], Mn[L], c, sl, ol );
+                bool hit = ( sl->curr_size > 0 || ol->curr_size > 0 );
+                answers[c][ ( size_t ) r / 32 * 32 * wpa + r % 32] = hit ? 0xFFFFFFFE : 0xFFFFFFFD;
+            }
+        }
+
+        SAListFree ( sl );
+        OCCListFree ( ol );
+    }
+    uint zeros[MAX_NUM_CASES];
+    memset ( zeros, 0, sizeof ( zeros ) );
+    hk[0].batchFirstReadId = 0;
+    hk[0].skipFirst = 0;
+    hk[0].numQueries = numQueries;
+    hk[0].word_per_query = R.wordPerQuery;
+    hk[0].queries = queries;
+    hk[0].answers = answers;
+    hk[0].alignedOcc = 0;
+    hk[0].alignedReads = 0;
+    hk[0].badReadIndices = NULL;
+    hk[0].badAnswers = NULL;
+    hk[0].badStartOffset = zeros;
+    hk[0].badCountOffset = zeros;
+    hk[0].outputGoodReads = TRUE;
+    hk[0].skip_round_2 = 1;
+    hk[0].isTerminalCase = isTerminalCase;
+    pthread_t th;
+    pthread_create ( &th, NULL, hostKernelThreadWrapper, ( void * ) &hk[0] );
+    pthread_join ( th, NULL );
+    numOfAnswer = hk[0].alignedOcc;
+    numOfAlignedRead = hk[0].alignedReads;
+    numOfUnAligned = hk[0].unAlignedOcc;
+    memcpy ( unAlignedReads, unAlignedId, ( size_t ) numOfUnAligned * sizeof ( uint ) );
+
+    for ( uint c = 0; c < numCases; c++ ) { free ( answers[c] ); }
+
+    for ( int i = 0; i <= MAX_READ_LENGTH; i++ )
+    {
+        if ( M[i] ) { SRAModelFree ( M[i] ); }
+
+        if ( M2[i] ) { SRAModelFree ( M2[i] ); }
+
+        if ( Mn[i] ) { SRAModelFree ( Mn[i] ); }
+
+        if ( M2n[i] ) { SRAModelFree ( M2n[i] ); }
+    }
+
+    OCCFree ( hk[0].occ );
+    free ( unAlignedId );
+    free ( hk );
+}
+
+static int modeSam ( int argc, char ** argv )
+{
+    // argv: ref_harness sam <ini> single <index> <reads> [options]
+    if ( argc < 6 ) { fprintf ( stderr, "sam <ini> single <index> <reads> [soap3-dp options]\n" ); return 1; }
+
+    Ctx C;
+
+    if ( ParseIniFile ( argv[2], C.ini ) != 0 ) { fprintf ( stderr, "bad ini\n" ); return 1; }
+
+    memset ( &C.opt, 0, sizeof ( C.opt ) );
+    argv[2] = argv[0];
+
+    if ( !parseInputArgs ( argc - 2, argv + 2, C.opt ) ) { return 1; }
+
+    if ( C.opt.readType != SINGLE_READ ) { fprintf ( stderr, "harness: single-end only\n" ); return 1; }
+
+    if ( C.opt.enableDP == 1 ) { C.opt.numMismatch = C.ini.Ini_Soap3MisMatchAllow; }
+
+    C.index = INDEXLoad ( &C.ini, C.opt.indexName, 0 );
+    uint maxNumQueries = 1 << 22;
+    size_t roundUp = ( ( size_t ) maxNumQueries + 31 ) / 32 * 32;
+    initHspAux ( C.index, C.ini, C.opt, roundUp );
+    HSP * hsp = C.index->sraIndex->hsp;
+    HSPAux * hspaux = C.index->sraIndex->hspaux;
+    Reads R = loadReads ( C.opt.queryFileName, C.index->charMap, C.opt.maxReadLength, C.ini.Ini_maxReadNameLen, maxNumQueries );
+    hspaux->isFastq = R.isFastq;
+    fprintf ( stderr, "[harness] %u reads loaded, numMismatch=%d alignmentType=%d enableDP=%d outputFormat=%d\n", R.numQueries, C.opt.numMismatch,
+              C.opt.alignmentType, ( int ) C.opt.enableDP, C.opt.outputFormat );
+    C.outName = ( char * ) malloc ( strlen ( C.opt.outputPrefix ) + 16 );
+    sprintf ( C.outName, "%s.gout.1", C.opt.outputPrefix );
+    bam_header_t samHeader;
+    SAMOutputHeaderConstruct ( &samHeader, hsp, hspaux, C.opt.maxReadLength );
+    C.samOut = samopen ( C.outName, "wh", &samHeader );
+    uint * seedLengths = NULL;
+
+    if ( C.opt.maxReadLength > LONG_READ_LEN )
+    {
+        seedLengths = ( uint * ) malloc ( roundUp * sizeof ( uint ) );
+
+        for ( uint i = 0; i < R.numQueries; i++ ) { seedLengths[i] = R.readLengths[i] > LONG_READ_LEN ? SOAP3_SEED_LEN : R.readLengths[i]; }
+    }
+
+    uint * unAligned = ( uint * ) malloc ( roundUp * sizeof ( uint ) );
+    uint numUn = 0, numQueries = R.numQueries;
+    unsigned long long totalAns = 0;
+    uint totalAligned = 0;
+    double t0 = setStartTime ();
+
+    if ( C.opt.alignmentType == OUTPUT_ALL_BEST )
+    {
+        // all_best_single_alignment, alignment.cu:1422-1465
+        uint nm = C.opt.numMismatch;
+
+        for ( uint mm = 1; mm <= ( nm > 0 ? nm : 1 ); mm++ )
+        {
+            unsigned long long a = 0;
+            uint b = 0;
+            allValid ( C, R, R.queries, R.readLengths, seedLengths, R.readIDs, numQueries, mm, unAligned, numUn, a, b, mm >= nm );
+            totalAns += a;
+            totalAligned += b;
+
+            if ( mm < nm )
+            {
+                packUnPairedReads ( R.queries, R.readIDs, R.readLengths, unAligned, R.wordPerQuery, numUn, 1 << 20 );
+
+                if ( seedLengths )
+                {
+                    for ( uint i = 0; i < numUn; i++ ) { seedLengths[i] = R.readLengths[i] > LONG_READ_LEN ? SOAP3_SEED_LEN : R.readLengths[i]; }
+                }
+
+                numQueries = numUn;
+            }
+        }
+    }
+    else if ( C.opt.alignmentType == OUTPUT_ALL_VALID )
+    {
+        unsigned long long a = 0;
+        uint b = 0;
+        allValid ( C, R, R.queries, R.readLengths, seedLengths, R.readIDs, numQueries, C.opt.numMismatch, unAligned, numUn, a, b, 1 );
+        totalAns += a;
+        totalAligned += b;
+    }
+    else
+    {
+        // best_single_alignment, alignment.cu:1377-1420
+        for ( uint mm = 0; mm <= ( uint ) C.opt.numMismatch; mm++ )
+        {
+            unsigned long long a = 0;
+            uint b = 0;
+            allValid ( C, R, R.queries, R.readLengths, seedLengths, R.readIDs, numQueries, mm, unAligned, numUn, a, b, mm == ( uint ) C.opt.numMismatch );
+            totalAns += a;
+            totalAligned += b;
+
+            if ( mm < ( uint ) C.opt.numMismatch )
+            {
+                packUnPairedReads ( R.queries, R.readIDs, R.readLengths, unAligned, R.wordPerQuery, numUn, 1 << 20 );
+                numQueries = numUn;
+            }
+        }
+    }
+
+    double dt = getElapsedTime ( t0 );
+    samclose ( C.samOut );
+    fprintf ( stderr, "[harness] aligned %u of %u reads, %llu alignments, %.3f s (%.1f reads/s, 1 thread)\n", totalAligned, R.numQueries, totalAns, dt,
+              R.numQueries / dt );
+    return 0;
+}
+
+int main ( int argc, char ** argv )
+{
+    if ( argc < 2 ) { fprintf ( stderr, "usage: ref_harness models|search|sam ...\n" ); return 1; }
+
+    if ( strcmp ( argv[1], "models" ) == 0 ) { dumpModels ( argv[2] ); return 0; }
+
+    if ( strcmp ( argv[1], "search" ) == 0 ) { return modeSearch ( argc, argv ); }
+
+    if ( strcmp ( argv[1], "sam" ) == 0 ) { return modeSam ( argc, argv ); }
+
+    fprintf ( stderr, "unknown mode %s\n", argv[1] );
+    return 1;
+}
