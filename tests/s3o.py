@@ -1,0 +1,174 @@
+"""ctypes binding of the CPU oracle (oracle/s3_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "libs3oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(ROOT, "oracle", "s3_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", LIB, src])
+    return LIB
+
+
+class Step(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("type", "start", "end", "ceThreshold", "ceStart", "ceEnd", "minErr", "maxErr", "dir", "len")]
+
+
+class Case(C.Structure):
+    _fields_ = [("id", C.c_int), ("nSteps", C.c_int), ("steps", Step * 5), ("leftMost", C.c_int16 * 1024)]
+
+
+class Model(C.Structure):
+    _fields_ = [("readLength", C.c_int), ("maxError", C.c_int), ("nCases", C.c_int), ("cases", Case * 10)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rankQueries", "ltLookups", "saReads", "ceWords", "hits")]
+
+
+HIT_DTYPE = np.dtype([("a", "<u4"), ("b", "<u4"), ("kind", "u1"), ("strand", "u1"), ("nmis", "u1"), ("cas", "u1")])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+        _lib.s3o_index_load.restype = C.c_void_p
+        _lib.s3o_index_load.argtypes = [C.c_char_p]
+        _lib.s3o_index_free.argtypes = [C.c_void_p]
+        _lib.s3o_model_build.argtypes = [C.c_int, C.c_int, C.POINTER(Model)]
+        _lib.s3o_search_batch.restype = C.c_long
+        _lib.s3o_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32,
+                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        _lib.s3o_decode.restype = C.c_int
+        _lib.s3o_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Stats)]
+    return _lib
+
+
+def model(L, e):
+    m = Model()
+    lib().s3o_model_build(L, e, C.byref(m))
+    return m
+
+
+def model_lma_hash(case):
+    h = 1469598103934665603
+    for s in range(case.nSteps):
+        st = case.steps[s]
+        for q in range(st.len):
+            pos = st.start + st.dir * q
+            h = ((h ^ (case.leftMost[pos] & 0xFFFFFFFF)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def model_lines(L, e):
+    """same text form as `ref_harness models`"""
+    m = model(L, e)
+    out = []
+    for c in range(m.nCases):
+        cs = m.cases[c]
+        s = "L %d E %d C %d id %d :" % (L, e, c, cs.id)
+        for k in range(cs.nSteps):
+            st = cs.steps[k]
+            err = 0 if st.type in (2, 4) else 1
+            s += " [%d %d %d ce %d %d %d err %d %d %d]" % (st.type, st.start, st.end, st.ceThreshold, st.ceStart, st.ceEnd,
+                                                           err, st.minErr, st.maxErr)
+        s += " lma %016x" % model_lma_hash(cs)
+        out.append(s)
+    return out
+
+
+class Index:
+    def __init__(self, prefix):
+        self.h = lib().s3o_index_load(prefix.encode())
+        if not self.h:
+            raise RuntimeError("cannot load index " + prefix)
+
+    def close(self):
+        if self.h:
+            lib().s3o_index_free(self.h)
+            self.h = None
+
+    def search(self, queries, read_lengths, wpq, mm, max_out=1000, hit_cap=None):
+        n = len(read_lengths)
+        queries = np.ascontiguousarray(queries, dtype=np.uint32)
+        read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
+        if hit_cap is None:
+            hit_cap = max(1024, 64 * n)
+        while True:
+            hits = np.zeros(hit_cap, dtype=HIT_DTYPE)
+            offs = np.zeros(n + 1, dtype=np.uint64)
+            tot = np.zeros(n, dtype=np.uint32)
+            werr = np.zeros((n, 8), dtype=np.uint32)
+            st = Stats()
+            rc = lib().s3o_search_batch(self.h, queries.ctypes.data, read_lengths.ctypes.data, n, wpq, mm, max_out,
+                                        hits.ctypes.data, hit_cap, offs.ctypes.data, tot.ctypes.data, werr.ctypes.data, C.byref(st))
+            if rc >= 0:
+                return hits[:rc], offs, tot, werr, st
+            hit_cap *= 4
+
+    def decode(self, hits):
+        cap = int(sum(1 if h["kind"] == 1 else int(h["b"]) - int(h["a"]) + 1 for h in hits)) + 1
+        pos = np.zeros(cap, dtype=np.uint32)
+        strand = np.zeros(cap, dtype=np.uint8)
+        nmis = np.zeros(cap, dtype=np.uint8)
+        hh = np.ascontiguousarray(hits)
+        k = lib().s3o_decode(self.h, hh.ctypes.data, len(hh), pos.ctypes.data, strand.ctypes.data, nmis.ctypes.data, cap, None)
+        return pos[:k], strand[:k], nmis[:k]
+
+
+CODE = np.full(256, 2, dtype=np.uint8)  # non-ACGT -> G (IndexHandler.cpp:44-48)
+for ch, v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+    CODE[ch] = v
+
+
+def word_per_query(max_read_length):
+    w = 1
+    while w < max_read_length:
+        w *= 2
+    return w // 16
+
+
+def pack_reads(reads, max_read_length):
+    """reads: list of bytes.  Reference layout: 32-interleaved words, 16 chars/word LSB first (QueryParser.cpp, DV-Kernel.cu:4268)."""
+    n = len(reads)
+    wpq = word_per_query(max_read_length)
+    round_up = (n + 31) // 32 * 32
+    q = np.zeros(round_up * wpq, dtype=np.uint32)
+    lens = np.zeros(round_up, dtype=np.uint32)
+    for r, s in enumerate(reads):
+        codes = CODE[np.frombuffer(s, dtype=np.uint8)].astype(np.uint32)
+        L = len(codes)
+        lens[r] = L
+        pad = np.zeros(wpq * 16, dtype=np.uint32)
+        pad[:L] = codes
+        words = (pad.reshape(wpq, 16) << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1).astype(np.uint32)
+        base = r // 32 * 32 * wpq + r % 32
+        q[base + 32 * np.arange(wpq)] = words
+    return q, lens[:n], wpq
+
+
+def read_fastq(path):
+    out = []
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    i = 0
+    while i < len(lines):
+        if lines[i].startswith(b"@"):
+            out.append(lines[i + 1].strip())
+            i += 4
+        elif lines[i].startswith(b">"):
+            out.append(lines[i + 1].strip())
+            i += 2
+        else:
+            i += 1
+    return out
