@@ -1,0 +1,137 @@
+/* s3dp.h -- C-ABI of the MI355X-native SOAP3-dp alignment hot path (libs3dp.so).
+ *
+ * Plain pointers and sizes only.  Each entry point names the reference interface it replaces
+ * (paths relative to aquaskyline/SOAP3-dp).  The reference has no plugin table: the boundary is
+ * the set of host functions in alignment.h:40-59 that alignment.cu implements around the CUDA
+ * kernels of DV-Kernel.cu, plus the CPU consumer (CPUfunctions.cpp) of their `answers` arrays.
+ *
+ * Error model: every function returns 0 on success, a negative S3_E* code otherwise, and
+ * s3_last_error() gives a message.  (The reference prints and exit(1)s -- alignment.cu:38-42 --
+ * the host wrapper reproduces that.)  There is no CPU fallback anywhere behind this ABI: if no
+ * HIP device is usable the calls fail with S3_ENODEV.
+ */
+#ifndef S3DP_H
+#define S3DP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3_OK        0
+#define S3_EINVAL   -1
+#define S3_ENODEV   -2
+#define S3_EHIP     -3
+#define S3_ENOMEM   -4
+#define S3_EOVERFLOW -5
+
+#define S3_MAX_READ_LENGTH 1024     /* definitions.h:38 */
+#define S3_MAX_MISMATCH    4
+
+typedef struct s3_index s3_index;
+typedef struct s3_batch s3_batch;
+
+/* One BWT of the 2BWT pair, host arrays in the on-disk layouts with file headers stripped:
+ *   bwt : .bwt / .rev.bwt payload, 2-bit chars, 16 per word, MSB first, '$' not stored (2bwt-lib/BWT.c:169-194)
+ *   occ : GPU-2BWT .fmv.gpu / .rev.fmv.gpu payload, (ceil(n/128)+1) x 4 words = Occ(c,128x)+C[c]
+ *         (writer BGS-Build.cpp:139-192; reader IndexHandler.cpp:158-199)                                    */
+typedef struct {
+    const uint32_t *bwt;
+    size_t          bwtWords;
+    const uint32_t *occ;
+    size_t          occRecs;
+    uint32_t        inverseSa0;
+    uint32_t        cumFreq[5];        /* cumulativeFreq[0..4], [4] = textLength */
+} s3_bwt_desc;
+
+typedef struct {
+    s3_bwt_desc     fwd, rev;
+    uint32_t        textLength;
+    const uint32_t *sa;                /* full suffix array (SaValueFreq=1), textLength+1 entries (.sa payload after 6 words) */
+    const uint32_t *packedDNA;         /* text, 16 chars/word MSB first as HSPLoad holds it (TextConverter.c:666-720) */
+    size_t          packedWords;
+    const uint32_t *lkt, *revLkt;      /* 13-mer cumulative lookup tables (.lkt/.rev.lkt payload after 1 word) */
+    int             lktSize;           /* LOOKUP_SIZE = 13 (2bwt-flex/LT.h:49) */
+} s3_index_desc;
+
+/* replaces GPUINDEXUpload (alignment.cu:27-107).  The device copy is re-laid out (one 64-byte line per
+ * rank query); SA, packed text and both lookup tables are made resident too so that check-and-extend
+ * and SA decode run on the device. */
+int  s3_index_upload(int device, const s3_index_desc *desc, s3_index **out);
+/* replaces GPUINDEXFree (alignment.cu:109-115) */
+void s3_index_free(s3_index *ix);
+size_t s3_index_device_bytes(const s3_index *ix);
+
+/* One emitted record of the k-mismatch search, in the reference CPU path's emission order
+ * (BGS-HostAlgnmtAlgo2.cpp: SA ranges -> SAList via addSAToSAList :1617,1692; check-and-extend hits
+ * -> OCCList via addToOCCList :169).  kind 0: SA range [a,b];  kind 1: text position a.
+ * strand 1 '+', 2 '-' (QUERY_POS_STRAND / QUERY_NEG_STRAND);  cas = case index in the model. */
+typedef struct {
+    uint32_t a, b;
+    uint8_t  kind, strand, nmis, cas;
+} s3_hit;
+
+typedef struct {
+    uint64_t rankQueries;      /* all-symbol rank queries issued (the roofline unit) */
+    uint64_t ltLookups;
+    uint64_t saReads;
+    uint64_t ceWindows;
+    uint64_t records;
+} s3_counters;
+
+/* Batch object: device-resident packed reads + all work buffers (persistent, no per-call allocation).
+ * Replaces the per-batch cudaMalloc/cudaMemcpy of perform_round1_alignment (alignment.cu:118-219). */
+int  s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPerQuery, s3_batch **out);
+void s3_batch_free(s3_batch *b);
+/* queries: the reference's packed layout -- 32-interleaved words, 16 chars/word LSB first
+ * (word w of read r at r/32*32*wpq + r%32 + 32*w; DV-Kernel.cu:4268-4270); readLengths[n]. Host pointers. */
+int  s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint32_t *readLengths, uint32_t n);
+
+/* All cases of the <= numMismatch model, both strands, for every read of the batch: the work of
+ * kernel / kernel_4mismatch_{1,2} (DV-Kernel.cu:4249,4505,4741) + round 2 + the CPU re-search of
+ * overflowing reads (collect_all_answers, CPUfunctions.cpp:1226-1416), with results identical to the
+ * CPU path ProcessReadDoubleStrand2 (CPUfunctions.cpp:555).  Asynchronous on the batch stream. */
+int  s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead);
+/* Wait and fetch: hitOffsets[n+1] (CSR), hits, per read TotalOccurrences and WithError[8]
+ * (SRAQueryResultCount).  Any pointer may be NULL.  hitCap = capacity of hits in records. */
+int  s3_batch_fetch_hits(s3_batch *b, uint64_t *hitOffsets, s3_hit *hits, size_t hitCap,
+                         uint32_t *totalOcc, uint32_t *withError, uint64_t *nHitsOut);
+
+/* Single-end all-best ladder on the device (all_best_single_alignment, alignment.cu:1422-1465 +
+ * the MAPQ special case of hostKernel, CPUfunctions.cpp:1755-1801): phases mm = 1..numMismatch, reads
+ * whose best hit has exactly mm mismatches are deferred to phase mm+1 (or re-searched with the mm+1
+ * model in the terminal phase), SA ranges decoded through the resident suffix array.
+ * Results per read: phase it was resolved in (0 = unaligned), occurrence CSR in the CPU path's
+ * final order (check-and-extend hits first, then SA ranges expanded; SAList.cpp:392-418). */
+int  s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead);
+int  s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError /* n x 8 */,
+                               uint64_t *occOffsets /* n+1 */, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis,
+                               size_t occCap, uint64_t *nOccOut);
+
+int  s3_batch_sync(s3_batch *b);
+/* device time of the work enqueued by the last search/align call, measured with HIP events on the batch stream;
+ * searchMs = time inside the BWT-search kernels only. */
+int  s3_batch_last_timing(s3_batch *b, float *totalMs, float *searchMs, uint32_t *searchLaunches);
+int  s3_batch_counters(s3_batch *b, s3_counters *out);      /* device-side tallies of the last call (if enabled) */
+int  s3_batch_enable_counters(s3_batch *b, int on);
+
+/* one-shot convenience (host in, host out), mirrors the call shape of perform_round1_alignment:
+ * creates a temporary batch.  Arrays are malloc()ed for the caller, free with s3_free(). */
+int  s3_bwt_search(s3_index *ix, const uint32_t *queries, const uint32_t *readLengths, uint32_t n, uint32_t wordPerQuery,
+                   uint32_t numMismatch, uint32_t maxOutputPerRead,
+                   uint64_t **hitOffsets, s3_hit **hits, uint32_t **totalOcc, uint32_t **withError);
+void s3_free(void *p);
+
+/* host-side model tables (SRAModelConstruct, 2bwt-flex/SRA2BWTMdl.c:4403) exposed for tests:
+ * writes one text line per case in the same form as the reference dump used by the oracle harness. */
+int  s3_model_describe(int readLength, int maxError, char *buf, size_t bufLen);
+
+int  s3_device_count(void);
+const char *s3_last_error(void);
+const char *s3_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -206,6 +206,35 @@ s3o_index *s3o_index_load(const char *prefix)
     return ix;
 }
 
+static void *dupw(const uint32_t *src, size_t words, size_t padWords)
+{
+    uint32_t *p = (uint32_t *)calloc(words + padWords + 4, 4);
+    memcpy(p, src, words * 4);
+    return p;
+}
+
+s3o_index *s3o_index_create(uint32_t n, const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, uint32_t inverseSa0, const uint32_t cum[5],
+                            const uint32_t *rbwt, size_t rbwtWords, const uint32_t *rocc, uint32_t rInverseSa0, const uint32_t rcum[5],
+                            const uint32_t *sa, const uint32_t *pacWordsMsb, size_t pacWords,
+                            const uint32_t *lkt, const uint32_t *rlkt, int ltSize)
+{
+    s3o_index *ix = (s3o_index *)calloc(1, sizeof(*ix));
+    size_t recs = ((size_t)n + 127) / 128 + 1, lt = (size_t)1 << (2 * ltSize);
+    ix->fwd.n = ix->rev.n = n;
+    ix->fwd.inverseSa0 = inverseSa0; ix->rev.inverseSa0 = rInverseSa0;
+    memcpy(ix->fwd.C, cum, 20); memcpy(ix->rev.C, rcum, 20);
+    ix->fwd.bwt = (uint32_t *)dupw(bwt, bwtWords, 64); ix->fwd.bwtWords = bwtWords;
+    ix->rev.bwt = (uint32_t *)dupw(rbwt, rbwtWords, 64); ix->rev.bwtWords = rbwtWords;
+    ix->fwd.occ = (uint32_t *)dupw(occ, recs * 4, 0); ix->fwd.occRecs = recs;
+    ix->rev.occ = (uint32_t *)dupw(rocc, recs * 4, 0); ix->rev.occRecs = recs;
+    ix->sa = (uint32_t *)dupw(sa, (size_t)n + 1, 0);
+    ix->sa[0] = 0xFFFFFFFFu;
+    ix->pac = (uint32_t *)dupw(pacWordsMsb, pacWords, 8); ix->pacWords = pacWords + 4;
+    ix->dnaLength = n;
+    ix->lkt = (uint32_t *)dupw(lkt, lt, 0); ix->rlkt = (uint32_t *)dupw(rlkt, lt, 0); ix->ltSize = ltSize;
+    return ix;
+}
+
 void s3o_index_free(s3o_index *ix)
 {
     if (!ix) return;

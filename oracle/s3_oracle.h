@@ -79,6 +79,11 @@ typedef struct {
 } s3o_stats;
 
 s3o_index *s3o_index_load(const char *prefix);       /* <prefix>.bwt, .fmv.gpu, .rev.*, .sa, .pac, .lkt, .rev.lkt */
+/* same index from caller arrays (copied): payloads of the files, headers stripped */
+s3o_index *s3o_index_create(uint32_t n, const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, uint32_t inverseSa0, const uint32_t cum[5],
+                            const uint32_t *rbwt, size_t rbwtWords, const uint32_t *rocc, uint32_t rInverseSa0, const uint32_t rcum[5],
+                            const uint32_t *sa, const uint32_t *pacWordsMsb, size_t pacWords,
+                            const uint32_t *lkt, const uint32_t *rlkt, int ltSize);
 void       s3o_index_free(s3o_index *);
 
 void s3o_model_build(int readLength, int maxError, s3o_model *out);

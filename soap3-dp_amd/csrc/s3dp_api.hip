@@ -1,0 +1,595 @@
+// s3dp_api.hip -- the C-ABI of libs3dp.so (include/s3dp.h): index residency, batch objects, the
+// k-mismatch search call and the single-end all-best ladder.  Host logic only; kernels are in
+// s3dp_kernels.hip.  No CPU fallback exists: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/s3dp.h"
+#include "s3dp_device.h"
+#include "s3dp_model.h"
+
+using namespace s3;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                          \
+    do {                                                                                                   \
+        hipError_t e_ = (x);                                                                               \
+        if (e_ != hipSuccess) return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+extern "C" const char *s3_last_error(void) { return g_err.c_str(); }
+extern "C" const char *s3_version(void) { return "s3dp 0.1 (gfx950)"; }
+extern "C" void s3_free(void *p) { free(p); }
+
+extern "C" int s3_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int s3_model_describe(int readLength, int maxError, char *buf, size_t bufLen)
+{
+    if (readLength < 1 || readLength > S3_MAX_READ_LENGTH || maxError < 0 || maxError > S3_MAX_MISMATCH) return fail(S3_EINVAL, "bad model args");
+    return s3_model_text(readLength, maxError, buf, (unsigned long)bufLen);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct s3_index {
+    int       dev = 0;
+    DevIndex  d{};
+    std::vector<void *> allocs;
+    S3Model  *models[S3_MAX_MISMATCH + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // device, indexed by read length
+    size_t    bytes = 0;
+};
+
+template <class T>
+static int devAlloc(s3_index *ix, T **p, size_t count)
+{
+    void *q = nullptr;
+    size_t b = count * sizeof(T);
+    if (b == 0) b = sizeof(T);
+    hipError_t e = hipMalloc(&q, b);
+    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    ix->allocs.push_back(q);
+    ix->bytes += b;
+    *p = (T *)q;
+    return S3_OK;
+}
+
+static int uploadHalf(s3_index *ix, const s3_bwt_desc &h, DevBwt *out, hipStream_t s)
+{
+    if (!h.bwt || !h.occ) return fail(S3_EINVAL, "s3_index_upload: missing bwt/occ array");
+    const size_t expectRecs = ((size_t)h.cumFreq[4] + 127) / 128 + 1;
+    if (h.occRecs != expectRecs) return fail(S3_EINVAL, "s3_index_upload: occRecs does not match textLength");
+    uint32_t *tb = nullptr, *to = nullptr;
+    uint4 *lines = nullptr;
+    HIPCHK(hipMalloc((void **)&tb, h.bwtWords * 4 + 16));
+    HIPCHK(hipMalloc((void **)&to, h.occRecs * 16));
+    int rc = devAlloc(ix, &lines, h.occRecs * 4);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(tb, h.bwt, h.bwtWords * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(to, h.occ, h.occRecs * 16, hipMemcpyHostToDevice, s));
+    launchRelayout(tb, h.bwtWords, to, h.occRecs, lines, s);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(tb));
+    HIPCHK(hipFree(to));
+    out->lines = lines;
+    out->inverseSa0 = h.inverseSa0;
+    out->n = h.cumFreq[4];
+    return S3_OK;
+}
+
+extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index **outp)
+{
+    if (!desc || !outp) return fail(S3_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(S3_ENODEV, "no HIP device available (libs3dp has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(S3_EINVAL, "bad device ordinal");
+    if (!desc->sa || !desc->packedDNA || !desc->lkt || !desc->revLkt) return fail(S3_EINVAL, "sa, packedDNA and both lookup tables are required");
+    if (desc->lktSize < 1 || desc->lktSize > 15) return fail(S3_EINVAL, "bad lookup table size");
+    HIPCHK(hipSetDevice(device));
+    s3_index *ix = new s3_index();
+    ix->dev = device;
+    hipStream_t s;
+    HIPCHK(hipStreamCreate(&s));
+    int rc = uploadHalf(ix, desc->fwd, &ix->d.fwd, s);
+    if (!rc) rc = uploadHalf(ix, desc->rev, &ix->d.rev, s);
+    if (rc) { s3_index_free(ix); return rc; }
+    const uint32_t n = desc->textLength;
+    uint32_t *sa = nullptr, *pac = nullptr, *lkt = nullptr, *rlkt = nullptr;
+    const size_t ltWords = (size_t)1 << (2 * desc->lktSize);
+    const size_t pacWords = desc->packedWords + 4;                     // + zero tail so 3-word windows never leave the buffer
+    if ((rc = devAlloc(ix, &sa, (size_t)n + 1)) || (rc = devAlloc(ix, &pac, pacWords)) || (rc = devAlloc(ix, &lkt, ltWords)) ||
+        (rc = devAlloc(ix, &rlkt, ltWords))) { s3_index_free(ix); return rc; }
+    HIPCHK(hipMemcpyAsync(sa, desc->sa, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(pac, 0, pacWords * 4, s));
+    HIPCHK(hipMemcpyAsync(pac, desc->packedDNA, desc->packedWords * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(lkt, desc->lkt, ltWords * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(rlkt, desc->revLkt, ltWords * 4, hipMemcpyHostToDevice, s));
+    ix->d.sa = sa; ix->d.pac = pac; ix->d.pacWords = pacWords; ix->d.lkt = lkt; ix->d.rlkt = rlkt;
+    ix->d.ltSize = desc->lktSize; ix->d.n = n;
+    // model tables for every read length and mismatch budget (built on the host, see s3dp_model.cpp)
+    std::vector<S3Model> host(S3_MAX_READ_LENGTH + 1);
+    for (int e = 0; e <= S3_MAX_MISMATCH; e++) {
+        memset(host.data(), 0, host.size() * sizeof(S3Model));
+        for (int L = 1; L <= S3_MAX_READ_LENGTH; L++) s3_model_build(L, e, &host[L]);
+        if ((rc = devAlloc(ix, &ix->models[e], host.size()))) { s3_index_free(ix); return rc; }
+        HIPCHK(hipMemcpyAsync(ix->models[e], host.data(), host.size() * sizeof(S3Model), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipStreamDestroy(s));
+    *outp = ix;
+    return S3_OK;
+}
+
+extern "C" void s3_index_free(s3_index *ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->dev);
+    for (void *p : ix->allocs) (void)hipFree(p);
+    delete ix;
+}
+
+extern "C" size_t s3_index_device_bytes(const s3_index *ix) { return ix ? ix->bytes : 0; }
+
+// ---------------------------------------------------------------------------------------------
+struct s3_batch {
+    s3_index *ix = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t maxReads = 0, wpq = 0, n = 0;
+    size_t   maxItems = 0;
+    uint32_t recCap = 0, occCap = 0;
+    // inputs
+    uint32_t *dQueries = nullptr, *dLens = nullptr;
+    // search / ordering work buffers
+    uint4    *dRecs = nullptr, *dOrdered = nullptr;
+    uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr;
+    unsigned long long *dCounters = nullptr;
+    uint32_t *dKept = nullptr, *dOccCounts = nullptr, *dCeCounts = nullptr, *dTotalOcc = nullptr, *dWithError = nullptr;
+    uint32_t *dHitOffsets = nullptr;
+    DevHit   *dHits = nullptr;
+    char     *dTemp = nullptr; size_t tempBytes = 0;
+    // ladder
+    uint32_t *dActive[2] = {nullptr, nullptr}, *dNumSel = nullptr, *dIota = nullptr;
+    uint8_t  *dState = nullptr, *dSelFlags = nullptr;
+    uint32_t *dOccOffsets = nullptr, *dMasked = nullptr;
+    uint32_t *dOccPos = nullptr, *dOccMeta = nullptr;
+    uint8_t  *dPhase = nullptr;
+    uint32_t *dFinalWithError = nullptr, *dOccStart = nullptr, *dOccCount = nullptr;
+    uint32_t *dOutOffsets = nullptr, *dOutPos = nullptr, *dOutMeta = nullptr;
+    std::vector<void *> allocs;
+    // state of the last call
+    int lastKind = 0;              // 1 = search, 2 = align
+    uint32_t lastNumCases = 0;
+    bool counting = false;
+    hipEvent_t evTotal[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> evSearch;
+    uint32_t searchLaunches = 0;
+    uint32_t occUsed = 0;
+};
+
+template <class T>
+static int balloc(s3_batch *b, T **p, size_t count)
+{
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (!bytes) bytes = 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch): ") + hipGetErrorString(e));
+    b->allocs.push_back(q);
+    *p = (T *)q;
+    return S3_OK;
+}
+
+static size_t envSize(const char *name, size_t dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return (size_t)strtoull(v, nullptr, 10);
+}
+
+extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPerQuery, s3_batch **outp)
+{
+    if (!ix || !outp || maxReads == 0 || wordPerQuery == 0 || wordPerQuery > 64) return fail(S3_EINVAL, "s3_batch_create: bad argument");
+    HIPCHK(hipSetDevice(ix->dev));
+    s3_batch *b = new s3_batch();
+    b->ix = ix; b->maxReads = maxReads; b->wpq = wordPerQuery;
+    const size_t roundUp = ((size_t)maxReads + 31) / 32 * 32;
+    b->maxItems = (size_t)maxReads * 20;                               // 10 cases x 2 strands at 4 mismatches
+    const size_t recPerRead = envSize("S3DP_REC_PER_READ", 6), occPerRead = envSize("S3DP_OCC_PER_READ", 12);
+    size_t recCap = (size_t)maxReads * recPerRead + 65536, occCap = (size_t)maxReads * occPerRead + 65536;
+    if (recCap > 0xFFFFFF00ull) recCap = 0xFFFFFF00ull;
+    if (occCap > 0xFFFFFF00ull) occCap = 0xFFFFFF00ull;
+    b->recCap = (uint32_t)recCap; b->occCap = (uint32_t)occCap;
+    HIPCHK(hipStreamCreate(&b->stream));
+    int rc;
+#define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
+    BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp);
+    BA(dRecs, recCap); BA(dOrdered, recCap);
+    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8);
+    BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
+    BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
+    BA(dWithError, (size_t)maxReads * 8);
+    BA(dHitOffsets, (size_t)maxReads + 1); BA(dHits, recCap);
+    BA(dActive[0], maxReads); BA(dActive[1], maxReads); BA(dNumSel, 4); BA(dIota, maxReads);
+    BA(dState, maxReads); BA(dSelFlags, maxReads);
+    BA(dOccOffsets, (size_t)maxReads + 1); BA(dMasked, (size_t)maxReads + 1);
+    BA(dOccPos, occCap); BA(dOccMeta, occCap);
+    BA(dPhase, maxReads); BA(dFinalWithError, (size_t)maxReads * 8); BA(dOccStart, maxReads); BA(dOccCount, (size_t)maxReads + 1);
+    BA(dOutOffsets, (size_t)maxReads + 1); BA(dOutPos, occCap); BA(dOutMeta, occCap);
+#undef BA
+    // scan / select scratch sized for the largest problem
+    size_t t1 = 0, t2 = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, t1, b->dItemCounts, b->dItemOffsets, (int)(b->maxItems + 1), b->stream);
+    hipcub::DeviceSelect::Flagged(nullptr, t2, b->dIota, b->dSelFlags, b->dActive[0], b->dNumSel, (int)maxReads, b->stream);
+    b->tempBytes = (t1 > t2 ? t1 : t2) + 256;
+    if ((rc = balloc(b, &b->dTemp, b->tempBytes))) { s3_batch_free(b); return rc; }
+    HIPCHK(hipEventCreate(&b->evTotal[0])); HIPCHK(hipEventCreate(&b->evTotal[1]));
+    b->evSearch.resize(16);
+    for (auto &e : b->evSearch) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    *outp = b;
+    return S3_OK;
+}
+
+extern "C" void s3_batch_free(s3_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ix->dev);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (void *p : b->allocs) (void)hipFree(p);
+    for (auto e : b->evSearch) if (e) (void)hipEventDestroy(e);
+    for (auto e : b->evTotal) if (e) (void)hipEventDestroy(e);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint32_t *readLengths, uint32_t n)
+{
+    if (!b || !queries || !readLengths) return fail(S3_EINVAL, "s3_batch_upload: null argument");
+    if (n > b->maxReads) return fail(S3_EINVAL, "s3_batch_upload: n exceeds batch capacity");
+    for (uint32_t i = 0; i < n; i++)
+        if (readLengths[i] < 16 || readLengths[i] > S3_MAX_READ_LENGTH || readLengths[i] > b->wpq * 16u)
+            return fail(S3_EINVAL, "s3_batch_upload: read length out of range for wordPerQuery");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    const size_t roundUp = ((size_t)n + 31) / 32 * 32;
+    HIPCHK(hipMemcpyAsync(b->dQueries, queries, roundUp * b->wpq * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->dLens, readLengths, (size_t)n * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->n = n;
+    b->lastKind = 0;
+    return S3_OK;
+}
+
+extern "C" int s3_batch_enable_counters(s3_batch *b, int on)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    b->counting = on != 0;
+    return S3_OK;
+}
+
+// search + order + merge for `nActive` slots.  Leaves per-slot results in dTotalOcc / dWithError / dKept / ...
+static int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint32_t modelMm, uint32_t maxOut)
+{
+    const int nCases = s3_num_cases((int)modelMm);
+    const size_t nItems = (size_t)nActive * nCases * 2;
+    HIPCHK(hipMemsetAsync(b->dRecCount, 0, 4, b->stream));
+    SearchIn in{};
+    in.queries = b->dQueries; in.readLengths = b->dLens; in.active = active; in.nActive = nActive; in.wpq = b->wpq;
+    in.models = b->ix->models[modelMm]; in.nCases = nCases; in.maxOut = maxOut;
+    SearchOut out{};
+    out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
+    out.counters = b->counting ? b->dCounters : nullptr;
+    if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
+    launchSearch(b->ix->d, in, out, 256u * 8u * 4u, b->stream);
+    if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
+    b->searchLaunches++;
+    HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, 4, b->stream));
+    size_t tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dItemCounts, b->dItemOffsets, (int)(nItems + 1), b->stream));
+    launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->stream);
+    MergeArgs m{};
+    m.nActive = nActive; m.nCases = (uint32_t)nCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
+    m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
+    launchMergeCount(m, b->stream);
+    b->lastNumCases = (uint32_t)nCases;
+    HIPCHK(hipGetLastError());
+    return S3_OK;
+}
+
+static int checkFlags(s3_batch *b)
+{
+    uint32_t flags = 0;
+    HIPCHK(hipMemcpyAsync(&flags, b->dFlags, 4, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (flags & S3_FLAG_STACK_OVERFLOW) return fail(S3_EOVERFLOW, "search stack overflow (internal bound exceeded)");
+    if (flags & S3_FLAG_REC_OVERFLOW) return fail(S3_EOVERFLOW, "record buffer overflow: raise S3DP_REC_PER_READ");
+    if (flags & S3_FLAG_OCC_OVERFLOW) return fail(S3_EOVERFLOW, "occurrence buffer overflow: raise S3DP_OCC_PER_READ");
+    return S3_OK;
+}
+
+extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
+    if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    b->searchLaunches = 0;
+    HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
+    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
+    int rc = searchPass(b, nullptr, b->n, numMismatch, maxOutputPerRead);
+    if (rc) return rc;
+    // hits in the ABI format
+    HIPCHK(hipMemsetAsync(b->dKept + b->n, 0, 4, b->stream));
+    size_t tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dKept, b->dHitOffsets, (int)(b->n + 1), b->stream));
+    MergeArgs m{};
+    m.nActive = b->n; m.nCases = b->lastNumCases; m.maxOut = maxOutputPerRead; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
+    m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
+    launchMergeFill(m, b->dHitOffsets, b->dHits, b->stream);
+    HIPCHK(hipEventRecord(b->evTotal[1], b->stream));
+    b->lastKind = 1;
+    return S3_OK;
+}
+
+extern "C" int s3_batch_sync(s3_batch *b)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return checkFlags(b);
+}
+
+extern "C" int s3_batch_fetch_hits(s3_batch *b, uint64_t *hitOffsets, s3_hit *hits, size_t hitCap, uint32_t *totalOcc, uint32_t *withError,
+                                   uint64_t *nHitsOut)
+{
+    if (!b || b->lastKind != 1) return fail(S3_EINVAL, "s3_batch_fetch_hits: no search result pending");
+    int rc = s3_batch_sync(b);
+    if (rc) return rc;
+    const uint32_t n = b->n;
+    std::vector<uint32_t> off((size_t)n + 1);
+    HIPCHK(hipMemcpy(off.data(), b->dHitOffsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    const uint64_t total = off[n];
+    if (nHitsOut) *nHitsOut = total;
+    if (hitOffsets) for (size_t i = 0; i <= n; i++) hitOffsets[i] = off[i];
+    if (hits) {
+        if (total > hitCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_hits: hit buffer too small");
+        static_assert(sizeof(s3_hit) == sizeof(DevHit), "hit layout");
+        HIPCHK(hipMemcpy(hits, b->dHits, total * sizeof(DevHit), hipMemcpyDeviceToHost));
+    }
+    if (totalOcc) HIPCHK(hipMemcpy(totalOcc, b->dTotalOcc, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (withError) HIPCHK(hipMemcpy(withError, b->dWithError, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return S3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helper kernels of the ladder (plumbing, not hot)
+// ---------------------------------------------------------------------------------------------
+__global__ void iotaKernel(uint32_t *p, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
+
+__global__ void maskKernel(uint32_t n, const uint8_t *state, uint8_t want, const uint32_t *occCounts, uint32_t *masked, uint8_t *selFlags,
+                           uint8_t selectWhen /*0: state!=1, 2: state==2*/)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { masked[i] = 0; return; }
+    masked[i] = state[i] == want ? occCounts[i] : 0u;
+    selFlags[i] = selectWhen == 0 ? (state[i] != 1) : (state[i] == 2);
+}
+
+// record the resolved reads of this pass in the per-read (global index) result arrays
+__global__ void publishKernel(uint32_t nActive, const uint32_t *active, const uint8_t *state, uint8_t want, uint8_t phase, const uint32_t *withError,
+                              const uint32_t *occOffsets, uint32_t occBase, uint8_t *outPhase, uint32_t *outWithError, uint32_t *outOccStart,
+                              uint32_t *outOccCount)
+{
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nActive || state[slot] != want) return;
+    const uint32_t r = active ? active[slot] : slot;
+    outPhase[r] = phase;
+    for (int k = 0; k < 8; k++) outWithError[(size_t)r * 8 + k] = withError[(size_t)slot * 8 + k];
+    outOccStart[r] = occBase + occOffsets[slot];
+    outOccCount[r] = occOffsets[slot + 1] - occOffsets[slot];
+}
+
+__global__ void stateAllKernel(uint32_t n, const uint32_t *totalOcc, uint8_t *state)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) state[i] = totalOcc[i] > 0 ? 1 : 0;
+}
+
+__global__ void gatherOccKernel(uint32_t n, const uint32_t *occStart, const uint32_t *outOffsets, const uint32_t *pos, const uint32_t *meta,
+                                uint32_t *outPos, uint32_t *outMeta)
+{
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t cnt = outOffsets[r + 1] - outOffsets[r], src = occStart[r], dst = outOffsets[r];
+    for (uint32_t k = 0; k < cnt; k++) { outPos[dst + k] = pos[src + k]; outMeta[dst + k] = meta[src + k]; }
+}
+
+// decode + publish the slots whose state == want; the occurrence region is appended at *dOccBase
+static int decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive, uint8_t want, uint8_t phase, uint32_t maxOut, uint8_t selectWhen)
+{
+    if (!nActive) return S3_OK;
+    const unsigned g = (nActive + 1 + 255) / 256;
+    hipLaunchKernelGGL(maskKernel, dim3(g), dim3(256), 0, b->stream, nActive, b->dState, want, b->dOccCounts, b->dMasked, b->dSelFlags, selectWhen);
+    size_t tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dMasked, b->dOccOffsets, (int)(nActive + 1), b->stream));
+    const uint32_t base = b->occUsed;
+    hipLaunchKernelGGL(publishKernel, dim3((nActive + 255) / 256), dim3(256), 0, b->stream, nActive, active, b->dState, want, phase, b->dWithError,
+                       b->dOccOffsets, base, b->dPhase, b->dFinalWithError, b->dOccStart, b->dOccCount);
+    MergeArgs m{};
+    m.nActive = nActive; m.nCases = b->lastNumCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
+    m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
+    m.decodeMask = b->dState; m.decodeWant = want;
+    launchDecode(m, b->ix->d, b->dOccOffsets, base, b->occCap, b->dOccPos, b->dOccMeta, b->dFlags, b->stream);
+    uint32_t added = 0;
+    HIPCHK(hipMemcpyAsync(&added, b->dOccOffsets + nActive, 4, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if ((uint64_t)b->occUsed + added > b->occCap) return fail(S3_EOVERFLOW, "occurrence buffer overflow: raise S3DP_OCC_PER_READ");
+    b->occUsed += added;
+    return S3_OK;
+}
+
+extern "C" int s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
+    if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    const uint32_t n = b->n;
+    b->searchLaunches = 0;
+    b->occUsed = 0;
+    HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
+    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
+    HIPCHK(hipMemsetAsync(b->dPhase, 0, n, b->stream));
+    HIPCHK(hipMemsetAsync(b->dFinalWithError, 0, (size_t)n * 32, b->stream));
+    HIPCHK(hipMemsetAsync(b->dOccStart, 0, (size_t)n * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dOccCount, 0, ((size_t)n + 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dNumSel, 0, 16, b->stream));
+    const uint32_t last = numMismatch > 0 ? numMismatch : 1;             // all_best_single_alignment, alignment.cu:1439
+    const uint32_t *active = nullptr;
+    uint32_t nActive = n;
+    int pp = 0;
+    for (uint32_t mm = 1; mm <= last && nActive > 0; mm++) {
+        const bool terminal = mm >= numMismatch;
+        int rc = searchPass(b, active, nActive, mm, maxOutputPerRead);
+        if (rc) return rc;
+        // MAPQ special case needs the (mm+1) model, which exists only for mm < 4 (CPUfunctions.cpp:1756)
+        launchClassify(nActive, b->dTotalOcc, b->dWithError, mm, mm < 4 ? 1u : 0u, b->dState, b->stream);
+        rc = decodeAndPublish(b, active, nActive, 1, (uint8_t)mm, maxOutputPerRead, terminal ? 2 : 0);
+        if (rc) return rc;
+        // reads that go on: no hit or best == mm (non terminal: next phase; terminal: state 2 re-searched with mm+1 model)
+        const uint32_t *idsIn = active;
+        if (!idsIn) {
+            hipLaunchKernelGGL(iotaKernel, dim3((nActive + 255) / 256), dim3(256), 0, b->stream, b->dIota, nActive);
+            idsIn = b->dIota;
+        }
+        size_t tb = b->tempBytes;
+        uint32_t *nextList = b->dActive[pp];
+        HIPCHK(hipcub::DeviceSelect::Flagged(b->dTemp, tb, idsIn, b->dSelFlags, nextList, b->dNumSel, (int)nActive, b->stream));
+        uint32_t nNext = 0;
+        HIPCHK(hipMemcpyAsync(&nNext, b->dNumSel, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (terminal) {
+            if (mm < 4 && nNext > 0) {
+                // ProcessOneMoreMismatchAllCases (CPUfunctions.cpp:624, called at :1790): the read is re-searched with the
+                // (mm+1)-mismatch model and THAT result is what gets reported
+                rc = searchPass(b, nextList, nNext, mm + 1, maxOutputPerRead);
+                if (rc) return rc;
+                hipLaunchKernelGGL(stateAllKernel, dim3((nNext + 255) / 256), dim3(256), 0, b->stream, nNext, b->dTotalOcc, b->dState);
+                rc = decodeAndPublish(b, nextList, nNext, 1, (uint8_t)mm, maxOutputPerRead, 0);
+                if (rc) return rc;
+            }
+            break;
+        }
+        active = nextList;
+        nActive = nNext;
+        pp ^= 1;
+    }
+    // read-ordered CSR of the occurrences
+    size_t tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dOccCount, b->dOutOffsets, (int)(n + 1), b->stream));
+    if (n) hipLaunchKernelGGL(gatherOccKernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, n, b->dOccStart, b->dOutOffsets, b->dOccPos, b->dOccMeta,
+                              b->dOutPos, b->dOutMeta);
+    HIPCHK(hipEventRecord(b->evTotal[1], b->stream));
+    HIPCHK(hipGetLastError());
+    b->lastKind = 2;
+    return S3_OK;
+}
+
+extern "C" int s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError, uint64_t *occOffsets, uint32_t *occPos, uint8_t *occStrand,
+                                         uint8_t *occMis, size_t occCap, uint64_t *nOccOut)
+{
+    if (!b || b->lastKind != 2) return fail(S3_EINVAL, "s3_batch_fetch_alignments: no alignment result pending");
+    int rc = s3_batch_sync(b);
+    if (rc) return rc;
+    const uint32_t n = b->n;
+    std::vector<uint32_t> off((size_t)n + 1);
+    HIPCHK(hipMemcpy(off.data(), b->dOutOffsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    const uint64_t total = off[n];
+    if (nOccOut) *nOccOut = total;
+    if (phase) HIPCHK(hipMemcpy(phase, b->dPhase, n, hipMemcpyDeviceToHost));
+    if (withError) HIPCHK(hipMemcpy(withError, b->dFinalWithError, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (occOffsets) for (size_t i = 0; i <= n; i++) occOffsets[i] = off[i];
+    if (occPos || occStrand || occMis) {
+        if (total > occCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_alignments: output arrays too small");
+        if (occPos) HIPCHK(hipMemcpy(occPos, b->dOutPos, total * 4, hipMemcpyDeviceToHost));
+        if (occStrand || occMis) {
+            std::vector<uint32_t> meta(total);
+            HIPCHK(hipMemcpy(meta.data(), b->dOutMeta, total * 4, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < total; i++) {
+                if (occStrand) occStrand[i] = (uint8_t)(meta[i] & 0xFF);
+                if (occMis) occMis[i] = (uint8_t)((meta[i] >> 8) & 0xFF);
+            }
+        }
+    }
+    return S3_OK;
+}
+
+extern "C" int s3_batch_last_timing(s3_batch *b, float *totalMs, float *searchMs, uint32_t *searchLaunches)
+{
+    if (!b || b->lastKind == 0) return fail(S3_EINVAL, "no timed call");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    float t = 0, s = 0;
+    HIPCHK(hipEventElapsedTime(&t, b->evTotal[0], b->evTotal[1]));
+    uint32_t timed = b->searchLaunches;
+    if (timed * 2 > b->evSearch.size()) timed = (uint32_t)(b->evSearch.size() / 2);
+    for (uint32_t i = 0; i < timed; i++) {
+        float x = 0;
+        HIPCHK(hipEventElapsedTime(&x, b->evSearch[2 * i], b->evSearch[2 * i + 1]));
+        s += x;
+    }
+    if (totalMs) *totalMs = t;
+    if (searchMs) *searchMs = s;
+    if (searchLaunches) *searchLaunches = b->searchLaunches;
+    return S3_OK;
+}
+
+extern "C" int s3_batch_counters(s3_batch *b, s3_counters *out)
+{
+    if (!b || !out) return fail(S3_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    unsigned long long c[8] = {0};
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(c, b->dCounters, 64, hipMemcpyDeviceToHost));
+    out->rankQueries = c[0]; out->ltLookups = c[1]; out->saReads = c[2]; out->ceWindows = c[3];
+    uint32_t rc = 0;
+    HIPCHK(hipMemcpy(&rc, b->dRecCount, 4, hipMemcpyDeviceToHost));
+    out->records = rc;
+    return S3_OK;
+}
+
+extern "C" int s3_bwt_search(s3_index *ix, const uint32_t *queries, const uint32_t *readLengths, uint32_t n, uint32_t wordPerQuery,
+                             uint32_t numMismatch, uint32_t maxOutputPerRead, uint64_t **hitOffsets, s3_hit **hits, uint32_t **totalOcc,
+                             uint32_t **withError)
+{
+    if (!ix || !hitOffsets || !hits) return fail(S3_EINVAL, "null argument");
+    s3_batch *b = nullptr;
+    int rc = s3_batch_create(ix, n ? n : 1, wordPerQuery, &b);
+    if (rc) return rc;
+    rc = s3_batch_upload(b, queries, readLengths, n);
+    if (!rc) rc = s3_batch_search(b, numMismatch, maxOutputPerRead);
+    uint64_t nh = 0;
+    uint64_t *off = (uint64_t *)malloc(((size_t)n + 1) * 8);
+    uint32_t *tot = (uint32_t *)malloc((size_t)(n ? n : 1) * 4), *we = (uint32_t *)malloc((size_t)(n ? n : 1) * 32);
+    if (!rc) rc = s3_batch_fetch_hits(b, off, nullptr, 0, tot, we, &nh);
+    s3_hit *h = (s3_hit *)malloc((size_t)(nh ? nh : 1) * sizeof(s3_hit));
+    if (!rc) rc = s3_batch_fetch_hits(b, nullptr, h, nh, nullptr, nullptr, nullptr);
+    s3_batch_free(b);
+    if (rc) { free(off); free(tot); free(we); free(h); return rc; }
+    *hitOffsets = off; *hits = h;
+    if (totalOcc) *totalOcc = tot; else free(tot);
+    if (withError) *withError = we; else free(we);
+    return S3_OK;
+}

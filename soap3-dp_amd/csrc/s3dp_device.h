@@ -1,0 +1,71 @@
+// s3dp_device.h -- structures shared between the kernels (s3dp_kernels.hip) and the C-ABI layer (s3dp_api.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "s3dp_model.h"
+
+#define S3_SEARCH_BLOCK 256
+#define S3_FLAG_STACK_OVERFLOW 1u
+#define S3_FLAG_REC_OVERFLOW   2u
+#define S3_FLAG_OCC_OVERFLOW   4u
+
+namespace s3 {
+
+struct DevBwt {
+    const uint4 *lines;          // 64-byte lines, 4 x uint4 per 128 BWT characters (see s3dp_kernels.hip)
+    uint32_t     inverseSa0;
+    uint32_t     n;
+};
+
+struct DevIndex {
+    DevBwt          fwd, rev;
+    const uint32_t *sa;
+    const uint32_t *pac;
+    size_t          pacWords;
+    const uint32_t *lkt, *rlkt;
+    int             ltSize;
+    uint32_t        n;
+};
+
+struct SearchIn {
+    const uint32_t *queries;     // packed reads, reference layout
+    const uint32_t *readLengths;
+    const uint32_t *active;      // optional indirection: slot -> read index
+    uint32_t        nActive;
+    uint32_t        wpq;
+    const S3Model  *models;      // indexed by read length, for this phase's mismatch budget
+    int             nCases;
+    uint32_t        maxOut;
+};
+
+struct SearchOut {
+    uint4              *recs;    // {item, seq|kind<<24|nmis<<25, a, b}
+    uint32_t            recCap;
+    uint32_t           *recCount;
+    uint32_t           *itemCounts;
+    uint32_t           *flags;
+    unsigned long long *counters;   // optional: rank, lt, sa, ce tallies
+};
+
+struct DevHit { uint32_t a, b, meta; };       // binary-identical to s3_hit (kind, strand, nmis, cas bytes)
+
+struct MergeArgs {
+    uint32_t        nActive, nCases, maxOut;
+    const uint32_t *itemOffsets;
+    const uint4    *ordered;
+    uint32_t       *keptRecs, *occCounts, *ceCounts, *totalOcc, *withError;
+    const uint8_t  *decodeMask;   // optional per-slot state; only slots with state == decodeWant are decoded
+    uint8_t         decodeWant;
+};
+
+void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
+void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
+void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, hipStream_t s);
+void launchMergeCount(const MergeArgs &a, hipStream_t s);
+void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s);
+void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOffsets, uint32_t occBase, uint32_t occCap, uint32_t *occPos,
+                  uint32_t *occMeta, uint32_t *flags, hipStream_t s);
+void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *withError, uint32_t mm, uint32_t allowSpecial, uint8_t *state,
+                    hipStream_t s);
+
+}  // namespace s3

@@ -1,0 +1,545 @@
+// s3dp_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X): 2BWT exact / k-mismatch search.
+//
+// What is computed is fixed by the reference's CPU path (BGS-HostAlgnmtAlgo2.cpp driven by the
+// SRA2BWTMdl.c case tables): same cases, same DFS order, same lookup-table start, same
+// check-and-extend rule, so the emitted records are the CPU path's, in its order.  How it is
+// computed is MI355X-first:
+//   * index re-laid out at upload: ONE 64-byte line per rank query
+//       [ Occ(.,128k)+C : 16 B | BWT chars 128k-64..128k-1 : 16 B | BWT chars 128k..128k+63 : 16 B | pad ]
+//     (the file layout needs two uncorrelated 16-B gathers; DV-Kernel.cu:256-299)
+//   * one work item = (read, case, strand); items are ordered so that a 64-lane wavefront shares
+//     case and strand -> the step table walk is wave-uniform, divergence is data-only
+//   * oriented reads live in LDS, word-interleaved by lane (bank = lane, conflict free)
+//   * suffix array, packed text and both 13-mer lookup tables are HBM-resident, so check-and-extend
+//     and SA decode happen on the device (no CPU fallback / second round as in alignment.cu:221-326)
+//   * records are appended with wave-aggregated atomics and re-ordered by a counting scatter
+//     (exclusive scan of per-item counts), no sort, no fixed answer slots.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "s3dp_model.h"
+#include "s3dp_device.h"
+
+namespace s3 {
+
+// ---------------------------------------------------------------------------------------------
+// rank
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t hiMask(uint32_t nChars)   // first nChars of a 32-char MSB-first word
+{
+    return nChars >= 32 ? ~0ULL : (nChars == 0 ? 0ULL : (~0ULL << (64 - 2 * nChars)));
+}
+__device__ __forceinline__ uint64_t loMask(uint32_t nChars)   // last nChars
+{
+    return nChars >= 32 ? ~0ULL : ((1ULL << (2 * nChars)) - 1ULL);
+}
+
+__device__ __forceinline__ void count4(uint64_t w, uint64_t m, uint32_t c[4])
+{
+    const uint64_t M5 = 0x5555555555555555ULL;
+    const uint64_t lo = w & M5, hi = (w >> 1) & M5;
+    m &= M5;
+    const uint32_t c3 = __popcll(hi & lo & m), c2 = __popcll(hi & ~lo & m), c1 = __popcll(~hi & lo & m);
+    c[3] += c3; c[2] += c2; c[1] += c1; c[0] += __popcll(m) - c1 - c2 - c3;
+}
+
+// v[c] = Occ(c, i) + C[c]   (GPUBWTAllOccValue, DV-Kernel.cu:282-299; BWTAllOccValue, BWT.c:1211)
+__device__ __forceinline__ void rankAll(const DevBwt &b, uint32_t i, uint32_t v[4])
+{
+    i -= (i > b.inverseSa0);
+    const uint32_t k = (i + 63u) >> 7, p = k << 7;
+    const uint4 *line = b.lines + (size_t)k * 4;
+    const uint4 o = line[0];
+    v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
+    if (i != p) {
+        const bool fwd = i > p;
+        const uint32_t d = fwd ? i - p : p - i;
+        const uint4 w = line[fwd ? 2 : 1];
+        const uint64_t w0 = ((uint64_t)w.x << 32) | w.y, w1 = ((uint64_t)w.z << 32) | w.w;
+        uint32_t c[4] = {0, 0, 0, 0};
+        if (fwd) {
+            count4(w0, hiMask(d), c);
+            if (d > 32) count4(w1, hiMask(d - 32), c);
+            v[0] += c[0]; v[1] += c[1]; v[2] += c[2]; v[3] += c[3];
+        } else {
+            count4(w1, loMask(d), c);
+            if (d > 32) count4(w0, loMask(d - 32), c);
+            v[0] -= c[0]; v[1] -= c[1]; v[2] -= c[2]; v[3] -= c[3];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-lane search state
+// ---------------------------------------------------------------------------------------------
+struct Range { uint32_t fl, fr, rl, rr; };            // forward-index range, reverse-index range (equal sizes)
+
+struct Frame {
+    Range   g;
+    int16_t s, i;
+    int8_t  ins, occ;
+    int16_t pad;
+};
+
+#define S3_STACK 24
+
+struct Lane {
+    const DevIndex *ix;
+    const S3Case   *cs;
+    const uint32_t *rd;          // LDS: oriented read, word w at rd[w * stride]
+    uint32_t        stride;
+    uint32_t        maxOut, total;
+    uint32_t        seq;
+    uint32_t        cntIdx;      // read-major item id: (slot * nCases + case) * 2 + strandIdx
+    uint32_t        strand;      // 1 '+', 2 '-'
+    SearchOut       out;
+    // tallies
+    uint32_t        nRank, nLt, nSa, nCe;
+};
+
+__device__ __forceinline__ uint32_t readChar(const Lane &L, int pos)
+{
+    return (L.rd[(uint32_t)(pos >> 4) * L.stride] >> ((pos & 15) * 2)) & 3u;
+}
+
+__device__ __forceinline__ void emit(Lane &L, uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis)
+{
+    const uint32_t slot = atomicAdd(L.out.recCount, 1u);            // hipcc folds this into one atomic per wave
+    if (slot < L.out.recCap) {
+        uint4 r;
+        r.x = L.cntIdx;
+        r.y = L.seq | (kind << 24) | (nmis << 25);
+        r.z = a; r.w = b;
+        L.out.recs[slot] = r;
+    } else atomicOr(L.out.flags, S3_FLAG_REC_OVERFLOW);
+    L.seq++;
+}
+
+// 32 text characters from position pos, MSB first; beyond the text is zero padding (TextConverter.c:696-701)
+__device__ __forceinline__ uint64_t text64(const DevIndex &ix, uint32_t pos)
+{
+    const uint32_t idx = pos >> 4, sh = pos & 15;
+    if ((size_t)idx + 2 >= ix.pacWords) return 0;
+    uint64_t w = ((uint64_t)ix.pac[idx] << 32) | ix.pac[idx + 1];
+    if (sh) { w <<= 2 * sh; w |= ix.pac[idx + 2] >> (2 * (16 - sh)); }
+    return w;
+}
+
+__device__ int ceMismatches(Lane &L, uint32_t tpos, int left, int len)
+{
+    int mm = 0;
+    for (int o = 0; o < len; o += 32) {
+        const int chunk = len - o > 32 ? 32 : len - o;
+        uint64_t key = 0;
+        for (int j = 0; j < chunk; j++) key = (key << 2) | readChar(L, left + o + j);
+        uint64_t t = text64(*L.ix, tpos + (uint32_t)o);
+        if (chunk < 32) t >>= 64 - 2 * chunk;
+        uint64_t x = t ^ key;
+        x = (x | (x >> 1)) & 0x5555555555555555ULL;
+        mm += __popcll(x);
+        L.nCe++;
+    }
+    return mm;
+}
+
+// check and extend: verify every suffix of a small SA range directly against the packed text
+// (BWTMismatchModelAnyDirection_CE2, BGS-HostAlgnmtAlgo2.cpp:36-176).  Candidates are independent, so they
+// are taken one at a time in SA order -- the same order in which the reference appends survivors.
+__device__ void checkAndExtend(Lane &L, int s, int i, int inserted, uint32_t l, uint32_t r, int occMis)
+{
+    if (L.total >= L.maxOut) return;
+    const S3Case &cs = *L.cs;
+    const S3Step &st0 = cs.st[s];
+    const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i;
+    for (uint32_t q = l; q <= r; q++) {
+        const uint32_t rp = L.ix->sa[q] - (uint32_t)leftAlign;     // 32-bit wrap, as in the reference
+        L.nSa++;
+        int acc = occMis, ii = i, ins = inserted;
+        bool ok = true;
+        for (int t = s; t < cs.nSteps; t++) {
+            const S3Step &st = cs.st[t];
+            const int pos = st.start + st.dir * ii;
+            const int left = pos < st.end ? pos : st.end, right = pos < st.end ? st.end : pos;
+            int mce;
+            if (rp + (uint32_t)left > L.ix->n) mce = 16;          // MAX_NUM_OF_ERROR + 1 (:122-125)
+            else mce = ceMismatches(L, rp + (uint32_t)left, left, right - left + 1);
+            const int tot = mce + ins;
+            if (tot < st.minErr || tot > st.maxErr) { ok = false; break; }
+            acc += tot; ii = 0; ins = 0;
+        }
+        if (ok) {
+            emit(L, 1, rp, rp, (uint32_t)acc);
+            if (++L.total >= L.maxOut) return;
+        }
+        if (q == 0xFFFFFFFFu) break;
+    }
+}
+
+__device__ __forceinline__ void stepRanks(Lane &L, int dir, const Range &g, uint32_t oL[4], uint32_t oR[4])
+{
+    const DevBwt &b = dir < 0 ? L.ix->fwd : L.ix->rev;
+    rankAll(b, dir < 0 ? g.fl : g.rl, oL);
+    rankAll(b, (dir < 0 ? g.fr : g.rr) + 1u, oR);
+    L.nRank += 2;
+}
+
+__device__ __forceinline__ Range childRange(int dir, const Range &g, const uint32_t oL[4], const uint32_t oR[4], uint32_t ch)
+{
+    // active range advances by rank; passive range shrinks by the occurrences of the larger symbols
+    const uint32_t al = oL[ch] + 1u, ar = oR[ch];
+    uint32_t oc = 0;
+    if (ch < 3) oc += oR[3] - oL[3];
+    if (ch < 2) oc += oR[2] - oL[2];
+    if (ch < 1) oc += oR[1] - oL[1];
+    const uint32_t pr = (dir < 0 ? g.rr : g.fr) - oc, pl = pr - (ar - al);
+    Range o;
+    if (dir < 0) { o.fl = al; o.fr = ar; o.rl = pl; o.rr = pr; }
+    else { o.rl = al; o.rr = ar; o.fl = pl; o.fr = pr; }
+    return o;
+}
+
+__device__ __forceinline__ uint32_t ltRange(Lane &L, const uint32_t *tab, int tableSize, int from, int n, int stride, uint32_t &rOut)
+{
+    uint32_t lp = 0;
+    for (int k = 0; k < n; k++) lp = (lp << 2) | readChar(L, from + k * stride);
+    uint32_t rp = lp;
+    for (int k = n; k < tableSize; k++) { lp <<= 2; rp = (rp << 2) | 3u; }
+    L.nLt += 2;
+    rOut = tab[rp];
+    return lp ? tab[lp - 1] + 1u : 1u;
+}
+
+// One (read, case, strand) item: lookup-table start, exact continuation of step 0, then an explicit-stack
+// DFS over the remaining steps (BWTExactModel{Backward,Forward}_Lookup2 :270-548, BWTModelSwitch*2 :1582-1728,
+// Exact/Mismatch models :725-1181).
+__device__ void runItem(Lane &L)
+{
+    const DevIndex &ix = *L.ix;
+    const S3Case &cs = *L.cs;
+    Frame stack[S3_STACK];
+    int sp = 0;
+    {
+        const S3Step &st = cs.st[0];
+        const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
+        Range g;
+        int i = ll, pos;
+        if (st.type == S3_T_BACK_LOOKUP) {
+            g.fl = ltRange(L, ix.lkt, ix.ltSize, st.start - ll + 1, ll, 1, g.fr);
+            g.rl = g.fl; g.rr = g.fr;
+            pos = st.start - ll;
+        } else {
+            uint32_t l, r, rl, rr;
+            l = ltRange(L, ix.lkt, ix.ltSize, st.start, ll, 1, r);
+            rl = ltRange(L, ix.rlkt, ix.ltSize, st.start + ll - 1, ll, -1, rr);
+            if (r - l < rr - rl) rl = rr - (r - l);             // :349-356
+            else if (r - l > rr - rl) l = r - (rr - rl);
+            g.fl = l; g.fr = r; g.rl = rl; g.rr = rr;
+            pos = st.start + ll;
+        }
+        bool done = false;
+        while (i < st.len && g.fl <= g.fr) {
+            if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
+                checkAndExtend(L, 0, i, 0, g.fl, g.fr, 0);
+                done = true;
+                break;
+            }
+            uint32_t oL[4], oR[4];
+            stepRanks(L, st.dir, g, oL, oR);
+            g = childRange(st.dir, g, oL, oR, readChar(L, pos));
+            i++; pos += st.dir;
+        }
+        if (!done && g.fl <= g.fr) {
+            Frame &f = stack[sp++];
+            f.g = g; f.s = 1; f.i = 0; f.ins = 0; f.occ = 0;
+        }
+    }
+    while (sp > 0) {
+        const Frame f = stack[--sp];
+        if (L.total >= L.maxOut) break;                          // nothing below can emit any more
+        if (f.s >= cs.nSteps) {                                  // SRA_STEP_TYPE_COMPLETE (:1603-1625)
+            uint32_t l = f.g.fl, r = f.g.fr;
+            if (r >= l) {
+                if (L.total + (r - l + 1u) > L.maxOut) r = l + L.maxOut - L.total - 1u;
+                emit(L, 0, l, r, (uint32_t)(f.ins + f.occ));
+                L.total += r - l + 1u;
+            }
+            continue;
+        }
+        const S3Step &st = cs.st[f.s];
+        const int inserted = f.ins;
+        const bool exact = inserted >= st.maxErr;                // :1639 / :1714
+        int len = st.len;
+        if (!exact && st.minErr > inserted + 1) len -= st.minErr - inserted - 1;    // :976 / :1109
+        int i = f.i, pos = st.start + st.dir * i;
+        Range g = f.g;
+        bool suspended = false;
+        while (i < len && g.fl <= g.fr) {
+            if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
+                checkAndExtend(L, f.s, i, inserted, g.fl, g.fr, f.occ);
+                suspended = true;
+                break;
+            }
+            const uint32_t ch = readChar(L, pos);
+            uint32_t oL[4], oR[4];
+            stepRanks(L, st.dir, g, oL, oR);
+            const Range gc = childRange(st.dir, g, oL, oR, ch);
+            if (!exact) {
+                // children k != ch must be explored (k ascending) before the walk continues with ch:
+                // push the continuation first, then the children in descending k.
+                int pushed = 0;
+                Frame cont;
+                cont.g = gc; cont.s = f.s; cont.i = (int16_t)(i + 1); cont.ins = (int8_t)inserted; cont.occ = f.occ;
+                Frame kids[3];
+                for (int k = 3; k >= 0; k--) {
+                    if ((uint32_t)k == ch) continue;
+                    const Range e = childRange(st.dir, g, oL, oR, (uint32_t)k);
+                    if (e.fl <= e.fr) {
+                        Frame &c = kids[pushed++];
+                        c.g = e; c.s = f.s; c.i = (int16_t)(i + 1); c.ins = (int8_t)(inserted + 1); c.occ = f.occ;
+                    }
+                }
+                if (pushed > 0) {
+                    if (sp + pushed + 1 > S3_STACK) { atomicOr(L.out.flags, S3_FLAG_STACK_OVERFLOW); return; }
+                    stack[sp++] = cont;
+                    for (int k = 0; k < pushed; k++) stack[sp++] = kids[k];
+                    suspended = true;
+                    break;
+                }
+            }
+            g = gc;
+            i++; pos += st.dir;
+        }
+        if (!suspended && inserted >= st.minErr && g.fl <= g.fr) {
+            if (sp + 1 > S3_STACK) { atomicOr(L.out.flags, S3_FLAG_STACK_OVERFLOW); return; }
+            Frame &n = stack[sp++];
+            n.g = g; n.s = (int16_t)(f.s + 1); n.i = 0; n.ins = 0; n.occ = (int8_t)(f.occ + inserted);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// search kernel: thread per item, items laid out (case, strand)-major so a wave is uniform in both
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(S3_SEARCH_BLOCK)
+searchKernel(DevIndex ix, SearchIn in, SearchOut out)
+{
+    extern __shared__ uint32_t shRead[];                         // [wpq][blockDim]
+    const uint32_t nSlots = in.nActive;
+    const uint32_t groups = (uint32_t)in.nCases * 2u;
+    const uint32_t slotsPadded = (nSlots + 63u) & ~63u;          // keep waves uniform in (case, strand)
+    const uint64_t nItems = (uint64_t)slotsPadded * groups;
+    uint32_t nRank = 0, nLt = 0, nSa = 0, nCe = 0;
+    for (uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t grp = (uint32_t)(item / slotsPadded), slot = (uint32_t)(item % slotsPadded);
+        if (slot >= nSlots) continue;
+        const uint32_t cas = grp >> 1, strandIdx = grp & 1u;
+        const uint32_t r = in.active ? in.active[slot] : slot;
+        const uint32_t len = in.readLengths[r];
+        const S3Model &model = in.models[len];
+        // oriented read -> LDS (word-interleaved by lane)
+        const uint32_t *src = in.queries + (size_t)(r >> 5) * 32u * in.wpq + (r & 31u);
+        uint32_t *dst = shRead + threadIdx.x;
+        if (strandIdx == 0) {
+            for (uint32_t w = 0; w < in.wpq; w++) dst[w * blockDim.x] = src[(size_t)w * 32u];
+        } else {
+            for (uint32_t w = 0; w < in.wpq; w++) dst[w * blockDim.x] = 0;
+            for (uint32_t p = 0; p < len; p++) {                 // reverse complement, 3 - c (DV-Kernel.h:35)
+                const uint32_t q = len - 1u - p;
+                const uint32_t c = 3u - ((src[(size_t)(q >> 4) * 32u] >> ((q & 15u) * 2u)) & 3u);
+                dst[(p >> 4) * blockDim.x] |= c << ((p & 15u) * 2u);
+            }
+        }
+        Lane L;
+        L.ix = &ix; L.cs = &model.cs[cas]; L.rd = dst; L.stride = blockDim.x;
+        L.maxOut = in.maxOut; L.total = 0; L.seq = 0;
+        L.cntIdx = (slot * (uint32_t)in.nCases + cas) * 2u + strandIdx;
+        L.strand = strandIdx + 1u; L.out = out;
+        L.nRank = L.nLt = L.nSa = L.nCe = 0;
+        runItem(L);
+        out.itemCounts[L.cntIdx] = L.seq;
+        nRank += L.nRank; nLt += L.nLt; nSa += L.nSa; nCe += L.nCe;
+    }
+    if (out.counters) {
+        atomicAdd(&out.counters[0], (unsigned long long)nRank);
+        atomicAdd(&out.counters[1], (unsigned long long)nLt);
+        atomicAdd(&out.counters[2], (unsigned long long)nSa);
+        atomicAdd(&out.counters[3], (unsigned long long)nCe);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ordering: records -> CSR by item (counting scatter; offsets = exclusive scan of itemCounts)
+// ---------------------------------------------------------------------------------------------
+__global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered)
+{
+    uint32_t n = *recCount;
+    if (n > recCap) n = recCap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint4 r = recs[i];
+        ordered[itemOffsets[r.x] + (r.y & 0xFFFFFFu)] = r;
+    }
+}
+
+// Per read: walk the items in the CPU path's order (case 0 '+', case 0 '-', case 1 '+', ...), apply the
+// MaxOutputPerRead truncation across items (TotalOccurrences is per read: CPUfunctions.cpp:1246, the cut is
+// BGS-HostAlgnmtAlgo2.cpp:1612-1615 / :160-163), tally WithError[], and count what survives.
+__global__ void mergeCountKernel(MergeArgs a)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.nActive) return;
+    const uint32_t groups = a.nCases * 2u;
+    const uint32_t first = slot * groups;
+    const uint32_t beg = a.itemOffsets[first], end = a.itemOffsets[first + groups];
+    uint32_t total = 0, nRec = 0, nOcc = 0, nCe = 0;
+    uint32_t we[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = beg; i < end && total < a.maxOut; i++) {
+        const uint4 r = a.ordered[i];
+        const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
+        uint32_t cnt = kind ? 1u : r.w - r.z + 1u;
+        if (total + cnt > a.maxOut) cnt = a.maxOut - total;
+        total += cnt; we[nmis] += cnt; nRec++; nOcc += cnt; nCe += kind;
+    }
+    a.keptRecs[slot] = nRec;
+    a.occCounts[slot] = nOcc;
+    a.ceCounts[slot] = nCe;
+    a.totalOcc[slot] = total;
+    for (int k = 0; k < 8; k++) a.withError[(size_t)slot * 8 + k] = we[k];
+}
+
+// final per-read record list in the hit format of the C-ABI (kept records only, last range truncated)
+__global__ void mergeFillKernel(MergeArgs a, const uint32_t *hitOffsets, DevHit *hits)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.nActive) return;
+    const uint32_t groups = a.nCases * 2u;
+    const uint32_t beg = a.itemOffsets[slot * groups];
+    const uint32_t n = a.keptRecs[slot];
+    uint32_t total = 0;
+    DevHit *dst = hits + hitOffsets[slot];
+    for (uint32_t k = 0; k < n; k++) {
+        const uint4 r = a.ordered[beg + k];
+        const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
+        const uint32_t grp = r.x % groups;
+        uint32_t lo = r.z, hi = r.w;
+        uint32_t cnt = kind ? 1u : hi - lo + 1u;
+        if (total + cnt > a.maxOut) { cnt = a.maxOut - total; hi = lo + cnt - 1u; }
+        total += cnt;
+        DevHit h;
+        h.a = lo; h.b = hi; h.meta = kind | ((grp & 1u) + 1u) << 8 | nmis << 16 | (grp >> 1) << 24;
+        dst[k] = h;
+    }
+}
+
+// occurrences in the CPU path's final order: check-and-extend hits first, then every SA range expanded
+// through the suffix array (transferAllSAToOcc, SAList.cpp:392-418; BWTFullSaValue, BWT.c:1726)
+__global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffsets, uint32_t occBase, uint32_t occCap, uint32_t *occPos,
+                             uint32_t *occMeta, uint32_t *flags)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.nActive) return;
+    if (a.decodeMask && a.decodeMask[slot] != a.decodeWant) return;
+    const uint32_t groups = a.nCases * 2u;
+    const uint32_t beg = a.itemOffsets[slot * groups];
+    const uint32_t n = a.keptRecs[slot];
+    uint32_t o = occBase + occOffsets[slot], oSa = o + a.ceCounts[slot];
+    if ((uint64_t)occBase + occOffsets[slot + 1] > occCap) { atomicOr(flags, S3_FLAG_OCC_OVERFLOW); return; }
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint4 r = a.ordered[beg + k];
+        const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
+        const uint32_t strand = ((r.x % groups) & 1u) + 1u;
+        const uint32_t meta = strand | nmis << 8;
+        if (kind) { occPos[o] = r.z; occMeta[o] = meta; o++; total++; }
+        else {
+            uint32_t cnt = r.w - r.z + 1u;
+            if (total + cnt > a.maxOut) cnt = a.maxOut - total;
+            for (uint32_t q = 0; q < cnt; q++) { occPos[oSa] = ix.sa[r.z + q]; occMeta[oSa] = meta; oSa++; }
+            total += cnt;
+        }
+    }
+}
+
+// all-best ladder bookkeeping (hostKernel single-end branch, CPUfunctions.cpp:1755-1801,1858-1867):
+//   state 0: no hit          -> carried to the next phase (unaligned after the last)
+//   state 1: resolved        -> reported in this phase
+//   state 2: best == mm      -> deferred to phase mm+1 (non terminal), or re-searched with the mm+1 model (terminal)
+__global__ void classifyKernel(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *withError,
+                               uint32_t mm, uint32_t allowSpecial, uint8_t *state)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nActive) return;
+    uint8_t st = 1;
+    if (totalOcc[slot] == 0) st = 0;
+    else if (allowSpecial) {
+        uint32_t best = 999;
+        for (uint32_t k = 0; k <= mm; k++) if (withError[(size_t)slot * 8 + k] > 0) { best = k; break; }
+        if (best == mm) st = 2;
+    }
+    state[slot] = st;
+}
+
+__global__ void relayoutKernel(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= occRecs) return;
+    auto word = [&](long long idx) -> uint32_t { return (idx >= 0 && (size_t)idx < bwtWords) ? bwt[idx] : 0u; };
+    const long long w0 = (long long)k * 8;
+    uint4 o, prev, next, pad;
+    o.x = occ[4 * k]; o.y = occ[4 * k + 1]; o.z = occ[4 * k + 2]; o.w = occ[4 * k + 3];
+    prev.x = word(w0 - 4); prev.y = word(w0 - 3); prev.z = word(w0 - 2); prev.w = word(w0 - 1);
+    next.x = word(w0); next.y = word(w0 + 1); next.z = word(w0 + 2); next.w = word(w0 + 3);
+    pad.x = pad.y = pad.z = pad.w = 0;
+    lines[4 * k] = o; lines[4 * k + 1] = prev; lines[4 * k + 2] = next; lines[4 * k + 3] = pad;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (called from s3dp_api.cpp through s3dp_device.h)
+// ---------------------------------------------------------------------------------------------
+void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)((occRecs + 255) / 256);
+    hipLaunchKernelGGL(relayoutKernel, dim3(blocks), dim3(256), 0, s, bwt, bwtWords, occ, occRecs, lines);
+}
+
+void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
+{
+    const uint64_t slotsPadded = ((uint64_t)in.nActive + 63u) & ~63ull;
+    const uint64_t nItems = slotsPadded * (uint64_t)in.nCases * 2u;
+    if (nItems == 0) return;
+    uint64_t blocks = (nItems + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    if (blocks > maxBlocks) blocks = maxBlocks;
+    const size_t lds = (size_t)in.wpq * 4u * S3_SEARCH_BLOCK;
+    hipLaunchKernelGGL(searchKernel, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+}
+
+void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, hipStream_t s)
+{
+    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered);
+}
+
+void launchMergeCount(const MergeArgs &a, hipStream_t s)
+{
+    if (!a.nActive) return;
+    hipLaunchKernelGGL(mergeCountKernel, dim3((a.nActive + 127) / 128), dim3(128), 0, s, a);
+}
+
+void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s)
+{
+    if (!a.nActive) return;
+    hipLaunchKernelGGL(mergeFillKernel, dim3((a.nActive + 127) / 128), dim3(128), 0, s, a, hitOffsets, hits);
+}
+
+void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOffsets, uint32_t occBase, uint32_t occCap, uint32_t *occPos,
+                  uint32_t *occMeta, uint32_t *flags, hipStream_t s)
+{
+    if (!a.nActive) return;
+    hipLaunchKernelGGL(decodeKernel, dim3((a.nActive + 127) / 128), dim3(128), 0, s, a, ix, occOffsets, occBase, occCap, occPos, occMeta, flags);
+}
+
+void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *withError, uint32_t mm, uint32_t allowSpecial, uint8_t *state,
+                    hipStream_t s)
+{
+    if (!nActive) return;
+    hipLaunchKernelGGL(classifyKernel, dim3((nActive + 255) / 256), dim3(256), 0, s, nActive, totalOcc, withError, mm, allowSpecial, state);
+}
+
+}  // namespace s3

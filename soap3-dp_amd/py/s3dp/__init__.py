@@ -1,0 +1,322 @@
+"""s3dp -- thin ctypes binding of libs3dp.so (include/s3dp.h) used by tests and bench.py.
+
+The product is the native library; this module only moves numpy arrays across the C-ABI and
+reads the 2BWT / GPU-2BWT index files.  There is no Python or CPU implementation of the search
+here: if the library or a HIP device is missing the calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))          # soap3-dp_amd/
+LIB_PATH = os.path.join(PKG_ROOT, "libs3dp.so")
+
+HIT_DTYPE = np.dtype([("a", "<u4"), ("b", "<u4"), ("kind", "u1"), ("strand", "u1"), ("nmis", "u1"), ("cas", "u1")])
+
+
+class S3Error(RuntimeError):
+    pass
+
+
+class BwtDesc(C.Structure):
+    _fields_ = [("bwt", C.c_void_p), ("bwtWords", C.c_size_t), ("occ", C.c_void_p), ("occRecs", C.c_size_t),
+                ("inverseSa0", C.c_uint32), ("cumFreq", C.c_uint32 * 5)]
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("fwd", BwtDesc), ("rev", BwtDesc), ("textLength", C.c_uint32), ("sa", C.c_void_p),
+                ("packedDNA", C.c_void_p), ("packedWords", C.c_size_t), ("lkt", C.c_void_p), ("revLkt", C.c_void_p),
+                ("lktSize", C.c_int)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rankQueries", "ltLookups", "saReads", "ceWindows", "records")]
+
+
+EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
+           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_fetch_alignments", "s3_batch_sync",
+           "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
+           "s3_device_count", "s3_last_error", "s3_version"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise S3Error("libs3dp.so is not built (run `make -C soap3-dp_amd` or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.s3_last_error.restype = C.c_char_p
+        L.s3_version.restype = C.c_char_p
+        L.s3_index_device_bytes.restype = C.c_size_t
+        L.s3_index_device_bytes.argtypes = [C.c_void_p]
+        L.s3_index_upload.argtypes = [C.c_int, C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
+        L.s3_index_free.argtypes = [C.c_void_p]
+        L.s3_batch_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.s3_batch_free.argtypes = [C.c_void_p]
+        L.s3_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.s3_batch_search.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.s3_batch_fetch_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.s3_batch_align_single_allbest.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.s3_batch_fetch_alignments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_size_t, C.POINTER(C.c_uint64)]
+        L.s3_batch_sync.argtypes = [C.c_void_p]
+        L.s3_batch_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.s3_batch_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.s3_batch_enable_counters.argtypes = [C.c_void_p, C.c_int]
+        L.s3_model_describe.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise S3Error("libs3dp error %d: %s" % (rc, lib().s3_last_error().decode()))
+
+
+def device_count():
+    return lib().s3_device_count()
+
+
+def model_text(L, e):
+    buf = C.create_string_buffer(8192)
+    n = lib().s3_model_describe(L, e, buf, 8192)
+    if n < 0:
+        _chk(n)
+    return buf.value.decode()
+
+
+# ------------------------------------------------------------------------------------------------
+# index files
+# ------------------------------------------------------------------------------------------------
+def build_lookup_table(codes, table_size=13):
+    """cumulative k-mer counts with the text padded by (k-1) 'A's, as 2bwt-flex/LTConstruct.c:45-101 writes them"""
+    n = len(codes)
+    padded = np.concatenate([codes.astype(np.uint32), np.zeros(table_size - 1, dtype=np.uint32)])
+    v = np.zeros(n, dtype=np.uint32)
+    for j in range(table_size):
+        v = (v << np.uint32(2)) | padded[j:j + n]
+    vals, counts = np.unique(v, return_counts=True)
+    cnt = np.zeros(1 << (2 * table_size), dtype=np.uint32)
+    cnt[vals] = counts.astype(np.uint32)
+    return np.cumsum(cnt, dtype=np.uint32)
+
+
+def unpack_pac(path):
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = (len(raw) - 2) * 4 + int(raw[-1])
+    data = raw[:-1]
+    codes = np.empty(len(data) * 4, dtype=np.uint8)
+    codes[0::4] = data >> 6
+    codes[1::4] = (data >> 4) & 3
+    codes[2::4] = (data >> 2) & 3
+    codes[3::4] = data & 3
+    return codes[:n]
+
+
+def pack_text_words(codes):
+    """16 chars per uint32, first char in the most significant bits, zero padded (TextConverter.c:666-720)"""
+    n = len(codes)
+    words = (n + 63) // 64 * 4 + 8
+    padded = np.zeros(words * 16, dtype=np.uint32)
+    padded[:n] = codes
+    sh = (2 * (15 - np.arange(16, dtype=np.uint32))).astype(np.uint32)
+    return (padded.reshape(words, 16) << sh).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+
+
+class HostIndex:
+    """host arrays of one 2BWT + GPU-2BWT index in the file layouts"""
+
+    def __init__(self):
+        self.keep = []
+
+    @classmethod
+    def from_files(cls, prefix, lkt=None, rev_lkt=None):
+        self = cls()
+
+        def half(mid):
+            raw = np.fromfile(prefix + mid + ".bwt", dtype=np.uint32)
+            occ = np.fromfile(prefix + mid + ".fmv.gpu", dtype=np.uint32)
+            assert (raw[:5] == occ[:5]).all(), "header mismatch between .bwt and .fmv.gpu"
+            return dict(inverseSa0=int(raw[0]), cum=[0] + [int(x) for x in raw[1:5]], bwt=np.ascontiguousarray(raw[5:]),
+                        occ=np.ascontiguousarray(occ[5:]))
+        self.fwd = half("")
+        self.rev = half(".rev")
+        self.n = self.fwd["cum"][4]
+        sa = np.fromfile(prefix + ".sa", dtype=np.uint32)
+        assert int(sa[5]) == 1, "full suffix array (SaValueFreq=1) required"
+        self.sa = np.ascontiguousarray(sa[6:6 + self.n + 1]).copy()
+        self.sa[0] = 0xFFFFFFFF                                   # BWT.c:286
+        self.codes = unpack_pac(prefix + ".pac")
+        assert len(self.codes) == self.n
+        self.pac = pack_text_words(self.codes)
+        if lkt is None:
+            if os.path.exists(prefix + ".lkt"):
+                lkt = np.fromfile(prefix + ".lkt", dtype=np.uint32)[1:]
+                rev_lkt = np.fromfile(prefix + ".rev.lkt", dtype=np.uint32)[1:]
+            else:
+                lkt = build_lookup_table(self.codes)
+                rev_lkt = build_lookup_table(self.codes[::-1])
+        self.lkt = np.ascontiguousarray(lkt)
+        self.rev_lkt = np.ascontiguousarray(rev_lkt)
+        self.lkt_size = 13
+        return self
+
+    def desc(self):
+        d = IndexDesc()
+        for name, h in (("fwd", self.fwd), ("rev", self.rev)):
+            b = getattr(d, name)
+            b.bwt = h["bwt"].ctypes.data
+            b.bwtWords = len(h["bwt"])
+            b.occ = h["occ"].ctypes.data
+            b.occRecs = len(h["occ"]) // 4
+            b.inverseSa0 = h["inverseSa0"]
+            for i in range(5):
+                b.cumFreq[i] = h["cum"][i]
+        d.textLength = self.n
+        d.sa = self.sa.ctypes.data
+        d.packedDNA = self.pac.ctypes.data
+        d.packedWords = len(self.pac)
+        d.lkt = self.lkt.ctypes.data
+        d.revLkt = self.rev_lkt.ctypes.data
+        d.lktSize = self.lkt_size
+        return d
+
+
+class Index:
+    def __init__(self, host_index, device=0):
+        self.h = C.c_void_p()
+        d = host_index.desc()
+        _chk(lib().s3_index_upload(device, C.byref(d), C.byref(self.h)))
+
+    def device_bytes(self):
+        return lib().s3_index_device_bytes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().s3_index_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    def __init__(self, index, max_reads, wpq):
+        self.index = index
+        self.h = C.c_void_p()
+        self.n = 0
+        _chk(lib().s3_batch_create(index.h, max_reads, wpq, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().s3_batch_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, queries, read_lengths):
+        queries = np.ascontiguousarray(queries, dtype=np.uint32)
+        read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
+        self.n = len(read_lengths)
+        _chk(lib().s3_batch_upload(self.h, queries.ctypes.data, read_lengths.ctypes.data, self.n))
+
+    def enable_counters(self, on=True):
+        _chk(lib().s3_batch_enable_counters(self.h, 1 if on else 0))
+
+    def search(self, mm, max_out=1000):
+        _chk(lib().s3_batch_search(self.h, mm, max_out))
+
+    def sync(self):
+        _chk(lib().s3_batch_sync(self.h))
+
+    def fetch_hits(self):
+        n = self.n
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        tot = np.zeros(n, dtype=np.uint32)
+        werr = np.zeros((n, 8), dtype=np.uint32)
+        nh = C.c_uint64()
+        _chk(lib().s3_batch_fetch_hits(self.h, offs.ctypes.data, None, 0, tot.ctypes.data, werr.ctypes.data, C.byref(nh)))
+        hits = np.zeros(max(1, nh.value), dtype=HIT_DTYPE)
+        _chk(lib().s3_batch_fetch_hits(self.h, None, hits.ctypes.data, len(hits), None, None, None))
+        return hits[:nh.value], offs, tot, werr
+
+    def align_single_allbest(self, mm, max_out=1000):
+        _chk(lib().s3_batch_align_single_allbest(self.h, mm, max_out))
+
+    def fetch_alignments(self):
+        n = self.n
+        phase = np.zeros(n, dtype=np.uint8)
+        werr = np.zeros((n, 8), dtype=np.uint32)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        no = C.c_uint64()
+        _chk(lib().s3_batch_fetch_alignments(self.h, phase.ctypes.data, werr.ctypes.data, offs.ctypes.data, None, None, None, 0, C.byref(no)))
+        k = max(1, no.value)
+        pos = np.zeros(k, dtype=np.uint32)
+        strand = np.zeros(k, dtype=np.uint8)
+        mis = np.zeros(k, dtype=np.uint8)
+        _chk(lib().s3_batch_fetch_alignments(self.h, None, None, None, pos.ctypes.data, strand.ctypes.data, mis.ctypes.data, k, None))
+        return phase, werr, offs, pos[:no.value], strand[:no.value], mis[:no.value]
+
+    def timing(self):
+        t, s, k = C.c_float(), C.c_float(), C.c_uint32()
+        _chk(lib().s3_batch_last_timing(self.h, C.byref(t), C.byref(s), C.byref(k)))
+        return t.value, s.value, k.value
+
+    def counters(self):
+        c = Counters()
+        _chk(lib().s3_batch_counters(self.h, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in Counters._fields_}
+
+
+# ------------------------------------------------------------------------------------------------
+# read packing (the layout loadSingleReadsGz produces; QueryParser.cpp:996, DV-Kernel.cu:4268-4270)
+# ------------------------------------------------------------------------------------------------
+CODE = np.full(256, 2, dtype=np.uint8)          # non-ACGT -> G (IndexHandler.cpp:44-48)
+for _ch, _v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+    CODE[_ch] = _v
+
+
+def word_per_query(max_read_length):
+    w = 1
+    while w < max_read_length:
+        w *= 2
+    return max(1, w // 16)
+
+
+def pack_codes(codes2d, lengths, wpq):
+    """codes2d: (n, maxL) uint8 array of 2-bit codes (rows padded with 0).  Vectorised packer."""
+    n, maxl = codes2d.shape
+    width = wpq * 16
+    buf = np.zeros((n, width), dtype=np.uint32)
+    buf[:, :maxl] = codes2d
+    sh = (2 * np.arange(16, dtype=np.uint32)).astype(np.uint32)
+    words = (buf.reshape(n, wpq, 16) << sh).sum(axis=2, dtype=np.uint64).astype(np.uint32)   # (n, wpq)
+    round_up = (n + 31) // 32 * 32
+    full = np.zeros((round_up, wpq), dtype=np.uint32)
+    full[:n] = words
+    # group of 32 reads: word w of read r at group*32*wpq + w*32 + r%32
+    q = full.reshape(round_up // 32, 32, wpq).transpose(0, 2, 1).reshape(-1)
+    return np.ascontiguousarray(q), np.ascontiguousarray(lengths, dtype=np.uint32)
+
+
+def pack_reads(reads, max_read_length):
+    n = len(reads)
+    wpq = word_per_query(max_read_length)
+    maxl = max([len(r) for r in reads] + [1])
+    codes = np.zeros((n, maxl), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    for i, r in enumerate(reads):
+        codes[i, :len(r)] = CODE[np.frombuffer(r, dtype=np.uint8)]
+        lens[i] = len(r)
+    q, lens = pack_codes(codes, lens, wpq)
+    return q, lens, wpq

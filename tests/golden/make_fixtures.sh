@@ -1,0 +1,39 @@
+#!/bin/bash
+# Regenerates the golden fixtures with the REAL reference (oracle/_ref, built by oracle/ref.mk from
+# /root/reference).  Runs only in the authoring container; the outputs below are committed data
+# (inputs + expected outputs), never reference source.
+#   g1: 200 kbp, 3 chromosomes, 4 N-runs, 6 planted repeat families; 2000 x 100 bp reads (0-4 substitutions)
+#   g2: 60 kbp, heavy repeats (exceeds MaxOutputPerRead=1000 with the small-cap ini), mixed read lengths 25..120
+set -euo pipefail
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+REF=$ROOT/oracle/_ref
+INI=$ROOT/soap3-dp_amd/host/soap3-dp.ini
+OUT=$ROOT/tests/golden
+W=$(mktemp -d)
+trap 'rm -rf $W' EXIT
+
+mk() {  # name genome_args read_args maxlen
+  local name=$1; shift
+  local gargs=$1; shift
+  local rargs=$1; shift
+  local L=$1; shift
+  mkdir -p $OUT/$name
+  ( cd $W && python $ROOT/tools/simulate.py $gargs --fasta $name.fa $rargs --fastq $name.fq --truth $name.truth
+    $REF/soap3-dp-builder $name.fa > /dev/null
+    $REF/BGS-Build $name.fa.index > /dev/null
+    for mm in 0 1 2 3 4; do $REF/ref_harness search $INI $name.fa.index $name.fq $L $mm search_mm$mm.txt > /dev/null 2>&1; done
+    $REF/ref_harness sam $INI single $name.fa.index $name.fq -L $L -s 4 -b 2 -o sam_s4 > /dev/null 2>&1
+    $REF/ref_harness sam $INI single $name.fa.index $name.fq -L $L -s 2 -b 2 -o sam_s2 > /dev/null 2>&1
+    sha256sum $name.fa.index.lkt $name.fa.index.rev.lkt | awk '{print $1}' > lkt.sha256
+    for f in bwt rev.bwt fmv.gpu rev.fmv.gpu sa pac ann amb tra; do cp $name.fa.index.$f $OUT/$name/index.$f; done
+    cp $name.fa $OUT/$name/genome.fa; cp $name.fq $OUT/$name/reads.fq; cp $name.truth $OUT/$name/reads.truth; cp lkt.sha256 $OUT/$name/
+    for mm in 0 1 2 3 4; do gzip -9n < search_mm$mm.txt > $OUT/$name/search_mm$mm.txt.gz; done
+    grep -v '^@PG' sam_s4.gout.1 | gzip -9n > $OUT/$name/sam_s4.sam.gz
+    grep -v '^@PG' sam_s2.gout.1 | gzip -9n > $OUT/$name/sam_s2.sam.gz
+  )
+}
+
+mk g1 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 6 --genome-seed 1" "--reads 2000 --read-len 100 --read-seed 2026" 100
+mk g2 "--genome-len 60000 --chroms 2 --n-runs 2 --repeats 40 --genome-seed 7" "--reads 1500 --read-len 100 --var-len 25 120 --read-seed 11" 120
+( cd $W && $REF/ref_harness models models.txt && gzip -9n < models.txt > $OUT/models.txt.gz )
+du -sh $OUT

@@ -88,10 +88,24 @@ def model_lines(L, e):
 
 
 class Index:
-    def __init__(self, prefix):
-        self.h = lib().s3o_index_load(prefix.encode())
+    def __init__(self, prefix=None, host_index=None):
+        if host_index is not None:
+            hi = host_index
+            u32p = lambda a: a.ctypes.data_as(C.c_void_p)
+            cum = (C.c_uint32 * 5)(*hi.fwd["cum"])
+            rcum = (C.c_uint32 * 5)(*hi.rev["cum"])
+            f = lib().s3o_index_create
+            f.restype = C.c_void_p
+            f.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p,
+                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p,
+                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+            self.h = f(hi.n, u32p(hi.fwd["bwt"]), len(hi.fwd["bwt"]), u32p(hi.fwd["occ"]), hi.fwd["inverseSa0"], cum,
+                       u32p(hi.rev["bwt"]), len(hi.rev["bwt"]), u32p(hi.rev["occ"]), hi.rev["inverseSa0"], rcum,
+                       u32p(hi.sa), u32p(hi.pac), len(hi.pac), u32p(hi.lkt), u32p(hi.rev_lkt), hi.lkt_size)
+        else:
+            self.h = lib().s3o_index_load(prefix.encode())
         if not self.h:
-            raise RuntimeError("cannot load index " + prefix)
+            raise RuntimeError("cannot load index")
 
     def close(self):
         if self.h:

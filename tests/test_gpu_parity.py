@@ -1,0 +1,63 @@
+"""-m gpu: the HIP path, called through the C-ABI, against the CPU oracle and the reference's golden dumps."""
+import os
+
+import numpy as np
+import pytest
+
+import s3dp
+import s3o
+from conftest import GOLDEN, golden_reads, hits_to_lines, host_index, read_gz_lines
+
+pytestmark = pytest.mark.gpu
+
+_DEV = {}
+
+
+def dev_index(name):
+    if name not in _DEV:
+        _DEV[name] = s3dp.Index(host_index(name))
+    return _DEV[name]
+
+
+@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
+@pytest.mark.parametrize("mm", [0, 1, 2, 3, 4])
+def test_search_bit_exact_vs_reference_dump_and_oracle(name, maxlen, mm):
+    reads = golden_reads(name)
+    q, lens, wpq = s3dp.pack_reads(reads, maxlen)
+    b = s3dp.Batch(dev_index(name), len(reads), wpq)
+    b.upload(q, lens)
+    b.enable_counters(True)
+    b.search(mm, 1000)
+    hits, offs, tot, werr = b.fetch_hits()
+    mine = hits_to_lines(hits, offs, tot, werr, len(reads))
+    ref = read_gz_lines(os.path.join(GOLDEN, name, "search_mm%d.txt.gz" % mm))
+    assert mine == ref
+    # full record order (including interleaving of SA ranges and check-and-extend hits) vs the oracle
+    oix = s3o.Index(host_index=host_index(name))
+    ohits, ooffs, otot, owerr, st = oix.search(q, lens, wpq, mm, max_out=1000)
+    assert (offs == ooffs).all()
+    assert hits.tobytes() == ohits.tobytes()
+    assert (tot == otot).all() and (werr == owerr).all()
+    c = b.counters()
+    assert c["rankQueries"] == st.rankQueries
+    assert c["ltLookups"] == st.ltLookups
+    oix.close()
+    b.close()
+
+
+@pytest.mark.parametrize("cap", [1, 3, 17])
+def test_max_output_truncation(cap):
+    name, maxlen, mm = "g2", 120, 2
+    reads = golden_reads(name)
+    q, lens, wpq = s3dp.pack_reads(reads, maxlen)
+    b = s3dp.Batch(dev_index(name), len(reads), wpq)
+    b.upload(q, lens)
+    b.search(mm, cap)
+    hits, offs, tot, werr = b.fetch_hits()
+    oix = s3o.Index(host_index=host_index(name))
+    ohits, ooffs, otot, owerr, st = oix.search(q, lens, wpq, mm, max_out=cap)
+    assert (offs == ooffs).all() and hits.tobytes() == ohits.tobytes()
+    assert (tot == otot).all() and (werr == owerr).all()
+    assert tot.max() <= cap
+    oix.close()
+    b.close()
