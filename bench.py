@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the alignment hot path (BASELINE.json configs[1]): synthetic genome of GRCh38
+scale with a full-SA 2BWT + GPU-2BWT index resident in HBM, synthetic 100 bp single-end reads,
+<= 4 mismatches, all-best (soap3-dp single ... -s 4 -h 2 -b 2), DP off.
+
+A "step" = one pass of the whole single-end ladder (phases 1..4 mismatches: BWT search with lookup-table
+start and check-and-extend, ordering, per-read merge, SA decode) over one resident batch of reads.
+One process per GPU; reads are sharded (weak scaling), the index is replicated per GPU; the only
+collective is the final reduce of the counters.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "soap3-dp_amd", "py"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def make_genome(n, seed, device, repeat_frac=0.0):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    codes = torch.empty(n, dtype=torch.uint8, device=device)
+    step = 1 << 28
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        codes[a:b] = torch.randint(0, 4, (b - a,), generator=g, device=device, dtype=torch.uint8)
+    if repeat_frac > 0:
+        # planted repeat families: 300..3000 bp units copied with ~1 % divergence
+        cpu = torch.Generator()
+        cpu.manual_seed(seed + 1)
+        target = int(n * repeat_frac)
+        placed = 0
+        while placed < target:
+            ulen = int(torch.randint(300, 3000, (1,), generator=cpu))
+            copies = int(torch.randint(5, 200, (1,), generator=cpu))
+            src = int(torch.randint(0, n - ulen, (1,), generator=cpu))
+            unit = codes[src:src + ulen].clone()
+            dst = torch.randint(0, n - ulen, (copies,), generator=cpu)
+            for d in dst.tolist():
+                u = unit.clone()
+                nsub = max(1, ulen // 100)
+                p = torch.randint(0, ulen, (nsub,), generator=cpu).to(device)
+                u[p] = (u[p] + torch.randint(1, 4, (nsub,), generator=cpu).to(device).to(torch.uint8)) % 4
+                codes[d:d + ulen] = u
+            placed += ulen * copies
+    return codes
+
+
+def make_reads(codes, n_reads, L, seed, device, mix=(0.55, 0.25, 0.12, 0.05, 0.03)):
+    """uniform start, strand Bernoulli(0.5), substitutions per read ~ Categorical(mix)"""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n = codes.numel()
+    out = torch.empty((n_reads, L), dtype=torch.uint8, device=device)
+    truth_pos = torch.empty(n_reads, dtype=torch.int64, device=device)
+    truth_strand = torch.empty(n_reads, dtype=torch.uint8, device=device)
+    truth_sub = torch.empty(n_reads, dtype=torch.uint8, device=device)
+    ar = torch.arange(L, device=device)
+    probs = torch.tensor(mix, device=device, dtype=torch.float32)
+    chunk = 1 << 20
+    for a in range(0, n_reads, chunk):
+        b = min(n_reads, a + chunk)
+        m = b - a
+        start = torch.randint(0, n - L, (m,), generator=g, device=device)
+        seg = codes[start[:, None] + ar[None, :]]
+        nsub = torch.multinomial(probs, m, replacement=True, generator=g)
+        score = torch.rand((m, L), generator=g, device=device)
+        kth = torch.topk(score, len(mix) - 1, dim=1).indices                  # up to 4 distinct positions
+        delta = torch.randint(1, 4, (m, len(mix) - 1), generator=g, device=device, dtype=torch.uint8)
+        for j in range(len(mix) - 1):
+            sel = nsub > j
+            rows = torch.nonzero(sel).squeeze(1)
+            cols = kth[rows, j]
+            seg[rows, cols] = (seg[rows, cols] + delta[rows, j]) % 4
+        strand = torch.randint(0, 2, (m,), generator=g, device=device, dtype=torch.uint8)
+        rc = 3 - torch.flip(seg, [1])
+        seg = torch.where(strand[:, None] == 1, rc, seg)
+        out[a:b] = seg
+        truth_pos[a:b] = start
+        truth_strand[a:b] = strand
+        truth_sub[a:b] = nsub.to(torch.uint8)
+    return out, truth_pos, truth_strand, truth_sub
+
+
+def pack_on_device(codes2d, wpq):
+    """reference packed layout (32-interleaved words, chars LSB first) built on the device"""
+    import torch
+    n, L = codes2d.shape
+    dev = codes2d.device
+    round_up = (n + 31) // 32 * 32
+    buf = torch.zeros((round_up, wpq * 16), dtype=torch.int64, device=dev)
+    buf[:n, :L] = codes2d.to(torch.int64)
+    sh = 2 * torch.arange(16, dtype=torch.int64, device=dev)
+    words = (buf.view(round_up, wpq, 16) << sh).sum(dim=2)
+    q = words.view(round_up // 32, 32, wpq).permute(0, 2, 1).reshape(-1)
+    return (q & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
+
+
+def cpu_baseline(hi, q, lens, wpq, mm, max_out, budget_s):
+    """oracle (CPU restatement of the reference path) timed on a bounded sample with every host core"""
+    import concurrent.futures as cf
+    import s3o
+    cores = os.cpu_count() or 1
+    oix = s3o.Index(host_index=hi)
+    n_all = len(lens)
+    # calibrate on 512 reads, one thread
+    t0 = time.perf_counter()
+    oix.align_single_allbest(q, lens, wpq, mm, max_out, first=0, count=min(512, n_all))
+    rate1 = min(512, n_all) / max(1e-6, time.perf_counter() - t0)
+    per_thread = int(max(256, min(rate1 * budget_s, n_all // cores)) // 32 * 32)
+    per_thread = max(32, per_thread)
+    threads = max(1, min(cores, n_all // per_thread))
+
+    def work(t):
+        return oix.align_single_allbest(q, lens, wpq, mm, max_out, first=t * per_thread, count=per_thread)[6].rankQueries
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        ranks = list(ex.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    oix.close()
+    total = per_thread * threads
+    return {"value": total / dt / 1e6, "unit": "M reads/s", "cores": threads, "kind": "port",
+            "sample": "%d reads (%d per thread x %d threads) of the same batch, same ladder, %.1f s wall; oracle/s3_oracle.c" %
+                      (total, per_thread, threads, dt),
+            "reads_per_s_per_core": total / dt / threads, "rank_queries_per_read": sum(ranks) / total}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-bp", type=int, default=int(os.environ.get("S3DP_BENCH_GENOME_BP", 3_100_000_000)))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("S3DP_BENCH_READS", 10_000_000)), help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--mismatch", type=int, default=4)
+    ap.add_argument("--max-out", type=int, default=1000)
+    ap.add_argument("--repeat-frac", type=float, default=0.0)
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
+    ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle after the run")
+    a = ap.parse_args()
+
+    import torch
+    import s3dp
+    from s3dp import builder
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or s3dp.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    t_all = time.perf_counter()
+    # ---- index (replicated per GPU): same seed on every rank -----------------------------------------
+    t0 = time.perf_counter()
+    codes = make_genome(a.genome_bp, 1, dev, a.repeat_frac)
+    log("genome %d bp generated in %.1f s" % (a.genome_bp, time.perf_counter() - t0))
+    t0 = time.perf_counter()
+    reads2d, tpos, tstrand, tsub = make_reads(codes, a.reads, a.read_len, 2026 + rank, dev)
+    wpq = s3dp.word_per_query(a.read_len)
+    q = pack_on_device(reads2d, wpq)
+    lens = np.full(a.reads, a.read_len, dtype=np.uint32)
+    del reads2d
+    log("%d reads generated + packed in %.1f s" % (a.reads, time.perf_counter() - t0))
+    t0 = time.perf_counter()
+    hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=(rank == 0))
+    del codes
+    torch.cuda.empty_cache()
+    log("index built on the GPU in %.1f s" % (time.perf_counter() - t0))
+    t0 = time.perf_counter()
+    ix = s3dp.Index(hi, device=local)
+    log("index resident: %.2f GB in HBM, upload %.1f s" % (ix.device_bytes() / 1e9, time.perf_counter() - t0))
+    b = s3dp.Batch(ix, a.reads, wpq)
+    b.upload(q, lens)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- one counted pass: algorithmic work (N_rank etc.) ------------------------------------------------
+    b.enable_counters(True)
+    b.align_single_allbest(a.mismatch, a.max_out)
+    b.sync()
+    cnt = b.counters()
+    phase, werr, offs, pos, strand, mis = b.fetch_alignments()
+    aligned = int((phase > 0).sum())
+    n_occ = int(offs[-1])
+    b.enable_counters(False)
+
+    # ---- timed region ------------------------------------------------------------------------------------
+    for _ in range(a.warmup):
+        b.align_single_allbest(a.mismatch, a.max_out)
+        b.sync()
+    barrier()
+    t0 = time.perf_counter()
+    search_ms = 0.0
+    launches = 0
+    for _ in range(a.steps):
+        b.align_single_allbest(a.mismatch, a.max_out)
+        b.sync()
+        tot_ms, s_ms, k = b.timing()        # HIP events on the batch stream
+        search_ms += s_ms
+        launches += k
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    agg = torch.tensor([float(aligned), float(n_occ), float(cnt["rankQueries"])], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)           # the only collective of the path: final counters
+    dt = float(tmax.item())
+    total_reads = a.reads * world
+    value = total_reads * a.steps / dt / 1e6
+
+    # ---- roofline of the dominant kernel (searchKernel) --------------------------------------------------
+    # algorithmic bytes: 32 B per rank query + packed read + length per read + 12 B per record
+    bytes_step = 32.0 * cnt["rankQueries"] + a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
+    search_s_per_step = search_ms / 1e3 / max(1, a.steps)
+    achieved = bytes_step / search_s_per_step / 1e9 if search_s_per_step > 0 else 0.0
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "s3::searchKernel", "launches_per_step": launches // max(1, a.steps),
+            "kernel_ms_per_step": search_ms / max(1, a.steps),
+            "rank_queries_per_step": cnt["rankQueries"], "line_bytes_GBs": 64.0 * cnt["rankQueries"] / search_s_per_step / 1e9 if search_s_per_step else 0.0}
+
+    out = {"metric": "M reads/sec aligned (100 bp SE, GRCh38-scale synthetic genome)", "value": value, "unit": "M reads/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+           "config": {"workload": "synthetic uniform-ACGT genome, full-SA 2BWT+GPU-2BWT index in HBM; 100 bp single-end reads, "
+                                  "0-4 substitutions (55/25/12/5/3 %), <=4 mismatch all-best ladder (-s 4 -h 2), DP off; "
+                                  "BASELINE.json configs[1] with GRCh38 replaced by a synthetic genome of the same scale",
+                      "genome_bp": a.genome_bp, "reads_per_gpu": a.reads, "read_len": a.read_len, "max_mismatch": a.mismatch,
+                      "max_output_per_read": a.max_out, "repeat_frac": a.repeat_frac, "parallelism": "reads sharded x%d, index replicated" % world},
+           "roofline": roof,
+           "aligned_reads": int(agg[0].item()), "occurrences": int(agg[1].item()),
+           "rank_queries_per_read": cnt["rankQueries"] / a.reads}
+
+    # ---- correctness spot check + CPU baseline (rank 0, N = 1) ------------------------------------------
+    if rank == 0:
+        if a.check > 0:
+            import s3o
+            oix = s3o.Index(host_index=hi)
+            m = min(a.check, a.reads) // 32 * 32
+            oph, owe, ooff, opos, ostr, omis, _ = oix.align_single_allbest(q, lens, wpq, a.mismatch, a.max_out, first=0, count=m)
+            ok = (phase[:m] == oph).all() and (werr[:m] == owe).all() and (offs[:m + 1] == ooff).all() and \
+                (pos[:int(ooff[-1])] == opos).all() and (strand[:int(ooff[-1])] == ostr).all() and (mis[:int(ooff[-1])] == omis).all()
+            out["oracle_check"] = {"reads": m, "bit_exact": bool(ok)}
+            oix.close()
+            if not ok:
+                raise SystemExit("bench.py: HIP result differs from the CPU oracle")
+        if world == 1 and a.cpu_budget > 0:
+            out["cpu_baseline"] = cpu_baseline(hi, q, lens, wpq, a.mismatch, a.max_out, a.cpu_budget)
+        out["wall_s_total"] = time.perf_counter() - t_all
+        print(json.dumps(out), flush=True)
+    b.close()
+    ix.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

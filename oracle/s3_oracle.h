@@ -107,6 +107,16 @@ long s3o_search_batch(const s3o_index *ix, const uint32_t *queries, const uint32
 int s3o_decode(const s3o_index *ix, const s3o_hit *hits, int nHits, uint32_t *pos, uint8_t *strand, uint8_t *nmis, int cap,
                s3o_stats *st);
 
+/* Single-end all-best ladder (all_best_single_alignment, alignment.cu:1422-1465, with the per-read decisions of
+ * hostKernel, CPUfunctions.cpp:1744-1801,1848-1867): phases mm = 1..numMismatch; a read whose best hit has exactly mm
+ * mismatches is deferred to the next phase, or, in the terminal phase (mm < 4), re-searched with the (mm+1)-mismatch
+ * model (ProcessOneMoreMismatchAllCases, CPUfunctions.cpp:624).  phase[r] = mm in which the read was reported (0 = none).
+ * Occurrences are in the final order of the CPU path.  Returns total occurrences or -1 on overflow of occCap. */
+long s3o_align_single_allbest(const s3o_index *ix, const uint32_t *queries, const uint32_t *readLengths, uint32_t n,
+                              uint32_t wordPerQuery, int numMismatch, uint32_t maxOutputPerRead,
+                              uint8_t *phase, uint32_t *withError /* n x 8 */, uint64_t *occOffsets /* n+1 */,
+                              uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st);
+
 /* all-symbol rank on the GPU-2BWT layout (DV-Kernel.cu:85-153,282-299 / BWT.c:1211) : v[c] = Occ(c, i) + C[c] */
 void s3o_rank_all(const s3o_bwt *b, uint32_t i, uint32_t v[4]);
 

@@ -1,0 +1,37 @@
+"""Our own index builder (soap3-dp_amd/py/s3dp/builder.py) must write, for the same text, exactly what the
+reference tools (soap3-dp-builder + BGS-Build) wrote into the golden index files."""
+import os
+
+import numpy as np
+import pytest
+
+import s3dp
+from s3dp import builder
+from conftest import GOLDEN, host_index
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_builder_matches_reference_index_files(name):
+    ref = host_index(name)
+    mine = builder.build_host_index(ref.codes, device="cpu")
+    assert mine.n == ref.n
+    for half in ("fwd", "rev"):
+        a, b = getattr(mine, half), getattr(ref, half)
+        assert a["inverseSa0"] == b["inverseSa0"]
+        assert a["cum"] == b["cum"]
+        assert (a["bwt"] == b["bwt"]).all()
+        assert (a["occ"] == b["occ"]).all()
+    assert (mine.sa == ref.sa).all()
+    assert (mine.lkt == ref.lkt).all() and (mine.rev_lkt == ref.rev_lkt).all()
+    assert (mine.pac == ref.pac).all()
+
+
+def test_suffix_array_with_long_repeats_and_small_buckets():
+    import torch
+    rng = np.random.default_rng(5)
+    unit = rng.integers(0, 4, size=97, dtype=np.uint8)
+    codes = np.concatenate([unit] * 9 + [rng.integers(0, 4, size=500, dtype=np.uint8), unit, unit, np.zeros(70, np.uint8)])
+    sa = builder.suffix_array(torch.from_numpy(codes), max_bucket=64).numpy()
+    s = codes.tobytes()
+    want = sorted(range(len(codes)), key=lambda p: s[p:] + b"")   # bytes compare: shorter prefix first == '$' smallest
+    assert list(sa) == want

@@ -61,3 +61,22 @@ def test_max_output_truncation(cap):
     assert tot.max() <= cap
     oix.close()
     b.close()
+
+
+@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
+@pytest.mark.parametrize("mm", [0, 1, 2, 3, 4])
+def test_allbest_ladder_matches_oracle(name, maxlen, mm):
+    reads = golden_reads(name)
+    q, lens, wpq = s3dp.pack_reads(reads, maxlen)
+    b = s3dp.Batch(dev_index(name), len(reads), wpq)
+    b.upload(q, lens)
+    b.align_single_allbest(mm, 1000)
+    phase, werr, offs, pos, strand, mis = b.fetch_alignments()
+    oix = s3o.Index(host_index=host_index(name))
+    ophase, owerr, ooffs, opos, ostrand, omis, st = oix.align_single_allbest(q, lens, wpq, mm, 1000)
+    assert (phase == ophase).all()
+    assert (werr == owerr).all()
+    assert (offs == ooffs).all()
+    assert (pos == opos).all() and (strand == ostrand).all() and (mis == omis).all()
+    oix.close()
+    b.close()
