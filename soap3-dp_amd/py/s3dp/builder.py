@@ -33,6 +33,79 @@ def _kmer_keys(codes, k, chunk=1 << 28):
     return keys
 
 
+CH = 1 << 30   # every elementwise / scan / nonzero call is issued on at most this many elements (32-bit safe)
+
+
+def _nonzero_big(mask):
+    out = []
+    n = mask.numel()
+    for a in range(0, n, CH):
+        nz = torch.nonzero(mask[a:min(n, a + CH)]).squeeze(1)
+        if a:
+            nz = nz + a
+        out.append(nz)
+    return out[0] if len(out) == 1 else torch.cat(out)
+
+
+def _cumsum_big(x):
+    """inclusive cumsum of a bool/int tensor as int64, chunked with carry"""
+    n = x.numel()
+    out = torch.empty(n, dtype=torch.int64, device=x.device)
+    carry = 0
+    for a in range(0, n, CH):
+        b = min(n, a + CH)
+        c = torch.cumsum(x[a:b].to(torch.int64), 0)
+        if carry:
+            c += carry
+        out[a:b] = c
+        carry = int(c[-1])
+    return out
+
+
+def _group_starts(newgrp, slots=None):
+    """for a boolean 'new group starts here' vector: the slot value of the group's first member, per element.
+    slots: the values to propagate (default: the element's own index)"""
+    n = newgrp.numel()
+    dev = newgrp.device
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    carry = 0
+    for a in range(0, n, CH):
+        b = min(n, a + CH)
+        v = slots[a:b] if slots is not None else torch.arange(a, b, dtype=torch.int64, device=dev)
+        v = torch.where(newgrp[a:b], v, torch.zeros_like(v))
+        v = torch.cummax(v, 0).values
+        if carry:
+            v = torch.clamp(v, min=carry)
+        out[a:b] = v
+        carry = int(v[-1])
+    return out
+
+
+def _gather_big(src, idx):
+    n = idx.numel()
+    out = torch.empty(n, dtype=src.dtype, device=src.device)
+    for a in range(0, n, CH):
+        b = min(n, a + CH)
+        out[a:b] = src[idx[a:b]]
+    return out
+
+
+def _scatter_big(dst, idx, val):
+    n = idx.numel()
+    for a in range(0, n, CH):
+        b = min(n, a + CH)
+        dst[idx[a:b]] = val[a:b]
+
+
+def _tied(newgrp):
+    """members of groups of size > 1"""
+    n = newgrp.numel()
+    t = torch.empty(n, dtype=torch.bool, device=newgrp.device)
+    t[:-1] = ~(newgrp[:-1] & newgrp[1:])
+    t[-1] = ~newgrp[-1]
+    return t
+
+
 def suffix_array(codes, max_bucket=1 << 30, verbose=False):
     """codes: uint8 tensor (values 0..3).  Returns int64 tensor sa of length n: sorted suffix start positions
     (the '$' suffix, SA[0] = n in the reference's numbering, is NOT included)."""
@@ -40,75 +113,82 @@ def suffix_array(codes, max_bucket=1 << 30, verbose=False):
     dev = codes.device
     keys = _kmer_keys(codes, K0)
     sa = torch.empty(n, dtype=torch.int64, device=dev)
+    newgrp = torch.ones(n, dtype=torch.bool, device=dev)
     # bucket by leading characters so that every sort is well below 2^31 elements
     lead_chars = 0
     while (n >> (2 * lead_chars)) > max_bucket // 2 and lead_chars < 8:
         lead_chars += 1
     nb = 1 << (2 * lead_chars)
     if nb == 1:
-        order = torch.argsort(keys)
+        ks, order = torch.sort(keys)
         sa[:] = order
-        skeys = keys[order]
+        newgrp[1:] = ks[1:] != ks[:-1]
+        del ks, order
     else:
-        bid = (keys >> (2 * (K0 - lead_chars))).to(torch.int16)
-        skeys = torch.empty(n, dtype=torch.int64, device=dev)
+        shift = 2 * (K0 - lead_chars)
         off = 0
         for b in range(nb):
-            pos = torch.nonzero(bid == b).squeeze(1)
-            if pos.numel() == 0:
-                continue
-            kb = keys[pos]
-            ks, o = torch.sort(kb)
+            parts = []
+            for a in range(0, n, CH):
+                e = min(n, a + CH)
+                nz = torch.nonzero((keys[a:e] >> shift) == b).squeeze(1)
+                parts.append(nz + a if a else nz)
+            pos = parts[0] if len(parts) == 1 else torch.cat(parts)
+            del parts
             m = pos.numel()
+            if m == 0:
+                continue
+            ks, o = torch.sort(keys[pos])
             sa[off:off + m] = pos[o]
-            skeys[off:off + m] = ks
+            newgrp[off + 1:off + m] = ks[1:] != ks[:-1]          # a bucket boundary is always a group boundary
             off += m
-            del pos, kb, ks, o
-        del bid
+            del pos, ks, o
     del keys
-    # group starts: rank[p] = SA index of the first member of p's group
-    newgrp = torch.ones(n, dtype=torch.bool, device=dev)
-    newgrp[1:] = skeys[1:] != skeys[:-1]
-    del skeys
-    idx = torch.arange(n, dtype=torch.int64, device=dev)
-    gstart = torch.cummax(torch.where(newgrp, idx, torch.zeros_like(idx)), 0).values
+    unresolved = _tied(newgrp)
+    if not bool(unresolved.any()):
+        if verbose:
+            print("  [sa] all suffixes distinct within %d characters" % K0)
+        return sa
+    # rank[p] = SA index of the first member of p's group
+    gstart = _group_starts(newgrp)
     rank = torch.empty(n, dtype=torch.int64, device=dev)
-    rank[sa] = gstart
-    # unresolved = members of groups of size > 1
-    nxt = torch.ones(n, dtype=torch.bool, device=dev)
-    nxt[:-1] = newgrp[1:]
-    unresolved = ~(newgrp & nxt)
-    del nxt, newgrp, gstart
+    _scatter_big(rank, sa, gstart)
+    del gstart, newgrp
     h = K0
     rounds = 0
     while True:
-        sidx = torch.nonzero(unresolved).squeeze(1)          # SA slots still tied, ascending
+        sidx = _nonzero_big(unresolved)                      # SA slots still tied, ascending
         m = sidx.numel()
         if verbose:
             print("  [sa] h=%d unresolved=%d" % (h, m))
         if m == 0:
             break
-        pos = sa[sidx]
-        g = rank[pos]                                        # group id = SA index of group start
+        pos = _gather_big(sa, sidx)
+        g = _gather_big(rank, pos)                           # group id = SA index of group start
         q = pos + h
-        r2 = torch.where(q < n, rank[torch.clamp(q, max=n - 1)], n - q - 1)    # beyond the end: shorter suffix first
+        r2 = torch.where(q < n, _gather_big(rank, torch.clamp(q, max=n - 1)), n - q - 1)   # beyond the end: shorter suffix first
         # dense group labels keep the composite key inside int64
         gl = torch.ones(m, dtype=torch.bool, device=dev)
         gl[1:] = g[1:] != g[:-1]
-        dense = torch.cumsum(gl.to(torch.int64), 0) - 1
+        dense = _cumsum_big(gl) - 1
         span = n + h + 2
         comp = dense * span + (r2 + h + 1)
+        del g, q, r2, gl, dense
+        if m >= (1 << 31):
+            raise RuntimeError("too many tied suffixes for one sort (%d); text is too repetitive for this builder" % m)
         cs, o = torch.sort(comp)
+        del comp
         pos_sorted = pos[o]
-        sa[sidx] = pos_sorted
+        del pos, o
+        _scatter_big(sa, sidx, pos_sorted)
         newg = torch.ones(m, dtype=torch.bool, device=dev)
         newg[1:] = cs[1:] != cs[:-1]
-        gs = torch.cummax(torch.where(newg, sidx, torch.zeros_like(sidx)), 0).values
-        rank[pos_sorted] = gs
-        nx = torch.ones(m, dtype=torch.bool, device=dev)
-        nx[:-1] = newg[1:]
-        still = ~(newg & nx)
-        unresolved[sidx] = still
+        del cs
+        gs = _group_starts(newg, sidx)
+        _scatter_big(rank, pos_sorted, gs)
+        del gs, pos_sorted
+        unresolved[sidx] = _tied(newg)
+        del newg, sidx
         h *= 2
         rounds += 1
         if rounds > 40:
@@ -117,13 +197,20 @@ def suffix_array(codes, max_bucket=1 << 30, verbose=False):
 
 
 def _pack_msb_words(codes, n_words):
-    """codes (uint8 tensor) -> uint32 words, 16 chars per word, first char in the most significant bits"""
+    """codes (uint8 tensor) -> words (int64 holding uint32 values), 16 chars per word, first char in the top bits"""
     dev = codes.device
-    buf = torch.zeros(n_words * 16, dtype=torch.int64, device=dev)
-    buf[:codes.numel()] = codes.to(torch.int64)
+    n = codes.numel()
+    out = torch.empty(n_words, dtype=torch.int64, device=dev)
     sh = (2 * (15 - torch.arange(16, dtype=torch.int64, device=dev)))
-    w = (buf.view(n_words, 16) << sh).sum(dim=1)
-    return w
+    wch = CH // 16
+    for a in range(0, n_words, wch):
+        b = min(n_words, a + wch)
+        buf = torch.zeros((b - a) * 16, dtype=torch.int64, device=dev)
+        lo, hi = a * 16, min(n, b * 16)
+        if hi > lo:
+            buf[:hi - lo] = codes[lo:hi].to(torch.int64)
+        out[a:b] = (buf.view(b - a, 16) << sh).sum(dim=1)
+    return out
 
 
 def _half_index(codes, verbose=False):
@@ -136,22 +223,43 @@ def _half_index(codes, verbose=False):
     sa_full[0] = n
     sa_full[1:] = sa
     del sa
-    inv0 = int(torch.nonzero(sa_full == 0).item())
-    prev = sa_full - 1
-    keep = torch.ones(n + 1, dtype=torch.bool, device=dev)
-    keep[inv0] = False
-    stored = codes[prev[keep]]                                # n characters, '$' dropped (BWT.c:169-194)
-    del prev, keep
-    cnt = torch.bincount(codes.to(torch.int64), minlength=4)
+    inv0 = -1
+    for a in range(0, n + 1, CH):
+        z = torch.nonzero(sa_full[a:min(n + 1, a + CH)] == 0)
+        if z.numel():
+            inv0 = a + int(z[0])
+    # stored BWT: text[SA[i]-1] for every i except the one where SA[i] = 0 ('$' is not stored; BWT.c:169-194)
+    stored = torch.empty(n, dtype=torch.uint8, device=dev)
+    for a in range(0, n + 1, CH):
+        b = min(n + 1, a + CH)
+        ch = codes[torch.clamp(sa_full[a:b] - 1, min=0)]
+        # destination index: i for i < inv0, i-1 for i > inv0
+        if b <= inv0:
+            stored[a:b] = ch
+        elif a > inv0:
+            stored[a - 1:b - 1] = ch
+        else:
+            k = inv0 - a
+            stored[a:inv0] = ch[:k]
+            stored[inv0:b - 1] = ch[k + 1:]
+    cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    for a in range(0, n, CH):
+        cnt += torch.bincount(codes[a:min(n, a + CH)].to(torch.int64), minlength=4)
     cum = [0] + [int(x) for x in torch.cumsum(cnt, 0)]
     n_words = (n + 15) // 16
     bwt_words = _pack_msb_words(stored, n_words)
     # sampled ranks every 128 characters over the zero-padded stored string, + C[c]  (BGS-Build.cpp:139-161)
     recs = (n + 127) // 128 + 1
-    padded = torch.zeros((recs - 1) * 128, dtype=torch.int64, device=dev)
-    padded[:n] = stored.to(torch.int64)
-    blk = torch.arange((recs - 1) * 128, dtype=torch.int64, device=dev) // 128
-    per = torch.bincount(blk * 4 + padded, minlength=(recs - 1) * 4).view(recs - 1, 4)
+    per = torch.zeros(((recs - 1), 4), dtype=torch.int64, device=dev)
+    bch = CH // 128
+    for a in range(0, recs - 1, bch):
+        b = min(recs - 1, a + bch)
+        seg = torch.zeros((b - a) * 128, dtype=torch.int64, device=dev)
+        lo, hi = a * 128, min(n, b * 128)
+        if hi > lo:
+            seg[:hi - lo] = stored[lo:hi].to(torch.int64)
+        blk = torch.arange((b - a) * 128, dtype=torch.int64, device=dev) // 128
+        per[a:b] = torch.bincount(blk * 4 + seg, minlength=(b - a) * 4).view(b - a, 4)
     occ = torch.zeros((recs, 4), dtype=torch.int64, device=dev)
     occ[1:] = torch.cumsum(per, 0)
     occ += torch.tensor(cum[:4], dtype=torch.int64, device=dev)
@@ -160,8 +268,16 @@ def _half_index(codes, verbose=False):
 
 def _lookup_table(codes, k=13):
     n = codes.numel()
-    keys = _kmer_keys(codes, k)
-    cnt = torch.bincount(keys, minlength=1 << (2 * k))
+    dev = codes.device
+    padded = torch.zeros(n + k, dtype=torch.uint8, device=dev)
+    padded[:n] = codes
+    cnt = torch.zeros(1 << (2 * k), dtype=torch.int64, device=dev)
+    for a in range(0, n, CH // 4):
+        b = min(n, a + CH // 4)
+        acc = torch.zeros(b - a, dtype=torch.int64, device=dev)
+        for j in range(k):
+            acc = (acc << 2) | padded[a + j:b + j].to(torch.int64)
+        cnt += torch.bincount(acc, minlength=1 << (2 * k))
     return torch.cumsum(cnt, 0)
 
 

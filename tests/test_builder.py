@@ -35,3 +35,17 @@ def test_suffix_array_with_long_repeats_and_small_buckets():
     s = codes.tobytes()
     want = sorted(range(len(codes)), key=lambda p: s[p:] + b"")   # bytes compare: shorter prefix first == '$' smallest
     assert list(sa) == want
+
+
+def test_builder_chunked_paths(monkeypatch):
+    """same result when every scan / nonzero / gather is forced through the multi-chunk code path (used above 2^30 elements)"""
+    monkeypatch.setattr(builder, "CH", 1 << 12)
+    ref = host_index("g2")
+    mine = builder.build_host_index(ref.codes, device="cpu")
+    for half in ("fwd", "rev"):
+        a, b = getattr(mine, half), getattr(ref, half)
+        assert a["inverseSa0"] == b["inverseSa0"] and a["cum"] == b["cum"]
+        assert (a["bwt"] == b["bwt"]).all() and (a["occ"] == b["occ"]).all()
+    assert (mine.sa == ref.sa).all()
+    assert (mine.lkt == ref.lkt).all() and (mine.rev_lkt == ref.rev_lkt).all()
+    assert (mine.pac == ref.pac).all()
