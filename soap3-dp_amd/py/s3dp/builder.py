@@ -242,10 +242,12 @@ def _half_index(codes, verbose=False):
             k = inv0 - a
             stored[a:inv0] = ch[:k]
             stored[inv0:b - 1] = ch[k + 1:]
-    cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    cnt = [0, 0, 0, 0]
     for a in range(0, n, CH):
-        cnt += torch.bincount(codes[a:min(n, a + CH)].to(torch.int64), minlength=4)
-    cum = [0] + [int(x) for x in torch.cumsum(cnt, 0)]
+        seg = codes[a:min(n, a + CH)]
+        for c in range(4):
+            cnt[c] += int((seg == c).sum())
+    cum = [0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2], n]
     n_words = (n + 15) // 16
     bwt_words = _pack_msb_words(stored, n_words)
     # sampled ranks every 128 characters over the zero-padded stored string, + C[c]  (BGS-Build.cpp:139-161)
@@ -254,12 +256,13 @@ def _half_index(codes, verbose=False):
     bch = CH // 128
     for a in range(0, recs - 1, bch):
         b = min(recs - 1, a + bch)
-        seg = torch.zeros((b - a) * 128, dtype=torch.int64, device=dev)
+        seg = torch.zeros((b - a) * 128, dtype=torch.uint8, device=dev)
         lo, hi = a * 128, min(n, b * 128)
         if hi > lo:
-            seg[:hi - lo] = stored[lo:hi].to(torch.int64)
-        blk = torch.arange((b - a) * 128, dtype=torch.int64, device=dev) // 128
-        per[a:b] = torch.bincount(blk * 4 + seg, minlength=(b - a) * 4).view(b - a, 4)
+            seg[:hi - lo] = stored[lo:hi]
+        seg = seg.view(b - a, 128)
+        for c in range(4):
+            per[a:b, c] = (seg == c).sum(dim=1)
     occ = torch.zeros((recs, 4), dtype=torch.int64, device=dev)
     occ[1:] = torch.cumsum(per, 0)
     occ += torch.tensor(cum[:4], dtype=torch.int64, device=dev)
@@ -272,8 +275,9 @@ def _lookup_table(codes, k=13):
     padded = torch.zeros(n + k, dtype=torch.uint8, device=dev)
     padded[:n] = codes
     cnt = torch.zeros(1 << (2 * k), dtype=torch.int64, device=dev)
-    for a in range(0, n, CH // 4):
-        b = min(n, a + CH // 4)
+    step = min(CH, 1 << 26)          # torch.bincount on ROCm dies (SIGFPE) on 2^30-element inputs: keep calls small
+    for a in range(0, n, step):
+        b = min(n, a + step)
         acc = torch.zeros(b - a, dtype=torch.int64, device=dev)
         for j in range(k):
             acc = (acc << 2) | padded[a + j:b + j].to(torch.int64)
