@@ -127,6 +127,11 @@ void s3_free(void *p);
  * writes one text line per case in the same form as the reference dump used by the oracle harness. */
 int  s3_model_describe(int readLength, int maxError, char *buf, size_t bufLen);
 
+/* measurement aid, not part of the alignment path: rate of random 64-byte-line gathers on this device
+ * (the practical ceiling of a rank-query stream).  Reports the average kernel time and lines read per launch. */
+int  s3_probe_gather(int device, size_t tableBytes, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,
+                     int repeats, float *msOut, uint64_t *linesOut);
+
 int  s3_device_count(void);
 const char *s3_last_error(void);
 const char *s3_version(void);

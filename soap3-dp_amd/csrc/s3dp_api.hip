@@ -593,3 +593,37 @@ extern "C" int s3_bwt_search(s3_index *ix, const uint32_t *queries, const uint32
     if (withError) *withError = we; else free(we);
     return S3_OK;
 }
+
+// measurement aid (tools/hbm_probe.py): random 64-byte-line gather rate of the device
+extern "C" int s3_probe_gather(int device, size_t tableBytes, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,
+                               int repeats, float *msOut, uint64_t *linesOut)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(S3_ENODEV, "no HIP device available");
+    HIPCHK(hipSetDevice(device));
+    uint4 *table = nullptr;
+    uint32_t *sink = nullptr;
+    const uint64_t nLines = tableBytes / 64;
+    if (nLines == 0 || repeats < 1) return fail(S3_EINVAL, "bad probe arguments");
+    HIPCHK(hipMalloc((void **)&table, nLines * 64));
+    HIPCHK(hipMalloc((void **)&sink, 16));
+    HIPCHK(hipMemset(table, 1, nLines * 64));
+    hipStream_t s;
+    hipEvent_t e0, e1;
+    HIPCHK(hipStreamCreate(&s));
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    launchGatherProbe(table, nLines, blocks, itersPerLane, ilp, loadsPerLine, dependent, sink, s);     // warm-up
+    HIPCHK(hipEventRecord(e0, s));
+    for (int r = 0; r < repeats; r++) launchGatherProbe(table, nLines, blocks, itersPerLane, ilp, loadsPerLine, dependent, sink, s);
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    const int eff = ilp >= 8 ? 8 : ilp >= 4 ? 4 : ilp >= 2 ? 2 : 1;
+    if (msOut) *msOut = ms / repeats;
+    if (linesOut) *linesOut = (uint64_t)blocks * 256ull * itersPerLane * eff;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    (void)hipFree(table); (void)hipFree(sink);
+    return S3_OK;
+}

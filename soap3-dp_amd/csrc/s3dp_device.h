@@ -68,4 +68,7 @@ void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOff
 void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *withError, uint32_t mm, uint32_t allowSpecial, uint8_t *state,
                     hipStream_t s);
 
+void launchGatherProbe(const uint4 *table, uint64_t nLines, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,
+                       uint32_t *sink, hipStream_t s);
+
 }  // namespace s3

@@ -543,3 +543,48 @@ void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *
 }
 
 }  // namespace s3
+
+// ---------------------------------------------------------------------------------------------
+// measurement aid: random 64-byte-line gather rate of this GPU (the practical ceiling of a rank-query
+// stream).  Every lane draws pseudo-random lines of a table, reads `loadsPerLine` x 16 B from each and
+// keeps `ILP` independent lines in flight.  Not part of the alignment path.
+// ---------------------------------------------------------------------------------------------
+namespace s3 {
+
+template <int ILP>
+__global__ void __launch_bounds__(256) gatherProbeKernel(const uint4 *table, uint64_t nLines, uint32_t itersPerLane, int loadsPerLine, int dependent,
+                                                         uint32_t *sink)
+{
+    uint64_t x = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < itersPerLane; it++) {
+        uint4 v[ILP];
+        uint64_t line[ILP];
+#pragma unroll
+        for (int k = 0; k < ILP; k++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;                 // xorshift64
+            line[k] = (x + (dependent ? acc : 0u)) % nLines;
+        }
+#pragma unroll
+        for (int k = 0; k < ILP; k++) {
+            const uint4 *p = table + line[k] * 4;
+            v[k] = p[0];
+            if (loadsPerLine > 1) { uint4 w = p[1 + (line[k] & 1)]; v[k].x ^= w.x; v[k].y ^= w.w; }
+            if (loadsPerLine > 2) { uint4 w = p[3]; v[k].z ^= w.y; }
+        }
+#pragma unroll
+        for (int k = 0; k < ILP; k++) acc += v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;                           // keeps the loads alive
+}
+
+void launchGatherProbe(const uint4 *table, uint64_t nLines, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,
+                       uint32_t *sink, hipStream_t s)
+{
+    if (ilp >= 8) hipLaunchKernelGGL(gatherProbeKernel<8>, dim3(blocks), dim3(256), 0, s, table, nLines, itersPerLane, loadsPerLine, dependent, sink);
+    else if (ilp >= 4) hipLaunchKernelGGL(gatherProbeKernel<4>, dim3(blocks), dim3(256), 0, s, table, nLines, itersPerLane, loadsPerLine, dependent, sink);
+    else if (ilp >= 2) hipLaunchKernelGGL(gatherProbeKernel<2>, dim3(blocks), dim3(256), 0, s, table, nLines, itersPerLane, loadsPerLine, dependent, sink);
+    else hipLaunchKernelGGL(gatherProbeKernel<1>, dim3(blocks), dim3(256), 0, s, table, nLines, itersPerLane, loadsPerLine, dependent, sink);
+}
+
+}  // namespace s3

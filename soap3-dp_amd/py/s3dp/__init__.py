@@ -37,7 +37,7 @@ class Counters(C.Structure):
 EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
            "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_fetch_alignments", "s3_batch_sync",
            "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
-           "s3_device_count", "s3_last_error", "s3_version"]
+           "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather"]
 
 _lib = None
 
@@ -74,6 +74,14 @@ def lib():
 def _chk(rc):
     if rc != 0:
         raise S3Error("libs3dp error %d: %s" % (rc, lib().s3_last_error().decode()))
+
+
+def probe_gather(table_bytes, blocks=256 * 8, iters=256, ilp=4, loads_per_line=2, dependent=0, repeats=3, device=0):
+    ms, lines = C.c_float(), C.c_uint64()
+    f = lib().s3_probe_gather
+    f.argtypes = [C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+    _chk(f(device, table_bytes, blocks, iters, ilp, loads_per_line, dependent, repeats, C.byref(ms), C.byref(lines)))
+    return ms.value, lines.value
 
 
 def device_count():
