@@ -33,40 +33,37 @@ __device__ __forceinline__ uint64_t loMask(uint32_t nChars)   // last nChars
     return nChars >= 32 ? ~0ULL : ((1ULL << (2 * nChars)) - 1ULL);
 }
 
-__device__ __forceinline__ void count4(uint64_t w, uint64_t m, uint32_t c[4])
-{
-    const uint64_t M5 = 0x5555555555555555ULL;
-    const uint64_t lo = w & M5, hi = (w >> 1) & M5;
-    m &= M5;
-    const uint32_t c3 = __popcll(hi & lo & m), c2 = __popcll(hi & ~lo & m), c1 = __popcll(~hi & lo & m);
-    c[3] += c3; c[2] += c2; c[1] += c1; c[0] += __popcll(m) - c1 - c2 - c3;
-}
-
 // v[c] = Occ(c, i) + C[c]   (GPUBWTAllOccValue, DV-Kernel.cu:282-299; BWTAllOccValue, BWT.c:1211)
-__device__ __forceinline__ void rankAll(const DevBwt &b, uint32_t i, uint32_t v[4])
+// Everything stays in registers: no dynamically indexed arrays (they would live in scratch memory).
+__device__ __forceinline__ uint4 rankAll(const DevBwt &b, uint32_t i)
 {
     i -= (i > b.inverseSa0);
     const uint32_t k = (i + 63u) >> 7, p = k << 7;
     const uint4 *line = b.lines + (size_t)k * 4;
-    const uint4 o = line[0];
-    v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
+    uint4 v = line[0];
     if (i != p) {
         const bool fwd = i > p;
         const uint32_t d = fwd ? i - p : p - i;
         const uint4 w = line[fwd ? 2 : 1];
         const uint64_t w0 = ((uint64_t)w.x << 32) | w.y, w1 = ((uint64_t)w.z << 32) | w.w;
-        uint32_t c[4] = {0, 0, 0, 0};
-        if (fwd) {
-            count4(w0, hiMask(d), c);
-            if (d > 32) count4(w1, hiMask(d - 32), c);
-            v[0] += c[0]; v[1] += c[1]; v[2] += c[2]; v[3] += c[3];
-        } else {
-            count4(w1, loMask(d), c);
-            if (d > 32) count4(w0, loMask(d - 32), c);
-            v[0] -= c[0]; v[1] -= c[1]; v[2] -= c[2]; v[3] -= c[3];
-        }
+        // characters counted: the first d of the 64 after the sample, or the last d of the 64 before it
+        const uint64_t mA = fwd ? hiMask(d) : loMask(d);
+        const uint64_t mB = d > 32 ? (fwd ? hiMask(d - 32) : loMask(d - 32)) : 0ULL;
+        const uint64_t wA = fwd ? w0 : w1, wB = fwd ? w1 : w0;
+        const uint64_t M5 = 0x5555555555555555ULL;
+        const uint64_t loA = wA & M5, hiA = (wA >> 1) & M5, loB = wB & M5, hiB = (wB >> 1) & M5;
+        const uint64_t a = mA & M5, bm = mB & M5;
+        const uint32_t c3 = __popcll(hiA & loA & a) + __popcll(hiB & loB & bm);
+        const uint32_t c2 = __popcll(hiA & ~loA & a) + __popcll(hiB & ~loB & bm);
+        const uint32_t c1 = __popcll(~hiA & loA & a) + __popcll(~hiB & loB & bm);
+        const uint32_t c0 = d - c1 - c2 - c3;
+        if (fwd) { v.x += c0; v.y += c1; v.z += c2; v.w += c3; }
+        else { v.x -= c0; v.y -= c1; v.z -= c2; v.w -= c3; }
     }
+    return v;
 }
+
+__device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
 
 // ---------------------------------------------------------------------------------------------
 // per-lane search state
@@ -174,22 +171,22 @@ __device__ void checkAndExtend(Lane &L, int s, int i, int inserted, uint32_t l, 
     }
 }
 
-__device__ __forceinline__ void stepRanks(Lane &L, int dir, const Range &g, uint32_t oL[4], uint32_t oR[4])
+__device__ __forceinline__ void stepRanks(Lane &L, int dir, const Range &g, uint4 &oL, uint4 &oR)
 {
     const DevBwt &b = dir < 0 ? L.ix->fwd : L.ix->rev;
-    rankAll(b, dir < 0 ? g.fl : g.rl, oL);
-    rankAll(b, (dir < 0 ? g.fr : g.rr) + 1u, oR);
+    oL = rankAll(b, dir < 0 ? g.fl : g.rl);
+    oR = rankAll(b, (dir < 0 ? g.fr : g.rr) + 1u);
     L.nRank += 2;
 }
 
-__device__ __forceinline__ Range childRange(int dir, const Range &g, const uint32_t oL[4], const uint32_t oR[4], uint32_t ch)
+__device__ __forceinline__ Range childRange(int dir, const Range &g, const uint4 &oL, const uint4 &oR, uint32_t ch)
 {
     // active range advances by rank; passive range shrinks by the occurrences of the larger symbols
-    const uint32_t al = oL[ch] + 1u, ar = oR[ch];
+    const uint32_t al = sel4(oL, ch) + 1u, ar = sel4(oR, ch);
     uint32_t oc = 0;
-    if (ch < 3) oc += oR[3] - oL[3];
-    if (ch < 2) oc += oR[2] - oL[2];
-    if (ch < 1) oc += oR[1] - oL[1];
+    if (ch < 3) oc += oR.w - oL.w;
+    if (ch < 2) oc += oR.z - oL.z;
+    if (ch < 1) oc += oR.y - oL.y;
     const uint32_t pr = (dir < 0 ? g.rr : g.fr) - oc, pl = pr - (ar - al);
     Range o;
     if (dir < 0) { o.fl = al; o.fr = ar; o.rl = pl; o.rr = pr; }
@@ -242,7 +239,7 @@ __device__ void runItem(Lane &L)
                 done = true;
                 break;
             }
-            uint32_t oL[4], oR[4];
+            uint4 oL, oR;
             stepRanks(L, st.dir, g, oL, oR);
             g = childRange(st.dir, g, oL, oR, readChar(L, pos));
             i++; pos += st.dir;
@@ -279,28 +276,27 @@ __device__ void runItem(Lane &L)
                 break;
             }
             const uint32_t ch = readChar(L, pos);
-            uint32_t oL[4], oR[4];
+            uint4 oL, oR;
             stepRanks(L, st.dir, g, oL, oR);
             const Range gc = childRange(st.dir, g, oL, oR, ch);
             if (!exact) {
                 // children k != ch must be explored (k ascending) before the walk continues with ch:
-                // push the continuation first, then the children in descending k.
-                int pushed = 0;
-                Frame cont;
-                cont.g = gc; cont.s = f.s; cont.i = (int16_t)(i + 1); cont.ins = (int8_t)inserted; cont.occ = f.occ;
-                Frame kids[3];
-                for (int k = 3; k >= 0; k--) {
-                    if ((uint32_t)k == ch) continue;
-                    const Range e = childRange(st.dir, g, oL, oR, (uint32_t)k);
-                    if (e.fl <= e.fr) {
-                        Frame &c = kids[pushed++];
-                        c.g = e; c.s = f.s; c.i = (int16_t)(i + 1); c.ins = (int8_t)(inserted + 1); c.occ = f.occ;
-                    }
-                }
-                if (pushed > 0) {
-                    if (sp + pushed + 1 > S3_STACK) { atomicOr(L.out.flags, S3_FLAG_STACK_OVERFLOW); return; }
-                    stack[sp++] = cont;
-                    for (int k = 0; k < pushed; k++) stack[sp++] = kids[k];
+                // push the continuation first, then the live children in descending k.
+                const Range e0 = childRange(st.dir, g, oL, oR, 0u), e1 = childRange(st.dir, g, oL, oR, 1u);
+                const Range e2 = childRange(st.dir, g, oL, oR, 2u), e3 = childRange(st.dir, g, oL, oR, 3u);
+                const bool a0 = ch != 0 && e0.fl <= e0.fr, a1 = ch != 1 && e1.fl <= e1.fr;
+                const bool a2 = ch != 2 && e2.fl <= e2.fr, a3 = ch != 3 && e3.fl <= e3.fr;
+                if (a0 || a1 || a2 || a3) {
+                    if (sp + 4 > S3_STACK) { atomicOr(L.out.flags, S3_FLAG_STACK_OVERFLOW); return; }
+                    Frame c;
+                    c.s = f.s; c.i = (int16_t)(i + 1); c.occ = f.occ; c.pad = 0;
+                    c.g = gc; c.ins = (int8_t)inserted;
+                    stack[sp++] = c;
+                    c.ins = (int8_t)(inserted + 1);
+                    if (a3) { c.g = e3; stack[sp++] = c; }
+                    if (a2) { c.g = e2; stack[sp++] = c; }
+                    if (a1) { c.g = e1; stack[sp++] = c; }
+                    if (a0) { c.g = e0; stack[sp++] = c; }
                     suspended = true;
                     break;
                 }
