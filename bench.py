@@ -229,13 +229,12 @@ def main():
         launches += k
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    agg = torch.tensor([float(aligned), float(n_occ), float(cnt["rankQueries"])], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)           # the only collective of the path: final counters
-    dt = float(tmax.item())
-    total_reads = a.reads * world
+    from s3dp import dist as sd
+    dt = sd.max_over_ranks(dt, device=dev)
+    # the only collective of the path: the final reduce of the counters (RCCL all-reduce of 5 numbers)
+    tot = sd.reduce_counters({"reads": a.reads, "readsAligned": aligned, "alignments": n_occ, "rankQueries": cnt["rankQueries"],
+                              "records": cnt["records"]}, device=dev)
+    total_reads = tot["reads"]
     value = total_reads * a.steps / dt / 1e6
 
     # ---- roofline of the dominant kernel (searchKernel) --------------------------------------------------
@@ -257,7 +256,7 @@ def main():
                       "genome_bp": a.genome_bp, "reads_per_gpu": a.reads, "read_len": a.read_len, "max_mismatch": a.mismatch,
                       "max_output_per_read": a.max_out, "repeat_frac": a.repeat_frac, "parallelism": "reads sharded x%d, index replicated" % world},
            "roofline": roof,
-           "aligned_reads": int(agg[0].item()), "occurrences": int(agg[1].item()),
+           "aligned_reads": tot["readsAligned"], "occurrences": tot["alignments"],
            "rank_queries_per_read": cnt["rankQueries"] / a.reads}
 
     # ---- correctness spot check + CPU baseline (rank 0, N = 1) ------------------------------------------
