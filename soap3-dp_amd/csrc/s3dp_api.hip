@@ -289,7 +289,13 @@ static int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uin
     out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
     out.counters = b->counting ? b->dCounters : nullptr;
     if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
-    launchSearch(b->ix->d, in, out, 256u * 8u * 4u, b->stream);
+    {
+        // S3DP_KERNEL=v1 selects the first-generation one-thread-per-item kernel (kept for A/B measurements)
+        static const bool useV1 = [] { const char *e = getenv("S3DP_KERNEL"); return e && strcmp(e, "v1") == 0; }();
+        static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", 6);
+        if (useV1) launchSearch(b->ix->d, in, out, 256u * 8u * 4u, b->stream);
+        else launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
+    }
     if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
     b->searchLaunches++;
     HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, 4, b->stream));

@@ -1,0 +1,444 @@
+// s3dp_search_v2.hip -- wave-cooperative 2BWT k-mismatch search for gfx950 (the production search kernel).
+//
+// Same results, record for record, as s3::searchKernel (v1, s3dp_kernels.hip) and as the reference CPU path;
+// different machine mapping.  Measurement on MI355X (tools/hbm_probe.py) shows that a rank-query stream is bound
+// by the number of vector-memory REQUESTS, not by DRAM bytes: two 16-B lane loads into the same 64-B line cost
+// as much as two lines.  So v2 issues ONE coalesced 64-B request per rank line:
+//
+//   * a wavefront runs 64 items (same case, same strand) as a flat state machine: every iteration first ISSUES
+//     all memory operations of all lanes (rank lines, suffix-array entries, packed-text windows), then waits
+//     once, then every lane advances its own search (pure ALU + LDS) until it needs memory again;
+//   * rank lines are fetched cooperatively: 4 adjacent lanes load the 4 x 16 B of one owner's line (the owner's
+//     line id travels by ds_bpermute), the line is staged in LDS and read back by its owner -- "Occ/rank tables
+//     staged through LDS for coalesced HBM reads".  l and r+1 almost always fall into the same line once the
+//     range is narrow; only lanes whose two lines differ issue a private second fetch;
+//   * the case's step table sits in LDS (one copy per wave), raw read words sit in LDS word-interleaved by
+//     lane; strand orientation and the MSB-first windows needed by check-and-extend are computed on the fly
+//     with funnel shifts, no per-character loops;
+//   * check-and-extend is part of the same state machine (SA entry -> text window -> compare), so its memory
+//     latency overlaps with the other lanes' rank fetches instead of serialising behind divergent branches.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "s3dp_device.h"
+#include "s3dp_model.h"
+
+namespace s3 {
+
+namespace v2 {
+
+enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_CESA = 2, ST_CETXT = 3 };
+constexpr uint32_t ID_NONE = 0x7FFFFFFFu;
+constexpr int STACK = 20;
+constexpr uint32_t CE_CHUNK = 112;                   // text characters compared per iteration (8 words minus alignment slack)
+
+struct Frame { uint32_t fl, fr, rl, meta; };        // rr = rl + (fr - fl);  meta = s | i << 3 | ins << 14 | occ << 17
+
+__device__ __forceinline__ uint64_t hiMask(uint32_t nChars) { return nChars >= 32 ? ~0ULL : (nChars == 0 ? 0ULL : (~0ULL << (64 - 2 * nChars))); }
+__device__ __forceinline__ uint64_t loMask(uint32_t nChars) { return nChars >= 32 ? ~0ULL : ((1ULL << (2 * nChars)) - 1ULL); }
+__device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+__device__ __forceinline__ uint32_t pairRev(uint32_t x)   // reverse the order of the 16 2-bit characters of a word
+{
+    x = __brev(x);
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+
+// rank from a staged line: occ = Occ(.,128k)+C, w = the 64 characters before (i < p) or after (i > p) the sample
+__device__ __forceinline__ uint4 rankFromLine(uint32_t i, uint4 occ, uint4 w)
+{
+    const uint32_t k = (i + 63u) >> 7, p = k << 7;
+    uint4 v = occ;
+    if (i != p) {
+        const bool fwd = i > p;
+        const uint32_t d = fwd ? i - p : p - i;
+        const uint64_t w0 = ((uint64_t)w.x << 32) | w.y, w1 = ((uint64_t)w.z << 32) | w.w;
+        const uint64_t mA = fwd ? hiMask(d) : loMask(d);
+        const uint64_t mB = d > 32 ? (fwd ? hiMask(d - 32) : loMask(d - 32)) : 0ULL;
+        const uint64_t wA = fwd ? w0 : w1, wB = fwd ? w1 : w0;
+        const uint64_t M5 = 0x5555555555555555ULL;
+        const uint64_t loA = wA & M5, hiA = (wA >> 1) & M5, loB = wB & M5, hiB = (wB >> 1) & M5;
+        const uint64_t a = mA & M5, bm = mB & M5;
+        const uint32_t c3 = __popcll(hiA & loA & a) + __popcll(hiB & loB & bm);
+        const uint32_t c2 = __popcll(hiA & ~loA & a) + __popcll(hiB & ~loB & bm);
+        const uint32_t c1 = __popcll(~hiA & loA & a) + __popcll(~hiB & loB & bm);
+        const uint32_t c0 = d - c1 - c2 - c3;
+        if (fwd) { v.x += c0; v.y += c1; v.z += c2; v.w += c3; }
+        else { v.x -= c0; v.y -= c1; v.z -= c2; v.w -= c3; }
+    }
+    return v;
+}
+
+struct Range { uint32_t fl, fr, rl, rr; };
+
+__device__ __forceinline__ Range childRange(int dir, const Range &g, const uint4 &oL, const uint4 &oR, uint32_t ch)
+{
+    const uint32_t al = sel4(oL, ch) + 1u, ar = sel4(oR, ch);
+    uint32_t oc = 0;
+    if (ch < 3) oc += oR.w - oL.w;
+    if (ch < 2) oc += oR.z - oL.z;
+    if (ch < 1) oc += oR.y - oL.y;
+    const uint32_t pr = (dir < 0 ? g.rr : g.fr) - oc, pl = pr - (ar - al);
+    Range o;
+    if (dir < 0) { o.fl = al; o.fr = ar; o.rl = pl; o.rr = pr; }
+    else { o.rl = al; o.rr = ar; o.fl = pl; o.fr = pr; }
+    return o;
+}
+
+}  // namespace v2
+
+using namespace v2;
+
+__global__ void __launch_bounds__(S3_SEARCH_BLOCK)
+searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
+{
+    extern __shared__ __align__(16) unsigned char shmem[];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t wpq = in.wpq;
+    const uint32_t waveBytes = 4096u + wpq * 256u + 128u;
+    uint4 *stage = (uint4 *)(shmem + wv * waveBytes);                       // [64 owners][4 x 16 B]
+    uint32_t *rdw = (uint32_t *)(shmem + wv * waveBytes + 4096u);           // raw read words: rdw[w * 64 + lane]
+    const S3Case *tab = (const S3Case *)(shmem + wv * waveBytes + 4096u + wpq * 256u);
+    uint32_t *myStage32 = (uint32_t *)(stage + lane * 4u);
+
+    const uint32_t nSlots = in.nActive;
+    const uint32_t groups = (uint32_t)in.nCases * 2u;
+    const uint32_t slotsPadded = (nSlots + 63u) & ~63u;
+    const uint64_t nItems = (uint64_t)slotsPadded * groups;
+    const uint64_t wavesTotal = (uint64_t)gridDim.x * (S3_SEARCH_BLOCK / 64);
+    uint32_t nRank = 0, nLt = 0, nSa = 0, nCe = 0;
+
+    for (uint64_t base = ((uint64_t)blockIdx.x * (S3_SEARCH_BLOCK / 64) + wv) * 64u; base < nItems; base += wavesTotal * 64u) {
+        const uint32_t grp = (uint32_t)(base / slotsPadded);                // wave-uniform
+        const uint32_t slot = (uint32_t)(base % slotsPadded) + lane;
+        const uint32_t cas = grp >> 1, strand = grp & 1u;                   // strand 0 '+', 1 '-'
+        const bool valid = slot < nSlots;
+        const uint32_t r = valid ? (in.active ? in.active[slot] : slot) : 0u;
+        const uint32_t len = valid ? in.readLengths[r] : 0u;
+        const uint32_t cntIdx = (slot * (uint32_t)in.nCases + cas) * 2u + strand;
+        uint32_t seq = 0, total = 0;
+
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            // ---- one pass per distinct read length in the wave (almost always exactly one) ------------------
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t L0 = (uint32_t)__shfl((int)len, leader);
+            const bool mine = valid && len == L0;
+            todo &= ~__ballot(mine);
+            {
+                const uint32_t *src = (const uint32_t *)&in.models[L0].cs[cas];
+                if (lane < sizeof(S3Case) / 4) ((uint32_t *)tab)[lane] = src[lane];
+            }
+            if (mine) {
+                const uint32_t *src = in.queries + (size_t)(r >> 5) * 32u * wpq + (r & 31u);
+                for (uint32_t w = 0; w < wpq; w++) rdw[w * 64u + lane] = src[(size_t)w * 32u];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int nSteps = tab->nSteps;
+            const int Li = (int)L0;
+
+            auto rawWord = [&](int w) -> uint32_t { return (w >= 0 && w < (int)wpq) ? rdw[(uint32_t)w * 64u + lane] : 0u; };
+            auto readChar = [&](int pos) -> uint32_t {
+                const int q = strand ? Li - 1 - pos : pos;
+                const uint32_t c = (rdw[(uint32_t)(q >> 4) * 64u + lane] >> ((q & 15) * 2)) & 3u;
+                return strand ? 3u - c : c;
+            };
+            // 16 oriented read characters starting at oriented position p0, first character in the top bits
+            auto readWindow = [&](int p0) -> uint32_t {
+                if (!strand) {
+                    const int w = p0 >> 4, sh = (p0 & 15) * 2;
+                    const uint64_t two = ((uint64_t)rawWord(w + 1) << 32) | rawWord(w);
+                    return pairRev((uint32_t)(two >> sh));
+                }
+                const int a = Li - 16 - p0;                      // raw characters a .. a+15, a+15 = oriented p0
+                uint32_t x;
+                if (a >= 0) {
+                    const int w = a >> 4, sh = (a & 15) * 2;
+                    const uint64_t two = ((uint64_t)rawWord(w + 1) << 32) | rawWord(w);
+                    x = (uint32_t)(two >> sh);
+                } else x = (-a < 16) ? (rawWord(0) << (2 * (-a))) : 0u;
+                return ~x;
+            };
+
+            // ---- per-lane state ------------------------------------------------------------------------------
+            uint32_t state = ST_DONE;
+            Range g = {0, 0, 0, 0};
+            int s = 0, i = 0, ins = 0, occ = 0;
+            Frame stack[STACK];
+            int sp = 0;
+            // check-and-extend context
+            uint32_t ceQ = 0, ceQEnd = 0, ceRp = 0, ceOff = 0;
+            int ceS = 0, ceI = 0, ceIns = 0, ceOcc = 0;          // where CE was entered
+            int ceT = 0, ceII = 0, ceInsCur = 0, ceAcc = 0, ceMm = 0;
+
+            auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
+                const uint32_t at = atomicAdd(out.recCount, 1u);
+                if (at < out.recCap) {
+                    uint4 rec;
+                    rec.x = cntIdx; rec.y = seq | (kind << 24) | (nmis << 25); rec.z = a; rec.w = b;
+                    out.recs[at] = rec;
+                } else atomicOr(out.flags, S3_FLAG_REC_OVERFLOW);
+                seq++;
+            };
+
+            // advance without memory until the lane needs ranks / SA / text or is finished
+            auto settle = [&](bool needPop) {
+                for (;;) {
+                    if (total >= in.maxOut) { state = ST_DONE; return; }
+                    if (needPop) {
+                        if (sp == 0) { state = ST_DONE; return; }
+                        const Frame f = stack[--sp];
+                        g.fl = f.fl; g.fr = f.fr; g.rl = f.rl; g.rr = f.rl + (f.fr - f.fl);
+                        s = (int)(f.meta & 7u); i = (int)((f.meta >> 3) & 0x7FFu); ins = (int)((f.meta >> 14) & 7u); occ = (int)((f.meta >> 17) & 7u);
+                        needPop = false;
+                    }
+                    if (s >= nSteps) {                                       // SRA_STEP_TYPE_COMPLETE
+                        uint32_t l = g.fl, rr_ = g.fr;
+                        if (rr_ >= l) {
+                            if (total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - total - 1u;
+                            emit(0, l, rr_, (uint32_t)(ins + occ));
+                            total += rr_ - l + 1u;
+                        }
+                        needPop = true;
+                        continue;
+                    }
+                    const S3Step st = tab->st[s];
+                    const bool exact = ins >= st.maxErr;
+                    int lenEff = st.len;
+                    if (!exact && st.minErr > ins + 1) lenEff -= st.minErr - ins - 1;
+                    const bool alive = g.fl <= g.fr;
+                    if (i < lenEff && alive) {
+                        const int pos = st.start + st.dir * i;
+                        if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
+                            ceQ = g.fl; ceQEnd = g.fr; ceS = s; ceI = i; ceIns = ins; ceOcc = occ;
+                            state = ST_CESA;
+                            return;
+                        }
+                        state = ST_STEP;
+                        return;
+                    }
+                    if (ins >= st.minErr && alive) { occ += ins; ins = 0; s++; i = 0; continue; }
+                    needPop = true;
+                }
+            };
+
+            // ---- item start: lookup-table range (BWTExactModel{Backward,Forward}_Lookup2) ---------------------
+            if (mine) {
+                const S3Step st = tab->st[0];
+                const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
+                auto ltKey = [&](int from, int stride, uint32_t &lp, uint32_t &rp) {
+                    lp = 0;
+                    for (int k = 0; k < ll; k++) lp = (lp << 2) | readChar(from + k * stride);
+                    rp = lp;
+                    for (int k = ll; k < ix.ltSize; k++) { lp <<= 2; rp = (rp << 2) | 3u; }
+                };
+                if (st.type == S3_T_BACK_LOOKUP) {
+                    uint32_t lp, rp;
+                    ltKey(st.start - ll + 1, 1, lp, rp);
+                    const uint32_t a = lp ? ix.lkt[lp - 1] : 0u, b = ix.lkt[rp];
+                    g.fl = lp ? a + 1u : 1u; g.fr = b; g.rl = g.fl; g.rr = g.fr;
+                    nLt += 2;
+                } else {
+                    uint32_t lp, rp, lp2, rp2;
+                    ltKey(st.start, 1, lp, rp);
+                    ltKey(st.start + ll - 1, -1, lp2, rp2);
+                    const uint32_t a = lp ? ix.lkt[lp - 1] : 0u, b = ix.lkt[rp];
+                    const uint32_t c = lp2 ? ix.rlkt[lp2 - 1] : 0u, d = ix.rlkt[rp2];
+                    uint32_t l = lp ? a + 1u : 1u, rr_ = b, rl = lp2 ? c + 1u : 1u, rrr = d;
+                    if (rr_ - l < rrr - rl) rl = rrr - (rr_ - l);
+                    else if (rr_ - l > rrr - rl) l = rr_ - (rrr - rl);
+                    g.fl = l; g.fr = rr_; g.rl = rl; g.rr = rrr;
+                    nLt += 4;
+                }
+                s = 0; i = ll; ins = 0; occ = 0;
+                settle(false);
+            }
+
+            // ---- main loop: issue all memory, wait once, advance every lane ------------------------------------
+            while (__any(state != ST_DONE)) {
+                // ---------- what does this lane need? ----------
+                uint32_t idA = ID_NONE, iL = 0, iR = 0;
+                bool needB = false;
+                int dir = 0;
+                if (state == ST_STEP) {
+                    dir = tab->st[s].dir;
+                    const DevBwt &b = dir < 0 ? ix.fwd : ix.rev;
+                    iL = dir < 0 ? g.fl : g.rl;
+                    iR = (dir < 0 ? g.fr : g.rr) + 1u;
+                    iL -= (iL > b.inverseSa0);
+                    iR -= (iR > b.inverseSa0);
+                    const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
+                    idA = kL | (dir < 0 ? 0u : 0x80000000u);
+                    needB = kR != kL;
+                }
+                // ---------- issue: cooperative rank lines ----------
+                uint4 va0, va1, va2, va3;
+                uint32_t o0, o1, o2, o3;
+                {
+                    const uint32_t sub = lane & 3u, q4 = lane >> 2;
+                    o0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((q4) * 4u), (int)idA);
+                    o1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u + q4) * 4u), (int)idA);
+                    o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((32u + q4) * 4u), (int)idA);
+                    o3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((48u + q4) * 4u), (int)idA);
+                    va0 = va1 = va2 = va3 = make_uint4(0, 0, 0, 0);
+                    if (o0 != ID_NONE) va0 = ((o0 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o0 & 0x7FFFFFFFu) * 4u + sub];
+                    if (o1 != ID_NONE) va1 = ((o1 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o1 & 0x7FFFFFFFu) * 4u + sub];
+                    if (o2 != ID_NONE) va2 = ((o2 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o2 & 0x7FFFFFFFu) * 4u + sub];
+                    if (o3 != ID_NONE) va3 = ((o3 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o3 & 0x7FFFFFFFu) * 4u + sub];
+                }
+                // ---------- issue: private loads (second rank line / SA entry / text window) ----------
+                uint4 p0 = make_uint4(0, 0, 0, 0), p1 = make_uint4(0, 0, 0, 0);
+                uint32_t saVal = 0;
+                bool ceReject = false;
+                uint32_t ceCnt = 0, ceLeft = 0, ceLen = 0, tpos = 0;
+                if (needB) {
+                    const DevBwt &b = dir < 0 ? ix.fwd : ix.rev;
+                    const uint32_t kR = (iR + 63u) >> 7;
+                    const uint4 *line = b.lines + (size_t)kR * 4u;
+                    p0 = line[0];
+                    if (iR != (kR << 7)) p1 = line[iR > (kR << 7) ? 2 : 1];
+                } else if (state == ST_CESA) {
+                    saVal = ix.sa[ceQ];
+                    nSa++;
+                } else if (state == ST_CETXT) {
+                    const S3Step st = tab->st[ceT];
+                    const int pos = st.start + st.dir * ceII;
+                    const int left = pos < st.end ? pos : st.end, right = pos < st.end ? st.end : pos;
+                    ceLeft = (uint32_t)left; ceLen = (uint32_t)(right - left + 1);
+                    if (ceOff == 0 && ceRp + ceLeft > ix.n) ceReject = true;          // BGS-HostAlgnmtAlgo2.cpp:122-125
+                    else {
+                        ceCnt = ceLen - ceOff > CE_CHUNK ? CE_CHUNK : ceLen - ceOff;
+                        tpos = ceRp + ceLeft + ceOff;
+                        const size_t bw = tpos >> 4;
+                        const uint32_t words = ((tpos & 15u) + ceCnt + 15u) >> 4;
+                        if (bw + 4 <= ix.pacWords) p0 = *(const uint4 *)(ix.pac + bw);
+                        if (words > 4 && bw + 8 <= ix.pacWords) p1 = *(const uint4 *)(ix.pac + bw + 4);
+                        nCe += (ceCnt + 31u) >> 5;
+                    }
+                }
+                // ---------- stage the cooperative lines in LDS (owner slot = 64 B) ----------
+                {
+                    const uint32_t sub = lane & 3u, q4 = lane >> 2;
+                    if (o0 != ID_NONE) stage[(q4) * 4u + sub] = va0;
+                    if (o1 != ID_NONE) stage[(16u + q4) * 4u + sub] = va1;
+                    if (o2 != ID_NONE) stage[(32u + q4) * 4u + sub] = va2;
+                    if (o3 != ID_NONE) stage[(48u + q4) * 4u + sub] = va3;
+                }
+                __builtin_amdgcn_wave_barrier();
+
+                // ---------- advance ----------
+                if (state == ST_STEP) {
+                    const uint32_t kL = (iL + 63u) >> 7;
+                    const uint4 occA = stage[lane * 4u];
+                    uint4 wL = make_uint4(0, 0, 0, 0);
+                    if (iL != (kL << 7)) wL = stage[lane * 4u + (iL > (kL << 7) ? 2u : 1u)];
+                    const uint4 oL = rankFromLine(iL, occA, wL);
+                    uint4 oR;
+                    if (needB) oR = rankFromLine(iR, p0, p1);
+                    else {
+                        uint4 wR = make_uint4(0, 0, 0, 0);
+                        if (iR != (kL << 7)) wR = stage[lane * 4u + (iR > (kL << 7) ? 2u : 1u)];
+                        oR = rankFromLine(iR, occA, wR);
+                    }
+                    nRank += 2;
+                    const S3Step st = tab->st[s];
+                    const bool exact = ins >= st.maxErr;
+                    const int pos = st.start + st.dir * i;
+                    const uint32_t ch = readChar(pos);
+                    const Range gc = childRange(st.dir, g, oL, oR, ch);
+                    bool needPop = false;
+                    if (!exact) {
+                        const Range e0 = childRange(st.dir, g, oL, oR, 0u), e1 = childRange(st.dir, g, oL, oR, 1u);
+                        const Range e2 = childRange(st.dir, g, oL, oR, 2u), e3 = childRange(st.dir, g, oL, oR, 3u);
+                        const bool a0 = ch != 0 && e0.fl <= e0.fr, a1 = ch != 1 && e1.fl <= e1.fr;
+                        const bool a2 = ch != 2 && e2.fl <= e2.fr, a3 = ch != 3 && e3.fl <= e3.fr;
+                        if (a0 || a1 || a2 || a3) {
+                            if (sp + 4 > STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = ST_DONE; sp = 0; }
+                            else {
+                                const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
+                                const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
+                                Frame f;
+                                f.fl = gc.fl; f.fr = gc.fr; f.rl = gc.rl; f.meta = mCont; stack[sp++] = f;
+                                f.meta = mKid;
+                                if (a3) { f.fl = e3.fl; f.fr = e3.fr; f.rl = e3.rl; stack[sp++] = f; }
+                                if (a2) { f.fl = e2.fl; f.fr = e2.fr; f.rl = e2.rl; stack[sp++] = f; }
+                                if (a1) { f.fl = e1.fl; f.fr = e1.fr; f.rl = e1.rl; stack[sp++] = f; }
+                                if (a0) { f.fl = e0.fl; f.fr = e0.fr; f.rl = e0.rl; stack[sp++] = f; }
+                                needPop = true;
+                            }
+                        }
+                    }
+                    if (state != ST_DONE) {
+                        if (!needPop) { g = gc; i++; }
+                        settle(needPop);
+                    }
+                } else if (state == ST_CESA) {
+                    const S3Step st0 = tab->st[ceS];
+                    const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - ceI;
+                    ceRp = saVal - (uint32_t)leftAlign;                       // 32-bit wrap, as the reference
+                    ceT = ceS; ceII = ceI; ceInsCur = ceIns; ceAcc = ceOcc; ceOff = 0; ceMm = 0;
+                    state = ST_CETXT;
+                } else if (state == ST_CETXT) {
+                    bool stepDone = false, reject = ceReject;
+                    if (!reject) {
+                        // text words -> own stage slot, then 16 characters at a time: XOR, fold, popcount
+                        myStage32[0] = p0.x; myStage32[1] = p0.y; myStage32[2] = p0.z; myStage32[3] = p0.w;
+                        myStage32[4] = p1.x; myStage32[5] = p1.y; myStage32[6] = p1.z; myStage32[7] = p1.w;
+                        myStage32[8] = 0;
+                        const uint32_t tsh = tpos & 15u;
+                        int mm = 0;
+                        for (uint32_t o = 0; o < ceCnt; o += 16u) {
+                            const uint32_t c = ceCnt - o > 16u ? 16u : ceCnt - o;
+                            const uint32_t tw0 = myStage32[(tsh + o) >> 4], tw1 = myStage32[((tsh + o) >> 4) + 1];
+                            const uint32_t sh = ((tsh + o) & 15u) * 2u;
+                            const uint32_t tw = sh ? (tw0 << sh) | (tw1 >> (32u - sh)) : tw0;
+                            const uint32_t rw = readWindow((int)(ceLeft + ceOff + o));
+                            uint32_t x = tw ^ rw;
+                            x = (x | (x >> 1)) & 0x55555555u;
+                            if (c < 16u) x &= ~0u << (32u - 2u * c);
+                            mm += __popc(x);
+                        }
+                        ceMm += mm;
+                        ceOff += ceCnt;
+                        stepDone = ceOff >= ceLen;
+                        if (stepDone) {
+                            const S3Step st = tab->st[ceT];
+                            const int tot = ceMm + ceInsCur;
+                            if (tot < st.minErr || tot > st.maxErr) reject = true;
+                            else { ceAcc += tot; ceT++; ceII = 0; ceInsCur = 0; ceOff = 0; ceMm = 0; }
+                        }
+                    }
+                    bool candidateDone = reject;
+                    if (!reject && stepDone && ceT >= nSteps) {
+                        emit(1, ceRp, ceRp, (uint32_t)ceAcc);
+                        total++;
+                        candidateDone = true;
+                    }
+                    if (candidateDone) {
+                        if (total >= in.maxOut || ceQ >= ceQEnd) settle(true);            // CE of this range is finished
+                        else { ceQ++; state = ST_CESA; }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (valid) out.itemCounts[cntIdx] = seq;
+    }
+    if (out.counters) {
+        atomicAdd(&out.counters[0], (unsigned long long)nRank);
+        atomicAdd(&out.counters[1], (unsigned long long)nLt);
+        atomicAdd(&out.counters[2], (unsigned long long)nSa);
+        atomicAdd(&out.counters[3], (unsigned long long)nCe);
+    }
+}
+
+void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
+{
+    const uint64_t slotsPadded = ((uint64_t)in.nActive + 63u) & ~63ull;
+    const uint64_t nItems = slotsPadded * (uint64_t)in.nCases * 2u;
+    if (nItems == 0) return;
+    uint64_t blocks = (nItems + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    if (blocks > maxBlocks) blocks = maxBlocks;
+    const size_t lds = (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + in.wpq * 256u + 128u);
+    hipLaunchKernelGGL(searchKernelV2, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+}
+
+}  // namespace s3
