@@ -151,7 +151,8 @@ struct s3_batch {
     // search / ordering work buffers
     uint4    *dRecs = nullptr, *dOrdered = nullptr;
     uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr;
-    unsigned long long *dCounters = nullptr;
+    unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;
+    uint32_t uniformLen = 0;
     uint32_t *dKept = nullptr, *dOccCounts = nullptr, *dCeCounts = nullptr, *dTotalOcc = nullptr, *dWithError = nullptr;
     uint32_t *dHitOffsets = nullptr;
     DevHit   *dHits = nullptr;
@@ -213,7 +214,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp);
     BA(dRecs, recCap); BA(dOrdered, recCap);
-    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8);
+    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
     BA(dWithError, (size_t)maxReads * 8);
@@ -266,6 +267,8 @@ extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint3
     HIPCHK(hipStreamSynchronize(b->stream));
     b->n = n;
     b->lastKind = 0;
+    b->uniformLen = n ? readLengths[0] : 0;
+    for (uint32_t i = 1; i < n; i++) if (readLengths[i] != readLengths[0]) { b->uniformLen = 0; break; }
     return S3_OK;
 }
 
@@ -284,15 +287,17 @@ static int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uin
     HIPCHK(hipMemsetAsync(b->dRecCount, 0, 4, b->stream));
     SearchIn in{};
     in.queries = b->dQueries; in.readLengths = b->dLens; in.active = active; in.nActive = nActive; in.wpq = b->wpq;
-    in.models = b->ix->models[modelMm]; in.nCases = nCases; in.maxOut = maxOut;
+    in.models = b->ix->models[modelMm]; in.nCases = nCases; in.maxOut = maxOut; in.uniformLen = b->uniformLen;
     SearchOut out{};
     out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
     out.counters = b->counting ? b->dCounters : nullptr;
+    out.workHead = b->dWorkHead;
+    HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
     if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
     {
         // S3DP_KERNEL=v1 selects the first-generation one-thread-per-item kernel (kept for A/B measurements)
         static const bool useV1 = [] { const char *e = getenv("S3DP_KERNEL"); return e && strcmp(e, "v1") == 0; }();
-        static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", 6);
+        static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", S3_V2_WAVES_PER_SIMD);
         if (useV1) launchSearch(b->ix->d, in, out, 256u * 8u * 4u, b->stream);
         else launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
     }

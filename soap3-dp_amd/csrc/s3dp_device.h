@@ -5,6 +5,9 @@
 #include "s3dp_model.h"
 
 #define S3_SEARCH_BLOCK 256
+#define S3_V2_WAVES_PER_SIMD 5            // register budget of the v2 search kernel (512 / 5 -> 96 VGPRs)
+#define S3_V2_CHUNK 256u                  // items a wave takes from the work queue at a time
+#define S3_V2_MODEL_BYTES 1104u           // sizeof(S3Model) rounded up to 16
 #define S3_FLAG_STACK_OVERFLOW 1u
 #define S3_FLAG_REC_OVERFLOW   2u
 #define S3_FLAG_OCC_OVERFLOW   4u
@@ -36,6 +39,7 @@ struct SearchIn {
     const S3Model  *models;      // indexed by read length, for this phase's mismatch budget
     int             nCases;
     uint32_t        maxOut;
+    uint32_t        uniformLen;  // != 0: every active read has this length (model kept in LDS by the v2 kernel)
 };
 
 struct SearchOut {
@@ -45,6 +49,7 @@ struct SearchOut {
     uint32_t           *itemCounts;
     uint32_t           *flags;
     unsigned long long *counters;   // optional: rank, lt, sa, ce tallies
+    unsigned long long *workHead;   // v2 kernel: head of the item queue (zeroed before every launch)
 };
 
 struct DevHit { uint32_t a, b, meta; };       // binary-identical to s3_hit (kind, strand, nmis, cas bytes)

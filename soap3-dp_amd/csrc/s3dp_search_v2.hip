@@ -26,7 +26,7 @@ namespace s3 {
 
 namespace v2 {
 
-enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_CESA = 2, ST_CETXT = 3 };
+enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_CESA = 2, ST_CETXT = 3, ST_LOAD = 4, ST_LT = 5 };
 constexpr uint32_t ID_NONE = 0x7FFFFFFFu;
 constexpr int STACK = 20;
 constexpr uint32_t CE_CHUNK = 112;                   // text characters compared per iteration (8 words minus alignment slack)
@@ -87,142 +87,315 @@ __device__ __forceinline__ Range childRange(int dir, const Range &g, const uint4
 
 using namespace v2;
 
-__global__ void __launch_bounds__(S3_SEARCH_BLOCK)
+// Persistent wavefronts with per-lane refill: a lane that finishes its (read, case, strand) item immediately takes
+// the next one from the wave's chunk of the global work queue, so all 64 lanes keep a memory request in flight.
+// UNIFORM: every read of the launch has the same length, the model (all cases) then lives in LDS; otherwise step
+// descriptors are read from the global table (L1/L2 resident).
+template <bool UNIFORM>
+__global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_V2_WAVES_PER_SIMD)
 searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 {
     extern __shared__ __align__(16) unsigned char shmem[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t wpq = in.wpq;
-    const uint32_t waveBytes = 4096u + wpq * 256u + 128u;
-    uint4 *stage = (uint4 *)(shmem + wv * waveBytes);                       // [64 owners][4 x 16 B]
-    uint32_t *rdw = (uint32_t *)(shmem + wv * waveBytes + 4096u);           // raw read words: rdw[w * 64 + lane]
-    const S3Case *tab = (const S3Case *)(shmem + wv * waveBytes + 4096u + wpq * 256u);
+    const uint32_t waveBytes = 4096u + wpq * 256u;
+    unsigned char *wbase = shmem + S3_V2_MODEL_BYTES + wv * waveBytes;
+    uint4 *stage = (uint4 *)wbase;                                          // [64 owners][4 x 16 B]
+    uint32_t *rdw = (uint32_t *)(wbase + 4096u);                            // raw read words: rdw[w * 64 + lane]
     uint32_t *myStage32 = (uint32_t *)(stage + lane * 4u);
 
+    if (UNIFORM) {
+        const uint32_t *src = (const uint32_t *)&in.models[in.uniformLen];
+        for (uint32_t k = threadIdx.x; k < sizeof(S3Model) / 4; k += blockDim.x) ((uint32_t *)shmem)[k] = src[k];
+        __syncthreads();
+    }
+
     const uint32_t nSlots = in.nActive;
-    const uint32_t groups = (uint32_t)in.nCases * 2u;
+    const uint32_t nCases = (uint32_t)in.nCases;
+    const uint32_t groups = nCases * 2u;
     const uint32_t slotsPadded = (nSlots + 63u) & ~63u;
     const uint64_t nItems = (uint64_t)slotsPadded * groups;
-    const uint64_t wavesTotal = (uint64_t)gridDim.x * (S3_SEARCH_BLOCK / 64);
     uint32_t nRank = 0, nLt = 0, nSa = 0, nCe = 0;
 
-    for (uint64_t base = ((uint64_t)blockIdx.x * (S3_SEARCH_BLOCK / 64) + wv) * 64u; base < nItems; base += wavesTotal * 64u) {
-        const uint32_t grp = (uint32_t)(base / slotsPadded);                // wave-uniform
-        const uint32_t slot = (uint32_t)(base % slotsPadded) + lane;
-        const uint32_t cas = grp >> 1, strand = grp & 1u;                   // strand 0 '+', 1 '-'
-        const bool valid = slot < nSlots;
-        const uint32_t r = valid ? (in.active ? in.active[slot] : slot) : 0u;
-        const uint32_t len = valid ? in.readLengths[r] : 0u;
-        const uint32_t cntIdx = (slot * (uint32_t)in.nCases + cas) * 2u + strand;
-        uint32_t seq = 0, total = 0;
+    // ---- per-lane item + search state ---------------------------------------------------------------------
+    uint32_t state = ST_DONE;
+    bool hasItem = false;
+    uint32_t cntIdx = 0, seq = 0, total = 0, rIdx = 0, loadOff = 0;
+    uint32_t strand = 0;
+    int Li = 0, nSteps = 0;
+    uint32_t casIdx = 0;
+    Range g = {0, 0, 0, 0};
+    int s = 0, i = 0, ins = 0, occ = 0;
+    Frame stack[STACK];
+    int sp = 0;
+    uint32_t ceQ = 0, ceQEnd = 0, ceRp = 0, ceOff = 0;
+    int ceS = 0, ceI = 0, ceIns = 0, ceOcc = 0;
+    int ceT = 0, ceII = 0, ceInsCur = 0, ceAcc = 0, ceMm = 0;
+    uint32_t ltA = 0, ltB = 0, ltC = 0, ltD = 0;                            // lookup-table keys of the starting item
+    // wave-uniform work queue window
+    uint64_t chunkCur = 0, chunkEnd = 0;
+    bool queueEmpty = false;
 
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            // ---- one pass per distinct read length in the wave (almost always exactly one) ------------------
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t L0 = (uint32_t)__shfl((int)len, leader);
-            const bool mine = valid && len == L0;
-            todo &= ~__ballot(mine);
-            {
-                const uint32_t *src = (const uint32_t *)&in.models[L0].cs[cas];
-                if (lane < sizeof(S3Case) / 4) ((uint32_t *)tab)[lane] = src[lane];
+    auto stepAt = [&](int k) -> S3Step {
+        if constexpr (UNIFORM) return ((const S3Model *)shmem)->cs[casIdx].st[k];      // LDS (address space known to the compiler)
+        else return in.models[Li].cs[casIdx].st[k];                                    // global, L1/L2 resident
+    };
+    auto rawWord = [&](int w) -> uint32_t { return (w >= 0 && w < (int)wpq) ? rdw[(uint32_t)w * 64u + lane] : 0u; };
+    auto readChar = [&](int pos) -> uint32_t {
+        const int q = strand ? Li - 1 - pos : pos;
+        const uint32_t c = (rdw[(uint32_t)(q >> 4) * 64u + lane] >> ((q & 15) * 2)) & 3u;
+        return strand ? 3u - c : c;
+    };
+    auto readWindow = [&](int p0) -> uint32_t {               // 16 oriented characters from p0, first one in the top bits
+        if (!strand) {
+            const int w = p0 >> 4, sh = (p0 & 15) * 2;
+            const uint64_t two = ((uint64_t)rawWord(w + 1) << 32) | rawWord(w);
+            return pairRev((uint32_t)(two >> sh));
+        }
+        const int a = Li - 16 - p0;
+        uint32_t x;
+        if (a >= 0) {
+            const int w = a >> 4, sh = (a & 15) * 2;
+            const uint64_t two = ((uint64_t)rawWord(w + 1) << 32) | rawWord(w);
+            x = (uint32_t)(two >> sh);
+        } else x = (-a < 16) ? (rawWord(0) << (2 * (-a))) : 0u;
+        return ~x;
+    };
+    auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
+        const uint32_t at = atomicAdd(out.recCount, 1u);
+        if (at < out.recCap) {
+            uint4 rec;
+            rec.x = cntIdx; rec.y = seq | (kind << 24) | (nmis << 25); rec.z = a; rec.w = b;
+            out.recs[at] = rec;
+        } else atomicOr(out.flags, S3_FLAG_REC_OVERFLOW);
+        seq++;
+    };
+    // advance without memory until the lane needs ranks / SA / text or its item is finished
+    auto settle = [&](bool needPop) {
+        for (;;) {
+            if (total >= in.maxOut) { state = ST_DONE; return; }
+            if (needPop) {
+                if (sp == 0) { state = ST_DONE; return; }
+                const Frame f = stack[--sp];
+                g.fl = f.fl; g.fr = f.fr; g.rl = f.rl; g.rr = f.rl + (f.fr - f.fl);
+                s = (int)(f.meta & 7u); i = (int)((f.meta >> 3) & 0x7FFu); ins = (int)((f.meta >> 14) & 7u); occ = (int)((f.meta >> 17) & 7u);
+                needPop = false;
             }
-            if (mine) {
-                const uint32_t *src = in.queries + (size_t)(r >> 5) * 32u * wpq + (r & 31u);
-                for (uint32_t w = 0; w < wpq; w++) rdw[w * 64u + lane] = src[(size_t)w * 32u];
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int nSteps = tab->nSteps;
-            const int Li = (int)L0;
-
-            auto rawWord = [&](int w) -> uint32_t { return (w >= 0 && w < (int)wpq) ? rdw[(uint32_t)w * 64u + lane] : 0u; };
-            auto readChar = [&](int pos) -> uint32_t {
-                const int q = strand ? Li - 1 - pos : pos;
-                const uint32_t c = (rdw[(uint32_t)(q >> 4) * 64u + lane] >> ((q & 15) * 2)) & 3u;
-                return strand ? 3u - c : c;
-            };
-            // 16 oriented read characters starting at oriented position p0, first character in the top bits
-            auto readWindow = [&](int p0) -> uint32_t {
-                if (!strand) {
-                    const int w = p0 >> 4, sh = (p0 & 15) * 2;
-                    const uint64_t two = ((uint64_t)rawWord(w + 1) << 32) | rawWord(w);
-                    return pairRev((uint32_t)(two >> sh));
+            if (s >= nSteps) {                                               // SRA_STEP_TYPE_COMPLETE
+                uint32_t l = g.fl, rr_ = g.fr;
+                if (rr_ >= l) {
+                    if (total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - total - 1u;
+                    emit(0, l, rr_, (uint32_t)(ins + occ));
+                    total += rr_ - l + 1u;
                 }
-                const int a = Li - 16 - p0;                      // raw characters a .. a+15, a+15 = oriented p0
-                uint32_t x;
-                if (a >= 0) {
-                    const int w = a >> 4, sh = (a & 15) * 2;
-                    const uint64_t two = ((uint64_t)rawWord(w + 1) << 32) | rawWord(w);
-                    x = (uint32_t)(two >> sh);
-                } else x = (-a < 16) ? (rawWord(0) << (2 * (-a))) : 0u;
-                return ~x;
-            };
+                needPop = true;
+                continue;
+            }
+            const S3Step st = stepAt(s);
+            const bool exact = ins >= st.maxErr;
+            int lenEff = st.len;
+            if (!exact && st.minErr > ins + 1) lenEff -= st.minErr - ins - 1;
+            const bool alive = g.fl <= g.fr;
+            if (i < lenEff && alive) {
+                const int pos = st.start + st.dir * i;
+                if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
+                    ceQ = g.fl; ceQEnd = g.fr; ceS = s; ceI = i; ceIns = ins; ceOcc = occ;
+                    state = ST_CESA;
+                    return;
+                }
+                state = ST_STEP;
+                return;
+            }
+            if (ins >= st.minErr && alive) { occ += ins; ins = 0; s++; i = 0; continue; }
+            needPop = true;
+        }
+    };
 
-            // ---- per-lane state ------------------------------------------------------------------------------
-            uint32_t state = ST_DONE;
-            Range g = {0, 0, 0, 0};
-            int s = 0, i = 0, ins = 0, occ = 0;
-            Frame stack[STACK];
-            int sp = 0;
-            // check-and-extend context
-            uint32_t ceQ = 0, ceQEnd = 0, ceRp = 0, ceOff = 0;
-            int ceS = 0, ceI = 0, ceIns = 0, ceOcc = 0;          // where CE was entered
-            int ceT = 0, ceII = 0, ceInsCur = 0, ceAcc = 0, ceMm = 0;
-
-            auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
-                const uint32_t at = atomicAdd(out.recCount, 1u);
-                if (at < out.recCap) {
-                    uint4 rec;
-                    rec.x = cntIdx; rec.y = seq | (kind << 24) | (nmis << 25); rec.z = a; rec.w = b;
-                    out.recs[at] = rec;
-                } else atomicOr(out.flags, S3_FLAG_REC_OVERFLOW);
-                seq++;
-            };
-
-            // advance without memory until the lane needs ranks / SA / text or is finished
-            auto settle = [&](bool needPop) {
-                for (;;) {
-                    if (total >= in.maxOut) { state = ST_DONE; return; }
-                    if (needPop) {
-                        if (sp == 0) { state = ST_DONE; return; }
-                        const Frame f = stack[--sp];
-                        g.fl = f.fl; g.fr = f.fr; g.rl = f.rl; g.rr = f.rl + (f.fr - f.fl);
-                        s = (int)(f.meta & 7u); i = (int)((f.meta >> 3) & 0x7FFu); ins = (int)((f.meta >> 14) & 7u); occ = (int)((f.meta >> 17) & 7u);
-                        needPop = false;
+    for (;;) {
+        // ---------- retire finished items, hand out new ones ----------
+        if (state == ST_DONE && hasItem) { out.itemCounts[cntIdx] = seq; hasItem = false; }
+        const unsigned long long idleMask = __ballot(state == ST_DONE);
+        if (idleMask) {
+            if (chunkCur >= chunkEnd && !queueEmpty) {
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(out.workHead, (unsigned long long)S3_V2_CHUNK);
+                b = (unsigned long long)__shfl((long long)b, 0);
+                if (b >= nItems) queueEmpty = true;
+                else { chunkCur = b; chunkEnd = b + S3_V2_CHUNK < nItems ? b + S3_V2_CHUNK : nItems; }
+            }
+            const uint64_t avail = chunkEnd > chunkCur ? chunkEnd - chunkCur : 0;
+            if (avail) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+                const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+                if (state == ST_DONE && rank < avail) {
+                    const uint64_t item = chunkCur + rank;
+                    const uint32_t grp = (uint32_t)(item / slotsPadded), slot = (uint32_t)(item % slotsPadded);
+                    if (slot < nSlots) {
+                        const uint32_t cas = grp >> 1;
+                        strand = grp & 1u;
+                        rIdx = in.active ? in.active[slot] : slot;
+                        Li = (int)in.readLengths[rIdx];
+                        casIdx = cas;
+                        if constexpr (UNIFORM) nSteps = ((const S3Model *)shmem)->cs[cas].nSteps;
+                        else nSteps = in.models[Li].cs[cas].nSteps;
+                        cntIdx = (slot * nCases + cas) * 2u + strand;
+                        seq = 0; total = 0; sp = 0; loadOff = 0;
+                        hasItem = true;
+                        state = ST_LOAD;
                     }
-                    if (s >= nSteps) {                                       // SRA_STEP_TYPE_COMPLETE
-                        uint32_t l = g.fl, rr_ = g.fr;
-                        if (rr_ >= l) {
-                            if (total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - total - 1u;
-                            emit(0, l, rr_, (uint32_t)(ins + occ));
-                            total += rr_ - l + 1u;
-                        }
+                }
+                chunkCur += nIdle < avail ? nIdle : avail;
+            } else if (queueEmpty && idleMask == ~0ULL) break;                 // nothing left anywhere
+        }
+
+        // ---------- what does this lane need? ----------
+        uint32_t idA = ID_NONE, iL = 0, iR = 0;
+        bool needB = false;
+        int dir = 0;
+        if (state == ST_STEP) {
+            dir = stepAt(s).dir;
+            const DevBwt &b = dir < 0 ? ix.fwd : ix.rev;
+            iL = dir < 0 ? g.fl : g.rl;
+            iR = (dir < 0 ? g.fr : g.rr) + 1u;
+            iL -= (iL > b.inverseSa0);
+            iR -= (iR > b.inverseSa0);
+            const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
+            idA = kL | (dir < 0 ? 0u : 0x80000000u);
+            needB = kR != kL;
+        }
+        // ---------- issue: cooperative rank lines (4 adjacent lanes fetch one owner's 64-B line) ----------
+        uint4 va0, va1, va2, va3;
+        uint32_t o0, o1, o2, o3;
+        {
+            const uint32_t sub = lane & 3u, q4 = lane >> 2;
+            o0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((q4) * 4u), (int)idA);
+            o1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u + q4) * 4u), (int)idA);
+            o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((32u + q4) * 4u), (int)idA);
+            o3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((48u + q4) * 4u), (int)idA);
+            va0 = va1 = va2 = va3 = make_uint4(0, 0, 0, 0);
+            if (o0 != ID_NONE) va0 = ((o0 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o0 & 0x7FFFFFFFu) * 4u + sub];
+            if (o1 != ID_NONE) va1 = ((o1 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o1 & 0x7FFFFFFFu) * 4u + sub];
+            if (o2 != ID_NONE) va2 = ((o2 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o2 & 0x7FFFFFFFu) * 4u + sub];
+            if (o3 != ID_NONE) va3 = ((o3 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o3 & 0x7FFFFFFFu) * 4u + sub];
+        }
+        // ---------- issue: private loads (second rank line / read words / lookup table / SA entry / text) ----------
+        uint4 p0 = make_uint4(0, 0, 0, 0), p1 = make_uint4(0, 0, 0, 0);
+        uint32_t saVal = 0;
+        bool ceReject = false;
+        uint32_t ceCnt = 0, ceLeft = 0, ceLen = 0, tpos = 0;
+        if (needB) {
+            const DevBwt &b = dir < 0 ? ix.fwd : ix.rev;
+            const uint32_t kR = (iR + 63u) >> 7;
+            const uint4 *line = b.lines + (size_t)kR * 4u;
+            p0 = line[0];
+            if (iR != (kR << 7)) p1 = line[iR > (kR << 7) ? 2 : 1];
+        } else if (state == ST_LOAD) {
+            const uint32_t *src = in.queries + (size_t)(rIdx >> 5) * 32u * wpq + (rIdx & 31u) + (size_t)loadOff * 32u;
+            const uint32_t left = wpq - loadOff;
+            p0.x = src[0];
+            if (left > 1) p0.y = src[32];
+            if (left > 2) p0.z = src[64];
+            if (left > 3) p0.w = src[96];
+            if (left > 4) p1.x = src[128];
+            if (left > 5) p1.y = src[160];
+            if (left > 6) p1.z = src[192];
+            if (left > 7) p1.w = src[224];
+        } else if (state == ST_LT) {
+            const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
+            p0.x = ltA ? ix.lkt[ltA - 1] : 0u;
+            p0.y = ix.lkt[ltB];
+            if (bidir) { p0.z = ltC ? ix.rlkt[ltC - 1] : 0u; p0.w = ix.rlkt[ltD]; }
+            nLt += bidir ? 4 : 2;
+        } else if (state == ST_CESA) {
+            saVal = ix.sa[ceQ];
+            nSa++;
+        } else if (state == ST_CETXT) {
+            const S3Step st = stepAt(ceT);
+            const int pos = st.start + st.dir * ceII;
+            const int left = pos < st.end ? pos : st.end, right = pos < st.end ? st.end : pos;
+            ceLeft = (uint32_t)left; ceLen = (uint32_t)(right - left + 1);
+            if (ceOff == 0 && ceRp + ceLeft > ix.n) ceReject = true;                  // BGS-HostAlgnmtAlgo2.cpp:122-125
+            else {
+                ceCnt = ceLen - ceOff > CE_CHUNK ? CE_CHUNK : ceLen - ceOff;
+                tpos = ceRp + ceLeft + ceOff;
+                const size_t bw = tpos >> 4;
+                const uint32_t words = ((tpos & 15u) + ceCnt + 15u) >> 4;
+                if (bw + 4 <= ix.pacWords) p0 = *(const uint4 *)(ix.pac + bw);
+                if (words > 4 && bw + 8 <= ix.pacWords) p1 = *(const uint4 *)(ix.pac + bw + 4);
+                nCe += (ceCnt + 31u) >> 5;
+            }
+        }
+        // ---------- stage the cooperative lines in LDS (owner slot = 64 B) ----------
+        {
+            const uint32_t sub = lane & 3u, q4 = lane >> 2;
+            if (o0 != ID_NONE) stage[(q4) * 4u + sub] = va0;
+            if (o1 != ID_NONE) stage[(16u + q4) * 4u + sub] = va1;
+            if (o2 != ID_NONE) stage[(32u + q4) * 4u + sub] = va2;
+            if (o3 != ID_NONE) stage[(48u + q4) * 4u + sub] = va3;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------- advance ----------
+        if (state == ST_STEP) {
+            const uint32_t kL = (iL + 63u) >> 7;
+            const uint4 occA = stage[lane * 4u];
+            uint4 wL = make_uint4(0, 0, 0, 0);
+            if (iL != (kL << 7)) wL = stage[lane * 4u + (iL > (kL << 7) ? 2u : 1u)];
+            const uint4 oL = rankFromLine(iL, occA, wL);
+            uint4 oR;
+            if (needB) oR = rankFromLine(iR, p0, p1);
+            else {
+                uint4 wR = make_uint4(0, 0, 0, 0);
+                if (iR != (kL << 7)) wR = stage[lane * 4u + (iR > (kL << 7) ? 2u : 1u)];
+                oR = rankFromLine(iR, occA, wR);
+            }
+            nRank += 2;
+            const S3Step st = stepAt(s);
+            const bool exact = ins >= st.maxErr;
+            const int pos = st.start + st.dir * i;
+            const uint32_t ch = readChar(pos);
+            const Range gc = childRange(st.dir, g, oL, oR, ch);
+            bool needPop = false;
+            if (!exact) {
+                const Range e0 = childRange(st.dir, g, oL, oR, 0u), e1 = childRange(st.dir, g, oL, oR, 1u);
+                const Range e2 = childRange(st.dir, g, oL, oR, 2u), e3 = childRange(st.dir, g, oL, oR, 3u);
+                const bool a0 = ch != 0 && e0.fl <= e0.fr, a1 = ch != 1 && e1.fl <= e1.fr;
+                const bool a2 = ch != 2 && e2.fl <= e2.fr, a3 = ch != 3 && e3.fl <= e3.fr;
+                if (a0 || a1 || a2 || a3) {
+                    if (sp + 4 > STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = ST_DONE; sp = 0; }
+                    else {
+                        const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
+                        const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
+                        Frame f;
+                        f.fl = gc.fl; f.fr = gc.fr; f.rl = gc.rl; f.meta = mCont; stack[sp++] = f;
+                        f.meta = mKid;
+                        if (a3) { f.fl = e3.fl; f.fr = e3.fr; f.rl = e3.rl; stack[sp++] = f; }
+                        if (a2) { f.fl = e2.fl; f.fr = e2.fr; f.rl = e2.rl; stack[sp++] = f; }
+                        if (a1) { f.fl = e1.fl; f.fr = e1.fr; f.rl = e1.rl; stack[sp++] = f; }
+                        if (a0) { f.fl = e0.fl; f.fr = e0.fr; f.rl = e0.rl; stack[sp++] = f; }
                         needPop = true;
-                        continue;
                     }
-                    const S3Step st = tab->st[s];
-                    const bool exact = ins >= st.maxErr;
-                    int lenEff = st.len;
-                    if (!exact && st.minErr > ins + 1) lenEff -= st.minErr - ins - 1;
-                    const bool alive = g.fl <= g.fr;
-                    if (i < lenEff && alive) {
-                        const int pos = st.start + st.dir * i;
-                        if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
-                            ceQ = g.fl; ceQEnd = g.fr; ceS = s; ceI = i; ceIns = ins; ceOcc = occ;
-                            state = ST_CESA;
-                            return;
-                        }
-                        state = ST_STEP;
-                        return;
-                    }
-                    if (ins >= st.minErr && alive) { occ += ins; ins = 0; s++; i = 0; continue; }
-                    needPop = true;
                 }
-            };
-
-            // ---- item start: lookup-table range (BWTExactModel{Backward,Forward}_Lookup2) ---------------------
-            if (mine) {
-                const S3Step st = tab->st[0];
+            }
+            if (state != ST_DONE) {
+                if (!needPop) { g = gc; i++; }
+                settle(needPop);
+            }
+        } else if (state == ST_LOAD) {
+            uint32_t *dst = rdw + (size_t)loadOff * 64u + lane;
+            const uint32_t left = wpq - loadOff;
+            dst[0] = p0.x;
+            if (left > 1) dst[64] = p0.y;
+            if (left > 2) dst[128] = p0.z;
+            if (left > 3) dst[192] = p0.w;
+            if (left > 4) dst[256] = p1.x;
+            if (left > 5) dst[320] = p1.y;
+            if (left > 6) dst[384] = p1.z;
+            if (left > 7) dst[448] = p1.w;
+            loadOff += 8;
+            if (loadOff >= wpq) {
+                // lookup-table keys (BWTExactModel{Backward,Forward}_Lookup2, BGS-HostAlgnmtAlgo2.cpp:311-347)
+                const S3Step st = stepAt(0);
                 const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
                 auto ltKey = [&](int from, int stride, uint32_t &lp, uint32_t &rp) {
                     lp = 0;
@@ -230,197 +403,71 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     rp = lp;
                     for (int k = ll; k < ix.ltSize; k++) { lp <<= 2; rp = (rp << 2) | 3u; }
                 };
-                if (st.type == S3_T_BACK_LOOKUP) {
-                    uint32_t lp, rp;
-                    ltKey(st.start - ll + 1, 1, lp, rp);
-                    const uint32_t a = lp ? ix.lkt[lp - 1] : 0u, b = ix.lkt[rp];
-                    g.fl = lp ? a + 1u : 1u; g.fr = b; g.rl = g.fl; g.rr = g.fr;
-                    nLt += 2;
-                } else {
-                    uint32_t lp, rp, lp2, rp2;
-                    ltKey(st.start, 1, lp, rp);
-                    ltKey(st.start + ll - 1, -1, lp2, rp2);
-                    const uint32_t a = lp ? ix.lkt[lp - 1] : 0u, b = ix.lkt[rp];
-                    const uint32_t c = lp2 ? ix.rlkt[lp2 - 1] : 0u, d = ix.rlkt[rp2];
-                    uint32_t l = lp ? a + 1u : 1u, rr_ = b, rl = lp2 ? c + 1u : 1u, rrr = d;
-                    if (rr_ - l < rrr - rl) rl = rrr - (rr_ - l);
-                    else if (rr_ - l > rrr - rl) l = rr_ - (rrr - rl);
-                    g.fl = l; g.fr = rr_; g.rl = rl; g.rr = rrr;
-                    nLt += 4;
-                }
-                s = 0; i = ll; ins = 0; occ = 0;
-                settle(false);
+                if (st.type == S3_T_BACK_LOOKUP) ltKey(st.start - ll + 1, 1, ltA, ltB);
+                else { ltKey(st.start, 1, ltA, ltB); ltKey(st.start + ll - 1, -1, ltC, ltD); }
+                state = ST_LT;
             }
-
-            // ---- main loop: issue all memory, wait once, advance every lane ------------------------------------
-            while (__any(state != ST_DONE)) {
-                // ---------- what does this lane need? ----------
-                uint32_t idA = ID_NONE, iL = 0, iR = 0;
-                bool needB = false;
-                int dir = 0;
-                if (state == ST_STEP) {
-                    dir = tab->st[s].dir;
-                    const DevBwt &b = dir < 0 ? ix.fwd : ix.rev;
-                    iL = dir < 0 ? g.fl : g.rl;
-                    iR = (dir < 0 ? g.fr : g.rr) + 1u;
-                    iL -= (iL > b.inverseSa0);
-                    iR -= (iR > b.inverseSa0);
-                    const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
-                    idA = kL | (dir < 0 ? 0u : 0x80000000u);
-                    needB = kR != kL;
+        } else if (state == ST_LT) {
+            const S3Step st = stepAt(0);
+            const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
+            if (st.type == S3_T_BACK_LOOKUP) {
+                g.fl = ltA ? p0.x + 1u : 1u; g.fr = p0.y; g.rl = g.fl; g.rr = g.fr;
+            } else {
+                uint32_t l = ltA ? p0.x + 1u : 1u, rr_ = p0.y, rl = ltC ? p0.z + 1u : 1u, rrr = p0.w;
+                if (rr_ - l < rrr - rl) rl = rrr - (rr_ - l);                          // :349-356
+                else if (rr_ - l > rrr - rl) l = rr_ - (rrr - rl);
+                g.fl = l; g.fr = rr_; g.rl = rl; g.rr = rrr;
+            }
+            s = 0; i = ll; ins = 0; occ = 0;
+            settle(false);
+        } else if (state == ST_CESA) {
+            const S3Step st0 = stepAt(ceS);
+            const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - ceI;
+            ceRp = saVal - (uint32_t)leftAlign;                               // 32-bit wrap, as the reference
+            ceT = ceS; ceII = ceI; ceInsCur = ceIns; ceAcc = ceOcc; ceOff = 0; ceMm = 0;
+            state = ST_CETXT;
+        } else if (state == ST_CETXT) {
+            bool stepDone = false, reject = ceReject;
+            if (!reject) {
+                // text words -> own stage slot, then 16 characters at a time: XOR, fold, popcount
+                myStage32[0] = p0.x; myStage32[1] = p0.y; myStage32[2] = p0.z; myStage32[3] = p0.w;
+                myStage32[4] = p1.x; myStage32[5] = p1.y; myStage32[6] = p1.z; myStage32[7] = p1.w;
+                myStage32[8] = 0;
+                const uint32_t tsh = tpos & 15u;
+                int mm = 0;
+                for (uint32_t o = 0; o < ceCnt; o += 16u) {
+                    const uint32_t c = ceCnt - o > 16u ? 16u : ceCnt - o;
+                    const uint32_t tw0 = myStage32[(tsh + o) >> 4], tw1 = myStage32[((tsh + o) >> 4) + 1];
+                    const uint32_t sh = ((tsh + o) & 15u) * 2u;
+                    const uint32_t tw = sh ? (tw0 << sh) | (tw1 >> (32u - sh)) : tw0;
+                    const uint32_t rw = readWindow((int)(ceLeft + ceOff + o));
+                    uint32_t x = tw ^ rw;
+                    x = (x | (x >> 1)) & 0x55555555u;
+                    if (c < 16u) x &= ~0u << (32u - 2u * c);
+                    mm += __popc(x);
                 }
-                // ---------- issue: cooperative rank lines ----------
-                uint4 va0, va1, va2, va3;
-                uint32_t o0, o1, o2, o3;
-                {
-                    const uint32_t sub = lane & 3u, q4 = lane >> 2;
-                    o0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((q4) * 4u), (int)idA);
-                    o1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u + q4) * 4u), (int)idA);
-                    o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((32u + q4) * 4u), (int)idA);
-                    o3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((48u + q4) * 4u), (int)idA);
-                    va0 = va1 = va2 = va3 = make_uint4(0, 0, 0, 0);
-                    if (o0 != ID_NONE) va0 = ((o0 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o0 & 0x7FFFFFFFu) * 4u + sub];
-                    if (o1 != ID_NONE) va1 = ((o1 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o1 & 0x7FFFFFFFu) * 4u + sub];
-                    if (o2 != ID_NONE) va2 = ((o2 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o2 & 0x7FFFFFFFu) * 4u + sub];
-                    if (o3 != ID_NONE) va3 = ((o3 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o3 & 0x7FFFFFFFu) * 4u + sub];
+                ceMm += mm;
+                ceOff += ceCnt;
+                stepDone = ceOff >= ceLen;
+                if (stepDone) {
+                    const S3Step st = stepAt(ceT);
+                    const int tot = ceMm + ceInsCur;
+                    if (tot < st.minErr || tot > st.maxErr) reject = true;
+                    else { ceAcc += tot; ceT++; ceII = 0; ceInsCur = 0; ceOff = 0; ceMm = 0; }
                 }
-                // ---------- issue: private loads (second rank line / SA entry / text window) ----------
-                uint4 p0 = make_uint4(0, 0, 0, 0), p1 = make_uint4(0, 0, 0, 0);
-                uint32_t saVal = 0;
-                bool ceReject = false;
-                uint32_t ceCnt = 0, ceLeft = 0, ceLen = 0, tpos = 0;
-                if (needB) {
-                    const DevBwt &b = dir < 0 ? ix.fwd : ix.rev;
-                    const uint32_t kR = (iR + 63u) >> 7;
-                    const uint4 *line = b.lines + (size_t)kR * 4u;
-                    p0 = line[0];
-                    if (iR != (kR << 7)) p1 = line[iR > (kR << 7) ? 2 : 1];
-                } else if (state == ST_CESA) {
-                    saVal = ix.sa[ceQ];
-                    nSa++;
-                } else if (state == ST_CETXT) {
-                    const S3Step st = tab->st[ceT];
-                    const int pos = st.start + st.dir * ceII;
-                    const int left = pos < st.end ? pos : st.end, right = pos < st.end ? st.end : pos;
-                    ceLeft = (uint32_t)left; ceLen = (uint32_t)(right - left + 1);
-                    if (ceOff == 0 && ceRp + ceLeft > ix.n) ceReject = true;          // BGS-HostAlgnmtAlgo2.cpp:122-125
-                    else {
-                        ceCnt = ceLen - ceOff > CE_CHUNK ? CE_CHUNK : ceLen - ceOff;
-                        tpos = ceRp + ceLeft + ceOff;
-                        const size_t bw = tpos >> 4;
-                        const uint32_t words = ((tpos & 15u) + ceCnt + 15u) >> 4;
-                        if (bw + 4 <= ix.pacWords) p0 = *(const uint4 *)(ix.pac + bw);
-                        if (words > 4 && bw + 8 <= ix.pacWords) p1 = *(const uint4 *)(ix.pac + bw + 4);
-                        nCe += (ceCnt + 31u) >> 5;
-                    }
-                }
-                // ---------- stage the cooperative lines in LDS (owner slot = 64 B) ----------
-                {
-                    const uint32_t sub = lane & 3u, q4 = lane >> 2;
-                    if (o0 != ID_NONE) stage[(q4) * 4u + sub] = va0;
-                    if (o1 != ID_NONE) stage[(16u + q4) * 4u + sub] = va1;
-                    if (o2 != ID_NONE) stage[(32u + q4) * 4u + sub] = va2;
-                    if (o3 != ID_NONE) stage[(48u + q4) * 4u + sub] = va3;
-                }
-                __builtin_amdgcn_wave_barrier();
-
-                // ---------- advance ----------
-                if (state == ST_STEP) {
-                    const uint32_t kL = (iL + 63u) >> 7;
-                    const uint4 occA = stage[lane * 4u];
-                    uint4 wL = make_uint4(0, 0, 0, 0);
-                    if (iL != (kL << 7)) wL = stage[lane * 4u + (iL > (kL << 7) ? 2u : 1u)];
-                    const uint4 oL = rankFromLine(iL, occA, wL);
-                    uint4 oR;
-                    if (needB) oR = rankFromLine(iR, p0, p1);
-                    else {
-                        uint4 wR = make_uint4(0, 0, 0, 0);
-                        if (iR != (kL << 7)) wR = stage[lane * 4u + (iR > (kL << 7) ? 2u : 1u)];
-                        oR = rankFromLine(iR, occA, wR);
-                    }
-                    nRank += 2;
-                    const S3Step st = tab->st[s];
-                    const bool exact = ins >= st.maxErr;
-                    const int pos = st.start + st.dir * i;
-                    const uint32_t ch = readChar(pos);
-                    const Range gc = childRange(st.dir, g, oL, oR, ch);
-                    bool needPop = false;
-                    if (!exact) {
-                        const Range e0 = childRange(st.dir, g, oL, oR, 0u), e1 = childRange(st.dir, g, oL, oR, 1u);
-                        const Range e2 = childRange(st.dir, g, oL, oR, 2u), e3 = childRange(st.dir, g, oL, oR, 3u);
-                        const bool a0 = ch != 0 && e0.fl <= e0.fr, a1 = ch != 1 && e1.fl <= e1.fr;
-                        const bool a2 = ch != 2 && e2.fl <= e2.fr, a3 = ch != 3 && e3.fl <= e3.fr;
-                        if (a0 || a1 || a2 || a3) {
-                            if (sp + 4 > STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = ST_DONE; sp = 0; }
-                            else {
-                                const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
-                                const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
-                                Frame f;
-                                f.fl = gc.fl; f.fr = gc.fr; f.rl = gc.rl; f.meta = mCont; stack[sp++] = f;
-                                f.meta = mKid;
-                                if (a3) { f.fl = e3.fl; f.fr = e3.fr; f.rl = e3.rl; stack[sp++] = f; }
-                                if (a2) { f.fl = e2.fl; f.fr = e2.fr; f.rl = e2.rl; stack[sp++] = f; }
-                                if (a1) { f.fl = e1.fl; f.fr = e1.fr; f.rl = e1.rl; stack[sp++] = f; }
-                                if (a0) { f.fl = e0.fl; f.fr = e0.fr; f.rl = e0.rl; stack[sp++] = f; }
-                                needPop = true;
-                            }
-                        }
-                    }
-                    if (state != ST_DONE) {
-                        if (!needPop) { g = gc; i++; }
-                        settle(needPop);
-                    }
-                } else if (state == ST_CESA) {
-                    const S3Step st0 = tab->st[ceS];
-                    const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - ceI;
-                    ceRp = saVal - (uint32_t)leftAlign;                       // 32-bit wrap, as the reference
-                    ceT = ceS; ceII = ceI; ceInsCur = ceIns; ceAcc = ceOcc; ceOff = 0; ceMm = 0;
-                    state = ST_CETXT;
-                } else if (state == ST_CETXT) {
-                    bool stepDone = false, reject = ceReject;
-                    if (!reject) {
-                        // text words -> own stage slot, then 16 characters at a time: XOR, fold, popcount
-                        myStage32[0] = p0.x; myStage32[1] = p0.y; myStage32[2] = p0.z; myStage32[3] = p0.w;
-                        myStage32[4] = p1.x; myStage32[5] = p1.y; myStage32[6] = p1.z; myStage32[7] = p1.w;
-                        myStage32[8] = 0;
-                        const uint32_t tsh = tpos & 15u;
-                        int mm = 0;
-                        for (uint32_t o = 0; o < ceCnt; o += 16u) {
-                            const uint32_t c = ceCnt - o > 16u ? 16u : ceCnt - o;
-                            const uint32_t tw0 = myStage32[(tsh + o) >> 4], tw1 = myStage32[((tsh + o) >> 4) + 1];
-                            const uint32_t sh = ((tsh + o) & 15u) * 2u;
-                            const uint32_t tw = sh ? (tw0 << sh) | (tw1 >> (32u - sh)) : tw0;
-                            const uint32_t rw = readWindow((int)(ceLeft + ceOff + o));
-                            uint32_t x = tw ^ rw;
-                            x = (x | (x >> 1)) & 0x55555555u;
-                            if (c < 16u) x &= ~0u << (32u - 2u * c);
-                            mm += __popc(x);
-                        }
-                        ceMm += mm;
-                        ceOff += ceCnt;
-                        stepDone = ceOff >= ceLen;
-                        if (stepDone) {
-                            const S3Step st = tab->st[ceT];
-                            const int tot = ceMm + ceInsCur;
-                            if (tot < st.minErr || tot > st.maxErr) reject = true;
-                            else { ceAcc += tot; ceT++; ceII = 0; ceInsCur = 0; ceOff = 0; ceMm = 0; }
-                        }
-                    }
-                    bool candidateDone = reject;
-                    if (!reject && stepDone && ceT >= nSteps) {
-                        emit(1, ceRp, ceRp, (uint32_t)ceAcc);
-                        total++;
-                        candidateDone = true;
-                    }
-                    if (candidateDone) {
-                        if (total >= in.maxOut || ceQ >= ceQEnd) settle(true);            // CE of this range is finished
-                        else { ceQ++; state = ST_CESA; }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
+            }
+            bool candidateDone = reject;
+            if (!reject && stepDone && ceT >= nSteps) {
+                emit(1, ceRp, ceRp, (uint32_t)ceAcc);
+                total++;
+                candidateDone = true;
+            }
+            if (candidateDone) {
+                if (total >= in.maxOut || ceQ >= ceQEnd) settle(true);            // check-and-extend of this range is finished
+                else { ceQ++; state = ST_CESA; }
             }
         }
-        if (valid) out.itemCounts[cntIdx] = seq;
+        __builtin_amdgcn_wave_barrier();
     }
     if (out.counters) {
         atomicAdd(&out.counters[0], (unsigned long long)nRank);
@@ -437,8 +484,9 @@ void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out
     if (nItems == 0) return;
     uint64_t blocks = (nItems + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
-    const size_t lds = (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + in.wpq * 256u + 128u);
-    hipLaunchKernelGGL(searchKernelV2, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + in.wpq * 256u);
+    if (in.uniformLen) hipLaunchKernelGGL(searchKernelV2<true>, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+    else hipLaunchKernelGGL(searchKernelV2<false>, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
 }
 
 }  // namespace s3
