@@ -147,7 +147,7 @@ struct s3_batch {
     size_t   maxItems = 0;
     uint32_t recCap = 0, occCap = 0;
     // inputs
-    uint32_t *dQueries = nullptr, *dLens = nullptr;
+    uint32_t *dQueries = nullptr, *dLens = nullptr, *dReadsT = nullptr;
     // search / ordering work buffers
     uint4    *dRecs = nullptr, *dOrdered = nullptr;
     uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr;
@@ -212,7 +212,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     HIPCHK(hipStreamCreate(&b->stream));
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
-    BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp);
+    BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dReadsT, roundUp * wordPerQuery + 16);
     BA(dRecs, recCap); BA(dOrdered, recCap);
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
@@ -264,6 +264,7 @@ extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint3
     const size_t roundUp = ((size_t)n + 31) / 32 * 32;
     HIPCHK(hipMemcpyAsync(b->dQueries, queries, roundUp * b->wpq * 4, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->dLens, readLengths, (size_t)n * 4, hipMemcpyHostToDevice, b->stream));
+    launchTransposeReads(b->dQueries, b->dReadsT, n, b->wpq, b->stream);
     HIPCHK(hipStreamSynchronize(b->stream));
     b->n = n;
     b->lastKind = 0;
@@ -286,7 +287,7 @@ static int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uin
     const size_t nItems = (size_t)nActive * nCases * 2;
     HIPCHK(hipMemsetAsync(b->dRecCount, 0, 4, b->stream));
     SearchIn in{};
-    in.queries = b->dQueries; in.readLengths = b->dLens; in.active = active; in.nActive = nActive; in.wpq = b->wpq;
+    in.queries = b->dQueries; in.readsT = b->dReadsT; in.readLengths = b->dLens; in.active = active; in.nActive = nActive; in.wpq = b->wpq;
     in.models = b->ix->models[modelMm]; in.nCases = nCases; in.maxOut = maxOut; in.uniformLen = b->uniformLen;
     SearchOut out{};
     out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;

@@ -6,7 +6,7 @@
 
 #define S3_SEARCH_BLOCK 256
 #define S3_V2_WAVES_PER_SIMD 5            // register budget of the v2 search kernel (512 / 5 -> 96 VGPRs)
-#define S3_V2_CHUNK 256u                  // items a wave takes from the work queue at a time
+#define S3_V2_CHUNK 128u                  // reads a wave takes from the work queue at a time
 #define S3_V2_MODEL_BYTES 1104u           // sizeof(S3Model) rounded up to 16
 #define S3_FLAG_STACK_OVERFLOW 1u
 #define S3_FLAG_REC_OVERFLOW   2u
@@ -32,6 +32,7 @@ struct DevIndex {
 
 struct SearchIn {
     const uint32_t *queries;     // packed reads, reference layout
+    const uint32_t *readsT;      // same words, contiguous per read: readsT[r * wpq + w]  (v2 kernel)
     const uint32_t *readLengths;
     const uint32_t *active;      // optional indirection: slot -> read index
     uint32_t        nActive;
@@ -63,6 +64,7 @@ struct MergeArgs {
     uint8_t         decodeWant;
 };
 
+void launchTransposeReads(const uint32_t *queries, uint32_t *readsT, uint32_t n, uint32_t wpq, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
 void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
 void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);

@@ -490,6 +490,21 @@ __global__ void relayoutKernel(const uint32_t *bwt, size_t bwtWords, const uint3
 // ---------------------------------------------------------------------------------------------
 // launchers (called from s3dp_api.cpp through s3dp_device.h)
 // ---------------------------------------------------------------------------------------------
+__global__ void transposeReadsKernel(const uint32_t *queries, uint32_t *readsT, uint32_t n, uint32_t wpq)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n * wpq) return;
+    const uint32_t r = (uint32_t)(t / wpq), w = (uint32_t)(t % wpq);
+    readsT[t] = queries[(size_t)(r >> 5) * 32u * wpq + (r & 31u) + (size_t)w * 32u];
+}
+
+void launchTransposeReads(const uint32_t *queries, uint32_t *readsT, uint32_t n, uint32_t wpq, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)n * wpq;
+    if (!total) return;
+    hipLaunchKernelGGL(transposeReadsKernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, queries, readsT, n, wpq);
+}
+
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s)
 {
     const unsigned blocks = (unsigned)((occRecs + 255) / 256);

@@ -26,7 +26,7 @@ namespace s3 {
 
 namespace v2 {
 
-enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_CESA = 2, ST_CETXT = 3, ST_LOAD = 4, ST_LT = 5 };
+enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_CESA = 2, ST_CETXT = 3, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6 };
 constexpr uint32_t ID_NONE = 0x7FFFFFFFu;
 constexpr int STACK = 20;
 constexpr uint32_t CE_CHUNK = 112;                   // text characters compared per iteration (8 words minus alignment slack)
@@ -87,8 +87,10 @@ __device__ __forceinline__ Range childRange(int dir, const Range &g, const uint4
 
 using namespace v2;
 
-// Persistent wavefronts with per-lane refill: a lane that finishes its (read, case, strand) item immediately takes
-// the next one from the wave's chunk of the global work queue, so all 64 lanes keep a memory request in flight.
+// Persistent wavefronts with per-lane refill: a lane owns one READ at a time and walks all its (case, strand) items
+// back to back (the read is loaded once, as two 16-B requests from a per-read contiguous copy); when the read is
+// finished the lane immediately takes the next one from the wave's chunk of the global work queue, so all 64 lanes
+// keep a memory request in flight.
 // UNIFORM: every read of the launch has the same length, the model (all cases) then lives in LDS; otherwise step
 // descriptors are read from the global table (L1/L2 resident).
 template <bool UNIFORM>
@@ -113,14 +115,12 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     const uint32_t nSlots = in.nActive;
     const uint32_t nCases = (uint32_t)in.nCases;
     const uint32_t groups = nCases * 2u;
-    const uint32_t slotsPadded = (nSlots + 63u) & ~63u;
-    const uint64_t nItems = (uint64_t)slotsPadded * groups;
     uint32_t nRank = 0, nLt = 0, nSa = 0, nCe = 0;
 
     // ---- per-lane item + search state ---------------------------------------------------------------------
     uint32_t state = ST_DONE;
     bool hasItem = false;
-    uint32_t cntIdx = 0, seq = 0, total = 0, rIdx = 0, loadOff = 0;
+    uint32_t cntIdx = 0, seq = 0, total = 0, rIdx = 0, loadOff = 0, slotIdx = 0, sub = 0;
     uint32_t strand = 0;
     int Li = 0, nSteps = 0;
     uint32_t casIdx = 0;
@@ -212,42 +212,62 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     };
 
     for (;;) {
-        // ---------- retire finished items, hand out new ones ----------
-        if (state == ST_DONE && hasItem) { out.itemCounts[cntIdx] = seq; hasItem = false; }
+        // ---------- retire finished items; next (case, strand) of the same read, or a new read ----------
+        if (state == ST_DONE && hasItem) {
+            out.itemCounts[cntIdx] = seq;
+            sub++;
+            if (sub < groups) {
+                casIdx = sub >> 1; strand = sub & 1u;
+                if constexpr (UNIFORM) nSteps = ((const S3Model *)shmem)->cs[casIdx].nSteps;
+                else nSteps = in.models[Li].cs[casIdx].nSteps;
+                cntIdx = slotIdx * groups + sub;
+                seq = 0; total = 0; sp = 0;
+                state = ST_KEYS;
+            } else hasItem = false;
+        }
         const unsigned long long idleMask = __ballot(state == ST_DONE);
         if (idleMask) {
             if (chunkCur >= chunkEnd && !queueEmpty) {
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(out.workHead, (unsigned long long)S3_V2_CHUNK);
                 b = (unsigned long long)__shfl((long long)b, 0);
-                if (b >= nItems) queueEmpty = true;
-                else { chunkCur = b; chunkEnd = b + S3_V2_CHUNK < nItems ? b + S3_V2_CHUNK : nItems; }
+                if (b >= nSlots) queueEmpty = true;
+                else { chunkCur = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots; }
             }
             const uint64_t avail = chunkEnd > chunkCur ? chunkEnd - chunkCur : 0;
             if (avail) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
                 const uint32_t nIdle = (uint32_t)__popcll(idleMask);
                 if (state == ST_DONE && rank < avail) {
-                    const uint64_t item = chunkCur + rank;
-                    const uint32_t grp = (uint32_t)(item / slotsPadded), slot = (uint32_t)(item % slotsPadded);
-                    if (slot < nSlots) {
-                        const uint32_t cas = grp >> 1;
-                        strand = grp & 1u;
-                        rIdx = in.active ? in.active[slot] : slot;
-                        Li = (int)in.readLengths[rIdx];
-                        casIdx = cas;
-                        if constexpr (UNIFORM) nSteps = ((const S3Model *)shmem)->cs[cas].nSteps;
-                        else nSteps = in.models[Li].cs[cas].nSteps;
-                        cntIdx = (slot * nCases + cas) * 2u + strand;
-                        seq = 0; total = 0; sp = 0; loadOff = 0;
-                        hasItem = true;
-                        state = ST_LOAD;
-                    }
+                    slotIdx = (uint32_t)(chunkCur + rank);
+                    rIdx = in.active ? in.active[slotIdx] : slotIdx;
+                    Li = (int)in.readLengths[rIdx];
+                    sub = 0; casIdx = 0; strand = 0;
+                    if constexpr (UNIFORM) nSteps = ((const S3Model *)shmem)->cs[0].nSteps;
+                    else nSteps = in.models[Li].cs[0].nSteps;
+                    cntIdx = slotIdx * groups;
+                    seq = 0; total = 0; sp = 0; loadOff = 0;
+                    hasItem = true;
+                    state = ST_LOAD;
                 }
                 chunkCur += nIdle < avail ? nIdle : avail;
             } else if (queueEmpty && idleMask == ~0ULL) break;                 // nothing left anywhere
         }
 
+        // ---------- lookup-table keys of a starting item (BWTExactModel{Backward,Forward}_Lookup2, BGS-HostAlgnmtAlgo2.cpp:311-347) ----------
+        if (state == ST_KEYS) {
+            const S3Step st = stepAt(0);
+            const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
+            auto ltKey = [&](int from, int stride, uint32_t &lp, uint32_t &rp) {
+                lp = 0;
+                for (int k = 0; k < ll; k++) lp = (lp << 2) | readChar(from + k * stride);
+                rp = lp;
+                for (int k = ll; k < ix.ltSize; k++) { lp <<= 2; rp = (rp << 2) | 3u; }
+            };
+            if (st.type == S3_T_BACK_LOOKUP) ltKey(st.start - ll + 1, 1, ltA, ltB);
+            else { ltKey(st.start, 1, ltA, ltB); ltKey(st.start + ll - 1, -1, ltC, ltD); }
+            state = ST_LT;
+        }
         // ---------- what does this lane need? ----------
         uint32_t idA = ID_NONE, iL = 0, iR = 0;
         bool needB = false;
@@ -290,16 +310,9 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             p0 = line[0];
             if (iR != (kR << 7)) p1 = line[iR > (kR << 7) ? 2 : 1];
         } else if (state == ST_LOAD) {
-            const uint32_t *src = in.queries + (size_t)(rIdx >> 5) * 32u * wpq + (rIdx & 31u) + (size_t)loadOff * 32u;
-            const uint32_t left = wpq - loadOff;
-            p0.x = src[0];
-            if (left > 1) p0.y = src[32];
-            if (left > 2) p0.z = src[64];
-            if (left > 3) p0.w = src[96];
-            if (left > 4) p1.x = src[128];
-            if (left > 5) p1.y = src[160];
-            if (left > 6) p1.z = src[192];
-            if (left > 7) p1.w = src[224];
+            const uint4 *src = (const uint4 *)(in.readsT + (size_t)rIdx * wpq + loadOff);      // wpq is a power of two >= 2
+            p0 = src[0];
+            if (wpq - loadOff > 4) p1 = src[1];
         } else if (state == ST_LT) {
             const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
             p0.x = ltA ? ix.lkt[ltA - 1] : 0u;
@@ -393,20 +406,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (left > 6) dst[384] = p1.z;
             if (left > 7) dst[448] = p1.w;
             loadOff += 8;
-            if (loadOff >= wpq) {
-                // lookup-table keys (BWTExactModel{Backward,Forward}_Lookup2, BGS-HostAlgnmtAlgo2.cpp:311-347)
-                const S3Step st = stepAt(0);
-                const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
-                auto ltKey = [&](int from, int stride, uint32_t &lp, uint32_t &rp) {
-                    lp = 0;
-                    for (int k = 0; k < ll; k++) lp = (lp << 2) | readChar(from + k * stride);
-                    rp = lp;
-                    for (int k = ll; k < ix.ltSize; k++) { lp <<= 2; rp = (rp << 2) | 3u; }
-                };
-                if (st.type == S3_T_BACK_LOOKUP) ltKey(st.start - ll + 1, 1, ltA, ltB);
-                else { ltKey(st.start, 1, ltA, ltB); ltKey(st.start + ll - 1, -1, ltC, ltD); }
-                state = ST_LT;
-            }
+            if (loadOff >= wpq) state = ST_KEYS;
         } else if (state == ST_LT) {
             const S3Step st = stepAt(0);
             const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
@@ -479,10 +479,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 
 void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
 {
-    const uint64_t slotsPadded = ((uint64_t)in.nActive + 63u) & ~63ull;
-    const uint64_t nItems = slotsPadded * (uint64_t)in.nCases * 2u;
-    if (nItems == 0) return;
-    uint64_t blocks = (nItems + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    if (in.nActive == 0) return;
+    uint64_t blocks = ((uint64_t)in.nActive + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + in.wpq * 256u);
     if (in.uniformLen) hipLaunchKernelGGL(searchKernelV2<true>, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
