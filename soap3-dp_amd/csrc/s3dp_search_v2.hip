@@ -67,6 +67,30 @@ __device__ __forceinline__ uint4 rankFromLine(uint32_t i, uint4 occ, uint4 w)
     return v;
 }
 
+// exact-step variant: only the read character's rank (eq) and the total rank of the larger symbols (gt) are needed
+__device__ __forceinline__ void rankEqGt(uint32_t i, uint4 occ, uint4 w, uint32_t ch, uint32_t &eq, uint32_t &gt)
+{
+    const uint32_t k = (i + 63u) >> 7, p = k << 7;
+    eq = sel4(occ, ch);
+    gt = (ch < 3 ? occ.w : 0u) + (ch < 2 ? occ.z : 0u) + (ch < 1 ? occ.y : 0u);
+    if (i != p) {
+        const bool fwd = i > p;
+        const uint32_t d = fwd ? i - p : p - i;
+        const uint64_t w0 = ((uint64_t)w.x << 32) | w.y, w1 = ((uint64_t)w.z << 32) | w.w;
+        const uint64_t M5 = 0x5555555555555555ULL;
+        const uint64_t mA = (fwd ? hiMask(d) : loMask(d)) & M5;
+        const uint64_t mB = (d > 32 ? (fwd ? hiMask(d - 32) : loMask(d - 32)) : 0ULL) & M5;
+        const uint64_t wA = fwd ? w0 : w1, wB = fwd ? w1 : w0;
+        const uint64_t loA = wA & M5, hiA = (wA >> 1) & M5, loB = wB & M5, hiB = (wB >> 1) & M5;
+        // per-character indicator bits (on the even bit of each 2-bit character)
+        const uint64_t eqA = (ch & 2u ? hiA : ~hiA) & (ch & 1u ? loA : ~loA), eqB = (ch & 2u ? hiB : ~hiB) & (ch & 1u ? loB : ~loB);
+        const uint64_t gtA = ch == 0 ? (hiA | loA) : ch == 1 ? hiA : ch == 2 ? (hiA & loA) : 0ULL;
+        const uint64_t gtB = ch == 0 ? (hiB | loB) : ch == 1 ? hiB : ch == 2 ? (hiB & loB) : 0ULL;
+        const uint32_t ce = __popcll(eqA & mA) + __popcll(eqB & mB), cg = __popcll(gtA & mA) + __popcll(gtB & mB);
+        if (fwd) { eq += ce; gt += cg; } else { eq -= ce; gt -= cg; }
+    }
+}
+
 struct Range { uint32_t fl, fr, rl, rr; };
 
 __device__ __forceinline__ Range childRange(int dir, const Range &g, const uint4 &oL, const uint4 &oR, uint32_t ch)
@@ -257,15 +281,18 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         // ---------- lookup-table keys of a starting item (BWTExactModel{Backward,Forward}_Lookup2, BGS-HostAlgnmtAlgo2.cpp:311-347) ----------
         if (state == ST_KEYS) {
             const S3Step st = stepAt(0);
-            const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
-            auto ltKey = [&](int from, int stride, uint32_t &lp, uint32_t &rp) {
-                lp = 0;
-                for (int k = 0; k < ll; k++) lp = (lp << 2) | readChar(from + k * stride);
-                rp = lp;
-                for (int k = ll; k < ix.ltSize; k++) { lp <<= 2; rp = (rp << 2) | 3u; }
-            };
-            if (st.type == S3_T_BACK_LOOKUP) ltKey(st.start - ll + 1, 1, ltA, ltB);
-            else { ltKey(st.start, 1, ltA, ltB); ltKey(st.start + ll - 1, -1, ltC, ltD); }
+            const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;            // <= 13 characters = 26 bits of one window
+            const uint32_t padOnes = ll < ix.ltSize ? ((1u << (2 * (ix.ltSize - ll))) - 1u) : 0u;
+            const int shPad = 2 * (ix.ltSize - ll);
+            if (st.type == S3_T_BACK_LOOKUP) {
+                const uint32_t key = readWindow(st.start - ll + 1) >> (32 - 2 * ll);
+                ltA = key << shPad; ltB = (key << shPad) | padOnes;
+            } else {
+                const uint32_t key = readWindow(st.start) >> (32 - 2 * ll);
+                ltA = key << shPad; ltB = (key << shPad) | padOnes;
+                const uint32_t rkey = pairRev(readWindow(st.start)) & ((1u << (2 * ll)) - 1u);     // same characters, reversed order
+                ltC = rkey << shPad; ltD = (rkey << shPad) | padOnes;
+            }
             state = ST_LT;
         }
         // ---------- what does this lane need? ----------
@@ -349,7 +376,36 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         __builtin_amdgcn_wave_barrier();
 
         // ---------- advance ----------
-        if (state == ST_STEP) {
+        bool doSettle = false, needPop = false;
+        const bool stepping = state == ST_STEP;
+        S3Step stS;
+        bool exact = true;
+        if (stepping) { stS = stepAt(s); exact = ins >= stS.maxErr; }
+        if (__ballot(stepping && !exact) == 0) {
+            // every stepping lane is in an exact region (the common case): one symbol's rank + the larger-symbol total
+            if (stepping) {
+                const uint32_t kL = (iL + 63u) >> 7;
+                const uint4 occA = stage[lane * 4u];
+                uint4 wL = make_uint4(0, 0, 0, 0), wR = make_uint4(0, 0, 0, 0);
+                if (iL != (kL << 7)) wL = stage[lane * 4u + (iL > (kL << 7) ? 2u : 1u)];
+                const int pos = stS.start + stS.dir * i;
+                const uint32_t ch = readChar(pos);
+                uint32_t eqL, gtL, eqR, gtR;
+                rankEqGt(iL, occA, wL, ch, eqL, gtL);
+                if (needB) rankEqGt(iR, p0, p1, ch, eqR, gtR);
+                else {
+                    if (iR != (kL << 7)) wR = stage[lane * 4u + (iR > (kL << 7) ? 2u : 1u)];
+                    rankEqGt(iR, occA, wR, ch, eqR, gtR);
+                }
+                nRank += 2;
+                const uint32_t al = eqL + 1u, ar = eqR, oc = gtR - gtL;
+                const uint32_t pr = (stS.dir < 0 ? g.rr : g.fr) - oc, pl = pr - (ar - al);
+                if (stS.dir < 0) { g.fl = al; g.fr = ar; g.rl = pl; g.rr = pr; }
+                else { g.rl = al; g.rr = ar; g.fl = pl; g.fr = pr; }
+                i++;
+                doSettle = true;
+            }
+        } else if (stepping) {
             const uint32_t kL = (iL + 63u) >> 7;
             const uint4 occA = stage[lane * 4u];
             uint4 wL = make_uint4(0, 0, 0, 0);
@@ -363,19 +419,17 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 oR = rankFromLine(iR, occA, wR);
             }
             nRank += 2;
-            const S3Step st = stepAt(s);
-            const bool exact = ins >= st.maxErr;
-            const int pos = st.start + st.dir * i;
+            const int pos = stS.start + stS.dir * i;
             const uint32_t ch = readChar(pos);
-            const Range gc = childRange(st.dir, g, oL, oR, ch);
-            bool needPop = false;
+            const Range gc = childRange(stS.dir, g, oL, oR, ch);
+            doSettle = true;
             if (!exact) {
-                const Range e0 = childRange(st.dir, g, oL, oR, 0u), e1 = childRange(st.dir, g, oL, oR, 1u);
-                const Range e2 = childRange(st.dir, g, oL, oR, 2u), e3 = childRange(st.dir, g, oL, oR, 3u);
+                const Range e0 = childRange(stS.dir, g, oL, oR, 0u), e1 = childRange(stS.dir, g, oL, oR, 1u);
+                const Range e2 = childRange(stS.dir, g, oL, oR, 2u), e3 = childRange(stS.dir, g, oL, oR, 3u);
                 const bool a0 = ch != 0 && e0.fl <= e0.fr, a1 = ch != 1 && e1.fl <= e1.fr;
                 const bool a2 = ch != 2 && e2.fl <= e2.fr, a3 = ch != 3 && e3.fl <= e3.fr;
                 if (a0 || a1 || a2 || a3) {
-                    if (sp + 4 > STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = ST_DONE; sp = 0; }
+                    if (sp + 4 > STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = ST_DONE; sp = 0; doSettle = false; }
                     else {
                         const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
                         const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
@@ -390,11 +444,9 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     }
                 }
             }
-            if (state != ST_DONE) {
-                if (!needPop) { g = gc; i++; }
-                settle(needPop);
-            }
-        } else if (state == ST_LOAD) {
+            if (doSettle && !needPop) { g = gc; i++; }
+        }
+        if (state == ST_LOAD) {
             uint32_t *dst = rdw + (size_t)loadOff * 64u + lane;
             const uint32_t left = wpq - loadOff;
             dst[0] = p0.x;
@@ -419,7 +471,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 g.fl = l; g.fr = rr_; g.rl = rl; g.rr = rrr;
             }
             s = 0; i = ll; ins = 0; occ = 0;
-            settle(false);
+            doSettle = true;
         } else if (state == ST_CESA) {
             const S3Step st0 = stepAt(ceS);
             const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - ceI;
@@ -463,10 +515,11 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 candidateDone = true;
             }
             if (candidateDone) {
-                if (total >= in.maxOut || ceQ >= ceQEnd) settle(true);            // check-and-extend of this range is finished
+                if (total >= in.maxOut || ceQ >= ceQEnd) { doSettle = true; needPop = true; }   // check-and-extend of this range is finished
                 else { ceQ++; state = ST_CESA; }
             }
         }
+        if (doSettle) settle(needPop);
         __builtin_amdgcn_wave_barrier();
     }
     if (out.counters) {
