@@ -289,6 +289,12 @@ static int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uin
     SearchIn in{};
     in.queries = b->dQueries; in.readsT = b->dReadsT; in.readLengths = b->dLens; in.active = active; in.nActive = nActive; in.wpq = b->wpq;
     in.models = b->ix->models[modelMm]; in.nCases = nCases; in.maxOut = maxOut; in.uniformLen = b->uniformLen;
+    {
+        S3Model m;
+        s3_model_build(100, (int)modelMm, &m);
+        in.nStepsPacked = 0;
+        for (int c = 0; c < m.nCases; c++) in.nStepsPacked |= (uint32_t)m.cs[c].nSteps << (3 * c);
+    }
     SearchOut out{};
     out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
     out.counters = b->counting ? b->dCounters : nullptr;

@@ -40,6 +40,7 @@ struct SearchIn {
     const S3Model  *models;      // indexed by read length, for this phase's mismatch budget
     int             nCases;
     uint32_t        maxOut;
+    uint32_t        nStepsPacked;  // 3 bits per case: number of steps (depends on the mismatch budget only)
     uint32_t        uniformLen;  // != 0: every active read has this length (model kept in LDS by the v2 kernel)
 };
 

@@ -157,7 +157,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     int ceT = 0, ceII = 0, ceInsCur = 0, ceAcc = 0, ceMm = 0;
     uint32_t ltA = 0, ltB = 0, ltC = 0, ltD = 0;                            // lookup-table keys of the starting item
     // wave-uniform work queue window
-    uint64_t chunkCur = 0, chunkEnd = 0;
+    uint64_t chunkCur = 0, chunkEnd = 0, chunkBase = 0;
+    uint32_t act0 = 0, act1 = 0;
     bool queueEmpty = false;
 
     auto stepAt = [&](int k) -> S3Step {
@@ -237,13 +238,14 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 
     for (;;) {
         // ---------- retire finished items; next (case, strand) of the same read, or a new read ----------
+        // (no global load in this section may stall the wave: step counts come packed in a kernel argument, the
+        //  read index list of a whole chunk is prefetched into two registers per lane when the chunk is taken)
         if (state == ST_DONE && hasItem) {
             out.itemCounts[cntIdx] = seq;
             sub++;
             if (sub < groups) {
                 casIdx = sub >> 1; strand = sub & 1u;
-                if constexpr (UNIFORM) nSteps = ((const S3Model *)shmem)->cs[casIdx].nSteps;
-                else nSteps = in.models[Li].cs[casIdx].nSteps;
+                nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
                 cntIdx = slotIdx * groups + sub;
                 seq = 0; total = 0; sp = 0;
                 state = ST_KEYS;
@@ -256,19 +258,27 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 if (lane == 0) b = atomicAdd(out.workHead, (unsigned long long)S3_V2_CHUNK);
                 b = (unsigned long long)__shfl((long long)b, 0);
                 if (b >= nSlots) queueEmpty = true;
-                else { chunkCur = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots; }
+                else {
+                    chunkCur = chunkBase = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots;
+                    if (in.active) {
+                        act0 = b + lane < nSlots ? in.active[b + lane] : 0u;
+                        act1 = b + 64u + lane < nSlots ? in.active[b + 64u + lane] : 0u;
+                    }
+                }
             }
             const uint64_t avail = chunkEnd > chunkCur ? chunkEnd - chunkCur : 0;
             if (avail) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
                 const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+                const uint32_t off = (uint32_t)(chunkCur - chunkBase) + rank;          // position inside the chunk, < 128 when taken
+                const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)act0);
+                const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)act1);
                 if (state == ST_DONE && rank < avail) {
                     slotIdx = (uint32_t)(chunkCur + rank);
-                    rIdx = in.active ? in.active[slotIdx] : slotIdx;
-                    Li = (int)in.readLengths[rIdx];
+                    rIdx = in.active ? (off < 64u ? a0 : a1) : slotIdx;
+                    if constexpr (UNIFORM) Li = (int)in.uniformLen;
                     sub = 0; casIdx = 0; strand = 0;
-                    if constexpr (UNIFORM) nSteps = ((const S3Model *)shmem)->cs[0].nSteps;
-                    else nSteps = in.models[Li].cs[0].nSteps;
+                    nSteps = (int)(in.nStepsPacked & 7u);
                     cntIdx = slotIdx * groups;
                     seq = 0; total = 0; sp = 0; loadOff = 0;
                     hasItem = true;
@@ -340,6 +350,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const uint4 *src = (const uint4 *)(in.readsT + (size_t)rIdx * wpq + loadOff);      // wpq is a power of two >= 2
             p0 = src[0];
             if (wpq - loadOff > 4) p1 = src[1];
+            if constexpr (!UNIFORM) saVal = in.readLengths[rIdx];
         } else if (state == ST_LT) {
             const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
             p0.x = ltA ? ix.lkt[ltA - 1] : 0u;
@@ -458,6 +469,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (left > 6) dst[384] = p1.z;
             if (left > 7) dst[448] = p1.w;
             loadOff += 8;
+            if constexpr (!UNIFORM) Li = (int)saVal;
             if (loadOff >= wpq) state = ST_KEYS;
         } else if (state == ST_LT) {
             const S3Step st = stepAt(0);
