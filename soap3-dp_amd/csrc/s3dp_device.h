@@ -5,7 +5,7 @@
 #include "s3dp_model.h"
 
 #define S3_SEARCH_BLOCK 256
-#define S3_V2_WAVES_PER_SIMD 5            // register budget of the v2 search kernel (512 / 5 -> 96 VGPRs)
+#define S3_V2_WAVES_PER_SIMD 4            // register budget of the v2 search kernel (512 / 4 -> 128 VGPRs, no spills in the loop)
 #define S3_V2_CHUNK 128u                  // reads a wave takes from the work queue at a time
 #define S3_V2_MODEL_BYTES 1104u           // sizeof(S3Model) rounded up to 16
 #define S3_FLAG_STACK_OVERFLOW 1u

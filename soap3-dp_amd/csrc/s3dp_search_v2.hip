@@ -305,60 +305,43 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             state = ST_LT;
         }
-        // ---------- what does this lane need? ----------
+        // ---------- what does this lane need? (addresses only; no load may be consumed before the single wait) ----------
         uint32_t idA = ID_NONE, iL = 0, iR = 0;
         bool needB = false;
         int dir = 0;
+        const uint4 *dummy16 = (const uint4 *)ix.pac;                // always-valid, cache-hot address for lanes that need nothing
+        const uint4 *aP0 = dummy16, *aP1 = dummy16;
+        const uint32_t *aD0 = ix.pac, *aD1 = ix.pac, *aD2 = ix.pac, *aD3 = ix.pac;
+        bool zeroP0 = false, zeroP1 = false, ceReject = false;
+        uint32_t ceCnt = 0, ceLeft = 0, ceLen = 0, tpos = 0;
         if (state == ST_STEP) {
             dir = stepAt(s).dir;
-            const DevBwt &b = dir < 0 ? ix.fwd : ix.rev;
+            const uint32_t inv = dir < 0 ? ix.fwd.inverseSa0 : ix.rev.inverseSa0;
             iL = dir < 0 ? g.fl : g.rl;
             iR = (dir < 0 ? g.fr : g.rr) + 1u;
-            iL -= (iL > b.inverseSa0);
-            iR -= (iR > b.inverseSa0);
+            iL -= (iL > inv);
+            iR -= (iR > inv);
             const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
             idA = kL | (dir < 0 ? 0u : 0x80000000u);
             needB = kR != kL;
-        }
-        // ---------- issue: cooperative rank lines (4 adjacent lanes fetch one owner's 64-B line) ----------
-        uint4 va0, va1, va2, va3;
-        uint32_t o0, o1, o2, o3;
-        {
-            const uint32_t sub = lane & 3u, q4 = lane >> 2;
-            o0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((q4) * 4u), (int)idA);
-            o1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u + q4) * 4u), (int)idA);
-            o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((32u + q4) * 4u), (int)idA);
-            o3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((48u + q4) * 4u), (int)idA);
-            va0 = va1 = va2 = va3 = make_uint4(0, 0, 0, 0);
-            if (o0 != ID_NONE) va0 = ((o0 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o0 & 0x7FFFFFFFu) * 4u + sub];
-            if (o1 != ID_NONE) va1 = ((o1 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o1 & 0x7FFFFFFFu) * 4u + sub];
-            if (o2 != ID_NONE) va2 = ((o2 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o2 & 0x7FFFFFFFu) * 4u + sub];
-            if (o3 != ID_NONE) va3 = ((o3 >> 31) ? ix.rev.lines : ix.fwd.lines)[(size_t)(o3 & 0x7FFFFFFFu) * 4u + sub];
-        }
-        // ---------- issue: private loads (second rank line / read words / lookup table / SA entry / text) ----------
-        uint4 p0 = make_uint4(0, 0, 0, 0), p1 = make_uint4(0, 0, 0, 0);
-        uint32_t saVal = 0;
-        bool ceReject = false;
-        uint32_t ceCnt = 0, ceLeft = 0, ceLen = 0, tpos = 0;
-        if (needB) {
-            const DevBwt &b = dir < 0 ? ix.fwd : ix.rev;
-            const uint32_t kR = (iR + 63u) >> 7;
-            const uint4 *line = b.lines + (size_t)kR * 4u;
-            p0 = line[0];
-            if (iR != (kR << 7)) p1 = line[iR > (kR << 7) ? 2 : 1];
+            if (needB) {
+                const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
+                aP0 = line;
+                aP1 = line + (iR > (kR << 7) ? 2 : 1);
+            }
         } else if (state == ST_LOAD) {
-            const uint4 *src = (const uint4 *)(in.readsT + (size_t)rIdx * wpq + loadOff);      // wpq is a power of two >= 2
-            p0 = src[0];
-            if (wpq - loadOff > 4) p1 = src[1];
-            if constexpr (!UNIFORM) saVal = in.readLengths[rIdx];
+            const uint4 *src = (const uint4 *)(in.readsT + (size_t)rIdx * wpq + loadOff);      // wpq is a power of two
+            aP0 = src;
+            if (wpq - loadOff > 4) aP1 = src + 1;
+            if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
         } else if (state == ST_LT) {
             const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
-            p0.x = ltA ? ix.lkt[ltA - 1] : 0u;
-            p0.y = ix.lkt[ltB];
-            if (bidir) { p0.z = ltC ? ix.rlkt[ltC - 1] : 0u; p0.w = ix.rlkt[ltD]; }
+            aD0 = ix.lkt + (ltA ? ltA - 1u : 0u);
+            aD1 = ix.lkt + ltB;
+            if (bidir) { aD2 = ix.rlkt + (ltC ? ltC - 1u : 0u); aD3 = ix.rlkt + ltD; }
             nLt += bidir ? 4 : 2;
         } else if (state == ST_CESA) {
-            saVal = ix.sa[ceQ];
+            aD0 = ix.sa + ceQ;
             nSa++;
         } else if (state == ST_CETXT) {
             const S3Step st = stepAt(ceT);
@@ -371,19 +354,33 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 tpos = ceRp + ceLeft + ceOff;
                 const size_t bw = tpos >> 4;
                 const uint32_t words = ((tpos & 15u) + ceCnt + 15u) >> 4;
-                if (bw + 4 <= ix.pacWords) p0 = *(const uint4 *)(ix.pac + bw);
-                if (words > 4 && bw + 8 <= ix.pacWords) p1 = *(const uint4 *)(ix.pac + bw + 4);
+                if (bw + 4 <= ix.pacWords) aP0 = (const uint4 *)(ix.pac + bw); else zeroP0 = true;
+                if (words > 4 && bw + 8 <= ix.pacWords) aP1 = (const uint4 *)(ix.pac + bw + 4); else zeroP1 = true;
                 nCe += (ceCnt + 31u) >> 5;
             }
         }
-        // ---------- stage the cooperative lines in LDS (owner slot = 64 B) ----------
-        {
-            const uint32_t sub = lane & 3u, q4 = lane >> 2;
-            if (o0 != ID_NONE) stage[(q4) * 4u + sub] = va0;
-            if (o1 != ID_NONE) stage[(16u + q4) * 4u + sub] = va1;
-            if (o2 != ID_NONE) stage[(32u + q4) * 4u + sub] = va2;
-            if (o3 != ID_NONE) stage[(48u + q4) * 4u + sub] = va3;
-        }
+        // ---------- issue: every lane issues the same 10 loads, back to back, no branches ----------
+        // cooperative rank lines: 4 adjacent lanes fetch the 4 x 16 B of one owner's line (owners without a request: line 0)
+        const uint32_t sub = lane & 3u, q4 = lane >> 2;
+        const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((q4) * 4u), (int)idA);
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u + q4) * 4u), (int)idA);
+        const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((32u + q4) * 4u), (int)idA);
+        const uint32_t o3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((48u + q4) * 4u), (int)idA);
+        auto lineAddr = [&](uint32_t o) -> const uint4 * {
+            const uint4 *base = (o >> 31) ? ix.rev.lines : ix.fwd.lines;
+            return base + (o == ID_NONE ? (size_t)sub : (size_t)(o & 0x7FFFFFFFu) * 4u + sub);
+        };
+        const uint4 va0 = *lineAddr(o0), va1 = *lineAddr(o1), va2 = *lineAddr(o2), va3 = *lineAddr(o3);
+        uint4 p0 = *aP0, p1 = *aP1;
+        const uint32_t d0 = *aD0, d1 = *aD1, d2 = *aD2, d3 = *aD3;
+        // ---------- stage the cooperative lines in LDS (owner slot = 64 B); slots of owners without a request get line 0 ----------
+        stage[(q4) * 4u + sub] = va0;
+        stage[(16u + q4) * 4u + sub] = va1;
+        stage[(32u + q4) * 4u + sub] = va2;
+        stage[(48u + q4) * 4u + sub] = va3;
+        if (zeroP0) p0 = make_uint4(0, 0, 0, 0);
+        if (zeroP1) p1 = make_uint4(0, 0, 0, 0);
+        const uint32_t saVal = d0;
         __builtin_amdgcn_wave_barrier();
 
         // ---------- advance ----------
@@ -475,9 +472,9 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const S3Step st = stepAt(0);
             const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
             if (st.type == S3_T_BACK_LOOKUP) {
-                g.fl = ltA ? p0.x + 1u : 1u; g.fr = p0.y; g.rl = g.fl; g.rr = g.fr;
+                g.fl = ltA ? d0 + 1u : 1u; g.fr = d1; g.rl = g.fl; g.rr = g.fr;
             } else {
-                uint32_t l = ltA ? p0.x + 1u : 1u, rr_ = p0.y, rl = ltC ? p0.z + 1u : 1u, rrr = p0.w;
+                uint32_t l = ltA ? d0 + 1u : 1u, rr_ = d1, rl = ltC ? d2 + 1u : 1u, rrr = d3;
                 if (rr_ - l < rrr - rl) rl = rrr - (rr_ - l);                          // :349-356
                 else if (rr_ - l > rrr - rl) l = rr_ - (rrr - rl);
                 g.fl = l; g.fr = rr_; g.rl = rl; g.rr = rrr;
