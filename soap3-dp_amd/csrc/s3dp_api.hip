@@ -174,6 +174,7 @@ struct s3_batch {
     std::vector<hipEvent_t> evSearch;
     uint32_t searchLaunches = 0;
     uint32_t occUsed = 0;
+    uint64_t recordsTotal = 0;      // records of all search passes of the last call (read back when counters are enabled)
 };
 
 template <class T>
@@ -205,7 +206,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     const size_t roundUp = ((size_t)maxReads + 31) / 32 * 32;
     b->maxItems = (size_t)maxReads * 20;                               // 10 cases x 2 strands at 4 mismatches
     const size_t recPerRead = envSize("S3DP_REC_PER_READ", 6), occPerRead = envSize("S3DP_OCC_PER_READ", 12);
-    size_t recCap = (size_t)maxReads * recPerRead + 65536, occCap = (size_t)maxReads * occPerRead + 65536;
+    size_t recCap = (size_t)maxReads * recPerRead + 65536 + (size_t)S3_V2_REC_BLOCK * 8192, occCap = (size_t)maxReads * occPerRead + 65536;
     if (recCap > 0xFFFFFF00ull) recCap = 0xFFFFFF00ull;
     if (occCap > 0xFFFFFF00ull) occCap = 0xFFFFFF00ull;
     b->recCap = (uint32_t)recCap; b->occCap = (uint32_t)occCap;
@@ -319,6 +320,12 @@ static int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uin
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     launchMergeCount(m, b->stream);
     b->lastNumCases = (uint32_t)nCases;
+    if (b->counting) {
+        uint32_t t = 0;
+        HIPCHK(hipMemcpyAsync(&t, b->dItemOffsets + nItems, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        b->recordsTotal += t;
+    }
     HIPCHK(hipGetLastError());
     return S3_OK;
 }
@@ -341,6 +348,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
     HIPCHK(hipSetDevice(b->ix->dev));
     b->searchLaunches = 0;
+    b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
     if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
@@ -466,6 +474,7 @@ extern "C" int s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, 
     const uint32_t n = b->n;
     b->searchLaunches = 0;
     b->occUsed = 0;
+    b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
     if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
@@ -582,9 +591,7 @@ extern "C" int s3_batch_counters(s3_batch *b, s3_counters *out)
     HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipMemcpy(c, b->dCounters, 64, hipMemcpyDeviceToHost));
     out->rankQueries = c[0]; out->ltLookups = c[1]; out->saReads = c[2]; out->ceWindows = c[3];
-    uint32_t rc = 0;
-    HIPCHK(hipMemcpy(&rc, b->dRecCount, 4, hipMemcpyDeviceToHost));
-    out->records = rc;
+    out->records = b->recordsTotal;
     return S3_OK;
 }
 

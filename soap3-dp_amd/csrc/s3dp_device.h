@@ -7,6 +7,7 @@
 #define S3_SEARCH_BLOCK 256
 #define S3_V2_WAVES_PER_SIMD 4            // register budget of the v2 search kernel (512 / 4 -> 128 VGPRs, no spills in the loop)
 #define S3_V2_CHUNK 128u                  // reads a wave takes from the work queue at a time
+#define S3_V2_REC_BLOCK 256u              // record slots a wave reserves with one atomic
 #define S3_V2_MODEL_BYTES 1104u           // sizeof(S3Model) rounded up to 16
 #define S3_FLAG_STACK_OVERFLOW 1u
 #define S3_FLAG_REC_OVERFLOW   2u

@@ -371,6 +371,7 @@ __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint3
     if (n > recCap) n = recCap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint4 r = recs[i];
+        if (r.x == 0xFFFFFFFFu) continue;                                   // unused slot of a reserved block (v2 kernel)
         ordered[itemOffsets[r.x] + (r.y & 0xFFFFFFu)] = r;
     }
 }

@@ -26,7 +26,7 @@ namespace s3 {
 
 namespace v2 {
 
-enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_CESA = 2, ST_CETXT = 3, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6 };
+enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_CESA = 2, ST_CETXT = 3, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6, ST_RESUME = 7 };
 constexpr uint32_t ID_NONE = 0x7FFFFFFFu;
 constexpr int STACK = 20;
 constexpr uint32_t CE_CHUNK = 112;                   // text characters compared per iteration (8 words minus alignment slack)
@@ -186,13 +186,15 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         } else x = (-a < 16) ? (rawWord(0) << (2 * (-a))) : 0u;
         return ~x;
     };
+    // A record is not written where it is found: the lane parks it (one per iteration) and the whole wave writes the
+    // parked records at the end of the iteration into a block of record slots it reserved with ONE atomic per
+    // S3_V2_REC_BLOCK records.  (Per-record atomics on one counter saturate the L2 atomic unit once lanes run
+    // desynchronised: that was 20 M atomics per launch.)
+    uint32_t pendMeta = 0, pendA = 0, pendB = 0;                // pendMeta bit 31 = valid
+    uint32_t recCur = 0, recEnd = 0;                             // wave-uniform: reserved block [recCur, recEnd)
     auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
-        const uint32_t at = atomicAdd(out.recCount, 1u);
-        if (at < out.recCap) {
-            uint4 rec;
-            rec.x = cntIdx; rec.y = seq | (kind << 24) | (nmis << 25); rec.z = a; rec.w = b;
-            out.recs[at] = rec;
-        } else atomicOr(out.flags, S3_FLAG_REC_OVERFLOW);
+        pendMeta = 0x80000000u | seq | (kind << 24) | (nmis << 25);
+        pendA = a; pendB = b;
         seq++;
     };
     // advance without memory until the lane needs ranks / SA / text or its item is finished
@@ -212,6 +214,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     if (total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - total - 1u;
                     emit(0, l, rr_, (uint32_t)(ins + occ));
                     total += rr_ - l + 1u;
+                    state = ST_RESUME;                                       // the parked record is written first; pop next iteration
+                    return;
                 }
                 needPop = true;
                 continue;
@@ -454,6 +458,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             if (doSettle && !needPop) { g = gc; i++; }
         }
+        if (state == ST_RESUME && !(pendMeta >> 31)) { doSettle = true; needPop = true; }
         if (state == ST_LOAD) {
             uint32_t *dst = rdw + (size_t)loadOff * 64u + lane;
             const uint32_t left = wpq - loadOff;
@@ -524,13 +529,36 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 candidateDone = true;
             }
             if (candidateDone) {
-                if (total >= in.maxOut || ceQ >= ceQEnd) { doSettle = true; needPop = true; }   // check-and-extend of this range is finished
+                if (total >= in.maxOut || ceQ >= ceQEnd) state = ST_RESUME;                // check-and-extend of this range is finished
                 else { ceQ++; state = ST_CESA; }
             }
         }
         if (doSettle) settle(needPop);
+        // ---------- write the parked records (convergent) ----------
+        {
+            const unsigned long long pm = __ballot((pendMeta >> 31) != 0);
+            if (pm) {
+                const uint32_t np = (uint32_t)__popcll(pm);
+                if (recCur + np > recEnd) {
+                    for (uint32_t k = recCur + lane; k < recEnd; k += 64u) out.recs[k] = make_uint4(0xFFFFFFFFu, 0, 0, 0);   // unused tail
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(out.recCount, S3_V2_REC_BLOCK);
+                    b = (uint32_t)__shfl((int)b, 0);
+                    recCur = b; recEnd = b + S3_V2_REC_BLOCK;
+                    if (recEnd > out.recCap || recEnd < b) { recEnd = b < out.recCap ? out.recCap : b; atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
+                }
+                if (pendMeta >> 31) {
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                    pendMeta = 0;
+                }
+                recCur += np;
+                if (recCur > recEnd) recCur = recEnd;
+            }
+        }
         __builtin_amdgcn_wave_barrier();
     }
+    for (uint32_t k = recCur + lane; k < recEnd; k += 64u) out.recs[k] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
     if (out.counters) {
         atomicAdd(&out.counters[0], (unsigned long long)nRank);
         atomicAdd(&out.counters[1], (unsigned long long)nLt);
