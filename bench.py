@@ -243,7 +243,7 @@ def main():
     search_s_per_step = search_ms / 1e3 / max(1, a.steps)
     achieved = bytes_step / search_s_per_step / 1e9 if search_s_per_step > 0 else 0.0
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "s3::searchKernel", "launches_per_step": launches // max(1, a.steps),
+            "kernel": "s3::searchKernelV2", "launches_per_step": launches // max(1, a.steps),
             "kernel_ms_per_step": search_ms / max(1, a.steps),
             "rank_queries_per_step": cnt["rankQueries"], "line_bytes_GBs": 64.0 * cnt["rankQueries"] / search_s_per_step / 1e9 if search_s_per_step else 0.0}
 
