@@ -10,6 +10,8 @@ Suffix sorting: one radix sort of 31-mer keys per 2-character bucket, then prefi
 to the groups that are still tied (repeats longer than 31 characters).  Suffixes that run off the end
 of the text compare as if followed by '$' < A.
 """
+import sys
+
 import numpy as np
 import torch
 
@@ -147,7 +149,7 @@ def suffix_array(codes, max_bucket=1 << 30, verbose=False):
     unresolved = _tied(newgrp)
     if not bool(unresolved.any()):
         if verbose:
-            print("  [sa] all suffixes distinct within %d characters" % K0)
+            print("  [sa] all suffixes distinct within %d characters" % K0, file=sys.stderr)
         return sa
     # rank[p] = SA index of the first member of p's group
     gstart = _group_starts(newgrp)
@@ -160,7 +162,7 @@ def suffix_array(codes, max_bucket=1 << 30, verbose=False):
         sidx = _nonzero_big(unresolved)                      # SA slots still tied, ascending
         m = sidx.numel()
         if verbose:
-            print("  [sa] h=%d unresolved=%d" % (h, m))
+            print("  [sa] h=%d unresolved=%d" % (h, m), file=sys.stderr)
         if m == 0:
             break
         pos = _gather_big(sa, sidx)
