@@ -1,0 +1,75 @@
+// s3_host.h -- host side of the drop-in `soap3-dp` program above the C-ABI (include/s3dp.h):
+// index files, read files, SAM records.  Mirrors the reference's host interfaces for this path:
+//   IndexHandler.cpp (INDEXLoad), QueryParser.cpp (loadSingleReadsGz), BGS-IO.cpp (OCCOutputSAMAPI,
+//   noAnsOutputSAMAPI, getChrAndPos, BoundaryCheck, MAPQ), SAM.cpp (SAMOutputHeaderConstruct).
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/s3dp.h"
+
+namespace s3host {
+
+struct Translate { uint32_t startPos, chrID, correction; };
+
+struct HostIndex {
+    // search structures (file payloads, headers stripped)
+    std::vector<uint32_t> bwt, occ, rbwt, rocc, sa, pac, lkt, rlkt;
+    uint32_t inverseSa0 = 0, rInverseSa0 = 0, cum[5] = {0, 0, 0, 0, 0}, rcum[5] = {0, 0, 0, 0, 0};
+    uint32_t n = 0;
+    // annotation (HSPLoad, 2bwt-lib/HSP.c:256-531)
+    uint32_t dnaLength = 0;
+    int numOfSeq = 0;
+    std::vector<std::string> seqName;
+    std::vector<uint32_t> seqStart, seqEnd;              // seqOffset[].startPos / endPos (inclusive)
+    std::vector<uint32_t> actualStart, actualEnd;        // seqActualOffset[]
+    uint32_t numOfRemovedSegment = 0;
+    std::vector<uint32_t> ambiguityMap;                  // grid: position >> 18 -> translate entry
+    std::vector<Translate> translate;
+    s3_index_desc desc() const;
+};
+
+bool loadIndex(const std::string &prefix, HostIndex &ix, std::string &err);
+void buildLookupTable(const std::vector<uint32_t> &pacWords, uint32_t n, bool reversed, std::vector<uint32_t> &table);
+
+struct ReadSet {
+    std::vector<uint32_t> queries;                       // reference packed layout
+    std::vector<uint32_t> lengths;
+    std::vector<std::string> names;
+    std::vector<uint8_t> codes;                          // n x maxReadLength, 2-bit codes
+    std::vector<char> quals;                             // n x maxReadLength, Phred (char - 33 / 64)
+    uint32_t n = 0, wpq = 0, maxReadLength = 0;
+    bool isFastq = false;
+};
+
+bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err);
+
+struct SamOptions {
+    std::string readGroup, sampleName, readGrpOption;
+    int alignmentType = 2;                               // OUTPUT_ALL_BEST
+    int minMAPQ = 1, maxMAPQ = 40, bwaLikeScore = 1;
+    bool printMDNM = false;
+};
+
+class SamWriter {
+public:
+    SamWriter(const HostIndex &ix, const SamOptions &opt, FILE *out);
+    void header();
+    // one read of the single-end path: occurrence list in the CPU path's final order (OCCOutputSAMAPI, BGS-IO.cpp:5556)
+    void singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, const uint8_t *strand, const uint8_t *mis, size_t nOcc);
+    void unaligned(const ReadSet &rs, uint32_t r);       // noAnsOutputSAMAPI, BGS-IO.cpp:5829
+    uint64_t records() const { return nRecords; }
+
+private:
+    uint32_t chrAndPos(uint32_t ambPos, uint64_t &tp, uint32_t &chr) const;                    // getChrAndPos, BGS-IO.cpp:1746
+    int chrAndPosChecked(uint32_t readLen, uint32_t ambPos, uint64_t &tp, uint32_t &chr, std::string *cigar) const;   // :1981
+    void seqAndQual(const ReadSet &rs, uint32_t r, bool negative, std::string &line) const;
+    const HostIndex &ix;
+    SamOptions opt;
+    FILE *out;
+    int gLogN[256];
+    uint64_t nRecords = 0;
+};
+
+}  // namespace s3host

@@ -1,0 +1,126 @@
+// soap3-dp -- drop-in command line for the alignment path (single-end so far), same arguments, .ini keys and index files as
+// the reference program (SOAP3-DP.cu main, IniParam.cpp:237-767), driving the MI355X kernels through the C-ABI of libs3dp.so.
+//
+//   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
+//
+// Output: <prefix>.gout.1 (SAM), <prefix>.done, like SOAP3-DP.cu:251-258 with NumOfCpuThreads = 1.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "s3_host.h"
+
+using namespace s3host;
+
+struct Ini {
+    unsigned maxOutputPerRead = 1000;
+    int minMAPQ = 1, maxMAPQ = 40, bwaLike = 0, maxLenReadName = 64;     // code defaults of IniParam.cpp:237-362
+};
+
+static void parseIni(const std::string &file, Ini &ini)
+{
+    FILE *f = fopen(file.c_str(), "r");
+    if (!f) return;
+    char line[1024];
+    while (fgets(line, sizeof line, f)) {
+        char key[256], val[256];
+        if (line[0] == '#' || line[0] == '[') continue;
+        if (sscanf(line, " %255[^= ] = %255s", key, val) != 2) continue;
+        if (!strcmp(key, "MaxOutputPerRead")) ini.maxOutputPerRead = (unsigned)strtoul(val, nullptr, 10);
+        else if (!strcmp(key, "MinMAPQ")) ini.minMAPQ = atoi(val);
+        else if (!strcmp(key, "MaxMAPQ")) ini.maxMAPQ = atoi(val);
+        else if (!strcmp(key, "BWALikeScore")) ini.bwaLike = atoi(val);
+        else if (!strcmp(key, "MaxLenReadName")) ini.maxLenReadName = atoi(val);
+    }
+    fclose(f);
+}
+
+static int die(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); return 1; }
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) return die("usage: soap3-dp single <index> <reads> [options]   (pair mode: not built yet)");
+    if (strcmp(argv[1], "single") != 0) return die("only 'single' is implemented in this build");
+    Ini ini;
+    parseIni(std::string(argv[0]) + ".ini", ini);
+    const std::string indexName = argv[2], queryFile = argv[3];
+    int maxReadLength = 120, numMismatch = -1, alignmentType = 2, outputFormat = 2, device = 0;   // DEFAULT_MAX_READ_LEN, all-best, SAM
+    bool enableDP = true;
+    std::string prefix = queryFile, readGroup, sampleName, readGrpOption;
+    bool printMDNM = false;
+    for (int i = 4; i < argc; i++) {
+        const std::string a = argv[i];
+        auto need = [&](const char *what) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "Please specify %s after '%s'\n", what, a.c_str()); exit(1); } return argv[++i]; };
+        if (a == "-L" || a == "-l") maxReadLength = atoi(need("the length"));
+        else if (a == "-h") alignmentType = atoi(need("the output option"));
+        else if (a == "-b") outputFormat = atoi(need("the output file format"));
+        else if (a == "-o") prefix = need("the output prefix");
+        else if (a == "-c") device = atoi(need("the GPU device ID"));
+        else if (a == "-D") readGroup = need("the read group");
+        else if (a == "-A") sampleName = need("the sample name");
+        else if (a == "-R") readGrpOption = need("the read group option");
+        else if (a == "-p") printMDNM = true;
+        else if (a == "-s") {
+            enableDP = false;
+            if (i + 1 < argc && argv[i + 1][0] >= '0' && argv[i + 1][0] <= '9') numMismatch = atoi(argv[++i]);
+        } else return die("unknown option " + a);
+    }
+    if (enableDP) return die("the DP stages are not built yet: run with -s <k>");
+    if (outputFormat != 2) return die("only SAM output (-b 2) is built");
+    if (alignmentType != 2) return die("only all-best (-h 2) is built");
+    if (maxReadLength > S3_MAX_READ_LENGTH) return die("The length should not be greater than 1024");
+    if (maxReadLength > 120) return die("long-read mode (reads > 120 bp) is not built yet");
+    if (readGroup.empty()) readGroup = queryFile;
+    if (sampleName.empty()) sampleName = "default";
+    std::string err;
+    HostIndex hix;
+    printf("[Main] loading index into host...\n");
+    if (!loadIndex(indexName, hix, err)) return die(err);
+    printf("[Main] Reference sequence length : %u\n", hix.n);
+    ReadSet rs;
+    if (!loadSingleReads(queryFile, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, err)) return die(err);
+    printf("[Main] Loaded %u short reads from the query file.\n", rs.n);
+    if (numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;          // getDefaultMismatchNum, CPUfunctions.cpp:26-35
+    s3_index *ix = nullptr;
+    s3_index_desc d = hix.desc();
+    if (s3_index_upload(device, &d, &ix) != S3_OK) return die(s3_last_error());
+    printf("[Main] Finished copying index into device (GPU).\n");
+    const std::string outName = prefix + ".gout.1";
+    FILE *out = fopen(outName.c_str(), "w");
+    if (!out) return die("Could not open the output file " + outName);
+    SamOptions so;
+    so.readGroup = readGroup; so.sampleName = sampleName; so.readGrpOption = readGrpOption; so.alignmentType = alignmentType;
+    so.minMAPQ = ini.minMAPQ; so.maxMAPQ = ini.maxMAPQ; so.bwaLikeScore = ini.bwaLike; so.printMDNM = printMDNM;
+    SamWriter sam(hix, so, out);
+    sam.header();
+    const uint32_t maxBatch = 1u << 22;
+    s3_batch *b = nullptr;
+    if (s3_batch_create(ix, rs.n < maxBatch ? (rs.n ? rs.n : 1) : maxBatch, rs.wpq, &b) != S3_OK) return die(s3_last_error());
+    uint64_t aligned = 0;
+    for (uint32_t first = 0; first < rs.n; first += maxBatch) {
+        const uint32_t cnt = rs.n - first < maxBatch ? rs.n - first : maxBatch;   // first is a multiple of 32
+        if (s3_batch_upload(b, rs.queries.data() + (size_t)first * rs.wpq, rs.lengths.data() + first, cnt) != S3_OK) return die(s3_last_error());
+        if (s3_batch_align_single_allbest(b, (uint32_t)numMismatch, ini.maxOutputPerRead) != S3_OK) return die(s3_last_error());
+        std::vector<uint8_t> phase(cnt);
+        std::vector<uint64_t> offs((size_t)cnt + 1);
+        uint64_t nOcc = 0;
+        if (s3_batch_fetch_alignments(b, phase.data(), nullptr, offs.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return die(s3_last_error());
+        std::vector<uint32_t> pos(nOcc ? nOcc : 1);
+        std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
+        if (s3_batch_fetch_alignments(b, nullptr, nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK) return die(s3_last_error());
+        for (uint32_t k = 0; k < cnt; k++) {
+            const size_t o = offs[k], m = offs[k + 1] - offs[k];
+            if (m) aligned++;
+            sam.singleEnd(rs, first + k, pos.data() + o, strand.data() + o, mis.data() + o, m);
+        }
+    }
+    fclose(out);
+    printf("[Main] Overall number of reads aligned: %llu\n", (unsigned long long)aligned);
+    printf("[Main] Overall number of unaligned reads: %llu\n", (unsigned long long)(rs.n - aligned));
+    s3_batch_free(b);
+    s3_index_free(ix);
+    FILE *done = fopen((prefix + ".done").c_str(), "w");
+    if (done) fclose(done);
+    return 0;
+}

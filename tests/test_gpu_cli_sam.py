@@ -1,0 +1,46 @@
+"""-m gpu: the drop-in `soap3-dp` command line (host C++ above the C-ABI) must write, read for read, the SAM records the
+reference's CPU path wrote (tests/golden/*/sam_s*.sam.gz, produced by oracle/_ref/ref_harness with the reference's own
+hostKernel + OCCOutputSAMAPI): position, strand, CIGAR, MAPQ, X0/X1/XM and the XA:Z list."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
+
+
+def sam_records(text):
+    hdr, rec = [], {}
+    for l in text.split("\n"):
+        if not l:
+            continue
+        if l.startswith("@"):
+            if not l.startswith("@PG"):
+                hdr.append(l)
+        else:
+            rec[l.split("\t", 1)[0]] = l
+    return hdr, rec
+
+
+@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
+@pytest.mark.parametrize("s", [2, 4])
+def test_cli_sam_matches_reference_cpu_path(tmp_path, name, maxlen, s):
+    assert os.path.exists(BIN), "soap3-dp binary not built"
+    fq = tmp_path / (name + ".fq")                      # the read-group id is the query file name as typed
+    shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), fq)
+    out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", str(maxlen), "-s", str(s), "-b", "2",
+                          "-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    mine_h, mine = sam_records(open(tmp_path / "out.gout.1").read())
+    ref_h, ref = sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_s%d.sam.gz" % s), "rt").read())
+    assert mine_h == ref_h
+    assert set(mine) == set(ref)
+    bad = [(k, ref[k], mine[k]) for k in ref if ref[k] != mine[k]]
+    assert not bad, "first differing record:\n%s\n%s" % (bad[0][1], bad[0][2])
+    assert os.path.exists(tmp_path / "out.done")
