@@ -127,6 +127,29 @@ void s3_free(void *p);
  * writes one text line per case in the same form as the reference dump used by the oracle harness. */
 int  s3_model_describe(int readLength, int maxError, char *buf, size_t bufLen);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Semi-global affine-gap DP extension -- replaces SemiGlobalAligner::{decideConfiguration,init,performAlignment,freeMemory}
+ * (DV-DPfunctions.h:120-164, DV-DPfunctions.cu:538-741) and its kernels SemiGlobalAligntment / GPUBacktrack (:243-512).
+ * Sequences use the reference's packing (DV-DPfunctions.cu:57-59): 1-based characters, 16 per word with the first one in
+ * the most significant bits, word w of problem t at (t/32)*(ceil(maxLen/16)*32) + t%32 + 32*w.  Arrays are host pointers. */
+typedef struct s3_dp s3_dp;
+typedef struct { int matchScore, mismatchScore, gapOpenScore, gapExtendScore; } s3_dp_scores;
+
+/* decideConfiguration (:538-619): with 288 GB of HBM the full table (scheme 1, maxDPTableLength = maxDNALength) always
+ * fits; scheme 2 (score pass + window of L + L/2 + 8 columns) is kept because its results differ and a caller may ask for it. */
+int  s3_dp_config(int maxReadLength, int maxDNALength, int wantScheme, int *scheme, int *maxDPTableLength, int *patternLength);
+int  s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLength, uint32_t maxDNALength, uint32_t maxDPTableLength,
+                  int scheme, const s3_dp_scores *sc, s3_dp **out);
+/* performAlignment (:669-721).  clipRt is in/out (the kernel overwrites it with the actual right clip, :308-309); scores,
+ * hitLocs (alignment START column when score >= cutoff), maxScoreCounts and pattern (patternLength bytes per problem:
+ * reversed op string of M m D I S and V<n> run markers, 0-terminated) are outputs.  clipLt/clipRt/anchor arrays may be NULL. */
+int  s3_dp_align(s3_dp *h, const uint32_t *packedDNA, const uint32_t *DNALengths, const uint32_t *packedReads, const uint32_t *readLengths,
+                 const int32_t *cutoffThresholds, uint32_t nProblems,
+                 const uint32_t *clipLtSizes, uint32_t *clipRtSizes, const uint32_t *anchorLeftLocs, const uint32_t *anchorRightLocs,
+                 int32_t *scores, uint32_t *hitLocs, uint32_t *maxScoreCounts, uint8_t *pattern);
+int  s3_dp_last_timing(s3_dp *h, float *ms);      /* device time of the last s3_dp_align (fill + backtrack), HIP events */
+void s3_dp_free(s3_dp *h);
+
 /* measurement aid, not part of the alignment path: rate of random 64-byte-line gathers on this device
  * (the practical ceiling of a rank-query stream).  Reports the average kernel time and lines read per launch. */
 int  s3_probe_gather(int device, size_t tableBytes, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,

@@ -652,3 +652,142 @@ extern "C" int s3_probe_gather(int device, size_t tableBytes, uint32_t blocks, u
     (void)hipFree(table); (void)hipFree(sink);
     return S3_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// semi-global DP
+// ---------------------------------------------------------------------------------------------
+struct s3_dp {
+    int dev = 0, scheme = 1;
+    uint32_t maxProblems = 0, maxRead = 0, maxDNA = 0, maxTable = 0, patternLen = 0;
+    s3_dp_scores sc{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<void *> allocs;
+    uint32_t *dDna = nullptr, *dReads = nullptr, *dDnaLen = nullptr, *dReadLen = nullptr, *dClipLt = nullptr, *dClipRt = nullptr, *dAL = nullptr, *dAR = nullptr;
+    int32_t *dCut = nullptr, *dScores = nullptr;
+    uint32_t *dHit = nullptr, *dStart = nullptr, *dCnt = nullptr, *dCols = nullptr, *dTable = nullptr;
+    unsigned char *dPattern = nullptr;
+    size_t tableWords = 0;
+    bool timed = false;
+};
+
+extern "C" int s3_dp_config(int maxReadLength, int maxDNALength, int wantScheme, int *scheme, int *maxDPTableLength, int *patternLength)
+{
+    if (maxReadLength < 1 || maxDNALength < 1) return fail(S3_EINVAL, "s3_dp_config: bad lengths");
+    int sch = wantScheme == 2 ? 2 : 1;
+    int tab = sch == 1 ? maxDNALength : maxReadLength + maxReadLength / 2 + 8;      // DP_Effective_Region (:574)
+    if (sch == 2 && tab > maxDNALength) { sch = 1; tab = maxDNALength; }
+    if (scheme) *scheme = sch;
+    if (maxDPTableLength) *maxDPTableLength = tab;
+    if (patternLength) *patternLength = maxReadLength + tab;
+    return S3_OK;
+}
+
+extern "C" void s3_dp_free(s3_dp *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->dev);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    for (auto e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+template <class T>
+static int dalloc(s3_dp *h, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
+    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp): ") + hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return S3_OK;
+}
+
+extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLength, uint32_t maxDNALength, uint32_t maxDPTableLength, int scheme,
+                            const s3_dp_scores *sc, s3_dp **outp)
+{
+    if (!sc || !outp || !maxProblems || !maxReadLength || !maxDNALength || !maxDPTableLength) return fail(S3_EINVAL, "s3_dp_create: bad argument");
+    if (maxReadLength > 4096 || maxDNALength > 16384) return fail(S3_EINVAL, "s3_dp_create: lengths too large");
+    if (scheme == 1 && maxDPTableLength < maxDNALength) return fail(S3_EINVAL, "s3_dp_create: scheme 1 needs maxDPTableLength >= maxDNALength");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(S3_ENODEV, "no HIP device available (libs3dp has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(S3_EINVAL, "bad device ordinal");
+    HIPCHK(hipSetDevice(device));
+    s3_dp *h = new s3_dp();
+    h->dev = device; h->scheme = scheme == 2 ? 2 : 1; h->maxProblems = maxProblems; h->maxRead = maxReadLength; h->maxDNA = maxDNALength;
+    h->maxTable = maxDPTableLength; h->patternLen = maxReadLength + maxDPTableLength; h->sc = *sc;
+    const size_t rnd = ((size_t)maxProblems + 31) / 32 * 32;
+    const size_t dnaW = rnd * ((maxDNALength + 15) / 16), rdW = rnd * ((maxReadLength + 15) / 16);
+    h->tableWords = (size_t)((maxReadLength + 63) / 64) * (maxDPTableLength + 64) * 64;
+    int rc;
+#define DA(p, c) if ((rc = dalloc(h, &h->p, (c)))) { s3_dp_free(h); return rc; }
+    DA(dDna, dnaW); DA(dReads, rdW); DA(dDnaLen, rnd); DA(dReadLen, rnd); DA(dClipLt, rnd); DA(dClipRt, rnd); DA(dAL, rnd); DA(dAR, rnd);
+    DA(dCut, rnd); DA(dScores, rnd); DA(dHit, rnd); DA(dStart, rnd); DA(dCnt, rnd); DA(dCols, rnd);
+    DA(dPattern, (size_t)maxProblems * h->patternLen);
+    DA(dTable, h->tableWords * maxProblems);
+#undef DA
+    HIPCHK(hipStreamCreate(&h->stream));
+    HIPCHK(hipEventCreate(&h->ev[0])); HIPCHK(hipEventCreate(&h->ev[1]));
+    *outp = h;
+    return S3_OK;
+}
+
+extern "C" int s3_dp_align(s3_dp *h, const uint32_t *packedDNA, const uint32_t *DNALengths, const uint32_t *packedReads, const uint32_t *readLengths,
+                           const int32_t *cutoffThresholds, uint32_t n, const uint32_t *clipLtSizes, uint32_t *clipRtSizes,
+                           const uint32_t *anchorLeftLocs, const uint32_t *anchorRightLocs, int32_t *scores, uint32_t *hitLocs,
+                           uint32_t *maxScoreCounts, uint8_t *pattern)
+{
+    if (!h || !packedDNA || !DNALengths || !packedReads || !readLengths || !cutoffThresholds || !scores || !hitLocs || !maxScoreCounts || !pattern)
+        return fail(S3_EINVAL, "s3_dp_align: null argument");
+    if (n > h->maxProblems) return fail(S3_EINVAL, "s3_dp_align: too many problems for this aligner");
+    for (uint32_t t = 0; t < n; t++) {
+        if (readLengths[t] < 1 || readLengths[t] > h->maxRead) return fail(S3_EINVAL, "s3_dp_align: read length out of range");
+        if (DNALengths[t] < 1 || DNALengths[t] > h->maxDNA) return fail(S3_EINVAL, "s3_dp_align: DNA length out of range");
+        if (clipRtSizes && clipRtSizes[t] > readLengths[t]) return fail(S3_EINVAL, "s3_dp_align: clipRt larger than the read");
+    }
+    HIPCHK(hipSetDevice(h->dev));
+    const size_t rnd = ((size_t)n + 31) / 32 * 32;
+    const size_t dnaW = rnd * ((h->maxDNA + 15) / 16), rdW = rnd * ((h->maxRead + 15) / 16);
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->dDna, packedDNA, dnaW * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dReads, packedReads, rdW * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dDnaLen, DNALengths, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dReadLen, readLengths, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dCut, cutoffThresholds, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (clipLtSizes) HIPCHK(hipMemcpyAsync(h->dClipLt, clipLtSizes, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (clipRtSizes) HIPCHK(hipMemcpyAsync(h->dClipRt, clipRtSizes, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (anchorLeftLocs) HIPCHK(hipMemcpyAsync(h->dAL, anchorLeftLocs, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (anchorRightLocs) HIPCHK(hipMemcpyAsync(h->dAR, anchorRightLocs, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    DpArgs a{};
+    a.dna = h->dDna; a.dnaLengths = h->dDnaLen; a.reads = h->dReads; a.readLengths = h->dReadLen;
+    a.clipLt = clipLtSizes ? h->dClipLt : nullptr; a.clipRt = clipRtSizes ? h->dClipRt : nullptr;
+    a.anchorLeft = anchorLeftLocs ? h->dAL : nullptr; a.anchorRight = anchorRightLocs ? h->dAR : nullptr;
+    a.cutoffs = h->dCut; a.scores = h->dScores; a.hitLocs = h->dHit; a.startOffsets = h->dStart; a.maxScoreCounts = h->dCnt; a.tableCols = h->dCols;
+    a.pattern = h->dPattern; a.table = h->dTable; a.tableWordsPerProblem = h->tableWords;
+    a.n = n; a.maxDNALength = h->maxDNA; a.maxReadLength = h->maxRead; a.maxDPTableLength = h->maxTable; a.patternLen = h->patternLen;
+    a.ldsPerWave = (((h->maxDNA + 1u + 15u) & ~15u) + (h->maxDNA + 1u) * 12u + 15u) & ~15u;
+    a.match = h->sc.matchScore; a.mismatch = h->sc.mismatchScore; a.gapOpen = h->sc.gapOpenScore; a.gapExtend = h->sc.gapExtendScore; a.scheme = h->scheme;
+    if ((size_t)a.ldsPerWave * 4 > 160 * 1024) return fail(S3_EINVAL, "s3_dp_align: maxDNALength too large for the LDS-resident window");
+    HIPCHK(hipEventRecord(h->ev[0], s));
+    launchDp(a, s);
+    HIPCHK(hipEventRecord(h->ev[1], s));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(scores, h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hitLocs, h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(maxScoreCounts, h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pattern, h->dPattern, (size_t)n * h->patternLen, hipMemcpyDeviceToHost, s));
+    if (clipRtSizes) HIPCHK(hipMemcpyAsync(clipRtSizes, h->dClipRt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->timed = true;
+    return S3_OK;
+}
+
+extern "C" int s3_dp_last_timing(s3_dp *h, float *ms)
+{
+    if (!h || !h->timed || !ms) return fail(S3_EINVAL, "no timed DP call");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipEventElapsedTime(ms, h->ev[0], h->ev[1]));
+    return S3_OK;
+}

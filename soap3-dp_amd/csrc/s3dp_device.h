@@ -66,6 +66,22 @@ struct MergeArgs {
     uint8_t         decodeWant;
 };
 
+// semi-global DP (s3dp_dp.hip)
+struct DpArgs {
+    const uint32_t *dna, *dnaLengths, *reads, *readLengths;     // reference layouts (1-based, MSB first, 32-interleaved)
+    const uint32_t *clipLt, *anchorLeft, *anchorRight;            // optional
+    uint32_t       *clipRt;                                       // optional, in/out
+    const int32_t  *cutoffs;
+    int32_t        *scores;
+    uint32_t       *hitLocs, *startOffsets, *maxScoreCounts, *tableCols;
+    unsigned char  *pattern;
+    uint32_t       *table;                                        // per problem: chunks x (maxDPTableLength + 64) x 64 dwords (H | E << 16)
+    size_t          tableWordsPerProblem;
+    uint32_t        n, maxDNALength, maxReadLength, maxDPTableLength, patternLen, ldsPerWave;
+    int             match, mismatch, gapOpen, gapExtend, scheme;
+};
+void launchDp(const DpArgs &a, hipStream_t s);
+
 void launchTransposeReads(const uint32_t *queries, uint32_t *readsT, uint32_t n, uint32_t wpq, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
 void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);

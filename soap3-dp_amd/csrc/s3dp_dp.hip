@@ -1,0 +1,236 @@
+// s3dp_dp.hip -- semi-global affine-gap DP for gfx950: anti-diagonal wavefront, one problem per 64-lane wavefront.
+//
+// What is computed is the reference's DP (DV-DPfunctions.cu:61-512: DPScoreNHitPos, GenerateDPTable, the scheme-1/2
+// driver SemiGlobalAligntment, GPUBacktrack), cell for cell: int running values inside a column, every stored cell
+// clamped to int16 >= -32000, free left-clip re-seeding, anchors, first maximum in (column, row) order with a tie
+// count, and the value-comparing traceback with its fixed priority.  How it is computed is different:
+//   * the reference gives one CUDA thread a whole problem and keeps two short tables in global memory that the same
+//     thread reads back (8 B of table traffic per cell, 97 k serial cells per thread for a 150 x 650 problem);
+//   * here a wavefront sweeps the table by anti-diagonals: lane k owns read row 64c+1+k of the current 64-row chunk,
+//     at step t it computes column t-k; H[j][i-1], the running insertion score and the diagonal travel to the next
+//     lane by a one-lane shuffle; the previous column's H/E stay in the lane's registers; chunk-to-chunk boundary rows
+//     and the window characters live in LDS; the reference window and read are read once;
+//   * the tables needed by the traceback are written as ONE coalesced 256-B store per wave step (H and E packed in one
+//     dword per cell, anti-diagonal-major), never re-read by the fill;
+//   * the maximum is tracked order-independently (max score, then smallest (column,row), plus tie count) and reduced
+//     across the wave, which equals the reference's strictly-greater update in (column outer, row inner) order.
+// Bound: integer VALU / LDS (about one wave instruction per cell); HBM traffic is 4 B written per cell.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "s3dp_device.h"
+
+namespace s3 {
+
+namespace dp {
+
+constexpr int NEG_INF = -32000;
+__device__ __forceinline__ int clampS(int x) { return x > NEG_INF ? x : NEG_INF; }
+
+// the reference's packed sequences: 1-based, 16 chars per word MSB first, words of problem t interleaved by 32 (:57-59)
+__device__ __forceinline__ uint32_t seqChar(const uint32_t *packed, uint32_t t, uint32_t maxLen, uint32_t i)
+{
+    const uint32_t base = (t >> 5) * (((maxLen + 15u) >> 4) << 5) + (t & 31u);
+    return (packed[base + ((i >> 4) << 5)] >> ((15u - (i & 15u)) << 1)) & 3u;
+}
+
+struct Best { int score; uint32_t key; uint32_t count; };       // key = column << 16 | row  (smaller = earlier in the reference's order)
+
+__device__ __forceinline__ void bestMerge(Best &a, int score, uint32_t key, uint32_t count)
+{
+    if (score > a.score) { a.score = score; a.key = key; a.count = count; }
+    else if (score == a.score) { a.count += count; a.key = key < a.key ? key : a.key; }
+}
+
+// one sweep over W columns (starting after refOffset) of problem p by the calling wavefront
+template <bool TABLE>
+__device__ void sweep(const DpArgs &a, uint32_t p, uint32_t W, uint32_t L, uint32_t refOffset, int clipLt, int clipRtLoc, uint32_t aL, uint32_t aR,
+                      unsigned char *refLds, int *bnd, uint32_t *table, uint32_t T, Best &best)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const int go = a.gapOpen, ge = a.gapExtend, gi = go - ge;
+    for (uint32_t j = lane; j <= W; j += 64u) refLds[j] = j ? (unsigned char)seqChar(a.dna, p, a.maxDNALength, j + refOffset) : 0;
+    // row 0 boundary: H[j][0] = init(j), running open = init + gi, diagonal for row 1 = init(j-1)
+    for (uint32_t j = lane; j <= W; j += 64u) {
+        const int init = (j + refOffset >= aL) ? NEG_INF : 0;
+        const int prevInit = (j <= 1) ? 0 : ((j - 1 + refOffset >= aL) ? NEG_INF : 0);
+        bnd[3 * j] = init; bnd[3 * j + 1] = init + gi; bnd[3 * j + 2] = prevInit;
+    }
+    __builtin_amdgcn_wave_barrier();
+    best.score = NEG_INF; best.key = 0xFFFFFFFFu; best.count = 0;
+    const uint32_t chunks = (L + 63u) >> 6;
+    for (uint32_t c = 0; c < chunks; c++) {
+        const uint32_t i = (c << 6) + 1u + lane;                      // this lane's read row
+        const bool rowOk = i <= L;
+        const uint32_t rc = rowOk ? seqChar(a.reads, p, a.maxReadLength, i) : 0u;
+        // column 0 of this row (:165-183)
+        int hPrev, ePrev;
+        if ((int)i <= clipLt) { hPrev = clampS(go); ePrev = clampS(go + gi); }
+        else { const int up0 = gi + ge * ((int)i - (clipLt > 0 ? clipLt : 0)); hPrev = clampS(up0); ePrev = clampS(up0 + gi); }
+        int upIn = 0, fIn = 0, dgIn = 0;                               // what lane-1 produced in the previous step
+        const uint32_t steps = W + 63u;
+        for (uint32_t t = 1; t <= steps; t++) {
+            // values handed down from the row above: lane 0 reads the boundary row, the others shuffle
+            int upS = __shfl_up(upIn, 1), fS = __shfl_up(fIn, 1), dgS = __shfl_up(dgIn, 1);
+            const int j = (int)t - (int)lane;
+            const bool act = rowOk && j >= 1 && j <= (int)W;
+            if (lane == 0 && act) { upS = bnd[3 * j]; fS = bnd[3 * j + 1]; dgS = bnd[3 * j + 2]; }
+            int upOut = 0, fOut = 0, dgOut = 0;
+            if (act) {
+                const int init = ((uint32_t)j + refOffset >= aL) ? NEG_INF : 0;
+                const int prevInit = (j <= 1) ? 0 : (((uint32_t)j - 1u + refOffset >= aL) ? NEG_INF : 0);
+                const int prevR = hPrev;
+                int gapped = max(go + prevR, ge + ePrev);
+                const int eSt = clampS(gapped);
+                int f = max(ge + fS, go + upS);
+                gapped = max(f, gapped);
+                const int up = max(gapped, dgS + ((uint32_t)refLds[j] == rc ? a.match : a.mismatch));
+                const int hSt = clampS(up);
+                hPrev = hSt; ePrev = eSt;
+                int dg = prevR;
+                if ((int)i <= clipLt) { f = max(init + gi, f); dg = max(prevInit, dg); }
+                upOut = up; fOut = f; dgOut = dg;
+                if (TABLE) table[((size_t)c * T + t) * 64u + lane] = ((uint32_t)(uint16_t)(int16_t)hSt) | ((uint32_t)(uint16_t)(int16_t)eSt << 16);
+                if ((int)i >= clipRtLoc && (uint32_t)j + refOffset >= aR) bestMerge(best, up, ((uint32_t)j << 16) | i, 1u);
+                if (lane == 63u || i == L) { /* last row of the chunk: becomes the boundary of the next chunk */ }
+            }
+            // the boundary row for the next chunk is the chunk's last lane (row 64c+64); written after lane 0 consumed column j
+            if (lane == 63u && act) { bnd[3 * j] = upOut; bnd[3 * j + 1] = fOut; bnd[3 * j + 2] = dgOut; }
+            upIn = upOut; fIn = fOut; dgIn = dgOut;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // wave reduction: max score, then smallest key, summed count of the maxima
+    for (int off = 32; off > 0; off >>= 1) {
+        const int s2 = __shfl_xor(best.score, off);
+        const uint32_t k2 = (uint32_t)__shfl_xor((int)best.key, off), c2 = (uint32_t)__shfl_xor((int)best.count, off);
+        bestMerge(best, s2, k2, c2);
+    }
+}
+
+}  // namespace dp
+
+using namespace dp;
+
+// SemiGlobalAligntment (:243-314): scheme 1 = one table sweep; scheme 2 = score-only sweep, then a windowed table sweep
+__global__ void __launch_bounds__(256) dpFillKernel(DpArgs a)
+{
+    extern __shared__ __align__(16) unsigned char sh[];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t p = blockIdx.x * 4u + wv;
+    if (p >= a.n) return;
+    const uint32_t perWave = a.ldsPerWave;
+    unsigned char *refLds = sh + wv * perWave;
+    int *bnd = (int *)(sh + wv * perWave + ((a.maxDNALength + 1u + 15u) & ~15u));
+    const uint32_t clipLt = a.clipLt ? a.clipLt[p] : 0u, clipRt = a.clipRt ? a.clipRt[p] : 0u;
+    const uint32_t aL = a.anchorLeft ? a.anchorLeft[p] : a.maxDNALength, aR = a.anchorRight ? a.anchorRight[p] : 0u;
+    const uint32_t L = a.readLengths[p];
+    uint32_t W = a.dnaLengths[p], refOffset = 0;
+    Best best;
+    if (a.scheme == 2) {
+        sweep<false>(a, p, W, L, 0u, (int)clipLt, (int)(L - clipRt), aL, aR, refLds, bnd, nullptr, 0u, best);
+        // a maximum that never rose above the initial -32000 leaves hitPos at 0 in the reference (strict > update, :131-138)
+        const uint32_t hitPos = (best.count && best.score > NEG_INF) ? best.key >> 16 : 0u;
+        if (W > a.maxDPTableLength - 1u) W = a.maxDPTableLength - 1u;
+        if (hitPos > W) {
+            refOffset = hitPos - W;
+            if (refOffset >= aL) refOffset = aL > 0 ? aL - 1u : 0u;
+        }
+    }
+    const uint32_t T = a.maxDPTableLength + 64u;
+    uint32_t *table = a.table + (size_t)p * a.tableWordsPerProblem;
+    sweep<true>(a, p, W, L, refOffset, (int)clipLt, (int)(L - clipRt), aL, aR, refLds, bnd, table, T, best);
+    if (lane == 0) {
+        const bool found = best.count && best.score > NEG_INF;     // ties with the initial -32000 only count (:228-236)
+        const uint32_t hitPos = found ? best.key >> 16 : 0u, row = found ? best.key & 0xFFFFu : 0u;
+        a.startOffsets[p] = refOffset;
+        a.hitLocs[p] = hitPos;
+        a.scores[p] = best.score;
+        a.maxScoreCounts[p] = best.count;
+        a.tableCols[p] = W;
+        if (a.clipRt) a.clipRt[p] = found ? L - row : 0u;
+    }
+}
+
+// GPUBacktrack (:316-512): serial walk, one lane per problem, over the tables written by dpFillKernel
+__global__ void dpBacktrackKernel(DpArgs a)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    unsigned char *pat = a.pattern + (size_t)p * a.patternLen;
+    pat[0] = 0;
+    if (a.scores[p] < a.cutoffs[p]) return;
+    const int go = a.gapOpen, ge = a.gapExtend, gi = go - ge;
+    const uint32_t T = a.maxDPTableLength + 64u;
+    const uint32_t *table = a.table + (size_t)p * a.tableWordsPerProblem;
+    const uint32_t L = a.readLengths[p], refOffset = a.startOffsets[p];
+    const uint32_t aL = a.anchorLeft ? a.anchorLeft[p] : a.maxDNALength;
+    const uint32_t cl = a.clipLt ? a.clipLt[p] : 0u, clipRtLen = a.clipRt ? a.clipRt[p] : 0u;
+    uint32_t pi = 0;
+    auto app = [&](uint32_t x) { if (pi < a.patternLen) pat[pi] = (unsigned char)x; ++pi; };
+    auto cell = [&](uint32_t j, uint32_t i, bool wantE) -> int {
+        if (j == 0) {                                               // column 0 (:165-183)
+            int up0;
+            if (i == 0) up0 = wantE ? gi : 0;
+            else if (i <= cl) up0 = wantE ? go + gi : go;
+            else { up0 = gi + ge * (int)(i - cl); if (wantE) up0 += gi; }
+            return clampS(up0);
+        }
+        if (i == 0) {                                               // row 0 (:192-198)
+            const int init = (j + refOffset >= aL) ? NEG_INF : 0;
+            return clampS(wantE ? init + gi : init);
+        }
+        const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
+        const uint32_t w = table[((size_t)c * T + (j + k)) * 64u + k];
+        return (int)(int16_t)(wantE ? (w >> 16) : (w & 0xFFFFu));
+    };
+    if (clipRtLen > 0) { app('S'); app('V'); app(clipRtLen); }
+    uint32_t readPos = L - clipRtLen, refIndex = a.hitLocs[p];
+    uint32_t readChar = seqChar(a.reads, p, a.maxReadLength, readPos), refChar = seqChar(a.dna, p, a.maxDNALength, refOffset + refIndex);
+    int16_t cur = (int16_t)cell(refIndex, readPos, false), next = 0;
+    int16_t init = (refOffset + refIndex >= aL) ? NEG_INF : 0, prevInit = (refOffset + refIndex > aL) ? NEG_INF : 0;
+    enum { NORMAL, I_EXT, D_EXT, SM_EXIT, SI_EXIT } state = NORMAL;
+    auto nextRef = [&]() { --refIndex; refChar = seqChar(a.dna, p, a.maxDNALength, refOffset + refIndex); init = prevInit; prevInit = (refOffset + refIndex > aL) ? NEG_INF : 0; };
+    auto nextRead = [&]() { --readPos; readChar = seqChar(a.reads, p, a.maxReadLength, readPos); };
+    auto dist = [&]() -> int { return refChar == readChar ? a.match : a.mismatch; };
+    while (readPos > 0 && refIndex > 0) {
+        if (state == NORMAL) {
+            if (cur == dist() + (next = (int16_t)cell(refIndex - 1, readPos - 1, false))) { app('m' - ((refChar == readChar) << 5)); nextRef(); nextRead(); cur = next; }
+            else if (cur == go + (next = (int16_t)cell(refIndex - 1, readPos, false))) { app('D'); nextRef(); cur = next; }
+            else if (cur == ge + cell(refIndex - 1, readPos, true)) { app('D'); nextRef(); cur = (int16_t)(cur - ge); state = D_EXT; }
+            else {
+                if (readPos <= cl + 1u) {
+                    if (cur == prevInit + dist()) { state = SM_EXIT; break; }
+                    else if (cur == init + go) { state = SI_EXIT; break; }
+                }
+                if (cur == go + (next = (int16_t)cell(refIndex, readPos - 1, false))) { app('I'); nextRead(); cur = next; }
+                else { app('I'); nextRead(); cur = (int16_t)(cur - ge); state = I_EXT; }
+            }
+        } else {
+            if (state == D_EXT) { app('D'); nextRef(); }
+            else {
+                if (readPos <= cl + 1u && cur == init + go) { state = SI_EXIT; break; }
+                app('I'); nextRead();
+            }
+            if (cur == go + (next = (int16_t)cell(refIndex, readPos, false))) { state = NORMAL; cur = next; }
+            else cur = (int16_t)(cur - ge);
+        }
+    }
+    if (refIndex == 0) {
+        const uint32_t scNum = cl < readPos ? cl : readPos;
+        if (scNum < readPos) { app('I'); app('V'); app(readPos - scNum); }
+        app('S'); app('V'); app(scNum);
+    } else if (state == SI_EXIT) { app('I'); app('S'); app('V'); app(readPos - 1u); }
+    else if (state == SM_EXIT) { app('m' - ((refChar == readChar) << 5)); app('S'); app('V'); app(readPos - 1u); refIndex -= 1u; }
+    app(0);
+    a.hitLocs[p] = refOffset + refIndex;
+}
+
+void launchDp(const DpArgs &a, hipStream_t s)
+{
+    if (!a.n) return;
+    const size_t lds = (size_t)a.ldsPerWave * 4u;
+    hipLaunchKernelGGL(dpFillKernel, dim3((a.n + 3u) / 4u), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(dpBacktrackKernel, dim3((a.n + 63u) / 64u), dim3(64), 0, s, a);
+}
+
+}  // namespace s3

@@ -328,3 +328,88 @@ def pack_reads(reads, max_read_length):
         lens[i] = len(r)
     q, lens = pack_codes(codes, lens, wpq)
     return q, lens, wpq
+
+
+# ------------------------------------------------------------------------------------------------
+# semi-global DP (s3_dp_* of the C-ABI)
+# ------------------------------------------------------------------------------------------------
+class DpScores(C.Structure):
+    _fields_ = [("matchScore", C.c_int), ("mismatchScore", C.c_int), ("gapOpenScore", C.c_int), ("gapExtendScore", C.c_int)]
+
+
+EXPORTS += ["s3_dp_config", "s3_dp_create", "s3_dp_align", "s3_dp_last_timing", "s3_dp_free"]
+
+
+def pack_dp_sequences(seqs, max_len):
+    """list of uint8 code arrays -> the reference DP packing: 1-based characters, 16 per word, first in the top bits,
+    word w of problem t at (t//32)*(ceil(max_len/16)*32) + t%32 + 32*w   (DV-DPfunctions.cu:57-59, packers :2111-2167)"""
+    n = len(seqs)
+    wps = (max_len + 15) // 16
+    rnd = (n + 31) // 32 * 32
+    out = np.zeros(rnd * wps, dtype=np.uint32)
+    for t, s in enumerate(seqs):
+        L = len(s)
+        buf = np.zeros(wps * 16, dtype=np.uint32)
+        buf[1:L + 1] = s[:wps * 16 - 1]
+        sh = (2 * (15 - np.arange(16, dtype=np.uint32))).astype(np.uint32)
+        words = (buf.reshape(wps, 16) << sh).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+        base = (t // 32) * (wps * 32) + t % 32
+        out[base + 32 * np.arange(wps)] = words
+    return out
+
+
+def dp_config(max_read, max_dna, want_scheme=1):
+    f = lib().s3_dp_config
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    sch, tab, pat = C.c_int(), C.c_int(), C.c_int()
+    _chk(f(max_read, max_dna, want_scheme, C.byref(sch), C.byref(tab), C.byref(pat)))
+    return sch.value, tab.value, pat.value
+
+
+class DpAligner:
+    def __init__(self, max_problems, max_read, max_dna, scheme=1, scores=(1, -2, -3, -1), device=0):
+        self.scheme, self.max_table, self.pattern_len = dp_config(max_read, max_dna, scheme)
+        self.max_read, self.max_dna, self.max_problems = max_read, max_dna, max_problems
+        self.h = C.c_void_p()
+        sc = DpScores(*scores)
+        f = lib().s3_dp_create
+        f.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(DpScores), C.POINTER(C.c_void_p)]
+        _chk(f(device, max_problems, max_read, max_dna, self.max_table, self.scheme, C.byref(sc), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            f = lib().s3_dp_free
+            f.argtypes = [C.c_void_p]
+            f(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def align(self, packed_dna, dna_lengths, packed_reads, read_lengths, cutoffs, clip_lt=None, clip_rt=None, anchor_lt=None, anchor_rt=None):
+        n = len(read_lengths)
+        u32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
+        packed_dna, dna_lengths, packed_reads, read_lengths = u32(packed_dna), u32(dna_lengths), u32(packed_reads), u32(read_lengths)
+        clip_lt, anchor_lt, anchor_rt = u32(clip_lt), u32(anchor_lt), u32(anchor_rt)
+        clip_rt = None if clip_rt is None else np.array(clip_rt, dtype=np.uint32)
+        cutoffs = np.ascontiguousarray(cutoffs, dtype=np.int32)
+        scores = np.zeros(n, dtype=np.int32)
+        hit = np.zeros(n, dtype=np.uint32)
+        cnt = np.zeros(n, dtype=np.uint32)
+        pat = np.zeros((n, self.pattern_len), dtype=np.uint8)
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        f = lib().s3_dp_align
+        f.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint32] + [C.c_void_p] * 8
+        _chk(f(self.h, p(packed_dna), p(dna_lengths), p(packed_reads), p(read_lengths), p(cutoffs), n, p(clip_lt), p(clip_rt), p(anchor_lt),
+               p(anchor_rt), p(scores), p(hit), p(cnt), p(pat)))
+        return scores, hit, cnt, pat, clip_rt
+
+    def timing(self):
+        ms = C.c_float()
+        f = lib().s3_dp_last_timing
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        _chk(f(self.h, C.byref(ms)))
+        return ms.value

@@ -10,8 +10,9 @@ LIB = os.path.join(ROOT, "oracle", "libs3oracle.so")
 
 def build(force=False):
     src = os.path.join(ROOT, "oracle", "s3_oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", LIB, src])
+    src2 = os.path.join(ROOT, "oracle", "s3_oracle_dp.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(src2)):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", LIB, src, os.path.join(ROOT, "oracle", "s3_oracle_dp.c")])
     return LIB
 
 
@@ -214,3 +215,54 @@ def read_fastq(path):
         else:
             i += 1
     return out
+
+
+# ---- DP oracle (oracle/s3_oracle_dp.c; PARITY UNPINNED, see its header) ----
+class DpScoresO(C.Structure):
+    _fields_ = [("match", C.c_int), ("mismatch", C.c_int), ("gapOpen", C.c_int), ("gapExtend", C.c_int)]
+
+
+def dp_align(packed_dna, dna_lengths, max_dna, max_table, packed_reads, read_lengths, max_read, cutoffs, scheme=1, scores=(1, -2, -3, -1),
+             clip_lt=None, clip_rt=None, anchor_lt=None, anchor_rt=None):
+    n = len(read_lengths)
+    u32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
+    packed_dna, dna_lengths, packed_reads, read_lengths = u32(packed_dna), u32(dna_lengths), u32(packed_reads), u32(read_lengths)
+    clip_lt, anchor_lt, anchor_rt = u32(clip_lt), u32(anchor_lt), u32(anchor_rt)
+    clip_rt = None if clip_rt is None else np.array(clip_rt, dtype=np.uint32)
+    cutoffs = np.ascontiguousarray(cutoffs, dtype=np.int32)
+    pat_len = max_read + max_table
+    sc = np.zeros(n, dtype=np.int32)
+    hit = np.zeros(n, dtype=np.uint32)
+    start = np.zeros(n, dtype=np.uint32)
+    cnt = np.zeros(n, dtype=np.uint32)
+    pat = np.zeros((n, pat_len), dtype=np.uint8)
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    f = lib().s3o_dp_align
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.POINTER(DpScoresO), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
+    s = DpScoresO(*scores)
+    f(p(packed_dna), p(dna_lengths), max_dna, max_table, p(packed_reads), p(read_lengths), max_read, n, p(clip_lt), p(clip_rt), p(anchor_lt), p(anchor_rt),
+      C.byref(s), p(cutoffs), scheme, p(sc), p(hit), p(start), p(cnt), p(pat), pat_len)
+    return sc, hit, cnt, pat, clip_rt, start
+
+
+def dp_pattern_ops(pat_row):
+    """decode the reversed op string (M m D I S + V<n> run markers) into a forward list of (op, count)"""
+    ops = []
+    k = 0
+    raw = []
+    while k < len(pat_row) and pat_row[k] != 0:
+        ch = chr(pat_row[k])
+        if k + 2 < len(pat_row) + 1 and k + 1 < len(pat_row) and chr(pat_row[k + 1]) == 'V' and ch in "SI":
+            raw.append((ch, int(pat_row[k + 2])))
+            k += 3
+        else:
+            raw.append((ch, 1))
+            k += 1
+    for op, cnt in reversed(raw):
+        if ops and ops[-1][0] == op:
+            ops[-1] = (op, ops[-1][1] + cnt)
+        else:
+            ops.append((op, cnt))
+    return ops

@@ -1,0 +1,44 @@
+"""-m gpu: the wavefront DP kernels (s3dp_dp.hip) through the C-ABI against the CPU restatement of the reference's
+DP (oracle/s3_oracle_dp.c): scores, alignment start columns, actual right clips, tie counts and the op strings must be
+identical, for both alignment schemes, with soft-clip allowances and anchors."""
+import numpy as np
+import pytest
+
+import s3dp
+import s3o
+from dp_cases import make_problems
+
+pytestmark = pytest.mark.gpu
+SC = (1, -2, -3, -1)
+
+
+@pytest.mark.parametrize("scheme", [1, 2])
+@pytest.mark.parametrize("max_read,max_dna,seed,rl", [(152, 650, 11, (60, 150)), (100, 200, 12, (30, 100)), (304, 700, 13, (150, 300)), (64, 130, 14, (16, 64))])
+def test_dp_matches_oracle(scheme, max_read, max_dna, seed, rl):
+    n = 200
+    P = make_problems(n, max_read, max_dna, seed, read_len_range=rl)
+    al = s3dp.DpAligner(n, max_read, max_dna, scheme=scheme, scores=SC)
+    sc, hit, cnt, pat, crt = al.align(P["dna"], P["dna_len"], P["reads"], P["read_len"], P["cutoffs"], clip_lt=P["clip_lt"], clip_rt=P["clip_rt"],
+                                      anchor_lt=P["a_lt"], anchor_rt=P["a_rt"])
+    osc, ohit, ocnt, opat, ocrt, ostart = s3o.dp_align(P["dna"], P["dna_len"], max_dna, al.max_table, P["reads"], P["read_len"], max_read, P["cutoffs"],
+                                                       scheme=al.scheme, scores=SC, clip_lt=P["clip_lt"], clip_rt=P["clip_rt"], anchor_lt=P["a_lt"],
+                                                       anchor_rt=P["a_rt"])
+    assert (sc == osc).all()
+    assert (cnt == ocnt).all()
+    assert (crt == ocrt).all()
+    assert (hit == ohit).all()
+    ok = sc >= P["cutoffs"]
+    assert ok.sum() > n // 3
+    for t in np.nonzero(ok)[0]:
+        a, b = bytes(pat[t]), bytes(opat[t])
+        assert a[:a.index(0) + 1] == b[:b.index(0) + 1], t
+    al.close()
+
+
+def test_dp_without_optional_arrays():
+    P = make_problems(64, 100, 160, seed=21, clip=False, anchors=False)
+    al = s3dp.DpAligner(64, 100, 160, scheme=1, scores=SC)
+    sc, hit, cnt, pat, crt = al.align(P["dna"], P["dna_len"], P["reads"], P["read_len"], P["cutoffs"])
+    osc, ohit, ocnt, opat, _, _ = s3o.dp_align(P["dna"], P["dna_len"], 160, al.max_table, P["reads"], P["read_len"], 100, P["cutoffs"], scheme=1, scores=SC)
+    assert (sc == osc).all() and (hit == ohit).all() and (cnt == ocnt).all()
+    al.close()
