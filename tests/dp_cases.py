@@ -32,8 +32,8 @@ def make_problems(n, max_read, max_dna, seed, read_len_range=(30, 150), clip=Tru
         if kind == 7:                           # unrelated read
             read = rng.integers(0, 4, size=L, dtype=np.uint8)
         dna.append(win); reads.append(read)
-        clip_lt.append(int(rng.integers(0, 20)) if clip else 0)
-        clip_rt.append(int(rng.integers(0, 20)) if clip else 0)
+        clip_lt.append(int(rng.integers(0, min(20, L // 3 + 1))) if clip else 0)
+        clip_rt.append(int(rng.integers(0, min(20, L // 3 + 1))) if clip else 0)
         if anchors and t % 3 == 0:
             a_lt.append(int(rng.integers(1, W + 1))); a_rt.append(int(rng.integers(0, W // 2 + 1)))
         else:
