@@ -105,6 +105,10 @@ int  s3_batch_fetch_hits(s3_batch *b, uint64_t *hitOffsets, s3_hit *hits, size_t
  * Results per read: phase it was resolved in (0 = unaligned), occurrence CSR in the CPU path's
  * final order (check-and-extend hits first, then SA ranges expanded; SAList.cpp:392-418). */
 int  s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead);
+/* same, for every report type of the reference's -h option: 1 all valid (one phase at numMismatch, alignment.cu:2530),
+ * 2 all best, 3 unique best / 4 random best (best_single_alignment, alignment.cu:1377: phases 0..numMismatch, no MAPQ special
+ * case; phase[] is then mismatch-phase + 1 so that 0 still means unaligned). */
+int  s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead, int reportType);
 int  s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError /* n x 8 */,
                                uint64_t *occOffsets /* n+1 */, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis,
                                size_t occCap, uint64_t *nOccOut);

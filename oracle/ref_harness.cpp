@@ -401,7 +401,45 @@ static void allValid ( Ctx & C, Reads & R, uint * queries, uint * readLengths, u
                 OCCListReset ( ol );
                 ProcessReadDoubleStrand2 ( &qP, &qN, M[L], Mn[L], c, sl, ol );
                 bool hit = ( sl->curr_size > 0 || ol->curr_size > 0 );
-                answers[c][ ( size_t ) r / 32 * 32 * wpa + r % 32] = hit ? 0xFFFFFFFE : 0xFFFFFFFD;
+                uint * ans = answers[c] + ( size_t ) r / 32 * 32 * wpa + r % 32;
+                ans[0] = hit ? 0xFFFFFFFE : 0xFFFFFFFD;
+
+                // unique-best decides on `isMoreThanSA1` (CPUfunctions.cpp:1262-1266), which the all-0xFFFFFFFE shortcut above
+                // would make true for every aligned read.  For that mode a case with at most sa_range_allowed_1 ranges is handed
+                // over the way the device does it: (l, r-l | mismatches << 24 | (strand-1) << 27) per range (CPUfunctions.cpp:1276-1295)
+                if ( hit && C.opt.alignmentType == OUTPUT_UNIQUE_BEST && sl->curr_size + ol->curr_size <= sa1 )
+                {
+                    static std::vector<uint> invSa;
+                    BWT * bwt = hk[0].sraIndex.bwt;
+
+                    if ( invSa.empty () )
+                    {
+                        invSa.resize ( ( size_t ) bwt->textLength + 1 );
+
+                        for ( unsigned long long i = 0; i <= bwt->textLength; i++ )
+                        {
+                            unsigned int v = ( *bwt->_bwtSaValue ) ( bwt, i );      // SA[0] is stored as -1
+
+                            if ( v <= bwt->textLength ) { invSa[v] = ( uint ) i; }
+                        }
+                    }
+
+                    uint k = 0;
+
+                    for ( unsigned int x = 0; x < sl->curr_size; x++, k++ )
+                    {
+                        ans[ ( k * 2 ) * 32] = sl->sa[x].saIndexLeft;
+                        ans[ ( k * 2 + 1 ) * 32] = ( sl->sa[x].saIndexRight - sl->sa[x].saIndexLeft ) | ( ( uint ) sl->sa[x].mismatchCount << BGS_GPU_ANSWER_OFFSET_LENGTH ) |
+                                                   ( ( uint ) ( sl->sa[x].strand - 1 ) << ( BGS_GPU_ANSWER_OFFSET_LENGTH + 3 ) );
+                    }
+
+                    for ( unsigned int x = 0; x < ol->curr_size; x++, k++ )
+                    {
+                        ans[ ( k * 2 ) * 32] = invSa[ol->occ[x].ambPosition];
+                        ans[ ( k * 2 + 1 ) * 32] = ( ( uint ) ol->occ[x].mismatchCount << BGS_GPU_ANSWER_OFFSET_LENGTH ) |
+                                                   ( ( uint ) ( ol->occ[x].strand - 1 ) << ( BGS_GPU_ANSWER_OFFSET_LENGTH + 3 ) );
+                    }
+                }
             }
         }
 

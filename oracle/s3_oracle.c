@@ -559,18 +559,37 @@ int s3o_decode(const s3o_index *ix, const s3o_hit *hits, int nHits, uint32_t *po
     return n;
 }
 
+long s3o_align_single(const s3o_index *ix, const uint32_t *queries, const uint32_t *readLengths, uint32_t n,
+                      uint32_t wordPerQuery, int numMismatch, uint32_t maxOutputPerRead, int reportType,
+                      uint8_t *phase, uint32_t *withError, uint64_t *occOffsets,
+                      uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st);
+
 long s3o_align_single_allbest(const s3o_index *ix, const uint32_t *queries, const uint32_t *readLengths, uint32_t n,
                               uint32_t wordPerQuery, int numMismatch, uint32_t maxOutputPerRead,
                               uint8_t *phase, uint32_t *withError, uint64_t *occOffsets,
                               uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st)
 {
+    return s3o_align_single(ix, queries, readLengths, n, wordPerQuery, numMismatch, maxOutputPerRead, 2, phase, withError, occOffsets, pos, strand, nmis,
+                            occCap, st);
+}
+
+/* reportType (the -h option): 1 all valid = one terminal phase at numMismatch (alignment.cu:2530); 2 all best (alignment.cu:1422);
+ * 3/4 unique / random best = phases 0..numMismatch without the MAPQ special case (best_single_alignment, alignment.cu:1377;
+ * needOutputMAPQ is false there, CPUfunctions.cpp:1637); phase[] is then phase + 1. */
+long s3o_align_single(const s3o_index *ix, const uint32_t *queries, const uint32_t *readLengths, uint32_t n,
+                      uint32_t wordPerQuery, int numMismatch, uint32_t maxOutputPerRead, int reportType,
+                      uint8_t *phase, uint32_t *withError, uint64_t *occOffsets,
+                      uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st)
+{
+    const int bestMode = reportType >= 3, allValid = reportType == 1;
     static const int HCAP = 1 << 16;
     s3o_model *models[5][S3O_MAX_READ + 1];
     s3o_hit *hits = (s3o_hit *)malloc(sizeof(s3o_hit) * (size_t)HCAP);
     uint8_t read[S3O_MAX_READ];
     size_t used = 0;
     uint32_t r;
-    int last = numMismatch > 0 ? numMismatch : 1, e, overflow = 0;
+    int last = (bestMode || allValid) ? numMismatch : (numMismatch > 0 ? numMismatch : 1), e, overflow = 0;
+    const int firstPhase = bestMode ? 0 : (allValid ? numMismatch : 1);
     memset(models, 0, sizeof models);
     for (r = 0; r < n && !overflow; r++) {
         int L = (int)readLengths[r], mm;
@@ -578,14 +597,14 @@ long s3o_align_single_allbest(const s3o_index *ix, const uint32_t *queries, cons
         phase[r] = 0;
         memset(&withError[(size_t)r * 8], 0, 32);
         occOffsets[r] = used;
-        for (mm = 1; mm <= last; mm++) {
+        for (mm = firstPhase; mm <= last; mm++) {
             uint32_t total, we[8];
             int k, best = 999, terminal = mm >= numMismatch, use = mm;
             if (!models[mm][L]) { models[mm][L] = (s3o_model *)malloc(sizeof(s3o_model)); s3o_model_build(L, mm, models[mm][L]); }
             k = s3o_search_read(ix, models[mm][L], read, L, maxOutputPerRead, hits, HCAP, &total, we, st);
             if (k < 0) { overflow = 1; break; }
             if (total == 0) continue;                                   /* nohit: carried to the next phase */
-            if (mm < 4) {                                               /* MAPQ special case, CPUfunctions.cpp:1756-1801 */
+            if (!bestMode && mm < 4) {                                  /* MAPQ special case, CPUfunctions.cpp:1756-1801 */
                 for (e = 0; e <= mm; e++) if (we[e] > 0) { best = e; break; }
                 if (best == mm) {
                     if (!terminal) continue;                            /* deferred */
@@ -600,7 +619,7 @@ long s3o_align_single_allbest(const s3o_index *ix, const uint32_t *queries, cons
                 int d = s3o_decode(ix, hits, k, pos + used, strand + used, nmis + used, room > 0x7fffffff ? 0x7fffffff : (int)room, st);
                 if ((size_t)d > room) { overflow = 1; break; }
                 used += (size_t)d;
-                phase[r] = (uint8_t)mm;
+                phase[r] = (uint8_t)(bestMode ? mm + 1 : mm);
                 memcpy(&withError[(size_t)r * 8], we, 32);
             }
             break;

@@ -465,8 +465,14 @@ static int decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActiv
     return S3_OK;
 }
 
-extern "C" int s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead)
+// reportType as the reference's -h option: 1 all valid, 2 all best, 3 unique best, 4 random best.
+//   all best   : all_best_single_alignment (alignment.cu:1422): phases 1..k, reads whose best == phase are deferred / re-searched
+//   all valid  : one phase at k (soap3_dp_single_align -> all_valid_alignment, alignment.cu:2530), terminal, same MAPQ special case
+//   unique/random best: best_single_alignment (alignment.cu:1377): phases 0..k, a read is reported in the first phase with a hit
+extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead, int reportType)
 {
+    if (reportType < 1 || reportType > 4) return fail(S3_EINVAL, "reportType must be 1..4");
+    const bool bestMode = reportType >= 3, allValid = reportType == 1;
     if (!b) return fail(S3_EINVAL, "null batch");
     if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
     if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
@@ -483,17 +489,18 @@ extern "C" int s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, 
     HIPCHK(hipMemsetAsync(b->dOccStart, 0, (size_t)n * 4, b->stream));
     HIPCHK(hipMemsetAsync(b->dOccCount, 0, ((size_t)n + 1) * 4, b->stream));
     HIPCHK(hipMemsetAsync(b->dNumSel, 0, 16, b->stream));
-    const uint32_t last = numMismatch > 0 ? numMismatch : 1;             // all_best_single_alignment, alignment.cu:1439
+    const uint32_t last = (bestMode || allValid) ? numMismatch : (numMismatch > 0 ? numMismatch : 1);   // alignment.cu:1439
+    const uint32_t first = bestMode ? 0u : (allValid ? numMismatch : 1u);
     const uint32_t *active = nullptr;
     uint32_t nActive = n;
     int pp = 0;
-    for (uint32_t mm = 1; mm <= last && nActive > 0; mm++) {
+    for (uint32_t mm = first; mm <= last && nActive > 0; mm++) {
         const bool terminal = mm >= numMismatch;
         int rc = searchPass(b, active, nActive, mm, maxOutputPerRead);
         if (rc) return rc;
         // MAPQ special case needs the (mm+1) model, which exists only for mm < 4 (CPUfunctions.cpp:1756)
-        launchClassify(nActive, b->dTotalOcc, b->dWithError, mm, mm < 4 ? 1u : 0u, b->dState, b->stream);
-        rc = decodeAndPublish(b, active, nActive, 1, (uint8_t)mm, maxOutputPerRead, terminal ? 2 : 0);
+        launchClassify(nActive, b->dTotalOcc, b->dWithError, mm, (!bestMode && mm < 4) ? 1u : 0u, b->dState, b->stream);
+        rc = decodeAndPublish(b, active, nActive, 1, (uint8_t)(bestMode ? mm + 1 : mm), maxOutputPerRead, terminal ? 2 : 0);
         if (rc) return rc;
         // reads that go on: no hit or best == mm (non terminal: next phase; terminal: state 2 re-searched with mm+1 model)
         const uint32_t *idsIn = active;
@@ -508,7 +515,7 @@ extern "C" int s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, 
         HIPCHK(hipMemcpyAsync(&nNext, b->dNumSel, 4, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
         if (terminal) {
-            if (mm < 4 && nNext > 0) {
+            if (!bestMode && mm < 4 && nNext > 0) {
                 // ProcessOneMoreMismatchAllCases (CPUfunctions.cpp:624, called at :1790): the read is re-searched with the
                 // (mm+1)-mismatch model and THAT result is what gets reported
                 rc = searchPass(b, nextList, nNext, mm + 1, maxOutputPerRead);
@@ -532,6 +539,11 @@ extern "C" int s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, 
     HIPCHK(hipGetLastError());
     b->lastKind = 2;
     return S3_OK;
+}
+
+extern "C" int s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead)
+{
+    return s3_batch_align_single(b, numMismatch, maxOutputPerRead, 2);
 }
 
 extern "C" int s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError, uint64_t *occOffsets, uint32_t *occPos, uint8_t *occStrand,

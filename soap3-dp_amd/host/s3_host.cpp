@@ -453,4 +453,42 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
     nRecords++;
 }
 
+void SamWriter::singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_t strand, uint8_t mis)
+{
+    const uint32_t readLen = rs.lengths[r];
+    const bool negative = strand == 2;
+    uint64_t tp = 0;
+    uint32_t chr = 0;
+    chrAndPos(pos, tp, chr);
+    std::string md;
+    int avgQual = 40;
+    mdString(ix, &rs.codes[(size_t)r * rs.maxReadLength], &rs.quals[(size_t)r * rs.maxReadLength], readLen, pos, negative, (int)mis, 0, md, avgQual);
+    // getMapQualScore with n = 1 (BGS-IO.cpp:2280): the mismatch x quality-class table, second-best hits not considered
+    int mi = mis > 5 ? 5 : (int)mis;
+    int qi = ((rs.isFastq ? avgQual : 20) - 1) / 20;
+    qi = qi > 1 ? 1 : qi < 0 ? 0 : qi;
+    int mapq = (int)(opt.maxMAPQ * kMappingScore[mi][qi]);
+    if (mapq < opt.minMAPQ) mapq = opt.minMAPQ;
+    std::string line = rs.names[r];
+    line.push_back('\t');
+    line += std::to_string(negative ? 16 : 0);
+    line.push_back('\t');
+    line += ix.seqName[chr - 1];
+    line.push_back('\t');
+    line += std::to_string((unsigned long long)tp);
+    line.push_back('\t');
+    line += std::to_string(mapq);
+    line.push_back('\t');
+    line += std::to_string(readLen);
+    line += "M\t*\t0\t0\t";
+    seqAndQual(rs, r, negative, line);
+    line += "\tRG:Z:" + opt.readGroup;
+    if (opt.printMDNM) line += "\tNM:i:" + std::to_string((unsigned)mis);
+    line += "\tX0:i:1\tXM:i:" + std::to_string((unsigned)mis) + "\tXO:i:0\tXG:i:0";
+    if (opt.printMDNM && !md.empty()) line += "\tMD:Z:" + md;
+    line.push_back('\n');
+    fwrite(line.data(), 1, line.size(), out);
+    nRecords++;
+}
+
 }  // namespace s3host

@@ -68,7 +68,7 @@ int main(int argc, char **argv)
     }
     if (enableDP) return die("the DP stages are not built yet: run with -s <k>");
     if (outputFormat != 2) return die("only SAM output (-b 2) is built");
-    if (alignmentType != 2) return die("only all-best (-h 2) is built");
+    if (alignmentType < 1 || alignmentType > 4) return die("The output option should be 1, 2, 3 or 4");
     if (maxReadLength > S3_MAX_READ_LENGTH) return die("The length should not be greater than 1024");
     if (maxReadLength > 120) return die("long-read mode (reads > 120 bp) is not built yet");
     if (readGroup.empty()) readGroup = queryFile;
@@ -101,7 +101,7 @@ int main(int argc, char **argv)
     for (uint32_t first = 0; first < rs.n; first += maxBatch) {
         const uint32_t cnt = rs.n - first < maxBatch ? rs.n - first : maxBatch;   // first is a multiple of 32
         if (s3_batch_upload(b, rs.queries.data() + (size_t)first * rs.wpq, rs.lengths.data() + first, cnt) != S3_OK) return die(s3_last_error());
-        if (s3_batch_align_single_allbest(b, (uint32_t)numMismatch, ini.maxOutputPerRead) != S3_OK) return die(s3_last_error());
+        if (s3_batch_align_single(b, (uint32_t)numMismatch, ini.maxOutputPerRead, alignmentType) != S3_OK) return die(s3_last_error());
         std::vector<uint8_t> phase(cnt);
         std::vector<uint64_t> offs((size_t)cnt + 1);
         uint64_t nOcc = 0;
@@ -111,6 +111,12 @@ int main(int argc, char **argv)
         if (s3_batch_fetch_alignments(b, nullptr, nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK) return die(s3_last_error());
         for (uint32_t k = 0; k < cnt; k++) {
             const size_t o = offs[k], m = offs[k + 1] - offs[k];
+            if (alignmentType >= 3) {
+                // unique best: exactly one hit, otherwise a no-answer record; random best: the first hit (hostKernel, CPUfunctions.cpp:1861-1930)
+                if (m == 0 || (alignmentType == 3 && m > 1)) sam.unaligned(rs, first + k);
+                else { aligned++; sam.singleAnswer(rs, first + k, pos[o], strand[o], mis[o]); }
+                continue;
+            }
             if (m) aligned++;
             sam.singleEnd(rs, first + k, pos.data() + o, strand.data() + o, mis.data() + o, m);
         }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the golden fixtures with the REAL reference (oracle/_ref, built by oracle/ref.mk from
 # /root/reference).  Runs only in the authoring container; the outputs below are committed data
-# (inputs + expected outputs), never reference source.
+# (inputs + expected outputs), never reference source.  index.ann carries a random build stamp: keep the committed one.
 #   g1: 200 kbp, 3 chromosomes, 4 N-runs, 6 planted repeat families; 2000 x 100 bp reads (0-4 substitutions)
 #   g2: 60 kbp, heavy repeats (exceeds MaxOutputPerRead=1000 with the small-cap ini), mixed read lengths 25..120
 set -euo pipefail
@@ -24,12 +24,17 @@ mk() {  # name genome_args read_args maxlen
     for mm in 0 1 2 3 4; do $REF/ref_harness search $INI $name.fa.index $name.fq $L $mm search_mm$mm.txt > /dev/null 2>&1; done
     $REF/ref_harness sam $INI single $name.fa.index $name.fq -L $L -s 4 -b 2 -o sam_s4 > /dev/null 2>&1
     $REF/ref_harness sam $INI single $name.fa.index $name.fq -L $L -s 2 -b 2 -o sam_s2 > /dev/null 2>&1
+    $REF/ref_harness sam $INI single $name.fa.index $name.fq -L $L -s 2 -h 1 -b 2 -o sam_h1_s2 > /dev/null 2>&1
+    $REF/ref_harness sam $INI single $name.fa.index $name.fq -L $L -s 0 -h 1 -b 2 -o sam_h1_s0 > /dev/null 2>&1
+    $REF/ref_harness sam $INI single $name.fa.index $name.fq -L $L -s 3 -h 3 -b 2 -o sam_h3_s3 > /dev/null 2>&1
+    $REF/ref_harness sam $INI single $name.fa.index $name.fq -L $L -s 3 -h 4 -b 2 -p -o sam_h4_s3 > /dev/null 2>&1
     sha256sum $name.fa.index.lkt $name.fa.index.rev.lkt | awk '{print $1}' > lkt.sha256
     for f in bwt rev.bwt fmv.gpu rev.fmv.gpu sa pac ann amb tra; do cp $name.fa.index.$f $OUT/$name/index.$f; done
     cp $name.fa $OUT/$name/genome.fa; cp $name.fq $OUT/$name/reads.fq; cp $name.truth $OUT/$name/reads.truth; cp lkt.sha256 $OUT/$name/
     for mm in 0 1 2 3 4; do gzip -9n < search_mm$mm.txt > $OUT/$name/search_mm$mm.txt.gz; done
     grep -v '^@PG' sam_s4.gout.1 | gzip -9n > $OUT/$name/sam_s4.sam.gz
     grep -v '^@PG' sam_s2.gout.1 | gzip -9n > $OUT/$name/sam_s2.sam.gz
+    for v in h1_s2 h1_s0 h3_s3 h4_s3; do grep -v '^@PG' sam_$v.gout.1 | gzip -9n > $OUT/$name/sam_$v.sam.gz; done
   )
 }
 

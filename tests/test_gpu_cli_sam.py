@@ -28,17 +28,22 @@ def sam_records(text):
     return hdr, rec
 
 
+# (fixture, extra options): -h 2 all best (default), -h 1 all valid, -h 3 unique best, -h 4 random best (+ -p: NM/MD tags)
+VARIANTS = [("s2", ["-s", "2"]), ("s4", ["-s", "4"]), ("h1_s2", ["-s", "2", "-h", "1"]), ("h1_s0", ["-s", "0", "-h", "1"]),
+            ("h3_s3", ["-s", "3", "-h", "3"]), ("h4_s3", ["-s", "3", "-h", "4", "-p"])]
+
+
 @pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
-@pytest.mark.parametrize("s", [2, 4])
-def test_cli_sam_matches_reference_cpu_path(tmp_path, name, maxlen, s):
+@pytest.mark.parametrize("variant,opts", VARIANTS)
+def test_cli_sam_matches_reference_cpu_path(tmp_path, name, maxlen, variant, opts):
     assert os.path.exists(BIN), "soap3-dp binary not built"
     fq = tmp_path / (name + ".fq")                      # the read-group id is the query file name as typed
     shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), fq)
-    out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", str(maxlen), "-s", str(s), "-b", "2",
+    out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", str(maxlen)] + opts + ["-b", "2",
                           "-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
     mine_h, mine = sam_records(open(tmp_path / "out.gout.1").read())
-    ref_h, ref = sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_s%d.sam.gz" % s), "rt").read())
+    ref_h, ref = sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_%s.sam.gz" % variant), "rt").read())
     assert mine_h == ref_h
     assert set(mine) == set(ref)
     bad = [(k, ref[k], mine[k]) for k in ref if ref[k] != mine[k]]

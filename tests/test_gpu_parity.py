@@ -80,3 +80,28 @@ def test_allbest_ladder_matches_oracle(name, maxlen, mm):
     assert (pos == opos).all() and (strand == ostrand).all() and (mis == omis).all()
     oix.close()
     b.close()
+
+
+@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
+@pytest.mark.parametrize("report_type,mm", [(1, 0), (1, 2), (1, 4), (3, 0), (3, 3), (4, 2), (4, 4)])
+def test_report_type_ladders_match_oracle(name, maxlen, report_type, mm):
+    """-h 1 (all valid: one terminal phase), -h 3/4 (unique/random best: phases 0..k, phase reported + 1)"""
+    reads = golden_reads(name)
+    q, lens, wpq = s3dp.pack_reads(reads, maxlen)
+    b = s3dp.Batch(dev_index(name), len(reads), wpq)
+    b.upload(q, lens)
+    b.align_single(mm, 1000, report_type)
+    phase, werr, offs, pos, strand, mis = b.fetch_alignments()
+    oix = s3o.Index(host_index=host_index(name))
+    ophase, owerr, ooffs, opos, ostrand, omis, st = oix.align_single_allbest(q, lens, wpq, mm, 1000, report_type=report_type)
+    assert (phase == ophase).all()
+    assert (werr == owerr).all()
+    assert (offs == ooffs).all()
+    assert (pos == opos).all() and (strand == ostrand).all() and (mis == omis).all()
+    if report_type >= 3:
+        n = offs[1:] - offs[:-1]
+        assert ((phase > 0) == (n > 0)).all()
+        for r in range(len(reads)):                       # every reported hit of a best mode carries exactly phase-1 mismatches
+            assert (mis[offs[r]:offs[r + 1]].astype(int) == int(phase[r]) - 1).all()
+    oix.close()
+    b.close()
