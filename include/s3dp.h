@@ -87,6 +87,12 @@ void s3_batch_free(s3_batch *b);
 /* queries: the reference's packed layout -- 32-interleaved words, 16 chars/word LSB first
  * (word w of read r at r/32*32*wpq + r%32 + 32*w; DV-Kernel.cu:4268-4270); readLengths[n]. Host pointers. */
 int  s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint32_t *readLengths, uint32_t n);
+/* Long-read mode = the `seedLengths` argument of all_valid_alignment / all_best_single_alignment / best_single_alignment
+ * (alignment.cu:534,1422,1377; the array is built at alignment.cu:2473-2491: 100 for reads longer than 120 bases, else the read
+ * length).  Call after s3_batch_upload; NULL switches it off.  Searches then run on the first seedLengths[i] (16..128) bases of read
+ * i without a hit limit, and s3_batch_align_single verifies the remaining bases of every hit against the packed text
+ * (validateAlignments, CPUfunctions.cpp:1129-1222): positions and mismatch counts reported are those of the whole read. */
+int  s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLengths);
 
 /* All cases of the <= numMismatch model, both strands, for every read of the batch: the work of
  * kernel / kernel_4mismatch_{1,2} (DV-Kernel.cu:4249,4505,4741) + round 2 + the CPU re-search of

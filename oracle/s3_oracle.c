@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 /* ------------------------------------------------------------------------------------------
  * Model tables: SRAMismatchCasesPopulate (2bwt-flex/SRA2BWTMdl.c:1171-1700) for MaxError 0..4,
@@ -559,18 +560,47 @@ int s3o_decode(const s3o_index *ix, const s3o_hit *hits, int nHits, uint32_t *po
     return n;
 }
 
-long s3o_align_single(const s3o_index *ix, const uint32_t *queries, const uint32_t *readLengths, uint32_t n,
-                      uint32_t wordPerQuery, int numMismatch, uint32_t maxOutputPerRead, int reportType,
-                      uint8_t *phase, uint32_t *withError, uint64_t *occOffsets,
-                      uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st);
-
 long s3o_align_single_allbest(const s3o_index *ix, const uint32_t *queries, const uint32_t *readLengths, uint32_t n,
                               uint32_t wordPerQuery, int numMismatch, uint32_t maxOutputPerRead,
                               uint8_t *phase, uint32_t *withError, uint64_t *occOffsets,
                               uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st)
 {
-    return s3o_align_single(ix, queries, readLengths, n, wordPerQuery, numMismatch, maxOutputPerRead, 2, phase, withError, occOffsets, pos, strand, nmis,
-                            occCap, st);
+    return s3o_align_single_long(ix, queries, readLengths, NULL, n, wordPerQuery, numMismatch, maxOutputPerRead, 2, phase, withError, occOffsets, pos,
+                                 strand, nmis, occCap, st);
+}
+
+static unsigned text_char(const s3o_index *ix, uint64_t p) { return (ix->pac[p >> 4] >> (2 * (15 - (p & 15)))) & 3u; }
+
+/* validateAlignments (CPUfunctions.cpp:1129-1222): long-read mode aligned only the first seedLen bases; every hit is extended
+ * over the remaining readLen - seedLen bases by counting mismatching characters against the packed text (numMismatchNew,
+ * PE.cpp:148), kept when seed + extension mismatches <= maxMismatch, moved to the leftmost text position of the whole read.
+ * Returns the new list size (filtered in place, order kept). */
+static int validate_long(const s3o_index *ix, const uint8_t *read, int seedLen, int readLen, uint32_t *pos, uint8_t *strand, uint8_t *nmis, int cnt,
+                         int onlyBest, int minSeedMis, int maxMis, uint32_t maxHit)
+{
+    const int ext = readLen - seedLen;
+    int i, out = 0, pre = maxMis;
+    if (readLen <= seedLen) return cnt;
+    for (i = 0; i < cnt; i++) {
+        int mis = maxMis + 1, tot, t;
+        if ((int)nmis[i] < minSeedMis) continue;
+        if (strand[i] == 1 && (uint64_t)pos[i] + (uint32_t)readLen <= ix->dnaLength) {
+            for (mis = 0, t = 0; t < ext; t++) mis += read[seedLen + t] != text_char(ix, (uint64_t)pos[i] + seedLen + t);
+        }
+        if (strand[i] == 2 && pos[i] >= (uint32_t)ext) {
+            for (mis = 0, t = 0; t < ext; t++) mis += (3u - read[readLen - 1 - t]) != text_char(ix, (uint64_t)pos[i] - ext + t);
+        }
+        tot = mis + nmis[i];
+        if (tot > maxMis) continue;
+        if (onlyBest && tot > pre) continue;
+        if (onlyBest && tot < pre) { out = 0; pre = tot; }
+        pos[out] = strand[i] == 1 ? pos[i] : pos[i] - (uint32_t)ext;
+        strand[out] = strand[i];
+        nmis[out] = (uint8_t)tot;
+        out++;
+        if (pre == minSeedMis && (uint32_t)out >= maxHit) break;
+    }
+    return out;
 }
 
 /* reportType (the -h option): 1 all valid = one terminal phase at numMismatch (alignment.cu:2530); 2 all best (alignment.cu:1422);
@@ -581,7 +611,21 @@ long s3o_align_single(const s3o_index *ix, const uint32_t *queries, const uint32
                       uint8_t *phase, uint32_t *withError, uint64_t *occOffsets,
                       uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st)
 {
+    return s3o_align_single_long(ix, queries, readLengths, NULL, n, wordPerQuery, numMismatch, maxOutputPerRead, reportType, phase, withError, occOffsets,
+                                 pos, strand, nmis, occCap, st);
+}
+
+/* seedLengths != NULL is the reference's long-read mode (maxReadLength > 120, alignment.cu:2473-2491 and hostKernel,
+ * CPUfunctions.cpp:1649-1657,1813-1840): the search runs on the first seedLengths[r] bases without a hit limit, the MAPQ special case
+ * looks at the seed statistics, then validateAlignments filters; a read whose list comes out empty is "nohit" and moves on. */
+long s3o_align_single_long(const s3o_index *ix, const uint32_t *queries, const uint32_t *readLengths, const uint32_t *seedLengths, uint32_t n,
+                           uint32_t wordPerQuery, int numMismatch, uint32_t maxOutputPerRead, int reportType,
+                           uint8_t *phase, uint32_t *withError, uint64_t *occOffsets,
+                           uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st)
+{
     const int bestMode = reportType >= 3, allValid = reportType == 1;
+    const int needMapq = !bestMode;                                     /* SAM output, CPUfunctions.cpp:1642 */
+    const uint32_t searchLimit = seedLengths ? 0xFFFFFFFFu : maxOutputPerRead;
     static const int HCAP = 1 << 16;
     s3o_model *models[5][S3O_MAX_READ + 1];
     s3o_hit *hits = (s3o_hit *)malloc(sizeof(s3o_hit) * (size_t)HCAP);
@@ -592,8 +636,9 @@ long s3o_align_single(const s3o_index *ix, const uint32_t *queries, const uint32
     const int firstPhase = bestMode ? 0 : (allValid ? numMismatch : 1);
     memset(models, 0, sizeof models);
     for (r = 0; r < n && !overflow; r++) {
-        int L = (int)readLengths[r], mm;
-        unpack_read(queries, r, wordPerQuery, L, read);
+        const int fullLen = (int)readLengths[r];
+        int L = seedLengths ? (int)seedLengths[r] : fullLen, mm;
+        unpack_read(queries, r, wordPerQuery, fullLen, read);
         phase[r] = 0;
         memset(&withError[(size_t)r * 8], 0, 32);
         occOffsets[r] = used;
@@ -601,7 +646,7 @@ long s3o_align_single(const s3o_index *ix, const uint32_t *queries, const uint32
             uint32_t total, we[8];
             int k, best = 999, terminal = mm >= numMismatch, use = mm;
             if (!models[mm][L]) { models[mm][L] = (s3o_model *)malloc(sizeof(s3o_model)); s3o_model_build(L, mm, models[mm][L]); }
-            k = s3o_search_read(ix, models[mm][L], read, L, maxOutputPerRead, hits, HCAP, &total, we, st);
+            k = s3o_search_read(ix, models[mm][L], read, L, searchLimit, hits, HCAP, &total, we, st);
             if (k < 0) { overflow = 1; break; }
             if (total == 0) continue;                                   /* nohit: carried to the next phase */
             if (!bestMode && mm < 4) {                                  /* MAPQ special case, CPUfunctions.cpp:1756-1801 */
@@ -610,7 +655,7 @@ long s3o_align_single(const s3o_index *ix, const uint32_t *queries, const uint32
                     if (!terminal) continue;                            /* deferred */
                     use = mm + 1;
                     if (!models[use][L]) { models[use][L] = (s3o_model *)malloc(sizeof(s3o_model)); s3o_model_build(L, use, models[use][L]); }
-                    k = s3o_search_read(ix, models[use][L], read, L, maxOutputPerRead, hits, HCAP, &total, we, st);
+                    k = s3o_search_read(ix, models[use][L], read, L, searchLimit, hits, HCAP, &total, we, st);
                     if (k < 0) { overflow = 1; break; }
                 }
             }
@@ -618,6 +663,13 @@ long s3o_align_single(const s3o_index *ix, const uint32_t *queries, const uint32
                 size_t room = occCap - used;
                 int d = s3o_decode(ix, hits, k, pos + used, strand + used, nmis + used, room > 0x7fffffff ? 0x7fffffff : (int)room, st);
                 if ((size_t)d > room) { overflow = 1; break; }
+                if (seedLengths) {
+                    int maxMis = (int)ceil(0.02 * fullLen);             /* MISMATCH_RATIO_FOR_LONG, CPUfunctions.cpp:1819 */
+                    if (needMapq) maxMis *= 2;
+                    d = validate_long(ix, read, L, fullLen, pos + used, strand + used, nmis + used, d, bestMode, bestMode ? mm : 0, maxMis, maxOutputPerRead);
+                    if ((uint32_t)d > maxOutputPerRead) d = (int)maxOutputPerRead;
+                    if (d == 0) { if (terminal) break; continue; }      /* nohit after validation: next phase */
+                }
                 used += (size_t)d;
                 phase[r] = (uint8_t)(bestMode ? mm + 1 : mm);
                 memcpy(&withError[(size_t)r * 8], we, 32);

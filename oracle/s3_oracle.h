@@ -123,6 +123,12 @@ long s3o_align_single(const s3o_index *ix, const uint32_t *queries, const uint32
                       uint8_t *phase, uint32_t *withError /* n x 8 */, uint64_t *occOffsets /* n+1 */,
                       uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st);
 
+/* the same with the reference's long-read mode: seedLengths[r] bases are searched, the rest verified (NULL = off) */
+long s3o_align_single_long(const s3o_index *ix, const uint32_t *queries, const uint32_t *readLengths, const uint32_t *seedLengths, uint32_t n,
+                           uint32_t wordPerQuery, int numMismatch, uint32_t maxOutputPerRead, int reportType,
+                           uint8_t *phase, uint32_t *withError /* n x 8 */, uint64_t *occOffsets /* n+1 */,
+                           uint32_t *pos, uint8_t *strand, uint8_t *nmis, size_t occCap, s3o_stats *st);
+
 /* all-symbol rank on the GPU-2BWT layout (DV-Kernel.cu:85-153,282-299 / BWT.c:1211) : v[c] = Occ(c, i) + C[c] */
 void s3o_rank_all(const s3o_bwt *b, uint32_t i, uint32_t v[4]);
 

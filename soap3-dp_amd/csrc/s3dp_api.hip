@@ -147,7 +147,9 @@ struct s3_batch {
     size_t   maxItems = 0;
     uint32_t recCap = 0, occCap = 0;
     // inputs
-    uint32_t *dQueries = nullptr, *dLens = nullptr, *dReadsT = nullptr;
+    uint32_t *dQueries = nullptr, *dLens = nullptr, *dReadsT = nullptr, *dSeedLens = nullptr;
+    bool longMode = false;          // seed lengths set: the reference's long-read mode
+    uint32_t fullUniformLen = 0;
     // search / ordering work buffers
     uint4    *dRecs = nullptr, *dOrdered = nullptr;
     uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr;
@@ -190,6 +192,54 @@ static int balloc(s3_batch *b, T **p, size_t count)
     return S3_OK;
 }
 
+// replace a batch buffer by a larger one, keeping the first `keep` elements
+template <class T>
+static int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, newCount * sizeof(T));
+    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch grow): ") + hipGetErrorString(e));
+    if (keep) {
+        e = hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) { (void)hipFree(q); return fail(S3_EHIP, std::string("grow copy: ") + hipGetErrorString(e)); }
+    }
+    for (auto &a : b->allocs) if (a == (void *)*p) a = q;
+    (void)hipFree(*p);
+    *p = (T *)q;
+    return S3_OK;
+}
+
+static const size_t kMaxEntries = 0xFFFFFF00ull;         // record / occurrence indices are 32 bit
+
+static int growRecords(s3_batch *b)
+{
+    if (b->recCap >= kMaxEntries) return fail(S3_EOVERFLOW, "record buffer overflow at the 32-bit limit");
+    size_t cap = (size_t)b->recCap * 2;
+    if (cap > kMaxEntries) cap = kMaxEntries;
+    int rc;
+    if ((rc = bgrow(b, &b->dRecs, cap, 0))) return rc;
+    if ((rc = bgrow(b, &b->dOrdered, cap, 0))) return rc;
+    if ((rc = bgrow(b, &b->dHits, cap, 0))) return rc;
+    b->recCap = (uint32_t)cap;
+    return S3_OK;
+}
+
+static int growOccurrences(s3_batch *b, uint64_t need)
+{
+    if (need > kMaxEntries) return fail(S3_EOVERFLOW, "occurrence buffer overflow at the 32-bit limit");
+    size_t cap = (size_t)b->occCap * 2;
+    if (cap < need + need / 4) cap = need + need / 4;
+    if (cap > kMaxEntries) cap = kMaxEntries;
+    int rc;
+    if ((rc = bgrow(b, &b->dOccPos, cap, b->occUsed))) return rc;
+    if ((rc = bgrow(b, &b->dOccMeta, cap, b->occUsed))) return rc;
+    if ((rc = bgrow(b, &b->dOutPos, cap, 0))) return rc;
+    if ((rc = bgrow(b, &b->dOutMeta, cap, 0))) return rc;
+    b->occCap = (uint32_t)cap;
+    return S3_OK;
+}
+
 static size_t envSize(const char *name, size_t dflt)
 {
     const char *v = getenv(name);
@@ -206,14 +256,18 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     const size_t roundUp = ((size_t)maxReads + 31) / 32 * 32;
     b->maxItems = (size_t)maxReads * 20;                               // 10 cases x 2 strands at 4 mismatches
     const size_t recPerRead = envSize("S3DP_REC_PER_READ", 6), occPerRead = envSize("S3DP_OCC_PER_READ", 12);
-    size_t recCap = (size_t)maxReads * recPerRead + 65536 + (size_t)S3_V2_REC_BLOCK * 8192, occCap = (size_t)maxReads * occPerRead + 65536;
+    // every wave of the persistent search grid may hold one partly filled block of record slots: that is the floor.  Both buffers
+    // grow on demand (growRecords / growOccurrences); the sizes here only avoid regrowth in the common case.
+    const size_t recFloor = envSize("S3DP_REC_FLOOR", 65536 + (size_t)S3_V2_REC_BLOCK * 8192);
+    size_t recCap = (size_t)maxReads * recPerRead + recFloor, occCap = (size_t)maxReads * occPerRead + 65536;
+    if (recCap < 4096) recCap = 4096;
     if (recCap > 0xFFFFFF00ull) recCap = 0xFFFFFF00ull;
     if (occCap > 0xFFFFFF00ull) occCap = 0xFFFFFF00ull;
     b->recCap = (uint32_t)recCap; b->occCap = (uint32_t)occCap;
     HIPCHK(hipStreamCreate(&b->stream));
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
-    BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dReadsT, roundUp * wordPerQuery + 16);
+    BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * wordPerQuery + 16);
     BA(dRecs, recCap); BA(dOrdered, recCap);
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
@@ -271,6 +325,30 @@ extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint3
     b->lastKind = 0;
     b->uniformLen = n ? readLengths[0] : 0;
     for (uint32_t i = 1; i < n; i++) if (readLengths[i] != readLengths[0]) { b->uniformLen = 0; break; }
+    b->fullUniformLen = b->uniformLen;
+    b->longMode = false;
+    return S3_OK;
+}
+
+// Long-read mode: the seedLengths argument of all_valid_alignment (alignment.cu:534; built at :2473-2491).  The search then runs on
+// the first seedLengths[i] bases of read i and the ladder verifies the remaining bases (validateAlignments, CPUfunctions.cpp:1129).
+extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLengths)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    if (!seedLengths) { b->longMode = false; b->uniformLen = b->fullUniformLen; return S3_OK; }
+    const uint32_t n = b->n;
+    std::vector<uint32_t> lens(n);
+    HIPCHK(hipMemcpy(lens.data(), b->dLens, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++)
+        if (seedLengths[i] < 16 || seedLengths[i] > lens[i] || seedLengths[i] > 128)
+            return fail(S3_EINVAL, "s3_batch_set_seed_lengths: a seed must have 16..128 bases and not exceed its read");
+    HIPCHK(hipMemcpyAsync(b->dSeedLens, seedLengths, (size_t)n * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->uniformLen = n ? seedLengths[0] : 0;
+    for (uint32_t i = 1; i < n; i++) if (seedLengths[i] != seedLengths[0]) { b->uniformLen = 0; break; }
+    b->longMode = true;
+    b->lastKind = 0;
     return S3_OK;
 }
 
@@ -286,9 +364,10 @@ static int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uin
 {
     const int nCases = s3_num_cases((int)modelMm);
     const size_t nItems = (size_t)nActive * nCases * 2;
-    HIPCHK(hipMemsetAsync(b->dRecCount, 0, 4, b->stream));
     SearchIn in{};
-    in.queries = b->dQueries; in.readsT = b->dReadsT; in.readLengths = b->dLens; in.active = active; in.nActive = nActive; in.wpq = b->wpq;
+    in.queries = b->dQueries; in.readsT = b->dReadsT; in.readLengths = b->longMode ? b->dSeedLens : b->dLens; in.active = active; in.nActive = nActive;
+    in.wpq = b->wpq;
+    in.wpqLoad = (b->longMode && b->wpq > 8) ? 8 : b->wpq;                // seeds have at most 128 bases
     in.models = b->ix->models[modelMm]; in.nCases = nCases; in.maxOut = maxOut; in.uniformLen = b->uniformLen;
     {
         S3Model m;
@@ -296,20 +375,39 @@ static int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uin
         in.nStepsPacked = 0;
         for (int c = 0; c < m.nCases; c++) in.nStepsPacked |= (uint32_t)m.cs[c].nSteps << (3 * c);
     }
-    SearchOut out{};
-    out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
-    out.counters = b->counting ? b->dCounters : nullptr;
-    out.workHead = b->dWorkHead;
-    HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-    if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
-    {
-        // S3DP_KERNEL=v1 selects the first-generation one-thread-per-item kernel (kept for A/B measurements)
-        static const bool useV1 = [] { const char *e = getenv("S3DP_KERNEL"); return e && strcmp(e, "v1") == 0; }();
-        static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", S3_V2_WAVES_PER_SIMD);
-        if (useV1) launchSearch(b->ix->d, in, out, 256u * 8u * 4u, b->stream);
-        else launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
+    unsigned long long counterSnap[8];
+    if (b->counting) {
+        HIPCHK(hipMemcpyAsync(counterSnap, b->dCounters, 64, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
     }
-    if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
+    for (;;) {
+        HIPCHK(hipMemsetAsync(b->dRecCount, 0, 4, b->stream));
+        SearchOut out{};
+        out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
+        out.counters = b->counting ? b->dCounters : nullptr;
+        out.workHead = b->dWorkHead;
+        HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
+        if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
+        {
+            // S3DP_KERNEL=v1 selects the first-generation one-thread-per-item kernel (kept for A/B measurements)
+            static const bool useV1 = [] { const char *e = getenv("S3DP_KERNEL"); return e && strcmp(e, "v1") == 0; }();
+            static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", S3_V2_WAVES_PER_SIMD);
+            if (useV1) launchSearch(b->ix->d, in, out, 256u * 8u * 4u, b->stream);
+            else launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
+        }
+        if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
+        // a record that did not fit was dropped but counted: the ordering below must not run on such a pass.  Grow and search again.
+        uint32_t flags = 0;
+        HIPCHK(hipMemcpyAsync(&flags, b->dFlags, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (!(flags & S3_FLAG_REC_OVERFLOW)) break;
+        int rc = growRecords(b);
+        if (rc) return rc;
+        flags &= ~S3_FLAG_REC_OVERFLOW;
+        HIPCHK(hipMemcpyAsync(b->dFlags, &flags, 4, hipMemcpyHostToDevice, b->stream));
+        if (b->counting) HIPCHK(hipMemcpyAsync(b->dCounters, counterSnap, 64, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
     b->searchLaunches++;
     HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, 4, b->stream));
     size_t tb = b->tempBytes;
@@ -441,14 +539,100 @@ __global__ void gatherOccKernel(uint32_t n, const uint32_t *occStart, const uint
     for (uint32_t k = 0; k < cnt; k++) { outPos[dst + k] = pos[src + k]; outMeta[dst + k] = meta[src + k]; }
 }
 
+// Long-read mode (validateAlignments, CPUfunctions.cpp:1129-1222, called at :1832): the published occurrences are seed hits; every one
+// is extended over the rest of the read by counting mismatching characters against the packed text (numMismatchNew, PE.cpp:148),
+// kept when seed + extension mismatches <= maxMismatch and moved to the leftmost text position of the whole read; best modes keep
+// only the hits with the fewest mismatches.  The list is filtered in place in the reference's order, one lane per read.  A read whose
+// list comes out empty is "nohit": unaligned, and carried to the next phase when there is one.
+struct ValidateArgs {
+    uint32_t nActive;
+    const uint32_t *active;
+    const uint8_t *state;
+    uint8_t want;
+    const uint32_t *occOffsets;
+    uint32_t occBase;
+    uint32_t *occPos, *occMeta;
+    const uint32_t *readsT;
+    uint32_t wpq;
+    const uint32_t *lens, *seedLens;
+    const uint32_t *text;
+    uint32_t textLength;
+    int onlyBest, minSeedMis, needMapq;
+    uint32_t maxHit;
+    int carryOn;                  // not the terminal phase: empty lists go on
+    uint8_t *outPhase;
+    uint32_t *outOccCount;
+    uint8_t *selFlags;
+};
+
+__global__ void validateKernel(ValidateArgs a)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.nActive || a.state[slot] != a.want) return;
+    const uint32_t r = a.active ? a.active[slot] : slot;
+    const uint32_t readLen = a.lens[r], seedLen = a.seedLens[r];
+    const uint32_t base = a.occBase + a.occOffsets[slot];
+    const uint32_t cnt = a.occOffsets[slot + 1] - a.occOffsets[slot];
+    uint32_t out = cnt;
+    if (readLen > seedLen) {
+        const uint32_t ext = readLen - seedLen;
+        int maxMis = (int)ceil(0.02 * (double)readLen);                  // MISMATCH_RATIO_FOR_LONG, CPUfunctions.cpp:1819
+        if (a.needMapq) maxMis *= 2;
+        int pre = maxMis;
+        const uint32_t *rd = a.readsT + (size_t)r * a.wpq;
+        auto readChar = [&](uint32_t q) -> uint32_t { return (rd[q >> 4] >> ((q & 15u) * 2u)) & 3u; };
+        auto textChar = [&](uint64_t p) -> uint32_t { return (a.text[p >> 4] >> (2u * (15u - (uint32_t)(p & 15u)))) & 3u; };
+        out = 0;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const uint32_t pos = a.occPos[base + i], meta = a.occMeta[base + i];
+            const uint32_t strand = meta & 0xFFu;
+            const int seedMis = (int)((meta >> 8) & 0xFFu);
+            if (seedMis < a.minSeedMis) continue;
+            int mis = maxMis + 1;
+            if (strand == 1u && (uint64_t)pos + readLen <= a.textLength) {
+                mis = 0;
+                for (uint32_t t = 0; t < ext; t++) mis += readChar(seedLen + t) != textChar((uint64_t)pos + seedLen + t);
+            }
+            if (strand == 2u && pos >= ext) {
+                mis = 0;
+                for (uint32_t t = 0; t < ext; t++) mis += (3u - readChar(readLen - 1u - t)) != textChar((uint64_t)pos - ext + t);
+            }
+            const int tot = mis + seedMis;
+            if (tot > maxMis) continue;
+            if (a.onlyBest && tot > pre) continue;
+            if (a.onlyBest && tot < pre) { out = 0; pre = tot; }
+            a.occPos[base + out] = strand == 1u ? pos : pos - ext;
+            a.occMeta[base + out] = strand | (uint32_t)tot << 8;
+            out++;
+            if (pre == a.minSeedMis && out >= a.maxHit) break;
+        }
+    }
+    if (out > a.maxHit) out = a.maxHit;                                  // origHitLimit, CPUfunctions.cpp:1838
+    a.outOccCount[r] = out;
+    if (out == 0) {
+        a.outPhase[r] = 0;
+        if (a.carryOn) a.selFlags[slot] = 1;
+    }
+}
+
 // decode + publish the slots whose state == want; the occurrence region is appended at *dOccBase
-static int decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive, uint8_t want, uint8_t phase, uint32_t maxOut, uint8_t selectWhen)
+struct LongArgs { bool on; int onlyBest, minSeedMis, needMapq; uint32_t maxHit; int carryOn; };
+
+static int decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive, uint8_t want, uint8_t phase, uint32_t maxOut, uint8_t selectWhen,
+                            const LongArgs &lg)
 {
     if (!nActive) return S3_OK;
     const unsigned g = (nActive + 1 + 255) / 256;
     hipLaunchKernelGGL(maskKernel, dim3(g), dim3(256), 0, b->stream, nActive, b->dState, want, b->dOccCounts, b->dMasked, b->dSelFlags, selectWhen);
     size_t tb = b->tempBytes;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dMasked, b->dOccOffsets, (int)(nActive + 1), b->stream));
+    uint32_t added = 0;
+    HIPCHK(hipMemcpyAsync(&added, b->dOccOffsets + nActive, 4, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if ((uint64_t)b->occUsed + added > b->occCap) {
+        int rc = growOccurrences(b, (uint64_t)b->occUsed + added);
+        if (rc) return rc;
+    }
     const uint32_t base = b->occUsed;
     hipLaunchKernelGGL(publishKernel, dim3((nActive + 255) / 256), dim3(256), 0, b->stream, nActive, active, b->dState, want, phase, b->dWithError,
                        b->dOccOffsets, base, b->dPhase, b->dFinalWithError, b->dOccStart, b->dOccCount);
@@ -457,10 +641,15 @@ static int decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActiv
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     m.decodeMask = b->dState; m.decodeWant = want;
     launchDecode(m, b->ix->d, b->dOccOffsets, base, b->occCap, b->dOccPos, b->dOccMeta, b->dFlags, b->stream);
-    uint32_t added = 0;
-    HIPCHK(hipMemcpyAsync(&added, b->dOccOffsets + nActive, 4, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
-    if ((uint64_t)b->occUsed + added > b->occCap) return fail(S3_EOVERFLOW, "occurrence buffer overflow: raise S3DP_OCC_PER_READ");
+    if (lg.on) {
+        ValidateArgs v{};
+        v.nActive = nActive; v.active = active; v.state = b->dState; v.want = want; v.occOffsets = b->dOccOffsets; v.occBase = base;
+        v.occPos = b->dOccPos; v.occMeta = b->dOccMeta; v.readsT = b->dReadsT; v.wpq = b->wpq; v.lens = b->dLens; v.seedLens = b->dSeedLens;
+        v.text = b->ix->d.pac; v.textLength = b->ix->d.n;
+        v.onlyBest = lg.onlyBest; v.minSeedMis = lg.minSeedMis; v.needMapq = lg.needMapq; v.maxHit = lg.maxHit; v.carryOn = lg.carryOn;
+        v.outPhase = b->dPhase; v.outOccCount = b->dOccCount; v.selFlags = b->dSelFlags;
+        hipLaunchKernelGGL(validateKernel, dim3((nActive + 255) / 256), dim3(256), 0, b->stream, v);
+    }
     b->occUsed += added;
     return S3_OK;
 }
@@ -491,16 +680,19 @@ extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t
     HIPCHK(hipMemsetAsync(b->dNumSel, 0, 16, b->stream));
     const uint32_t last = (bestMode || allValid) ? numMismatch : (numMismatch > 0 ? numMismatch : 1);   // alignment.cu:1439
     const uint32_t first = bestMode ? 0u : (allValid ? numMismatch : 1u);
+    const uint32_t searchLimit = b->longMode ? 0xFFFFFFFFu : maxOutputPerRead;
     const uint32_t *active = nullptr;
     uint32_t nActive = n;
     int pp = 0;
     for (uint32_t mm = first; mm <= last && nActive > 0; mm++) {
         const bool terminal = mm >= numMismatch;
-        int rc = searchPass(b, active, nActive, mm, maxOutputPerRead);
+        // long-read mode lifts the hit limit during the search (CPUfunctions.cpp:1655-1656) and applies it after the verification
+        LongArgs lg{b->longMode, bestMode ? 1 : 0, bestMode ? (int)mm : 0, bestMode ? 0 : 1, maxOutputPerRead, terminal ? 0 : 1};
+        int rc = searchPass(b, active, nActive, mm, searchLimit);
         if (rc) return rc;
         // MAPQ special case needs the (mm+1) model, which exists only for mm < 4 (CPUfunctions.cpp:1756)
         launchClassify(nActive, b->dTotalOcc, b->dWithError, mm, (!bestMode && mm < 4) ? 1u : 0u, b->dState, b->stream);
-        rc = decodeAndPublish(b, active, nActive, 1, (uint8_t)(bestMode ? mm + 1 : mm), maxOutputPerRead, terminal ? 2 : 0);
+        rc = decodeAndPublish(b, active, nActive, 1, (uint8_t)(bestMode ? mm + 1 : mm), searchLimit, terminal ? 2 : 0, lg);
         if (rc) return rc;
         // reads that go on: no hit or best == mm (non terminal: next phase; terminal: state 2 re-searched with mm+1 model)
         const uint32_t *idsIn = active;
@@ -518,10 +710,10 @@ extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t
             if (!bestMode && mm < 4 && nNext > 0) {
                 // ProcessOneMoreMismatchAllCases (CPUfunctions.cpp:624, called at :1790): the read is re-searched with the
                 // (mm+1)-mismatch model and THAT result is what gets reported
-                rc = searchPass(b, nextList, nNext, mm + 1, maxOutputPerRead);
+                rc = searchPass(b, nextList, nNext, mm + 1, searchLimit);
                 if (rc) return rc;
                 hipLaunchKernelGGL(stateAllKernel, dim3((nNext + 255) / 256), dim3(256), 0, b->stream, nNext, b->dTotalOcc, b->dState);
-                rc = decodeAndPublish(b, nextList, nNext, 1, (uint8_t)mm, maxOutputPerRead, 0);
+                rc = decodeAndPublish(b, nextList, nNext, 1, (uint8_t)mm, searchLimit, 0, lg);
                 if (rc) return rc;
             }
             break;

@@ -37,7 +37,8 @@ struct SearchIn {
     const uint32_t *readLengths;
     const uint32_t *active;      // optional indirection: slot -> read index
     uint32_t        nActive;
-    uint32_t        wpq;
+    uint32_t        wpq;         // words per read in `queries` / `readsT` (stride)
+    uint32_t        wpqLoad;     // words per read the search needs (covers the longest searched length; power of two, <= wpq)
     const S3Model  *models;      // indexed by read length, for this phase's mismatch budget
     int             nCases;
     uint32_t        maxOut;

@@ -335,9 +335,9 @@ searchKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint32_t *src = in.queries + (size_t)(r >> 5) * 32u * in.wpq + (r & 31u);
         uint32_t *dst = shRead + threadIdx.x;
         if (strandIdx == 0) {
-            for (uint32_t w = 0; w < in.wpq; w++) dst[w * blockDim.x] = src[(size_t)w * 32u];
+            for (uint32_t w = 0; w < in.wpqLoad; w++) dst[w * blockDim.x] = src[(size_t)w * 32u];
         } else {
-            for (uint32_t w = 0; w < in.wpq; w++) dst[w * blockDim.x] = 0;
+            for (uint32_t w = 0; w < in.wpqLoad; w++) dst[w * blockDim.x] = 0;
             for (uint32_t p = 0; p < len; p++) {                 // reverse complement, 3 - c (DV-Kernel.h:35)
                 const uint32_t q = len - 1u - p;
                 const uint32_t c = 3u - ((src[(size_t)(q >> 4) * 32u] >> ((q & 15u) * 2u)) & 3u);
@@ -519,7 +519,7 @@ void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, 
     if (nItems == 0) return;
     uint64_t blocks = (nItems + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
-    const size_t lds = (size_t)in.wpq * 4u * S3_SEARCH_BLOCK;
+    const size_t lds = (size_t)in.wpqLoad * 4u * S3_SEARCH_BLOCK;
     hipLaunchKernelGGL(searchKernel, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
 }
 

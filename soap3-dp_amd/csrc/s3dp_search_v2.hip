@@ -123,7 +123,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 {
     extern __shared__ __align__(16) unsigned char shmem[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t wpq = in.wpq;
+    const uint32_t wpq = in.wpqLoad, wpqStride = in.wpq;
     const uint32_t waveBytes = 4096u + wpq * 256u;
     unsigned char *wbase = shmem + S3_V2_MODEL_BYTES + wv * waveBytes;
     uint4 *stage = (uint4 *)wbase;                                          // [64 owners][4 x 16 B]
@@ -334,7 +334,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 aP1 = line + (iR > (kR << 7) ? 2 : 1);
             }
         } else if (state == ST_LOAD) {
-            const uint4 *src = (const uint4 *)(in.readsT + (size_t)rIdx * wpq + loadOff);      // wpq is a power of two
+            const uint4 *src = (const uint4 *)(in.readsT + (size_t)rIdx * wpqStride + loadOff);  // both are powers of two
             aP0 = src;
             if (wpq - loadOff > 4) aP1 = src + 1;
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
@@ -572,7 +572,11 @@ void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out
     if (in.nActive == 0) return;
     uint64_t blocks = ((uint64_t)in.nActive + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
-    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + in.wpq * 256u);
+    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + in.wpqLoad * 256u);
+    if (lds > 48u * 1024u) {
+        (void)hipFuncSetAttribute((const void *)searchKernelV2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)searchKernelV2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (in.uniformLen) hipLaunchKernelGGL(searchKernelV2<true>, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
     else hipLaunchKernelGGL(searchKernelV2<false>, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
 }

@@ -351,10 +351,11 @@ static int mdString(const HostIndex &ix, const uint8_t *query, const char *qual,
 // mismatches (0..5) x average mismatch quality class: fraction of MaxMAPQ (the reference's mapping_score table, BGS-IO.cpp:33)
 static const double kMappingScore[6][2] = {{1.0, 1.0}, {0.875, 0.85}, {0.75, 0.7}, {0.625, 0.55}, {0.475, 0.4}, {0.325, 0.25}};
 
-void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, const uint8_t *strand, const uint8_t *mis, size_t nOcc)
+void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, const uint8_t *strand, const uint8_t *mis, size_t nOcc, uint32_t checkLen)
 {
     if (nOcc == 0) { unaligned(rs, r); return; }
-    const uint32_t readLen = rs.lengths[r];
+    const uint32_t fullLen = rs.lengths[r];
+    const uint32_t readLen = checkLen ? checkLen : fullLen;             // boundary check + XA CIGAR length
     // best hit = first hit with the fewest mismatches (BGS-IO.cpp:5590-5610)
     size_t best = 0;
     uint32_t bestMis = mis[0];
@@ -408,7 +409,7 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
     const uint8_t *codes = &rs.codes[(size_t)r * rs.maxReadLength];
     const char *quals = &rs.quals[(size_t)r * rs.maxReadLength];
     // bestMis == 9999 cannot reach here: a hit is always chosen
-    const int mdLen = mdString(ix, codes, quals, readLen, pos[best], negative, (int)mis[best], boundTrim, md, avgQual);
+    const int mdLen = mdString(ix, codes, quals, fullLen, pos[best], negative, (int)mis[best], boundTrim, md, avgQual);
     uint32_t outMis = mis[best];
     if (boundTrim && outMis) {                                            // :5706-5712
         outMis = 0;
@@ -440,7 +441,7 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
     line.push_back('\t');
     line += std::to_string(mapq);
     line.push_back('\t');
-    if (!newCigar.empty()) line += newCigar; else { line += std::to_string(readLen); line.push_back('M'); }
+    if (!newCigar.empty()) line += newCigar; else { line += std::to_string(fullLen); line.push_back('M'); }
     line += "\t*\t0\t0\t";
     seqAndQual(rs, r, negative, line);
     line += "\tRG:Z:" + opt.readGroup;

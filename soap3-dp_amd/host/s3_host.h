@@ -57,7 +57,9 @@ public:
     SamWriter(const HostIndex &ix, const SamOptions &opt, FILE *out);
     void header();
     // one read of the single-end path: occurrence list in the CPU path's final order (OCCOutputSAMAPI, BGS-IO.cpp:5556)
-    void singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, const uint8_t *strand, const uint8_t *mis, size_t nOcc);
+    // checkLen: the length the reference hands to the boundary check and writes into the XA:Z CIGARs -- the SEARCHED length, i.e. the
+    // seed length in long-read mode (hostKernel passes its local readLength, CPUfunctions.cpp:1684,1938); 0 = the read length
+    void singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, const uint8_t *strand, const uint8_t *mis, size_t nOcc, uint32_t checkLen = 0);
     // unique-best / random-best record: one hit, X0 = 1, no X1, no XA, no boundary check (SingleAnsOutputSAMAPI, BGS-IO.cpp:5774)
     void singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_t strand, uint8_t mis);
     void unaligned(const ReadSet &rs, uint32_t r);       // noAnsOutputSAMAPI, BGS-IO.cpp:5829

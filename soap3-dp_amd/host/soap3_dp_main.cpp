@@ -70,7 +70,6 @@ int main(int argc, char **argv)
     if (outputFormat != 2) return die("only SAM output (-b 2) is built");
     if (alignmentType < 1 || alignmentType > 4) return die("The output option should be 1, 2, 3 or 4");
     if (maxReadLength > S3_MAX_READ_LENGTH) return die("The length should not be greater than 1024");
-    if (maxReadLength > 120) return die("long-read mode (reads > 120 bp) is not built yet");
     if (readGroup.empty()) readGroup = queryFile;
     if (sampleName.empty()) sampleName = "default";
     std::string err;
@@ -101,6 +100,13 @@ int main(int argc, char **argv)
     for (uint32_t first = 0; first < rs.n; first += maxBatch) {
         const uint32_t cnt = rs.n - first < maxBatch ? rs.n - first : maxBatch;   // first is a multiple of 32
         if (s3_batch_upload(b, rs.queries.data() + (size_t)first * rs.wpq, rs.lengths.data() + first, cnt) != S3_OK) return die(s3_last_error());
+        // reads longer than 120 bases: only the first 100 are searched, the rest is verified on the device (alignment.cu:2473-2491)
+        std::vector<uint32_t> seeds;
+        if (maxReadLength > 120) {
+            seeds.resize(cnt);
+            for (uint32_t k = 0; k < cnt; k++) seeds[k] = rs.lengths[first + k] > 120 ? 100u : rs.lengths[first + k];
+            if (s3_batch_set_seed_lengths(b, seeds.data()) != S3_OK) return die(s3_last_error());
+        }
         if (s3_batch_align_single(b, (uint32_t)numMismatch, ini.maxOutputPerRead, alignmentType) != S3_OK) return die(s3_last_error());
         std::vector<uint8_t> phase(cnt);
         std::vector<uint64_t> offs((size_t)cnt + 1);
@@ -118,7 +124,7 @@ int main(int argc, char **argv)
                 continue;
             }
             if (m) aligned++;
-            sam.singleEnd(rs, first + k, pos.data() + o, strand.data() + o, mis.data() + o, m);
+            sam.singleEnd(rs, first + k, pos.data() + o, strand.data() + o, mis.data() + o, m, seeds.empty() ? 0u : seeds[k]);
         }
     }
     fclose(out);

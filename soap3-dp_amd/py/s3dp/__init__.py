@@ -35,7 +35,7 @@ class Counters(C.Structure):
 
 
 EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
-           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_fetch_alignments", "s3_batch_sync",
+           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_fetch_alignments", "s3_batch_sync",
            "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather"]
 
@@ -260,6 +260,16 @@ class Batch:
 
     def align_single_allbest(self, mm, max_out=1000):
         _chk(lib().s3_batch_align_single_allbest(self.h, mm, max_out))
+
+    def set_seed_lengths(self, seed_lengths):
+        """long-read mode (reference: seedLengths of all_valid_alignment); None switches it off"""
+        f = lib().s3_batch_set_seed_lengths
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        if seed_lengths is None:
+            _chk(f(self.h, None))
+            return
+        a = np.ascontiguousarray(seed_lengths, dtype=np.uint32)
+        _chk(f(self.h, a.ctypes.data))
 
     def align_single(self, mm, max_out=1000, report_type=2):
         f = lib().s3_batch_align_single

@@ -12,7 +12,7 @@ def build(force=False):
     src = os.path.join(ROOT, "oracle", "s3_oracle.c")
     src2 = os.path.join(ROOT, "oracle", "s3_oracle_dp.c")
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(src2)):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", LIB, src, os.path.join(ROOT, "oracle", "s3_oracle_dp.c")])
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", LIB, src, os.path.join(ROOT, "oracle", "s3_oracle_dp.c"), "-lm"])
     return LIB
 
 
@@ -131,20 +131,24 @@ class Index:
                 return hits[:rc], offs, tot, werr, st
             hit_cap *= 4
 
-    def align_single_allbest(self, queries, read_lengths, wpq, mm, max_out=1000, occ_cap=None, first=0, count=None, report_type=2):
+    def align_single_allbest(self, queries, read_lengths, wpq, mm, max_out=1000, occ_cap=None, first=0, count=None, report_type=2, seed_lengths=None):
         n_all = len(read_lengths)
         queries = np.ascontiguousarray(queries, dtype=np.uint32)
         read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
         n = n_all if count is None else count
         assert first % 32 == 0
-        f = lib().s3o_align_single
+        f = lib().s3o_align_single_long
         f.restype = C.c_long
-        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Stats)]
         if occ_cap is None:
             occ_cap = max(4096, 32 * n)
         qptr = queries.ctypes.data + first * wpq * 4
         lptr = read_lengths.ctypes.data + first * 4
+        sptr = None
+        if seed_lengths is not None:
+            seed_lengths = np.ascontiguousarray(seed_lengths, dtype=np.uint32)
+            sptr = seed_lengths.ctypes.data + first * 4
         while True:
             phase = np.zeros(n, dtype=np.uint8)
             werr = np.zeros((n, 8), dtype=np.uint32)
@@ -153,7 +157,7 @@ class Index:
             strand = np.zeros(occ_cap, dtype=np.uint8)
             nmis = np.zeros(occ_cap, dtype=np.uint8)
             st = Stats()
-            rc = f(self.h, qptr, lptr, n, wpq, mm, max_out, report_type, phase.ctypes.data, werr.ctypes.data, offs.ctypes.data,
+            rc = f(self.h, qptr, lptr, sptr, n, wpq, mm, max_out, report_type, phase.ctypes.data, werr.ctypes.data, offs.ctypes.data,
                    pos.ctypes.data, strand.ctypes.data, nmis.ctypes.data, occ_cap, C.byref(st))
             if rc >= 0:
                 return phase, werr, offs, pos[:rc], strand[:rc], nmis[:rc], st

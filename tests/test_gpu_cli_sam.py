@@ -49,3 +49,24 @@ def test_cli_sam_matches_reference_cpu_path(tmp_path, name, maxlen, variant, opt
     bad = [(k, ref[k], mine[k]) for k in ref if ref[k] != mine[k]]
     assert not bad, "first differing record:\n%s\n%s" % (bad[0][1], bad[0][2])
     assert os.path.exists(tmp_path / "out.done")
+
+
+# long-read mode: -L 200, reads of 121..200 bases
+LONG_VARIANTS = [("s3", ["-s", "3"]), ("s1", ["-s", "1", "-p"]), ("h1_s2", ["-s", "2", "-h", "1"]), ("h3_s2", ["-s", "2", "-h", "3"]),
+                 ("h4_s3", ["-s", "3", "-h", "4"])]
+
+
+@pytest.mark.parametrize("variant,opts", LONG_VARIANTS)
+def test_cli_sam_long_read_mode(tmp_path, variant, opts):
+    name = "g3"
+    fq = tmp_path / (name + ".fq")
+    shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), fq)
+    out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", "200"] + opts + ["-b", "2", "-o", "out"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    mine_h, mine = sam_records(open(tmp_path / "out.gout.1").read())
+    ref_h, ref = sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_%s.sam.gz" % variant), "rt").read())
+    assert mine_h == ref_h
+    assert set(mine) == set(ref)
+    bad = [(k, ref[k], mine[k]) for k in ref if ref[k] != mine[k]]
+    assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][1], bad[0][2])

@@ -105,3 +105,55 @@ def test_report_type_ladders_match_oracle(name, maxlen, report_type, mm):
             assert (mis[offs[r]:offs[r + 1]].astype(int) == int(phase[r]) - 1).all()
     oix.close()
     b.close()
+
+
+@pytest.mark.parametrize("report_type,mm", [(2, 3), (2, 1), (1, 2), (3, 2), (4, 3)])
+def test_long_read_mode_matches_oracle(report_type, mm):
+    """reads of 121..200 bases (-L 200): the first 100 bases are searched without a hit limit, the rest is verified on the device"""
+    name, maxlen = "g3", 200
+    reads = golden_reads(name)
+    q, lens, wpq = s3dp.pack_reads(reads, maxlen)
+    assert wpq == 16
+    seeds = np.where(lens > 120, 100, lens).astype(np.uint32)
+    b = s3dp.Batch(dev_index(name), len(reads), wpq)
+    b.upload(q, lens)
+    b.set_seed_lengths(seeds)
+    b.align_single(mm, 1000, report_type)
+    phase, werr, offs, pos, strand, mis = b.fetch_alignments()
+    oix = s3o.Index(host_index=host_index(name))
+    ophase, owerr, ooffs, opos, ostrand, omis, st = oix.align_single_allbest(q, lens, wpq, mm, 1000, report_type=report_type, seed_lengths=seeds)
+    assert (phase == ophase).all()
+    assert (offs == ooffs).all()
+    assert (pos == opos).all() and (strand == ostrand).all() and (mis == omis).all()
+    assert (offs[1:] - offs[:-1]).max() > 1 and phase.max() > 0
+    # the same batch without seeds must still behave as a plain batch afterwards
+    b.set_seed_lengths(None)
+    oix.close()
+    b.close()
+
+
+def test_buffers_grow_instead_of_overflowing(monkeypatch):
+    """record and occurrence buffers start tiny (env) and must grow transparently: same result as the oracle"""
+    monkeypatch.setenv("S3DP_REC_PER_READ", "0")
+    monkeypatch.setenv("S3DP_REC_FLOOR", "0")
+    monkeypatch.setenv("S3DP_OCC_PER_READ", "0")
+    name, maxlen, mm, copies = "g2", 120, 3, 8
+    one = golden_reads(name)
+    n1 = len(one)
+    assert n1 % 32 != 0                                   # copies do not line up with the 32-read interleave: pack them all
+    q, lens, wpq = s3dp.pack_reads(one * copies, maxlen)
+    b = s3dp.Batch(dev_index(name), n1 * copies, wpq)
+    b.upload(q, lens)
+    b.align_single(mm, 1000, 2)
+    phase, werr, offs, pos, strand, mis = b.fetch_alignments()
+    q1, lens1, _ = s3dp.pack_reads(one, maxlen)
+    oix = s3o.Index(host_index=host_index(name))
+    ophase, owerr, ooffs, opos, ostrand, omis, st = oix.align_single_allbest(q1, lens1, wpq, mm, 1000)
+    assert (phase.reshape(copies, n1) == ophase).all()
+    assert ((offs[1:] - offs[:-1]).reshape(copies, n1) == (ooffs[1:] - ooffs[:-1])).all()
+    assert int(offs[-1]) == copies * len(opos) and int(offs[-1]) > 65536 * 2
+    for c in (0, copies - 1):
+        lo, hi = int(offs[c * n1]), int(offs[(c + 1) * n1])
+        assert (pos[lo:hi] == opos).all() and (strand[lo:hi] == ostrand).all() and (mis[lo:hi] == omis).all()
+    oix.close()
+    b.close()

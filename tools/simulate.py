@@ -105,11 +105,12 @@ def main():
     ap.add_argument("--read-seed", type=int, default=2026)
     ap.add_argument("--fastq", default=None)
     ap.add_argument("--truth", default=None)
+    ap.add_argument("--mix", type=float, nargs="+", default=None, help="weights of 0,1,2,... substitutions per read")
     a = ap.parse_args()
     chroms = make_genome(a.genome_len, a.chroms, a.n_runs, a.genome_seed, a.repeats)
     write_fasta(a.fasta, chroms)
     if a.reads:
-        reads, truth = make_reads(chroms, a.reads, a.read_len, a.read_seed, var_len=a.var_len)
+        reads, truth = make_reads(chroms, a.reads, a.read_len, a.read_seed, var_len=a.var_len, **({"mix": tuple(a.mix)} if a.mix else {}))
         write_fastq(a.fastq, reads)
         if a.truth:
             with open(a.truth, "w") as f:
