@@ -119,6 +119,35 @@ int  s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError 
                                uint64_t *occOffsets /* n+1 */, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis,
                                size_t occCap, uint64_t *nOccOut);
 
+/* ---- paired-end reads, DP stages off (`soap3-dp pair <index> <r1> <r2> -u <max insert> -v <min insert> -s k`) -------------------------
+ * Reads 2p and 2p+1 of the batch are the two ends of pair p (the interleaving loadPairReadsGz2 produces, QueryParser.cpp:177).
+ * s3_batch_align_pair replaces soap3_dp_pair_align's ladders with DP disabled (alignment.cu:1965-2013: all_best_alignment :1236 = phases
+ * 1, 2, k for -h 2; four_phases_alignment :1119 = phases 0, 1, 2, k for -h 3/4; one all_valid_alignment pass for -h 1), the PAIR_END_READ
+ * branch of hostKernel (CPUfunctions.cpp:1980-2560: deferral of a pair whose first end's best hit has exactly the phase's mismatches,
+ * the extra (mm+1) search of such an end, the carry-over of pairs without a proper pairing) and the pairing itself
+ * (PEMappingOccurrences + PEStatsPEOutput, PEAlgnmt.cpp:480,834): '+' left leg, '-' right leg,
+ * insertLow <= right.pos + len(2nd end) - left.pos <= insertHigh.  maxHitsPerEnd is the ini's MaxHitsEachEndForPairing
+ * (CPUfunctions.cpp:845), peMaxOutputPerPair its MaxOutputPerPair. */
+typedef struct {
+    uint8_t  phase;               /* 0: no proper pairing (the occurrence lists of both ends are returned); else pairing phase + 1 */
+    uint8_t  min1, min2;          /* fewest mismatches of each end in that phase (255: end without hit, or -h 3/4) */
+    uint8_t  minTotal, secMinTotal;   /* mismatch sum of the optimal pair / of the last demoted optimal (127: none), PEStatsPEPairList */
+    uint8_t  bestS1, bestS2, bestM1, bestM2;   /* the optimal pair: strand (1 '+', 2 '-') and mismatches of each end */
+    uint8_t  pad[3];
+    uint32_t x0_1, x1_1, x0_2, x1_2;  /* WithError[min], WithError[min + 1] of each end: X0 / X1 (-h 1/2) */
+    uint32_t numPairs, numMin;    /* valid pairings; pairings with the optimal mismatch sum */
+    uint32_t bestA1, bestA2;      /* the optimal pair: text position of each end */
+} s3_pair_result;
+typedef struct { uint32_t a1, a2; uint8_t s1, s2, m1, m2; } s3_pair_xa;   /* one more pairing with the optimal mismatch sum (XA:Z) */
+
+int  s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t maxHitsPerEnd, int reportType, uint32_t insertLow, uint32_t insertHigh,
+                         uint32_t peMaxOutputPerPair);
+/* pairs[n/2]; xaOffsets[n/2 + 1] + xa[]: the other optimal pairings in pairing order, at most peMaxOutputPerPair - 1 per pair;
+ * occOffsets[n + 1] + occ arrays: occurrence lists of the reads of pairs with phase == 0, in the order unproperlypairOutputSAMAPI
+ * (BGS-IO.cpp:2582) walks them (sorted by position when both ends had hits).  Any output pointer may be NULL. */
+int  s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t *xaOffsets, s3_pair_xa *xa, size_t xaCap, uint64_t *nXa,
+                          uint64_t *occOffsets, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis, size_t occCap, uint64_t *nOcc);
+
 int  s3_batch_sync(s3_batch *b);
 /* device time of the work enqueued by the last search/align call, measured with HIP events on the batch stream;
  * searchMs = time inside the BWT-search kernels only. */

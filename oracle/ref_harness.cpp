@@ -136,6 +136,39 @@ static Reads loadReads ( const char * fileName, unsigned char * charMap, uint ma
     return R;
 }
 
+// paired-end input: mates interleaved (read 2k from file 1, read 2k+1 from file 2), as SOAP3-DP.cu feeds loadPairReadsGz2
+static Reads loadPairs ( const char * fileName, const char * fileName2, unsigned char * charMap, uint maxReadLength, int maxLenReadName, uint maxNumQueries )
+{
+    Reads R;
+    R.maxReadLength = maxReadLength;
+    uint wpq = 1;
+
+    while ( wpq < maxReadLength ) { wpq *= 2; }
+
+    R.wordPerQuery = wpq / CHAR_PER_WORD;
+    size_t roundUp = ( ( size_t ) maxNumQueries + 31 ) / 32 * 32;
+    R.queries = ( uint * ) calloc ( roundUp * R.wordPerQuery, sizeof ( uint ) );
+    R.readLengths = ( uint * ) calloc ( roundUp, sizeof ( uint ) );
+    R.readIDs = ( uint * ) calloc ( roundUp, sizeof ( uint ) );
+    R.upkdQualities = ( char * ) calloc ( roundUp * maxReadLength, 1 );
+    R.upkdQueryNames = ( char * ) calloc ( roundUp * maxLenReadName, 1 );
+    gzFile gz = gzopen ( fileName, "r" ), gz2 = gzopen ( fileName2, "r" );
+
+    if ( gz == NULL || gz2 == NULL ) { fprintf ( stderr, "cannot open %s / %s\n", fileName, fileName2 ); exit ( 1 ); }
+
+    char * buf = ( char * ) malloc ( INPUT_BUFFER_SIZE ), * buf2 = ( char * ) malloc ( INPUT_BUFFER_SIZE );
+    size_t bufferSize = gzread ( gz, buf, INPUT_BUFFER_SIZE ), bufferSize2 = gzread ( gz2, buf2, INPUT_BUFFER_SIZE );
+    uint bufferIndex = 0, bufferIndex2 = 0;
+    char queryChar = buf[bufferIndex++], queryChar2 = buf2[bufferIndex2++];
+    R.isFastq = 0;
+    R.numQueries = loadPairReadsGz2 ( gz, buf, gz2, buf2, charMap, R.queries, R.readLengths, R.readIDs, R.upkdQualities, R.upkdQueryNames,
+                                      maxReadLength, maxNumQueries, bufferSize, queryChar, bufferIndex, bufferSize2, queryChar2, bufferIndex2,
+                                      0, R.wordPerQuery, DEFAULT_QUAL_CONST, R.isFastq, maxLenReadName );
+    gzclose ( gz ); gzclose ( gz2 );
+    free ( buf ); free ( buf2 );
+    return R;
+}
+
 static void initHspAux ( Soap3Index * index, IniParams & ini, InputOptions & opt, size_t roundUp )
 {
     HSPAux * hspaux = index->sraIndex->hspaux;
@@ -503,7 +536,7 @@ static int modeSam ( int argc, char ** argv )
 
     if ( !parseInputArgs ( argc - 2, argv + 2, C.opt ) ) { return 1; }
 
-    if ( C.opt.readType != SINGLE_READ ) { fprintf ( stderr, "harness: single-end only\n" ); return 1; }
+    const bool paired = C.opt.readType == PAIR_END_READ;
 
     if ( C.opt.enableDP == 1 ) { C.opt.numMismatch = C.ini.Ini_Soap3MisMatchAllow; }
 
@@ -513,7 +546,8 @@ static int modeSam ( int argc, char ** argv )
     initHspAux ( C.index, C.ini, C.opt, roundUp );
     HSP * hsp = C.index->sraIndex->hsp;
     HSPAux * hspaux = C.index->sraIndex->hspaux;
-    Reads R = loadReads ( C.opt.queryFileName, C.index->charMap, C.opt.maxReadLength, C.ini.Ini_maxReadNameLen, maxNumQueries );
+    Reads R = paired ? loadPairs ( C.opt.queryFileName, C.opt.queryFileName2, C.index->charMap, C.opt.maxReadLength, C.ini.Ini_maxReadNameLen, maxNumQueries )
+              : loadReads ( C.opt.queryFileName, C.index->charMap, C.opt.maxReadLength, C.ini.Ini_maxReadNameLen, maxNumQueries );
     hspaux->isFastq = R.isFastq;
     fprintf ( stderr, "[harness] %u reads loaded, numMismatch=%d alignmentType=%d enableDP=%d outputFormat=%d\n", R.numQueries, C.opt.numMismatch,
               C.opt.alignmentType, ( int ) C.opt.enableDP, C.opt.outputFormat );
@@ -537,7 +571,34 @@ static int modeSam ( int argc, char ** argv )
     uint totalAligned = 0;
     double t0 = setStartTime ();
 
-    if ( C.opt.alignmentType == OUTPUT_ALL_BEST )
+    if ( paired )
+    {
+        // soap3_dp_pair_align with DP disabled (alignment.cu:1965-2013): all-best + SAM = all_best_alignment (phases 1, 2, k; :1236-1376),
+        // unique / random best = four_phases_alignment (phases 0, 1, 2, k; :1119-1234), all valid = one pass at k
+        uint nm = C.opt.numMismatch;
+        std::vector<uint> phases;
+
+        if ( C.opt.alignmentType == OUTPUT_ALL_BEST ) { phases.push_back ( 1 ); if ( nm > 1 ) { phases.push_back ( 2 ); } if ( nm > 2 ) { phases.push_back ( nm ); } }
+        else if ( C.opt.alignmentType == OUTPUT_ALL_VALID ) { phases.push_back ( nm ); }
+        else { phases.push_back ( 0 ); if ( nm > 0 ) { phases.push_back ( 1 ); } if ( nm > 1 ) { phases.push_back ( 2 ); } if ( nm > 2 ) { phases.push_back ( nm ); } }
+
+        for ( size_t ph = 0; ph < phases.size (); ph++ )
+        {
+            unsigned long long a = 0;
+            uint b = 0;
+            bool last = ph + 1 == phases.size ();
+            // the terminal flags of the reference: phase 1 is terminal when numMismatch <= 1 (all best), phase p when numMismatch == p
+            allValid ( C, R, R.queries, R.readLengths, NULL, R.readIDs, numQueries, phases[ph], unAligned, numUn, a, b, last );
+            totalAns += a;
+            totalAligned += b;
+
+            if ( last || b >= numQueries ) { break; }
+
+            packUnPairedReads ( R.queries, R.readIDs, R.readLengths, unAligned, R.wordPerQuery, numUn, 1 << 20 );
+            numQueries = numUn;
+        }
+    }
+    else if ( C.opt.alignmentType == OUTPUT_ALL_BEST )
     {
         // all_best_single_alignment, alignment.cu:1422-1465
         uint nm = C.opt.numMismatch;

@@ -167,9 +167,21 @@ struct s3_batch {
     uint8_t  *dPhase = nullptr;
     uint32_t *dFinalWithError = nullptr, *dOccStart = nullptr, *dOccCount = nullptr;
     uint32_t *dOutOffsets = nullptr, *dOutPos = nullptr, *dOutMeta = nullptr;
+    // paired-end ladder (allocated by the first s3_batch_align_pair)
+    bool pairReady = false;
+    DevPair  *dPairs = nullptr;
+    uint8_t  *dPairMin = nullptr, *dPairNext = nullptr;
+    uint32_t *dReadList = nullptr, *dPairActive[2] = {nullptr, nullptr}, *dBestIdx = nullptr, *dXaCount = nullptr, *dXaOffsets = nullptr;
+    uint32_t *dXaStart = nullptr, *dXaCountOut = nullptr, *dXaOutOffsets = nullptr, *dOccCountIn = nullptr, *dSegBegin = nullptr, *dSegEnd = nullptr;
+    DevPairXa *dXa = nullptr, *dXaOut = nullptr;
+    uint32_t xaCap = 0, xaUsed = 0;
+    uint64_t *dSortKeys[2] = {nullptr, nullptr};
+    uint32_t *dSortMeta = nullptr;
+    char     *dSortTemp = nullptr;
+    size_t    sortItems = 0, sortTempBytes = 0;
     std::vector<void *> allocs;
     // state of the last call
-    int lastKind = 0;              // 1 = search, 2 = align
+    int lastKind = 0;              // 1 = search, 2 = align (single), 3 = align (pairs)
     uint32_t lastNumCases = 0;
     bool counting = false;
     hipEvent_t evTotal[2] = {nullptr, nullptr};
@@ -283,8 +295,8 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
 #undef BA
     // scan / select scratch sized for the largest problem
     size_t t1 = 0, t2 = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, t1, b->dItemCounts, b->dItemOffsets, (int)(b->maxItems + 1), b->stream);
-    hipcub::DeviceSelect::Flagged(nullptr, t2, b->dIota, b->dSelFlags, b->dActive[0], b->dNumSel, (int)maxReads, b->stream);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, b->dItemCounts, b->dItemOffsets, (int)(b->maxItems + 1), b->stream);
+    (void)hipcub::DeviceSelect::Flagged(nullptr, t2, b->dIota, b->dSelFlags, b->dActive[0], b->dNumSel, (int)maxReads, b->stream);
     b->tempBytes = (t1 > t2 ? t1 : t2) + 256;
     if ((rc = balloc(b, &b->dTemp, b->tempBytes))) { s3_batch_free(b); return rc; }
     HIPCHK(hipEventCreate(&b->evTotal[0])); HIPCHK(hipEventCreate(&b->evTotal[1]));
@@ -756,6 +768,234 @@ extern "C" int s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *
         if (total > occCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_alignments: output arrays too small");
         if (occPos) HIPCHK(hipMemcpy(occPos, b->dOutPos, total * 4, hipMemcpyDeviceToHost));
         if (occStrand || occMis) {
+            std::vector<uint32_t> meta(total);
+            HIPCHK(hipMemcpy(meta.data(), b->dOutMeta, total * 4, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < total; i++) {
+                if (occStrand) occStrand[i] = (uint8_t)(meta[i] & 0xFF);
+                if (occMis) occMis[i] = (uint8_t)((meta[i] >> 8) & 0xFF);
+            }
+        }
+    }
+    return S3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// paired-end ladder with the DP stages off.  Replaces, for `soap3-dp pair ... -s k`:
+//   soap3_dp_pair_align's choice of ladder (alignment.cu:1965-2013), all_best_alignment (:1236, phases 1, 2, k),
+//   four_phases_alignment (:1119, phases 0, 1, 2, k), all_valid_alignment for pairs (:534), the PAIR_END_READ branch of hostKernel
+//   (CPUfunctions.cpp:1980-2560) and PEMappingOccurrences / PEStatsPEOutput (PEAlgnmt.cpp:480,834).
+// ---------------------------------------------------------------------------------------------
+__global__ void pairInitKernel(uint32_t n, DevPair *pairs)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    DevPair z{};
+    z.min1 = z.min2 = 255; z.minTotal = z.secMinTotal = 127;
+    pairs[p] = z;
+}
+
+static int ensurePairBuffers(s3_batch *b)
+{
+    if (b->pairReady) return S3_OK;
+    const size_t maxReads = b->maxReads, maxPairs = maxReads / 2 + 1;
+    int rc;
+#define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) return rc;
+    BA(dPairs, maxPairs); BA(dPairMin, maxReads + 2); BA(dPairNext, maxPairs); BA(dReadList, maxReads + 2);
+    BA(dPairActive[0], maxPairs); BA(dPairActive[1], maxPairs); BA(dBestIdx, maxPairs); BA(dXaCount, maxPairs + 1); BA(dXaOffsets, maxPairs + 1);
+    BA(dXaStart, maxPairs); BA(dXaCountOut, maxPairs + 1); BA(dXaOutOffsets, maxPairs + 1); BA(dOccCountIn, maxReads + 2);
+    BA(dSegBegin, maxReads + 2); BA(dSegEnd, maxReads + 2);
+    b->xaCap = (uint32_t)(maxPairs + 65536);
+    BA(dXa, b->xaCap); BA(dXaOut, b->xaCap);
+#undef BA
+    b->pairReady = true;
+    return S3_OK;
+}
+
+static int ensureSortBuffers(s3_batch *b, size_t items, int segments)
+{
+    int rc;
+    if (items > b->sortItems) {
+        const size_t cap = items + items / 2 + 1024;
+        if (b->sortItems == 0) {
+            if ((rc = balloc(b, &b->dSortKeys[0], cap)) || (rc = balloc(b, &b->dSortKeys[1], cap)) || (rc = balloc(b, &b->dSortMeta, cap))) return rc;
+        } else {
+            if ((rc = bgrow(b, &b->dSortKeys[0], cap, 0)) || (rc = bgrow(b, &b->dSortKeys[1], cap, 0)) || (rc = bgrow(b, &b->dSortMeta, cap, 0))) return rc;
+        }
+        b->sortItems = cap;
+    }
+    size_t tb = 0;
+    HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb, b->dSortKeys[0], b->dSortKeys[1], b->dOccMeta, b->dSortMeta, (int)items, segments,
+                                                       b->dSegBegin, b->dSegEnd, 0, 64, b->stream));
+    if (tb > b->sortTempBytes) {
+        const size_t cap = tb + tb / 2 + 256;
+        if (b->sortTempBytes == 0) { if ((rc = balloc(b, &b->dSortTemp, cap))) return rc; }
+        else if ((rc = bgrow(b, &b->dSortTemp, cap, 0))) return rc;
+        b->sortTempBytes = cap;
+    }
+    return S3_OK;
+}
+
+extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t maxHitsPerEnd, int reportType, uint32_t insertLow, uint32_t insertHigh,
+                                   uint32_t peMaxOutputPerPair)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    if (reportType < 1 || reportType > 4) return fail(S3_EINVAL, "reportType must be 1..4");
+    if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
+    if (maxHitsPerEnd == 0 || maxHitsPerEnd > 0xFFFFFFu) return fail(S3_EINVAL, "maxHitsPerEnd must be 1..16777215");
+    if (b->n & 1u) return fail(S3_EINVAL, "s3_batch_align_pair: the batch must hold an even number of reads (read 2p and 2p+1 are a pair)");
+    if (b->longMode) return fail(S3_EINVAL, "s3_batch_align_pair: seed lengths are a single-end feature");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    int rc = ensurePairBuffers(b);
+    if (rc) return rc;
+    const bool bestMode = reportType >= 3, mapq = !bestMode;
+    const uint32_t n = b->n, nPairs = n / 2;
+    b->searchLaunches = 0;
+    b->occUsed = 0;
+    b->xaUsed = 0;
+    b->recordsTotal = 0;
+    HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
+    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
+    HIPCHK(hipMemsetAsync(b->dPhase, 0, n ? n : 1, b->stream));
+    HIPCHK(hipMemsetAsync(b->dFinalWithError, 0, (size_t)(n ? n : 1) * 32, b->stream));
+    HIPCHK(hipMemsetAsync(b->dOccStart, 0, (size_t)(n ? n : 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dOccCount, 0, ((size_t)n + 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dXaStart, 0, ((size_t)nPairs + 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dXaCountOut, 0, ((size_t)nPairs + 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dPairMin, 255, n ? n : 1, b->stream));
+    HIPCHK(hipMemsetAsync(b->dNumSel, 0, 16, b->stream));
+    if (nPairs) hipLaunchKernelGGL(pairInitKernel, dim3((nPairs + 255) / 256), dim3(256), 0, b->stream, nPairs, b->dPairs);
+    uint32_t phases[4];
+    int nPhases = 0;
+    if (reportType == 2) { phases[nPhases++] = 1; if (numMismatch > 1) phases[nPhases++] = 2; if (numMismatch > 2) phases[nPhases++] = numMismatch; }
+    else if (reportType == 1) phases[nPhases++] = numMismatch;
+    else { phases[nPhases++] = 0; if (numMismatch > 0) phases[nPhases++] = 1; if (numMismatch > 1) phases[nPhases++] = 2; if (numMismatch > 2) phases[nPhases++] = numMismatch; }
+    const LongArgs noLong{false, 0, 0, 0, 0, 0};
+    const uint32_t *active = nullptr;
+    uint32_t nA = nPairs;
+    int pp = 0;
+    for (int ph = 0; ph < nPhases && nA > 0; ph++) {
+        const uint32_t mm = phases[ph];
+        const bool terminal = ph + 1 == nPhases;
+        launchPairExpand(nA, active, b->dReadList, b->stream);
+        rc = searchPass(b, b->dReadList, 2 * nA, mm, maxHitsPerEnd);
+        if (rc) return rc;
+        PairClassifyArgs ca{};
+        ca.nPairs = nA; ca.activePairs = active; ca.totalOcc = b->dTotalOcc; ca.withError = b->dWithError; ca.mm = mm; ca.maxHits = maxHitsPerEnd;
+        ca.terminal = terminal; ca.mapq = mapq; ca.slotState = b->dState; ca.pairNext = b->dPairNext; ca.pairMin = b->dPairMin; ca.occCount = b->dOccCount;
+        launchPairClassify(ca, b->stream);
+        const uint32_t regionBase = b->occUsed;
+        rc = decodeAndPublish(b, b->dReadList, 2 * nA, 1, 0, maxHitsPerEnd, 2, noLong);       // selFlags = ends to search again
+        if (rc) return rc;
+        if (mapq && mm < 4) {
+            size_t tb = b->tempBytes;
+            HIPCHK(hipcub::DeviceSelect::Flagged(b->dTemp, tb, b->dReadList, b->dSelFlags, b->dActive[0], b->dNumSel, (int)(2 * nA), b->stream));
+            uint32_t nR = 0;
+            HIPCHK(hipMemcpyAsync(&nR, b->dNumSel, 4, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+            if (nR) {
+                // ProcessOneMoreMismatchAllCases on that end; THAT result is what the pairing sees
+                rc = searchPass(b, b->dActive[0], nR, mm + 1, maxHitsPerEnd);
+                if (rc) return rc;
+                hipLaunchKernelGGL(stateAllKernel, dim3((nR + 255) / 256), dim3(256), 0, b->stream, nR, b->dTotalOcc, b->dState);
+                rc = decodeAndPublish(b, b->dActive[0], nR, 1, 0, maxHitsPerEnd, 0, noLong);
+                if (rc) return rc;
+            }
+        }
+        // position-sort both lists of every pair with hits on both ends (PERadixSort), then pair them up
+        const size_t items = (size_t)b->occUsed - regionBase;
+        PairSortArgs sa{};
+        sa.nPairs = nA; sa.activePairs = active; sa.pairNext = b->dPairNext; sa.occStart = b->dOccStart; sa.occCount = b->dOccCount;
+        sa.regionBase = regionBase; sa.occPos = b->dOccPos; sa.occMeta = b->dOccMeta; sa.segBegin = b->dSegBegin; sa.segEnd = b->dSegEnd;
+        if (items) {
+            rc = ensureSortBuffers(b, items, (int)(2 * nA));
+            if (rc) return rc;
+            sa.keys = b->dSortKeys[0];
+            launchPairSortKeys(sa, b->stream);
+            size_t tb = b->sortTempBytes;
+            HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(b->dSortTemp, tb, b->dSortKeys[0], b->dSortKeys[1], b->dOccMeta + regionBase, b->dSortMeta,
+                                                               (int)items, (int)(2 * nA), b->dSegBegin, b->dSegEnd, 0, 64, b->stream));
+            launchPairSortBack(sa, b->dSortKeys[1], b->dSortMeta, b->stream);
+        }
+        launchPairSnapshotCounts(nA, active, b->dOccCount, b->dOccCountIn, b->stream);
+        PairSweepArgs sw{};
+        sw.nPairs = nA; sw.activePairs = active; sw.pairNext = b->dPairNext; sw.pairMin = b->dPairMin; sw.finalWithError = b->dFinalWithError;
+        sw.occStart = b->dOccStart; sw.occCount = b->dOccCount; sw.occCountIn = b->dOccCountIn; sw.occPos = b->dOccPos; sw.occMeta = b->dOccMeta;
+        sw.readLengths = b->dLens; sw.insertLow = insertLow; sw.insertHigh = insertHigh; sw.peMaxOutputPerPair = peMaxOutputPerPair; sw.mm = mm;
+        sw.terminal = terminal; sw.pairs = b->dPairs; sw.bestIdx = b->dBestIdx; sw.xaCount = b->dXaCount; sw.xaStart = b->dXaStart; sw.xaCountOut = b->dXaCountOut;
+        launchPairStats(sw, b->stream);
+        HIPCHK(hipMemsetAsync(b->dXaCount + nA, 0, 4, b->stream));
+        size_t tb = b->tempBytes;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dXaCount, b->dXaOffsets, (int)(nA + 1), b->stream));
+        uint32_t xaAdded = 0;
+        HIPCHK(hipMemcpyAsync(&xaAdded, b->dXaOffsets + nA, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if ((uint64_t)b->xaUsed + xaAdded > b->xaCap) {
+            uint64_t cap = (uint64_t)b->xaCap * 2;
+            if (cap < (uint64_t)b->xaUsed + xaAdded) cap = (uint64_t)b->xaUsed + xaAdded + 65536;
+            if (cap > kMaxEntries) return fail(S3_EOVERFLOW, "pair list overflow at the 32-bit limit");
+            if ((rc = bgrow(b, &b->dXa, (size_t)cap, b->xaUsed)) || (rc = bgrow(b, &b->dXaOut, (size_t)cap, 0))) return rc;
+            b->xaCap = (uint32_t)cap;
+        }
+        launchPairEmit(sw, b->dXaOffsets, b->xaUsed, b->dXa, b->stream);
+        b->xaUsed += xaAdded;
+        if (terminal) break;
+        const uint32_t *idsIn = active;
+        if (!idsIn) {
+            hipLaunchKernelGGL(iotaKernel, dim3((nA + 255) / 256), dim3(256), 0, b->stream, b->dIota, nA);
+            idsIn = b->dIota;
+        }
+        tb = b->tempBytes;
+        uint32_t *nextList = b->dPairActive[pp];
+        HIPCHK(hipcub::DeviceSelect::Flagged(b->dTemp, tb, idsIn, b->dPairNext, nextList, b->dNumSel, (int)nA, b->stream));
+        uint32_t nNext = 0;
+        HIPCHK(hipMemcpyAsync(&nNext, b->dNumSel, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        active = nextList;
+        nA = nNext;
+        pp ^= 1;
+    }
+    // read-ordered CSR of the occurrence lists of the pairs without a proper pairing, pair-ordered CSR of the XA pairs
+    size_t tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dOccCount, b->dOutOffsets, (int)(n + 1), b->stream));
+    if (n) hipLaunchKernelGGL(gatherOccKernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, n, b->dOccStart, b->dOutOffsets, b->dOccPos, b->dOccMeta,
+                              b->dOutPos, b->dOutMeta);
+    tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dXaCountOut, b->dXaOutOffsets, (int)(nPairs + 1), b->stream));
+    launchPairGatherXa(nPairs, b->dXaStart, b->dXaOutOffsets, b->dXa, b->dXaOut, b->stream);
+    HIPCHK(hipEventRecord(b->evTotal[1], b->stream));
+    HIPCHK(hipGetLastError());
+    b->lastKind = 3;
+    return S3_OK;
+}
+
+extern "C" int s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t *xaOffsets, s3_pair_xa *xa, size_t xaCap, uint64_t *nXaOut,
+                                    uint64_t *occOffsets, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis, size_t occCap, uint64_t *nOccOut)
+{
+    if (!b || b->lastKind != 3) return fail(S3_EINVAL, "s3_batch_fetch_pairs: no paired-end result pending");
+    int rc = s3_batch_sync(b);
+    if (rc) return rc;
+    static_assert(sizeof(s3_pair_result) == sizeof(DevPair) && sizeof(s3_pair_xa) == sizeof(DevPairXa), "pair layouts");
+    const uint32_t n = b->n, nPairs = n / 2;
+    if (pairs && nPairs) HIPCHK(hipMemcpy(pairs, b->dPairs, (size_t)nPairs * sizeof(DevPair), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> off((size_t)nPairs + 1);
+    HIPCHK(hipMemcpy(off.data(), b->dXaOutOffsets, ((size_t)nPairs + 1) * 4, hipMemcpyDeviceToHost));
+    const uint64_t nXa = off[nPairs];
+    if (nXaOut) *nXaOut = nXa;
+    if (xaOffsets) for (size_t i = 0; i <= nPairs; i++) xaOffsets[i] = off[i];
+    if (xa) {
+        if (nXa > xaCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_pairs: pair list array too small");
+        if (nXa) HIPCHK(hipMemcpy(xa, b->dXaOut, nXa * sizeof(DevPairXa), hipMemcpyDeviceToHost));
+    }
+    std::vector<uint32_t> ooff((size_t)n + 1);
+    HIPCHK(hipMemcpy(ooff.data(), b->dOutOffsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    const uint64_t total = ooff[n];
+    if (nOccOut) *nOccOut = total;
+    if (occOffsets) for (size_t i = 0; i <= n; i++) occOffsets[i] = ooff[i];
+    if (occPos || occStrand || occMis) {
+        if (total > occCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_pairs: occurrence arrays too small");
+        if (occPos && total) HIPCHK(hipMemcpy(occPos, b->dOutPos, total * 4, hipMemcpyDeviceToHost));
+        if ((occStrand || occMis) && total) {
             std::vector<uint32_t> meta(total);
             HIPCHK(hipMemcpy(meta.data(), b->dOutMeta, total * 4, hipMemcpyDeviceToHost));
             for (uint64_t i = 0; i < total; i++) {

@@ -95,6 +95,57 @@ void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOff
 void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *withError, uint32_t mm, uint32_t allowSpecial, uint8_t *state,
                     hipStream_t s);
 
+// paired-end bookkeeping (s3dp_pair.hip); DevPair / DevPairXa are the ABI's s3_pair_result / s3_pair_xa
+struct DevPair {
+    uint8_t  phase, min1, min2, minTotal, secMinTotal, bestS1, bestS2, bestM1, bestM2, pad[3];
+    uint32_t x0_1, x1_1, x0_2, x1_2, numPairs, numMin, bestA1, bestA2;
+};
+struct DevPairXa { uint32_t a1, a2; uint8_t s1, s2, m1, m2; };
+
+struct PairClassifyArgs {
+    uint32_t        nPairs;
+    const uint32_t *activePairs;                 // optional: slot -> pair index
+    const uint32_t *totalOcc, *withError;        // per slot (2 per pair) of the search pass
+    uint32_t        mm, maxHits;
+    int             terminal, mapq;
+    uint8_t        *slotState, *pairNext, *pairMin;   // pairMin is per read (global index)
+    uint32_t       *occCount;                    // per read: reset here
+};
+struct PairSortArgs {
+    uint32_t        nPairs;
+    const uint32_t *activePairs;
+    const uint8_t  *pairNext;
+    const uint32_t *occStart, *occCount;
+    uint32_t        regionBase;
+    uint32_t       *occPos, *occMeta;
+    uint64_t       *keys;
+    uint32_t       *segBegin, *segEnd;
+};
+struct PairSweepArgs {
+    uint32_t        nPairs;
+    const uint32_t *activePairs;
+    uint8_t        *pairNext;
+    const uint8_t  *pairMin;
+    const uint32_t *finalWithError;
+    const uint32_t *occStart;
+    uint32_t       *occCount;
+    const uint32_t *occCountIn;                  // per slot snapshot taken before the statistics pass
+    const uint32_t *occPos, *occMeta, *readLengths;
+    uint32_t        insertLow, insertHigh, peMaxOutputPerPair, mm;
+    int             terminal;
+    DevPair        *pairs;
+    uint32_t       *bestIdx, *xaCount;           // per slot-pair
+    uint32_t       *xaStart, *xaCountOut;        // per pair (global index)
+};
+void launchPairExpand(uint32_t nPairs, const uint32_t *activePairs, uint32_t *readList, hipStream_t s);
+void launchPairClassify(const PairClassifyArgs &a, hipStream_t s);
+void launchPairSortKeys(const PairSortArgs &a, hipStream_t s);
+void launchPairSortBack(const PairSortArgs &a, const uint64_t *keysSorted, const uint32_t *metaSorted, hipStream_t s);
+void launchPairSnapshotCounts(uint32_t nPairs, const uint32_t *activePairs, const uint32_t *occCount, uint32_t *occCountIn, hipStream_t s);
+void launchPairStats(const PairSweepArgs &a, hipStream_t s);
+void launchPairEmit(const PairSweepArgs &a, const uint32_t *xaOffsets, uint32_t xaBase, DevPairXa *xa, hipStream_t s);
+void launchPairGatherXa(uint32_t nPairs, const uint32_t *xaStart, const uint32_t *outOffsets, const DevPairXa *xa, DevPairXa *out, hipStream_t s);
+
 void launchGatherProbe(const uint4 *table, uint64_t nLines, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,
                        uint32_t *sink, hipStream_t s);
 

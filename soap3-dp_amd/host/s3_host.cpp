@@ -246,6 +246,35 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
     return true;
 }
 
+bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs,
+                   std::string &err)
+{
+    ReadSet a, b;
+    if (!loadSingleReads(file1, maxReadLength, qualityConstant, maxLenReadName, a, err)) return false;
+    if (!loadSingleReads(file2, maxReadLength, qualityConstant, maxLenReadName, b, err)) return false;
+    const uint32_t np = a.n < b.n ? a.n : b.n;                          // the reference stops at the shorter file
+    rs = ReadSet();
+    rs.maxReadLength = maxReadLength; rs.wpq = a.wpq; rs.isFastq = a.isFastq; rs.n = 2 * np;
+    const size_t roundUp = ((size_t)rs.n + 31) / 32 * 32;
+    rs.queries.assign(roundUp * rs.wpq, 0);
+    rs.lengths.assign(rs.n, 0);
+    rs.names.resize(rs.n);
+    rs.codes.assign((size_t)rs.n * maxReadLength, 0);
+    rs.quals.assign((size_t)rs.n * maxReadLength, 0);
+    for (uint32_t r = 0; r < rs.n; r++) {
+        const ReadSet &src = (r & 1) ? b : a;
+        const uint32_t k = r >> 1;
+        rs.lengths[r] = src.lengths[k];
+        rs.names[r] = src.names[k];
+        memcpy(&rs.codes[(size_t)r * maxReadLength], &src.codes[(size_t)k * maxReadLength], maxReadLength);
+        memcpy(&rs.quals[(size_t)r * maxReadLength], &src.quals[(size_t)k * maxReadLength], maxReadLength);
+        uint32_t *dst = rs.queries.data() + (size_t)(r / 32) * 32 * rs.wpq + r % 32;
+        const uint32_t *sq = src.queries.data() + (size_t)(k / 32) * 32 * src.wpq + k % 32;
+        for (uint32_t w = 0; w < rs.wpq; w++) dst[(size_t)w * 32] = sq[(size_t)w * 32];
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // SAM
 // ------------------------------------------------------------------------------------------------
@@ -490,6 +519,249 @@ void SamWriter::singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_
     line.push_back('\n');
     fwrite(line.data(), 1, line.size(), out);
     nRecords++;
+}
+
+// ------------------------------------------------------------------------------------------------
+// paired-end records
+// ------------------------------------------------------------------------------------------------
+// one SAM line the way samtools prints a bam1_t: RNAME/RNEXT from tid/mtid ("=" when equal), POS/PNEXT one-based
+struct SamWriter::Rec {
+    uint32_t r = 0;
+    int flag = 0, tid = -1, mtid = -1, mapq = 0;
+    long long pos0 = -1, mpos0 = -1, isize = 0;
+    std::string cigar;                                   // empty = "*"
+    bool negative = false;
+    std::string tags;                                    // after RG:Z
+};
+
+void SamWriter::emit(const ReadSet &rs, const Rec &c)
+{
+    std::string line = rs.names[c.r];
+    line.push_back('\t'); line += std::to_string(c.flag);
+    line.push_back('\t'); line += c.tid < 0 ? std::string("*") : ix.seqName[c.tid];
+    line.push_back('\t'); line += std::to_string(c.pos0 + 1);
+    line.push_back('\t'); line += std::to_string(c.mapq);
+    line.push_back('\t'); line += c.cigar.empty() ? std::string("*") : c.cigar;
+    line.push_back('\t');
+    if (c.mtid < 0) line += "*";
+    else if (c.tid >= 0 && c.mtid == c.tid) line += "=";
+    else line += ix.seqName[c.mtid];
+    line.push_back('\t'); line += std::to_string(c.mpos0 + 1);
+    line.push_back('\t'); line += std::to_string(c.isize);
+    line.push_back('\t');
+    seqAndQual(rs, c.r, c.negative, line);
+    line += "\tRG:Z:" + opt.readGroup + c.tags + "\n";
+    fwrite(line.data(), 1, line.size(), out);
+    nRecords++;
+}
+
+static int bwaLikeSingle(int x0, int x1, const int *gLogN)                // bwaLikeSingleQualScore, BGS-IO.cpp:2310
+{
+    if (x0 > 1) return 0;
+    if (x1 == 0) return 37;
+    x1 = x1 > 255 ? 255 : x1;
+    const int n = gLogN[x1];
+    return 23 < n ? 0 : 23 - n;
+}
+
+static int tableScore(int mismatchNum, int avgQual, int maxMAPQ, int minMAPQ)
+{
+    int mi = mismatchNum > 5 ? 5 : mismatchNum;
+    int qi = (avgQual - 1) / 20;
+    qi = qi > 1 ? 1 : qi < 0 ? 0 : qi;
+    int v = (int)(maxMAPQ * kMappingScore[mi][qi]);
+    return v < minMAPQ ? minMAPQ : v;
+}
+
+void SamWriter::properPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const s3_pair_result &P, const s3_pair_xa *xa, size_t nXa)
+{
+    const int type = opt.alignmentType;
+    const bool mapqMode = type == 1 || type == 2;
+    // unique best with several optimal pairings: both ends are written as unmapped (CPUfunctions.cpp:2366-2377, BGS-IO.cpp:3767-3804)
+    if (type == 3 && P.numMin != 1) {
+        Rec a; a.r = r1; a.flag = 1 | 0x40 | 0x4 | 0x8;
+        Rec b; b.r = r2; b.flag = 1 | 0x80 | 0x4 | 0x8;
+        emit(rs, a); emit(rs, b);
+        return;
+    }
+    const uint32_t len1 = rs.lengths[r1], len2 = rs.lengths[r2];
+    uint64_t tp1 = 0, tp2 = 0;
+    uint32_t chr1 = 0, chr2 = 0;
+    std::string cig1, cig2, md1, md2;
+    const int trim1 = chrAndPosChecked(len1, P.bestA1, tp1, chr1, &cig1);
+    const int trim2 = chrAndPosChecked(len2, P.bestA2, tp2, chr2, &cig2);
+    const bool neg1 = P.bestS1 == 2, neg2 = P.bestS2 == 2;
+    int avg1 = 40, avg2 = 40;
+    mdString(ix, &rs.codes[(size_t)r1 * rs.maxReadLength], &rs.quals[(size_t)r1 * rs.maxReadLength], len1, P.bestA1, neg1, P.bestM1, trim1, md1, avg1);
+    mdString(ix, &rs.codes[(size_t)r2 * rs.maxReadLength], &rs.quals[(size_t)r2 * rs.maxReadLength], len2, P.bestA2, neg2, P.bestM2, trim2, md2, avg2);
+    int mis1 = P.bestM1, mis2 = P.bestM2;
+    if (trim1 && mis1) { mis1 = 0; for (char c : md1) mis1 += c > '9'; }
+    if (trim2 && mis2) { mis2 = 0; for (char c : md2) mis2 += c > '9'; }
+    int mapq1 = 255, mapq2 = 255;                                       // SAM_MAPQ_UNAVAILABLE for unique / random best
+    int x0a = -1, x0b = -1, x1a = -1, x1b = -1;
+    if (type == 3) { x0a = x0b = 1; }
+    if (mapqMode) {
+        x0a = (int)P.x0_1; x1a = (int)P.x1_1; x0b = (int)P.x0_2; x1b = (int)P.x1_2;
+        if (opt.bwaLikeScore) {                                         // bwaLikePairQualScore, BGS-IO.cpp:2415-2463
+            int op = ((int)(len1 + len2) - (int)P.minTotal) * opt.dpMatchScore + (int)P.minTotal * opt.dpMismatchScore;
+            int sub = ((int)(len1 + len2) - (int)(signed char)P.secMinTotal) * opt.dpMatchScore + (int)(signed char)P.secMinTotal * opt.dpMismatchScore;
+            int subNum = (int)P.numPairs - (int)P.numMin > 0 ? (int)P.numPairs - (int)P.numMin : 0;
+            int q0 = bwaLikeSingle(x0a, x1a, gLogN), q1 = bwaLikeSingle(x0b, x1b, gLogN), qp = 0;
+            op *= 10; sub *= 10;
+            if (q0 > 0 && q1 > 0) { qp = q0 + q1; if (qp > 60) qp = 60; q0 = q1 = qp; }
+            else {
+                if (P.numMin == 1) {
+                    if (subNum == 0) qp = 29;
+                    else if (op - sub > 0.3 * ((int)(len1 + len2) / 2)) qp = 23;
+                    else { subNum = subNum > 255 ? 255 : subNum; qp = (op - sub) / 2 - gLogN[subNum]; if (qp < 0) qp = 0; }
+                }
+                if (q0 == 0) q0 = qp + 7 < q1 ? qp + 7 : q1;
+                if (q1 == 0) q1 = qp + 7 < q0 ? qp + 7 : q0;
+            }
+            mapq1 = q0; mapq2 = q1;
+        } else {                                                        // getMapQualScore2 + getMapQualScoreForPair, BGS-IO.cpp:2465,2577
+            auto one = [&](int mis, int avg, int x0, int x1, bool isBest) {
+                if (x0 == 1 && P.numPairs == 1) { if (!isBest && x1 > 1) return opt.minMAPQ; return tableScore(mis, rs.isFastq ? avg : 20, opt.maxMAPQ, opt.minMAPQ); }
+                return opt.minMAPQ;
+            };
+            const int s1 = one(P.bestM1, avg1, x0a, x1a, P.min1 == P.bestM1), s2 = one(P.bestM2, avg2, x0b, x1b, P.min2 == P.bestM2);
+            mapq1 = mapq2 = s1 > s2 ? (int)(s1 * 0.2 + s2 * 0.8) : (int)(s1 * 0.8 + s2 * 0.2);
+        }
+        if (trim1) mapq1 = 0;
+        if (trim2) mapq2 = 0;
+    }
+    auto xaString = [&](bool first) {
+        std::string s;
+        if (!mapqMode) return s;
+        for (size_t k = 0; k < nXa; k++) {
+            uint64_t tp; uint32_t ch;
+            chrAndPos(first ? xa[k].a1 : xa[k].a2, tp, ch);
+            s += ix.seqName[ch - 1];
+            s.push_back(',');
+            s.push_back((first ? xa[k].s1 : xa[k].s2) == 2 ? '-' : '+');
+            s += std::to_string((unsigned long long)tp);
+            s.push_back(',');
+            s += std::to_string(first ? len1 : len2);
+            s += "M,";
+            s += std::to_string((unsigned)(first ? xa[k].m1 : xa[k].m2));
+            s.push_back(';');
+        }
+        return s;
+    };
+    auto tags = [&](int mis, int x0, int x1, const std::string &md, const std::string &xaz) {
+        std::string t;
+        if (opt.printMDNM) t += "\tNM:i:" + std::to_string(mis);
+        if (x0 >= 0) t += "\tX0:i:" + std::to_string(x0);
+        if (x1 >= 0) t += "\tX1:i:" + std::to_string(x1);
+        t += "\tXM:i:" + std::to_string(mis) + "\tXO:i:0\tXG:i:0";
+        if (opt.printMDNM && !md.empty()) t += "\tMD:Z:" + md;
+        if (!xaz.empty()) t += "\tXA:Z:" + xaz;
+        return t;
+    };
+    Rec a, b;
+    a.r = r1; a.negative = neg1; a.flag = 1 | 2 | 0x40 | (neg1 ? 0x10 : 0) | (neg2 ? 0x20 : 0);
+    a.tid = (int)chr1 - 1; a.pos0 = (long long)tp1 - 1; a.mtid = (int)chr2 - 1; a.mpos0 = (long long)tp2 - 1; a.mapq = mapq1;
+    a.cigar = cig1.empty() ? std::to_string(len1) + "M" : cig1;
+    if (chr1 == chr2) a.isize = tp2 > tp1 ? (long long)(tp2 + len2 - tp1) : -(long long)(tp1 + len1 - tp2);
+    a.tags = tags(mis1, x0a, x1a, md1, xaString(true));
+    b.r = r2; b.negative = neg2; b.flag = 1 | 2 | 0x80 | (neg2 ? 0x10 : 0) | (neg1 ? 0x20 : 0);
+    b.tid = (int)chr2 - 1; b.pos0 = (long long)tp2 - 1; b.mtid = (int)chr1 - 1; b.mpos0 = (long long)tp1 - 1; b.mapq = mapq2;
+    b.cigar = cig2.empty() ? std::to_string(len2) + "M" : cig2;
+    if (chr1 == chr2) b.isize = tp1 > tp2 ? (long long)(tp1 + len1 - tp2) : -(long long)(tp2 + len2 - tp1);
+    b.tags = tags(mis2, x0b, x1b, md2, xaString(false));
+    emit(rs, a); emit(rs, b);
+}
+
+void SamWriter::improperPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const uint32_t *pos1, const uint8_t *strand1, const uint8_t *mis1, size_t n1,
+                             const uint32_t *pos2, const uint8_t *strand2, const uint8_t *mis2, size_t n2, uint32_t xaLimit)
+{
+    const int type = opt.alignmentType;
+    struct End {
+        long best = -1; int bestScore = 0, bestNum = 0, secNum = 0; uint64_t tp = 0; uint32_t chr = 0; int mapq = 0; std::string md, xaz; bool mapped = false;
+    } e[2];
+    const uint32_t rr[2] = {r1, r2};
+    const uint32_t *pos[2] = {pos1, pos2};
+    const uint8_t *strand[2] = {strand1, strand2}, *mis[2] = {mis1, mis2};
+    const size_t nn[2] = {n1, n2};
+    for (int k = 0; k < 2; k++) {
+        End &E = e[k];
+        if (nn[k] > 0) {                                                 // best = first with the fewest mismatches; X1 counts best + 1 (BGS-IO.cpp:2628-2700)
+            E.best = 0; E.bestScore = mis[k][0]; E.bestNum = 1;
+            for (size_t i = 1; i < nn[k]; i++) {
+                const int m = mis[k][i];
+                if (m < E.bestScore) { E.secNum = E.bestScore == m + 1 ? E.bestNum : 0; E.best = (long)i; E.bestScore = m; E.bestNum = 1; }
+                else if (m == E.bestScore) E.bestNum++;
+                else if (m == E.bestScore + 1) E.secNum++;
+            }
+        }
+        if (E.best >= 0 && (type != 3 || E.bestNum == 1)) {
+            E.mapped = true;
+            chrAndPos(pos[k][E.best], E.tp, E.chr);
+            int avg = 40;
+            const uint32_t len = rs.lengths[rr[k]];
+            mdString(ix, &rs.codes[(size_t)rr[k] * rs.maxReadLength], &rs.quals[(size_t)rr[k] * rs.maxReadLength], len, pos[k][E.best], strand[k][E.best] == 2,
+                     mis[k][E.best], 0, E.md, avg);
+            if (type >= 3) E.mapq = 255;
+            else {                                                       // getMapQualScoreSingle halved, floored at MinMAPQ (BGS-IO.cpp:2714-2722)
+                int q;
+                if (opt.bwaLikeScore) q = bwaLikeSingle(E.bestNum, E.secNum, gLogN);
+                else if (E.bestNum == 1) q = E.secNum > 0 ? opt.minMAPQ : tableScore(mis[k][E.best], rs.isFastq ? avg : 20, opt.maxMAPQ, opt.minMAPQ);
+                else q = opt.minMAPQ;
+                q >>= 1;
+                E.mapq = q < opt.minMAPQ ? opt.minMAPQ : q;
+            }
+        } else E.best = -1;
+    }
+    if (type == 1 || type == 2) {
+        for (int k = 0; k < 2; k++) {
+            uint32_t total = 1;
+            const uint32_t len = rs.lengths[rr[k]];
+            for (size_t i = 0; i < nn[k] && total < xaLimit; i++) {
+                if ((long)i == e[k].best) continue;
+                if (type == 2 && (int)mis[k][i] > e[k].bestScore) continue;
+                uint64_t tp; uint32_t ch;
+                chrAndPos(pos[k][i], tp, ch);
+                e[k].xaz += ix.seqName[ch - 1];
+                e[k].xaz.push_back(',');
+                e[k].xaz.push_back(strand[k][i] == 2 ? '-' : '+');
+                e[k].xaz += std::to_string((unsigned long long)tp) + "," + std::to_string(len) + "M," + std::to_string((unsigned)mis[k][i]) + ";";
+                total++;
+            }
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        const End &me = e[k], &mate = e[1 - k];
+        Rec c;
+        c.r = rr[k];
+        c.flag = 1 | (k == 0 ? 0x40 : 0x80) | (me.mapped ? 0 : 0x4) | (mate.mapped ? 0 : 0x8);
+        const bool negMe = me.mapped && strand[k][me.best] == 2, negMate = mate.mapped && strand[1 - k][mate.best] == 2;
+        if (negMe) c.flag |= 0x10;
+        if (negMate) c.flag |= 0x20;
+        c.negative = negMe;
+        // an unmapped end takes the coordinates of its mate (BGS-IO.cpp:2819-2822)
+        c.tid = me.chr ? (int)me.chr - 1 : (mate.chr ? (int)mate.chr - 1 : -1);
+        c.pos0 = me.tp ? (long long)me.tp - 1 : (mate.tp ? (long long)mate.tp - 1 : -1);
+        c.mtid = mate.chr ? (int)mate.chr - 1 : (me.chr ? (int)me.chr - 1 : -1);
+        c.mpos0 = mate.tp ? (long long)mate.tp - 1 : (me.tp ? (long long)me.tp - 1 : -1);
+        const uint32_t len1 = rs.lengths[r1], len2 = rs.lengths[r2];
+        if (e[0].chr > 0 && e[0].chr == e[1].chr) {
+            const uint64_t t1 = e[0].tp, t2 = e[1].tp;
+            if (k == 0) c.isize = t2 > t1 ? (long long)(t2 + len2 - t1) : -(long long)(t1 + len1 - t2);
+            else c.isize = t1 > t2 ? (long long)(t1 + len1 - t2) : -(long long)(t2 + len2 - t1);
+        }
+        if (me.mapped) {
+            const int m = mis[k][me.best];
+            c.mapq = me.mapq;
+            c.cigar = std::to_string(rs.lengths[rr[k]]) + "M";
+            if (opt.printMDNM) c.tags += "\tNM:i:" + std::to_string(m);
+            if (type != 4) c.tags += "\tX0:i:" + std::to_string(me.bestNum);
+            if (type == 1 || type == 2) c.tags += "\tX1:i:" + std::to_string(me.secNum);
+            c.tags += "\tXM:i:" + std::to_string(m) + "\tXO:i:0\tXG:i:0";
+            if (opt.printMDNM && !me.md.empty()) c.tags += "\tMD:Z:" + me.md;
+            if (!me.xaz.empty()) c.tags += "\tXA:Z:" + me.xaz;
+        }
+        emit(rs, c);
+    }
 }
 
 }  // namespace s3host

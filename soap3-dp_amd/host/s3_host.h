@@ -44,11 +44,15 @@ struct ReadSet {
 };
 
 bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err);
+// two files, mates interleaved: read 2p from file 1, read 2p+1 from file 2 (loadPairReadsGz2, QueryParser.cpp:177)
+bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs,
+                   std::string &err);
 
 struct SamOptions {
     std::string readGroup, sampleName, readGrpOption;
     int alignmentType = 2;                               // OUTPUT_ALL_BEST
     int minMAPQ = 1, maxMAPQ = 40, bwaLikeScore = 1;
+    int dpMatchScore = 1, dpMismatchScore = -2;          // only for the BWA-like pair MAPQ (BGS-IO.cpp:3550-3554)
     bool printMDNM = false;
 };
 
@@ -63,12 +67,19 @@ public:
     // unique-best / random-best record: one hit, X0 = 1, no X1, no XA, no boundary check (SingleAnsOutputSAMAPI, BGS-IO.cpp:5774)
     void singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_t strand, uint8_t mis);
     void unaligned(const ReadSet &rs, uint32_t r);       // noAnsOutputSAMAPI, BGS-IO.cpp:5829
+    // a pair with a proper pairing (pairOutputSAMAPI, BGS-IO.cpp:3478): reads r1 = 2p, r2 = 2p+1; xa = the other optimal pairings
+    void properPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const s3_pair_result &P, const s3_pair_xa *xa, size_t nXa);
+    // a pair without one (unproperlypairOutputSAMAPI, BGS-IO.cpp:2582): the occurrence lists of both ends; xaLimit = the hit limit per end
+    void improperPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const uint32_t *pos1, const uint8_t *strand1, const uint8_t *mis1, size_t n1,
+                      const uint32_t *pos2, const uint8_t *strand2, const uint8_t *mis2, size_t n2, uint32_t xaLimit);
     uint64_t records() const { return nRecords; }
 
 private:
     uint32_t chrAndPos(uint32_t ambPos, uint64_t &tp, uint32_t &chr) const;                    // getChrAndPos, BGS-IO.cpp:1746
     int chrAndPosChecked(uint32_t readLen, uint32_t ambPos, uint64_t &tp, uint32_t &chr, std::string *cigar) const;   // :1981
     void seqAndQual(const ReadSet &rs, uint32_t r, bool negative, std::string &line) const;
+    struct Rec;
+    void emit(const ReadSet &rs, const Rec &rec);
     const HostIndex &ix;
     SamOptions opt;
     FILE *out;

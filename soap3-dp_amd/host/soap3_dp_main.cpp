@@ -1,7 +1,8 @@
-// soap3-dp -- drop-in command line for the alignment path (single-end so far), same arguments, .ini keys and index files as
+// soap3-dp -- drop-in command line for the alignment path (single-end; paired-end with the DP stages off), same arguments, .ini keys and index files as
 // the reference program (SOAP3-DP.cu main, IniParam.cpp:237-767), driving the MI355X kernels through the C-ABI of libs3dp.so.
 //
 //   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
+//   soap3-dp pair   <index prefix> <reads 1> <reads 2> [-u maxInsert] [-v minInsert] -s k [the same options]
 //
 // Output: <prefix>.gout.1 (SAM), <prefix>.done, like SOAP3-DP.cu:251-258 with NumOfCpuThreads = 1.
 #include <stdio.h>
@@ -14,8 +15,9 @@
 using namespace s3host;
 
 struct Ini {
-    unsigned maxOutputPerRead = 1000;
+    unsigned maxOutputPerRead = 1000, peMaxOutputPerPair = 1000, maxHitsEachEndForPairing = 10000;
     int minMAPQ = 1, maxMAPQ = 40, bwaLike = 0, maxLenReadName = 64;     // code defaults of IniParam.cpp:237-362
+    int matchScore = 1, mismatchScore = -2;
 };
 
 static void parseIni(const std::string &file, Ini &ini)
@@ -32,6 +34,10 @@ static void parseIni(const std::string &file, Ini &ini)
         else if (!strcmp(key, "MaxMAPQ")) ini.maxMAPQ = atoi(val);
         else if (!strcmp(key, "BWALikeScore")) ini.bwaLike = atoi(val);
         else if (!strcmp(key, "MaxLenReadName")) ini.maxLenReadName = atoi(val);
+        else if (!strcmp(key, "MaxOutputPerPair")) ini.peMaxOutputPerPair = (unsigned)strtoul(val, nullptr, 10);
+        else if (!strcmp(key, "MaxHitsEachEndForPairing")) ini.maxHitsEachEndForPairing = (unsigned)strtoul(val, nullptr, 10);
+        else if (!strcmp(key, "MatchScore")) ini.matchScore = atoi(val);
+        else if (!strcmp(key, "MismatchScore")) ini.mismatchScore = atoi(val);
     }
     fclose(f);
 }
@@ -40,16 +46,19 @@ static int die(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); retur
 
 int main(int argc, char **argv)
 {
-    if (argc < 4) return die("usage: soap3-dp single <index> <reads> [options]   (pair mode: not built yet)");
-    if (strcmp(argv[1], "single") != 0) return die("only 'single' is implemented in this build");
+    if (argc < 4) return die("usage: soap3-dp single <index> <reads> [options]\n       soap3-dp pair <index> <reads 1> <reads 2> [-u max insert] [-v min insert] [options]");
+    const bool paired = strcmp(argv[1], "pair") == 0;
+    if (!paired && strcmp(argv[1], "single") != 0) return die("the first argument must be 'single' or 'pair'");
+    if (paired && argc < 5) return die("pair mode needs two read files");
     Ini ini;
     parseIni(std::string(argv[0]) + ".ini", ini);
-    const std::string indexName = argv[2], queryFile = argv[3];
+    const std::string indexName = argv[2], queryFile = argv[3], queryFile2 = paired ? argv[4] : "";
+    int insertHigh = 500, insertLow = 1;                                       // IniParam.cpp:482-483
     int maxReadLength = 120, numMismatch = -1, alignmentType = 2, outputFormat = 2, device = 0;   // DEFAULT_MAX_READ_LEN, all-best, SAM
     bool enableDP = true;
     std::string prefix = queryFile, readGroup, sampleName, readGrpOption;
     bool printMDNM = false;
-    for (int i = 4; i < argc; i++) {
+    for (int i = paired ? 5 : 4; i < argc; i++) {
         const std::string a = argv[i];
         auto need = [&](const char *what) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "Please specify %s after '%s'\n", what, a.c_str()); exit(1); } return argv[++i]; };
         if (a == "-L" || a == "-l") maxReadLength = atoi(need("the length"));
@@ -61,6 +70,8 @@ int main(int argc, char **argv)
         else if (a == "-A") sampleName = need("the sample name");
         else if (a == "-R") readGrpOption = need("the read group option");
         else if (a == "-p") printMDNM = true;
+        else if (a == "-u") insertHigh = atoi(need("the maximum insert size"));
+        else if (a == "-v") insertLow = atoi(need("the minimum insert size"));
         else if (a == "-s") {
             enableDP = false;
             if (i + 1 < argc && argv[i + 1][0] >= '0' && argv[i + 1][0] <= '9') numMismatch = atoi(argv[++i]);
@@ -78,7 +89,8 @@ int main(int argc, char **argv)
     if (!loadIndex(indexName, hix, err)) return die(err);
     printf("[Main] Reference sequence length : %u\n", hix.n);
     ReadSet rs;
-    if (!loadSingleReads(queryFile, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, err)) return die(err);
+    if (paired ? !loadPairReads(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, err)
+               : !loadSingleReads(queryFile, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, err)) return die(err);
     printf("[Main] Loaded %u short reads from the query file.\n", rs.n);
     if (numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;          // getDefaultMismatchNum, CPUfunctions.cpp:26-35
     s3_index *ix = nullptr;
@@ -91,6 +103,7 @@ int main(int argc, char **argv)
     SamOptions so;
     so.readGroup = readGroup; so.sampleName = sampleName; so.readGrpOption = readGrpOption; so.alignmentType = alignmentType;
     so.minMAPQ = ini.minMAPQ; so.maxMAPQ = ini.maxMAPQ; so.bwaLikeScore = ini.bwaLike; so.printMDNM = printMDNM;
+    so.dpMatchScore = ini.matchScore; so.dpMismatchScore = ini.mismatchScore;
     SamWriter sam(hix, so, out);
     sam.header();
     const uint32_t maxBatch = 1u << 22;
@@ -101,6 +114,33 @@ int main(int argc, char **argv)
         const uint32_t cnt = rs.n - first < maxBatch ? rs.n - first : maxBatch;   // first is a multiple of 32
         if (s3_batch_upload(b, rs.queries.data() + (size_t)first * rs.wpq, rs.lengths.data() + first, cnt) != S3_OK) return die(s3_last_error());
         // reads longer than 120 bases: only the first 100 are searched, the rest is verified on the device (alignment.cu:2473-2491)
+        if (paired) {
+            // pairs keep to the whole read (seedLengths is NULL for pairs, alignment.cu:1965-2013); DP stages are off (-s)
+            if (s3_batch_align_pair(b, (uint32_t)numMismatch, ini.maxHitsEachEndForPairing, alignmentType, (uint32_t)insertLow, (uint32_t)insertHigh,
+                                    ini.peMaxOutputPerPair) != S3_OK) return die(s3_last_error());
+            const uint32_t np = cnt / 2;
+            std::vector<s3_pair_result> pr(np ? np : 1);
+            std::vector<uint64_t> xoff((size_t)np + 1), ooff((size_t)cnt + 1);
+            uint64_t nXa = 0, nOcc = 0;
+            if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, ooff.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return die(s3_last_error());
+            std::vector<s3_pair_xa> xa(nXa ? nXa : 1);
+            std::vector<uint32_t> pos(nOcc ? nOcc : 1);
+            std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
+            if (s3_batch_fetch_pairs(b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK)
+                return die(s3_last_error());
+            for (uint32_t p = 0; p < np; p++) {
+                const uint32_t r1 = first + 2 * p, r2 = r1 + 1;
+                if (pr[p].phase) {
+                    if (!(alignmentType == 3 && pr[p].numMin != 1)) aligned += 2;
+                    sam.properPair(rs, r1, r2, pr[p], xa.data() + xoff[p], (size_t)(xoff[p + 1] - xoff[p]));
+                } else {
+                    const size_t o1 = ooff[2 * p], n1 = ooff[2 * p + 1] - o1, o2 = ooff[2 * p + 1], n2 = ooff[2 * p + 2] - o2;
+                    sam.improperPair(rs, r1, r2, pos.data() + o1, strand.data() + o1, mis.data() + o1, n1, pos.data() + o2, strand.data() + o2, mis.data() + o2, n2,
+                                     ini.maxHitsEachEndForPairing);
+                }
+            }
+            continue;
+        }
         std::vector<uint32_t> seeds;
         if (maxReadLength > 120) {
             seeds.resize(cnt);

@@ -35,7 +35,7 @@ class Counters(C.Structure):
 
 
 EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
-           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_fetch_alignments", "s3_batch_sync",
+           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_batch_fetch_alignments", "s3_batch_sync",
            "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather"]
 
@@ -290,6 +290,28 @@ class Batch:
         _chk(lib().s3_batch_fetch_alignments(self.h, None, None, None, pos.ctypes.data, strand.ctypes.data, mis.ctypes.data, k, None))
         return phase, werr, offs, pos[:no.value], strand[:no.value], mis[:no.value]
 
+    def align_pair(self, mm, max_hits_per_end, report_type, insert_low, insert_high, pe_max_output=1000):
+        """reads 2p / 2p+1 are the ends of pair p; paired-end ladder with the DP stages off"""
+        f = lib().s3_batch_align_pair
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
+        _chk(f(self.h, mm, max_hits_per_end, report_type, insert_low, insert_high, pe_max_output))
+
+    def fetch_pairs(self):
+        f = lib().s3_batch_fetch_pairs
+        f.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+        n, npairs = self.n, self.n // 2
+        pairs = np.zeros(npairs, dtype=PAIR_DTYPE)
+        xoff = np.zeros(npairs + 1, dtype=np.uint64)
+        ooff = np.zeros(n + 1, dtype=np.uint64)
+        nx, no = C.c_uint64(), C.c_uint64()
+        _chk(f(self.h, pairs.ctypes.data, xoff.ctypes.data, None, 0, C.byref(nx), ooff.ctypes.data, None, None, None, 0, C.byref(no)))
+        xa = np.zeros(max(1, nx.value), dtype=PAIR_XA_DTYPE)
+        pos = np.zeros(max(1, no.value), dtype=np.uint32)
+        strand = np.zeros(max(1, no.value), dtype=np.uint8)
+        mis = np.zeros(max(1, no.value), dtype=np.uint8)
+        _chk(f(self.h, None, None, xa.ctypes.data, len(xa), None, None, pos.ctypes.data, strand.ctypes.data, mis.ctypes.data, len(pos), None))
+        return pairs, xoff, xa[:nx.value], ooff, pos[:no.value], strand[:no.value], mis[:no.value]
+
     def timing(self):
         t, s, k = C.c_float(), C.c_float(), C.c_uint32()
         _chk(lib().s3_batch_last_timing(self.h, C.byref(t), C.byref(s), C.byref(k)))
@@ -300,6 +322,12 @@ class Batch:
         _chk(lib().s3_batch_counters(self.h, C.byref(c)))
         return {k: getattr(c, k) for k, _ in Counters._fields_}
 
+
+# s3_pair_result / s3_pair_xa of include/s3dp.h
+PAIR_DTYPE = np.dtype([("phase", "u1"), ("min1", "u1"), ("min2", "u1"), ("minTotal", "u1"), ("secMinTotal", "u1"), ("bestS1", "u1"), ("bestS2", "u1"),
+                       ("bestM1", "u1"), ("bestM2", "u1"), ("pad", "u1", 3), ("x0_1", "<u4"), ("x1_1", "<u4"), ("x0_2", "<u4"), ("x1_2", "<u4"),
+                       ("numPairs", "<u4"), ("numMin", "<u4"), ("bestA1", "<u4"), ("bestA2", "<u4")])
+PAIR_XA_DTYPE = np.dtype([("a1", "<u4"), ("a2", "<u4"), ("s1", "u1"), ("s2", "u1"), ("m1", "u1"), ("m2", "u1")])
 
 # ------------------------------------------------------------------------------------------------
 # read packing (the layout loadSingleReadsGz produces; QueryParser.cpp:996, DV-Kernel.cu:4268-4270)

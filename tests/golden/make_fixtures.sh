@@ -60,8 +60,34 @@ mkl() {  # name genome_args read_args maxlen
   )
 }
 
+# paired-end, DP stages off (pair ... -s k): SAM only
+mkp() {  # name genome_args pair_args maxlen
+  local name=$1; shift
+  local gargs=$1; shift
+  local rargs=$1; shift
+  local L=$1; shift
+  mkdir -p $OUT/$name
+  ( cd $W && python $ROOT/tools/simulate.py $gargs --fasta $name.fa $rargs --fastq ${name}_1.fq --fastq2 ${name}_2.fq --truth $name.truth
+    $REF/soap3-dp-builder $name.fa > /dev/null
+    $REF/BGS-Build $name.fa.index > /dev/null
+    P="$REF/ref_harness sam $INI pair $name.fa.index ${name}_1.fq ${name}_2.fq -L $L -u 500 -v 200 -b 2"
+    $P -s 3 -o pe_s3 > /dev/null 2>&1
+    $P -s 1 -p -o pe_s1 > /dev/null 2>&1
+    $P -s 4 -o pe_s4 > /dev/null 2>&1
+    $P -s 2 -h 1 -o pe_h1_s2 > /dev/null 2>&1
+    $P -s 3 -h 3 -o pe_h3_s3 > /dev/null 2>&1
+    $P -s 2 -h 4 -o pe_h4_s2 > /dev/null 2>&1
+    sha256sum $name.fa.index.lkt $name.fa.index.rev.lkt | awk '{print $1}' > lkt.sha256
+    for f in bwt rev.bwt fmv.gpu rev.fmv.gpu sa pac ann amb tra; do cp $name.fa.index.$f $OUT/$name/index.$f; done
+    cp $name.fa $OUT/$name/genome.fa; cp ${name}_1.fq $OUT/$name/reads_1.fq; cp ${name}_2.fq $OUT/$name/reads_2.fq; cp $name.truth $OUT/$name/reads.truth
+    cp lkt.sha256 $OUT/$name/
+    for v in s3 s1 s4 h1_s2 h3_s3 h4_s2; do grep -v '^@PG' pe_$v.gout.1 | gzip -9n > $OUT/$name/pe_$v.sam.gz; done
+  )
+}
+
 mk g1 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 6 --genome-seed 1" "--reads 2000 --read-len 100 --read-seed 2026" 100
 mk g2 "--genome-len 60000 --chroms 2 --n-runs 2 --repeats 40 --genome-seed 7" "--reads 1500 --read-len 100 --var-len 25 120 --read-seed 11" 120
 mkl g3 "--genome-len 120000 --chroms 2 --n-runs 4 --repeats 12 --genome-seed 5" "--reads 1200 --var-len 121 200 --read-seed 31 --mix 0.3 0.2 0.15 0.1 0.08 0.07 0.05 0.03 0.02" 200
+mkp g4 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 8 --genome-seed 9" "--pairs 1200 --read-len 100 --read-seed 77" 100
 ( cd $W && $REF/ref_harness models models.txt && gzip -9n < models.txt > $OUT/models.txt.gz )
 du -sh $OUT

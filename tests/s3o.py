@@ -11,8 +11,9 @@ LIB = os.path.join(ROOT, "oracle", "libs3oracle.so")
 def build(force=False):
     src = os.path.join(ROOT, "oracle", "s3_oracle.c")
     src2 = os.path.join(ROOT, "oracle", "s3_oracle_dp.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(src2)):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", LIB, src, os.path.join(ROOT, "oracle", "s3_oracle_dp.c"), "-lm"])
+    src3 = os.path.join(ROOT, "oracle", "s3_oracle_pe.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(x) for x in (src, src2, src3)):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", LIB, src, src2, src3, "-lm"])
     return LIB
 
 
@@ -162,6 +163,35 @@ class Index:
             if rc >= 0:
                 return phase, werr, offs, pos[:rc], strand[:rc], nmis[:rc], st
             occ_cap *= 4
+
+    def align_pair(self, queries, read_lengths, wpq, mm, max_hits, report_type, insert_low, insert_high, pe_max_output=1000):
+        """paired-end ladder (oracle/s3_oracle_pe.c); reads 2p / 2p+1 are a pair.  Returns the arrays of s3dp.Batch.fetch_pairs."""
+        import s3dp
+        queries = np.ascontiguousarray(queries, dtype=np.uint32)
+        read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
+        n = len(read_lengths)
+        f = lib().s3o_align_pair
+        f.restype = C.c_long
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Stats)]
+        xcap = ocap = max(4096, 64 * n)
+        while True:
+            pairs = np.zeros(n // 2, dtype=s3dp.PAIR_DTYPE)
+            xoff = np.zeros(n // 2 + 1, dtype=np.uint64)
+            xa = np.zeros(xcap, dtype=s3dp.PAIR_XA_DTYPE)
+            ooff = np.zeros(n + 1, dtype=np.uint64)
+            pos = np.zeros(ocap, dtype=np.uint32)
+            strand = np.zeros(ocap, dtype=np.uint8)
+            mis = np.zeros(ocap, dtype=np.uint8)
+            st = Stats()
+            rc = f(self.h, queries.ctypes.data, read_lengths.ctypes.data, n, wpq, mm, max_hits, report_type, insert_low, insert_high, pe_max_output,
+                   pairs.ctypes.data, xoff.ctypes.data, xa.ctypes.data, xcap, ooff.ctypes.data, pos.ctypes.data, strand.ctypes.data, mis.ctypes.data,
+                   ocap, C.byref(st))
+            if rc == 0:
+                nx, no = int(xoff[-1]), int(ooff[-1])
+                return pairs, xoff, xa[:nx], ooff, pos[:no], strand[:no], mis[:no]
+            xcap *= 4
+            ocap *= 4
 
     def decode(self, hits):
         cap = int(sum(1 if h["kind"] == 1 else int(h["b"]) - int(h["a"]) + 1 for h in hits)) + 1

@@ -157,3 +157,55 @@ def test_buffers_grow_instead_of_overflowing(monkeypatch):
         assert (pos[lo:hi] == opos).all() and (strand[lo:hi] == ostrand).all() and (mis[lo:hi] == omis).all()
     oix.close()
     b.close()
+
+
+def golden_pairs(name):
+    a = s3o.read_fastq(os.path.join(GOLDEN, name, "reads_1.fq"))
+    b = s3o.read_fastq(os.path.join(GOLDEN, name, "reads_2.fq"))
+    return [x for ab in zip(a, b) for x in ab]
+
+
+@pytest.mark.parametrize("report_type,mm", [(2, 3), (2, 1), (2, 4), (2, 0), (1, 2), (3, 3), (4, 2), (4, 0)])
+def test_pair_ladder_matches_oracle(report_type, mm):
+    """paired-end ladder with the DP stages off: per-pair decisions, pairing, optimal pair, XA pairs, improper-pair lists"""
+    name, maxlen = "g4", 100
+    reads = golden_pairs(name)
+    q, lens, wpq = s3dp.pack_reads(reads, maxlen)
+    b = s3dp.Batch(dev_index(name), len(reads), wpq)
+    b.upload(q, lens)
+    b.align_pair(mm, 8000, report_type, 200, 500, 1000)
+    got = b.fetch_pairs()
+    oix = s3o.Index(host_index=host_index(name))
+    want = oix.align_pair(q, lens, wpq, mm, 8000, report_type, 200, 500, 1000)
+    gp, wp = got[0], want[0]
+    for f in gp.dtype.names:
+        if f == "pad":
+            continue
+        bad = np.nonzero(gp[f] != wp[f])[0]
+        assert len(bad) == 0, "pair field %s differs at pair %d: %s vs %s" % (f, bad[0], gp[bad[0]], wp[bad[0]])
+    for k in range(1, 7):
+        assert len(got[k]) == len(want[k]) and (got[k] == want[k]).all(), "output array %d differs" % k
+    assert (gp["phase"] > 0).sum() > 100 and (gp["phase"] == 0).sum() > 50
+    oix.close()
+    b.close()
+
+
+def test_pair_small_caps():
+    """tiny per-end hit limit and XA limit: the cuts must fall where the reference's fall"""
+    name, maxlen = "g4", 100
+    reads = golden_pairs(name)
+    q, lens, wpq = s3dp.pack_reads(reads, maxlen)
+    b = s3dp.Batch(dev_index(name), len(reads), wpq)
+    b.upload(q, lens)
+    oix = s3o.Index(host_index=host_index(name))
+    for max_hits, pe_max in ((3, 2), (1, 1), (50, 3)):
+        b.align_pair(2, max_hits, 2, 200, 500, pe_max)
+        got = b.fetch_pairs()
+        want = oix.align_pair(q, lens, wpq, 2, max_hits, 2, 200, 500, pe_max)
+        for f in got[0].dtype.names:
+            if f != "pad":
+                assert (got[0][f] == want[0][f]).all(), (max_hits, pe_max, f)
+        for k in range(1, 7):
+            assert len(got[k]) == len(want[k]) and (got[k] == want[k]).all(), (max_hits, pe_max, k)
+    oix.close()
+    b.close()

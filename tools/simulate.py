@@ -81,10 +81,60 @@ def make_reads(chroms, n, L, seed=2026, mix=(0.55, 0.25, 0.12, 0.05, 0.03), var_
     return out, truth
 
 
-def write_fastq(path, reads, prefix="r"):
+def make_pairs(chroms, n, L, seed=2026, mix=(0.55, 0.25, 0.12, 0.05, 0.03), ins_mean=350, ins_sd=40, ins_max=500,
+               frac_half=0.08, frac_none=0.04, frac_far=0.08, var_len=None):
+    """read pairs in +/- orientation: a fragment of `insert` bases, mate A = its first L bases, mate B = reverse complement of its last
+    L bases; which of the two is written to file 1 is random.  A fraction has one or both mates replaced by random sequence
+    (half-aligned / unaligned pairs) or the second mate taken from a distant place (both align, no proper pair)."""
+    rng = np.random.default_rng(seed)
+    clen = np.array([len(c) for c in chroms])
+    r1, r2, truth = [], [], []
+
+    def mutate(seg):
+        nsub = int(rng.choice(len(mix), p=np.array(mix) / sum(mix)))
+        for p in rng.choice(len(seg), size=nsub, replace=False):
+            seg[p] = ALPHA[(np.searchsorted(ALPHA, seg[p]) + rng.integers(1, 4)) % 4]
+        return seg, nsub
+
+    while len(r1) < n:
+        ci = int(rng.choice(len(chroms), p=clen / clen.sum()))
+        la = L if var_len is None else int(rng.integers(var_len[0], var_len[1] + 1))
+        lb = L if var_len is None else int(rng.integers(var_len[0], var_len[1] + 1))
+        ins = int(np.clip(round(rng.normal(ins_mean, ins_sd)), max(la, lb) + 1, ins_max))
+        st = int(rng.integers(0, clen[ci] - ins - 4000))
+        frag = chroms[ci][st:st + ins]
+        kind = rng.random()
+        a = frag[:la].copy()
+        b = frag[ins - lb:].copy()
+        if kind < frac_far:                                   # second mate from 1.5-3.5 kbp further on: both align, insert too large
+            off = int(rng.integers(1500, 3500))
+            b = chroms[ci][st + off:st + off + lb].copy()
+        if (a == ord("N")).any() or (b == ord("N")).any():
+            continue
+        a, na = mutate(a)
+        b, nb = mutate(b)
+        b = COMP[b[::-1]]
+        if frac_far <= kind < frac_far + frac_half:           # one mate unalignable
+            if rng.random() < 0.5:
+                a = ALPHA[rng.integers(0, 4, size=la)]
+            else:
+                b = ALPHA[rng.integers(0, 4, size=lb)]
+        elif frac_far + frac_half <= kind < frac_far + frac_half + frac_none:
+            a = ALPHA[rng.integers(0, 4, size=la)]
+            b = ALPHA[rng.integers(0, 4, size=lb)]
+        swap = int(rng.integers(0, 2))
+        if swap:
+            a, b = b, a
+        r1.append(a.tobytes())
+        r2.append(b.tobytes())
+        truth.append((ci, st, ins, swap))
+    return r1, r2, truth
+
+
+def write_fastq(path, reads, prefix="r", suffix=""):
     with open(path, "wb") as f:
         for i, r in enumerate(reads):
-            f.write(b"@%s%d\n" % (prefix.encode(), i))
+            f.write(b"@%s%d%s\n" % (prefix.encode(), i, suffix.encode()))
             f.write(r)
             f.write(b"\n+\n")
             f.write(b"I" * len(r))
@@ -106,12 +156,25 @@ def main():
     ap.add_argument("--fastq", default=None)
     ap.add_argument("--truth", default=None)
     ap.add_argument("--mix", type=float, nargs="+", default=None, help="weights of 0,1,2,... substitutions per read")
+    ap.add_argument("--pairs", type=int, default=0, help="number of read pairs (written to --fastq and --fastq2)")
+    ap.add_argument("--fastq2", default=None)
+    ap.add_argument("--insert-mean", type=float, default=350)
+    ap.add_argument("--insert-sd", type=float, default=40)
     a = ap.parse_args()
     chroms = make_genome(a.genome_len, a.chroms, a.n_runs, a.genome_seed, a.repeats)
     write_fasta(a.fasta, chroms)
     if a.reads:
         reads, truth = make_reads(chroms, a.reads, a.read_len, a.read_seed, var_len=a.var_len, **({"mix": tuple(a.mix)} if a.mix else {}))
         write_fastq(a.fastq, reads)
+        if a.truth:
+            with open(a.truth, "w") as f:
+                for t in truth:
+                    f.write("%d %d %d %d\n" % t)
+    if a.pairs:
+        kw = {"mix": tuple(a.mix)} if a.mix else {}
+        r1, r2, truth = make_pairs(chroms, a.pairs, a.read_len, a.read_seed, ins_mean=a.insert_mean, ins_sd=a.insert_sd, var_len=a.var_len, **kw)
+        write_fastq(a.fastq, r1, prefix="p", suffix="/1")
+        write_fastq(a.fastq2, r2, prefix="p", suffix="/2")
         if a.truth:
             with open(a.truth, "w") as f:
                 for t in truth:
