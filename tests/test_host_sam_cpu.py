@@ -1,0 +1,70 @@
+"""not gpu: the product's host code (index + read loaders, SAM writer with the reference's MAPQ / XA / boundary rules) checked against the
+reference's golden SAM WITHOUT a device: tests/tools/oracle_sam.cpp drives it with the CPU oracle's alignments.  This pins, on the CPU,
+both the oracle's ladders (single-end -h 1..4, long-read mode, paired-end) and the host formatting, record for record."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import s3o
+from conftest import GOLDEN, ROOT
+from test_gpu_cli_sam import LONG_VARIANTS, PAIR_VARIANTS, VARIANTS, sam_pair_records, sam_records
+
+TOOL = os.path.join(ROOT, "tests", "tools", "oracle_sam")
+_built = {}
+
+
+def tool():
+    if "ok" not in _built:
+        s3o.build()
+        src = [os.path.join(ROOT, "tests", "tools", "oracle_sam.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host.cpp")]
+        osrc = [os.path.join(ROOT, "oracle", f) for f in ("s3_oracle.c", "s3_oracle_pe.c")]
+        objs = []
+        for c in osrc:
+            o = os.path.join("/tmp", "s3o_" + os.path.basename(c) + ".o")
+            subprocess.check_call(["gcc", "-O2", "-c", c, "-o", o])
+            objs.append(o)
+        lib = os.path.join(ROOT, "soap3-dp_amd")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", TOOL] + src + objs + ["-L" + lib, "-ls3dp", "-lz", "-lm", "-Wl,-rpath," + lib])
+        _built["ok"] = True
+    return TOOL
+
+
+def run(tmp_path, args):
+    out = subprocess.run([tool()] + args + ["-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return open(tmp_path / "out.gout.1").read()
+
+
+def compare(mine, ref):
+    assert mine[0] == ref[0]
+    assert set(mine[1]) == set(ref[1])
+    bad = [(k, ref[1][k], mine[1][k]) for k in ref[1] if ref[1][k] != mine[1][k]]
+    assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][1], bad[0][2])
+
+
+@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
+@pytest.mark.parametrize("variant,opts", VARIANTS)
+def test_single_end_sam(tmp_path, name, maxlen, variant, opts):
+    shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), tmp_path / (name + ".fq"))
+    text = run(tmp_path, ["single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", str(maxlen)] + opts)
+    compare(sam_records(text), sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_%s.sam.gz" % variant), "rt").read()))
+
+
+@pytest.mark.parametrize("variant,opts", LONG_VARIANTS)
+def test_long_read_sam(tmp_path, variant, opts):
+    name = "g3"
+    shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), tmp_path / (name + ".fq"))
+    text = run(tmp_path, ["single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", "200"] + opts)
+    compare(sam_records(text), sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_%s.sam.gz" % variant), "rt").read()))
+
+
+@pytest.mark.parametrize("variant,opts", PAIR_VARIANTS)
+def test_pair_sam(tmp_path, variant, opts):
+    name = "g4"
+    for k in ("1", "2"):
+        shutil.copy(os.path.join(GOLDEN, name, "reads_%s.fq" % k), tmp_path / ("%s_%s.fq" % (name, k)))
+    text = run(tmp_path, ["pair", os.path.join(GOLDEN, name, "index"), name + "_1.fq", name + "_2.fq", "-L", "100", "-u", "500", "-v", "200"] + opts)
+    compare(sam_pair_records(text), sam_pair_records(gzip.open(os.path.join(GOLDEN, name, "pe_%s.sam.gz" % variant), "rt").read()))
