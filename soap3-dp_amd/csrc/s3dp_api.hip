@@ -279,7 +279,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     HIPCHK(hipStreamCreate(&b->stream));
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
-    BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * wordPerQuery + 16);
+    BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
     BA(dRecs, recCap); BA(dOrdered, recCap);
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
@@ -331,7 +331,7 @@ extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint3
     const size_t roundUp = ((size_t)n + 31) / 32 * 32;
     HIPCHK(hipMemcpyAsync(b->dQueries, queries, roundUp * b->wpq * 4, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->dLens, readLengths, (size_t)n * 4, hipMemcpyHostToDevice, b->stream));
-    launchTransposeReads(b->dQueries, b->dReadsT, n, b->wpq, b->stream);
+    launchOrientReads(b->dQueries, b->dLens, b->dReadsT, n, b->wpq, b->wpq, b->stream);
     HIPCHK(hipStreamSynchronize(b->stream));
     b->n = n;
     b->lastKind = 0;
@@ -348,7 +348,14 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
 {
     if (!b) return fail(S3_EINVAL, "null batch");
     HIPCHK(hipSetDevice(b->ix->dev));
-    if (!seedLengths) { b->longMode = false; b->uniformLen = b->fullUniformLen; return S3_OK; }
+    if (!seedLengths) {
+        if (b->longMode) {
+            launchOrientReads(b->dQueries, b->dLens, b->dReadsT, b->n, b->wpq, b->wpq, b->stream);
+            HIPCHK(hipStreamSynchronize(b->stream));
+        }
+        b->longMode = false; b->uniformLen = b->fullUniformLen;
+        return S3_OK;
+    }
     const uint32_t n = b->n;
     std::vector<uint32_t> lens(n);
     HIPCHK(hipMemcpy(lens.data(), b->dLens, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -356,6 +363,7 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
         if (seedLengths[i] < 16 || seedLengths[i] > lens[i] || seedLengths[i] > 128)
             return fail(S3_EINVAL, "s3_batch_set_seed_lengths: a seed must have 16..128 bases and not exceed its read");
     HIPCHK(hipMemcpyAsync(b->dSeedLens, seedLengths, (size_t)n * 4, hipMemcpyHostToDevice, b->stream));
+    launchOrientReads(b->dQueries, b->dSeedLens, b->dReadsT, n, b->wpq, b->wpq > 8 ? 8u : b->wpq, b->stream);   // seeds have at most 128 bases
     HIPCHK(hipStreamSynchronize(b->stream));
     b->uniformLen = n ? seedLengths[0] : 0;
     for (uint32_t i = 1; i < n; i++) if (seedLengths[i] != seedLengths[0]) { b->uniformLen = 0; break; }
@@ -564,7 +572,7 @@ struct ValidateArgs {
     const uint32_t *occOffsets;
     uint32_t occBase;
     uint32_t *occPos, *occMeta;
-    const uint32_t *readsT;
+    const uint32_t *queries;      // packed reads, reference layout (32-interleaved, LSB-first characters)
     uint32_t wpq;
     const uint32_t *lens, *seedLens;
     const uint32_t *text;
@@ -591,8 +599,8 @@ __global__ void validateKernel(ValidateArgs a)
         int maxMis = (int)ceil(0.02 * (double)readLen);                  // MISMATCH_RATIO_FOR_LONG, CPUfunctions.cpp:1819
         if (a.needMapq) maxMis *= 2;
         int pre = maxMis;
-        const uint32_t *rd = a.readsT + (size_t)r * a.wpq;
-        auto readChar = [&](uint32_t q) -> uint32_t { return (rd[q >> 4] >> ((q & 15u) * 2u)) & 3u; };
+        const uint32_t *rd = a.queries + (size_t)(r >> 5) * 32u * a.wpq + (r & 31u);
+        auto readChar = [&](uint32_t q) -> uint32_t { return (rd[(size_t)(q >> 4) * 32u] >> ((q & 15u) * 2u)) & 3u; };
         auto textChar = [&](uint64_t p) -> uint32_t { return (a.text[p >> 4] >> (2u * (15u - (uint32_t)(p & 15u)))) & 3u; };
         out = 0;
         for (uint32_t i = 0; i < cnt; i++) {
@@ -656,7 +664,7 @@ static int decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActiv
     if (lg.on) {
         ValidateArgs v{};
         v.nActive = nActive; v.active = active; v.state = b->dState; v.want = want; v.occOffsets = b->dOccOffsets; v.occBase = base;
-        v.occPos = b->dOccPos; v.occMeta = b->dOccMeta; v.readsT = b->dReadsT; v.wpq = b->wpq; v.lens = b->dLens; v.seedLens = b->dSeedLens;
+        v.occPos = b->dOccPos; v.occMeta = b->dOccMeta; v.queries = b->dQueries; v.wpq = b->wpq; v.lens = b->dLens; v.seedLens = b->dSeedLens;
         v.text = b->ix->d.pac; v.textLength = b->ix->d.n;
         v.onlyBest = lg.onlyBest; v.minSeedMis = lg.minSeedMis; v.needMapq = lg.needMapq; v.maxHit = lg.maxHit; v.carryOn = lg.carryOn;
         v.outPhase = b->dPhase; v.outOccCount = b->dOccCount; v.selFlags = b->dSelFlags;

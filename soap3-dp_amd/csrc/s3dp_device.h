@@ -33,7 +33,7 @@ struct DevIndex {
 
 struct SearchIn {
     const uint32_t *queries;     // packed reads, reference layout
-    const uint32_t *readsT;      // same words, contiguous per read: readsT[r * wpq + w]  (v2 kernel)
+    const uint32_t *readsT;      // both orientations, MSB-first words: readsT[r * 2 * wpqLoad + strand * wpqLoad + w]  (v2 kernel)
     const uint32_t *readLengths;
     const uint32_t *active;      // optional indirection: slot -> read index
     uint32_t        nActive;
@@ -83,7 +83,7 @@ struct DpArgs {
 };
 void launchDp(const DpArgs &a, hipStream_t s);
 
-void launchTransposeReads(const uint32_t *queries, uint32_t *readsT, uint32_t n, uint32_t wpq, hipStream_t s);
+void launchOrientReads(const uint32_t *queries, const uint32_t *lengths, uint32_t *readsT, uint32_t n, uint32_t wpq, uint32_t S, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
 void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
 void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);

@@ -44,12 +44,11 @@ __device__ __forceinline__ uint4 rankAll(const DevBwt &b, uint32_t i)
     if (i != p) {
         const bool fwd = i > p;
         const uint32_t d = fwd ? i - p : p - i;
+        // the d characters next to the sample are the FIRST d of either half-block: the half before the sample is stored reversed
         const uint4 w = line[fwd ? 2 : 1];
-        const uint64_t w0 = ((uint64_t)w.x << 32) | w.y, w1 = ((uint64_t)w.z << 32) | w.w;
-        // characters counted: the first d of the 64 after the sample, or the last d of the 64 before it
-        const uint64_t mA = fwd ? hiMask(d) : loMask(d);
-        const uint64_t mB = d > 32 ? (fwd ? hiMask(d - 32) : loMask(d - 32)) : 0ULL;
-        const uint64_t wA = fwd ? w0 : w1, wB = fwd ? w1 : w0;
+        const uint64_t wA = ((uint64_t)w.x << 32) | w.y, wB = ((uint64_t)w.z << 32) | w.w;
+        const uint64_t mA = hiMask(d);
+        const uint64_t mB = d > 32 ? hiMask(d - 32) : 0ULL;
         const uint64_t M5 = 0x5555555555555555ULL;
         const uint64_t loA = wA & M5, hiA = (wA >> 1) & M5, loB = wB & M5, hiB = (wB >> 1) & M5;
         const uint64_t a = mA & M5, bm = mB & M5;
@@ -474,36 +473,68 @@ __global__ void classifyKernel(uint32_t nActive, const uint32_t *totalOcc, const
     state[slot] = st;
 }
 
+// One 64-byte line per 128 BWT characters (sample k at position p = 128 k):
+//   [0] Occ(c, p) + C[c], c = 0..3
+//   [1] the 64 characters BEFORE the sample in REVERSED order (character t = BWT[p - 1 - t]), 16 per word, first in the top bits
+//   [2] the 64 characters from the sample on (character t = BWT[p + t])
+//   [3] .x / .y: counts of the symbols 1, 2, 3 (one byte each, bits 0-7 / 8-15 / 16-23) among the first 32 characters of [1] / [2]
+// so a rank query is: the sampled counts +/- the symbol counts of the first d <= 64 characters of ONE half, and with [3] never more than
+// 32 characters (two words) have to be counted.
 __global__ void relayoutKernel(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines)
 {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= occRecs) return;
     auto word = [&](long long idx) -> uint32_t { return (idx >= 0 && (size_t)idx < bwtWords) ? bwt[idx] : 0u; };
+    auto rev16 = [](uint32_t x) -> uint32_t { x = __brev(x); return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); };
+    auto counts = [](uint32_t a, uint32_t b) -> uint32_t {
+        uint32_t c1 = 0, c2 = 0, c3 = 0;
+        for (int t = 0; t < 32; t++) {
+            const uint32_t ch = ((t < 16 ? a : b) >> (30 - 2 * (t & 15))) & 3u;
+            c1 += ch == 1; c2 += ch == 2; c3 += ch == 3;
+        }
+        return c1 | c2 << 8 | c3 << 16;
+    };
     const long long w0 = (long long)k * 8;
     uint4 o, prev, next, pad;
     o.x = occ[4 * k]; o.y = occ[4 * k + 1]; o.z = occ[4 * k + 2]; o.w = occ[4 * k + 3];
-    prev.x = word(w0 - 4); prev.y = word(w0 - 3); prev.z = word(w0 - 2); prev.w = word(w0 - 1);
+    prev.x = rev16(word(w0 - 1)); prev.y = rev16(word(w0 - 2)); prev.z = rev16(word(w0 - 3)); prev.w = rev16(word(w0 - 4));
     next.x = word(w0); next.y = word(w0 + 1); next.z = word(w0 + 2); next.w = word(w0 + 3);
-    pad.x = pad.y = pad.z = pad.w = 0;
+    pad.x = counts(prev.x, prev.y); pad.y = counts(next.x, next.y); pad.z = pad.w = 0;
     lines[4 * k] = o; lines[4 * k + 1] = prev; lines[4 * k + 2] = next; lines[4 * k + 3] = pad;
 }
 
 // ---------------------------------------------------------------------------------------------
 // launchers (called from s3dp_api.cpp through s3dp_device.h)
 // ---------------------------------------------------------------------------------------------
-__global__ void transposeReadsKernel(const uint32_t *queries, uint32_t *readsT, uint32_t n, uint32_t wpq)
+// Per read, both orientations of the searched prefix as MSB-first words (16 characters per word, first one in the top bits), the layout
+// the wave-cooperative search kernel keeps in LDS:  readsT[r * 2 S + strand * S + w], strand 0 = the read, 1 = its reverse complement
+// (3 - c, DV-Kernel.h:35), S = words per orientation.  `lengths` are the SEARCHED lengths (the seed length in long-read mode).
+__global__ void orientReadsKernel(const uint32_t *queries, const uint32_t *lengths, uint32_t *readsT, uint32_t n, uint32_t wpq, uint32_t S)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)n * wpq) return;
-    const uint32_t r = (uint32_t)(t / wpq), w = (uint32_t)(t % wpq);
-    readsT[t] = queries[(size_t)(r >> 5) * 32u * wpq + (r & 31u) + (size_t)w * 32u];
+    if (t >= (uint64_t)n * 2u * S) return;
+    const uint32_t r = (uint32_t)(t / (2u * S)), k = (uint32_t)(t % (2u * S)), strand = k / S, w = k % S;
+    const uint32_t *src = queries + (size_t)(r >> 5) * 32u * wpq + (r & 31u);
+    const uint32_t len = lengths[r];
+    uint32_t out = 0;
+    for (uint32_t c = 0; c < 16u; c++) {
+        const uint32_t pos = w * 16u + c;
+        uint32_t ch = 0;
+        if (pos < len) {
+            const uint32_t q = strand ? len - 1u - pos : pos;
+            ch = (src[(size_t)(q >> 4) * 32u] >> ((q & 15u) * 2u)) & 3u;
+            if (strand) ch = 3u - ch;
+        }
+        out |= ch << (30u - 2u * c);
+    }
+    readsT[t] = out;
 }
 
-void launchTransposeReads(const uint32_t *queries, uint32_t *readsT, uint32_t n, uint32_t wpq, hipStream_t s)
+void launchOrientReads(const uint32_t *queries, const uint32_t *lengths, uint32_t *readsT, uint32_t n, uint32_t wpq, uint32_t S, hipStream_t s)
 {
-    const uint64_t total = (uint64_t)n * wpq;
+    const uint64_t total = (uint64_t)n * 2u * S;
     if (!total) return;
-    hipLaunchKernelGGL(transposeReadsKernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, queries, readsT, n, wpq);
+    hipLaunchKernelGGL(orientReadsKernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, queries, lengths, readsT, n, wpq, S);
 }
 
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s)

@@ -42,70 +42,46 @@ __device__ __forceinline__ uint32_t pairRev(uint32_t x)   // reverse the order o
     return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
 }
 
-// rank from a staged line: occ = Occ(.,128k)+C, w = the 64 characters before (i < p) or after (i > p) the sample
-__device__ __forceinline__ uint4 rankFromLine(uint32_t i, uint4 occ, uint4 w)
+// mask of the first n (0..16) characters of an MSB-first word, on the even bit of every character
+__device__ __forceinline__ uint32_t topChars(uint32_t n)
 {
-    const uint32_t k = (i + 63u) >> 7, p = k << 7;
+    const uint32_t t = 2u * n;
+    return (t >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> t)) & 0x55555555u;
+}
+
+// Rank of all four symbols at index i from the line of sample k = (i + 63) >> 7 (layout: relayoutKernel, s3dp_kernels.hip):
+//   occ  = line[0]; half = the two words of the half-block that hold the counted characters; sub = line[3].x (before) / .y (after).
+// d = |i - 128 k| <= 64 characters next to the sample are counted; the first 32 of them come precounted in `sub`, so at most two
+// words go through the popcount.  32-bit VALU only.
+struct RankSel { uint32_t d, n; bool fwd, far; };     // far: d > 32 -> words z,w of the half + precounts, else words x,y
+__device__ __forceinline__ RankSel rankSel(uint32_t i)
+{
+    const uint32_t p = ((i + 63u) >> 7) << 7;
+    RankSel r;
+    r.fwd = i > p;
+    r.d = r.fwd ? i - p : p - i;
+    r.far = r.d > 32u;
+    r.n = r.far ? r.d - 32u : r.d;
+    return r;
+}
+__device__ __forceinline__ uint4 rankFromWords(const RankSel &q, uint4 occ, uint32_t wa, uint32_t wb, uint32_t sub)
+{
+    const uint32_t n0 = q.n < 16u ? q.n : 16u, n1 = q.n - n0;
+    const uint32_t m0 = topChars(n0), m1 = topChars(n1);
+    const uint32_t la = wa & m0, ha = (wa >> 1) & m0, ba = la & ha;
+    const uint32_t lb = wb & m1, hb = (wb >> 1) & m1, bb = lb & hb;
+    uint32_t c3 = __popc(ba) + __popc(bb);
+    uint32_t c2 = __popc(ha ^ ba) + __popc(hb ^ bb);
+    uint32_t c1 = __popc(la ^ ba) + __popc(lb ^ bb);
+    if (q.far) { c1 += sub & 0xFFu; c2 += (sub >> 8) & 0xFFu; c3 += (sub >> 16) & 0xFFu; }
+    const uint32_t c0 = q.d - c1 - c2 - c3;
     uint4 v = occ;
-    if (i != p) {
-        const bool fwd = i > p;
-        const uint32_t d = fwd ? i - p : p - i;
-        const uint64_t w0 = ((uint64_t)w.x << 32) | w.y, w1 = ((uint64_t)w.z << 32) | w.w;
-        const uint64_t mA = fwd ? hiMask(d) : loMask(d);
-        const uint64_t mB = d > 32 ? (fwd ? hiMask(d - 32) : loMask(d - 32)) : 0ULL;
-        const uint64_t wA = fwd ? w0 : w1, wB = fwd ? w1 : w0;
-        const uint64_t M5 = 0x5555555555555555ULL;
-        const uint64_t loA = wA & M5, hiA = (wA >> 1) & M5, loB = wB & M5, hiB = (wB >> 1) & M5;
-        const uint64_t a = mA & M5, bm = mB & M5;
-        const uint32_t c3 = __popcll(hiA & loA & a) + __popcll(hiB & loB & bm);
-        const uint32_t c2 = __popcll(hiA & ~loA & a) + __popcll(hiB & ~loB & bm);
-        const uint32_t c1 = __popcll(~hiA & loA & a) + __popcll(~hiB & loB & bm);
-        const uint32_t c0 = d - c1 - c2 - c3;
-        if (fwd) { v.x += c0; v.y += c1; v.z += c2; v.w += c3; }
-        else { v.x -= c0; v.y -= c1; v.z -= c2; v.w -= c3; }
-    }
+    if (q.fwd) { v.x += c0; v.y += c1; v.z += c2; v.w += c3; }
+    else { v.x -= c0; v.y -= c1; v.z -= c2; v.w -= c3; }
     return v;
 }
 
-// exact-step variant: only the read character's rank (eq) and the total rank of the larger symbols (gt) are needed
-__device__ __forceinline__ void rankEqGt(uint32_t i, uint4 occ, uint4 w, uint32_t ch, uint32_t &eq, uint32_t &gt)
-{
-    const uint32_t k = (i + 63u) >> 7, p = k << 7;
-    eq = sel4(occ, ch);
-    gt = (ch < 3 ? occ.w : 0u) + (ch < 2 ? occ.z : 0u) + (ch < 1 ? occ.y : 0u);
-    if (i != p) {
-        const bool fwd = i > p;
-        const uint32_t d = fwd ? i - p : p - i;
-        const uint64_t w0 = ((uint64_t)w.x << 32) | w.y, w1 = ((uint64_t)w.z << 32) | w.w;
-        const uint64_t M5 = 0x5555555555555555ULL;
-        const uint64_t mA = (fwd ? hiMask(d) : loMask(d)) & M5;
-        const uint64_t mB = (d > 32 ? (fwd ? hiMask(d - 32) : loMask(d - 32)) : 0ULL) & M5;
-        const uint64_t wA = fwd ? w0 : w1, wB = fwd ? w1 : w0;
-        const uint64_t loA = wA & M5, hiA = (wA >> 1) & M5, loB = wB & M5, hiB = (wB >> 1) & M5;
-        // per-character indicator bits (on the even bit of each 2-bit character)
-        const uint64_t eqA = (ch & 2u ? hiA : ~hiA) & (ch & 1u ? loA : ~loA), eqB = (ch & 2u ? hiB : ~hiB) & (ch & 1u ? loB : ~loB);
-        const uint64_t gtA = ch == 0 ? (hiA | loA) : ch == 1 ? hiA : ch == 2 ? (hiA & loA) : 0ULL;
-        const uint64_t gtB = ch == 0 ? (hiB | loB) : ch == 1 ? hiB : ch == 2 ? (hiB & loB) : 0ULL;
-        const uint32_t ce = __popcll(eqA & mA) + __popcll(eqB & mB), cg = __popcll(gtA & mA) + __popcll(gtB & mB);
-        if (fwd) { eq += ce; gt += cg; } else { eq -= ce; gt -= cg; }
-    }
-}
-
 struct Range { uint32_t fl, fr, rl, rr; };
-
-__device__ __forceinline__ Range childRange(int dir, const Range &g, const uint4 &oL, const uint4 &oR, uint32_t ch)
-{
-    const uint32_t al = sel4(oL, ch) + 1u, ar = sel4(oR, ch);
-    uint32_t oc = 0;
-    if (ch < 3) oc += oR.w - oL.w;
-    if (ch < 2) oc += oR.z - oL.z;
-    if (ch < 1) oc += oR.y - oL.y;
-    const uint32_t pr = (dir < 0 ? g.rr : g.fr) - oc, pl = pr - (ar - al);
-    Range o;
-    if (dir < 0) { o.fl = al; o.fr = ar; o.rl = pl; o.rr = pr; }
-    else { o.rl = al; o.rr = ar; o.fl = pl; o.fr = pr; }
-    return o;
-}
 
 }  // namespace v2
 
@@ -123,11 +99,11 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 {
     extern __shared__ __align__(16) unsigned char shmem[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t wpq = in.wpqLoad, wpqStride = in.wpq;
-    const uint32_t waveBytes = 4096u + wpq * 256u;
+    const uint32_t wpq = in.wpqLoad;                                        // words per orientation of the searched prefix
+    const uint32_t waveBytes = 4096u + 2u * wpq * 256u;
     unsigned char *wbase = shmem + S3_V2_MODEL_BYTES + wv * waveBytes;
     uint4 *stage = (uint4 *)wbase;                                          // [64 owners][4 x 16 B]
-    uint32_t *rdw = (uint32_t *)(wbase + 4096u);                            // raw read words: rdw[w * 64 + lane]
+    uint32_t *ro = (uint32_t *)(wbase + 4096u);                             // oriented read words, MSB first: ro[(strand * wpq + w) * 64 + lane]
     uint32_t *myStage32 = (uint32_t *)(stage + lane * 4u);
 
     if (UNIFORM) {
@@ -165,26 +141,12 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         if constexpr (UNIFORM) return ((const S3Model *)shmem)->cs[casIdx].st[k];      // LDS (address space known to the compiler)
         else return in.models[Li].cs[casIdx].st[k];                                    // global, L1/L2 resident
     };
-    auto rawWord = [&](int w) -> uint32_t { return (w >= 0 && w < (int)wpq) ? rdw[(uint32_t)w * 64u + lane] : 0u; };
-    auto readChar = [&](int pos) -> uint32_t {
-        const int q = strand ? Li - 1 - pos : pos;
-        const uint32_t c = (rdw[(uint32_t)(q >> 4) * 64u + lane] >> ((q & 15) * 2)) & 3u;
-        return strand ? 3u - c : c;
-    };
-    auto readWindow = [&](int p0) -> uint32_t {               // 16 oriented characters from p0, first one in the top bits
-        if (!strand) {
-            const int w = p0 >> 4, sh = (p0 & 15) * 2;
-            const uint64_t two = ((uint64_t)rawWord(w + 1) << 32) | rawWord(w);
-            return pairRev((uint32_t)(two >> sh));
-        }
-        const int a = Li - 16 - p0;
-        uint32_t x;
-        if (a >= 0) {
-            const int w = a >> 4, sh = (a & 15) * 2;
-            const uint64_t two = ((uint64_t)rawWord(w + 1) << 32) | rawWord(w);
-            x = (uint32_t)(two >> sh);
-        } else x = (-a < 16) ? (rawWord(0) << (2 * (-a))) : 0u;
-        return ~x;
+    auto oword = [&](uint32_t w) -> uint32_t { return w < wpq ? ro[(strand * wpq + w) * 64u + lane] : 0u; };
+    auto readChar = [&](int pos) -> uint32_t { return (ro[(strand * wpq + ((uint32_t)pos >> 4)) * 64u + lane] >> (30u - 2u * ((uint32_t)pos & 15u))) & 3u; };
+    auto readWindow = [&](int p0) -> uint32_t {               // 16 oriented characters from p0 >= 0, first one in the top bits
+        const uint32_t w = (uint32_t)p0 >> 4, sh = ((uint32_t)p0 & 15u) * 2u;
+        const uint32_t a = oword(w), b2 = oword(w + 1u);
+        return sh ? (a << sh) | (b2 >> (32u - sh)) : a;
     };
     // A record is not written where it is found: the lane parks it (one per iteration) and the whole wave writes the
     // parked records at the end of the iteration into a block of record slots it reserved with ONE atomic per
@@ -330,13 +292,15 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             needB = kR != kL;
             if (needB) {
                 const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
+                const bool fw = iR > (kR << 7);
                 aP0 = line;
-                aP1 = line + (iR > (kR << 7) ? 2 : 1);
+                aP1 = line + (fw ? 2 : 1);
+                aD0 = (const uint32_t *)(line + 3) + (fw ? 1 : 0);
             }
         } else if (state == ST_LOAD) {
-            const uint4 *src = (const uint4 *)(in.readsT + (size_t)rIdx * wpqStride + loadOff);  // both are powers of two
+            const uint4 *src = (const uint4 *)(in.readsT + (size_t)rIdx * 2u * wpq + loadOff);   // wpq is a power of two
             aP0 = src;
-            if (wpq - loadOff > 4) aP1 = src + 1;
+            if (2u * wpq - loadOff > 4) aP1 = src + 1;
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
         } else if (state == ST_LT) {
             const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
@@ -389,57 +353,39 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 
         // ---------- advance ----------
         bool doSettle = false, needPop = false;
-        const bool stepping = state == ST_STEP;
-        S3Step stS;
-        bool exact = true;
-        if (stepping) { stS = stepAt(s); exact = ins >= stS.maxErr; }
-        if (__ballot(stepping && !exact) == 0) {
-            // every stepping lane is in an exact region (the common case): one symbol's rank + the larger-symbol total
-            if (stepping) {
-                const uint32_t kL = (iL + 63u) >> 7;
-                const uint4 occA = stage[lane * 4u];
-                uint4 wL = make_uint4(0, 0, 0, 0), wR = make_uint4(0, 0, 0, 0);
-                if (iL != (kL << 7)) wL = stage[lane * 4u + (iL > (kL << 7) ? 2u : 1u)];
-                const int pos = stS.start + stS.dir * i;
-                const uint32_t ch = readChar(pos);
-                uint32_t eqL, gtL, eqR, gtR;
-                rankEqGt(iL, occA, wL, ch, eqL, gtL);
-                if (needB) rankEqGt(iR, p0, p1, ch, eqR, gtR);
-                else {
-                    if (iR != (kL << 7)) wR = stage[lane * 4u + (iR > (kL << 7) ? 2u : 1u)];
-                    rankEqGt(iR, occA, wR, ch, eqR, gtR);
-                }
-                nRank += 2;
-                const uint32_t al = eqL + 1u, ar = eqR, oc = gtR - gtL;
-                const uint32_t pr = (stS.dir < 0 ? g.rr : g.fr) - oc, pl = pr - (ar - al);
-                if (stS.dir < 0) { g.fl = al; g.fr = ar; g.rl = pl; g.rr = pr; }
-                else { g.rl = al; g.rr = ar; g.fl = pl; g.fr = pr; }
-                i++;
-                doSettle = true;
-            }
-        } else if (stepping) {
-            const uint32_t kL = (iL + 63u) >> 7;
+        if (state == ST_STEP) {
+            const S3Step stS = stepAt(s);
+            const bool exact = ins >= stS.maxErr;
+            const RankSel qL = rankSel(iL), qR = rankSel(iR);
             const uint4 occA = stage[lane * 4u];
-            uint4 wL = make_uint4(0, 0, 0, 0);
-            if (iL != (kL << 7)) wL = stage[lane * 4u + (iL > (kL << 7) ? 2u : 1u)];
-            const uint4 oL = rankFromLine(iL, occA, wL);
+            // own line in LDS as words: [0..3] counts, [4..7] half before (reversed), [8..11] half after, [12] / [13] precounts
+            const uint32_t offL = (qL.fwd ? 8u : 4u) + (qL.far ? 2u : 0u);
+            const uint4 oL = rankFromWords(qL, occA, myStage32[offL], myStage32[offL + 1u], myStage32[12u + (qL.fwd ? 1u : 0u)]);
             uint4 oR;
-            if (needB) oR = rankFromLine(iR, p0, p1);
+            if (needB) oR = rankFromWords(qR, p0, qR.far ? p1.z : p1.x, qR.far ? p1.w : p1.y, d0);
             else {
-                uint4 wR = make_uint4(0, 0, 0, 0);
-                if (iR != (kL << 7)) wR = stage[lane * 4u + (iR > (kL << 7) ? 2u : 1u)];
-                oR = rankFromLine(iR, occA, wR);
+                const uint32_t offR = (qR.fwd ? 8u : 4u) + (qR.far ? 2u : 0u);
+                oR = rankFromWords(qR, occA, myStage32[offR], myStage32[offR + 1u], myStage32[12u + (qR.fwd ? 1u : 0u)]);
             }
             nRank += 2;
             const int pos = stS.start + stS.dir * i;
             const uint32_t ch = readChar(pos);
-            const Range gc = childRange(stS.dir, g, oL, oR, ch);
+            // child ranges: the active range advances by rank, the passive one shrinks by the occurrences of the larger symbols
+            const uint32_t d1 = oR.y - oL.y, d2 = oR.z - oL.z, d3 = oR.w - oL.w;
+            const uint32_t base = stS.dir < 0 ? g.rr : g.fr;
+            auto child = [&](uint32_t al, uint32_t ar, uint32_t oc) -> Range {
+                const uint32_t pr = base - oc, pl = pr - (ar - al);
+                Range o;
+                if (stS.dir < 0) { o.fl = al; o.fr = ar; o.rl = pl; o.rr = pr; }
+                else { o.rl = al; o.rr = ar; o.fl = pl; o.fr = pr; }
+                return o;
+            };
+            const Range gc = child((ch == 0 ? oL.x : ch == 1 ? oL.y : ch == 2 ? oL.z : oL.w) + 1u, ch == 0 ? oR.x : ch == 1 ? oR.y : ch == 2 ? oR.z : oR.w,
+                                   ch == 0 ? d1 + d2 + d3 : ch == 1 ? d2 + d3 : ch == 2 ? d3 : 0u);
             doSettle = true;
             if (!exact) {
-                const Range e0 = childRange(stS.dir, g, oL, oR, 0u), e1 = childRange(stS.dir, g, oL, oR, 1u);
-                const Range e2 = childRange(stS.dir, g, oL, oR, 2u), e3 = childRange(stS.dir, g, oL, oR, 3u);
-                const bool a0 = ch != 0 && e0.fl <= e0.fr, a1 = ch != 1 && e1.fl <= e1.fr;
-                const bool a2 = ch != 2 && e2.fl <= e2.fr, a3 = ch != 3 && e3.fl <= e3.fr;
+                const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
+                const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
                 if (a0 || a1 || a2 || a3) {
                     if (sp + 4 > STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = ST_DONE; sp = 0; doSettle = false; }
                     else {
@@ -448,10 +394,10 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         Frame f;
                         f.fl = gc.fl; f.fr = gc.fr; f.rl = gc.rl; f.meta = mCont; stack[sp++] = f;
                         f.meta = mKid;
-                        if (a3) { f.fl = e3.fl; f.fr = e3.fr; f.rl = e3.rl; stack[sp++] = f; }
-                        if (a2) { f.fl = e2.fl; f.fr = e2.fr; f.rl = e2.rl; stack[sp++] = f; }
-                        if (a1) { f.fl = e1.fl; f.fr = e1.fr; f.rl = e1.rl; stack[sp++] = f; }
-                        if (a0) { f.fl = e0.fl; f.fr = e0.fr; f.rl = e0.rl; stack[sp++] = f; }
+                        if (a3) { const Range k = child(oL.w + 1u, oR.w, 0u); f.fl = k.fl; f.fr = k.fr; f.rl = k.rl; stack[sp++] = f; }
+                        if (a2) { const Range k = child(oL.z + 1u, oR.z, d3); f.fl = k.fl; f.fr = k.fr; f.rl = k.rl; stack[sp++] = f; }
+                        if (a1) { const Range k = child(oL.y + 1u, oR.y, d2 + d3); f.fl = k.fl; f.fr = k.fr; f.rl = k.rl; stack[sp++] = f; }
+                        if (a0) { const Range k = child(oL.x + 1u, oR.x, d1 + d2 + d3); f.fl = k.fl; f.fr = k.fr; f.rl = k.rl; stack[sp++] = f; }
                         needPop = true;
                     }
                 }
@@ -460,8 +406,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         }
         if (state == ST_RESUME && !(pendMeta >> 31)) { doSettle = true; needPop = true; }
         if (state == ST_LOAD) {
-            uint32_t *dst = rdw + (size_t)loadOff * 64u + lane;
-            const uint32_t left = wpq - loadOff;
+            uint32_t *dst = ro + (size_t)loadOff * 64u + lane;
+            const uint32_t left = 2u * wpq - loadOff;
             dst[0] = p0.x;
             if (left > 1) dst[64] = p0.y;
             if (left > 2) dst[128] = p0.z;
@@ -472,7 +418,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (left > 7) dst[448] = p1.w;
             loadOff += 8;
             if constexpr (!UNIFORM) Li = (int)saVal;
-            if (loadOff >= wpq) state = ST_KEYS;
+            if (loadOff >= 2u * wpq) state = ST_KEYS;
         } else if (state == ST_LT) {
             const S3Step st = stepAt(0);
             const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
@@ -572,7 +518,7 @@ void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out
     if (in.nActive == 0) return;
     uint64_t blocks = ((uint64_t)in.nActive + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
-    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + in.wpqLoad * 256u);
+    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wpqLoad * 256u);
     if (lds > 48u * 1024u) {
         (void)hipFuncSetAttribute((const void *)searchKernelV2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)searchKernelV2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
