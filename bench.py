@@ -242,7 +242,19 @@ def main():
     bytes_step = 32.0 * cnt["rankQueries"] + a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
     search_s_per_step = search_ms / 1e3 / max(1, a.steps)
     achieved = bytes_step / search_s_per_step / 1e9 if search_s_per_step > 0 else 0.0
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    # HBM traffic of that kernel comes from a separate rocprofv3 --pmc FETCH_SIZE pass (it cannot be collected from inside this process);
+    # the committed measurement is attached when it was taken on exactly this workload, per launch like `achieved`
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            for w in json.load(f)["workloads"]:
+                if all(w[k] == v for k, v in (("genome_bp", a.genome_bp), ("reads_per_gpu", a.reads), ("read_len", a.read_len),
+                                              ("max_mismatch", a.mismatch), ("max_output_per_read", a.max_out), ("repeat_frac", a.repeat_frac))):
+                    traffic = w["fetch_bytes_per_step"] / w["launches_per_step"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_unit": "bytes per launch (FETCH_SIZE, profiles/pmc_traffic.json)", "algorithmic_bytes_per_launch": bytes_step / max(1, launches // max(1, a.steps)),
             "kernel": "s3::searchKernelV2", "launches_per_step": launches // max(1, a.steps),
             "kernel_ms_per_step": search_ms / max(1, a.steps),
             "rank_queries_per_step": cnt["rankQueries"], "line_bytes_GBs": 64.0 * cnt["rankQueries"] / search_s_per_step / 1e9 if search_s_per_step else 0.0}

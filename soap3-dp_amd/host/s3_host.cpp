@@ -5,6 +5,8 @@
 #include <string.h>
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 namespace s3host {
 
@@ -164,10 +166,67 @@ s3_index_desc HostIndex::desc() const
 // ------------------------------------------------------------------------------------------------
 // reads: FASTA / FASTQ, plain or gzip (behaviour of loadSingleReadsGz, QueryParser.cpp:996-1355)
 // ------------------------------------------------------------------------------------------------
+// The whole file is inflated into memory, cut into one piece per host thread at record boundaries, and the pieces are parsed in
+// parallel (count pass, then fill pass straight into the packed arrays).  S3DP_HOST_THREADS overrides the thread count.
+int hostThreads()
+{
+    const char *e = getenv("S3DP_HOST_THREADS");
+    int t = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    if (t < 1) t = 1;
+    if (t > 256) t = 256;
+    return t;
+}
+
+namespace {
+struct Piece { size_t beg = 0, end = 0; uint32_t first = 0, count = 0; };
+
+// one record starting at p (which points at '>' or '@'); returns the position after it.  Emits through `rec` when asked to.
+template <class F>
+size_t parseRecord(const std::string &all, size_t p, bool fq, uint32_t maxReadLength, int maxLenReadName, const unsigned char *charMap, int qualityConstant, F &&rec,
+                   bool fill, std::string &name, std::vector<uint8_t> &seq, std::string &q, bool &bad)
+{
+    const size_t N = all.size();
+    p++;
+    if (fill) name.clear();
+    bool cropped = false;
+    while (p < N && all[p] != '\n') {
+        if (all[p] == ' ' || all[p] == '\t') cropped = true;
+        if (fill && !cropped && (int)name.size() < maxLenReadName - 1) name.push_back(all[p]);
+        p++;
+    }
+    if (fill && name.size() >= 2 && name[name.size() - 2] == '/') name.resize(name.size() - 2);
+    if (p < N) p++;
+    if (fill) seq.clear();
+    uint32_t nuc = 0;
+    while (p < N && all[p] != '>' && all[p] != '@' && all[p] != '+') {
+        if (all[p] != '\n') {
+            if (fill && nuc < maxReadLength) seq.push_back(charMap[(unsigned char)all[p]]);
+            nuc++;
+        }
+        p++;
+    }
+    if (nuc == 0) bad = true;
+    if (fill) q.assign(seq.size(), (char)0);
+    if (fq) {
+        while (p < N && all[p] != '+') p++;
+        while (p < N && all[p] != '\n') p++;
+        if (p < N) p++;
+        for (uint32_t i = 0; i < nuc && p < N; i++) {
+            if (all[p] == '\n') break;
+            if (fill && i < q.size()) q[i] = (char)(all[p] - qualityConstant);
+            p++;
+        }
+    }
+    rec();
+    return p;
+}
+}  // namespace
+
 bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err)
 {
     gzFile gz = gzopen(file.c_str(), "r");
     if (!gz) { err = "cannot open " + file; return false; }
+    gzbuffer(gz, 1 << 20);
     unsigned char charMap[256];
     memset(charMap, 0, sizeof charMap);                                 // INDEXFillCharMap, IndexHandler.cpp:25-48
     const char *acgt = "ACGT";
@@ -177,72 +236,110 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
     uint32_t w = 1;
     while (w < maxReadLength) w *= 2;
     rs.wpq = w / 16 ? w / 16 : 1;
-    std::vector<char> buf(1 << 20);
     std::string all;
-    int got;
-    while ((got = gzread(gz, buf.data(), (unsigned)buf.size())) > 0) all.append(buf.data(), (size_t)got);
-    gzclose(gz);
-    size_t p = 0;
-    const size_t N = all.size();
-    std::vector<std::vector<uint8_t>> codes;
-    std::vector<std::string> quals;
-    while (p < N) {
-        while (p < N && all[p] != '>' && all[p] != '@') p++;
-        if (p >= N) break;
-        const bool fq = all[p] == '@';
-        rs.isFastq = fq;
-        p++;
-        // name: up to the first blank, at most maxLenReadName-1 chars; a trailing "/1" or "/2" is cut
-        std::string name;
-        bool cropped = false;
-        while (p < N && all[p] != '\n') {
-            if (all[p] == ' ' || all[p] == '\t') cropped = true;
-            if (!cropped && (int)name.size() < maxLenReadName - 1) name.push_back(all[p]);
-            p++;
-        }
-        if (name.size() >= 2 && name[name.size() - 2] == '/') name.resize(name.size() - 2);
-        if (p < N) p++;
-        std::vector<uint8_t> seq;
-        uint32_t nuc = 0;
-        while (p < N && all[p] != '>' && all[p] != '@' && all[p] != '+') {
-            if (all[p] != '\n') {
-                if (nuc < maxReadLength) seq.push_back(charMap[(unsigned char)all[p]]);
-                nuc++;
-            }
-            p++;
-        }
-        if (nuc == 0) { err = "a read of length 0 in the read file"; return false; }
-        std::string q(seq.size(), (char)0);
-        if (fq) {
-            while (p < N && all[p] != '+') p++;
-            while (p < N && all[p] != '\n') p++;
-            if (p < N) p++;
-            for (uint32_t i = 0; i < nuc && p < N; i++) {
-                if (all[p] == '\n') break;
-                if (i < q.size()) q[i] = (char)(all[p] - qualityConstant);
-                p++;
-            }
-        }
-        rs.names.push_back(name);
-        codes.push_back(seq);
-        quals.push_back(q);
+    if (gzdirect(gz)) {
+        // not compressed: read the file itself, one slice per thread
+        gzclose(gz);
+        FILE *f = fopen(file.c_str(), "rb");
+        if (!f) { err = "cannot open " + file; return false; }
+        fseek(f, 0, SEEK_END);
+        const long long size = ftell(f);
+        fclose(f);
+        all.resize((size_t)size);
+        const int Tr = hostThreads() > 16 ? 16 : hostThreads();
+        std::vector<std::thread> rd;
+        std::atomic<bool> bad(false);
+        for (int t = 0; t < Tr; t++) rd.emplace_back([&, t] {
+            const size_t lo = (size_t)size / (size_t)Tr * (size_t)t, hi = t + 1 == Tr ? (size_t)size : (size_t)size / (size_t)Tr * (size_t)(t + 1);
+            FILE *g = fopen(file.c_str(), "rb");
+            if (!g || fseek(g, (long)lo, SEEK_SET) != 0 || fread(&all[lo], 1, hi - lo, g) != hi - lo) bad = true;
+            if (g) fclose(g);
+        });
+        for (auto &x : rd) x.join();
+        if (bad) { err = "cannot read " + file; return false; }
+    } else {
+        std::vector<char> buf(1 << 24);
+        int got;
+        while ((got = gzread(gz, buf.data(), (unsigned)buf.size())) > 0) all.append(buf.data(), (size_t)got);
+        gzclose(gz);
     }
-    rs.n = (uint32_t)codes.size();
+    const size_t N = all.size();
+    size_t p0 = 0;
+    while (p0 < N && all[p0] != '>' && all[p0] != '@') p0++;
+    const bool fq = p0 < N && all[p0] == '@';
+    rs.isFastq = fq;
+    // a record starts at a line that begins with the marker; for FASTQ the line after next must begin with '+' (a quality line may begin with '@')
+    auto isStart = [&](size_t p) -> bool {
+        if (p >= N || all[p] != (fq ? '@' : '>')) return false;
+        if (p > 0 && all[p - 1] != '\n') return false;
+        if (!fq) return true;
+        size_t q = p;
+        for (int k = 0; k < 2; k++) { while (q < N && all[q] != '\n') q++; if (q < N) q++; }
+        return q < N && all[q] == '+';
+    };
+    const int T = hostThreads();
+    std::vector<Piece> pieces((size_t)T);
+    for (int t = 0; t < T; t++) {
+        size_t b = p0 + (N - p0) / (size_t)T * (size_t)t;
+        if (t == 0) b = p0;
+        else { while (b < N && !isStart(b)) b++; }
+        pieces[(size_t)t].beg = b;
+    }
+    for (int t = 0; t < T; t++) pieces[(size_t)t].end = t + 1 < T ? pieces[(size_t)t + 1].beg : N;
+    std::atomic<bool> anyBad(false);
+    std::vector<std::thread> th;
+    // count pass
+    for (int t = 0; t < T; t++) th.emplace_back([&, t] {
+        Piece &P = pieces[(size_t)t];
+        std::string name, q; std::vector<uint8_t> seq; bool bad = false;
+        uint32_t c = 0;
+        size_t p = P.beg;
+        while (p < P.end) {
+            while (p < P.end && all[p] != '>' && all[p] != '@') p++;
+            if (p >= P.end) break;
+            p = parseRecord(all, p, fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] { c++; }, false, name, seq, q, bad);
+        }
+        P.count = c;
+        if (bad) anyBad = true;
+    });
+    for (auto &x : th) x.join();
+    th.clear();
+    if (anyBad) { err = "a read of length 0 in the read file"; return false; }
+    uint32_t n = 0;
+    for (auto &P : pieces) { P.first = n; n += P.count; }
+    rs.n = n;
     const size_t roundUp = ((size_t)rs.n + 31) / 32 * 32;
     rs.queries.assign(roundUp * rs.wpq, 0);
     rs.lengths.assign(rs.n, 0);
+    rs.names.assign(rs.n, std::string());
     rs.codes.assign((size_t)rs.n * maxReadLength, 0);
     rs.quals.assign((size_t)rs.n * maxReadLength, 0);
-    for (uint32_t r = 0; r < rs.n; r++) {
-        const std::vector<uint8_t> &s = codes[r];
-        rs.lengths[r] = (uint32_t)s.size();
-        uint32_t *dst = rs.queries.data() + (size_t)(r / 32) * 32 * rs.wpq + r % 32;
-        for (size_t i = 0; i < s.size(); i++) {
-            dst[(i / 16) * 32] |= (uint32_t)s[i] << (2 * (i % 16));
-            rs.codes[(size_t)r * maxReadLength + i] = s[i];
-            rs.quals[(size_t)r * maxReadLength + i] = quals[r][i];
+    // fill pass; 32 consecutive reads share packed words (32-interleaved layout), so a piece boundary inside a group of 32 is written by
+    // two threads -- to different words (word index = group base + r % 32 + 32 w), never the same one
+    for (int t = 0; t < T; t++) th.emplace_back([&, t] {
+        const Piece &P = pieces[(size_t)t];
+        std::string name, q; std::vector<uint8_t> seq; bool bad = false;
+        uint32_t r = P.first;
+        size_t p = P.beg;
+        while (p < P.end) {
+            while (p < P.end && all[p] != '>' && all[p] != '@') p++;
+            if (p >= P.end) break;
+            p = parseRecord(all, p, fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] {
+                rs.names[r] = name;
+                rs.lengths[r] = (uint32_t)seq.size();
+                uint32_t *dst = rs.queries.data() + (size_t)(r / 32) * 32 * rs.wpq + r % 32;
+                uint8_t *cd = &rs.codes[(size_t)r * maxReadLength];
+                char *qd = &rs.quals[(size_t)r * maxReadLength];
+                for (size_t i = 0; i < seq.size(); i++) {
+                    dst[(i / 16) * 32] |= (uint32_t)seq[i] << (2 * (i % 16));
+                    cd[i] = seq[i];
+                    qd[i] = q[i];
+                }
+                r++;
+            }, true, name, seq, q, bad);
         }
-    }
+    });
+    for (auto &x : th) x.join();
     return true;
 }
 
@@ -282,6 +379,19 @@ SamWriter::SamWriter(const HostIndex &ix_, const SamOptions &o, FILE *f) : ix(ix
 {
     for (int i = 1; i != 256; ++i) gLogN[i] = (int)(4.343 * log((double)i) + 0.5);      // bwase_initialize, CPUfunctions.cpp:3014
     gLogN[0] = 0;
+}
+
+SamWriter::SamWriter(const HostIndex &ix_, const SamOptions &o, std::string *sk) : ix(ix_), opt(o), out(nullptr), sink(sk)
+{
+    for (int i = 1; i != 256; ++i) gLogN[i] = (int)(4.343 * log((double)i) + 0.5);
+    gLogN[0] = 0;
+}
+
+void SamWriter::put(const std::string &line)
+{
+    if (sink) sink->append(line);
+    else fwrite(line.data(), 1, line.size(), out);
+    nRecords++;
 }
 
 void SamWriter::header()
@@ -340,8 +450,7 @@ void SamWriter::unaligned(const ReadSet &rs, uint32_t r)
     std::string line = rs.names[r] + "\t4\t*\t0\t0\t*\t*\t0\t0\t";
     seqAndQual(rs, r, false, line);
     line += "\tRG:Z:" + opt.readGroup + "\n";
-    fwrite(line.data(), 1, line.size(), out);
-    nRecords++;
+    put(line);
 }
 
 // MD string and average quality at the mismatching positions (getMdStr / mdStr, PE.cpp:209-284,374-420)
@@ -479,8 +588,7 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
     if (opt.printMDNM && !md.empty()) line += "\tMD:Z:" + md;
     if (nOcc > 1 && !xa.empty()) line += "\tXA:Z:" + xa;
     line.push_back('\n');
-    fwrite(line.data(), 1, line.size(), out);
-    nRecords++;
+    put(line);
 }
 
 void SamWriter::singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_t strand, uint8_t mis)
@@ -517,8 +625,7 @@ void SamWriter::singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_
     line += "\tX0:i:1\tXM:i:" + std::to_string((unsigned)mis) + "\tXO:i:0\tXG:i:0";
     if (opt.printMDNM && !md.empty()) line += "\tMD:Z:" + md;
     line.push_back('\n');
-    fwrite(line.data(), 1, line.size(), out);
-    nRecords++;
+    put(line);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -551,8 +658,7 @@ void SamWriter::emit(const ReadSet &rs, const Rec &c)
     line.push_back('\t');
     seqAndQual(rs, c.r, c.negative, line);
     line += "\tRG:Z:" + opt.readGroup + c.tags + "\n";
-    fwrite(line.data(), 1, line.size(), out);
-    nRecords++;
+    put(line);
 }
 
 static int bwaLikeSingle(int x0, int x1, const int *gLogN)                // bwaLikeSingleQualScore, BGS-IO.cpp:2310

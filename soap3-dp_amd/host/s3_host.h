@@ -31,6 +31,7 @@ struct HostIndex {
 };
 
 bool loadIndex(const std::string &prefix, HostIndex &ix, std::string &err);
+int hostThreads();                                       // S3DP_HOST_THREADS or the hardware concurrency (1..256)
 void buildLookupTable(const std::vector<uint32_t> &pacWords, uint32_t n, bool reversed, std::vector<uint32_t> &table);
 
 struct ReadSet {
@@ -59,6 +60,8 @@ struct SamOptions {
 class SamWriter {
 public:
     SamWriter(const HostIndex &ix, const SamOptions &opt, FILE *out);
+    // records are appended to *sink instead of a file: one writer + buffer per formatting thread, buffers written in read order
+    SamWriter(const HostIndex &ix, const SamOptions &opt, std::string *sink);
     void header();
     // one read of the single-end path: occurrence list in the CPU path's final order (OCCOutputSAMAPI, BGS-IO.cpp:5556)
     // checkLen: the length the reference hands to the boundary check and writes into the XA:Z CIGARs -- the SEARCHED length, i.e. the
@@ -83,6 +86,8 @@ private:
     const HostIndex &ix;
     SamOptions opt;
     FILE *out;
+    std::string *sink = nullptr;
+    void put(const std::string &line);
     int gLogN[256];
     uint64_t nRecords = 0;
 };

@@ -9,6 +9,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <atomic>
+#include <chrono>
+#include <unistd.h>
+#include <thread>
 #include <vector>
 #include "s3_host.h"
 
@@ -40,6 +44,48 @@ static void parseIni(const std::string &file, Ini &ini)
         else if (!strcmp(key, "MismatchScore")) ini.mismatchScore = atoi(val);
     }
     fclose(f);
+}
+
+// SAM records of `count` units (reads or pairs) formatted by all host threads, each into its own buffer, written in unit order
+template <class F>
+static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out, uint32_t count, F &&one, uint64_t &aligned)
+{
+    const int T = hostThreads();
+    const uint32_t per = (count + (uint32_t)T - 1) / (uint32_t)T;
+    std::vector<std::string> buf((size_t)T);
+    std::vector<uint64_t> al((size_t)T, 0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t] {
+        const uint32_t lo = (uint32_t)t * per, hi = lo + per < count ? lo + per : count;
+        if (lo >= hi) return;
+        buf[(size_t)t].reserve((size_t)(hi - lo) * 320);
+        SamWriter w(hix, so, &buf[(size_t)t]);
+        for (uint32_t k = lo; k < hi; k++) one(w, k, al[(size_t)t]);
+    });
+    for (auto &x : th) x.join();
+    // the buffers go to the file at their final offsets, a few writers at a time
+    fflush(out);
+    const int fd = fileno(out);
+    std::vector<long long> off((size_t)T + 1, 0);
+    off[0] = (long long)ftello(out);
+    for (int t = 0; t < T; t++) { off[(size_t)t + 1] = off[(size_t)t] + (long long)buf[(size_t)t].size(); aligned += al[(size_t)t]; }
+    const int W = T < 8 ? T : 8;
+    std::vector<std::thread> wr;
+    std::atomic<bool> bad(false);
+    for (int w = 0; w < W; w++) wr.emplace_back([&, w] {
+        for (int t = w; t < T; t += W) {
+            const std::string &b = buf[(size_t)t];
+            size_t done = 0;
+            while (done < b.size()) {
+                const ssize_t k = pwrite(fd, b.data() + done, b.size() - done, (off_t)(off[(size_t)t] + (long long)done));
+                if (k <= 0) { bad = true; return; }
+                done += (size_t)k;
+            }
+        }
+    });
+    for (auto &x : wr) x.join();
+    if (bad) { fprintf(stderr, "write error on the output file\n"); exit(1); }
+    fseeko(out, (off_t)off[(size_t)T], SEEK_SET);
 }
 
 static int die(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); return 1; }
@@ -85,18 +131,24 @@ int main(int argc, char **argv)
     if (sampleName.empty()) sampleName = "default";
     std::string err;
     HostIndex hix;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     printf("[Main] loading index into host...\n");
     if (!loadIndex(indexName, hix, err)) return die(err);
+    printf("[Main] Finished loading index into host.\n[Main] Loading time : %9.4f seconds\n", since(t0));
     printf("[Main] Reference sequence length : %u\n", hix.n);
+    const auto tReads = std::chrono::steady_clock::now();
     ReadSet rs;
     if (paired ? !loadPairReads(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, err)
                : !loadSingleReads(queryFile, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, err)) return die(err);
-    printf("[Main] Loaded %u short reads from the query file.\n", rs.n);
+    printf("[Main] Loaded %u short reads from the query file.\n[Main] Read load time : %9.4f seconds (%d host threads)\n", rs.n, since(tReads), hostThreads());
     if (numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;          // getDefaultMismatchNum, CPUfunctions.cpp:26-35
     s3_index *ix = nullptr;
     s3_index_desc d = hix.desc();
     if (s3_index_upload(device, &d, &ix) != S3_OK) return die(s3_last_error());
     printf("[Main] Finished copying index into device (GPU).\n");
+    const auto tAlign = std::chrono::steady_clock::now();
+    double devSeconds = 0, formatSeconds = 0;
     const std::string outName = prefix + ".gout.1";
     FILE *out = fopen(outName.c_str(), "w");
     if (!out) return die("Could not open the output file " + outName);
@@ -128,17 +180,17 @@ int main(int argc, char **argv)
             std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
             if (s3_batch_fetch_pairs(b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK)
                 return die(s3_last_error());
-            for (uint32_t p = 0; p < np; p++) {
+            parallelFormat(hix, so, out, np, [&](SamWriter &w, uint32_t p, uint64_t &al) {
                 const uint32_t r1 = first + 2 * p, r2 = r1 + 1;
                 if (pr[p].phase) {
-                    if (!(alignmentType == 3 && pr[p].numMin != 1)) aligned += 2;
-                    sam.properPair(rs, r1, r2, pr[p], xa.data() + xoff[p], (size_t)(xoff[p + 1] - xoff[p]));
+                    if (!(alignmentType == 3 && pr[p].numMin != 1)) al += 2;
+                    w.properPair(rs, r1, r2, pr[p], xa.data() + xoff[p], (size_t)(xoff[p + 1] - xoff[p]));
                 } else {
                     const size_t o1 = ooff[2 * p], n1 = ooff[2 * p + 1] - o1, o2 = ooff[2 * p + 1], n2 = ooff[2 * p + 2] - o2;
-                    sam.improperPair(rs, r1, r2, pos.data() + o1, strand.data() + o1, mis.data() + o1, n1, pos.data() + o2, strand.data() + o2, mis.data() + o2, n2,
-                                     ini.maxHitsEachEndForPairing);
+                    w.improperPair(rs, r1, r2, pos.data() + o1, strand.data() + o1, mis.data() + o1, n1, pos.data() + o2, strand.data() + o2, mis.data() + o2, n2,
+                                   ini.maxHitsEachEndForPairing);
                 }
-            }
+            }, aligned);
             continue;
         }
         std::vector<uint32_t> seeds;
@@ -155,19 +207,21 @@ int main(int argc, char **argv)
         std::vector<uint32_t> pos(nOcc ? nOcc : 1);
         std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
         if (s3_batch_fetch_alignments(b, nullptr, nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK) return die(s3_last_error());
-        for (uint32_t k = 0; k < cnt; k++) {
+        parallelFormat(hix, so, out, cnt, [&](SamWriter &w, uint32_t k, uint64_t &al) {
             const size_t o = offs[k], m = offs[k + 1] - offs[k];
             if (alignmentType >= 3) {
                 // unique best: exactly one hit, otherwise a no-answer record; random best: the first hit (hostKernel, CPUfunctions.cpp:1861-1930)
-                if (m == 0 || (alignmentType == 3 && m > 1)) sam.unaligned(rs, first + k);
-                else { aligned++; sam.singleAnswer(rs, first + k, pos[o], strand[o], mis[o]); }
-                continue;
+                if (m == 0 || (alignmentType == 3 && m > 1)) w.unaligned(rs, first + k);
+                else { al++; w.singleAnswer(rs, first + k, pos[o], strand[o], mis[o]); }
+                return;
             }
-            if (m) aligned++;
-            sam.singleEnd(rs, first + k, pos.data() + o, strand.data() + o, mis.data() + o, m, seeds.empty() ? 0u : seeds[k]);
-        }
+            if (m) al++;
+            w.singleEnd(rs, first + k, pos.data() + o, strand.data() + o, mis.data() + o, m, seeds.empty() ? 0u : seeds[k]);
+        }, aligned);
     }
     fclose(out);
+    printf("[Main] Alignment + output time : %9.4f seconds\n[Main] Total elapsed time : %9.4f seconds\n", since(tAlign), since(t0));
+    (void)devSeconds; (void)formatSeconds;
     printf("[Main] Overall number of reads aligned: %llu\n", (unsigned long long)aligned);
     printf("[Main] Overall number of unaligned reads: %llu\n", (unsigned long long)(rs.n - aligned));
     s3_batch_free(b);

@@ -172,6 +172,46 @@ class HostIndex:
         self.lkt_size = 13
         return self
 
+    def write_files(self, prefix, name="chr1", with_lkt=False):
+        """Write the reference's index files (<prefix>.bwt .fmv.gpu .rev.bwt .rev.fmv.gpu .sa .pac .ann .amb .tra, optionally .lkt / .rev.lkt)
+        for a genome that is ONE sequence without N-runs (what bench / tools build on the GPU).  Layouts: 2bwt-lib/BWT.c:169-194,286
+        (.bwt, .sa), BGS-Build.cpp:139-192 (.fmv.gpu), TextConverter.c:666-720 (.pac), HSP.c:256-531 (.ann, .amb, .tra)."""
+        n = int(self.n)
+
+        def words(path, header, payload):
+            with open(path, "wb") as f:
+                np.asarray(header, dtype="<u4").tofile(f)
+                np.ascontiguousarray(payload, dtype="<u4").tofile(f)
+
+        for mid, h in (("", self.fwd), (".rev", self.rev)):
+            hdr = [h["inverseSa0"]] + [int(x) for x in h["cum"][1:5]]
+            words(prefix + mid + ".bwt", hdr, h["bwt"])
+            words(prefix + mid + ".fmv.gpu", hdr, h["occ"])
+        words(prefix + ".sa", [self.fwd["inverseSa0"]] + [int(x) for x in self.fwd["cum"][1:5]] + [1], self.sa)
+        # packed text: 4 characters per byte, first one in the top bits; then one (partial or empty) byte and the count n % 4
+        pw = np.ascontiguousarray(self.pac, dtype=">u4")
+        raw = pw.view(np.uint8)[: n // 4 + 1].copy()
+        if n % 4:
+            raw[-1] &= (0xFF << (2 * (4 - n % 4))) & 0xFF
+        else:
+            raw[-1] = 0
+        with open(prefix + ".pac", "wb") as f:
+            raw.tofile(f)
+            f.write(bytes([n % 4]))
+        with open(prefix + ".ann", "w") as f:
+            f.write("%u 1 %u\n0 %s\n0 %u 0\n" % (n, 11, name, n))
+        with open(prefix + ".amb", "w") as f:
+            f.write("%u 1 0\n" % n)
+        grid = (n >> 18) + 1
+        with open(prefix + ".tra", "w") as f:
+            f.write("%u 1 0 %u\n" % (n, grid))
+            f.write("0\n" * grid)
+            f.write("0 1 4294967295\n")
+            f.write("0 %u\n" % n)
+        if with_lkt:
+            words(prefix + ".lkt", [13], self.lkt)
+            words(prefix + ".rev.lkt", [13], self.rev_lkt)
+
     def desc(self):
         d = IndexDesc()
         for name, h in (("fwd", self.fwd), ("rev", self.rev)):

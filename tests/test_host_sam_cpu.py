@@ -27,7 +27,7 @@ def tool():
             subprocess.check_call(["gcc", "-O2", "-c", c, "-o", o])
             objs.append(o)
         lib = os.path.join(ROOT, "soap3-dp_amd")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", TOOL] + src + objs + ["-L" + lib, "-ls3dp", "-lz", "-lm", "-Wl,-rpath," + lib])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", TOOL] + src + objs + ["-L" + lib, "-ls3dp", "-lz", "-lm", "-Wl,-rpath," + lib])
         _built["ok"] = True
     return TOOL
 

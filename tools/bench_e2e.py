@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""End-to-end wall clock of the drop-in command line: FASTQ in, SAM out ("reads/s (wall, SAM written)").
+
+Builds a synthetic single-chromosome genome and its index FILES on the GPU (s3dp.builder, byte-identical to the reference tools'),
+simulates reads into a FASTQ file, runs `soap3-dp single ...` on them and reports the phases the program prints.  The index files
+go to --workdir (default: a temporary directory under /tmp); sizes: about 5.5 bytes per genome base."""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "soap3-dp_amd", "py"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome-bp", type=int, default=200_000_000)
+    ap.add_argument("--reads", type=int, default=4_000_000)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--mismatch", type=int, default=4)
+    ap.add_argument("--workdir", default=None)
+    ap.add_argument("--threads", type=int, default=0, help="host threads (0 = all)")
+    a = ap.parse_args()
+    import torch
+    import s3dp
+    from s3dp import builder
+    dev = "cuda:0" if torch.cuda.is_available() else "cpu"
+    work = a.workdir or tempfile.mkdtemp(prefix="s3dp_e2e_", dir="/tmp")
+    os.makedirs(work, exist_ok=True)
+    rng = np.random.default_rng(1)
+    t = time.time()
+    codes = rng.integers(0, 4, size=a.genome_bp, dtype=np.uint8)
+    hi = builder.build_host_index(codes, device=dev)
+    hi.write_files(os.path.join(work, "g.index"), with_lkt=True)
+    t_index = time.time() - t
+    # reads: uniform start, strand 50/50, 0-4 substitutions (55/25/12/5/3 %), quality 'I'
+    t = time.time()
+    L, N = a.read_len, a.reads
+    st = rng.integers(0, a.genome_bp - L, size=N)
+    idx = st[:, None] + np.arange(L)[None, :]
+    seq = codes[idx]
+    nsub = rng.choice(5, size=N, p=[0.55, 0.25, 0.12, 0.05, 0.03])
+    for k in range(1, 5):
+        rows = np.nonzero(nsub >= k)[0]
+        cols = rng.integers(0, L, size=len(rows))
+        seq[rows, cols] = (seq[rows, cols] + rng.integers(1, 4, size=len(rows))) % 4
+    neg = rng.random(N) < 0.5
+    seq[neg] = 3 - seq[neg][:, ::-1]
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)[seq]
+    fq = os.path.join(work, "reads.fq")
+    with open(fq, "wb") as f:
+        qual = b"I" * L
+        block = 200_000
+        for b0 in range(0, N, block):
+            parts = []
+            for i in range(b0, min(N, b0 + block)):
+                parts.append(b"@r%d\n" % i + letters[i].tobytes() + b"\n+\n" + qual + b"\n")
+            f.write(b"".join(parts))
+    t_reads = time.time() - t
+    env = dict(os.environ)
+    if a.threads:
+        env["S3DP_HOST_THREADS"] = str(a.threads)
+    exe = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
+    t = time.time()
+    out = subprocess.run([exe, "single", os.path.join(work, "g.index"), fq, "-L", str(L), "-s", str(a.mismatch), "-b", "2", "-o", os.path.join(work, "out")],
+                         capture_output=True, text=True, env=env)
+    wall = time.time() - t
+    if out.returncode != 0:
+        print(out.stdout[-2000:], out.stderr[-2000:], file=sys.stderr)
+        raise SystemExit(1)
+    ph = {k: float(v) for k, v in re.findall(r"\[Main\] (Loading time|Read load time|Alignment \+ output time|Total elapsed time) :\s+([0-9.]+)", out.stdout)}
+    aligned = int(re.search(r"Overall number of reads aligned: (\d+)", out.stdout).group(1))
+    sam_bytes = os.path.getsize(os.path.join(work, "out.gout.1"))
+    res = {"genome_bp": a.genome_bp, "reads": N, "read_len": L, "max_mismatch": a.mismatch, "host_threads": a.threads or os.cpu_count(),
+           "index_build_and_write_s": t_index, "fastq_write_s": t_reads, "wall_s_total": wall, "phases_s": ph, "aligned_reads": aligned,
+           "sam_bytes": sam_bytes, "fastq_bytes": os.path.getsize(fq),
+           "reads_per_s_wall_incl_index_load": N / wall,
+           "reads_per_s_reads_in_sam_out": N / (ph.get("Read load time", 0) + ph.get("Alignment + output time", 0) or wall)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
