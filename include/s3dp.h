@@ -119,6 +119,20 @@ int  s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError 
                                uint64_t *occOffsets /* n+1 */, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis,
                                size_t occCap, uint64_t *nOccOut);
 
+/* ---- parameters of the DP stages (host-side integer rules) ------------------------------------------------------------------
+ * s3_dp_stage_parameters replaces getParameterForSingleDP / DefaultDP / NewDefaultDP / DeepDP and getMaxHitNumForDefaultDP
+ * (CPUfunctions.cpp:36-260) for one read length; s3_seed_positions replaces getSeedPositions (definitions.h:323-442): the seed length,
+ * the number of seeds and their offsets in the read for the seeding of a DP stage. */
+#define S3_STAGE_SINGLE_DP       1
+#define S3_STAGE_DEFAULT_DP      2
+#define S3_STAGE_NEW_DEFAULT_DP  3
+#define S3_STAGE_DEEP_DP_ROUND1  4
+#define S3_STAGE_DEEP_DP_ROUND2  5
+typedef struct { int dpScoreThreshold /* < 0: DEFAULT = ceil(0.3 L) */, softClipLeft, softClipRight; } s3_dp_ini;   /* [DP] / [Clipping] ini keys */
+typedef struct { int cutoffThreshold, maxHitNum, seedLength, sampleDist, tailTrimLen, softClipLeft, softClipRight, singleDPSeedNum; } s3_dp_stage_params;
+int  s3_dp_stage_parameters(int stage, uint32_t readLength, const s3_dp_ini *ini, s3_dp_stage_params *out);
+int  s3_seed_positions(int stage, int readLength, int *seedLength, int *positions /* room for 128 */, int *seedNum);
+
 /* ---- paired-end reads, DP stages off (`soap3-dp pair <index> <r1> <r2> -u <max insert> -v <min insert> -s k`) -------------------------
  * Reads 2p and 2p+1 of the batch are the two ends of pair p (the interleaving loadPairReadsGz2 produces, QueryParser.cpp:177).
  * s3_batch_align_pair replaces soap3_dp_pair_align's ladders with DP disabled (alignment.cu:1965-2013: all_best_alignment :1236 = phases

@@ -658,11 +658,67 @@ static int modeSam ( int argc, char ** argv )
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// mode "dpparams": the DP stage parameters (getParameterFor*DP, CPUfunctions.cpp:46-260) and the seed tables (getSeedPositions,
+// definitions.h:323-442) for every read length, as the reference computes them with the ini given
+static int modeDpParams ( int argc, char ** argv )
+{
+    // argv: ref_harness dpparams <ini> <out>
+    IniParams ini;
+
+    if ( ParseIniFile ( argv[2], ini ) != 0 ) { fprintf ( stderr, "bad ini\n" ); return 1; }
+
+    InputOptions opt;
+    memset ( &opt, 0, sizeof ( opt ) );
+    FILE * f = fopen ( argv[3], "w" );
+
+    for ( uint L = 25; L <= 1024; L++ )
+    {
+        DPParameters d;
+        memset ( &d, 0, sizeof ( d ) );
+        getParameterForAllDP ( d, opt, ini );
+        fprintf ( f, "L %u all %d %d %d %d\n", L, d.matchScore, d.mismatchScore, d.openGapScore, d.extendGapScore );
+        memset ( &d, 0, sizeof ( d ) );
+        getParameterForDefaultDP ( d, opt, ini, L, L );
+        fprintf ( f, "L %u default cutoff %d clip %d %d maxhit %d\n", L, d.paramRead[0].cutoffThreshold, d.softClipLeft, d.softClipRight, d.paramRead[0].maxHitNum );
+        memset ( &d, 0, sizeof ( d ) );
+        getParameterForNewDefaultDP ( d, opt, ini, L, L );
+        fprintf ( f, "L %u newdefault cutoff %d maxhit %d seedlen %d\n", L, d.paramRead[0].cutoffThreshold, d.paramRead[0].maxHitNum, d.paramRead[0].seedLength );
+        memset ( &d, 0, sizeof ( d ) );
+        getParameterForDeepDP ( d, opt, ini, L, L );
+        fprintf ( f, "L %u deep cutoff %d maxhit %d seedlen %d sample %d tailtrim %d\n", L, d.paramRead[0].cutoffThreshold, d.paramRead[0].maxHitNum,
+                  d.paramRead[0].seedLength, d.paramRead[0].sampleDist, d.tailTrimLen );
+        memset ( &d, 0, sizeof ( d ) );
+        getParameterForSingleDP ( d, opt, ini, L );
+        fprintf ( f, "L %u single cutoff %d maxhit %d seedlen %d seednum %d\n", L, d.paramRead[0].cutoffThreshold, d.paramRead[0].maxHitNum, d.paramRead[0].seedLength,
+                  d.singleDPSeedNum );
+        fprintf ( f, "L %u defaultmaxhit %d\n", L, getMaxHitNumForDefaultDP ( L ) );
+
+        for ( int stage = 1; stage <= 5; stage++ )
+        {
+            if ( stage == STAGE_DEFAULT_DP ) { continue; }
+
+            int seedLength = 0, seedNum = 0, pos[256];
+            getSeedPositions ( stage, ( int ) L, &seedLength, pos, &seedNum );
+            fprintf ( f, "L %u seeds %d len %d n %d :", L, stage, seedLength, seedNum );
+
+            for ( int i = 0; i < seedNum; i++ ) { fprintf ( f, " %d", pos[i] ); }
+
+            fprintf ( f, "\n" );
+        }
+    }
+
+    fclose ( f );
+    return 0;
+}
+
 int main ( int argc, char ** argv )
 {
     if ( argc < 2 ) { fprintf ( stderr, "usage: ref_harness models|search|sam ...\n" ); return 1; }
 
     if ( strcmp ( argv[1], "models" ) == 0 ) { dumpModels ( argv[2] ); return 0; }
+
+    if ( strcmp ( argv[1], "dpparams" ) == 0 ) { return modeDpParams ( argc, argv ); }
 
     if ( strcmp ( argv[1], "search" ) == 0 ) { return modeSearch ( argc, argv ); }
 

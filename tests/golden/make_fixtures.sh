@@ -90,4 +90,5 @@ mk g2 "--genome-len 60000 --chroms 2 --n-runs 2 --repeats 40 --genome-seed 7" "-
 mkl g3 "--genome-len 120000 --chroms 2 --n-runs 4 --repeats 12 --genome-seed 5" "--reads 1200 --var-len 121 200 --read-seed 31 --mix 0.3 0.2 0.15 0.1 0.08 0.07 0.05 0.03 0.02" 200
 mkp g4 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 8 --genome-seed 9" "--pairs 1200 --read-len 100 --read-seed 77" 100
 ( cd $W && $REF/ref_harness models models.txt && gzip -9n < models.txt > $OUT/models.txt.gz )
+( cd $W && $REF/ref_harness dpparams $INI dpparams.txt && gzip -9n < dpparams.txt > $OUT/dpparams.txt.gz )
 du -sh $OUT
