@@ -31,6 +31,7 @@ extern "C" {
 
 typedef struct s3_index s3_index;
 typedef struct s3_batch s3_batch;
+typedef struct s3_dp s3_dp;          /* semi-global DP aligner, see s3_dp_create */
 
 /* One BWT of the 2BWT pair, host arrays in the on-disk layouts with file headers stripped:
  *   bwt : .bwt / .rev.bwt payload, 2-bit chars, 16 per word, MSB first, '$' not stored (2bwt-lib/BWT.c:169-194)
@@ -119,6 +120,27 @@ int  s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError 
                                uint64_t *occOffsets /* n+1 */, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis,
                                size_t occCap, uint64_t *nOccOut);
 
+/* ---- default DP for half-aligned pairs -------------------------------------------------------------------------------------
+ * Replaces HalfEndAlignmentEngine (DV-DPfunctions.cu:1888-2540): for every occurrence of the aligned end (HalfEndOccStream order) the
+ * window the insert size allows is cut from the RESIDENT text (HalfEndAlgnBatch::pack :2027-2109: '+' aligned end -> mate to its right
+ * on '-', '-' aligned end -> mate to its left on '+'; soft-clip allowances and anchors as there), the mate is packed in that strand
+ * (packRead / repackDNA :2111-2167, on the device), the semi-global DP runs (s3_dp) and the traceback is decoded like
+ * DP_Space::algnmtCPUThread (:2329-2441): CIGAR (CigarStringEncoder, DV-DPfunctions.h:548), edit distance
+ * I + D + (L match + gapPenalty - score) / (match - mismatch), insert size.  `b` holds the reads (s3_batch_upload; reads 2p / 2p+1 are
+ * a pair), `h` must have been created with maxReadLength >= the longest read and maxDNALength >= insertHigh.  One result per
+ * candidate window, in input order; results and the CIGAR pool are malloc'ed: release with s3_free.  PARITY UNPINNED. */
+typedef struct { uint32_t readID, pos; uint8_t strand, mismatchCount, pad[2]; } s3_occ;        /* SRAOccurrence of the ALIGNED end */
+typedef struct {
+    uint32_t readID;                /* first read of the pair */
+    uint32_t algnmt_1, algnmt_2;    /* text positions of end 1 / end 2 (0xFFFFFFFF: the DP found nothing above the cutoff) */
+    int32_t  score_1, score_2;      /* mismatches of the BWT-aligned end, DP score of the other */
+    uint8_t  strand_1, strand_2, whichFromDP /* 0: end 1 from DP, 1: end 2, 2: none */, pad;
+    uint32_t editdist, insertSize, num_sameScore;
+    uint32_t cigarOffset;           /* into the CIGAR pool, 0xFFFFFFFF if none */
+} s3_dp_half_result;
+int  s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3_occ *occ, size_t nOcc, int insertLow, int insertHigh,
+                    const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_half_result **results, size_t *nResults, char **cigarPool);
+
 /* ---- parameters of the DP stages (host-side integer rules) ------------------------------------------------------------------
  * s3_dp_stage_parameters replaces getParameterForSingleDP / DefaultDP / NewDefaultDP / DeepDP and getMaxHitNumForDefaultDP
  * (CPUfunctions.cpp:36-260) for one read length; s3_seed_positions replaces getSeedPositions (definitions.h:323-442): the seed length,
@@ -185,7 +207,6 @@ int  s3_model_describe(int readLength, int maxError, char *buf, size_t bufLen);
  * (DV-DPfunctions.h:120-164, DV-DPfunctions.cu:538-741) and its kernels SemiGlobalAligntment / GPUBacktrack (:243-512).
  * Sequences use the reference's packing (DV-DPfunctions.cu:57-59): 1-based characters, 16 per word with the first one in
  * the most significant bits, word w of problem t at (t/32)*(ceil(maxLen/16)*32) + t%32 + 32*w.  Arrays are host pointers. */
-typedef struct s3_dp s3_dp;
 typedef struct { int matchScore, mismatchScore, gapOpenScore, gapExtendScore; } s3_dp_scores;
 
 /* decideConfiguration (:538-619): with 288 GB of HBM the full table (scheme 1, maxDPTableLength = maxDNALength) always

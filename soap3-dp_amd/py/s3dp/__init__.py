@@ -35,7 +35,7 @@ class Counters(C.Structure):
 
 
 EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
-           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_dp_stage_parameters", "s3_seed_positions", "s3_batch_fetch_alignments", "s3_batch_sync",
+           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_batch_fetch_alignments", "s3_batch_sync",
            "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather"]
 
@@ -363,6 +363,11 @@ class Batch:
         return {k: getattr(c, k) for k, _ in Counters._fields_}
 
 
+OCC_DTYPE = np.dtype([("readID", "<u4"), ("pos", "<u4"), ("strand", "u1"), ("mismatchCount", "u1"), ("pad", "u1", 2)])     # s3_occ
+HALF_RESULT_DTYPE = np.dtype([("readID", "<u4"), ("algnmt_1", "<u4"), ("algnmt_2", "<u4"), ("score_1", "<i4"), ("score_2", "<i4"), ("strand_1", "u1"),
+                              ("strand_2", "u1"), ("whichFromDP", "u1"), ("pad", "u1"), ("editdist", "<u4"), ("insertSize", "<u4"),
+                              ("num_sameScore", "<u4"), ("cigarOffset", "<u4")])                                                 # s3_dp_half_result
+
 # s3_pair_result / s3_pair_xa of include/s3dp.h
 PAIR_DTYPE = np.dtype([("phase", "u1"), ("min1", "u1"), ("min2", "u1"), ("minTotal", "u1"), ("secMinTotal", "u1"), ("bestS1", "u1"), ("bestS2", "u1"),
                        ("bestM1", "u1"), ("bestM2", "u1"), ("pad", "u1", 3), ("x0_1", "<u4"), ("x1_1", "<u4"), ("x0_2", "<u4"), ("x1_2", "<u4"),
@@ -471,6 +476,27 @@ class DpAligner:
             self.close()
         except Exception:
             pass
+
+    def half_end(self, batch, read_lengths, occ, insert_low, insert_high, cutoffs, clip_left, clip_right):
+        """default DP for half-aligned pairs: occ = structured array OCC_DTYPE of the ALIGNED ends' hits; returns (results, cigars)"""
+        read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
+        occ = np.ascontiguousarray(occ, dtype=OCC_DTYPE)
+        f = lib().s3_dp_half_end
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+        cut = (C.c_int * 2)(*cutoffs)
+        res, n, pool = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        _chk(f(self.h, batch.h, read_lengths.ctypes.data, occ.ctypes.data, len(occ), insert_low, insert_high, cut, clip_left, clip_right,
+               C.byref(res), C.byref(n), C.byref(pool)))
+        out = np.frombuffer(C.string_at(res, n.value * HALF_RESULT_DTYPE.itemsize), dtype=HALF_RESULT_DTYPE).copy() if n.value else np.zeros(0, HALF_RESULT_DTYPE)
+        cigars = []
+        for r in out:
+            cigars.append(None if r["cigarOffset"] == 0xFFFFFFFF else C.string_at(pool.value + int(r["cigarOffset"])).decode())
+        free = lib().s3_free
+        free.argtypes = [C.c_void_p]
+        free(res)
+        free(pool)
+        return out, cigars
 
     def align(self, packed_dna, dna_lengths, packed_reads, read_lengths, cutoffs, clip_lt=None, clip_rt=None, anchor_lt=None, anchor_rt=None):
         n = len(read_lengths)
