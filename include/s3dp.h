@@ -141,6 +141,18 @@ typedef struct {
 int  s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3_occ *occ, size_t nOcc, int insertLow, int insertHigh,
                     const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_half_result **results, size_t *nResults, char **cigarPool);
 
+/* ---- seeding for the DP stages (single reads) --------------------------------------------------------------------------------
+ * Replaces SingleEndSeedingBatch::packSeeds (DV-DPfunctions.cu:1058-1100), single_1_mismatch_alignment2 (alignment.cu:1839-1894: every
+ * seed searched exactly, the seeds without a hit once more with one mismatch), the hit limit of hostKernelSingle
+ * (CPUfunctions.cpp:2843-2876: a seed with more than maxHitNum hits is dropped, status 4), decodePositions and singleMerge
+ * (DV-DPfunctions.cu:1102-1219: hit -> estimated read position, sorted by strand / read / position, positions within 50 of the last kept
+ * one collapse).  `reads` holds the uploaded reads, `seedBatch` is a second batch on the same index (wordPerQuery >= 8, room for every
+ * seed: at most 12 per read below 400 bases).  Candidates come back sorted by (strand, read, position); seedStatus (optional) holds per
+ * seed 0 = no hit, 1 = hits used, 4 = dropped for too many hits.  Both arrays are malloc'ed: release with s3_free.  PARITY UNPINNED. */
+typedef struct { uint32_t readID, pos; uint8_t strand, pad[3]; } s3_seed_candidate;
+int  s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, int stage, uint32_t maxHitNum,
+                        s3_seed_candidate **candidates, size_t *nCandidates, uint8_t **seedStatus, size_t *nSeeds);
+
 /* ---- parameters of the DP stages (host-side integer rules) ------------------------------------------------------------------
  * s3_dp_stage_parameters replaces getParameterForSingleDP / DefaultDP / NewDefaultDP / DeepDP and getMaxHitNumForDefaultDP
  * (CPUfunctions.cpp:36-260) for one read length; s3_seed_positions replaces getSeedPositions (definitions.h:323-442): the seed length,

@@ -35,7 +35,7 @@ class Counters(C.Structure):
 
 
 EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
-           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_batch_fetch_alignments", "s3_batch_sync",
+           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_batch_fetch_alignments", "s3_batch_sync",
            "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather"]
 
@@ -330,6 +330,22 @@ class Batch:
         _chk(lib().s3_batch_fetch_alignments(self.h, None, None, None, pos.ctypes.data, strand.ctypes.data, mis.ctypes.data, k, None))
         return phase, werr, offs, pos[:no.value], strand[:no.value], mis[:no.value]
 
+    def seed_candidates(self, seed_batch, read_lengths, stage, max_hit_num):
+        """seeding for the DP stages: returns (candidates SEED_CAND_DTYPE sorted by strand/read/position, per-seed status)"""
+        read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
+        f = lib().s3_seed_candidates
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                      C.POINTER(C.c_size_t)]
+        cand, n, st, ns = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        _chk(f(self.h, seed_batch.h, read_lengths.ctypes.data, stage, max_hit_num, C.byref(cand), C.byref(n), C.byref(st), C.byref(ns)))
+        out = np.frombuffer(C.string_at(cand, n.value * SEED_CAND_DTYPE.itemsize), dtype=SEED_CAND_DTYPE).copy() if n.value else np.zeros(0, SEED_CAND_DTYPE)
+        status = np.frombuffer(C.string_at(st, ns.value), dtype=np.uint8).copy() if ns.value else np.zeros(0, np.uint8)
+        free = lib().s3_free
+        free.argtypes = [C.c_void_p]
+        free(cand)
+        free(st)
+        return out, status
+
     def align_pair(self, mm, max_hits_per_end, report_type, insert_low, insert_high, pe_max_output=1000):
         """reads 2p / 2p+1 are the ends of pair p; paired-end ladder with the DP stages off"""
         f = lib().s3_batch_align_pair
@@ -367,6 +383,8 @@ OCC_DTYPE = np.dtype([("readID", "<u4"), ("pos", "<u4"), ("strand", "u1"), ("mis
 HALF_RESULT_DTYPE = np.dtype([("readID", "<u4"), ("algnmt_1", "<u4"), ("algnmt_2", "<u4"), ("score_1", "<i4"), ("score_2", "<i4"), ("strand_1", "u1"),
                               ("strand_2", "u1"), ("whichFromDP", "u1"), ("pad", "u1"), ("editdist", "<u4"), ("insertSize", "<u4"),
                               ("num_sameScore", "<u4"), ("cigarOffset", "<u4")])                                                 # s3_dp_half_result
+
+SEED_CAND_DTYPE = np.dtype([("readID", "<u4"), ("pos", "<u4"), ("strand", "u1"), ("pad", "u1", 3)])                                    # s3_seed_candidate
 
 # s3_pair_result / s3_pair_xa of include/s3dp.h
 PAIR_DTYPE = np.dtype([("phase", "u1"), ("min1", "u1"), ("min2", "u1"), ("minTotal", "u1"), ("secMinTotal", "u1"), ("bestS1", "u1"), ("bestS2", "u1"),

@@ -1,0 +1,107 @@
+"""-m gpu: seeding for the DP stages (s3_seed_candidates: seed packing, exact + 1-mismatch seed search, hit limit, estimated positions,
+merge) against a restatement built here on the pinned search oracle; plus the semantic check that reads too damaged for the BWT stage
+get their true position among the candidates.  (The reference's seeding engine is host code inside CUDA sources: parity unpinned.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import s3dp
+import s3o
+from s3dp import builder
+
+pytestmark = pytest.mark.gpu
+
+COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
+
+
+def seed_table(stage, L):
+    sl, n = C.c_int(), C.c_int()
+    pos = (C.c_int * 128)()
+    assert s3dp.lib().s3_seed_positions(stage, L, C.byref(sl), pos, C.byref(n)) == 0
+    return sl.value, list(pos[:n.value])
+
+
+@pytest.mark.parametrize("stage,max_hit", [(1, 10), (4, 100), (5, 1000)])
+def test_seed_candidates_match_restatement(stage, max_hit):
+    rng = np.random.default_rng(5 + stage)
+    n = 80000
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    # a planted repeat family so that some seeds exceed the hit limit
+    unit = codes[1000:1300].copy()
+    for k in range(15):
+        p = int(rng.integers(2000, n - 400))
+        codes[p:p + 300] = unit
+    hi = builder.build_host_index(codes, device="cpu")
+    ix = s3dp.Index(hi)
+    reads, truth = [], []
+    for r in range(160):
+        L = 100 if r % 2 == 0 else 150
+        st = int(rng.integers(0, n - L)) if r % 10 else 1000 + int(rng.integers(0, 100))
+        seg = codes[st:st + L].copy()
+        kind = r % 4
+        if kind == 1:                                     # 7 substitutions
+            for q in rng.choice(L, size=7, replace=False):
+                seg[q] = (seg[q] + 1 + rng.integers(0, 3)) % 4
+        elif kind == 2:                                   # 4-base deletion
+            c = int(rng.integers(40, 60))
+            seg = np.concatenate([codes[st:st + c], codes[st + c + 4:st + L + 4]])
+        elif kind == 3:                                   # 3-base insertion
+            c = int(rng.integers(40, 60))
+            seg = np.concatenate([codes[st:st + c], rng.integers(0, 4, size=3, dtype=np.uint8), codes[st + c:st + L - 3]])
+        strand = int(rng.integers(1, 3))
+        if strand == 2:
+            seg = COMP[seg[::-1]]
+        reads.append(bytes(b"ACGT"[c] for c in seg))
+        truth.append((st, strand))
+    q, lens, wpq = s3dp.pack_reads(reads, 150)
+    b = s3dp.Batch(ix, len(reads), wpq)
+    b.upload(q, lens)
+    sb = s3dp.Batch(ix, len(reads) * 16, 8)
+    cand, status = b.seed_candidates(sb, lens, stage, max_hit)
+    # ---- restatement on the search oracle -----------------------------------------------------------------
+    oix = s3o.Index(host_index=hi)
+    seeds = []
+    for r, rd in enumerate(reads):
+        sl, pos = seed_table(stage, len(rd))
+        for off in pos:
+            if off >= 0 and sl >= 16 and off + sl <= len(rd):
+                seeds.append((r, off, sl))
+    sq, slens, swpq = s3dp.pack_reads([reads[r][off:off + sl] for r, off, sl in seeds], 128)
+    keys, want_status = [], []
+    h0, o0, t0, _, _ = oix.search(sq, slens, swpq, 0, max_out=0xFFFFFFFF)
+    h1, o1, t1, _, _ = oix.search(sq, slens, swpq, 1, max_out=0xFFFFFFFF)
+    for j, (r, off, sl) in enumerate(seeds):
+        hits, offs, tot = (h0, o0, t0) if t0[j] > 0 else (h1, o1, t1)
+        if tot[j] == 0:
+            want_status.append(0)
+            continue
+        if tot[j] > max_hit:
+            want_status.append(4)
+            continue
+        want_status.append(1)
+        p, s, _ = oix.decode(hits[int(offs[j]):int(offs[j + 1])])
+        for pos, strand in zip(p, s):
+            est = (int(pos) - off) if strand == 1 else (int(pos) + sl + off - len(reads[r]))
+            keys.append((int(strand), r, est & 0xFFFFFFFF))
+    keys.sort()
+    want = []
+    prev_run, prev = None, 0
+    for strand, r, est in keys:
+        if (strand, r) != prev_run:
+            want.append((r, est, strand)); prev_run = (strand, r); prev = est
+        elif prev + 50 < est:
+            want.append((r, est, strand)); prev = est
+    got = [(int(c["readID"]), int(c["pos"]), int(c["strand"])) for c in cand]
+    assert list(status) == want_status
+    assert got == want
+    assert 4 in want_status or max_hit >= 100
+    # ---- semantics: the true place of every read is among its candidates (+- the indel size) -------------
+    found = 0
+    for r, (st, strand) in enumerate(truth):
+        if any(rr == r and ss == strand and abs(pp - st) <= 4 for rr, pp, ss in got):
+            found += 1
+    assert found >= 0.8 * len(truth), found            # reads inside the planted repeat lose their seeds to the hit limit
+    oix.close()
+    b.close()
+    sb.close()
