@@ -153,6 +153,14 @@ typedef struct { uint32_t readID, pos; uint8_t strand, pad[3]; } s3_seed_candida
 int  s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, int stage, uint32_t maxHitNum,
                         s3_seed_candidate **candidates, size_t *nCandidates, uint8_t **seedStatus, size_t *nSeeds);
 
+/* ---- DP for single reads (after s3_seed_candidates) ------------------------------------------------------------------------------
+ * Replaces SingleEndAlignmentEngine (DV-DPfunctions.cu:1373-1770): window = candidate position -/+ margin (readLength > 100 ? readLength / 4
+ * : 25), read packed in the candidate's strand, results below the cutoff dropped; CIGAR / edit distance as in s3_dp_half_end.
+ * Results and the CIGAR pool are malloc'ed: release with s3_free.  PARITY UNPINNED. */
+typedef struct { uint32_t readID, algnmt; int32_t score; uint32_t editdist, num_sameScore, cigarOffset; uint8_t strand, pad[3]; } s3_dp_single_result;
+int  s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3_seed_candidate *candidates, size_t nCandidates, int cutoffThreshold,
+                      int softClipLeft, int softClipRight, s3_dp_single_result **results, size_t *nResults, char **cigarPool);
+
 /* ---- parameters of the DP stages (host-side integer rules) ------------------------------------------------------------------
  * s3_dp_stage_parameters replaces getParameterForSingleDP / DefaultDP / NewDefaultDP / DeepDP and getMaxHitNumForDefaultDP
  * (CPUfunctions.cpp:36-260) for one read length; s3_seed_positions replaces getSeedPositions (definitions.h:323-442): the seed length,

@@ -1467,6 +1467,102 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
     return S3_OK;
 }
 
+// Single-end DP (SingleEndAlignmentEngine, DV-DPfunctions.cu:1373-1770): every seeding candidate gets the window
+// [pos - margin, pos - margin + readLength + 2 margin) (SingleEndAlgnBatch::pack :1425-1467, margin = DPS_MARGIN), the read is packed
+// in the candidate's strand, no anchors; results below the cutoff are dropped (SingleDP_Space::algnmtCPUThread :1682-1741).
+extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3_seed_candidate *candidates, size_t nCand, int cutoffThreshold,
+                                int softClipLeft, int softClipRight, s3_dp_single_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut)
+{
+    if (!h || !b || !readLengths || (!candidates && nCand) || !resultsOut || !nResultsOut || !cigarPoolOut) return fail(S3_EINVAL, "s3_dp_single_end: null argument");
+    if (h->dev != b->ix->dev) return fail(S3_EINVAL, "s3_dp_single_end: aligner and batch live on different devices");
+    HIPCHK(hipSetDevice(h->dev));
+    const uint32_t fullDNALength = b->ix->d.n;
+    const uint32_t wordsPerDNA = (h->maxDNA + 15) / 16, wordsPerRead = (h->maxRead + 15) / 16;
+    std::vector<s3_dp_single_result> results;
+    std::string pool;
+    DpCand *dCand = nullptr;
+    {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64);
+        if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp candidates): ") + hipGetErrorString(e));
+        dCand = (DpCand *)q;
+    }
+    int rc = S3_OK;
+    for (size_t base = 0; base < nCand && rc == S3_OK; base += h->maxProblems) {
+        const uint32_t n = (uint32_t)(nCand - base < h->maxProblems ? nCand - base : h->maxProblems);
+        std::vector<DpCand> cand(n);
+        std::vector<uint32_t> dnaLens(n), rdLens(n), clipLt(n), clipRt(n);
+        std::vector<int32_t> cut(n, cutoffThreshold);
+        for (uint32_t t = 0; t < n && rc == S3_OK; t++) {
+            const s3_seed_candidate &c = candidates[base + t];
+            if (c.readID >= b->n || (c.strand != 1 && c.strand != 2)) { rc = fail(S3_EINVAL, "s3_dp_single_end: bad candidate"); break; }
+            const uint32_t L = readLengths[c.readID];
+            const uint32_t margin = L > 100 ? L / 4 : 25;                      // DPS_MARGIN, DV-DPfunctions.h
+            uint32_t start = c.pos - margin;
+            if (start >= fullDNALength) start = 0;
+            uint32_t len = L + 2 * margin;
+            if (start + len > fullDNALength) len = fullDNALength - start;
+            if (L > h->maxRead || len > h->maxDNA) { rc = fail(S3_EINVAL, "s3_dp_single_end: the aligner is too small for this read (maxReadLength / maxDNALength)"); break; }
+            cand[t] = DpCand{c.readID, c.strand, start, len};
+            dnaLens[t] = len; rdLens[t] = L;
+            clipLt[t] = c.strand == 1 ? (uint32_t)softClipLeft : (uint32_t)softClipRight;
+            clipRt[t] = c.strand == 1 ? (uint32_t)softClipRight : (uint32_t)softClipLeft;
+        }
+        if (rc) break;
+        hipStream_t s = h->stream;
+#define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipFree(dCand); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+        ECHK(hipMemcpyAsync(dCand, cand.data(), (size_t)n * sizeof(DpCand), hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dDnaLen, dnaLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dReadLen, rdLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dCut, cut.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dClipLt, clipLt.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dClipRt, clipRt.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        const uint64_t threads = (uint64_t)n * (wordsPerDNA + wordsPerRead);
+        hipLaunchKernelGGL(dpPackKernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, n, dCand, b->ix->d.pac, b->dQueries, b->wpq, b->dLens,
+                           wordsPerDNA, wordsPerRead, h->dDna, h->dReads);
+        rc = dpRun(h, n, true, true, false, false);
+        if (rc) break;
+        std::vector<int32_t> scores(n);
+        std::vector<uint32_t> hit(n), cnt(n);
+        std::vector<uint8_t> pat((size_t)n * h->patternLen);
+        ECHK(hipMemcpyAsync(scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        ECHK(hipMemcpyAsync(hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        ECHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        ECHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
+        ECHK(hipStreamSynchronize(s));
+#undef ECHK
+        for (uint32_t i = 0; i < n; i++) {
+            if (scores[i] < cutoffThreshold) continue;
+            CigarEnc enc;
+            char last = 'N';
+            for (const uint8_t *p = pat.data() + (size_t)i * h->patternLen; *p != 0; p++) {
+                if (*p == 'V') enc.append(last, (int)*(++p) - 1);
+                else { enc.append((char)*p, 1); last = (char)*p; }
+            }
+            enc.encode(h->sc.gapOpenScore, h->sc.gapExtendScore);
+            s3_dp_single_result r{};
+            r.readID = cand[i].readId; r.strand = (uint8_t)cand[i].strand; r.algnmt = cand[i].start + hit[i]; r.score = scores[i];
+            const int L = (int)rdLens[i] - enc.count['I'] - enc.count['S'];
+            const int numMis = (L * h->sc.matchScore + enc.gapPenalty - scores[i]) / (h->sc.matchScore - h->sc.mismatchScore);
+            r.editdist = (uint32_t)(enc.count['I'] + enc.count['D'] + numMis);
+            r.num_sameScore = cnt[i];
+            r.cigarOffset = (uint32_t)pool.size();
+            pool += enc.text;
+            pool.push_back('\0');
+            results.push_back(r);
+        }
+    }
+    (void)hipFree(dCand);
+    if (rc) return rc;
+    s3_dp_single_result *out = (s3_dp_single_result *)malloc(results.size() * sizeof(s3_dp_single_result) + 1);
+    char *cp = (char *)malloc(pool.size() + 1);
+    if (!out || !cp) { free(out); free(cp); return fail(S3_ENOMEM, "s3_dp_single_end: out of host memory"); }
+    memcpy(out, results.data(), results.size() * sizeof(s3_dp_single_result));
+    memcpy(cp, pool.data(), pool.size());
+    *resultsOut = out; *nResultsOut = results.size(); *cigarPoolOut = cp;
+    return S3_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Seeding for the DP stages of single reads: seeds cut from the reads at the tabulated offsets, searched exactly, the seeds
 // without a hit once more with one mismatch, every hit turned into an estimated read position, positions of one read and strand merged.

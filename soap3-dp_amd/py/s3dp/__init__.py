@@ -35,7 +35,7 @@ class Counters(C.Structure):
 
 
 EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
-           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_batch_fetch_alignments", "s3_batch_sync",
+           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_dp_single_end", "s3_batch_fetch_alignments", "s3_batch_sync",
            "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather"]
 
@@ -384,6 +384,8 @@ HALF_RESULT_DTYPE = np.dtype([("readID", "<u4"), ("algnmt_1", "<u4"), ("algnmt_2
                               ("strand_2", "u1"), ("whichFromDP", "u1"), ("pad", "u1"), ("editdist", "<u4"), ("insertSize", "<u4"),
                               ("num_sameScore", "<u4"), ("cigarOffset", "<u4")])                                                 # s3_dp_half_result
 
+SINGLE_RESULT_DTYPE = np.dtype([("readID", "<u4"), ("algnmt", "<u4"), ("score", "<i4"), ("editdist", "<u4"), ("num_sameScore", "<u4"),
+                                ("cigarOffset", "<u4"), ("strand", "u1"), ("pad", "u1", 3)])                                             # s3_dp_single_result
 SEED_CAND_DTYPE = np.dtype([("readID", "<u4"), ("pos", "<u4"), ("strand", "u1"), ("pad", "u1", 3)])                                    # s3_seed_candidate
 
 # s3_pair_result / s3_pair_xa of include/s3dp.h
@@ -510,6 +512,24 @@ class DpAligner:
         cigars = []
         for r in out:
             cigars.append(None if r["cigarOffset"] == 0xFFFFFFFF else C.string_at(pool.value + int(r["cigarOffset"])).decode())
+        free = lib().s3_free
+        free.argtypes = [C.c_void_p]
+        free(res)
+        free(pool)
+        return out, cigars
+
+    def single_end(self, batch, read_lengths, candidates, cutoff, clip_left, clip_right):
+        """DP of single reads at their seeding candidates (SEED_CAND_DTYPE); returns (results SINGLE_RESULT_DTYPE, cigars)"""
+        read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
+        cand = np.ascontiguousarray(candidates, dtype=SEED_CAND_DTYPE)
+        f = lib().s3_dp_single_end
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                      C.POINTER(C.c_void_p)]
+        res, n, pool = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        _chk(f(self.h, batch.h, read_lengths.ctypes.data, cand.ctypes.data, len(cand), cutoff, clip_left, clip_right, C.byref(res), C.byref(n), C.byref(pool)))
+        out = (np.frombuffer(C.string_at(res, n.value * SINGLE_RESULT_DTYPE.itemsize), dtype=SINGLE_RESULT_DTYPE).copy() if n.value
+               else np.zeros(0, SINGLE_RESULT_DTYPE))
+        cigars = [C.string_at(pool.value + int(r["cigarOffset"])).decode() for r in out]
         free = lib().s3_free
         free.argtypes = [C.c_void_p]
         free(res)

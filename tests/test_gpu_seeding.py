@@ -105,3 +105,64 @@ def test_seed_candidates_match_restatement(stage, max_hit):
     oix.close()
     b.close()
     sb.close()
+
+
+def test_single_end_dp_pipeline_recovers_damaged_reads():
+    """seeds -> candidates -> DP: reads with 7 substitutions or an indel (beyond the 4-mismatch BWT stage) come back at their true place
+    with a CIGAR that reproduces the read and the reported score"""
+    import re
+    from test_gpu_dp_half_end import apply_cigar, MATCH
+    rng = np.random.default_rng(17)
+    n = 60000
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    hi = builder.build_host_index(codes, device="cpu")
+    ix = s3dp.Index(hi)
+    reads, truth = [], []
+    for r in range(96):
+        L = 100 if r % 2 == 0 else 150
+        st = int(rng.integers(200, n - L - 200))
+        kind = r % 3
+        if kind == 0:
+            seg = codes[st:st + L].copy()
+            for q in rng.choice(np.arange(5, L - 5), size=7, replace=False):
+                seg[q] = (seg[q] + 1 + rng.integers(0, 3)) % 4
+            best = (L - 7) * MATCH + 7 * -2
+        elif kind == 1:
+            c = int(rng.integers(40, 60))
+            seg = np.concatenate([codes[st:st + c], codes[st + c + 4:st + L + 4]])
+            best = L * MATCH + (-3 - 3)
+        else:
+            c = int(rng.integers(40, 60))
+            seg = np.concatenate([codes[st:st + c], (codes[st + c:st + c + 3] + 1) % 4, codes[st + c:st + L - 3]])
+            best = (L - 3) * MATCH + (-3 - 2)
+        strand = int(rng.integers(1, 3))
+        fwd = seg.copy()
+        if strand == 2:
+            seg = COMP[seg[::-1]]
+        reads.append(bytes(b"ACGT"[c] for c in seg))
+        truth.append((st, strand, fwd, best))
+    q, lens, wpq = s3dp.pack_reads(reads, 150)
+    b = s3dp.Batch(ix, len(reads), wpq)
+    b.upload(q, lens)
+    sb = s3dp.Batch(ix, len(reads) * 16, 8)
+    cand, status = b.seed_candidates(sb, lens, 1, 10)
+    dp = s3dp.DpAligner(4096, 152, 152 + 2 * 38 + 8, scheme=1)
+    res, cigars = dp.single_end(b, lens, cand, 30, 49, 49)
+    best_by_read = {}
+    for r, cg in zip(res, cigars):
+        k = int(r["readID"])
+        if k not in best_by_read or r["score"] > best_by_read[k][0]["score"]:
+            best_by_read[k] = (r, cg)
+    ok = 0
+    for k, (st, strand, fwd, best) in enumerate(truth):
+        if k not in best_by_read:
+            continue
+        r, cg = best_by_read[k]
+        score, edits, span = apply_cigar(cg, fwd, codes, int(r["algnmt"]))
+        assert score == r["score"] and edits == r["editdist"], (k, cg)
+        if r["strand"] == strand and abs(int(r["algnmt"]) - st) <= 4 and r["score"] >= best:
+            ok += 1
+    assert ok >= 0.8 * len(truth), ok                  # 7 substitutions can spoil all three 38-base seeds (one mismatch each at most)
+    dp.close()
+    b.close()
+    sb.close()
