@@ -112,6 +112,90 @@ def pack_on_device(codes2d, wpq):
     return (q & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
 
 
+def make_pairs(codes, n_pairs, L, seed, device):
+    """2 x L pairs, insert ~ N(350, 40) clipped to [L + 1, 500], '+/-' orientation, 0-4 substitutions per end"""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n = codes.numel()
+    ins = torch.clamp(torch.round(torch.randn(n_pairs, generator=g, device=device) * 40 + 350), L + 1, 500).to(torch.int64)
+    start = torch.randint(0, n - 600, (n_pairs,), generator=g, device=device)
+    ar = torch.arange(L, device=device)
+    a = codes[start[:, None] + ar[None, :]]
+    bb = codes[(start + ins - L)[:, None] + ar[None, :]]
+    probs = torch.tensor((0.55, 0.25, 0.12, 0.05, 0.03), device=device)
+    for seg in (a, bb):
+        nsub = torch.multinomial(probs, n_pairs, replacement=True, generator=g)
+        kth = torch.topk(torch.rand((n_pairs, L), generator=g, device=device), 4, dim=1).indices
+        delta = torch.randint(1, 4, (n_pairs, 4), generator=g, device=device, dtype=torch.uint8)
+        for j in range(4):
+            rows = torch.nonzero(nsub > j).squeeze(1)
+            seg[rows, kth[rows, j]] = (seg[rows, kth[rows, j]] + delta[rows, j]) % 4
+    bb = 3 - torch.flip(bb, [1])
+    swap = torch.rand(n_pairs, generator=g, device=device) < 0.5
+    first = torch.where(swap[:, None], bb, a)
+    second = torch.where(swap[:, None], a, bb)
+    out = torch.empty((2 * n_pairs, L), dtype=torch.uint8, device=device)
+    out[0::2] = first
+    out[1::2] = second
+    return out
+
+
+def extras(s3dp, ix, codes, dev, rank):
+    """secondary figures (not the headline metric): BASELINE configs[2] shapes -- 2 x 150 bp pairs through the paired-end BWT stage, and the
+    semi-global DP kernel on default-DP windows"""
+    import torch
+    res = {}
+    L, n_pairs = 150, 2_000_000
+    reads2d = make_pairs(codes, n_pairs, L, 4242, dev)
+    wpq = s3dp.word_per_query(L)
+    q = pack_on_device(reads2d, wpq)
+    del reads2d
+    lens = np.full(2 * n_pairs, L, dtype=np.uint32)
+    b = s3dp.Batch(ix, 2 * n_pairs, wpq)
+    b.upload(q, lens)
+    b.align_pair(3, 8000, 2, 1, 500, 1000)
+    b.sync()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        b.align_pair(3, 8000, 2, 1, 500, 1000)
+        b.sync()
+    dt = (time.perf_counter() - t0) / 2
+    pairs = b.fetch_pairs()[0]
+    res["paired_end_2x150_bwt_stage"] = {"pairs": n_pairs, "ms_per_pass": dt * 1e3, "M_pairs_per_s": n_pairs / dt / 1e6,
+                                          "properly_paired": int((pairs["phase"] > 0).sum()),
+                                          "options": "pair -L 150 -s 3 -h 2 -u 500 -v 1 (DP stages off)"}
+    b.close()
+    # DP kernel: 150 bp reads against 648-column windows cut from the genome at the reads' places (default-DP shape), device time
+    n_dp = 32768
+    rng = np.random.default_rng(3)
+    occ = np.zeros(n_dp, dtype=s3dp.OCC_DTYPE)
+    reads2d = make_pairs(codes, n_dp, L, 777, dev)
+    q = pack_on_device(reads2d, wpq)
+    lens = np.full(2 * n_dp, L, dtype=np.uint32)
+    bb = s3dp.Batch(ix, 2 * n_dp, wpq)
+    bb.upload(q, lens)
+    bb.align_pair(3, 8000, 2, 1, 500, 1000)
+    pr = bb.fetch_pairs()[0]
+    k = 0
+    for p in range(n_dp):                                              # the first end's hit of every properly paired pair anchors a DP of the second end
+        if pr["phase"][p] and k < n_dp:
+            occ[k] = (2 * p, pr["bestA1"][p], pr["bestS1"][p], pr["bestM1"][p], (0, 0))
+            k += 1
+    dp = s3dp.DpAligner(n_dp, 152, 500 - 1 + 152 + 1, scheme=1)
+    dp.half_end(bb, lens, occ[:k], 1, 500, (45, 45), 49, 49)
+    t0 = time.perf_counter()
+    resd, cig = dp.half_end(bb, lens, occ[:k], 1, 500, (45, 45), 49, 49)
+    wall = time.perf_counter() - t0
+    ms = dp.timing()
+    cells = float(k) * L * 499.0
+    res["default_dp_half_end"] = {"problems": k, "read_len": L, "window": 499, "kernel_ms": ms, "GCUPS_kernel": cells / (ms / 1e3) / 1e9,
+                                  "wall_ms_incl_pack_decode": wall * 1e3, "aligned_by_dp": int((resd["whichFromDP"] < 2).sum())}
+    dp.close()
+    bb.close()
+    return res
+
+
 def cpu_baseline(hi, q, lens, wpq, mm, max_out, budget_s):
     """oracle (CPU restatement of the reference path) timed on a bounded sample with every host core"""
     import concurrent.futures as cf
@@ -155,6 +239,7 @@ def main():
     ap.add_argument("--repeat-frac", type=float, default=0.0)
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle after the run")
+    ap.add_argument("--extras", type=int, default=1, help="after the timed region (N = 1): paired-end 2x150 BWT stage and DP kernel throughput")
     a = ap.parse_args()
 
     import torch
@@ -188,7 +273,8 @@ def main():
     log("%d reads generated + packed in %.1f s" % (a.reads, time.perf_counter() - t0))
     t0 = time.perf_counter()
     hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=(rank == 0))
-    del codes
+    if not (rank == 0 and world == 1 and a.extras):
+        del codes
     torch.cuda.empty_cache()
     log("index built on the GPU in %.1f s" % (time.perf_counter() - t0))
     t0 = time.perf_counter()
@@ -286,6 +372,11 @@ def main():
                 raise SystemExit("bench.py: HIP result differs from the CPU oracle")
         if world == 1 and a.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(hi, q, lens, wpq, a.mismatch, a.max_out, a.cpu_budget)
+        if world == 1 and a.extras:
+            try:
+                out["extras"] = extras(s3dp, ix, codes, dev, rank)
+            except Exception as e:                                      # secondary figures must never cost the headline line
+                out["extras"] = {"error": repr(e)}
         out["wall_s_total"] = time.perf_counter() - t_all
         print(json.dumps(out), flush=True)
     b.close()

@@ -1204,6 +1204,7 @@ static int dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasA
     launchDp(a, s);
     HIPCHK(hipEventRecord(h->ev[1], s));
     HIPCHK(hipGetLastError());
+    h->timed = true;
     return S3_OK;
 }
 
