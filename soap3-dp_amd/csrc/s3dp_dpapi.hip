@@ -1,0 +1,461 @@
+// s3dp_dpapi.hip -- the semi-global DP part of the C-ABI: the aligner object (s3_dp_*) and the engines around the kernel for half-aligned
+// pairs and single reads (window geometry, on-device packing, traceback decode).  Kernels: s3dp_dp.hip.
+#include <hipcub/hipcub.hpp>
+#include "s3dp_internal.h"
+
+using namespace s3;
+using namespace s3i;
+
+// ---------------------------------------------------------------------------------------------
+// semi-global DP
+// ---------------------------------------------------------------------------------------------
+
+extern "C" int s3_dp_config(int maxReadLength, int maxDNALength, int wantScheme, int *scheme, int *maxDPTableLength, int *patternLength)
+{
+    if (maxReadLength < 1 || maxDNALength < 1) return fail(S3_EINVAL, "s3_dp_config: bad lengths");
+    int sch = wantScheme == 2 ? 2 : 1;
+    int tab = sch == 1 ? maxDNALength : maxReadLength + maxReadLength / 2 + 8;      // DP_Effective_Region (:574)
+    if (sch == 2 && tab > maxDNALength) { sch = 1; tab = maxDNALength; }
+    if (scheme) *scheme = sch;
+    if (maxDPTableLength) *maxDPTableLength = tab;
+    if (patternLength) *patternLength = maxReadLength + tab;
+    return S3_OK;
+}
+
+extern "C" void s3_dp_free(s3_dp *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->dev);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    for (auto e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+template <class T>
+static int dalloc(s3_dp *h, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
+    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp): ") + hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return S3_OK;
+}
+
+extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLength, uint32_t maxDNALength, uint32_t maxDPTableLength, int scheme,
+                            const s3_dp_scores *sc, s3_dp **outp)
+{
+    if (!sc || !outp || !maxProblems || !maxReadLength || !maxDNALength || !maxDPTableLength) return fail(S3_EINVAL, "s3_dp_create: bad argument");
+    if (maxReadLength > 4096 || maxDNALength > 16384) return fail(S3_EINVAL, "s3_dp_create: lengths too large");
+    if (scheme == 1 && maxDPTableLength < maxDNALength) return fail(S3_EINVAL, "s3_dp_create: scheme 1 needs maxDPTableLength >= maxDNALength");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(S3_ENODEV, "no HIP device available (libs3dp has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(S3_EINVAL, "bad device ordinal");
+    HIPCHK(hipSetDevice(device));
+    s3_dp *h = new s3_dp();
+    h->dev = device; h->scheme = scheme == 2 ? 2 : 1; h->maxProblems = maxProblems; h->maxRead = maxReadLength; h->maxDNA = maxDNALength;
+    h->maxTable = maxDPTableLength; h->patternLen = maxReadLength + maxDPTableLength; h->sc = *sc;
+    const size_t rnd = ((size_t)maxProblems + 31) / 32 * 32;
+    const size_t dnaW = rnd * ((maxDNALength + 15) / 16), rdW = rnd * ((maxReadLength + 15) / 16);
+    h->tableWords = (size_t)((maxReadLength + 63) / 64) * (maxDPTableLength + 64) * 64;
+    int rc;
+#define DA(p, c) if ((rc = dalloc(h, &h->p, (c)))) { s3_dp_free(h); return rc; }
+    DA(dDna, dnaW); DA(dReads, rdW); DA(dDnaLen, rnd); DA(dReadLen, rnd); DA(dClipLt, rnd); DA(dClipRt, rnd); DA(dAL, rnd); DA(dAR, rnd);
+    DA(dCut, rnd); DA(dScores, rnd); DA(dHit, rnd); DA(dStart, rnd); DA(dCnt, rnd); DA(dCols, rnd);
+    DA(dPattern, (size_t)maxProblems * h->patternLen);
+    DA(dTable, h->tableWords * maxProblems);
+#undef DA
+    HIPCHK(hipStreamCreate(&h->stream));
+    HIPCHK(hipEventCreate(&h->ev[0])); HIPCHK(hipEventCreate(&h->ev[1]));
+    *outp = h;
+    return S3_OK;
+}
+
+// launch the DP kernels on what is in the aligner's device buffers
+int s3i::dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR)
+{
+    hipStream_t s = h->stream;
+    DpArgs a{};
+    a.dna = h->dDna; a.dnaLengths = h->dDnaLen; a.reads = h->dReads; a.readLengths = h->dReadLen;
+    a.clipLt = hasClipLt ? h->dClipLt : nullptr; a.clipRt = hasClipRt ? h->dClipRt : nullptr;
+    a.anchorLeft = hasAL ? h->dAL : nullptr; a.anchorRight = hasAR ? h->dAR : nullptr;
+    a.cutoffs = h->dCut; a.scores = h->dScores; a.hitLocs = h->dHit; a.startOffsets = h->dStart; a.maxScoreCounts = h->dCnt; a.tableCols = h->dCols;
+    a.pattern = h->dPattern; a.table = h->dTable; a.tableWordsPerProblem = h->tableWords;
+    a.n = n; a.maxDNALength = h->maxDNA; a.maxReadLength = h->maxRead; a.maxDPTableLength = h->maxTable; a.patternLen = h->patternLen;
+    a.ldsPerWave = (((h->maxDNA + 1u + 15u) & ~15u) + (h->maxDNA + 1u) * 12u + 15u) & ~15u;
+    a.match = h->sc.matchScore; a.mismatch = h->sc.mismatchScore; a.gapOpen = h->sc.gapOpenScore; a.gapExtend = h->sc.gapExtendScore; a.scheme = h->scheme;
+    if ((size_t)a.ldsPerWave * 4 > 160 * 1024) return fail(S3_EINVAL, "s3_dp_align: maxDNALength too large for the LDS-resident window");
+    HIPCHK(hipEventRecord(h->ev[0], s));
+    launchDp(a, s);
+    HIPCHK(hipEventRecord(h->ev[1], s));
+    HIPCHK(hipGetLastError());
+    h->timed = true;
+    return S3_OK;
+}
+
+extern "C" int s3_dp_align(s3_dp *h, const uint32_t *packedDNA, const uint32_t *DNALengths, const uint32_t *packedReads, const uint32_t *readLengths,
+                           const int32_t *cutoffThresholds, uint32_t n, const uint32_t *clipLtSizes, uint32_t *clipRtSizes,
+                           const uint32_t *anchorLeftLocs, const uint32_t *anchorRightLocs, int32_t *scores, uint32_t *hitLocs,
+                           uint32_t *maxScoreCounts, uint8_t *pattern)
+{
+    if (!h || !packedDNA || !DNALengths || !packedReads || !readLengths || !cutoffThresholds || !scores || !hitLocs || !maxScoreCounts || !pattern)
+        return fail(S3_EINVAL, "s3_dp_align: null argument");
+    if (n > h->maxProblems) return fail(S3_EINVAL, "s3_dp_align: too many problems for this aligner");
+    for (uint32_t t = 0; t < n; t++) {
+        if (readLengths[t] < 1 || readLengths[t] > h->maxRead) return fail(S3_EINVAL, "s3_dp_align: read length out of range");
+        if (DNALengths[t] < 1 || DNALengths[t] > h->maxDNA) return fail(S3_EINVAL, "s3_dp_align: DNA length out of range");
+        if (clipRtSizes && clipRtSizes[t] > readLengths[t]) return fail(S3_EINVAL, "s3_dp_align: clipRt larger than the read");
+    }
+    HIPCHK(hipSetDevice(h->dev));
+    const size_t rnd = ((size_t)n + 31) / 32 * 32;
+    const size_t dnaW = rnd * ((h->maxDNA + 15) / 16), rdW = rnd * ((h->maxRead + 15) / 16);
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->dDna, packedDNA, dnaW * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dReads, packedReads, rdW * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dDnaLen, DNALengths, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dReadLen, readLengths, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->dCut, cutoffThresholds, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (clipLtSizes) HIPCHK(hipMemcpyAsync(h->dClipLt, clipLtSizes, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (clipRtSizes) HIPCHK(hipMemcpyAsync(h->dClipRt, clipRtSizes, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (anchorLeftLocs) HIPCHK(hipMemcpyAsync(h->dAL, anchorLeftLocs, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (anchorRightLocs) HIPCHK(hipMemcpyAsync(h->dAR, anchorRightLocs, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    {
+        int rc = dpRun(h, n, clipLtSizes != nullptr, clipRtSizes != nullptr, anchorLeftLocs != nullptr, anchorRightLocs != nullptr);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(scores, h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hitLocs, h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(maxScoreCounts, h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pattern, h->dPattern, (size_t)n * h->patternLen, hipMemcpyDeviceToHost, s));
+    if (clipRtSizes) HIPCHK(hipMemcpyAsync(clipRtSizes, h->dClipRt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->timed = true;
+    return S3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Default DP for half-aligned pairs: one end has BWT hits, the other is aligned by DP inside the window the insert size allows.
+// Replaces, of the reference's HalfEndAlignmentEngine (DV-DPfunctions.cu:1888-2540):
+//   HalfEndAlgnBatch::pack      :2027-2109  window geometry, clip sizes, anchors               -> host loop below
+//   packRead / repackDNA        :2111-2167  1-based MSB-first 32-interleaved words             -> dpPackKernel, from the RESIDENT text and reads
+//   DP_Space::algnmtCPUThread   :2329-2441  pattern -> CIGAR, edit distance, insert size       -> decode loop below
+//   CigarStringEncoder          DV-DPfunctions.h:548-597
+// The reference packs windows on the host and copies them to the card; here text and reads already live in HBM, only the candidate
+// list travels.  PARITY UNPINNED (host code inside a CUDA source file): restated from the source, checked on simulated indel pairs.
+// ---------------------------------------------------------------------------------------------
+struct DpCand { uint32_t readId, strand, start, dnaLen; };     // read to align (global index), strand to pack it in, window start / length
+
+__global__ void dpPackKernel(uint32_t n, const DpCand *cand, const uint32_t *text, const uint32_t *queries, uint32_t wpq, const uint32_t *readLens,
+                             uint32_t wordsPerDNA, uint32_t wordsPerRead, uint32_t *dna, uint32_t *reads)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per = wordsPerDNA + wordsPerRead;
+    if (g >= (uint64_t)n * per) return;
+    const uint32_t t = (uint32_t)(g / per), w = (uint32_t)(g % per);
+    const DpCand c = cand[t];
+    uint32_t out = 0;
+    if (w < wordsPerDNA) {
+        // characters i = 16 w .. 16 w + 15 of the 1-based sequence; character i sits at bit 2 (15 - (i & 15)); i = 0 stays empty
+        for (uint32_t k = 0; k < 16u; k++) {
+            const uint32_t i = w * 16u + k;
+            if (i >= 1u && i <= c.dnaLen) {
+                const uint64_t p = (uint64_t)c.start + i - 1u;
+                out |= ((text[p >> 4] >> (2u * (15u - (uint32_t)(p & 15u)))) & 3u) << (2u * (15u - k));
+            }
+        }
+        dna[(size_t)(t >> 5) * 32u * wordsPerDNA + (t & 31u) + (size_t)w * 32u] = out;
+    } else {
+        const uint32_t wr = w - wordsPerDNA, len = readLens[c.readId];
+        const uint32_t *src = queries + (size_t)(c.readId >> 5) * 32u * wpq + (c.readId & 31u);
+        for (uint32_t k = 0; k < 16u; k++) {
+            const uint32_t i = wr * 16u + k;
+            if (i >= 1u && i <= len) {
+                const uint32_t q = c.strand == 1u ? i - 1u : len - i;
+                uint32_t ch = (src[(size_t)(q >> 4) * 32u] >> ((q & 15u) * 2u)) & 3u;
+                if (c.strand != 1u) ch = 3u - ch;
+                out |= ch << (2u * (15u - k));
+            }
+        }
+        reads[(size_t)(t >> 5) * 32u * wordsPerRead + (t & 31u) + (size_t)wr * 32u] = out;
+    }
+}
+
+namespace {
+// CigarStringEncoder (DV-DPfunctions.h:548-597): runs are collected in traceback order and written out reversed
+struct CigarEnc {
+    std::vector<std::pair<char, int>> runs;
+    char lastType = 'N';
+    int lastCnt = 0;
+    int count[128];
+    int gapPenalty = 0;
+    std::string text;
+    void append(char type, int cnt)
+    {
+        if (lastType == type) lastCnt += cnt;
+        else { runs.emplace_back(lastType, lastCnt); lastType = type; lastCnt = cnt; }
+    }
+    void encode(int gapOpen, int gapExtend)
+    {
+        memset(count, 0, sizeof count);
+        gapPenalty = 0;
+        append('N', 0);
+        for (size_t i = runs.size(); i-- > 1;) {
+            const char type = runs[i].first;
+            const int cnt = runs[i].second;
+            if (cnt > 0) {
+                text += std::to_string(cnt);
+                text.push_back(type);
+                count[(int)type] += cnt;
+                if (type == 'I' || type == 'D') gapPenalty += gapOpen + (cnt - 1) * gapExtend;
+            }
+        }
+    }
+};
+}  // namespace
+
+extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3_occ *occ, size_t nOcc, int insertLow, int insertHigh,
+                              const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_half_result **resultsOut, size_t *nResultsOut,
+                              char **cigarPoolOut)
+{
+    if (!h || !b || !readLengths || (!occ && nOcc) || !cutoffThreshold || !resultsOut || !nResultsOut || !cigarPoolOut)
+        return fail(S3_EINVAL, "s3_dp_half_end: null argument");
+    if (h->dev != b->ix->dev) return fail(S3_EINVAL, "s3_dp_half_end: aligner and batch live on different devices");
+    HIPCHK(hipSetDevice(h->dev));
+    const uint32_t fullDNALength = b->ix->d.n;
+    const int leftLeg = 1, rightLeg = 2;                                  // StrandArrangement "+/-" (IniParam.cpp:317-330)
+    std::vector<s3_dp_half_result> results;
+    std::string pool;
+    std::vector<DpCand> cand;
+    std::vector<uint32_t> dnaLens, rdLens, clipLt, clipRt, aL, aR, startLocs;
+    std::vector<int32_t> cut;
+    std::vector<uint8_t> leftOrRight;
+    std::vector<s3_occ> refer;
+    DpCand *dCand = nullptr;
+    const uint32_t wordsPerDNA = (h->maxDNA + 15) / 16, wordsPerRead = (h->maxRead + 15) / 16;
+    auto flush = [&]() -> int {
+        const uint32_t n = (uint32_t)cand.size();
+        if (!n) return S3_OK;
+        hipStream_t s = h->stream;
+        HIPCHK(hipMemcpyAsync(dCand, cand.data(), (size_t)n * sizeof(DpCand), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->dDnaLen, dnaLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->dReadLen, rdLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->dCut, cut.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->dClipLt, clipLt.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->dClipRt, clipRt.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->dAL, aL.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->dAR, aR.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        const uint64_t threads = (uint64_t)n * (wordsPerDNA + wordsPerRead);
+        hipLaunchKernelGGL(dpPackKernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, n, dCand, b->ix->d.pac, b->dQueries, b->wpq, b->dLens,
+                           wordsPerDNA, wordsPerRead, h->dDna, h->dReads);
+        int rc = dpRun(h, n, true, true, true, true);
+        if (rc) return rc;
+        std::vector<int32_t> scores(n);
+        std::vector<uint32_t> hit(n), cnt(n);
+        std::vector<uint8_t> pat((size_t)n * h->patternLen);
+        HIPCHK(hipMemcpyAsync(scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        // algnmtCPUThread (:2329-2441)
+        for (uint32_t id = 0; id < n; id++) {
+            s3_dp_half_result r{};
+            const uint32_t alignedID = refer[id].readID, alignedIsMate = alignedID & 1u;
+            r.readID = alignedID - alignedIsMate;
+            r.cigarOffset = 0xFFFFFFFFu;
+            uint32_t dpPos;
+            if (scores[id] >= cutoffThreshold[1 - alignedIsMate]) {
+                CigarEnc enc;
+                char last = 'N';
+                for (const uint8_t *p = pat.data() + (size_t)id * h->patternLen; *p != 0; p++) {
+                    if (*p == 'V') enc.append(last, (int)*(++p) - 1);
+                    else { enc.append((char)*p, 1); last = (char)*p; }
+                }
+                enc.encode(h->sc.gapOpenScore, h->sc.gapExtendScore);
+                r.cigarOffset = (uint32_t)pool.size();
+                pool += enc.text;
+                pool.push_back('\0');
+                const int L = (int)rdLens[id] - enc.count['I'] - enc.count['S'];
+                const int numMis = (L * h->sc.matchScore + enc.gapPenalty - scores[id]) / (h->sc.matchScore - h->sc.mismatchScore);
+                r.editdist = (uint32_t)(enc.count['I'] + enc.count['D'] + numMis);
+                r.whichFromDP = (uint8_t)(1 - alignedIsMate);
+                dpPos = startLocs[id] + hit[id];
+                if (dpPos < refer[id].pos) r.insertSize = refer[id].pos - dpPos + readLengths[alignedID];
+                else r.insertSize = dpPos - refer[id].pos + rdLens[id] + (uint32_t)enc.count['D'] - (uint32_t)enc.count['I'] - (uint32_t)enc.count['S'];
+                r.num_sameScore = cnt[id];
+            } else { r.whichFromDP = 2; dpPos = 0xFFFFFFFFu; }
+            const uint8_t dpStrand = (uint8_t)(leftOrRight[id] == 0 ? leftLeg : rightLeg);
+            if (!alignedIsMate) {
+                r.algnmt_1 = refer[id].pos; r.algnmt_2 = dpPos; r.score_1 = refer[id].mismatchCount; r.score_2 = scores[id];
+                r.strand_1 = refer[id].strand; r.strand_2 = dpStrand;
+            } else {
+                r.algnmt_1 = dpPos; r.algnmt_2 = refer[id].pos; r.score_1 = scores[id]; r.score_2 = refer[id].mismatchCount;
+                r.strand_1 = dpStrand; r.strand_2 = refer[id].strand;
+            }
+            results.push_back(r);
+        }
+        cand.clear(); dnaLens.clear(); rdLens.clear(); clipLt.clear(); clipRt.clear(); aL.clear(); aR.clear(); startLocs.clear(); cut.clear();
+        leftOrRight.clear(); refer.clear();
+        return S3_OK;
+    };
+    {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64);
+        if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp candidates): ") + hipGetErrorString(e));
+        dCand = (DpCand *)q;
+    }
+    int rc = S3_OK;
+    for (size_t k = 0; k < nOcc && rc == S3_OK; k++) {
+        const s3_occ &cur = occ[k];
+        if (cur.strand != leftLeg && cur.strand != rightLeg) continue;
+        if (cur.readID >= b->n) { rc = fail(S3_EINVAL, "s3_dp_half_end: read index out of range"); break; }
+        const uint32_t alignedLen = readLengths[cur.readID];
+        const int unalignedIsMate = 1 - (int)(cur.readID & 1u);
+        const uint32_t unalignedID = unalignedIsMate == 0 ? cur.readID - 1 : cur.readID + 1;
+        if (unalignedID >= b->n) { rc = fail(S3_EINVAL, "s3_dp_half_end: the mate is not in the batch"); break; }
+        const uint32_t unalignedLen = readLengths[unalignedID];
+        if (unalignedLen > h->maxRead) { rc = fail(S3_EINVAL, "s3_dp_half_end: read longer than the aligner's maxReadLength"); break; }
+        auto add = [&](uint32_t start, uint32_t end, uint8_t lor, uint32_t anchorL, uint32_t anchorR, uint32_t strand) {
+            DpCand c{unalignedID, strand, start, end - start};
+            cand.push_back(c);
+            dnaLens.push_back(end - start); rdLens.push_back(unalignedLen); startLocs.push_back(start);
+            cut.push_back(cutoffThreshold[unalignedIsMate]);
+            clipLt.push_back(strand == 1 ? (uint32_t)softClipLeft : (uint32_t)softClipRight);
+            clipRt.push_back(strand == 1 ? (uint32_t)softClipRight : (uint32_t)softClipLeft);
+            aL.push_back(anchorL); aR.push_back(anchorR);
+            leftOrRight.push_back(lor); refer.push_back(cur);
+        };
+        if (cur.strand == leftLeg) {                                        // aligned end at the left, the other end somewhere to its right
+            const uint32_t rightEnd = cur.pos + (uint32_t)insertHigh;
+            uint32_t rightStart = cur.pos + (uint32_t)insertLow - unalignedLen;
+            if (rightStart < cur.pos) rightStart = cur.pos;
+            if (rightStart < fullDNALength && rightEnd <= fullDNALength && rightEnd - rightStart <= h->maxDNA)
+                add(rightStart, rightEnd, 1, h->maxDNA, unalignedLen, (uint32_t)rightLeg);
+        }
+        if (cur.strand == rightLeg) {                                       // aligned end at the right
+            const uint32_t leftStart = cur.pos + alignedLen - (uint32_t)insertHigh;
+            uint32_t leftEnd = cur.pos + alignedLen - (uint32_t)insertLow + unalignedLen;
+            if (leftEnd >= cur.pos + alignedLen) leftEnd = cur.pos + alignedLen - 1;
+            if (leftStart < fullDNALength && leftEnd <= fullDNALength && leftEnd - leftStart <= h->maxDNA)
+                add(leftStart, leftEnd, 0, (uint32_t)(insertHigh - insertLow + 1), 0, (uint32_t)leftLeg);
+        }
+        if (cand.size() + 1 > h->maxProblems) rc = flush();
+    }
+    if (rc == S3_OK) rc = flush();
+    (void)hipFree(dCand);
+    if (rc) return rc;
+    s3_dp_half_result *out = (s3_dp_half_result *)malloc(results.size() * sizeof(s3_dp_half_result) + 1);
+    char *cp = (char *)malloc(pool.size() + 1);
+    if (!out || !cp) { free(out); free(cp); return fail(S3_ENOMEM, "s3_dp_half_end: out of host memory"); }
+    memcpy(out, results.data(), results.size() * sizeof(s3_dp_half_result));
+    memcpy(cp, pool.data(), pool.size());
+    *resultsOut = out; *nResultsOut = results.size(); *cigarPoolOut = cp;
+    return S3_OK;
+}
+
+// Single-end DP (SingleEndAlignmentEngine, DV-DPfunctions.cu:1373-1770): every seeding candidate gets the window
+// [pos - margin, pos - margin + readLength + 2 margin) (SingleEndAlgnBatch::pack :1425-1467, margin = DPS_MARGIN), the read is packed
+// in the candidate's strand, no anchors; results below the cutoff are dropped (SingleDP_Space::algnmtCPUThread :1682-1741).
+extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3_seed_candidate *candidates, size_t nCand, int cutoffThreshold,
+                                int softClipLeft, int softClipRight, s3_dp_single_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut)
+{
+    if (!h || !b || !readLengths || (!candidates && nCand) || !resultsOut || !nResultsOut || !cigarPoolOut) return fail(S3_EINVAL, "s3_dp_single_end: null argument");
+    if (h->dev != b->ix->dev) return fail(S3_EINVAL, "s3_dp_single_end: aligner and batch live on different devices");
+    HIPCHK(hipSetDevice(h->dev));
+    const uint32_t fullDNALength = b->ix->d.n;
+    const uint32_t wordsPerDNA = (h->maxDNA + 15) / 16, wordsPerRead = (h->maxRead + 15) / 16;
+    std::vector<s3_dp_single_result> results;
+    std::string pool;
+    DpCand *dCand = nullptr;
+    {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64);
+        if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp candidates): ") + hipGetErrorString(e));
+        dCand = (DpCand *)q;
+    }
+    int rc = S3_OK;
+    for (size_t base = 0; base < nCand && rc == S3_OK; base += h->maxProblems) {
+        const uint32_t n = (uint32_t)(nCand - base < h->maxProblems ? nCand - base : h->maxProblems);
+        std::vector<DpCand> cand(n);
+        std::vector<uint32_t> dnaLens(n), rdLens(n), clipLt(n), clipRt(n);
+        std::vector<int32_t> cut(n, cutoffThreshold);
+        for (uint32_t t = 0; t < n && rc == S3_OK; t++) {
+            const s3_seed_candidate &c = candidates[base + t];
+            if (c.readID >= b->n || (c.strand != 1 && c.strand != 2)) { rc = fail(S3_EINVAL, "s3_dp_single_end: bad candidate"); break; }
+            const uint32_t L = readLengths[c.readID];
+            const uint32_t margin = L > 100 ? L / 4 : 25;                      // DPS_MARGIN, DV-DPfunctions.h
+            uint32_t start = c.pos - margin;
+            if (start >= fullDNALength) start = 0;
+            uint32_t len = L + 2 * margin;
+            if (start + len > fullDNALength) len = fullDNALength - start;
+            if (L > h->maxRead || len > h->maxDNA) { rc = fail(S3_EINVAL, "s3_dp_single_end: the aligner is too small for this read (maxReadLength / maxDNALength)"); break; }
+            cand[t] = DpCand{c.readID, c.strand, start, len};
+            dnaLens[t] = len; rdLens[t] = L;
+            clipLt[t] = c.strand == 1 ? (uint32_t)softClipLeft : (uint32_t)softClipRight;
+            clipRt[t] = c.strand == 1 ? (uint32_t)softClipRight : (uint32_t)softClipLeft;
+        }
+        if (rc) break;
+        hipStream_t s = h->stream;
+#define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipFree(dCand); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+        ECHK(hipMemcpyAsync(dCand, cand.data(), (size_t)n * sizeof(DpCand), hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dDnaLen, dnaLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dReadLen, rdLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dCut, cut.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dClipLt, clipLt.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dClipRt, clipRt.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        const uint64_t threads = (uint64_t)n * (wordsPerDNA + wordsPerRead);
+        hipLaunchKernelGGL(dpPackKernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, n, dCand, b->ix->d.pac, b->dQueries, b->wpq, b->dLens,
+                           wordsPerDNA, wordsPerRead, h->dDna, h->dReads);
+        rc = dpRun(h, n, true, true, false, false);
+        if (rc) break;
+        std::vector<int32_t> scores(n);
+        std::vector<uint32_t> hit(n), cnt(n);
+        std::vector<uint8_t> pat((size_t)n * h->patternLen);
+        ECHK(hipMemcpyAsync(scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        ECHK(hipMemcpyAsync(hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        ECHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        ECHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
+        ECHK(hipStreamSynchronize(s));
+#undef ECHK
+        for (uint32_t i = 0; i < n; i++) {
+            if (scores[i] < cutoffThreshold) continue;
+            CigarEnc enc;
+            char last = 'N';
+            for (const uint8_t *p = pat.data() + (size_t)i * h->patternLen; *p != 0; p++) {
+                if (*p == 'V') enc.append(last, (int)*(++p) - 1);
+                else { enc.append((char)*p, 1); last = (char)*p; }
+            }
+            enc.encode(h->sc.gapOpenScore, h->sc.gapExtendScore);
+            s3_dp_single_result r{};
+            r.readID = cand[i].readId; r.strand = (uint8_t)cand[i].strand; r.algnmt = cand[i].start + hit[i]; r.score = scores[i];
+            const int L = (int)rdLens[i] - enc.count['I'] - enc.count['S'];
+            const int numMis = (L * h->sc.matchScore + enc.gapPenalty - scores[i]) / (h->sc.matchScore - h->sc.mismatchScore);
+            r.editdist = (uint32_t)(enc.count['I'] + enc.count['D'] + numMis);
+            r.num_sameScore = cnt[i];
+            r.cigarOffset = (uint32_t)pool.size();
+            pool += enc.text;
+            pool.push_back('\0');
+            results.push_back(r);
+        }
+    }
+    (void)hipFree(dCand);
+    if (rc) return rc;
+    s3_dp_single_result *out = (s3_dp_single_result *)malloc(results.size() * sizeof(s3_dp_single_result) + 1);
+    char *cp = (char *)malloc(pool.size() + 1);
+    if (!out || !cp) { free(out); free(cp); return fail(S3_ENOMEM, "s3_dp_single_end: out of host memory"); }
+    memcpy(out, results.data(), results.size() * sizeof(s3_dp_single_result));
+    memcpy(cp, pool.data(), pool.size());
+    *resultsOut = out; *nResultsOut = results.size(); *cigarPoolOut = cp;
+    return S3_OK;
+}
+
+extern "C" int s3_dp_last_timing(s3_dp *h, float *ms)
+{
+    if (!h || !h->timed || !ms) return fail(S3_EINVAL, "no timed DP call");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipEventElapsedTime(ms, h->ev[0], h->ev[1]));
+    return S3_OK;
+}
+

@@ -1,0 +1,143 @@
+// s3dp_internal.h -- private to libs3dp.so: the objects behind the C-ABI handles and the helpers the source files share.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/s3dp.h"
+#include "s3dp_device.h"
+#include "s3dp_model.h"
+
+namespace s3i {
+int fail(int code, const std::string &msg);               // records the message for s3_last_error and returns `code`
+}
+#define HIPCHK(x)                                                                                          \
+    do {                                                                                                   \
+        hipError_t e_ = (x);                                                                               \
+        if (e_ != hipSuccess) return s3i::fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+struct s3_index {
+    int       dev = 0;
+    s3::DevIndex  d{};
+    std::vector<void *> allocs;
+    S3Model  *models[S3_MAX_MISMATCH + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // device, indexed by read length
+    size_t    bytes = 0;
+};
+
+struct s3_batch {
+    s3_index *ix = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t maxReads = 0, wpq = 0, n = 0;
+    size_t   maxItems = 0;
+    uint32_t recCap = 0, occCap = 0;
+    // inputs
+    uint32_t *dQueries = nullptr, *dLens = nullptr, *dReadsT = nullptr, *dSeedLens = nullptr;
+    bool longMode = false;          // seed lengths set: the reference's long-read mode
+    uint32_t fullUniformLen = 0;
+    // search / ordering work buffers
+    uint4    *dRecs = nullptr, *dOrdered = nullptr;
+    uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr;
+    unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;
+    uint32_t uniformLen = 0;
+    uint32_t *dKept = nullptr, *dOccCounts = nullptr, *dCeCounts = nullptr, *dTotalOcc = nullptr, *dWithError = nullptr;
+    uint32_t *dHitOffsets = nullptr;
+    s3::DevHit   *dHits = nullptr;
+    char     *dTemp = nullptr; size_t tempBytes = 0;
+    // ladder
+    uint32_t *dActive[2] = {nullptr, nullptr}, *dNumSel = nullptr, *dIota = nullptr;
+    uint8_t  *dState = nullptr, *dSelFlags = nullptr;
+    uint32_t *dOccOffsets = nullptr, *dMasked = nullptr;
+    uint32_t *dOccPos = nullptr, *dOccMeta = nullptr;
+    uint8_t  *dPhase = nullptr;
+    uint32_t *dFinalWithError = nullptr, *dOccStart = nullptr, *dOccCount = nullptr;
+    uint32_t *dOutOffsets = nullptr, *dOutPos = nullptr, *dOutMeta = nullptr;
+    // paired-end ladder (allocated by the first s3_batch_align_pair)
+    bool pairReady = false;
+    s3::DevPair  *dPairs = nullptr;
+    uint8_t  *dPairMin = nullptr, *dPairNext = nullptr;
+    uint32_t *dReadList = nullptr, *dPairActive[2] = {nullptr, nullptr}, *dBestIdx = nullptr, *dXaCount = nullptr, *dXaOffsets = nullptr;
+    uint32_t *dXaStart = nullptr, *dXaCountOut = nullptr, *dXaOutOffsets = nullptr, *dOccCountIn = nullptr, *dSegBegin = nullptr, *dSegEnd = nullptr;
+    s3::DevPairXa *dXa = nullptr, *dXaOut = nullptr;
+    uint32_t xaCap = 0, xaUsed = 0;
+    uint64_t *dSortKeys[2] = {nullptr, nullptr};
+    uint32_t *dSortMeta = nullptr;
+    char     *dSortTemp = nullptr;
+    size_t    sortItems = 0, sortTempBytes = 0;
+    std::vector<void *> allocs;
+    // state of the last call
+    int lastKind = 0;              // 1 = search, 2 = align (single), 3 = align (pairs)
+    uint32_t lastNumCases = 0;
+    bool counting = false;
+    hipEvent_t evTotal[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> evSearch;
+    uint32_t searchLaunches = 0;
+    uint32_t occUsed = 0;
+    uint64_t recordsTotal = 0;      // records of all search passes of the last call (read back when counters are enabled)
+};
+
+struct s3_dp {
+    int dev = 0, scheme = 1;
+    uint32_t maxProblems = 0, maxRead = 0, maxDNA = 0, maxTable = 0, patternLen = 0;
+    s3_dp_scores sc{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::vector<void *> allocs;
+    uint32_t *dDna = nullptr, *dReads = nullptr, *dDnaLen = nullptr, *dReadLen = nullptr, *dClipLt = nullptr, *dClipRt = nullptr, *dAL = nullptr, *dAR = nullptr;
+    int32_t *dCut = nullptr, *dScores = nullptr;
+    uint32_t *dHit = nullptr, *dStart = nullptr, *dCnt = nullptr, *dCols = nullptr, *dTable = nullptr;
+    unsigned char *dPattern = nullptr;
+    size_t tableWords = 0;
+    bool timed = false;
+};
+
+namespace s3i {
+template <class T>
+inline int balloc(s3_batch *b, T **p, size_t count)
+{
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (!bytes) bytes = 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch): ") + hipGetErrorString(e));
+    b->allocs.push_back(q);
+    *p = (T *)q;
+    return S3_OK;
+}
+
+// replace a batch buffer by a larger one, keeping the first `keep` elements
+template <class T>
+inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, newCount * sizeof(T));
+    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch grow): ") + hipGetErrorString(e));
+    if (keep) {
+        e = hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) { (void)hipFree(q); return fail(S3_EHIP, std::string("grow copy: ") + hipGetErrorString(e)); }
+    }
+    for (auto &a : b->allocs) if (a == (void *)*p) a = q;
+    (void)hipFree(*p);
+    *p = (T *)q;
+    return S3_OK;
+}
+
+
+static const size_t kMaxEntries = 0xFFFFFF00ull;         // record / occurrence indices are 32 bit
+int growRecords(s3_batch *b);
+int growOccurrences(s3_batch *b, uint64_t need);
+size_t envSize(const char *name, size_t dflt);
+// search + order + merge for `nActive` slots (s3dp_api.hip); per-slot results land in dTotalOcc / dWithError / dKept / ...
+int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint32_t modelMm, uint32_t maxOut);
+int checkFlags(s3_batch *b);
+// ladders (s3dp_ladder.hip)
+struct LongArgs { bool on; int onlyBest, minSeedMis, needMapq; uint32_t maxHit; int carryOn; };
+int decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive, uint8_t want, uint8_t phase, uint32_t maxOut, uint8_t selectWhen, const LongArgs &lg);
+void launchIota(uint32_t *p, uint32_t n, hipStream_t s);
+void launchStateAll(uint32_t n, const uint32_t *totalOcc, uint8_t *state, hipStream_t s);
+// DP (s3dp_dpapi.hip): launch the DP kernels on what is in the aligner's device buffers
+int dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR);
+}  // namespace s3i

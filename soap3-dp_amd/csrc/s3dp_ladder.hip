@@ -1,0 +1,517 @@
+// s3dp_ladder.hip -- the phase ladders of the C-ABI: single-end report types (all valid / all best / unique best / random best), long-read
+// verification, and the paired-end ladder with pairing.  Host orchestration + small bookkeeping kernels; the search passes themselves are
+// s3i::searchPass (s3dp_api.hip).
+#include <hipcub/hipcub.hpp>
+#include "s3dp_internal.h"
+
+using namespace s3;
+using namespace s3i;
+
+// ---------------------------------------------------------------------------------------------
+// small helper kernels of the ladder (plumbing, not hot)
+// ---------------------------------------------------------------------------------------------
+__global__ void iotaKernel(uint32_t *p, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
+
+__global__ void maskKernel(uint32_t n, const uint8_t *state, uint8_t want, const uint32_t *occCounts, uint32_t *masked, uint8_t *selFlags,
+                           uint8_t selectWhen /*0: state!=1, 2: state==2*/)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { masked[i] = 0; return; }
+    masked[i] = state[i] == want ? occCounts[i] : 0u;
+    selFlags[i] = selectWhen == 0 ? (state[i] != 1) : (state[i] == 2);
+}
+
+// record the resolved reads of this pass in the per-read (global index) result arrays
+__global__ void publishKernel(uint32_t nActive, const uint32_t *active, const uint8_t *state, uint8_t want, uint8_t phase, const uint32_t *withError,
+                              const uint32_t *occOffsets, uint32_t occBase, uint8_t *outPhase, uint32_t *outWithError, uint32_t *outOccStart,
+                              uint32_t *outOccCount)
+{
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nActive || state[slot] != want) return;
+    const uint32_t r = active ? active[slot] : slot;
+    outPhase[r] = phase;
+    for (int k = 0; k < 8; k++) outWithError[(size_t)r * 8 + k] = withError[(size_t)slot * 8 + k];
+    outOccStart[r] = occBase + occOffsets[slot];
+    outOccCount[r] = occOffsets[slot + 1] - occOffsets[slot];
+}
+
+__global__ void stateAllKernel(uint32_t n, const uint32_t *totalOcc, uint8_t *state)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) state[i] = totalOcc[i] > 0 ? 1 : 0;
+}
+
+__global__ void gatherOccKernel(uint32_t n, const uint32_t *occStart, const uint32_t *outOffsets, const uint32_t *pos, const uint32_t *meta,
+                                uint32_t *outPos, uint32_t *outMeta)
+{
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t cnt = outOffsets[r + 1] - outOffsets[r], src = occStart[r], dst = outOffsets[r];
+    for (uint32_t k = 0; k < cnt; k++) { outPos[dst + k] = pos[src + k]; outMeta[dst + k] = meta[src + k]; }
+}
+
+void s3i::launchIota(uint32_t *p, uint32_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(iotaKernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+}
+void s3i::launchStateAll(uint32_t n, const uint32_t *totalOcc, uint8_t *state, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(stateAllKernel, dim3((n + 255) / 256), dim3(256), 0, s, n, totalOcc, state);
+}
+
+// Long-read mode (validateAlignments, CPUfunctions.cpp:1129-1222, called at :1832): the published occurrences are seed hits; every one
+// is extended over the rest of the read by counting mismatching characters against the packed text (numMismatchNew, PE.cpp:148),
+// kept when seed + extension mismatches <= maxMismatch and moved to the leftmost text position of the whole read; best modes keep
+// only the hits with the fewest mismatches.  The list is filtered in place in the reference's order, one lane per read.  A read whose
+// list comes out empty is "nohit": unaligned, and carried to the next phase when there is one.
+struct ValidateArgs {
+    uint32_t nActive;
+    const uint32_t *active;
+    const uint8_t *state;
+    uint8_t want;
+    const uint32_t *occOffsets;
+    uint32_t occBase;
+    uint32_t *occPos, *occMeta;
+    const uint32_t *queries;      // packed reads, reference layout (32-interleaved, LSB-first characters)
+    uint32_t wpq;
+    const uint32_t *lens, *seedLens;
+    const uint32_t *text;
+    uint32_t textLength;
+    int onlyBest, minSeedMis, needMapq;
+    uint32_t maxHit;
+    int carryOn;                  // not the terminal phase: empty lists go on
+    uint8_t *outPhase;
+    uint32_t *outOccCount;
+    uint8_t *selFlags;
+};
+
+__global__ void validateKernel(ValidateArgs a)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= a.nActive || a.state[slot] != a.want) return;
+    const uint32_t r = a.active ? a.active[slot] : slot;
+    const uint32_t readLen = a.lens[r], seedLen = a.seedLens[r];
+    const uint32_t base = a.occBase + a.occOffsets[slot];
+    const uint32_t cnt = a.occOffsets[slot + 1] - a.occOffsets[slot];
+    uint32_t out = cnt;
+    if (readLen > seedLen) {
+        const uint32_t ext = readLen - seedLen;
+        int maxMis = (int)ceil(0.02 * (double)readLen);                  // MISMATCH_RATIO_FOR_LONG, CPUfunctions.cpp:1819
+        if (a.needMapq) maxMis *= 2;
+        int pre = maxMis;
+        const uint32_t *rd = a.queries + (size_t)(r >> 5) * 32u * a.wpq + (r & 31u);
+        auto readChar = [&](uint32_t q) -> uint32_t { return (rd[(size_t)(q >> 4) * 32u] >> ((q & 15u) * 2u)) & 3u; };
+        auto textChar = [&](uint64_t p) -> uint32_t { return (a.text[p >> 4] >> (2u * (15u - (uint32_t)(p & 15u)))) & 3u; };
+        out = 0;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const uint32_t pos = a.occPos[base + i], meta = a.occMeta[base + i];
+            const uint32_t strand = meta & 0xFFu;
+            const int seedMis = (int)((meta >> 8) & 0xFFu);
+            if (seedMis < a.minSeedMis) continue;
+            int mis = maxMis + 1;
+            if (strand == 1u && (uint64_t)pos + readLen <= a.textLength) {
+                mis = 0;
+                for (uint32_t t = 0; t < ext; t++) mis += readChar(seedLen + t) != textChar((uint64_t)pos + seedLen + t);
+            }
+            if (strand == 2u && pos >= ext) {
+                mis = 0;
+                for (uint32_t t = 0; t < ext; t++) mis += (3u - readChar(readLen - 1u - t)) != textChar((uint64_t)pos - ext + t);
+            }
+            const int tot = mis + seedMis;
+            if (tot > maxMis) continue;
+            if (a.onlyBest && tot > pre) continue;
+            if (a.onlyBest && tot < pre) { out = 0; pre = tot; }
+            a.occPos[base + out] = strand == 1u ? pos : pos - ext;
+            a.occMeta[base + out] = strand | (uint32_t)tot << 8;
+            out++;
+            if (pre == a.minSeedMis && out >= a.maxHit) break;
+        }
+    }
+    if (out > a.maxHit) out = a.maxHit;                                  // origHitLimit, CPUfunctions.cpp:1838
+    a.outOccCount[r] = out;
+    if (out == 0) {
+        a.outPhase[r] = 0;
+        if (a.carryOn) a.selFlags[slot] = 1;
+    }
+}
+
+// decode + publish the slots whose state == want; the occurrence region is appended at *dOccBase
+
+int s3i::decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive, uint8_t want, uint8_t phase, uint32_t maxOut, uint8_t selectWhen,
+                            const LongArgs &lg)
+{
+    if (!nActive) return S3_OK;
+    const unsigned g = (nActive + 1 + 255) / 256;
+    hipLaunchKernelGGL(maskKernel, dim3(g), dim3(256), 0, b->stream, nActive, b->dState, want, b->dOccCounts, b->dMasked, b->dSelFlags, selectWhen);
+    size_t tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dMasked, b->dOccOffsets, (int)(nActive + 1), b->stream));
+    uint32_t added = 0;
+    HIPCHK(hipMemcpyAsync(&added, b->dOccOffsets + nActive, 4, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if ((uint64_t)b->occUsed + added > b->occCap) {
+        int rc = growOccurrences(b, (uint64_t)b->occUsed + added);
+        if (rc) return rc;
+    }
+    const uint32_t base = b->occUsed;
+    hipLaunchKernelGGL(publishKernel, dim3((nActive + 255) / 256), dim3(256), 0, b->stream, nActive, active, b->dState, want, phase, b->dWithError,
+                       b->dOccOffsets, base, b->dPhase, b->dFinalWithError, b->dOccStart, b->dOccCount);
+    MergeArgs m{};
+    m.nActive = nActive; m.nCases = b->lastNumCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
+    m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
+    m.decodeMask = b->dState; m.decodeWant = want;
+    launchDecode(m, b->ix->d, b->dOccOffsets, base, b->occCap, b->dOccPos, b->dOccMeta, b->dFlags, b->stream);
+    if (lg.on) {
+        ValidateArgs v{};
+        v.nActive = nActive; v.active = active; v.state = b->dState; v.want = want; v.occOffsets = b->dOccOffsets; v.occBase = base;
+        v.occPos = b->dOccPos; v.occMeta = b->dOccMeta; v.queries = b->dQueries; v.wpq = b->wpq; v.lens = b->dLens; v.seedLens = b->dSeedLens;
+        v.text = b->ix->d.pac; v.textLength = b->ix->d.n;
+        v.onlyBest = lg.onlyBest; v.minSeedMis = lg.minSeedMis; v.needMapq = lg.needMapq; v.maxHit = lg.maxHit; v.carryOn = lg.carryOn;
+        v.outPhase = b->dPhase; v.outOccCount = b->dOccCount; v.selFlags = b->dSelFlags;
+        hipLaunchKernelGGL(validateKernel, dim3((nActive + 255) / 256), dim3(256), 0, b->stream, v);
+    }
+    b->occUsed += added;
+    return S3_OK;
+}
+
+// reportType as the reference's -h option: 1 all valid, 2 all best, 3 unique best, 4 random best.
+//   all best   : all_best_single_alignment (alignment.cu:1422): phases 1..k, reads whose best == phase are deferred / re-searched
+//   all valid  : one phase at k (soap3_dp_single_align -> all_valid_alignment, alignment.cu:2530), terminal, same MAPQ special case
+//   unique/random best: best_single_alignment (alignment.cu:1377): phases 0..k, a read is reported in the first phase with a hit
+extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead, int reportType)
+{
+    if (reportType < 1 || reportType > 4) return fail(S3_EINVAL, "reportType must be 1..4");
+    const bool bestMode = reportType >= 3, allValid = reportType == 1;
+    if (!b) return fail(S3_EINVAL, "null batch");
+    if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
+    if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    const uint32_t n = b->n;
+    b->searchLaunches = 0;
+    b->occUsed = 0;
+    b->recordsTotal = 0;
+    HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
+    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
+    HIPCHK(hipMemsetAsync(b->dPhase, 0, n, b->stream));
+    HIPCHK(hipMemsetAsync(b->dFinalWithError, 0, (size_t)n * 32, b->stream));
+    HIPCHK(hipMemsetAsync(b->dOccStart, 0, (size_t)n * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dOccCount, 0, ((size_t)n + 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dNumSel, 0, 16, b->stream));
+    const uint32_t last = (bestMode || allValid) ? numMismatch : (numMismatch > 0 ? numMismatch : 1);   // alignment.cu:1439
+    const uint32_t first = bestMode ? 0u : (allValid ? numMismatch : 1u);
+    const uint32_t searchLimit = b->longMode ? 0xFFFFFFFFu : maxOutputPerRead;
+    const uint32_t *active = nullptr;
+    uint32_t nActive = n;
+    int pp = 0;
+    for (uint32_t mm = first; mm <= last && nActive > 0; mm++) {
+        const bool terminal = mm >= numMismatch;
+        // long-read mode lifts the hit limit during the search (CPUfunctions.cpp:1655-1656) and applies it after the verification
+        LongArgs lg{b->longMode, bestMode ? 1 : 0, bestMode ? (int)mm : 0, bestMode ? 0 : 1, maxOutputPerRead, terminal ? 0 : 1};
+        int rc = searchPass(b, active, nActive, mm, searchLimit);
+        if (rc) return rc;
+        // MAPQ special case needs the (mm+1) model, which exists only for mm < 4 (CPUfunctions.cpp:1756)
+        launchClassify(nActive, b->dTotalOcc, b->dWithError, mm, (!bestMode && mm < 4) ? 1u : 0u, b->dState, b->stream);
+        rc = decodeAndPublish(b, active, nActive, 1, (uint8_t)(bestMode ? mm + 1 : mm), searchLimit, terminal ? 2 : 0, lg);
+        if (rc) return rc;
+        // reads that go on: no hit or best == mm (non terminal: next phase; terminal: state 2 re-searched with mm+1 model)
+        const uint32_t *idsIn = active;
+        if (!idsIn) {
+            launchIota(b->dIota, nActive, b->stream);
+            idsIn = b->dIota;
+        }
+        size_t tb = b->tempBytes;
+        uint32_t *nextList = b->dActive[pp];
+        HIPCHK(hipcub::DeviceSelect::Flagged(b->dTemp, tb, idsIn, b->dSelFlags, nextList, b->dNumSel, (int)nActive, b->stream));
+        uint32_t nNext = 0;
+        HIPCHK(hipMemcpyAsync(&nNext, b->dNumSel, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (terminal) {
+            if (!bestMode && mm < 4 && nNext > 0) {
+                // ProcessOneMoreMismatchAllCases (CPUfunctions.cpp:624, called at :1790): the read is re-searched with the
+                // (mm+1)-mismatch model and THAT result is what gets reported
+                rc = searchPass(b, nextList, nNext, mm + 1, searchLimit);
+                if (rc) return rc;
+                launchStateAll(nNext, b->dTotalOcc, b->dState, b->stream);
+                rc = decodeAndPublish(b, nextList, nNext, 1, (uint8_t)mm, searchLimit, 0, lg);
+                if (rc) return rc;
+            }
+            break;
+        }
+        active = nextList;
+        nActive = nNext;
+        pp ^= 1;
+    }
+    // read-ordered CSR of the occurrences
+    size_t tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dOccCount, b->dOutOffsets, (int)(n + 1), b->stream));
+    if (n) hipLaunchKernelGGL(gatherOccKernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, n, b->dOccStart, b->dOutOffsets, b->dOccPos, b->dOccMeta,
+                              b->dOutPos, b->dOutMeta);
+    HIPCHK(hipEventRecord(b->evTotal[1], b->stream));
+    HIPCHK(hipGetLastError());
+    b->lastKind = 2;
+    return S3_OK;
+}
+
+extern "C" int s3_batch_align_single_allbest(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead)
+{
+    return s3_batch_align_single(b, numMismatch, maxOutputPerRead, 2);
+}
+
+extern "C" int s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError, uint64_t *occOffsets, uint32_t *occPos, uint8_t *occStrand,
+                                         uint8_t *occMis, size_t occCap, uint64_t *nOccOut)
+{
+    if (!b || b->lastKind != 2) return fail(S3_EINVAL, "s3_batch_fetch_alignments: no alignment result pending");
+    int rc = s3_batch_sync(b);
+    if (rc) return rc;
+    const uint32_t n = b->n;
+    std::vector<uint32_t> off((size_t)n + 1);
+    HIPCHK(hipMemcpy(off.data(), b->dOutOffsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    const uint64_t total = off[n];
+    if (nOccOut) *nOccOut = total;
+    if (phase) HIPCHK(hipMemcpy(phase, b->dPhase, n, hipMemcpyDeviceToHost));
+    if (withError) HIPCHK(hipMemcpy(withError, b->dFinalWithError, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (occOffsets) for (size_t i = 0; i <= n; i++) occOffsets[i] = off[i];
+    if (occPos || occStrand || occMis) {
+        if (total > occCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_alignments: output arrays too small");
+        if (occPos) HIPCHK(hipMemcpy(occPos, b->dOutPos, total * 4, hipMemcpyDeviceToHost));
+        if (occStrand || occMis) {
+            std::vector<uint32_t> meta(total);
+            HIPCHK(hipMemcpy(meta.data(), b->dOutMeta, total * 4, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < total; i++) {
+                if (occStrand) occStrand[i] = (uint8_t)(meta[i] & 0xFF);
+                if (occMis) occMis[i] = (uint8_t)((meta[i] >> 8) & 0xFF);
+            }
+        }
+    }
+    return S3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// paired-end ladder with the DP stages off.  Replaces, for `soap3-dp pair ... -s k`:
+//   soap3_dp_pair_align's choice of ladder (alignment.cu:1965-2013), all_best_alignment (:1236, phases 1, 2, k),
+//   four_phases_alignment (:1119, phases 0, 1, 2, k), all_valid_alignment for pairs (:534), the PAIR_END_READ branch of hostKernel
+//   (CPUfunctions.cpp:1980-2560) and PEMappingOccurrences / PEStatsPEOutput (PEAlgnmt.cpp:480,834).
+// ---------------------------------------------------------------------------------------------
+__global__ void pairInitKernel(uint32_t n, DevPair *pairs)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    DevPair z{};
+    z.min1 = z.min2 = 255; z.minTotal = z.secMinTotal = 127;
+    pairs[p] = z;
+}
+
+static int ensurePairBuffers(s3_batch *b)
+{
+    if (b->pairReady) return S3_OK;
+    const size_t maxReads = b->maxReads, maxPairs = maxReads / 2 + 1;
+    int rc;
+#define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) return rc;
+    BA(dPairs, maxPairs); BA(dPairMin, maxReads + 2); BA(dPairNext, maxPairs); BA(dReadList, maxReads + 2);
+    BA(dPairActive[0], maxPairs); BA(dPairActive[1], maxPairs); BA(dBestIdx, maxPairs); BA(dXaCount, maxPairs + 1); BA(dXaOffsets, maxPairs + 1);
+    BA(dXaStart, maxPairs); BA(dXaCountOut, maxPairs + 1); BA(dXaOutOffsets, maxPairs + 1); BA(dOccCountIn, maxReads + 2);
+    BA(dSegBegin, maxReads + 2); BA(dSegEnd, maxReads + 2);
+    b->xaCap = (uint32_t)(maxPairs + 65536);
+    BA(dXa, b->xaCap); BA(dXaOut, b->xaCap);
+#undef BA
+    b->pairReady = true;
+    return S3_OK;
+}
+
+static int ensureSortBuffers(s3_batch *b, size_t items, int segments)
+{
+    int rc;
+    if (items > b->sortItems) {
+        const size_t cap = items + items / 2 + 1024;
+        if (b->sortItems == 0) {
+            if ((rc = balloc(b, &b->dSortKeys[0], cap)) || (rc = balloc(b, &b->dSortKeys[1], cap)) || (rc = balloc(b, &b->dSortMeta, cap))) return rc;
+        } else {
+            if ((rc = bgrow(b, &b->dSortKeys[0], cap, 0)) || (rc = bgrow(b, &b->dSortKeys[1], cap, 0)) || (rc = bgrow(b, &b->dSortMeta, cap, 0))) return rc;
+        }
+        b->sortItems = cap;
+    }
+    size_t tb = 0;
+    HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb, b->dSortKeys[0], b->dSortKeys[1], b->dOccMeta, b->dSortMeta, (int)items, segments,
+                                                       b->dSegBegin, b->dSegEnd, 0, 64, b->stream));
+    if (tb > b->sortTempBytes) {
+        const size_t cap = tb + tb / 2 + 256;
+        if (b->sortTempBytes == 0) { if ((rc = balloc(b, &b->dSortTemp, cap))) return rc; }
+        else if ((rc = bgrow(b, &b->dSortTemp, cap, 0))) return rc;
+        b->sortTempBytes = cap;
+    }
+    return S3_OK;
+}
+
+extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t maxHitsPerEnd, int reportType, uint32_t insertLow, uint32_t insertHigh,
+                                   uint32_t peMaxOutputPerPair)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    if (reportType < 1 || reportType > 4) return fail(S3_EINVAL, "reportType must be 1..4");
+    if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
+    if (maxHitsPerEnd == 0 || maxHitsPerEnd > 0xFFFFFFu) return fail(S3_EINVAL, "maxHitsPerEnd must be 1..16777215");
+    if (b->n & 1u) return fail(S3_EINVAL, "s3_batch_align_pair: the batch must hold an even number of reads (read 2p and 2p+1 are a pair)");
+    if (b->longMode) return fail(S3_EINVAL, "s3_batch_align_pair: seed lengths are a single-end feature");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    int rc = ensurePairBuffers(b);
+    if (rc) return rc;
+    const bool bestMode = reportType >= 3, mapq = !bestMode;
+    const uint32_t n = b->n, nPairs = n / 2;
+    b->searchLaunches = 0;
+    b->occUsed = 0;
+    b->xaUsed = 0;
+    b->recordsTotal = 0;
+    HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
+    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
+    HIPCHK(hipMemsetAsync(b->dPhase, 0, n ? n : 1, b->stream));
+    HIPCHK(hipMemsetAsync(b->dFinalWithError, 0, (size_t)(n ? n : 1) * 32, b->stream));
+    HIPCHK(hipMemsetAsync(b->dOccStart, 0, (size_t)(n ? n : 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dOccCount, 0, ((size_t)n + 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dXaStart, 0, ((size_t)nPairs + 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dXaCountOut, 0, ((size_t)nPairs + 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dPairMin, 255, n ? n : 1, b->stream));
+    HIPCHK(hipMemsetAsync(b->dNumSel, 0, 16, b->stream));
+    if (nPairs) hipLaunchKernelGGL(pairInitKernel, dim3((nPairs + 255) / 256), dim3(256), 0, b->stream, nPairs, b->dPairs);
+    uint32_t phases[4];
+    int nPhases = 0;
+    if (reportType == 2) { phases[nPhases++] = 1; if (numMismatch > 1) phases[nPhases++] = 2; if (numMismatch > 2) phases[nPhases++] = numMismatch; }
+    else if (reportType == 1) phases[nPhases++] = numMismatch;
+    else { phases[nPhases++] = 0; if (numMismatch > 0) phases[nPhases++] = 1; if (numMismatch > 1) phases[nPhases++] = 2; if (numMismatch > 2) phases[nPhases++] = numMismatch; }
+    const LongArgs noLong{false, 0, 0, 0, 0, 0};
+    const uint32_t *active = nullptr;
+    uint32_t nA = nPairs;
+    int pp = 0;
+    for (int ph = 0; ph < nPhases && nA > 0; ph++) {
+        const uint32_t mm = phases[ph];
+        const bool terminal = ph + 1 == nPhases;
+        launchPairExpand(nA, active, b->dReadList, b->stream);
+        rc = searchPass(b, b->dReadList, 2 * nA, mm, maxHitsPerEnd);
+        if (rc) return rc;
+        PairClassifyArgs ca{};
+        ca.nPairs = nA; ca.activePairs = active; ca.totalOcc = b->dTotalOcc; ca.withError = b->dWithError; ca.mm = mm; ca.maxHits = maxHitsPerEnd;
+        ca.terminal = terminal; ca.mapq = mapq; ca.slotState = b->dState; ca.pairNext = b->dPairNext; ca.pairMin = b->dPairMin; ca.occCount = b->dOccCount;
+        launchPairClassify(ca, b->stream);
+        const uint32_t regionBase = b->occUsed;
+        rc = decodeAndPublish(b, b->dReadList, 2 * nA, 1, 0, maxHitsPerEnd, 2, noLong);       // selFlags = ends to search again
+        if (rc) return rc;
+        if (mapq && mm < 4) {
+            size_t tb = b->tempBytes;
+            HIPCHK(hipcub::DeviceSelect::Flagged(b->dTemp, tb, b->dReadList, b->dSelFlags, b->dActive[0], b->dNumSel, (int)(2 * nA), b->stream));
+            uint32_t nR = 0;
+            HIPCHK(hipMemcpyAsync(&nR, b->dNumSel, 4, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+            if (nR) {
+                // ProcessOneMoreMismatchAllCases on that end; THAT result is what the pairing sees
+                rc = searchPass(b, b->dActive[0], nR, mm + 1, maxHitsPerEnd);
+                if (rc) return rc;
+                launchStateAll(nR, b->dTotalOcc, b->dState, b->stream);
+                rc = decodeAndPublish(b, b->dActive[0], nR, 1, 0, maxHitsPerEnd, 0, noLong);
+                if (rc) return rc;
+            }
+        }
+        // position-sort both lists of every pair with hits on both ends (PERadixSort), then pair them up
+        const size_t items = (size_t)b->occUsed - regionBase;
+        PairSortArgs sa{};
+        sa.nPairs = nA; sa.activePairs = active; sa.pairNext = b->dPairNext; sa.occStart = b->dOccStart; sa.occCount = b->dOccCount;
+        sa.regionBase = regionBase; sa.occPos = b->dOccPos; sa.occMeta = b->dOccMeta; sa.segBegin = b->dSegBegin; sa.segEnd = b->dSegEnd;
+        if (items) {
+            rc = ensureSortBuffers(b, items, (int)(2 * nA));
+            if (rc) return rc;
+            sa.keys = b->dSortKeys[0];
+            launchPairSortKeys(sa, b->stream);
+            size_t tb = b->sortTempBytes;
+            HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(b->dSortTemp, tb, b->dSortKeys[0], b->dSortKeys[1], b->dOccMeta + regionBase, b->dSortMeta,
+                                                               (int)items, (int)(2 * nA), b->dSegBegin, b->dSegEnd, 0, 64, b->stream));
+            launchPairSortBack(sa, b->dSortKeys[1], b->dSortMeta, b->stream);
+        }
+        launchPairSnapshotCounts(nA, active, b->dOccCount, b->dOccCountIn, b->stream);
+        PairSweepArgs sw{};
+        sw.nPairs = nA; sw.activePairs = active; sw.pairNext = b->dPairNext; sw.pairMin = b->dPairMin; sw.finalWithError = b->dFinalWithError;
+        sw.occStart = b->dOccStart; sw.occCount = b->dOccCount; sw.occCountIn = b->dOccCountIn; sw.occPos = b->dOccPos; sw.occMeta = b->dOccMeta;
+        sw.readLengths = b->dLens; sw.insertLow = insertLow; sw.insertHigh = insertHigh; sw.peMaxOutputPerPair = peMaxOutputPerPair; sw.mm = mm;
+        sw.terminal = terminal; sw.pairs = b->dPairs; sw.bestIdx = b->dBestIdx; sw.xaCount = b->dXaCount; sw.xaStart = b->dXaStart; sw.xaCountOut = b->dXaCountOut;
+        launchPairStats(sw, b->stream);
+        HIPCHK(hipMemsetAsync(b->dXaCount + nA, 0, 4, b->stream));
+        size_t tb = b->tempBytes;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dXaCount, b->dXaOffsets, (int)(nA + 1), b->stream));
+        uint32_t xaAdded = 0;
+        HIPCHK(hipMemcpyAsync(&xaAdded, b->dXaOffsets + nA, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if ((uint64_t)b->xaUsed + xaAdded > b->xaCap) {
+            uint64_t cap = (uint64_t)b->xaCap * 2;
+            if (cap < (uint64_t)b->xaUsed + xaAdded) cap = (uint64_t)b->xaUsed + xaAdded + 65536;
+            if (cap > kMaxEntries) return fail(S3_EOVERFLOW, "pair list overflow at the 32-bit limit");
+            if ((rc = bgrow(b, &b->dXa, (size_t)cap, b->xaUsed)) || (rc = bgrow(b, &b->dXaOut, (size_t)cap, 0))) return rc;
+            b->xaCap = (uint32_t)cap;
+        }
+        launchPairEmit(sw, b->dXaOffsets, b->xaUsed, b->dXa, b->stream);
+        b->xaUsed += xaAdded;
+        if (terminal) break;
+        const uint32_t *idsIn = active;
+        if (!idsIn) {
+            launchIota(b->dIota, nA, b->stream);
+            idsIn = b->dIota;
+        }
+        tb = b->tempBytes;
+        uint32_t *nextList = b->dPairActive[pp];
+        HIPCHK(hipcub::DeviceSelect::Flagged(b->dTemp, tb, idsIn, b->dPairNext, nextList, b->dNumSel, (int)nA, b->stream));
+        uint32_t nNext = 0;
+        HIPCHK(hipMemcpyAsync(&nNext, b->dNumSel, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        active = nextList;
+        nA = nNext;
+        pp ^= 1;
+    }
+    // read-ordered CSR of the occurrence lists of the pairs without a proper pairing, pair-ordered CSR of the XA pairs
+    size_t tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dOccCount, b->dOutOffsets, (int)(n + 1), b->stream));
+    if (n) hipLaunchKernelGGL(gatherOccKernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, n, b->dOccStart, b->dOutOffsets, b->dOccPos, b->dOccMeta,
+                              b->dOutPos, b->dOutMeta);
+    tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dXaCountOut, b->dXaOutOffsets, (int)(nPairs + 1), b->stream));
+    launchPairGatherXa(nPairs, b->dXaStart, b->dXaOutOffsets, b->dXa, b->dXaOut, b->stream);
+    HIPCHK(hipEventRecord(b->evTotal[1], b->stream));
+    HIPCHK(hipGetLastError());
+    b->lastKind = 3;
+    return S3_OK;
+}
+
+extern "C" int s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t *xaOffsets, s3_pair_xa *xa, size_t xaCap, uint64_t *nXaOut,
+                                    uint64_t *occOffsets, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis, size_t occCap, uint64_t *nOccOut)
+{
+    if (!b || b->lastKind != 3) return fail(S3_EINVAL, "s3_batch_fetch_pairs: no paired-end result pending");
+    int rc = s3_batch_sync(b);
+    if (rc) return rc;
+    static_assert(sizeof(s3_pair_result) == sizeof(DevPair) && sizeof(s3_pair_xa) == sizeof(DevPairXa), "pair layouts");
+    const uint32_t n = b->n, nPairs = n / 2;
+    if (pairs && nPairs) HIPCHK(hipMemcpy(pairs, b->dPairs, (size_t)nPairs * sizeof(DevPair), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> off((size_t)nPairs + 1);
+    HIPCHK(hipMemcpy(off.data(), b->dXaOutOffsets, ((size_t)nPairs + 1) * 4, hipMemcpyDeviceToHost));
+    const uint64_t nXa = off[nPairs];
+    if (nXaOut) *nXaOut = nXa;
+    if (xaOffsets) for (size_t i = 0; i <= nPairs; i++) xaOffsets[i] = off[i];
+    if (xa) {
+        if (nXa > xaCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_pairs: pair list array too small");
+        if (nXa) HIPCHK(hipMemcpy(xa, b->dXaOut, nXa * sizeof(DevPairXa), hipMemcpyDeviceToHost));
+    }
+    std::vector<uint32_t> ooff((size_t)n + 1);
+    HIPCHK(hipMemcpy(ooff.data(), b->dOutOffsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    const uint64_t total = ooff[n];
+    if (nOccOut) *nOccOut = total;
+    if (occOffsets) for (size_t i = 0; i <= n; i++) occOffsets[i] = ooff[i];
+    if (occPos || occStrand || occMis) {
+        if (total > occCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_pairs: occurrence arrays too small");
+        if (occPos && total) HIPCHK(hipMemcpy(occPos, b->dOutPos, total * 4, hipMemcpyDeviceToHost));
+        if ((occStrand || occMis) && total) {
+            std::vector<uint32_t> meta(total);
+            HIPCHK(hipMemcpy(meta.data(), b->dOutMeta, total * 4, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < total; i++) {
+                if (occStrand) occStrand[i] = (uint8_t)(meta[i] & 0xFF);
+                if (occMis) occMis[i] = (uint8_t)((meta[i] >> 8) & 0xFF);
+            }
+        }
+    }
+    return S3_OK;
+}
+
