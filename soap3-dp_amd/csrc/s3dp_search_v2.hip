@@ -173,13 +173,12 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (s >= nSteps) {                                               // SRA_STEP_TYPE_COMPLETE
                 uint32_t l = g.fl, rr_ = g.fr;
                 if (rr_ >= l) {
+                    if (pendMeta >> 31) { state = ST_RESUME; return; }       // one record per lane and trip: this frame waits for the next trip
                     if (total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - total - 1u;
                     emit(0, l, rr_, (uint32_t)(ins + occ));
                     total += rr_ - l + 1u;
-                    state = ST_RESUME;                                       // the parked record is written first; pop next iteration
-                    return;
                 }
-                needPop = true;
+                needPop = true;                                              // the DFS goes on in the same trip
                 continue;
             }
             const S3Step st = stepAt(s);
@@ -404,7 +403,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             if (doSettle && !needPop) { g = gc; i++; }
         }
-        if (state == ST_RESUME && !(pendMeta >> 31)) { doSettle = true; needPop = true; }
+        if (state == ST_RESUME) { doSettle = true; needPop = false; }          // the completed frame that had to wait: emit it now, then pop
         if (state == ST_LOAD) {
             uint32_t *dst = ro + (size_t)loadOff * 64u + lane;
             const uint32_t left = 2u * wpq - loadOff;
@@ -475,7 +474,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 candidateDone = true;
             }
             if (candidateDone) {
-                if (total >= in.maxOut || ceQ >= ceQEnd) state = ST_RESUME;                // check-and-extend of this range is finished
+                if (total >= in.maxOut || ceQ >= ceQEnd) { doSettle = true; needPop = true; }   // check-and-extend of this range is finished: pop in this trip
                 else { ceQ++; state = ST_CESA; }
             }
         }
