@@ -161,6 +161,26 @@ typedef struct { uint32_t readID, algnmt; int32_t score; uint32_t editdist, num_
 int  s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3_seed_candidate *candidates, size_t nCandidates, int cutoffThreshold,
                       int softClipLeft, int softClipRight, s3_dp_single_result **results, size_t *nResults, char **cigarPool);
 
+/* ---- deep DP for pairs whose ends both failed the BWT stage --------------------------------------------------------------------
+ * Replaces DeepDP_Space (DV-DPfunctions.cu:2552-3900; driver DV-DPForBothUnalign.cu): seeds of both ends (PairEndSeedingBatch), their hits
+ * sorted per end and strand (decodePositions), '+' hits of one end paired with '-' hits of the other inside the insert window
+ * (pairEndMerge: left run compressed by 50, window [insertLow - L - margin, insertHigh - L + margin]), the left end aligned first, the right
+ * end's window cut by the left hit and the insert bounds (PairEndAlgnBatch::packLeft / packRight), results where both scores pass their
+ * cutoffs (DP2CPUAlgnThread).  pairFirstReads: index of the first read (even) of every pair to process, ascending.  stage =
+ * S3_STAGE_DEEP_DP_ROUND1 / ROUND2.  tooManyHits (optional, one byte per input pair): a seed of the pair was dropped for too many hits.
+ * Arrays are malloc'ed: release with s3_free.  PARITY UNPINNED. */
+typedef struct {
+    uint32_t readID;                 /* first read of the pair */
+    uint32_t algnmt_1, algnmt_2;
+    int32_t  score_1, score_2;
+    uint32_t editdist_1, editdist_2, insertSize, num_sameScore_1, num_sameScore_2;
+    uint32_t cigarOffset_1, cigarOffset_2;
+    uint8_t  strand_1, strand_2, pad[2];
+} s3_dp_deep_result;
+int  s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *pairFirstReads, size_t nPairs, int stage,
+                uint32_t maxHitNum, int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight,
+                s3_dp_deep_result **results, size_t *nResults, char **cigarPool, uint8_t **tooManyHits);
+
 /* ---- parameters of the DP stages (host-side integer rules) ------------------------------------------------------------------
  * s3_dp_stage_parameters replaces getParameterForSingleDP / DefaultDP / NewDefaultDP / DeepDP and getMaxHitNumForDefaultDP
  * (CPUfunctions.cpp:36-260) for one read length; s3_seed_positions replaces getSeedPositions (definitions.h:323-442): the seed length,

@@ -1,5 +1,6 @@
 // s3dp_dpapi.hip -- the semi-global DP part of the C-ABI: the aligner object (s3_dp_*) and the engines around the kernel for half-aligned
 // pairs and single reads (window geometry, on-device packing, traceback decode).  Kernels: s3dp_dp.hip.
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 #include "s3dp_internal.h"
 
@@ -447,6 +448,246 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
     if (!out || !cp) { free(out); free(cp); return fail(S3_ENOMEM, "s3_dp_single_end: out of host memory"); }
     memcpy(out, results.data(), results.size() * sizeof(s3_dp_single_result));
     memcpy(cp, pool.data(), pool.size());
+    *resultsOut = out; *nResultsOut = results.size(); *cigarPoolOut = cp;
+    return S3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deep DP for pairs whose ends both failed the BWT stage.  Replaces, of the reference's DeepDP_Space (DV-DPfunctions.cu:2552-3900):
+//   PairEndSeedingBatch::packSeeds :2681-2705          seeds of both ends of a pair (tables: s3_seed_positions)
+//   decodePositions :2885-2958, findRevStart :2626     per end: estimated positions sorted by (strand, pair, position)
+//   pairEndMerge :2780-2883                            '+' positions of one end against '-' positions of the other inside the insert window
+//   decodeMergePositions :2960-2990                    both orientations, candidates ordered by the left read
+//   PairEndAlgnBatch::packLeft / packRight :3374-3472  left end first; the right end's window is cut by the left hit and the insert bounds
+//   DP2CPUAlgnThread :3731-3828                        both scores above their cutoffs -> CIGARs, edit distances, insert size
+// Seeds and DP run on the device (the seed batch is a second s3_batch); the sequential merge runs on the host.  PARITY UNPINNED.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct PairCand { uint32_t pos[2]; uint32_t readIDLeft; };
+}
+
+extern "C" int s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *pairFirstReads, size_t nPairs, int stage,
+                          uint32_t maxHitNum, int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight,
+                          s3_dp_deep_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut, uint8_t **tooManyHitsOut)
+{
+    if (!h || !b || !seedBatch || !readLengths || (!pairFirstReads && nPairs) || !cutoffThreshold || !resultsOut || !nResultsOut || !cigarPoolOut)
+        return fail(S3_EINVAL, "s3_dp_deep: null argument");
+    if (b->ix != seedBatch->ix || b == seedBatch || h->dev != b->ix->dev) return fail(S3_EINVAL, "s3_dp_deep: batches / aligner do not belong together");
+    const int leftLeg = 1, rightLeg = 2;
+    // ---- seeds of both ends; key = end << 31 | strand << 30 | first read of the pair (30 bits), then the estimated position --------------
+    std::vector<SeedDesc> seeds;
+    for (size_t k = 0; k < nPairs; k++) {
+        const uint32_t even = pairFirstReads[k];
+        if ((even & 1u) || even + 1 >= b->n) return fail(S3_EINVAL, "s3_dp_deep: bad pair index");
+        if (even >= (1u << 30)) return fail(S3_EINVAL, "s3_dp_deep: read index too large");
+        for (uint32_t e = 0; e < 2; e++) {
+            const uint32_t r = even + e;
+            int seedLength = 0, num = 0, pos[128];
+            if (s3_seed_positions(stage, (int)readLengths[r], &seedLength, pos, &num) != S3_OK) return fail(S3_EINVAL, "s3_dp_deep: bad stage");
+            for (int i = 0; i < num; i++) {
+                if (pos[i] < 0 || seedLength < 16 || (uint32_t)(pos[i] + seedLength) > readLengths[r]) continue;
+                seeds.push_back(SeedDesc{r, (uint32_t)pos[i], (uint32_t)seedLength, e << 31 | even});
+            }
+        }
+    }
+    std::vector<uint64_t> keys;
+    std::vector<uint8_t> status;
+    int rc = seedSearchKeys(b, seedBatch, seeds, maxHitNum, 30, keys, status);
+    if (rc) return rc;
+    // a pair with a seed dropped for too many hits is flagged (tooManyHitFlags, :2940-2944)
+    std::vector<uint8_t> tooMany(nPairs, 0);
+    if (tooManyHitsOut) {
+        size_t j = 0;
+        for (size_t k = 0; k < nPairs; k++)
+            for (; j < seeds.size() && (seeds[j].keyHi & 0x3FFFFFFFu) == pairFirstReads[k]; j++) if (status[j] == 4) tooMany[k] = 1;
+    }
+    // four sorted runs: [end][strand], entries = (pair's first read, position)
+    struct Pos { uint32_t id, pos; };
+    std::vector<Pos> arr[2][2];
+    for (uint64_t key : keys) {
+        const uint32_t hi = (uint32_t)(key >> 32);
+        arr[hi >> 31][(hi >> 30) & 1u].push_back(Pos{hi & 0x3FFFFFFFu, (uint32_t)key});
+    }
+    // ---- pairEndMerge: left = '+' hits of one end (compressed by DP2_DIVIDE_GAP), right = '-' hits of the other end --------------------
+    std::vector<PairCand> cands;
+    auto merge = [&](std::vector<Pos> &left, const std::vector<Pos> &right, uint32_t leftIsMate) {
+        size_t li = 0, ri = 0;
+        while (li < left.size() && ri < right.size()) {
+            if (left[li].id < right[ri].id) { li++; continue; }
+            if (right[ri].id < left[li].id) { ri++; continue; }
+            const uint32_t id = left[li].id;
+            size_t le = li, re = ri;
+            while (le < left.size() && left[le].id == id) le++;
+            while (re < right.size() && right[re].id == id) re++;
+            // MC_Compress on the left run
+            size_t w = li;
+            uint32_t prev = left[li].pos;
+            for (size_t p = li + 1; p < le; p++) if (prev + 50u < left[p].pos) { left[++w] = left[p]; prev = left[p].pos; }
+            const size_t lend = w + 1;
+            const int readLength = (int)readLengths[id];                            // readLengths[readID] with the pair's first read, as the reference
+            const int margin = readLength > 100 ? readLength >> 2 : 25;            // DP2_MARGIN
+            int lengthLow = insertLow - readLength - margin;
+            if (lengthLow < 0) lengthLow = 0;
+            const int lengthHigh = insertHigh - readLength + margin;
+            size_t lp = li, rp = ri;
+            while (lp < lend && rp < re) {
+                const uint32_t readLoc = left[lp].pos, mateLoc = right[rp].pos;
+                if (readLoc + (uint32_t)lengthLow > mateLoc) rp++;
+                else if (readLoc + (uint32_t)lengthHigh < mateLoc) lp++;
+                else { cands.push_back(PairCand{{readLoc, mateLoc}, id + leftIsMate}); lp++; }
+            }
+            li = le; ri = re;
+        }
+    };
+    merge(arr[0][leftLeg - 1], arr[1][rightLeg - 1], 0);                            // read left, mate right
+    merge(arr[1][leftLeg - 1], arr[0][rightLeg - 1], 1);                            // mate left, read right
+    std::stable_sort(cands.begin(), cands.end(), [](const PairCand &x, const PairCand &y) { return x.readIDLeft < y.readIDLeft; });
+    // ---- two DP rounds per batch of candidates ---------------------------------------------------------------------------------------
+    HIPCHK(hipSetDevice(h->dev));
+    const uint32_t fullDNALength = b->ix->d.n;
+    const uint32_t wordsPerDNA = (h->maxDNA + 15) / 16, wordsPerRead = (h->maxRead + 15) / 16;
+    std::vector<s3_dp_deep_result> results;
+    std::string pool;
+    DpCand *dCand = nullptr;
+    {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64);
+        if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp candidates): ") + hipGetErrorString(e));
+        dCand = (DpCand *)q;
+    }
+#define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipFree(dCand); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    struct Round { std::vector<int32_t> scores; std::vector<uint32_t> hit, cnt; std::vector<uint8_t> pat; };
+    auto runRound = [&](const std::vector<DpCand> &cand, const std::vector<uint32_t> &dnaLens, const std::vector<uint32_t> &rdLens, const std::vector<int32_t> &cut,
+                        const std::vector<uint32_t> &clipLt, const std::vector<uint32_t> &clipRt, const std::vector<uint32_t> &aL, const std::vector<uint32_t> &aR,
+                        Round &R) -> int {
+        const uint32_t n = (uint32_t)cand.size();
+        hipStream_t s = h->stream;
+        ECHK(hipMemcpyAsync(dCand, cand.data(), (size_t)n * sizeof(DpCand), hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dDnaLen, dnaLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dReadLen, rdLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dCut, cut.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dClipLt, clipLt.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dClipRt, clipRt.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dAL, aL.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        ECHK(hipMemcpyAsync(h->dAR, aR.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        const uint64_t threads = (uint64_t)n * (wordsPerDNA + wordsPerRead);
+        hipLaunchKernelGGL(dpPackKernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, n, dCand, b->ix->d.pac, b->dQueries, b->wpq, b->dLens,
+                           wordsPerDNA, wordsPerRead, h->dDna, h->dReads);
+        int rc2 = dpRun(h, n, true, true, true, true);
+        if (rc2) return rc2;
+        R.scores.resize(n); R.hit.resize(n); R.cnt.resize(n); R.pat.resize((size_t)n * h->patternLen);
+        ECHK(hipMemcpyAsync(R.scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        ECHK(hipMemcpyAsync(R.hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        ECHK(hipMemcpyAsync(R.cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        ECHK(hipMemcpyAsync(R.pat.data(), h->dPattern, R.pat.size(), hipMemcpyDeviceToHost, s));
+        ECHK(hipStreamSynchronize(s));
+        return S3_OK;
+    };
+    auto window = [&](uint32_t pos, uint32_t readLength, uint32_t &start, uint32_t &len) {
+        const uint32_t margin = readLength > 100 ? readLength >> 2 : 25;
+        start = pos - margin;
+        if (start >= fullDNALength) start = 0;
+        len = readLength + margin * 2;
+        if (start + len > fullDNALength) len = fullDNALength - start;
+    };
+    for (size_t base = 0; base < cands.size() && rc == S3_OK; base += h->maxProblems) {
+        const uint32_t n = (uint32_t)(cands.size() - base < h->maxProblems ? cands.size() - base : h->maxProblems);
+        // left ends (packLeft): no anchors
+        std::vector<DpCand> cand(n);
+        std::vector<uint32_t> dnaLens(n), rdLens(n), clipLt(n), clipRt(n), aL(n, h->maxDNA), aR(n, 0), startL(n);
+        std::vector<int32_t> cut(n);
+        for (uint32_t i = 0; i < n && rc == S3_OK; i++) {
+            const PairCand &c = cands[base + i];
+            const uint32_t L = readLengths[c.readIDLeft];
+            uint32_t st, len;
+            window(c.pos[0], L, st, len);
+            if (L > h->maxRead || len > h->maxDNA) { rc = fail(S3_EINVAL, "s3_dp_deep: the aligner is too small for this read"); break; }
+            cand[i] = DpCand{c.readIDLeft, (uint32_t)leftLeg, st, len};
+            dnaLens[i] = len; rdLens[i] = L; startL[i] = st;
+            cut[i] = cutoffThreshold[c.readIDLeft & 1u];
+            clipLt[i] = leftLeg == 1 ? (uint32_t)softClipLeft : (uint32_t)softClipRight;
+            clipRt[i] = leftLeg == 1 ? (uint32_t)softClipRight : (uint32_t)softClipLeft;
+        }
+        if (rc) break;
+        Round RL, RR;
+        if ((rc = runRound(cand, dnaLens, rdLens, cut, clipLt, clipRt, aL, aR, RL))) break;
+        // right ends (packRight) of the candidates whose left end passed; the others are not aligned again
+        std::vector<uint32_t> sel;
+        for (uint32_t i = 0; i < n; i++) if (RL.scores[i] >= cutoffThreshold[cands[base + i].readIDLeft & 1u]) sel.push_back(i);
+        const uint32_t m = (uint32_t)sel.size();
+        std::vector<DpCand> candR(m);
+        std::vector<uint32_t> dnaR(m), rdR(m), clipLtR(m), clipRtR(m), aLR(m, h->maxDNA), aRR(m), startR(m);
+        std::vector<int32_t> cutR(m);
+        for (uint32_t k = 0; k < m && rc == S3_OK; k++) {
+            const uint32_t i = sel[k];
+            const PairCand &c = cands[base + i];
+            const uint32_t leftIsOdd = c.readIDLeft & 1u, right = leftIsOdd ? c.readIDLeft - 1 : c.readIDLeft + 1;
+            const uint32_t L = readLengths[right];
+            uint32_t st, len;
+            window(c.pos[1], L, st, len);
+            const uint32_t hitPosLeft = startL[i] + RL.hit[i];
+            const uint32_t bounded = hitPosLeft + (uint32_t)insertHigh - st;            // restrict the maximum insert size
+            if (bounded < len) len = bounded;
+            const int rightAnchor = (int)(hitPosLeft + (uint32_t)insertLow - st);      // restrict the minimum insert size
+            if (L > h->maxRead || len > h->maxDNA || len == 0) { rc = fail(S3_EINVAL, "s3_dp_deep: right window out of range for the aligner"); break; }
+            candR[k] = DpCand{right, (uint32_t)rightLeg, st, len};
+            dnaR[k] = len; rdR[k] = L; startR[k] = st; aRR[k] = rightAnchor > 0 ? (uint32_t)rightAnchor : 0u;
+            cutR[k] = cutoffThreshold[right & 1u];
+            clipLtR[k] = rightLeg == 1 ? (uint32_t)softClipLeft : (uint32_t)softClipRight;
+            clipRtR[k] = rightLeg == 1 ? (uint32_t)softClipRight : (uint32_t)softClipLeft;
+        }
+        if (rc) break;
+        if (m && (rc = runRound(candR, dnaR, rdR, cutR, clipLtR, clipRtR, aLR, aRR, RR))) break;
+        // DP2CPUAlgnThread: both ends above their cutoffs
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t i = sel[k];
+            const PairCand &c = cands[base + i];
+            const int readSide = (int)(c.readIDLeft & 1u), mateSide = 1 - readSide;
+            if (RR.scores[k] < cutoffThreshold[mateSide]) continue;
+            // index 0 = left end, 1 = right end.  Both edit distances use the RIGHT end's length (batch->lengths[] after packRight), as the reference
+            const Round *rd[2] = {&RL, &RR};
+            const uint32_t idx[2] = {i, k};
+            std::string cig[2];
+            int editdist[2], DIS[2];
+            for (int lOr = 0; lOr < 2; lOr++) {
+                CigarEnc enc;
+                char last = 'N';
+                for (const uint8_t *p = rd[lOr]->pat.data() + (size_t)idx[lOr] * h->patternLen; *p != 0; p++) {
+                    if (*p == 'V') enc.append(last, (int)*(++p) - 1);
+                    else { enc.append((char)*p, 1); last = (char)*p; }
+                }
+                enc.encode(h->sc.gapOpenScore, h->sc.gapExtendScore);
+                cig[lOr] = enc.text;
+                const int L = (int)rdR[k] - enc.count['I'] - enc.count['S'];
+                const int numMis = (L * h->sc.matchScore + enc.gapPenalty - rd[lOr]->scores[idx[lOr]]) / (h->sc.matchScore - h->sc.mismatchScore);
+                editdist[lOr] = enc.count['I'] + enc.count['D'] + numMis;
+                DIS[lOr] = enc.count['D'] - enc.count['I'] - enc.count['S'];
+            }
+            const uint32_t posOf[2] = {startL[i] + RL.hit[i], startR[k] + RR.hit[k]};
+            s3_dp_deep_result r{};
+            r.readID = c.readIDLeft - (uint32_t)readSide;
+            r.strand_1 = (uint8_t)(readSide == 0 ? leftLeg : rightLeg);
+            r.strand_2 = (uint8_t)(mateSide == 0 ? leftLeg : rightLeg);
+            r.algnmt_1 = posOf[readSide]; r.algnmt_2 = posOf[mateSide];
+            r.score_1 = rd[readSide]->scores[idx[readSide]]; r.score_2 = rd[mateSide]->scores[idx[mateSide]];
+            r.editdist_1 = (uint32_t)editdist[readSide]; r.editdist_2 = (uint32_t)editdist[mateSide];
+            r.insertSize = r.algnmt_1 < r.algnmt_2 ? r.algnmt_2 - r.algnmt_1 + rdR[k] + (uint32_t)DIS[mateSide] : r.algnmt_1 - r.algnmt_2 + rdR[k] + (uint32_t)DIS[readSide];
+            r.num_sameScore_1 = rd[readSide]->cnt[idx[readSide]]; r.num_sameScore_2 = rd[mateSide]->cnt[idx[mateSide]];
+            r.cigarOffset_1 = (uint32_t)pool.size(); pool += cig[readSide]; pool.push_back('\0');
+            r.cigarOffset_2 = (uint32_t)pool.size(); pool += cig[mateSide]; pool.push_back('\0');
+            results.push_back(r);
+        }
+    }
+#undef ECHK
+    (void)hipFree(dCand);
+    if (rc) return rc;
+    s3_dp_deep_result *out = (s3_dp_deep_result *)malloc(results.size() * sizeof(s3_dp_deep_result) + 1);
+    char *cp = (char *)malloc(pool.size() + 1);
+    uint8_t *tm = tooManyHitsOut ? (uint8_t *)malloc(nPairs + 1) : nullptr;
+    if (!out || !cp || (tooManyHitsOut && !tm)) { free(out); free(cp); free(tm); return fail(S3_ENOMEM, "s3_dp_deep: out of host memory"); }
+    memcpy(out, results.data(), results.size() * sizeof(s3_dp_deep_result));
+    memcpy(cp, pool.data(), pool.size());
+    if (tm) { memcpy(tm, tooMany.data(), nPairs); *tooManyHitsOut = tm; }
     *resultsOut = out; *nResultsOut = results.size(); *cigarPoolOut = cp;
     return S3_OK;
 }

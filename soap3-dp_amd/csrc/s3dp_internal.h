@@ -138,6 +138,10 @@ struct LongArgs { bool on; int onlyBest, minSeedMis, needMapq; uint32_t maxHit; 
 int decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive, uint8_t want, uint8_t phase, uint32_t maxOut, uint8_t selectWhen, const LongArgs &lg);
 void launchIota(uint32_t *p, uint32_t n, hipStream_t s);
 void launchStateAll(uint32_t n, const uint32_t *totalOcc, uint8_t *state, hipStream_t s);
+// seeding (s3dp_seed.hip)
+struct SeedDesc { uint32_t readId, off, len, keyHi; };   // seed of read `readId` at `off`; keyHi = the upper key bits its hits sort by
+int seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<SeedDesc> &seeds, uint32_t maxHitNum, uint32_t strandBit,
+                   std::vector<uint64_t> &keysSorted, std::vector<uint8_t> &seedStatus);
 // DP (s3dp_dpapi.hip): launch the DP kernels on what is in the aligner's device buffers
 int dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR);
 }  // namespace s3i

@@ -15,7 +15,6 @@ using namespace s3i;
 // DPS_DIVIDE_GAP = 50 collapse into the first).  Everything runs on the device next to the resident reads; the seed batch is an
 // ordinary s3_batch.  PARITY UNPINNED (host code inside CUDA sources); tested against a restatement built on the pinned search oracle.
 // ---------------------------------------------------------------------------------------------
-struct SeedDesc { uint32_t readId, off, len; };
 
 __global__ void seedPackKernel(uint32_t nSeeds, const SeedDesc *seeds, const uint32_t *queries, uint32_t wpq, uint32_t *seedQueries, uint32_t seedWpq,
                                uint32_t *seedLens)
@@ -51,7 +50,7 @@ __global__ void seedClassifyKernel(uint32_t n, const uint32_t *active, const uin
 // estimated read position of every seed hit (MC_EstimatedPos, DV-DPfunctions.cu:1163): '+': pos - offset, '-': pos + seedLen + offset - readLen;
 // key = strand << 63 | readID << 32 | position, the order decodePositions sorts into
 __global__ void seedKeysKernel(uint32_t nSeeds, const SeedDesc *seeds, const uint32_t *readLens, const uint32_t *occStart, const uint32_t *occCount,
-                               const uint32_t *outOffsets, const uint32_t *occPos, const uint32_t *occMeta, uint64_t *keys)
+                               const uint32_t *outOffsets, const uint32_t *occPos, const uint32_t *occMeta, uint32_t strandBit, uint64_t *keys)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nSeeds) return;
@@ -60,47 +59,22 @@ __global__ void seedKeysKernel(uint32_t nSeeds, const SeedDesc *seeds, const uin
     for (uint32_t k = 0; k < cnt; k++) {
         const uint32_t pos = occPos[src + k], strand = occMeta[src + k] & 0xFFu;
         const uint32_t est = strand == 1u ? pos - d.off : pos + d.len + d.off - readLen;
-        keys[dst + k] = (uint64_t)(strand == 2u) << 63 | (uint64_t)d.readId << 32 | est;
+        keys[dst + k] = (uint64_t)(d.keyHi | (strand == 2u ? 1u << strandBit : 0u)) << 32 | est;
     }
 }
 
-// singleMerge: within one (strand, read) run the first position is kept, then every position more than 50 beyond the last kept one
-__global__ void seedMergeFlagKernel(uint64_t n, const uint64_t *keys, uint8_t *keep)
+// Search the seeds and return their hits as sorted 64-bit keys: (keyHi | strand bit) << 32 | estimated read position.
+int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<SeedDesc> &seeds, uint32_t maxHitNum, uint32_t strandBit,
+                        std::vector<uint64_t> &keysOut, std::vector<uint8_t> &statusOut)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t me = keys[i];
-    if (i > 0 && (keys[i - 1] >> 32) == (me >> 32)) return;             // not the start of a run: the run's first thread walks it
-    uint32_t prev = (uint32_t)me;
-    keep[i] = 1;
-    for (uint64_t k = i + 1; k < n && (keys[k] >> 32) == (me >> 32); k++) {
-        const uint32_t cur = (uint32_t)keys[k];
-        if ((uint64_t)prev + 50u < cur) { keep[k] = 1; prev = cur; } else keep[k] = 0;
-    }
-}
-
-extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, int stage, uint32_t maxHitNum,
-                                  s3_seed_candidate **candOut, size_t *nCandOut, uint8_t **seedStatusOut, size_t *nSeedsOut)
-{
-    if (!reads || !seedBatch || !readLengths || !candOut || !nCandOut) return fail(S3_EINVAL, "s3_seed_candidates: null argument");
-    if (reads->ix != seedBatch->ix || reads == seedBatch) return fail(S3_EINVAL, "s3_seed_candidates: the seed batch must be a second batch on the same index");
     HIPCHK(hipSetDevice(reads->ix->dev));
-    std::vector<SeedDesc> seeds;
-    for (uint32_t r = 0; r < reads->n; r++) {
-        int seedLength = 0, num = 0, pos[128];
-        if (s3_seed_positions(stage, (int)readLengths[r], &seedLength, pos, &num) != S3_OK) return fail(S3_EINVAL, "s3_seed_candidates: bad stage");
-        for (int i = 0; i < num; i++) {
-            if (pos[i] < 0 || seedLength < 16 || (uint32_t)(pos[i] + seedLength) > readLengths[r]) continue;   // reads too short for the stage's seeds
-            seeds.push_back(SeedDesc{r, (uint32_t)pos[i], (uint32_t)seedLength});
-        }
-    }
     const uint32_t nSeeds = (uint32_t)seeds.size();
     if (nSeeds > seedBatch->maxReads) return fail(S3_EINVAL, "s3_seed_candidates: seed batch too small");
     if (seedBatch->wpq * 16u < 70u) return fail(S3_EINVAL, "s3_seed_candidates: the seed batch needs wordPerQuery >= 8");
     s3_batch *b = seedBatch;
     hipStream_t st = b->stream;
     SeedDesc *dSeeds = nullptr;
-    uint8_t *dRetry = nullptr, *dStatus = nullptr, *dKeep = nullptr;
+    uint8_t *dRetry = nullptr, *dStatus = nullptr;
     uint64_t *dKeys = nullptr, *dKeysOut = nullptr;
     char *dSortTmp = nullptr;
     std::vector<void *> tmp;
@@ -156,31 +130,59 @@ extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const ui
     uint32_t total = 0;
     SCHK(hipMemcpyAsync(&total, b->dOutOffsets + nSeeds, 4, hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
-    std::vector<s3_seed_candidate> out;
+    keysOut.clear();
     if (total) {
         size_t sortBytes = 0;
         SCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, sortBytes, dKeys, dKeysOut, (int)total, 0, 64, st));
-        if ((rc = talloc((void **)&dKeys, (size_t)total * 8)) || (rc = talloc((void **)&dKeysOut, (size_t)total * 8)) || (rc = talloc((void **)&dKeep, total)) ||
+        if ((rc = talloc((void **)&dKeys, (size_t)total * 8)) || (rc = talloc((void **)&dKeysOut, (size_t)total * 8))||
             (rc = talloc((void **)&dSortTmp, sortBytes))) { cleanup(); return rc; }
         hipLaunchKernelGGL(seedKeysKernel, dim3((nSeeds + 255) / 256), dim3(256), 0, st, nSeeds, dSeeds, reads->dLens, b->dOccStart, b->dOccCount, b->dOutOffsets,
-                           b->dOccPos, b->dOccMeta, dKeys);
+                           b->dOccPos, b->dOccMeta, strandBit, dKeys);
         SCHK(hipcub::DeviceRadixSort::SortKeys(dSortTmp, sortBytes, dKeys, dKeysOut, (int)total, 0, 64, st));
-        SCHK(hipMemsetAsync(dKeep, 0, total, st));
-        hipLaunchKernelGGL(seedMergeFlagKernel, dim3((total + 255) / 256), dim3(256), 0, st, (uint64_t)total, dKeysOut, dKeep);
-        std::vector<uint64_t> keys(total);
-        std::vector<uint8_t> keep(total);
-        SCHK(hipMemcpyAsync(keys.data(), dKeysOut, (size_t)total * 8, hipMemcpyDeviceToHost, st));
-        SCHK(hipMemcpyAsync(keep.data(), dKeep, total, hipMemcpyDeviceToHost, st));
+        keysOut.resize(total);
+        SCHK(hipMemcpyAsync(keysOut.data(), dKeysOut, (size_t)total * 8, hipMemcpyDeviceToHost, st));
         SCHK(hipStreamSynchronize(st));
-        for (uint32_t i = 0; i < total; i++)
-            if (keep[i]) out.push_back(s3_seed_candidate{(uint32_t)((keys[i] >> 32) & 0x7FFFFFFFu), (uint32_t)keys[i], (uint8_t)((keys[i] >> 63) ? 2 : 1), {0, 0, 0}});
     }
-    std::vector<uint8_t> status(nSeeds);
-    if (nSeeds) SCHK(hipMemcpy(status.data(), dStatus, nSeeds, hipMemcpyDeviceToHost));
+    statusOut.resize(nSeeds);
+    if (nSeeds) SCHK(hipMemcpy(statusOut.data(), dStatus, nSeeds, hipMemcpyDeviceToHost));
 #undef SCHK
     cleanup();
-    rc = checkFlags(b);
+    return checkFlags(b);
+}
+
+extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, int stage, uint32_t maxHitNum,
+                                  s3_seed_candidate **candOut, size_t *nCandOut, uint8_t **seedStatusOut, size_t *nSeedsOut)
+{
+    if (!reads || !seedBatch || !readLengths || !candOut || !nCandOut) return fail(S3_EINVAL, "s3_seed_candidates: null argument");
+    if (reads->ix != seedBatch->ix || reads == seedBatch) return fail(S3_EINVAL, "s3_seed_candidates: the seed batch must be a second batch on the same index");
+    std::vector<SeedDesc> seeds;
+    for (uint32_t r = 0; r < reads->n; r++) {
+        int seedLength = 0, num = 0, pos[128];
+        if (s3_seed_positions(stage, (int)readLengths[r], &seedLength, pos, &num) != S3_OK) return fail(S3_EINVAL, "s3_seed_candidates: bad stage");
+        for (int i = 0; i < num; i++) {
+            if (pos[i] < 0 || seedLength < 16 || (uint32_t)(pos[i] + seedLength) > readLengths[r]) continue;   // reads too short for the stage's seeds
+            seeds.push_back(SeedDesc{r, (uint32_t)pos[i], (uint32_t)seedLength, r});
+        }
+    }
+    std::vector<uint64_t> keys;
+    std::vector<uint8_t> status;
+    int rc = seedSearchKeys(reads, seedBatch, seeds, maxHitNum, 31, keys, status);
     if (rc) return rc;
+    // singleMerge (DV-DPfunctions.cu:1102-1141): within one (strand, read) run the first position is kept, then every position more than
+    // DPS_DIVIDE_GAP = 50 beyond the last kept one
+    std::vector<s3_seed_candidate> out;
+    for (size_t i = 0; i < keys.size();) {
+        const uint64_t run = keys[i] >> 32;
+        uint32_t prev = (uint32_t)keys[i];
+        out.push_back(s3_seed_candidate{(uint32_t)(run & 0x7FFFFFFFu), prev, (uint8_t)((run >> 31) ? 2 : 1), {0, 0, 0}});
+        size_t k = i + 1;
+        for (; k < keys.size() && (keys[k] >> 32) == run; k++) {
+            const uint32_t cur = (uint32_t)keys[k];
+            if ((uint64_t)prev + 50u < cur) { out.push_back(s3_seed_candidate{(uint32_t)(run & 0x7FFFFFFFu), cur, (uint8_t)((run >> 31) ? 2 : 1), {0, 0, 0}}); prev = cur; }
+        }
+        i = k;
+    }
+    const size_t nSeeds = status.size();
     s3_seed_candidate *c = (s3_seed_candidate *)malloc(out.size() * sizeof(s3_seed_candidate) + 1);
     if (!c) return fail(S3_ENOMEM, "s3_seed_candidates: out of host memory");
     memcpy(c, out.data(), out.size() * sizeof(s3_seed_candidate));
@@ -194,4 +196,3 @@ extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const ui
     if (nSeedsOut) *nSeedsOut = nSeeds;
     return S3_OK;
 }
-

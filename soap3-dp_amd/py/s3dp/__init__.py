@@ -35,7 +35,7 @@ class Counters(C.Structure):
 
 
 EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
-           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_dp_single_end", "s3_batch_fetch_alignments", "s3_batch_sync",
+           "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_dp_single_end", "s3_dp_deep", "s3_batch_fetch_alignments", "s3_batch_sync",
            "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather"]
 
@@ -384,6 +384,9 @@ HALF_RESULT_DTYPE = np.dtype([("readID", "<u4"), ("algnmt_1", "<u4"), ("algnmt_2
                               ("strand_2", "u1"), ("whichFromDP", "u1"), ("pad", "u1"), ("editdist", "<u4"), ("insertSize", "<u4"),
                               ("num_sameScore", "<u4"), ("cigarOffset", "<u4")])                                                 # s3_dp_half_result
 
+DEEP_RESULT_DTYPE = np.dtype([("readID", "<u4"), ("algnmt_1", "<u4"), ("algnmt_2", "<u4"), ("score_1", "<i4"), ("score_2", "<i4"), ("editdist_1", "<u4"),
+                              ("editdist_2", "<u4"), ("insertSize", "<u4"), ("num_sameScore_1", "<u4"), ("num_sameScore_2", "<u4"), ("cigarOffset_1", "<u4"),
+                              ("cigarOffset_2", "<u4"), ("strand_1", "u1"), ("strand_2", "u1"), ("pad", "u1", 2)])                          # s3_dp_deep_result
 SINGLE_RESULT_DTYPE = np.dtype([("readID", "<u4"), ("algnmt", "<u4"), ("score", "<i4"), ("editdist", "<u4"), ("num_sameScore", "<u4"),
                                 ("cigarOffset", "<u4"), ("strand", "u1"), ("pad", "u1", 3)])                                             # s3_dp_single_result
 SEED_CAND_DTYPE = np.dtype([("readID", "<u4"), ("pos", "<u4"), ("strand", "u1"), ("pad", "u1", 3)])                                    # s3_seed_candidate
@@ -517,6 +520,26 @@ class DpAligner:
         free(res)
         free(pool)
         return out, cigars
+
+    def deep(self, batch, seed_batch, read_lengths, pair_first_reads, stage, max_hit_num, insert_low, insert_high, cutoffs, clip_left, clip_right):
+        """deep DP of pairs whose ends both failed the BWT stage; returns (results DEEP_RESULT_DTYPE, [(cigar1, cigar2)], tooManyHits flags)"""
+        read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
+        ids = np.ascontiguousarray(pair_first_reads, dtype=np.uint32)
+        f = lib().s3_dp_deep
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        cut = (C.c_int * 2)(*cutoffs)
+        res, n, pool, tm = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_void_p()
+        _chk(f(self.h, batch.h, seed_batch.h, read_lengths.ctypes.data, ids.ctypes.data, len(ids), stage, max_hit_num, insert_low, insert_high, cut, clip_left,
+               clip_right, C.byref(res), C.byref(n), C.byref(pool), C.byref(tm)))
+        out = np.frombuffer(C.string_at(res, n.value * DEEP_RESULT_DTYPE.itemsize), dtype=DEEP_RESULT_DTYPE).copy() if n.value else np.zeros(0, DEEP_RESULT_DTYPE)
+        cigars = [(C.string_at(pool.value + int(r["cigarOffset_1"])).decode(), C.string_at(pool.value + int(r["cigarOffset_2"])).decode()) for r in out]
+        too_many = np.frombuffer(C.string_at(tm, len(ids)), dtype=np.uint8).copy() if len(ids) else np.zeros(0, np.uint8)
+        free = lib().s3_free
+        free.argtypes = [C.c_void_p]
+        for x in (res, pool, tm):
+            free(x)
+        return out, cigars, too_many
 
     def single_end(self, batch, read_lengths, candidates, cutoff, clip_left, clip_right):
         """DP of single reads at their seeding candidates (SEED_CAND_DTYPE); returns (results SINGLE_RESULT_DTYPE, cigars)"""

@@ -166,3 +166,73 @@ def test_single_end_dp_pipeline_recovers_damaged_reads():
     dp.close()
     b.close()
     sb.close()
+
+
+@pytest.mark.parametrize("stage,max_hit", [(4, 100), (5, 1000)])
+def test_deep_dp_recovers_pairs_whose_ends_both_fail_the_bwt_stage(stage, max_hit):
+    """paired seeding -> pair candidates inside the insert window -> left DP -> right DP bounded by the left hit: both ends damaged
+    (6 substitutions or an indel each), both orientations of the pair"""
+    from test_gpu_dp_half_end import apply_cigar
+    rng = np.random.default_rng(23 + stage)
+    n = 80000
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    hi = builder.build_host_index(codes, device="cpu")
+    ix = s3dp.Index(hi)
+    L = 100
+
+    def damage(seg_start, kind):
+        if kind == 0:
+            s = codes[seg_start:seg_start + L].copy()
+            for q in rng.choice(np.arange(3, L - 3), size=6, replace=False):
+                s[q] = (s[q] + 1 + rng.integers(0, 3)) % 4
+            return s, seg_start, (L - 6) - 12, 6
+        if kind == 1:
+            c = int(rng.integers(35, 65))
+            return np.concatenate([codes[seg_start:seg_start + c], codes[seg_start + c + 3:seg_start + L + 3]]), seg_start, L - 5, 3
+        c = int(rng.integers(35, 65))
+        s = np.concatenate([codes[seg_start:seg_start + c], (codes[seg_start + c:seg_start + c + 2] + 2) % 4, codes[seg_start + c:seg_start + L - 2]])
+        return s, seg_start, (L - 2) - 4, 2
+
+    reads, truth = [], []
+    for p in range(90):
+        ins = int(rng.integers(260, 470))
+        st = int(rng.integers(500, n - 1500))
+        a, a_pos, a_score, a_ed = damage(st, p % 3)
+        b, b_pos, b_score, b_ed = damage(st + ins - L, (p + 1) % 3)
+        first, second = (a, COMP[b[::-1]]) if p % 2 == 0 else (COMP[b[::-1]], a)
+        reads += [bytes(b"ACGT"[c] for c in first), bytes(b"ACGT"[c] for c in second)]
+        # (forward sequence, true position, best score, edits, strand) of read 1 and read 2 of the pair
+        ta, tb = (a, a_pos, a_score, a_ed, 1), (b, b_pos, b_score, b_ed, 2)
+        truth.append((ta, tb) if p % 2 == 0 else (tb, ta))
+    q, lens, wpq = s3dp.pack_reads(reads, 120)
+    b = s3dp.Batch(ix, len(reads), wpq)
+    b.upload(q, lens)
+    sb = s3dp.Batch(ix, len(reads) * 16, 8)
+    dp = s3dp.DpAligner(4096, 104, 104 + 2 * 25 + 8, scheme=1)
+    res, cigars, too_many = dp.deep(b, sb, lens, np.arange(0, len(reads), 2), stage, max_hit, 200, 500, (30, 30), 49, 49)
+    assert too_many.sum() == 0
+    best = {}
+    for r, cg in zip(res, cigars):
+        k = int(r["readID"]) // 2
+        tot = int(r["score_1"]) + int(r["score_2"])
+        if k not in best or tot > best[k][2]:
+            best[k] = (r, cg, tot)
+    ok = 0
+    for k, (t1, t2) in enumerate(truth):
+        if k not in best:
+            continue
+        r, cg, _ = best[k]
+        good = True
+        for end, t in ((1, t1), (2, t2)):
+            fwd, pos, score, edits, strand = t
+            got_pos, got_score, got_ed, got_strand = int(r["algnmt_%d" % end]), int(r["score_%d" % end]), int(r["editdist_%d" % end]), int(r["strand_%d" % end])
+            s, e, span = apply_cigar(cg[end - 1], fwd, codes, got_pos)
+            assert s == got_score and e == got_ed, (k, end, cg)
+            good &= got_strand == strand and abs(got_pos - pos) <= 4 and got_score >= score
+        lo = min(int(r["algnmt_1"]), int(r["algnmt_2"]))
+        assert 200 <= int(r["insertSize"]) <= 520
+        ok += good
+    assert ok >= 0.8 * len(truth), ok
+    dp.close()
+    b.close()
+    sb.close()
