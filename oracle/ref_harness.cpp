@@ -25,6 +25,7 @@
 #include "QueryParser.h"
 #include "IndexHandler.h"
 #include "SAM.h"
+#include "OutputDPResult.h"
 #include "2bwt-lib/Timing.h"
 
 // defined (non-static) in CPUfunctions.cpp but not declared in its header
@@ -712,6 +713,79 @@ static int modeDpParams ( int argc, char ** argv )
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// mode "dpsingle": SAM records of single-read DP results, written by the reference's own outputDPSingleResult2 (OutputDPResult.cpp:937)
+// -> SingleDPOutputSAMAPI (BGS-IO.cpp:5857).  The DP results come from a text file (one per line, grouped by read, in the order the
+// output stage receives them): readID strand algnmt score editdist num_sameScore cigar   (algnmt 4294967295 + cigar * = unaligned)
+static int modeDpSingle ( int argc, char ** argv )
+{
+    // argv: ref_harness dpsingle <ini> <results.txt> single <index> <reads> [options]
+    Ctx C;
+
+    if ( ParseIniFile ( argv[2], C.ini ) != 0 ) { fprintf ( stderr, "bad ini\n" ); return 1; }
+
+    const char * resultFile = argv[3];
+    memset ( &C.opt, 0, sizeof ( C.opt ) );
+    argv[3] = argv[0];
+
+    if ( !parseInputArgs ( argc - 3, argv + 3, C.opt ) ) { return 1; }
+
+    C.index = INDEXLoad ( &C.ini, C.opt.indexName, 0 );
+    uint maxNumQueries = 1 << 20;
+    size_t roundUp = ( ( size_t ) maxNumQueries + 31 ) / 32 * 32;
+    initHspAux ( C.index, C.ini, C.opt, roundUp );
+    HSP * hsp = C.index->sraIndex->hsp;
+    HSPAux * hspaux = C.index->sraIndex->hspaux;
+    Reads R = loadReads ( C.opt.queryFileName, C.index->charMap, C.opt.maxReadLength, C.ini.Ini_maxReadNameLen, maxNumQueries );
+    hspaux->isFastq = R.isFastq;
+    // the DP stage of soap3_dp_single_align (alignment.cu:2558-2585): parameters from the detected read length
+    uint detected = GetReadLength ( R.readLengths, R.numQueries, 10 );
+    DPParameters dp;
+    memset ( &dp, 0, sizeof ( dp ) );
+    getParameterForAllDP ( dp, C.opt, C.ini );
+    getParameterForSingleDP ( dp, C.opt, C.ini, detected );
+    hspaux->singleDPcutoffThreshold = dp.paramRead[0].cutoffThreshold;
+    C.outName = ( char * ) malloc ( strlen ( C.opt.outputPrefix ) + 16 );
+    sprintf ( C.outName, "%s.dpout.1", C.opt.outputPrefix );
+    bam_header_t samHeader;
+    SAMOutputHeaderConstruct ( &samHeader, hsp, hspaux, C.opt.maxReadLength );
+    C.samOut = samopen ( C.outName, "wh", &samHeader );
+    std::vector<SingleAlgnmtResult> res;
+    FILE * f = fopen ( resultFile, "r" );
+
+    if ( !f ) { fprintf ( stderr, "cannot open %s\n", resultFile ); return 1; }
+
+    unsigned int readID, algnmt;
+    int strand, score, editdist, same;
+    char cigar[4096];
+
+    while ( fscanf ( f, "%u %d %u %d %d %d %4095s", &readID, &strand, &algnmt, &score, &editdist, &same, cigar ) == 7 )
+    {
+        SingleAlgnmtResult r;
+        r.readID = readID; r.strand = ( char ) strand; r.algnmt = algnmt; r.score = score; r.editdist = editdist; r.num_sameScore = same;
+        r.cigarString = cigar[0] == '*' ? NULL : strdup ( cigar );
+        res.push_back ( r );
+    }
+
+    fclose ( f );
+    fprintf ( stderr, "[harness] %u reads, %zu DP results, detected read length %u, cutoff %d\n", R.numQueries, res.size (), detected, hspaux->singleDPcutoffThreshold );
+
+    // one call per read, as DPSOutputThread does after OutputBuffer::ready (DV-DPfunctions.cu:1776-1830)
+    for ( size_t i = 0; i < res.size (); )
+    {
+        size_t j = i;
+
+        while ( j < res.size () && res[j].readID == res[i].readID ) { j++; }
+
+        outputDPSingleResult2 ( &res[i], ( unsigned int ) ( j - i ), R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities,
+                                C.opt.maxReadLength, 0, SRA_OUTPUT_FORMAT_SAM_API, NULL, C.samOut, C.index );
+        i = j;
+    }
+
+    samclose ( C.samOut );
+    return 0;
+}
+
 int main ( int argc, char ** argv )
 {
     if ( argc < 2 ) { fprintf ( stderr, "usage: ref_harness models|search|sam ...\n" ); return 1; }
@@ -719,6 +793,8 @@ int main ( int argc, char ** argv )
     if ( strcmp ( argv[1], "models" ) == 0 ) { dumpModels ( argv[2] ); return 0; }
 
     if ( strcmp ( argv[1], "dpparams" ) == 0 ) { return modeDpParams ( argc, argv ); }
+
+    if ( strcmp ( argv[1], "dpsingle" ) == 0 ) { return modeDpSingle ( argc, argv ); }
 
     if ( strcmp ( argv[1], "search" ) == 0 ) { return modeSearch ( argc, argv ); }
 

@@ -57,6 +57,9 @@ struct SamOptions {
     bool printMDNM = false;
 };
 
+// one DP result of a read, as the DP engines return it (SingleAlgnmtResult, PEAlgnmt.h:434); cigar in the engine's dialect ('m' = mismatch run)
+struct DpHit { uint32_t pos; uint8_t strand; int score, editdist; std::string cigar; };
+
 class SamWriter {
 public:
     SamWriter(const HostIndex &ix, const SamOptions &opt, FILE *out);
@@ -70,6 +73,9 @@ public:
     // unique-best / random-best record: one hit, X0 = 1, no X1, no XA, no boundary check (SingleAnsOutputSAMAPI, BGS-IO.cpp:5774)
     void singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_t strand, uint8_t mis);
     void unaligned(const ReadSet &rs, uint32_t r);       // noAnsOutputSAMAPI, BGS-IO.cpp:5829
+    // the DP results of one single read (SingleDPOutputSAMAPI, BGS-IO.cpp:5857); hits[0].pos == 0xFFFFFFFF or n == 0: unaligned record
+    void singleDP(const ReadSet &rs, uint32_t r, const DpHit *hits, size_t n, int singleDPcutoffThreshold);
+    static std::string convertCigar(const std::string &engineCigar);                             // convertToCigarStr, PE.cpp:421
     // a pair with a proper pairing (pairOutputSAMAPI, BGS-IO.cpp:3478): reads r1 = 2p, r2 = 2p+1; xa = the other optimal pairings
     void properPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const s3_pair_result &P, const s3_pair_xa *xa, size_t nXa);
     // a pair without one (unproperlypairOutputSAMAPI, BGS-IO.cpp:2582): the occurrence lists of both ends; xaLimit = the hit limit per end
@@ -81,6 +87,9 @@ private:
     uint32_t chrAndPos(uint32_t ambPos, uint64_t &tp, uint32_t &chr) const;                    // getChrAndPos, BGS-IO.cpp:1746
     int chrAndPosChecked(uint32_t readLen, uint32_t ambPos, uint64_t &tp, uint32_t &chr, std::string *cigar) const;   // :1981
     void seqAndQual(const ReadSet &rs, uint32_t r, bool negative, std::string &line) const;
+    int boundaryCheckDP(uint32_t readLen, uint32_t pacPos, const std::string &cigar, uint64_t &tp, uint32_t &chr, std::string *newCigar) const;
+    int misInfoDP(const ReadSet &rs, uint32_t r, uint32_t pos, bool negative, const std::string &engineCigar, int trim, std::string &md, int &numMis,
+                  int &gapOpen, int &gapExt, int &avgQual) const;
     struct Rec;
     void emit(const ReadSet &rs, const Rec &rec);
     const HostIndex &ix;

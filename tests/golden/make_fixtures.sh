@@ -89,6 +89,18 @@ mk g1 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 6 --genome-seed 1" "-
 mk g2 "--genome-len 60000 --chroms 2 --n-runs 2 --repeats 40 --genome-seed 7" "--reads 1500 --read-len 100 --var-len 25 120 --read-seed 11" 120
 mkl g3 "--genome-len 120000 --chroms 2 --n-runs 4 --repeats 12 --genome-seed 5" "--reads 1200 --var-len 121 200 --read-seed 31 --mix 0.3 0.2 0.15 0.1 0.08 0.07 0.05 0.03 0.02" 200
 mkp g4 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 8 --genome-seed 9" "--pairs 1200 --read-len 100 --read-seed 77" 100
+# output stage of the single-read DP: reads + synthetic DP result vectors -> the reference's own SAM records
+mkdir -p $OUT/dp1
+( cd $W && python $ROOT/tools/simulate.py --genome-len 90000 --chroms 3 --n-runs 4 --genome-seed 21 --fasta dp1.fa
+  $REF/soap3-dp-builder dp1.fa > /dev/null
+  $REF/BGS-Build dp1.fa.index > /dev/null
+  python $ROOT/tools/simulate_dp_results.py --index dp1.fa.index --fastq dp1.fq --results dp1.results
+  P="$REF/ref_harness dpsingle $INI dp1.results single dp1.fa.index dp1.fq -L 100"
+  $P -o dp_h2 > /dev/null 2>&1; $P -h 1 -o dp_h1 > /dev/null 2>&1; $P -p -o dp_h2_p > /dev/null 2>&1; $P -h 1 -p -o dp_h1_p > /dev/null 2>&1
+  for f in bwt rev.bwt fmv.gpu rev.fmv.gpu sa pac ann amb tra; do cp dp1.fa.index.$f $OUT/dp1/index.$f; done
+  cp dp1.fq $OUT/dp1/reads.fq; cp dp1.results $OUT/dp1/results.txt
+  for v in h2 h1 h2_p h1_p; do grep -v '^@PG' dp_$v.dpout.1 | gzip -9n > $OUT/dp1/dpout_$v.sam.gz; done
+)
 ( cd $W && $REF/ref_harness models models.txt && gzip -9n < models.txt > $OUT/models.txt.gz )
 ( cd $W && $REF/ref_harness dpparams $INI dpparams.txt && gzip -9n < dpparams.txt > $OUT/dpparams.txt.gz )
 du -sh $OUT

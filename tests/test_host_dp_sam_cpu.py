@@ -1,0 +1,39 @@
+"""not gpu: SAM records of single-read DP results.  tests/golden/dp1 holds reads, DP result vectors (synthetic, tools/simulate_dp_results.py) and
+the records the reference's own outputDPSingleResult2 / SingleDPOutputSAMAPI wrote for them (oracle/ref_harness.cpp, mode dpsingle); the
+product's writer (soap3-dp_amd/host/s3_host_dp.cpp) must reproduce every record: CIGAR conversion, boundary trimming, MD / NM, X0 / X1 /
+XM / XO / XG, XA:Z, MAPQ."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+from test_gpu_cli_sam import sam_records
+
+TOOL = os.path.join(ROOT, "tests", "tools", "dp_sam")
+
+
+def tool():
+    src = [os.path.join(ROOT, "tests", "tools", "dp_sam.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host.cpp"),
+           os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host_dp.cpp")]
+    if not os.path.exists(TOOL) or os.path.getmtime(TOOL) < max(os.path.getmtime(s) for s in src):
+        lib = os.path.join(ROOT, "soap3-dp_amd")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", TOOL] + src + ["-L" + lib, "-ls3dp", "-lz", "-lm", "-Wl,-rpath," + lib])
+    return TOOL
+
+
+@pytest.mark.parametrize("variant,opts", [("h2", []), ("h1", ["-h", "1"]), ("h2_p", ["-p"]), ("h1_p", ["-h", "1", "-p"])])
+def test_single_read_dp_records(tmp_path, variant, opts):
+    d = os.path.join(GOLDEN, "dp1")
+    shutil.copy(os.path.join(d, "reads.fq"), tmp_path / "dp1.fq")
+    out = subprocess.run([tool(), os.path.join(d, "index"), "dp1.fq", os.path.join(d, "results.txt"), "out", "-L", "100"] + opts, cwd=tmp_path,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    mine = sam_records(open(tmp_path / "out.dpout.1").read())
+    ref = sam_records(gzip.open(os.path.join(d, "dpout_%s.sam.gz" % variant), "rt").read())
+    assert mine[0] == ref[0]
+    assert set(mine[1]) == set(ref[1])
+    bad = [(k, ref[1][k], mine[1][k]) for k in ref[1] if ref[1][k] != mine[1][k]]
+    assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][1], bad[0][2])
