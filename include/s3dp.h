@@ -150,8 +150,8 @@ int  s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3
  * seed: at most 12 per read below 400 bases).  Candidates come back sorted by (strand, read, position); seedStatus (optional) holds per
  * seed 0 = no hit, 1 = hits used, 4 = dropped for too many hits.  Both arrays are malloc'ed: release with s3_free.  PARITY UNPINNED. */
 typedef struct { uint32_t readID, pos; uint8_t strand, pad[3]; } s3_seed_candidate;
-int  s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, int stage, uint32_t maxHitNum,
-                        s3_seed_candidate **candidates, size_t *nCandidates, uint8_t **seedStatus, size_t *nSeeds);
+int  s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *readIDs /* NULL = every read */, size_t nReadIDs,
+                        int stage, uint32_t maxHitNum, s3_seed_candidate **candidates, size_t *nCandidates, uint8_t **seedStatus, size_t *nSeeds);
 
 /* ---- DP for single reads (after s3_seed_candidates) ------------------------------------------------------------------------------
  * Replaces SingleEndAlignmentEngine (DV-DPfunctions.cu:1373-1770): window = candidate position -/+ margin (readLength > 100 ? readLength / 4

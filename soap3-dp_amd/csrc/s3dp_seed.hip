@@ -150,13 +150,16 @@ int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<
     return checkFlags(b);
 }
 
-extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, int stage, uint32_t maxHitNum,
-                                  s3_seed_candidate **candOut, size_t *nCandOut, uint8_t **seedStatusOut, size_t *nSeedsOut)
+extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *readIDs, size_t nReadIDs, int stage,
+                                  uint32_t maxHitNum, s3_seed_candidate **candOut, size_t *nCandOut, uint8_t **seedStatusOut, size_t *nSeedsOut)
 {
     if (!reads || !seedBatch || !readLengths || !candOut || !nCandOut) return fail(S3_EINVAL, "s3_seed_candidates: null argument");
     if (reads->ix != seedBatch->ix || reads == seedBatch) return fail(S3_EINVAL, "s3_seed_candidates: the seed batch must be a second batch on the same index");
     std::vector<SeedDesc> seeds;
-    for (uint32_t r = 0; r < reads->n; r++) {
+    const size_t nSel = readIDs ? nReadIDs : reads->n;
+    for (size_t k = 0; k < nSel; k++) {
+        const uint32_t r = readIDs ? readIDs[k] : (uint32_t)k;
+        if (r >= reads->n) return fail(S3_EINVAL, "s3_seed_candidates: read index out of range");
         int seedLength = 0, num = 0, pos[128];
         if (s3_seed_positions(stage, (int)readLengths[r], &seedLength, pos, &num) != S3_OK) return fail(S3_EINVAL, "s3_seed_candidates: bad stage");
         for (int i = 0; i < num; i++) {

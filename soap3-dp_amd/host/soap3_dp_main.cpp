@@ -3,12 +3,15 @@
 //
 //   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
 //   soap3-dp pair   <index prefix> <reads 1> <reads 2> [-u maxInsert] [-v minInsert] -s k [the same options]
+// Without -s the DP stages are on (the reference's default): single reads the BWT stage leaves unaligned go through seeding + semi-global DP
+// and are written to <prefix>.dpout.1.
 //
 // Output: <prefix>.gout.1 (SAM), <prefix>.done, like SOAP3-DP.cu:251-258 with NumOfCpuThreads = 1.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <unistd.h>
@@ -21,7 +24,8 @@ using namespace s3host;
 struct Ini {
     unsigned maxOutputPerRead = 1000, peMaxOutputPerPair = 1000, maxHitsEachEndForPairing = 10000;
     int minMAPQ = 1, maxMAPQ = 40, bwaLike = 0, maxLenReadName = 64;     // code defaults of IniParam.cpp:237-362
-    int matchScore = 1, mismatchScore = -2;
+    int matchScore = 1, mismatchScore = -2, gapOpenScore = -3, gapExtendScore = -1;
+    int soap3MisMatchAllow = 2, dpScoreThreshold = -1 /* DEFAULT */, maxFrontLenClipped = 3, maxEndLenClipped = 8;   // IniParam.cpp:300-362
 };
 
 static void parseIni(const std::string &file, Ini &ini)
@@ -42,6 +46,12 @@ static void parseIni(const std::string &file, Ini &ini)
         else if (!strcmp(key, "MaxHitsEachEndForPairing")) ini.maxHitsEachEndForPairing = (unsigned)strtoul(val, nullptr, 10);
         else if (!strcmp(key, "MatchScore")) ini.matchScore = atoi(val);
         else if (!strcmp(key, "MismatchScore")) ini.mismatchScore = atoi(val);
+        else if (!strcmp(key, "GapOpenScore")) ini.gapOpenScore = atoi(val);
+        else if (!strcmp(key, "GapExtendScore")) ini.gapExtendScore = atoi(val);
+        else if (!strcmp(key, "Soap3MisMatchAllow")) ini.soap3MisMatchAllow = atoi(val);
+        else if (!strcmp(key, "DPScoreThreshold")) ini.dpScoreThreshold = strcmp(val, "DEFAULT") == 0 ? -1 : atoi(val);
+        else if (!strcmp(key, "MaxFrontLenClipped")) ini.maxFrontLenClipped = atoi(val);
+        else if (!strcmp(key, "MaxEndLenClipped")) ini.maxEndLenClipped = atoi(val);
     }
     fclose(f);
 }
@@ -123,7 +133,7 @@ int main(int argc, char **argv)
             if (i + 1 < argc && argv[i + 1][0] >= '0' && argv[i + 1][0] <= '9') numMismatch = atoi(argv[++i]);
         } else return die("unknown option " + a);
     }
-    if (enableDP) return die("the DP stages are not built yet: run with -s <k>");
+    if (enableDP && paired) return die("the DP stages of paired-end runs are not wired into this program yet (the engines exist behind the C-ABI): run with -s <k>");
     if (outputFormat != 2) return die("only SAM output (-b 2) is built");
     if (alignmentType < 1 || alignmentType > 4) return die("The output option should be 1, 2, 3 or 4");
     if (maxReadLength > S3_MAX_READ_LENGTH) return die("The length should not be greater than 1024");
@@ -143,6 +153,14 @@ int main(int argc, char **argv)
                : !loadSingleReads(queryFile, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, err)) return die(err);
     printf("[Main] Loaded %u short reads from the query file.\n[Main] Read load time : %9.4f seconds (%d host threads)\n", rs.n, since(tReads), hostThreads());
     if (numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;          // getDefaultMismatchNum, CPUfunctions.cpp:26-35
+    // DP enabled (the default): the BWT stage runs with Soap3MisMatchAllow mismatches (SOAP3-DP.cu:208-213); reads it leaves unaligned go
+    // through seeding + DP and are reported in <prefix>.dpout.1.  Too short reads switch the DP off (SOAP3-DP.cu:643-652).
+    uint32_t detectedReadLength = 0;                                       // GetReadLength: the longest of the first ten reads
+    for (uint32_t i = 0; i < rs.n && i < 10; i++) detectedReadLength = std::max(detectedReadLength, rs.lengths[i]);
+    if (enableDP) {
+        numMismatch = ini.soap3MisMatchAllow;
+        if (detectedReadLength < 30) { enableDP = false; printf("Dynamic programming is disabled because read length < %i\n", 30); }
+    }
     s3_index *ix = nullptr;
     s3_index_desc d = hix.desc();
     if (s3_index_upload(device, &d, &ix) != S3_OK) return die(s3_last_error());
@@ -158,6 +176,26 @@ int main(int argc, char **argv)
     so.dpMatchScore = ini.matchScore; so.dpMismatchScore = ini.mismatchScore;
     SamWriter sam(hix, so, out);
     sam.header();
+    FILE *dpOut = nullptr;
+    s3_dp *dp = nullptr;
+    s3_batch *seedBatch = nullptr;
+    s3_dp_stage_params dpPar{};
+    uint64_t dpAlignedReads = 0;
+    if (enableDP) {
+        const std::string dpName = prefix + ".dpout.1";
+        dpOut = fopen(dpName.c_str(), "w");
+        if (!dpOut) return die("Could not open the output file " + dpName);
+        SamWriter dpHdr(hix, so, dpOut);
+        dpHdr.header();
+        s3_dp_ini di{ini.dpScoreThreshold, ini.maxFrontLenClipped, ini.maxEndLenClipped};
+        s3_dp_stage_parameters(S3_STAGE_SINGLE_DP, detectedReadLength, &di, &dpPar);      // getParameterForSingleDP on the detected length (alignment.cu:2580)
+        const int maxRL = (maxReadLength / 4 + 1) * 4, margin = maxReadLength > 100 ? maxReadLength >> 2 : 25, maxDNA = maxRL + 2 * margin + 8;   // DV-DPfunctions.cu:1580
+        int scheme = 1, tableLen = 0, patLen = 0;
+        s3_dp_config(maxRL, maxDNA, 1, &scheme, &tableLen, &patLen);
+        s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
+        if (s3_dp_create(device, 32768, (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &dp) != S3_OK) return die(s3_last_error());
+        if (s3_batch_create(ix, 262144 + 64, 8, &seedBatch) != S3_OK) return die(s3_last_error());
+    }
     const uint32_t maxBatch = 1u << 22;
     s3_batch *b = nullptr;
     if (s3_batch_create(ix, rs.n < maxBatch ? (rs.n ? rs.n : 1) : maxBatch, rs.wpq, &b) != S3_OK) return die(s3_last_error());
@@ -211,15 +249,85 @@ int main(int argc, char **argv)
             const size_t o = offs[k], m = offs[k + 1] - offs[k];
             if (alignmentType >= 3) {
                 // unique best: exactly one hit, otherwise a no-answer record; random best: the first hit (hostKernel, CPUfunctions.cpp:1861-1930)
+                if (m == 0 && enableDP) return;                                   // goes to the DP stage
                 if (m == 0 || (alignmentType == 3 && m > 1)) w.unaligned(rs, first + k);
                 else { al++; w.singleAnswer(rs, first + k, pos[o], strand[o], mis[o]); }
                 return;
             }
             if (m) al++;
+            else if (enableDP) return;                                            // goes to the DP stage
             w.singleEnd(rs, first + k, pos.data() + o, strand.data() + o, mis.data() + o, m, seeds.empty() ? 0u : seeds[k]);
         }, aligned);
+        if (enableDP) {
+            // DPForUnalignSingle2 (DV-DPForSingleReads.cu): seeding in batches of at most 256 Ki seeds, DP at the candidates, one record per run of
+            // results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776), the rest as unaligned records
+            if (!seeds.empty() && s3_batch_set_seed_lengths(b, nullptr) != S3_OK) return die(s3_last_error());
+            std::vector<uint32_t> todo;
+            for (uint32_t k = 0; k < cnt; k++) if (offs[k + 1] == offs[k]) todo.push_back(k);
+            std::vector<uint8_t> doneFlag(cnt, 0);
+            const uint32_t *lens = rs.lengths.data() + first;
+            size_t at = 0;
+            while (at < todo.size()) {
+                size_t end = at, nSeeds = 0;
+                while (end < todo.size()) {
+                    int sl = 0, num = 0, sp[128];
+                    s3_seed_positions(S3_STAGE_SINGLE_DP, (int)lens[todo[end]], &sl, sp, &num);
+                    if (nSeeds + (size_t)num > 262144) break;
+                    nSeeds += (size_t)num;
+                    end++;
+                }
+                if (end == at) end = at + 1;
+                s3_seed_candidate *cand = nullptr;
+                size_t nCand = 0;
+                if (s3_seed_candidates(b, seedBatch, lens, todo.data() + at, end - at, S3_STAGE_SINGLE_DP, (uint32_t)dpPar.maxHitNum, &cand, &nCand, nullptr, nullptr) != S3_OK)
+                    return die(s3_last_error());
+                s3_dp_single_result *res = nullptr;
+                size_t nRes = 0;
+                char *pool = nullptr;
+                if (s3_dp_single_end(dp, b, lens, cand, nCand, dpPar.cutoffThreshold, dpPar.softClipLeft, dpPar.softClipRight, &res, &nRes, &pool) != S3_OK)
+                    return die(s3_last_error());
+                SamWriter w(hix, so, dpOut);
+                for (size_t i = 0; i < nRes;) {
+                    size_t j = i;
+                    while (j < nRes && res[j].readID == res[i].readID) j++;
+                    // OutputBuffer::ready (DV-DPfunctions.h:367-412) with the DP module's type (all-best + SAM runs it as all-valid, alignment.cu:2563):
+                    // sorted by position, one result per position; then best-only for -h 3 / 4
+                    std::vector<DpHit> hits;
+                    for (size_t q = i; q < j; q++) hits.push_back(DpHit{res[q].algnmt, res[q].strand, res[q].score, (int)res[q].editdist, std::string(pool + res[q].cigarOffset)});
+                    std::sort(hits.begin(), hits.end(), [](const DpHit &x, const DpHit &y) { return x.pos < y.pos; });
+                    size_t u = 0;
+                    for (size_t q = 1; q < hits.size(); q++) if (hits[u].pos < hits[q].pos) hits[++u] = hits[q];
+                    hits.resize(hits.empty() ? 0 : u + 1);
+                    if (alignmentType >= 3 && !hits.empty()) {
+                        std::vector<DpHit> bestOnes;
+                        int bestScore = hits[0].score;
+                        for (const DpHit &hh : hits) bestScore = std::max(bestScore, hh.score);
+                        for (const DpHit &hh : hits) if (hh.score == bestScore) bestOnes.push_back(hh);
+                        if (alignmentType == 3 && bestOnes.size() != 1) bestOnes.clear();
+                        if (alignmentType == 4) bestOnes.resize(1);
+                        hits.swap(bestOnes);
+                    }
+                    if (!hits.empty()) {
+                        w.singleDP(rs, first + res[i].readID, hits.data(), hits.size(), dpPar.cutoffThreshold);
+                        if (!doneFlag[res[i].readID]) { doneFlag[res[i].readID] = 1; dpAlignedReads++; }
+                    }
+                    i = j;
+                }
+                s3_free(cand); s3_free(res); s3_free(pool);
+                at = end;
+            }
+            SamWriter w(hix, so, dpOut);
+            for (uint32_t k : todo) if (!doneFlag[k]) w.unaligned(rs, first + k);
+        }
     }
     fclose(out);
+    if (dpOut) {
+        fclose(dpOut);
+        printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)dpAlignedReads);
+        aligned += dpAlignedReads;
+        s3_dp_free(dp);
+        s3_batch_free(seedBatch);
+    }
     printf("[Main] Alignment + output time : %9.4f seconds\n[Main] Total elapsed time : %9.4f seconds\n", since(tAlign), since(t0));
     (void)devSeconds; (void)formatSeconds;
     printf("[Main] Overall number of reads aligned: %llu\n", (unsigned long long)aligned);

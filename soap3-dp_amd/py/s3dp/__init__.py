@@ -330,14 +330,16 @@ class Batch:
         _chk(lib().s3_batch_fetch_alignments(self.h, None, None, None, pos.ctypes.data, strand.ctypes.data, mis.ctypes.data, k, None))
         return phase, werr, offs, pos[:no.value], strand[:no.value], mis[:no.value]
 
-    def seed_candidates(self, seed_batch, read_lengths, stage, max_hit_num):
+    def seed_candidates(self, seed_batch, read_lengths, stage, max_hit_num, read_ids=None):
         """seeding for the DP stages: returns (candidates SEED_CAND_DTYPE sorted by strand/read/position, per-seed status)"""
         read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
         f = lib().s3_seed_candidates
-        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
-                      C.POINTER(C.c_size_t)]
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         cand, n, st, ns = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
-        _chk(f(self.h, seed_batch.h, read_lengths.ctypes.data, stage, max_hit_num, C.byref(cand), C.byref(n), C.byref(st), C.byref(ns)))
+        ids = None if read_ids is None else np.ascontiguousarray(read_ids, dtype=np.uint32)
+        _chk(f(self.h, seed_batch.h, read_lengths.ctypes.data, None if ids is None else ids.ctypes.data, 0 if ids is None else len(ids), stage, max_hit_num,
+               C.byref(cand), C.byref(n), C.byref(st), C.byref(ns)))
         out = np.frombuffer(C.string_at(cand, n.value * SEED_CAND_DTYPE.itemsize), dtype=SEED_CAND_DTYPE).copy() if n.value else np.zeros(0, SEED_CAND_DTYPE)
         status = np.frombuffer(C.string_at(st, ns.value), dtype=np.uint8).copy() if ns.value else np.zeros(0, np.uint8)
         free = lib().s3_free

@@ -105,3 +105,87 @@ def test_cli_sam_pairs(tmp_path, variant, opts):
     assert set(mine) == set(ref)
     bad = [(k, ref[k], mine[k]) for k in ref if ref[k] != mine[k]]
     assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][1], bad[0][2])
+
+
+def test_cli_default_mode_single_reads_with_dp(tmp_path):
+    """`soap3-dp single <index> <reads>` without -s: BWT stage at Soap3MisMatchAllow = 2 mismatches into .gout.1, the reads it leaves unaligned
+    through seeding + DP into .dpout.1.  The DP engines are unpinned: the check is semantic -- every read is reported once, the
+    damaged reads (indels, 5 substitutions) come back at their true place with a CIGAR of the expected shape."""
+    import re
+    import numpy as np
+    name = "g1"
+    rng = np.random.default_rng(8)
+    chroms = {}
+    cur = None
+    for l in open(os.path.join(GOLDEN, name, "genome.fa")):
+        if l.startswith(">"):
+            cur = l[1:].split()[0]
+            chroms[cur] = []
+        else:
+            chroms[cur].append(l.strip())
+    chroms = {k: "".join(v) for k, v in chroms.items()}
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    L, reads, truth = 100, [], []
+    names = sorted(chroms)
+    while len(reads) < 400:
+        ch = names[int(rng.integers(0, len(names)))]
+        st = int(rng.integers(0, len(chroms[ch]) - L - 10))
+        seg = chroms[ch][st:st + L + 10]
+        if "N" in seg:
+            continue
+        kind = len(reads) % 4
+        if kind == 0:
+            s, shape = seg[:L], "exact"
+        elif kind == 1:
+            c = int(rng.integers(30, 70))
+            s, shape = seg[:c] + seg[c + 3:L + 3], "D"
+        elif kind == 2:
+            c = int(rng.integers(30, 70))
+            s, shape = seg[:c] + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=2)) + seg[c:L - 2], "I"
+        else:
+            b = list(seg[:L])
+            for q in rng.choice(np.arange(5, L - 5), size=5, replace=False):
+                b[q] = "ACGT"[("ACGT".index(b[q]) + 1 + int(rng.integers(0, 3))) % 4]
+            s, shape = "".join(b), "sub"
+        neg = bool(rng.integers(0, 2))
+        if neg:
+            s = "".join(comp[c] for c in reversed(s))
+        reads.append(s)
+        truth.append((ch, st + 1, neg, shape))
+    with open(tmp_path / "r.fq", "w") as f:
+        for i, s in enumerate(reads):
+            f.write("@q%d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), "r.fq", "-L", "100", "-o", "out"], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    gout = [l.rstrip("\n").split("\t") for l in open(tmp_path / "out.gout.1") if not l.startswith("@")]
+    dpout = [l.rstrip("\n").split("\t") for l in open(tmp_path / "out.dpout.1") if not l.startswith("@")]
+    seen = [f[0] for f in gout] + [f[0] for f in dpout]
+    assert sorted(seen) == sorted("q%d" % i for i in range(len(reads))), "every read exactly once over .gout.1 and .dpout.1"
+    by_name = {f[0]: ("bwt", f) for f in gout}
+    by_name.update({f[0]: ("dp", f) for f in dpout})
+    ok = {"exact": 0, "D": 0, "I": 0, "sub": 0}
+    tot = {"exact": 0, "D": 0, "I": 0, "sub": 0}
+    for i, (ch, pos, neg, shape) in enumerate(truth):
+        src, f = by_name["q%d" % i]
+        tot[shape] += 1
+        if shape == "exact":
+            assert src == "bwt" and f[5] == "100M"
+            if "X0:i:1" in f:                                   # not inside one of the planted repeats
+                assert f[2] == ch and int(f[3]) == pos
+            ok[shape] += 1
+            continue
+        assert src == "dp"                                     # 3-base deletion / 2-base insertion / 5 substitutions never pass a 2-mismatch BWT stage
+        if int(f[1]) & 4:
+            continue
+        ops = re.sub(r"\d+", "", f[5])
+        good = f[2] == ch and abs(int(f[3]) - pos) <= 3 and (int(f[1]) & 16 != 0) == neg
+        if shape == "D":
+            good &= ops == "MDM" and "XO:i:1" in f and "XG:i:3" in f
+        elif shape == "I":
+            good &= ops == "MIM" and "XO:i:1" in f and "XG:i:2" in f
+        else:
+            good &= ops == "M" and "XM:i:5" in f
+        ok[shape] += good
+    assert ok["D"] >= 0.8 * tot["D"] and ok["I"] >= 0.8 * tot["I"] and ok["sub"] >= 0.6 * tot["sub"], (ok, tot)   # repeats and spoiled seeds take their share
+    assert "Number of reads aligned by DP" in out.stdout
