@@ -37,7 +37,7 @@ FLEXOBJ := $(addprefix $(OBJ)/flex_,$(addsuffix .o,$(FLEX)))
 SAMOBJ  := $(addprefix $(OBJ)/sam_,$(addsuffix .o,$(SAMT)))
 HOSTOBJ := $(addprefix $(OBJ)/host_,$(addsuffix .o,$(HOST)))
 
-all: $(OUT)/soap3-dp-builder $(OUT)/BGS-Build $(OUT)/ref_harness
+all: $(OUT)/soap3-dp-builder $(OUT)/BGS-Build $(OUT)/ref_harness $(OUT)/libdpref.so
 
 $(OBJ):
 	mkdir -p $(OBJ)
@@ -74,6 +74,20 @@ $(OUT)/BGS-Build: $(REF)/BGS-Build.cpp $(BWTOBJ)
 # our driver around the reference's CPU alignment path
 $(OUT)/ref_harness: oracle/ref_harness.cpp $(HOSTOBJ) $(BWTOBJ) $(FLEXOBJ) $(SAMOBJ)
 	$(CXX) $(FLAGS) -I$(REF) $< $(HOSTOBJ) $(filter-out $(OBJ)/lib_BWTConstruct.o,$(BWTOBJ)) $(FLEXOBJ) $(SAMOBJ) -lz -lm -lpthread -o $@
+
+# The reference's semi-global DP DEVICE code (DV-DPfunctions.cu:35-512) built for gfx950 with hipcc -- CUDA and HIP share the kernel language.
+# The region is streamed out of the reference file (never copied into the repository; obj/ does not travel to the GPU box either), with
+# the two edits CDNA forces: no texture units, so the `texture <uint>` declarations go and MC_ReadUnpack indexes its array argument (the
+# texture was bound to exactly that array, DV-DPfunctions.cu:660).  Four lines of DV-DPfunctions.h (its typedefs / macros; the header itself
+# includes <cuda.h>) are streamed the same way.  The host driver around it is ours: oracle/ref_dp_driver.hip.
+HIPCC ?= /opt/rocm/bin/hipcc
+$(OBJ)/dp_device.inc: $(REF)/DV-DPfunctions.cu | $(OBJ)
+	sed -n '35,512p' $< | sed -e '/^texture <uint> tex/d' -e 's/tex1Dfetch(texPatterns, readTPARA + (((i)>>4)<<5))/X[readTPARA + (((i)>>4)<<5)]/' > $@
+	! grep -q "tex1Dfetch\|^texture" $@
+$(OBJ)/dp_header_lines.inc: $(REF)/DV-DPfunctions.h | $(OBJ)
+	sed -n -e '/^#define DP_THREADS_PER_BLOCK/p' -e '/^typedef unsigned char uchar;/p' -e '/^typedef unsigned int uint;/p' -e '/^#define MC_CeilDivide16/p' $< > $@
+$(OUT)/libdpref.so: oracle/ref_dp_driver.hip $(OBJ)/dp_device.inc $(OBJ)/dp_header_lines.inc
+	$(HIPCC) -O2 -std=c++17 -fPIC -shared --offload-arch=gfx950 -ffp-contract=off -Ioracle -o $@ $<
 
 clean:
 	rm -rf $(OUT)

@@ -6,12 +6,13 @@
  *   driver          SemiGlobalAligntment:243-314   (scheme 1: full table; scheme 2: score pass + windowed refill)
  *   traceback       GPUBacktrack        :316-512
  *
- * PARITY UNPINNED: the reference has no CPU implementation of this DP (it exists only as CUDA device code) and no
- * golden vectors; compiling the device code here would need stand-in CUDA headers, which this repo does not write.
- * This restatement follows the source line by line in behaviour (int running values, int16 clamp at -32000 on every
- * stored cell, first-maximum in (column, row) order, the backtrack priority M > D-open > D-ext > clip exits > I-open
- * > I-ext, the 'V'<n> run markers) and is checked by self-consistency tests (tests/test_oracle_dp.py): the score
- * recomputed from the emitted pattern equals the reported score, and the known answers quoted in SURVEY.md 8c-5.
+ * PINNED on the GPU box: the reference's DP exists only as device code, and that device code itself is the check -- oracle/ref.mk builds
+ * DV-DPfunctions.cu:35-512 with hipcc for gfx950 from where it lies (oracle/_ref/libdpref.so, driver oracle/ref_dp_driver.hip), and
+ * tests/test_gpu_dp_reference.py requires this restatement and the product's kernels to equal it bit for bit (scores, start columns, start
+ * offsets, actual right clips, tie counts, traceback op strings; both schemes, clips, anchors).  On the CPU the restatement is checked by
+ * self-consistency (tests/test_oracle_dp.py: the score recomputed from the emitted pattern equals the reported score) and by the known
+ * answers quoted in SURVEY.md 8c-5.  Domain: readLength < maxReadLength, as in the reference's engines (its table rows have maxReadLength
+ * cells for read positions 0..readLength).
  *
  * Input layout = the reference's: sequences are 1-based, 2 bits per character, 16 per word, first character of a
  * word in the most significant bits, words of problem t interleaved by 32:

@@ -251,7 +251,7 @@ def read_fastq(path):
     return out
 
 
-# ---- DP oracle (oracle/s3_oracle_dp.c; PARITY UNPINNED, see its header) ----
+# ---- DP oracle (oracle/s3_oracle_dp.c; pinned on the GPU box against the reference's own device code, see its header) ----
 class DpScoresO(C.Structure):
     _fields_ = [("match", C.c_int), ("mismatch", C.c_int), ("gapOpen", C.c_int), ("gapExtend", C.c_int)]
 

@@ -1,6 +1,6 @@
-"""DP oracle (oracle/s3_oracle_dp.c).  PARITY UNPINNED: there is no reference CPU implementation and no reference vectors
-for the DP; these tests hold the restatement to (a) the known answers SURVEY.md 8c-5 reports from the reference's own
-device code, and (b) self-consistency: the score recomputed from the emitted op string equals the reported score."""
+"""DP oracle (oracle/s3_oracle_dp.c) on the CPU: self-consistency (the score recomputed from the emitted pattern equals the reported
+score) and the known answers quoted in SURVEY.md 8c-5.  The bit-for-bit check against the reference's own DP device code needs a GPU
+(the reference has no CPU implementation): tests/test_gpu_dp_reference.py."""
 import numpy as np
 
 import s3dp
