@@ -610,6 +610,12 @@ __global__ void __launch_bounds__(256) gatherProbeKernel(const uint4 *table, uin
         }
 #pragma unroll
         for (int k = 0; k < ILP; k++) {
+            if (loadsPerLine >= 10) {                                   // 32-byte granules: does the memory system fetch less than 64 B for them?
+                const uint4 *p32 = table + (line[k] * 4 + ((x >> 40) & 2));     // one of the two 32-B halves of a random 64-B line
+                v[k] = p32[0];
+                if (loadsPerLine > 11) { uint4 w = p32[1]; v[k].x ^= w.x; v[k].y ^= w.w; }
+                continue;
+            }
             const uint4 *p = table + line[k] * 4;
             v[k] = p[0];
             if (loadsPerLine > 1) { uint4 w = p[1 + (line[k] & 1)]; v[k].x ^= w.x; v[k].y ^= w.w; }
