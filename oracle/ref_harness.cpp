@@ -786,6 +786,123 @@ static int modeDpSingle ( int argc, char ** argv )
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// mode "dppair": SAM records of the DP stages for pairs, written by the reference's own outputRead2 (OutputDPResult.cpp:217) ->
+// pairDPOutputSAMAPI (BGS-IO.cpp:4504) and outputDeepDPResult2 (OutputDPResult.cpp:564) -> pairDeepDPOutputSAMAPI (BGS-IO.cpp:3824).
+// Result vectors come from a text file, grouped by pair, in the order the output stage receives them:
+//   D readID which pos1 strand1 score1 pos2 strand2 score2 editdist insert same cigar              (AlgnmtDPResult)
+//   P readID pos1 strand1 score1 edit1 same1 cigar1 pos2 strand2 score2 edit2 same2 cigar2 insert  (DeepDPAlignResult)
+// and what the BWT stage left in hspaux (x0_array / x1_array / mismatch_array) from a second file:  readID x0 x1 mismatch
+static int modeDpPair ( int argc, char ** argv )
+{
+    // argv: ref_harness dppair <ini> <results.txt> <stats.txt> pair <index> <reads1> <reads2> -u <ins> [options]
+    Ctx C;
+
+    if ( ParseIniFile ( argv[2], C.ini ) != 0 ) { fprintf ( stderr, "bad ini\n" ); return 1; }
+
+    const char * resultFile = argv[3];
+    const char * statsFile = argv[4];
+    memset ( &C.opt, 0, sizeof ( C.opt ) );
+    argv[4] = argv[0];
+
+    if ( !parseInputArgs ( argc - 4, argv + 4, C.opt ) ) { return 1; }
+
+    C.index = INDEXLoad ( &C.ini, C.opt.indexName, 0 );
+    uint maxNumQueries = 1 << 20;
+    size_t roundUp = ( ( size_t ) maxNumQueries + 31 ) / 32 * 32;
+    initHspAux ( C.index, C.ini, C.opt, roundUp );
+    HSP * hsp = C.index->sraIndex->hsp;
+    HSPAux * hspaux = C.index->sraIndex->hspaux;
+    memset ( hspaux->x0_array, 0, roundUp * sizeof ( int ) );
+    memset ( hspaux->x1_array, 0, roundUp * sizeof ( int ) );
+    memset ( hspaux->mismatch_array, 0, roundUp * sizeof ( int ) );
+    Reads R = loadPairs ( C.opt.queryFileName, C.opt.queryFileName2, C.index->charMap, C.opt.maxReadLength, C.ini.Ini_maxReadNameLen, maxNumQueries );
+    hspaux->isFastq = R.isFastq;
+    C.outName = ( char * ) malloc ( strlen ( C.opt.outputPrefix ) + 16 );
+    sprintf ( C.outName, "%s.dpout.1", C.opt.outputPrefix );
+    bam_header_t samHeader;
+    SAMOutputHeaderConstruct ( &samHeader, hsp, hspaux, C.opt.maxReadLength );
+    C.samOut = samopen ( C.outName, "wh", &samHeader );
+    FILE * f = fopen ( statsFile, "r" );
+
+    if ( !f ) { fprintf ( stderr, "cannot open %s\n", statsFile ); return 1; }
+
+    unsigned int readID;
+    int x0, x1, mm;
+
+    while ( fscanf ( f, "%u %d %d %d", &readID, &x0, &x1, &mm ) == 4 )
+    { hspaux->x0_array[readID] = x0; hspaux->x1_array[readID] = x1; hspaux->mismatch_array[readID] = mm; }
+
+    fclose ( f );
+    std::vector<AlgnmtDPResult> dres;
+    std::vector<DeepDPAlignResult> pres;
+    f = fopen ( resultFile, "r" );
+
+    if ( !f ) { fprintf ( stderr, "cannot open %s\n", resultFile ); return 1; }
+
+    char kind[8], cigar[4096], cigar2[4096];
+
+    while ( fscanf ( f, "%7s", kind ) == 1 )
+    {
+        if ( kind[0] == 'D' )
+        {
+            AlgnmtDPResult r;
+            int which, s1, s2;
+            memset ( &r, 0, sizeof ( r ) );
+
+            if ( fscanf ( f, "%u %d %u %d %d %u %d %d %d %d %d %4095s", &r.readID, &which, &r.algnmt_1, &s1, &r.score_1, &r.algnmt_2, &s2, &r.score_2, &r.editdist,
+                          &r.insertSize, &r.num_sameScore, cigar ) != 12 ) { fprintf ( stderr, "bad D line\n" ); return 1; }
+
+            r.whichFromDP = ( char ) which; r.strand_1 = ( char ) s1; r.strand_2 = ( char ) s2;
+            r.cigarString = cigar[0] == '*' ? NULL : strdup ( cigar );
+            dres.push_back ( r );
+        }
+        else
+        {
+            DeepDPAlignResult r;
+            int s1, s2;
+            memset ( &r, 0, sizeof ( r ) );
+
+            if ( fscanf ( f, "%u %u %d %d %d %d %4095s %u %d %d %d %d %4095s %d", &r.readID, &r.algnmt_1, &s1, &r.score_1, &r.editdist_1, &r.num_sameScore_1, cigar,
+                          &r.algnmt_2, &s2, &r.score_2, &r.editdist_2, &r.num_sameScore_2, cigar2, &r.insertSize ) != 14 ) { fprintf ( stderr, "bad P line\n" ); return 1; }
+
+            r.strand_1 = ( char ) s1; r.strand_2 = ( char ) s2;
+            r.cigarString_1 = cigar[0] == '*' ? NULL : strdup ( cigar );
+            r.cigarString_2 = cigar2[0] == '*' ? NULL : strdup ( cigar2 );
+            pres.push_back ( r );
+        }
+    }
+
+    fclose ( f );
+    fprintf ( stderr, "[harness] %u reads, %zu default-DP and %zu deep-DP results\n", R.numQueries, dres.size (), pres.size () );
+
+    // one call per pair, as DPOutputThread / DP2OutputThread do after OutputBuffer::ready (DV-DPfunctions.cu:2490-2505, 3840-3860)
+    for ( size_t i = 0; i < dres.size (); )
+    {
+        size_t j = i;
+
+        while ( j < dres.size () && dres[j].readID == dres[i].readID ) { j++; }
+
+        outputRead2 ( &dres[i], ( unsigned int ) ( j - i ), R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities,
+                      C.opt.maxReadLength, 0, SRA_OUTPUT_FORMAT_SAM_API, NULL, C.samOut, C.index, C.ini.Ini_PEStrandLeftLeg, C.ini.Ini_PEStrandRightLeg );
+        i = j;
+    }
+
+    for ( size_t i = 0; i < pres.size (); )
+    {
+        size_t j = i;
+
+        while ( j < pres.size () && pres[j].readID == pres[i].readID ) { j++; }
+
+        outputDeepDPResult2 ( &pres[i], ( unsigned int ) ( j - i ), R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities,
+                              C.opt.maxReadLength, 0, SRA_OUTPUT_FORMAT_SAM_API, NULL, C.samOut, C.index, C.ini.Ini_PEStrandLeftLeg, C.ini.Ini_PEStrandRightLeg );
+        i = j;
+    }
+
+    samclose ( C.samOut );
+    return 0;
+}
+
 int main ( int argc, char ** argv )
 {
     if ( argc < 2 ) { fprintf ( stderr, "usage: ref_harness models|search|sam ...\n" ); return 1; }
@@ -795,6 +912,8 @@ int main ( int argc, char ** argv )
     if ( strcmp ( argv[1], "dpparams" ) == 0 ) { return modeDpParams ( argc, argv ); }
 
     if ( strcmp ( argv[1], "dpsingle" ) == 0 ) { return modeDpSingle ( argc, argv ); }
+
+    if ( strcmp ( argv[1], "dppair" ) == 0 ) { return modeDpPair ( argc, argv ); }
 
     if ( strcmp ( argv[1], "search" ) == 0 ) { return modeSearch ( argc, argv ); }
 

@@ -454,8 +454,8 @@ void SamWriter::unaligned(const ReadSet &rs, uint32_t r)
 }
 
 // MD string and average quality at the mismatching positions (getMdStr / mdStr, PE.cpp:209-284,374-420)
-static int mdString(const HostIndex &ix, const uint8_t *query, const char *qual, uint32_t qlen, uint32_t pos, bool negative, int mismatchNum, int trim,
-                    std::string &md, int &avgQual)
+int mdString(const HostIndex &ix, const uint8_t *query, const char *qual, uint32_t qlen, uint32_t pos, bool negative, int mismatchNum, int trim,
+             std::string &md, int &avgQual)
 {
     if (!negative) {
         if (trim > 0) { query += trim; pos += (uint32_t)trim; qlen -= (uint32_t)trim; }
@@ -464,7 +464,7 @@ static int mdString(const HostIndex &ix, const uint8_t *query, const char *qual,
         if (trim > 0) { pos += (uint32_t)trim; qlen -= (uint32_t)trim; }
         else if (trim < 0) { query += -trim; qlen -= (uint32_t)(-trim); }
     }
-    avgQual = 40;                                                         // DEFAULT_QUAL_VALUE
+    avgQual = 20;                                                         // DEFAULT_QUAL_VALUE, PE.h:27
     md.clear();
     if (mismatchNum == 0) { md = std::to_string(qlen); return (int)md.size(); }
     double sum = 0;
@@ -543,7 +543,7 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
         }
     }
     std::string md;
-    int avgQual = 40;
+    int avgQual = 20;
     const uint8_t *codes = &rs.codes[(size_t)r * rs.maxReadLength];
     const char *quals = &rs.quals[(size_t)r * rs.maxReadLength];
     // bestMis == 9999 cannot reach here: a hit is always chosen
@@ -599,7 +599,7 @@ void SamWriter::singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_
     uint32_t chr = 0;
     chrAndPos(pos, tp, chr);
     std::string md;
-    int avgQual = 40;
+    int avgQual = 20;
     mdString(ix, &rs.codes[(size_t)r * rs.maxReadLength], &rs.quals[(size_t)r * rs.maxReadLength], readLen, pos, negative, (int)mis, 0, md, avgQual);
     // getMapQualScore with n = 1 (BGS-IO.cpp:2280): the mismatch x quality-class table, second-best hits not considered
     int mi = mis > 5 ? 5 : (int)mis;
@@ -632,14 +632,6 @@ void SamWriter::singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_
 // paired-end records
 // ------------------------------------------------------------------------------------------------
 // one SAM line the way samtools prints a bam1_t: RNAME/RNEXT from tid/mtid ("=" when equal), POS/PNEXT one-based
-struct SamWriter::Rec {
-    uint32_t r = 0;
-    int flag = 0, tid = -1, mtid = -1, mapq = 0;
-    long long pos0 = -1, mpos0 = -1, isize = 0;
-    std::string cigar;                                   // empty = "*"
-    bool negative = false;
-    std::string tags;                                    // after RG:Z
-};
 
 void SamWriter::emit(const ReadSet &rs, const Rec &c)
 {
@@ -661,7 +653,7 @@ void SamWriter::emit(const ReadSet &rs, const Rec &c)
     put(line);
 }
 
-static int bwaLikeSingle(int x0, int x1, const int *gLogN)                // bwaLikeSingleQualScore, BGS-IO.cpp:2310
+int bwaLikeSingle(int x0, int x1, const int *gLogN)                // bwaLikeSingleQualScore, BGS-IO.cpp:2310
 {
     if (x0 > 1) return 0;
     if (x1 == 0) return 37;
@@ -670,7 +662,7 @@ static int bwaLikeSingle(int x0, int x1, const int *gLogN)                // bwa
     return 23 < n ? 0 : 23 - n;
 }
 
-static int tableScore(int mismatchNum, int avgQual, int maxMAPQ, int minMAPQ)
+int tableScore(int mismatchNum, int avgQual, int maxMAPQ, int minMAPQ)
 {
     int mi = mismatchNum > 5 ? 5 : mismatchNum;
     int qi = (avgQual - 1) / 20;
@@ -697,7 +689,7 @@ void SamWriter::properPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const s3
     const int trim1 = chrAndPosChecked(len1, P.bestA1, tp1, chr1, &cig1);
     const int trim2 = chrAndPosChecked(len2, P.bestA2, tp2, chr2, &cig2);
     const bool neg1 = P.bestS1 == 2, neg2 = P.bestS2 == 2;
-    int avg1 = 40, avg2 = 40;
+    int avg1 = 20, avg2 = 20;
     mdString(ix, &rs.codes[(size_t)r1 * rs.maxReadLength], &rs.quals[(size_t)r1 * rs.maxReadLength], len1, P.bestA1, neg1, P.bestM1, trim1, md1, avg1);
     mdString(ix, &rs.codes[(size_t)r2 * rs.maxReadLength], &rs.quals[(size_t)r2 * rs.maxReadLength], len2, P.bestA2, neg2, P.bestM2, trim2, md2, avg2);
     int mis1 = P.bestM1, mis2 = P.bestM2;
@@ -803,7 +795,7 @@ void SamWriter::improperPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const 
         if (E.best >= 0 && (type != 3 || E.bestNum == 1)) {
             E.mapped = true;
             chrAndPos(pos[k][E.best], E.tp, E.chr);
-            int avg = 40;
+            int avg = 20;
             const uint32_t len = rs.lengths[rr[k]];
             mdString(ix, &rs.codes[(size_t)rr[k] * rs.maxReadLength], &rs.quals[(size_t)rr[k] * rs.maxReadLength], len, pos[k][E.best], strand[k][E.best] == 2,
                      mis[k][E.best], 0, E.md, avg);

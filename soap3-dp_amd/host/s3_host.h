@@ -60,6 +60,14 @@ struct SamOptions {
 // one DP result of a read, as the DP engines return it (SingleAlgnmtResult, PEAlgnmt.h:434); cigar in the engine's dialect ('m' = mismatch run)
 struct DpHit { uint32_t pos; uint8_t strand; int score, editdist; std::string cigar; };
 
+// one result of the default DP for a pair (AlgnmtDPResult, PEAlgnmt.h:384): one end from the BWT stage (score = mismatches), the other from the
+// DP (score = DP score; cigar / editdist / numSameScore belong to it); whichFromDP 0: first end, 1: second end, 2: the DP found nothing
+struct PairDpHit { uint32_t pos1, pos2; uint8_t strand1, strand2, whichFromDP; int score1, score2, editdist, insertSize, numSameScore; std::string cigar; };
+// one result of the deep DP (DeepDPAlignResult, PEAlgnmt.h:409): both ends from the DP
+struct DeepDpHit { uint32_t pos1, pos2; uint8_t strand1, strand2; int score1, score2, editdist1, editdist2, insertSize, numSame1, numSame2; std::string cigar1, cigar2; };
+// what the BWT stage left for a read in hspaux->x0_array / x1_array / mismatch_array (CPUfunctions.cpp:2099-2103): X0, X1, fewest mismatches; zeros without a hit
+struct BwtEndStats { int x0 = 0, x1 = 0, mismatch = 0; };
+
 class SamWriter {
 public:
     SamWriter(const HostIndex &ix, const SamOptions &opt, FILE *out);
@@ -75,6 +83,11 @@ public:
     void unaligned(const ReadSet &rs, uint32_t r);       // noAnsOutputSAMAPI, BGS-IO.cpp:5829
     // the DP results of one single read (SingleDPOutputSAMAPI, BGS-IO.cpp:5857); hits[0].pos == 0xFFFFFFFF or n == 0: unaligned record
     void singleDP(const ReadSet &rs, uint32_t r, const DpHit *hits, size_t n, int singleDPcutoffThreshold);
+    // the default-DP results of one pair, in the engine's order after OutputBuffer::ready: choice of the reported result (outputRead2,
+    // OutputDPResult.cpp:217-447) and the two records (pairDPOutputSAMAPI, BGS-IO.cpp:4504-5554).  r1 = first read of the pair
+    void pairDP(const ReadSet &rs, uint32_t r1, const PairDpHit *hits, size_t n, const BwtEndStats st[2]);
+    // the deep-DP results of one pair (outputDeepDPResult2, OutputDPResult.cpp:564-845; pairDeepDPOutputSAMAPI, BGS-IO.cpp:3824-4502)
+    void pairDeepDP(const ReadSet &rs, uint32_t r1, const DeepDpHit *hits, size_t n, const BwtEndStats st[2]);
     static std::string convertCigar(const std::string &engineCigar);                             // convertToCigarStr, PE.cpp:421
     // a pair with a proper pairing (pairOutputSAMAPI, BGS-IO.cpp:3478): reads r1 = 2p, r2 = 2p+1; xa = the other optimal pairings
     void properPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const s3_pair_result &P, const s3_pair_xa *xa, size_t nXa);
@@ -90,7 +103,16 @@ private:
     int boundaryCheckDP(uint32_t readLen, uint32_t pacPos, const std::string &cigar, uint64_t &tp, uint32_t &chr, std::string *newCigar) const;
     int misInfoDP(const ReadSet &rs, uint32_t r, uint32_t pos, bool negative, const std::string &engineCigar, int trim, std::string &md, int &numMis,
                   int &gapOpen, int &gapExt, int &avgQual) const;
-    struct Rec;
+    struct Rec {
+        uint32_t r = 0;
+        int flag = 0, tid = -1, mtid = -1, mapq = 0;
+        long long pos0 = -1, mpos0 = -1, isize = 0;
+        std::string cigar;                               // empty = "*"
+        bool negative = false;
+        std::string tags;                                // after RG:Z
+    };
+    struct EndView;
+    void pairRecords(const ReadSet &rs, uint32_t r1, EndView *e, int bestInsert, const std::string xa[2]);
     void emit(const ReadSet &rs, const Rec &rec);
     const HostIndex &ix;
     SamOptions opt;
@@ -100,5 +122,11 @@ private:
     int gLogN[256];
     uint64_t nRecords = 0;
 };
+
+// shared by the record writers (s3_host.cpp)
+int mdString(const HostIndex &ix, const uint8_t *query, const char *qual, uint32_t qlen, uint32_t pos, bool negative, int mismatchNum, int trim, std::string &md,
+             int &avgQual);                                  // getMdStr, PE.cpp
+int bwaLikeSingle(int x0, int x1, const int *gLogN);         // bwaLikeSingleQualScore, BGS-IO.cpp:2310
+int tableScore(int index, int avgQual, int maxMAPQ, int minMAPQ);   // maxMAPQ * mapping_score[min(index, 5)][quality class], floor minMAPQ
 
 }  // namespace s3host

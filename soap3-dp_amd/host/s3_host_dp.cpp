@@ -114,7 +114,7 @@ int SamWriter::misInfoDP(const ReadSet &rs, uint32_t r, uint32_t pos, bool negat
     // a trimmed left part moves the start on the reference; the quality array is NOT moved there (only the unused query pointer is)
     if (trim > 0) pos += (uint32_t)trim;
     (void)qlen;
-    avgQual = 40;
+    avgQual = 20;                                                         // DEFAULT_QUAL_VALUE, PE.h:27
     numMis = gapOpen = gapExt = 0;
     md.clear();
     static const char dna[] = "ACGT";
@@ -199,7 +199,7 @@ void SamWriter::singleDP(const ReadSet &rs, uint32_t r, const DpHit *hits, size_
     const std::string &useSp = boundTrim ? newSp : hits[best].cigar;
     const std::string cigar = convertCigar(useSp);
     std::string md;
-    int numMis = 0, gapOpen = 0, gapExt = 0, avgQual = 40;
+    int numMis = 0, gapOpen = 0, gapExt = 0, avgQual = 20;
     misInfoDP(rs, r, hits[best].pos, negative, useSp, boundTrim, md, numMis, gapOpen, gapExt, avgQual);
     const int editDist = gapExt + numMis;
     int mapq;

@@ -101,6 +101,15 @@ mkdir -p $OUT/dp1
   cp dp1.fq $OUT/dp1/reads.fq; cp dp1.results $OUT/dp1/results.txt
   for v in h2 h1 h2_p h1_p; do grep -v '^@PG' dp_$v.dpout.1 | gzip -9n > $OUT/dp1/dpout_$v.sam.gz; done
 )
+# output stage of the paired DP stages (default DP, deep DP): synthetic result vectors on the dp1 index -> the reference's own records
+mkdir -p $OUT/dp2
+( cd $W && python $ROOT/tools/simulate_dp_pair_results.py --index dp1.fa.index --fastq1 dp2_1.fq --fastq2 dp2_2.fq --results dp2.results --stats dp2.stats
+  sed 's/^BWALikeScore *= *1/BWALikeScore=0/' $INI > nobwa.ini
+  run() { $REF/ref_harness dppair $1 dp2.results dp2.stats pair dp1.fa.index dp2_1.fq dp2_2.fq -u 500 -v 100 -L 100 $3 -o r_$2 > /dev/null 2>&1; }
+  run $INI h2 ""; run $INI h1 "-h 1"; run $INI h2p "-p"; run $INI h1p "-h 1 -p"; run $INI h3 "-h 3"; run $INI h4p "-h 4 -p"; run nobwa.ini nb2 "-p"; run nobwa.ini nb1 "-h 1"
+  cp dp2_1.fq $OUT/dp2/reads_1.fq; cp dp2_2.fq $OUT/dp2/reads_2.fq; cp dp2.results $OUT/dp2/results.txt; cp dp2.stats $OUT/dp2/stats.txt
+  for v in h2 h1 h2p h1p h3 h4p nb2 nb1; do grep -v '^@PG' r_$v.dpout.1 | gzip -9n > $OUT/dp2/dpout_$v.sam.gz; done
+)
 ( cd $W && $REF/ref_harness models models.txt && gzip -9n < models.txt > $OUT/models.txt.gz )
 ( cd $W && $REF/ref_harness dpparams $INI dpparams.txt && gzip -9n < dpparams.txt > $OUT/dpparams.txt.gz )
 du -sh $OUT

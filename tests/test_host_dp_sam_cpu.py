@@ -1,4 +1,4 @@
-"""not gpu: SAM records of single-read DP results.  tests/golden/dp1 holds reads, DP result vectors (synthetic, tools/simulate_dp_results.py) and
+"""not gpu: SAM records of DP results (single reads: dp1; pairs: dp2).  tests/golden/dp1 holds reads, DP result vectors (synthetic, tools/simulate_dp_results.py) and
 the records the reference's own outputDPSingleResult2 / SingleDPOutputSAMAPI wrote for them (oracle/ref_harness.cpp, mode dpsingle); the
 product's writer (soap3-dp_amd/host/s3_host_dp.cpp) must reproduce every record: CIGAR conversion, boundary trimming, MD / NM, X0 / X1 /
 XM / XO / XG, XA:Z, MAPQ."""
@@ -37,3 +37,35 @@ def test_single_read_dp_records(tmp_path, variant, opts):
     assert set(mine[1]) == set(ref[1])
     bad = [(k, ref[1][k], mine[1][k]) for k in ref[1] if ref[1][k] != mine[1][k]]
     assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][1], bad[0][2])
+
+
+PAIR_TOOL = os.path.join(ROOT, "tests", "tools", "dp_pair_sam")
+
+
+def pair_tool():
+    host = os.path.join(ROOT, "soap3-dp_amd", "host")
+    src = [os.path.join(ROOT, "tests", "tools", "dp_pair_sam.cpp")] + [os.path.join(host, f) for f in ("s3_host.cpp", "s3_host_dp.cpp", "s3_host_dp_pair.cpp")]
+    if not os.path.exists(PAIR_TOOL) or os.path.getmtime(PAIR_TOOL) < max(os.path.getmtime(s) for s in src + [os.path.join(host, "s3_host.h")]):
+        lib = os.path.join(ROOT, "soap3-dp_amd")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", PAIR_TOOL] + src + ["-L" + lib, "-ls3dp", "-lz", "-lm", "-Wl,-rpath," + lib])
+    return PAIR_TOOL
+
+
+@pytest.mark.parametrize("variant,opts", [("h2", []), ("h1", ["-h", "1"]), ("h2p", ["-p"]), ("h1p", ["-h", "1", "-p"]), ("h3", ["-h", "3"]),
+                                          ("h4p", ["-h", "4", "-p"]), ("nb2", ["-p", "-B", "0"]), ("nb1", ["-h", "1", "-B", "0"])])
+def test_paired_dp_records(tmp_path, variant, opts):
+    """tests/golden/dp2: result vectors of the default DP (one end from the BWT stage) and of the deep DP (both ends from the DP) for 480
+    pairs -- equal / weaker extra results, both ends through the DP, boundary crossings, read-through pairs, BWT-stage statistics -- and
+    the records the reference's outputRead2 / pairDPOutputSAMAPI and outputDeepDPResult2 / pairDeepDPOutputSAMAPI wrote for them
+    (oracle/ref_harness.cpp, mode dppair).  nb*: the ini with BWALikeScore=0, i.e. the table-driven MAPQ rules."""
+    d = os.path.join(GOLDEN, "dp2")
+    shutil.copy(os.path.join(d, "reads_1.fq"), tmp_path / "dp2_1.fq")
+    shutil.copy(os.path.join(d, "reads_2.fq"), tmp_path / "dp2_2.fq")
+    out = subprocess.run([pair_tool(), os.path.join(GOLDEN, "dp1", "index"), "dp2_1.fq", "dp2_2.fq", os.path.join(d, "results.txt"), os.path.join(d, "stats.txt"), "out",
+                          "-L", "100"] + opts, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    mine = [l for l in open(tmp_path / "out.dpout.1").read().split("\n") if l and not l.startswith("@")]
+    ref = [l for l in gzip.open(os.path.join(d, "dpout_%s.sam.gz" % variant), "rt").read().split("\n") if l and not l.startswith("@")]
+    assert len(mine) == len(ref) == 960
+    bad = [(a, b) for a, b in zip(ref, mine) if a != b]
+    assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][0], bad[0][1])
