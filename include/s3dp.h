@@ -167,7 +167,8 @@ int  s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const 
  * (pairEndMerge: left run compressed by 50, window [insertLow - L - margin, insertHigh - L + margin]), the left end aligned first, the right
  * end's window cut by the left hit and the insert bounds (PairEndAlgnBatch::packLeft / packRight), results where both scores pass their
  * cutoffs (DP2CPUAlgnThread).  pairFirstReads: index of the first read (even) of every pair to process, ascending.  stage =
- * S3_STAGE_DEEP_DP_ROUND1 / ROUND2.  tooManyHits (optional, one byte per input pair): a seed of the pair was dropped for too many hits.
+ * S3_STAGE_DEEP_DP_ROUND1 / ROUND2.  tooManyHits (optional, one byte per input pair): bit 0 = a seed of the pair was dropped for too many hits,
+ * bit 1 = the pair had candidate positions (pairs with bit 0 and without bit 1 are what the reference seeds again in round 2, :3110-3121).
  * Arrays are malloc'ed: release with s3_free.  PARITY UNPINNED. */
 typedef struct {
     uint32_t readID;                 /* first read of the pair */
@@ -223,6 +224,11 @@ int  s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t maxHitsPerE
  * (BGS-IO.cpp:2582) walks them (sorted by position when both ends had hits).  Any output pointer may be NULL. */
 int  s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t *xaOffsets, s3_pair_xa *xa, size_t xaCap, uint64_t *nXa,
                           uint64_t *occOffsets, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis, size_t occCap, uint64_t *nOcc);
+
+/* fromSaRange[i] = 1 when occurrence i of the lists above was expanded from an SA range, 0 when it came from check-and-extend.  The
+ * reference keeps the two kinds in separate lists (SAList / OCCList) and its default-DP stage reads the SA ranges of a pair first
+ * (HalfEndOccStream::fetchNextOcc, DV-DPfunctions.cu:1901-1960), while the lists here hold the check-and-extend hits first. */
+int  s3_batch_fetch_pair_origins(s3_batch *b, uint8_t *fromSaRange, size_t cap);
 
 int  s3_batch_sync(s3_batch *b);
 /* device time of the work enqueued by the last search/align call, measured with HIP events on the batch stream;

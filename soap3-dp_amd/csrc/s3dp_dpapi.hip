@@ -542,6 +542,14 @@ extern "C" int s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint
     merge(arr[0][leftLeg - 1], arr[1][rightLeg - 1], 0);                            // read left, mate right
     merge(arr[1][leftLeg - 1], arr[0][rightLeg - 1], 1);                            // mate left, read right
     std::stable_sort(cands.begin(), cands.end(), [](const PairCand &x, const PairCand &y) { return x.readIDLeft < y.readIDLeft; });
+    // bit 1 of the per-pair flag: the pair has candidates (alignFlags of performSeeding, :3110-3121 -- only pairs WITHOUT candidates are
+    // seeded again in round 2 or handed on as unseeded)
+    if (tooManyHitsOut)
+        for (const PairCand &c : cands) {
+            const uint32_t even = c.readIDLeft & ~1u;
+            const uint32_t *it = std::lower_bound(pairFirstReads, pairFirstReads + nPairs, even);
+            if (it != pairFirstReads + nPairs && *it == even) tooMany[(size_t)(it - pairFirstReads)] |= 2;
+        }
     // ---- two DP rounds per batch of candidates ---------------------------------------------------------------------------------------
     HIPCHK(hipSetDevice(h->dev));
     const uint32_t fullDNALength = b->ix->d.n;

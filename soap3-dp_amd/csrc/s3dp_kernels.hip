@@ -448,7 +448,7 @@ __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffset
         else {
             uint32_t cnt = r.w - r.z + 1u;
             if (total + cnt > a.maxOut) cnt = a.maxOut - total;
-            for (uint32_t q = 0; q < cnt; q++) { occPos[oSa] = ix.sa[r.z + q]; occMeta[oSa] = meta; oSa++; }
+            for (uint32_t q = 0; q < cnt; q++) { occPos[oSa] = ix.sa[r.z + q]; occMeta[oSa] = meta | 0x10000u; oSa++; }   // bit 16: came out of an SA range
             total += cnt;
         }
     }

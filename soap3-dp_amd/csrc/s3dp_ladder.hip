@@ -515,3 +515,16 @@ extern "C" int s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t
     return S3_OK;
 }
 
+extern "C" int s3_batch_fetch_pair_origins(s3_batch *b, uint8_t *fromSaRange, size_t cap)
+{
+    if (!b || b->lastKind != 3 || !fromSaRange) return fail(S3_EINVAL, "s3_batch_fetch_pair_origins: no paired-end result pending");
+    int rc = s3_batch_sync(b);
+    if (rc) return rc;
+    uint32_t total = 0;
+    HIPCHK(hipMemcpy(&total, b->dOutOffsets + b->n, 4, hipMemcpyDeviceToHost));
+    if (total > cap) return fail(S3_EOVERFLOW, "s3_batch_fetch_pair_origins: array too small");
+    std::vector<uint32_t> meta(total ? total : 1);
+    if (total) HIPCHK(hipMemcpy(meta.data(), b->dOutMeta, (size_t)total * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < total; i++) fromSaRange[i] = (uint8_t)((meta[i] >> 16) & 1u);
+    return S3_OK;
+}

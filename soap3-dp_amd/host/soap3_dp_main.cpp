@@ -98,6 +98,201 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
     fseeko(out, (off_t)off[(size_t)T], SEEK_SET);
 }
 
+// ---- DP stages of a paired-end batch (soap3_dp_pair_align after the BWT ladder, alignment.cu:2021-2420) --------------------------------------
+struct PairDpCtx {
+    const HostIndex &hix; const SamOptions &so; const ReadSet &rs; const Ini &ini;
+    s3_batch *b, *seedBatch; s3_dp *dp, *dpHalf; FILE *dpOut, *unpairOut;
+    uint32_t first, cnt; int alignmentType, insertLow, insertHigh;
+    const s3_dp_stage_params *halfPar; const s3_dp_stage_params (*deepPar)[2];
+};
+
+// Routing of the pairs the ladder left without a proper pairing (hostKernel with needProceedDP, CPUfunctions.cpp:2153-2262, 2444-2543), the default
+// DP on the half-aligned ones (semiGlobalDP2 -> HalfEndAlignmentEngine -> DPOutputThread -> outputRead2), the deep DP on the rest
+// (DPForUnalignPairs2: seeding round 1, round 2 for the pairs that only lost seeds to the hit limit, PairEndAlignmentEngine ->
+// outputDeepDPResult2).  NOT built: the new default DP for ends with too many hits (newSemiGlobalDP; such pairs go to the deep DP here) and the
+// single-end DP of the ends of pairs every stage failed on (DPForUnalignSingle2 + outputSingleResultForPairEnds): those pairs are written to
+// <prefix>.unpair with what the BWT stage knows about them (unproperlypairOutputSAMAPI).
+static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &pr, const std::vector<uint64_t> &ooff, const std::vector<uint32_t> &pos,
+                         const std::vector<uint8_t> &strand, const std::vector<uint8_t> &mis, const std::vector<uint8_t> &fromSa, uint64_t &defaultDpPairs,
+                         uint64_t &deepDpPairs, uint64_t &leftoverPairs, std::string &err)
+{
+    const uint32_t np = c.cnt / 2;
+    const bool mapqMode = c.alignmentType == 1 || c.alignmentType == 2;
+    const int moduleType = c.alignmentType == 2 ? 1 : c.alignmentType;          // all-best + SAM runs the DP module as all-valid (alignment.cu:2023-2030)
+    const uint32_t maxHit[2] = {(uint32_t)c.halfPar[0].maxHitNum, (uint32_t)c.halfPar[1].maxHitNum};
+    const uint32_t *lens = c.rs.lengths.data() + c.first;
+    std::vector<s3_occ> dpOcc;
+    std::vector<uint32_t> deepPairs;                                             // first read (batch index) of the pairs for the deep DP
+    std::vector<uint8_t> inDefault(np, 0);
+    // an end's hits in the order the reference hands them on: half-aligned pairs keep SA ranges and check-and-extend hits apart and the DP input
+    // stream reads the SA ranges first; with hits on both ends everything was merged and sorted by position for the pairing attempt
+    auto endHits = [&](uint32_t r, bool saFirst, std::vector<s3_occ> &out) {
+        out.clear();
+        const size_t o = ooff[r], n = ooff[r + 1] - o;
+        for (int pass = saFirst ? 0 : 1; pass < 2; pass++)
+            for (size_t k = 0; k < n; k++) {
+                if (saFirst && (fromSa[o + k] != 0) != (pass == 0)) continue;
+                s3_occ x{}; x.readID = r; x.pos = pos[o + k]; x.strand = strand[o + k]; x.mismatchCount = mis[o + k];
+                out.push_back(x);
+            }
+    };
+    auto retainBest = [&](std::vector<s3_occ> &v) {                              // retainAllBestAndSecBest / retainAllBest, SAList.cpp:140,290
+        uint8_t mn = 255;
+        for (const s3_occ &x : v) mn = std::min(mn, x.mismatchCount);
+        size_t w = 0;
+        for (const s3_occ &x : v) if (x.mismatchCount <= mn + (mapqMode ? 1 : 0)) v[w++] = x;
+        v.resize(w);
+    };
+    std::vector<s3_occ> h1, h2;
+    for (uint32_t p = 0; p < np; p++) {
+        if (pr[p].phase) continue;
+        const uint32_t r1 = 2 * p, r2 = r1 + 1;
+        const size_t n1 = ooff[r1 + 1] - ooff[r1], n2 = ooff[r2 + 1] - ooff[r2];
+        if (n1 == 0 && n2 == 0) { deepPairs.push_back(r1); continue; }
+        if (n1 == 0 || n2 == 0) {
+            const int e = n1 ? 0 : 1;
+            endHits(e ? r2 : r1, true, h1);
+            if (h1.size() > maxHit[e]) retainBest(h1);
+            if (h1.size() <= maxHit[e]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; }
+            else deepPairs.push_back(r1);                                            // reference: new default DP
+            continue;
+        }
+        endHits(r1, false, h1); endHits(r2, false, h2);
+        if (h1.size() > maxHit[0]) retainBest(h1);
+        if (h2.size() > maxHit[1]) retainBest(h2);
+        if (h1.size() <= maxHit[0] && h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; }
+        else if (h1.size() < h2.size()) { if (h1.size() <= maxHit[0]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else deepPairs.push_back(r1); }
+        else { if (h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; } else deepPairs.push_back(r1); }
+    }
+    auto statsOf = [&](uint32_t p, BwtEndStats st[2]) {
+        st[0] = BwtEndStats(); st[1] = BwtEndStats();
+        if (pr[p].min1 != 255) { st[0].x0 = (int)pr[p].x0_1; st[0].x1 = (int)pr[p].x1_1; st[0].mismatch = pr[p].min1; }
+        if (pr[p].min2 != 255) { st[1].x0 = (int)pr[p].x0_2; st[1].x1 = (int)pr[p].x1_2; st[1].mismatch = pr[p].min2; }
+    };
+    SamWriter w(c.hix, c.so, c.dpOut);
+    // ---- default DP ----
+    if (!dpOcc.empty()) {
+        s3_dp_half_result *res = nullptr;
+        size_t nRes = 0;
+        char *pool = nullptr;
+        const int cut[2] = {c.halfPar[0].cutoffThreshold, c.halfPar[1].cutoffThreshold};
+        if (s3_dp_half_end(c.dpHalf, c.b, lens, dpOcc.data(), dpOcc.size(), c.insertLow, c.insertHigh, cut, c.halfPar[0].softClipLeft, c.halfPar[0].softClipRight, &res, &nRes,
+                           &pool) != S3_OK) { err = s3_last_error(); return false; }
+        std::vector<uint8_t> done(np, 0);
+        for (size_t i = 0; i < nRes;) {
+            size_t j = i;
+            while (j < nRes && res[j].readID == res[i].readID) j++;
+            // OutputBuffer::ready(OUTPUT_AS_INPUT_ORDER | DO_NOT_OUTPUT_HALF_ALIGNED), DV-DPfunctions.h:367-412 with ScoreCompare<AlgnmtDPResult> (:886)
+            std::vector<PairDpHit> hits;
+            auto value = [](const s3_dp_half_result &x) -> uint64_t {
+                uint64_t al, mm, sc;
+                if (x.whichFromDP == 0) { al = 1; mm = (uint32_t)x.score_2; sc = (uint32_t)x.score_1; }
+                else if (x.whichFromDP == 1) { al = 1; mm = (uint32_t)x.score_1; sc = (uint32_t)x.score_2; }
+                else { al = 0; mm = (uint32_t)(x.algnmt_1 != 0xFFFFFFFFu ? x.score_1 : x.score_2); sc = 0; }
+                return al << 63 | (uint64_t)(uint32_t)(0x1FFFFFFFu - (uint32_t)mm) << 32 | (uint32_t)((uint32_t)sc + 0x1FFFFFFFu);
+            };
+            uint64_t bestV = 0;
+            if (moduleType != 1) for (size_t q = i; q < j; q++) bestV = std::max(bestV, value(res[q]));
+            for (size_t q = i; q < j; q++) {
+                if (moduleType == 1 ? res[q].whichFromDP >= 2 : value(res[q]) != bestV) continue;
+                PairDpHit h;
+                h.pos1 = res[q].algnmt_1; h.pos2 = res[q].algnmt_2; h.strand1 = res[q].strand_1; h.strand2 = res[q].strand_2; h.whichFromDP = res[q].whichFromDP;
+                h.score1 = res[q].score_1; h.score2 = res[q].score_2; h.editdist = (int)res[q].editdist; h.insertSize = (int)res[q].insertSize;
+                h.numSameScore = (int)res[q].num_sameScore;
+                if (res[q].cigarOffset != 0xFFFFFFFFu) h.cigar = pool + res[q].cigarOffset;
+                hits.push_back(h);
+            }
+            if (moduleType == 3 && hits.size() != 1) hits.clear();
+            if (moduleType == 4 && hits.size() > 1) hits.resize(1);
+            const uint32_t p = res[i].readID / 2;
+            if (!hits.empty() && hits[0].whichFromDP < 2) {
+                BwtEndStats st[2];
+                statsOf(p, st);
+                w.pairDP(c.rs, c.first + res[i].readID, hits.data(), hits.size(), st);
+                done[p] = 1;
+                defaultDpPairs++;
+            }
+            i = j;
+        }
+        s3_free(res); s3_free(pool);
+        for (uint32_t p = 0; p < np; p++) if (inDefault[p] && !done[p]) deepPairs.push_back(2 * p);
+        std::sort(deepPairs.begin(), deepPairs.end());
+    }
+    // ---- deep DP ----
+    std::vector<uint8_t> deepDone(np, 0);
+    if (!deepPairs.empty()) {
+        std::vector<uint32_t> todo = deepPairs;
+        for (int round = 0; round < 2 && !todo.empty(); round++) {
+            s3_dp_deep_result *res = nullptr;
+            size_t nRes = 0;
+            char *pool = nullptr;
+            uint8_t *flags = nullptr;
+            const s3_dp_stage_params *par = c.deepPar[round];
+            const int cut[2] = {par[0].cutoffThreshold, par[1].cutoffThreshold};
+            // seeds go through the seed batch in pieces (at most 12 seeds per read below 400 bases)
+            std::vector<uint32_t> next;
+            const size_t piece = 8192;
+            for (size_t at = 0; at < todo.size(); at += piece) {
+                const size_t m = std::min(piece, todo.size() - at);
+                if (s3_dp_deep(c.dp, c.b, c.seedBatch, lens, todo.data() + at, m, round == 0 ? S3_STAGE_DEEP_DP_ROUND1 : S3_STAGE_DEEP_DP_ROUND2, (uint32_t)par[0].maxHitNum,
+                               c.insertLow, c.insertHigh, cut, par[0].softClipLeft, par[0].softClipRight, &res, &nRes, &pool, &flags) != S3_OK) { err = s3_last_error(); return false; }
+                for (size_t k = 0; k < m; k++) if (round == 0 && flags[k] == 1) next.push_back(todo[at + k]);
+                for (size_t i = 0; i < nRes;) {
+                    size_t j = i;
+                    while (j < nRes && res[j].readID / 2 == res[i].readID / 2) j++;
+                    // OutputBuffer::ready(): sorted by the first end's position, one result per position; best only for -h 3 / 4 (ScoreCompare: score sum)
+                    std::vector<DeepDpHit> hits;
+                    for (size_t q = i; q < j; q++) {
+                        DeepDpHit h;
+                        h.pos1 = res[q].algnmt_1; h.pos2 = res[q].algnmt_2; h.strand1 = res[q].strand_1; h.strand2 = res[q].strand_2;
+                        h.score1 = res[q].score_1; h.score2 = res[q].score_2; h.editdist1 = (int)res[q].editdist_1; h.editdist2 = (int)res[q].editdist_2;
+                        h.insertSize = (int)res[q].insertSize; h.numSame1 = (int)res[q].num_sameScore_1; h.numSame2 = (int)res[q].num_sameScore_2;
+                        if (res[q].cigarOffset_1 != 0xFFFFFFFFu) h.cigar1 = pool + res[q].cigarOffset_1;
+                        if (res[q].cigarOffset_2 != 0xFFFFFFFFu) h.cigar2 = pool + res[q].cigarOffset_2;
+                        hits.push_back(h);
+                    }
+                    std::stable_sort(hits.begin(), hits.end(), [](const DeepDpHit &x, const DeepDpHit &y) { return x.pos1 < y.pos1; });
+                    size_t u = 0;
+                    for (size_t q = 1; q < hits.size(); q++) if (hits[u].pos1 < hits[q].pos1) hits[++u] = hits[q];
+                    hits.resize(u + 1);
+                    if (moduleType != 1) {
+                        int best = hits[0].score1 + hits[0].score2;
+                        for (const DeepDpHit &h : hits) best = std::max(best, h.score1 + h.score2);
+                        size_t w2 = 0;
+                        for (const DeepDpHit &h : hits) if (h.score1 + h.score2 == best) hits[w2++] = h;
+                        hits.resize(w2);
+                        if (moduleType == 3 && hits.size() != 1) hits.clear();
+                        if (moduleType == 4) hits.resize(1);
+                    }
+                    const uint32_t p = res[i].readID / 2;
+                    if (!hits.empty()) {
+                        BwtEndStats st[2];
+                        statsOf(p, st);
+                        w.pairDeepDP(c.rs, c.first + 2 * p, hits.data(), hits.size(), st);
+                        deepDone[p] = 1;
+                        deepDpPairs++;
+                    }
+                    i = j;
+                }
+                s3_free(res); s3_free(pool); s3_free(flags);
+            }
+            todo.swap(next);
+        }
+    }
+    // ---- what every stage failed on ----
+    SamWriter up(c.hix, c.so, c.unpairOut);
+    for (uint32_t r1 : deepPairs) {
+        const uint32_t p = r1 / 2;
+        if (deepDone[p]) continue;
+        const uint32_t r2 = r1 + 1;
+        const size_t o1 = ooff[r1], n1 = ooff[r1 + 1] - o1, o2 = ooff[r2], n2 = ooff[r2 + 1] - o2;
+        up.improperPair(c.rs, c.first + r1, c.first + r2, pos.data() + o1, strand.data() + o1, mis.data() + o1, n1, pos.data() + o2, strand.data() + o2, mis.data() + o2, n2,
+                        c.ini.maxHitsEachEndForPairing);
+        leftoverPairs++;
+    }
+    return true;
+}
+
 static int die(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); return 1; }
 
 int main(int argc, char **argv)
@@ -133,7 +328,6 @@ int main(int argc, char **argv)
             if (i + 1 < argc && argv[i + 1][0] >= '0' && argv[i + 1][0] <= '9') numMismatch = atoi(argv[++i]);
         } else return die("unknown option " + a);
     }
-    if (enableDP && paired) return die("the DP stages of paired-end runs are not wired into this program yet (the engines exist behind the C-ABI): run with -s <k>");
     if (outputFormat != 2) return die("only SAM output (-b 2) is built");
     if (alignmentType < 1 || alignmentType > 4) return die("The output option should be 1, 2, 3 or 4");
     if (maxReadLength > S3_MAX_READ_LENGTH) return die("The length should not be greater than 1024");
@@ -155,11 +349,21 @@ int main(int argc, char **argv)
     if (numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;          // getDefaultMismatchNum, CPUfunctions.cpp:26-35
     // DP enabled (the default): the BWT stage runs with Soap3MisMatchAllow mismatches (SOAP3-DP.cu:208-213); reads it leaves unaligned go
     // through seeding + DP and are reported in <prefix>.dpout.1.  Too short reads switch the DP off (SOAP3-DP.cu:643-652).
-    uint32_t detectedReadLength = 0;                                       // GetReadLength: the longest of the first ten reads
-    for (uint32_t i = 0; i < rs.n && i < 10; i++) detectedReadLength = std::max(detectedReadLength, rs.lengths[i]);
+    uint32_t detectedReadLength = 0, detectedReadLength2 = 0;              // GetReadLength: the longest of the first ten reads (of each end)
+    if (!paired) for (uint32_t i = 0; i < rs.n && i < 10; i++) detectedReadLength = std::max(detectedReadLength, rs.lengths[i]);
+    else
+        for (uint32_t i = 0, k = 0; i + 1 < rs.n && k < 10; i += 2, k++) {
+            detectedReadLength = std::max(detectedReadLength, rs.lengths[i]);
+            detectedReadLength2 = std::max(detectedReadLength2, rs.lengths[i + 1]);
+        }
+    if (paired && insertLow < (int)detectedReadLength2) insertLow = (int)detectedReadLength2;   // SOAP3-DP.cu:632-634
     if (enableDP) {
         numMismatch = ini.soap3MisMatchAllow;
-        if (detectedReadLength < 30) { enableDP = false; printf("Dynamic programming is disabled because read length < %i\n", 30); }
+        if (detectedReadLength < 30 || (paired && detectedReadLength2 < 30)) { enableDP = false; printf("Dynamic programming is disabled because read length < %i\n", 30); }
+        else if (paired && (detectedReadLength > 150 || detectedReadLength2 > 150))
+            return die("reads longer than 150 bases skip the BWT stage in paired-end DP runs (SOAP3-DP.cu:658-662): that path is not built, run with -s <k>");
+        else if (paired && (detectedReadLength <= 50 || detectedReadLength2 <= 50)) numMismatch = 1;   // SOAP3-DP.cu:663-666
+        if (!enableDP && numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;
     }
     s3_index *ix = nullptr;
     s3_index_desc d = hix.desc();
@@ -179,8 +383,10 @@ int main(int argc, char **argv)
     FILE *dpOut = nullptr;
     s3_dp *dp = nullptr;
     s3_batch *seedBatch = nullptr;
-    s3_dp_stage_params dpPar{};
-    uint64_t dpAlignedReads = 0;
+    s3_dp_stage_params dpPar{}, halfPar[2] = {}, deepPar[2][2] = {};
+    s3_dp *dpHalf = nullptr;
+    FILE *unpairOut = nullptr;
+    uint64_t dpAlignedReads = 0, defaultDpPairs = 0, deepDpPairs = 0, leftoverPairs = 0;
     if (enableDP) {
         const std::string dpName = prefix + ".dpout.1";
         dpOut = fopen(dpName.c_str(), "w");
@@ -195,6 +401,23 @@ int main(int argc, char **argv)
         s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
         if (s3_dp_create(device, 32768, (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &dp) != S3_OK) return die(s3_last_error());
         if (s3_batch_create(ix, 262144 + 64, 8, &seedBatch) != S3_OK) return die(s3_last_error());
+        if (paired) {
+            // default DP (half-aligned pairs): HalfEndAlignmentEngine::performAlignment sizes, DV-DPfunctions.cu:2221-2224
+            const int maxDNAHalf = insertHigh - insertLow + maxReadLength + 1;
+            s3_dp_config(maxRL, maxDNAHalf, 1, &scheme, &tableLen, &patLen);
+            if (s3_dp_create(device, 32768, (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &dpHalf) != S3_OK) return die(s3_last_error());
+            s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength, &di, &halfPar[0]);
+            s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength2, &di, &halfPar[1]);
+            for (int e = 0; e < 2; e++) {
+                s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND1, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[0][e]);
+                s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND2, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[1][e]);
+            }
+            const std::string upName = prefix + ".unpair";
+            unpairOut = fopen(upName.c_str(), "w");
+            if (!unpairOut) return die("Could not open the output file " + upName);
+            SamWriter upHdr(hix, so, unpairOut);
+            upHdr.header();
+        }
     }
     const uint32_t maxBatch = 1u << 22;
     s3_batch *b = nullptr;
@@ -223,12 +446,21 @@ int main(int argc, char **argv)
                 if (pr[p].phase) {
                     if (!(alignmentType == 3 && pr[p].numMin != 1)) al += 2;
                     w.properPair(rs, r1, r2, pr[p], xa.data() + xoff[p], (size_t)(xoff[p + 1] - xoff[p]));
+                } else if (enableDP) {
+                    return;                                                          // goes to the DP stages
                 } else {
                     const size_t o1 = ooff[2 * p], n1 = ooff[2 * p + 1] - o1, o2 = ooff[2 * p + 1], n2 = ooff[2 * p + 2] - o2;
                     w.improperPair(rs, r1, r2, pos.data() + o1, strand.data() + o1, mis.data() + o1, n1, pos.data() + o2, strand.data() + o2, mis.data() + o2, n2,
                                    ini.maxHitsEachEndForPairing);
                 }
             }, aligned);
+            if (enableDP) {
+                PairDpCtx c{hix, so, rs, ini, b, seedBatch, dp, dpHalf, dpOut, unpairOut, first, cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar};
+                std::vector<uint8_t> fromSa(nOcc ? nOcc : 1);
+                if (s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return die(s3_last_error());
+                std::string e2;
+                if (!pairDpStages(c, pr, ooff, pos, strand, mis, fromSa, defaultDpPairs, deepDpPairs, leftoverPairs, e2)) return die(e2);
+            }
             continue;
         }
         std::vector<uint32_t> seeds;
@@ -323,7 +555,13 @@ int main(int argc, char **argv)
     fclose(out);
     if (dpOut) {
         fclose(dpOut);
-        printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)dpAlignedReads);
+        if (paired) {
+            fclose(unpairOut);
+            printf("[Main] Number of pairs aligned by DP: %llu\n[Main] Number of pairs aligned by deep DP: %llu\n[Main] Pairs left without a proper pairing: %llu\n",
+                   (unsigned long long)defaultDpPairs, (unsigned long long)deepDpPairs, (unsigned long long)leftoverPairs);
+            dpAlignedReads = 2 * (defaultDpPairs + deepDpPairs);
+            s3_dp_free(dpHalf);
+        } else printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)dpAlignedReads);
         aligned += dpAlignedReads;
         s3_dp_free(dp);
         s3_batch_free(seedBatch);

@@ -189,3 +189,92 @@ def test_cli_default_mode_single_reads_with_dp(tmp_path):
         ok[shape] += good
     assert ok["D"] >= 0.8 * tot["D"] and ok["I"] >= 0.8 * tot["I"] and ok["sub"] >= 0.6 * tot["sub"], (ok, tot)   # repeats and spoiled seeds take their share
     assert "Number of reads aligned by DP" in out.stdout
+
+
+def test_cli_default_mode_pairs_with_dp(tmp_path):
+    """`soap3-dp pair <index> <r1> <r2> -u 500 -v 100` without -s: the BWT ladder pairs what it can (.gout.1); pairs with one damaged end go
+    through the default DP (mate rescue next to the aligned end), pairs with two damaged ends through the deep DP (seeding both ends), both into
+    .dpout.1; what is left goes to .unpair.  The record writers are pinned (tests/golden/dp2), the engines are not: the check is semantic --
+    every pair is reported once as two records, rescued mates sit at their true place with a CIGAR of the expected shape and proper-pair flags."""
+    import re
+    import numpy as np
+    name = "g1"
+    rng = np.random.default_rng(21)
+    chroms, cur = {}, None
+    for l in open(os.path.join(GOLDEN, name, "genome.fa")):
+        if l.startswith(">"):
+            cur = l[1:].split()[0]
+            chroms[cur] = []
+        else:
+            chroms[cur].append(l.strip())
+    chroms = {k: "".join(v) for k, v in chroms.items()}
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+    L = 100
+
+    def damage(seg, kind):
+        if kind == "exact":
+            return seg[:L]
+        if kind == "D":
+            c = int(rng.integers(30, 70))
+            return seg[:c] + seg[c + 3:L + 3]
+        if kind == "I":
+            c = int(rng.integers(30, 70))
+            return seg[:c] + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=2)) + seg[c:L - 2]
+        b = list(seg[:L])
+        for q in rng.choice(np.arange(5, L - 5), size=6, replace=False):
+            b[q] = "ACGT"[("ACGT".index(b[q]) + 1 + int(rng.integers(0, 3))) % 4]
+        return "".join(b)
+    names = sorted(chroms)
+    r1s, r2s, truth = [], [], []
+    kinds = [("exact", "exact"), ("exact", "D"), ("I", "exact"), ("exact", "sub"), ("D", "I"), ("sub", "D")]
+    while len(r1s) < 360:
+        ch = names[int(rng.integers(0, len(names)))]
+        ins = int(rng.integers(250, 450))
+        st = int(rng.integers(0, len(chroms[ch]) - ins - 20))
+        left, right = chroms[ch][st:st + L + 10], chroms[ch][st + ins - L:st + ins + 10]
+        if "N" in left or "N" in right or len(right) < L + 10:
+            continue
+        kl, kr = kinds[len(r1s) % len(kinds)]
+        a, b = damage(left, kl), rc(damage(right, kr))
+        swap = bool(rng.integers(0, 2))                       # which file holds the '+' end
+        r1s.append(b if swap else a); r2s.append(a if swap else b)
+        truth.append((ch, st + 1, st + ins - L + 1, swap, kl, kr))
+    for fn, rr, tag in (("r1.fq", r1s, 1), ("r2.fq", r2s, 2)):
+        with open(tmp_path / fn, "w") as f:
+            for i, s in enumerate(rr):
+                f.write("@p%d/%d\n%s\n+\n%s\n" % (i, tag, s, "I" * len(s)))
+    out = subprocess.run([BIN, "pair", os.path.join(GOLDEN, name, "index"), "r1.fq", "r2.fq", "-u", "500", "-v", "100", "-L", "100", "-o", "out"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    recs = {}
+    for src in ("gout.1", "dpout.1", "unpair"):
+        for l in open(tmp_path / ("out." + src)):
+            if l.startswith("@"):
+                continue
+            f = l.rstrip("\n").split("\t")
+            recs.setdefault(f[0], []).append((src, f))
+    assert sorted(recs) == sorted("p%d" % i for i in range(len(r1s)))
+    assert all(len(v) == 2 and v[0][0] == v[1][0] for v in recs.values()), "every pair: two records in one file"
+    ok, tot = {}, {}
+    for i, (ch, lp, rp, swap, kl, kr) in enumerate(truth):
+        src, _ = recs["p%d" % i][0]
+        key = "%s/%s" % (kl, kr)
+        tot[key] = tot.get(key, 0) + 1
+        fl = {int(f[1]) & 0xC0: f for _, f in recs["p%d" % i]}
+        fa, fb = (fl[0x80], fl[0x40]) if swap else (fl[0x40], fl[0x80])      # record of the '+' (left) end, of the '-' (right) end
+        if key == "exact/exact":
+            assert src == "gout.1"
+        else:
+            assert src != "gout.1"
+        if src == "unpair":
+            continue
+        good = int(fa[1]) & 2 and int(fb[1]) & 2 and fa[2] == ch and fb[2] == ch and abs(int(fa[3]) - lp) <= 3 and abs(int(fb[3]) - rp) <= 3
+        good = good and not int(fa[1]) & 16 and int(fb[1]) & 16
+        for f, k in ((fa, kl), (fb, kr)):
+            ops = re.sub(r"\d+", "", f[5])
+            good = good and ops == {"exact": "M", "sub": "M", "D": "MDM", "I": "MIM"}[k]
+        ok[key] = ok.get(key, 0) + bool(good)
+    for key in tot:
+        assert ok.get(key, 0) >= 0.75 * tot[key], (ok, tot)
+    assert "Number of pairs aligned by DP" in out.stdout and "aligned by deep DP" in out.stdout
