@@ -1,12 +1,13 @@
-// soap3-dp -- drop-in command line for the alignment path (single-end; paired-end with the DP stages off), same arguments, .ini keys and index files as
+// soap3-dp -- drop-in command line for the alignment path (single-end and paired-end, DP stages on or off), same arguments, .ini keys and index files as
 // the reference program (SOAP3-DP.cu main, IniParam.cpp:237-767), driving the MI355X kernels through the C-ABI of libs3dp.so.
 //
 //   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
-//   soap3-dp pair   <index prefix> <reads 1> <reads 2> [-u maxInsert] [-v minInsert] -s k [the same options]
+//   soap3-dp pair   <index prefix> <reads 1> <reads 2> [-u maxInsert] [-v minInsert] [-s k] [the same options]
 // Without -s the DP stages are on (the reference's default): single reads the BWT stage leaves unaligned go through seeding + semi-global DP
-// and are written to <prefix>.dpout.1.
+// and are written to <prefix>.dpout.1; pairs without a proper pairing go through the default DP (mate rescue next to an aligned end) or the deep
+// DP (both ends seeded) into <prefix>.dpout.1, the rest into <prefix>.unpair (pairDpStages below says which reference stages are missing).
 //
-// Output: <prefix>.gout.1 (SAM), <prefix>.done, like SOAP3-DP.cu:251-258 with NumOfCpuThreads = 1.
+// Output: <prefix>.gout.1 (SAM), <prefix>.dpout.1, <prefix>.unpair, <prefix>.done, like SOAP3-DP.cu:251-258 with NumOfCpuThreads = 1.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
