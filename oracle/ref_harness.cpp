@@ -836,6 +836,7 @@ static int modeDpPair ( int argc, char ** argv )
     fclose ( f );
     std::vector<AlgnmtDPResult> dres;
     std::vector<DeepDPAlignResult> pres;
+    std::vector<SingleAlgnmtResult> ures;
     f = fopen ( resultFile, "r" );
 
     if ( !f ) { fprintf ( stderr, "cannot open %s\n", resultFile ); return 1; }
@@ -844,7 +845,19 @@ static int modeDpPair ( int argc, char ** argv )
 
     while ( fscanf ( f, "%7s", kind ) == 1 )
     {
-        if ( kind[0] == 'D' )
+        if ( kind[0] == 'U' )
+        {
+            SingleAlgnmtResult r;
+            int s1, fromDP;
+            memset ( &r, 0, sizeof ( r ) );
+
+            if ( fscanf ( f, "%u %d %u %d %d %d %4095s", &r.readID, &fromDP, &r.algnmt, &s1, &r.score, &r.editdist, cigar ) != 7 ) { fprintf ( stderr, "bad U line\n" ); return 1; }
+
+            r.strand = ( char ) s1; r.num_sameScore = fromDP;      // carried to the patch below
+            r.cigarString = cigar[0] == '*' ? NULL : strdup ( cigar );
+            ures.push_back ( r );
+        }
+        else if ( kind[0] == 'D' )
         {
             AlgnmtDPResult r;
             int which, s1, s2;
@@ -897,6 +910,46 @@ static int modeDpPair ( int argc, char ** argv )
         outputDeepDPResult2 ( &pres[i], ( unsigned int ) ( j - i ), R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities,
                               C.opt.maxReadLength, 0, SRA_OUTPUT_FORMAT_SAM_API, NULL, C.samOut, C.index, C.ini.Ini_PEStrandLeftLeg, C.ini.Ini_PEStrandRightLeg );
         i = j;
+    }
+
+    // U lines: the hits each end of a leftover pair has on its own (fromDP 1: single-end DP, 0: carried over from the BWT stage), through the
+    // reference's AllHits store and outputSingleResultForPairEnds (OutputDPResult.cpp:1062) -> unproperlypairDPOutputSAMAPI (BGS-IO.cpp:2932)
+    if ( !ures.empty () )
+    {
+        uint detected = GetReadLength ( R.readLengths, R.numQueries, 10 );
+        DPParameters dp;
+        memset ( &dp, 0, sizeof ( dp ) );
+        getParameterForAllDP ( dp, C.opt, C.ini );
+        getParameterForSingleDP ( dp, C.opt, C.ini, detected );
+        hspaux->singleDPcutoffThreshold = dp.paramRead[0].cutoffThreshold;
+        AllHits * allHits = ( AllHits * ) hspaux->allHits;
+        resetAllHits ( allHits );
+
+        for ( size_t i = 0; i < ures.size (); )
+        {
+            size_t j = i;
+
+            while ( j < ures.size () && ures[j].readID == ures[i].readID ) { j++; }
+
+            unsigned int before = allHits->hitNum;
+            inputAlgnmtsToArray ( allHits, &ures[i], ( int ) ( j - i ) );
+            unsigned int at = before;
+
+            for ( size_t q = i; q < j; q++ )
+            {
+                if ( ures[q].algnmt == 0xFFFFFFFF ) { continue; }
+
+                allHits->hitArray[at].isFromDP = ures[q].num_sameScore;
+                allHits->hitArray[at].num_sameScore = ures[q].num_sameScore ? 1 : 0;
+                at++;
+            }
+
+            i = j;
+        }
+
+        sortReadPtrs ( allHits );
+        outputSingleResultForPairEnds ( allHits, R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities, C.opt.maxReadLength, 0, SRA_OUTPUT_FORMAT_SAM_API,
+                                        C.samOut, C.index );
     }
 
     samclose ( C.samOut );

@@ -58,7 +58,9 @@ struct SamOptions {
 };
 
 // one DP result of a read, as the DP engines return it (SingleAlgnmtResult, PEAlgnmt.h:434); cigar in the engine's dialect ('m' = mismatch run)
-struct DpHit { uint32_t pos; uint8_t strand; int score, editdist; std::string cigar; };
+// fromDP = false: a hit of the BWT stage carried into the pair leftover records (inputSoap3AnsToArray, PEAlgnmt.cpp:1180: score = L x match + mismatches x
+// mismatch score, editdist = mismatches, cigar "<L>M")
+struct DpHit { uint32_t pos; uint8_t strand; int score, editdist; std::string cigar; bool fromDP = true; };
 
 // one result of the default DP for a pair (AlgnmtDPResult, PEAlgnmt.h:384): one end from the BWT stage (score = mismatches), the other from the
 // DP (score = DP score; cigar / editdist / numSameScore belong to it); whichFromDP 0: first end, 1: second end, 2: the DP found nothing
@@ -88,7 +90,10 @@ public:
     void pairDP(const ReadSet &rs, uint32_t r1, const PairDpHit *hits, size_t n, const BwtEndStats st[2]);
     // the deep-DP results of one pair (outputDeepDPResult2, OutputDPResult.cpp:564-845; pairDeepDPOutputSAMAPI, BGS-IO.cpp:3824-4502)
     void pairDeepDP(const ReadSet &rs, uint32_t r1, const DeepDpHit *hits, size_t n, const BwtEndStats st[2]);
-    static std::string convertCigar(const std::string &engineCigar);                             // convertToCigarStr, PE.cpp:421
+    // a pair no stage could pair: each end with the hits it has on its own -- from the single-end DP or from the BWT stage -- scored like single
+    // reads (outputSingleResultForPairEnds, OutputDPResult.cpp:1062; unproperlypairDPOutputSAMAPI, BGS-IO.cpp:2932-3390)
+    void unpairedDP(const ReadSet &rs, uint32_t r1, const DpHit *hits1, size_t n1, const DpHit *hits2, size_t n2, int singleDPcutoffThreshold);
+    static std::string convertCigar(const std::string &engineCigar, int *deletedEnd = nullptr);                             // convertToCigarStr, PE.cpp:421
     // a pair with a proper pairing (pairOutputSAMAPI, BGS-IO.cpp:3478): reads r1 = 2p, r2 = 2p+1; xa = the other optimal pairings
     void properPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const s3_pair_result &P, const s3_pair_xa *xa, size_t nXa);
     // a pair without one (unproperlypairOutputSAMAPI, BGS-IO.cpp:2582): the occurrence lists of both ends; xaLimit = the hit limit per end
@@ -112,6 +117,7 @@ private:
         std::string tags;                                // after RG:Z
     };
     struct EndView;
+    int mapqSingleDP(int maxDP, int avgMismatchQual, int x0, int x1t1, int x1t2, int bestDP, int secDP, int cutoff) const;
     void pairRecords(const ReadSet &rs, uint32_t r1, EndView *e, int bestInsert, const std::string xa[2]);
     void emit(const ReadSet &rs, const Rec &rec);
     const HostIndex &ix;

@@ -27,16 +27,20 @@ static float penaltyRatioX1(int x1)
     return 0.01f;
 }
 
-std::string SamWriter::convertCigar(const std::string &sp)
+std::string SamWriter::convertCigar(const std::string &sp, int *deletedEnd)
 {
     std::string out;
     int cur = 0, m = 0;
     const size_t n = sp.size();
+    if (deletedEnd) *deletedEnd = 0;
     for (size_t i = 0; i < n; i++) {
         const char c = sp[i];
         if (isdigit((unsigned char)c)) { cur = cur * 10 + (c - '0'); continue; }
         if (c == 'M' || c == 'm') { m += cur; cur = 0; continue; }
-        if (c == 'D' && ((out.empty() && m == 0) || i == n - 1)) continue;      // a deletion in front or at the very end is dropped (the count stays pending, as there)
+        if (c == 'D' && ((out.empty() && m == 0) || i == n - 1)) {               // a deletion in front or at the very end is dropped (the count stays pending, as there)
+            if (i == n - 1 && deletedEnd) *deletedEnd = m;                       // the reference stores the pending MATCH count here, not the deletion's length (PE.cpp:452)
+            continue;
+        }
         if (c == 'D' || c == 'I' || c == 'S') {
             if (m > 0) { out += std::to_string(m) + "M"; m = 0; }
             out += std::to_string(cur);
@@ -151,6 +155,20 @@ int SamWriter::misInfoDP(const ReadSet &rs, uint32_t r, uint32_t pos, bool negat
     return (int)md.size();
 }
 
+// getMapQualScoreForSingleDP (BGS-IO.cpp:2370-2412), float arithmetic as there
+int SamWriter::mapqSingleDP(int maxDP, int avgMismatchQual, int x0, int x1t1, int x1t2, int bestDP, int secDP, int cutoff) const
+{
+    if (opt.bwaLikeScore) return bwaLikeSingle(x0, x1t1 + x1t2, gLogN);
+    if (x0 > 1 || x1t1 > 0) return opt.minMAPQ;
+    float R1 = 1.0f;
+    if (x1t2 > 0) R1 = (float)(1.0 - ((float)(secDP - cutoff)) / (0.7 * bestDP - cutoff));
+    const float R2 = penaltyRatioX1(x1t1 + x1t2);
+    const float R3 = ((float)(bestDP - cutoff)) / (maxDP - cutoff);
+    const int aq = avgMismatchQual < 0 ? 0 : avgMismatchQual > 40 ? 40 : avgMismatchQual;
+    const int mapq = (int)(opt.maxMAPQ * R1 * R2 * R3 - kPenaltyAvgMisQual[aq]);
+    return mapq < opt.minMAPQ ? opt.minMAPQ : mapq;
+}
+
 void SamWriter::singleDP(const ReadSet &rs, uint32_t r, const DpHit *hits, size_t n, int singleDPcutoff)
 {
     if (n == 0 || hits[0].pos == 0xFFFFFFFFu) { unaligned(rs, r); return; }
@@ -202,24 +220,7 @@ void SamWriter::singleDP(const ReadSet &rs, uint32_t r, const DpHit *hits, size_
     int numMis = 0, gapOpen = 0, gapExt = 0, avgQual = 20;
     misInfoDP(rs, r, hits[best].pos, negative, useSp, boundTrim, md, numMis, gapOpen, gapExt, avgQual);
     const int editDist = gapExt + numMis;
-    int mapq;
-    if (opt.bwaLikeScore) {
-        const int x1 = x1t1 + x1t2;
-        if (bestHitNum > 1) mapq = 0;
-        else if (x1 == 0) mapq = 37;
-        else { const int nl = gLogN[x1 > 255 ? 255 : x1]; mapq = 23 < nl ? 0 : 23 - nl; }
-    } else if (bestHitNum > 1 || x1t1 > 0) mapq = opt.minMAPQ;
-    else {                                                                // getMapQualScoreForSingleDP, float arithmetic as there
-        const int maxDP = (int)readLen * opt.dpMatchScore, bestDP = (int)bestScore, secDP = (int)secBestScore;
-        float R1 = 1.0f;
-        if (x1t2 > 0) R1 = (float)(1.0 - ((float)(secDP - singleDPcutoff)) / (0.7 * bestDP - singleDPcutoff));
-        const float R2 = penaltyRatioX1(x1t1 + x1t2);
-        const float R3 = ((float)(bestDP - singleDPcutoff)) / (maxDP - singleDPcutoff);
-        int aq = rs.isFastq ? avgQual : 20;
-        aq = aq < 0 ? 0 : aq > 40 ? 40 : aq;
-        mapq = (int)(opt.maxMAPQ * R1 * R2 * R3 - kPenaltyAvgMisQual[aq]);
-        if (mapq < opt.minMAPQ) mapq = opt.minMAPQ;
-    }
+    const int mapq = mapqSingleDP((int)readLen * opt.dpMatchScore, rs.isFastq ? avgQual : 20, bestHitNum, x1t1, x1t2, (int)bestScore, (int)secBestScore, singleDPcutoff);
     std::string line = rs.names[r];
     line.push_back('\t'); line += std::to_string(negative ? 16 : 0);
     line.push_back('\t'); line += ix.seqName[bestChr - 1];

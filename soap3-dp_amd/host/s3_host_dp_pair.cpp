@@ -451,4 +451,108 @@ void SamWriter::pairDeepDP(const ReadSet &rs, uint32_t r1, const DeepDpHit *H, s
     pairRecords(rs, r1, e, bestInsert, xa);
 }
 
+void SamWriter::unpairedDP(const ReadSet &rs, uint32_t r1, const DpHit *hits1, size_t n1, const DpHit *hits2, size_t n2, int cutoff)
+{
+    const int type = opt.alignmentType;
+    const DpHit *H[2] = {hits1, hits2};
+    const size_t N[2] = {n1, n2};
+    struct End {
+        bool aligned = false, negative = false;
+        uint64_t tp = 0; uint32_t chr = 0;
+        int trim = 0, deletedEnd = 0, mis = 0, gapOpen = 0, gapExt = 0, avg = 20, mapq = 0, x0 = 0, x1 = 0;
+        std::string cigar, md, xa;
+        uint32_t len = 0, r = 0;
+    } e[2];
+    for (int k = 0; k < 2; k++) {
+        End &a = e[k];
+        a.r = r1 + (uint32_t)k; a.len = rs.lengths[a.r];
+        const DpHit *h = H[k];
+        const size_t n = N[k];
+        size_t best = 0;
+        int bestScore = 0, bestNum = 0;
+        if (n > 0) {
+            bestScore = h[0].score; bestNum = 1;
+            for (size_t i = 1; i < n; i++) {
+                if (h[i].score > bestScore) { best = i; bestScore = h[i].score; bestNum = 1; }
+                else if (h[i].score == bestScore) bestNum++;
+            }
+        }
+        int x1t1 = 0, x1t2 = 0, secBest = -9999;
+        const int thres = (int)(0.7 * bestScore);
+        for (size_t i = 0; i < n; i++)
+            if (h[i].score < bestScore) {
+                if (h[i].score > secBest) secBest = h[i].score;
+                if (h[i].score >= thres) x1t1++; else x1t2++;
+            }
+        a.x0 = bestNum;
+        a.x1 = (type == 3 || type == 4) ? -1 : x1t1 + x1t2;
+        if (n > 0 && (type != 3 || bestNum == 1)) {
+            a.aligned = true;
+            a.negative = h[best].strand == 2;
+            if (h[best].fromDP) {
+                std::string tmp;
+                a.trim = boundaryCheckDP(a.len, h[best].pos, h[best].cigar, a.tp, a.chr, &tmp);
+                a.cigar = a.trim ? convertCigar(tmp) : convertCigar(h[best].cigar, &a.deletedEnd);
+                misInfoDP(rs, a.r, h[best].pos, a.negative, a.trim ? tmp : h[best].cigar, a.trim, a.md, a.mis, a.gapOpen, a.gapExt, a.avg);
+            } else {
+                a.trim = chrAndPosChecked(a.len, h[best].pos, a.tp, a.chr, &a.cigar);
+                mdString(ix, &rs.codes[(size_t)a.r * rs.maxReadLength], &rs.quals[(size_t)a.r * rs.maxReadLength], a.len, h[best].pos, a.negative, h[best].editdist, a.trim,
+                         a.md, a.avg);
+                a.mis = 0;
+                for (char c : a.md) a.mis += c > '9';
+            }
+            if (type == 3 || type == 4) a.mapq = 255;
+            else {
+                a.mapq = mapqSingleDP((int)a.len * opt.dpMatchScore, rs.isFastq ? a.avg : 20, bestNum, x1t1, x1t2, bestScore, secBest, cutoff);
+                if (!opt.bwaLikeScore) a.mapq >>= 1;
+                if (a.mapq < opt.minMAPQ) a.mapq = opt.minMAPQ;
+            }
+            // the first end loses its MAPQ to a boundary trim in every mode, the second only where a MAPQ is computed (:3127 vs :3186)
+            if (a.trim && (k == 0 || !(type == 3 || type == 4))) a.mapq = 0;
+        }
+        if (type == 1 || type == 2)
+            for (size_t i = 0; i < n; i++) {
+                if (a.aligned && i == best) continue;
+                if (type == 2 && h[i].score < bestScore) continue;
+                uint64_t tp; uint32_t ch;
+                chrAndPos(h[i].pos, tp, ch);
+                a.xa += ix.seqName[ch - 1];
+                a.xa.push_back(',');
+                a.xa.push_back(h[i].strand == 2 ? '-' : '+');
+                a.xa += std::to_string((unsigned long long)tp) + "," + convertCigar(h[i].cigar) + "," + std::to_string(h[i].editdist) + ";";
+            }
+    }
+    // the XA:Z buffer is shared and only rebuilt in the all-valid / all-best modes: nothing to carry over in the others
+    for (int k = 0; k < 2; k++) {
+        End &a = e[k], &b = e[1 - k];
+        Rec c;
+        c.r = a.r;
+        c.flag = 1 | (k == 0 ? 0x40 : 0x80);
+        if (!a.aligned) c.flag |= 4;
+        if (!b.aligned) c.flag |= 8;
+        if (a.aligned && a.negative) c.flag |= 0x10;
+        if (b.aligned && b.negative) c.flag |= 0x20;
+        c.tid = a.chr == 0 ? (b.chr == 0 ? -1 : (int)b.chr - 1) : (int)a.chr - 1;
+        c.pos0 = a.tp == 0 ? (b.tp == 0 ? -1 : (long long)b.tp - 1) : (long long)a.tp - 1;
+        c.mtid = b.chr == 0 ? (a.chr == 0 ? -1 : (int)a.chr - 1) : (int)b.chr - 1;
+        c.mpos0 = b.tp == 0 ? (a.tp == 0 ? -1 : (long long)a.tp - 1) : (long long)b.tp - 1;
+        if (e[0].chr > 0 && e[0].chr == e[1].chr)
+            c.isize = b.tp > a.tp ? (long long)(b.tp - (uint64_t)b.deletedEnd + b.len - a.tp) : -(long long)(a.tp - (uint64_t)a.deletedEnd + a.len - b.tp);
+        if (a.aligned) {
+            c.negative = a.negative;
+            c.mapq = a.mapq;
+            c.cigar = a.cigar.empty() ? std::to_string(a.len) + "M" : a.cigar;
+            std::string t;
+            if (opt.printMDNM) t += "\tNM:i:" + std::to_string(a.mis + a.gapExt);
+            t += "\tX0:i:" + std::to_string(a.x0);
+            if (a.x1 >= 0) t += "\tX1:i:" + std::to_string(a.x1);
+            t += "\tXM:i:" + std::to_string(a.mis) + "\tXO:i:" + std::to_string(a.gapOpen) + "\tXG:i:" + std::to_string(a.gapExt);
+            if (opt.printMDNM && !a.md.empty()) t += "\tMD:Z:" + a.md;
+            if (!a.xa.empty()) t += "\tXA:Z:" + a.xa;
+            c.tags = t;
+        }
+        emit(rs, c);
+    }
+}
+
 }  // namespace s3host

@@ -57,7 +57,8 @@ def test_paired_dp_records(tmp_path, variant, opts):
     """tests/golden/dp2: result vectors of the default DP (one end from the BWT stage) and of the deep DP (both ends from the DP) for 480
     pairs -- equal / weaker extra results, both ends through the DP, boundary crossings, read-through pairs, BWT-stage statistics -- and
     the records the reference's outputRead2 / pairDPOutputSAMAPI and outputDeepDPResult2 / pairDeepDPOutputSAMAPI wrote for them
-    (oracle/ref_harness.cpp, mode dppair).  nb*: the ini with BWALikeScore=0, i.e. the table-driven MAPQ rules."""
+    (oracle/ref_harness.cpp, mode dppair); 240 more pairs no stage could pair, each end with hits of the single-end DP or of the BWT stage or
+    none, through the reference's AllHits store and outputSingleResultForPairEnds / unproperlypairDPOutputSAMAPI.  nb*: the ini with BWALikeScore=0, i.e. the table-driven MAPQ rules."""
     d = os.path.join(GOLDEN, "dp2")
     shutil.copy(os.path.join(d, "reads_1.fq"), tmp_path / "dp2_1.fq")
     shutil.copy(os.path.join(d, "reads_2.fq"), tmp_path / "dp2_2.fq")
@@ -66,6 +67,6 @@ def test_paired_dp_records(tmp_path, variant, opts):
     assert out.returncode == 0, out.stderr[-2000:]
     mine = [l for l in open(tmp_path / "out.dpout.1").read().split("\n") if l and not l.startswith("@")]
     ref = [l for l in gzip.open(os.path.join(d, "dpout_%s.sam.gz" % variant), "rt").read().split("\n") if l and not l.startswith("@")]
-    assert len(mine) == len(ref) == 960
+    assert len(mine) == len(ref) == 1440
     bad = [(a, b) for a, b in zip(ref, mine) if a != b]
     assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][0], bad[0][1])

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -43,6 +44,7 @@ int main(int argc, char **argv)
     if (!f) return 1;
     std::vector<PairDpHit> dh;
     std::vector<DeepDpHit> ph;
+    std::map<unsigned, std::vector<DpHit>> uh;                 // leftover pairs: hits per read
     long cur = -1;
     auto flush = [&]() {
         if (cur < 0) return;
@@ -53,7 +55,13 @@ int main(int argc, char **argv)
     };
     char kind[8], c1[4096], c2[4096];
     while (fscanf(f, "%7s", kind) == 1) {
-        if (kind[0] == 'D') {
+        if (kind[0] == 'U') {
+            unsigned pos;
+            int fromDP, s1, score, ed;
+            if (fscanf(f, "%u %d %u %d %d %d %4095s", &rid, &fromDP, &pos, &s1, &score, &ed, c1) != 7) return 1;
+            std::vector<DpHit> &v = uh[rid];
+            if (pos != 0xFFFFFFFFu) { DpHit h{pos, (uint8_t)s1, score, ed, c1}; h.fromDP = fromDP != 0; v.push_back(h); }
+        } else if (kind[0] == 'D') {
             PairDpHit h;
             int which, s1, s2;
             if (fscanf(f, "%u %d %u %d %d %u %d %d %d %d %d %4095s", &rid, &which, &h.pos1, &s1, &h.score1, &h.pos2, &s2, &h.score2, &h.editdist, &h.insertSize, &h.numSameScore, c1) != 12) return 1;
@@ -72,6 +80,15 @@ int main(int argc, char **argv)
     }
     flush();
     fclose(f);
+    // cutoff of the single-read DP stage on the detected read length (first ten reads), as tests/tools/dp_sam.cpp
+    uint32_t detected = 0;
+    for (uint32_t i = 0; i < rs.n && i < 10; i++) detected = detected > rs.lengths[i] ? detected : rs.lengths[i];
+    const int cutoff = (int)ceil(0.3 * (double)detected);
+    for (auto it = uh.begin(); it != uh.end(); ++it) {
+        if (it->first & 1u) continue;
+        const std::vector<DpHit> &a = it->second, &b = uh[it->first + 1];
+        sam.unpairedDP(rs, it->first, a.data(), a.size(), b.data(), b.size(), cutoff);
+    }
     fclose(out);
     return 0;
 }

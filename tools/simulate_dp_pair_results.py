@@ -5,6 +5,8 @@ Reads are cut from an index's own packed text and damaged in a known way.  The r
 the DP engines' CIGAR dialect ('m' = mismatch run):
   D readID which pos1 strand1 score1 pos2 strand2 score2 editdist insert same cigar              default DP: one end from the BWT stage
   P readID pos1 strand1 score1 edit1 same1 cigar1 pos2 strand2 score2 edit2 same2 cigar2 insert  deep DP: both ends from the DP
+  U readID fromDP pos strand score editdist cigar      a hit of ONE read of a pair no stage could pair (fromDP 0: carried over from the BWT stage;
+                                                       pos 4294967295: the read has no hit)
 and a stats file (readID x0 x1 mismatch) what the BWT stage would have left for the reads.  Fabricated extra results per pair (equal,
 weaker, other positions) walk the X0 / X1 / XA:Z / MAPQ branches; some pairs cross a chromosome end or read through each other.  Only the
 SAM formatting is under test with these vectors."""
@@ -69,6 +71,7 @@ def main():
     ap.add_argument("--index", required=True)
     ap.add_argument("--pairs", type=int, default=480)
     ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--unpair", type=int, default=240, help="more pairs, for the leftover records (U lines)")
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--fastq1", required=True)
     ap.add_argument("--fastq2", required=True)
@@ -176,13 +179,44 @@ def main():
             if scen in (2, 6, 10, 11):
                 stats.append("%d %d %d %d" % (rid, 1 + int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 5))))
                 stats.append("%d %d %d %d" % (rid + 1, 1 + int(rng.integers(0, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 5))))
+    # ---------------- leftover pairs: each end on its own ----------------
+    ulines = []
+    for pr in range(a.pairs, a.pairs + a.unpair):
+        for e in range(2):
+            rid = 2 * pr + e
+            scen = (pr + 5 * e) % 8
+            lo, hi = bounds[int(rng.integers(0, nseq - 1 if scen == 6 else nseq))]
+            p = int(rng.integers(lo + 10, hi - 3 * L - 10))
+            strand = 1 + int(rng.integers(0, 2))
+            if scen == 7:                                     # no hit at all
+                fwd = rng.integers(0, 4, size=L, dtype=np.uint8)
+                ulines.append("U %d 1 4294967295 1 0 0 *" % rid)
+            elif scen in (4, 5):                              # hits carried over from the BWT stage
+                mm = int(rng.integers(0, 4))
+                fwd = bwt_end(rng, text, p, L, mm)
+                grp = ["U %d 0 %d %d %d %d %dM" % (rid, p, strand, L * M + mm * X, mm, L)]
+                for t in range(int(rng.integers(0, 4)) if scen == 5 else 0):
+                    m2 = mm + int(rng.integers(0, 3)) * int(t > 0)
+                    grp.append("U %d 0 %d %d %d %d %dM" % (rid, int(rng.integers(lo + 10, hi - 2 * L)), 1 + int(rng.integers(0, 2)), L * M + m2 * X, m2, L))
+                ulines += [grp[i] for i in rng.permutation(len(grp))]
+            else:                                             # hits of the single-end DP
+                if scen == 6:
+                    p = hi - int(rng.integers(30, 80))        # crosses the end of its chromosome
+                fwd, q, cig, score, ed = dp_end(rng, text, p, L, int(rng.integers(0, 6)))
+                grp = ["U %d 1 %d %d %d %d %s" % (rid, q, strand, score, ed, cig)]
+                for t in range(int(rng.integers(1, 5)) if scen in (1, 2, 3) else 0):
+                    sc = score if (scen == 1 and t == 0) else score - int(rng.integers(1, 40))
+                    grp.append("U %d 1 %d %d %d %d %s" % (rid, int(rng.integers(lo + 10, hi - 2 * L)), 1 + int(rng.integers(0, 2)), sc, ed + (score - sc) // 3,
+                                                          cig if sc == score else "48M1m%dM" % (L - 49)))
+                ulines += [grp[i] for i in rng.permutation(len(grp))]
+            ends[e].append(fwd if strand == 1 else COMP[fwd[::-1]])
     for k, name in ((0, a.fastq1), (1, a.fastq2)):
         with open(name, "w") as f:
             for i, s in enumerate(ends[k]):
                 qual = "".join(chr(33 + int(x)) for x in rng.integers(5, 41, size=len(s)))
                 f.write("@q%d/%d\n%s\n+\n%s\n" % (i, k + 1, bytes(b"ACGT"[c] for c in s).decode(), qual))
     with open(a.results, "w") as f:
-        f.write("\n".join(dlines + plines) + "\n")
+        f.write("\n".join(dlines + plines + ulines) + "\n")
     with open(a.stats, "w") as f:
         f.write("\n".join(stats) + "\n")
 
