@@ -99,20 +99,79 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
     fseeko(out, (off_t)off[(size_t)T], SEEK_SET);
 }
 
+// ---- single-end DP of a list of reads (DPForUnalignSingle2, DV-DPForSingleReads.cu): seeding in batches of at most 256 Ki seeds, DP at the candidates;
+// `emit` gets one call per run of results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776 -- results arrive in (strand, read, position)
+// order, so a read with hits on both strands comes twice) after OutputBuffer::ready (DV-DPfunctions.h:367-412) with the DP module's type
+// (all-best + SAM runs it as all-valid, alignment.cu:2563): sorted by position, one result per position; then best-only for -h 3 / 4 --------------
+template <class Emit>
+static bool singleDpRuns(s3_batch *b, s3_batch *seedBatch, s3_dp *dp, const uint32_t *lens, const std::vector<uint32_t> &todo, const s3_dp_stage_params &dpPar,
+                         int alignmentType, Emit &&emit, std::string &err)
+{
+    size_t at = 0;
+    while (at < todo.size()) {
+        size_t end = at, nSeeds = 0;
+        while (end < todo.size()) {
+            int sl = 0, num = 0, sp[128];
+            s3_seed_positions(S3_STAGE_SINGLE_DP, (int)lens[todo[end]], &sl, sp, &num);
+            if (nSeeds + (size_t)num > 262144) break;
+            nSeeds += (size_t)num;
+            end++;
+        }
+        if (end == at) end = at + 1;
+        s3_seed_candidate *cand = nullptr;
+        size_t nCand = 0;
+        if (s3_seed_candidates(b, seedBatch, lens, todo.data() + at, end - at, S3_STAGE_SINGLE_DP, (uint32_t)dpPar.maxHitNum, &cand, &nCand, nullptr, nullptr) != S3_OK) {
+            err = s3_last_error();
+            return false;
+        }
+        s3_dp_single_result *res = nullptr;
+        size_t nRes = 0;
+        char *pool = nullptr;
+        if (s3_dp_single_end(dp, b, lens, cand, nCand, dpPar.cutoffThreshold, dpPar.softClipLeft, dpPar.softClipRight, &res, &nRes, &pool) != S3_OK) {
+            err = s3_last_error();
+            s3_free(cand);
+            return false;
+        }
+        for (size_t i = 0; i < nRes;) {
+            size_t j = i;
+            while (j < nRes && res[j].readID == res[i].readID) j++;
+            std::vector<DpHit> hits;
+            for (size_t q = i; q < j; q++) hits.push_back(DpHit{res[q].algnmt, res[q].strand, res[q].score, (int)res[q].editdist, std::string(pool + res[q].cigarOffset)});
+            std::sort(hits.begin(), hits.end(), [](const DpHit &x, const DpHit &y) { return x.pos < y.pos; });
+            size_t u = 0;
+            for (size_t q = 1; q < hits.size(); q++) if (hits[u].pos < hits[q].pos) hits[++u] = hits[q];
+            hits.resize(hits.empty() ? 0 : u + 1);
+            if (alignmentType >= 3 && !hits.empty()) {
+                std::vector<DpHit> bestOnes;
+                int bestScore = hits[0].score;
+                for (const DpHit &hh : hits) bestScore = std::max(bestScore, hh.score);
+                for (const DpHit &hh : hits) if (hh.score == bestScore) bestOnes.push_back(hh);
+                if (alignmentType == 3 && bestOnes.size() != 1) bestOnes.clear();
+                if (alignmentType == 4) bestOnes.resize(1);
+                hits.swap(bestOnes);
+            }
+            if (!hits.empty()) emit(res[i].readID, hits);
+            i = j;
+        }
+        s3_free(cand); s3_free(res); s3_free(pool);
+        at = end;
+    }
+    return true;
+}
+
 // ---- DP stages of a paired-end batch (soap3_dp_pair_align after the BWT ladder, alignment.cu:2021-2420) --------------------------------------
 struct PairDpCtx {
     const HostIndex &hix; const SamOptions &so; const ReadSet &rs; const Ini &ini;
     s3_batch *b, *seedBatch; s3_dp *dp, *dpHalf; FILE *dpOut, *unpairOut;
     uint32_t first, cnt; int alignmentType, insertLow, insertHigh;
-    const s3_dp_stage_params *halfPar; const s3_dp_stage_params (*deepPar)[2];
+    const s3_dp_stage_params *halfPar; const s3_dp_stage_params (*deepPar)[2]; const s3_dp_stage_params &singlePar;
 };
 
 // Routing of the pairs the ladder left without a proper pairing (hostKernel with needProceedDP, CPUfunctions.cpp:2153-2262, 2444-2543), the default
 // DP on the half-aligned ones (semiGlobalDP2 -> HalfEndAlignmentEngine -> DPOutputThread -> outputRead2), the deep DP on the rest
 // (DPForUnalignPairs2: seeding round 1, round 2 for the pairs that only lost seeds to the hit limit, PairEndAlignmentEngine ->
-// outputDeepDPResult2).  NOT built: the new default DP for ends with too many hits (newSemiGlobalDP; such pairs go to the deep DP here) and the
-// single-end DP of the ends of pairs every stage failed on (DPForUnalignSingle2 + outputSingleResultForPairEnds): those pairs are written to
-// <prefix>.unpair with what the BWT stage knows about them (unproperlypairOutputSAMAPI).
+// outputDeepDPResult2), and for the pairs every stage failed on the single-end DP of their ends (DPForUnalignSingle2 + outputSingleResultForPairEnds)
+// into <prefix>.unpair.  NOT built: the new default DP for ends with too many hits (newSemiGlobalDP; such pairs go to the deep DP here).
 static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &pr, const std::vector<uint64_t> &ooff, const std::vector<uint32_t> &pos,
                          const std::vector<uint8_t> &strand, const std::vector<uint8_t> &mis, const std::vector<uint8_t> &fromSa, uint64_t &defaultDpPairs,
                          uint64_t &deepDpPairs, uint64_t &leftoverPairs, std::string &err)
@@ -145,6 +204,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         v.resize(w);
     };
     std::vector<s3_occ> h1, h2;
+    std::vector<std::vector<s3_occ>> kept(c.cnt);                                // keepSoap3Results: what the BWT stage leaves of a read for the later stages
     for (uint32_t p = 0; p < np; p++) {
         if (pr[p].phase) continue;
         const uint32_t r1 = 2 * p, r2 = r1 + 1;
@@ -154,6 +214,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             const int e = n1 ? 0 : 1;
             endHits(e ? r2 : r1, true, h1);
             if (h1.size() > maxHit[e]) retainBest(h1);
+            kept[e ? r2 : r1] = h1;
             if (h1.size() <= maxHit[e]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; }
             else deepPairs.push_back(r1);                                            // reference: new default DP
             continue;
@@ -161,6 +222,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         endHits(r1, false, h1); endHits(r2, false, h2);
         if (h1.size() > maxHit[0]) retainBest(h1);
         if (h2.size() > maxHit[1]) retainBest(h2);
+        kept[r1] = h1; kept[r2] = h2;
         if (h1.size() <= maxHit[0] && h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; }
         else if (h1.size() < h2.size()) { if (h1.size() <= maxHit[0]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else deepPairs.push_back(r1); }
         else { if (h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; } else deepPairs.push_back(r1); }
@@ -280,15 +342,34 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             todo.swap(next);
         }
     }
-    // ---- what every stage failed on ----
+    // ---- what every stage failed on: each end on its own (outputDeepDPResult2 :624-650: an end without BWT hits goes through the single-end DP;
+    //      with hits the FIRST end keeps them, the second end keeps its own only when the first had none) ----
+    std::vector<uint32_t> left, todo;
+    for (uint32_t r1 : deepPairs) if (!deepDone[r1 / 2]) left.push_back(r1);
+    std::vector<uint8_t> viaDP(c.cnt, 0);
+    for (uint32_t r1 : left) {
+        const bool no1 = kept[r1].empty(), no2 = kept[r1 + 1].empty();
+        if (no1) { viaDP[r1] = 1; todo.push_back(r1); }
+        if (no2 || !no1) { viaDP[r1 + 1] = 1; todo.push_back(r1 + 1); }
+    }
+    std::vector<std::vector<DpHit>> own(c.cnt);
+    // a read with DP hits on both strands reaches the reference's store as two entries and breaks its pairing by position in the list
+    // (outputSingleResultForPairEnds :1106-1112 prints an error); here the two runs are one list
+    if (!singleDpRuns(c.b, c.seedBatch, c.dp, lens, todo, c.singlePar, moduleType, [&](uint32_t k, std::vector<DpHit> &hits) {
+            own[k].insert(own[k].end(), hits.begin(), hits.end());
+        }, err)) return false;
     SamWriter up(c.hix, c.so, c.unpairOut);
-    for (uint32_t r1 : deepPairs) {
-        const uint32_t p = r1 / 2;
-        if (deepDone[p]) continue;
-        const uint32_t r2 = r1 + 1;
-        const size_t o1 = ooff[r1], n1 = ooff[r1 + 1] - o1, o2 = ooff[r2], n2 = ooff[r2 + 1] - o2;
-        up.improperPair(c.rs, c.first + r1, c.first + r2, pos.data() + o1, strand.data() + o1, mis.data() + o1, n1, pos.data() + o2, strand.data() + o2, mis.data() + o2, n2,
-                        c.ini.maxHitsEachEndForPairing);
+    for (uint32_t r1 : left) {
+        for (uint32_t r = r1; r < r1 + 2; r++) {
+            if (viaDP[r]) continue;
+            const int L = (int)lens[r];
+            for (const s3_occ &x : kept[r]) {                                      // inputSoap3AnsToArray, PEAlgnmt.cpp:1180
+                DpHit h{x.pos, x.strand, L * c.so.dpMatchScore + (int)x.mismatchCount * c.so.dpMismatchScore, (int)x.mismatchCount, std::to_string(L) + "M"};
+                h.fromDP = false;
+                own[r].push_back(h);
+            }
+        }
+        up.unpairedDP(c.rs, c.first + r1, own[r1].data(), own[r1].size(), own[r1 + 1].data(), own[r1 + 1].size(), c.singlePar.cutoffThreshold);
         leftoverPairs++;
     }
     return true;
@@ -456,7 +537,7 @@ int main(int argc, char **argv)
                 }
             }, aligned);
             if (enableDP) {
-                PairDpCtx c{hix, so, rs, ini, b, seedBatch, dp, dpHalf, dpOut, unpairOut, first, cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar};
+                PairDpCtx c{hix, so, rs, ini, b, seedBatch, dp, dpHalf, dpOut, unpairOut, first, cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar};
                 std::vector<uint8_t> fromSa(nOcc ? nOcc : 1);
                 if (s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return die(s3_last_error());
                 std::string e2;
@@ -499,55 +580,13 @@ int main(int argc, char **argv)
             for (uint32_t k = 0; k < cnt; k++) if (offs[k + 1] == offs[k]) todo.push_back(k);
             std::vector<uint8_t> doneFlag(cnt, 0);
             const uint32_t *lens = rs.lengths.data() + first;
-            size_t at = 0;
-            while (at < todo.size()) {
-                size_t end = at, nSeeds = 0;
-                while (end < todo.size()) {
-                    int sl = 0, num = 0, sp[128];
-                    s3_seed_positions(S3_STAGE_SINGLE_DP, (int)lens[todo[end]], &sl, sp, &num);
-                    if (nSeeds + (size_t)num > 262144) break;
-                    nSeeds += (size_t)num;
-                    end++;
-                }
-                if (end == at) end = at + 1;
-                s3_seed_candidate *cand = nullptr;
-                size_t nCand = 0;
-                if (s3_seed_candidates(b, seedBatch, lens, todo.data() + at, end - at, S3_STAGE_SINGLE_DP, (uint32_t)dpPar.maxHitNum, &cand, &nCand, nullptr, nullptr) != S3_OK)
-                    return die(s3_last_error());
-                s3_dp_single_result *res = nullptr;
-                size_t nRes = 0;
-                char *pool = nullptr;
-                if (s3_dp_single_end(dp, b, lens, cand, nCand, dpPar.cutoffThreshold, dpPar.softClipLeft, dpPar.softClipRight, &res, &nRes, &pool) != S3_OK)
-                    return die(s3_last_error());
+            {
                 SamWriter w(hix, so, dpOut);
-                for (size_t i = 0; i < nRes;) {
-                    size_t j = i;
-                    while (j < nRes && res[j].readID == res[i].readID) j++;
-                    // OutputBuffer::ready (DV-DPfunctions.h:367-412) with the DP module's type (all-best + SAM runs it as all-valid, alignment.cu:2563):
-                    // sorted by position, one result per position; then best-only for -h 3 / 4
-                    std::vector<DpHit> hits;
-                    for (size_t q = i; q < j; q++) hits.push_back(DpHit{res[q].algnmt, res[q].strand, res[q].score, (int)res[q].editdist, std::string(pool + res[q].cigarOffset)});
-                    std::sort(hits.begin(), hits.end(), [](const DpHit &x, const DpHit &y) { return x.pos < y.pos; });
-                    size_t u = 0;
-                    for (size_t q = 1; q < hits.size(); q++) if (hits[u].pos < hits[q].pos) hits[++u] = hits[q];
-                    hits.resize(hits.empty() ? 0 : u + 1);
-                    if (alignmentType >= 3 && !hits.empty()) {
-                        std::vector<DpHit> bestOnes;
-                        int bestScore = hits[0].score;
-                        for (const DpHit &hh : hits) bestScore = std::max(bestScore, hh.score);
-                        for (const DpHit &hh : hits) if (hh.score == bestScore) bestOnes.push_back(hh);
-                        if (alignmentType == 3 && bestOnes.size() != 1) bestOnes.clear();
-                        if (alignmentType == 4) bestOnes.resize(1);
-                        hits.swap(bestOnes);
-                    }
-                    if (!hits.empty()) {
-                        w.singleDP(rs, first + res[i].readID, hits.data(), hits.size(), dpPar.cutoffThreshold);
-                        if (!doneFlag[res[i].readID]) { doneFlag[res[i].readID] = 1; dpAlignedReads++; }
-                    }
-                    i = j;
-                }
-                s3_free(cand); s3_free(res); s3_free(pool);
-                at = end;
+                std::string e2;
+                if (!singleDpRuns(b, seedBatch, dp, lens, todo, dpPar, alignmentType, [&](uint32_t k, std::vector<DpHit> &hits) {
+                        w.singleDP(rs, first + k, hits.data(), hits.size(), dpPar.cutoffThreshold);
+                        if (!doneFlag[k]) { doneFlag[k] = 1; dpAlignedReads++; }
+                    }, e2)) return die(e2);
             }
             SamWriter w(hix, so, dpOut);
             for (uint32_t k : todo) if (!doneFlag[k]) w.unaligned(rs, first + k);

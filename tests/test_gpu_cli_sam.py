@@ -227,16 +227,22 @@ def test_cli_default_mode_pairs_with_dp(tmp_path):
         return "".join(b)
     names = sorted(chroms)
     r1s, r2s, truth = [], [], []
-    kinds = [("exact", "exact"), ("exact", "D"), ("I", "exact"), ("exact", "sub"), ("D", "I"), ("sub", "D")]
-    while len(r1s) < 360:
+    kinds = [("exact", "exact"), ("exact", "D"), ("I", "exact"), ("exact", "sub"), ("D", "I"), ("sub", "D"), ("exact", "far"), ("exact", "junk")]
+    while len(r1s) < 480:
         ch = names[int(rng.integers(0, len(names)))]
         ins = int(rng.integers(250, 450))
         st = int(rng.integers(0, len(chroms[ch]) - ins - 20))
+        kl, kr = kinds[len(r1s) % len(kinds)]
+        if kr == "far":                                       # the mate comes from 5 kb further on: both ends align, no proper pairing exists
+            ins += 5000
+            if st + ins + 10 > len(chroms[ch]):
+                continue
         left, right = chroms[ch][st:st + L + 10], chroms[ch][st + ins - L:st + ins + 10]
         if "N" in left or "N" in right or len(right) < L + 10:
             continue
-        kl, kr = kinds[len(r1s) % len(kinds)]
-        a, b = damage(left, kl), rc(damage(right, kr))
+        if kr == "junk":
+            right = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=L + 10))
+        a, b = damage(left, kl), rc(damage(right, "exact" if kr in ("far", "junk") else kr))
         swap = bool(rng.integers(0, 2))                       # which file holds the '+' end
         r1s.append(b if swap else a); r2s.append(a if swap else b)
         truth.append((ch, st + 1, st + ins - L + 1, swap, kl, kr))
@@ -267,6 +273,16 @@ def test_cli_default_mode_pairs_with_dp(tmp_path):
             assert src == "gout.1"
         else:
             assert src != "gout.1"
+        if kr in ("far", "junk"):
+            # no stage can pair these: each end on its own in .unpair -- the first keeps its BWT hit, the second goes through the single-end DP
+            assert src == "unpair"
+            good = not int(fa[1]) & 2 and not int(fa[1]) & 4 and fa[2] == ch and int(fa[3]) == lp and fa[5] == "100M"
+            if kr == "far":
+                good = good and not int(fb[1]) & 4 and fb[2] == ch and int(fb[3]) == rp and int(fb[1]) & 16
+            else:
+                good = good and int(fb[1]) & 4 and int(fa[1]) & 8
+            ok[key] = ok.get(key, 0) + bool(good)
+            continue
         if src == "unpair":
             continue
         good = int(fa[1]) & 2 and int(fb[1]) & 2 and fa[2] == ch and fb[2] == ch and abs(int(fa[3]) - lp) <= 3 and abs(int(fb[3]) - rp) <= 3
