@@ -182,6 +182,16 @@ int  s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *read
                 uint32_t maxHitNum, int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight,
                 s3_dp_deep_result **results, size_t *nResults, char **cigarPool, uint8_t **tooManyHits);
 
+/* ---- new default DP: pairs with an end the BWT stage aligned to too many places for the default DP ----------------------------------------
+ * Replaces newSemiGlobalDP (DV-SemiDP.cu:345; SemiDPWrapper::run2 -> newDefaultDP :237-246): the aligned end's hits are taken as they are
+ * (PairEndSeedingBatch::packSeedsOneSide, DV-DPfunctions.cu:2756-2776), only its mate is seeded (S3_STAGE_NEW_DEFAULT_DP), both lists go through the
+ * deep DP's pairing and its two DP rounds (pairEndMerge, PairEndAlignmentEngine), so BOTH ends are aligned by the DP and the results are deep-DP
+ * results.  occ: the aligned ends' hits, grouped by pair, pairs ascending (the ReadInputForDP stream).  pairFirstReads / pairFlags (optional
+ * outputs): the pairs found in occ and their flags as in s3_dp_deep.  PARITY UNPINNED. */
+int  s3_dp_new_default(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const s3_occ *occ, size_t nOcc, uint32_t maxHitNum,
+                       int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_deep_result **results,
+                       size_t *nResults, char **cigarPool, uint8_t **pairFlags, uint32_t **pairFirstReads, size_t *nPairs);
+
 /* ---- parameters of the DP stages (host-side integer rules) ------------------------------------------------------------------
  * s3_dp_stage_parameters replaces getParameterForSingleDP / DefaultDP / NewDefaultDP / DeepDP and getMaxHitNumForDefaultDP
  * (CPUfunctions.cpp:36-260) for one read length; s3_seed_positions replaces getSeedPositions (definitions.h:323-442): the seed length,

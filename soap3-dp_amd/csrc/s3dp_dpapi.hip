@@ -466,12 +466,58 @@ namespace {
 struct PairCand { uint32_t pos[2]; uint32_t readIDLeft; };
 }
 
+// shared by the deep DP (both ends seeded) and the new default DP (one end's positions given by the BWT stage, only its mate seeded)
+static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *pairFirstReads, size_t nPairs, int stage,
+                    uint32_t maxHitNum, int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight,
+                    s3_dp_deep_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut, uint8_t **tooManyHitsOut, const s3_occ *given, size_t nGiven);
+
 extern "C" int s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *pairFirstReads, size_t nPairs, int stage,
                           uint32_t maxHitNum, int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight,
                           s3_dp_deep_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut, uint8_t **tooManyHitsOut)
 {
+    return deepImpl(h, b, seedBatch, readLengths, pairFirstReads, nPairs, stage, maxHitNum, insertLow, insertHigh, cutoffThreshold, softClipLeft, softClipRight, resultsOut,
+                    nResultsOut, cigarPoolOut, tooManyHitsOut, nullptr, 0);
+}
+
+extern "C" int s3_dp_new_default(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const s3_occ *occ, size_t nOcc, uint32_t maxHitNum,
+                                 int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_deep_result **resultsOut,
+                                 size_t *nResultsOut, char **cigarPoolOut, uint8_t **pairFlagsOut, uint32_t **pairFirstReadsOut, size_t *nPairsOut)
+{
+    if (!occ && nOcc) return fail(S3_EINVAL, "s3_dp_new_default: null argument");
+    std::vector<uint32_t> pairs;
+    for (size_t i = 0; i < nOcc; i++) {
+        const uint32_t even = occ[i].readID & ~1u;
+        if (!pairs.empty() && even < pairs.back()) return fail(S3_EINVAL, "s3_dp_new_default: occurrences must be grouped by pair, pairs ascending");
+        if (pairs.empty() || pairs.back() != even) pairs.push_back(even);
+    }
+    int rc = deepImpl(h, b, seedBatch, readLengths, pairs.data(), pairs.size(), S3_STAGE_NEW_DEFAULT_DP, maxHitNum, insertLow, insertHigh, cutoffThreshold, softClipLeft,
+                      softClipRight, resultsOut, nResultsOut, cigarPoolOut, pairFlagsOut, occ, nOcc);
+    if (rc) return rc;
+    if (pairFirstReadsOut) {
+        uint32_t *p = (uint32_t *)malloc(pairs.size() * 4 + 4);
+        if (!p) return fail(S3_ENOMEM, "s3_dp_new_default: out of host memory");
+        memcpy(p, pairs.data(), pairs.size() * 4);
+        *pairFirstReadsOut = p;
+    }
+    if (nPairsOut) *nPairsOut = pairs.size();
+    return S3_OK;
+}
+
+static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *pairFirstReads, size_t nPairs, int stage,
+                    uint32_t maxHitNum, int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight,
+                    s3_dp_deep_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut, uint8_t **tooManyHitsOut, const s3_occ *given, size_t nGiven)
+{
     if (!h || !b || !seedBatch || !readLengths || (!pairFirstReads && nPairs) || !cutoffThreshold || !resultsOut || !nResultsOut || !cigarPoolOut)
         return fail(S3_EINVAL, "s3_dp_deep: null argument");
+    // new default DP: the end whose hits are given is not seeded (packSeedsOneSide seeds the mate of the pair's FIRST occurrence, DV-DPfunctions.cu:2756-2776)
+    std::vector<uint8_t> givenEnd(nPairs, 255);
+    for (size_t i = 0; i < nGiven; i++) {
+        const uint32_t even = given[i].readID & ~1u;
+        const uint32_t *it = std::lower_bound(pairFirstReads, pairFirstReads + nPairs, even);
+        if (it == pairFirstReads + nPairs || *it != even) return fail(S3_EINVAL, "s3_dp_new_default: occurrence of a pair that is not listed");
+        uint8_t &g = givenEnd[(size_t)(it - pairFirstReads)];
+        if (g == 255) g = (uint8_t)(given[i].readID & 1u);
+    }
     if (b->ix != seedBatch->ix || b == seedBatch || h->dev != b->ix->dev) return fail(S3_EINVAL, "s3_dp_deep: batches / aligner do not belong together");
     const int leftLeg = 1, rightLeg = 2;
     // ---- seeds of both ends; key = end << 31 | strand << 30 | first read of the pair (30 bits), then the estimated position --------------
@@ -481,6 +527,7 @@ extern "C" int s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint
         if ((even & 1u) || even + 1 >= b->n) return fail(S3_EINVAL, "s3_dp_deep: bad pair index");
         if (even >= (1u << 30)) return fail(S3_EINVAL, "s3_dp_deep: read index too large");
         for (uint32_t e = 0; e < 2; e++) {
+            if (givenEnd[k] != 255 && e == givenEnd[k]) continue;
             const uint32_t r = even + e;
             int seedLength = 0, num = 0, pos[128];
             if (s3_seed_positions(stage, (int)readLengths[r], &seedLength, pos, &num) != S3_OK) return fail(S3_EINVAL, "s3_dp_deep: bad stage");
@@ -507,6 +554,16 @@ extern "C" int s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint
     for (uint64_t key : keys) {
         const uint32_t hi = (uint32_t)(key >> 32);
         arr[hi >> 31][(hi >> 30) & 1u].push_back(Pos{hi & 0x3FFFFFFFu, (uint32_t)key});
+    }
+    if (nGiven) {
+        // the given hits stand in front of the seed hits (decodePositions :2896-2899) and everything is sorted by (pair, position) again
+        for (size_t i = 0; i < nGiven; i++) {
+            if (given[i].strand < 1 || given[i].strand > 2) return fail(S3_EINVAL, "s3_dp_new_default: bad strand");
+            arr[given[i].readID & 1u][given[i].strand - 1].push_back(Pos{given[i].readID & ~1u, given[i].pos});
+        }
+        for (int e = 0; e < 2; e++)
+            for (int st2 = 0; st2 < 2; st2++)
+                std::stable_sort(arr[e][st2].begin(), arr[e][st2].end(), [](const Pos &x, const Pos &y) { return x.id != y.id ? x.id < y.id : x.pos < y.pos; });
     }
     // ---- pairEndMerge: left = '+' hits of one end (compressed by DP2_DIVIDE_GAP), right = '-' hits of the other end --------------------
     std::vector<PairCand> cands;

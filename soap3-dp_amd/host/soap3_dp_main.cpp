@@ -164,24 +164,24 @@ struct PairDpCtx {
     const HostIndex &hix; const SamOptions &so; const ReadSet &rs; const Ini &ini;
     s3_batch *b, *seedBatch; s3_dp *dp, *dpHalf; FILE *dpOut, *unpairOut;
     uint32_t first, cnt; int alignmentType, insertLow, insertHigh;
-    const s3_dp_stage_params *halfPar; const s3_dp_stage_params (*deepPar)[2]; const s3_dp_stage_params &singlePar;
+    const s3_dp_stage_params *halfPar; const s3_dp_stage_params (*deepPar)[2]; const s3_dp_stage_params &singlePar; const s3_dp_stage_params *newPar;
 };
 
 // Routing of the pairs the ladder left without a proper pairing (hostKernel with needProceedDP, CPUfunctions.cpp:2153-2262, 2444-2543), the default
 // DP on the half-aligned ones (semiGlobalDP2 -> HalfEndAlignmentEngine -> DPOutputThread -> outputRead2), the deep DP on the rest
 // (DPForUnalignPairs2: seeding round 1, round 2 for the pairs that only lost seeds to the hit limit, PairEndAlignmentEngine ->
 // outputDeepDPResult2), and for the pairs every stage failed on the single-end DP of their ends (DPForUnalignSingle2 + outputSingleResultForPairEnds)
-// into <prefix>.unpair.  NOT built: the new default DP for ends with too many hits (newSemiGlobalDP; such pairs go to the deep DP here).
+// into <prefix>.unpair; pairs with an end aligned to too many places for the default DP go through the new default DP first (newSemiGlobalDP).
 static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &pr, const std::vector<uint64_t> &ooff, const std::vector<uint32_t> &pos,
                          const std::vector<uint8_t> &strand, const std::vector<uint8_t> &mis, const std::vector<uint8_t> &fromSa, uint64_t &defaultDpPairs,
-                         uint64_t &deepDpPairs, uint64_t &leftoverPairs, std::string &err)
+                         uint64_t &newDefaultPairs, uint64_t &deepDpPairs, uint64_t &leftoverPairs, std::string &err)
 {
     const uint32_t np = c.cnt / 2;
     const bool mapqMode = c.alignmentType == 1 || c.alignmentType == 2;
     const int moduleType = c.alignmentType == 2 ? 1 : c.alignmentType;          // all-best + SAM runs the DP module as all-valid (alignment.cu:2023-2030)
     const uint32_t maxHit[2] = {(uint32_t)c.halfPar[0].maxHitNum, (uint32_t)c.halfPar[1].maxHitNum};
     const uint32_t *lens = c.rs.lengths.data() + c.first;
-    std::vector<s3_occ> dpOcc;
+    std::vector<s3_occ> dpOcc, newOcc;                                          // input of the default DP / of the new default DP
     std::vector<uint32_t> deepPairs;                                             // first read (batch index) of the pairs for the deep DP
     std::vector<uint8_t> inDefault(np, 0);
     // an end's hits in the order the reference hands them on: half-aligned pairs keep SA ranges and check-and-extend hits apart and the DP input
@@ -216,7 +216,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             if (h1.size() > maxHit[e]) retainBest(h1);
             kept[e ? r2 : r1] = h1;
             if (h1.size() <= maxHit[e]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; }
-            else deepPairs.push_back(r1);                                            // reference: new default DP
+            else newOcc.insert(newOcc.end(), h1.begin(), h1.end());
             continue;
         }
         endHits(r1, false, h1); endHits(r2, false, h2);
@@ -224,8 +224,8 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         if (h2.size() > maxHit[1]) retainBest(h2);
         kept[r1] = h1; kept[r2] = h2;
         if (h1.size() <= maxHit[0] && h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; }
-        else if (h1.size() < h2.size()) { if (h1.size() <= maxHit[0]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else deepPairs.push_back(r1); }
-        else { if (h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; } else deepPairs.push_back(r1); }
+        else if (h1.size() < h2.size()) { if (h1.size() <= maxHit[0]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else newOcc.insert(newOcc.end(), h1.begin(), h1.end()); }
+        else { if (h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; } else newOcc.insert(newOcc.end(), h2.begin(), h2.end()); }
     }
     auto statsOf = [&](uint32_t p, BwtEndStats st[2]) {
         st[0] = BwtEndStats(); st[1] = BwtEndStats();
@@ -281,8 +281,62 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         for (uint32_t p = 0; p < np; p++) if (inDefault[p] && !done[p]) deepPairs.push_back(2 * p);
         std::sort(deepPairs.begin(), deepPairs.end());
     }
-    // ---- deep DP ----
+    // deep-DP results of a run of pairs -> records (DP2OutputThread :3846-3858: OutputBuffer::ready(), then outputDeepDPResult2)
     std::vector<uint8_t> deepDone(np, 0);
+    auto deepRecords = [&](const s3_dp_deep_result *res, size_t nRes, const char *pool, uint64_t &counter) {
+    for (size_t i = 0; i < nRes;) {
+        size_t j = i;
+        while (j < nRes && res[j].readID / 2 == res[i].readID / 2) j++;
+        // OutputBuffer::ready(): sorted by the first end's position, one result per position; best only for -h 3 / 4 (ScoreCompare: score sum)
+        std::vector<DeepDpHit> hits;
+        for (size_t q = i; q < j; q++) {
+            DeepDpHit h;
+            h.pos1 = res[q].algnmt_1; h.pos2 = res[q].algnmt_2; h.strand1 = res[q].strand_1; h.strand2 = res[q].strand_2;
+            h.score1 = res[q].score_1; h.score2 = res[q].score_2; h.editdist1 = (int)res[q].editdist_1; h.editdist2 = (int)res[q].editdist_2;
+            h.insertSize = (int)res[q].insertSize; h.numSame1 = (int)res[q].num_sameScore_1; h.numSame2 = (int)res[q].num_sameScore_2;
+            if (res[q].cigarOffset_1 != 0xFFFFFFFFu) h.cigar1 = pool + res[q].cigarOffset_1;
+            if (res[q].cigarOffset_2 != 0xFFFFFFFFu) h.cigar2 = pool + res[q].cigarOffset_2;
+            hits.push_back(h);
+        }
+        std::stable_sort(hits.begin(), hits.end(), [](const DeepDpHit &x, const DeepDpHit &y) { return x.pos1 < y.pos1; });
+        size_t u = 0;
+        for (size_t q = 1; q < hits.size(); q++) if (hits[u].pos1 < hits[q].pos1) hits[++u] = hits[q];
+        hits.resize(u + 1);
+        if (moduleType != 1) {
+            int best = hits[0].score1 + hits[0].score2;
+            for (const DeepDpHit &h : hits) best = std::max(best, h.score1 + h.score2);
+            size_t w2 = 0;
+            for (const DeepDpHit &h : hits) if (h.score1 + h.score2 == best) hits[w2++] = h;
+            hits.resize(w2);
+            if (moduleType == 3 && hits.size() != 1) hits.clear();
+            if (moduleType == 4) hits.resize(1);
+        }
+        const uint32_t p = res[i].readID / 2;
+        if (!hits.empty()) {
+            BwtEndStats st[2];
+            statsOf(p, st);
+            w.pairDeepDP(c.rs, c.first + 2 * p, hits.data(), hits.size(), st);
+            deepDone[p] = 1;
+            counter++;
+        }
+        i = j;
+    }
+    };
+    // ---- new default DP (the reference runs it before the default DP; the stages are independent of each other) ----
+    if (!newOcc.empty()) {
+        s3_dp_deep_result *res = nullptr;
+        size_t nRes = 0, nNewPairs = 0;
+        char *pool = nullptr;
+        uint32_t *newPairs = nullptr;
+        const int cut[2] = {c.newPar[0].cutoffThreshold, c.newPar[1].cutoffThreshold};
+        if (s3_dp_new_default(c.dp, c.b, c.seedBatch, lens, newOcc.data(), newOcc.size(), (uint32_t)c.newPar[0].maxHitNum, c.insertLow, c.insertHigh, cut,
+                              c.newPar[0].softClipLeft, c.newPar[0].softClipRight, &res, &nRes, &pool, nullptr, &newPairs, &nNewPairs) != S3_OK) { err = s3_last_error(); return false; }
+        deepRecords(res, nRes, pool, newDefaultPairs);
+        for (size_t k = 0; k < nNewPairs; k++) if (!deepDone[newPairs[k] / 2]) deepPairs.push_back(newPairs[k]);   // passUnalignedToDeepDP
+        std::sort(deepPairs.begin(), deepPairs.end());
+        s3_free(res); s3_free(pool); s3_free(newPairs);
+    }
+    // ---- deep DP ----
     if (!deepPairs.empty()) {
         std::vector<uint32_t> todo = deepPairs;
         for (int round = 0; round < 2 && !todo.empty(); round++) {
@@ -300,43 +354,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
                 if (s3_dp_deep(c.dp, c.b, c.seedBatch, lens, todo.data() + at, m, round == 0 ? S3_STAGE_DEEP_DP_ROUND1 : S3_STAGE_DEEP_DP_ROUND2, (uint32_t)par[0].maxHitNum,
                                c.insertLow, c.insertHigh, cut, par[0].softClipLeft, par[0].softClipRight, &res, &nRes, &pool, &flags) != S3_OK) { err = s3_last_error(); return false; }
                 for (size_t k = 0; k < m; k++) if (round == 0 && flags[k] == 1) next.push_back(todo[at + k]);
-                for (size_t i = 0; i < nRes;) {
-                    size_t j = i;
-                    while (j < nRes && res[j].readID / 2 == res[i].readID / 2) j++;
-                    // OutputBuffer::ready(): sorted by the first end's position, one result per position; best only for -h 3 / 4 (ScoreCompare: score sum)
-                    std::vector<DeepDpHit> hits;
-                    for (size_t q = i; q < j; q++) {
-                        DeepDpHit h;
-                        h.pos1 = res[q].algnmt_1; h.pos2 = res[q].algnmt_2; h.strand1 = res[q].strand_1; h.strand2 = res[q].strand_2;
-                        h.score1 = res[q].score_1; h.score2 = res[q].score_2; h.editdist1 = (int)res[q].editdist_1; h.editdist2 = (int)res[q].editdist_2;
-                        h.insertSize = (int)res[q].insertSize; h.numSame1 = (int)res[q].num_sameScore_1; h.numSame2 = (int)res[q].num_sameScore_2;
-                        if (res[q].cigarOffset_1 != 0xFFFFFFFFu) h.cigar1 = pool + res[q].cigarOffset_1;
-                        if (res[q].cigarOffset_2 != 0xFFFFFFFFu) h.cigar2 = pool + res[q].cigarOffset_2;
-                        hits.push_back(h);
-                    }
-                    std::stable_sort(hits.begin(), hits.end(), [](const DeepDpHit &x, const DeepDpHit &y) { return x.pos1 < y.pos1; });
-                    size_t u = 0;
-                    for (size_t q = 1; q < hits.size(); q++) if (hits[u].pos1 < hits[q].pos1) hits[++u] = hits[q];
-                    hits.resize(u + 1);
-                    if (moduleType != 1) {
-                        int best = hits[0].score1 + hits[0].score2;
-                        for (const DeepDpHit &h : hits) best = std::max(best, h.score1 + h.score2);
-                        size_t w2 = 0;
-                        for (const DeepDpHit &h : hits) if (h.score1 + h.score2 == best) hits[w2++] = h;
-                        hits.resize(w2);
-                        if (moduleType == 3 && hits.size() != 1) hits.clear();
-                        if (moduleType == 4) hits.resize(1);
-                    }
-                    const uint32_t p = res[i].readID / 2;
-                    if (!hits.empty()) {
-                        BwtEndStats st[2];
-                        statsOf(p, st);
-                        w.pairDeepDP(c.rs, c.first + 2 * p, hits.data(), hits.size(), st);
-                        deepDone[p] = 1;
-                        deepDpPairs++;
-                    }
-                    i = j;
-                }
+                deepRecords(res, nRes, pool, deepDpPairs);
                 s3_free(res); s3_free(pool); s3_free(flags);
             }
             todo.swap(next);
@@ -465,10 +483,10 @@ int main(int argc, char **argv)
     FILE *dpOut = nullptr;
     s3_dp *dp = nullptr;
     s3_batch *seedBatch = nullptr;
-    s3_dp_stage_params dpPar{}, halfPar[2] = {}, deepPar[2][2] = {};
+    s3_dp_stage_params dpPar{}, halfPar[2] = {}, deepPar[2][2] = {}, newPar[2] = {};
     s3_dp *dpHalf = nullptr;
     FILE *unpairOut = nullptr;
-    uint64_t dpAlignedReads = 0, defaultDpPairs = 0, deepDpPairs = 0, leftoverPairs = 0;
+    uint64_t dpAlignedReads = 0, defaultDpPairs = 0, newDefaultPairs = 0, deepDpPairs = 0, leftoverPairs = 0;
     if (enableDP) {
         const std::string dpName = prefix + ".dpout.1";
         dpOut = fopen(dpName.c_str(), "w");
@@ -491,6 +509,7 @@ int main(int argc, char **argv)
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength, &di, &halfPar[0]);
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength2, &di, &halfPar[1]);
             for (int e = 0; e < 2; e++) {
+                s3_dp_stage_parameters(S3_STAGE_NEW_DEFAULT_DP, e ? detectedReadLength2 : detectedReadLength, &di, &newPar[e]);
                 s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND1, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[0][e]);
                 s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND2, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[1][e]);
             }
@@ -537,11 +556,11 @@ int main(int argc, char **argv)
                 }
             }, aligned);
             if (enableDP) {
-                PairDpCtx c{hix, so, rs, ini, b, seedBatch, dp, dpHalf, dpOut, unpairOut, first, cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar};
+                PairDpCtx c{hix, so, rs, ini, b, seedBatch, dp, dpHalf, dpOut, unpairOut, first, cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
                 std::vector<uint8_t> fromSa(nOcc ? nOcc : 1);
                 if (s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return die(s3_last_error());
                 std::string e2;
-                if (!pairDpStages(c, pr, ooff, pos, strand, mis, fromSa, defaultDpPairs, deepDpPairs, leftoverPairs, e2)) return die(e2);
+                if (!pairDpStages(c, pr, ooff, pos, strand, mis, fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) return die(e2);
             }
             continue;
         }
@@ -597,9 +616,10 @@ int main(int argc, char **argv)
         fclose(dpOut);
         if (paired) {
             fclose(unpairOut);
-            printf("[Main] Number of pairs aligned by DP: %llu\n[Main] Number of pairs aligned by deep DP: %llu\n[Main] Pairs left without a proper pairing: %llu\n",
-                   (unsigned long long)defaultDpPairs, (unsigned long long)deepDpPairs, (unsigned long long)leftoverPairs);
-            dpAlignedReads = 2 * (defaultDpPairs + deepDpPairs);
+            printf("[Main] Number of pairs aligned by new default DP: %llu\n[Main] Number of pairs aligned by DP: %llu\n[Main] Number of pairs aligned by deep DP: %llu\n"
+                   "[Main] Pairs left without a proper pairing: %llu\n",
+                   (unsigned long long)newDefaultPairs, (unsigned long long)defaultDpPairs, (unsigned long long)deepDpPairs, (unsigned long long)leftoverPairs);
+            dpAlignedReads = 2 * (defaultDpPairs + newDefaultPairs + deepDpPairs);
             s3_dp_free(dpHalf);
         } else printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)dpAlignedReads);
         aligned += dpAlignedReads;

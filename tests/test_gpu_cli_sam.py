@@ -297,3 +297,56 @@ def test_cli_default_mode_pairs_with_dp(tmp_path):
         # single-end DP (10 hits per seed) and stays unaligned, as it would in the reference
         assert ok.get(key, 0) >= (0.6 if key == "exact/far" else 0.9) * tot[key], (ok, tot)
     assert "Number of pairs aligned by DP" in out.stdout and "aligned by deep DP" in out.stdout
+
+
+def test_cli_pairs_new_default_dp_for_ends_with_too_many_hits(tmp_path):
+    """An end that sits in a repeat with more copies than the default DP takes (getMaxHitNumForDefaultDP) while its mate failed the BWT stage:
+    the pair goes through the new default DP -- the aligned end's hits as they are, the mate seeded, both aligned by the DP -- and comes out in
+    .dpout.1 as a proper pair next to the right copy of the repeat."""
+    import re
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "soap3-dp_amd", "py"))
+    import s3dp
+    from s3dp import builder
+    rng = np.random.default_rng(4)
+    n, L, copies = 200000, 100, 90
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    rep = rng.integers(0, 4, size=L, dtype=np.uint8)
+    starts = [1000 + 2100 * k for k in range(copies)]
+    for st in starts:
+        codes[st:st + L] = rep
+    hi = builder.build_host_index(codes, device="cpu")
+    hi.write_files(str(tmp_path / "g.index"), with_lkt=True)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+    txt = lambda a: "".join("ACGT"[int(c)] for c in a)
+    r1, r2, truth = [], [], []
+    for k in range(0, copies, 4):                             # the repeat as the '+' end, its mate 300 further on with a 3-base deletion
+        st = starts[k]
+        m = st + 300
+        c = int(rng.integers(30, 70))
+        mate = np.concatenate([codes[m:m + c], codes[m + c + 3:m + L + 3]])
+        r1.append(txt(rep)); r2.append(txt(comp[mate[::-1]]))
+        truth.append((st + 1, m + 1))
+    for fn, rr, tag in (("r1.fq", r1, 1), ("r2.fq", r2, 2)):
+        with open(tmp_path / fn, "w") as f:
+            for i, s in enumerate(rr):
+                f.write("@n%d/%d\n%s\n+\n%s\n" % (i, tag, s, "I" * len(s)))
+    out = subprocess.run([BIN, "pair", "g.index", "r1.fq", "r2.fq", "-u", "500", "-v", "100", "-L", "100", "-o", "out"], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    recs = {}
+    for l in open(tmp_path / "out.dpout.1"):
+        if not l.startswith("@"):
+            f = l.rstrip("\n").split("\t")
+            recs.setdefault(f[0], {})[int(f[1]) & 0xC0] = f
+    m = re.search(r"aligned by new default DP: (\d+)", out.stdout)
+    assert m and int(m.group(1)) >= 0.9 * len(truth), out.stdout[-1500:]
+    good = 0
+    for i, (p1, p2) in enumerate(truth):
+        pr = recs.get("n%d" % i)
+        if not pr or 0x40 not in pr or 0x80 not in pr:
+            continue
+        a, b = pr[0x40], pr[0x80]
+        good += bool(int(a[1]) & 2 and int(a[3]) == p1 and a[5] == "100M" and abs(int(b[3]) - p2) <= 3 and re.sub(r"\d+", "", b[5]) == "MDM" and int(b[1]) & 16)
+    assert good >= 0.9 * len(truth), (good, len(truth))
