@@ -20,6 +20,8 @@
 #include <pthread.h>
 #include <zlib.h>
 #include <vector>
+#include <algorithm>
+#include <string>
 
 #include "CPUfunctions.h"
 #include "QueryParser.h"
@@ -322,6 +324,9 @@ struct Ctx
     InputOptions opt;
     samfile_t * samOut;
     char * outName;
+    // pairs with the DP stages on: where hostKernel's needProceedDP branch (CPUfunctions.cpp:2153-2262, 2444-2543) sends what it cannot pair
+    ReadInputForDP * dpInput, * dpInputNew, * otherSoap3;
+    BothUnalignedPairs * bothUnaligned;
 };
 
 static void allValid ( Ctx & C, Reads & R, uint * queries, uint * readLengths, uint * seedLengths, uint * readIDs, uint numQueries, uint numMismatch,
@@ -360,6 +365,13 @@ static void allValid ( Ctx & C, Reads & R, uint * queries, uint * readLengths, u
     hk[0].sa_range_allowed_2 = sa2;
     hk[0].maxNumMismatch = numMismatch;
     hk[0].bothUnalignedPairs = ( ( BothUnalignedPairsArrays * ) C.index->sraIndex->hspaux->readsIDForSingleDP )->array[0];
+
+    if ( C.dpInput )
+    {
+        hk[0].readInput = C.dpInput; hk[0].readInputForNewDefault = C.dpInputNew; hk[0].otherSoap3Result = C.otherSoap3;
+        hk[0].bothUnalignedPairs = C.bothUnaligned;
+    }
+
     hk[0].sraQuerySettings.SAMOutFilePtr = C.samOut;
     uint * lens = seedLengths ? seedLengths : readLengths;
 
@@ -566,6 +578,28 @@ static int modeSam ( int argc, char ** argv )
         for ( uint i = 0; i < R.numQueries; i++ ) { seedLengths[i] = R.readLengths[i] > LONG_READ_LEN ? SOAP3_SEED_LEN : R.readLengths[i]; }
     }
 
+    C.dpInput = C.dpInputNew = C.otherSoap3 = NULL;
+    C.bothUnaligned = NULL;
+    std::vector<uint> origID ( R.readIDs, R.readIDs + R.numQueries );      // packUnPairedReads renumbers the reads between phases
+
+    if ( paired && C.opt.enableDP == 1 )
+    {
+        uint d1 = GetReadLength ( R.readLengths, R.numQueries, 2 ), d2 = GetReadLength ( R.readLengths + 1, R.numQueries, 2 );
+
+        if ( C.opt.insert_low < ( int ) d2 ) { C.opt.insert_low = d2; }     // SOAP3-DP.cu:632-634
+
+        if ( d1 <= 50 || d2 <= 50 ) { C.opt.numMismatch = 1; }
+
+        C.opt.maxHitNum = getMaxHitNumForDefaultDP ( d1 );
+        C.opt.maxHitNum2 = getMaxHitNumForDefaultDP ( d2 );
+        C.dpInput = constructReadInputForDP ( 1 ); C.dpInputNew = constructReadInputForDP ( 1 ); C.otherSoap3 = constructReadInputForDP ( 1 );
+        C.bothUnaligned = constructBothUnalignedPairs ();
+        memset ( hspaux->x0_array, 0, roundUp * sizeof ( int ) ); memset ( hspaux->x1_array, 0, roundUp * sizeof ( int ) );
+        memset ( hspaux->mismatch_array, 0, roundUp * sizeof ( int ) );
+        memset ( hspaux->sa_num, 0, roundUp * sizeof ( unsigned int ) ); memset ( hspaux->occ_num, 0, roundUp * sizeof ( unsigned int ) );
+        memset ( hspaux->soap3AnsArray, 0, roundUp * sizeof ( void * ) );
+    }
+
     uint * unAligned = ( uint * ) malloc ( roundUp * sizeof ( uint ) );
     uint numUn = 0, numQueries = R.numQueries;
     unsigned long long totalAns = 0;
@@ -656,6 +690,56 @@ static int modeSam ( int argc, char ** argv )
     samclose ( C.samOut );
     fprintf ( stderr, "[harness] aligned %u of %u reads, %llu alignments, %.3f s (%.1f reads/s, 1 thread)\n", totalAligned, R.numQueries, totalAns, dt,
               R.numQueries / dt );
+
+    if ( C.dpInput )
+    {
+        // <prefix>.routing: one line per hit handed on, in the order of the lists (per read: SA ranges expanded, then occurrences):
+        //   D|N|O <read> <strand> <mismatches> <position>      default DP / new default DP / kept for the unpaired output;   U <first read of the pair>
+        // read = index in the input (the ladder packs the unpaired reads to the front between phases: readIDs[] maps back)
+        std::string rn = std::string ( C.opt.outputPrefix ) + ".routing";
+        FILE * f = fopen ( rn.c_str (), "w" );
+        BWT * bwt = C.index->sraIndex->bwt;
+        ReadInputForDP * lists[3] = { C.dpInput, C.dpInputNew, C.otherSoap3 };
+        const char tag[3] = { 'D', 'N', 'O' };
+
+        for ( int l = 0; l < 3; l++ )
+        {
+            ReadInputForDP * in = lists[l];
+            std::vector<std::pair<uint, std::string> > rows;     // keyed by read so that SA ranges stand before the occurrences of the same read
+
+            for ( unsigned int i = 0; i < in->saRangeTotalNum; i++ )
+                for ( unsigned int k = in->sa_list[i].saIndexLeft; k <= in->sa_list[i].saIndexRight; k++ )
+                {
+                    char buf[128];
+                    uint rd = R.readIDs[in->sa_list[i].readID] - 1;
+                    sprintf ( buf, "%c %u %d %d %u", tag[l], rd, ( int ) in->sa_list[i].strand, ( int ) in->sa_list[i].mismatchCount, ( uint ) ( *bwt->_bwtSaValue ) ( bwt, k ) );
+                    rows.push_back ( std::make_pair ( rd, std::string ( buf ) ) );
+                }
+
+            for ( unsigned int i = 0; i < in->occTotalNum; i++ )
+            {
+                char buf[128];
+                uint rd = R.readIDs[in->occ_list[i].readID] - 1;
+                sprintf ( buf, "%c %u %d %d %u", tag[l], rd, ( int ) in->occ_list[i].strand, ( int ) in->occ_list[i].mismatchCount, ( uint ) in->occ_list[i].ambPosition );
+                rows.push_back ( std::make_pair ( rd, std::string ( buf ) ) );
+            }
+
+            std::stable_sort ( rows.begin (), rows.end (), [] ( const std::pair<uint, std::string> & a, const std::pair<uint, std::string> & b ) { return a.first < b.first; } );
+
+            for ( size_t i = 0; i < rows.size (); i++ ) { fprintf ( f, "%s\n", rows[i].second.c_str () ); }
+        }
+
+        std::vector<uint> un;
+
+        for ( unsigned int i = 0; i < C.bothUnaligned->totalNum; i++ ) { un.push_back ( R.readIDs[C.bothUnaligned->readIDs[i]] - 1 ); }
+
+        std::sort ( un.begin (), un.end () );
+
+        for ( size_t i = 0; i < un.size (); i++ ) { fprintf ( f, "U %u\n", un[i] ); }
+
+        fclose ( f );
+    }
+
     return 0;
 }
 

@@ -181,6 +181,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
     const int moduleType = c.alignmentType == 2 ? 1 : c.alignmentType;          // all-best + SAM runs the DP module as all-valid (alignment.cu:2023-2030)
     const uint32_t maxHit[2] = {(uint32_t)c.halfPar[0].maxHitNum, (uint32_t)c.halfPar[1].maxHitNum};
     const uint32_t *lens = c.rs.lengths.data() + c.first;
+    std::vector<s3_occ> otherOcc;                                                // otherSoap3Result: kept for the unpaired output only
     std::vector<s3_occ> dpOcc, newOcc;                                          // input of the default DP / of the new default DP
     std::vector<uint32_t> deepPairs;                                             // first read (batch index) of the pairs for the deep DP
     std::vector<uint8_t> inDefault(np, 0);
@@ -224,8 +225,23 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         if (h2.size() > maxHit[1]) retainBest(h2);
         kept[r1] = h1; kept[r2] = h2;
         if (h1.size() <= maxHit[0] && h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; }
-        else if (h1.size() < h2.size()) { if (h1.size() <= maxHit[0]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else newOcc.insert(newOcc.end(), h1.begin(), h1.end()); }
-        else { if (h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; } else newOcc.insert(newOcc.end(), h2.begin(), h2.end()); }
+        else if (h1.size() < h2.size()) {
+            if (h1.size() <= maxHit[0]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else newOcc.insert(newOcc.end(), h1.begin(), h1.end());
+            otherOcc.insert(otherOcc.end(), h2.begin(), h2.end());
+        } else {
+            if (h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; } else newOcc.insert(newOcc.end(), h2.begin(), h2.end());
+            otherOcc.insert(otherOcc.end(), h1.begin(), h1.end());
+        }
+    }
+    if (const char *dump = getenv("S3DP_DUMP_ROUTING")) {                        // the routing, for tests/test_gpu_cli_sam.py (format: oracle/ref_harness.cpp)
+        FILE *f = fopen(dump, c.first ? "a" : "w");
+        if (f) {
+            const std::vector<s3_occ> *lists[3] = {&dpOcc, &newOcc, &otherOcc};
+            for (int l = 0; l < 3; l++)
+                for (const s3_occ &x : *lists[l]) fprintf(f, "%c %u %d %d %u\n", "DNO"[l], c.first + x.readID, (int)x.strand, (int)x.mismatchCount, x.pos);
+            for (uint32_t r1 : deepPairs) fprintf(f, "U %u\n", c.first + r1);
+            fclose(f);
+        }
     }
     auto statsOf = [&](uint32_t p, BwtEndStats st[2]) {
         st[0] = BwtEndStats(); st[1] = BwtEndStats();

@@ -89,6 +89,26 @@ mk g1 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 6 --genome-seed 1" "-
 mk g2 "--genome-len 60000 --chroms 2 --n-runs 2 --repeats 40 --genome-seed 7" "--reads 1500 --read-len 100 --var-len 25 120 --read-seed 11" 120
 mkl g3 "--genome-len 120000 --chroms 2 --n-runs 4 --repeats 12 --genome-seed 5" "--reads 1200 --var-len 121 200 --read-seed 31 --mix 0.3 0.2 0.15 0.1 0.08 0.07 0.05 0.03 0.02" 200
 mkp g4 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 8 --genome-seed 9" "--pairs 1200 --read-len 100 --read-seed 77" 100
+# routing of unpaired pairs with the DP stages on (hostKernel's needProceedDP branch): which end goes to which DP stage, in which order
+( cd $W && $REF/ref_harness sam $INI pair g4.fa.index $OUT/g4/reads_1.fq $OUT/g4/reads_2.fq -u 500 -v 100 -L 100 -o g4dp > /dev/null 2>&1
+  gzip -9n < g4dp.routing > $OUT/g4/pe_routing.txt.gz
+  mkdir -p $OUT/g5
+  python $ROOT/tools/simulate_routing_case.py --fasta g5.fa --fastq1 g5_1.fq --fastq2 g5_2.fq
+  $REF/soap3-dp-builder g5.fa > /dev/null; $REF/BGS-Build g5.fa.index > /dev/null
+  $REF/ref_harness sam $INI pair g5.fa.index g5_1.fq g5_2.fq -u 500 -v 100 -L 100 -o g5dp > /dev/null 2>&1
+  for f in bwt rev.bwt fmv.gpu rev.fmv.gpu sa pac ann amb tra; do cp g5.fa.index.$f $OUT/g5/index.$f; done
+  cp g5_1.fq $OUT/g5/reads_1.fq; cp g5_2.fq $OUT/g5/reads_2.fq; gzip -9n < g5dp.routing > $OUT/g5/pe_routing.txt.gz
+)
+# routing of unpaired pairs with the DP stages on (hostKernel's needProceedDP branch): which end goes to which DP stage, in which order
+( cd $W && $REF/ref_harness sam $INI pair g4.fa.index g4_1.fq g4_2.fq -u 500 -v 100 -L 100 -o g4dp > /dev/null 2>&1
+  gzip -9n < g4dp.routing > $OUT/g4/pe_routing.txt.gz
+  mkdir -p $OUT/g5
+  python $ROOT/tools/simulate_routing_case.py --fasta g5.fa --fastq1 g5_1.fq --fastq2 g5_2.fq
+  $REF/soap3-dp-builder g5.fa > /dev/null; $REF/BGS-Build g5.fa.index > /dev/null
+  $REF/ref_harness sam $INI pair g5.fa.index g5_1.fq g5_2.fq -u 500 -v 100 -L 100 -o g5dp > /dev/null 2>&1
+  for f in bwt rev.bwt fmv.gpu rev.fmv.gpu sa pac ann amb tra; do cp g5.fa.index.$f $OUT/g5/index.$f; done
+  cp g5_1.fq $OUT/g5/reads_1.fq; cp g5_2.fq $OUT/g5/reads_2.fq; gzip -9n < g5dp.routing > $OUT/g5/pe_routing.txt.gz
+)
 # output stage of the single-read DP: reads + synthetic DP result vectors -> the reference's own SAM records
 mkdir -p $OUT/dp1
 ( cd $W && python $ROOT/tools/simulate.py --genome-len 90000 --chroms 3 --n-runs 4 --genome-seed 21 --fasta dp1.fa

@@ -350,3 +350,35 @@ def test_cli_pairs_new_default_dp_for_ends_with_too_many_hits(tmp_path):
         a, b = pr[0x40], pr[0x80]
         good += bool(int(a[1]) & 2 and int(a[3]) == p1 and a[5] == "100M" and abs(int(b[3]) - p2) <= 3 and re.sub(r"\d+", "", b[5]) == "MDM" and int(b[1]) & 16)
     assert good >= 0.9 * len(truth), (good, len(truth))
+
+
+@pytest.mark.parametrize("name", ["g4", "g5"])
+def test_cli_pair_dp_routing_matches_the_reference(tmp_path, name):
+    """Pairs the BWT ladder leaves without a proper pairing, DP stages on: which end goes to the default DP (D), to the new default DP (N), is
+    only kept for the unpaired output (O), which pairs go straight to the deep DP (U) -- and the hits in the order the DP stages will read them.
+    Golden: the reference's own hostKernel (needProceedDP branch, CPUfunctions.cpp:2153-2262, 2444-2543) through oracle/ref_harness.cpp.  g5 is
+    built for this: repeat families above and below the default DP's hit limit, mates damaged / random / far away."""
+    env = dict(os.environ, S3DP_DUMP_ROUTING=str(tmp_path / "routing.txt"))
+    out = subprocess.run([BIN, "pair", os.path.join(GOLDEN, name, "index"), os.path.join(GOLDEN, name, "reads_1.fq"), os.path.join(GOLDEN, name, "reads_2.fq"),
+                          "-u", "500", "-v", "100", "-L", "100", "-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+
+    def parse(text):
+        lists, un = {}, set()
+        for l in text.split("\n"):
+            f = l.split()
+            if not f:
+                continue
+            if f[0] == "U":
+                un.add(int(f[1]))
+            else:
+                lists.setdefault((f[0], int(f[1])), []).append(tuple(int(x) for x in f[2:]))
+        return lists, un
+    mine, mine_un = parse(open(tmp_path / "routing.txt").read())
+    ref, ref_un = parse(gzip.open(os.path.join(GOLDEN, name, "pe_routing.txt.gz"), "rt").read())
+    assert mine_un == ref_un
+    assert set(mine) == set(ref), (sorted(set(mine) ^ set(ref))[:10])
+    bad = [k for k in ref if ref[k] != mine[k]]
+    assert not bad, (bad[:5], ref[bad[0]][:6], mine[bad[0]][:6])
+    if name == "g5":
+        assert {k[0] for k in ref} == {"D", "N", "O"}
