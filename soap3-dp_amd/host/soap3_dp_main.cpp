@@ -486,7 +486,7 @@ int main(int argc, char **argv)
     if (s3_index_upload(device, &d, &ix) != S3_OK) return die(s3_last_error());
     printf("[Main] Finished copying index into device (GPU).\n");
     const auto tAlign = std::chrono::steady_clock::now();
-    double devSeconds = 0, formatSeconds = 0;
+    double devSeconds = 0, formatSeconds = 0, dpStageSeconds = 0;
     const std::string outName = prefix + ".gout.1";
     FILE *out = fopen(outName.c_str(), "w");
     if (!out) return die("Could not open the output file " + outName);
@@ -576,7 +576,9 @@ int main(int argc, char **argv)
                 std::vector<uint8_t> fromSa(nOcc ? nOcc : 1);
                 if (s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return die(s3_last_error());
                 std::string e2;
+                const auto tDp = std::chrono::steady_clock::now();
                 if (!pairDpStages(c, pr, ooff, pos, strand, mis, fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) return die(e2);
+                dpStageSeconds += since(tDp);
             }
             continue;
         }
@@ -633,8 +635,8 @@ int main(int argc, char **argv)
         if (paired) {
             fclose(unpairOut);
             printf("[Main] Number of pairs aligned by new default DP: %llu\n[Main] Number of pairs aligned by DP: %llu\n[Main] Number of pairs aligned by deep DP: %llu\n"
-                   "[Main] Pairs left without a proper pairing: %llu\n",
-                   (unsigned long long)newDefaultPairs, (unsigned long long)defaultDpPairs, (unsigned long long)deepDpPairs, (unsigned long long)leftoverPairs);
+                   "[Main] Pairs left without a proper pairing: %llu\n[Main] DP stages time : %9.4f seconds\n",
+                   (unsigned long long)newDefaultPairs, (unsigned long long)defaultDpPairs, (unsigned long long)deepDpPairs, (unsigned long long)leftoverPairs, dpStageSeconds);
             dpAlignedReads = 2 * (defaultDpPairs + newDefaultPairs + deepDpPairs);
             s3_dp_free(dpHalf);
         } else printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)dpAlignedReads);

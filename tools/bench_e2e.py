@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--mismatch", type=int, default=4)
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--threads", type=int, default=0, help="host threads (0 = all)")
+    ap.add_argument("--pairs", type=int, default=0, help="paired-end default mode (DP stages on) with this many 2 x read-len pairs instead of single reads")
     a = ap.parse_args()
     import torch
     import s3dp
@@ -40,6 +41,8 @@ def main():
     hi = builder.build_host_index(codes, device=dev)
     hi.write_files(os.path.join(work, "g.index"), with_lkt=True)
     t_index = time.time() - t
+    if a.pairs:
+        return pairs_mode(a, codes, work, rng, t_index)
     # reads: uniform start, strand 50/50, 0-4 substitutions (55/25/12/5/3 %), quality 'I'
     t = time.time()
     L, N = a.read_len, a.reads
@@ -83,6 +86,77 @@ def main():
            "sam_bytes": sam_bytes, "fastq_bytes": os.path.getsize(fq),
            "reads_per_s_wall_incl_index_load": N / wall,
            "reads_per_s_reads_in_sam_out": N / (ph.get("Read load time", 0) + ph.get("Alignment + output time", 0) or wall)}
+    print(json.dumps(res))
+
+
+def pairs_mode(a, codes, work, rng, t_index):
+    """BASELINE.json configs[2] in small: 2 x L pairs, insert 350 +- 40, `soap3-dp pair -u 500 -v 1` with the DP stages on.  90 % of the pairs
+    carry 0-2 substitutions per end (the BWT ladder pairs them), 6 % have a 3-base deletion or 2-base insertion in one end (default DP),
+    3 % in both ends (deep DP), 1 % a random mate (single-end DP, .unpair)."""
+    t = time.time()
+    L, N = a.read_len, a.pairs
+    ins = np.clip(rng.normal(350, 40, size=N).astype(np.int64), 2 * L // 2 + 20, 480)
+    ins = np.maximum(ins, L + 10)
+    st = rng.integers(0, a.genome_bp - 600, size=N)
+    kind = rng.choice(4, size=N, p=[0.90, 0.06, 0.03, 0.01])
+    left = codes[st[:, None] + np.arange(L + 4)[None, :]]
+    right = codes[(st + ins - L)[:, None] + np.arange(L + 4)[None, :]]
+
+    def subs(x):
+        n = rng.choice(3, size=len(x), p=[0.7, 0.2, 0.1])
+        for k in (1, 2):
+            rows = np.nonzero(n >= k)[0]
+            cols = rng.integers(0, L, size=len(rows))
+            x[rows, cols] = (x[rows, cols] + rng.integers(1, 4, size=len(rows))) % 4
+
+    def indel(x, rows):
+        for r in rows:
+            c = int(rng.integers(40, L - 40))
+            if r & 1:
+                x[r, c:L] = x[r, c + 3:L + 3]                                   # deletion of 3
+            else:
+                x[r, c + 2:L] = x[r, c:L - 2].copy(); x[r, c:c + 2] = rng.integers(0, 4, size=2)   # insertion of 2
+    subs(left); subs(right)
+    indel(right, np.nonzero(kind == 1)[0])
+    indel(left, np.nonzero(kind == 2)[0]); indel(right, np.nonzero(kind == 2)[0])
+    junk = np.nonzero(kind == 3)[0]
+    right[junk] = rng.integers(0, 4, size=(len(junk), L + 4))
+    a_ = left[:, :L]
+    b_ = 3 - right[:, :L][:, ::-1]
+    swap = rng.random(N) < 0.5
+    r1 = np.where(swap[:, None], b_, a_)
+    r2 = np.where(swap[:, None], a_, b_)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    files = []
+    for tag, rr in ((1, r1), (2, r2)):
+        fq = os.path.join(work, "reads_%d.fq" % tag)
+        files.append(fq)
+        txt = letters[rr]
+        with open(fq, "wb") as f:
+            qual = b"I" * L
+            for b0 in range(0, N, 200_000):
+                f.write(b"".join(b"@p%d/%d\n" % (i, tag) + txt[i].tobytes() + b"\n+\n" + qual + b"\n" for i in range(b0, min(N, b0 + 200_000))))
+    t_reads = time.time() - t
+    env = dict(os.environ)
+    if a.threads:
+        env["S3DP_HOST_THREADS"] = str(a.threads)
+    exe = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
+    t = time.time()
+    out = subprocess.run([exe, "pair", os.path.join(work, "g.index"), files[0], files[1], "-L", str(L), "-u", "500", "-v", "1", "-o", os.path.join(work, "out")],
+                         capture_output=True, text=True, env=env)
+    wall = time.time() - t
+    if out.returncode != 0:
+        print(out.stdout[-2000:], out.stderr[-2000:], file=sys.stderr)
+        raise SystemExit(1)
+    ph = {k: float(v) for k, v in re.findall(r"\[Main\] (Loading time|Read load time|Alignment \+ output time|Total elapsed time|DP stages time) :\s+([0-9.]+)", out.stdout)}
+    counts = {k: int(v) for k, v in re.findall(r"\[Main\] (Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|"
+                                               r"Pairs left without a proper pairing|Overall number of reads aligned): (\d+)", out.stdout)}
+    res = {"mode": "pair, DP stages on", "genome_bp": a.genome_bp, "pairs": N, "read_len": L, "host_threads": a.threads or os.cpu_count(),
+           "pair_mix": {"bwt": 0.90, "one_end_indel": 0.06, "both_ends_indel": 0.03, "random_mate": 0.01},
+           "index_build_and_write_s": t_index, "fastq_write_s": t_reads, "wall_s_total": wall, "phases_s": ph, "counts": counts,
+           "sam_bytes": sum(os.path.getsize(os.path.join(work, "out." + e)) for e in ("gout.1", "dpout.1", "unpair")),
+           "pairs_per_s_wall_incl_index_load": N / wall,
+           "pairs_per_s_reads_in_sam_out": N / (ph.get("Read load time", 0) + ph.get("Alignment + output time", 0) or wall)}
     print(json.dumps(res))
 
 
