@@ -95,12 +95,10 @@ def pairs_mode(a, codes, work, rng, t_index):
     3 % in both ends (deep DP), 1 % a random mate (single-end DP, .unpair)."""
     t = time.time()
     L, N = a.read_len, a.pairs
-    ins = np.clip(rng.normal(350, 40, size=N).astype(np.int64), 2 * L // 2 + 20, 480)
-    ins = np.maximum(ins, L + 10)
-    st = rng.integers(0, a.genome_bp - 600, size=N)
-    kind = rng.choice(4, size=N, p=[0.90, 0.06, 0.03, 0.01])
-    left = codes[st[:, None] + np.arange(L + 4)[None, :]]
-    right = codes[(st + ins - L)[:, None] + np.arange(L + 4)[None, :]]
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    files = [os.path.join(work, "reads_%d.fq" % tag) for tag in (1, 2)]
+    fh = [open(f, "wb") for f in files]
+    qual = b"I" * L
 
     def subs(x):
         n = rng.choice(3, size=len(x), p=[0.7, 0.2, 0.1])
@@ -116,26 +114,26 @@ def pairs_mode(a, codes, work, rng, t_index):
                 x[r, c:L] = x[r, c + 3:L + 3]                                   # deletion of 3
             else:
                 x[r, c + 2:L] = x[r, c:L - 2].copy(); x[r, c:c + 2] = rng.integers(0, 4, size=2)   # insertion of 2
-    subs(left); subs(right)
-    indel(right, np.nonzero(kind == 1)[0])
-    indel(left, np.nonzero(kind == 2)[0]); indel(right, np.nonzero(kind == 2)[0])
-    junk = np.nonzero(kind == 3)[0]
-    right[junk] = rng.integers(0, 4, size=(len(junk), L + 4))
-    a_ = left[:, :L]
-    b_ = 3 - right[:, :L][:, ::-1]
-    swap = rng.random(N) < 0.5
-    r1 = np.where(swap[:, None], b_, a_)
-    r2 = np.where(swap[:, None], a_, b_)
-    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
-    files = []
-    for tag, rr in ((1, r1), (2, r2)):
-        fq = os.path.join(work, "reads_%d.fq" % tag)
-        files.append(fq)
-        txt = letters[rr]
-        with open(fq, "wb") as f:
-            qual = b"I" * L
-            for b0 in range(0, N, 200_000):
-                f.write(b"".join(b"@p%d/%d\n" % (i, tag) + txt[i].tobytes() + b"\n+\n" + qual + b"\n" for i in range(b0, min(N, b0 + 200_000))))
+    for b0 in range(0, N, 500_000):
+        n = min(500_000, N - b0)
+        ins = np.maximum(np.clip(rng.normal(350, 40, size=n).astype(np.int64), 0, 480), L + 10)
+        st = rng.integers(0, a.genome_bp - 600, size=n)
+        kind = rng.choice(4, size=n, p=[0.90, 0.06, 0.03, 0.01])
+        left = codes[st[:, None] + np.arange(L + 4)[None, :]]
+        right = codes[(st + ins - L)[:, None] + np.arange(L + 4)[None, :]]
+        subs(left); subs(right)
+        indel(right, np.nonzero(kind == 1)[0])
+        indel(left, np.nonzero(kind == 2)[0]); indel(right, np.nonzero(kind == 2)[0])
+        junk = np.nonzero(kind == 3)[0]
+        right[junk] = rng.integers(0, 4, size=(len(junk), L + 4))
+        a_ = left[:, :L]
+        b_ = 3 - right[:, :L][:, ::-1]
+        swap = rng.random(n) < 0.5
+        for tag, rr in ((1, np.where(swap[:, None], b_, a_)), (2, np.where(swap[:, None], a_, b_))):
+            txt = letters[rr]
+            fh[tag - 1].write(b"".join(b"@p%d/%d\n" % (b0 + i, tag) + txt[i].tobytes() + b"\n+\n" + qual + b"\n" for i in range(n)))
+    for f in fh:
+        f.close()
     t_reads = time.time() - t
     env = dict(os.environ)
     if a.threads:
