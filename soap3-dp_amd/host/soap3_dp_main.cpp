@@ -159,6 +159,8 @@ static bool singleDpRuns(s3_batch *b, s3_batch *seedBatch, s3_dp *dp, const uint
     return true;
 }
 
+static double g_pairStageSeconds[5] = {0, 0, 0, 0, 0};          // routing, default DP, new default DP, deep DP, single-end DP of the leftovers
+
 // ---- DP stages of a paired-end batch (soap3_dp_pair_align after the BWT ladder, alignment.cu:2021-2420) --------------------------------------
 struct PairDpCtx {
     const HostIndex &hix; const SamOptions &so; const ReadSet &rs; const Ini &ini;
@@ -177,6 +179,8 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
                          uint64_t &newDefaultPairs, uint64_t &deepDpPairs, uint64_t &leftoverPairs, std::string &err)
 {
     const uint32_t np = c.cnt / 2;
+    auto tStage = std::chrono::steady_clock::now();
+    auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); g_pairStageSeconds[k] += std::chrono::duration<double>(now - tStage).count(); tStage = now; };
     const bool mapqMode = c.alignmentType == 1 || c.alignmentType == 2;
     const int moduleType = c.alignmentType == 2 ? 1 : c.alignmentType;          // all-best + SAM runs the DP module as all-valid (alignment.cu:2023-2030)
     const uint32_t maxHit[2] = {(uint32_t)c.halfPar[0].maxHitNum, (uint32_t)c.halfPar[1].maxHitNum};
@@ -249,6 +253,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         if (pr[p].min2 != 255) { st[1].x0 = (int)pr[p].x0_2; st[1].x1 = (int)pr[p].x1_2; st[1].mismatch = pr[p].min2; }
     };
     SamWriter w(c.hix, c.so, c.dpOut);
+    lap(0);
     // ---- default DP ----
     if (!dpOcc.empty()) {
         s3_dp_half_result *res = nullptr;
@@ -338,6 +343,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         i = j;
     }
     };
+    lap(1);
     // ---- new default DP (the reference runs it before the default DP; the stages are independent of each other) ----
     if (!newOcc.empty()) {
         s3_dp_deep_result *res = nullptr;
@@ -352,6 +358,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         std::sort(deepPairs.begin(), deepPairs.end());
         s3_free(res); s3_free(pool); s3_free(newPairs);
     }
+    lap(2);
     // ---- deep DP ----
     if (!deepPairs.empty()) {
         std::vector<uint32_t> todo = deepPairs;
@@ -376,6 +383,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             todo.swap(next);
         }
     }
+    lap(3);
     // ---- what every stage failed on: each end on its own (outputDeepDPResult2 :624-650: an end without BWT hits goes through the single-end DP;
     //      with hits the FIRST end keeps them, the second end keeps its own only when the first had none) ----
     std::vector<uint32_t> left, todo;
@@ -406,6 +414,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         up.unpairedDP(c.rs, c.first + r1, own[r1].data(), own[r1].size(), own[r1 + 1].data(), own[r1 + 1].size(), c.singlePar.cutoffThreshold);
         leftoverPairs++;
     }
+    lap(4);
     return true;
 }
 
@@ -635,8 +644,9 @@ int main(int argc, char **argv)
         if (paired) {
             fclose(unpairOut);
             printf("[Main] Number of pairs aligned by new default DP: %llu\n[Main] Number of pairs aligned by DP: %llu\n[Main] Number of pairs aligned by deep DP: %llu\n"
-                   "[Main] Pairs left without a proper pairing: %llu\n[Main] DP stages time : %9.4f seconds\n",
-                   (unsigned long long)newDefaultPairs, (unsigned long long)defaultDpPairs, (unsigned long long)deepDpPairs, (unsigned long long)leftoverPairs, dpStageSeconds);
+                   "[Main] Pairs left without a proper pairing: %llu\n[Main] DP stages time : %9.4f seconds (routing %.3f, default DP %.3f, new default DP %.3f, deep DP %.3f, leftovers %.3f)\n",
+                   (unsigned long long)newDefaultPairs, (unsigned long long)defaultDpPairs, (unsigned long long)deepDpPairs, (unsigned long long)leftoverPairs, dpStageSeconds,
+                   g_pairStageSeconds[0], g_pairStageSeconds[1], g_pairStageSeconds[2], g_pairStageSeconds[3], g_pairStageSeconds[4]);
             dpAlignedReads = 2 * (defaultDpPairs + newDefaultPairs + deepDpPairs);
             s3_dp_free(dpHalf);
         } else printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)dpAlignedReads);

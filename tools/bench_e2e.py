@@ -149,7 +149,8 @@ def pairs_mode(a, codes, work, rng, t_index):
     ph = {k: float(v) for k, v in re.findall(r"\[Main\] (Loading time|Read load time|Alignment \+ output time|Total elapsed time|DP stages time) :\s+([0-9.]+)", out.stdout)}
     counts = {k: int(v) for k, v in re.findall(r"\[Main\] (Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|"
                                                r"Pairs left without a proper pairing|Overall number of reads aligned): (\d+)", out.stdout)}
-    res = {"mode": "pair, DP stages on", "genome_bp": a.genome_bp, "pairs": N, "read_len": L, "host_threads": a.threads or os.cpu_count(),
+    stage = re.search(r"DP stages time :\s+[0-9.]+ seconds \((.*)\)", out.stdout)
+    res = {"mode": "pair, DP stages on", "dp_stage_seconds": stage.group(1) if stage else None, "genome_bp": a.genome_bp, "pairs": N, "read_len": L, "host_threads": a.threads or os.cpu_count(),
            "pair_mix": {"bwt": 0.90, "one_end_indel": 0.06, "both_ends_indel": 0.03, "random_mate": 0.01},
            "index_build_and_write_s": t_index, "fastq_write_s": t_reads, "wall_s_total": wall, "phases_s": ph, "counts": counts,
            "sam_bytes": sum(os.path.getsize(os.path.join(work, "out." + e)) for e in ("gout.1", "dpout.1", "unpair")),
