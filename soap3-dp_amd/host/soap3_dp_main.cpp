@@ -431,7 +431,7 @@ int main(int argc, char **argv)
     const std::string indexName = argv[2], queryFile = argv[3], queryFile2 = paired ? argv[4] : "";
     int insertHigh = 500, insertLow = 1;                                       // IniParam.cpp:482-483
     int maxReadLength = 120, numMismatch = -1, alignmentType = 2, outputFormat = 2, device = 0;   // DEFAULT_MAX_READ_LEN, all-best, SAM
-    bool enableDP = true;
+    bool enableDP = true, skipSoap3 = false;
     std::string prefix = queryFile, readGroup, sampleName, readGrpOption;
     bool printMDNM = false;
     for (int i = paired ? 5 : 4; i < argc; i++) {
@@ -485,8 +485,10 @@ int main(int argc, char **argv)
     if (enableDP) {
         numMismatch = ini.soap3MisMatchAllow;
         if (detectedReadLength < 30 || (paired && detectedReadLength2 < 30)) { enableDP = false; printf("Dynamic programming is disabled because read length < %i\n", 30); }
-        else if (paired && (detectedReadLength > 150 || detectedReadLength2 > 150))
-            return die("reads longer than 150 bases skip the BWT stage in paired-end DP runs (SOAP3-DP.cu:658-662): that path is not built, run with -s <k>");
+        else if (paired && (detectedReadLength > 150 || detectedReadLength2 > 150)) {
+            skipSoap3 = true;                                                  // SOAP3-DP.cu:658-662, alignment.cu:1928-1944: every pair goes straight to the deep DP
+            printf("All reads are directly processed by DP, because the read length > 150\n");
+        }
         else if (paired && (detectedReadLength <= 50 || detectedReadLength2 <= 50)) numMismatch = 1;   // SOAP3-DP.cu:663-666
         if (!enableDP && numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;
     }
@@ -524,13 +526,19 @@ int main(int argc, char **argv)
         int scheme = 1, tableLen = 0, patLen = 0;
         s3_dp_config(maxRL, maxDNA, 1, &scheme, &tableLen, &patLen);
         s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
-        if (s3_dp_create(device, 32768, (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &dp) != S3_OK) return die(s3_last_error());
+        // problems per DP launch: the traceback tables of one launch stay under 24 GB (7 MB per problem at 1024 bases)
+        auto problems = [&](int rl, int tl) -> uint32_t {
+            const double perProblem = (double)((rl + 63) / 64) * (tl + 64) * 64 * 4;
+            const double n = 24e9 / perProblem;
+            return n >= 32768 ? 32768u : n < 256 ? 256u : (uint32_t)n;
+        };
+        if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &dp) != S3_OK) return die(s3_last_error());
         if (s3_batch_create(ix, 262144 + 64, 8, &seedBatch) != S3_OK) return die(s3_last_error());
         if (paired) {
             // default DP (half-aligned pairs): HalfEndAlignmentEngine::performAlignment sizes, DV-DPfunctions.cu:2221-2224
             const int maxDNAHalf = insertHigh - insertLow + maxReadLength + 1;
             s3_dp_config(maxRL, maxDNAHalf, 1, &scheme, &tableLen, &patLen);
-            if (s3_dp_create(device, 32768, (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &dpHalf) != S3_OK) return die(s3_last_error());
+            if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &dpHalf) != S3_OK) return die(s3_last_error());
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength, &di, &halfPar[0]);
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength2, &di, &halfPar[1]);
             for (int e = 0; e < 2; e++) {
@@ -555,18 +563,24 @@ int main(int argc, char **argv)
         // reads longer than 120 bases: only the first 100 are searched, the rest is verified on the device (alignment.cu:2473-2491)
         if (paired) {
             // pairs keep to the whole read (seedLengths is NULL for pairs, alignment.cu:1965-2013); DP stages are off (-s)
-            if (s3_batch_align_pair(b, (uint32_t)numMismatch, ini.maxHitsEachEndForPairing, alignmentType, (uint32_t)insertLow, (uint32_t)insertHigh,
-                                    ini.peMaxOutputPerPair) != S3_OK) return die(s3_last_error());
             const uint32_t np = cnt / 2;
             std::vector<s3_pair_result> pr(np ? np : 1);
-            std::vector<uint64_t> xoff((size_t)np + 1), ooff((size_t)cnt + 1);
+            std::vector<uint64_t> xoff((size_t)np + 1, 0), ooff((size_t)cnt + 1, 0);
             uint64_t nXa = 0, nOcc = 0;
-            if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, ooff.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return die(s3_last_error());
-            std::vector<s3_pair_xa> xa(nXa ? nXa : 1);
-            std::vector<uint32_t> pos(nOcc ? nOcc : 1);
-            std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
-            if (s3_batch_fetch_pairs(b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK)
-                return die(s3_last_error());
+            std::vector<s3_pair_xa> xa(1);
+            std::vector<uint32_t> pos(1);
+            std::vector<uint8_t> strand(1), mis(1), fromSa(1);
+            if (skipSoap3) {
+                for (s3_pair_result &x : pr) { memset(&x, 0, sizeof x); x.min1 = x.min2 = 255; }     // no BWT stage: nothing paired, no hits
+            } else {
+                if (s3_batch_align_pair(b, (uint32_t)numMismatch, ini.maxHitsEachEndForPairing, alignmentType, (uint32_t)insertLow, (uint32_t)insertHigh,
+                                        ini.peMaxOutputPerPair) != S3_OK) return die(s3_last_error());
+                if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, ooff.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return die(s3_last_error());
+                xa.resize(nXa ? nXa : 1); pos.resize(nOcc ? nOcc : 1); strand.resize(nOcc ? nOcc : 1); mis.resize(nOcc ? nOcc : 1); fromSa.resize(nOcc ? nOcc : 1);
+                if (s3_batch_fetch_pairs(b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK)
+                    return die(s3_last_error());
+                if (enableDP && s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return die(s3_last_error());
+            }
             parallelFormat(hix, so, out, np, [&](SamWriter &w, uint32_t p, uint64_t &al) {
                 const uint32_t r1 = first + 2 * p, r2 = r1 + 1;
                 if (pr[p].phase) {
@@ -582,8 +596,6 @@ int main(int argc, char **argv)
             }, aligned);
             if (enableDP) {
                 PairDpCtx c{hix, so, rs, ini, b, seedBatch, dp, dpHalf, dpOut, unpairOut, first, cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
-                std::vector<uint8_t> fromSa(nOcc ? nOcc : 1);
-                if (s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return die(s3_last_error());
                 std::string e2;
                 const auto tDp = std::chrono::steady_clock::now();
                 if (!pairDpStages(c, pr, ooff, pos, strand, mis, fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) return die(e2);

@@ -382,3 +382,70 @@ def test_cli_pair_dp_routing_matches_the_reference(tmp_path, name):
     assert not bad, (bad[:5], ref[bad[0]][:6], mine[bad[0]][:6])
     if name == "g5":
         assert {k[0] for k in ref} == {"D", "N", "O"}
+
+
+def test_cli_pairs_longer_than_150_bases_skip_the_bwt_stage(tmp_path):
+    """2 x 200 bp pairs with the DP stages on: the reference skips its BWT stage above 150 bases (SOAP3-DP.cu:658-662) and hands every pair to the
+    deep DP; so does the program.  Pairs with an indel or a few substitutions per end must come back as proper pairs at their true place."""
+    import re
+    import numpy as np
+    name = "g1"
+    rng = np.random.default_rng(33)
+    chroms, cur = {}, None
+    for l in open(os.path.join(GOLDEN, name, "genome.fa")):
+        if l.startswith(">"):
+            cur = l[1:].split()[0]
+            chroms[cur] = []
+        else:
+            chroms[cur].append(l.strip())
+    chroms = {k: "".join(v) for k, v in chroms.items()}
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+    L = 200
+
+    def damage(seg, kind):
+        if kind == 0:
+            return seg[:L]
+        if kind == 1:
+            c = int(rng.integers(60, 140))
+            return seg[:c] + seg[c + 4:L + 4]
+        b = list(seg[:L])
+        for q in rng.choice(np.arange(5, L - 5), size=4, replace=False):
+            b[q] = "ACGT"[("ACGT".index(b[q]) + 1 + int(rng.integers(0, 3))) % 4]
+        return "".join(b)
+    names = sorted(chroms)
+    r1s, r2s, truth = [], [], []
+    while len(r1s) < 90:
+        ch = names[int(rng.integers(0, len(names)))]
+        ins = int(rng.integers(450, 560))
+        st = int(rng.integers(0, len(chroms[ch]) - ins - 20))
+        left, right = chroms[ch][st:st + L + 10], chroms[ch][st + ins - L:st + ins + 10]
+        if "N" in left or "N" in right or len(right) < L + 10:
+            continue
+        k = len(r1s) % 3
+        a, b = damage(left, k), rc(damage(right, (k + 1) % 3))
+        swap = bool(rng.integers(0, 2))
+        r1s.append(b if swap else a); r2s.append(a if swap else b)
+        truth.append((ch, st + 1, st + ins - L + 1, swap))
+    for fn, rr, tag in (("r1.fq", r1s, 1), ("r2.fq", r2s, 2)):
+        with open(tmp_path / fn, "w") as f:
+            for i, s in enumerate(rr):
+                f.write("@w%d/%d\n%s\n+\n%s\n" % (i, tag, s, "I" * len(s)))
+    out = subprocess.run([BIN, "pair", os.path.join(GOLDEN, name, "index"), "r1.fq", "r2.fq", "-u", "600", "-v", "200", "-L", "200", "-o", "out"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    assert "All reads are directly processed by DP" in out.stdout
+    assert sum(1 for l in open(tmp_path / "out.gout.1") if not l.startswith("@")) == 0
+    recs = {}
+    for src in ("dpout.1", "unpair"):
+        for l in open(tmp_path / ("out." + src)):
+            if not l.startswith("@"):
+                f = l.rstrip("\n").split("\t")
+                recs.setdefault(f[0], {})[int(f[1]) & 0xC0] = f
+    assert sorted(recs) == sorted("w%d" % i for i in range(len(r1s)))
+    good = 0
+    for i, (ch, lp, rp, swap) in enumerate(truth):
+        pr = recs["w%d" % i]
+        fa, fb = (pr[0x80], pr[0x40]) if swap else (pr[0x40], pr[0x80])
+        good += bool(int(fa[1]) & 2 and fa[2] == ch and abs(int(fa[3]) - lp) <= 4 and abs(int(fb[3]) - rp) <= 4 and int(fb[1]) & 16)
+    assert good >= 0.85 * len(truth), (good, len(truth))
