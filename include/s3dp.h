@@ -244,6 +244,9 @@ int  s3_batch_sync(s3_batch *b);
 /* device time of the work enqueued by the last search/align call, measured with HIP events on the batch stream;
  * searchMs = time inside the BWT-search kernels only. */
 int  s3_batch_last_timing(s3_batch *b, float *totalMs, float *searchMs, uint32_t *searchLaunches);
+/* device time inside the check-and-extend kernels of the last call (they run right behind each BWT-search kernel; 0 launches when check-and-extend
+ * is kept inside the search kernel, S3DP_CE=inline) */
+int  s3_batch_last_ce_timing(s3_batch *b, float *ceMs, uint32_t *ceLaunches);
 int  s3_batch_counters(s3_batch *b, s3_counters *out);      /* device-side tallies of the last call (if enabled) */
 int  s3_batch_enable_counters(s3_batch *b, int on);
 

@@ -130,7 +130,7 @@ int s3i::growRecords(s3_batch *b)
     if (cap > kMaxEntries) cap = kMaxEntries;
     int rc;
     if ((rc = bgrow(b, &b->dRecs, cap, 0))) return rc;
-    if ((rc = bgrow(b, &b->dOrdered, cap, 0))) return rc;
+    if (cap > b->ordCap) { if ((rc = bgrow(b, &b->dOrdered, cap, 0))) return rc; b->ordCap = (uint32_t)cap; }
     if ((rc = bgrow(b, &b->dHits, cap, 0))) return rc;
     b->recCap = (uint32_t)cap;
     return S3_OK;
@@ -179,8 +179,8 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
-    BA(dRecs, recCap); BA(dOrdered, recCap);
-    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2);
+    BA(dRecs, recCap); BA(dOrdered, recCap); b->ordCap = recCap;
+    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskEnd, 4);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
     BA(dWithError, (size_t)maxReads * 8);
@@ -201,6 +201,8 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     HIPCHK(hipEventCreate(&b->evTotal[0])); HIPCHK(hipEventCreate(&b->evTotal[1]));
     b->evSearch.resize(16);
     for (auto &e : b->evSearch) HIPCHK(hipEventCreate(&e));
+    b->evCe.resize(16);
+    for (auto &e : b->evCe) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     *outp = b;
@@ -214,6 +216,7 @@ extern "C" void s3_batch_free(s3_batch *b)
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void *p : b->allocs) (void)hipFree(p);
     for (auto e : b->evSearch) if (e) (void)hipEventDestroy(e);
+    for (auto e : b->evCe) if (e) (void)hipEventDestroy(e);
     for (auto e : b->evTotal) if (e) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -311,10 +314,19 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             // S3DP_KERNEL=v1 selects the first-generation one-thread-per-item kernel (kept for A/B measurements)
             static const bool useV1 = [] { const char *e = getenv("S3DP_KERNEL"); return e && strcmp(e, "v1") == 0; }();
             static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", S3_V2_WAVES_PER_SIMD);
+            // S3DP_CE=inline keeps check-and-extend inside the stepping kernel (the first form of the v2 kernel, for A/B measurements)
+            static const bool splitCe = [] { const char *e = getenv("S3DP_CE"); return !(e && strcmp(e, "inline") == 0); }();
             if (useV1) launchSearch(b->ix->d, in, out, 256u * 8u * 4u, b->stream);
-            else launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
+            else launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, splitCe, b->stream);
+            if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
+            if (!useV1 && splitCe) {
+                // the task records end where the stepping kernel stopped writing; the check-and-extend kernel appends behind them
+                HIPCHK(hipMemcpyAsync(b->dTaskEnd, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
+                if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2], b->stream));
+                launchCheckExtend(b->ix->d, in, out, b->dTaskEnd, b->stream);
+                if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2 + 1], b->stream));
+            }
         }
-        if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
         // a record that did not fit was dropped but counted: the ordering below must not run on such a pass.  Grow and search again.
         uint32_t flags = 0;
         HIPCHK(hipMemcpyAsync(&flags, b->dFlags, 4, hipMemcpyDeviceToHost, b->stream));
@@ -328,9 +340,26 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     b->searchLaunches++;
+    b->ceLaunches++;
     HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, 4, b->stream));
     size_t tb = b->tempBytes;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dItemCounts, b->dItemOffsets, (int)(nItems + 1), b->stream));
+    {
+        // sequence numbers include the rejected check-and-extend candidates: the ordered array can need more slots than there are records
+        uint32_t slots = 0;
+        HIPCHK(hipMemcpyAsync(&slots, b->dItemOffsets + nItems, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (slots > b->ordCap) {
+            size_t cap = b->ordCap;
+            while (cap < slots) cap *= 2;
+            if (cap > kMaxEntries) cap = kMaxEntries;
+            if (slots > cap) return fail(S3_EOVERFLOW, "ordering buffer overflow at the 32-bit limit");
+            int rc = bgrow(b, &b->dOrdered, cap, 0);
+            if (rc) return rc;
+            b->ordCap = (uint32_t)cap;
+        }
+    }
+    launchFillInvalid(b->dOrdered, b->dItemOffsets + nItems, b->ordCap, b->stream);
     launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->stream);
     MergeArgs m{};
     m.nActive = nActive; m.nCases = (uint32_t)nCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
@@ -364,7 +393,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
     if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
     HIPCHK(hipSetDevice(b->ix->dev));
-    b->searchLaunches = 0;
+    b->searchLaunches = 0; b->ceLaunches = 0;
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
     if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
@@ -431,6 +460,26 @@ extern "C" int s3_batch_last_timing(s3_batch *b, float *totalMs, float *searchMs
     if (totalMs) *totalMs = t;
     if (searchMs) *searchMs = s;
     if (searchLaunches) *searchLaunches = b->searchLaunches;
+    return S3_OK;
+}
+
+extern "C" int s3_batch_last_ce_timing(s3_batch *b, float *ceMs, uint32_t *ceLaunches)
+{
+    if (!b || b->lastKind == 0) return fail(S3_EINVAL, "no timed call");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    float s = 0;
+    uint32_t timed = b->ceLaunches;
+    if (timed * 2 > b->evCe.size()) timed = (uint32_t)(b->evCe.size() / 2);
+    static const bool splitCe = [] { const char *e = getenv("S3DP_CE"); return !(e && strcmp(e, "inline") == 0); }();
+    if (!splitCe) timed = 0;
+    for (uint32_t i = 0; i < timed; i++) {
+        float x = 0;
+        HIPCHK(hipEventElapsedTime(&x, b->evCe[2 * i], b->evCe[2 * i + 1]));
+        s += x;
+    }
+    if (ceMs) *ceMs = s;
+    if (ceLaunches) *ceLaunches = timed;
     return S3_OK;
 }
 

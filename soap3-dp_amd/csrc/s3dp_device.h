@@ -46,8 +46,10 @@ struct SearchIn {
     uint32_t        uniformLen;  // != 0: every active read has this length (model kept in LDS by the v2 kernel)
 };
 
+#define S3_REC_TASK (1u << 28)
+
 struct SearchOut {
-    uint4              *recs;    // {item, seq|kind<<24|nmis<<25, a, b}
+    uint4              *recs;    // {item, seq|kind<<24|nmis<<25, a, b};  S3_REC_TASK set: a check-and-extend task {item, first seq, SA left, size-1 | state<<8}
     uint32_t            recCap;
     uint32_t           *recCount;
     uint32_t           *itemCounts;
@@ -86,7 +88,9 @@ void launchDp(const DpArgs &a, hipStream_t s);
 void launchOrientReads(const uint32_t *queries, const uint32_t *lengths, uint32_t *readsT, uint32_t n, uint32_t wpq, uint32_t S, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
 void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
-void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
+void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, bool splitCe, hipStream_t s);
+void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskEnd, hipStream_t s);
+void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s);
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, hipStream_t s);
 void launchMergeCount(const MergeArgs &a, hipStream_t s);
 void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s);

@@ -32,14 +32,14 @@ struct s3_batch {
     hipStream_t stream = nullptr;
     uint32_t maxReads = 0, wpq = 0, n = 0;
     size_t   maxItems = 0;
-    uint32_t recCap = 0, occCap = 0;
+    uint32_t recCap = 0, occCap = 0, ordCap = 0;
     // inputs
     uint32_t *dQueries = nullptr, *dLens = nullptr, *dReadsT = nullptr, *dSeedLens = nullptr;
     bool longMode = false;          // seed lengths set: the reference's long-read mode
     uint32_t fullUniformLen = 0;
     // search / ordering work buffers
     uint4    *dRecs = nullptr, *dOrdered = nullptr;
-    uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr;
+    uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr, *dTaskEnd = nullptr;
     unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;
     uint32_t uniformLen = 0;
     uint32_t *dKept = nullptr, *dOccCounts = nullptr, *dCeCounts = nullptr, *dTotalOcc = nullptr, *dWithError = nullptr;
@@ -72,7 +72,8 @@ struct s3_batch {
     uint32_t lastNumCases = 0;
     bool counting = false;
     hipEvent_t evTotal[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> evSearch;
+    std::vector<hipEvent_t> evSearch, evCe;          // per launch of the stepping kernel / of the check-and-extend kernel
+    uint32_t ceLaunches = 0;
     uint32_t searchLaunches = 0;
     uint32_t occUsed = 0;
     uint64_t recordsTotal = 0;      // records of all search passes of the last call (read back when counters are enabled)

@@ -370,7 +370,7 @@ __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint3
     if (n > recCap) n = recCap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint4 r = recs[i];
-        if (r.x == 0xFFFFFFFFu) continue;                                   // unused slot of a reserved block (v2 kernel)
+        if (r.x == 0xFFFFFFFFu || (r.y & S3_REC_TASK)) continue;            // unused slot of a reserved block / check-and-extend task (v2 kernel)
         ordered[itemOffsets[r.x] + (r.y & 0xFFFFFFu)] = r;
     }
 }
@@ -389,6 +389,7 @@ __global__ void mergeCountKernel(MergeArgs a)
     uint32_t we[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = beg; i < end && total < a.maxOut; i++) {
         const uint4 r = a.ordered[i];
+        if (r.x == 0xFFFFFFFFu) continue;                                   // sequence number of a rejected check-and-extend candidate
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
         uint32_t cnt = kind ? 1u : r.w - r.z + 1u;
         if (total + cnt > a.maxOut) cnt = a.maxOut - total;
@@ -411,8 +412,9 @@ __global__ void mergeFillKernel(MergeArgs a, const uint32_t *hitOffsets, DevHit 
     const uint32_t n = a.keptRecs[slot];
     uint32_t total = 0;
     DevHit *dst = hits + hitOffsets[slot];
-    for (uint32_t k = 0; k < n; k++) {
-        const uint4 r = a.ordered[beg + k];
+    for (uint32_t k = 0, i = beg; k < n; i++) {
+        const uint4 r = a.ordered[i];
+        if (r.x == 0xFFFFFFFFu) continue;
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
         const uint32_t grp = r.x % groups;
         uint32_t lo = r.z, hi = r.w;
@@ -422,6 +424,7 @@ __global__ void mergeFillKernel(MergeArgs a, const uint32_t *hitOffsets, DevHit 
         DevHit h;
         h.a = lo; h.b = hi; h.meta = kind | ((grp & 1u) + 1u) << 8 | nmis << 16 | (grp >> 1) << 24;
         dst[k] = h;
+        k++;
     }
 }
 
@@ -439,8 +442,10 @@ __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffset
     uint32_t o = occBase + occOffsets[slot], oSa = o + a.ceCounts[slot];
     if ((uint64_t)occBase + occOffsets[slot + 1] > occCap) { atomicOr(flags, S3_FLAG_OCC_OVERFLOW); return; }
     uint32_t total = 0;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint4 r = a.ordered[beg + k];
+    for (uint32_t k = 0, i = beg; k < n; i++) {
+        const uint4 r = a.ordered[i];
+        if (r.x == 0xFFFFFFFFu) continue;
+        k++;
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
         const uint32_t strand = ((r.x % groups) & 1u) + 1u;
         const uint32_t meta = strand | nmis << 8;
@@ -552,6 +557,18 @@ void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, 
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = (size_t)in.wpqLoad * 4u * S3_SEARCH_BLOCK;
     hipLaunchKernelGGL(searchKernel, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+}
+
+__global__ void fillInvalidKernel(uint4 *ordered, const uint32_t *total, uint32_t cap)
+{
+    uint32_t n = *total;
+    if (n > cap) n = cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) ordered[i] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+}
+
+void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s)
+{
+    hipLaunchKernelGGL(fillInvalidKernel, dim3(2048), dim3(256), 0, s, ordered, total, cap);
 }
 
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, hipStream_t s)

@@ -93,7 +93,13 @@ using namespace v2;
 // keep a memory request in flight.
 // UNIFORM: every read of the launch has the same length, the model (all cases) then lives in LDS; otherwise step
 // descriptors are read from the global table (L1/L2 resident).
-template <bool UNIFORM>
+// SPLIT: check-and-extend runs in its own kernel (ceKernel below).  A lane that reaches a small SA range inside the check window writes a
+// TASK record (range + where it stands in the model) instead of walking the range itself, reserves one sequence number per candidate and goes
+// on with its search: two dependent round trips per candidate (SA value, then text) and the compare code leave the stepping loop, which is
+// bound by its instruction count.  The record stream keeps the CPU path's order because accepted candidates are written under the reserved
+// numbers; rejected ones leave holes the ordering pass skips.  Not counting the candidates in `total` only delays the early stop at
+// MaxOutputPerRead: the per-read cut is applied again, exactly, when the records are merged.
+template <bool UNIFORM, bool SPLIT>
 __global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_V2_WAVES_PER_SIMD)
 searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 {
@@ -189,9 +195,19 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (i < lenEff && alive) {
                 const int pos = st.start + st.dir * i;
                 if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
-                    ceQ = g.fl; ceQEnd = g.fr; ceS = s; ceI = i; ceIns = ins; ceOcc = occ;
-                    state = ST_CESA;
-                    return;
+                    if constexpr (SPLIT) {
+                        if (pendMeta >> 31) { state = ST_RESUME; return; }   // one record per lane and trip
+                        pendMeta = 0x80000000u | seq | S3_REC_TASK;
+                        pendA = g.fl;
+                        pendB = (g.fr - g.fl) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+                        seq += g.fr - g.fl + 1u;
+                        needPop = true;
+                        continue;
+                    } else {
+                        ceQ = g.fl; ceQEnd = g.fr; ceS = s; ceI = i; ceIns = ins; ceOcc = occ;
+                        state = ST_CESA;
+                        return;
+                    }
                 }
                 state = ST_STEP;
                 return;
@@ -307,10 +323,10 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             aD1 = ix.lkt + ltB;
             if (bidir) { aD2 = ix.rlkt + (ltC ? ltC - 1u : 0u); aD3 = ix.rlkt + ltD; }
             nLt += bidir ? 4 : 2;
-        } else if (state == ST_CESA) {
+        } else if (!SPLIT && state == ST_CESA) {
             aD0 = ix.sa + ceQ;
             nSa++;
-        } else if (state == ST_CETXT) {
+        } else if (!SPLIT && state == ST_CETXT) {
             const S3Step st = stepAt(ceT);
             const int pos = st.start + st.dir * ceII;
             const int left = pos < st.end ? pos : st.end, right = pos < st.end ? st.end : pos;
@@ -431,13 +447,13 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             s = 0; i = ll; ins = 0; occ = 0;
             doSettle = true;
-        } else if (state == ST_CESA) {
+        } else if (!SPLIT && state == ST_CESA) {
             const S3Step st0 = stepAt(ceS);
             const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - ceI;
             ceRp = saVal - (uint32_t)leftAlign;                               // 32-bit wrap, as the reference
             ceT = ceS; ceII = ceI; ceInsCur = ceIns; ceAcc = ceOcc; ceOff = 0; ceMm = 0;
             state = ST_CETXT;
-        } else if (state == ST_CETXT) {
+        } else if (!SPLIT && state == ST_CETXT) {
             bool stepDone = false, reject = ceReject;
             if (!reject) {
                 // text words -> own stage slot, then 16 characters at a time: XOR, fold, popcount
@@ -512,18 +528,122 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     }
 }
 
-void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
+// ---- check-and-extend of the task records (SPLIT mode) --------------------------------------------------------------------------------
+// One lane per task; the lanes of a wave walk their candidates in lockstep (k-th candidate of every task), accepted ones are appended to the
+// record stream with one atomic per wave and round.  Per candidate: SA value, then per remaining model step the text against the oriented read,
+// 16 characters at a time (XOR, fold, popcount), the step's error window checked as in the stepping kernel (BGS-HostAlgnmtAlgo2.cpp:86-169).
+__global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, SearchOut out, const uint32_t *taskEnd)
+{
+    uint32_t nRec = *taskEnd;
+    if (nRec > out.recCap) nRec = out.recCap;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t groups = (uint32_t)in.nCases * 2u;
+    const uint32_t S = in.wpqLoad;
+    const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t nSa = 0, nCe = 0;
+    for (uint64_t base = (uint64_t)waveId * 64u; base < nRec; base += (uint64_t)nWaves * 64u) {
+        const uint64_t idx = base + lane;
+        uint4 rec = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+        if (idx < nRec) rec = out.recs[idx];
+        const bool task = rec.x != 0xFFFFFFFFu && (rec.y & S3_REC_TASK);
+        uint32_t size = 0, rIdx = 0, casIdx = 0, strand = 0;
+        int Li = 0, nSteps = 0, s0 = 0, i0 = 0, ins0 = 0, occ0 = 0;
+        if (task) {
+            size = (rec.w & 0xFFu) + 1u;
+            const uint32_t meta = rec.w >> 8;
+            s0 = (int)(meta & 7u); i0 = (int)((meta >> 3) & 0x7FFu); ins0 = (int)((meta >> 14) & 7u); occ0 = (int)((meta >> 17) & 7u);
+            const uint32_t slot = rec.x / groups, sub = rec.x % groups;
+            casIdx = sub >> 1; strand = sub & 1u;
+            rIdx = in.active ? in.active[slot] : slot;
+            Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
+            nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
+        }
+        const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
+        const S3Case &cs = in.models[Li].cs[casIdx];
+        for (uint32_t k = 0; __ballot(k < size); k++) {
+            bool hit = false;
+            uint32_t rp = 0;
+            int acc = occ0;
+            if (k < size) {
+                const uint32_t sa = ix.sa[rec.z + k];
+                nSa++;
+                const S3Step st0 = cs.st[s0];
+                const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i0;
+                rp = sa - (uint32_t)leftAlign;                                   // 32-bit wrap, as the reference
+                int t = s0, ii = i0, insCur = ins0;
+                hit = true;
+                while (t < nSteps) {
+                    const S3Step st = cs.st[t];
+                    const int pos = st.start + st.dir * ii;
+                    const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end), right = (uint32_t)(pos < st.end ? st.end : pos);
+                    const uint32_t len = right - left + 1u;
+                    if (rp + left > ix.n) { hit = false; break; }                // BGS-HostAlgnmtAlgo2.cpp:122-125
+                    const uint32_t tpos = rp + left;
+                    int mm = 0;
+                    for (uint32_t o = 0; o < len; o += 16u) {
+                        const uint32_t c = len - o > 16u ? 16u : len - o;
+                        const uint32_t tp = tpos + o, tw_ = tp >> 4, tsh = (tp & 15u) * 2u;
+                        const uint32_t ta = tw_ < ix.pacWords ? ix.pac[tw_] : 0u, tb = tw_ + 1u < ix.pacWords ? ix.pac[tw_ + 1u] : 0u;
+                        const uint32_t tw = tsh ? (ta << tsh) | (tb >> (32u - tsh)) : ta;
+                        const uint32_t qp = left + o, qw = qp >> 4, qsh = (qp & 15u) * 2u;
+                        const uint32_t qa = qw < S ? rd[qw] : 0u, qb = qw + 1u < S ? rd[qw + 1u] : 0u;
+                        const uint32_t rw = qsh ? (qa << qsh) | (qb >> (32u - qsh)) : qa;
+                        uint32_t x = tw ^ rw;
+                        x = (x | (x >> 1)) & 0x55555555u;
+                        if (c < 16u) x &= ~0u << (32u - 2u * c);
+                        mm += __popc(x);
+                    }
+                    nCe += (len + 31u) >> 5;
+                    const int tot = mm + insCur;
+                    if (tot < st.minErr || tot > st.maxErr) { hit = false; break; }
+                    acc += tot; t++; ii = 0; insCur = 0;
+                }
+            }
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                const uint32_t np = (uint32_t)__popcll(hm);
+                uint32_t b0 = 0;
+                if (lane == (uint32_t)(__ffsll((long long)hm) - 1)) b0 = atomicAdd(out.recCount, np);
+                b0 = (uint32_t)__shfl((int)b0, __ffsll((long long)hm) - 1);
+                if (b0 + np > out.recCap || b0 + np < b0) { if (lane == 0) atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
+                else if (hit) {
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                    out.recs[b0 + rk] = make_uint4(rec.x, ((rec.y & 0xFFFFFFu) + k) | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
+                }
+            }
+        }
+    }
+    if (out.counters) {
+        atomicAdd(&out.counters[2], (unsigned long long)nSa);
+        atomicAdd(&out.counters[3], (unsigned long long)nCe);
+    }
+}
+
+void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, bool splitCe, hipStream_t s)
 {
     if (in.nActive == 0) return;
     uint64_t blocks = ((uint64_t)in.nActive + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wpqLoad * 256u);
     if (lds > 48u * 1024u) {
-        (void)hipFuncSetAttribute((const void *)searchKernelV2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)searchKernelV2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)searchKernelV2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)searchKernelV2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)searchKernelV2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)searchKernelV2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    if (in.uniformLen) hipLaunchKernelGGL(searchKernelV2<true>, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
-    else hipLaunchKernelGGL(searchKernelV2<false>, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+    if (splitCe) {
+        if (in.uniformLen) hipLaunchKernelGGL((searchKernelV2<true, true>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+        else hipLaunchKernelGGL((searchKernelV2<false, true>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+    } else {
+        if (in.uniformLen) hipLaunchKernelGGL((searchKernelV2<true, false>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+        else hipLaunchKernelGGL((searchKernelV2<false, false>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+    }
+}
+
+void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskEnd, hipStream_t s)
+{
+    if (in.nActive == 0) return;
+    hipLaunchKernelGGL(ceKernel, dim3(256u * 8u), dim3(256), 0, s, ix, in, out, taskEnd);
 }
 
 }  // namespace s3
