@@ -306,12 +306,16 @@ def main():
     barrier()
     t0 = time.perf_counter()
     search_ms = 0.0
+    ce_ms = 0.0
+    dev_ms = 0.0
     launches = 0
     for _ in range(a.steps):
         b.align_single_allbest(a.mismatch, a.max_out)
         b.sync()
         tot_ms, s_ms, k = b.timing()        # HIP events on the batch stream
         search_ms += s_ms
+        dev_ms += tot_ms
+        ce_ms += b.ce_timing()[0]
         launches += k
     barrier()
     dt = time.perf_counter() - t0
@@ -343,6 +347,8 @@ def main():
             "traffic_unit": "bytes per launch (FETCH_SIZE, profiles/pmc_traffic.json)", "algorithmic_bytes_per_launch": bytes_step / max(1, launches // max(1, a.steps)),
             "kernel": "s3::searchKernelV2", "launches_per_step": launches // max(1, a.steps),
             "kernel_ms_per_step": search_ms / max(1, a.steps),
+            "check_extend_kernel_ms_per_step": ce_ms / max(1, a.steps), "device_ms_per_step": dev_ms / max(1, a.steps),
+            "sa_reads_per_step": cnt["saReads"], "ce_windows_per_step": cnt["ceWindows"],
             "rank_queries_per_step": cnt["rankQueries"], "line_bytes_GBs": 64.0 * cnt["rankQueries"] / search_s_per_step / 1e9 if search_s_per_step else 0.0}
 
     out = {"metric": "M reads/sec aligned (100 bp SE, GRCh38-scale synthetic genome)", "value": value, "unit": "M reads/s", "n_gpus": world,

@@ -375,6 +375,14 @@ class Batch:
         _chk(lib().s3_batch_last_timing(self.h, C.byref(t), C.byref(s), C.byref(k)))
         return t.value, s.value, k.value
 
+    def ce_timing(self):
+        """(ms inside the check-and-extend kernels of the last call, launches)"""
+        s, k = C.c_float(), C.c_uint32()
+        f = lib().s3_batch_last_ce_timing
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        _chk(f(self.h, C.byref(s), C.byref(k)))
+        return s.value, k.value
+
     def counters(self):
         c = Counters()
         _chk(lib().s3_batch_counters(self.h, C.byref(c)))
