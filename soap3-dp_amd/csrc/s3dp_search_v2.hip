@@ -541,6 +541,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
     const uint32_t S = in.wpqLoad;
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t nSa = 0, nCe = 0;
+    uint32_t recCur = 0, recEnd = 0;                          // wave-uniform: reserved block [recCur, recEnd)
     for (uint64_t base = (uint64_t)waveId * 64u; base < nRec; base += (uint64_t)nWaves * 64u) {
         const uint64_t idx = base + lane;
         uint4 rec = make_uint4(0xFFFFFFFFu, 0, 0, 0);
@@ -580,18 +581,30 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                     if (rp + left > ix.n) { hit = false; break; }                // BGS-HostAlgnmtAlgo2.cpp:122-125
                     const uint32_t tpos = rp + left;
                     int mm = 0;
-                    for (uint32_t o = 0; o < len; o += 16u) {
-                        const uint32_t c = len - o > 16u ? 16u : len - o;
-                        const uint32_t tp = tpos + o, tw_ = tp >> 4, tsh = (tp & 15u) * 2u;
-                        const uint32_t ta = tw_ < ix.pacWords ? ix.pac[tw_] : 0u, tb = tw_ + 1u < ix.pacWords ? ix.pac[tw_ + 1u] : 0u;
-                        const uint32_t tw = tsh ? (ta << tsh) | (tb >> (32u - tsh)) : ta;
-                        const uint32_t qp = left + o, qw = qp >> 4, qsh = (qp & 15u) * 2u;
-                        const uint32_t qa = qw < S ? rd[qw] : 0u, qb = qw + 1u < S ? rd[qw + 1u] : 0u;
-                        const uint32_t rw = qsh ? (qa << qsh) | (qb >> (32u - qsh)) : qa;
-                        uint32_t x = tw ^ rw;
-                        x = (x | (x >> 1)) & 0x55555555u;
-                        if (c < 16u) x &= ~0u << (32u - 2u * c);
-                        mm += __popc(x);
+                    // 128 characters at a time: all text and read words of the piece are requested before the first is used
+                    for (uint32_t o0 = 0; o0 < len; o0 += 128u) {
+                        const uint32_t piece = len - o0 > 128u ? 128u : len - o0;
+                        const uint32_t tp0 = tpos + o0, tw0 = tp0 >> 4, tsh = (tp0 & 15u) * 2u;
+                        const uint32_t qp0 = left + o0, qw0 = qp0 >> 4, qsh = (qp0 & 15u) * 2u;
+                        uint32_t tw[9], qw[9];
+#pragma unroll
+                        for (uint32_t j = 0; j < 9; j++) {
+                            const uint32_t need = j * 16u < piece + 16u;              // word j + the one behind it for the shift
+                            tw[j] = (need && tw0 + j < ix.pacWords) ? ix.pac[tw0 + j] : 0u;
+                            qw[j] = (need && qw0 + j < S) ? rd[qw0 + j] : 0u;
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) {
+                            if (j * 16u < piece) {
+                                const uint32_t c = piece - j * 16u > 16u ? 16u : piece - j * 16u;
+                                const uint32_t a_ = tsh ? (tw[j] << tsh) | (tw[j + 1] >> (32u - tsh)) : tw[j];
+                                const uint32_t b_ = qsh ? (qw[j] << qsh) | (qw[j + 1] >> (32u - qsh)) : qw[j];
+                                uint32_t x = a_ ^ b_;
+                                x = (x | (x >> 1)) & 0x55555555u;
+                                if (c < 16u) x &= ~0u << (32u - 2u * c);
+                                mm += __popc(x);
+                            }
+                        }
                     }
                     nCe += (len + 31u) >> 5;
                     const int tot = mm + insCur;
@@ -601,18 +614,26 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
             }
             const unsigned long long hm = __ballot(hit);
             if (hm) {
+                // accepted candidates go into a block of record slots the wave reserved with one atomic (as the stepping kernel does)
                 const uint32_t np = (uint32_t)__popcll(hm);
-                uint32_t b0 = 0;
-                if (lane == (uint32_t)(__ffsll((long long)hm) - 1)) b0 = atomicAdd(out.recCount, np);
-                b0 = (uint32_t)__shfl((int)b0, __ffsll((long long)hm) - 1);
-                if (b0 + np > out.recCap || b0 + np < b0) { if (lane == 0) atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
-                else if (hit) {
-                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-                    out.recs[b0 + rk] = make_uint4(rec.x, ((rec.y & 0xFFFFFFu) + k) | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
+                if (recCur + np > recEnd) {
+                    for (uint32_t j = recCur + lane; j < recEnd; j += 64u) out.recs[j] = make_uint4(0xFFFFFFFFu, 0, 0, 0);   // unused tail
+                    uint32_t b0 = 0;
+                    if (lane == 0) b0 = atomicAdd(out.recCount, S3_V2_REC_BLOCK);
+                    b0 = (uint32_t)__shfl((int)b0, 0);
+                    recCur = b0; recEnd = b0 + S3_V2_REC_BLOCK;
+                    if (recEnd > out.recCap || recEnd < b0) { recEnd = b0 < out.recCap ? out.recCap : b0; if (lane == 0) atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
                 }
+                if (hit) {
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(rec.x, ((rec.y & 0xFFFFFFu) + k) | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
+                }
+                recCur += np;
+                if (recCur > recEnd) recCur = recEnd;
             }
         }
     }
+    for (uint32_t j = recCur + lane; j < recEnd; j += 64u) out.recs[j] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
     if (out.counters) {
         atomicAdd(&out.counters[2], (unsigned long long)nSa);
         atomicAdd(&out.counters[3], (unsigned long long)nCe);
