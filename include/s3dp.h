@@ -63,6 +63,10 @@ int  s3_index_upload(int device, const s3_index_desc *desc, s3_index **out);
 /* replaces GPUINDEXFree (alignment.cu:109-115) */
 void s3_index_free(s3_index *ix);
 size_t s3_index_device_bytes(const s3_index *ix);
+/* characters the lookup step of an item starts from: the file format's table (lktSize) or the longer tables the library builds in HBM at upload
+ * (S3DP_LT_EXTRA = 0 | 1 | 2 more characters; default 2 for texts of a gigabase and more): entries hold exactly the state the shorter table plus one / two
+ * exact steps give, so results do not change -- an item just starts two rank steps further on */
+int  s3_index_lookup_chars(const s3_index *ix);
 
 /* One emitted record of the k-mismatch search, in the reference CPU path's emission order
  * (BGS-HostAlgnmtAlgo2.cpp: SA ranges -> SAList via addSAToSAList :1617,1692; check-and-extend hits

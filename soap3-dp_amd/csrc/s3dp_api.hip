@@ -95,6 +95,27 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     HIPCHK(hipMemcpyAsync(rlkt, desc->revLkt, ltWords * 4, hipMemcpyHostToDevice, s));
     ix->d.sa = sa; ix->d.pac = pac; ix->d.pacWords = pacWords; ix->d.lkt = lkt; ix->d.rlkt = rlkt;
     ix->d.ltSize = desc->lktSize; ix->d.n = n;
+    ix->d.ltBack = nullptr; ix->d.ltBi = nullptr; ix->d.ltK = 0;
+    {
+        // longer lookup tables in HBM: S3DP_LT_EXTRA = 0 | 1 | 2 characters on top of the file format's table; default 2 (25.8 GB for 15-mers) for texts of
+        // a gigabase and more, where a run is long enough to pay for the allocation, 0 below
+        HIPCHK(hipStreamSynchronize(s));
+        const size_t deflt = n >= (1u << 30) ? 2 : 0;
+        int extra = (int)envSize("S3DP_LT_EXTRA", deflt);
+        if (extra > 2) extra = 2;
+        if (desc->lktSize + extra > 15) extra = 15 - desc->lktSize;
+        if (extra > 0) {
+            uint2 *tb = nullptr;
+            uint4 *ti = nullptr;
+            const int e = s3::launchLongLookup(ix->d, extra, &tb, &ti, s);
+            if (e == 0) {
+                ix->allocs.push_back(tb); ix->allocs.push_back(ti);
+                ix->d.ltBack = tb; ix->d.ltBi = ti; ix->d.ltK = desc->lktSize + extra;
+                ix->bytes += ((size_t)1 << (2 * ix->d.ltK)) * 24;
+            } else if (e != (int)hipErrorOutOfMemory) { s3_index_free(ix); return fail(S3_EHIP, std::string("long lookup tables: ") + hipGetErrorString((hipError_t)e)); }
+            else (void)hipGetLastError();                                  // no room: the search runs from the file format's table
+        }
+    }
     // model tables for every read length and mismatch budget (built on the host, see s3dp_model.cpp)
     std::vector<S3Model> host(S3_MAX_READ_LENGTH + 1);
     for (int e = 0; e <= S3_MAX_MISMATCH; e++) {
@@ -119,6 +140,7 @@ extern "C" void s3_index_free(s3_index *ix)
 }
 
 extern "C" size_t s3_index_device_bytes(const s3_index *ix) { return ix ? ix->bytes : 0; }
+extern "C" int s3_index_lookup_chars(const s3_index *ix) { return !ix ? 0 : ix->d.ltK ? ix->d.ltK : ix->d.ltSize; }
 
 // ---------------------------------------------------------------------------------------------
 

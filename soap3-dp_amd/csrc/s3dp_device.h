@@ -29,6 +29,11 @@ struct DevIndex {
     const uint32_t *lkt, *rlkt;
     int             ltSize;
     uint32_t        n;
+    // long lookup tables held in HBM (built at upload, s3dp_kernels.hip::launchLongLookup): the state of an item after its lookup step's first
+    // ltK = ltSize + 1 or 2 characters -- what the ltSize-mer table plus one / two exact steps give, stored so that the steps are not walked again
+    const uint2    *ltBack;      // backward lookup steps: {l, r}, indexed by the ltK characters in read order
+    const uint4    *ltBi;        // bidirectional lookup steps: {l, r, rev l, rev r}, indexed by the ltK characters REVERSED (order of the reverse index)
+    int             ltK;         // 0: none
 };
 
 struct SearchIn {
@@ -90,6 +95,7 @@ void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, s
 void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
 void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, bool splitCe, hipStream_t s);
 void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskEnd, hipStream_t s);
+int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int
 void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s);
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, hipStream_t s);
 void launchMergeCount(const MergeArgs &a, hipStream_t s);

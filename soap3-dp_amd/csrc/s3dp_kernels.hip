@@ -559,6 +559,94 @@ void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, 
     hipLaunchKernelGGL(searchKernel, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// long lookup tables: level k+1 from level k by ONE exact step for each of the four characters, computed exactly as the search kernels step
+// (same rank, same child ranges), so that an item that starts from the longer table is in the state it would have reached by walking.
+// Entry c * 4^k + x of level k+1 extends entry x of level k with character c: in the index order of the table (read order for the backward
+// table, reversed for the bidirectional one) the new character is the most significant -- inputs, outputs and the rank lines touched are all
+// visited in increasing order: the build streams.
+// ---------------------------------------------------------------------------------------------
+__global__ void ltBaseBackKernel(DevIndex ix, uint2 *out, uint32_t n)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    out[x] = make_uint2(x ? ix.lkt[x - 1] + 1u : 1u, ix.lkt[x]);          // BWTExactModelBackward_Lookup2, BGS-HostAlgnmtAlgo2.cpp:311-330
+}
+
+__global__ void ltExtendBackKernel(DevIndex ix, const uint2 *in, uint2 *out, uint32_t nIn)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4ull * nIn) return;
+    const uint32_t c = (uint32_t)(idx / nIn), x = (uint32_t)(idx % nIn);
+    const uint2 g = in[x];
+    if (g.x > g.y) { out[idx] = make_uint2(1u, 0u); return; }             // a dead range is never stepped
+    const uint4 oL = rankAll(ix.fwd, g.x), oR = rankAll(ix.fwd, g.y + 1u);
+    out[idx] = make_uint2(sel4(oL, c) + 1u, sel4(oR, c));
+}
+
+__global__ void ltBaseBiKernel(DevIndex ix, uint4 *out, uint32_t n, int K)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;               // the K characters reversed: character 0 in the lowest bits
+    if (t >= n) return;
+    uint32_t key = 0;
+    for (int j = 0; j < K; j++) key |= ((t >> (2 * j)) & 3u) << (2 * (K - 1 - j));
+    uint32_t l = key ? ix.lkt[key - 1] + 1u : 1u, rr_ = ix.lkt[key], rl = t ? ix.rlkt[t - 1] + 1u : 1u, rrr = ix.rlkt[t];
+    if (rr_ - l < rrr - rl) rl = rrr - (rr_ - l);                          // BWTExactModelForward_Lookup2 :349-356, 32-bit arithmetic as there
+    else if (rr_ - l > rrr - rl) l = rr_ - (rrr - rl);
+    out[t] = make_uint4(l, rr_, rl, rrr);
+}
+
+__global__ void ltExtendBiKernel(DevIndex ix, const uint4 *in, uint4 *out, uint32_t nIn)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4ull * nIn) return;
+    const uint32_t c = (uint32_t)(idx / nIn), t = (uint32_t)(idx % nIn);
+    const uint4 g = in[t];
+    if (g.x > g.y) { out[idx] = make_uint4(1u, 0u, 1u, 0u); return; }
+    const uint4 oL = rankAll(ix.rev, g.z), oR = rankAll(ix.rev, g.w + 1u);
+    const uint32_t d1 = oR.y - oL.y, d2 = oR.z - oL.z, d3 = oR.w - oL.w;
+    const uint32_t oc = c == 0 ? d1 + d2 + d3 : c == 1 ? d2 + d3 : c == 2 ? d3 : 0u;
+    const uint32_t al = sel4(oL, c) + 1u, ar = sel4(oR, c);
+    const uint32_t pr = g.y - oc, pl = pr - (ar - al);                      // the passive (forward-index) range shrinks by the occurrences of the larger characters
+    out[idx] = make_uint4(pl, pr, al, ar);
+}
+
+int launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s)
+{
+    *backOut = nullptr; *biOut = nullptr;
+    if (extra < 1 || d.ltSize + extra > 15) return (int)hipErrorInvalidValue;
+    const int K0 = d.ltSize;
+    uint2 *back[3] = {nullptr, nullptr, nullptr};
+    uint4 *bi[3] = {nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int lv = 0; lv <= extra && e == hipSuccess; lv++) {
+        const size_t n = (size_t)1 << (2 * (K0 + lv));
+        if ((e = hipMalloc((void **)&back[lv], n * sizeof(uint2))) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&bi[lv], n * sizeof(uint4))) != hipSuccess) break;
+    }
+    if (e == hipSuccess) {
+        const uint32_t n0 = 1u << (2 * K0);
+        hipLaunchKernelGGL(ltBaseBackKernel, dim3((n0 + 255) / 256), dim3(256), 0, s, d, back[0], n0);
+        hipLaunchKernelGGL(ltBaseBiKernel, dim3((n0 + 255) / 256), dim3(256), 0, s, d, bi[0], n0, K0);
+        for (int lv = 0; lv < extra; lv++) {
+            const uint32_t nIn = 1u << (2 * (K0 + lv));
+            const uint64_t nOut = 4ull * nIn;
+            hipLaunchKernelGGL(ltExtendBackKernel, dim3((unsigned)((nOut + 255) / 256)), dim3(256), 0, s, d, back[lv], back[lv + 1], nIn);
+            hipLaunchKernelGGL(ltExtendBiKernel, dim3((unsigned)((nOut + 255) / 256)), dim3(256), 0, s, d, bi[lv], bi[lv + 1], nIn);
+        }
+        e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    for (int lv = 0; lv < 3; lv++) {
+        if (e == hipSuccess && lv == extra) continue;
+        if (back[lv]) (void)hipFree(back[lv]);
+        if (bi[lv]) (void)hipFree(bi[lv]);
+    }
+    if (e != hipSuccess) return (int)e;
+    *backOut = back[extra]; *biOut = bi[extra];
+    return 0;
+}
+
 __global__ void fillInvalidKernel(uint4 *ordered, const uint32_t *total, uint32_t cap)
 {
     uint32_t n = *total;

@@ -275,7 +275,13 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;            // <= 13 characters = 26 bits of one window
             const uint32_t padOnes = ll < ix.ltSize ? ((1u << (2 * (ix.ltSize - ll))) - 1u) : 0u;
             const int shPad = 2 * (ix.ltSize - ll);
-            if (st.type == S3_T_BACK_LOOKUP) {
+            if (ix.ltK && st.len >= ix.ltK && st.ceThr == 0) {                 // (a lookup step that may switch to check-and-extend on its way -- exact-match models -- is walked)
+                // long table (<= 15 characters): one entry holds the state behind the lookup step's first ltK characters; ltB = ~0 marks the item
+                const int K = ix.ltK;
+                if (st.type == S3_T_BACK_LOOKUP) ltA = readWindow(st.start - K + 1) >> (32 - 2 * K);
+                else ltA = pairRev(readWindow(st.start)) & ((1u << (2 * K)) - 1u);
+                ltB = 0xFFFFFFFFu;
+            } else if (st.type == S3_T_BACK_LOOKUP) {
                 const uint32_t key = readWindow(st.start - ll + 1) >> (32 - 2 * ll);
                 ltA = key << shPad; ltB = (key << shPad) | padOnes;
             } else {
@@ -319,10 +325,16 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
         } else if (state == ST_LT) {
             const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
-            aD0 = ix.lkt + (ltA ? ltA - 1u : 0u);
-            aD1 = ix.lkt + ltB;
-            if (bidir) { aD2 = ix.rlkt + (ltC ? ltC - 1u : 0u); aD3 = ix.rlkt + ltD; }
-            nLt += bidir ? 4 : 2;
+            if (ltB == 0xFFFFFFFFu) {
+                if (bidir) aP0 = ix.ltBi + ltA;
+                else { aD0 = (const uint32_t *)(ix.ltBack + ltA); aD1 = aD0 + 1; }
+                nLt += 1;
+            } else {
+                aD0 = ix.lkt + (ltA ? ltA - 1u : 0u);
+                aD1 = ix.lkt + ltB;
+                if (bidir) { aD2 = ix.rlkt + (ltC ? ltC - 1u : 0u); aD3 = ix.rlkt + ltD; }
+                nLt += bidir ? 4 : 2;
+            }
         } else if (!SPLIT && state == ST_CESA) {
             aD0 = ix.sa + ceQ;
             nSa++;
@@ -436,8 +448,12 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (loadOff >= 2u * wpq) state = ST_KEYS;
         } else if (state == ST_LT) {
             const S3Step st = stepAt(0);
-            const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
-            if (st.type == S3_T_BACK_LOOKUP) {
+            int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
+            if (ltB == 0xFFFFFFFFu) {
+                ll = ix.ltK;
+                if (st.type == S3_T_BACK_LOOKUP) { g.fl = d0; g.fr = d1; g.rl = g.fl; g.rr = g.fr; }
+                else { g.fl = p0.x; g.fr = p0.y; g.rl = p0.z; g.rr = p0.w; }
+            } else if (st.type == S3_T_BACK_LOOKUP) {
                 g.fl = ltA ? d0 + 1u : 1u; g.fr = d1; g.rl = g.fl; g.rr = g.fr;
             } else {
                 uint32_t l = ltA ? d0 + 1u : 1u, rr_ = d1, rl = ltC ? d2 + 1u : 1u, rrr = d3;

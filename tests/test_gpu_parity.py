@@ -45,6 +45,37 @@ def test_search_bit_exact_vs_reference_dump_and_oracle(name, maxlen, mm):
     b.close()
 
 
+@pytest.mark.parametrize("extra", [1, 2])
+@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
+def test_long_lookup_tables_do_not_change_results(monkeypatch, name, maxlen, extra):
+    """S3DP_LT_EXTRA: 14- / 15-mer tables built in HBM at upload (the state after the 13-mer lookup plus one / two exact steps).  Records, their
+    order and the per-read tallies must stay bit-identical to the oracle for every mismatch budget; only the number of rank queries drops."""
+    monkeypatch.setenv("S3DP_LT_EXTRA", str(extra))
+    ix = s3dp.Index(host_index(name))
+    assert s3dp.lib().s3_index_lookup_chars(ix.h) == 13 + extra
+    reads = golden_reads(name)
+    q, lens, wpq = s3dp.pack_reads(reads, maxlen)
+    b = s3dp.Batch(ix, len(reads), wpq)
+    b.upload(q, lens)
+    b.enable_counters(True)
+    oix = s3o.Index(host_index=host_index(name))
+    for mm in range(5):
+        b.search(mm, 1000)
+        hits, offs, tot, werr = b.fetch_hits()
+        ohits, ooffs, otot, owerr, st = oix.search(q, lens, wpq, mm, max_out=1000)
+        assert (offs == ooffs).all() and hits.tobytes() == ohits.tobytes()
+        assert (tot == otot).all() and (werr == owerr).all()
+        c = b.counters()
+        assert c["rankQueries"] <= st.rankQueries and (mm == 0 or c["rankQueries"] < st.rankQueries)
+    b.align_single_allbest(4, 1000)
+    phase, we, off2, pos, strand, mis = b.fetch_alignments()
+    oph, owe, ooff, opos, ostr, omis, _ = oix.align_single_allbest(q, lens, wpq, 4, 1000)
+    assert (phase == oph).all() and (off2 == ooff).all() and (pos[:int(ooff[-1])] == opos).all() and (mis[:int(ooff[-1])] == omis).all()
+    oix.close()
+    b.close()
+    ix.close()
+
+
 @pytest.mark.parametrize("cap", [1, 3, 17])
 def test_max_output_truncation(cap):
     name, maxlen, mm = "g2", 120, 2
