@@ -64,8 +64,8 @@ int  s3_index_upload(int device, const s3_index_desc *desc, s3_index **out);
 void s3_index_free(s3_index *ix);
 size_t s3_index_device_bytes(const s3_index *ix);
 /* characters the lookup step of an item starts from: the file format's table (lktSize) or the longer tables the library builds in HBM at upload
- * (S3DP_LT_EXTRA = 0 | 1 | 2 more characters; default 2 for texts of a gigabase and more): entries hold exactly the state the shorter table plus one / two
- * exact steps give, so results do not change -- an item just starts two rank steps further on */
+ * (S3DP_LT_EXTRA = 0 .. 3 more characters; default 3 = 16-mers, 103 GB, for texts of two gigabases and more, 2 from one gigabase, 0 below): entries hold
+ * exactly the state the shorter table plus that many exact steps give, so results do not change -- an item just starts that many rank steps further on */
 int  s3_index_lookup_chars(const s3_index *ix);
 
 /* One emitted record of the k-mismatch search, in the reference CPU path's emission order

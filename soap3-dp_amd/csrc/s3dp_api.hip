@@ -97,14 +97,15 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     ix->d.ltSize = desc->lktSize; ix->d.n = n;
     ix->d.ltBack = nullptr; ix->d.ltBi = nullptr; ix->d.ltK = 0;
     {
-        // longer lookup tables in HBM: S3DP_LT_EXTRA = 0 | 1 | 2 characters on top of the file format's table; default 2 (25.8 GB for 15-mers) for texts of
-        // a gigabase and more, where a run is long enough to pay for the allocation, 0 below
+        // longer lookup tables in HBM: S3DP_LT_EXTRA = 0 .. 3 characters on top of the file format's 13-mer table.  Default: 3 (16-mers, 103 GB) for texts
+        // of two gigabases and more -- 288 GB of HBM are there to be used and every character saves two rank queries per item --, 2 (15-mers, 25.8 GB)
+        // from one gigabase, 0 below, where a run is too short to pay for the allocation.  Out of memory: one character less.
         HIPCHK(hipStreamSynchronize(s));
-        const size_t deflt = n >= (1u << 30) ? 2 : 0;
+        const size_t deflt = n >= (1u << 31) ? 3 : n >= (1u << 30) ? 2 : 0;
         int extra = (int)envSize("S3DP_LT_EXTRA", deflt);
-        if (extra > 2) extra = 2;
-        if (desc->lktSize + extra > 15) extra = 15 - desc->lktSize;
-        if (extra > 0) {
+        if (extra > 3) extra = 3;
+        if (desc->lktSize + extra > 16) extra = 16 - desc->lktSize;
+        for (; extra > 0; extra--) {
             uint2 *tb = nullptr;
             uint4 *ti = nullptr;
             const int e = s3::launchLongLookup(ix->d, extra, &tb, &ti, s);
@@ -112,8 +113,10 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
                 ix->allocs.push_back(tb); ix->allocs.push_back(ti);
                 ix->d.ltBack = tb; ix->d.ltBi = ti; ix->d.ltK = desc->lktSize + extra;
                 ix->bytes += ((size_t)1 << (2 * ix->d.ltK)) * 24;
-            } else if (e != (int)hipErrorOutOfMemory) { s3_index_free(ix); return fail(S3_EHIP, std::string("long lookup tables: ") + hipGetErrorString((hipError_t)e)); }
-            else (void)hipGetLastError();                                  // no room: the search runs from the file format's table
+                break;
+            }
+            (void)hipGetLastError();
+            if (e != (int)hipErrorOutOfMemory) { s3_index_free(ix); return fail(S3_EHIP, std::string("long lookup tables: ") + hipGetErrorString((hipError_t)e)); }
         }
     }
     // model tables for every read length and mismatch budget (built on the host, see s3dp_model.cpp)

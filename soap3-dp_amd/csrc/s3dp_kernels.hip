@@ -575,13 +575,16 @@ __global__ void ltBaseBackKernel(DevIndex ix, uint2 *out, uint32_t n)
 
 __global__ void ltExtendBackKernel(DevIndex ix, const uint2 *in, uint2 *out, uint32_t nIn)
 {
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 4ull * nIn) return;
-    const uint32_t c = (uint32_t)(idx / nIn), x = (uint32_t)(idx % nIn);
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;               // one rank pair serves the four extensions of an entry
+    if (x >= nIn) return;
     const uint2 g = in[x];
-    if (g.x > g.y) { out[idx] = make_uint2(1u, 0u); return; }             // a dead range is never stepped
-    const uint4 oL = rankAll(ix.fwd, g.x), oR = rankAll(ix.fwd, g.y + 1u);
-    out[idx] = make_uint2(sel4(oL, c) + 1u, sel4(oR, c));
+    uint2 o[4] = {make_uint2(1u, 0u), make_uint2(1u, 0u), make_uint2(1u, 0u), make_uint2(1u, 0u)};   // a dead range is never stepped
+    if (g.x <= g.y) {
+        const uint4 oL = rankAll(ix.fwd, g.x), oR = rankAll(ix.fwd, g.y + 1u);
+        o[0] = make_uint2(oL.x + 1u, oR.x); o[1] = make_uint2(oL.y + 1u, oR.y); o[2] = make_uint2(oL.z + 1u, oR.z); o[3] = make_uint2(oL.w + 1u, oR.w);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) out[(size_t)c * nIn + x] = o[c];
 }
 
 __global__ void ltBaseBiKernel(DevIndex ix, uint4 *out, uint32_t n, int K)
@@ -598,26 +601,32 @@ __global__ void ltBaseBiKernel(DevIndex ix, uint4 *out, uint32_t n, int K)
 
 __global__ void ltExtendBiKernel(DevIndex ix, const uint4 *in, uint4 *out, uint32_t nIn)
 {
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 4ull * nIn) return;
-    const uint32_t c = (uint32_t)(idx / nIn), t = (uint32_t)(idx % nIn);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nIn) return;
     const uint4 g = in[t];
-    if (g.x > g.y) { out[idx] = make_uint4(1u, 0u, 1u, 0u); return; }
-    const uint4 oL = rankAll(ix.rev, g.z), oR = rankAll(ix.rev, g.w + 1u);
-    const uint32_t d1 = oR.y - oL.y, d2 = oR.z - oL.z, d3 = oR.w - oL.w;
-    const uint32_t oc = c == 0 ? d1 + d2 + d3 : c == 1 ? d2 + d3 : c == 2 ? d3 : 0u;
-    const uint32_t al = sel4(oL, c) + 1u, ar = sel4(oR, c);
-    const uint32_t pr = g.y - oc, pl = pr - (ar - al);                      // the passive (forward-index) range shrinks by the occurrences of the larger characters
-    out[idx] = make_uint4(pl, pr, al, ar);
+    uint4 o[4] = {make_uint4(1u, 0u, 1u, 0u), make_uint4(1u, 0u, 1u, 0u), make_uint4(1u, 0u, 1u, 0u), make_uint4(1u, 0u, 1u, 0u)};
+    if (g.x <= g.y) {
+        const uint4 oL = rankAll(ix.rev, g.z), oR = rankAll(ix.rev, g.w + 1u);
+        const uint32_t d1 = oR.y - oL.y, d2 = oR.z - oL.z, d3 = oR.w - oL.w;
+        // the passive (forward-index) range shrinks by the occurrences of the larger characters
+        const uint32_t al[4] = {oL.x + 1u, oL.y + 1u, oL.z + 1u, oL.w + 1u}, ar[4] = {oR.x, oR.y, oR.z, oR.w}, oc[4] = {d1 + d2 + d3, d2 + d3, d3, 0u};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t pr = g.y - oc[c], pl = pr - (ar[c] - al[c]);
+            o[c] = make_uint4(pl, pr, al[c], ar[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) out[(size_t)c * nIn + t] = o[c];
 }
 
 int launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s)
 {
     *backOut = nullptr; *biOut = nullptr;
-    if (extra < 1 || d.ltSize + extra > 15) return (int)hipErrorInvalidValue;
+    if (extra < 1 || extra > 3 || d.ltSize + extra > 16) return (int)hipErrorInvalidValue;
     const int K0 = d.ltSize;
-    uint2 *back[3] = {nullptr, nullptr, nullptr};
-    uint4 *bi[3] = {nullptr, nullptr, nullptr};
+    uint2 *back[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint4 *bi[4] = {nullptr, nullptr, nullptr, nullptr};
     hipError_t e = hipSuccess;
     for (int lv = 0; lv <= extra && e == hipSuccess; lv++) {
         const size_t n = (size_t)1 << (2 * (K0 + lv));
@@ -630,14 +639,13 @@ int launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hip
         hipLaunchKernelGGL(ltBaseBiKernel, dim3((n0 + 255) / 256), dim3(256), 0, s, d, bi[0], n0, K0);
         for (int lv = 0; lv < extra; lv++) {
             const uint32_t nIn = 1u << (2 * (K0 + lv));
-            const uint64_t nOut = 4ull * nIn;
-            hipLaunchKernelGGL(ltExtendBackKernel, dim3((unsigned)((nOut + 255) / 256)), dim3(256), 0, s, d, back[lv], back[lv + 1], nIn);
-            hipLaunchKernelGGL(ltExtendBiKernel, dim3((unsigned)((nOut + 255) / 256)), dim3(256), 0, s, d, bi[lv], bi[lv + 1], nIn);
+            hipLaunchKernelGGL(ltExtendBackKernel, dim3((nIn + 255) / 256), dim3(256), 0, s, d, back[lv], back[lv + 1], nIn);
+            hipLaunchKernelGGL(ltExtendBiKernel, dim3((nIn + 255) / 256), dim3(256), 0, s, d, bi[lv], bi[lv + 1], nIn);
         }
         e = hipStreamSynchronize(s);
         if (e == hipSuccess) e = hipGetLastError();
     }
-    for (int lv = 0; lv < 3; lv++) {
+    for (int lv = 0; lv < 4; lv++) {
         if (e == hipSuccess && lv == extra) continue;
         if (back[lv]) (void)hipFree(back[lv]);
         if (bi[lv]) (void)hipFree(bi[lv]);

@@ -276,10 +276,10 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const uint32_t padOnes = ll < ix.ltSize ? ((1u << (2 * (ix.ltSize - ll))) - 1u) : 0u;
             const int shPad = 2 * (ix.ltSize - ll);
             if (ix.ltK && st.len >= ix.ltK && st.ceThr == 0) {                 // (a lookup step that may switch to check-and-extend on its way -- exact-match models -- is walked)
-                // long table (<= 15 characters): one entry holds the state behind the lookup step's first ltK characters; ltB = ~0 marks the item
+                // long table (<= 16 characters): one entry holds the state behind the lookup step's first ltK characters; ltB = ~0 marks the item
                 const int K = ix.ltK;
                 if (st.type == S3_T_BACK_LOOKUP) ltA = readWindow(st.start - K + 1) >> (32 - 2 * K);
-                else ltA = pairRev(readWindow(st.start)) & ((1u << (2 * K)) - 1u);
+                else ltA = pairRev(readWindow(st.start)) & (K >= 16 ? 0xFFFFFFFFu : (1u << (2 * K)) - 1u);
                 ltB = 0xFFFFFFFFu;
             } else if (st.type == S3_T_BACK_LOOKUP) {
                 const uint32_t key = readWindow(st.start - ll + 1) >> (32 - 2 * ll);

@@ -45,10 +45,10 @@ def test_search_bit_exact_vs_reference_dump_and_oracle(name, maxlen, mm):
     b.close()
 
 
-@pytest.mark.parametrize("extra", [1, 2])
+@pytest.mark.parametrize("extra", [1, 2, 3])
 @pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
 def test_long_lookup_tables_do_not_change_results(monkeypatch, name, maxlen, extra):
-    """S3DP_LT_EXTRA: 14- / 15-mer tables built in HBM at upload (the state after the 13-mer lookup plus one / two exact steps).  Records, their
+    """S3DP_LT_EXTRA: 14- / 15- / 16-mer tables built in HBM at upload (the state after the 13-mer lookup plus one / two / three exact steps).  Records, their
     order and the per-read tallies must stay bit-identical to the oracle for every mismatch budget; only the number of rank queries drops."""
     monkeypatch.setenv("S3DP_LT_EXTRA", str(extra))
     ix = s3dp.Index(host_index(name))
