@@ -41,6 +41,9 @@ __device__ __forceinline__ void bestMerge(Best &a, int score, uint32_t key, uint
     else if (score == a.score) { a.count += count; a.key = key < a.key ? key : a.key; }
 }
 
+// value of the lane below (lane 0: 0): one DPP move across the whole wavefront (wave_shr:1) instead of a trip through the LDS crossbar
+__device__ __forceinline__ int waveShr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
+
 // one sweep over W columns (starting after refOffset) of problem p by the calling wavefront
 template <bool TABLE>
 __device__ void sweep(const DpArgs &a, uint32_t p, uint32_t W, uint32_t L, uint32_t refOffset, int clipLt, int clipRtLoc, uint32_t aL, uint32_t aR,
@@ -70,7 +73,7 @@ __device__ void sweep(const DpArgs &a, uint32_t p, uint32_t W, uint32_t L, uint3
         const uint32_t steps = W + 63u;
         for (uint32_t t = 1; t <= steps; t++) {
             // values handed down from the row above: lane 0 reads the boundary row, the others shuffle
-            int upS = __shfl_up(upIn, 1), fS = __shfl_up(fIn, 1), dgS = __shfl_up(dgIn, 1);
+            int upS = waveShr1(upIn), fS = waveShr1(fIn), dgS = waveShr1(dgIn);
             const int j = (int)t - (int)lane;
             const bool act = rowOk && j >= 1 && j <= (int)W;
             if (lane == 0 && act) { upS = bnd[3 * j]; fS = bnd[3 * j + 1]; dgS = bnd[3 * j + 2]; }
