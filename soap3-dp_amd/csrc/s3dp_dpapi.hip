@@ -2,6 +2,7 @@
 // pairs and single reads (window geometry, on-device packing, traceback decode).  Kernels: s3dp_dp.hip.
 #include <algorithm>
 #include <hipcub/hipcub.hpp>
+#include <thread>
 #include "s3dp_internal.h"
 
 using namespace s3;
@@ -216,6 +217,30 @@ struct CigarEnc {
 };
 }  // namespace
 
+// Decode of one DP batch by the host threads: fn(id, results, pool) appends the results of problem id with CIGAR offsets relative to the pool it is
+// given; the parts are joined in id order (fix adds the part's base to the offsets), so the output is what a serial loop would produce.
+template <class R, class Fn, class Fix>
+static void decodeParallel(uint32_t n, std::vector<R> &results, std::string &pool, Fn &&fn, Fix &&fix)
+{
+    unsigned T = std::thread::hardware_concurrency();
+    if (T > 32) T = 32;
+    if (T < 2 || n < 4096) { for (uint32_t id = 0; id < n; id++) fn(id, results, pool); return; }
+    struct Part { std::vector<R> res; std::string pool; };
+    std::vector<Part> parts(T);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+            for (uint32_t id = lo; id < hi; id++) fn(id, parts[t].res, parts[t].pool);
+        });
+    for (auto &x : th) x.join();
+    for (unsigned t = 0; t < T; t++) {
+        const uint32_t base = (uint32_t)pool.size();
+        for (R &r : parts[t].res) { fix(r, base); results.push_back(r); }
+        pool += parts[t].pool;
+    }
+}
+
 extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3_occ *occ, size_t nOcc, int insertLow, int insertHigh,
                               const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_half_result **resultsOut, size_t *nResultsOut,
                               char **cigarPoolOut)
@@ -261,7 +286,7 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
         HIPCHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         // algnmtCPUThread (:2329-2441)
-        for (uint32_t id = 0; id < n; id++) {
+        decodeParallel<s3_dp_half_result>(n, results, pool, [&](uint32_t id, std::vector<s3_dp_half_result> &results, std::string &pool) {
             s3_dp_half_result r{};
             const uint32_t alignedID = refer[id].readID, alignedIsMate = alignedID & 1u;
             r.readID = alignedID - alignedIsMate;
@@ -296,7 +321,7 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
                 r.strand_1 = dpStrand; r.strand_2 = refer[id].strand;
             }
             results.push_back(r);
-        }
+        }, [](s3_dp_half_result &r, uint32_t base) { if (r.cigarOffset != 0xFFFFFFFFu) r.cigarOffset += base; });
         cand.clear(); dnaLens.clear(); rdLens.clear(); clipLt.clear(); clipRt.clear(); aL.clear(); aR.clear(); startLocs.clear(); cut.clear();
         leftOrRight.clear(); refer.clear();
         return S3_OK;
@@ -420,8 +445,8 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
         ECHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
         ECHK(hipStreamSynchronize(s));
 #undef ECHK
-        for (uint32_t i = 0; i < n; i++) {
-            if (scores[i] < cutoffThreshold) continue;
+        decodeParallel<s3_dp_single_result>(n, results, pool, [&](uint32_t i, std::vector<s3_dp_single_result> &results, std::string &pool) {
+            if (scores[i] < cutoffThreshold) return;
             CigarEnc enc;
             char last = 'N';
             for (const uint8_t *p = pat.data() + (size_t)i * h->patternLen; *p != 0; p++) {
@@ -439,7 +464,7 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
             pool += enc.text;
             pool.push_back('\0');
             results.push_back(r);
-        }
+        }, [](s3_dp_single_result &r, uint32_t base) { r.cigarOffset += base; });
     }
     (void)hipFree(dCand);
     if (rc) return rc;
@@ -704,11 +729,11 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
         if (rc) break;
         if (m && (rc = runRound(candR, dnaR, rdR, cutR, clipLtR, clipRtR, aLR, aRR, RR))) break;
         // DP2CPUAlgnThread: both ends above their cutoffs
-        for (uint32_t k = 0; k < m; k++) {
+        decodeParallel<s3_dp_deep_result>(m, results, pool, [&](uint32_t k, std::vector<s3_dp_deep_result> &results, std::string &pool) {
             const uint32_t i = sel[k];
             const PairCand &c = cands[base + i];
             const int readSide = (int)(c.readIDLeft & 1u), mateSide = 1 - readSide;
-            if (RR.scores[k] < cutoffThreshold[mateSide]) continue;
+            if (RR.scores[k] < cutoffThreshold[mateSide]) return;
             // index 0 = left end, 1 = right end.  Both edit distances use the RIGHT end's length (batch->lengths[] after packRight), as the reference
             const Round *rd[2] = {&RL, &RR};
             const uint32_t idx[2] = {i, k};
@@ -741,7 +766,7 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
             r.cigarOffset_1 = (uint32_t)pool.size(); pool += cig[readSide]; pool.push_back('\0');
             r.cigarOffset_2 = (uint32_t)pool.size(); pool += cig[mateSide]; pool.push_back('\0');
             results.push_back(r);
-        }
+        }, [](s3_dp_deep_result &r, uint32_t base) { r.cigarOffset_1 += base; r.cigarOffset_2 += base; });
     }
 #undef ECHK
     (void)hipFree(dCand);
