@@ -100,6 +100,7 @@ public:
     void improperPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const uint32_t *pos1, const uint8_t *strand1, const uint8_t *mis1, size_t n1,
                       const uint32_t *pos2, const uint8_t *strand2, const uint8_t *mis2, size_t n2, uint32_t xaLimit);
     uint64_t records() const { return nRecords; }
+    void flush() { if (out) fflush(out); }
 
 private:
     uint32_t chrAndPos(uint32_t ambPos, uint64_t &tp, uint32_t &chr) const;                    // getChrAndPos, BGS-IO.cpp:1746

@@ -263,9 +263,16 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         if (s3_dp_half_end(c.dpHalf, c.b, lens, dpOcc.data(), dpOcc.size(), c.insertLow, c.insertHigh, cut, c.halfPar[0].softClipLeft, c.halfPar[0].softClipRight, &res, &nRes,
                            &pool) != S3_OK) { err = s3_last_error(); return false; }
         std::vector<uint8_t> done(np, 0);
+        std::vector<std::pair<size_t, size_t>> groups;                              // runs of results of the same pair
         for (size_t i = 0; i < nRes;) {
             size_t j = i;
             while (j < nRes && res[j].readID == res[i].readID) j++;
+            groups.push_back({i, j});
+            i = j;
+        }
+        w.flush();
+        parallelFormat(c.hix, c.so, c.dpOut, (uint32_t)groups.size(), [&](SamWriter &w, uint32_t gk, uint64_t &al) {
+            const size_t i = groups[gk].first, j = groups[gk].second;
             // OutputBuffer::ready(OUTPUT_AS_INPUT_ORDER | DO_NOT_OUTPUT_HALF_ALIGNED), DV-DPfunctions.h:367-412 with ScoreCompare<AlgnmtDPResult> (:886)
             std::vector<PairDpHit> hits;
             auto value = [](const s3_dp_half_result &x) -> uint64_t {
@@ -294,10 +301,9 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
                 statsOf(p, st);
                 w.pairDP(c.rs, c.first + res[i].readID, hits.data(), hits.size(), st);
                 done[p] = 1;
-                defaultDpPairs++;
+                al++;
             }
-            i = j;
-        }
+        }, defaultDpPairs);
         s3_free(res); s3_free(pool);
         for (uint32_t p = 0; p < np; p++) if (inDefault[p] && !done[p]) deepPairs.push_back(2 * p);
         std::sort(deepPairs.begin(), deepPairs.end());
@@ -305,9 +311,16 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
     // deep-DP results of a run of pairs -> records (DP2OutputThread :3846-3858: OutputBuffer::ready(), then outputDeepDPResult2)
     std::vector<uint8_t> deepDone(np, 0);
     auto deepRecords = [&](const s3_dp_deep_result *res, size_t nRes, const char *pool, uint64_t &counter) {
+    std::vector<std::pair<size_t, size_t>> groups;
     for (size_t i = 0; i < nRes;) {
         size_t j = i;
         while (j < nRes && res[j].readID / 2 == res[i].readID / 2) j++;
+        groups.push_back({i, j});
+        i = j;
+    }
+    w.flush();
+    parallelFormat(c.hix, c.so, c.dpOut, (uint32_t)groups.size(), [&](SamWriter &w, uint32_t gk, uint64_t &al) {
+        const size_t i = groups[gk].first, j = groups[gk].second;
         // OutputBuffer::ready(): sorted by the first end's position, one result per position; best only for -h 3 / 4 (ScoreCompare: score sum)
         std::vector<DeepDpHit> hits;
         for (size_t q = i; q < j; q++) {
@@ -338,10 +351,9 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             statsOf(p, st);
             w.pairDeepDP(c.rs, c.first + 2 * p, hits.data(), hits.size(), st);
             deepDone[p] = 1;
-            counter++;
+            al++;
         }
-        i = j;
-    }
+    }, counter);
     };
     lap(1);
     // ---- new default DP (the reference runs it before the default DP; the stages are independent of each other) ----
@@ -400,8 +412,8 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
     if (!singleDpRuns(c.b, c.seedBatch, c.dp, lens, todo, c.singlePar, moduleType, [&](uint32_t k, std::vector<DpHit> &hits) {
             own[k].insert(own[k].end(), hits.begin(), hits.end());
         }, err)) return false;
-    SamWriter up(c.hix, c.so, c.unpairOut);
-    for (uint32_t r1 : left) {
+    parallelFormat(c.hix, c.so, c.unpairOut, (uint32_t)left.size(), [&](SamWriter &up, uint32_t lk, uint64_t &al) {
+        const uint32_t r1 = left[lk];
         for (uint32_t r = r1; r < r1 + 2; r++) {
             if (viaDP[r]) continue;
             const int L = (int)lens[r];
@@ -412,8 +424,8 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             }
         }
         up.unpairedDP(c.rs, c.first + r1, own[r1].data(), own[r1].size(), own[r1 + 1].data(), own[r1 + 1].size(), c.singlePar.cutoffThreshold);
-        leftoverPairs++;
-    }
+        al++;
+    }, leftoverPairs);
     lap(4);
     return true;
 }
