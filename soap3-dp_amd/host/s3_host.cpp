@@ -347,8 +347,16 @@ bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t 
                    std::string &err)
 {
     ReadSet a, b;
-    if (!loadSingleReads(file1, maxReadLength, qualityConstant, maxLenReadName, a, err)) return false;
-    if (!loadSingleReads(file2, maxReadLength, qualityConstant, maxLenReadName, b, err)) return false;
+    {
+        // both files at once (each load is parallel inside already; the file reads and the serial parts overlap)
+        std::string err2;
+        bool ok2 = true;
+        std::thread second([&] { ok2 = loadSingleReads(file2, maxReadLength, qualityConstant, maxLenReadName, b, err2); });
+        const bool ok1 = loadSingleReads(file1, maxReadLength, qualityConstant, maxLenReadName, a, err);
+        second.join();
+        if (!ok1) return false;
+        if (!ok2) { err = err2; return false; }
+    }
     const uint32_t np = a.n < b.n ? a.n : b.n;                          // the reference stops at the shorter file
     rs = ReadSet();
     rs.maxReadLength = maxReadLength; rs.wpq = a.wpq; rs.isFastq = a.isFastq; rs.n = 2 * np;
@@ -358,7 +366,12 @@ bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t 
     rs.names.resize(rs.n);
     rs.codes.assign((size_t)rs.n * maxReadLength, 0);
     rs.quals.assign((size_t)rs.n * maxReadLength, 0);
-    for (uint32_t r = 0; r < rs.n; r++) {
+    const int T = hostThreads();
+    std::vector<std::thread> th;
+    const uint32_t per = ((rs.n + (uint32_t)T - 1) / (uint32_t)T + 31u) / 32u * 32u;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t] {
+    const uint32_t lo = (uint32_t)t * per, hi = lo + per < rs.n ? lo + per : rs.n;
+    for (uint32_t r = lo; r < hi; r++) {
         const ReadSet &src = (r & 1) ? b : a;
         const uint32_t k = r >> 1;
         rs.lengths[r] = src.lengths[k];
@@ -369,6 +382,8 @@ bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t 
         const uint32_t *sq = src.queries.data() + (size_t)(k / 32) * 32 * src.wpq + k % 32;
         for (uint32_t w = 0; w < rs.wpq; w++) dst[(size_t)w * 32] = sq[(size_t)w * 32];
     }
+    });
+    for (auto &x : th) x.join();
     return true;
 }
 
