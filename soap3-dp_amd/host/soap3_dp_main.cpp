@@ -103,9 +103,11 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
 // `emit` gets one call per run of results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776 -- results arrive in (strand, read, position)
 // order, so a read with hits on both strands comes twice) after OutputBuffer::ready (DV-DPfunctions.h:367-412) with the DP module's type
 // (all-best + SAM runs it as all-valid, alignment.cu:2563): sorted by position, one result per position; then best-only for -h 3 / 4 --------------
+// parallelOut != NULL: the runs of a batch are handed to `emit` by all host threads at once, each with a writer whose records land in parallelOut in run
+// order; NULL: one call after the other (the writer argument is then a dummy that must not be used).
 template <class Emit>
-static bool singleDpRuns(s3_batch *b, s3_batch *seedBatch, s3_dp *dp, const uint32_t *lens, const std::vector<uint32_t> &todo, const s3_dp_stage_params &dpPar,
-                         int alignmentType, Emit &&emit, std::string &err)
+static bool singleDpRuns(const HostIndex &hix, const SamOptions &so, FILE *parallelOut, s3_batch *b, s3_batch *seedBatch, s3_dp *dp, const uint32_t *lens,
+                         const std::vector<uint32_t> &todo, const s3_dp_stage_params &dpPar, int alignmentType, Emit &&emit, std::string &err)
 {
     size_t at = 0;
     while (at < todo.size()) {
@@ -132,9 +134,15 @@ static bool singleDpRuns(s3_batch *b, s3_batch *seedBatch, s3_dp *dp, const uint
             s3_free(cand);
             return false;
         }
+        std::vector<std::pair<size_t, size_t>> groups;
         for (size_t i = 0; i < nRes;) {
             size_t j = i;
             while (j < nRes && res[j].readID == res[i].readID) j++;
+            groups.push_back({i, j});
+            i = j;
+        }
+        auto one = [&](SamWriter &w, uint32_t gk) {
+            const size_t i = groups[gk].first, j = groups[gk].second;
             std::vector<DpHit> hits;
             for (size_t q = i; q < j; q++) hits.push_back(DpHit{res[q].algnmt, res[q].strand, res[q].score, (int)res[q].editdist, std::string(pool + res[q].cigarOffset)});
             std::sort(hits.begin(), hits.end(), [](const DpHit &x, const DpHit &y) { return x.pos < y.pos; });
@@ -150,8 +158,15 @@ static bool singleDpRuns(s3_batch *b, s3_batch *seedBatch, s3_dp *dp, const uint
                 if (alignmentType == 4) bestOnes.resize(1);
                 hits.swap(bestOnes);
             }
-            if (!hits.empty()) emit(res[i].readID, hits);
-            i = j;
+            if (!hits.empty()) emit(w, res[i].readID, hits);
+        };
+        if (parallelOut) {
+            uint64_t unused = 0;
+            parallelFormat(hix, so, parallelOut, (uint32_t)groups.size(), [&](SamWriter &w, uint32_t gk, uint64_t &) { one(w, gk); }, unused);
+        } else {
+            std::string sink;
+            SamWriter dummy(hix, so, &sink);
+            for (uint32_t gk = 0; gk < groups.size(); gk++) one(dummy, gk);
         }
         s3_free(cand); s3_free(res); s3_free(pool);
         at = end;
@@ -409,7 +424,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
     std::vector<std::vector<DpHit>> own(c.cnt);
     // a read with DP hits on both strands reaches the reference's store as two entries and breaks its pairing by position in the list
     // (outputSingleResultForPairEnds :1106-1112 prints an error); here the two runs are one list
-    if (!singleDpRuns(c.b, c.seedBatch, c.dp, lens, todo, c.singlePar, moduleType, [&](uint32_t k, std::vector<DpHit> &hits) {
+    if (!singleDpRuns(c.hix, c.so, nullptr, c.b, c.seedBatch, c.dp, lens, todo, c.singlePar, moduleType, [&](SamWriter &, uint32_t k, std::vector<DpHit> &hits) {
             own[k].insert(own[k].end(), hits.begin(), hits.end());
         }, err)) return false;
     parallelFormat(c.hix, c.so, c.unpairOut, (uint32_t)left.size(), [&](SamWriter &up, uint32_t lk, uint64_t &al) {
@@ -651,12 +666,14 @@ int main(int argc, char **argv)
             std::vector<uint8_t> doneFlag(cnt, 0);
             const uint32_t *lens = rs.lengths.data() + first;
             {
-                SamWriter w(hix, so, dpOut);
+                // a read with DP hits on both strands comes as two runs (two records, as in the reference): its flag may be set by two threads at once,
+                // to the same value; the count of aligned reads is taken from the flags afterwards
                 std::string e2;
-                if (!singleDpRuns(b, seedBatch, dp, lens, todo, dpPar, alignmentType, [&](uint32_t k, std::vector<DpHit> &hits) {
+                if (!singleDpRuns(hix, so, dpOut, b, seedBatch, dp, lens, todo, dpPar, alignmentType, [&](SamWriter &w, uint32_t k, std::vector<DpHit> &hits) {
                         w.singleDP(rs, first + k, hits.data(), hits.size(), dpPar.cutoffThreshold);
-                        if (!doneFlag[k]) { doneFlag[k] = 1; dpAlignedReads++; }
+                        doneFlag[k] = 1;
                     }, e2)) return die(e2);
+                for (uint32_t k : todo) dpAlignedReads += doneFlag[k];
             }
             SamWriter w(hix, so, dpOut);
             for (uint32_t k : todo) if (!doneFlag[k]) w.unaligned(rs, first + k);
