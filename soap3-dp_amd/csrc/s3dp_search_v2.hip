@@ -5,18 +5,19 @@
 // by the number of vector-memory REQUESTS, not by DRAM bytes: two 16-B lane loads into the same 64-B line cost
 // as much as two lines.  So v2 issues ONE coalesced 64-B request per rank line:
 //
-//   * a wavefront runs 64 items (same case, same strand) as a flat state machine: every iteration first ISSUES
-//     all memory operations of all lanes (rank lines, suffix-array entries, packed-text windows), then waits
-//     once, then every lane advances its own search (pure ALU + LDS) until it needs memory again;
+//   * the grid is persistent; a lane owns one READ at a time, walks its (case, strand) items back to back as a flat state machine and takes the
+//     next read from a work queue when it is done.  Every trip of the loop first ISSUES all memory operations of all lanes (rank lines, lookup
+//     entries, read words), then waits once, then every lane advances its own search (pure ALU + LDS) until it needs memory again;
 //   * rank lines are fetched cooperatively: 4 adjacent lanes load the 4 x 16 B of one owner's line (the owner's
 //     line id travels by ds_bpermute), the line is staged in LDS and read back by its owner -- "Occ/rank tables
 //     staged through LDS for coalesced HBM reads".  l and r+1 almost always fall into the same line once the
 //     range is narrow; only lanes whose two lines differ issue a private second fetch;
-//   * the case's step table sits in LDS (one copy per wave), raw read words sit in LDS word-interleaved by
-//     lane; strand orientation and the MSB-first windows needed by check-and-extend are computed on the fly
-//     with funnel shifts, no per-character loops;
-//   * check-and-extend is part of the same state machine (SA entry -> text window -> compare), so its memory
-//     latency overlaps with the other lanes' rank fetches instead of serialising behind divergent branches.
+//   * the case's step table sits in LDS (one copy per block), the read's words -- both orientations, MSB first, prepared once per upload -- sit
+//     in LDS word-interleaved by lane: a read character is one LDS word and a shift;
+//   * an item starts from the longest lookup table the index holds (13-mers of the file format, or the 14- / 15- / 16-mer tables built in HBM at
+//     upload: the state behind the lookup step's first characters, s3dp_kernels.hip::launchLongLookup);
+//   * check-and-extend runs in its own kernel (ceKernel, below): the stepping kernel writes task records and goes on (template parameter SPLIT;
+//     SPLIT = false keeps it inside the state machine, the first form of this kernel, S3DP_CE=inline).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "s3dp_device.h"
