@@ -398,14 +398,24 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             const int cut[2] = {par[0].cutoffThreshold, par[1].cutoffThreshold};
             // seeds go through the seed batch in pieces (at most 12 seeds per read below 400 bases)
             std::vector<uint32_t> next;
-            const size_t piece = 8192;
-            for (size_t at = 0; at < todo.size(); at += piece) {
-                const size_t m = std::min(piece, todo.size() - at);
-                if (s3_dp_deep(c.dp, c.b, c.seedBatch, lens, todo.data() + at, m, round == 0 ? S3_STAGE_DEEP_DP_ROUND1 : S3_STAGE_DEEP_DP_ROUND2, (uint32_t)par[0].maxHitNum,
+            const int stageId = round == 0 ? S3_STAGE_DEEP_DP_ROUND1 : S3_STAGE_DEEP_DP_ROUND2;
+            for (size_t at = 0; at < todo.size();) {
+                size_t m = 0, nSeeds = 0;                                         // as many pairs as the seed batch holds seeds for
+                while (at + m < todo.size()) {
+                    int sl = 0, n1 = 0, n2 = 0, sp[128];
+                    s3_seed_positions(stageId, (int)lens[todo[at + m]], &sl, sp, &n1);
+                    s3_seed_positions(stageId, (int)lens[todo[at + m] + 1], &sl, sp, &n2);
+                    if (nSeeds + (size_t)(n1 + n2) > 262144) break;
+                    nSeeds += (size_t)(n1 + n2);
+                    m++;
+                }
+                if (m == 0) m = 1;
+                if (s3_dp_deep(c.dp, c.b, c.seedBatch, lens, todo.data() + at, m, stageId, (uint32_t)par[0].maxHitNum,
                                c.insertLow, c.insertHigh, cut, par[0].softClipLeft, par[0].softClipRight, &res, &nRes, &pool, &flags) != S3_OK) { err = s3_last_error(); return false; }
                 for (size_t k = 0; k < m; k++) if (round == 0 && flags[k] == 1) next.push_back(todo[at + k]);
                 deepRecords(res, nRes, pool, deepDpPairs);
                 s3_free(res); s3_free(pool); s3_free(flags);
+                at += m;
             }
             todo.swap(next);
         }
