@@ -97,6 +97,23 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     ix->d.ltSize = desc->lktSize; ix->d.n = n;
     ix->d.ltBack = nullptr; ix->d.ltBi = nullptr; ix->d.ltK = 0;
     {
+        // padded k-mers of the two tables (see DevIndex): text[n-j .. n-1] + 'A' x (K-j) and, for the reverse table, text[j-1 .. 0] + 'A' x (K-j), j = 1 .. K-1
+        const int K = desc->lktSize;
+        auto ch = [&](uint64_t p) -> uint32_t { return (desc->packedDNA[p >> 4] >> (2 * (15 - (p & 15)))) & 3u; };
+        auto rev = [&](uint32_t key) { uint32_t r = 0; for (int j = 0; j < K; j++) r |= ((key >> (2 * j)) & 3u) << (2 * (K - 1 - j)); return r; };
+        for (int j = 1; j <= 12; j++) {
+            uint32_t kf = 0xFFFFFFFFu, kr = 0xFFFFFFFFu;                     // unused slots never match (keys have at most 26 bits)
+            if (j < K && (uint32_t)j <= n) {
+                kf = 0; kr = 0;
+                for (int q = 0; q < j; q++) { kf = (kf << 2) | ch((uint64_t)n - j + q); kr = (kr << 2) | ch((uint64_t)(j - 1 - q)); }
+                kf <<= 2 * (K - j); kr <<= 2 * (K - j);
+            }
+            ix->d.padBack[j - 1] = kf;
+            ix->d.padBi[j - 1] = kr;
+            ix->d.padBi[12 + j - 1] = kf == 0xFFFFFFFFu ? kf : rev(kf);
+        }
+    }
+    {
         // longer lookup tables in HBM: S3DP_LT_EXTRA = 0 .. 3 characters on top of the file format's 13-mer table.  Default: 3 (16-mers, 103 GB) for texts
         // of two gigabases and more -- 288 GB of HBM are there to be used and every character saves two rank queries per item --, 2 (15-mers, 25.8 GB)
         // from one gigabase, 0 below, where a run is too short to pay for the allocation.  Out of memory: one character less.
@@ -316,6 +333,11 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.wpq = b->wpq;
     in.wpqLoad = (b->longMode && b->wpq > 8) ? 8 : b->wpq;                // seeds have at most 128 bases
     in.models = b->ix->models[modelMm]; in.nCases = nCases; in.maxOut = maxOut; in.uniformLen = b->uniformLen;
+    {
+        // S3DP_EARLY_CE=0: single-suffix ranges walk their exact lookup step to the end, as the CPU path does (same results, more rank queries)
+        static const bool early = [] { const char *e = getenv("S3DP_EARLY_CE"); return !(e && strcmp(e, "0") == 0); }();
+        in.earlyCe = early ? 1u : 0u;
+    }
     {
         S3Model m;
         s3_model_build(100, (int)modelMm, &m);

@@ -34,6 +34,10 @@ struct DevIndex {
     const uint2    *ltBack;      // backward lookup steps: {l, r}, indexed by the ltK characters in read order
     const uint4    *ltBi;        // bidirectional lookup steps: {l, r, rev l, rev r}, indexed by the ltK characters REVERSED (order of the reverse index)
     int             ltK;         // 0: none
+    // The 13-mers that the file format's tables count for text positions closer than 13 characters to an end (padded with 'A', LTConstruct.c:45-101):
+    // a lookup range for one of them may hold an element that is no occurrence.  padBack: as a backward item builds its key (read order);
+    // padBi: as a bidirectional item builds its reversed key -- the reverse table's own ones and the forward table's, pairs reversed.
+    uint32_t        padBack[12], padBi[24];
 };
 
 struct SearchIn {
@@ -49,9 +53,11 @@ struct SearchIn {
     uint32_t        maxOut;
     uint32_t        nStepsPacked;  // 3 bits per case: number of steps (depends on the mismatch budget only)
     uint32_t        uniformLen;  // != 0: every active read has this length (model kept in LDS by the v2 kernel)
+    uint32_t        earlyCe;     // 1: single-suffix ranges leave the exact lookup step for check-and-extend at once (s3dp_search_v2.hip)
 };
 
-#define S3_REC_TASK (1u << 28)
+#define S3_REC_TASK  (1u << 28)
+#define S3_REC_EARLY (1u << 29)              // task written inside the exact lookup step (single-suffix range): the rest of that step is verified too
 
 struct SearchOut {
     uint4              *recs;    // {item, seq|kind<<24|nmis<<25, a, b};  S3_REC_TASK set: a check-and-extend task {item, first seq, SA left, size-1 | state<<8}

@@ -139,6 +139,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     int ceS = 0, ceI = 0, ceIns = 0, ceOcc = 0;
     int ceT = 0, ceII = 0, ceInsCur = 0, ceAcc = 0, ceMm = 0;
     uint32_t ltA = 0, ltB = 0, ltC = 0, ltD = 0;                            // lookup-table keys of the starting item
+    bool padded = false;                                                    // the item's lookup range may hold an element that is no occurrence
     // wave-uniform work queue window
     uint64_t chunkCur = 0, chunkEnd = 0, chunkBase = 0;
     uint32_t act0 = 0, act1 = 0;
@@ -210,6 +211,23 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         return;
                     }
                 }
+                if constexpr (SPLIT) {
+                    // ONE suffix left inside the exact lookup step: walking the rest of the step can only keep it or lose it, and the next step hands it to
+                    // check-and-extend at its first position anyway.  Hand it over now; the task also verifies what is left of this step, inside the text.
+                    // (Not for ranges that may hold a padded table element: those are walked, as the CPU path walks them.)
+                    if (in.earlyCe && s == 0 && g.fl == g.fr && st.ceThr == 0 && nSteps > 1 && !padded) {
+                        const S3Step nx = stepAt(1);
+                        if (nx.ceThr >= 1 && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
+                            if (pendMeta >> 31) { state = ST_RESUME; return; }
+                            pendMeta = 0x80000000u | seq | S3_REC_TASK | S3_REC_EARLY;
+                            pendA = g.fl;
+                            pendB = ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+                            seq += 1u;
+                            needPop = true;
+                            continue;
+                        }
+                    }
+                }
                 state = ST_STEP;
                 return;
             }
@@ -276,6 +294,23 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;            // <= 13 characters = 26 bits of one window
             const uint32_t padOnes = ll < ix.ltSize ? ((1u << (2 * (ix.ltSize - ll))) - 1u) : 0u;
             const int shPad = 2 * (ix.ltSize - ll);
+            {
+                // does the item's 13-mer belong to the padded ones of the tables it reads?
+                const int k0 = ix.ltSize;
+                const uint32_t m13 = (1u << (2 * k0)) - 1u;
+                padded = st.len < k0;                                        // shorter lookup steps read a whole block of entries: walked
+                if (!padded) {
+                    if (st.type == S3_T_BACK_LOOKUP) {
+                        const uint32_t k13 = (readWindow(st.start - k0 + 1) >> (32 - 2 * k0)) & m13;
+#pragma unroll
+                        for (int j = 0; j < 12; j++) padded |= k13 == ix.padBack[j];
+                    } else {
+                        const uint32_t r13 = pairRev(readWindow(st.start)) & m13;
+#pragma unroll
+                        for (int j = 0; j < 24; j++) padded |= r13 == ix.padBi[j];
+                    }
+                }
+            }
             if (ix.ltK && st.len >= ix.ltK && st.ceThr == 0) {                 // (a lookup step that may switch to check-and-extend on its way -- exact-match models -- is walked)
                 // long table (<= 16 characters): one entry holds the state behind the lookup step's first ltK characters; ltB = ~0 marks the item
                 const int K = ix.ltK;
@@ -564,6 +599,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         uint4 rec = make_uint4(0xFFFFFFFFu, 0, 0, 0);
         if (idx < nRec) rec = out.recs[idx];
         const bool task = rec.x != 0xFFFFFFFFu && (rec.y & S3_REC_TASK);
+        const bool early = task && (rec.y & S3_REC_EARLY);
         uint32_t size = 0, rIdx = 0, casIdx = 0, strand = 0;
         int Li = 0, nSteps = 0, s0 = 0, i0 = 0, ins0 = 0, occ0 = 0;
         if (task) {
@@ -595,6 +631,11 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                     const int pos = st.start + st.dir * ii;
                     const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end), right = (uint32_t)(pos < st.end ? st.end : pos);
                     const uint32_t len = right - left + 1u;
+                    if (early && t == s0) {
+                        // what is left of the exact lookup step: the walk this replaces matches real text only
+                        const long long rpS = (long long)sa - (long long)leftAlign;
+                        if (rpS + (long long)left < 0 || rpS + (long long)right >= (long long)ix.n) { hit = false; break; }
+                    }
                     if (rp + left > ix.n) { hit = false; break; }                // BGS-HostAlgnmtAlgo2.cpp:122-125
                     const uint32_t tpos = rp + left;
                     int mm = 0;

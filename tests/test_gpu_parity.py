@@ -39,7 +39,11 @@ def test_search_bit_exact_vs_reference_dump_and_oracle(name, maxlen, mm):
     assert hits.tobytes() == ohits.tobytes()
     assert (tot == otot).all() and (werr == owerr).all()
     c = b.counters()
-    assert c["rankQueries"] == st.rankQueries
+    # single-suffix ranges leave the exact lookup step early (same records, fewer rank queries); S3DP_EARLY_CE=0 walks like the CPU path
+    if os.environ.get("S3DP_EARLY_CE") == "0":
+        assert c["rankQueries"] == st.rankQueries
+    else:
+        assert c["rankQueries"] <= st.rankQueries
     assert c["ltLookups"] == st.ltLookups
     oix.close()
     b.close()
@@ -67,6 +71,7 @@ def test_long_lookup_tables_do_not_change_results(monkeypatch, name, maxlen, ext
         assert (tot == otot).all() and (werr == owerr).all()
         c = b.counters()
         assert c["rankQueries"] <= st.rankQueries and (mm == 0 or c["rankQueries"] < st.rankQueries)
+        assert c["ltLookups"] <= st.ltLookups
     b.align_single_allbest(4, 1000)
     phase, we, off2, pos, strand, mis = b.fetch_alignments()
     oph, owe, ooff, opos, ostr, omis, _ = oix.align_single_allbest(q, lens, wpq, 4, 1000)
