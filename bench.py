@@ -327,12 +327,15 @@ def main():
     total_reads = tot["reads"]
     value = total_reads * a.steps / dt / 1e6
 
-    # ---- roofline of the dominant kernel (searchKernel) --------------------------------------------------
-    # algorithmic bytes: 32 B per rank query + packed read + length per read + 12 B per record
-    bytes_step = 32.0 * cnt["rankQueries"] + a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
-    search_s_per_step = search_ms / 1e3 / max(1, a.steps)
+    # ---- roofline of the search (stepping kernel + check-and-extend kernel: the two halves of one search pass) ----------------
+    # algorithmic bytes (extended by what check-and-extend reads since it became half of the pass): 32 B per rank query, 16 B per lookup
+    # (one long-table entry, or the four 4-byte entries of the 13-mer tables), 4 B per suffix-array entry, 16 B per 32-character compare window
+    # (8 B of packed text + 8 B of the read), packed read + length per read, 12 B per record
+    bytes_step = 32.0 * cnt["rankQueries"] + 16.0 * cnt["ltLookups"] + 4.0 * cnt["saReads"] + 16.0 * cnt["ceWindows"] + \
+        a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
+    search_s_per_step = (search_ms + ce_ms) / 1e3 / max(1, a.steps)
     achieved = bytes_step / search_s_per_step / 1e9 if search_s_per_step > 0 else 0.0
-    # HBM traffic of that kernel comes from a separate rocprofv3 --pmc FETCH_SIZE pass (it cannot be collected from inside this process);
+    # HBM traffic of the two kernels comes from a separate rocprofv3 --pmc FETCH_SIZE pass (it cannot be collected from inside this process);
     # the committed measurement is attached when it was taken on exactly this workload, per launch like `achieved`
     traffic = None
     try:
@@ -343,13 +346,21 @@ def main():
                     traffic = w["fetch_bytes_per_step"] / w["launches_per_step"]
     except (OSError, ValueError, KeyError):
         traffic = None
+    n_launch = max(1, launches // max(1, a.steps))
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_unit": "bytes per launch (FETCH_SIZE, profiles/pmc_traffic.json)", "algorithmic_bytes_per_launch": bytes_step / max(1, launches // max(1, a.steps)),
-            "kernel": "s3::searchKernelV2", "launches_per_step": launches // max(1, a.steps),
-            "kernel_ms_per_step": search_ms / max(1, a.steps),
+            "traffic_unit": "bytes per launch pair (FETCH_SIZE of both kernels, profiles/pmc_traffic.json)",
+            "algorithmic_bytes_per_launch": bytes_step / n_launch,
+            "kernel": "s3::searchKernelV2 + s3::ceKernel", "launches_per_step": n_launch,
+            "kernel_ms_per_step": (search_ms + ce_ms) / max(1, a.steps),
+            "stepping_kernel_ms_per_step": search_ms / max(1, a.steps),
             "check_extend_kernel_ms_per_step": ce_ms / max(1, a.steps), "device_ms_per_step": dev_ms / max(1, a.steps),
-            "sa_reads_per_step": cnt["saReads"], "ce_windows_per_step": cnt["ceWindows"],
-            "rank_queries_per_step": cnt["rankQueries"], "line_bytes_GBs": 64.0 * cnt["rankQueries"] / search_s_per_step / 1e9 if search_s_per_step else 0.0}
+            "sa_reads_per_step": cnt["saReads"], "ce_windows_per_step": cnt["ceWindows"], "lt_lookups_per_step": cnt["ltLookups"],
+            "rank_queries_per_step": cnt["rankQueries"]}
+    if traffic:
+        # the path is made of random accesses with 4-32 B payloads; the GPU moves 64 B per access at ~50 G accesses/s (tools/hbm_probe.py), so the
+        # rate of fetched 64-byte lines is what tells how busy the memory system is
+        lines = traffic * n_launch / 64.0 / search_s_per_step / 1e9
+        roof["random_line_rate"] = {"achieved_Glines_per_s": lines, "probe_Glines_per_s": 50.0, "frac": lines / 50.0}
 
     out = {"metric": "M reads/sec aligned (100 bp SE, GRCh38-scale synthetic genome)", "value": value, "unit": "M reads/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
