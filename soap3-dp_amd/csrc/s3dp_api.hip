@@ -344,6 +344,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         in.nStepsPacked = 0;
         for (int c = 0; c < m.nCases; c++) in.nStepsPacked |= (uint32_t)m.cs[c].nSteps << (3 * c);
     }
+    uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
     unsigned long long counterSnap[8];
     if (b->counting) {
         HIPCHK(hipMemcpyAsync(counterSnap, b->dCounters, 64, hipMemcpyDeviceToHost, b->stream));
@@ -374,9 +375,16 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                 if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2 + 1], b->stream));
             }
         }
+        // offsets of the items in the ordered array (the scan runs before the host looks at the flags: one synchronisation per pass for both answers)
+        HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, 4, b->stream));
+        {
+            size_t tb = b->tempBytes;
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dItemCounts, b->dItemOffsets, (int)(nItems + 1), b->stream));
+        }
         // a record that did not fit was dropped but counted: the ordering below must not run on such a pass.  Grow and search again.
         uint32_t flags = 0;
         HIPCHK(hipMemcpyAsync(&flags, b->dFlags, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipMemcpyAsync(&slots, b->dItemOffsets + nItems, 4, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
         if (!(flags & S3_FLAG_REC_OVERFLOW)) break;
         int rc = growRecords(b);
@@ -388,14 +396,8 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     }
     b->searchLaunches++;
     b->ceLaunches++;
-    HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, 4, b->stream));
-    size_t tb = b->tempBytes;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dItemCounts, b->dItemOffsets, (int)(nItems + 1), b->stream));
     {
         // sequence numbers include the rejected check-and-extend candidates: the ordered array can need more slots than there are records
-        uint32_t slots = 0;
-        HIPCHK(hipMemcpyAsync(&slots, b->dItemOffsets + nItems, 4, hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
         if (slots > b->ordCap) {
             size_t cap = b->ordCap;
             while (cap < slots) cap *= 2;
@@ -413,12 +415,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     launchMergeCount(m, b->stream);
     b->lastNumCases = (uint32_t)nCases;
-    if (b->counting) {
-        uint32_t t = 0;
-        HIPCHK(hipMemcpyAsync(&t, b->dItemOffsets + nItems, 4, hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
-        b->recordsTotal += t;
-    }
+    if (b->counting) b->recordsTotal += slots;
     HIPCHK(hipGetLastError());
     return S3_OK;
 }
