@@ -334,9 +334,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.wpqLoad = (b->longMode && b->wpq > 8) ? 8 : b->wpq;                // seeds have at most 128 bases
     in.models = b->ix->models[modelMm]; in.nCases = nCases; in.maxOut = maxOut; in.uniformLen = b->uniformLen;
     {
-        // S3DP_EARLY_CE=0: single-suffix ranges walk their exact lookup step to the end, as the CPU path does (same results, more rank queries)
-        static const bool early = [] { const char *e = getenv("S3DP_EARLY_CE"); return !(e && strcmp(e, "0") == 0); }();
-        in.earlyCe = early ? 1u : 0u;
+        // S3DP_EARLY_CE=0: ranges walk their exact lookup step to the end, as the CPU path does (same results, more rank queries); n: ranges of up to n
+        // suffixes leave it for check-and-extend at once (default 1)
+        static const uint32_t early = (uint32_t)envSize("S3DP_EARLY_CE", 1);                    // largest range (suffixes) handed over early
+        in.earlyCe = early;
     }
     {
         S3Model m;

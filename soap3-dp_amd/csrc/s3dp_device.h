@@ -53,7 +53,7 @@ struct SearchIn {
     uint32_t        maxOut;
     uint32_t        nStepsPacked;  // 3 bits per case: number of steps (depends on the mismatch budget only)
     uint32_t        uniformLen;  // != 0: every active read has this length (model kept in LDS by the v2 kernel)
-    uint32_t        earlyCe;     // 1: single-suffix ranges leave the exact lookup step for check-and-extend at once (s3dp_search_v2.hip)
+    uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_v2.hip)
 };
 
 #define S3_REC_TASK  (1u << 28)

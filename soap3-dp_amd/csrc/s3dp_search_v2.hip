@@ -212,17 +212,20 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     }
                 }
                 if constexpr (SPLIT) {
-                    // ONE suffix left inside the exact lookup step: walking the rest of the step can only keep it or lose it, and the next step hands it to
-                    // check-and-extend at its first position anyway.  Hand it over now; the task also verifies what is left of this step, inside the text.
-                    // (Not for ranges that may hold a padded table element: those are walked, as the CPU path walks them.)
-                    if (in.earlyCe && s == 0 && g.fl == g.fr && st.ceThr == 0 && nSteps > 1 && !padded) {
+                    // Few suffixes left inside the exact lookup step: walking the rest of the step can only keep or lose each of them -- in the same
+                    // relative order, exact steps map a range onto a range order-preservingly -- and with fewer than the next step's threshold the next step
+                    // hands them to check-and-extend at its first position anyway (in.earlyCe: the largest range handed over; a candidate costs three random
+                    // lines, a step one and it drops three candidates in four -- beyond ONE suffix walking is cheaper).  Hand them over now; the task also verifies what is left of this
+                    // step, inside the text.  (Not for ranges that may hold a padded table element: those are walked, as the CPU path walks them.)
+                    if (in.earlyCe && s == 0 && st.ceThr == 0 && nSteps > 1 && !padded) {
                         const S3Step nx = stepAt(1);
-                        if (nx.ceThr >= 1 && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
+                        const uint32_t lim = in.earlyCe < (uint32_t)nx.ceThr ? in.earlyCe : (uint32_t)nx.ceThr;     // nx.ceThr >= 0 for every step
+                        if ((g.fr - g.fl) < lim && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
                             if (pendMeta >> 31) { state = ST_RESUME; return; }
                             pendMeta = 0x80000000u | seq | S3_REC_TASK | S3_REC_EARLY;
                             pendA = g.fl;
-                            pendB = ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
-                            seq += 1u;
+                            pendB = (g.fr - g.fl) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+                            seq += g.fr - g.fl + 1u;
                             needPop = true;
                             continue;
                         }
