@@ -332,6 +332,8 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.queries = b->dQueries; in.readsT = b->dReadsT; in.readLengths = b->longMode ? b->dSeedLens : b->dLens; in.active = active; in.nActive = nActive;
     in.wpq = b->wpq;
     in.wpqLoad = (b->longMode && b->wpq > 8) ? 8 : b->wpq;                // seeds have at most 128 bases
+    in.wLds = b->uniformLen ? (b->uniformLen + 15u) / 16u : in.wpqLoad;   // LDS per wave decides how many waves a CU holds: no padding words there
+    if (in.wLds > in.wpqLoad) in.wLds = in.wpqLoad;
     in.models = b->ix->models[modelMm]; in.nCases = nCases; in.maxOut = maxOut; in.uniformLen = b->uniformLen;
     {
         // S3DP_EARLY_CE=0: ranges walk their exact lookup step to the end, as the CPU path does (same results, more rank queries); n: ranges of up to n

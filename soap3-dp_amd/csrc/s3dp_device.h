@@ -48,6 +48,7 @@ struct SearchIn {
     uint32_t        nActive;
     uint32_t        wpq;         // words per read in `queries` / `readsT` (stride)
     uint32_t        wpqLoad;     // words per read the search needs (covers the longest searched length; power of two, <= wpq)
+    uint32_t        wLds;        // of those, the words per orientation the v2 kernel keeps in LDS (ceil(longest searched length / 16), <= wpqLoad)
     const S3Model  *models;      // indexed by read length, for this phase's mismatch budget
     int             nCases;
     uint32_t        maxOut;

@@ -106,11 +106,12 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 {
     extern __shared__ __align__(16) unsigned char shmem[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t wpq = in.wpqLoad;                                        // words per orientation of the searched prefix
-    const uint32_t waveBytes = 4096u + 2u * wpq * 256u;
+    const uint32_t wpq = in.wpqLoad;                                        // words per orientation in readsT (stride, a power of two)
+    const uint32_t wl = in.wLds;                                            // words per orientation kept in LDS: what the longest searched length needs
+    const uint32_t waveBytes = 4096u + 2u * wl * 256u;
     unsigned char *wbase = shmem + S3_V2_MODEL_BYTES + wv * waveBytes;
     uint4 *stage = (uint4 *)wbase;                                          // [64 owners][4 x 16 B]
-    uint32_t *ro = (uint32_t *)(wbase + 4096u);                             // oriented read words, MSB first: ro[(strand * wpq + w) * 64 + lane]
+    uint32_t *ro = (uint32_t *)(wbase + 4096u);                             // oriented read words, MSB first: ro[(strand * wl + w) * 64 + lane]
     uint32_t *myStage32 = (uint32_t *)(stage + lane * 4u);
 
     if (UNIFORM) {
@@ -149,8 +150,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         if constexpr (UNIFORM) return ((const S3Model *)shmem)->cs[casIdx].st[k];      // LDS (address space known to the compiler)
         else return in.models[Li].cs[casIdx].st[k];                                    // global, L1/L2 resident
     };
-    auto oword = [&](uint32_t w) -> uint32_t { return w < wpq ? ro[(strand * wpq + w) * 64u + lane] : 0u; };
-    auto readChar = [&](int pos) -> uint32_t { return (ro[(strand * wpq + ((uint32_t)pos >> 4)) * 64u + lane] >> (30u - 2u * ((uint32_t)pos & 15u))) & 3u; };
+    auto oword = [&](uint32_t w) -> uint32_t { return w < wl ? ro[(strand * wl + w) * 64u + lane] : 0u; };
+    auto readChar = [&](int pos) -> uint32_t { return (ro[(strand * wl + ((uint32_t)pos >> 4)) * 64u + lane] >> (30u - 2u * ((uint32_t)pos & 15u))) & 3u; };
     auto readWindow = [&](int p0) -> uint32_t {               // 16 oriented characters from p0 >= 0, first one in the top bits
         const uint32_t w = (uint32_t)p0 >> 4, sh = ((uint32_t)p0 & 15u) * 2u;
         const uint32_t a = oword(w), b2 = oword(w + 1u);
@@ -472,16 +473,14 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         }
         if (state == ST_RESUME) { doSettle = true; needPop = false; }          // the completed frame that had to wait: emit it now, then pop
         if (state == ST_LOAD) {
-            uint32_t *dst = ro + (size_t)loadOff * 64u + lane;
-            const uint32_t left = 2u * wpq - loadOff;
-            dst[0] = p0.x;
-            if (left > 1) dst[64] = p0.y;
-            if (left > 2) dst[128] = p0.z;
-            if (left > 3) dst[192] = p0.w;
-            if (left > 4) dst[256] = p1.x;
-            if (left > 5) dst[320] = p1.y;
-            if (left > 6) dst[384] = p1.z;
-            if (left > 7) dst[448] = p1.w;
+            // word gi of the read's row in readsT (both orientations, wpq words each) -> LDS word (orientation * wl + w); words past wl are padding
+            const uint32_t vals[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t gi = loadOff + k;
+                const uint32_t so = gi >= wpq ? 1u : 0u, w = gi - so * wpq;
+                if (gi < 2u * wpq && w < wl) ro[(so * wl + w) * 64u + lane] = vals[k];
+            }
             loadOff += 8;
             if constexpr (!UNIFORM) Li = (int)saVal;
             if (loadOff >= 2u * wpq) state = ST_KEYS;
@@ -706,7 +705,7 @@ void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out
     if (in.nActive == 0) return;
     uint64_t blocks = ((uint64_t)in.nActive + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
-    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wpqLoad * 256u);
+    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wLds * 256u);
     if (lds > 48u * 1024u) {
         (void)hipFuncSetAttribute((const void *)searchKernelV2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)searchKernelV2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
