@@ -551,6 +551,28 @@ class DpAligner:
             free(x)
         return out, cigars, too_many
 
+    def new_default(self, batch, seed_batch, read_lengths, occ, max_hit, insert_low, insert_high, cutoffs, clip_left, clip_right):
+        """new default DP: occ = OCC_DTYPE hits of the aligned ends (grouped by pair, pairs ascending); their mates are seeded, both ends aligned by the DP.
+        Returns (results DEEP_RESULT_DTYPE, [(cigar1, cigar2)], first reads of the pairs, flags as in deep())"""
+        read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
+        occ = np.ascontiguousarray(occ, dtype=OCC_DTYPE)
+        f = lib().s3_dp_new_default
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        cut = (C.c_int * 2)(*cutoffs)
+        res, n, pool, fl, pf, npairs = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _chk(f(self.h, batch.h, seed_batch.h, read_lengths.ctypes.data, occ.ctypes.data, len(occ), max_hit, insert_low, insert_high, cut, clip_left, clip_right,
+               C.byref(res), C.byref(n), C.byref(pool), C.byref(fl), C.byref(pf), C.byref(npairs)))
+        out = (np.frombuffer(C.string_at(res, n.value * DEEP_RESULT_DTYPE.itemsize), dtype=DEEP_RESULT_DTYPE).copy() if n.value else np.zeros(0, DEEP_RESULT_DTYPE))
+        cigars = [(C.string_at(pool.value + int(r["cigarOffset_1"])).decode(), C.string_at(pool.value + int(r["cigarOffset_2"])).decode()) for r in out]
+        pairs = np.frombuffer(C.string_at(pf, npairs.value * 4), dtype=np.uint32).copy() if npairs.value else np.zeros(0, np.uint32)
+        flags = np.frombuffer(C.string_at(fl, npairs.value), dtype=np.uint8).copy() if npairs.value else np.zeros(0, np.uint8)
+        free = lib().s3_free
+        free.argtypes = [C.c_void_p]
+        for x in (res, pool, fl, pf):
+            free(x)
+        return out, cigars, pairs, flags
+
     def single_end(self, batch, read_lengths, candidates, cutoff, clip_left, clip_right):
         """DP of single reads at their seeding candidates (SEED_CAND_DTYPE); returns (results SINGLE_RESULT_DTYPE, cigars)"""
         read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)

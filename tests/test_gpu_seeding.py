@@ -236,3 +236,49 @@ def test_deep_dp_recovers_pairs_whose_ends_both_fail_the_bwt_stage(stage, max_hi
     dp.close()
     b.close()
     sb.close()
+
+
+def test_new_default_dp_pairs_given_hits_with_seeded_mates():
+    """s3_dp_new_default: the aligned end's hits are taken as positions (70 copies of a repeat), only the mate is seeded; the deep DP's pairing keeps the
+    copy next to the mate and both ends come back aligned by the DP with the mate's deletion in its CIGAR"""
+    import re
+    rng = np.random.default_rng(9)
+    n, L, copies = 120000, 100, 70
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    rep = rng.integers(0, 4, size=L, dtype=np.uint8)
+    starts = [800 + 1600 * k for k in range(copies)]
+    for st in starts:
+        codes[st:st + L] = rep
+    hi = builder.build_host_index(codes, device="cpu")
+    ix = s3dp.Index(hi)
+    reads, truth = [], []
+    for k in range(0, copies, 5):
+        st, m = starts[k], starts[k] + 310
+        c = int(rng.integers(30, 70))
+        mate = np.concatenate([codes[m:m + c], codes[m + c + 3:m + L + 3]])
+        reads.append(bytes(b"ACGT"[x] for x in rep))
+        reads.append(bytes(b"ACGT"[x] for x in COMP[mate[::-1]]))
+        truth.append((st, m))
+    q, lens, wpq = s3dp.pack_reads(reads, 100)
+    b = s3dp.Batch(ix, len(reads), wpq)
+    b.upload(q, lens)
+    sb = s3dp.Batch(ix, len(reads) * 16, 8)
+    occ = np.zeros(len(truth) * copies, dtype=s3dp.OCC_DTYPE)
+    for p in range(len(truth)):
+        for j, st in enumerate(starts):
+            o = occ[p * copies + j]
+            o["readID"], o["pos"], o["strand"], o["mismatchCount"] = 2 * p, st, 1, 0
+    dp = s3dp.DpAligner(4096, 104, 104 + 2 * 25 + 8, scheme=1)
+    res, cigars, pairs, flags = dp.new_default(b, sb, lens, occ, 100, 100, 500, (30, 30), 49, 49)
+    assert list(pairs) == [2 * p for p in range(len(truth))]
+    assert (flags & 2).all()                                  # every pair had candidates
+    ok = 0
+    for p, (st, m) in enumerate(truth):
+        mine = [(r, cg) for r, cg in zip(res, cigars) if int(r["readID"]) == 2 * p]
+        assert mine, p
+        best = max(mine, key=lambda x: int(x[0]["score_1"]) + int(x[0]["score_2"]))
+        r, (c1, c2) = best
+        ok += bool(int(r["algnmt_1"]) == st and abs(int(r["algnmt_2"]) - m) <= 3 and r["strand_1"] == 1 and r["strand_2"] == 2 and
+                   re.sub(r"\d+", "", c1) == "M" and re.sub(r"\d+", "", c2) == "MDM")
+    assert ok == len(truth), (ok, len(truth))
+    dp.close(); b.close(); sb.close(); ix.close()
