@@ -8,7 +8,7 @@ set -euo pipefail
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 REF=$ROOT/oracle/_ref
 INI=$ROOT/soap3-dp_amd/host/soap3-dp.ini
-OUT=$ROOT/tests/golden
+OUT=${S3_FIXTURE_OUT:-$ROOT/tests/golden}
 W=$(mktemp -d)
 trap 'rm -rf $W' EXIT
 
