@@ -181,8 +181,17 @@ namespace {
 struct Piece { size_t beg = 0, end = 0; uint32_t first = 0, count = 0; };
 
 // one record starting at p (which points at '>' or '@'); returns the position after it.  Emits through `rec` when asked to.
+// the whole read file in memory: a malloc'ed buffer when the file is plain (no value-initialisation: the slices are filled by the reading threads, which
+// also take the page faults in parallel), a string when it had to be inflated
+struct TextView {
+    const char *p = nullptr;
+    size_t n = 0;
+    char operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+};
+
 template <class F>
-size_t parseRecord(const std::string &all, size_t p, bool fq, uint32_t maxReadLength, int maxLenReadName, const unsigned char *charMap, int qualityConstant, F &&rec,
+size_t parseRecord(const TextView &all, size_t p, bool fq, uint32_t maxReadLength, int maxLenReadName, const unsigned char *charMap, int qualityConstant, F &&rec,
                    bool fill, std::string &name, std::vector<uint8_t> &seq, std::string &q, bool &bad)
 {
     const size_t N = all.size();
@@ -236,7 +245,9 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
     uint32_t w = 1;
     while (w < maxReadLength) w *= 2;
     rs.wpq = w / 16 ? w / 16 : 1;
-    std::string all;
+    std::string inflated;
+    std::unique_ptr<char, void (*)(void *)> plain(nullptr, free);
+    TextView all;
     if (gzdirect(gz)) {
         // not compressed: read the file itself, one slice per thread
         gzclose(gz);
@@ -245,14 +256,17 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
         fseek(f, 0, SEEK_END);
         const long long size = ftell(f);
         fclose(f);
-        all.resize((size_t)size);
+        plain.reset((char *)malloc((size_t)size + 1));
+        if (!plain) { err = "out of memory reading " + file; return false; }
+        char *buf0 = plain.get();
+        all.p = buf0; all.n = (size_t)size;
         const int Tr = hostThreads() > 16 ? 16 : hostThreads();
         std::vector<std::thread> rd;
         std::atomic<bool> bad(false);
         for (int t = 0; t < Tr; t++) rd.emplace_back([&, t] {
             const size_t lo = (size_t)size / (size_t)Tr * (size_t)t, hi = t + 1 == Tr ? (size_t)size : (size_t)size / (size_t)Tr * (size_t)(t + 1);
             FILE *g = fopen(file.c_str(), "rb");
-            if (!g || fseek(g, (long)lo, SEEK_SET) != 0 || fread(&all[lo], 1, hi - lo, g) != hi - lo) bad = true;
+            if (!g || fseek(g, (long)lo, SEEK_SET) != 0 || fread(buf0 + lo, 1, hi - lo, g) != hi - lo) bad = true;
             if (g) fclose(g);
         });
         for (auto &x : rd) x.join();
@@ -260,8 +274,9 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
     } else {
         std::vector<char> buf(1 << 24);
         int got;
-        while ((got = gzread(gz, buf.data(), (unsigned)buf.size())) > 0) all.append(buf.data(), (size_t)got);
+        while ((got = gzread(gz, buf.data(), (unsigned)buf.size())) > 0) inflated.append(buf.data(), (size_t)got);
         gzclose(gz);
+        all.p = inflated.data(); all.n = inflated.size();
     }
     const size_t N = all.size();
     size_t p0 = 0;
@@ -309,11 +324,25 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
     for (auto &P : pieces) { P.first = n; n += P.count; }
     rs.n = n;
     const size_t roundUp = ((size_t)rs.n + 31) / 32 * 32;
-    rs.queries.assign(roundUp * rs.wpq, 0);
+    rs.queries.resize(roundUp * rs.wpq);
     rs.lengths.assign(rs.n, 0);
     rs.names.assign(rs.n, std::string());
-    rs.codes.assign((size_t)rs.n * maxReadLength, 0);
-    rs.quals.assign((size_t)rs.n * maxReadLength, 0);
+    rs.codes.resize((size_t)rs.n * maxReadLength);
+    rs.quals.resize((size_t)rs.n * maxReadLength);
+    {
+        // zeros are content (bits are OR-ed into the packed words, bytes behind a read's end stay 0): written by all threads, slice by slice
+        auto zero = [&](void *base, size_t bytes) {
+            std::vector<std::thread> z;
+            for (int t = 0; t < T; t++) z.emplace_back([=] {
+                const size_t lo = bytes / (size_t)T * (size_t)t, hi = t + 1 == T ? bytes : bytes / (size_t)T * (size_t)(t + 1);
+                memset((char *)base + lo, 0, hi - lo);
+            });
+            for (auto &x : z) x.join();
+        };
+        zero(rs.queries.data(), rs.queries.size() * 4);
+        zero(rs.codes.data(), rs.codes.size());
+        zero(rs.quals.data(), rs.quals.size());
+    }
     // fill pass; 32 consecutive reads share packed words (32-interleaved layout), so a piece boundary inside a group of 32 is written by
     // two threads -- to different words (word index = group base + r % 32 + 32 w), never the same one
     for (int t = 0; t < T; t++) th.emplace_back([&, t] {
@@ -361,11 +390,13 @@ bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t 
     rs = ReadSet();
     rs.maxReadLength = maxReadLength; rs.wpq = a.wpq; rs.isFastq = a.isFastq; rs.n = 2 * np;
     const size_t roundUp = ((size_t)rs.n + 31) / 32 * 32;
-    rs.queries.assign(roundUp * rs.wpq, 0);
+    rs.queries.resize(roundUp * rs.wpq);                                  // every read's words, code and quality rows are copied in full below
     rs.lengths.assign(rs.n, 0);
     rs.names.resize(rs.n);
-    rs.codes.assign((size_t)rs.n * maxReadLength, 0);
-    rs.quals.assign((size_t)rs.n * maxReadLength, 0);
+    rs.codes.resize((size_t)rs.n * maxReadLength);
+    rs.quals.resize((size_t)rs.n * maxReadLength);
+    for (size_t r = rs.n; r < roundUp; r++)                                 // the unused reads of the last group of 32
+        for (uint32_t w = 0; w < rs.wpq; w++) rs.queries[(r / 32) * 32 * rs.wpq + r % 32 + (size_t)w * 32] = 0;
     const int T = hostThreads();
     std::vector<std::thread> th;
     const uint32_t per = ((rs.n + (uint32_t)T - 1) / (uint32_t)T + 31u) / 32u * 32u;

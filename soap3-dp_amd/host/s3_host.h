@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <string>
 #include <vector>
+#include <memory>
+#include <utility>
 #include "../../include/s3dp.h"
 
 namespace s3host {
@@ -34,12 +36,23 @@ bool loadIndex(const std::string &prefix, HostIndex &ix, std::string &err);
 int hostThreads();                                       // S3DP_HOST_THREADS or the hardware concurrency (1..256)
 void buildLookupTable(const std::vector<uint32_t> &pacWords, uint32_t n, bool reversed, std::vector<uint32_t> &table);
 
+// vector whose resize() leaves new elements uninitialised: the big per-read arrays are sized once and then filled (and, where zeros are part of the
+// content, zeroed) by all host threads, which also spreads the page faults
+template <class T> struct DefaultInit : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInit<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using RawVec = std::vector<T, DefaultInit<T>>;
+
 struct ReadSet {
-    std::vector<uint32_t> queries;                       // reference packed layout
+    RawVec<uint32_t> queries;                            // reference packed layout
     std::vector<uint32_t> lengths;
     std::vector<std::string> names;
-    std::vector<uint8_t> codes;                          // n x maxReadLength, 2-bit codes
-    std::vector<char> quals;                             // n x maxReadLength, Phred (char - 33 / 64)
+    RawVec<uint8_t> codes;                               // n x maxReadLength, 2-bit codes
+    RawVec<char> quals;                                  // n x maxReadLength, Phred (char - 33 / 64)
     uint32_t n = 0, wpq = 0, maxReadLength = 0;
     bool isFastq = false;
 };
