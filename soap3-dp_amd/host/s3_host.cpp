@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 
 namespace s3host {
 
@@ -231,7 +234,11 @@ size_t parseRecord(const TextView &all, size_t p, bool fq, uint32_t maxReadLengt
 }
 }  // namespace
 
-bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err)
+// Parses one read file with all host threads (count pass, then fill pass).  Read k of the file becomes read stride * k + offset of `rs`; `allocate` is
+// called between the passes with the number of reads found (and whether the file is FASTQ, and the packed words per read): it sizes and zeroes `rs` and
+// returns how many reads of this file are to be stored (0xFFFFFFFF: failure).
+static bool loadInto(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err, uint32_t stride,
+                     uint32_t offset, const std::function<uint32_t(uint32_t, bool, uint32_t)> &allocate)
 {
     gzFile gz = gzopen(file.c_str(), "r");
     if (!gz) { err = "cannot open " + file; return false; }
@@ -241,10 +248,9 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
     const char *acgt = "ACGT";
     for (int i = 0; i < 4; i++) { charMap[(int)acgt[i]] = (unsigned char)i; charMap[(int)acgt[i] - 'A' + 'a'] = (unsigned char)i; }
     charMap['U'] = charMap['T']; charMap['N'] = charMap['G']; charMap['u'] = charMap['t']; charMap['n'] = charMap['g'];
-    rs.maxReadLength = maxReadLength;
     uint32_t w = 1;
     while (w < maxReadLength) w *= 2;
-    rs.wpq = w / 16 ? w / 16 : 1;
+    const uint32_t wpq = w / 16 ? w / 16 : 1;
     std::string inflated;
     std::unique_ptr<char, void (*)(void *)> plain(nullptr, free);
     TextView all;
@@ -282,7 +288,6 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
     size_t p0 = 0;
     while (p0 < N && all[p0] != '>' && all[p0] != '@') p0++;
     const bool fq = p0 < N && all[p0] == '@';
-    rs.isFastq = fq;
     // a record starts at a line that begins with the marker; for FASTQ the line after next must begin with '+' (a quality line may begin with '@')
     auto isStart = [&](size_t p) -> bool {
         if (p >= N || all[p] != (fq ? '@' : '>')) return false;
@@ -322,27 +327,8 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
     if (anyBad) { err = "a read of length 0 in the read file"; return false; }
     uint32_t n = 0;
     for (auto &P : pieces) { P.first = n; n += P.count; }
-    rs.n = n;
-    const size_t roundUp = ((size_t)rs.n + 31) / 32 * 32;
-    rs.queries.resize(roundUp * rs.wpq);
-    rs.lengths.assign(rs.n, 0);
-    rs.names.assign(rs.n, std::string());
-    rs.codes.resize((size_t)rs.n * maxReadLength);
-    rs.quals.resize((size_t)rs.n * maxReadLength);
-    {
-        // zeros are content (bits are OR-ed into the packed words, bytes behind a read's end stay 0): written by all threads, slice by slice
-        auto zero = [&](void *base, size_t bytes) {
-            std::vector<std::thread> z;
-            for (int t = 0; t < T; t++) z.emplace_back([=] {
-                const size_t lo = bytes / (size_t)T * (size_t)t, hi = t + 1 == T ? bytes : bytes / (size_t)T * (size_t)(t + 1);
-                memset((char *)base + lo, 0, hi - lo);
-            });
-            for (auto &x : z) x.join();
-        };
-        zero(rs.queries.data(), rs.queries.size() * 4);
-        zero(rs.codes.data(), rs.codes.size());
-        zero(rs.quals.data(), rs.quals.size());
-    }
+    const uint32_t limit = allocate(n, fq, wpq);
+    if (limit == 0xFFFFFFFFu) { err = "out of memory for the reads of " + file; return false; }
     // fill pass; 32 consecutive reads share packed words (32-interleaved layout), so a piece boundary inside a group of 32 is written by
     // two threads -- to different words (word index = group base + r % 32 + 32 w), never the same one
     for (int t = 0; t < T; t++) th.emplace_back([&, t] {
@@ -354,15 +340,18 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
             while (p < P.end && all[p] != '>' && all[p] != '@') p++;
             if (p >= P.end) break;
             p = parseRecord(all, p, fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] {
-                rs.names[r] = name;
-                rs.lengths[r] = (uint32_t)seq.size();
-                uint32_t *dst = rs.queries.data() + (size_t)(r / 32) * 32 * rs.wpq + r % 32;
-                uint8_t *cd = &rs.codes[(size_t)r * maxReadLength];
-                char *qd = &rs.quals[(size_t)r * maxReadLength];
-                for (size_t i = 0; i < seq.size(); i++) {
-                    dst[(i / 16) * 32] |= (uint32_t)seq[i] << (2 * (i % 16));
-                    cd[i] = seq[i];
-                    qd[i] = q[i];
+                if (r < limit) {
+                    const size_t rd = (size_t)stride * r + offset;
+                    rs.names[rd] = name;
+                    rs.lengths[rd] = (uint32_t)seq.size();
+                    uint32_t *dst = rs.queries.data() + (rd / 32) * 32 * wpq + rd % 32;
+                    uint8_t *cd = &rs.codes[rd * maxReadLength];
+                    char *qd = &rs.quals[rd * maxReadLength];
+                    for (size_t i = 0; i < seq.size(); i++) {
+                        dst[(i / 16) * 32] |= (uint32_t)seq[i] << (2 * (i % 16));
+                        cd[i] = seq[i];
+                        qd[i] = q[i];
+                    }
                 }
                 r++;
             }, true, name, seq, q, bad);
@@ -372,49 +361,75 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
     return true;
 }
 
+// sizes the arrays of `rs` for n reads and writes the zeros that are content (bits are OR-ed into the packed words, bytes behind a read's end stay 0),
+// slice by slice with all threads
+static void allocateReads(ReadSet &rs, uint32_t n, bool fq, uint32_t wpq, uint32_t maxReadLength)
+{
+    rs.maxReadLength = maxReadLength; rs.wpq = wpq; rs.isFastq = fq; rs.n = n;
+    const size_t roundUp = ((size_t)n + 31) / 32 * 32;
+    rs.queries.resize(roundUp * wpq);
+    rs.lengths.assign(n, 0);
+    rs.names.assign(n, std::string());
+    rs.codes.resize((size_t)n * maxReadLength);
+    rs.quals.resize((size_t)n * maxReadLength);
+    const int T = hostThreads();
+    auto zero = [&](void *base, size_t bytes) {
+        std::vector<std::thread> z;
+        for (int t = 0; t < T; t++) z.emplace_back([=] {
+            const size_t lo = bytes / (size_t)T * (size_t)t, hi = t + 1 == T ? bytes : bytes / (size_t)T * (size_t)(t + 1);
+            memset((char *)base + lo, 0, hi - lo);
+        });
+        for (auto &x : z) x.join();
+    };
+    zero(rs.queries.data(), rs.queries.size() * 4);
+    zero(rs.codes.data(), rs.codes.size());
+    zero(rs.quals.data(), rs.quals.size());
+}
+
+bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err)
+{
+    rs = ReadSet();
+    return loadInto(file, maxReadLength, qualityConstant, maxLenReadName, rs, err, 1, 0, [&](uint32_t n, bool fq, uint32_t wpq) -> uint32_t {
+        allocateReads(rs, n, fq, wpq, maxReadLength);
+        return n;
+    });
+}
+
 bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs,
                    std::string &err)
 {
-    ReadSet a, b;
-    {
-        // both files at once (each load is parallel inside already; the file reads and the serial parts overlap)
-        std::string err2;
-        bool ok2 = true;
-        std::thread second([&] { ok2 = loadSingleReads(file2, maxReadLength, qualityConstant, maxLenReadName, b, err2); });
-        const bool ok1 = loadSingleReads(file1, maxReadLength, qualityConstant, maxLenReadName, a, err);
-        second.join();
-        if (!ok1) return false;
-        if (!ok2) { err = err2; return false; }
-    }
-    const uint32_t np = a.n < b.n ? a.n : b.n;                          // the reference stops at the shorter file
+    // both files at once, each parsed straight into its half of the interleaved set: the loader that finishes counting second sizes the arrays for
+    // 2 x min(n1, n2) reads (the reference stops at the shorter file)
     rs = ReadSet();
-    rs.maxReadLength = maxReadLength; rs.wpq = a.wpq; rs.isFastq = a.isFastq; rs.n = 2 * np;
-    const size_t roundUp = ((size_t)rs.n + 31) / 32 * 32;
-    rs.queries.resize(roundUp * rs.wpq);                                  // every read's words, code and quality rows are copied in full below
-    rs.lengths.assign(rs.n, 0);
-    rs.names.resize(rs.n);
-    rs.codes.resize((size_t)rs.n * maxReadLength);
-    rs.quals.resize((size_t)rs.n * maxReadLength);
-    for (size_t r = rs.n; r < roundUp; r++)                                 // the unused reads of the last group of 32
-        for (uint32_t w = 0; w < rs.wpq; w++) rs.queries[(r / 32) * 32 * rs.wpq + r % 32 + (size_t)w * 32] = 0;
-    const int T = hostThreads();
-    std::vector<std::thread> th;
-    const uint32_t per = ((rs.n + (uint32_t)T - 1) / (uint32_t)T + 31u) / 32u * 32u;
-    for (int t = 0; t < T; t++) th.emplace_back([&, t] {
-    const uint32_t lo = (uint32_t)t * per, hi = lo + per < rs.n ? lo + per : rs.n;
-    for (uint32_t r = lo; r < hi; r++) {
-        const ReadSet &src = (r & 1) ? b : a;
-        const uint32_t k = r >> 1;
-        rs.lengths[r] = src.lengths[k];
-        rs.names[r] = src.names[k];
-        memcpy(&rs.codes[(size_t)r * maxReadLength], &src.codes[(size_t)k * maxReadLength], maxReadLength);
-        memcpy(&rs.quals[(size_t)r * maxReadLength], &src.quals[(size_t)k * maxReadLength], maxReadLength);
-        uint32_t *dst = rs.queries.data() + (size_t)(r / 32) * 32 * rs.wpq + r % 32;
-        const uint32_t *sq = src.queries.data() + (size_t)(k / 32) * 32 * src.wpq + k % 32;
-        for (uint32_t w = 0; w < rs.wpq; w++) dst[(size_t)w * 32] = sq[(size_t)w * 32];
-    }
-    });
-    for (auto &x : th) x.join();
+    std::mutex mu;
+    std::condition_variable cv;
+    int counted = 0;
+    uint32_t n[2] = {0, 0}, np = 0;
+    bool ready = false, fq1 = false;
+    auto side = [&](int which) {
+        return [&, which](uint32_t nThis, bool fq, uint32_t wpq) -> uint32_t {
+            std::unique_lock<std::mutex> lk(mu);
+            n[which] = nThis;
+            if (which == 0) fq1 = fq;
+            if (++counted == 2) {
+                np = n[0] < n[1] ? n[0] : n[1];
+                lk.unlock();
+                allocateReads(rs, 2 * np, fq1, wpq, maxReadLength);
+                lk.lock();
+                ready = true;
+                cv.notify_all();
+            } else cv.wait(lk, [&] { return ready; });
+            return np;
+        };
+    };
+    std::string err2;
+    bool ok2 = true;
+    std::thread second([&] { ok2 = loadInto(file2, maxReadLength, qualityConstant, maxLenReadName, rs, err2, 2, 1, side(1)); if (!ok2) { std::lock_guard<std::mutex> g(mu); if (!ready) { counted = 2; ready = true; np = 0; cv.notify_all(); } } });
+    const bool ok1 = loadInto(file1, maxReadLength, qualityConstant, maxLenReadName, rs, err, 2, 0, side(0));
+    if (!ok1) { std::lock_guard<std::mutex> g(mu); if (!ready) { counted = 2; ready = true; np = 0; cv.notify_all(); } }
+    second.join();
+    if (!ok1) return false;
+    if (!ok2) { err = err2; return false; }
     return true;
 }
 
