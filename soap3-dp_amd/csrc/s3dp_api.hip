@@ -340,6 +340,8 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         // suffixes leave it for check-and-extend at once (default 1)
         static const uint32_t early = (uint32_t)envSize("S3DP_EARLY_CE", 1);                    // largest range (suffixes) handed over early
         in.earlyCe = early;
+        static const uint32_t earlyMin = (uint32_t)envSize("S3DP_EARLY_MIN", 0);
+        in.earlyMinI = earlyMin;
     }
     {
         S3Model m;

@@ -54,6 +54,8 @@ struct SearchIn {
     uint32_t        maxOut;
     uint32_t        nStepsPacked;  // 3 bits per case: number of steps (depends on the mismatch budget only)
     uint32_t        uniformLen;  // != 0: every active read has this length (model kept in LDS by the v2 kernel)
+    uint32_t        earlyMinI;   // ... but only once this many characters are matched: a chance match of the lookup characters costs a step (one line) to drop,
+                                 // a candidate three lines to verify
     uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_v2.hip)
 };
 

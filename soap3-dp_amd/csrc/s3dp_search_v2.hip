@@ -218,7 +218,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     // hands them to check-and-extend at its first position anyway (in.earlyCe: the largest range handed over; a candidate costs three random
                     // lines, a step one and it drops three candidates in four -- beyond ONE suffix walking is cheaper).  Hand them over now; the task also verifies what is left of this
                     // step, inside the text.  (Not for ranges that may hold a padded table element: those are walked, as the CPU path walks them.)
-                    if (in.earlyCe && s == 0 && st.ceThr == 0 && nSteps > 1 && !padded) {
+                    if (in.earlyCe && s == 0 && i >= (int)in.earlyMinI && st.ceThr == 0 && nSteps > 1 && !padded) {
                         const S3Step nx = stepAt(1);
                         const uint32_t lim = in.earlyCe < (uint32_t)nx.ceThr ? in.earlyCe : (uint32_t)nx.ceThr;     // nx.ceThr >= 0 for every step
                         if ((g.fr - g.fl) < lim && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
