@@ -369,7 +369,8 @@ def main():
                                   "0-4 substitutions (55/25/12/5/3 %), <=4 mismatch all-best ladder (-s 4 -h 2), DP off; "
                                   "BASELINE.json configs[1] with GRCh38 replaced by a synthetic genome of the same scale",
                       "genome_bp": a.genome_bp, "reads_per_gpu": a.reads, "read_len": a.read_len, "max_mismatch": a.mismatch,
-                      "max_output_per_read": a.max_out, "repeat_frac": a.repeat_frac, "parallelism": "reads sharded x%d, index replicated" % world},
+                      "max_output_per_read": a.max_out, "repeat_frac": a.repeat_frac, "parallelism": "reads sharded x%d, index replicated" % world,
+                      "lookup_chars": int(s3dp.lib().s3_index_lookup_chars(ix.h))},
            "roofline": roof,
            "aligned_reads": tot["readsAligned"], "occurrences": tot["alignments"],
            "rank_queries_per_read": cnt["rankQueries"] / a.reads}
