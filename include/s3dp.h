@@ -79,10 +79,10 @@ typedef struct {
 
 typedef struct {
     uint64_t rankQueries;      /* all-symbol rank queries issued (the roofline unit) */
-    uint64_t ltLookups;
-    uint64_t saReads;
-    uint64_t ceWindows;
-    uint64_t records;
+    uint64_t ltLookups;        /* lookup-table entries read: one per item from the long tables, two / four 4-byte entries from the 13-mer tables */
+    uint64_t saReads;          /* suffix-array entries read by check-and-extend (= candidates verified) */
+    uint64_t ceWindows;        /* 32-character compare windows of check-and-extend */
+    uint64_t records;          /* sequence numbers given out: SA-range records + check-and-extend candidates (accepted or not) */
 } s3_counters;
 
 /* Batch object: device-resident packed reads + all work buffers (persistent, no per-call allocation).
