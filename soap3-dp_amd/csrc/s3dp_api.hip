@@ -339,7 +339,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         // S3DP_EARLY_CE=0: ranges walk their exact lookup step to the end, as the CPU path does (same results, more rank queries); n: ranges of up to n
         // suffixes leave it for check-and-extend at once (default 1)
         static const uint32_t early = (uint32_t)envSize("S3DP_EARLY_CE", 1);                    // largest range (suffixes) handed over early
-        in.earlyCe = early;
+        in.earlyCe = b->ix->d.ltSize <= 13 ? early : 0u;                       // the list of padded keys (DevIndex::padBack / padBi) holds twelve per table
         static const uint32_t earlyMin = (uint32_t)envSize("S3DP_EARLY_MIN", 0);
         in.earlyMinI = earlyMin;
     }
