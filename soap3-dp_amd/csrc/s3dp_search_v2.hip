@@ -221,7 +221,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     if (in.earlyCe && s == 0 && i >= (int)in.earlyMinI && st.ceThr == 0 && nSteps > 1 && !padded) {
                         const S3Step nx = stepAt(1);
                         const uint32_t lim = in.earlyCe < (uint32_t)nx.ceThr ? in.earlyCe : (uint32_t)nx.ceThr;     // nx.ceThr >= 0 for every step
-                        if ((g.fr - g.fl) < lim && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
+                        const int nxLenEff = nx.minErr > 1 ? nx.len - (nx.minErr - 1) : nx.len;                    // the next step must have a first position to stand on
+                        if ((g.fr - g.fl) < lim && nxLenEff > 0 && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
                             if (pendMeta >> 31) { state = ST_RESUME; return; }
                             pendMeta = 0x80000000u | seq | S3_REC_TASK | S3_REC_EARLY;
                             pendA = g.fl;
