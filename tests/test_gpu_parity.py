@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import s3dp
+from s3dp import builder
 import s3o
 from conftest import GOLDEN, golden_reads, hits_to_lines, host_index, read_gz_lines
 
@@ -245,3 +246,54 @@ def test_pair_small_caps():
             assert len(got[k]) == len(want[k]) and (got[k] == want[k]).all(), (max_hits, pe_max, k)
     oix.close()
     b.close()
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_text_ends_and_padded_lookup_keys_stress(seed):
+    """A tiny genome searched with reads that hug or overhang its ends with runs of A -- the 13-mers the lookup tables count for the last / first text
+    positions (padded with A), the in-text rule of the early check-and-extend hand-over, wrap-around of positions before the text start -- and with reads
+    from its repeats.  Every record, order included, must equal the oracle's for every mismatch budget and for the all-best ladder."""
+    rng = np.random.default_rng(seed)
+    n, L = 4000, 100
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    codes[700:900] = codes[100:300]                          # a repeat
+    codes[n - 9:] = 0                                        # the text ends with A's: padded and real 13-mers coincide
+    codes[:5] = 0
+    hi = builder.build_host_index(codes, device="cpu")
+    ix = s3dp.Index(hi)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+    reads = []
+    for k in range(600):
+        kind = k % 6
+        if kind == 0:                                         # inside, near the end
+            st = int(rng.integers(n - 140, n - L + 1)); seg = codes[st:st + L].copy()
+        elif kind == 1:                                       # overhangs the end: the rest is A
+            st = int(rng.integers(n - 95, n - 5)); seg = np.concatenate([codes[st:], np.zeros(L - (n - st), np.uint8)])
+        elif kind == 2:                                       # overhangs the start
+            ov = int(rng.integers(1, 60)); seg = np.concatenate([np.zeros(ov, np.uint8), codes[:L - ov]])
+        elif kind == 3:                                       # near the start
+            st = int(rng.integers(0, 40)); seg = codes[st:st + L].copy()
+        elif kind == 4:                                       # from the repeat
+            st = int(rng.integers(100, 200)); seg = codes[st:st + L].copy()
+        else:
+            st = int(rng.integers(0, n - L)); seg = codes[st:st + L].copy()
+        for q in rng.choice(L, size=int(rng.integers(0, 4)), replace=False):
+            seg[q] = (seg[q] + 1 + rng.integers(0, 3)) % 4
+        if rng.integers(0, 2):
+            seg = comp[seg[::-1]]
+        reads.append(bytes(b"ACGT"[c] for c in seg))
+    q, lens, wpq = s3dp.pack_reads(reads, L)
+    b = s3dp.Batch(ix, len(reads), wpq)
+    b.upload(q, lens)
+    oix = s3o.Index(host_index=hi)
+    for mm in range(5):
+        b.search(mm, 1000)
+        hits, offs, tot, werr = b.fetch_hits()
+        ohits, ooffs, otot, owerr, st_ = oix.search(q, lens, wpq, mm, max_out=1000)
+        assert (offs == ooffs).all() and hits.tobytes() == ohits.tobytes(), mm
+        assert (tot == otot).all() and (werr == owerr).all()
+    b.align_single_allbest(4, 1000)
+    phase, we, off2, pos, strand, mis = b.fetch_alignments()
+    oph, owe, ooff, opos, ostr, omis, _ = oix.align_single_allbest(q, lens, wpq, 4, 1000)
+    assert (phase == oph).all() and (off2 == ooff).all() and (pos[:int(ooff[-1])] == opos).all() and (mis[:int(ooff[-1])] == omis).all()
+    oix.close(); b.close(); ix.close()
