@@ -109,6 +109,17 @@ mkp g4 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 8 --genome-seed 9" "
   for f in bwt rev.bwt fmv.gpu rev.fmv.gpu sa pac ann amb tra; do cp g5.fa.index.$f $OUT/g5/index.$f; done
   cp g5_1.fq $OUT/g5/reads_1.fq; cp g5_2.fq $OUT/g5/reads_2.fq; gzip -9n < g5dp.routing > $OUT/g5/pe_routing.txt.gz
 )
+# g6: the ends of the text -- reads that hug / overhang them with runs of A (padded lookup keys), a repeat, a sequence boundary
+mkdir -p $OUT/g6
+( cd $W && python $ROOT/tools/simulate_edge_case.py --fasta g6.fa --fastq g6.fq
+  $REF/soap3-dp-builder g6.fa > /dev/null; $REF/BGS-Build g6.fa.index > /dev/null
+  for mm in 0 1 2 3 4; do $REF/ref_harness search $INI g6.fa.index g6.fq 100 $mm search_mm$mm.txt > /dev/null 2>&1; gzip -9n < search_mm$mm.txt > $OUT/g6/search_mm$mm.txt.gz; done
+  $REF/ref_harness sam $INI single g6.fa.index g6.fq -L 100 -s 4 -b 2 -o sam_s4 > /dev/null 2>&1
+  $REF/ref_harness sam $INI single g6.fa.index g6.fq -L 100 -s 2 -h 1 -p -b 2 -o sam_h1_s2 > /dev/null 2>&1
+  for f in bwt rev.bwt fmv.gpu rev.fmv.gpu sa pac ann amb tra; do cp g6.fa.index.$f $OUT/g6/index.$f; done
+  cp g6.fq $OUT/g6/reads.fq
+  grep -v '^@PG' sam_s4.gout.1 | gzip -9n > $OUT/g6/sam_s4.sam.gz; grep -v '^@PG' sam_h1_s2.gout.1 | gzip -9n > $OUT/g6/sam_h1_s2p.sam.gz
+)
 # output stage of the single-read DP: reads + synthetic DP result vectors -> the reference's own SAM records
 mkdir -p $OUT/dp1
 ( cd $W && python $ROOT/tools/simulate.py --genome-len 90000 --chroms 3 --n-runs 4 --genome-seed 21 --fasta dp1.fa

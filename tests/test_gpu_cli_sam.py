@@ -51,6 +51,21 @@ def test_cli_sam_matches_reference_cpu_path(tmp_path, name, maxlen, variant, opt
     assert os.path.exists(tmp_path / "out.done")
 
 
+@pytest.mark.parametrize("variant,opts", [("s4", ["-s", "4"]), ("h1_s2p", ["-s", "2", "-h", "1", "-p"])])
+def test_cli_sam_at_the_ends_of_the_text(tmp_path, variant, opts):
+    """fixture g6: reads that hug or overhang the ends of the text and a sequence boundary (boundary trimming, soft clips, padded lookup keys)"""
+    name = "g6"
+    shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), tmp_path / "g6.fq")
+    out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), "g6.fq", "-L", "100"] + opts + ["-b", "2", "-o", "out"], cwd=tmp_path, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    mine_h, mine = sam_records(open(tmp_path / "out.gout.1").read())
+    ref_h, ref = sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_%s.sam.gz" % variant), "rt").read())
+    assert mine_h == ref_h and set(mine) == set(ref)
+    bad = [(k, ref[k], mine[k]) for k in ref if ref[k] != mine[k]]
+    assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][1], bad[0][2])
+
+
 # long-read mode: -L 200, reads of 121..200 bases
 LONG_VARIANTS = [("s3", ["-s", "3"]), ("s1", ["-s", "1", "-p"]), ("h1_s2", ["-s", "2", "-h", "1"]), ("h3_s2", ["-s", "2", "-h", "3"]),
                  ("h4_s3", ["-s", "3", "-h", "4"])]

@@ -20,7 +20,7 @@ def dev_index(name):
     return _DEV[name]
 
 
-@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
+@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120), ("g6", 100)])     # g6: the ends of the text, padded lookup keys (tools/simulate_edge_case.py)
 @pytest.mark.parametrize("mm", [0, 1, 2, 3, 4])
 def test_search_bit_exact_vs_reference_dump_and_oracle(name, maxlen, mm):
     reads = golden_reads(name)

@@ -21,7 +21,7 @@ def test_model_tables_all_lengths():
     assert ref == mine
 
 
-@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
+@pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120), ("g6", 100)])
 @pytest.mark.parametrize("mm", [0, 1, 2, 3, 4])
 def test_search_matches_reference(name, maxlen, mm):
     ix = s3o.Index(host_index=host_index(name))
