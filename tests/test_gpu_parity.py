@@ -45,7 +45,10 @@ def test_search_bit_exact_vs_reference_dump_and_oracle(name, maxlen, mm):
         assert c["rankQueries"] == st.rankQueries
     else:
         assert c["rankQueries"] <= st.rankQueries
-    assert c["ltLookups"] == st.ltLookups
+    if os.environ.get("S3DP_LT_EXTRA", "0") == "0":
+        assert c["ltLookups"] == st.ltLookups               # the long tables answer an item with one entry
+    else:
+        assert c["ltLookups"] <= st.ltLookups
     oix.close()
     b.close()
 
