@@ -41,8 +41,103 @@ __device__ __forceinline__ void bestMerge(Best &a, int score, uint32_t key, uint
     else if (score == a.score) { a.count += count; a.key = key < a.key ? key : a.key; }
 }
 
-// value of the lane below (lane 0: 0): one DPP move across the whole wavefront (wave_shr:1) instead of a trip through the LDS crossbar
-__device__ __forceinline__ int waveShr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
+// one DPP move across the whole wavefront (wave_shr:1) instead of a trip through the LDS crossbar
+// value of the lane below; lane 0 keeps `first` (the boundary row, the same LDS word in every lane): bound_ctrl off leaves the old value there
+__device__ __forceinline__ int waveShr1From(int first, int v) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false); }
+
+// what a lane carries through one 64-row chunk
+struct LaneState {
+    int hPrev, ePrev;                 // H and E of this row in the previous column
+    int upIn, fIn, dgIn, rIn;         // what this lane produced in the previous step (the lane above consumes it by DPP)
+    int nb0, nb1, nb2, nr;            // boundary row + window character of the column lane 0 meets next (prefetched from LDS)
+    int bS; uint32_t bT, bC;          // this row's maximum: score, step of its first occurrence, occurrences
+};
+
+struct ChunkConst {
+    int go, ge, gi, match, mismatch;
+    uint32_t lane, W, rc, refOffset, aL, dBase;
+    int span;
+    bool rowClip, rowBest;
+    const unsigned char *refLds;
+    int *bnd;
+    uint32_t *tab;                    // this chunk's part of the table: [step][lane]
+};
+
+// one anti-diagonal step.  Lanes outside the table (column < 1 while RAMP, column > W, rows beyond the read) compute on garbage that no
+// cell inside the table ever consumes: the lane above a live cell was live one step earlier.  Their table words are written and never read.
+//   CLIP: some row of the chunk lies inside the free left clip;  BEST: some row of the chunk may hold the maximum;
+//   RAMP: steps 1..63, where lanes have not reached column 1 yet (their column-0 state must survive) and lane 63 writes no boundary
+template <bool TABLE, bool CLIP, bool BEST, bool RAMP>
+__device__ __forceinline__ void dpStep(const ChunkConst &k, LaneState &s, uint32_t t)
+{
+    const int upS = waveShr1From(s.nb0, s.upIn), fS = waveShr1From(s.nb1, s.fIn), dgS = waveShr1From(s.nb2, s.dgIn), rS = waveShr1From(s.nr, s.rIn);
+    const uint32_t jn = t + 1u < k.W ? t + 1u : k.W;                  // uniform: the column lane 0 computes in the next step
+    s.nb0 = k.bnd[3u * jn]; s.nb1 = k.bnd[3u * jn + 1u]; s.nb2 = k.bnd[3u * jn + 2u]; s.nr = k.refLds[jn];
+    const int prevR = s.hPrev;
+    int gapped = max(k.go + prevR, k.ge + s.ePrev);
+    const int eSt = clampS(gapped);
+    int f = max(k.ge + fS, k.go + upS);
+    gapped = max(f, gapped);
+    const int up = max(gapped, dgS + ((uint32_t)rS == k.rc ? k.match : k.mismatch));
+    const int hSt = clampS(up);
+    int dg = prevR;
+    if (CLIP) {
+        const uint32_t j = t - k.lane;
+        const int init = (j + k.refOffset >= k.aL) ? NEG_INF : 0;
+        const int prevInit = ((int)j <= 1) ? 0 : ((j - 1u + k.refOffset >= k.aL) ? NEG_INF : 0);
+        if (k.rowClip) { f = max(init + k.gi, f); dg = max(prevInit, dg); }
+    }
+    if (RAMP) { const bool started = t > k.lane; s.hPrev = started ? hSt : s.hPrev; s.ePrev = started ? eSt : s.ePrev; }
+    else { s.hPrev = hSt; s.ePrev = eSt; }
+    s.upIn = up; s.fIn = f; s.dgIn = dg; s.rIn = rS;
+    if (TABLE) { uint32_t *row = k.tab + (size_t)t * 64u; row[k.lane] = __builtin_amdgcn_perm((uint32_t)eSt, (uint32_t)hSt, 0x05040100u); }   // H | E << 16, two int16
+    if (BEST) {
+        // columns jLo..W of the rows that may end the alignment; inside a row the columns come in increasing order, so the first maximum is the
+        // reference's (strictly-greater update) and later equals only count
+        const bool in = k.rowBest && (t - k.dBase) <= (uint32_t)k.span;
+        const bool gt = in && up > s.bS, eq = in && up == s.bS;
+        s.bC = gt ? 1u : s.bC + (eq ? 1u : 0u);
+        s.bT = gt ? t : s.bT;
+        s.bS = gt ? up : s.bS;
+    }
+    if (!RAMP) {
+        // the chunk's last row becomes the boundary of the next chunk; lane 0 fetched this column 64 steps ago
+        if (k.lane == 63u) { const uint32_t j = t - 63u; k.bnd[3u * j] = up; k.bnd[3u * j + 1u] = f; k.bnd[3u * j + 2u] = dg; }
+    }
+}
+
+template <bool TABLE, bool CLIP, bool BEST>
+__device__ __forceinline__ void chunkSweep(const DpArgs &a, uint32_t p, uint32_t c, uint32_t W, uint32_t L, uint32_t refOffset, int clipLt, int clipRtLoc,
+                                           uint32_t aL, uint32_t aR, const unsigned char *refLds, int *bnd, uint32_t *table, uint32_t T, Best &best)
+{
+    ChunkConst k;
+    k.go = a.gapOpen; k.ge = a.gapExtend; k.gi = k.go - k.ge; k.match = a.match; k.mismatch = a.mismatch;
+    asm volatile("" : "+v"(k.match), "+v"(k.mismatch));              // the select between them wants vector registers: move once, not per step
+    k.lane = threadIdx.x & 63u; k.W = W; k.refOffset = refOffset; k.aL = aL; k.refLds = refLds; k.bnd = bnd;
+    k.tab = TABLE ? table + (size_t)c * T * 64u : nullptr;
+    const uint32_t i = (c << 6) + 1u + k.lane;                       // this lane's read row
+    const bool rowOk = i <= L;
+    k.rc = rowOk ? seqChar(a.reads, p, a.maxReadLength, i) : 0u;
+    const int jLo = max(1, (int)aR - (int)refOffset);                // first column that may hold the maximum (right anchor)
+    k.span = (int)W - jLo;
+    k.dBase = k.lane + (uint32_t)jLo;
+    k.rowBest = BEST && rowOk && (int)i >= clipRtLoc && k.span >= 0;
+    k.rowClip = CLIP && (int)i <= clipLt;
+    LaneState s;
+    // column 0 of this row (:165-183)
+    if ((int)i <= clipLt) { s.hPrev = clampS(k.go); s.ePrev = clampS(k.go + k.gi); }
+    else { const int up0 = k.gi + k.ge * ((int)i - (clipLt > 0 ? clipLt : 0)); s.hPrev = clampS(up0); s.ePrev = clampS(up0 + k.gi); }
+    s.upIn = 0; s.fIn = 0; s.dgIn = 0; s.rIn = 0;
+    s.bS = NEG_INF; s.bT = 0; s.bC = 0;
+    const uint32_t j1 = W ? 1u : 0u;
+    s.nb0 = bnd[3u * j1]; s.nb1 = bnd[3u * j1 + 1u]; s.nb2 = bnd[3u * j1 + 2u]; s.nr = refLds[j1];
+    const uint32_t steps = W + 63u;
+    uint32_t t = 1;
+    for (; t <= 63u; t++) dpStep<TABLE, CLIP, BEST, true>(k, s, t);
+    for (; t + 1u <= steps; t += 2u) { dpStep<TABLE, CLIP, BEST, false>(k, s, t); dpStep<TABLE, CLIP, BEST, false>(k, s, t + 1u); }
+    if (t <= steps) dpStep<TABLE, CLIP, BEST, false>(k, s, t);
+    if (BEST && s.bC) bestMerge(best, s.bS, ((s.bT - k.lane) << 16) | i, s.bC);
+}
 
 // one sweep over W columns (starting after refOffset) of problem p by the calling wavefront
 template <bool TABLE>
@@ -50,7 +145,7 @@ __device__ void sweep(const DpArgs &a, uint32_t p, uint32_t W, uint32_t L, uint3
                       unsigned char *refLds, int *bnd, uint32_t *table, uint32_t T, Best &best)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const int go = a.gapOpen, ge = a.gapExtend, gi = go - ge;
+    const int gi = a.gapOpen - a.gapExtend;
     for (uint32_t j = lane; j <= W; j += 64u) refLds[j] = j ? (unsigned char)seqChar(a.dna, p, a.maxDNALength, j + refOffset) : 0;
     // row 0 boundary: H[j][0] = init(j), running open = init + gi, diagonal for row 1 = init(j-1)
     for (uint32_t j = lane; j <= W; j += 64u) {
@@ -62,43 +157,15 @@ __device__ void sweep(const DpArgs &a, uint32_t p, uint32_t W, uint32_t L, uint3
     best.score = NEG_INF; best.key = 0xFFFFFFFFu; best.count = 0;
     const uint32_t chunks = (L + 63u) >> 6;
     for (uint32_t c = 0; c < chunks; c++) {
-        const uint32_t i = (c << 6) + 1u + lane;                      // this lane's read row
-        const bool rowOk = i <= L;
-        const uint32_t rc = rowOk ? seqChar(a.reads, p, a.maxReadLength, i) : 0u;
-        // column 0 of this row (:165-183)
-        int hPrev, ePrev;
-        if ((int)i <= clipLt) { hPrev = clampS(go); ePrev = clampS(go + gi); }
-        else { const int up0 = gi + ge * ((int)i - (clipLt > 0 ? clipLt : 0)); hPrev = clampS(up0); ePrev = clampS(up0 + gi); }
-        int upIn = 0, fIn = 0, dgIn = 0;                               // what lane-1 produced in the previous step
-        const uint32_t steps = W + 63u;
-        for (uint32_t t = 1; t <= steps; t++) {
-            // values handed down from the row above: lane 0 reads the boundary row, the others shuffle
-            int upS = waveShr1(upIn), fS = waveShr1(fIn), dgS = waveShr1(dgIn);
-            const int j = (int)t - (int)lane;
-            const bool act = rowOk && j >= 1 && j <= (int)W;
-            if (lane == 0 && act) { upS = bnd[3 * j]; fS = bnd[3 * j + 1]; dgS = bnd[3 * j + 2]; }
-            int upOut = 0, fOut = 0, dgOut = 0;
-            if (act) {
-                const int init = ((uint32_t)j + refOffset >= aL) ? NEG_INF : 0;
-                const int prevInit = (j <= 1) ? 0 : (((uint32_t)j - 1u + refOffset >= aL) ? NEG_INF : 0);
-                const int prevR = hPrev;
-                int gapped = max(go + prevR, ge + ePrev);
-                const int eSt = clampS(gapped);
-                int f = max(ge + fS, go + upS);
-                gapped = max(f, gapped);
-                const int up = max(gapped, dgS + ((uint32_t)refLds[j] == rc ? a.match : a.mismatch));
-                const int hSt = clampS(up);
-                hPrev = hSt; ePrev = eSt;
-                int dg = prevR;
-                if ((int)i <= clipLt) { f = max(init + gi, f); dg = max(prevInit, dg); }
-                upOut = up; fOut = f; dgOut = dg;
-                if (TABLE) table[((size_t)c * T + t) * 64u + lane] = ((uint32_t)(uint16_t)(int16_t)hSt) | ((uint32_t)(uint16_t)(int16_t)eSt << 16);
-                if ((int)i >= clipRtLoc && (uint32_t)j + refOffset >= aR) bestMerge(best, up, ((uint32_t)j << 16) | i, 1u);
-                if (lane == 63u || i == L) { /* last row of the chunk: becomes the boundary of the next chunk */ }
-            }
-            // the boundary row for the next chunk is the chunk's last lane (row 64c+64); written after lane 0 consumed column j
-            if (lane == 63u && act) { bnd[3 * j] = upOut; bnd[3 * j + 1] = fOut; bnd[3 * j + 2] = dgOut; }
-            upIn = upOut; fIn = fOut; dgIn = dgOut;
+        // wave-uniform: does the chunk touch the free left clip / hold rows that may end the alignment?
+        const bool clip = clipLt > (int)(c << 6);
+        const bool mayEnd = (int)((c << 6) + 64u) >= clipRtLoc;
+        if (clip) {
+            if (mayEnd) chunkSweep<TABLE, true, true>(a, p, c, W, L, refOffset, clipLt, clipRtLoc, aL, aR, refLds, bnd, table, T, best);
+            else chunkSweep<TABLE, true, false>(a, p, c, W, L, refOffset, clipLt, clipRtLoc, aL, aR, refLds, bnd, table, T, best);
+        } else {
+            if (mayEnd) chunkSweep<TABLE, false, true>(a, p, c, W, L, refOffset, clipLt, clipRtLoc, aL, aR, refLds, bnd, table, T, best);
+            else chunkSweep<TABLE, false, false>(a, p, c, W, L, refOffset, clipLt, clipRtLoc, aL, aR, refLds, bnd, table, T, best);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -118,7 +185,8 @@ using namespace dp;
 __global__ void __launch_bounds__(256) dpFillKernel(DpArgs a)
 {
     extern __shared__ __align__(16) unsigned char sh[];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // the wavefront number is uniform: saying so keeps the problem's lengths, clips, anchors and loop counters in scalar registers
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const uint32_t p = blockIdx.x * 4u + wv;
     if (p >= a.n) return;
     const uint32_t perWave = a.ldsPerWave;
