@@ -90,7 +90,8 @@ __device__ __forceinline__ void dpStep(const ChunkConst &k, LaneState &s, uint32
     if (RAMP) { const bool started = t > k.lane; s.hPrev = started ? hSt : s.hPrev; s.ePrev = started ? eSt : s.ePrev; }
     else { s.hPrev = hSt; s.ePrev = eSt; }
     s.upIn = up; s.fIn = f; s.dgIn = dg; s.rIn = rS;
-    if (TABLE) { uint32_t *row = k.tab + (size_t)t * 64u; row[k.lane] = __builtin_amdgcn_perm((uint32_t)eSt, (uint32_t)hSt, 0x05040100u); }   // H | E << 16, two int16
+    // H | E << 16, two int16; written once and read only by the traceback kernel: streaming stores keep the table out of the caches' way
+    if (TABLE) { uint32_t *row = k.tab + (size_t)t * 64u; __builtin_nontemporal_store(__builtin_amdgcn_perm((uint32_t)eSt, (uint32_t)hSt, 0x05040100u), &row[k.lane]); }
     if (BEST) {
         // columns jLo..W of the rows that may end the alignment; inside a row the columns come in increasing order, so the first maximum is the
         // reference's (strictly-greater update) and later equals only count
