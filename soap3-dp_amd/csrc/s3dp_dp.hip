@@ -7,14 +7,16 @@
 //   * the reference gives one CUDA thread a whole problem and keeps two short tables in global memory that the same
 //     thread reads back (8 B of table traffic per cell, 97 k serial cells per thread for a 150 x 650 problem);
 //   * here a wavefront sweeps the table by anti-diagonals: lane k owns read row 64c+1+k of the current 64-row chunk,
-//     at step t it computes column t-k; H[j][i-1], the running insertion score and the diagonal travel to the next
-//     lane by a one-lane shuffle; the previous column's H/E stay in the lane's registers; chunk-to-chunk boundary rows
-//     and the window characters live in LDS; the reference window and read are read once;
-//   * the tables needed by the traceback are written as ONE coalesced 256-B store per wave step (H and E packed in one
-//     dword per cell, anti-diagonal-major), never re-read by the fill;
+//     at step t it computes column t-k; H[j][i-1], the running insertion score, the diagonal and the window character
+//     travel to the next lane by DPP (wave_shr:1), lane 0 taking the boundary row prefetched from LDS as the move's
+//     "old" operand; the previous column's H/E stay in the lane's registers; the read is read once;
+//   * the tables needed by the traceback are written as ONE coalesced 256-B streaming store per wave step (H and E
+//     packed in one dword per cell, anti-diagonal-major), never re-read by the fill;
 //   * the maximum is tracked order-independently (max score, then smallest (column,row), plus tie count) and reduced
-//     across the wave, which equals the reference's strictly-greater update in (column outer, row inner) order.
-// Bound: integer VALU / LDS (about one wave instruction per cell); HBM traffic is 4 B written per cell.
+//     across the wave, which equals the reference's strictly-greater update in (column outer, row inner) order;
+//   * the steady-state step carries no per-lane activity test and no clip / maximum code unless the chunk needs it
+//     (dpStep's template flags): about 21 vector instructions per 64 cells.
+// Bound: integer VALU (3.05 of the 3.9 ms at 150 x 648); HBM traffic is 4 B written per cell (the other 0.9 ms).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "s3dp_device.h"
