@@ -19,6 +19,7 @@
 //   * check-and-extend runs in its own kernel (ceKernel, below): the stepping kernel writes task records and goes on (template parameter SPLIT;
 //     SPLIT = false keeps it inside the state machine, the first form of this kernel, S3DP_CE=inline).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "s3dp_device.h"
 #include "s3dp_model.h"
@@ -725,7 +726,17 @@ void launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out
 void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskEnd, hipStream_t s)
 {
     if (in.nActive == 0) return;
-    hipLaunchKernelGGL(ceKernel, dim3(256u * 8u), dim3(256), 0, s, ix, in, out, taskEnd);
+    // the waves split the task records statically: launch exactly the blocks that are resident at once (a partial second round would run on a
+    // third of the chip while the rest idles).  S3DP_CE_BLOCKS_PER_CU overrides the occupancy the runtime reports.
+    static const unsigned blocks = [] {
+        int dev = 0, cus = 256, perCu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, ceKernel, 256, 0) != hipSuccess || perCu < 1) perCu = 6;
+        if (const char *e = getenv("S3DP_CE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
+        return (unsigned)(cus * perCu);
+    }();
+    hipLaunchKernelGGL(ceKernel, dim3(blocks), dim3(256), 0, s, ix, in, out, taskEnd);
 }
 
 }  // namespace s3
