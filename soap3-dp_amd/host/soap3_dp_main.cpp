@@ -17,6 +17,7 @@
 #include <chrono>
 #include <unistd.h>
 #include <thread>
+#include <future>
 #include <vector>
 #include "s3_host.h"
 
@@ -499,15 +500,27 @@ int main(int argc, char **argv)
     HostIndex hix;
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+    // the read files are parsed while the index is read and copied to the device: neither needs the other
+    ReadSet rs;
+    std::string readErr;
+    double readSeconds = 0;
+    std::future<bool> readsLoaded = std::async(std::launch::async, [&] {
+        const auto tReads = std::chrono::steady_clock::now();
+        const bool ok = paired ? loadPairReads(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, readErr)
+                               : loadSingleReads(queryFile, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, readErr);
+        readSeconds = since(tReads);
+        return ok;
+    });
     printf("[Main] loading index into host...\n");
-    if (!loadIndex(indexName, hix, err)) return die(err);
+    if (!loadIndex(indexName, hix, err)) { readsLoaded.wait(); return die(err); }
     printf("[Main] Finished loading index into host.\n[Main] Loading time : %9.4f seconds\n", since(t0));
     printf("[Main] Reference sequence length : %u\n", hix.n);
-    const auto tReads = std::chrono::steady_clock::now();
-    ReadSet rs;
-    if (paired ? !loadPairReads(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, err)
-               : !loadSingleReads(queryFile, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, err)) return die(err);
-    printf("[Main] Loaded %u short reads from the query file.\n[Main] Read load time : %9.4f seconds (%d host threads)\n", rs.n, since(tReads), hostThreads());
+    s3_index *ix = nullptr;
+    s3_index_desc d = hix.desc();
+    if (s3_index_upload(device, &d, &ix) != S3_OK) { readsLoaded.wait(); return die(s3_last_error()); }
+    printf("[Main] Finished copying index into device (GPU).\n");
+    if (!readsLoaded.get()) return die(readErr);
+    printf("[Main] Loaded %u short reads from the query file.\n[Main] Read load time : %9.4f seconds (%d host threads, alongside the index)\n", rs.n, readSeconds, hostThreads());
     if (numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;          // getDefaultMismatchNum, CPUfunctions.cpp:26-35
     // DP enabled (the default): the BWT stage runs with Soap3MisMatchAllow mismatches (SOAP3-DP.cu:208-213); reads it leaves unaligned go
     // through seeding + DP and are reported in <prefix>.dpout.1.  Too short reads switch the DP off (SOAP3-DP.cu:643-652).
@@ -529,10 +542,6 @@ int main(int argc, char **argv)
         else if (paired && (detectedReadLength <= 50 || detectedReadLength2 <= 50)) numMismatch = 1;   // SOAP3-DP.cu:663-666
         if (!enableDP && numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;
     }
-    s3_index *ix = nullptr;
-    s3_index_desc d = hix.desc();
-    if (s3_index_upload(device, &d, &ix) != S3_OK) return die(s3_last_error());
-    printf("[Main] Finished copying index into device (GPU).\n");
     const auto tAlign = std::chrono::steady_clock::now();
     double devSeconds = 0, formatSeconds = 0, dpStageSeconds = 0;
     const std::string outName = prefix + ".gout.1";
