@@ -1,0 +1,29 @@
+#!/bin/bash
+# AddressSanitizer + UBSan over the host side (read loaders, SAM writers, DP record writers) and the oracle, CPU build only
+# (GPU sanitizers are not available on the pool).  Runs the CPU tools of tests/tools on the golden fixtures; prints one line per run.
+# libs3dp.so must be built (make -C soap3-dp_amd); nothing here calls a device function.
+set -u
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+H=$ROOT/soap3-dp_amd/host; L=$ROOT/soap3-dp_amd; G=$ROOT/tests/golden
+W=${1:-/tmp/s3dp_sanitize}; mkdir -p "$W"; cd "$W" || exit 1
+SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
+LINK="-L$L -ls3dp -lz -lm -Wl,-rpath,$L"
+gcc $SAN -c "$ROOT/oracle/s3_oracle.c" -o o1.o && gcc $SAN -c "$ROOT/oracle/s3_oracle_pe.c" -o o2.o || exit 1
+g++ $SAN -std=c++17 -pthread -o oracle_sam "$ROOT/tests/tools/oracle_sam.cpp" "$H/s3_host.cpp" o1.o o2.o $LINK || exit 1
+g++ $SAN -std=c++17 -pthread -o dp_sam "$ROOT/tests/tools/dp_sam.cpp" "$H/s3_host.cpp" "$H/s3_host_dp.cpp" $LINK || exit 1
+g++ $SAN -std=c++17 -pthread -o dp_pair_sam "$ROOT/tests/tools/dp_pair_sam.cpp" "$H/s3_host.cpp" "$H/s3_host_dp.cpp" "$H/s3_host_dp_pair.cpp" $LINK || exit 1
+export ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1
+cp "$G/g1/reads.fq" g1.fq; cp "$G/g6/reads.fq" g6.fq; cp "$G/g3/reads.fq" g3.fq; cp "$G/g4/reads_1.fq" g4_1.fq; cp "$G/g4/reads_2.fq" g4_2.fq
+cp "$G/dp1/reads.fq" dp1.fq; cp "$G/dp2/reads_1.fq" dp2_1.fq; cp "$G/dp2/reads_2.fq" dp2_2.fq
+bad=0
+run() { local name=$1; shift; timeout 900 "$@" > "$name.log" 2>&1 < /dev/null; local rc=$?
+        local n; n=$(grep -c 'runtime error\|ERROR: AddressSanitizer' "$name.log"); echo "$name rc=$rc findings=$n"; [ $rc -ne 0 ] || [ "$n" -ne 0 ] && bad=1; }
+run g1_s4 ./oracle_sam single "$G/g1/index" g1.fq -L 100 -s 4 -o o1
+run g6_s4 ./oracle_sam single "$G/g6/index" g6.fq -L 100 -s 4 -o o6
+run g3_long ./oracle_sam single "$G/g3/index" g3.fq -L 200 -s 3 -h 3 -o o3
+run g4_pair ./oracle_sam pair "$G/g4/index" g4_1.fq g4_2.fq -L 100 -u 500 -v 200 -s 3 -h 3 -o o4
+run dp1 ./dp_sam "$G/dp1/index" dp1.fq "$G/dp1/results.txt" d1 -L 100 -h 1 -p
+for o in "" "-h 1 -p" "-h 4 -p" "-p -B 0" "-h 3"; do
+    run "dp2_$(echo $o | tr -d ' -')" ./dp_pair_sam "$G/dp1/index" dp2_1.fq dp2_2.fq "$G/dp2/results.txt" "$G/dp2/stats.txt" d2 -L 100 $o
+done
+exit $bad
