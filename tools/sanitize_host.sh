@@ -26,4 +26,10 @@ run dp1 ./dp_sam "$G/dp1/index" dp1.fq "$G/dp1/results.txt" d1 -L 100 -h 1 -p
 for o in "" "-h 1 -p" "-h 4 -p" "-p -B 0" "-h 3"; do
     run "dp2_$(echo $o | tr -d ' -')" ./dp_pair_sam "$G/dp1/index" dp2_1.fq dp2_2.fq "$G/dp2/results.txt" "$G/dp2/stats.txt" d2 -L 100 $o
 done
+# ThreadSanitizer over the two-thread pair loader and the record formatting
+TS="-O1 -g -fsanitize=thread"
+gcc $TS -c "$ROOT/oracle/s3_oracle.c" -o t1.o && gcc $TS -c "$ROOT/oracle/s3_oracle_pe.c" -o t2.o &&
+g++ $TS -std=c++17 -pthread -o oracle_sam_tsan "$ROOT/tests/tools/oracle_sam.cpp" "$H/s3_host.cpp" t1.o t2.o $LINK || exit 1
+timeout 900 ./oracle_sam_tsan pair "$G/g4/index" g4_1.fq g4_2.fq -L 100 -u 500 -v 200 -s 3 -h 3 -o t4 > tsan_g4.log 2>&1 < /dev/null; rc=$?
+n=$(grep -c 'WARNING: ThreadSanitizer' tsan_g4.log); echo "tsan_g4_pair rc=$rc findings=$n"; [ $rc -ne 0 ] || [ "$n" -ne 0 ] && bad=1
 exit $bad
