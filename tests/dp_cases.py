@@ -4,11 +4,14 @@ import numpy as np
 import s3dp
 
 
-def make_problems(n, max_read, max_dna, seed, read_len_range=(30, 150), clip=True, anchors=True):
+def make_problems(n, max_read, max_dna, seed, read_len_range=(30, 150), clip=True, anchors=True, lengths=None, clip_max=None):
+    """lengths: read lengths to cycle through instead of random ones; clip_max: soft-clip allowances up to min(clip_max, L // 2) instead of < 20"""
     rng = np.random.default_rng(seed)
     dna, reads, clip_lt, clip_rt, a_lt, a_rt, cut = [], [], [], [], [], [], []
     for t in range(n):
         L = int(rng.integers(read_len_range[0], min(read_len_range[1], max_read) + 1))
+        if lengths is not None:
+            L = int(lengths[t % len(lengths)])
         W = int(rng.integers(L + 2, max_dna + 1)) if max_dna > L + 2 else max_dna
         win = rng.integers(0, 4, size=W, dtype=np.uint8)
         kind = t % 8
@@ -32,8 +35,9 @@ def make_problems(n, max_read, max_dna, seed, read_len_range=(30, 150), clip=Tru
         if kind == 7:                           # unrelated read
             read = rng.integers(0, 4, size=L, dtype=np.uint8)
         dna.append(win); reads.append(read)
-        clip_lt.append(int(rng.integers(0, min(20, L // 3 + 1))) if clip else 0)
-        clip_rt.append(int(rng.integers(0, min(20, L // 3 + 1))) if clip else 0)
+        cmax = min(20, L // 3 + 1) if clip_max is None else max(1, min(clip_max, L // 2))
+        clip_lt.append(int(rng.integers(0, cmax)) if clip else 0)
+        clip_rt.append(int(rng.integers(0, cmax)) if clip else 0)
         if anchors and t % 3 == 0:
             a_lt.append(int(rng.integers(1, W + 1))); a_rt.append(int(rng.integers(0, W // 2 + 1)))
         else:

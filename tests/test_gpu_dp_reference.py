@@ -79,6 +79,34 @@ def test_reference_kernels_restatement_and_product_agree(scheme, max_read, max_d
     al.close()
 
 
+@pytest.mark.parametrize("scheme", [1, 2])
+def test_chunk_boundaries_and_long_clips(scheme):
+    """read lengths around the 64-row chunks of the wavefront kernel (63, 64, 65, 127, 128, 129, 191, 192, 193), windows of 66 to 419
+    columns, soft-clip allowances that reach into the second and third chunk: the reference's kernels, the restatement and the
+    product agree on everything"""
+    assert os.path.exists(LIB)
+    n, max_read, max_dna = 288, 200, 420
+    P = make_problems(n, max_read, max_dna, 51, lengths=[63, 64, 65, 127, 128, 129, 191, 192, 193], clip_max=100)
+    assert (P["clip_lt"] > 64).sum() > 5 and (P["clip_rt"] > 64).sum() > 5
+    al = s3dp.DpAligner(n, max_read, max_dna, scheme=scheme, scores=SC)
+    mine = al.align(P["dna"], P["dna_len"], P["reads"], P["read_len"], P["cutoffs"], clip_lt=P["clip_lt"], clip_rt=P["clip_rt"], anchor_lt=P["a_lt"],
+                    anchor_rt=P["a_rt"])
+    orc = s3o.dp_align(P["dna"], P["dna_len"], max_dna, al.max_table, P["reads"], P["read_len"], max_read, P["cutoffs"], scheme=al.scheme, scores=SC,
+                       clip_lt=P["clip_lt"], clip_rt=P["clip_rt"], anchor_lt=P["a_lt"], anchor_rt=P["a_rt"])
+    ref = dpref_align(P, max_dna, al.max_table, max_read, al.scheme)
+    for who, got in (("restatement", orc), ("product", mine)):
+        assert (got[0] == ref[0]).all(), who + ": scores"
+        assert (got[2] == ref[2]).all(), who + ": tie counts"
+        assert (got[4] == ref[4]).all(), who + ": actual right clips"
+        assert (got[1] == ref[1]).all(), who + ": start columns"
+    ok = ref[0] >= P["cutoffs"]
+    assert ok.sum() > n // 4
+    for t in np.nonzero(ok)[0]:
+        assert op_string(orc[3][t]) == op_string(ref[3][t]), ("restatement", t)
+        assert op_string(mine[3][t]) == op_string(ref[3][t]), ("product", t)
+    al.close()
+
+
 def test_reference_kernels_without_clips_and_anchors():
     assert os.path.exists(LIB)
     P = make_problems(128, 104, 160, seed=41, clip=False, anchors=False, read_len_range=(40, 100))
