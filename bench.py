@@ -30,6 +30,109 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+# Repeat structure of a human-like genome (round-2 headline workload).  Shares are fractions of the genome at repeat_frac = 0.5 and
+# scale with it.  GRCh38 is about half interspersed / tandem repeats: Alu ~ 1.1 M copies of a 300 bp unit (10 %), L1 ~ 0.5 M mostly
+# 5'-truncated copies of a 6 kbp unit (17 %), many mid-size families, a few per cent of recent segmental duplications and satellites.
+# Old copies sit 5-15 % from their consensus, young sub-families 0.5-2 % (those make reads that hit MaxOutputPerRead and multi-map).
+REPEAT_FAMILIES = (
+    # name, share, unit length, copy length as a fraction of the unit (lo, hi), young share, young divergence, old divergence
+    ("sine_alu_like", 0.10, 300, (0.85, 1.0), 0.15, (0.005, 0.02), (0.05, 0.15)),
+    ("line_l1_like", 0.17, 6000, (0.03, 1.0), 0.05, (0.005, 0.02), (0.03, 0.15)),
+    ("mid_families", 0.15, 0, (0.3, 1.0), 0.10, (0.01, 0.03), (0.02, 0.12)),          # 40 families, units of 500-5000 bp
+    ("segmental_duplications", 0.05, -1, (1.0, 1.0), 1.0, (0.005, 0.02), (0.005, 0.02)),   # units of 20-200 kbp, 2-10 copies
+    ("satellites", 0.03, 171, (1.0, 1.0), 1.0, (0.01, 0.03), (0.01, 0.03)),            # tandem arrays of 1000-5000 units
+)
+
+
+def _plant(codes, unit, copies, frac_lo, frac_hi, young_share, young_div, old_div, g, tandem=0):
+    """write `copies` mutated (and half of them reverse-complemented) copies of `unit` at random places; copies are 3'-anchored pieces of the
+    unit (LINE-like truncation); tandem > 0: arrays of `tandem` units in a row instead of dispersed copies"""
+    import torch
+    dev = codes.device
+    n = codes.numel()
+    ulen = unit.numel()
+    ar = torch.arange(ulen, device=dev)
+    per = max(1, (1 << 25) // ulen)
+    done = 0
+    while done < copies:
+        m = min(per, copies - done)
+        lens = (torch.rand(m, generator=g, device=dev) * (frac_hi - frac_lo) + frac_lo) * ulen
+        lens = torch.clamp(lens.to(torch.int64), 20, ulen)
+        young = torch.rand(m, generator=g, device=dev) < young_share
+        u = torch.rand(m, generator=g, device=dev)
+        div = torch.where(young, young_div[0] + u * (young_div[1] - young_div[0]), old_div[0] + u * (old_div[1] - old_div[0]))
+        src = unit[None, :].expand(m, ulen)
+        mut = torch.rand((m, ulen), generator=g, device=dev) < div[:, None]
+        delta = torch.randint(1, 4, (m, ulen), generator=g, device=dev, dtype=torch.uint8)
+        seq = torch.where(mut, (src + delta) % 4, src)
+        # 3'-anchored piece of length lens: element j of the copy is unit position (ulen - lens + j)
+        pos = torch.clamp(ar[None, :] + (ulen - lens)[:, None], max=ulen - 1)
+        rc = torch.rand(m, generator=g, device=dev) < 0.5
+        pos_rc = torch.clamp((ulen - 1 - ar)[None, :].expand(m, ulen), min=0)
+        pos = torch.where(rc[:, None], torch.clamp(pos_rc, min=0), pos)
+        piece = torch.gather(seq, 1, pos)
+        piece = torch.where(rc[:, None], 3 - piece, piece)
+        valid = ar[None, :] < lens[:, None]
+        if tandem:
+            arrays = max(1, m // tandem)
+            base = torch.randint(0, max(1, n - tandem * ulen - 1), (arrays,), generator=g, device=dev)
+            k = torch.arange(m, device=dev)
+            dst = base[torch.clamp(k // tandem, max=arrays - 1)] + (k % tandem) * ulen
+        else:
+            dst = torch.randint(0, n - ulen - 1, (m,), generator=g, device=dev)
+        flat = dst[:, None] + ar[None, :]
+        codes[flat[valid]] = piece[valid]
+        done += m
+
+
+def plant_repeats(codes, repeat_frac, seed):
+    """overwrite about repeat_frac of `codes` with copies of repeat families (REPEAT_FAMILIES); returns the per-family copy counts"""
+    import torch
+    dev = codes.device
+    n = codes.numel()
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    scale = repeat_frac / 0.5
+    report = {}
+    for name, share, ulen, (flo, fhi), yshare, ydiv, odiv in REPEAT_FAMILIES:
+        budget = int(n * share * scale)
+        if budget <= 0:
+            continue
+        mean_frac = (flo + fhi) / 2
+        if ulen > 0:
+            tandem = 0
+            copies = max(2, int(budget / (ulen * mean_frac)))
+            if name == "satellites":
+                tandem = min(3000, max(2, copies // 4))
+            unit = torch.randint(0, 4, (ulen,), generator=g, device=dev, dtype=torch.uint8)
+            _plant(codes, unit, copies, flo, fhi, yshare, ydiv, odiv, g, tandem)
+            report[name] = {"unit": ulen, "copies": copies}
+        elif ulen == 0:
+            fams = 40
+            tot = 0
+            for f in range(fams):
+                ul = int(torch.randint(500, 5001, (1,), generator=g, device=dev))
+                copies = max(2, int(budget / fams / (ul * mean_frac)))
+                unit = torch.randint(0, 4, (ul,), generator=g, device=dev, dtype=torch.uint8)
+                _plant(codes, unit, copies, flo, fhi, yshare, ydiv, odiv, g)
+                tot += copies
+            report[name] = {"families": fams, "copies": tot}
+        else:
+            placed = 0
+            cnt = 0
+            while placed < budget:
+                ul = int(torch.randint(20_000, 200_001, (1,), generator=g, device=dev))
+                ul = min(ul, max(1000, n // 50))
+                copies = int(torch.randint(2, 11, (1,), generator=g, device=dev))
+                src = int(torch.randint(0, n - ul - 1, (1,), generator=g, device=dev))
+                unit = codes[src:src + ul].clone()
+                _plant(codes, unit, copies, 1.0, 1.0, yshare, ydiv, odiv, g)
+                placed += ul * copies
+                cnt += copies
+            report[name] = {"copies": cnt}
+    return report
+
+
 def make_genome(n, seed, device, repeat_frac=0.0):
     import torch
     g = torch.Generator(device=device)
@@ -39,26 +142,8 @@ def make_genome(n, seed, device, repeat_frac=0.0):
     for a in range(0, n, step):
         b = min(n, a + step)
         codes[a:b] = torch.randint(0, 4, (b - a,), generator=g, device=device, dtype=torch.uint8)
-    if repeat_frac > 0:
-        # planted repeat families: 300..3000 bp units copied with ~1 % divergence
-        cpu = torch.Generator()
-        cpu.manual_seed(seed + 1)
-        target = int(n * repeat_frac)
-        placed = 0
-        while placed < target:
-            ulen = int(torch.randint(300, 3000, (1,), generator=cpu))
-            copies = int(torch.randint(5, 200, (1,), generator=cpu))
-            src = int(torch.randint(0, n - ulen, (1,), generator=cpu))
-            unit = codes[src:src + ulen].clone()
-            dst = torch.randint(0, n - ulen, (copies,), generator=cpu)
-            for d in dst.tolist():
-                u = unit.clone()
-                nsub = max(1, ulen // 100)
-                p = torch.randint(0, ulen, (nsub,), generator=cpu).to(device)
-                u[p] = (u[p] + torch.randint(1, 4, (nsub,), generator=cpu).to(device).to(torch.uint8)) % 4
-                codes[d:d + ulen] = u
-            placed += ulen * copies
-    return codes
+    families = plant_repeats(codes, repeat_frac, seed + 1) if repeat_frac > 0 else {}
+    return codes, families
 
 
 def make_reads(codes, n_reads, L, seed, device, mix=(0.55, 0.25, 0.12, 0.05, 0.03)):
@@ -226,60 +311,91 @@ def cpu_baseline(hi, q, lens, wpq, mm, max_out, budget_s):
             "reads_per_s_per_core": total / dt / threads, "rank_queries_per_read": sum(ranks) / total}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-bp", type=int, default=int(os.environ.get("S3DP_BENCH_GENOME_BP", 3_100_000_000)))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("S3DP_BENCH_READS", 10_000_000)), help="reads per GPU")
-    ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--mismatch", type=int, default=4)
-    ap.add_argument("--max-out", type=int, default=1000)
-    ap.add_argument("--repeat-frac", type=float, default=0.0)
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
-    ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle after the run")
-    ap.add_argument("--extras", type=int, default=1, help="after the timed region (N = 1): paired-end 2x150 BWT stage and DP kernel throughput")
-    a = ap.parse_args()
+def truth_check(phase, offs, pos, strand, mis, tpos, tstrand, tsub, max_out):
+    """The simulated place of every read against what the ladder reported.  All-best reports the best stratum only, cut at MaxOutputPerRead,
+    so for every read with at most 4 substitutions: it must be aligned; its best hit has at most as many mismatches as were planted; and
+    when it has exactly that many (and the list was not cut) the true (position, strand) must be in the list."""
+    n = len(phase)
+    counts = np.diff(offs.astype(np.int64))
+    ridx = np.repeat(np.arange(n, dtype=np.int64), counts)
+    no = int(offs[-1])
+    want_strand = np.where(tstrand == 1, 2, 1).astype(np.uint8)          # reference coding: 1 = read as given, 2 = reverse complement
+    hit_true = (pos[:no] == tpos[ridx].astype(np.uint32)) & (strand[:no] == want_strand[ridx])
+    found = np.bincount(ridx[hit_true], minlength=n) > 0
+    best = np.full(n, 255, dtype=np.int64)
+    np.minimum.at(best, ridx, mis[:no].astype(np.int64))
+    aligned = counts > 0
+    cut = counts >= max_out
+    unaligned = int((~aligned).sum())
+    worse = int((aligned & (best > tsub)).sum())
+    must = aligned & (best == tsub) & ~cut
+    missing = int((must & ~found).sum())
+    return {"reads": int(n), "unaligned": unaligned, "best_worse_than_planted": worse, "true_place_missing": missing,
+            "true_place_reported": int((must & found).sum()), "better_hit_elsewhere": int((aligned & (best < tsub)).sum()),
+            "cut_at_max_output": int(cut.sum()), "multi_mapped_reads": int((counts > 1).sum()),
+            "ok": bool(unaligned == 0 and worse == 0 and missing == 0)}
 
+
+def measured_peaks(dev, local):
+    """the two denominators, measured on this GPU at the start of the run: streaming copy bandwidth (read + write bytes per second of a
+    device-to-device copy of 2 GiB, HIP events) and the random 64-byte-line gather rate (s3_probe_gather, the product library's own probe)"""
     import torch
     import s3dp
-    from s3dp import builder
+    n = 1 << 31
+    x = torch.empty(n, dtype=torch.uint8, device=dev)
+    y = torch.empty(n, dtype=torch.uint8, device=dev)
+    x.zero_()
+    y.copy_(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for _ in range(3):
+        e0.record()
+        for _ in range(4):
+            y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * n * 4 / (e0.elapsed_time(e1) / 1e3) / 1e9)
+    del x, y
+    torch.cuda.empty_cache()
+    ms, lines = s3dp.probe_gather(int(6e9), blocks=2048, iters=128, ilp=4, loads_per_line=1, device=local)
+    return {"copy_GBps": best, "random_Glines_per_s": lines / ms / 1e6,
+            "how": "device-to-device copy of 2 GiB (read + write bytes, best of 3 x 4 copies); s3_probe_gather over a 6 GB table, 4 independent "
+                   "64-byte lines in flight per lane"}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available() or s3dp.device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)
 
-    t_all = time.perf_counter()
-    # ---- index (replicated per GPU): same seed on every rank -----------------------------------------
+def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_frac, label, index_dir=None):
+    """one workload = genome + index + reads + counted pass + timed region + checks; returns (json fragment, objects kept for the extras)"""
+    import torch
+    from s3dp import dist as sd
     t0 = time.perf_counter()
-    codes = make_genome(a.genome_bp, 1, dev, a.repeat_frac)
-    log("genome %d bp generated in %.1f s" % (a.genome_bp, time.perf_counter() - t0))
+    codes, families = make_genome(a.genome_bp, 1, dev, repeat_frac)
+    log("[%s] genome %d bp (repeat_frac %.2f) generated in %.1f s" % (label, a.genome_bp, repeat_frac, time.perf_counter() - t0))
     t0 = time.perf_counter()
     reads2d, tpos, tstrand, tsub = make_reads(codes, a.reads, a.read_len, 2026 + rank, dev)
     wpq = s3dp.word_per_query(a.read_len)
     q = pack_on_device(reads2d, wpq)
     lens = np.full(a.reads, a.read_len, dtype=np.uint32)
+    tpos, tstrand, tsub = tpos.cpu().numpy(), tstrand.cpu().numpy(), tsub.cpu().numpy().astype(np.int64)
     del reads2d
-    log("%d reads generated + packed in %.1f s" % (a.reads, time.perf_counter() - t0))
+    log("[%s] %d reads generated + packed in %.1f s" % (label, a.reads, time.perf_counter() - t0))
+    # index: built ONCE (rank 0, on its GPU), written in the reference's file formats, loaded by every rank
     t0 = time.perf_counter()
-    hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=(rank == 0))
-    if not (rank == 0 and world == 1 and a.extras):
-        del codes
+    if world > 1:
+        prefix = os.path.join(index_dir, "bench_%s.index" % label)
+        if rank == 0:
+            hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=True)
+            hi.write_files(prefix, with_lkt=True)
+        dist.barrier()
+        if rank != 0:
+            hi = s3dp.HostIndex.from_files(prefix)
+    else:
+        hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=(rank == 0))
     torch.cuda.empty_cache()
-    log("index built on the GPU in %.1f s" % (time.perf_counter() - t0))
+    log("[%s] index built in %.1f s" % (label, time.perf_counter() - t0))
     t0 = time.perf_counter()
     ix = s3dp.Index(hi, device=local)
-    log("index resident: %.2f GB in HBM, upload %.1f s" % (ix.device_bytes() / 1e9, time.perf_counter() - t0))
+    log("[%s] index resident: %.2f GB in HBM, upload %.1f s" % (label, ix.device_bytes() / 1e9, time.perf_counter() - t0))
     b = s3dp.Batch(ix, a.reads, wpq)
     b.upload(q, lens)
 
@@ -299,15 +415,13 @@ def main():
     n_occ = int(offs[-1])
     b.enable_counters(False)
 
-    # ---- timed region ------------------------------------------------------------------------------------
+    # ---- timed region: resident batch ----------------------------------------------------------------------
     for _ in range(a.warmup):
         b.align_single_allbest(a.mismatch, a.max_out)
         b.sync()
     barrier()
     t0 = time.perf_counter()
-    search_ms = 0.0
-    ce_ms = 0.0
-    dev_ms = 0.0
+    search_ms = ce_ms = dev_ms = 0.0
     launches = 0
     for _ in range(a.steps):
         b.align_single_allbest(a.mismatch, a.max_out)
@@ -319,22 +433,28 @@ def main():
         launches += k
     barrier()
     dt = time.perf_counter() - t0
-    from s3dp import dist as sd
     dt = sd.max_over_ranks(dt, device=dev)
-    # the only collective of the path: the final reduce of the counters (RCCL all-reduce of 5 numbers)
+    # the only collective of the path: the final reduce of the counters (RCCL all-reduce)
     tot = sd.reduce_counters({"reads": a.reads, "readsAligned": aligned, "alignments": n_occ, "rankQueries": cnt["rankQueries"],
                               "records": cnt["records"]}, device=dev)
-    total_reads = tot["reads"]
-    value = total_reads * a.steps / dt / 1e6
+    value = tot["reads"] * a.steps / dt / 1e6
+
+    # ---- streamed: upload of the packed reads and download of the results inside the timed region -------------
+    streamed = None
+    if hasattr(s3dp, "Stream") and a.streaming:
+        streamed = s3dp.stream_bench(ix, q, lens, wpq, a.mismatch, a.max_out, a.stream_batch, a.steps)
+        streamed["M_reads_per_s"] = sd.reduce_counters({"r": int(streamed["reads"])}, device=dev)["r"] / \
+            sd.max_over_ranks(streamed["seconds"], device=dev) / 1e6
 
     # ---- roofline of the search (stepping kernel + check-and-extend kernel: the two halves of one search pass) ----------------
-    # algorithmic bytes (extended by what check-and-extend reads since it became half of the pass): 32 B per rank query, 16 B per lookup
+    # algorithmic bytes: SURVEY.md 8d's formula (strict), and the same extended by what the lookup tables and check-and-extend read: 16 B per lookup
     # (one long-table entry, or the four 4-byte entries of the 13-mer tables), 4 B per suffix-array entry, 16 B per 32-character compare window
-    # (8 B of packed text + 8 B of the read), packed read + length per read, 12 B per record
-    bytes_step = 32.0 * cnt["rankQueries"] + 16.0 * cnt["ltLookups"] + 4.0 * cnt["saReads"] + 16.0 * cnt["ceWindows"] + \
-        a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
+    # (8 B of packed text + 8 B of the read)
+    bytes_strict = 32.0 * cnt["rankQueries"] + a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
+    bytes_step = bytes_strict + 16.0 * cnt["ltLookups"] + 4.0 * cnt["saReads"] + 16.0 * cnt["ceWindows"]
     search_s_per_step = (search_ms + ce_ms) / 1e3 / max(1, a.steps)
     achieved = bytes_step / search_s_per_step / 1e9 if search_s_per_step > 0 else 0.0
+    achieved_strict = bytes_strict / search_s_per_step / 1e9 if search_s_per_step > 0 else 0.0
     # HBM traffic of the two kernels comes from a separate rocprofv3 --pmc FETCH_SIZE pass (it cannot be collected from inside this process);
     # the committed measurement is attached when it was taken on exactly this workload, per launch like `achieved`
     traffic = None
@@ -342,12 +462,17 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             for w in json.load(f)["workloads"]:
                 if all(w[k] == v for k, v in (("genome_bp", a.genome_bp), ("reads_per_gpu", a.reads), ("read_len", a.read_len),
-                                              ("max_mismatch", a.mismatch), ("max_output_per_read", a.max_out), ("repeat_frac", a.repeat_frac))):
+                                              ("max_mismatch", a.mismatch), ("max_output_per_read", a.max_out), ("repeat_frac", repeat_frac))):
                     traffic = w["fetch_bytes_per_step"] / w["launches_per_step"]
     except (OSError, ValueError, KeyError):
         traffic = None
     n_launch = max(1, launches // max(1, a.steps))
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+    peak = peaks["copy_GBps"]
+    roof = {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": traffic,
+            "peak_is": "measured on this GPU at the start of the run (device-to-device copy, read + write bytes)",
+            "peak_spec": HBM_PEAK_GBS, "frac_of_spec": achieved / HBM_PEAK_GBS,
+            "achieved_strict": achieved_strict, "frac_strict": achieved_strict / peak,
+            "strict_is": "SURVEY.md 8d unextended: 32 B x rank queries + packed reads + 12 B x records",
             "traffic_unit": "bytes per launch pair (FETCH_SIZE of both kernels, profiles/pmc_traffic.json)",
             "algorithmic_bytes_per_launch": bytes_step / n_launch,
             "kernel": "s3::searchKernelV2 + s3::ceKernel", "launches_per_step": n_launch,
@@ -357,26 +482,22 @@ def main():
             "sa_reads_per_step": cnt["saReads"], "ce_windows_per_step": cnt["ceWindows"], "lt_lookups_per_step": cnt["ltLookups"],
             "rank_queries_per_step": cnt["rankQueries"]}
     if traffic:
-        # the path is made of random accesses with 4-32 B payloads; the GPU moves 64 B per access at ~50 G accesses/s (tools/hbm_probe.py), so the
-        # rate of fetched 64-byte lines is what tells how busy the memory system is
+        # the path is made of random accesses with 4-32 B payloads; the GPU moves 64 B per access (tools/hbm_probe.py), so the rate of fetched
+        # 64-byte lines against the probe measured in this run is what tells how busy the memory system is
         lines = traffic * n_launch / 64.0 / search_s_per_step / 1e9
-        roof["random_line_rate"] = {"achieved_Glines_per_s": lines, "probe_Glines_per_s": 50.0, "frac": lines / 50.0}
-
-    out = {"metric": "M reads/sec aligned (100 bp SE, GRCh38-scale synthetic genome)", "value": value, "unit": "M reads/s", "n_gpus": world,
-           "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-           "config": {"workload": "synthetic uniform-ACGT genome, full-SA 2BWT+GPU-2BWT index in HBM; 100 bp single-end reads, "
-                                  "0-4 substitutions (55/25/12/5/3 %), <=4 mismatch all-best ladder (-s 4 -h 2), DP off; "
-                                  "BASELINE.json configs[1] with GRCh38 replaced by a synthetic genome of the same scale",
-                      "genome_bp": a.genome_bp, "reads_per_gpu": a.reads, "read_len": a.read_len, "max_mismatch": a.mismatch,
-                      "max_output_per_read": a.max_out, "repeat_frac": a.repeat_frac, "parallelism": "reads sharded x%d, index replicated" % world,
+        roof["random_line_rate"] = {"achieved_Glines_per_s": lines, "probe_Glines_per_s": peaks["random_Glines_per_s"],
+                                    "frac": lines / peaks["random_Glines_per_s"]}
+    out = {"value": value, "ms_per_step": dt / a.steps * 1e3,
+           "config": {"workload": label, "genome_bp": a.genome_bp, "reads_per_gpu": a.reads, "read_len": a.read_len, "max_mismatch": a.mismatch,
+                      "max_output_per_read": a.max_out, "repeat_frac": repeat_frac, "repeat_families": families,
+                      "parallelism": "reads sharded x%d, index replicated" % world,
                       "lookup_chars": int(s3dp.lib().s3_index_lookup_chars(ix.h))},
-           "roofline": roof,
-           "aligned_reads": tot["readsAligned"], "occurrences": tot["alignments"],
+           "roofline": roof, "aligned_reads": tot["readsAligned"], "occurrences": tot["alignments"],
            "rank_queries_per_read": cnt["rankQueries"] / a.reads}
-
-    # ---- correctness spot check + CPU baseline (rank 0, N = 1) ------------------------------------------
+    if streamed:
+        out["streamed"] = streamed
     if rank == 0:
+        out["truth_check"] = truth_check(phase, offs, pos, strand, mis, tpos, tstrand, tsub, a.max_out)
         if a.check > 0:
             import s3o
             oix = s3o.Index(host_index=hi)
@@ -387,18 +508,101 @@ def main():
             out["oracle_check"] = {"reads": m, "bit_exact": bool(ok)}
             oix.close()
             if not ok:
-                raise SystemExit("bench.py: HIP result differs from the CPU oracle")
+                raise SystemExit("bench.py: HIP result differs from the CPU oracle (%s)" % label)
+        if not out["truth_check"]["ok"]:
+            raise SystemExit("bench.py: truth check failed (%s): %r" % (label, out["truth_check"]))
+    b.close()
+    return out, dict(ix=ix, hi=hi, codes=codes, q=q, lens=lens, wpq=wpq)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-bp", type=int, default=int(os.environ.get("S3DP_BENCH_GENOME_BP", 3_100_000_000)))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("S3DP_BENCH_READS", 10_000_000)), help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--mismatch", type=int, default=4)
+    ap.add_argument("--max-out", type=int, default=1000)
+    ap.add_argument("--repeat-frac", type=float, default=0.5, help="share of the genome planted with repeat families (GRCh38 is about one half)")
+    ap.add_argument("--uniform", type=int, default=1, help="N = 1 only: also run the repeat-free genome of round 1 (reported under extras)")
+    ap.add_argument("--streaming", type=int, default=1, help="also time the streamed form (uploads and downloads inside the timed region)")
+    ap.add_argument("--stream-batch", type=int, default=1 << 20, help="reads per streamed batch (the reference's batch, SOAP3-DP.cu:394)")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
+    ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle after the run")
+    ap.add_argument("--extras", type=int, default=1, help="after the timed region (N = 1): paired-end 2x150 BWT stage and DP kernel throughput")
+    a = ap.parse_args()
+
+    import torch
+    import s3dp
+    from s3dp import builder
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (for N > 1 launch one rank per GPU with torch.distributed.run)" % (a.gpus, world))
+    if not torch.cuda.is_available() or s3dp.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    index_dir = None
+    if world > 1:
+        import tempfile
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=dev)
+        box = [tempfile.mkdtemp(prefix="s3dp_bench_") if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        index_dir = box[0]
+
+    t_all = time.perf_counter()
+    peaks = measured_peaks(dev, local)
+    log("measured: copy %.0f GB/s, random 64-byte lines %.1f G/s" % (peaks["copy_GBps"], peaks["random_Glines_per_s"]))
+    label = "repeat-rich" if a.repeat_frac > 0 else "uniform"
+    res, keep = run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, a.repeat_frac, label, index_dir)
+    out = {"metric": "M reads/sec aligned (100 bp SE, GRCh38-scale synthetic genome)", "value": res["value"], "unit": "M reads/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u32", "data": "synthetic"}
+    res["config"]["workload"] = ("synthetic genome of GRCh38's size with GRCh38-like repeat families planted (%s), full-SA 2BWT+GPU-2BWT index in HBM; "
+                                 "100 bp single-end reads, 0-4 substitutions (55/25/12/5/3 %%), <=4 mismatch all-best ladder (-s 4 -h 2), DP off; "
+                                 "BASELINE.json configs[1] with GRCh38 replaced by a synthetic genome of the same scale" %
+                                 ("repeat_frac %.2f" % a.repeat_frac if a.repeat_frac > 0 else "none: uniform ACGT"))
+    out.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step")})
+    out["measured_peaks"] = peaks
+
+    if rank == 0:
         if world == 1 and a.cpu_budget > 0:
-            out["cpu_baseline"] = cpu_baseline(hi, q, lens, wpq, a.mismatch, a.max_out, a.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(keep["hi"], keep["q"], keep["lens"], keep["wpq"], a.mismatch, a.max_out, a.cpu_budget)
         if world == 1 and a.extras:
             try:
-                out["extras"] = extras(s3dp, ix, codes, dev, rank)
+                out["extras"] = extras(s3dp, keep["ix"], keep["codes"], dev, rank)
             except Exception as e:                                      # secondary figures must never cost the headline line
                 out["extras"] = {"error": repr(e)}
+    keep["ix"].close()
+    keep.clear()
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and a.uniform and a.repeat_frac > 0:
+        try:
+            a2 = argparse.Namespace(**vars(a))
+            a2.check = min(a.check, 1024)
+            a2.streaming = 0
+            ures, ukeep = run_workload(a2, s3dp, builder, dev, local, rank, world, dist, peaks, 0.0, "uniform")
+            ukeep["ix"].close()
+            out.setdefault("extras", {})["uniform_genome"] = ures
+        except Exception as e:
+            out.setdefault("extras", {})["uniform_genome"] = {"error": repr(e)}
+    if rank == 0:
         out["wall_s_total"] = time.perf_counter() - t_all
         print(json.dumps(out), flush=True)
-    b.close()
-    ix.close()
+    if index_dir and rank == 0:
+        import shutil
+        dist.barrier()
+        shutil.rmtree(index_dir, ignore_errors=True)
+    elif dist is not None:
+        dist.barrier()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,0 +1,34 @@
+"""bench.py's repeat-rich workload and its truth check, on the CPU: a small genome with the planted repeat families, reads simulated by bench.py,
+aligned by the oracle (the checker), judged by bench.truth_check.  Pins the conventions the check relies on (position = leftmost text position
+on the forward strand, strand 1 / 2) and that the check notices a wrong answer."""
+import numpy as np
+import torch
+
+import bench
+import s3dp
+import s3o
+from s3dp import builder
+
+
+def test_truth_check_on_a_repeat_rich_genome():
+    dev = torch.device("cpu")
+    codes, fam = bench.make_genome(1_500_000, 1, dev, 0.5)
+    assert fam["sine_alu_like"]["copies"] > 100
+    L, n = 100, 2048
+    reads2d, tpos, tstrand, tsub = bench.make_reads(codes, n, L, 7, dev)
+    wpq = s3dp.word_per_query(L)
+    q = bench.pack_on_device(reads2d, wpq)
+    lens = np.full(n, L, dtype=np.uint32)
+    hi = builder.build_host_index(codes.numpy(), device="cpu")
+    oix = s3o.Index(host_index=hi)
+    ph, we, off, pos, st, mis, _ = oix.align_single_allbest(q, lens, wpq, 4, 1000, first=0, count=n)
+    oix.close()
+    t = bench.truth_check(ph, off, pos, st, mis, tpos.numpy(), tstrand.numpy(), tsub.numpy().astype(np.int64), 1000)
+    assert t["ok"], t
+    assert t["true_place_reported"] > n * 0.9
+    assert t["multi_mapped_reads"] > 0          # the planted families make reads that map to several places
+    # a shifted answer must be noticed
+    bad = pos.copy()
+    bad[: len(bad) // 2] += 1
+    t2 = bench.truth_check(ph, off, bad, st, mis, tpos.numpy(), tstrand.numpy(), tsub.numpy().astype(np.int64), 1000)
+    assert not t2["ok"] and t2["true_place_missing"] > 0
