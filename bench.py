@@ -313,8 +313,9 @@ def cpu_baseline(hi, q, lens, wpq, mm, max_out, budget_s):
 
 def truth_check(phase, offs, pos, strand, mis, tpos, tstrand, tsub, max_out):
     """The simulated place of every read against what the ladder reported.  All-best reports the best stratum only, cut at MaxOutputPerRead,
-    so for every read with at most 4 substitutions: it must be aligned; its best hit has at most as many mismatches as were planted; and
-    when it has exactly that many (and the list was not cut) the true (position, strand) must be in the list."""
+    so for every read with at most 4 substitutions: it must be aligned; unless its list was cut at MaxOutputPerRead (the cut follows the search
+    order, not the mismatch count, so a cut list may lack the best hits -- reference behaviour, CPUfunctions.cpp:1612-1615) its best hit has at
+    most as many mismatches as were planted, and when it has exactly that many the true (position, strand) must be in the list."""
     n = len(phase)
     counts = np.diff(offs.astype(np.int64))
     ridx = np.repeat(np.arange(n, dtype=np.int64), counts)
@@ -327,7 +328,7 @@ def truth_check(phase, offs, pos, strand, mis, tpos, tstrand, tsub, max_out):
     aligned = counts > 0
     cut = counts >= max_out
     unaligned = int((~aligned).sum())
-    worse = int((aligned & (best > tsub)).sum())
+    worse = int((aligned & ~cut & (best > tsub)).sum())
     must = aligned & (best == tsub) & ~cut
     missing = int((must & ~found).sum())
     return {"reads": int(n), "unaligned": unaligned, "best_worse_than_planted": worse, "true_place_missing": missing,
