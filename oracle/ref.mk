@@ -71,9 +71,44 @@ $(OUT)/soap3-dp-builder: $(REF)/2bwt-flex/2BWT-Builder.c $(BWTOBJ) $(FLEXOBJ)
 $(OUT)/BGS-Build: $(REF)/BGS-Build.cpp $(BWTOBJ)
 	$(CXX) $(FLAGS) $< $(BWTOBJ) -lm -o $@
 
+# The reference's DP ENGINES: the host halves of DV-DPfunctions.cu (lines 742-3911: packers, decode, CIGAR encoder, seeding, candidate merges,
+# output filters, the thread plumbing) and their callers DV-SemiDP.cu / DV-DPForBothUnalign.cu / DV-DPForSingleReads.cu are plain C++ once the CUDA
+# runtime calls are out of the way.  They are streamed through sed into g++ from where they lie; the edits, all deletions of CUDA-only lines
+# except one, are:
+#   DV-DPfunctions.h   `#include <cuda.h>`, `static cudaError_t gpuErr;`, `cudaEvent_t start, stop;` (TimeRecorder, unused), the five
+#                      `CUcontext ctx;` members, the four `cudaFree ( _x );` lines of SOAP3Wrapper::freeIndex  -- written to obj/dpinc/ (never into the
+#                      repository), because the .cu files include it by name
+#   alignment.h        `#include "DV-Kernel.h"` (kernel prototypes with __global__ / __constant__)                 -- obj/dpinc/ likewise
+#   DV-DPfunctions.cu  lines 1-741 are not used (includes, the device code -- built for gfx950 into libdpref.so below -- and SemiGlobalAligner's
+#                      cudaMalloc / cudaMemcpy / launch code, whose contract oracle/ref_dp_glue.cpp implements on host memory); the 22
+#                      `cuCtxPushCurrent / cuCtxPopCurrent` lines (context hand-over between host threads); and line 2326, which names the type
+#                      through the constructor (`HalfEndAlignmentEngine::HalfEndAlignmentEngine *`): g++ >= 5 rejects that, the class name is used
+#   DV-DPForSingleReads.cu  `#include <cuda.h>`
+# No stand-in headers or libraries are written.
+DPINC := $(OBJ)/dpinc
+$(DPINC)/DV-DPfunctions.h: $(REF)/DV-DPfunctions.h | $(OBJ)
+	mkdir -p $(DPINC)
+	sed -e '/#include <cuda.h>/d' -e '/^static cudaError_t gpuErr;/d' -e '/cudaEvent_t start, stop;/d' -e '/^ *CUcontext ctx;/d' -e '/^ *cudaFree ( _[a-zA-Z]* );$$/d' $< > $@
+$(DPINC)/alignment.h: $(REF)/alignment.h | $(OBJ)
+	mkdir -p $(DPINC)
+	sed -e '/#include "DV-Kernel.h"/d' $< > $@
+DPHDR := $(DPINC)/DV-DPfunctions.h $(DPINC)/alignment.h
+$(OBJ)/dp_host.o: $(REF)/DV-DPfunctions.cu $(DPHDR)
+	( echo '#include "DV-DPfunctions.h"'; echo '#include "OutputDPResult.h"'; echo '#include <assert.h>'; echo '#include <algorithm>'; echo 'using namespace std;'; \
+	  sed -n '742,3911p' $< | sed -e '/cuCtxPopCurrent\|cuCtxPushCurrent/d' \
+	      -e 's/^HalfEndAlignmentEngine::HalfEndAlignmentEngine \* HalfEndAlignmentEngine::engine;/HalfEndAlignmentEngine * HalfEndAlignmentEngine::engine;/' ) | \
+	$(CXX) $(FLAGS) -I$(DPINC) -I$(REF) -x c++ -c - -o $@
+$(OBJ)/dp_%.o: $(REF)/DV-%.cu $(DPHDR)
+	sed -e '/#include <cuda.h>/d' $< | $(CXX) $(FLAGS) -I$(DPINC) -I$(REF) -x c++ -c - -o $@
+DPOBJ := $(OBJ)/dp_host.o $(OBJ)/dp_SemiDP.o $(OBJ)/dp_DPForBothUnalign.o $(OBJ)/dp_DPForSingleReads.o
+$(OBJ)/glue.o: oracle/ref_dp_glue.cpp $(DPHDR)
+	$(CXX) $(FLAGS) -I$(DPINC) -I$(REF) -c $< -o $@
+$(OBJ)/oracle_dp.o: oracle/s3_oracle_dp.c | $(OBJ)
+	$(CC) -O2 -c $< -o $@
+
 # our driver around the reference's CPU alignment path
-$(OUT)/ref_harness: oracle/ref_harness.cpp $(HOSTOBJ) $(BWTOBJ) $(FLEXOBJ) $(SAMOBJ)
-	$(CXX) $(FLAGS) -I$(REF) $< $(HOSTOBJ) $(filter-out $(OBJ)/lib_BWTConstruct.o,$(BWTOBJ)) $(FLEXOBJ) $(SAMOBJ) -lz -lm -lpthread -o $@
+$(OUT)/ref_harness: oracle/ref_harness.cpp $(HOSTOBJ) $(BWTOBJ) $(FLEXOBJ) $(SAMOBJ) $(DPOBJ) $(OBJ)/glue.o $(OBJ)/oracle_dp.o
+	$(CXX) $(FLAGS) -I$(REF) $< $(DPOBJ) $(OBJ)/glue.o $(OBJ)/oracle_dp.o $(HOSTOBJ) $(filter-out $(OBJ)/lib_BWTConstruct.o,$(BWTOBJ)) $(FLEXOBJ) $(SAMOBJ) -lz -lm -lpthread -o $@
 
 # The reference's semi-global DP DEVICE code (DV-DPfunctions.cu:35-512) built for gfx950 with hipcc -- CUDA and HIP share the kernel language.
 # The region is streamed out of the reference file (never copied into the repository; obj/ does not travel to the GPU box either), with

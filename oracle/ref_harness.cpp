@@ -14,6 +14,9 @@
 //   sam    <ini> single <index> <reads> [soap3-dp options]   all-best / all-valid single-end SAM
 //          (mirrors all_best_single_alignment, alignment.cu:1422-1465, and all_valid_alignment,
 //           alignment.cu:534-1115, with every (read,case) answer marked "resolve on CPU")
+//          With the DP stages on (no -s) the reference's own DP engines run behind the ladder (soap3_dp_pair_align /
+//          soap3_dp_single_align, alignment.cu:1896-2700): new default DP, default DP, deep DP, single-end DP of the leftovers;
+//          they are the reference's host code compiled by oracle/ref.mk, with oracle/ref_dp_glue.cpp in the device's place.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,6 +32,11 @@
 #include "SAM.h"
 #include "OutputDPResult.h"
 #include "2bwt-lib/Timing.h"
+#include "DV-SemiDP.h"
+#include "DV-DPForBothUnalign.h"
+#include "DV-DPForSingleReads.h"
+
+void refDpDumpNote ( const char * line );      // oracle/ref_dp_glue.cpp
 
 // defined (non-static) in CPUfunctions.cpp but not declared in its header
 unsigned long long ProcessReadDoubleStrand2 ( SRAQueryInput * qInput, SRAQueryInput * qInput_neg, SRAModel * aModel, SRAModel * aModel_neg,
@@ -327,6 +335,7 @@ struct Ctx
     // pairs with the DP stages on: where hostKernel's needProceedDP branch (CPUfunctions.cpp:2153-2262, 2444-2543) sends what it cannot pair
     ReadInputForDP * dpInput, * dpInputNew, * otherSoap3;
     BothUnalignedPairs * bothUnaligned;
+    BothUnalignedPairsArrays * bothUnalignedArrays;
 };
 
 static void allValid ( Ctx & C, Reads & R, uint * queries, uint * readLengths, uint * seedLengths, uint * readIDs, uint numQueries, uint numMismatch,
@@ -369,8 +378,9 @@ static void allValid ( Ctx & C, Reads & R, uint * queries, uint * readLengths, u
     if ( C.dpInput )
     {
         hk[0].readInput = C.dpInput; hk[0].readInputForNewDefault = C.dpInputNew; hk[0].otherSoap3Result = C.otherSoap3;
-        hk[0].bothUnalignedPairs = C.bothUnaligned;
     }
+
+    if ( C.bothUnaligned ) { hk[0].bothUnalignedPairs = C.bothUnaligned; }
 
     hk[0].sraQuerySettings.SAMOutFilePtr = C.samOut;
     uint * lens = seedLengths ? seedLengths : readLengths;
@@ -580,12 +590,28 @@ static int modeSam ( int argc, char ** argv )
 
     C.dpInput = C.dpInputNew = C.otherSoap3 = NULL;
     C.bothUnaligned = NULL;
+    C.bothUnalignedArrays = NULL;
     std::vector<uint> origID ( R.readIDs, R.readIDs + R.numQueries );      // packUnPairedReads renumbers the reads between phases
+    uint d1 = 0, d2 = 0;
+    bool skipSoap3 = false;
+
+    // SOAP3-DP.cu:620-686: what the detected read lengths switch
+    if ( paired ) { d1 = GetReadLength ( R.readLengths, R.numQueries, 2 ); d2 = GetReadLength ( R.readLengths + 1, R.numQueries, 2 ); }
+    else { d1 = GetReadLength ( R.readLengths, R.numQueries, 1 ); }
+
+    if ( C.opt.enableDP == 1 && ( d1 < MIN_READ_LEN_FOR_DP || ( paired && d2 < MIN_READ_LEN_FOR_DP ) ) ) { C.opt.enableDP = 0; }
+    else if ( C.opt.enableDP == 1 && paired && ( d1 > 150 || d2 > 150 ) ) { skipSoap3 = true; }
+
+    if ( C.opt.enableDP == 0 && C.opt.numMismatch == -1 ) { C.opt.numMismatch = getDefaultMismatchNum ( d1 ); }
+
+    if ( !paired && C.opt.enableDP == 1 )
+    {
+        C.bothUnalignedArrays = constructBothUnalignedPairsArrays ( 1 );
+        C.bothUnaligned = C.bothUnalignedArrays->array[0];
+    }
 
     if ( paired && C.opt.enableDP == 1 )
     {
-        uint d1 = GetReadLength ( R.readLengths, R.numQueries, 2 ), d2 = GetReadLength ( R.readLengths + 1, R.numQueries, 2 );
-
         if ( C.opt.insert_low < ( int ) d2 ) { C.opt.insert_low = d2; }     // SOAP3-DP.cu:632-634
 
         if ( d1 <= 50 || d2 <= 50 ) { C.opt.numMismatch = 1; }
@@ -593,7 +619,8 @@ static int modeSam ( int argc, char ** argv )
         C.opt.maxHitNum = getMaxHitNumForDefaultDP ( d1 );
         C.opt.maxHitNum2 = getMaxHitNumForDefaultDP ( d2 );
         C.dpInput = constructReadInputForDP ( 1 ); C.dpInputNew = constructReadInputForDP ( 1 ); C.otherSoap3 = constructReadInputForDP ( 1 );
-        C.bothUnaligned = constructBothUnalignedPairs ();
+        C.bothUnalignedArrays = constructBothUnalignedPairsArrays ( 2 );    // [0]: the host kernel's thread, [1]: what the default DP stages pass on
+        C.bothUnaligned = C.bothUnalignedArrays->array[0];
         memset ( hspaux->x0_array, 0, roundUp * sizeof ( int ) ); memset ( hspaux->x1_array, 0, roundUp * sizeof ( int ) );
         memset ( hspaux->mismatch_array, 0, roundUp * sizeof ( int ) );
         memset ( hspaux->sa_num, 0, roundUp * sizeof ( unsigned int ) ); memset ( hspaux->occ_num, 0, roundUp * sizeof ( unsigned int ) );
@@ -606,7 +633,12 @@ static int modeSam ( int argc, char ** argv )
     uint totalAligned = 0;
     double t0 = setStartTime ();
 
-    if ( paired )
+    if ( skipSoap3 )
+    {
+        // alignment.cu:1929-1933: paired reads above 150 bases skip the BWT stage, every pair goes to the deep DP
+        addAllFirstReadIDToBothUnalignedPairs ( C.bothUnaligned, R.numQueries );
+    }
+    else if ( paired )
     {
         // soap3_dp_pair_align with DP disabled (alignment.cu:1965-2013): all-best + SAM = all_best_alignment (phases 1, 2, k; :1236-1376),
         // unique / random best = four_phases_alignment (phases 0, 1, 2, k; :1119-1234), all valid = one pass at k
@@ -738,6 +770,112 @@ static int modeSam ( int argc, char ** argv )
         for ( size_t i = 0; i < un.size (); i++ ) { fprintf ( f, "U %u\n", un[i] ); }
 
         fclose ( f );
+    }
+
+    // -----------------------------------------------------------------------------------------------------------------------------
+    // the DP stages behind the ladder: the sequencing of soap3_dp_pair_align (alignment.cu:2014-2446) and soap3_dp_single_align
+    // (alignment.cu:2558-2690), calling the reference's own engines (REF_HARNESS_NO_DP=1 stops after the routing dump)
+    if ( C.opt.enableDP == 1 && getenv ( "REF_HARNESS_NO_DP" ) == NULL )
+    {
+        std::string dpName = std::string ( C.opt.outputPrefix ) + ".dpout.1", unName = std::string ( C.opt.outputPrefix ) + ".unpair";
+        samfile_t * samDP = samopen ( dpName.c_str (), "wh", &samHeader );
+        InputOptions o = C.opt;
+
+        if ( o.alignmentType == OUTPUT_ALL_BEST && o.outputFormat == SRA_OUTPUT_FORMAT_SAM_API ) { o.alignmentType = OUTPUT_ALL_VALID; }
+
+        IniParams ini = C.ini;
+        const char * th = getenv ( "REF_HARNESS_DP_THREADS" );
+        ini.Ini_NumOfCpuThreads = th ? atoi ( th ) : 1;
+        DPParameters dp;
+        memset ( &dp, 0, sizeof ( dp ) );
+        getParameterForAllDP ( dp, o, ini );
+        unsigned int nRead = 0, nAlg = 0;
+
+        if ( paired )
+        {
+            samfile_t * samUn = samopen ( unName.c_str (), "wh", &samHeader );
+            ReadInputForDPArrays arrNew, arrDef;
+            arrNew.inputArrays = &C.dpInputNew; arrNew.numArrays = 1;
+            arrDef.inputArrays = &C.dpInput; arrDef.numArrays = 1;
+
+            if ( !skipSoap3 )
+            {
+                getParameterForNewDefaultDP ( dp, o, ini, d1, d2 );
+                refDpDumpNote ( "new default DP" );
+
+                if ( C.dpInputNew->readNum > 0 )
+                {
+                    newSemiGlobalDP ( &arrNew, o.insert_high, o.insert_low, R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities,
+                                      C.opt.maxReadLength, C.ini.Ini_PEStrandLeftLeg, C.ini.Ini_PEStrandRightLeg, C.index, NULL, NULL, NULL, NULL,
+                                      o.alignmentType, &dp, nRead, nAlg, 0, o.outputFormat, NULL, samDP, C.bothUnalignedArrays->array[1] );
+                    fprintf ( stderr, "[harness] new default DP: %u pairs in, %u aligned\n", C.dpInputNew->readNum, nRead );
+                }
+            }
+
+            getParameterForDefaultDP ( dp, o, ini, d1, d2 );
+            refDpDumpNote ( "default DP" );
+
+            if ( C.dpInput->readNum > 0 )
+            {
+                nRead = nAlg = 0;
+                semiGlobalDP2 ( &arrDef, o.insert_high, o.insert_low, R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities,
+                                C.opt.maxReadLength, C.ini.Ini_PEStrandLeftLeg, C.ini.Ini_PEStrandRightLeg, C.index, NULL, NULL, NULL, NULL,
+                                o.alignmentType, &dp, nRead, nAlg, 0, o.outputFormat, NULL, samDP, C.bothUnalignedArrays->array[1] );
+                fprintf ( stderr, "[harness] default DP: %u pairs in, %u aligned\n", C.dpInput->readNum, nRead );
+            }
+
+            getParameterForDeepDP ( dp, o, ini, d1, d2 );
+            refDpDumpNote ( "deep DP" );
+            unsigned int toDeep = C.bothUnalignedArrays->array[0]->totalNum + C.bothUnalignedArrays->array[1]->totalNum;
+
+            if ( toDeep > 0 )
+            {
+                nRead = nAlg = 0;
+                DPForUnalignPairs2 ( C.bothUnalignedArrays, o.insert_high, o.insert_low, R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities,
+                                     C.opt.maxReadLength, C.ini.Ini_PEStrandLeftLeg, C.ini.Ini_PEStrandRightLeg, C.index, NULL, NULL, NULL, NULL,
+                                     o.alignmentType, &dp, nRead, nAlg, 0, o.outputFormat, NULL, samDP );
+                fprintf ( stderr, "[harness] deep DP: %u pairs in, %u aligned\n", toDeep, nRead );
+            }
+
+            // single-end DP of the ends of the pairs no stage could pair (alignment.cu:2368-2444)
+            if ( o.outputFormat == SRA_OUTPUT_FORMAT_SAM_API )
+            {
+                o.readType = SINGLE_READ;
+                getParameterForSingleDP ( dp, o, ini, d1 );
+                hspaux->singleDPcutoffThreshold = dp.paramRead[0].cutoffThreshold;
+                UnalignedSinglesArrays * us = ( UnalignedSinglesArrays * ) hspaux->readsIDForSingleDP;
+                refDpDumpNote ( "single-end DP of leftover ends" );
+                fprintf ( stderr, "[harness] single-end DP: %u ends in\n", us->array[0]->totalNum );
+
+                if ( us->array[0]->totalNum > 0 )
+                {
+                    nRead = nAlg = 0;
+                    DPForUnalignSingle2 ( us, R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities, C.opt.maxReadLength, C.index,
+                                          NULL, NULL, NULL, NULL, o.alignmentType, &dp, nRead, nAlg, 0, o.outputFormat, NULL, samUn );
+                    sortReadPtrs ( ( AllHits * ) hspaux->allHits );
+                    outputSingleResultForPairEnds ( ( AllHits * ) hspaux->allHits, R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities,
+                                                    C.opt.maxReadLength, 0, o.outputFormat, samUn, C.index );
+                }
+            }
+
+            samclose ( samUn );
+        }
+        else
+        {
+            getParameterForSingleDP ( dp, o, ini, d1 );
+            hspaux->singleDPcutoffThreshold = dp.paramRead[0].cutoffThreshold;
+            refDpDumpNote ( "single-end DP" );
+            fprintf ( stderr, "[harness] single-end DP: %u reads in\n", C.bothUnaligned->totalNum );
+
+            if ( C.bothUnaligned->totalNum > 0 )
+            {
+                DPForUnalignSingle2 ( C.bothUnalignedArrays, R.queries, R.readLengths, R.readIDs, R.upkdQueryNames, R.upkdQualities, C.opt.maxReadLength, C.index,
+                                      NULL, NULL, NULL, NULL, o.alignmentType, &dp, nRead, nAlg, 0, o.outputFormat, NULL, samDP );
+                fprintf ( stderr, "[harness] single-end DP: %u aligned\n", nRead );
+            }
+        }
+
+        samclose ( samDP );
     }
 
     return 0;

@@ -385,21 +385,17 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
         if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
         {
-            // S3DP_KERNEL=v1 selects the first-generation one-thread-per-item kernel (kept for A/B measurements)
-            static const bool useV1 = [] { const char *e = getenv("S3DP_KERNEL"); return e && strcmp(e, "v1") == 0; }();
             static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", S3_V2_WAVES_PER_SIMD);
-            // S3DP_CE=inline keeps check-and-extend inside the stepping kernel (the first form of the v2 kernel, for A/B measurements)
-            static const bool splitCe = [] { const char *e = getenv("S3DP_CE"); return !(e && strcmp(e, "inline") == 0); }();
-            if (useV1) launchSearch(b->ix->d, in, out, 256u * 8u * 4u, b->stream);
-            else launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, splitCe, b->stream);
-            if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
-            if (!useV1 && splitCe) {
-                // the task records end where the stepping kernel stopped writing; the check-and-extend kernel appends behind them
-                HIPCHK(hipMemcpyAsync(b->dTaskEnd, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
-                if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2], b->stream));
-                launchCheckExtend(b->ix->d, in, out, b->dTaskEnd, b->stream);
-                if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2 + 1], b->stream));
+            {
+                const hipError_t le = (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
+                if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
             }
+            if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
+            // the task records end where the stepping kernel stopped writing; the check-and-extend kernel appends behind them
+            HIPCHK(hipMemcpyAsync(b->dTaskEnd, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
+            if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2], b->stream));
+            launchCheckExtend(b->ix->d, in, out, b->dTaskEnd, b->stream);
+            if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2 + 1], b->stream));
         }
         // offsets of the items in the ordered array (the scan runs before the host looks at the flags: one synchronisation per pass for both answers)
         HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, 4, b->stream));
@@ -541,8 +537,6 @@ extern "C" int s3_batch_last_ce_timing(s3_batch *b, float *ceMs, uint32_t *ceLau
     float s = 0;
     uint32_t timed = b->ceLaunches;
     if (timed * 2 > b->evCe.size()) timed = (uint32_t)(b->evCe.size() / 2);
-    static const bool splitCe = [] { const char *e = getenv("S3DP_CE"); return !(e && strcmp(e, "inline") == 0); }();
-    if (!splitCe) timed = 0;
     for (uint32_t i = 0; i < timed; i++) {
         float x = 0;
         HIPCHK(hipEventElapsedTime(&x, b->evCe[2 * i], b->evCe[2 * i + 1]));

@@ -75,6 +75,65 @@ extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLe
     return S3_OK;
 }
 
+// S3DP_DUMP_DP=<file>: every DP problem the engines submit, inputs as the packers built them and outputs as the decode stage receives them, one
+// line per problem in the format of the reference-side dump (oracle/ref_dp_glue.cpp; tests/golden/*/dp_problems*.txt.gz):
+//   P <readLen> <windowLen> <clipLt> <clipRt> <anchorL> <anchorR> <cutoff> <read> <window> | <score> <hitLoc> <ties> <ops>
+static FILE *dpDumpFile()
+{
+    static FILE *f = nullptr;
+    static bool tried = false;
+    if (!tried) { const char *p = getenv("S3DP_DUMP_DP"); f = p && *p ? fopen(p, "w") : nullptr; tried = true; }
+    return f;
+}
+
+void s3i::dpDumpNote(const char *line)
+{
+    if (FILE *f = dpDumpFile()) { fprintf(f, "# %s\n", line); fflush(f); }
+}
+
+int s3i::dpDump(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR)
+{
+    FILE *f = dpDumpFile();
+    if (!f || !n) return S3_OK;
+    const size_t rnd = ((size_t)n + 31) / 32 * 32;
+    const uint32_t wD = (h->maxDNA + 15) / 16, wR = (h->maxRead + 15) / 16;
+    std::vector<uint32_t> dna(rnd * wD), rd(rnd * wR), dl(n), rl(n), cl(n, 0), al(n, h->maxDNA), ar(n, 0), hit(n), cnt(n);
+    std::vector<int32_t> cut(n), sc(n);
+    std::vector<uint8_t> pat((size_t)n * h->patternLen);
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(dna.data(), h->dDna, dna.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(rd.data(), h->dReads, rd.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(dl.data(), h->dDnaLen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(rl.data(), h->dReadLen, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (hasClipLt) HIPCHK(hipMemcpyAsync(cl.data(), h->dClipLt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (hasAL) HIPCHK(hipMemcpyAsync(al.data(), h->dAL, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (hasAR) HIPCHK(hipMemcpyAsync(ar.data(), h->dAR, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(cut.data(), h->dCut, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(sc.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (uint32_t t = 0; t < n; t++) {
+        const size_t rb = (size_t)(t >> 5) * (wR << 5) + (t & 31), db = (size_t)(t >> 5) * (wD << 5) + (t & 31);
+        fprintf(f, "P %u %u %u %u %u %u %d ", rl[t], dl[t], cl[t], hasClipRt && t < h->dumpClipRt.size() ? h->dumpClipRt[t] : 0u, al[t], ar[t], cut[t]);
+        for (uint32_t i = 1; i <= rl[t]; i++) fputc("ACGT"[(rd[rb + ((size_t)(i >> 4) << 5)] >> ((15 - (i & 15)) << 1)) & 3], f);
+        fputc(' ', f);
+        for (uint32_t i = 1; i <= dl[t]; i++) fputc("ACGT"[(dna[db + ((size_t)(i >> 4) << 5)] >> ((15 - (i & 15)) << 1)) & 3], f);
+        fprintf(f, " | %d %u %u ", sc[t], hit[t], cnt[t]);
+        if (sc[t] >= cut[t]) {
+            const uint8_t *p = pat.data() + (size_t)t * h->patternLen;
+            for (uint32_t k = 0; p[k]; k++) {
+                if (p[k] == 'V') { fprintf(f, "(%u)", (unsigned)p[++k]); if (p[k] == 0) break; }
+                else fputc(p[k], f);
+            }
+        } else fputc('*', f);
+        fputc('\n', f);
+    }
+    fflush(f);
+    return S3_OK;
+}
+
 // launch the DP kernels on what is in the aligner's device buffers
 int s3i::dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR)
 {
@@ -89,6 +148,10 @@ int s3i::dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL,
     a.ldsPerWave = (((h->maxDNA + 1u + 15u) & ~15u) + (h->maxDNA + 1u) * 12u + 15u) & ~15u;
     a.match = h->sc.matchScore; a.mismatch = h->sc.mismatchScore; a.gapOpen = h->sc.gapOpenScore; a.gapExtend = h->sc.gapExtendScore; a.scheme = h->scheme;
     if ((size_t)a.ldsPerWave * 4 > 160 * 1024) return fail(S3_EINVAL, "s3_dp_align: maxDNALength too large for the LDS-resident window");
+    if (dpDumpFile()) {
+        h->dumpClipRt.assign(n, 0);
+        if (hasClipRt) { HIPCHK(hipMemcpyAsync(h->dumpClipRt.data(), h->dClipRt, (size_t)n * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
+    }
     HIPCHK(hipEventRecord(h->ev[0], s));
     launchDp(a, s);
     HIPCHK(hipEventRecord(h->ev[1], s));
@@ -285,6 +348,7 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
         HIPCHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if ((rc = dpDump(h, n, true, true, true, true))) return rc;
         // algnmtCPUThread (:2329-2441)
         decodeParallel<s3_dp_half_result>(n, results, pool, [&](uint32_t id, std::vector<s3_dp_half_result> &results, std::string &pool) {
             s3_dp_half_result r{};
@@ -445,6 +509,7 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
         ECHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
         ECHK(hipStreamSynchronize(s));
 #undef ECHK
+        if ((rc = dpDump(h, n, true, true, false, false))) break;
         decodeParallel<s3_dp_single_result>(n, results, pool, [&](uint32_t i, std::vector<s3_dp_single_result> &results, std::string &pool) {
             if (scores[i] < cutoffThreshold) return;
             CigarEnc enc;
@@ -671,7 +736,7 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
         ECHK(hipMemcpyAsync(R.cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         ECHK(hipMemcpyAsync(R.pat.data(), h->dPattern, R.pat.size(), hipMemcpyDeviceToHost, s));
         ECHK(hipStreamSynchronize(s));
-        return S3_OK;
+        return dpDump(h, n, true, true, true, true);
     };
     auto window = [&](uint32_t pos, uint32_t readLength, uint32_t &start, uint32_t &len) {
         const uint32_t margin = readLength > 100 ? readLength >> 2 : 25;

@@ -92,6 +92,7 @@ struct s3_dp {
     unsigned char *dPattern = nullptr;
     size_t tableWords = 0;
     bool timed = false;
+    std::vector<uint32_t> dumpClipRt;      // S3DP_DUMP_DP: the right clips as the packer set them (the kernel overwrites them)
 };
 
 namespace s3i {
@@ -145,4 +146,7 @@ int seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<SeedD
                    std::vector<uint64_t> &keysSorted, std::vector<uint8_t> &seedStatus);
 // DP (s3dp_dpapi.hip): launch the DP kernels on what is in the aligner's device buffers
 int dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR);
+// S3DP_DUMP_DP=<file> (tests): the problems of the last dpRun with their results, and stage separators
+int dpDump(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR);
+void dpDumpNote(const char *line);
 }  // namespace s3i

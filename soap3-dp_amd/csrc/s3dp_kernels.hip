@@ -1,4 +1,5 @@
-// s3dp_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X): 2BWT exact / k-mismatch search.
+// s3dp_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X) around the 2BWT search: index re-layout, read orientation, long lookup
+// tables, record ordering, per-read merge, SA decode.  The search itself is s3dp_search_v2.hip.
 //
 // What is computed is fixed by the reference's CPU path (BGS-HostAlgnmtAlgo2.cpp driven by the
 // SRA2BWTMdl.c case tables): same cases, same DFS order, same lookup-table start, same
@@ -63,303 +64,6 @@ __device__ __forceinline__ uint4 rankAll(const DevBwt &b, uint32_t i)
 }
 
 __device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
-
-// ---------------------------------------------------------------------------------------------
-// per-lane search state
-// ---------------------------------------------------------------------------------------------
-struct Range { uint32_t fl, fr, rl, rr; };            // forward-index range, reverse-index range (equal sizes)
-
-struct Frame {
-    Range   g;
-    int16_t s, i;
-    int8_t  ins, occ;
-    int16_t pad;
-};
-
-#define S3_STACK 24
-
-struct Lane {
-    const DevIndex *ix;
-    const S3Case   *cs;
-    const uint32_t *rd;          // LDS: oriented read, word w at rd[w * stride]
-    uint32_t        stride;
-    uint32_t        maxOut, total;
-    uint32_t        seq;
-    uint32_t        cntIdx;      // read-major item id: (slot * nCases + case) * 2 + strandIdx
-    uint32_t        strand;      // 1 '+', 2 '-'
-    SearchOut       out;
-    // tallies
-    uint32_t        nRank, nLt, nSa, nCe;
-};
-
-__device__ __forceinline__ uint32_t readChar(const Lane &L, int pos)
-{
-    return (L.rd[(uint32_t)(pos >> 4) * L.stride] >> ((pos & 15) * 2)) & 3u;
-}
-
-__device__ __forceinline__ void emit(Lane &L, uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis)
-{
-    const uint32_t slot = atomicAdd(L.out.recCount, 1u);            // hipcc folds this into one atomic per wave
-    if (slot < L.out.recCap) {
-        uint4 r;
-        r.x = L.cntIdx;
-        r.y = L.seq | (kind << 24) | (nmis << 25);
-        r.z = a; r.w = b;
-        L.out.recs[slot] = r;
-    } else atomicOr(L.out.flags, S3_FLAG_REC_OVERFLOW);
-    L.seq++;
-}
-
-// 32 text characters from position pos, MSB first; beyond the text is zero padding (TextConverter.c:696-701)
-__device__ __forceinline__ uint64_t text64(const DevIndex &ix, uint32_t pos)
-{
-    const uint32_t idx = pos >> 4, sh = pos & 15;
-    if ((size_t)idx + 2 >= ix.pacWords) return 0;
-    uint64_t w = ((uint64_t)ix.pac[idx] << 32) | ix.pac[idx + 1];
-    if (sh) { w <<= 2 * sh; w |= ix.pac[idx + 2] >> (2 * (16 - sh)); }
-    return w;
-}
-
-__device__ int ceMismatches(Lane &L, uint32_t tpos, int left, int len)
-{
-    int mm = 0;
-    for (int o = 0; o < len; o += 32) {
-        const int chunk = len - o > 32 ? 32 : len - o;
-        uint64_t key = 0;
-        for (int j = 0; j < chunk; j++) key = (key << 2) | readChar(L, left + o + j);
-        uint64_t t = text64(*L.ix, tpos + (uint32_t)o);
-        if (chunk < 32) t >>= 64 - 2 * chunk;
-        uint64_t x = t ^ key;
-        x = (x | (x >> 1)) & 0x5555555555555555ULL;
-        mm += __popcll(x);
-        L.nCe++;
-    }
-    return mm;
-}
-
-// check and extend: verify every suffix of a small SA range directly against the packed text
-// (BWTMismatchModelAnyDirection_CE2, BGS-HostAlgnmtAlgo2.cpp:36-176).  Candidates are independent, so they
-// are taken one at a time in SA order -- the same order in which the reference appends survivors.
-__device__ void checkAndExtend(Lane &L, int s, int i, int inserted, uint32_t l, uint32_t r, int occMis)
-{
-    if (L.total >= L.maxOut) return;
-    const S3Case &cs = *L.cs;
-    const S3Step &st0 = cs.st[s];
-    const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i;
-    for (uint32_t q = l; q <= r; q++) {
-        const uint32_t rp = L.ix->sa[q] - (uint32_t)leftAlign;     // 32-bit wrap, as in the reference
-        L.nSa++;
-        int acc = occMis, ii = i, ins = inserted;
-        bool ok = true;
-        for (int t = s; t < cs.nSteps; t++) {
-            const S3Step &st = cs.st[t];
-            const int pos = st.start + st.dir * ii;
-            const int left = pos < st.end ? pos : st.end, right = pos < st.end ? st.end : pos;
-            int mce;
-            if (rp + (uint32_t)left > L.ix->n) mce = 16;          // MAX_NUM_OF_ERROR + 1 (:122-125)
-            else mce = ceMismatches(L, rp + (uint32_t)left, left, right - left + 1);
-            const int tot = mce + ins;
-            if (tot < st.minErr || tot > st.maxErr) { ok = false; break; }
-            acc += tot; ii = 0; ins = 0;
-        }
-        if (ok) {
-            emit(L, 1, rp, rp, (uint32_t)acc);
-            if (++L.total >= L.maxOut) return;
-        }
-        if (q == 0xFFFFFFFFu) break;
-    }
-}
-
-__device__ __forceinline__ void stepRanks(Lane &L, int dir, const Range &g, uint4 &oL, uint4 &oR)
-{
-    const DevBwt &b = dir < 0 ? L.ix->fwd : L.ix->rev;
-    oL = rankAll(b, dir < 0 ? g.fl : g.rl);
-    oR = rankAll(b, (dir < 0 ? g.fr : g.rr) + 1u);
-    L.nRank += 2;
-}
-
-__device__ __forceinline__ Range childRange(int dir, const Range &g, const uint4 &oL, const uint4 &oR, uint32_t ch)
-{
-    // active range advances by rank; passive range shrinks by the occurrences of the larger symbols
-    const uint32_t al = sel4(oL, ch) + 1u, ar = sel4(oR, ch);
-    uint32_t oc = 0;
-    if (ch < 3) oc += oR.w - oL.w;
-    if (ch < 2) oc += oR.z - oL.z;
-    if (ch < 1) oc += oR.y - oL.y;
-    const uint32_t pr = (dir < 0 ? g.rr : g.fr) - oc, pl = pr - (ar - al);
-    Range o;
-    if (dir < 0) { o.fl = al; o.fr = ar; o.rl = pl; o.rr = pr; }
-    else { o.rl = al; o.rr = ar; o.fl = pl; o.fr = pr; }
-    return o;
-}
-
-__device__ __forceinline__ uint32_t ltRange(Lane &L, const uint32_t *tab, int tableSize, int from, int n, int stride, uint32_t &rOut)
-{
-    uint32_t lp = 0;
-    for (int k = 0; k < n; k++) lp = (lp << 2) | readChar(L, from + k * stride);
-    uint32_t rp = lp;
-    for (int k = n; k < tableSize; k++) { lp <<= 2; rp = (rp << 2) | 3u; }
-    L.nLt += 2;
-    rOut = tab[rp];
-    return lp ? tab[lp - 1] + 1u : 1u;
-}
-
-// One (read, case, strand) item: lookup-table start, exact continuation of step 0, then an explicit-stack
-// DFS over the remaining steps (BWTExactModel{Backward,Forward}_Lookup2 :270-548, BWTModelSwitch*2 :1582-1728,
-// Exact/Mismatch models :725-1181).
-__device__ void runItem(Lane &L)
-{
-    const DevIndex &ix = *L.ix;
-    const S3Case &cs = *L.cs;
-    Frame stack[S3_STACK];
-    int sp = 0;
-    {
-        const S3Step &st = cs.st[0];
-        const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
-        Range g;
-        int i = ll, pos;
-        if (st.type == S3_T_BACK_LOOKUP) {
-            g.fl = ltRange(L, ix.lkt, ix.ltSize, st.start - ll + 1, ll, 1, g.fr);
-            g.rl = g.fl; g.rr = g.fr;
-            pos = st.start - ll;
-        } else {
-            uint32_t l, r, rl, rr;
-            l = ltRange(L, ix.lkt, ix.ltSize, st.start, ll, 1, r);
-            rl = ltRange(L, ix.rlkt, ix.ltSize, st.start + ll - 1, ll, -1, rr);
-            if (r - l < rr - rl) rl = rr - (r - l);             // :349-356
-            else if (r - l > rr - rl) l = r - (rr - rl);
-            g.fl = l; g.fr = r; g.rl = rl; g.rr = rr;
-            pos = st.start + ll;
-        }
-        bool done = false;
-        while (i < st.len && g.fl <= g.fr) {
-            if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
-                checkAndExtend(L, 0, i, 0, g.fl, g.fr, 0);
-                done = true;
-                break;
-            }
-            uint4 oL, oR;
-            stepRanks(L, st.dir, g, oL, oR);
-            g = childRange(st.dir, g, oL, oR, readChar(L, pos));
-            i++; pos += st.dir;
-        }
-        if (!done && g.fl <= g.fr) {
-            Frame &f = stack[sp++];
-            f.g = g; f.s = 1; f.i = 0; f.ins = 0; f.occ = 0;
-        }
-    }
-    while (sp > 0) {
-        const Frame f = stack[--sp];
-        if (L.total >= L.maxOut) break;                          // nothing below can emit any more
-        if (f.s >= cs.nSteps) {                                  // SRA_STEP_TYPE_COMPLETE (:1603-1625)
-            uint32_t l = f.g.fl, r = f.g.fr;
-            if (r >= l) {
-                if (L.total + (r - l + 1u) > L.maxOut) r = l + L.maxOut - L.total - 1u;
-                emit(L, 0, l, r, (uint32_t)(f.ins + f.occ));
-                L.total += r - l + 1u;
-            }
-            continue;
-        }
-        const S3Step &st = cs.st[f.s];
-        const int inserted = f.ins;
-        const bool exact = inserted >= st.maxErr;                // :1639 / :1714
-        int len = st.len;
-        if (!exact && st.minErr > inserted + 1) len -= st.minErr - inserted - 1;    // :976 / :1109
-        int i = f.i, pos = st.start + st.dir * i;
-        Range g = f.g;
-        bool suspended = false;
-        while (i < len && g.fl <= g.fr) {
-            if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
-                checkAndExtend(L, f.s, i, inserted, g.fl, g.fr, f.occ);
-                suspended = true;
-                break;
-            }
-            const uint32_t ch = readChar(L, pos);
-            uint4 oL, oR;
-            stepRanks(L, st.dir, g, oL, oR);
-            const Range gc = childRange(st.dir, g, oL, oR, ch);
-            if (!exact) {
-                // children k != ch must be explored (k ascending) before the walk continues with ch:
-                // push the continuation first, then the live children in descending k.
-                const Range e0 = childRange(st.dir, g, oL, oR, 0u), e1 = childRange(st.dir, g, oL, oR, 1u);
-                const Range e2 = childRange(st.dir, g, oL, oR, 2u), e3 = childRange(st.dir, g, oL, oR, 3u);
-                const bool a0 = ch != 0 && e0.fl <= e0.fr, a1 = ch != 1 && e1.fl <= e1.fr;
-                const bool a2 = ch != 2 && e2.fl <= e2.fr, a3 = ch != 3 && e3.fl <= e3.fr;
-                if (a0 || a1 || a2 || a3) {
-                    if (sp + 4 > S3_STACK) { atomicOr(L.out.flags, S3_FLAG_STACK_OVERFLOW); return; }
-                    Frame c;
-                    c.s = f.s; c.i = (int16_t)(i + 1); c.occ = f.occ; c.pad = 0;
-                    c.g = gc; c.ins = (int8_t)inserted;
-                    stack[sp++] = c;
-                    c.ins = (int8_t)(inserted + 1);
-                    if (a3) { c.g = e3; stack[sp++] = c; }
-                    if (a2) { c.g = e2; stack[sp++] = c; }
-                    if (a1) { c.g = e1; stack[sp++] = c; }
-                    if (a0) { c.g = e0; stack[sp++] = c; }
-                    suspended = true;
-                    break;
-                }
-            }
-            g = gc;
-            i++; pos += st.dir;
-        }
-        if (!suspended && inserted >= st.minErr && g.fl <= g.fr) {
-            if (sp + 1 > S3_STACK) { atomicOr(L.out.flags, S3_FLAG_STACK_OVERFLOW); return; }
-            Frame &n = stack[sp++];
-            n.g = g; n.s = (int16_t)(f.s + 1); n.i = 0; n.ins = 0; n.occ = (int8_t)(f.occ + inserted);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// search kernel: thread per item, items laid out (case, strand)-major so a wave is uniform in both
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(S3_SEARCH_BLOCK)
-searchKernel(DevIndex ix, SearchIn in, SearchOut out)
-{
-    extern __shared__ uint32_t shRead[];                         // [wpq][blockDim]
-    const uint32_t nSlots = in.nActive;
-    const uint32_t groups = (uint32_t)in.nCases * 2u;
-    const uint32_t slotsPadded = (nSlots + 63u) & ~63u;          // keep waves uniform in (case, strand)
-    const uint64_t nItems = (uint64_t)slotsPadded * groups;
-    uint32_t nRank = 0, nLt = 0, nSa = 0, nCe = 0;
-    for (uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; item < nItems; item += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t grp = (uint32_t)(item / slotsPadded), slot = (uint32_t)(item % slotsPadded);
-        if (slot >= nSlots) continue;
-        const uint32_t cas = grp >> 1, strandIdx = grp & 1u;
-        const uint32_t r = in.active ? in.active[slot] : slot;
-        const uint32_t len = in.readLengths[r];
-        const S3Model &model = in.models[len];
-        // oriented read -> LDS (word-interleaved by lane)
-        const uint32_t *src = in.queries + (size_t)(r >> 5) * 32u * in.wpq + (r & 31u);
-        uint32_t *dst = shRead + threadIdx.x;
-        if (strandIdx == 0) {
-            for (uint32_t w = 0; w < in.wpqLoad; w++) dst[w * blockDim.x] = src[(size_t)w * 32u];
-        } else {
-            for (uint32_t w = 0; w < in.wpqLoad; w++) dst[w * blockDim.x] = 0;
-            for (uint32_t p = 0; p < len; p++) {                 // reverse complement, 3 - c (DV-Kernel.h:35)
-                const uint32_t q = len - 1u - p;
-                const uint32_t c = 3u - ((src[(size_t)(q >> 4) * 32u] >> ((q & 15u) * 2u)) & 3u);
-                dst[(p >> 4) * blockDim.x] |= c << ((p & 15u) * 2u);
-            }
-        }
-        Lane L;
-        L.ix = &ix; L.cs = &model.cs[cas]; L.rd = dst; L.stride = blockDim.x;
-        L.maxOut = in.maxOut; L.total = 0; L.seq = 0;
-        L.cntIdx = (slot * (uint32_t)in.nCases + cas) * 2u + strandIdx;
-        L.strand = strandIdx + 1u; L.out = out;
-        L.nRank = L.nLt = L.nSa = L.nCe = 0;
-        runItem(L);
-        out.itemCounts[L.cntIdx] = L.seq;
-        nRank += L.nRank; nLt += L.nLt; nSa += L.nSa; nCe += L.nCe;
-    }
-    if (out.counters) {
-        atomicAdd(&out.counters[0], (unsigned long long)nRank);
-        atomicAdd(&out.counters[1], (unsigned long long)nLt);
-        atomicAdd(&out.counters[2], (unsigned long long)nSa);
-        atomicAdd(&out.counters[3], (unsigned long long)nCe);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // ordering: records -> CSR by item (counting scatter; offsets = exclusive scan of itemCounts)
@@ -546,17 +250,6 @@ void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, s
 {
     const unsigned blocks = (unsigned)((occRecs + 255) / 256);
     hipLaunchKernelGGL(relayoutKernel, dim3(blocks), dim3(256), 0, s, bwt, bwtWords, occ, occRecs, lines);
-}
-
-void launchSearch(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
-{
-    const uint64_t slotsPadded = ((uint64_t)in.nActive + 63u) & ~63ull;
-    const uint64_t nItems = slotsPadded * (uint64_t)in.nCases * 2u;
-    if (nItems == 0) return;
-    uint64_t blocks = (nItems + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
-    if (blocks > maxBlocks) blocks = maxBlocks;
-    const size_t lds = (size_t)in.wpqLoad * 4u * S3_SEARCH_BLOCK;
-    hipLaunchKernelGGL(searchKernel, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
 }
 
 // ---------------------------------------------------------------------------------------------

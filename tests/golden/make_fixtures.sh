@@ -85,6 +85,7 @@ mkp() {  # name genome_args pair_args maxlen
   )
 }
 
+if [ -z "${S3_FIXTURE_ONLY:-}" ]; then     # S3_FIXTURE_ONLY=dp: only the DP-stage fixtures below
 mk g1 "--genome-len 200000 --chroms 3 --n-runs 4 --repeats 6 --genome-seed 1" "--reads 2000 --read-len 100 --read-seed 2026" 100
 mk g2 "--genome-len 60000 --chroms 2 --n-runs 2 --repeats 40 --genome-seed 7" "--reads 1500 --read-len 100 --var-len 25 120 --read-seed 11" 120
 mkl g3 "--genome-len 120000 --chroms 2 --n-runs 4 --repeats 12 --genome-seed 5" "--reads 1200 --var-len 121 200 --read-seed 31 --mix 0.3 0.2 0.15 0.1 0.08 0.07 0.05 0.03 0.02" 200
@@ -141,6 +142,59 @@ mkdir -p $OUT/dp2
   cp dp2_1.fq $OUT/dp2/reads_1.fq; cp dp2_2.fq $OUT/dp2/reads_2.fq; cp dp2.results $OUT/dp2/results.txt; cp dp2.stats $OUT/dp2/stats.txt
   for v in h2 h1 h2p h1p h3 h4p nb2 nb1; do grep -v '^@PG' r_$v.dpout.1 | gzip -9n > $OUT/dp2/dpout_$v.sam.gz; done
 )
+fi  # S3_FIXTURE_ONLY
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# DP stages ON: the reference's own DP engines (host halves of DV-DPfunctions.cu and callers, compiled by oracle/ref.mk) run behind the
+# BWT ladder.  Per run: the three SAM files (.gout.1 / .dpout.1 / .unpair) and every DP problem the engines submitted (packer output +
+# what the decode stage received), sorted.
+dprun() {  # outdir tag index mode(single|pair) reads... -- options
+  local dir=$1 tag=$2; shift 2
+  ( cd $W && rm -f $tag.gout.1 $tag.dpout.1 $tag.unpair $tag.problems
+    REFDP_DUMP=$tag.problems $REF/ref_harness sam $INI "$@" -o $tag > $tag.log 2>&1
+    for k in gout.1 dpout.1 unpair; do if [ -f $tag.$k ]; then grep -v '^@PG' $tag.$k | gzip -9n > $dir/dp_$tag.${k%.1}.sam.gz; fi; done
+    grep '^P' $tag.problems | LC_ALL=C sort | gzip -9n > $dir/dp_$tag.problems.txt.gz )
+}
+( cd $W
+  [ -f g4.fa.index.bwt ] || { cp $OUT/g4/genome.fa g4.fa; $REF/soap3-dp-builder g4.fa > /dev/null; $REF/BGS-Build g4.fa.index > /dev/null; }
+  [ -f g5.fa.index.bwt ] || { python $ROOT/tools/simulate_routing_case.py --fasta g5.fa --fastq1 g5_1.fq --fastq2 g5_2.fq; $REF/soap3-dp-builder g5.fa > /dev/null; $REF/BGS-Build g5.fa.index > /dev/null; }
+  cmp g5_1.fq $OUT/g5/reads_1.fq
+  # g7: config C3's shape -- 2 x 150 bp, -u 500 -v 1; 10 % of the pairs carry an indel in one mate, 5 % are damaged in both
+  mkdir -p $OUT/g7
+  python $ROOT/tools/simulate.py --genome-len 300000 --chroms 3 --n-runs 4 --repeats 10 --genome-seed 13 --fasta g7.fa --pairs 1500 --read-len 150 --read-seed 91 \
+         --fastq g7_1.fq --fastq2 g7_2.fq --truth g7.truth --indel-frac 0.10 --damaged-frac 0.05
+  $REF/soap3-dp-builder g7.fa > /dev/null; $REF/BGS-Build g7.fa.index > /dev/null
+  for f in bwt rev.bwt fmv.gpu rev.fmv.gpu sa pac ann amb tra; do cp g7.fa.index.$f $OUT/g7/index.$f; done
+  cp g7.fa $OUT/g7/genome.fa; cp g7_1.fq $OUT/g7/reads_1.fq; cp g7_2.fq $OUT/g7/reads_2.fq; cp g7.truth $OUT/g7/reads.truth
+  sha256sum g7.fa.index.lkt g7.fa.index.rev.lkt | awk '{print $1}' > $OUT/g7/lkt.sha256
+  # 2 x 200 bp pairs on the same genome: above 150 bases the BWT stage is skipped and every pair goes to the deep DP (SOAP3-DP.cu:658-662)
+  python $ROOT/tools/simulate.py --genome-len 300000 --chroms 3 --n-runs 4 --repeats 10 --genome-seed 13 --fasta g7x.fa --pairs 300 --read-len 200 --read-seed 5 \
+         --fastq g7_long_1.fq --fastq2 g7_long_2.fq --insert-mean 450 --indel-frac 0.15 --damaged-frac 0.05
+  cmp g7.fa g7x.fa; cp g7_long_1.fq $OUT/g7/long_1.fq; cp g7_long_2.fq $OUT/g7/long_2.fq
+)
+# g7 with the DP stages off, every report type (the paired ladder at 150 bp, wordPerQuery 16)
+( cd $W
+  P="$REF/ref_harness sam $INI pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2"
+  $P -s 3 -o pe_s3 > /dev/null 2>&1; $P -s 3 -h 1 -o pe_h1_s3 > /dev/null 2>&1; $P -s 3 -h 3 -o pe_h3_s3 > /dev/null 2>&1; $P -s 3 -h 4 -p -o pe_h4_s3 > /dev/null 2>&1
+  for v in s3 h1_s3 h3_s3 h4_s3; do grep -v '^@PG' pe_$v.gout.1 | gzip -9n > $OUT/g7/pe_$v.sam.gz; done
+)
+dprun $OUT/g7 h2  pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2
+dprun $OUT/g7 h2p pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2 -p
+dprun $OUT/g7 h1  pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2 -h 1
+dprun $OUT/g7 h3  pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2 -h 3
+dprun $OUT/g7 h4  pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2 -h 4
+dprun $OUT/g7 long pair g7.fa.index g7_long_1.fq g7_long_2.fq -L 200 -u 600 -v 100 -b 2
+dprun $OUT/g7 se   single g7.fa.index g7_1.fq -L 150 -b 2
+dprun $OUT/g7 se_h1 single g7.fa.index g7_2.fq -L 150 -b 2 -h 1 -p
+rm -f $OUT/g7/dp_h2p.problems.txt.gz $OUT/g7/dp_h1.problems.txt.gz $OUT/g7/dp_h4.problems.txt.gz      # same problems as h2 / h3
+dprun $OUT/g4 h2  pair g4.fa.index $OUT/g4/reads_1.fq $OUT/g4/reads_2.fq -L 100 -u 500 -v 100 -b 2
+dprun $OUT/g4 h1  pair g4.fa.index $OUT/g4/reads_1.fq $OUT/g4/reads_2.fq -L 100 -u 500 -v 100 -b 2 -h 1
+rm -f $OUT/g4/dp_h1.problems.txt.gz
+dprun $OUT/g5 h2  pair g5.fa.index g5_1.fq g5_2.fq -L 100 -u 500 -v 100 -b 2
+( cd $W; [ -f g1.fa.index.bwt ] || { cp $OUT/g1/genome.fa g1.fa; $REF/soap3-dp-builder g1.fa > /dev/null; $REF/BGS-Build g1.fa.index > /dev/null; } )
+dprun $OUT/g1 se  single g1.fa.index $OUT/g1/reads.fq -L 100 -b 2
+if [ -z "${S3_FIXTURE_ONLY:-}" ]; then
 ( cd $W && $REF/ref_harness models models.txt && gzip -9n < models.txt > $OUT/models.txt.gz )
 ( cd $W && $REF/ref_harness dpparams $INI dpparams.txt && gzip -9n < dpparams.txt > $OUT/dpparams.txt.gz )
+fi
 du -sh $OUT

@@ -1,0 +1,126 @@
+"""-m gpu: the whole DP pipeline of the drop-in `soap3-dp` against the reference's OWN DP engines.
+
+The golden files tests/golden/*/dp_<tag>.* were written by oracle/_ref/ref_harness running the reference's host code for the DP stages --
+HalfEndAlgnBatch::pack / PairEndAlgnBatch::packLeft,packRight / SingleEndAlgnBatch::pack (window geometry, clips, anchors), the seeding
+engines with singleMerge / pairEndMerge, the decode threads (CIGAR, edit distance, insert size), OutputBuffer::ready and the record
+writers -- compiled from /root/reference by oracle/ref.mk, behind the reference's BWT ladder (tests/golden/make_fixtures.sh, section
+"DP stages ON").  Checked here:
+  * the three SAM files (.gout.1, .dpout.1, .unpair), record for record;
+  * the multiset of DP problems the engines submitted (S3DP_DUMP_DP): read / window sequences, lengths, clip allowances, anchors, cutoffs
+    as the packers built them, and score / start / tie count / op string as the decode stage received them.
+g7 is BASELINE config C3's shape (2 x 150 bp, -u 500 -v 1); dp_long (2 x 200 bp) skips the BWT stage; dp_se* are single reads."""
+import gzip
+import os
+import re
+import shutil
+import subprocess
+from collections import Counter
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
+REPORT = os.path.join(ROOT, "gpurun_out", "dp_pipeline")
+
+RG = re.compile(r"\tRG:Z:[^\t]*")
+
+
+def records(text):
+    """header lines (without @PG / @RG, whose id is the file name as typed) and the multiset of records with the read-group tag removed"""
+    hdr, rec = [], []
+    for l in text.split("\n"):
+        if not l:
+            continue
+        if l.startswith("@"):
+            if not l.startswith("@PG") and not l.startswith("@RG"):
+                hdr.append(l)
+        else:
+            rec.append(RG.sub("", l))
+    return hdr, Counter(rec)
+
+
+def report(case, name, lines):
+    try:
+        os.makedirs(REPORT, exist_ok=True)
+        with open(os.path.join(REPORT, "%s.%s.txt" % (case, name)), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+
+
+def by_read(counter):
+    d = {}
+    for l, c in counter.items():
+        f = l.split("\t", 2)
+        d.setdefault((f[0], int(f[1]) & 0xC0), []).extend([l] * c)
+    return d
+
+
+CASES = [
+    # case, golden dir, tag, mode, read files (golden names), options
+    ("g7_h2", "g7", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]),
+    ("g7_h2p", "g7", "h2p", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2", "-p"]),
+    ("g7_h1", "g7", "h1", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2", "-h", "1"]),
+    ("g7_h3", "g7", "h3", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2", "-h", "3"]),
+    ("g7_h4", "g7", "h4", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2", "-h", "4"]),
+    ("g7_long", "g7", "long", "pair", ("long_1.fq", "long_2.fq"), ["-L", "200", "-u", "600", "-v", "100", "-b", "2"]),
+    ("g7_se", "g7", "se", "single", ("reads_1.fq",), ["-L", "150", "-b", "2"]),
+    ("g7_se_h1", "g7", "se_h1", "single", ("reads_2.fq",), ["-L", "150", "-b", "2", "-h", "1", "-p"]),
+    ("g4_h2", "g4", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "100", "-u", "500", "-v", "100", "-b", "2"]),
+    ("g4_h1", "g4", "h1", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "100", "-u", "500", "-v", "100", "-b", "2", "-h", "1"]),
+    ("g5_h2", "g5", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "100", "-u", "500", "-v", "100", "-b", "2"]),
+    ("g1_se", "g1", "se", "single", ("reads.fq",), ["-L", "100", "-b", "2"]),
+]
+
+
+@pytest.mark.parametrize("case,gdir,tag,mode,reads,opts", CASES, ids=[c[0] for c in CASES])
+def test_dp_pipeline_matches_the_reference_engines(tmp_path, case, gdir, tag, mode, reads, opts):
+    assert os.path.exists(BIN), "soap3-dp binary not built"
+    names = []
+    for k, r in enumerate(reads):
+        n = "%s_%d.fq" % (gdir, k + 1)
+        shutil.copy(os.path.join(GOLDEN, gdir, r), tmp_path / n)
+        names.append(n)
+    env = dict(os.environ, S3DP_DUMP_DP=str(tmp_path / "problems.txt"))
+    out = subprocess.run([BIN, mode, os.path.join(GOLDEN, gdir, "index")] + names + opts + ["-o", "out"], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    problems = []
+    for kind in ("gout", "dpout", "unpair"):
+        g = os.path.join(GOLDEN, gdir, "dp_%s.%s.sam.gz" % (tag, kind))
+        mine_path = tmp_path / ("out.%s" % {"gout": "gout.1", "dpout": "dpout.1", "unpair": "unpair"}[kind])
+        if not os.path.exists(g):
+            continue
+        ref_h, ref = records(gzip.open(g, "rt").read())
+        mine_h, mine = records(open(mine_path).read()) if os.path.exists(mine_path) else ([], Counter())
+        if sum(ref.values()) == 0 and not os.path.exists(mine_path):
+            continue
+        if mine_h != ref_h:
+            problems.append("%s: header differs" % kind)
+        if mine != ref:
+            rb, mb = by_read(ref), by_read(mine)
+            lines = []
+            for k in sorted(set(rb) | set(mb)):
+                if sorted(rb.get(k, [])) != sorted(mb.get(k, [])):
+                    for l in rb.get(k, []):
+                        lines.append("REF  " + l)
+                    for l in mb.get(k, []):
+                        lines.append("MINE " + l)
+                    lines.append("")
+            nd = sum(1 for k in set(rb) | set(mb) if sorted(rb.get(k, [])) != sorted(mb.get(k, [])))
+            report(case, kind, lines)
+            problems.append("%s: %d of %d reads differ (ref %d records, mine %d)" % (kind, nd, len(rb), sum(ref.values()), sum(mine.values())))
+    g = os.path.join(GOLDEN, gdir, "dp_%s.problems.txt.gz" % tag)
+    if os.path.exists(g):
+        ref_p = Counter(l for l in gzip.open(g, "rt").read().split("\n") if l.startswith("P"))
+        mine_p = Counter(l for l in open(tmp_path / "problems.txt").read().split("\n") if l.startswith("P")) if os.path.exists(tmp_path / "problems.txt") else Counter()
+        if ref_p != mine_p:
+            only_ref = sorted((ref_p - mine_p).elements())
+            only_mine = sorted((mine_p - ref_p).elements())
+            report(case, "problems", ["only in the reference: %d" % len(only_ref)] + only_ref[:400] + ["", "only in the product: %d" % len(only_mine)] + only_mine[:400])
+            problems.append("DP problems: %d only in the reference, %d only in the product (of %d / %d)" % (len(only_ref), len(only_mine), sum(ref_p.values()),
+                                                                                                         sum(mine_p.values())))
+    assert not problems, "; ".join(problems) + "  (details: gpurun_out/dp_pipeline/%s.*.txt)" % case

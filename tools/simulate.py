@@ -82,10 +82,12 @@ def make_reads(chroms, n, L, seed=2026, mix=(0.55, 0.25, 0.12, 0.05, 0.03), var_
 
 
 def make_pairs(chroms, n, L, seed=2026, mix=(0.55, 0.25, 0.12, 0.05, 0.03), ins_mean=350, ins_sd=40, ins_max=500,
-               frac_half=0.08, frac_none=0.04, frac_far=0.08, var_len=None):
+               frac_half=0.08, frac_none=0.04, frac_far=0.08, var_len=None, frac_indel=0.0, frac_damaged=0.0):
     """read pairs in +/- orientation: a fragment of `insert` bases, mate A = its first L bases, mate B = reverse complement of its last
     L bases; which of the two is written to file 1 is random.  A fraction has one or both mates replaced by random sequence
-    (half-aligned / unaligned pairs) or the second mate taken from a distant place (both align, no proper pair)."""
+    (half-aligned / unaligned pairs) or the second mate taken from a distant place (both align, no proper pair).
+    frac_indel: one mate of an otherwise proper pair carries a 1-8 base insertion or deletion (-> default DP); frac_damaged: both mates
+    carry an indel or 5-8 substitutions (-> deep DP).  Both are 0 by default and then draw nothing from the generator."""
     rng = np.random.default_rng(seed)
     clen = np.array([len(c) for c in chroms])
     r1, r2, truth = [], [], []
@@ -113,6 +115,38 @@ def make_pairs(chroms, n, L, seed=2026, mix=(0.55, 0.25, 0.12, 0.05, 0.03), ins_
             continue
         a, na = mutate(a)
         b, nb = mutate(b)
+        if frac_indel > 0 or frac_damaged > 0:
+            u = rng.random()
+
+            def damage(which, heavy):
+                # which 0: mate A, anchored at its left end; 1: mate B, anchored at its right end (both still in fragment orientation)
+                L0 = la if which == 0 else lb
+                if heavy and rng.random() < 0.5:
+                    seg = (a if which == 0 else b).copy()
+                    for p in rng.choice(L0, size=int(rng.integers(5, 9)), replace=False):
+                        seg[p] = ALPHA[(np.searchsorted(ALPHA, seg[p]) + rng.integers(1, 4)) % 4]
+                    return seg
+                k = int(rng.integers(1, 9))
+                p = int(rng.integers(12, L0 - 12))
+                src = chroms[ci][st:st + L0 + 16].copy() if which == 0 else chroms[ci][st + ins - L0 - 16:st + ins].copy()
+                if (src == ord("N")).any() or len(src) < L0 + 16:
+                    return (a if which == 0 else b)
+                if which == 1:
+                    p += 16
+                if rng.random() < 0.5:
+                    seq = np.concatenate([src[:p], src[p + k:]])
+                else:
+                    seq = np.concatenate([src[:p], ALPHA[rng.integers(0, 4, size=k)], src[p:]])
+                return seq[:L0].copy() if which == 0 else seq[len(seq) - L0:].copy()
+            if kind >= frac_far + frac_half + frac_none:
+                if u < frac_indel:
+                    if rng.random() < 0.5:
+                        a = damage(0, False)
+                    else:
+                        b = damage(1, False)
+                elif u < frac_indel + frac_damaged:
+                    a = damage(0, True)
+                    b = damage(1, True)
         b = COMP[b[::-1]]
         if frac_far <= kind < frac_far + frac_half:           # one mate unalignable
             if rng.random() < 0.5:
@@ -160,6 +194,8 @@ def main():
     ap.add_argument("--fastq2", default=None)
     ap.add_argument("--insert-mean", type=float, default=350)
     ap.add_argument("--insert-sd", type=float, default=40)
+    ap.add_argument("--indel-frac", type=float, default=0.0, help="pairs: share with a 1-8 base indel in one mate")
+    ap.add_argument("--damaged-frac", type=float, default=0.0, help="pairs: share with an indel or 5-8 substitutions in both mates")
     a = ap.parse_args()
     chroms = make_genome(a.genome_len, a.chroms, a.n_runs, a.genome_seed, a.repeats)
     write_fasta(a.fasta, chroms)
@@ -172,7 +208,8 @@ def main():
                     f.write("%d %d %d %d\n" % t)
     if a.pairs:
         kw = {"mix": tuple(a.mix)} if a.mix else {}
-        r1, r2, truth = make_pairs(chroms, a.pairs, a.read_len, a.read_seed, ins_mean=a.insert_mean, ins_sd=a.insert_sd, var_len=a.var_len, **kw)
+        r1, r2, truth = make_pairs(chroms, a.pairs, a.read_len, a.read_seed, ins_mean=a.insert_mean, ins_sd=a.insert_sd, var_len=a.var_len, frac_indel=a.indel_frac,
+                                  frac_damaged=a.damaged_frac, **kw)
         write_fastq(a.fastq, r1, prefix="p", suffix="/1")
         write_fastq(a.fastq2, r2, prefix="p", suffix="/2")
         if a.truth:
