@@ -245,6 +245,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     BA(dRecs, recCap); BA(dOrdered, recCap); b->ordCap = recCap;
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskEnd, 4);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
+    BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4);
     BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
     BA(dWithError, (size_t)maxReads * 8);
     BA(dHitOffsets, (size_t)maxReads + 1); BA(dHits, recCap);
@@ -376,23 +377,37 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         HIPCHK(hipMemcpyAsync(counterSnap, b->dCounters, 64, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
+    // S3DP_HEAVY=0 switches the exact pass off (every read stays in the first pass: same results, reads in repeat families walk far beyond what
+    // MaxOutputPerRead keeps); n > 1: list a read once it has reserved more than n candidates (default: maxOut)
+    const size_t heavyEnv = envSize("S3DP_HEAVY", 1);                       // read per pass: tests switch it
+    in.heavyLimit = heavyEnv == 0 || maxOut >= 0x7FFFFFFFu ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : (maxOut < 64u ? 64u : maxOut));
+    in.slotList = nullptr; in.slotCount = nullptr;
     for (;;) {
         HIPCHK(hipMemsetAsync(b->dRecCount, 0, 4, b->stream));
+        HIPCHK(hipMemsetAsync(b->dHeavyCount, 0, 4, b->stream));
+        HIPCHK(hipMemsetAsync(b->dHeavyFlags, 0, nActive, b->stream));
         SearchOut out{};
         out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
         out.counters = b->counting ? b->dCounters : nullptr;
         out.workHead = b->dWorkHead;
+        out.heavyFlags = b->dHeavyFlags; out.heavyList = b->dHeavyList; out.heavyCount = b->dHeavyCount;
         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
         if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
         {
             static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", S3_V2_WAVES_PER_SIMD);
-            {
-                const hipError_t le = (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
-                if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
+            hipError_t le = (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, false, b->stream);
+            if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
+            // the task records end where the first pass stopped writing; the exact pass and the check-and-extend kernel append behind them
+            HIPCHK(hipMemcpyAsync(b->dTaskEnd, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
+            if (in.heavyLimit != 0xFFFFFFFFu) {
+                // exact pass over the listed reads (the kernel reads their number from device memory: no host round trip)
+                SearchIn in2 = in;
+                in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount;
+                HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
+                le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, true, b->stream);
+                if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (exact pass): ") + hipGetErrorString(le));
             }
             if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
-            // the task records end where the stepping kernel stopped writing; the check-and-extend kernel appends behind them
-            HIPCHK(hipMemcpyAsync(b->dTaskEnd, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
             if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2], b->stream));
             launchCheckExtend(b->ix->d, in, out, b->dTaskEnd, b->stream);
             if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2 + 1], b->stream));
@@ -431,7 +446,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         }
     }
     launchFillInvalid(b->dOrdered, b->dItemOffsets + nItems, b->ordCap, b->stream);
-    launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->stream);
+    launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->dHeavyFlags, (uint32_t)nCases * 2u, b->stream);
     MergeArgs m{};
     m.nActive = nActive; m.nCases = (uint32_t)nCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;

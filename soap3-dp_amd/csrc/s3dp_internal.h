@@ -41,6 +41,8 @@ struct s3_batch {
     uint4    *dRecs = nullptr, *dOrdered = nullptr;
     uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr, *dTaskEnd = nullptr;
     unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;
+    uint8_t  *dHeavyFlags = nullptr;                 // reads the first search pass listed for the exact pass (s3dp_search_v2.hip)
+    uint32_t *dHeavyList = nullptr, *dHeavyCount = nullptr;
     uint32_t uniformLen = 0;
     uint32_t *dKept = nullptr, *dOccCounts = nullptr, *dCeCounts = nullptr, *dTotalOcc = nullptr, *dWithError = nullptr;
     uint32_t *dHitOffsets = nullptr;

@@ -68,13 +68,17 @@ __device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t c) { return c 
 // ---------------------------------------------------------------------------------------------
 // ordering: records -> CSR by item (counting scatter; offsets = exclusive scan of itemCounts)
 // ---------------------------------------------------------------------------------------------
-__global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered)
+__global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered,
+                              const uint8_t *heavyFlags, uint32_t groups)
 {
     uint32_t n = *recCount;
     if (n > recCap) n = recCap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint4 r = recs[i];
+        uint4 r = recs[i];
         if (r.x == 0xFFFFFFFFu || (r.y & S3_REC_TASK)) continue;            // unused slot of a reserved block / check-and-extend task (v2 kernel)
+        // a read listed for the exact pass keeps only what that pass wrote
+        if (r.x & S3_REC_EXACT_PASS) r.x &= ~S3_REC_EXACT_PASS;
+        else if (heavyFlags[r.x / groups]) continue;
         ordered[itemOffsets[r.x] + (r.y & 0xFFFFFFu)] = r;
     }
 }
@@ -360,9 +364,10 @@ void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipS
     hipLaunchKernelGGL(fillInvalidKernel, dim3(2048), dim3(256), 0, s, ordered, total, cap);
 }
 
-void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, hipStream_t s)
+void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,
+                   uint32_t groups, hipStream_t s)
 {
-    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered);
+    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, heavyFlags, groups);
 }
 
 void launchMergeCount(const MergeArgs &a, hipStream_t s)
