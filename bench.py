@@ -238,77 +238,99 @@ def extras(s3dp, ix, codes, dev, rank):
     del reads2d
     lens = np.full(2 * n_pairs, L, dtype=np.uint32)
     b = s3dp.Batch(ix, 2 * n_pairs, wpq)
-    b.upload(q, lens)
-    b.align_pair(3, 8000, 2, 1, 500, 1000)
-    b.sync()
-    t0 = time.perf_counter()
-    for _ in range(2):
+    try:
+        b.upload(q, lens)
         b.align_pair(3, 8000, 2, 1, 500, 1000)
         b.sync()
-    dt = (time.perf_counter() - t0) / 2
-    pairs = b.fetch_pairs()[0]
-    res["paired_end_2x150_bwt_stage"] = {"pairs": n_pairs, "ms_per_pass": dt * 1e3, "M_pairs_per_s": n_pairs / dt / 1e6,
-                                          "properly_paired": int((pairs["phase"] > 0).sum()),
-                                          "options": "pair -L 150 -s 3 -h 2 -u 500 -v 1 (DP stages off)"}
-    b.close()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            b.align_pair(3, 8000, 2, 1, 500, 1000)
+            b.sync()
+        dt = (time.perf_counter() - t0) / 2
+        pairs = b.fetch_pairs()[0]
+        res["paired_end_2x150_bwt_stage"] = {"pairs": n_pairs, "ms_per_pass": dt * 1e3, "M_pairs_per_s": n_pairs / dt / 1e6,
+                                              "properly_paired": int((pairs["phase"] > 0).sum()),
+                                              "options": "pair -L 150 -s 3 -h 2 -u 500 -v 1 (DP stages off)"}
+    except Exception as e:
+        res["paired_end_2x150_bwt_stage"] = {"error": repr(e)}
+    finally:
+        b.close()
+    torch.cuda.empty_cache()
     # DP kernel: 150 bp reads against 648-column windows cut from the genome at the reads' places (default-DP shape), device time
     n_dp = 32768
-    rng = np.random.default_rng(3)
     occ = np.zeros(n_dp, dtype=s3dp.OCC_DTYPE)
     reads2d = make_pairs(codes, n_dp, L, 777, dev)
     q = pack_on_device(reads2d, wpq)
+    del reads2d
     lens = np.full(2 * n_dp, L, dtype=np.uint32)
     bb = s3dp.Batch(ix, 2 * n_dp, wpq)
-    bb.upload(q, lens)
-    bb.align_pair(3, 8000, 2, 1, 500, 1000)
-    pr = bb.fetch_pairs()[0]
-    k = 0
-    for p in range(n_dp):                                              # the first end's hit of every properly paired pair anchors a DP of the second end
-        if pr["phase"][p] and k < n_dp:
-            occ[k] = (2 * p, pr["bestA1"][p], pr["bestS1"][p], pr["bestM1"][p], (0, 0))
-            k += 1
-    dp = s3dp.DpAligner(n_dp, 152, 500 - 1 + 152 + 1, scheme=1)
-    dp.half_end(bb, lens, occ[:k], 1, 500, (45, 45), 49, 49)
-    t0 = time.perf_counter()
-    resd, cig = dp.half_end(bb, lens, occ[:k], 1, 500, (45, 45), 49, 49)
-    wall = time.perf_counter() - t0
-    ms = dp.timing()
-    cells = float(k) * L * 499.0
-    res["default_dp_half_end"] = {"problems": k, "read_len": L, "window": 499, "kernel_ms": ms, "GCUPS_kernel": cells / (ms / 1e3) / 1e9,
-                                  "wall_ms_incl_pack_decode": wall * 1e3, "aligned_by_dp": int((resd["whichFromDP"] < 2).sum())}
-    dp.close()
-    bb.close()
+    dp = None
+    try:
+        bb.upload(q, lens)
+        bb.align_pair(3, 8000, 2, 1, 500, 1000)
+        pr = bb.fetch_pairs()[0]
+        k = 0
+        for p in range(n_dp):                                              # the first end's hit of every properly paired pair anchors a DP of the second end
+            if pr["phase"][p] and k < n_dp:
+                occ[k] = (2 * p, pr["bestA1"][p], pr["bestS1"][p], pr["bestM1"][p], (0, 0))
+                k += 1
+        dp = s3dp.DpAligner(n_dp, 152, 500 - 1 + 152 + 1, scheme=1)
+        dp.half_end(bb, lens, occ[:k], 1, 500, (45, 45), 49, 49)
+        t0 = time.perf_counter()
+        resd, cig = dp.half_end(bb, lens, occ[:k], 1, 500, (45, 45), 49, 49)
+        wall = time.perf_counter() - t0
+        ms = dp.timing()
+        cells = float(k) * L * 499.0
+        res["default_dp_half_end"] = {"problems": k, "read_len": L, "window": 499, "kernel_ms": ms, "GCUPS_kernel": cells / (ms / 1e3) / 1e9,
+                                      "wall_ms_incl_pack_decode": wall * 1e3, "aligned_by_dp": int((resd["whichFromDP"] < 2).sum())}
+    except Exception as e:
+        res["default_dp_half_end"] = {"error": repr(e)}
+    finally:
+        if dp is not None:
+            dp.close()
+        bb.close()
     return res
 
 
 def cpu_baseline(hi, q, lens, wpq, mm, max_out, budget_s):
-    """oracle (CPU restatement of the reference path) timed on a bounded sample with every host core"""
+    """oracle (CPU restatement of the reference path) timed on a bounded sample with every host core: each thread aligns blocks of 256 reads of the
+    same batch, same ladder, until the time budget is used up (reads in repeat families cost thousands of times what unique reads cost, so the
+    sample is bounded by time, not by a read count fixed in advance)"""
     import concurrent.futures as cf
+    import itertools
+    import threading
     import s3o
     cores = os.cpu_count() or 1
     oix = s3o.Index(host_index=hi)
     n_all = len(lens)
-    # calibrate on 512 reads, one thread
+    block = 256
+    n_blocks = n_all // block
+    counter = itertools.count()
+    lock = threading.Lock()
     t0 = time.perf_counter()
-    oix.align_single_allbest(q, lens, wpq, mm, max_out, first=0, count=min(512, n_all))
-    rate1 = min(512, n_all) / max(1e-6, time.perf_counter() - t0)
-    per_thread = int(max(256, min(rate1 * budget_s, n_all // cores)) // 32 * 32)
-    per_thread = max(32, per_thread)
-    threads = max(1, min(cores, n_all // per_thread))
+    deadline = t0 + budget_s
 
-    def work(t):
-        return oix.align_single_allbest(q, lens, wpq, mm, max_out, first=t * per_thread, count=per_thread)[6].rankQueries
+    def work(_):
+        done, ranks = 0, 0
+        while time.perf_counter() < deadline:
+            with lock:
+                k = next(counter)
+            if k >= n_blocks:
+                break
+            ranks += oix.align_single_allbest(q, lens, wpq, mm, max_out, first=k * block, count=block)[6].rankQueries
+            done += block
+        return done, ranks
 
-    t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
-        ranks = list(ex.map(work, range(threads)))
+    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+        res = list(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
     oix.close()
-    total = per_thread * threads
-    return {"value": total / dt / 1e6, "unit": "M reads/s", "cores": threads, "kind": "port",
-            "sample": "%d reads (%d per thread x %d threads) of the same batch, same ladder, %.1f s wall; oracle/s3_oracle.c" %
-                      (total, per_thread, threads, dt),
-            "reads_per_s_per_core": total / dt / threads, "rank_queries_per_read": sum(ranks) / total}
+    total = sum(r[0] for r in res)
+    ranks = sum(r[1] for r in res)
+    return {"value": total / dt / 1e6, "unit": "M reads/s", "cores": cores, "kind": "port",
+            "sample": "the first %d reads of the same batch (blocks of %d dealt to %d threads until %.0f s were used), same ladder, %.1f s wall; "
+                      "oracle/s3_oracle.c" % (total, block, cores, budget_s, dt),
+            "reads_per_s_per_core": total / dt / cores, "rank_queries_per_read": ranks / max(1, total)}
 
 
 def truth_check(phase, offs, pos, strand, mis, tpos, tstrand, tsub, max_out):
@@ -584,6 +606,8 @@ def main():
                 out["extras"] = {"error": repr(e)}
     keep["ix"].close()
     keep.clear()
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and a.uniform and a.repeat_frac > 0:
         try:
