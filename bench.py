@@ -464,10 +464,23 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
 
     # ---- streamed: upload of the packed reads and download of the results inside the timed region -------------
     streamed = None
-    if hasattr(s3dp, "Stream") and a.streaming:
-        streamed = s3dp.stream_bench(ix, q, lens, wpq, a.mismatch, a.max_out, a.stream_batch, a.steps)
+    if a.streaming:
+        b.close()                                   # the stream's slots bring their own batches
+        mism = []
+
+        def chk(first, ph, of, po, sr, mi):         # the streamed results must be the resident batch's
+            m = len(ph)
+            lo, hi = int(offs[first]), int(offs[first + m])
+            if not ((ph == phase[first:first + m]).all() and (of.astype(np.int64) == (offs[first:first + m + 1].astype(np.int64) - lo)).all() and
+                    (po == pos[lo:hi]).all() and (sr == strand[lo:hi]).all() and (mi == mis[lo:hi]).all()):
+                mism.append(first)
+        streamed = s3dp.stream_bench(ix, q, lens, wpq, a.mismatch, a.max_out, a.stream_batch, a.steps, check=chk)
+        if mism:
+            raise SystemExit("bench.py: streamed results differ from the resident batch's (batches at reads %r)" % mism[:5])
+        streamed["same_results_as_resident"] = True
         streamed["M_reads_per_s"] = sd.reduce_counters({"r": int(streamed["reads"])}, device=dev)["r"] / \
             sd.max_over_ranks(streamed["seconds"], device=dev) / 1e6
+        streamed["vs_resident"] = streamed["M_reads_per_s"] / value
 
     # ---- roofline of the search (stepping kernel + check-and-extend kernel: the two halves of one search pass) ----------------
     # algorithmic bytes: SURVEY.md 8d's formula (strict), and the same extended by what the lookup tables and check-and-extend read: 16 B per lookup
@@ -534,7 +547,8 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
                 raise SystemExit("bench.py: HIP result differs from the CPU oracle (%s)" % label)
         if not out["truth_check"]["ok"]:
             raise SystemExit("bench.py: truth check failed (%s): %r" % (label, out["truth_check"]))
-    b.close()
+    if not a.streaming:
+        b.close()
     return out, dict(ix=ix, hi=hi, codes=codes, q=q, lens=lens, wpq=wpq)
 
 

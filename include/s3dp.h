@@ -90,7 +90,9 @@ typedef struct {
 int  s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPerQuery, s3_batch **out);
 void s3_batch_free(s3_batch *b);
 /* queries: the reference's packed layout -- 32-interleaved words, 16 chars/word LSB first
- * (word w of read r at r/32*32*wpq + r%32 + 32*w; DV-Kernel.cu:4268-4270); readLengths[n]. Host pointers. */
+ * (word w of read r at r/32*32*wpq + r%32 + 32*w; DV-Kernel.cu:4268-4270); readLengths[n]. Host pointers.
+ * The layout works in groups of 32 reads: `queries` must hold ceil(n/32)*32 x wordPerQuery words (the reference allocates its read
+ * arrays the same way, SOAP3-DP.cu:298-300); all of them are copied. */
 int  s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint32_t *readLengths, uint32_t n);
 /* Long-read mode = the `seedLengths` argument of all_valid_alignment / all_best_single_alignment / best_single_alignment
  * (alignment.cu:534,1422,1377; the array is built at alignment.cu:2473-2491: 100 for reads longer than 120 bases, else the read
@@ -123,6 +125,38 @@ int  s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t maxOutput
 int  s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError /* n x 8 */,
                                uint64_t *occOffsets /* n+1 */, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis,
                                size_t occCap, uint64_t *nOccOut);
+
+/* ---- streamed single-end alignment ------------------------------------------------------------------------------------------
+ * Replaces the batch loop of the reference's main (SOAP3-DP.cu:607-800: read a batch, align it, next) together with its overlap of the device
+ * work of batch i+1 with the CPU threads of batch i (alignment.cu:555-561, 1005-1031).  A stream owns `depth` slots, each one s3_batch on its own
+ * HIP stream + pinned host staging + a worker thread running upload -> s3_batch_align_single -> download; with depth 3 the upload of batch
+ * i+1, the kernels of batch i and the download of batch i-1 overlap, and so do the caller's parsing and formatting.
+ *   s3_stream_acquire   blocks until the next slot is free and returns its pinned input arrays (the layouts of s3_batch_upload; room for
+ *                       maxReads reads; queries must be written for ceil(n/32)*32 reads, zero beyond n): parse straight into them
+ *   s3_stream_submit    hands the acquired slot's n reads to its worker; seed lengths as in s3_batch_set_seed_lengths when useSeedLengths
+ *   s3_stream_next      blocks until the OLDEST submitted batch is done and returns views of its results in pinned host memory (valid until
+ *                       s3_stream_release): phase / withError as s3_batch_fetch_alignments, occOffsets[n + 1] (32-bit: a batch holds fewer than
+ *                       2^32 occurrences), occPos, occMeta = strand | mismatches << 8; `batch` is the slot's batch with the reads still resident
+ *                       (for the DP stages)
+ *   s3_stream_release   gives the oldest slot back
+ * One thread may drive all four calls as long as it never holds more than `depth` unreleased batches; or a producer thread acquires / submits
+ * while a consumer thread takes results.  Results come back in submission order. */
+typedef struct s3_stream s3_stream;
+typedef struct {
+    uint64_t        ticket;
+    uint32_t        n;
+    const uint8_t  *phase;
+    const uint32_t *withError;
+    const uint32_t *occOffsets, *occPos, *occMeta;
+    float           deviceMs;        /* device time of the batch's ladder (HIP events on its stream) */
+    s3_batch       *batch;
+} s3_stream_result;
+int  s3_stream_create(s3_index *ix, uint32_t maxReads, uint32_t wordPerQuery, int depth, s3_stream **out);
+int  s3_stream_acquire(s3_stream *st, uint32_t **queries, uint32_t **readLengths, uint32_t **seedLengths /* may be NULL */);
+int  s3_stream_submit(s3_stream *st, uint32_t n, int useSeedLengths, uint32_t numMismatch, uint32_t maxOutputPerRead, int reportType, uint64_t *ticket);
+int  s3_stream_next(s3_stream *st, s3_stream_result *res);
+int  s3_stream_release(s3_stream *st);
+void s3_stream_free(s3_stream *st);
 
 /* ---- default DP for half-aligned pairs -------------------------------------------------------------------------------------
  * Replaces HalfEndAlignmentEngine (DV-DPfunctions.cu:1888-2540): for every occurrence of the aligned end (HalfEndOccStream order) the

@@ -238,7 +238,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     if (recCap > 0xFFFFFF00ull) recCap = 0xFFFFFF00ull;
     if (occCap > 0xFFFFFF00ull) occCap = 0xFFFFFF00ull;
     b->recCap = (uint32_t)recCap; b->occCap = (uint32_t)occCap;
-    HIPCHK(hipStreamCreate(&b->stream));
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
@@ -324,7 +324,7 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
     }
     const uint32_t n = b->n;
     std::vector<uint32_t> lens(n);
-    HIPCHK(hipMemcpy(lens.data(), b->dLens, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(d2h(lens.data(), b->dLens, (size_t)n * 4, b->stream));
     for (uint32_t i = 0; i < n; i++)
         if (seedLengths[i] < 16 || seedLengths[i] > lens[i] || seedLengths[i] > 128)
             return fail(S3_EINVAL, "s3_batch_set_seed_lengths: a seed must have 16..128 bases and not exceed its read");
@@ -377,10 +377,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         HIPCHK(hipMemcpyAsync(counterSnap, b->dCounters, 64, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
-    // S3DP_HEAVY=0 switches the exact pass off (every read stays in the first pass: same results, reads in repeat families walk far beyond what
-    // MaxOutputPerRead keeps); n > 1: list a read once it has reserved more than n candidates (default: maxOut)
+    // S3DP_HEAVY=0 switches the second pass off (every read is walked by one lane: same results; reads in repeat families then hold the launch up);
+    // n > 1: list a read once it has reserved more than n candidates (default: 256)
     const size_t heavyEnv = envSize("S3DP_HEAVY", 1);                       // read per pass: tests switch it
-    in.heavyLimit = heavyEnv == 0 || maxOut >= 0x7FFFFFFFu ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : (maxOut < 64u ? 64u : maxOut));
+    in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : 256u);
     in.slotList = nullptr; in.slotCount = nullptr;
     for (;;) {
         HIPCHK(hipMemsetAsync(b->dRecCount, 0, 4, b->stream));
@@ -395,18 +395,18 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
         {
             static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", S3_V2_WAVES_PER_SIMD);
-            hipError_t le = (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, false, b->stream);
+            hipError_t le = (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
             if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
-            // the task records end where the first pass stopped writing; the exact pass and the check-and-extend kernel append behind them
-            HIPCHK(hipMemcpyAsync(b->dTaskEnd, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
             if (in.heavyLimit != 0xFFFFFFFFu) {
-                // exact pass over the listed reads (the kernel reads their number from device memory: no host round trip)
+                // second pass: the listed reads taken apart into (read, item) units (the kernel reads their number from device memory: no host round trip)
                 SearchIn in2 = in;
-                in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount;
+                in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu;
                 HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-                le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, true, b->stream);
-                if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (exact pass): ") + hipGetErrorString(le));
+                le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, b->stream);
+                if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
             }
+            // the task records end where the stepping kernel stopped writing; the check-and-extend kernel appends behind them
+            HIPCHK(hipMemcpyAsync(b->dTaskEnd, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
             if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
             if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2], b->stream));
             launchCheckExtend(b->ix->d, in, out, b->dTaskEnd, b->stream);
@@ -510,17 +510,17 @@ extern "C" int s3_batch_fetch_hits(s3_batch *b, uint64_t *hitOffsets, s3_hit *hi
     if (rc) return rc;
     const uint32_t n = b->n;
     std::vector<uint32_t> off((size_t)n + 1);
-    HIPCHK(hipMemcpy(off.data(), b->dHitOffsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(d2h(off.data(), b->dHitOffsets, ((size_t)n + 1) * 4, b->stream));
     const uint64_t total = off[n];
     if (nHitsOut) *nHitsOut = total;
     if (hitOffsets) for (size_t i = 0; i <= n; i++) hitOffsets[i] = off[i];
     if (hits) {
         if (total > hitCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_hits: hit buffer too small");
         static_assert(sizeof(s3_hit) == sizeof(DevHit), "hit layout");
-        HIPCHK(hipMemcpy(hits, b->dHits, total * sizeof(DevHit), hipMemcpyDeviceToHost));
+        HIPCHK(d2h(hits, b->dHits, total * sizeof(DevHit), b->stream));
     }
-    if (totalOcc) HIPCHK(hipMemcpy(totalOcc, b->dTotalOcc, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (withError) HIPCHK(hipMemcpy(withError, b->dWithError, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (totalOcc) HIPCHK(d2h(totalOcc, b->dTotalOcc, (size_t)n * 4, b->stream));
+    if (withError) HIPCHK(d2h(withError, b->dWithError, (size_t)n * 32, b->stream));
     return S3_OK;
 }
 
@@ -568,7 +568,7 @@ extern "C" int s3_batch_counters(s3_batch *b, s3_counters *out)
     HIPCHK(hipSetDevice(b->ix->dev));
     unsigned long long c[8] = {0};
     HIPCHK(hipStreamSynchronize(b->stream));
-    HIPCHK(hipMemcpy(c, b->dCounters, 64, hipMemcpyDeviceToHost));
+    HIPCHK(d2h(c, b->dCounters, 64, b->stream));
     out->rankQueries = c[0]; out->ltLookups = c[1]; out->saReads = c[2]; out->ceWindows = c[3];
     out->records = b->recordsTotal;
     return S3_OK;

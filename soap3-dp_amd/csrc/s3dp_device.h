@@ -56,14 +56,14 @@ struct SearchIn {
     uint32_t        uniformLen;  // != 0: every active read has this length (model kept in LDS by the v2 kernel)
     uint32_t        earlyMinI;   // ... but only once this many characters are matched: a chance match of the lookup characters costs a step (one line) to drop,
                                  // a candidate three lines to verify
-    uint32_t        heavyLimit;  // first pass: a read that reserves more check-and-extend candidates than this is listed for the exact pass
-    const uint32_t *slotList;    // exact pass: the listed slots ...
+    uint32_t        heavyLimit;  // first pass: a read that reserves more check-and-extend candidates than this is listed for the second pass
+    const uint32_t *slotList;    // second pass (item mode: one work unit per item of a listed read): the listed slots ...
     const uint32_t *slotCount;   // ... and how many (device memory, written by the first pass)
     uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_v2.hip)
 };
 
 #define S3_REC_TASK  (1u << 28)
-#define S3_REC_EXACT_PASS 0x80000000u       // in the item word: record written by the exact pass (records of a listed read without it are stale)
+#define S3_REC_PASS2 0x80000000u            // in the item word: record written by the second pass (records of a listed read without it are stale)
 #define S3_REC_EARLY (1u << 29)              // task written inside the exact lookup step (single-suffix range): the rest of that step is verified too
 
 struct SearchOut {
@@ -74,7 +74,7 @@ struct SearchOut {
     uint32_t           *flags;
     unsigned long long *counters;   // optional: rank, lt, sa, ce tallies
     unsigned long long *workHead;   // v2 kernel: head of the item queue (zeroed before every launch)
-    uint8_t            *heavyFlags; // per slot: listed for the exact pass (zeroed before every first pass)
+    uint8_t            *heavyFlags; // per slot: listed for the second pass (zeroed before every first pass)
     uint32_t           *heavyList, *heavyCount;
 };
 
@@ -107,7 +107,7 @@ void launchDp(const DpArgs &a, hipStream_t s);
 
 void launchOrientReads(const uint32_t *queries, const uint32_t *lengths, uint32_t *readsT, uint32_t n, uint32_t wpq, uint32_t S, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
-int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, bool exact, hipStream_t s);
+int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
 void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskEnd, hipStream_t s);
 int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int
 void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s);

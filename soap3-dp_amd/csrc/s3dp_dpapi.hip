@@ -69,7 +69,7 @@ extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLe
     DA(dPattern, (size_t)maxProblems * h->patternLen);
     DA(dTable, h->tableWords * maxProblems);
 #undef DA
-    HIPCHK(hipStreamCreate(&h->stream));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&h->ev[0])); HIPCHK(hipEventCreate(&h->ev[1]));
     *outp = h;
     return S3_OK;

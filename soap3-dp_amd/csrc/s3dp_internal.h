@@ -11,6 +11,13 @@
 #include "s3dp_model.h"
 
 namespace s3i {
+// blocking device-to-host copy on the object's own stream (the streams are non-blocking: nothing here may lean on the legacy default stream,
+// or two batches driven by two host threads would serialise)
+inline hipError_t d2h(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
 int fail(int code, const std::string &msg);               // records the message for s3_last_error and returns `code`
 }
 #define HIPCHK(x)                                                                                          \

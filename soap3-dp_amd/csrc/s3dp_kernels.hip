@@ -76,8 +76,8 @@ __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint3
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint4 r = recs[i];
         if (r.x == 0xFFFFFFFFu || (r.y & S3_REC_TASK)) continue;            // unused slot of a reserved block / check-and-extend task (v2 kernel)
-        // a read listed for the exact pass keeps only what that pass wrote
-        if (r.x & S3_REC_EXACT_PASS) r.x &= ~S3_REC_EXACT_PASS;
+        // a read listed for the second pass keeps only what that pass (and check-and-extend of its tasks) wrote
+        if (r.x & S3_REC_PASS2) r.x &= ~S3_REC_PASS2;
         else if (heavyFlags[r.x / groups]) continue;
         ordered[itemOffsets[r.x] + (r.y & 0xFFFFFFu)] = r;
     }

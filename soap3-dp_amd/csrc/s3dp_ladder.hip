@@ -266,18 +266,18 @@ extern "C" int s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *
     if (rc) return rc;
     const uint32_t n = b->n;
     std::vector<uint32_t> off((size_t)n + 1);
-    HIPCHK(hipMemcpy(off.data(), b->dOutOffsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(d2h(off.data(), b->dOutOffsets, ((size_t)n + 1) * 4, b->stream));
     const uint64_t total = off[n];
     if (nOccOut) *nOccOut = total;
-    if (phase) HIPCHK(hipMemcpy(phase, b->dPhase, n, hipMemcpyDeviceToHost));
-    if (withError) HIPCHK(hipMemcpy(withError, b->dFinalWithError, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (phase) HIPCHK(d2h(phase, b->dPhase, n, b->stream));
+    if (withError) HIPCHK(d2h(withError, b->dFinalWithError, (size_t)n * 32, b->stream));
     if (occOffsets) for (size_t i = 0; i <= n; i++) occOffsets[i] = off[i];
     if (occPos || occStrand || occMis) {
         if (total > occCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_alignments: output arrays too small");
-        if (occPos) HIPCHK(hipMemcpy(occPos, b->dOutPos, total * 4, hipMemcpyDeviceToHost));
+        if (occPos) HIPCHK(d2h(occPos, b->dOutPos, total * 4, b->stream));
         if (occStrand || occMis) {
             std::vector<uint32_t> meta(total);
-            HIPCHK(hipMemcpy(meta.data(), b->dOutMeta, total * 4, hipMemcpyDeviceToHost));
+            HIPCHK(d2h(meta.data(), b->dOutMeta, total * 4, b->stream));
             for (uint64_t i = 0; i < total; i++) {
                 if (occStrand) occStrand[i] = (uint8_t)(meta[i] & 0xFF);
                 if (occMis) occMis[i] = (uint8_t)((meta[i] >> 8) & 0xFF);
@@ -485,27 +485,27 @@ extern "C" int s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t
     if (rc) return rc;
     static_assert(sizeof(s3_pair_result) == sizeof(DevPair) && sizeof(s3_pair_xa) == sizeof(DevPairXa), "pair layouts");
     const uint32_t n = b->n, nPairs = n / 2;
-    if (pairs && nPairs) HIPCHK(hipMemcpy(pairs, b->dPairs, (size_t)nPairs * sizeof(DevPair), hipMemcpyDeviceToHost));
+    if (pairs && nPairs) HIPCHK(d2h(pairs, b->dPairs, (size_t)nPairs * sizeof(DevPair), b->stream));
     std::vector<uint32_t> off((size_t)nPairs + 1);
-    HIPCHK(hipMemcpy(off.data(), b->dXaOutOffsets, ((size_t)nPairs + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(d2h(off.data(), b->dXaOutOffsets, ((size_t)nPairs + 1) * 4, b->stream));
     const uint64_t nXa = off[nPairs];
     if (nXaOut) *nXaOut = nXa;
     if (xaOffsets) for (size_t i = 0; i <= nPairs; i++) xaOffsets[i] = off[i];
     if (xa) {
         if (nXa > xaCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_pairs: pair list array too small");
-        if (nXa) HIPCHK(hipMemcpy(xa, b->dXaOut, nXa * sizeof(DevPairXa), hipMemcpyDeviceToHost));
+        if (nXa) HIPCHK(d2h(xa, b->dXaOut, nXa * sizeof(DevPairXa), b->stream));
     }
     std::vector<uint32_t> ooff((size_t)n + 1);
-    HIPCHK(hipMemcpy(ooff.data(), b->dOutOffsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(d2h(ooff.data(), b->dOutOffsets, ((size_t)n + 1) * 4, b->stream));
     const uint64_t total = ooff[n];
     if (nOccOut) *nOccOut = total;
     if (occOffsets) for (size_t i = 0; i <= n; i++) occOffsets[i] = ooff[i];
     if (occPos || occStrand || occMis) {
         if (total > occCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_pairs: occurrence arrays too small");
-        if (occPos && total) HIPCHK(hipMemcpy(occPos, b->dOutPos, total * 4, hipMemcpyDeviceToHost));
+        if (occPos && total) HIPCHK(d2h(occPos, b->dOutPos, total * 4, b->stream));
         if ((occStrand || occMis) && total) {
             std::vector<uint32_t> meta(total);
-            HIPCHK(hipMemcpy(meta.data(), b->dOutMeta, total * 4, hipMemcpyDeviceToHost));
+            HIPCHK(d2h(meta.data(), b->dOutMeta, total * 4, b->stream));
             for (uint64_t i = 0; i < total; i++) {
                 if (occStrand) occStrand[i] = (uint8_t)(meta[i] & 0xFF);
                 if (occMis) occMis[i] = (uint8_t)((meta[i] >> 8) & 0xFF);
@@ -521,10 +521,10 @@ extern "C" int s3_batch_fetch_pair_origins(s3_batch *b, uint8_t *fromSaRange, si
     int rc = s3_batch_sync(b);
     if (rc) return rc;
     uint32_t total = 0;
-    HIPCHK(hipMemcpy(&total, b->dOutOffsets + b->n, 4, hipMemcpyDeviceToHost));
+    HIPCHK(d2h(&total, b->dOutOffsets + b->n, 4, b->stream));
     if (total > cap) return fail(S3_EOVERFLOW, "s3_batch_fetch_pair_origins: array too small");
     std::vector<uint32_t> meta(total ? total : 1);
-    if (total) HIPCHK(hipMemcpy(meta.data(), b->dOutMeta, (size_t)total * 4, hipMemcpyDeviceToHost));
+    if (total) HIPCHK(d2h(meta.data(), b->dOutMeta, (size_t)total * 4, b->stream));
     for (uint32_t i = 0; i < total; i++) fromSaRange[i] = (uint8_t)((meta[i] >> 16) & 1u);
     return S3_OK;
 }

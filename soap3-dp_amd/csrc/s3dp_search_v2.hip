@@ -15,10 +15,11 @@
 //     in LDS word-interleaved by lane: a read character is one LDS word and a shift;
 //   * an item starts from the longest lookup table the index holds (13-mers of the file format, or the 14- / 15- / 16-mer tables built in HBM at
 //     upload: the state behind the lookup step's first characters, s3dp_kernels.hip::launchLongLookup);
-//   * check-and-extend runs in its own kernel (ceKernel, below): the stepping kernel writes task records and goes on (template parameter SPLIT);
-//   * reads that reserve more candidates than MaxOutputPerRead can ever keep ("heavy" reads: repeat families) leave the first pass and are searched
-//     again by the SPLIT = false form of the kernel, which verifies candidates inside the state machine and therefore stops exactly where the CPU
-//     path stops (at MaxOutputPerRead accepted occurrences).  Without it a read inside a million-copy family walks its whole 4-mismatch neighbourhood.
+//   * check-and-extend runs in its own kernel (ceKernel, below): the stepping kernel writes task records and goes on;
+//   * a lane walks the (case, strand) items of its read one after the other -- fine for a read with a handful of candidates, a disaster for a read
+//     inside a repeat family with 10^5 copies, whose 4-mismatch neighbourhood is 10^5 rank queries long: a few such lanes run for a second while
+//     the chip idles.  So a read that reserves more candidates than in.heavyLimit leaves the first pass at once ("heavy" read, listed), and a
+//     second launch of the same kernel takes the listed reads apart: its work unit is ONE (read, case, strand) item, twenty lanes per read.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -29,10 +30,9 @@ namespace s3 {
 
 namespace v2 {
 
-enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_CESA = 2, ST_CETXT = 3, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6, ST_RESUME = 7 };
+enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6, ST_RESUME = 7 };
 constexpr uint32_t ID_NONE = 0x7FFFFFFFu;
 constexpr int STACK = 20;
-constexpr uint32_t CE_CHUNK = 112;                   // text characters compared per iteration (8 words minus alignment slack)
 
 struct Frame { uint32_t fl, fr, rl, meta; };        // rr = rl + (fr - fl);  meta = s | i << 3 | ins << 14 | occ << 17
 
@@ -96,13 +96,14 @@ using namespace v2;
 // keep a memory request in flight.
 // UNIFORM: every read of the launch has the same length, the model (all cases) then lives in LDS; otherwise step
 // descriptors are read from the global table (L1/L2 resident).
-// SPLIT: check-and-extend runs in its own kernel (ceKernel below).  A lane that reaches a small SA range inside the check window writes a
+// Check-and-extend runs in its own kernel (ceKernel below).  A lane that reaches a small SA range inside the check window writes a
 // TASK record (range + where it stands in the model) instead of walking the range itself, reserves one sequence number per candidate and goes
 // on with its search: two dependent round trips per candidate (SA value, then text) and the compare code leave the stepping loop, which is
 // bound by its instruction count.  The record stream keeps the CPU path's order because accepted candidates are written under the reserved
 // numbers; rejected ones leave holes the ordering pass skips.  Not counting the candidates in `total` only delays the early stop at
 // MaxOutputPerRead: the per-read cut is applied again, exactly, when the records are merged.
-template <bool UNIFORM, bool SPLIT>
+// in.slotList != NULL: item mode (second pass) -- the work queue holds (listed read, item) units instead of reads.
+template <bool UNIFORM>
 __global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_V2_WAVES_PER_SIMD)
 searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 {
@@ -122,17 +123,17 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         __syncthreads();
     }
 
-    const uint32_t nSlots = in.slotList ? *in.slotCount : in.nActive;       // exact pass: the slots the first pass listed
+    const unsigned long long nSlots = in.slotList ? (unsigned long long)*in.slotCount * ((uint32_t)in.nCases * 2u) : in.nActive;   // item mode: listed reads x items
     const uint32_t nCases = (uint32_t)in.nCases;
     const uint32_t groups = nCases * 2u;
-    uint32_t nRank = 0, nLt = 0, nSa = 0, nCe = 0;
+    uint32_t nRank = 0, nLt = 0;
 
     // ---- per-lane item + search state ---------------------------------------------------------------------
     uint32_t state = ST_DONE;
     bool hasItem = false;
     uint32_t cntIdx = 0, seq = 0, total = 0, rIdx = 0, loadOff = 0, slotIdx = 0, sub = 0;
     uint32_t readTotal = 0;                                                 // occurrences the read's finished items have for sure (the cut at maxOut runs across items)
-    uint32_t readCand = 0;                                                  // SPLIT: check-and-extend candidates this read has reserved
+    uint32_t readCand = 0;                                                  // check-and-extend candidates this read has reserved
     bool goHeavy = false;
     uint32_t strand = 0;
     int Li = 0, nSteps = 0;
@@ -141,9 +142,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     int s = 0, i = 0, ins = 0, occ = 0;
     Frame stack[STACK];
     int sp = 0;
-    uint32_t ceQ = 0, ceQEnd = 0, ceRp = 0, ceOff = 0;
-    int ceS = 0, ceI = 0, ceIns = 0, ceOcc = 0;
-    int ceT = 0, ceII = 0, ceInsCur = 0, ceAcc = 0, ceMm = 0;
     uint32_t ltA = 0, ltB = 0, ltC = 0, ltD = 0;                            // lookup-table keys of the starting item
     bool padded = false;                                                    // the item's lookup range may hold an element that is no occurrence
     // wave-uniform work queue window
@@ -203,23 +201,17 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (i < lenEff && alive) {
                 const int pos = st.start + st.dir * i;
                 if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
-                    if constexpr (SPLIT) {
-                        if (pendMeta >> 31) { state = ST_RESUME; return; }   // one record per lane and trip
-                        pendMeta = 0x80000000u | seq | S3_REC_TASK;
-                        pendA = g.fl;
-                        pendB = (g.fr - g.fl) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
-                        seq += g.fr - g.fl + 1u;
-                        readCand += g.fr - g.fl + 1u;
-                        if (readCand > in.heavyLimit) { goHeavy = true; state = ST_DONE; return; }
-                        needPop = true;
-                        continue;
-                    } else {
-                        ceQ = g.fl; ceQEnd = g.fr; ceS = s; ceI = i; ceIns = ins; ceOcc = occ;
-                        state = ST_CESA;
-                        return;
-                    }
+                    if (pendMeta >> 31) { state = ST_RESUME; return; }       // one record per lane and trip
+                    pendMeta = 0x80000000u | seq | S3_REC_TASK;
+                    pendA = g.fl;
+                    pendB = (g.fr - g.fl) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+                    seq += g.fr - g.fl + 1u;
+                    readCand += g.fr - g.fl + 1u;
+                    if (readCand > in.heavyLimit) { goHeavy = true; state = ST_DONE; return; }
+                    needPop = true;
+                    continue;
                 }
-                if constexpr (SPLIT) {
+                {
                     // Few suffixes left inside the exact lookup step: walking the rest of the step can only keep or lose each of them -- in the same
                     // relative order, exact steps map a range onto a range order-preservingly -- and with fewer than the next step's threshold the next step
                     // hands them to check-and-extend at its first position anyway (in.earlyCe: the largest range handed over; a candidate costs three random
@@ -255,8 +247,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         // (no global load in this section may stall the wave: step counts come packed in a kernel argument, the
         //  read index list of a whole chunk is prefetched into two registers per lane when the chunk is taken)
         if (state == ST_DONE && hasItem) {
-            if (SPLIT && goHeavy) {
-                // this read goes to the exact pass: whatever it wrote so far is ignored there (scatter / check-and-extend test the flag)
+            if (goHeavy) {
+                // this read goes to the second pass: whatever it wrote so far is ignored there (scatter / check-and-extend test the flag)
                 out.heavyFlags[slotIdx] = 1;
                 out.heavyList[atomicAdd(out.heavyCount, 1u)] = slotIdx;
                 pendMeta = 0;
@@ -266,7 +258,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 out.itemCounts[cntIdx] = seq;
                 readTotal += total;
                 sub++;
-                if (readTotal >= in.maxOut) {
+                if (in.slotList) sub = groups;                              // item mode: the unit was this one item
+                else if (readTotal >= in.maxOut) {
                     // the per-read cut (mergeCountKernel) ends inside this item or before: what follows can never be kept
                     for (; sub < groups; sub++) out.itemCounts[slotIdx * groups + sub] = 0;
                 }
@@ -289,8 +282,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 else {
                     chunkCur = chunkBase = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots;
                     if (in.slotList) {
-                        sl0 = b + lane < nSlots ? in.slotList[b + lane] : 0u;
-                        sl1 = b + 64u + lane < nSlots ? in.slotList[b + 64u + lane] : 0u;
+                        sl0 = b + lane < nSlots ? in.slotList[(b + lane) / groups] : 0u;
+                        sl1 = b + 64u + lane < nSlots ? in.slotList[(b + 64u + lane) / groups] : 0u;
                         if (in.active) { act0 = in.active[sl0]; act1 = in.active[sl1]; }
                     } else if (in.active) {
                         act0 = b + lane < nSlots ? in.active[b + lane] : 0u;
@@ -309,13 +302,14 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 const uint32_t s1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)sl1);
                 if (state == ST_DONE && rank < avail) {
                     slotIdx = (uint32_t)(chunkCur + rank);
-                    if (in.slotList) slotIdx = off < 64u ? s0 : s1;
+                    sub = 0;
+                    if (in.slotList) { sub = slotIdx % groups; slotIdx = off < 64u ? s0 : s1; }
                     rIdx = in.active ? (off < 64u ? a0 : a1) : slotIdx;
                     readTotal = 0; readCand = 0;
                     if constexpr (UNIFORM) Li = (int)in.uniformLen;
-                    sub = 0; casIdx = 0; strand = 0;
-                    nSteps = (int)(in.nStepsPacked & 7u);
-                    cntIdx = slotIdx * groups;
+                    casIdx = sub >> 1; strand = sub & 1u;
+                    nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
+                    cntIdx = slotIdx * groups + sub;
                     seq = 0; total = 0; sp = 0; loadOff = 0;
                     hasItem = true;
                     state = ST_LOAD;
@@ -371,8 +365,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         const uint4 *dummy16 = (const uint4 *)ix.pac;                // always-valid, cache-hot address for lanes that need nothing
         const uint4 *aP0 = dummy16, *aP1 = dummy16;
         const uint32_t *aD0 = ix.pac, *aD1 = ix.pac, *aD2 = ix.pac, *aD3 = ix.pac;
-        bool zeroP0 = false, zeroP1 = false, ceReject = false;
-        uint32_t ceCnt = 0, ceLeft = 0, ceLen = 0, tpos = 0;
         if (state == ST_STEP) {
             dir = stepAt(s).dir;
             const uint32_t inv = dir < 0 ? ix.fwd.inverseSa0 : ix.rev.inverseSa0;
@@ -407,24 +399,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 if (bidir) { aD2 = ix.rlkt + (ltC ? ltC - 1u : 0u); aD3 = ix.rlkt + ltD; }
                 nLt += bidir ? 4 : 2;
             }
-        } else if (!SPLIT && state == ST_CESA) {
-            aD0 = ix.sa + ceQ;
-            nSa++;
-        } else if (!SPLIT && state == ST_CETXT) {
-            const S3Step st = stepAt(ceT);
-            const int pos = st.start + st.dir * ceII;
-            const int left = pos < st.end ? pos : st.end, right = pos < st.end ? st.end : pos;
-            ceLeft = (uint32_t)left; ceLen = (uint32_t)(right - left + 1);
-            if (ceOff == 0 && ceRp + ceLeft > ix.n) ceReject = true;                  // BGS-HostAlgnmtAlgo2.cpp:122-125
-            else {
-                ceCnt = ceLen - ceOff > CE_CHUNK ? CE_CHUNK : ceLen - ceOff;
-                tpos = ceRp + ceLeft + ceOff;
-                const size_t bw = tpos >> 4;
-                const uint32_t words = ((tpos & 15u) + ceCnt + 15u) >> 4;
-                if (bw + 4 <= ix.pacWords) aP0 = (const uint4 *)(ix.pac + bw); else zeroP0 = true;
-                if (words > 4 && bw + 8 <= ix.pacWords) aP1 = (const uint4 *)(ix.pac + bw + 4); else zeroP1 = true;
-                nCe += (ceCnt + 31u) >> 5;
-            }
         }
         // ---------- issue: every lane issues the same 10 loads, back to back, no branches ----------
         // cooperative rank lines: 4 adjacent lanes fetch the 4 x 16 B of one owner's line (owners without a request: line 0)
@@ -438,15 +412,13 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             return base + (o == ID_NONE ? (size_t)sub : (size_t)(o & 0x7FFFFFFFu) * 4u + sub);
         };
         const uint4 va0 = *lineAddr(o0), va1 = *lineAddr(o1), va2 = *lineAddr(o2), va3 = *lineAddr(o3);
-        uint4 p0 = *aP0, p1 = *aP1;
+        const uint4 p0 = *aP0, p1 = *aP1;
         const uint32_t d0 = *aD0, d1 = *aD1, d2 = *aD2, d3 = *aD3;
         // ---------- stage the cooperative lines in LDS (owner slot = 64 B); slots of owners without a request get line 0 ----------
         stage[(q4) * 4u + sub] = va0;
         stage[(16u + q4) * 4u + sub] = va1;
         stage[(32u + q4) * 4u + sub] = va2;
         stage[(48u + q4) * 4u + sub] = va3;
-        if (zeroP0) p0 = make_uint4(0, 0, 0, 0);
-        if (zeroP1) p1 = make_uint4(0, 0, 0, 0);
         const uint32_t saVal = d0;
         __builtin_amdgcn_wave_barrier();
 
@@ -533,52 +505,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             s = 0; i = ll; ins = 0; occ = 0;
             doSettle = true;
-        } else if (!SPLIT && state == ST_CESA) {
-            const S3Step st0 = stepAt(ceS);
-            const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - ceI;
-            ceRp = saVal - (uint32_t)leftAlign;                               // 32-bit wrap, as the reference
-            ceT = ceS; ceII = ceI; ceInsCur = ceIns; ceAcc = ceOcc; ceOff = 0; ceMm = 0;
-            state = ST_CETXT;
-        } else if (!SPLIT && state == ST_CETXT) {
-            bool stepDone = false, reject = ceReject;
-            if (!reject) {
-                // text words -> own stage slot, then 16 characters at a time: XOR, fold, popcount
-                myStage32[0] = p0.x; myStage32[1] = p0.y; myStage32[2] = p0.z; myStage32[3] = p0.w;
-                myStage32[4] = p1.x; myStage32[5] = p1.y; myStage32[6] = p1.z; myStage32[7] = p1.w;
-                myStage32[8] = 0;
-                const uint32_t tsh = tpos & 15u;
-                int mm = 0;
-                for (uint32_t o = 0; o < ceCnt; o += 16u) {
-                    const uint32_t c = ceCnt - o > 16u ? 16u : ceCnt - o;
-                    const uint32_t tw0 = myStage32[(tsh + o) >> 4], tw1 = myStage32[((tsh + o) >> 4) + 1];
-                    const uint32_t sh = ((tsh + o) & 15u) * 2u;
-                    const uint32_t tw = sh ? (tw0 << sh) | (tw1 >> (32u - sh)) : tw0;
-                    const uint32_t rw = readWindow((int)(ceLeft + ceOff + o));
-                    uint32_t x = tw ^ rw;
-                    x = (x | (x >> 1)) & 0x55555555u;
-                    if (c < 16u) x &= ~0u << (32u - 2u * c);
-                    mm += __popc(x);
-                }
-                ceMm += mm;
-                ceOff += ceCnt;
-                stepDone = ceOff >= ceLen;
-                if (stepDone) {
-                    const S3Step st = stepAt(ceT);
-                    const int tot = ceMm + ceInsCur;
-                    if (tot < st.minErr || tot > st.maxErr) reject = true;
-                    else { ceAcc += tot; ceT++; ceII = 0; ceInsCur = 0; ceOff = 0; ceMm = 0; }
-                }
-            }
-            bool candidateDone = reject;
-            if (!reject && stepDone && ceT >= nSteps) {
-                emit(1, ceRp, ceRp, (uint32_t)ceAcc);
-                total++;
-                candidateDone = true;
-            }
-            if (candidateDone) {
-                if (readTotal + total >= in.maxOut || ceQ >= ceQEnd) { doSettle = true; needPop = true; }   // check-and-extend of this range is finished: pop in this trip
-                else { ceQ++; state = ST_CESA; }
-            }
         }
         if (doSettle) settle(needPop);
         // ---------- write the parked records (convergent) ----------
@@ -596,7 +522,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 }
                 if (pendMeta >> 31) {
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(SPLIT ? cntIdx : cntIdx | S3_REC_EXACT_PASS, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(in.slotList ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
                     pendMeta = 0;
                 }
                 recCur += np;
@@ -609,8 +535,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     if (out.counters) {
         atomicAdd(&out.counters[0], (unsigned long long)nRank);
         atomicAdd(&out.counters[1], (unsigned long long)nLt);
-        atomicAdd(&out.counters[2], (unsigned long long)nSa);
-        atomicAdd(&out.counters[3], (unsigned long long)nCe);
     }
 }
 
@@ -632,8 +556,9 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         const uint64_t idx = base + lane;
         uint4 rec = make_uint4(0xFFFFFFFFu, 0, 0, 0);
         if (idx < nRec) rec = out.recs[idx];
-        bool task = rec.x != 0xFFFFFFFFu && !(rec.x & S3_REC_EXACT_PASS) && (rec.y & S3_REC_TASK);
-        if (task && out.heavyFlags[rec.x / groups]) task = false;               // the exact pass searches this read again
+        bool task = rec.x != 0xFFFFFFFFu && (rec.y & S3_REC_TASK);
+        const uint32_t item = rec.x & ~S3_REC_PASS2;
+        if (task && !(rec.x & S3_REC_PASS2) && out.heavyFlags[item / groups]) task = false;     // stale: the second pass searched this read again
         const bool early = task && (rec.y & S3_REC_EARLY);
         uint32_t size = 0, rIdx = 0, casIdx = 0, strand = 0;
         int Li = 0, nSteps = 0, s0 = 0, i0 = 0, ins0 = 0, occ0 = 0;
@@ -641,7 +566,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
             size = (rec.w & 0xFFu) + 1u;
             const uint32_t meta = rec.w >> 8;
             s0 = (int)(meta & 7u); i0 = (int)((meta >> 3) & 0x7FFu); ins0 = (int)((meta >> 14) & 7u); occ0 = (int)((meta >> 17) & 7u);
-            const uint32_t slot = rec.x / groups, sub = rec.x % groups;
+            const uint32_t slot = item / groups, sub = item % groups;
             casIdx = sub >> 1; strand = sub & 1u;
             rIdx = in.active ? in.active[slot] : slot;
             Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
@@ -733,29 +658,22 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
     }
 }
 
-// exact = false: the first pass over in.nActive slots (check-and-extend handed to ceKernel, heavy reads listed);  exact = true: the second pass over the
-// listed slots with check-and-extend inside the state machine.  Returns a hipError_t.
-int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, bool exact, hipStream_t s)
+// First pass (in.slotList == NULL): one work unit per read of in.nActive slots.  Second pass: one unit per (listed read, item); the kernel reads
+// the number of listed reads from device memory, so the launch needs no host round trip.  Returns a hipError_t.
+int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
 {
     if (in.nActive == 0) return (int)hipSuccess;
-    uint64_t blocks = ((uint64_t)in.nActive + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    uint64_t blocks = ((uint64_t)in.nActive * (in.slotList ? (uint64_t)in.nCases * 2u : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wLds * 256u);
     if (lds > 48u * 1024u) {
         // more than the default dynamic LDS limit: without the attribute the launch itself fails later with a less useful error
-        hipError_t e = hipFuncSetAttribute((const void *)searchKernelV2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)searchKernelV2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)searchKernelV2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)searchKernelV2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)searchKernelV2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)searchKernelV2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    if (!exact) {
-        if (in.uniformLen) hipLaunchKernelGGL((searchKernelV2<true, true>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
-        else hipLaunchKernelGGL((searchKernelV2<false, true>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
-    } else {
-        if (in.uniformLen) hipLaunchKernelGGL((searchKernelV2<true, false>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
-        else hipLaunchKernelGGL((searchKernelV2<false, false>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
-    }
+    if (in.uniformLen) hipLaunchKernelGGL((searchKernelV2<true>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+    else hipLaunchKernelGGL((searchKernelV2<false>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
     return (int)hipSuccess;
 }
 

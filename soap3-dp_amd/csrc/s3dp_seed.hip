@@ -144,7 +144,7 @@ int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<
         SCHK(hipStreamSynchronize(st));
     }
     statusOut.resize(nSeeds);
-    if (nSeeds) SCHK(hipMemcpy(statusOut.data(), dStatus, nSeeds, hipMemcpyDeviceToHost));
+    if (nSeeds) SCHK(d2h(statusOut.data(), dStatus, nSeeds, st));
 #undef SCHK
     cleanup();
     return checkFlags(b);

@@ -4,6 +4,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -234,133 +237,6 @@ size_t parseRecord(const TextView &all, size_t p, bool fq, uint32_t maxReadLengt
 }
 }  // namespace
 
-// Parses one read file with all host threads (count pass, then fill pass).  Read k of the file becomes read stride * k + offset of `rs`; `allocate` is
-// called between the passes with the number of reads found (and whether the file is FASTQ, and the packed words per read): it sizes and zeroes `rs` and
-// returns how many reads of this file are to be stored (0xFFFFFFFF: failure).
-static bool loadInto(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err, uint32_t stride,
-                     uint32_t offset, const std::function<uint32_t(uint32_t, bool, uint32_t)> &allocate)
-{
-    gzFile gz = gzopen(file.c_str(), "r");
-    if (!gz) { err = "cannot open " + file; return false; }
-    gzbuffer(gz, 1 << 20);
-    unsigned char charMap[256];
-    memset(charMap, 0, sizeof charMap);                                 // INDEXFillCharMap, IndexHandler.cpp:25-48
-    const char *acgt = "ACGT";
-    for (int i = 0; i < 4; i++) { charMap[(int)acgt[i]] = (unsigned char)i; charMap[(int)acgt[i] - 'A' + 'a'] = (unsigned char)i; }
-    charMap['U'] = charMap['T']; charMap['N'] = charMap['G']; charMap['u'] = charMap['t']; charMap['n'] = charMap['g'];
-    uint32_t w = 1;
-    while (w < maxReadLength) w *= 2;
-    const uint32_t wpq = w / 16 ? w / 16 : 1;
-    std::string inflated;
-    std::unique_ptr<char, void (*)(void *)> plain(nullptr, free);
-    TextView all;
-    if (gzdirect(gz)) {
-        // not compressed: read the file itself, one slice per thread
-        gzclose(gz);
-        FILE *f = fopen(file.c_str(), "rb");
-        if (!f) { err = "cannot open " + file; return false; }
-        fseek(f, 0, SEEK_END);
-        const long long size = ftell(f);
-        fclose(f);
-        plain.reset((char *)malloc((size_t)size + 1));
-        if (!plain) { err = "out of memory reading " + file; return false; }
-        char *buf0 = plain.get();
-        all.p = buf0; all.n = (size_t)size;
-        const int Tr = hostThreads() > 16 ? 16 : hostThreads();
-        std::vector<std::thread> rd;
-        std::atomic<bool> bad(false);
-        for (int t = 0; t < Tr; t++) rd.emplace_back([&, t] {
-            const size_t lo = (size_t)size / (size_t)Tr * (size_t)t, hi = t + 1 == Tr ? (size_t)size : (size_t)size / (size_t)Tr * (size_t)(t + 1);
-            FILE *g = fopen(file.c_str(), "rb");
-            if (!g || fseek(g, (long)lo, SEEK_SET) != 0 || fread(buf0 + lo, 1, hi - lo, g) != hi - lo) bad = true;
-            if (g) fclose(g);
-        });
-        for (auto &x : rd) x.join();
-        if (bad) { err = "cannot read " + file; return false; }
-    } else {
-        std::vector<char> buf(1 << 24);
-        int got;
-        while ((got = gzread(gz, buf.data(), (unsigned)buf.size())) > 0) inflated.append(buf.data(), (size_t)got);
-        gzclose(gz);
-        all.p = inflated.data(); all.n = inflated.size();
-    }
-    const size_t N = all.size();
-    size_t p0 = 0;
-    while (p0 < N && all[p0] != '>' && all[p0] != '@') p0++;
-    const bool fq = p0 < N && all[p0] == '@';
-    // a record starts at a line that begins with the marker; for FASTQ the line after next must begin with '+' (a quality line may begin with '@')
-    auto isStart = [&](size_t p) -> bool {
-        if (p >= N || all[p] != (fq ? '@' : '>')) return false;
-        if (p > 0 && all[p - 1] != '\n') return false;
-        if (!fq) return true;
-        size_t q = p;
-        for (int k = 0; k < 2; k++) { while (q < N && all[q] != '\n') q++; if (q < N) q++; }
-        return q < N && all[q] == '+';
-    };
-    const int T = hostThreads();
-    std::vector<Piece> pieces((size_t)T);
-    for (int t = 0; t < T; t++) {
-        size_t b = p0 + (N - p0) / (size_t)T * (size_t)t;
-        if (t == 0) b = p0;
-        else { while (b < N && !isStart(b)) b++; }
-        pieces[(size_t)t].beg = b;
-    }
-    for (int t = 0; t < T; t++) pieces[(size_t)t].end = t + 1 < T ? pieces[(size_t)t + 1].beg : N;
-    std::atomic<bool> anyBad(false);
-    std::vector<std::thread> th;
-    // count pass
-    for (int t = 0; t < T; t++) th.emplace_back([&, t] {
-        Piece &P = pieces[(size_t)t];
-        std::string name, q; std::vector<uint8_t> seq; bool bad = false;
-        uint32_t c = 0;
-        size_t p = P.beg;
-        while (p < P.end) {
-            while (p < P.end && all[p] != '>' && all[p] != '@') p++;
-            if (p >= P.end) break;
-            p = parseRecord(all, p, fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] { c++; }, false, name, seq, q, bad);
-        }
-        P.count = c;
-        if (bad) anyBad = true;
-    });
-    for (auto &x : th) x.join();
-    th.clear();
-    if (anyBad) { err = "a read of length 0 in the read file"; return false; }
-    uint32_t n = 0;
-    for (auto &P : pieces) { P.first = n; n += P.count; }
-    const uint32_t limit = allocate(n, fq, wpq);
-    if (limit == 0xFFFFFFFFu) { err = "out of memory for the reads of " + file; return false; }
-    // fill pass; 32 consecutive reads share packed words (32-interleaved layout), so a piece boundary inside a group of 32 is written by
-    // two threads -- to different words (word index = group base + r % 32 + 32 w), never the same one
-    for (int t = 0; t < T; t++) th.emplace_back([&, t] {
-        const Piece &P = pieces[(size_t)t];
-        std::string name, q; std::vector<uint8_t> seq; bool bad = false;
-        uint32_t r = P.first;
-        size_t p = P.beg;
-        while (p < P.end) {
-            while (p < P.end && all[p] != '>' && all[p] != '@') p++;
-            if (p >= P.end) break;
-            p = parseRecord(all, p, fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] {
-                if (r < limit) {
-                    const size_t rd = (size_t)stride * r + offset;
-                    rs.names[rd] = name;
-                    rs.lengths[rd] = (uint32_t)seq.size();
-                    uint32_t *dst = rs.queries.data() + (rd / 32) * 32 * wpq + rd % 32;
-                    uint8_t *cd = &rs.codes[rd * maxReadLength];
-                    char *qd = &rs.quals[rd * maxReadLength];
-                    for (size_t i = 0; i < seq.size(); i++) {
-                        dst[(i / 16) * 32] |= (uint32_t)seq[i] << (2 * (i % 16));
-                        cd[i] = seq[i];
-                        qd[i] = q[i];
-                    }
-                }
-                r++;
-            }, true, name, seq, q, bad);
-        }
-    });
-    for (auto &x : th) x.join();
-    return true;
-}
-
 // sizes the arrays of `rs` for n reads and writes the zeros that are content (bits are OR-ed into the packed words, bytes behind a read's end stay 0),
 // slice by slice with all threads
 static void allocateReads(ReadSet &rs, uint32_t n, bool fq, uint32_t wpq, uint32_t maxReadLength)
@@ -386,50 +262,338 @@ static void allocateReads(ReadSet &rs, uint32_t n, bool fq, uint32_t wpq, uint32
     zero(rs.quals.data(), rs.quals.size());
 }
 
-bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err)
+// ---- the read files as a stream of chunks ------------------------------------------------------------------------------------------------------
+// The reference reads its input batch by batch (a loader thread fills the next buffer while the current one is aligned, aio_thread.cpp:582,
+// SOAP3-DP.cu:607-800).  Here a chunk is cut at a record boundary out of a text buffer that is refilled from the file (plain files: 16 threads pread
+// their slices; gzip: zlib), parsed by all host threads straight into the packed layout, and handed on; only the unparsed tail stays in the buffer.
+struct ReadChunker::File {
+    std::string name;
+    int fd = -1;
+    gzFile gz = nullptr;
+    uint64_t pos = 0, size = 0;           // plain files
+    bool eof = false, fq = false, kindKnown = false;
+    RawVec<char> buf;
+    size_t used = 0, have = 0;            // buf[used, have) is text not yet handed out
+    double bytesPerRead = 0;
+
+    ~File() { if (fd >= 0) close(fd); if (gz) gzclose(gz); }
+
+    bool open(const std::string &file, std::string &err)
+    {
+        name = file;
+        gzFile g = gzopen(file.c_str(), "r");
+        if (!g) { err = "cannot open " + file; return false; }
+        if (gzdirect(g)) {
+            gzclose(g);
+            fd = ::open(file.c_str(), O_RDONLY);
+            if (fd < 0) { err = "cannot open " + file; return false; }
+            struct stat sb;
+            if (fstat(fd, &sb) != 0) { err = "cannot stat " + file; return false; }
+            size = (uint64_t)sb.st_size;
+        } else { gz = g; gzbuffer(gz, 1 << 20); }
+        return true;
+    }
+
+    // make buf[used, have) at least `want` bytes long (or reach the end of the file)
+    bool fill(size_t want, std::string &err)
+    {
+        if (have - used >= want || eof) return true;
+        if (used > 0) {                                   // drop what was handed out
+            memmove(buf.data(), buf.data() + used, have - used);
+            have -= used; used = 0;
+        }
+        if (buf.size() < want + 1) buf.resize(want + 1);
+        const size_t need = want - have;
+        if (fd >= 0) {
+            const size_t got = (size_t)std::min<uint64_t>(need, size - pos);
+            const int Tr = got < (8u << 20) ? 1 : (hostThreads() > 16 ? 16 : hostThreads());
+            std::vector<std::thread> rd;
+            std::atomic<bool> bad(false);
+            char *dst = buf.data() + have;
+            for (int t = 0; t < Tr; t++) rd.emplace_back([&, t] {
+                const size_t lo = got / (size_t)Tr * (size_t)t, hi = t + 1 == Tr ? got : got / (size_t)Tr * (size_t)(t + 1);
+                size_t done = lo;
+                while (done < hi) {
+                    const ssize_t k = pread(fd, dst + done, hi - done, (off_t)(pos + done));
+                    if (k <= 0) { bad = true; return; }
+                    done += (size_t)k;
+                }
+            });
+            for (auto &x : rd) x.join();
+            if (bad) { err = "cannot read " + name; return false; }
+            have += got; pos += got;
+            if (pos >= size) eof = true;
+        } else {
+            size_t got = 0;
+            while (got < need) {
+                const size_t ask = std::min<size_t>(need - got, 1u << 30);
+                const int k = gzread(gz, buf.data() + have + got, (unsigned)ask);
+                if (k < 0) { err = "cannot inflate " + name; return false; }
+                if (k == 0) { eof = true; break; }
+                got += (size_t)k;
+            }
+            have += got;
+        }
+        return true;
+    }
+};
+
+namespace {
+// what one file contributes to a chunk: the text region, its pieces (one per thread) with their record counts
+struct Region {
+    TextView all;
+    bool fq = false;
+    std::vector<Piece> pieces;
+    uint32_t n = 0;
+    size_t consumed = 0;                  // bytes of the region that hold the records taken
+};
+
+bool isRecordStart(const TextView &all, bool fq, size_t p)
 {
-    rs = ReadSet();
-    return loadInto(file, maxReadLength, qualityConstant, maxLenReadName, rs, err, 1, 0, [&](uint32_t n, bool fq, uint32_t wpq) -> uint32_t {
-        allocateReads(rs, n, fq, wpq, maxReadLength);
-        return n;
-    });
+    const size_t N = all.size();
+    if (p >= N || all[p] != (fq ? '@' : '>')) return false;
+    if (p > 0 && all[p - 1] != '\n') return false;
+    if (!fq) return true;
+    // FASTQ: the line after next must begin with '+' (a quality line may begin with '@')
+    size_t q = p;
+    for (int k = 0; k < 2; k++) { while (q < N && all[q] != '\n') q++; if (q < N) q++; }
+    return q < N && all[q] == '+';
 }
 
+void fillCharMap(unsigned char *charMap)
+{
+    memset(charMap, 0, 256);                                            // INDEXFillCharMap, IndexHandler.cpp:25-48
+    const char *acgt = "ACGT";
+    for (int i = 0; i < 4; i++) { charMap[(int)acgt[i]] = (unsigned char)i; charMap[(int)acgt[i] - 'A' + 'a'] = (unsigned char)i; }
+    charMap['U'] = charMap['T']; charMap['N'] = charMap['G']; charMap['u'] = charMap['t']; charMap['n'] = charMap['g'];
+}
+
+// pieces + counts of the complete records in `all`, at most maxReads of them (the rest stays for the next chunk)
+bool scanRegion(Region &R, uint32_t maxReads, uint32_t maxReadLength, int maxLenReadName, int qualityConstant, const unsigned char *charMap, std::string &err)
+{
+    const TextView &all = R.all;
+    const size_t N = all.size();
+    size_t p0 = 0;
+    while (p0 < N && !isRecordStart(all, R.fq, p0)) p0++;
+    const int T = hostThreads();
+    R.pieces.assign((size_t)T, Piece());
+    for (int t = 0; t < T; t++) {
+        size_t b = p0 + (N - p0) / (size_t)T * (size_t)t;
+        if (t == 0) b = p0;
+        else { while (b < N && !isRecordStart(all, R.fq, b)) b++; }
+        R.pieces[(size_t)t].beg = b;
+    }
+    for (int t = 0; t < T; t++) R.pieces[(size_t)t].end = t + 1 < T ? R.pieces[(size_t)t + 1].beg : N;
+    std::atomic<bool> anyBad(false);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t] {
+        Piece &P = R.pieces[(size_t)t];
+        std::string name, q; std::vector<uint8_t> seq; bool bad = false;
+        uint32_t c = 0;
+        size_t p = P.beg;
+        while (p < P.end) {
+            while (p < P.end && all[p] != '>' && all[p] != '@') p++;
+            if (p >= P.end) break;
+            p = parseRecord(all, p, R.fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] { c++; }, false, name, seq, q, bad);
+        }
+        P.count = c;
+        if (bad) anyBad = true;
+    });
+    for (auto &x : th) x.join();
+    if (anyBad) { err = "a read of length 0 in the read file"; return false; }
+    uint32_t n = 0;
+    for (auto &P : R.pieces) { P.first = n; n += P.count; }
+    R.n = n; R.consumed = N;
+    (void)maxReads;
+    return true;
+}
+
+// keep only the first m records of the region (m <= R.n): the piece that holds record m ends there, later pieces are empty
+void cutRegion(Region &R, uint32_t m, uint32_t maxReadLength, int maxLenReadName, int qualityConstant, const unsigned char *charMap)
+{
+    if (m >= R.n) return;
+    const TextView &all = R.all;
+    bool cutSet = false;
+    for (size_t t = 0; t < R.pieces.size(); t++) {
+        Piece &P = R.pieces[t];
+        if (P.first + P.count <= m) continue;
+        if (P.first >= m) {
+            if (!cutSet) { R.consumed = P.beg; cutSet = true; }          // the cut falls on a piece boundary
+            P.end = P.beg; P.count = 0;
+            continue;
+        }
+        // record m lies in this piece: walk m - first records
+        std::string name, q; std::vector<uint8_t> seq; bool bad = false;
+        uint32_t c = 0;
+        size_t p = P.beg;
+        while (p < P.end && c < m - P.first) {
+            while (p < P.end && all[p] != '>' && all[p] != '@') p++;
+            if (p >= P.end) break;
+            p = parseRecord(all, p, R.fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] { c++; }, false, name, seq, q, bad);
+        }
+        while (p < P.end && !isRecordStart(all, R.fq, p)) p++;
+        P.end = p; P.count = c;
+        R.consumed = p; cutSet = true;
+    }
+    R.n = m;
+}
+
+// fill pass: record k of the region becomes read stride * k + offset of rs.  32 consecutive reads share packed words (32-interleaved layout), so a
+// piece boundary inside a group of 32 is written by two threads -- to different words (word index = group base + r % 32 + 32 w), never the same one
+void fillRegion(const Region &R, ReadSet &rs, uint32_t stride, uint32_t offset, uint32_t maxReadLength, int maxLenReadName, int qualityConstant,
+                const unsigned char *charMap)
+{
+    const TextView &all = R.all;
+    const uint32_t wpq = rs.wpq;
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < R.pieces.size(); t++) th.emplace_back([&, t] {
+        const Piece &P = R.pieces[t];
+        std::string name, q; std::vector<uint8_t> seq; bool bad = false;
+        uint32_t r = P.first;
+        size_t p = P.beg;
+        while (p < P.end) {
+            while (p < P.end && all[p] != '>' && all[p] != '@') p++;
+            if (p >= P.end) break;
+            p = parseRecord(all, p, R.fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] {
+                if (r < R.n) {
+                    const size_t rd = (size_t)stride * r + offset;
+                    rs.names[rd] = name;
+                    rs.lengths[rd] = (uint32_t)seq.size();
+                    uint32_t *dst = rs.queries.data() + (rd / 32) * 32 * wpq + rd % 32;
+                    uint8_t *cd = &rs.codes[rd * maxReadLength];
+                    char *qd = &rs.quals[rd * maxReadLength];
+                    for (size_t i = 0; i < seq.size(); i++) {
+                        dst[(i / 16) * 32] |= (uint32_t)seq[i] << (2 * (i % 16));
+                        cd[i] = seq[i];
+                        qd[i] = q[i];
+                    }
+                }
+                r++;
+            }, true, name, seq, q, bad);
+        }
+    });
+    for (auto &x : th) x.join();
+}
+}  // namespace
+
+ReadChunker::ReadChunker() {}
+ReadChunker::~ReadChunker() {}
+
+bool ReadChunker::open(const std::string &file1, const std::string &file2, uint32_t maxReadLength_, int qualityConstant_, int maxLenReadName_, std::string &err)
+{
+    maxReadLength = maxReadLength_; qualityConstant = qualityConstant_; maxLenReadName = maxLenReadName_;
+    files.clear();
+    files.emplace_back(new File());
+    if (!files[0]->open(file1, err)) return false;
+    if (!file2.empty()) {
+        files.emplace_back(new File());
+        if (!files[1]->open(file2, err)) return false;
+    }
+    return true;
+}
+
+bool ReadChunker::next(uint32_t maxReads, ReadSet &rs, std::string &err)
+{
+    err.clear();
+    rs = ReadSet();
+    const size_t F = files.size();
+    if (F == 2) maxReads &= ~1u;
+    const uint32_t perFile = F == 2 ? maxReads / 2 : maxReads;
+    if (perFile == 0) { err = "ReadChunker::next: bad chunk size"; return false; }
+    unsigned char charMap[256];
+    fillCharMap(charMap);
+    uint32_t w = 1;
+    while (w < maxReadLength) w *= 2;
+    const uint32_t wpq = w / 16 ? w / 16 : 1;
+    std::vector<Region> regs(F);
+    std::vector<bool> ok(F, true);
+    std::vector<std::string> errs(F);
+    // both files of a pair are refilled and scanned at the same time
+    auto prepare = [&](size_t f) {
+        File &X = *files[f];
+        double est = X.bytesPerRead > 0 ? X.bytesPerRead : 2.0 * maxReadLength + 96;
+        size_t want = (size_t)std::min<double>((double)perFile * est * 1.05 + 65536.0, 3.5e10);
+        // never ask for more than the file still holds (plain files), and approach an unknown size step by step (gzip)
+        if (X.fd >= 0) want = (size_t)std::min<uint64_t>(want, (uint64_t)(X.have - X.used) + (X.size - X.pos));
+        else if (X.bytesPerRead == 0) want = std::min<size_t>(want, (size_t)1 << 28);
+        if (want < 4096) want = 4096;
+        for (;;) {
+            if (!X.fill(want, errs[f])) { ok[f] = false; return; }
+            TextView all{X.buf.data() + X.used, X.have - X.used};
+            if (!X.kindKnown) {
+                size_t p0 = 0;
+                while (p0 < all.size() && all[p0] != '>' && all[p0] != '@') p0++;
+                if (p0 < all.size()) { X.fq = all[p0] == '@'; X.kindKnown = true; }
+            }
+            // the last record of the buffer may be incomplete unless the file has ended: the region stops at its start
+            size_t end = all.size();
+            if (!X.eof) {
+                size_t p = end;
+                while (p > 0) {
+                    p--;
+                    if ((p == 0 || all[p - 1] == '\n') && isRecordStart(all, X.fq, p)) break;
+                }
+                end = p;
+            }
+            regs[f].all = TextView{all.p, end};
+            regs[f].fq = X.fq;
+            if (!scanRegion(regs[f], perFile, maxReadLength, maxLenReadName, qualityConstant, charMap, errs[f])) { ok[f] = false; return; }
+            if (regs[f].n >= perFile || X.eof) return;
+            // fewer complete records than asked for and more file to come: read more (the estimate was low)
+            want = (size_t)((double)want * 1.5) + (1u << 20);
+            if (X.fd >= 0) want = (size_t)std::min<uint64_t>(want, (uint64_t)(X.have - X.used) + (X.size - X.pos));
+        }
+    };
+    if (F == 2) {
+        std::thread second([&] { prepare(1); });
+        prepare(0);
+        second.join();
+    } else prepare(0);
+    for (size_t f = 0; f < F; f++) if (!ok[f]) { err = errs[f]; return false; }
+    uint32_t m = perFile;
+    for (size_t f = 0; f < F; f++) m = std::min(m, regs[f].n);
+    if (m == 0) return false;                                           // end of the input (the reference stops at the shorter file of a pair)
+    for (size_t f = 0; f < F; f++) cutRegion(regs[f], m, maxReadLength, maxLenReadName, qualityConstant, charMap);
+    allocateReads(rs, (uint32_t)F * m, regs[0].fq, wpq, maxReadLength);
+    if (F == 2) {
+        std::thread second([&] { fillRegion(regs[1], rs, 2, 1, maxReadLength, maxLenReadName, qualityConstant, charMap); });
+        fillRegion(regs[0], rs, 2, 0, maxReadLength, maxLenReadName, qualityConstant, charMap);
+        second.join();
+    } else fillRegion(regs[0], rs, 1, 0, maxReadLength, maxLenReadName, qualityConstant, charMap);
+    for (size_t f = 0; f < F; f++) {
+        File &X = *files[f];
+        X.bytesPerRead = (double)regs[f].consumed / (double)m;
+        X.used += regs[f].consumed;
+    }
+    return true;
+}
+
+// the whole input as one chunk (the test tools; the command line streams)
+bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err)
+{
+    ReadChunker c;
+    if (!c.open(file, "", maxReadLength, qualityConstant, maxLenReadName, err)) return false;
+    if (!c.next(0xFFFFFFE0u, rs, err)) {
+        if (!err.empty()) return false;
+        uint32_t w = 1;
+        while (w < maxReadLength) w *= 2;
+        allocateReads(rs, 0, false, w / 16 ? w / 16 : 1, maxReadLength);
+    }
+    return true;
+}
+
+// two files, mates interleaved: read 2p from file 1, read 2p+1 from file 2 (loadPairReadsGz2, QueryParser.cpp:177)
 bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs,
                    std::string &err)
 {
-    // both files at once, each parsed straight into its half of the interleaved set: the loader that finishes counting second sizes the arrays for
-    // 2 x min(n1, n2) reads (the reference stops at the shorter file)
-    rs = ReadSet();
-    std::mutex mu;
-    std::condition_variable cv;
-    int counted = 0;
-    uint32_t n[2] = {0, 0}, np = 0;
-    bool ready = false, fq1 = false;
-    auto side = [&](int which) {
-        return [&, which](uint32_t nThis, bool fq, uint32_t wpq) -> uint32_t {
-            std::unique_lock<std::mutex> lk(mu);
-            n[which] = nThis;
-            if (which == 0) fq1 = fq;
-            if (++counted == 2) {
-                np = n[0] < n[1] ? n[0] : n[1];
-                lk.unlock();
-                allocateReads(rs, 2 * np, fq1, wpq, maxReadLength);
-                lk.lock();
-                ready = true;
-                cv.notify_all();
-            } else cv.wait(lk, [&] { return ready; });
-            return np;
-        };
-    };
-    std::string err2;
-    bool ok2 = true;
-    std::thread second([&] { ok2 = loadInto(file2, maxReadLength, qualityConstant, maxLenReadName, rs, err2, 2, 1, side(1)); if (!ok2) { std::lock_guard<std::mutex> g(mu); if (!ready) { counted = 2; ready = true; np = 0; cv.notify_all(); } } });
-    const bool ok1 = loadInto(file1, maxReadLength, qualityConstant, maxLenReadName, rs, err, 2, 0, side(0));
-    if (!ok1) { std::lock_guard<std::mutex> g(mu); if (!ready) { counted = 2; ready = true; np = 0; cv.notify_all(); } }
-    second.join();
-    if (!ok1) return false;
-    if (!ok2) { err = err2; return false; }
+    ReadChunker c;
+    if (!c.open(file1, file2, maxReadLength, qualityConstant, maxLenReadName, err)) return false;
+    if (!c.next(0xFFFFFFE0u, rs, err)) {
+        if (!err.empty()) return false;
+        uint32_t w = 1;
+        while (w < maxReadLength) w *= 2;
+        allocateReads(rs, 0, false, w / 16 ? w / 16 : 1, maxReadLength);
+    }
     return true;
 }
 

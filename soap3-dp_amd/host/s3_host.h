@@ -57,6 +57,23 @@ struct ReadSet {
     bool isFastq = false;
 };
 
+// The read files as a stream of chunks (the reference's loader thread fills the next batch while the current one is aligned, aio_thread.cpp:582,
+// SOAP3-DP.cu:607-800): next() returns the next at most maxReads reads (pairs: reads 2p / 2p+1 from file 1 / file 2, maxReads rounded down to even),
+// parsed by all host threads; false with an empty err at the end of the input (for pairs: of the shorter file).
+class ReadChunker {
+public:
+    ReadChunker();
+    ~ReadChunker();
+    bool open(const std::string &file1, const std::string &file2 /* empty: single reads */, uint32_t maxReadLength, int qualityConstant, int maxLenReadName,
+              std::string &err);
+    bool next(uint32_t maxReads, ReadSet &rs, std::string &err);
+private:
+    struct File;
+    std::vector<std::unique_ptr<File>> files;
+    uint32_t maxReadLength = 0;
+    int qualityConstant = 33, maxLenReadName = 64;
+};
+
 bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs, std::string &err);
 // two files, mates interleaved: read 2p from file 1, read 2p+1 from file 2 (loadPairReadsGz2, QueryParser.cpp:177)
 bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, ReadSet &rs,

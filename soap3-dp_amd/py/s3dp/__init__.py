@@ -30,6 +30,12 @@ class IndexDesc(C.Structure):
                 ("lktSize", C.c_int)]
 
 
+class StreamResult(C.Structure):
+    _fields_ = [("ticket", C.c_uint64), ("n", C.c_uint32), ("phase", C.POINTER(C.c_uint8)), ("withError", C.POINTER(C.c_uint32)),
+                ("occOffsets", C.POINTER(C.c_uint32)), ("occPos", C.POINTER(C.c_uint32)), ("occMeta", C.POINTER(C.c_uint32)),
+                ("deviceMs", C.c_float), ("batch", C.c_void_p)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rankQueries", "ltLookups", "saReads", "ceWindows", "records")]
 
@@ -37,7 +43,8 @@ class Counters(C.Structure):
 EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_index_lookup_chars", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
            "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_batch_fetch_pair_origins", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_dp_single_end", "s3_dp_deep", "s3_dp_new_default", "s3_batch_fetch_alignments", "s3_batch_sync", "s3_batch_last_ce_timing",
            "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
-           "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather"]
+           "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather",
+           "s3_stream_create", "s3_stream_acquire", "s3_stream_submit", "s3_stream_next", "s3_stream_release", "s3_stream_free"]
 
 _lib = None
 
@@ -67,6 +74,13 @@ def lib():
         L.s3_batch_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.s3_batch_enable_counters.argtypes = [C.c_void_p, C.c_int]
         L.s3_model_describe.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        L.s3_stream_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        L.s3_stream_acquire.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint32))]
+        L.s3_stream_submit.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]
+        L.s3_stream_next.argtypes = [C.c_void_p, C.POINTER(StreamResult)]
+        L.s3_stream_release.argtypes = [C.c_void_p]
+        L.s3_stream_free.argtypes = [C.c_void_p]
+        L.s3_stream_free.restype = None
         _lib = L
     return _lib
 
@@ -615,3 +629,106 @@ class DpAligner:
         f.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         _chk(f(self.h, C.byref(ms)))
         return ms.value
+
+
+# ------------------------------------------------------------------------------------------------
+# streamed single-end alignment (s3_stream_*): uploads and downloads overlap the kernels of the neighbouring batches
+# ------------------------------------------------------------------------------------------------
+class Stream:
+    def __init__(self, index, max_reads, wpq, depth=3):
+        self.h = C.c_void_p()
+        self.max_reads, self.wpq, self.depth = max_reads, wpq, depth
+        self.index = index
+        _chk(lib().s3_stream_create(index.h, max_reads, wpq, depth, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().s3_stream_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def acquire(self):
+        """numpy views of the next free slot's pinned input arrays: (queries, read lengths, seed lengths)"""
+        q, l, sl = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+        _chk(lib().s3_stream_acquire(self.h, C.byref(q), C.byref(l), C.byref(sl)))
+        ru = (self.max_reads + 31) // 32 * 32
+        return (np.ctypeslib.as_array(q, shape=(ru * self.wpq,)), np.ctypeslib.as_array(l, shape=(ru,)), np.ctypeslib.as_array(sl, shape=(ru,)))
+
+    def submit(self, n, mm, max_out=1000, report_type=2, use_seed_lengths=False):
+        t = C.c_uint64()
+        _chk(lib().s3_stream_submit(self.h, n, 1 if use_seed_lengths else 0, mm, max_out, report_type, C.byref(t)))
+        return t.value
+
+    def next(self, copy=True, split=True):
+        """results of the oldest submitted batch: (phase, withError, occOffsets, occPos, occStrand, occMis, deviceMs); views into pinned memory
+        unless copy (they die with release()).  split=False: (..., occPos, occMeta, None, deviceMs) with occMeta = strand | mismatches << 8"""
+        r = StreamResult()
+        _chk(lib().s3_stream_next(self.h, C.byref(r)))
+        n = r.n
+        offs = np.ctypeslib.as_array(r.occOffsets, shape=(n + 1,))
+        tot = int(offs[n])
+        phase = np.ctypeslib.as_array(r.phase, shape=(n,))
+        werr = np.ctypeslib.as_array(r.withError, shape=(n, 8))
+        pos = np.ctypeslib.as_array(r.occPos, shape=(max(tot, 1),))[:tot]
+        meta = np.ctypeslib.as_array(r.occMeta, shape=(max(tot, 1),))[:tot]
+        if copy:
+            phase, werr, offs, pos, meta = phase.copy(), werr.copy(), offs.copy(), pos.copy(), meta.copy()
+        if not split:
+            return phase, werr, offs, pos, meta, None, r.deviceMs
+        return phase, werr, offs, pos, (meta & 0xFF).astype(np.uint8), ((meta >> 8) & 0xFF).astype(np.uint8), r.deviceMs
+
+    def release(self):
+        _chk(lib().s3_stream_release(self.h))
+
+
+def stream_bench(index, queries, lens, wpq, mm, max_out, batch_reads, steps, depth=3, check=None):
+    """`steps` passes over the reads in batches of batch_reads through a Stream: the packed reads go host -> pinned -> device and the occurrence
+    lists device -> pinned inside the timed region.  check(first, phase, offs, pos, strand, mis) is called per batch of the first pass (outside the
+    clock is not possible here: it runs between batches, keep it cheap).  Returns {"reads", "seconds", "occurrences", "batch_reads", "depth"}."""
+    import time
+    n = len(lens)
+    batch_reads = min(batch_reads, n) // 32 * 32
+    st = Stream(index, batch_reads, wpq, depth)
+    starts = list(range(0, n - n % 32, batch_reads))
+    jobs = [(a, min(batch_reads, n - n % 32 - a)) for a in starts]
+    occ = 0
+    try:
+        # one untimed pass warms the slots (buffers grow to their working size)
+        for timed in (False, True):
+            reps = steps if timed else 1
+            pending = []
+            t0 = time.perf_counter()
+            for rep in range(reps):
+                for (a, m) in jobs:
+                    if len(pending) == depth:
+                        ph, we, of, po, me, _, ms = st.next(copy=False, split=False)
+                        if timed:
+                            occ += int(of[-1])
+                        elif check is not None:
+                            check(pending[0][0], ph, of, po, (me & 0xFF).astype(np.uint8), ((me >> 8) & 0xFF).astype(np.uint8))
+                        st.release()
+                        pending.pop(0)
+                    q, l, _ = st.acquire()
+                    ru = (m + 31) // 32 * 32
+                    q[:ru * wpq] = queries[a * wpq:(a + ru) * wpq]
+                    l[:m] = lens[a:a + m]
+                    st.submit(m, mm, max_out, 2)
+                    pending.append((a, m))
+            while pending:
+                ph, we, of, po, me, _, ms = st.next(copy=False, split=False)
+                if timed:
+                    occ += int(of[-1])
+                elif check is not None:
+                    check(pending[0][0], ph, of, po, (me & 0xFF).astype(np.uint8), ((me >> 8) & 0xFF).astype(np.uint8))
+                st.release()
+                pending.pop(0)
+            dt = time.perf_counter() - t0
+    finally:
+        st.close()
+    return {"reads": sum(m for _, m in jobs) * steps, "seconds": dt, "occurrences": occ // max(1, steps), "batch_reads": batch_reads, "depth": depth,
+            "what": "packed reads host -> device and occurrence lists device -> host inside the timed region, %d batches in flight" % depth}
