@@ -461,6 +461,8 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     tot = sd.reduce_counters({"reads": a.reads, "readsAligned": aligned, "alignments": n_occ, "rankQueries": cnt["rankQueries"],
                               "records": cnt["records"]}, device=dev)
     value = tot["reads"] * a.steps / dt / 1e6
+    log("[%s] resident: %.2f M reads/s, %.1f ms per step (stepping %.1f ms, check-and-extend %.1f ms, device %.1f ms); %.0f rank queries per read" %
+        (label, value, dt / a.steps * 1e3, search_ms / a.steps, ce_ms / a.steps, dev_ms / a.steps, cnt["rankQueries"] / a.reads))
 
     # ---- streamed: upload of the packed reads and download of the results inside the timed region -------------
     streamed = None
@@ -478,9 +480,10 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
         if mism:
             raise SystemExit("bench.py: streamed results differ from the resident batch's (batches at reads %r)" % mism[:5])
         streamed["same_results_as_resident"] = True
-        streamed["M_reads_per_s"] = sd.reduce_counters({"r": int(streamed["reads"])}, device=dev)["r"] / \
+        streamed["M_reads_per_s"] = sd.reduce_counters({"reads": int(streamed["reads"])}, device=dev)["reads"] / \
             sd.max_over_ranks(streamed["seconds"], device=dev) / 1e6
         streamed["vs_resident"] = streamed["M_reads_per_s"] / value
+        log("[%s] streamed: %.2f M reads/s (%.2f of resident)" % (label, streamed["M_reads_per_s"], streamed["vs_resident"]))
 
     # ---- roofline of the search (stepping kernel + check-and-extend kernel: the two halves of one search pass) ----------------
     # algorithmic bytes: SURVEY.md 8d's formula (strict), and the same extended by what the lookup tables and check-and-extend read: 16 B per lookup

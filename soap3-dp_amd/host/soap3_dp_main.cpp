@@ -19,6 +19,10 @@
 #include <thread>
 #include <future>
 #include <vector>
+#include <deque>
+#include <mutex>
+#include <condition_variable>
+#include <memory>
 #include "s3_host.h"
 
 using namespace s3host;
@@ -500,36 +504,73 @@ int main(int argc, char **argv)
     HostIndex hix;
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
-    // the read files are parsed while the index is read and copied to the device: neither needs the other
-    ReadSet rs;
-    std::string readErr;
-    double readSeconds = 0;
-    std::future<bool> readsLoaded = std::async(std::launch::async, [&] {
-        const auto tReads = std::chrono::steady_clock::now();
-        const bool ok = paired ? loadPairReads(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, readErr)
-                               : loadSingleReads(queryFile, (uint32_t)maxReadLength, 33, ini.maxLenReadName, rs, readErr);
-        readSeconds = since(tReads);
-        return ok;
+    // The read files come in chunks (ReadChunker): a loader thread parses chunk i+1 -- with all host threads -- while chunk i is aligned and
+    // chunk i-1 is formatted and written, as the reference's loader thread fills the next batch buffer (aio_thread.cpp:582, SOAP3-DP.cu:607-800).
+    // It starts before the index is read: neither needs the other.  S3DP_CHUNK_READS: reads per chunk (default 2 Mi single reads / 4 Mi paired).
+    size_t chunkReadsEnv = 0;
+    if (const char *e = getenv("S3DP_CHUNK_READS")) chunkReadsEnv = (size_t)strtoull(e, nullptr, 10);
+    const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : (paired ? (size_t)1 << 22 : (size_t)1 << 21)) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
+    ReadChunker chunker;
+    if (!chunker.open(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)) return die(err);
+    struct ChunkQueue {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<std::unique_ptr<ReadSet>> q;
+        bool done = false;
+        std::string err;
+        double seconds = 0;
+    } loaded;
+    std::thread loader([&] {
+        for (;;) {
+            std::unique_ptr<ReadSet> rs(new ReadSet());
+            std::string e;
+            const auto t = std::chrono::steady_clock::now();
+            const bool ok = chunker.next(chunkReads, *rs, e);
+            std::unique_lock<std::mutex> lk(loaded.mu);
+            loaded.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+            if (!ok) { loaded.err = e; loaded.done = true; loaded.cv.notify_all(); return; }
+            loaded.cv.wait(lk, [&] { return loaded.q.size() < 2; });
+            loaded.q.push_back(std::move(rs));
+            loaded.cv.notify_all();
+        }
     });
+    auto nextChunk = [&]() -> std::unique_ptr<ReadSet> {
+        std::unique_lock<std::mutex> lk(loaded.mu);
+        loaded.cv.wait(lk, [&] { return !loaded.q.empty() || loaded.done; });
+        if (loaded.q.empty()) return nullptr;
+        std::unique_ptr<ReadSet> r = std::move(loaded.q.front());
+        loaded.q.pop_front();
+        loaded.cv.notify_all();
+        return r;
+    };
+    // (a failure below leaves through exit(): the loader thread must not outlive main's locals silently)
+    auto dieJoin = [&](const std::string &m) -> int { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); return 1; };
     printf("[Main] loading index into host...\n");
-    if (!loadIndex(indexName, hix, err)) { readsLoaded.wait(); return die(err); }
+    if (!loadIndex(indexName, hix, err)) return dieJoin(err);
     printf("[Main] Finished loading index into host.\n[Main] Loading time : %9.4f seconds\n", since(t0));
     printf("[Main] Reference sequence length : %u\n", hix.n);
     s3_index *ix = nullptr;
     s3_index_desc d = hix.desc();
-    if (s3_index_upload(device, &d, &ix) != S3_OK) { readsLoaded.wait(); return die(s3_last_error()); }
+    if (s3_index_upload(device, &d, &ix) != S3_OK) return dieJoin(s3_last_error());
     printf("[Main] Finished copying index into device (GPU).\n");
-    if (!readsLoaded.get()) return die(readErr);
-    printf("[Main] Loaded %u short reads from the query file.\n[Main] Read load time : %9.4f seconds (%d host threads, alongside the index)\n", rs.n, readSeconds, hostThreads());
+    std::unique_ptr<ReadSet> chunk = nextChunk();
+    if (!chunk) {
+        if (!loaded.err.empty()) return dieJoin(loaded.err);
+        chunk.reset(new ReadSet());                                            // an empty input still gets its (header-only) output files
+        uint32_t w = 1;
+        while (w < (uint32_t)maxReadLength) w *= 2;
+        chunk->wpq = w / 16 ? w / 16 : 1; chunk->maxReadLength = (uint32_t)maxReadLength;
+    }
+    printf("[Main] Loaded %u short reads from the query file (first chunk; %d host threads, alongside the index).\n", chunk->n, hostThreads());
     if (numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;          // getDefaultMismatchNum, CPUfunctions.cpp:26-35
     // DP enabled (the default): the BWT stage runs with Soap3MisMatchAllow mismatches (SOAP3-DP.cu:208-213); reads it leaves unaligned go
     // through seeding + DP and are reported in <prefix>.dpout.1.  Too short reads switch the DP off (SOAP3-DP.cu:643-652).
     uint32_t detectedReadLength = 0, detectedReadLength2 = 0;              // GetReadLength: the longest of the first ten reads (of each end)
-    if (!paired) for (uint32_t i = 0; i < rs.n && i < 10; i++) detectedReadLength = std::max(detectedReadLength, rs.lengths[i]);
+    if (!paired) for (uint32_t i = 0; i < chunk->n && i < 10; i++) detectedReadLength = std::max(detectedReadLength, chunk->lengths[i]);
     else
-        for (uint32_t i = 0, k = 0; i + 1 < rs.n && k < 10; i += 2, k++) {
-            detectedReadLength = std::max(detectedReadLength, rs.lengths[i]);
-            detectedReadLength2 = std::max(detectedReadLength2, rs.lengths[i + 1]);
+        for (uint32_t i = 0, k = 0; i + 1 < chunk->n && k < 10; i += 2, k++) {
+            detectedReadLength = std::max(detectedReadLength, chunk->lengths[i]);
+            detectedReadLength2 = std::max(detectedReadLength2, chunk->lengths[i + 1]);
         }
     if (paired && insertLow < (int)detectedReadLength2) insertLow = (int)detectedReadLength2;   // SOAP3-DP.cu:632-634
     if (enableDP) {
@@ -546,7 +587,7 @@ int main(int argc, char **argv)
     double devSeconds = 0, formatSeconds = 0, dpStageSeconds = 0;
     const std::string outName = prefix + ".gout.1";
     FILE *out = fopen(outName.c_str(), "w");
-    if (!out) return die("Could not open the output file " + outName);
+    if (!out) return dieJoin("Could not open the output file " + outName);
     SamOptions so;
     so.readGroup = readGroup; so.sampleName = sampleName; so.readGrpOption = readGrpOption; so.alignmentType = alignmentType;
     so.minMAPQ = ini.minMAPQ; so.maxMAPQ = ini.maxMAPQ; so.bwaLikeScore = ini.bwaLike; so.printMDNM = printMDNM;
@@ -563,7 +604,7 @@ int main(int argc, char **argv)
     if (enableDP) {
         const std::string dpName = prefix + ".dpout.1";
         dpOut = fopen(dpName.c_str(), "w");
-        if (!dpOut) return die("Could not open the output file " + dpName);
+        if (!dpOut) return dieJoin("Could not open the output file " + dpName);
         SamWriter dpHdr(hix, so, dpOut);
         dpHdr.header();
         s3_dp_ini di{ini.dpScoreThreshold, ini.maxFrontLenClipped, ini.maxEndLenClipped};
@@ -578,13 +619,13 @@ int main(int argc, char **argv)
             const double n = 24e9 / perProblem;
             return n >= 32768 ? 32768u : n < 256 ? 256u : (uint32_t)n;
         };
-        if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &dp) != S3_OK) return die(s3_last_error());
-        if (s3_batch_create(ix, 262144 + 64, 8, &seedBatch) != S3_OK) return die(s3_last_error());
+        if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &dp) != S3_OK) return dieJoin(s3_last_error());
+        if (s3_batch_create(ix, 262144 + 64, 8, &seedBatch) != S3_OK) return dieJoin(s3_last_error());
         if (paired) {
             // default DP (half-aligned pairs): HalfEndAlignmentEngine::performAlignment sizes, DV-DPfunctions.cu:2221-2224
             const int maxDNAHalf = insertHigh - insertLow + maxReadLength + 1;
             s3_dp_config(maxRL, maxDNAHalf, 1, &scheme, &tableLen, &patLen);
-            if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &dpHalf) != S3_OK) return die(s3_last_error());
+            if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &dpHalf) != S3_OK) return dieJoin(s3_last_error());
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength, &di, &halfPar[0]);
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength2, &di, &halfPar[1]);
             for (int e = 0; e < 2; e++) {
@@ -594,18 +635,90 @@ int main(int argc, char **argv)
             }
             const std::string upName = prefix + ".unpair";
             unpairOut = fopen(upName.c_str(), "w");
-            if (!unpairOut) return die("Could not open the output file " + upName);
+            if (!unpairOut) return dieJoin("Could not open the output file " + upName);
             SamWriter upHdr(hix, so, unpairOut);
             upHdr.header();
         }
     }
-    const uint32_t maxBatch = 1u << 22;
+    // ---- single reads with the DP stages off: streamed -- three batches in flight (upload / kernels / download on their own HIP streams,
+    // s3_stream_*), this thread feeds them, a second one formats and writes what comes back ---------------------------------------------------
+    uint64_t aligned = 0, totalReads = 0;
+    if (!paired && !enableDP) {
+        s3_stream *st = nullptr;
+        const uint32_t cap = chunk->n == chunkReads ? chunkReads : (chunk->n ? chunk->n : 1);
+        if (s3_stream_create(ix, cap, chunk->wpq, 3, &st) != S3_OK) return dieJoin(s3_last_error());
+        struct InFlight { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<ReadSet>> q; bool done = false; } fl;
+        std::string werr;
+        std::thread writer([&] {
+            for (;;) {
+                std::unique_ptr<ReadSet> rsP;
+                {
+                    std::unique_lock<std::mutex> lk(fl.mu);
+                    fl.cv.wait(lk, [&] { return !fl.q.empty() || fl.done; });
+                    if (fl.q.empty()) return;
+                    rsP = std::move(fl.q.front());
+                    fl.q.pop_front();
+                }
+                fl.cv.notify_all();
+                const ReadSet &rs = *rsP;
+                s3_stream_result res;
+                if (s3_stream_next(st, &res) != S3_OK) { werr = s3_last_error(); fprintf(stderr, "%s\n", werr.c_str()); fflush(stderr); _exit(1); }
+                const uint32_t cnt = res.n;
+                parallelFormat(hix, so, out, cnt, [&](SamWriter &w, uint32_t k, uint64_t &al) {
+                    const size_t o = res.occOffsets[k], m = res.occOffsets[k + 1] - res.occOffsets[k];
+                    uint8_t sbuf[64], mbuf[64];
+                    std::vector<uint8_t> sv, mv;
+                    uint8_t *sp = sbuf, *mp = mbuf;
+                    if (m > 64) { sv.resize(m); mv.resize(m); sp = sv.data(); mp = mv.data(); }
+                    for (size_t j = 0; j < m; j++) { sp[j] = (uint8_t)(res.occMeta[o + j] & 0xFF); mp[j] = (uint8_t)((res.occMeta[o + j] >> 8) & 0xFF); }
+                    if (alignmentType >= 3) {
+                        // unique best: exactly one hit, otherwise a no-answer record; random best: the first hit (hostKernel, CPUfunctions.cpp:1861-1930)
+                        if (m == 0 || (alignmentType == 3 && m > 1)) w.unaligned(rs, k);
+                        else { al++; w.singleAnswer(rs, k, res.occPos[o], sp[0], mp[0]); }
+                        return;
+                    }
+                    if (m) al++;
+                    w.singleEnd(rs, k, res.occPos + o, sp, mp, m, maxReadLength > 120 ? (rs.lengths[k] > 120 ? 100u : rs.lengths[k]) : 0u);
+                }, aligned);
+                if (s3_stream_release(st) != S3_OK) { fprintf(stderr, "%s\n", s3_last_error()); fflush(stderr); _exit(1); }
+            }
+        });
+        while (chunk && chunk->n) {
+            uint32_t *q = nullptr, *l = nullptr, *sl = nullptr;
+            if (s3_stream_acquire(st, &q, &l, &sl) != S3_OK) return dieJoin(s3_last_error());
+            const uint32_t cnt = chunk->n;
+            memcpy(q, chunk->queries.data(), chunk->queries.size() * 4);
+            memcpy(l, chunk->lengths.data(), (size_t)cnt * 4);
+            // reads longer than 120 bases: only the first 100 are searched, the rest is verified on the device (alignment.cu:2473-2491)
+            if (maxReadLength > 120) for (uint32_t k = 0; k < cnt; k++) sl[k] = chunk->lengths[k] > 120 ? 100u : chunk->lengths[k];
+            if (s3_stream_submit(st, cnt, maxReadLength > 120, (uint32_t)numMismatch, ini.maxOutputPerRead, alignmentType, nullptr) != S3_OK) return dieJoin(s3_last_error());
+            totalReads += cnt;
+            {
+                std::unique_lock<std::mutex> lk(fl.mu);
+                fl.q.push_back(std::move(chunk));
+            }
+            fl.cv.notify_all();
+            chunk = nextChunk();
+        }
+        {
+            std::lock_guard<std::mutex> g(fl.mu);
+            fl.done = true;
+        }
+        fl.cv.notify_all();
+        writer.join();
+        s3_stream_free(st);
+        if (!loaded.err.empty()) return dieJoin(loaded.err);
+        chunk.reset();
+    }
     s3_batch *b = nullptr;
-    if (s3_batch_create(ix, rs.n < maxBatch ? (rs.n ? rs.n : 1) : maxBatch, rs.wpq, &b) != S3_OK) return die(s3_last_error());
-    uint64_t aligned = 0;
-    for (uint32_t first = 0; first < rs.n; first += maxBatch) {
-        const uint32_t cnt = rs.n - first < maxBatch ? rs.n - first : maxBatch;   // first is a multiple of 32
-        if (s3_batch_upload(b, rs.queries.data() + (size_t)first * rs.wpq, rs.lengths.data() + first, cnt) != S3_OK) return die(s3_last_error());
+    const uint32_t maxBatch = chunkReads;
+    if (chunk && s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : (chunk->n ? chunk->n : 1), chunk->wpq, &b) != S3_OK) return dieJoin(s3_last_error());
+    for (; chunk && chunk->n; chunk = nextChunk()) {
+        ReadSet &rs = *chunk;
+        const uint32_t first = 0, cnt = rs.n;
+        totalReads += cnt;
+        (void)maxBatch;
+        if (s3_batch_upload(b, rs.queries.data() + (size_t)first * rs.wpq, rs.lengths.data() + first, cnt) != S3_OK) return dieJoin(s3_last_error());
         // reads longer than 120 bases: only the first 100 are searched, the rest is verified on the device (alignment.cu:2473-2491)
         if (paired) {
             // pairs keep to the whole read (seedLengths is NULL for pairs, alignment.cu:1965-2013); DP stages are off (-s)
@@ -620,12 +733,12 @@ int main(int argc, char **argv)
                 for (s3_pair_result &x : pr) { memset(&x, 0, sizeof x); x.min1 = x.min2 = 255; }     // no BWT stage: nothing paired, no hits
             } else {
                 if (s3_batch_align_pair(b, (uint32_t)numMismatch, ini.maxHitsEachEndForPairing, alignmentType, (uint32_t)insertLow, (uint32_t)insertHigh,
-                                        ini.peMaxOutputPerPair) != S3_OK) return die(s3_last_error());
-                if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, ooff.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return die(s3_last_error());
+                                        ini.peMaxOutputPerPair) != S3_OK) return dieJoin(s3_last_error());
+                if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, ooff.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return dieJoin(s3_last_error());
                 xa.resize(nXa ? nXa : 1); pos.resize(nOcc ? nOcc : 1); strand.resize(nOcc ? nOcc : 1); mis.resize(nOcc ? nOcc : 1); fromSa.resize(nOcc ? nOcc : 1);
                 if (s3_batch_fetch_pairs(b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK)
-                    return die(s3_last_error());
-                if (enableDP && s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return die(s3_last_error());
+                    return dieJoin(s3_last_error());
+                if (enableDP && s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return dieJoin(s3_last_error());
             }
             parallelFormat(hix, so, out, np, [&](SamWriter &w, uint32_t p, uint64_t &al) {
                 const uint32_t r1 = first + 2 * p, r2 = r1 + 1;
@@ -644,7 +757,7 @@ int main(int argc, char **argv)
                 PairDpCtx c{hix, so, rs, ini, b, seedBatch, dp, dpHalf, dpOut, unpairOut, first, cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
                 std::string e2;
                 const auto tDp = std::chrono::steady_clock::now();
-                if (!pairDpStages(c, pr, ooff, pos, strand, mis, fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) return die(e2);
+                if (!pairDpStages(c, pr, ooff, pos, strand, mis, fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) return dieJoin(e2);
                 dpStageSeconds += since(tDp);
             }
             continue;
@@ -653,16 +766,16 @@ int main(int argc, char **argv)
         if (maxReadLength > 120) {
             seeds.resize(cnt);
             for (uint32_t k = 0; k < cnt; k++) seeds[k] = rs.lengths[first + k] > 120 ? 100u : rs.lengths[first + k];
-            if (s3_batch_set_seed_lengths(b, seeds.data()) != S3_OK) return die(s3_last_error());
+            if (s3_batch_set_seed_lengths(b, seeds.data()) != S3_OK) return dieJoin(s3_last_error());
         }
-        if (s3_batch_align_single(b, (uint32_t)numMismatch, ini.maxOutputPerRead, alignmentType) != S3_OK) return die(s3_last_error());
+        if (s3_batch_align_single(b, (uint32_t)numMismatch, ini.maxOutputPerRead, alignmentType) != S3_OK) return dieJoin(s3_last_error());
         std::vector<uint8_t> phase(cnt);
         std::vector<uint64_t> offs((size_t)cnt + 1);
         uint64_t nOcc = 0;
-        if (s3_batch_fetch_alignments(b, phase.data(), nullptr, offs.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return die(s3_last_error());
+        if (s3_batch_fetch_alignments(b, phase.data(), nullptr, offs.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return dieJoin(s3_last_error());
         std::vector<uint32_t> pos(nOcc ? nOcc : 1);
         std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
-        if (s3_batch_fetch_alignments(b, nullptr, nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK) return die(s3_last_error());
+        if (s3_batch_fetch_alignments(b, nullptr, nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK) return dieJoin(s3_last_error());
         parallelFormat(hix, so, out, cnt, [&](SamWriter &w, uint32_t k, uint64_t &al) {
             const size_t o = offs[k], m = offs[k + 1] - offs[k];
             if (alignmentType >= 3) {
@@ -679,7 +792,7 @@ int main(int argc, char **argv)
         if (enableDP) {
             // DPForUnalignSingle2 (DV-DPForSingleReads.cu): seeding in batches of at most 256 Ki seeds, DP at the candidates, one record per run of
             // results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776), the rest as unaligned records
-            if (!seeds.empty() && s3_batch_set_seed_lengths(b, nullptr) != S3_OK) return die(s3_last_error());
+            if (!seeds.empty() && s3_batch_set_seed_lengths(b, nullptr) != S3_OK) return dieJoin(s3_last_error());
             std::vector<uint32_t> todo;
             for (uint32_t k = 0; k < cnt; k++) if (offs[k + 1] == offs[k]) todo.push_back(k);
             std::vector<uint8_t> doneFlag(cnt, 0);
@@ -691,7 +804,7 @@ int main(int argc, char **argv)
                 if (!singleDpRuns(hix, so, dpOut, b, seedBatch, dp, lens, todo, dpPar, alignmentType, [&](SamWriter &w, uint32_t k, std::vector<DpHit> &hits) {
                         w.singleDP(rs, first + k, hits.data(), hits.size(), dpPar.cutoffThreshold);
                         doneFlag[k] = 1;
-                    }, e2)) return die(e2);
+                    }, e2)) return dieJoin(e2);
                 for (uint32_t k : todo) dpAlignedReads += doneFlag[k];
             }
             SamWriter w(hix, so, dpOut);
@@ -717,8 +830,11 @@ int main(int argc, char **argv)
     printf("[Main] Alignment + output time : %9.4f seconds\n[Main] Total elapsed time : %9.4f seconds\n", since(tAlign), since(t0));
     (void)devSeconds; (void)formatSeconds;
     printf("[Main] Overall number of reads aligned: %llu\n", (unsigned long long)aligned);
-    printf("[Main] Overall number of unaligned reads: %llu\n", (unsigned long long)(rs.n - aligned));
-    s3_batch_free(b);
+    printf("[Main] Overall number of unaligned reads: %llu\n", (unsigned long long)(totalReads - aligned));
+    printf("[Main] Read load time : %9.4f seconds (loader thread, overlapped)\n", loaded.seconds);
+    loader.join();
+    if (!loaded.err.empty()) return die(loaded.err);
+    if (b) s3_batch_free(b);
     s3_index_free(ix);
     FILE *done = fopen((prefix + ".done").c_str(), "w");
     if (done) fclose(done);

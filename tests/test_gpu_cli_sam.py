@@ -35,12 +35,18 @@ VARIANTS = [("s2", ["-s", "2"]), ("s4", ["-s", "4"]), ("h1_s2", ["-s", "2", "-h"
 
 @pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
 @pytest.mark.parametrize("variant,opts", VARIANTS)
-def test_cli_sam_matches_reference_cpu_path(tmp_path, name, maxlen, variant, opts):
+@pytest.mark.parametrize("chunk", ["", "192"])
+def test_cli_sam_matches_reference_cpu_path(tmp_path, name, maxlen, variant, opts, chunk):
+    """chunk: S3DP_CHUNK_READS -- the input is streamed in chunks of that many reads (several batches in flight on their own HIP streams, a loader
+    thread and a writer thread around them); '' = the default size, one chunk for these files"""
     assert os.path.exists(BIN), "soap3-dp binary not built"
     fq = tmp_path / (name + ".fq")                      # the read-group id is the query file name as typed
     shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), fq)
+    env = dict(os.environ)
+    if chunk:
+        env["S3DP_CHUNK_READS"] = chunk
     out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", str(maxlen)] + opts + ["-b", "2",
-                          "-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+                          "-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
     mine_h, mine = sam_records(open(tmp_path / "out.gout.1").read())
     ref_h, ref = sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_%s.sam.gz" % variant), "rt").read())
@@ -107,11 +113,35 @@ def sam_pair_records(text):
 
 
 @pytest.mark.parametrize("variant,opts", PAIR_VARIANTS)
-def test_cli_sam_pairs(tmp_path, variant, opts):
+@pytest.mark.parametrize("chunk", ["", "640"])
+def test_cli_sam_pairs(tmp_path, variant, opts, chunk):
     name = "g4"
     for k in ("1", "2"):
         shutil.copy(os.path.join(GOLDEN, name, "reads_%s.fq" % k), tmp_path / ("%s_%s.fq" % (name, k)))
+    env = dict(os.environ)
+    if chunk:
+        env["S3DP_CHUNK_READS"] = chunk
     out = subprocess.run([BIN, "pair", os.path.join(GOLDEN, name, "index"), name + "_1.fq", name + "_2.fq", "-L", "100", "-u", "500", "-v", "200"] + opts +
+                         ["-b", "2", "-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    mine_h, mine = sam_pair_records(open(tmp_path / "out.gout.1").read())
+    ref_h, ref = sam_pair_records(gzip.open(os.path.join(GOLDEN, name, "pe_%s.sam.gz" % variant), "rt").read())
+    assert mine_h == ref_h
+    assert set(mine) == set(ref)
+    bad = [(k, ref[k], mine[k]) for k in ref if ref[k] != mine[k]]
+    assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][1], bad[0][2])
+
+
+# BASELINE config C3's shape with the DP stages off: 2 x 150 bp, -u 500 -v 1 (fixture g7; with the DP stages on: tests/test_gpu_dp_pipeline.py)
+C3_VARIANTS = [("s3", ["-s", "3"]), ("h1_s3", ["-s", "3", "-h", "1"]), ("h3_s3", ["-s", "3", "-h", "3"]), ("h4_s3", ["-s", "3", "-h", "4", "-p"])]
+
+
+@pytest.mark.parametrize("variant,opts", C3_VARIANTS)
+def test_cli_sam_pairs_c3_shape(tmp_path, variant, opts):
+    name = "g7"
+    for k in ("1", "2"):
+        shutil.copy(os.path.join(GOLDEN, name, "reads_%s.fq" % k), tmp_path / ("%s_%s.fq" % (name, k)))
+    out = subprocess.run([BIN, "pair", os.path.join(GOLDEN, name, "index"), name + "_1.fq", name + "_2.fq", "-L", "150", "-u", "500", "-v", "1"] + opts +
                          ["-b", "2", "-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
     mine_h, mine = sam_pair_records(open(tmp_path / "out.gout.1").read())

@@ -75,6 +75,9 @@ CASES = [
     ("g4_h1", "g4", "h1", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "100", "-u", "500", "-v", "100", "-b", "2", "-h", "1"]),
     ("g5_h2", "g5", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "100", "-u", "500", "-v", "100", "-b", "2"]),
     ("g1_se", "g1", "se", "single", ("reads.fq",), ["-L", "100", "-b", "2"]),
+    # the same input in chunks of 1024 / 512 reads (the command line streams its input: S3DP_CHUNK_READS): nothing may depend on the chunking
+    ("g7_h2_chunked", "g7", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]),
+    ("g7_se_chunked", "g7", "se", "single", ("reads_1.fq",), ["-L", "150", "-b", "2"]),
 ]
 
 
@@ -87,6 +90,8 @@ def test_dp_pipeline_matches_the_reference_engines(tmp_path, case, gdir, tag, mo
         shutil.copy(os.path.join(GOLDEN, gdir, r), tmp_path / n)
         names.append(n)
     env = dict(os.environ, S3DP_DUMP_DP=str(tmp_path / "problems.txt"))
+    if case.endswith("_chunked"):
+        env["S3DP_CHUNK_READS"] = "1024" if mode == "pair" else "512"
     out = subprocess.run([BIN, mode, os.path.join(GOLDEN, gdir, "index")] + names + opts + ["-o", "out"], cwd=tmp_path, capture_output=True, text=True,
                          timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]

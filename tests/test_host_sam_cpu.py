@@ -10,7 +10,7 @@ import pytest
 
 import s3o
 from conftest import GOLDEN, ROOT
-from test_gpu_cli_sam import LONG_VARIANTS, PAIR_VARIANTS, VARIANTS, sam_pair_records, sam_records
+from test_gpu_cli_sam import C3_VARIANTS, LONG_VARIANTS, PAIR_VARIANTS, VARIANTS, sam_pair_records, sam_records
 
 TOOL = os.path.join(ROOT, "tests", "tools", "oracle_sam")
 _built = {}
@@ -67,4 +67,14 @@ def test_pair_sam(tmp_path, variant, opts):
     for k in ("1", "2"):
         shutil.copy(os.path.join(GOLDEN, name, "reads_%s.fq" % k), tmp_path / ("%s_%s.fq" % (name, k)))
     text = run(tmp_path, ["pair", os.path.join(GOLDEN, name, "index"), name + "_1.fq", name + "_2.fq", "-L", "100", "-u", "500", "-v", "200"] + opts)
+    compare(sam_pair_records(text), sam_pair_records(gzip.open(os.path.join(GOLDEN, name, "pe_%s.sam.gz" % variant), "rt").read()))
+
+
+@pytest.mark.parametrize("variant,opts", C3_VARIANTS)
+def test_pair_sam_c3_shape(tmp_path, variant, opts):
+    """fixture g7: BASELINE config C3's shape -- 2 x 150 bp, -u 500 -v 1 (wordPerQuery 16), DP stages off"""
+    name = "g7"
+    for k in ("1", "2"):
+        shutil.copy(os.path.join(GOLDEN, name, "reads_%s.fq" % k), tmp_path / ("%s_%s.fq" % (name, k)))
+    text = run(tmp_path, ["pair", os.path.join(GOLDEN, name, "index"), name + "_1.fq", name + "_2.fq", "-L", "150", "-u", "500", "-v", "1"] + opts)
     compare(sam_pair_records(text), sam_pair_records(gzip.open(os.path.join(GOLDEN, name, "pe_%s.sam.gz" % variant), "rt").read()))
