@@ -11,6 +11,17 @@ using namespace s3i;
 static thread_local std::string g_err;
 int s3i::fail(int code, const std::string &msg) { g_err = msg; return code; }
 
+namespace {
+struct U32ToU64 { __host__ __device__ unsigned long long operator()(const uint32_t &x) const { return (unsigned long long)x; } };
+}
+int s3i::sum64Async(s3_batch *b, const uint32_t *counts, uint32_t n)
+{
+    hipcub::TransformInputIterator<unsigned long long, U32ToU64, const uint32_t *> it(counts, U32ToU64());
+    size_t tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceReduce::Sum(b->dTemp, tb, it, b->dSum64, (int)n, b->stream));
+    return S3_OK;
+}
+
 extern "C" const char *s3_last_error(void) { return g_err.c_str(); }
 extern "C" const char *s3_version(void) { return "s3dp 0.1 (gfx950)"; }
 extern "C" void s3_free(void *p) { free(p); }
@@ -243,7 +254,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
     BA(dRecs, recCap); BA(dOrdered, recCap); b->ordCap = recCap;
-    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskEnd, 4);
+    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskEnd, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4);
     BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
@@ -260,6 +271,12 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     size_t t1 = 0, t2 = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, b->dItemCounts, b->dItemOffsets, (int)(b->maxItems + 1), b->stream);
     (void)hipcub::DeviceSelect::Flagged(nullptr, t2, b->dIota, b->dSelFlags, b->dActive[0], b->dNumSel, (int)maxReads, b->stream);
+    {
+        size_t t3 = 0;
+        hipcub::TransformInputIterator<unsigned long long, U32ToU64, const uint32_t *> it(b->dItemCounts, U32ToU64());
+        (void)hipcub::DeviceReduce::Sum(nullptr, t3, it, b->dSum64, (int)(b->maxItems + 1), b->stream);
+        if (t3 > t1) t1 = t3;
+    }
     b->tempBytes = (t1 > t2 ? t1 : t2) + 256;
     if ((rc = balloc(b, &b->dTemp, b->tempBytes))) { s3_batch_free(b); return rc; }
     HIPCHK(hipEventCreate(&b->evTotal[0])); HIPCHK(hipEventCreate(&b->evTotal[1]));
@@ -417,12 +434,19 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         {
             size_t tb = b->tempBytes;
             HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dItemCounts, b->dItemOffsets, (int)(nItems + 1), b->stream));
+            int rc = sum64Async(b, b->dItemCounts, (uint32_t)nItems);
+            if (rc) return rc;
         }
         // a record that did not fit was dropped but counted: the ordering below must not run on such a pass.  Grow and search again.
         uint32_t flags = 0;
         HIPCHK(hipMemcpyAsync(&flags, b->dFlags, 4, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipMemcpyAsync(&slots, b->dItemOffsets + nItems, 4, hipMemcpyDeviceToHost, b->stream));
+        unsigned long long slots64 = 0;
+        HIPCHK(hipMemcpyAsync(&slots64, b->dSum64, 8, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
+        if (slots64 != slots)
+            return fail(S3_EOVERFLOW, "more than 2^32 hit records and check-and-extend candidates in one search pass (" + std::to_string(slots64) +
+                                          "): use smaller batches");
         if (!(flags & S3_FLAG_REC_OVERFLOW)) break;
         int rc = growRecords(b);
         if (rc) return rc;

@@ -103,7 +103,7 @@ struct DpArgs {
     uint32_t        n, maxDNALength, maxReadLength, maxDPTableLength, patternLen, ldsPerWave;
     int             match, mismatch, gapOpen, gapExtend, scheme;
 };
-void launchDp(const DpArgs &a, hipStream_t s);
+int launchDp(const DpArgs &a, hipStream_t s);        // returns a hipError_t
 
 void launchOrientReads(const uint32_t *queries, const uint32_t *lengths, uint32_t *readsT, uint32_t n, uint32_t wpq, uint32_t S, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) dpFillKernel(DpArgs a)
     extern __shared__ __align__(16) unsigned char sh[];
     // the wavefront number is uniform: saying so keeps the problem's lengths, clips, anchors and loop counters in scalar registers
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    const uint32_t p = blockIdx.x * 4u + wv;
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + wv;                // 1, 2 or 4 problems per block: what the windows leave room for in LDS
     if (p >= a.n) return;
     const uint32_t perWave = a.ldsPerWave;
     unsigned char *refLds = sh + wv * perWave;
@@ -299,12 +299,25 @@ __global__ void dpBacktrackKernel(DpArgs a)
     a.hitLocs[p] = refOffset + refIndex;
 }
 
-void launchDp(const DpArgs &a, hipStream_t s)
+// returns a hipError_t (hipErrorInvalidValue: a window that does not fit into LDS even with one problem per block)
+int launchDp(const DpArgs &a, hipStream_t s)
 {
-    if (!a.n) return;
-    const size_t lds = (size_t)a.ldsPerWave * 4u;
-    hipLaunchKernelGGL(dpFillKernel, dim3((a.n + 3u) / 4u), dim3(256), lds, s, a);
+    if (!a.n) return (int)hipSuccess;
+    // a wave keeps its window and the boundary row of its pass in LDS (ldsPerWave bytes); blocks hold 4 waves while that fits into the CU's 160 KB,
+    // then 2, then 1 (windows up to about 12,000 columns)
+    const size_t kLdsMax = 160u * 1024u;
+    uint32_t waves = 4;
+    while (waves > 1 && (size_t)a.ldsPerWave * waves > kLdsMax) waves >>= 1;
+    const size_t lds = (size_t)a.ldsPerWave * waves;
+    if (lds > kLdsMax) return (int)hipErrorInvalidValue;
+    if (lds > 48u * 1024u) {
+        // above the default limit for dynamic LDS: without the attribute the launch fails (and only shows at the next synchronisation)
+        const hipError_t e = hipFuncSetAttribute((const void *)dpFillKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(dpFillKernel, dim3((a.n + waves - 1u) / waves), dim3(64u * waves), lds, s, a);
     hipLaunchKernelGGL(dpBacktrackKernel, dim3((a.n + 63u) / 64u), dim3(64), 0, s, a);
+    return (int)hipSuccess;
 }
 
 }  // namespace s3

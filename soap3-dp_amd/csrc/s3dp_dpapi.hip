@@ -50,8 +50,11 @@ extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLe
                             const s3_dp_scores *sc, s3_dp **outp)
 {
     if (!sc || !outp || !maxProblems || !maxReadLength || !maxDNALength || !maxDPTableLength) return fail(S3_EINVAL, "s3_dp_create: bad argument");
-    if (maxReadLength > 4096 || maxDNALength > 16384) return fail(S3_EINVAL, "s3_dp_create: lengths too large");
+    if (maxReadLength > 4096 || maxDNALength > 12000) return fail(S3_EINVAL, "s3_dp_create: lengths too large (reads up to 4096, windows up to 12000 columns)");
     if (scheme == 1 && maxDPTableLength < maxDNALength) return fail(S3_EINVAL, "s3_dp_create: scheme 1 needs maxDPTableLength >= maxDNALength");
+    // a wave keeps its window (1 byte per column) and one boundary row (12 bytes per column) in LDS: 160 KB per CU bound the window (s3dp_dp.hip::launchDp)
+    if ((size_t)(((maxDNALength + 1u + 15u) & ~15u) + (maxDNALength + 1u) * 12u + 15u) > 160u * 1024u)
+        return fail(S3_EINVAL, "s3_dp_create: maxDNALength above 12,000 columns does not fit the kernel's LDS-resident window");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(S3_ENODEV, "no HIP device available (libs3dp has no CPU path)");
     if (device < 0 || device >= ndev) return fail(S3_EINVAL, "bad device ordinal");
@@ -147,13 +150,16 @@ int s3i::dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL,
     a.n = n; a.maxDNALength = h->maxDNA; a.maxReadLength = h->maxRead; a.maxDPTableLength = h->maxTable; a.patternLen = h->patternLen;
     a.ldsPerWave = (((h->maxDNA + 1u + 15u) & ~15u) + (h->maxDNA + 1u) * 12u + 15u) & ~15u;
     a.match = h->sc.matchScore; a.mismatch = h->sc.mismatchScore; a.gapOpen = h->sc.gapOpenScore; a.gapExtend = h->sc.gapExtendScore; a.scheme = h->scheme;
-    if ((size_t)a.ldsPerWave * 4 > 160 * 1024) return fail(S3_EINVAL, "s3_dp_align: maxDNALength too large for the LDS-resident window");
+    if ((size_t)a.ldsPerWave > 160 * 1024) return fail(S3_EINVAL, "s3_dp_align: maxDNALength too large for the LDS-resident window");
     if (dpDumpFile()) {
         h->dumpClipRt.assign(n, 0);
         if (hasClipRt) { HIPCHK(hipMemcpyAsync(h->dumpClipRt.data(), h->dClipRt, (size_t)n * 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
     }
     HIPCHK(hipEventRecord(h->ev[0], s));
-    launchDp(a, s);
+    {
+        const hipError_t le = (hipError_t)launchDp(a, s);
+        if (le != hipSuccess) return fail(S3_EHIP, std::string("DP kernel launch: ") + hipGetErrorString(le));
+    }
     HIPCHK(hipEventRecord(h->ev[1], s));
     HIPCHK(hipGetLastError());
     h->timed = true;

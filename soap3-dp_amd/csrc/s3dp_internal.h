@@ -48,6 +48,7 @@ struct s3_batch {
     uint4    *dRecs = nullptr, *dOrdered = nullptr;
     uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr, *dTaskEnd = nullptr;
     unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;
+    unsigned long long *dSum64 = nullptr;            // 64-bit total next to a 32-bit scan (sum64Async): a wrapped total must not pass as a small one
     uint8_t  *dHeavyFlags = nullptr;                 // reads the first search pass listed for the exact pass (s3dp_search_v2.hip)
     uint32_t *dHeavyList = nullptr, *dHeavyCount = nullptr;
     uint32_t uniformLen = 0;
@@ -153,6 +154,8 @@ void launchStateAll(uint32_t n, const uint32_t *totalOcc, uint8_t *state, hipStr
 struct SeedDesc { uint32_t readId, off, len, keyHi; };   // seed of read `readId` at `off`; keyHi = the upper key bits its hits sort by
 int seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<SeedDesc> &seeds, uint32_t maxHitNum, uint32_t strandBit,
                    std::vector<uint64_t> &keysSorted, std::vector<uint8_t> &seedStatus);
+// enqueue the 64-bit sum of counts[0, n) into b->dSum64 (uses b->dTemp: call it after the scan that shares the scratch was enqueued, same stream)
+int sum64Async(s3_batch *b, const uint32_t *counts, uint32_t n);
 // DP (s3dp_dpapi.hip): launch the DP kernels on what is in the aligner's device buffers
 int dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR);
 // S3DP_DUMP_DP=<file> (tests): the problems of the last dpRun with their results, and stage separators

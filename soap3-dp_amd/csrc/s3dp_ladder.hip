@@ -146,9 +146,17 @@ int s3i::decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive,
     hipLaunchKernelGGL(maskKernel, dim3(g), dim3(256), 0, b->stream, nActive, b->dState, want, b->dOccCounts, b->dMasked, b->dSelFlags, selectWhen);
     size_t tb = b->tempBytes;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dMasked, b->dOccOffsets, (int)(nActive + 1), b->stream));
+    {
+        int rc = sum64Async(b, b->dMasked, nActive);
+        if (rc) return rc;
+    }
     uint32_t added = 0;
+    unsigned long long added64 = 0;
     HIPCHK(hipMemcpyAsync(&added, b->dOccOffsets + nActive, 4, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(&added64, b->dSum64, 8, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    if (added64 != added || added64 + b->occUsed >= 0xFFFFFF00ull)
+        return fail(S3_EOVERFLOW, "more than 2^32 occurrences in one batch (" + std::to_string(added64 + b->occUsed) + "): use smaller batches or a smaller hit limit");
     if ((uint64_t)b->occUsed + added > b->occCap) {
         int rc = growOccurrences(b, (uint64_t)b->occUsed + added);
         if (rc) return rc;
