@@ -402,20 +402,28 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     tpos, tstrand, tsub = tpos.cpu().numpy(), tstrand.cpu().numpy(), tsub.cpu().numpy().astype(np.int64)
     del reads2d
     log("[%s] %d reads generated + packed in %.1f s" % (label, a.reads, time.perf_counter() - t0))
-    # index: built ONCE (rank 0, on its GPU), written in the reference's file formats, loaded by every rank
+    # index: built ONCE (rank 0, on its GPU), written in the reference's file formats, loaded by every rank; --index-dir keeps the files for the
+    # next run (profiling runs load them instead of tracing the thousands of small kernels of the suffix sort)
     t0 = time.perf_counter()
-    if world > 1:
-        prefix = os.path.join(index_dir, "bench_%s.index" % label)
+    keep_dir = a.index_dir or index_dir
+    prefix = os.path.join(keep_dir, "bench_%s_%d.index" % (label, a.genome_bp)) if keep_dir else None
+    if prefix and os.path.exists(prefix + ".sa") and a.index_dir:
+        hi = s3dp.HostIndex.from_files(prefix)
+    elif world > 1 or prefix:
         if rank == 0:
+            os.makedirs(keep_dir, exist_ok=True)
             hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=True)
             hi.write_files(prefix, with_lkt=True)
-        dist.barrier()
-        if rank != 0:
-            hi = s3dp.HostIndex.from_files(prefix)
+        if world > 1:
+            dist.barrier()
+            if rank != 0:
+                hi = s3dp.HostIndex.from_files(prefix)
     else:
         hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=(rank == 0))
     torch.cuda.empty_cache()
     log("[%s] index built in %.1f s" % (label, time.perf_counter() - t0))
+    if a.build_only:
+        raise SystemExit(0)
     t0 = time.perf_counter()
     ix = s3dp.Index(hi, device=local)
     log("[%s] index resident: %.2f GB in HBM, upload %.1f s" % (label, ix.device_bytes() / 1e9, time.perf_counter() - t0))
@@ -571,6 +579,8 @@ def main():
     ap.add_argument("--stream-batch", type=int, default=1 << 20, help="reads per streamed batch (the reference's batch, SOAP3-DP.cu:394)")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle after the run")
+    ap.add_argument("--index-dir", default=None, help="keep / reuse the index files of the benchmark genome in this directory")
+    ap.add_argument("--build-only", type=int, default=0, help="stop after the index files are written (with --index-dir)")
     ap.add_argument("--extras", type=int, default=1, help="after the timed region (N = 1): paired-end 2x150 BWT stage and DP kernel throughput")
     a = ap.parse_args()
 

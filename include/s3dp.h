@@ -158,6 +158,23 @@ int  s3_stream_next(s3_stream *st, s3_stream_result *res);
 int  s3_stream_release(s3_stream *st);
 void s3_stream_free(s3_stream *st);
 
+/* ---- several devices -------------------------------------------------------------------------------------------------------------
+ * The reference takes ONE device (`-c <id>`, SOAP3-DP.cu:219-220, README.md:523-536).  The path shards by reads, so a group of devices each holds
+ * the whole index (s3_group_create uploads it to every member at once) and aligns its own batches -- s3_group_member_of_batch deals batch i to
+ * member i mod n; a batch holds whole pairs, mates stay together (CPUfunctions.cpp:1982,2029).  Batches, streams and DP aligners are created on
+ * s3_group_index(g, k) like on any index.  The single exchange step is the sum of the counters at the end (the `[Main] Overall ...` numbers,
+ * SOAP3-DP.cu:816-830): s3_group_allreduce takes nMembers rows of nCounters values and leaves the column sums in every row, computed by one
+ * ncclAllReduce over the members' devices (RCCL; members that share a device -- a test on one GPU -- are summed on the host instead, RCCL needs
+ * distinct devices).  Output: one set of files per member, as the reference writes one .gout.N per CPU thread (SOAP3-DP.cu:251-258). */
+typedef struct s3_group s3_group;
+int  s3_group_create(const int *devices, int nDevices, const s3_index_desc *desc, s3_group **out);
+int  s3_group_size(const s3_group *g);
+int  s3_group_device(const s3_group *g, int member);
+s3_index *s3_group_index(s3_group *g, int member);
+int  s3_group_member_of_batch(const s3_group *g, uint64_t batchNumber);
+int  s3_group_allreduce(s3_group *g, uint64_t *counters, int nCounters);
+void s3_group_free(s3_group *g);
+
 /* ---- default DP for half-aligned pairs -------------------------------------------------------------------------------------
  * Replaces HalfEndAlignmentEngine (DV-DPfunctions.cu:1888-2540): for every occurrence of the aligned end (HalfEndOccStream order) the
  * window the insert size allows is cut from the RESIDENT text (HalfEndAlgnBatch::pack :2027-2109: '+' aligned end -> mate to its right

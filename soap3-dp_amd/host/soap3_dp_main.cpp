@@ -179,7 +179,9 @@ static bool singleDpRuns(const HostIndex &hix, const SamOptions &so, FILE *paral
     return true;
 }
 
+static std::mutex g_pairStageMu;                                 // (several devices run the stages at once)
 static double g_pairStageSeconds[5] = {0, 0, 0, 0, 0};          // routing, default DP, new default DP, deep DP, single-end DP of the leftovers
+static double pairStageSeconds(int k) { std::lock_guard<std::mutex> g(g_pairStageMu); return g_pairStageSeconds[k]; }
 
 // ---- DP stages of a paired-end batch (soap3_dp_pair_align after the BWT ladder, alignment.cu:2021-2420) --------------------------------------
 struct PairDpCtx {
@@ -200,7 +202,11 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
 {
     const uint32_t np = c.cnt / 2;
     auto tStage = std::chrono::steady_clock::now();
-    auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); g_pairStageSeconds[k] += std::chrono::duration<double>(now - tStage).count(); tStage = now; };
+    auto lap = [&](int k) {
+        const auto now = std::chrono::steady_clock::now();
+        { std::lock_guard<std::mutex> g(g_pairStageMu); g_pairStageSeconds[k] += std::chrono::duration<double>(now - tStage).count(); }
+        tStage = now;
+    };
     const bool mapqMode = c.alignmentType == 1 || c.alignmentType == 2;
     const int moduleType = c.alignmentType == 2 ? 1 : c.alignmentType;          // all-best + SAM runs the DP module as all-valid (alignment.cu:2023-2030)
     const uint32_t maxHit[2] = {(uint32_t)c.halfPar[0].maxHitNum, (uint32_t)c.halfPar[1].maxHitNum};
@@ -472,7 +478,8 @@ int main(int argc, char **argv)
     parseIni(std::string(argv[0]) + ".ini", ini);
     const std::string indexName = argv[2], queryFile = argv[3], queryFile2 = paired ? argv[4] : "";
     int insertHigh = 500, insertLow = 1;                                       // IniParam.cpp:482-483
-    int maxReadLength = 120, numMismatch = -1, alignmentType = 2, outputFormat = 2, device = 0;   // DEFAULT_MAX_READ_LEN, all-best, SAM
+    int maxReadLength = 120, numMismatch = -1, alignmentType = 2, outputFormat = 2;             // DEFAULT_MAX_READ_LEN, all-best, SAM
+    std::vector<int> devices(1, 0);                                            // -c: the reference takes one GPU id (SOAP3-DP.cu:219-220); here also a list "0,1,2"
     bool enableDP = true, skipSoap3 = false;
     std::string prefix = queryFile, readGroup, sampleName, readGrpOption;
     bool printMDNM = false;
@@ -483,7 +490,16 @@ int main(int argc, char **argv)
         else if (a == "-h") alignmentType = atoi(need("the output option"));
         else if (a == "-b") outputFormat = atoi(need("the output file format"));
         else if (a == "-o") prefix = need("the output prefix");
-        else if (a == "-c") device = atoi(need("the GPU device ID"));
+        else if (a == "-c") {
+            devices.clear();
+            for (const char *q = need("the GPU device ID"); *q;) {
+                char *e = nullptr;
+                devices.push_back((int)strtol(q, &e, 10));
+                if (e == q) return die("The GPU device ID should be a number or a comma-separated list of numbers");
+                q = *e == ',' ? e + 1 : e;
+            }
+            if (devices.empty()) return die("Please specify the GPU device ID after '-c'");
+        }
         else if (a == "-D") readGroup = need("the read group");
         else if (a == "-A") sampleName = need("the sample name");
         else if (a == "-R") readGrpOption = need("the read group option");
@@ -549,9 +565,12 @@ int main(int argc, char **argv)
     if (!loadIndex(indexName, hix, err)) return dieJoin(err);
     printf("[Main] Finished loading index into host.\n[Main] Loading time : %9.4f seconds\n", since(t0));
     printf("[Main] Reference sequence length : %u\n", hix.n);
-    s3_index *ix = nullptr;
+    // the index is replicated: one copy per device, uploaded at the same time (s3_group_create); the read chunks are dealt to the devices as they
+    // come free, each device writes its own set of output files (as the reference writes one .gout.N per CPU thread, SOAP3-DP.cu:251-258)
+    s3_group *grp = nullptr;
     s3_index_desc d = hix.desc();
-    if (s3_index_upload(device, &d, &ix) != S3_OK) return dieJoin(s3_last_error());
+    if (s3_group_create(devices.data(), (int)devices.size(), &d, &grp) != S3_OK) return dieJoin(s3_last_error());
+    const int nMembers = (int)devices.size();
     printf("[Main] Finished copying index into device (GPU).\n");
     std::unique_ptr<ReadSet> chunk = nextChunk();
     if (!chunk) {
@@ -584,8 +603,26 @@ int main(int argc, char **argv)
         if (!enableDP && numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;
     }
     const auto tAlign = std::chrono::steady_clock::now();
-    double devSeconds = 0, formatSeconds = 0, dpStageSeconds = 0;
-    const std::string outName = prefix + ".gout.1";
+    // the first chunk goes back to the head of the queue: the members take their chunks from there
+    if (chunk->n) { std::lock_guard<std::mutex> g(loaded.mu); loaded.q.push_front(std::move(chunk)); }
+    chunk.reset();
+    enum { C_ALIGNED, C_READS, C_DP_READS, C_DEFAULT_DP, C_NEW_DEFAULT_DP, C_DEEP_DP, C_LEFTOVER, C_COUNTERS };
+    std::vector<uint64_t> counters((size_t)nMembers * C_COUNTERS, 0);
+    std::vector<double> memberDpSeconds((size_t)nMembers, 0);
+    auto runMember = [&](int member) -> int {
+    const int device = s3_group_device(grp, member);
+    s3_index *ix = s3_group_index(grp, member);
+    const std::string fileNo = std::to_string(member + 1);
+    double dpStageSeconds = 0;
+    std::unique_ptr<ReadSet> chunk = nextChunk();
+    if (!chunk) {
+        if (member > 0) return 0;                                              // fewer chunks than devices: nothing for this one (member 0 still writes the headers)
+        chunk.reset(new ReadSet());
+        uint32_t w = 1;
+        while (w < (uint32_t)maxReadLength) w *= 2;
+        chunk->wpq = w / 16 ? w / 16 : 1; chunk->maxReadLength = (uint32_t)maxReadLength;
+    }
+    const std::string outName = prefix + ".gout." + fileNo;
     FILE *out = fopen(outName.c_str(), "w");
     if (!out) return dieJoin("Could not open the output file " + outName);
     SamOptions so;
@@ -602,7 +639,7 @@ int main(int argc, char **argv)
     FILE *unpairOut = nullptr;
     uint64_t dpAlignedReads = 0, defaultDpPairs = 0, newDefaultPairs = 0, deepDpPairs = 0, leftoverPairs = 0;
     if (enableDP) {
-        const std::string dpName = prefix + ".dpout.1";
+        const std::string dpName = prefix + ".dpout." + fileNo;
         dpOut = fopen(dpName.c_str(), "w");
         if (!dpOut) return dieJoin("Could not open the output file " + dpName);
         SamWriter dpHdr(hix, so, dpOut);
@@ -633,7 +670,7 @@ int main(int argc, char **argv)
                 s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND1, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[0][e]);
                 s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND2, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[1][e]);
             }
-            const std::string upName = prefix + ".unpair";
+            const std::string upName = prefix + (member == 0 ? ".unpair" : ".unpair." + fileNo);
             unpairOut = fopen(upName.c_str(), "w");
             if (!unpairOut) return dieJoin("Could not open the output file " + upName);
             SamWriter upHdr(hix, so, unpairOut);
@@ -816,26 +853,47 @@ int main(int argc, char **argv)
         fclose(dpOut);
         if (paired) {
             fclose(unpairOut);
-            printf("[Main] Number of pairs aligned by new default DP: %llu\n[Main] Number of pairs aligned by DP: %llu\n[Main] Number of pairs aligned by deep DP: %llu\n"
-                   "[Main] Pairs left without a proper pairing: %llu\n[Main] DP stages time : %9.4f seconds (routing %.3f, default DP %.3f, new default DP %.3f, deep DP %.3f, leftovers %.3f)\n",
-                   (unsigned long long)newDefaultPairs, (unsigned long long)defaultDpPairs, (unsigned long long)deepDpPairs, (unsigned long long)leftoverPairs, dpStageSeconds,
-                   g_pairStageSeconds[0], g_pairStageSeconds[1], g_pairStageSeconds[2], g_pairStageSeconds[3], g_pairStageSeconds[4]);
             dpAlignedReads = 2 * (defaultDpPairs + newDefaultPairs + deepDpPairs);
             s3_dp_free(dpHalf);
-        } else printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)dpAlignedReads);
+        }
         aligned += dpAlignedReads;
         s3_dp_free(dp);
         s3_batch_free(seedBatch);
     }
+    if (b) s3_batch_free(b);
+    uint64_t *C = counters.data() + (size_t)member * C_COUNTERS;
+    C[C_ALIGNED] = aligned; C[C_READS] = totalReads; C[C_DP_READS] = dpAlignedReads; C[C_DEFAULT_DP] = defaultDpPairs; C[C_NEW_DEFAULT_DP] = newDefaultPairs;
+    C[C_DEEP_DP] = deepDpPairs; C[C_LEFTOVER] = leftoverPairs;
+    memberDpSeconds[(size_t)member] = dpStageSeconds;
+    return 0;
+    };   // runMember
+    {
+        std::vector<std::thread> mt;
+        for (int m = 1; m < nMembers; m++) mt.emplace_back([&, m] { runMember(m); });
+        runMember(0);
+        for (auto &t : mt) t.join();
+    }
+    // the one exchange step of the path: the counters of the devices summed (one ncclAllReduce over the group, s3_group_allreduce)
+    if (s3_group_allreduce(grp, counters.data(), C_COUNTERS) != S3_OK) return dieJoin(s3_last_error());
+    const uint64_t aligned = counters[C_ALIGNED], totalReads = counters[C_READS];
+    double dpStageSeconds = 0;
+    for (double x : memberDpSeconds) dpStageSeconds = std::max(dpStageSeconds, x);
+    if (enableDP) {
+        if (paired)
+            printf("[Main] Number of pairs aligned by new default DP: %llu\n[Main] Number of pairs aligned by DP: %llu\n[Main] Number of pairs aligned by deep DP: %llu\n"
+                   "[Main] Pairs left without a proper pairing: %llu\n[Main] DP stages time : %9.4f seconds (routing %.3f, default DP %.3f, new default DP %.3f, deep DP %.3f, leftovers %.3f)\n",
+                   (unsigned long long)counters[C_NEW_DEFAULT_DP], (unsigned long long)counters[C_DEFAULT_DP], (unsigned long long)counters[C_DEEP_DP],
+                   (unsigned long long)counters[C_LEFTOVER], dpStageSeconds, pairStageSeconds(0), pairStageSeconds(1), pairStageSeconds(2), pairStageSeconds(3), pairStageSeconds(4));
+        else printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)counters[C_DP_READS]);
+    }
+    if (nMembers > 1) printf("[Main] Devices: %d (index replicated, chunks of %u reads dealt as the devices come free, counters summed by one all-reduce)\n", nMembers, chunkReads);
     printf("[Main] Alignment + output time : %9.4f seconds\n[Main] Total elapsed time : %9.4f seconds\n", since(tAlign), since(t0));
-    (void)devSeconds; (void)formatSeconds;
     printf("[Main] Overall number of reads aligned: %llu\n", (unsigned long long)aligned);
     printf("[Main] Overall number of unaligned reads: %llu\n", (unsigned long long)(totalReads - aligned));
     printf("[Main] Read load time : %9.4f seconds (loader thread, overlapped)\n", loaded.seconds);
     loader.join();
     if (!loaded.err.empty()) return die(loaded.err);
-    if (b) s3_batch_free(b);
-    s3_index_free(ix);
+    s3_group_free(grp);
     FILE *done = fopen((prefix + ".done").c_str(), "w");
     if (done) fclose(done);
     return 0;

@@ -44,7 +44,8 @@ EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_inde
            "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_batch_fetch_pair_origins", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_dp_single_end", "s3_dp_deep", "s3_dp_new_default", "s3_batch_fetch_alignments", "s3_batch_sync", "s3_batch_last_ce_timing",
            "s3_batch_last_timing", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_last_error", "s3_version", "s3_probe_gather",
-           "s3_stream_create", "s3_stream_acquire", "s3_stream_submit", "s3_stream_next", "s3_stream_release", "s3_stream_free"]
+           "s3_stream_create", "s3_stream_acquire", "s3_stream_submit", "s3_stream_next", "s3_stream_release", "s3_stream_free",
+           "s3_group_create", "s3_group_size", "s3_group_device", "s3_group_index", "s3_group_member_of_batch", "s3_group_allreduce", "s3_group_free"]
 
 _lib = None
 
@@ -81,6 +82,15 @@ def lib():
         L.s3_stream_release.argtypes = [C.c_void_p]
         L.s3_stream_free.argtypes = [C.c_void_p]
         L.s3_stream_free.restype = None
+        L.s3_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
+        L.s3_group_size.argtypes = [C.c_void_p]
+        L.s3_group_device.argtypes = [C.c_void_p, C.c_int]
+        L.s3_group_index.argtypes = [C.c_void_p, C.c_int]
+        L.s3_group_index.restype = C.c_void_p
+        L.s3_group_member_of_batch.argtypes = [C.c_void_p, C.c_uint64]
+        L.s3_group_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.s3_group_free.argtypes = [C.c_void_p]
+        L.s3_group_free.restype = None
         _lib = L
     return _lib
 
@@ -732,3 +742,52 @@ def stream_bench(index, queries, lens, wpq, mm, max_out, batch_reads, steps, dep
         st.close()
     return {"reads": sum(m for _, m in jobs) * steps, "seconds": dt, "occurrences": occ // max(1, steps), "batch_reads": batch_reads, "depth": depth,
             "what": "packed reads host -> device and occurrence lists device -> host inside the timed region, %d batches in flight" % depth}
+
+
+# ------------------------------------------------------------------------------------------------
+# several devices (s3_group_*): index replicated per member, batches dealt in turn, one RCCL all-reduce of the counters
+# ------------------------------------------------------------------------------------------------
+class _MemberIndex:
+    """an index owned by a Group (not freed on its own)"""
+
+    def __init__(self, h):
+        self.h = C.c_void_p(h)
+
+    def device_bytes(self):
+        return lib().s3_index_device_bytes(self.h)
+
+    def close(self):
+        pass
+
+
+class Group:
+    def __init__(self, host_index, devices):
+        self.h = C.c_void_p()
+        d = host_index.desc()
+        arr = (C.c_int * len(devices))(*devices)
+        _chk(lib().s3_group_create(arr, len(devices), C.byref(d), C.byref(self.h)))
+        self.n = len(devices)
+
+    def index(self, k):
+        return _MemberIndex(lib().s3_group_index(self.h, k))
+
+    def member_of_batch(self, i):
+        return lib().s3_group_member_of_batch(self.h, i)
+
+    def allreduce(self, rows):
+        """rows: (members, counters) array of uint64; returns the array with every row = column sums"""
+        a = np.ascontiguousarray(rows, dtype=np.uint64).copy()
+        assert a.shape[0] == self.n
+        _chk(lib().s3_group_allreduce(self.h, a.ctypes.data, a.shape[1]))
+        return a
+
+    def close(self):
+        if self.h:
+            lib().s3_group_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
