@@ -256,7 +256,9 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     BA(dRecs, recCap); BA(dOrdered, recCap); b->ordCap = recCap;
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskEnd, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
-    BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4);
+    BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
+    BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4);
+    b->countCap = b->maxItems + 1;
     BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
     BA(dWithError, (size_t)maxReads * 8);
     BA(dHitOffsets, (size_t)maxReads + 1); BA(dHits, recCap);
@@ -386,8 +388,15 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         S3Model m;
         s3_model_build(100, (int)modelMm, &m);
         in.nStepsPacked = 0;
-        for (int c = 0; c < m.nCases; c++) in.nStepsPacked |= (uint32_t)m.cs[c].nSteps << (3 * c);
+        in.sStarPacked = 0;
+        for (int c = 0; c < m.nCases; c++) {
+            in.nStepsPacked |= (uint32_t)m.cs[c].nSteps << (3 * c);
+            int sStar = m.cs[c].nSteps;                                    // the first step that allows a mismatch (depends on the budget only)
+            for (int k = m.cs[c].nSteps - 1; k >= 0; k--) if (m.cs[c].st[k].maxErr > 0) sStar = k;
+            in.sStarPacked |= (uint32_t)sStar << (3 * c);
+        }
     }
+    in.unitsPerItem = 1; in.unitBase = 0;
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
     unsigned long long counterSnap[8];
     if (b->counting) {
@@ -399,6 +408,28 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     const size_t heavyEnv = envSize("S3DP_HEAVY", 1);                       // read per pass: tests switch it
     in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : 256u);
     in.slotList = nullptr; in.slotCount = nullptr;
+    // units of the second pass: first-mismatch positions of an item's first mismatch step, + 1 for "none" -- the longest such step over the cases
+    // and over the read lengths this batch can hold (S3DP_UNITS=0: whole items)
+    uint32_t unitsPerItem = 1;
+    if (in.heavyLimit != 0xFFFFFFFFu && envSize("S3DP_UNITS", 1) != 0) {
+        const uint32_t lo = b->uniformLen ? b->uniformLen : 16u, hi = b->uniformLen ? b->uniformLen : std::min<uint32_t>(in.wpqLoad * 16u, S3_MAX_READ_LENGTH);
+        bool ok = true;
+        int longest = 0;
+        for (uint32_t L = lo; L <= hi && ok; L++) {
+            S3Model m;
+            s3_model_build((int)L, (int)modelMm, &m);
+            for (int c = 0; c < m.nCases && ok; c++) {
+                const int sStar = (int)((in.sStarPacked >> (3 * c)) & 7u);
+                if (sStar >= m.cs[c].nSteps) continue;
+                if (sStar == 0) { ok = false; break; }                      // mismatches inside the lookup step: positions the lookup swallows cannot be units
+                const S3Step &st = m.cs[c].st[sStar];
+                const int lenEff = st.minErr > 1 ? st.len - (st.minErr - 1) : st.len;
+                if (lenEff > longest) longest = lenEff;
+            }
+        }
+        if (ok && longest > 0) unitsPerItem = (uint32_t)longest + 1u;
+    }
+    uint32_t nHeavy = 0, nCount = (uint32_t)nItems;                         // entries of itemCounts in use: the items, then the units of the listed reads
     for (;;) {
         HIPCHK(hipMemsetAsync(b->dRecCount, 0, 4, b->stream));
         HIPCHK(hipMemsetAsync(b->dHeavyCount, 0, 4, b->stream));
@@ -407,7 +438,8 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
         out.counters = b->counting ? b->dCounters : nullptr;
         out.workHead = b->dWorkHead;
-        out.heavyFlags = b->dHeavyFlags; out.heavyList = b->dHeavyList; out.heavyCount = b->dHeavyCount;
+        out.heavyFlags = b->dHeavyFlags; out.heavyList = b->dHeavyList; out.heavyCount = b->dHeavyCount; out.heavyIndex = b->dHeavyIndex;
+        nHeavy = 0; nCount = (uint32_t)nItems;
         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
         if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
         {
@@ -415,12 +447,40 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             hipError_t le = (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
             if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
             if (in.heavyLimit != 0xFFFFFFFFu) {
-                // second pass: the listed reads taken apart into (read, item) units (the kernel reads their number from device memory: no host round trip)
-                SearchIn in2 = in;
-                in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu;
-                HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-                le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, b->stream);
-                if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
+                // second pass: the listed reads taken apart into units.  Their number sizes the count / offset arrays: one host round trip (the first
+                // pass is short: it drops a heavy read after a few hundred candidates)
+                HIPCHK(hipMemcpyAsync(&nHeavy, b->dHeavyCount, 4, hipMemcpyDeviceToHost, b->stream));
+                HIPCHK(hipStreamSynchronize(b->stream));
+                if (nHeavy) {
+                    uint32_t U = unitsPerItem;
+                    const uint64_t groups = (uint64_t)nCases * 2u;
+                    if (nItems + (uint64_t)nHeavy * groups * U >= 0x7FFFFF00ull) U = 1;          // (unit indices share a word with a flag bit)
+                    if (nItems + (uint64_t)nHeavy * groups * U >= 0x7FFFFF00ull) return fail(S3_EOVERFLOW, "too many heavy reads in one batch: use smaller batches");
+                    const size_t need = nItems + (size_t)nHeavy * groups * U + 1;
+                    if (need > b->countCap) {
+                        size_t cap = b->countCap;
+                        while (cap < need) cap += cap / 2 + 1;
+                        int rc;
+                        if ((rc = bgrow(b, &b->dItemCounts, cap, nItems)) || (rc = bgrow(b, &b->dItemOffsets, cap, 0))) return rc;
+                        b->countCap = cap;
+                        size_t t1 = 0, t3 = 0;
+                        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, b->dItemCounts, b->dItemOffsets, (int)cap, b->stream);
+                        hipcub::TransformInputIterator<unsigned long long, U32ToU64, const uint32_t *> it(b->dItemCounts, U32ToU64());
+                        (void)hipcub::DeviceReduce::Sum(nullptr, t3, it, b->dSum64, (int)cap, b->stream);
+                        if (t3 > t1) t1 = t3;
+                        if (t1 + 256 > b->tempBytes) { if ((rc = bgrow(b, &b->dTemp, t1 + 256, 0))) return rc; b->tempBytes = t1 + 256; }
+                        out.itemCounts = b->dItemCounts;
+                    }
+                    nCount = (uint32_t)(need - 1);
+                    HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, (need - nItems) * 4, b->stream));
+                    SearchIn in2 = in;
+                    in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu;
+                    in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
+                    in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (check-and-extend and the scatter decode unit indices with them)
+                    HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
+                    le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, b->stream);
+                    if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
+                }
             }
             // the task records end where the stepping kernel stopped writing; the check-and-extend kernel appends behind them
             HIPCHK(hipMemcpyAsync(b->dTaskEnd, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
@@ -430,17 +490,17 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2 + 1], b->stream));
         }
         // offsets of the items in the ordered array (the scan runs before the host looks at the flags: one synchronisation per pass for both answers)
-        HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, 4, b->stream));
+        HIPCHK(hipMemsetAsync(b->dItemCounts + nCount, 0, 4, b->stream));
         {
             size_t tb = b->tempBytes;
-            HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dItemCounts, b->dItemOffsets, (int)(nItems + 1), b->stream));
-            int rc = sum64Async(b, b->dItemCounts, (uint32_t)nItems);
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dItemCounts, b->dItemOffsets, (int)(nCount + 1), b->stream));
+            int rc = sum64Async(b, b->dItemCounts, nCount);
             if (rc) return rc;
         }
         // a record that did not fit was dropped but counted: the ordering below must not run on such a pass.  Grow and search again.
         uint32_t flags = 0;
         HIPCHK(hipMemcpyAsync(&flags, b->dFlags, 4, hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipMemcpyAsync(&slots, b->dItemOffsets + nItems, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipMemcpyAsync(&slots, b->dItemOffsets + nCount, 4, hipMemcpyDeviceToHost, b->stream));
         unsigned long long slots64 = 0;
         HIPCHK(hipMemcpyAsync(&slots64, b->dSum64, 8, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
@@ -469,11 +529,18 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             b->ordCap = (uint32_t)cap;
         }
     }
-    launchFillInvalid(b->dOrdered, b->dItemOffsets + nItems, b->ordCap, b->stream);
-    launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->dHeavyFlags, (uint32_t)nCases * 2u, b->stream);
+    launchFillInvalid(b->dOrdered, b->dItemOffsets + nCount, b->ordCap, b->stream);
+    launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->dHeavyFlags, b->dHeavyList, (uint32_t)nCases * 2u, in.unitBase, in.unitsPerItem,
+                  b->stream);
+    // what the merge / decode kernels need to find a read's slice of the ordered array (kept for the decode calls that follow this pass)
+    b->mergeUnitBase = in.unitBase; b->mergeUnitsPerRead = nHeavy ? (uint32_t)nCases * 2u * in.unitsPerItem : 0u;
+    // the long-read list of the merge kernels shares the buffer of the heavy list, which the scatter above still reads: a second list
+    
     MergeArgs m{};
     m.nActive = nActive; m.nCases = (uint32_t)nCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
+    m.longList = b->dLongList; m.longCount = b->dLongCount;
+    m.heavyFlags = b->mergeUnitsPerRead ? b->dHeavyFlags : nullptr; m.heavyIndex = b->dHeavyIndex; m.unitBase = b->mergeUnitBase; m.unitsPerRead = b->mergeUnitsPerRead;
     launchMergeCount(m, b->stream);
     b->lastNumCases = (uint32_t)nCases;
     if (b->counting) b->recordsTotal += slots;
@@ -512,6 +579,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     MergeArgs m{};
     m.nActive = b->n; m.nCases = b->lastNumCases; m.maxOut = maxOutputPerRead; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
+    m.heavyFlags = b->mergeUnitsPerRead ? b->dHeavyFlags : nullptr; m.heavyIndex = b->dHeavyIndex; m.unitBase = b->mergeUnitBase; m.unitsPerRead = b->mergeUnitsPerRead;
     launchMergeFill(m, b->dHitOffsets, b->dHits, b->stream);
     HIPCHK(hipEventRecord(b->evTotal[1], b->stream));
     b->lastKind = 1;

@@ -59,6 +59,9 @@ struct SearchIn {
     uint32_t        heavyLimit;  // first pass: a read that reserves more check-and-extend candidates than this is listed for the second pass
     const uint32_t *slotList;    // second pass (item mode: one work unit per item of a listed read): the listed slots ...
     const uint32_t *slotCount;   // ... and how many (device memory, written by the first pass)
+    uint32_t        unitsPerItem;  // second pass: first-mismatch positions an item is cut into, + 1 for "none" (1: whole items)
+    uint32_t        unitBase;      // second pass: unit u counts its records in itemCounts[unitBase + u]
+    uint32_t        sStarPacked;   // 3 bits per case: the first step that allows a mismatch (= nSteps: none)
     uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_v2.hip)
 };
 
@@ -76,6 +79,7 @@ struct SearchOut {
     unsigned long long *workHead;   // v2 kernel: head of the item queue (zeroed before every launch)
     uint8_t            *heavyFlags; // per slot: listed for the second pass (zeroed before every first pass)
     uint32_t           *heavyList, *heavyCount;
+    uint32_t           *heavyIndex; // per listed slot: its place in heavyList
 };
 
 struct DevHit { uint32_t a, b, meta; };       // binary-identical to s3_hit (kind, strand, nmis, cas bytes)
@@ -87,7 +91,16 @@ struct MergeArgs {
     uint32_t       *keptRecs, *occCounts, *ceCounts, *totalOcc, *withError;
     const uint8_t  *decodeMask;   // optional per-slot state; only slots with state == decodeWant are decoded
     uint8_t         decodeWant;
+    // reads whose slice of the ordered array is longer than S3_MERGE_LONG entries (repeat families: mostly holes of rejected candidates) are listed by
+    // mergeCountKernel and walked by a whole wave each (mergeCountLongKernel / decodeLongKernel) instead of one lane
+    uint32_t       *longList, *longCount;
+    // reads the second search pass took apart count their records per unit: their slice of the ordered array starts at
+    // itemOffsets[unitBase + heavyIndex[slot] * unitsPerRead] and is unitsPerRead offsets long
+    const uint8_t  *heavyFlags;
+    const uint32_t *heavyIndex;
+    uint32_t        unitBase, unitsPerRead;
 };
+#define S3_MERGE_LONG 256u
 
 // semi-global DP (s3dp_dp.hip)
 struct DpArgs {
@@ -112,7 +125,7 @@ void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &
 int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int
 void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s);
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,
-                   uint32_t groups, hipStream_t s);
+                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, hipStream_t s);
 void launchMergeCount(const MergeArgs &a, hipStream_t s);
 void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s);
 void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOffsets, uint32_t occBase, uint32_t occCap, uint32_t *occPos,

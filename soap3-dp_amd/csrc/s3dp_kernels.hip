@@ -69,18 +69,31 @@ __device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t c) { return c 
 // ordering: records -> CSR by item (counting scatter; offsets = exclusive scan of itemCounts)
 // ---------------------------------------------------------------------------------------------
 __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered,
-                              const uint8_t *heavyFlags, uint32_t groups)
+                              const uint8_t *heavyFlags, const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem)
 {
     uint32_t n = *recCount;
     if (n > recCap) n = recCap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint4 r = recs[i];
         if (r.x == 0xFFFFFFFFu || (r.y & S3_REC_TASK)) continue;            // unused slot of a reserved block / check-and-extend task (v2 kernel)
-        // a read listed for the second pass keeps only what that pass (and check-and-extend of its tasks) wrote
-        if (r.x & S3_REC_PASS2) r.x &= ~S3_REC_PASS2;
-        else if (heavyFlags[r.x / groups]) continue;
-        ordered[itemOffsets[r.x] + (r.y & 0xFFFFFFu)] = r;
+        uint32_t at = r.x;
+        if (r.x & S3_REC_PASS2) {
+            // written by the second search pass (or by check-and-extend of its tasks): counted per unit; downstream the record carries its ITEM again
+            at = r.x & ~S3_REC_PASS2;
+            const uint32_t unit = at - unitBase;
+            r.x = heavyList[unit / (groups * unitsPerItem)] * groups + (unit / unitsPerItem) % groups;
+        } else if (heavyFlags[r.x / groups]) continue;                         // stale: the second pass searched this read again
+        ordered[itemOffsets[at] + (r.y & 0xFFFFFFu)] = r;
     }
+}
+
+// the read's slice [beg, end) of the ordered array: its items' offsets, or -- for a read the second search pass took apart -- its units' offsets
+__device__ __forceinline__ void readSlice(const MergeArgs &a, uint32_t slot, uint32_t groups, uint32_t &beg, uint32_t &end)
+{
+    if (a.heavyFlags && a.heavyFlags[slot]) {
+        const uint32_t u0 = a.unitBase + a.heavyIndex[slot] * a.unitsPerRead;
+        beg = a.itemOffsets[u0]; end = a.itemOffsets[u0 + a.unitsPerRead];
+    } else { beg = a.itemOffsets[slot * groups]; end = a.itemOffsets[slot * groups + groups]; }
 }
 
 // Per read: walk the items in the CPU path's order (case 0 '+', case 0 '-', case 1 '+', ...), apply the
@@ -91,8 +104,9 @@ __global__ void mergeCountKernel(MergeArgs a)
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= a.nActive) return;
     const uint32_t groups = a.nCases * 2u;
-    const uint32_t first = slot * groups;
-    const uint32_t beg = a.itemOffsets[first], end = a.itemOffsets[first + groups];
+    uint32_t beg, end;
+    readSlice(a, slot, groups, beg, end);
+    if (a.longList && end - beg > S3_MERGE_LONG) { a.longList[atomicAdd(a.longCount, 1u)] = slot; return; }   // a wave's job (mergeCountLongKernel)
     uint32_t total = 0, nRec = 0, nOcc = 0, nCe = 0;
     uint32_t we[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = beg; i < end && total < a.maxOut; i++) {
@@ -110,13 +124,70 @@ __global__ void mergeCountKernel(MergeArgs a)
     for (int k = 0; k < 8; k++) a.withError[(size_t)slot * 8 + k] = we[k];
 }
 
+__device__ __forceinline__ uint32_t waveExclusiveSum(uint32_t v, uint32_t lane, uint32_t &total)
+{
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, (int)d);
+        if (lane >= d) inc += t;
+    }
+    total = (uint32_t)__shfl((int)inc, 63);
+    return inc - v;
+}
+
+// mergeCountKernel for the listed (long) reads: one wave per read, 64 entries of its slice per step -- the holes of rejected check-and-extend
+// candidates (nine in ten entries of a read inside a repeat family) cost a coalesced load instead of a turn of a serial loop
+__global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nLong = *a.longCount, groups = a.nCases * 2u;
+    for (uint32_t idx = waveId; idx < nLong; idx += nWaves) {
+        const uint32_t slot = a.longList[idx];
+        uint32_t beg, end;
+        readSlice(a, slot, groups, beg, end);
+        uint32_t total = 0, nRec = 0, nOcc = 0, nCe = 0;                      // nRec / nOcc / nCe / we: per-lane partial sums
+        uint32_t we[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t base = beg; base < end && total < a.maxOut; base += 64u) {
+            const uint32_t i = base + lane;
+            uint4 r = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+            if (i < end) r = a.ordered[i];
+            const bool valid = r.x != 0xFFFFFFFFu;
+            const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
+            // a range is never longer than maxOut can use: clamp before the prefix sum (32-bit)
+            uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;
+            if (cnt > a.maxOut) cnt = a.maxOut;
+            uint32_t sum = 0;
+            const uint32_t pre = waveExclusiveSum(cnt, lane, sum);
+            const bool incl = valid && total + pre < a.maxOut;
+            uint32_t c = 0;
+            if (incl) { c = cnt; if (total + pre + c > a.maxOut) c = a.maxOut - total - pre; }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) we[k] += nmis == k ? c : 0u;
+            nRec += incl ? 1u : 0u; nOcc += c; nCe += incl ? kind : 0u;
+            total = total + sum > a.maxOut ? a.maxOut : total + sum;
+        }
+        uint32_t dummy = 0;
+        (void)waveExclusiveSum(nRec, lane, nRec); (void)waveExclusiveSum(nOcc, lane, nOcc); (void)waveExclusiveSum(nCe, lane, nCe);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) (void)waveExclusiveSum(we[k], lane, we[k]);
+        (void)dummy;
+        if (lane == 0) {
+            a.keptRecs[slot] = nRec; a.occCounts[slot] = nOcc; a.ceCounts[slot] = nCe; a.totalOcc[slot] = total;
+            for (int k = 0; k < 8; k++) a.withError[(size_t)slot * 8 + k] = we[k];
+        }
+    }
+}
+
 // final per-read record list in the hit format of the C-ABI (kept records only, last range truncated)
 __global__ void mergeFillKernel(MergeArgs a, const uint32_t *hitOffsets, DevHit *hits)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= a.nActive) return;
     const uint32_t groups = a.nCases * 2u;
-    const uint32_t beg = a.itemOffsets[slot * groups];
+    uint32_t beg, endUnused;
+    readSlice(a, slot, groups, beg, endUnused);
     const uint32_t n = a.keptRecs[slot];
     uint32_t total = 0;
     DevHit *dst = hits + hitOffsets[slot];
@@ -145,7 +216,9 @@ __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffset
     if (slot >= a.nActive) return;
     if (a.decodeMask && a.decodeMask[slot] != a.decodeWant) return;
     const uint32_t groups = a.nCases * 2u;
-    const uint32_t beg = a.itemOffsets[slot * groups];
+    uint32_t beg, end;
+    readSlice(a, slot, groups, beg, end);
+    if (a.longList && end - beg > S3_MERGE_LONG) return;                   // decodeLongKernel's
     const uint32_t n = a.keptRecs[slot];
     uint32_t o = occBase + occOffsets[slot], oSa = o + a.ceCounts[slot];
     if ((uint64_t)occBase + occOffsets[slot + 1] > occCap) { atomicOr(flags, S3_FLAG_OCC_OVERFLOW); return; }
@@ -163,6 +236,50 @@ __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffset
             if (total + cnt > a.maxOut) cnt = a.maxOut - total;
             for (uint32_t q = 0; q < cnt; q++) { occPos[oSa] = ix.sa[r.z + q]; occMeta[oSa] = meta | 0x10000u; oSa++; }   // bit 16: came out of an SA range
             total += cnt;
+        }
+    }
+}
+
+// decodeKernel for the listed (long) reads: one wave per read (see mergeCountLongKernel); the lanes place their entries with prefix sums, the
+// occurrences of an SA range are expanded by the lane that holds it
+__global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffsets, uint32_t occBase, uint32_t occCap, uint32_t *occPos,
+                                                        uint32_t *occMeta, uint32_t *flags)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nLong = *a.longCount, groups = a.nCases * 2u;
+    for (uint32_t idx = waveId; idx < nLong; idx += nWaves) {
+        const uint32_t slot = a.longList[idx];
+        if (a.decodeMask && a.decodeMask[slot] != a.decodeWant) continue;
+        uint32_t beg, end;
+        readSlice(a, slot, groups, beg, end);
+        if ((uint64_t)occBase + occOffsets[slot + 1] > occCap) { if (lane == 0) atomicOr(flags, S3_FLAG_OCC_OVERFLOW); continue; }
+        uint32_t o = occBase + occOffsets[slot], oSa = o + a.ceCounts[slot];  // wave-uniform cursors: check-and-extend hits / expanded SA ranges
+        uint32_t total = 0;
+        for (uint32_t base = beg; base < end && total < a.maxOut; base += 64u) {
+            const uint32_t i = base + lane;
+            uint4 r = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+            if (i < end) r = a.ordered[i];
+            const bool valid = r.x != 0xFFFFFFFFu;
+            const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
+            uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;
+            if (cnt > a.maxOut) cnt = a.maxOut;
+            uint32_t sum = 0;
+            const uint32_t pre = waveExclusiveSum(cnt, lane, sum);
+            const bool incl = valid && total + pre < a.maxOut;
+            uint32_t c = 0;
+            if (incl) { c = cnt; if (total + pre + c > a.maxOut) c = a.maxOut - total - pre; }
+            uint32_t nKind = 0, nSa = 0;
+            const uint32_t preKind = waveExclusiveSum(incl && kind ? 1u : 0u, lane, nKind);
+            const uint32_t preSa = waveExclusiveSum(incl && !kind ? c : 0u, lane, nSa);
+            if (incl) {
+                const uint32_t strand = ((r.x % groups) & 1u) + 1u;
+                const uint32_t meta = strand | nmis << 8;
+                if (kind) { occPos[o + preKind] = r.z; occMeta[o + preKind] = meta; }
+                else for (uint32_t q = 0; q < c; q++) { occPos[oSa + preSa + q] = ix.sa[r.z + q]; occMeta[oSa + preSa + q] = meta | 0x10000u; }
+            }
+            o += nKind; oSa += nSa;
+            total = total + sum > a.maxOut ? a.maxOut : total + sum;
         }
     }
 }
@@ -365,15 +482,17 @@ void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipS
 }
 
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,
-                   uint32_t groups, hipStream_t s)
+                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, hipStream_t s)
 {
-    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, heavyFlags, groups);
+    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, heavyFlags, heavyList, groups, unitBase, unitsPerItem);
 }
 
 void launchMergeCount(const MergeArgs &a, hipStream_t s)
 {
     if (!a.nActive) return;
+    if (a.longList) (void)hipMemsetAsync(a.longCount, 0, 4, s);
     hipLaunchKernelGGL(mergeCountKernel, dim3((a.nActive + 127) / 128), dim3(128), 0, s, a);
+    if (a.longList) hipLaunchKernelGGL(mergeCountLongKernel, dim3(2048), dim3(256), 0, s, a);
 }
 
 void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s)
@@ -387,6 +506,7 @@ void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOff
 {
     if (!a.nActive) return;
     hipLaunchKernelGGL(decodeKernel, dim3((a.nActive + 127) / 128), dim3(128), 0, s, a, ix, occOffsets, occBase, occCap, occPos, occMeta, flags);
+    if (a.longList) hipLaunchKernelGGL(decodeLongKernel, dim3(2048), dim3(256), 0, s, a, ix, occOffsets, occBase, occCap, occPos, occMeta, flags);
 }
 
 void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *withError, uint32_t mm, uint32_t allowSpecial, uint8_t *state,

@@ -168,6 +168,8 @@ int s3i::decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive,
     m.nActive = nActive; m.nCases = b->lastNumCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     m.decodeMask = b->dState; m.decodeWant = want;
+    m.longList = b->dLongList; m.longCount = b->dLongCount;                // the list mergeCountKernel of this search pass wrote
+    m.heavyFlags = b->mergeUnitsPerRead ? b->dHeavyFlags : nullptr; m.heavyIndex = b->dHeavyIndex; m.unitBase = b->mergeUnitBase; m.unitsPerRead = b->mergeUnitsPerRead;
     launchDecode(m, b->ix->d, b->dOccOffsets, base, b->occCap, b->dOccPos, b->dOccMeta, b->dFlags, b->stream);
     if (lg.on) {
         ValidateArgs v{};

@@ -19,7 +19,11 @@
 //   * a lane walks the (case, strand) items of its read one after the other -- fine for a read with a handful of candidates, a disaster for a read
 //     inside a repeat family with 10^5 copies, whose 4-mismatch neighbourhood is 10^5 rank queries long: a few such lanes run for a second while
 //     the chip idles.  So a read that reserves more candidates than in.heavyLimit leaves the first pass at once ("heavy" read, listed), and a
-//     second launch of the same kernel takes the listed reads apart: its work unit is ONE (read, case, strand) item, twenty lanes per read.
+//     second launch of the same kernel takes the listed reads apart: its work unit is a slice of ONE (read, case, strand) item -- the part of the
+//     item's search tree whose FIRST mismatch sits at one given position of the first step that allows mismatches (or that has none there).  The
+//     depth-first order of the CPU path visits exactly these subtrees one after the other (at every position: the mismatch children first,
+//     ascending, then the continuation), so the units of an item, numbered by position, ARE its sequence order: each unit counts its records
+//     from zero and the counting scatter puts them behind each other -- a thousand lanes per heavy read, no sort.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -102,7 +106,11 @@ using namespace v2;
 // bound by its instruction count.  The record stream keeps the CPU path's order because accepted candidates are written under the reserved
 // numbers; rejected ones leave holes the ordering pass skips.  Not counting the candidates in `total` only delays the early stop at
 // MaxOutputPerRead: the per-read cut is applied again, exactly, when the records are merged.
-// in.slotList != NULL: item mode (second pass) -- the work queue holds (listed read, item) units instead of reads.
+// in.slotList != NULL: unit mode (second pass) -- the work queue holds (listed read, item, first-mismatch position) units instead of reads.
+// A unit walks the trunk of its item (lookup step, exact steps, the mismatch step up to its position p without branching), branches at p into the
+// mismatch children only, and from there on is an ordinary depth-first search; the last unit of an item (p = unitsPerItem - 1) is the one that
+// takes no mismatch in that step at all.  What happens ON the trunk (a range handed to check-and-extend, a dead range) concerns every unit of the
+// item alike: the hand-over is written by the unit that owns the place (position i of the mismatch step: unit i; before that step: unit 0).
 template <bool UNIFORM>
 __global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_V2_WAVES_PER_SIMD)
 searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
@@ -123,7 +131,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         __syncthreads();
     }
 
-    const unsigned long long nSlots = in.slotList ? (unsigned long long)*in.slotCount * ((uint32_t)in.nCases * 2u) : in.nActive;   // item mode: listed reads x items
+    const unsigned long long nSlots = in.slotList ? (unsigned long long)*in.slotCount * ((uint32_t)in.nCases * 2u) * in.unitsPerItem : in.nActive;   // unit mode: listed reads x items x positions
     const uint32_t nCases = (uint32_t)in.nCases;
     const uint32_t groups = nCases * 2u;
     uint32_t nRank = 0, nLt = 0;
@@ -135,11 +143,22 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     uint32_t readTotal = 0;                                                 // occurrences the read's finished items have for sure (the cut at maxOut runs across items)
     uint32_t readCand = 0;                                                  // check-and-extend candidates this read has reserved
     bool goHeavy = false;
-    uint32_t strand = 0;
     int Li = 0, nSteps = 0;
     uint32_t casIdx = 0;
     Range g = {0, 0, 0, 0};
     int s = 0, i = 0, ins = 0, occ = 0;
+    // unit mode
+    const uint32_t U = in.slotList ? in.unitsPerItem : 1u;
+    bool trunk = false;                                                     // the lane is still on the part of the item that all its units share
+    uint32_t unitP = 0xFFFFFFFFu;                                           // position of the unit's first mismatch; 0xFFFFFFFF: none in the mismatch step
+    int sStar = 0;                                                          // the first step of the case that allows a mismatch (nSteps: none)
+    auto trunkOwner = [&]() -> bool {                                       // may THIS unit write what happens at the lane's place on the trunk?
+        if (!trunk) return true;
+        if (s < sStar) return unitP == 0u || (U == 1u);
+        if (s == sStar) return unitP == (uint32_t)i;
+        return true;
+    };
+    uint32_t strand = 0;
     Frame stack[STACK];
     int sp = 0;
     uint32_t ltA = 0, ltB = 0, ltC = 0, ltD = 0;                            // lookup-table keys of the starting item
@@ -184,6 +203,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             if (s >= nSteps) {                                               // SRA_STEP_TYPE_COMPLETE
                 uint32_t l = g.fl, rr_ = g.fr;
+                if (trunk && unitP != 0xFFFFFFFFu) { state = ST_DONE; return; }   // the whole trunk without a mismatch: the last unit's
                 if (rr_ >= l) {
                     if (pendMeta >> 31) { state = ST_RESUME; return; }       // one record per lane and trip: this frame waits for the next trip
                     if (readTotal + total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - readTotal - total - 1u;
@@ -201,6 +221,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (i < lenEff && alive) {
                 const int pos = st.start + st.dir * i;
                 if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
+                    if (!trunkOwner()) { state = ST_DONE; return; }          // another unit of the item writes this hand-over
                     if (pendMeta >> 31) { state = ST_RESUME; return; }       // one record per lane and trip
                     pendMeta = 0x80000000u | seq | S3_REC_TASK;
                     pendA = g.fl;
@@ -222,6 +243,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         const uint32_t lim = in.earlyCe < (uint32_t)nx.ceThr ? in.earlyCe : (uint32_t)nx.ceThr;     // nx.ceThr >= 0 for every step
                         const int nxLenEff = nx.minErr > 1 ? nx.len - (nx.minErr - 1) : nx.len;                    // the next step must have a first position to stand on
                         if ((g.fr - g.fl) < lim && nxLenEff > 0 && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
+                            if (!trunkOwner()) { state = ST_DONE; return; }
                             if (pendMeta >> 31) { state = ST_RESUME; return; }
                             pendMeta = 0x80000000u | seq | S3_REC_TASK | S3_REC_EARLY;
                             pendA = g.fl;
@@ -237,7 +259,14 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 state = ST_STEP;
                 return;
             }
-            if (ins >= st.minErr && alive) { occ += ins; ins = 0; s++; i = 0; continue; }
+            if (ins >= st.minErr && alive) {
+                if (trunk && s == sStar) {
+                    if (unitP != 0xFFFFFFFFu) { state = ST_DONE; return; }   // past the last position of the mismatch step: the last unit goes on alone
+                    trunk = false;
+                }
+                occ += ins; ins = 0; s++; i = 0;
+                continue;
+            }
             needPop = true;
         }
     };
@@ -250,7 +279,11 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (goHeavy) {
                 // this read goes to the second pass: whatever it wrote so far is ignored there (scatter / check-and-extend test the flag)
                 out.heavyFlags[slotIdx] = 1;
-                out.heavyList[atomicAdd(out.heavyCount, 1u)] = slotIdx;
+                {
+                    const uint32_t at = atomicAdd(out.heavyCount, 1u);
+                    out.heavyList[at] = slotIdx;
+                    out.heavyIndex[slotIdx] = at;
+                }
                 pendMeta = 0;
                 goHeavy = false;
                 sub = groups;
@@ -258,7 +291,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 out.itemCounts[cntIdx] = seq;
                 readTotal += total;
                 sub++;
-                if (in.slotList) sub = groups;                              // item mode: the unit was this one item
+                if (in.slotList) sub = groups;                              // unit mode: one unit per turn
                 else if (readTotal >= in.maxOut) {
                     // the per-read cut (mergeCountKernel) ends inside this item or before: what follows can never be kept
                     for (; sub < groups; sub++) out.itemCounts[slotIdx * groups + sub] = 0;
@@ -267,6 +300,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (sub < groups) {
                 casIdx = sub >> 1; strand = sub & 1u;
                 nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
+                sStar = (int)((in.sStarPacked >> (3u * casIdx)) & 7u);
                 cntIdx = slotIdx * groups + sub;
                 seq = 0; total = 0; sp = 0;
                 state = ST_KEYS;
@@ -282,8 +316,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 else {
                     chunkCur = chunkBase = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots;
                     if (in.slotList) {
-                        sl0 = b + lane < nSlots ? in.slotList[(b + lane) / groups] : 0u;
-                        sl1 = b + 64u + lane < nSlots ? in.slotList[(b + 64u + lane) / groups] : 0u;
+                        sl0 = b + lane < nSlots ? in.slotList[(b + lane) / (groups * U)] : 0u;
+                        sl1 = b + 64u + lane < nSlots ? in.slotList[(b + 64u + lane) / (groups * U)] : 0u;
                         if (in.active) { act0 = in.active[sl0]; act1 = in.active[sl1]; }
                     } else if (in.active) {
                         act0 = b + lane < nSlots ? in.active[b + lane] : 0u;
@@ -303,13 +337,24 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 if (state == ST_DONE && rank < avail) {
                     slotIdx = (uint32_t)(chunkCur + rank);
                     sub = 0;
-                    if (in.slotList) { sub = slotIdx % groups; slotIdx = off < 64u ? s0 : s1; }
+                    cntIdx = slotIdx * groups;
+                    trunk = false; unitP = 0xFFFFFFFFu;
+                    if (in.slotList) {
+                        const uint32_t unit = slotIdx;                     // = heavy read * groups * U + item * U + p
+                        cntIdx = in.unitBase + unit;
+                        sub = (unit / U) % groups;
+                        const uint32_t p = unit % U;
+                        unitP = p + 1u == U ? 0xFFFFFFFFu : p;
+                        trunk = U > 1u;
+                        slotIdx = off < 64u ? s0 : s1;
+                    }
                     rIdx = in.active ? (off < 64u ? a0 : a1) : slotIdx;
                     readTotal = 0; readCand = 0;
                     if constexpr (UNIFORM) Li = (int)in.uniformLen;
                     casIdx = sub >> 1; strand = sub & 1u;
                     nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
-                    cntIdx = slotIdx * groups + sub;
+                    sStar = (int)((in.sStarPacked >> (3u * casIdx)) & 7u);
+                    if (!in.slotList) cntIdx += sub;
                     seq = 0; total = 0; sp = 0; loadOff = 0;
                     hasItem = true;
                     state = ST_LOAD;
@@ -319,6 +364,16 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         }
 
         // ---------- lookup-table keys of a starting item (BWTExactModel{Backward,Forward}_Lookup2, BGS-HostAlgnmtAlgo2.cpp:311-347) ----------
+        if (state == ST_KEYS && trunk && unitP != 0xFFFFFFFFu) {
+            // a unit whose position lies behind the last one of this case's mismatch step (the cases differ in length) has nothing to do
+            bool empty = sStar >= nSteps;
+            if (!empty) {
+                const S3Step ss = stepAt(sStar);
+                const int lenEff = ss.minErr > 1 ? ss.len - (ss.minErr - 1) : ss.len;
+                empty = (int)unitP >= lenEff;
+            }
+            if (empty) state = ST_DONE;
+        }
         if (state == ST_KEYS) {
             const S3Step st = stepAt(0);
             const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;            // <= 13 characters = 26 bits of one window
@@ -454,16 +509,21 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const Range gc = child((ch == 0 ? oL.x : ch == 1 ? oL.y : ch == 2 ? oL.z : oL.w) + 1u, ch == 0 ? oR.x : ch == 1 ? oR.y : ch == 2 ? oR.z : oR.w,
                                    ch == 0 ? d1 + d2 + d3 : ch == 1 ? d2 + d3 : ch == 2 ? d3 : 0u);
             doSettle = true;
-            if (!exact) {
+            const bool onTrunkHere = trunk && s == sStar;                      // unit mode: before the unit's own position only the continuation is taken
+            const bool branchOnly = onTrunkHere && (uint32_t)i == unitP;        // at it: only the mismatch children
+            if (branchOnly) trunk = false;
+            if (!exact && !(onTrunkHere && !branchOnly)) {
                 const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
                 const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
-                if (a0 || a1 || a2 || a3) {
+                if (branchOnly && !(a0 || a1 || a2 || a3)) { needPop = true; }   // no child alive: the unit is empty (sp == 0: the pop ends it)
+                else if (a0 || a1 || a2 || a3) {
                     if (sp + 4 > STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = ST_DONE; sp = 0; doSettle = false; }
                     else {
                         const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
                         const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
                         Frame f;
-                        f.fl = gc.fl; f.fr = gc.fr; f.rl = gc.rl; f.meta = mCont; stack[sp++] = f;
+                        f.fl = gc.fl; f.fr = gc.fr; f.rl = gc.rl; f.meta = mCont;
+                        if (!branchOnly) stack[sp++] = f;                    // (the continuation past the unit's position belongs to the later units)
                         f.meta = mKid;
                         if (a3) { const Range k = child(oL.w + 1u, oR.w, 0u); f.fl = k.fl; f.fr = k.fr; f.rl = k.rl; stack[sp++] = f; }
                         if (a2) { const Range k = child(oL.z + 1u, oR.z, d3); f.fl = k.fl; f.fr = k.fr; f.rl = k.rl; stack[sp++] = f; }
@@ -557,8 +617,14 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         uint4 rec = make_uint4(0xFFFFFFFFu, 0, 0, 0);
         if (idx < nRec) rec = out.recs[idx];
         bool task = rec.x != 0xFFFFFFFFu && (rec.y & S3_REC_TASK);
-        const uint32_t item = rec.x & ~S3_REC_PASS2;
-        if (task && !(rec.x & S3_REC_PASS2) && out.heavyFlags[item / groups]) task = false;     // stale: the second pass searched this read again
+        uint32_t item = rec.x & ~S3_REC_PASS2;
+        uint32_t slotOf = item / groups;
+        if (task && (rec.x & S3_REC_PASS2)) {
+            // second-pass records count in unit space: unit = heavy read * groups * U + item * U + position
+            const uint32_t unit = item - in.unitBase, U = in.unitsPerItem;
+            slotOf = out.heavyList[unit / (groups * U)];
+            item = slotOf * groups + (unit / U) % groups;
+        } else if (task && out.heavyFlags[slotOf]) task = false;                 // stale: the second pass searched this read again
         const bool early = task && (rec.y & S3_REC_EARLY);
         uint32_t size = 0, rIdx = 0, casIdx = 0, strand = 0;
         int Li = 0, nSteps = 0, s0 = 0, i0 = 0, ins0 = 0, occ0 = 0;
@@ -566,7 +632,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
             size = (rec.w & 0xFFu) + 1u;
             const uint32_t meta = rec.w >> 8;
             s0 = (int)(meta & 7u); i0 = (int)((meta >> 3) & 0x7FFu); ins0 = (int)((meta >> 14) & 7u); occ0 = (int)((meta >> 17) & 7u);
-            const uint32_t slot = item / groups, sub = item % groups;
+            const uint32_t slot = slotOf, sub = item % groups;
             casIdx = sub >> 1; strand = sub & 1u;
             rIdx = in.active ? in.active[slot] : slot;
             Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
@@ -663,7 +729,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
 int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
 {
     if (in.nActive == 0) return (int)hipSuccess;
-    uint64_t blocks = ((uint64_t)in.nActive * (in.slotList ? (uint64_t)in.nCases * 2u : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    uint64_t blocks = ((uint64_t)in.nActive * (in.slotList ? (uint64_t)in.nCases * 2u * in.unitsPerItem : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wLds * 256u);
     if (lds > 48u * 1024u) {
