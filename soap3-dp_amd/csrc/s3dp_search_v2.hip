@@ -347,6 +347,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         unitP = p + 1u == U ? 0xFFFFFFFFu : p;
                         trunk = U > 1u;
                         slotIdx = off < 64u ? s0 : s1;
+                        // the listed read counts per unit now: what the first pass left in its items' own counters (or never wrote) is void
+                        if (p == 0u) out.itemCounts[slotIdx * groups + sub] = 0;
                     }
                     rIdx = in.active ? (off < 64u ? a0 : a1) : slotIdx;
                     readTotal = 0; readCand = 0;
