@@ -49,11 +49,15 @@ typedef struct {
 typedef struct {
     s3_bwt_desc     fwd, rev;
     uint32_t        textLength;
-    const uint32_t *sa;                /* full suffix array (SaValueFreq=1), textLength+1 entries (.sa payload after 6 words) */
+    const uint32_t *sa;                /* suffix array, .sa payload after 6 words: textLength+1 entries, or every saInterval-th (see saInterval) */
     const uint32_t *packedDNA;         /* text, 16 chars/word MSB first as HSPLoad holds it (TextConverter.c:666-720) */
     size_t          packedWords;
     const uint32_t *lkt, *revLkt;      /* 13-mer cumulative lookup tables (.lkt/.rev.lkt payload after 1 word) */
     int             lktSize;           /* LOOKUP_SIZE = 13 (2bwt-flex/LT.h:49) */
+    uint32_t        saInterval;        /* SaValueFreq of the .sa file (its header word 5): 0 or 1 = `sa` is the full array; k > 1 = `sa` holds
+                                          SA[0], SA[k], SA[2k], ... ((textLength + k) / k entries, 2bwt-lib/BWT.c:254-255).  The device copy is always the
+                                          full array: a sampled one is expanded at upload by the reference's own rule (BWTSaValue, BWT.c:1694-1724: walk
+                                          backwards through the BWT to the next sampled index, add the steps) -- 12 GB of HBM buy one access per hit */
 } s3_index_desc;
 
 /* replaces GPUINDEXUpload (alignment.cu:27-107).  The device copy is re-laid out (one 64-byte line per

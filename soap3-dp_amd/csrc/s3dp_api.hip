@@ -111,12 +111,27 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     const size_t pacWords = desc->packedWords + 4;                     // + zero tail so 3-word windows never leave the buffer
     if ((rc = devAlloc(ix, &sa, (size_t)n + 1)) || (rc = devAlloc(ix, &pac, pacWords)) || (rc = devAlloc(ix, &lkt, ltWords)) ||
         (rc = devAlloc(ix, &rlkt, ltWords))) { s3_index_free(ix); return rc; }
+    const uint32_t saInterval = desc->saInterval > 1 ? desc->saInterval : 1;
+    uint32_t *saSamples = nullptr;
     {
         // the suffix array in pieces: as one 12 GB copy from pageable memory it takes the runtime's staging path (3.4 GB/s measured); pieces of this size
         // are copied in place at PCIe speed.  Upload of a 3.1 Gbp index: 6.1 -> 3.9 s (S3DP_VERBOSE=1 prints the laps; S3DP_H2D_PIECE_MB to change)
-        const size_t total = ((size_t)n + 1) * 4, pieceMb = envSize("S3DP_H2D_PIECE_MB", 128), piece = pieceMb ? pieceMb << 20 : total;
+        const size_t entries = saInterval > 1 ? ((size_t)n + saInterval) / saInterval : (size_t)n + 1;
+        uint32_t *dst = sa;
+        if (saInterval > 1) {
+            HIPCHK(hipMalloc((void **)&saSamples, entries * 4));
+            dst = saSamples;
+        }
+        const size_t total = entries * 4, pieceMb = envSize("S3DP_H2D_PIECE_MB", 128), piece = pieceMb ? pieceMb << 20 : total;
         for (size_t off = 0; off < total; off += piece)
-            HIPCHK(hipMemcpyAsync((char *)sa + off, (const char *)desc->sa + off, total - off < piece ? total - off : piece, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync((char *)dst + off, (const char *)desc->sa + off, total - off < piece ? total - off : piece, hipMemcpyHostToDevice, s));
+        if (saInterval > 1) {
+            // a sampled array (SaValueFreq 2 / 4) is expanded here, once: every hit is then one access instead of a walk through the BWT
+            launchSaExpand(ix->d.fwd, saSamples, saInterval, n, sa, s);
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipGetLastError());
+            (void)hipFree(saSamples);
+        }
     }
     HIPCHK(hipMemsetAsync(pac, 0, pacWords * 4, s));
     HIPCHK(hipMemcpyAsync(pac, desc->packedDNA, desc->packedWords * 4, hipMemcpyHostToDevice, s));
@@ -204,8 +219,7 @@ int s3i::growRecords(s3_batch *b)
     if (cap > kMaxEntries) cap = kMaxEntries;
     int rc;
     if ((rc = bgrow(b, &b->dRecs, cap, 0))) return rc;
-    if (cap > b->ordCap) { if ((rc = bgrow(b, &b->dOrdered, cap, 0))) return rc; b->ordCap = (uint32_t)cap; }
-    if ((rc = bgrow(b, &b->dHits, cap, 0))) return rc;
+    if (b->dHits) { if ((rc = bgrow(b, &b->dHits, cap, 0))) return rc; }
     b->recCap = (uint32_t)cap;
     return S3_OK;
 }
@@ -261,7 +275,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     b->countCap = b->maxItems + 1;
     BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
     BA(dWithError, (size_t)maxReads * 8);
-    BA(dHitOffsets, (size_t)maxReads + 1); BA(dHits, recCap);
+    BA(dHitOffsets, (size_t)maxReads + 1);                                 // (dHits: on the first s3_batch_search -- the ladders never need it)
     BA(dActive[0], maxReads); BA(dActive[1], maxReads); BA(dNumSel, 4); BA(dIota, maxReads);
     BA(dState, maxReads); BA(dSelFlags, maxReads);
     BA(dOccOffsets, (size_t)maxReads + 1); BA(dMasked, (size_t)maxReads + 1);
@@ -520,8 +534,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     {
         // sequence numbers include the rejected check-and-extend candidates: the ordered array can need more slots than there are records
         if (slots > b->ordCap) {
-            size_t cap = b->ordCap;
-            while (cap < slots) cap *= 2;
+            size_t cap = (size_t)slots + slots / 8 + 65536;               // (not doubled: at 16 B per sequence number this is the batch's largest buffer)
             if (cap > kMaxEntries) cap = kMaxEntries;
             if (slots > cap) return fail(S3_EOVERFLOW, "ordering buffer overflow at the 32-bit limit");
             int rc = bgrow(b, &b->dOrdered, cap, 0);
@@ -580,6 +593,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     m.nActive = b->n; m.nCases = b->lastNumCases; m.maxOut = maxOutputPerRead; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     m.heavyFlags = b->mergeUnitsPerRead ? b->dHeavyFlags : nullptr; m.heavyIndex = b->dHeavyIndex; m.unitBase = b->mergeUnitBase; m.unitsPerRead = b->mergeUnitsPerRead;
+    if (!b->dHits) { int rc2 = balloc(b, &b->dHits, b->recCap); if (rc2) return rc2; }
     launchMergeFill(m, b->dHitOffsets, b->dHits, b->stream);
     HIPCHK(hipEventRecord(b->evTotal[1], b->stream));
     b->lastKind = 1;

@@ -127,8 +127,22 @@ template <class T>
 inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
 {
     void *q = nullptr;
+    if (!keep) {
+        // nothing to carry over: the old buffer goes first, so that the two never stand side by side (the ordering buffer of a batch of reads from
+        // repeat families is tens of gigabytes)
+        hipError_t e0 = hipStreamSynchronize(b->stream);
+        if (e0 == hipSuccess) e0 = hipFree(*p);
+        if (e0 != hipSuccess) return fail(S3_EHIP, std::string("grow (free): ") + hipGetErrorString(e0));
+        for (auto &a : b->allocs) if (a == (void *)*p) a = nullptr;
+        *p = nullptr;
+        e0 = hipMalloc(&q, newCount * sizeof(T));
+        if (e0 != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch grow, ") + std::to_string(newCount * sizeof(T) >> 20) + " MB): " + hipGetErrorString(e0));
+        b->allocs.push_back(q);
+        *p = (T *)q;
+        return S3_OK;
+    }
     hipError_t e = hipMalloc(&q, newCount * sizeof(T));
-    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch grow): ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch grow, ") + std::to_string(newCount * sizeof(T) >> 20) + " MB): " + hipGetErrorString(e));
     if (keep) {
         e = hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, b->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(b->stream);

@@ -65,6 +65,31 @@ __device__ __forceinline__ uint4 rankAll(const DevBwt &b, uint32_t i)
 
 __device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
 
+// Sampled suffix array -> full array (BWTSaValue, 2bwt-lib/BWT.c:1694-1724): from index i walk backwards through the BWT (BWTPsiMinusValue :1641:
+// the row of the previous text position, 0 from the row of the text's first character) until an index divisible by the sampling interval, and add
+// the steps to the value stored there.  SA[0] is stored as -1 (BWT.c:286), so the sums wrap the way the reference's do.
+__global__ void saExpandKernel(DevBwt b, const uint32_t *samples, uint32_t interval, uint32_t n, uint32_t *sa)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    uint32_t j = (uint32_t)i, steps = 0;
+    while (j % interval != 0u) {
+        if (j == b.inverseSa0) j = 0;
+        else {
+            // the character at BWT position j is the one whose count grows between j and j + 1; its new count + C[c] is the row
+            const uint4 lo = rankAll(b, j), hi = rankAll(b, j + 1u);
+            j = hi.x != lo.x ? hi.x : hi.y != lo.y ? hi.y : hi.z != lo.z ? hi.z : hi.w;
+        }
+        steps++;
+    }
+    sa[i] = samples[j / interval] + steps;
+}
+
+void launchSaExpand(const DevBwt &b, const uint32_t *samples, uint32_t interval, uint32_t n, uint32_t *sa, hipStream_t s)
+{
+    hipLaunchKernelGGL(saExpandKernel, dim3((unsigned)(((uint64_t)n + 1 + 255) / 256)), dim3(256), 0, s, b, samples, interval, n, sa);
+}
+
 // ---------------------------------------------------------------------------------------------
 // ordering: records -> CSR by item (counting scatter; offsets = exclusive scan of itemCounts)
 // ---------------------------------------------------------------------------------------------

@@ -77,9 +77,11 @@ bool loadIndex(const std::string &prefix, HostIndex &ix, std::string &err)
     for (int k = 1; k <= 4; k++) ix.rcum[k] = h1[k];
     std::vector<uint32_t> hs;
     if (!slurpWords(prefix + ".sa", 6, ix.sa, &hs, err)) return false;
-    if (hs[5] != 1) { err = "a full suffix array (SaValueFreq=1) is required"; return false; }
-    if (ix.sa.size() < (size_t)ix.n + 1) { err = ".sa too short"; return false; }
-    ix.sa.resize((size_t)ix.n + 1);
+    // SaValueFreq (README.md:55-65: 1 = full, 2 / 4 = sampled): the library expands a sampled array on the device at upload
+    ix.saInterval = hs[5] ? hs[5] : 1;
+    const size_t saEntries = ((size_t)ix.n + ix.saInterval) / ix.saInterval;       // BWT.c:255
+    if (ix.sa.size() < saEntries) { err = ".sa too short"; return false; }
+    ix.sa.resize(saEntries);
     ix.sa[0] = 0xFFFFFFFFu;                                            // BWT.c:286
     // packed text: bytes MSB first + trailing length byte -> words (TextConverter.c:666-720)
     {
@@ -163,7 +165,7 @@ s3_index_desc HostIndex::desc() const
     d.rev.bwt = rbwt.data(); d.rev.bwtWords = rbwt.size(); d.rev.occ = rocc.data(); d.rev.occRecs = rocc.size() / 4; d.rev.inverseSa0 = rInverseSa0;
     for (int k = 0; k < 5; k++) { d.fwd.cumFreq[k] = cum[k]; d.rev.cumFreq[k] = rcum[k]; }
     d.textLength = n;
-    d.sa = sa.data();
+    d.sa = sa.data(); d.saInterval = saInterval;
     d.packedDNA = pac.data(); d.packedWords = pac.size();
     d.lkt = lkt.data(); d.revLkt = rlkt.data(); d.lktSize = 13;
     return d;

@@ -20,6 +20,7 @@ struct HostIndex {
     std::vector<uint32_t> bwt, occ, rbwt, rocc, sa, pac, lkt, rlkt;
     uint32_t inverseSa0 = 0, rInverseSa0 = 0, cum[5] = {0, 0, 0, 0, 0}, rcum[5] = {0, 0, 0, 0, 0};
     uint32_t n = 0;
+    uint32_t saInterval = 1;                             // SaValueFreq of the .sa file (1: full suffix array)
     // annotation (HSPLoad, 2bwt-lib/HSP.c:256-531)
     uint32_t dnaLength = 0;
     int numOfSeq = 0;

@@ -27,7 +27,7 @@ class BwtDesc(C.Structure):
 class IndexDesc(C.Structure):
     _fields_ = [("fwd", BwtDesc), ("rev", BwtDesc), ("textLength", C.c_uint32), ("sa", C.c_void_p),
                 ("packedDNA", C.c_void_p), ("packedWords", C.c_size_t), ("lkt", C.c_void_p), ("revLkt", C.c_void_p),
-                ("lktSize", C.c_int)]
+                ("lktSize", C.c_int), ("saInterval", C.c_uint32)]
 
 
 class StreamResult(C.Structure):
@@ -178,8 +178,8 @@ class HostIndex:
         self.rev = half(".rev")
         self.n = self.fwd["cum"][4]
         sa = np.fromfile(prefix + ".sa", dtype=np.uint32)
-        assert int(sa[5]) == 1, "full suffix array (SaValueFreq=1) required"
-        self.sa = np.ascontiguousarray(sa[6:6 + self.n + 1]).copy()
+        self.sa_interval = int(sa[5])                            # SaValueFreq: 1 = full array, k = every k-th entry (BWT.c:254-255)
+        self.sa = np.ascontiguousarray(sa[6:6 + (self.n + self.sa_interval) // self.sa_interval]).copy()
         self.sa[0] = 0xFFFFFFFF                                   # BWT.c:286
         self.codes = unpack_pac(prefix + ".pac")
         assert len(self.codes) == self.n
@@ -211,7 +211,7 @@ class HostIndex:
             hdr = [h["inverseSa0"]] + [int(x) for x in h["cum"][1:5]]
             words(prefix + mid + ".bwt", hdr, h["bwt"])
             words(prefix + mid + ".fmv.gpu", hdr, h["occ"])
-        words(prefix + ".sa", [self.fwd["inverseSa0"]] + [int(x) for x in self.fwd["cum"][1:5]] + [1], self.sa)
+        words(prefix + ".sa", [self.fwd["inverseSa0"]] + [int(x) for x in self.fwd["cum"][1:5]] + [getattr(self, "sa_interval", 1)], self.sa)
         # packed text: 4 characters per byte, first one in the top bits; then one (partial or empty) byte and the count n % 4
         pw = np.ascontiguousarray(self.pac, dtype=">u4")
         raw = pw.view(np.uint8)[: n // 4 + 1].copy()
@@ -249,6 +249,7 @@ class HostIndex:
                 b.cumFreq[i] = h["cum"][i]
         d.textLength = self.n
         d.sa = self.sa.ctypes.data
+        d.saInterval = getattr(self, "sa_interval", 1)
         d.packedDNA = self.pac.ctypes.data
         d.packedWords = len(self.pac)
         d.lkt = self.lkt.ctypes.data

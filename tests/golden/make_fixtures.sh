@@ -191,6 +191,9 @@ dprun $OUT/g4 h2  pair g4.fa.index $OUT/g4/reads_1.fq $OUT/g4/reads_2.fq -L 100 
 dprun $OUT/g4 h1  pair g4.fa.index $OUT/g4/reads_1.fq $OUT/g4/reads_2.fq -L 100 -u 500 -v 100 -b 2 -h 1
 rm -f $OUT/g4/dp_h1.problems.txt.gz
 dprun $OUT/g5 h2  pair g5.fa.index g5_1.fq g5_2.fq -L 100 -u 500 -v 100 -b 2
+# the g1 index with a SAMPLED suffix array (SaValueFreq=4, README.md:55-65): only the .sa file differs
+( cd $W && mkdir -p sa4 && cd sa4 && cp $OUT/g1/genome.fa g1.fa && cp $REF/soap3-dp-builder . && sed 's/^SaValueFreq=1;/SaValueFreq=4;/' $ROOT/oracle/builder.ini > soap3-dp-builder.ini
+  ./soap3-dp-builder g1.fa > /dev/null && cmp g1.fa.index.bwt $OUT/g1/index.bwt && cp g1.fa.index.sa $OUT/g1/index_sa4.sa )
 ( cd $W; [ -f g1.fa.index.bwt ] || { cp $OUT/g1/genome.fa g1.fa; $REF/soap3-dp-builder g1.fa > /dev/null; $REF/BGS-Build g1.fa.index > /dev/null; } )
 dprun $OUT/g1 se  single g1.fa.index $OUT/g1/reads.fq -L 100 -b 2
 if [ -z "${S3_FIXTURE_ONLY:-}" ]; then
