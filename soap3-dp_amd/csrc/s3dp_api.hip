@@ -271,7 +271,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskEnd, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
-    BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4);
+    BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4); BA(dTrunk, 16); b->trunkCap = 16;
     b->countCap = b->maxItems + 1;
     BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
     BA(dWithError, (size_t)maxReads * 8);
@@ -410,7 +410,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             in.sStarPacked |= (uint32_t)sStar << (3 * c);
         }
     }
-    in.unitsPerItem = 1; in.unitBase = 0;
+    in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0;
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
     unsigned long long counterSnap[8];
     if (b->counting) {
@@ -487,13 +487,25 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     }
                     nCount = (uint32_t)(need - 1);
                     HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, (need - nItems) * 4, b->stream));
+                    // the trunk states: 16 B per (listed read, item, position)
+                    const size_t nStates = (size_t)nHeavy * groups * U;
+                    if (U > 1 && nStates > b->trunkCap) {
+                        int rc = bgrow(b, &b->dTrunk, nStates + nStates / 4, 0);
+                        if (rc) return rc;
+                        b->trunkCap = nStates + nStates / 4;
+                    }
+                    if (U > 1) HIPCHK(hipMemsetAsync(b->dTrunk, 0, nStates * sizeof(uint4), b->stream));
+                    out.trunkStates = b->dTrunk;
                     SearchIn in2 = in;
                     in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu;
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
                     in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (check-and-extend and the scatter decode unit indices with them)
-                    HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-                    le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, b->stream);
-                    if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
+                    for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass
+                        in2.unitMode = mode;
+                        HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
+                        le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, b->stream);
+                        if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
+                    }
                 }
             }
             // the task records end where the stepping kernel stopped writing; the check-and-extend kernel appends behind them

@@ -59,6 +59,7 @@ struct SearchIn {
     uint32_t        heavyLimit;  // first pass: a read that reserves more check-and-extend candidates than this is listed for the second pass
     const uint32_t *slotList;    // second pass (item mode: one work unit per item of a listed read): the listed slots ...
     const uint32_t *slotCount;   // ... and how many (device memory, written by the first pass)
+    uint32_t        unitMode;      // 0: first pass (a unit = a read); 1: trunk pass over the listed reads' items; 2: unit pass (s3dp_search_v2.hip)
     uint32_t        unitsPerItem;  // second pass: first-mismatch positions an item is cut into, + 1 for "none" (1: whole items)
     uint32_t        unitBase;      // second pass: unit u counts its records in itemCounts[unitBase + u]
     uint32_t        sStarPacked;   // 3 bits per case: the first step that allows a mismatch (= nSteps: none)
@@ -80,6 +81,7 @@ struct SearchOut {
     uint8_t            *heavyFlags; // per slot: listed for the second pass (zeroed before every first pass)
     uint32_t           *heavyList, *heavyCount;
     uint32_t           *heavyIndex; // per listed slot: its place in heavyList
+    uint4              *trunkStates; // second pass: {l, r, rev l, valid} per (listed read, item, position), written by the trunk pass
 };
 
 struct DevHit { uint32_t a, b, meta; };       // binary-identical to s3_hit (kind, strand, nmis, cas bytes)
@@ -111,7 +113,7 @@ struct DpArgs {
     int32_t        *scores;
     uint32_t       *hitLocs, *startOffsets, *maxScoreCounts, *tableCols;
     unsigned char  *pattern;
-    uint32_t       *table;                                        // per problem: chunks x (maxDPTableLength + 64) x 64 dwords (H | E << 16)
+    uint32_t       *table;                                        // per problem and 64-row chunk: (maxDPTableLength + 64) steps x 64 int16 H, then one 64-bit word per step
     size_t          tableWordsPerProblem;
     uint32_t        n, maxDNALength, maxReadLength, maxDPTableLength, patternLen, ldsPerWave;
     int             match, mismatch, gapOpen, gapExtend, scheme;

@@ -10,13 +10,15 @@
 //     at step t it computes column t-k; H[j][i-1], the running insertion score, the diagonal and the window character
 //     travel to the next lane by DPP (wave_shr:1), lane 0 taking the boundary row prefetched from LDS as the move's
 //     "old" operand; the previous column's H/E stay in the lane's registers; the read is read once;
-//   * the tables needed by the traceback are written as ONE coalesced 256-B streaming store per wave step (H and E
-//     packed in one dword per cell, anti-diagonal-major), never re-read by the fill;
+//   * what the traceback needs is written as ONE coalesced 128-B streaming store per wave step (H as int16, anti-diagonal-major) plus one
+//     64-bit word per step: the traceback looks at E in a single test -- "did H(j,i) come out of an extended deletion: H(j,i) == gapExtend +
+//     E(j-1,i)" -- and the lane that computes the cell has both values at hand, so the answer is a ballot bit (2.1 bytes per cell; the
+//     reference writes 4 and reads them back);
 //   * the maximum is tracked order-independently (max score, then smallest (column,row), plus tie count) and reduced
 //     across the wave, which equals the reference's strictly-greater update in (column outer, row inner) order;
 //   * the steady-state step carries no per-lane activity test and no clip / maximum code unless the chunk needs it
 //     (dpStep's template flags): about 21 vector instructions per 64 cells.
-// Bound: integer VALU (3.05 of the 3.9 ms at 150 x 648); HBM traffic is 4 B written per cell (the other 0.9 ms).
+// Bound: integer VALU; HBM traffic is 2.1 B written per cell.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "s3dp_device.h"
@@ -62,7 +64,8 @@ struct ChunkConst {
     bool rowClip, rowBest;
     const unsigned char *refLds;
     int *bnd;
-    uint32_t *tab;                    // this chunk's part of the table: [step][lane]
+    uint16_t *tabH;                   // this chunk's part of the table: H[step][lane] ...
+    unsigned long long *tabX;         // ... and per step the lanes whose H came out of an extended deletion
 };
 
 // one anti-diagonal step.  Lanes outside the table (column < 1 while RAMP, column > W, rows beyond the read) compute on garbage that no
@@ -75,7 +78,7 @@ __device__ __forceinline__ void dpStep(const ChunkConst &k, LaneState &s, uint32
     const int upS = waveShr1From(s.nb0, s.upIn), fS = waveShr1From(s.nb1, s.fIn), dgS = waveShr1From(s.nb2, s.dgIn), rS = waveShr1From(s.nr, s.rIn);
     const uint32_t jn = t + 1u < k.W ? t + 1u : k.W;                  // uniform: the column lane 0 computes in the next step
     s.nb0 = k.bnd[3u * jn]; s.nb1 = k.bnd[3u * jn + 1u]; s.nb2 = k.bnd[3u * jn + 2u]; s.nr = k.refLds[jn];
-    const int prevR = s.hPrev;
+    const int prevR = s.hPrev, ePrevIn = s.ePrev;
     int gapped = max(k.go + prevR, k.ge + s.ePrev);
     const int eSt = clampS(gapped);
     int f = max(k.ge + fS, k.go + upS);
@@ -92,8 +95,12 @@ __device__ __forceinline__ void dpStep(const ChunkConst &k, LaneState &s, uint32
     if (RAMP) { const bool started = t > k.lane; s.hPrev = started ? hSt : s.hPrev; s.ePrev = started ? eSt : s.ePrev; }
     else { s.hPrev = hSt; s.ePrev = eSt; }
     s.upIn = up; s.fIn = f; s.dgIn = dg; s.rIn = rS;
-    // H | E << 16, two int16; written once and read only by the traceback kernel: streaming stores keep the table out of the caches' way
-    if (TABLE) { uint32_t *row = k.tab + (size_t)t * 64u; __builtin_nontemporal_store(__builtin_amdgcn_perm((uint32_t)eSt, (uint32_t)hSt, 0x05040100u), &row[k.lane]); }
+    // written once and read only by the traceback kernel: streaming stores keep the table out of the caches' way
+    if (TABLE) {
+        __builtin_nontemporal_store((uint16_t)hSt, &k.tabH[(size_t)t * 64u + k.lane]);
+        const unsigned long long x = __ballot(hSt == k.ge + ePrevIn);
+        if (k.lane == 0u) __builtin_nontemporal_store(x, &k.tabX[t]);
+    }
     if (BEST) {
         // columns jLo..W of the rows that may end the alignment; inside a row the columns come in increasing order, so the first maximum is the
         // reference's (strictly-greater update) and later equals only count
@@ -117,7 +124,9 @@ __device__ __forceinline__ void chunkSweep(const DpArgs &a, uint32_t p, uint32_t
     k.go = a.gapOpen; k.ge = a.gapExtend; k.gi = k.go - k.ge; k.match = a.match; k.mismatch = a.mismatch;
     asm volatile("" : "+v"(k.match), "+v"(k.mismatch));              // the select between them wants vector registers: move once, not per step
     k.lane = threadIdx.x & 63u; k.W = W; k.refOffset = refOffset; k.aL = aL; k.refLds = refLds; k.bnd = bnd;
-    k.tab = TABLE ? table + (size_t)c * T * 64u : nullptr;
+    // per chunk: T steps of 64 int16 (T * 32 dwords), then T 64-bit words (T * 2 dwords)
+    k.tabH = TABLE ? (uint16_t *)(table + (size_t)c * T * 34u) : nullptr;
+    k.tabX = TABLE ? (unsigned long long *)(table + (size_t)c * T * 34u + (size_t)T * 32u) : nullptr;
     const uint32_t i = (c << 6) + 1u + k.lane;                       // this lane's read row
     const bool rowOk = i <= L;
     k.rc = rowOk ? seqChar(a.reads, p, a.maxReadLength, i) : 0u;
@@ -225,7 +234,37 @@ __global__ void __launch_bounds__(256) dpFillKernel(DpArgs a)
     }
 }
 
-// GPUBacktrack (:316-512): serial walk, one lane per problem, over the tables written by dpFillKernel
+// Traceback (what GPUBacktrack computes, DV-DPfunctions.cu:316-512): from the maximum back to the read's first aligned base.
+// The reference's walk decides every move by comparing table VALUES, in a fixed priority -- match/mismatch, then a deletion that opens here, then
+// one that extends, then (inside the left-clip allowance) the two ways out, then an insertion that opens, else one that extends -- and inside a gap
+// it follows the gap's own score downwards until the gap is seen to open.  The same decisions are taken here from H alone plus the one bit per
+// cell the fill kernel recorded; the walk is organised as "where am I, what does the cell say" (View) and three small movers, one lane per
+// problem (a walk is a chain of dependent reads: 64 problems per wave is what hides its latency).
+namespace tb {
+struct View {
+    const DpArgs &a; uint32_t p, T, refOffset, aL, cl;
+    const uint32_t *table;
+    int go, ge, gi;
+    // H(j, i) as the table holds it; column 0 and row 0 are never stored: they are the initial conditions (:165-198)
+    __device__ int H(uint32_t j, uint32_t i) const
+    {
+        if (j == 0u) return clampS(i == 0u ? 0 : (i <= cl ? go : gi + ge * (int)(i - cl)));
+        if (i == 0u) return (j + refOffset >= aL) ? NEG_INF : 0;
+        const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
+        const uint16_t *h = (const uint16_t *)(table + (size_t)c * T * 34u);
+        return (int)(int16_t)h[(size_t)(j + k) * 64u + k];
+    }
+    // did H(j, i) come out of an extended deletion, H(j,i) == gapExtend + E(j-1,i)?  (j >= 1; for j == 1 the previous column is the initial one)
+    __device__ bool fromExtendedDeletion(uint32_t j, uint32_t i) const
+    {
+        if (i == 0u) return false;
+        const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
+        const unsigned long long *x = (const unsigned long long *)(table + (size_t)c * T * 34u + (size_t)T * 32u);
+        return (x[j + k] >> k) & 1ull;
+    }
+};
+}  // namespace tb
+
 __global__ void dpBacktrackKernel(DpArgs a)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,70 +272,63 @@ __global__ void dpBacktrackKernel(DpArgs a)
     unsigned char *pat = a.pattern + (size_t)p * a.patternLen;
     pat[0] = 0;
     if (a.scores[p] < a.cutoffs[p]) return;
-    const int go = a.gapOpen, ge = a.gapExtend, gi = go - ge;
-    const uint32_t T = a.maxDPTableLength + 64u;
-    const uint32_t *table = a.table + (size_t)p * a.tableWordsPerProblem;
-    const uint32_t L = a.readLengths[p], refOffset = a.startOffsets[p];
-    const uint32_t aL = a.anchorLeft ? a.anchorLeft[p] : a.maxDNALength;
-    const uint32_t cl = a.clipLt ? a.clipLt[p] : 0u, clipRtLen = a.clipRt ? a.clipRt[p] : 0u;
-    uint32_t pi = 0;
-    auto app = [&](uint32_t x) { if (pi < a.patternLen) pat[pi] = (unsigned char)x; ++pi; };
-    auto cell = [&](uint32_t j, uint32_t i, bool wantE) -> int {
-        if (j == 0) {                                               // column 0 (:165-183)
-            int up0;
-            if (i == 0) up0 = wantE ? gi : 0;
-            else if (i <= cl) up0 = wantE ? go + gi : go;
-            else { up0 = gi + ge * (int)(i - cl); if (wantE) up0 += gi; }
-            return clampS(up0);
-        }
-        if (i == 0) {                                               // row 0 (:192-198)
-            const int init = (j + refOffset >= aL) ? NEG_INF : 0;
-            return clampS(wantE ? init + gi : init);
-        }
-        const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
-        const uint32_t w = table[((size_t)c * T + (j + k)) * 64u + k];
-        return (int)(int16_t)(wantE ? (w >> 16) : (w & 0xFFFFu));
-    };
-    if (clipRtLen > 0) { app('S'); app('V'); app(clipRtLen); }
-    uint32_t readPos = L - clipRtLen, refIndex = a.hitLocs[p];
-    uint32_t readChar = seqChar(a.reads, p, a.maxReadLength, readPos), refChar = seqChar(a.dna, p, a.maxDNALength, refOffset + refIndex);
-    int16_t cur = (int16_t)cell(refIndex, readPos, false), next = 0;
-    int16_t init = (refOffset + refIndex >= aL) ? NEG_INF : 0, prevInit = (refOffset + refIndex > aL) ? NEG_INF : 0;
-    enum { NORMAL, I_EXT, D_EXT, SM_EXIT, SI_EXIT } state = NORMAL;
-    auto nextRef = [&]() { --refIndex; refChar = seqChar(a.dna, p, a.maxDNALength, refOffset + refIndex); init = prevInit; prevInit = (refOffset + refIndex > aL) ? NEG_INF : 0; };
-    auto nextRead = [&]() { --readPos; readChar = seqChar(a.reads, p, a.maxReadLength, readPos); };
-    auto dist = [&]() -> int { return refChar == readChar ? a.match : a.mismatch; };
-    while (readPos > 0 && refIndex > 0) {
-        if (state == NORMAL) {
-            if (cur == dist() + (next = (int16_t)cell(refIndex - 1, readPos - 1, false))) { app('m' - ((refChar == readChar) << 5)); nextRef(); nextRead(); cur = next; }
-            else if (cur == go + (next = (int16_t)cell(refIndex - 1, readPos, false))) { app('D'); nextRef(); cur = next; }
-            else if (cur == ge + cell(refIndex - 1, readPos, true)) { app('D'); nextRef(); cur = (int16_t)(cur - ge); state = D_EXT; }
-            else {
-                if (readPos <= cl + 1u) {
-                    if (cur == prevInit + dist()) { state = SM_EXIT; break; }
-                    else if (cur == init + go) { state = SI_EXIT; break; }
-                }
-                if (cur == go + (next = (int16_t)cell(refIndex, readPos - 1, false))) { app('I'); nextRead(); cur = next; }
-                else { app('I'); nextRead(); cur = (int16_t)(cur - ge); state = I_EXT; }
+    const uint32_t L = a.readLengths[p];
+    const tb::View v{a, p, a.maxDPTableLength + 64u, a.startOffsets[p], a.anchorLeft ? a.anchorLeft[p] : a.maxDNALength, a.clipLt ? a.clipLt[p] : 0u,
+                     a.table + (size_t)p * a.tableWordsPerProblem, a.gapOpen, a.gapExtend, a.gapOpen - a.gapExtend};
+    const uint32_t clipRt = a.clipRt ? a.clipRt[p] : 0u;
+    uint32_t out = 0;
+    auto put = [&](uint32_t x) { if (out < a.patternLen) pat[out] = (unsigned char)x; ++out; };
+    auto run = [&](char op, uint32_t n) { put((uint32_t)op); put('V'); put(n); };       // 'V'<n>: n - 1 more of the op before (decoded by the engines)
+    uint32_t i = L - clipRt, j = a.hitLocs[p];                                           // read position, window column (1-based, 0 = before the first)
+    if (clipRt) run('S', clipRt);
+    auto readAt = [&](uint32_t q) { return seqChar(a.reads, p, a.maxReadLength, q); };
+    auto refAt = [&](uint32_t q) { return seqChar(a.dna, p, a.maxDNALength, v.refOffset + q); };
+    auto rowInit = [&](uint32_t q) -> int { return (v.refOffset + q >= v.aL) ? NEG_INF : 0; };     // H(q, 0)
+    enum Exit { NONE, CLIP_AFTER_MATCH, CLIP_AFTER_INSERT } exitBy = NONE;
+    int cur = v.H(j, i);
+    while (i > 0u && j > 0u && exitBy == NONE) {
+        const bool same = refAt(j) == readAt(i);
+        const int sub = same ? a.match : a.mismatch;
+        int nxt;
+        if (cur == sub + (nxt = v.H(j - 1u, i - 1u))) { put(same ? 'M' : 'm'); --j; --i; cur = nxt; continue; }
+        if (cur == v.go + (nxt = v.H(j - 1u, i))) { put('D'); --j; cur = nxt; continue; }
+        if (v.fromExtendedDeletion(j, i)) {
+            // inside a deletion: its score falls by gapExtend per base until the column where it opened out of H
+            put('D'); --j;
+            int gap = (int16_t)(cur - v.ge);
+            for (;;) {
+                if (!(i > 0u && j > 0u)) { cur = gap; break; }
+                put('D'); --j;
+                if (gap == v.go + (nxt = v.H(j, i))) { cur = nxt; break; }
+                gap = (int16_t)(gap - v.ge);
             }
-        } else {
-            if (state == D_EXT) { app('D'); nextRef(); }
-            else {
-                if (readPos <= cl + 1u && cur == init + go) { state = SI_EXIT; break; }
-                app('I'); nextRead();
-            }
-            if (cur == go + (next = (int16_t)cell(refIndex, readPos, false))) { state = NORMAL; cur = next; }
-            else cur = (int16_t)(cur - ge);
+            continue;
+        }
+        if (i <= v.cl + 1u) {                                                              // the read's start may be clipped away from here
+            if (cur == rowInit(j - 1u) + sub && j >= 1u) { exitBy = CLIP_AFTER_MATCH; break; }
+            if (cur == rowInit(j) + v.go) { exitBy = CLIP_AFTER_INSERT; break; }
+        }
+        if (cur == v.go + (nxt = v.H(j, i - 1u))) { put('I'); --i; cur = nxt; continue; }
+        // inside an insertion: likewise, along the read
+        put('I'); --i;
+        int gap = (int16_t)(cur - v.ge);
+        for (;;) {
+            if (!(i > 0u && j > 0u)) { cur = gap; break; }
+            if (i <= v.cl + 1u && gap == rowInit(j) + v.go) { cur = gap; exitBy = CLIP_AFTER_INSERT; break; }
+            put('I'); --i;
+            if (gap == v.go + (nxt = v.H(j, i))) { cur = nxt; break; }
+            gap = (int16_t)(gap - v.ge);
         }
     }
-    if (refIndex == 0) {
-        const uint32_t scNum = cl < readPos ? cl : readPos;
-        if (scNum < readPos) { app('I'); app('V'); app(readPos - scNum); }
-        app('S'); app('V'); app(scNum);
-    } else if (state == SI_EXIT) { app('I'); app('S'); app('V'); app(readPos - 1u); }
-    else if (state == SM_EXIT) { app('m' - ((refChar == readChar) << 5)); app('S'); app('V'); app(readPos - 1u); refIndex -= 1u; }
-    app(0);
-    a.hitLocs[p] = refOffset + refIndex;
+    if (j == 0u) {
+        // ran off the window's left edge: what is left of the read is clipped as far as allowed, the rest counts as inserted
+        const uint32_t clipped = v.cl < i ? v.cl : i;
+        if (clipped < i) run('I', i - clipped);
+        run('S', clipped);
+    } else if (exitBy == CLIP_AFTER_INSERT) { put('I'); run('S', i - 1u); }
+    else if (exitBy == CLIP_AFTER_MATCH) { put(refAt(j) == readAt(i) ? 'M' : 'm'); run('S', i - 1u); --j; }
+    put(0);
+    a.hitLocs[p] = v.refOffset + j;
 }
 
 // returns a hipError_t (hipErrorInvalidValue: a window that does not fit into LDS even with one problem per block)

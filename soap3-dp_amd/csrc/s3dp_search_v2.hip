@@ -34,7 +34,7 @@ namespace s3 {
 
 namespace v2 {
 
-enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6, ST_RESUME = 7 };
+enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_TRUNK = 2, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6, ST_RESUME = 7 };
 constexpr uint32_t ID_NONE = 0x7FFFFFFFu;
 constexpr int STACK = 20;
 
@@ -106,11 +106,13 @@ using namespace v2;
 // bound by its instruction count.  The record stream keeps the CPU path's order because accepted candidates are written under the reserved
 // numbers; rejected ones leave holes the ordering pass skips.  Not counting the candidates in `total` only delays the early stop at
 // MaxOutputPerRead: the per-read cut is applied again, exactly, when the records are merged.
-// in.slotList != NULL: unit mode (second pass) -- the work queue holds (listed read, item, first-mismatch position) units instead of reads.
-// A unit walks the trunk of its item (lookup step, exact steps, the mismatch step up to its position p without branching), branches at p into the
-// mismatch children only, and from there on is an ordinary depth-first search; the last unit of an item (p = unitsPerItem - 1) is the one that
-// takes no mismatch in that step at all.  What happens ON the trunk (a range handed to check-and-extend, a dead range) concerns every unit of the
-// item alike: the hand-over is written by the unit that owns the place (position i of the mismatch step: unit i; before that step: unit 0).
+// in.unitMode: the second pass over the listed reads, two launches.
+//   1 (trunk pass): one lane per (listed read, item) walks the TRUNK of the item -- lookup step, exact steps, then the first mismatch step without
+//     taking a mismatch -- and writes the range it holds at every position of that step into out.trunkStates; it then goes on as the item's last
+//     unit (no mismatch in that step at all).  Whatever ends the trunk early (a range handed to check-and-extend, a dead range) ends it for all
+//     units: positions it never reached keep an invalid state.
+//   2 (unit pass): one lane per (listed read, item, position p): it loads the read and the trunk state of p, takes ONLY the mismatch children at p
+//     and is from there on an ordinary depth-first search.
 template <bool UNIFORM>
 __global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_V2_WAVES_PER_SIMD)
 searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
@@ -131,7 +133,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         __syncthreads();
     }
 
-    const unsigned long long nSlots = in.slotList ? (unsigned long long)*in.slotCount * ((uint32_t)in.nCases * 2u) * in.unitsPerItem : in.nActive;   // unit mode: listed reads x items x positions
+    const unsigned long long nSlots = in.unitMode ? (unsigned long long)*in.slotCount * ((uint32_t)in.nCases * 2u) * (in.unitMode == 2u ? in.unitsPerItem - 1u : 1u)
+                                                  : in.nActive;            // second pass: listed reads x items (x positions)
     const uint32_t nCases = (uint32_t)in.nCases;
     const uint32_t groups = nCases * 2u;
     uint32_t nRank = 0, nLt = 0;
@@ -148,16 +151,11 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     Range g = {0, 0, 0, 0};
     int s = 0, i = 0, ins = 0, occ = 0;
     // unit mode
-    const uint32_t U = in.slotList ? in.unitsPerItem : 1u;
+    const uint32_t U = in.unitMode ? in.unitsPerItem : 1u;
+    const uint32_t unitsPerItemHere = in.unitMode == 2u ? U - 1u : 1u;       // work units per item in this launch
     bool trunk = false;                                                     // the lane is still on the part of the item that all its units share
     uint32_t unitP = 0xFFFFFFFFu;                                           // position of the unit's first mismatch; 0xFFFFFFFF: none in the mismatch step
     int sStar = 0;                                                          // the first step of the case that allows a mismatch (nSteps: none)
-    auto trunkOwner = [&]() -> bool {                                       // may THIS unit write what happens at the lane's place on the trunk?
-        if (!trunk) return true;
-        if (s < sStar) return unitP == 0u || (U == 1u);
-        if (s == sStar) return unitP == (uint32_t)i;
-        return true;
-    };
     uint32_t strand = 0;
     Frame stack[STACK];
     int sp = 0;
@@ -221,7 +219,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (i < lenEff && alive) {
                 const int pos = st.start + st.dir * i;
                 if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
-                    if (!trunkOwner()) { state = ST_DONE; return; }          // another unit of the item writes this hand-over
                     if (pendMeta >> 31) { state = ST_RESUME; return; }       // one record per lane and trip
                     pendMeta = 0x80000000u | seq | S3_REC_TASK;
                     pendA = g.fl;
@@ -243,7 +240,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         const uint32_t lim = in.earlyCe < (uint32_t)nx.ceThr ? in.earlyCe : (uint32_t)nx.ceThr;     // nx.ceThr >= 0 for every step
                         const int nxLenEff = nx.minErr > 1 ? nx.len - (nx.minErr - 1) : nx.len;                    // the next step must have a first position to stand on
                         if ((g.fr - g.fl) < lim && nxLenEff > 0 && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
-                            if (!trunkOwner()) { state = ST_DONE; return; }
                             if (pendMeta >> 31) { state = ST_RESUME; return; }
                             pendMeta = 0x80000000u | seq | S3_REC_TASK | S3_REC_EARLY;
                             pendA = g.fl;
@@ -291,7 +287,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 out.itemCounts[cntIdx] = seq;
                 readTotal += total;
                 sub++;
-                if (in.slotList) sub = groups;                              // unit mode: one unit per turn
+                if (in.unitMode) sub = groups;                              // second pass: one unit per turn
                 else if (readTotal >= in.maxOut) {
                     // the per-read cut (mergeCountKernel) ends inside this item or before: what follows can never be kept
                     for (; sub < groups; sub++) out.itemCounts[slotIdx * groups + sub] = 0;
@@ -316,8 +312,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 else {
                     chunkCur = chunkBase = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots;
                     if (in.slotList) {
-                        sl0 = b + lane < nSlots ? in.slotList[(b + lane) / (groups * U)] : 0u;
-                        sl1 = b + 64u + lane < nSlots ? in.slotList[(b + 64u + lane) / (groups * U)] : 0u;
+                        sl0 = b + lane < nSlots ? in.slotList[(b + lane) / (groups * unitsPerItemHere)] : 0u;
+                        sl1 = b + 64u + lane < nSlots ? in.slotList[(b + 64u + lane) / (groups * unitsPerItemHere)] : 0u;
                         if (in.active) { act0 = in.active[sl0]; act1 = in.active[sl1]; }
                     } else if (in.active) {
                         act0 = b + lane < nSlots ? in.active[b + lane] : 0u;
@@ -339,16 +335,15 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     sub = 0;
                     cntIdx = slotIdx * groups;
                     trunk = false; unitP = 0xFFFFFFFFu;
-                    if (in.slotList) {
-                        const uint32_t unit = slotIdx;                     // = heavy read * groups * U + item * U + p
-                        cntIdx = in.unitBase + unit;
-                        sub = (unit / U) % groups;
-                        const uint32_t p = unit % U;
-                        unitP = p + 1u == U ? 0xFFFFFFFFu : p;
+                    if (in.unitMode) {
+                        const uint32_t item = slotIdx / unitsPerItemHere;  // = listed read * groups + (case, strand)
+                        sub = item % groups;
+                        unitP = in.unitMode == 2u ? slotIdx % unitsPerItemHere : 0xFFFFFFFFu;
+                        cntIdx = in.unitBase + item * U + (in.unitMode == 2u ? unitP : U - 1u);
                         trunk = U > 1u;
                         slotIdx = off < 64u ? s0 : s1;
                         // the listed read counts per unit now: what the first pass left in its items' own counters (or never wrote) is void
-                        if (p == 0u) out.itemCounts[slotIdx * groups + sub] = 0;
+                        if (in.unitMode == 1u) out.itemCounts[slotIdx * groups + sub] = 0;
                     }
                     rIdx = in.active ? (off < 64u ? a0 : a1) : slotIdx;
                     readTotal = 0; readCand = 0;
@@ -356,7 +351,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     casIdx = sub >> 1; strand = sub & 1u;
                     nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
                     sStar = (int)((in.sStarPacked >> (3u * casIdx)) & 7u);
-                    if (!in.slotList) cntIdx += sub;
+                    if (!in.unitMode) cntIdx += sub;
                     seq = 0; total = 0; sp = 0; loadOff = 0;
                     hasItem = true;
                     state = ST_LOAD;
@@ -366,16 +361,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         }
 
         // ---------- lookup-table keys of a starting item (BWTExactModel{Backward,Forward}_Lookup2, BGS-HostAlgnmtAlgo2.cpp:311-347) ----------
-        if (state == ST_KEYS && trunk && unitP != 0xFFFFFFFFu) {
-            // a unit whose position lies behind the last one of this case's mismatch step (the cases differ in length) has nothing to do
-            bool empty = sStar >= nSteps;
-            if (!empty) {
-                const S3Step ss = stepAt(sStar);
-                const int lenEff = ss.minErr > 1 ? ss.len - (ss.minErr - 1) : ss.len;
-                empty = (int)unitP >= lenEff;
-            }
-            if (empty) state = ST_DONE;
-        }
         if (state == ST_KEYS) {
             const S3Step st = stepAt(0);
             const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;            // <= 13 characters = 26 bits of one window
@@ -444,6 +429,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             aP0 = src;
             if (2u * wpq - loadOff > 4) aP1 = src + 1;
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
+        } else if (state == ST_TRUNK) {
+            aP0 = out.trunkStates + (cntIdx - in.unitBase);
         } else if (state == ST_LT) {
             const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
             if (ltB == 0xFFFFFFFFu) {
@@ -511,9 +498,10 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const Range gc = child((ch == 0 ? oL.x : ch == 1 ? oL.y : ch == 2 ? oL.z : oL.w) + 1u, ch == 0 ? oR.x : ch == 1 ? oR.y : ch == 2 ? oR.z : oR.w,
                                    ch == 0 ? d1 + d2 + d3 : ch == 1 ? d2 + d3 : ch == 2 ? d3 : 0u);
             doSettle = true;
-            const bool onTrunkHere = trunk && s == sStar;                      // unit mode: before the unit's own position only the continuation is taken
-            const bool branchOnly = onTrunkHere && (uint32_t)i == unitP;        // at it: only the mismatch children
+            const bool onTrunkHere = trunk && s == sStar;                      // trunk pass: no mismatch is taken in this step ...
+            const bool branchOnly = onTrunkHere && (uint32_t)i == unitP;        // ... unit pass, at the unit's position: only the mismatch children
             if (branchOnly) trunk = false;
+            else if (onTrunkHere && (uint32_t)i + 1u < U) out.trunkStates[(cntIdx - in.unitBase) - (U - 1u) + (uint32_t)i] = make_uint4(g.fl, g.fr, g.rl, 1u);
             if (!exact && !(onTrunkHere && !branchOnly)) {
                 const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
                 const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
@@ -538,6 +526,11 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (doSettle && !needPop) { g = gc; i++; }
         }
         if (state == ST_RESUME) { doSettle = true; needPop = false; }          // the completed frame that had to wait: emit it now, then pop
+        if (state == ST_TRUNK) {
+            // the range the trunk pass held at this unit's position (.w = 0: the trunk never got there -- nothing to do)
+            if (p0.w == 0u) state = ST_DONE;
+            else { g.fl = p0.x; g.fr = p0.y; g.rl = p0.z; g.rr = p0.z + (p0.y - p0.x); s = sStar; i = (int)unitP; ins = 0; occ = 0; state = ST_STEP; }
+        } else
         if (state == ST_LOAD) {
             // word gi of the read's row in readsT (both orientations, wpq words each) -> LDS word (orientation * wl + w); words past wl are padding
             const uint32_t vals[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
@@ -549,7 +542,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             loadOff += 8;
             if constexpr (!UNIFORM) Li = (int)saVal;
-            if (loadOff >= 2u * wpq) state = ST_KEYS;
+            if (loadOff >= 2u * wpq) state = in.unitMode == 2u ? ST_TRUNK : ST_KEYS;
         } else if (state == ST_LT) {
             const S3Step st = stepAt(0);
             int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
@@ -584,7 +577,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 }
                 if (pendMeta >> 31) {
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(in.slotList ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(in.unitMode ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
                     pendMeta = 0;
                 }
                 recCur += np;
@@ -731,7 +724,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
 int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
 {
     if (in.nActive == 0) return (int)hipSuccess;
-    uint64_t blocks = ((uint64_t)in.nActive * (in.slotList ? (uint64_t)in.nCases * 2u * in.unitsPerItem : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    uint64_t blocks = ((uint64_t)in.nActive * (in.unitMode ? (uint64_t)in.nCases * 2u * (in.unitMode == 2u ? in.unitsPerItem : 1u) : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wLds * 256u);
     if (lds > 48u * 1024u) {
