@@ -496,6 +496,8 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     }
                     if (U > 1) HIPCHK(hipMemsetAsync(b->dTrunk, 0, nStates * sizeof(uint4), b->stream));
                     out.trunkStates = b->dTrunk;
+                    out.readCut = b->dLongList;                                // (free until the merge kernels list their long reads)
+                    HIPCHK(hipMemsetAsync(b->dLongList, 0xFF, (size_t)nHeavy * 4, b->stream));
                     SearchIn in2 = in;
                     in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu;
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;

@@ -81,6 +81,7 @@ struct SearchOut {
     uint8_t            *heavyFlags; // per slot: listed for the second pass (zeroed before every first pass)
     uint32_t           *heavyList, *heavyCount;
     uint32_t           *heavyIndex; // per listed slot: its place in heavyList
+    uint32_t           *readCut;     // second pass, per listed read: the smallest unit (item * units + position) that holds maxOut occurrences by itself
     uint4              *trunkStates; // second pass: {l, r, rev l, valid} per (listed read, item, position), written by the trunk pass
 };
 

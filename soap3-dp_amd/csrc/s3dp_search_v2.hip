@@ -156,6 +156,12 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     bool trunk = false;                                                     // the lane is still on the part of the item that all its units share
     uint32_t unitP = 0xFFFFFFFFu;                                           // position of the unit's first mismatch; 0xFFFFFFFF: none in the mismatch step
     int sStar = 0;                                                          // the first step of the case that allows a mismatch (nSteps: none)
+    // A unit that holds MaxOutputPerRead certain occurrences by itself ends the read's list: every later unit of the read (in sequence order: item,
+    // then position) lies behind the cut the merge will make.  It says so in out.readCut (smallest such unit per listed read); every lane of the second
+    // pass reads that word along with its rank lines and stops when it finds itself behind it -- what the single lane of an item-wise walk gets from
+    // its running total.
+    uint32_t unitInRead = 0;
+    const uint32_t *cutPtr = (const uint32_t *)ix.pac;
     uint32_t strand = 0;
     Frame stack[STACK];
     int sp = 0;
@@ -207,6 +213,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     if (readTotal + total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - readTotal - total - 1u;
                     emit(0, l, rr_, (uint32_t)(ins + occ));
                     total += rr_ - l + 1u;
+                    if (in.unitMode && total >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
                 }
                 needPop = true;                                              // the DFS goes on in the same trip
                 continue;
@@ -341,6 +348,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         unitP = in.unitMode == 2u ? slotIdx % unitsPerItemHere : 0xFFFFFFFFu;
                         cntIdx = in.unitBase + item * U + (in.unitMode == 2u ? unitP : U - 1u);
                         trunk = U > 1u;
+                        unitInRead = sub * U + (in.unitMode == 2u ? unitP : U - 1u);
+                        cutPtr = out.readCut + item / groups;
                         slotIdx = off < 64u ? s0 : s1;
                         // the listed read counts per unit now: what the first pass left in its items' own counters (or never wrote) is void
                         if (in.unitMode == 1u) out.itemCounts[slotIdx * groups + sub] = 0;
@@ -417,6 +426,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
             idA = kL | (dir < 0 ? 0u : 0x80000000u);
             needB = kR != kL;
+            if (in.unitMode) aD1 = cutPtr;
             if (needB) {
                 const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
                 const bool fw = iR > (kR << 7);
@@ -431,6 +441,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
         } else if (state == ST_TRUNK) {
             aP0 = out.trunkStates + (cntIdx - in.unitBase);
+            aD1 = cutPtr;
         } else if (state == ST_LT) {
             const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
             if (ltB == 0xFFFFFFFFu) {
@@ -468,6 +479,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 
         // ---------- advance ----------
         bool doSettle = false, needPop = false;
+        if (in.unitMode && (state == ST_STEP || state == ST_TRUNK) && unitInRead > d1) { state = ST_DONE; sp = 0; }    // behind the read's cut
         if (state == ST_STEP) {
             const S3Step stS = stepAt(s);
             const bool exact = ins >= stS.maxErr;

@@ -55,6 +55,9 @@ def op_string(row):
 @pytest.mark.parametrize("max_read,max_dna,seed,rl", [(152, 650, 31, (60, 150)), (104, 200, 32, (30, 100)), (304, 700, 33, (150, 300)), (68, 130, 34, (16, 64)), (128, 300, 35, (100, 127)),
                                                       (1028, 1548, 36, (900, 1024)), (204, 5000, 37, (150, 200))])
 def test_reference_kernels_restatement_and_product_agree(scheme, max_read, max_dna, seed, rl):
+    if max_dna > 2000 and scheme == 2:
+        pytest.skip("the 5000-column case pins the kernel's two-waves-per-block launch; scheme 2 (small-memory mode of the reference, DV-DPfunctions.cu:600-612) "
+                    "is compared on the shapes its engines use")
     # reads are always shorter than maxReadLength in the reference's engines (maxReadLength = (longest / 4 + 1) * 4, DV-DPfunctions.cu:1580,2223):
     # its table rows hold maxReadLength cells for the read positions 0..readLength, so readLength == maxReadLength is outside its range
     assert rl[1] < max_read
