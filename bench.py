@@ -387,7 +387,7 @@ def measured_peaks(dev, local):
                    "64-byte lines in flight per lane"}
 
 
-def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_frac, label, index_dir=None):
+def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_frac, label, index_dir=None, want_cpu=True):
     """one workload = genome + index + reads + counted pass + timed region + checks; returns (json fragment, objects kept for the extras)"""
     import torch
     from s3dp import dist as sd
@@ -497,7 +497,16 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     # algorithmic bytes: SURVEY.md 8d's formula (strict), and the same extended by what the lookup tables and check-and-extend read: 16 B per lookup
     # (one long-table entry, or the four 4-byte entries of the 13-mer tables), 4 B per suffix-array entry, 16 B per 32-character compare window
     # (8 B of packed text + 8 B of the read)
-    bytes_strict = 32.0 * cnt["rankQueries"] + a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
+    # N_rank: what the kernels counted, or -- when that is MORE than the reference's own algorithm needs on this input (reads taken apart into
+    # units walk shared parts again; a lane cannot stop where the CPU path's running total stops it) -- the count of the CPU restatement, scaled
+    # from its sample ("N_rank counted exactly by the build's CPU restatement on the same input")
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_budget > 0 and want_cpu:
+        cpu = cpu_baseline(hi, q, lens, wpq, a.mismatch, a.max_out, a.cpu_budget)
+    n_rank = float(cnt["rankQueries"])
+    if cpu and cpu["rank_queries_per_read"] * a.reads < n_rank:
+        n_rank = cpu["rank_queries_per_read"] * a.reads
+    bytes_strict = 32.0 * n_rank + a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
     bytes_step = bytes_strict + 16.0 * cnt["ltLookups"] + 4.0 * cnt["saReads"] + 16.0 * cnt["ceWindows"]
     search_s_per_step = (search_ms + ce_ms) / 1e3 / max(1, a.steps)
     achieved = bytes_step / search_s_per_step / 1e9 if search_s_per_step > 0 else 0.0
@@ -527,7 +536,8 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
             "stepping_kernel_ms_per_step": search_ms / max(1, a.steps),
             "check_extend_kernel_ms_per_step": ce_ms / max(1, a.steps), "device_ms_per_step": dev_ms / max(1, a.steps),
             "sa_reads_per_step": cnt["saReads"], "ce_windows_per_step": cnt["ceWindows"], "lt_lookups_per_step": cnt["ltLookups"],
-            "rank_queries_per_step": cnt["rankQueries"]}
+            "rank_queries_per_step": cnt["rankQueries"], "rank_queries_algorithmic": n_rank,
+            "rank_queries_algorithmic_is": "min(what the kernels issued, the CPU restatement's count scaled from its sample)"}
     if traffic:
         # the path is made of random accesses with 4-32 B payloads; the GPU moves 64 B per access (tools/hbm_probe.py), so the rate of fetched
         # 64-byte lines against the probe measured in this run is what tells how busy the memory system is
@@ -543,6 +553,8 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
            "rank_queries_per_read": cnt["rankQueries"] / a.reads}
     if streamed:
         out["streamed"] = streamed
+    if cpu:
+        out["cpu_baseline"] = cpu
     if rank == 0:
         out["truth_check"] = truth_check(phase, offs, pos, strand, mis, tpos, tstrand, tsub, a.max_out)
         if a.check > 0:
@@ -624,8 +636,6 @@ def main():
     out["measured_peaks"] = peaks
 
     if rank == 0:
-        if world == 1 and a.cpu_budget > 0:
-            out["cpu_baseline"] = cpu_baseline(keep["hi"], keep["q"], keep["lens"], keep["wpq"], a.mismatch, a.max_out, a.cpu_budget)
         if world == 1 and a.extras:
             try:
                 out["extras"] = extras(s3dp, keep["ix"], keep["codes"], dev, rank)
@@ -641,7 +651,7 @@ def main():
             a2 = argparse.Namespace(**vars(a))
             a2.check = min(a.check, 1024)
             a2.streaming = 0
-            ures, ukeep = run_workload(a2, s3dp, builder, dev, local, rank, world, dist, peaks, 0.0, "uniform")
+            ures, ukeep = run_workload(a2, s3dp, builder, dev, local, rank, world, dist, peaks, 0.0, "uniform", want_cpu=False)
             ukeep["ix"].close()
             out.setdefault("extras", {})["uniform_genome"] = ures
         except Exception as e:

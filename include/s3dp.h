@@ -187,7 +187,8 @@ void s3_group_free(s3_group *g);
  * DP_Space::algnmtCPUThread (:2329-2441): CIGAR (CigarStringEncoder, DV-DPfunctions.h:548), edit distance
  * I + D + (L match + gapPenalty - score) / (match - mismatch), insert size.  `b` holds the reads (s3_batch_upload; reads 2p / 2p+1 are
  * a pair), `h` must have been created with maxReadLength >= the longest read and maxDNALength >= insertHigh.  One result per
- * candidate window, in input order; results and the CIGAR pool are malloc'ed: release with s3_free.  PARITY UNPINNED. */
+ * candidate window, in input order; results and the CIGAR pool are malloc'ed: release with s3_free.  Pinned against the reference's own
+ * engine (tests/test_gpu_dp_pipeline.py). */
 typedef struct { uint32_t readID, pos; uint8_t strand, mismatchCount, pad[2]; } s3_occ;        /* SRAOccurrence of the ALIGNED end */
 typedef struct {
     uint32_t readID;                /* first read of the pair */
@@ -207,7 +208,8 @@ int  s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3
  * (DV-DPfunctions.cu:1102-1219: hit -> estimated read position, sorted by strand / read / position, positions within 50 of the last kept
  * one collapse).  `reads` holds the uploaded reads, `seedBatch` is a second batch on the same index (wordPerQuery >= 8, room for every
  * seed: at most 12 per read below 400 bases).  Candidates come back sorted by (strand, read, position); seedStatus (optional) holds per
- * seed 0 = no hit, 1 = hits used, 4 = dropped for too many hits.  Both arrays are malloc'ed: release with s3_free.  PARITY UNPINNED. */
+ * seed 0 = no hit, 1 = hits used, 4 = dropped for too many hits.  Both arrays are malloc'ed: release with s3_free.  Pinned through the reference's own engines
+ * (tests/test_gpu_dp_pipeline.py). */
 typedef struct { uint32_t readID, pos; uint8_t strand, pad[3]; } s3_seed_candidate;
 int  s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *readIDs /* NULL = every read */, size_t nReadIDs,
                         int stage, uint32_t maxHitNum, s3_seed_candidate **candidates, size_t *nCandidates, uint8_t **seedStatus, size_t *nSeeds);
@@ -215,7 +217,8 @@ int  s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *re
 /* ---- DP for single reads (after s3_seed_candidates) ------------------------------------------------------------------------------
  * Replaces SingleEndAlignmentEngine (DV-DPfunctions.cu:1373-1770): window = candidate position -/+ margin (readLength > 100 ? readLength / 4
  * : 25), read packed in the candidate's strand, results below the cutoff dropped; CIGAR / edit distance as in s3_dp_half_end.
- * Results and the CIGAR pool are malloc'ed: release with s3_free.  PARITY UNPINNED. */
+ * Results and the CIGAR pool are malloc'ed: release with s3_free.  Pinned through the reference's own engines
+ * (tests/test_gpu_dp_pipeline.py). */
 typedef struct { uint32_t readID, algnmt; int32_t score; uint32_t editdist, num_sameScore, cigarOffset; uint8_t strand, pad[3]; } s3_dp_single_result;
 int  s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const s3_seed_candidate *candidates, size_t nCandidates, int cutoffThreshold,
                       int softClipLeft, int softClipRight, s3_dp_single_result **results, size_t *nResults, char **cigarPool);
@@ -228,7 +231,8 @@ int  s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths, const 
  * cutoffs (DP2CPUAlgnThread).  pairFirstReads: index of the first read (even) of every pair to process, ascending.  stage =
  * S3_STAGE_DEEP_DP_ROUND1 / ROUND2.  tooManyHits (optional, one byte per input pair): bit 0 = a seed of the pair was dropped for too many hits,
  * bit 1 = the pair had candidate positions (pairs with bit 0 and without bit 1 are what the reference seeds again in round 2, :3110-3121).
- * Arrays are malloc'ed: release with s3_free.  PARITY UNPINNED. */
+ * Arrays are malloc'ed: release with s3_free.  Pinned through the reference's own engines
+ * (tests/test_gpu_dp_pipeline.py). */
 typedef struct {
     uint32_t readID;                 /* first read of the pair */
     uint32_t algnmt_1, algnmt_2;
@@ -246,7 +250,8 @@ int  s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *read
  * (PairEndSeedingBatch::packSeedsOneSide, DV-DPfunctions.cu:2756-2776), only its mate is seeded (S3_STAGE_NEW_DEFAULT_DP), both lists go through the
  * deep DP's pairing and its two DP rounds (pairEndMerge, PairEndAlignmentEngine), so BOTH ends are aligned by the DP and the results are deep-DP
  * results.  occ: the aligned ends' hits, grouped by pair, pairs ascending (the ReadInputForDP stream).  pairFirstReads / pairFlags (optional
- * outputs): the pairs found in occ and their flags as in s3_dp_deep.  PARITY UNPINNED. */
+ * outputs): the pairs found in occ and their flags as in s3_dp_deep.  Pinned through the reference's own engines
+ * (tests/test_gpu_dp_pipeline.py). */
 int  s3_dp_new_default(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const s3_occ *occ, size_t nOcc, uint32_t maxHitNum,
                        int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_deep_result **results,
                        size_t *nResults, char **cigarPool, uint8_t **pairFlags, uint32_t **pairFirstReads, size_t *nPairs);

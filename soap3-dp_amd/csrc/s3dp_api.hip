@@ -271,7 +271,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskEnd, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
-    BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4); BA(dTrunk, 16); b->trunkCap = 16;
+    BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4); BA(dTrunk, 16); b->trunkCap = 16; BA(dItemAcc, 16); b->accCap = 16;
     b->countCap = b->maxItems + 1;
     BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
     BA(dWithError, (size_t)maxReads * 8);
@@ -498,6 +498,13 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     out.trunkStates = b->dTrunk;
                     out.readCut = b->dLongList;                                // (free until the merge kernels list their long reads)
                     HIPCHK(hipMemsetAsync(b->dLongList, 0xFF, (size_t)nHeavy * 4, b->stream));
+                    if ((size_t)nHeavy * groups > b->accCap) {
+                        int rc = bgrow(b, &b->dItemAcc, (size_t)nHeavy * groups * 5 / 4, 0);
+                        if (rc) return rc;
+                        b->accCap = (size_t)nHeavy * groups * 5 / 4;
+                    }
+                    HIPCHK(hipMemsetAsync(b->dItemAcc, 0, (size_t)nHeavy * groups * 4, b->stream));
+                    out.itemAcc = b->dItemAcc;
                     SearchIn in2 = in;
                     in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu;
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;

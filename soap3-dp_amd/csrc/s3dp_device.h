@@ -82,6 +82,7 @@ struct SearchOut {
     uint32_t           *heavyList, *heavyCount;
     uint32_t           *heavyIndex; // per listed slot: its place in heavyList
     uint32_t           *readCut;     // second pass, per listed read: the smallest unit (item * units + position) that holds maxOut occurrences by itself
+    uint32_t           *itemAcc;     // second pass, per listed read and item: occurrences its units hold for sure (sums over the items give the cut too)
     uint4              *trunkStates; // second pass: {l, r, rev l, valid} per (listed read, item, position), written by the trunk pass
 };
 

@@ -214,7 +214,7 @@ extern "C" int s3_dp_align(s3_dp *h, const uint32_t *packedDNA, const uint32_t *
 //   DP_Space::algnmtCPUThread   :2329-2441  pattern -> CIGAR, edit distance, insert size       -> decode loop below
 //   CigarStringEncoder          DV-DPfunctions.h:548-597
 // The reference packs windows on the host and copies them to the card; here text and reads already live in HBM, only the candidate
-// list travels.  PARITY UNPINNED (host code inside a CUDA source file): restated from the source, checked on simulated indel pairs.
+// list travels.  Pinned: the reference's own engine runs in the oracle harness (tests/test_gpu_dp_pipeline.py).
 // ---------------------------------------------------------------------------------------------
 struct DpCand { uint32_t readId, strand, start, dnaLen; };     // read to align (global index), strand to pack it in, window start / length
 
@@ -556,7 +556,7 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
 //   decodeMergePositions :2960-2990                    both orientations, candidates ordered by the left read
 //   PairEndAlgnBatch::packLeft / packRight :3374-3472  left end first; the right end's window is cut by the left hit and the insert bounds
 //   DP2CPUAlgnThread :3731-3828                        both scores above their cutoffs -> CIGARs, edit distances, insert size
-// Seeds and DP run on the device (the seed batch is a second s3_batch); the sequential merge runs on the host.  PARITY UNPINNED.
+// Seeds and DP run on the device (the seed batch is a second s3_batch); the sequential merge runs on the host.  Pinned through the reference's own engines (tests/test_gpu_dp_pipeline.py).
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct PairCand { uint32_t pos[2]; uint32_t readIDLeft; };

@@ -52,6 +52,7 @@ struct s3_batch {
     uint8_t  *dHeavyFlags = nullptr;                 // reads the first search pass listed for the exact pass (s3dp_search_v2.hip)
     uint32_t *dHeavyList = nullptr, *dHeavyCount = nullptr, *dHeavyIndex = nullptr;
     uint32_t *dLongList = nullptr, *dLongCount = nullptr;      // reads whose slice of the ordered array is walked by a whole wave (merge / decode)
+    uint32_t *dItemAcc = nullptr; size_t accCap = 0;            // per listed read and item: certain occurrences (second search pass)
     uint4 *dTrunk = nullptr; size_t trunkCap = 0;              // trunk states of the second search pass
     size_t countCap = 0;                                       // entries of dItemCounts / dItemOffsets (items + units of the listed reads + 1)
     uint32_t mergeUnitBase = 0, mergeUnitsPerRead = 0;         // of the last search pass (0: no read was taken apart)

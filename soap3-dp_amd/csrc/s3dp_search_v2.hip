@@ -213,7 +213,16 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     if (readTotal + total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - readTotal - total - 1u;
                     emit(0, l, rr_, (uint32_t)(ins + occ));
                     total += rr_ - l + 1u;
-                    if (in.unitMode && total >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
+                    if (in.unitMode) {
+                        if (total >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
+                        // ... and so do the items up to this one together (the running total of the item-wise walk, kept per item here): everything
+                        // behind this item's last unit then lies behind the cut
+                        uint32_t *acc = out.itemAcc + (size_t)(cutPtr - out.readCut) * groups;
+                        atomicAdd(&acc[sub], rr_ - l + 1u);
+                        uint32_t pre = 0;
+                        for (uint32_t q = 0; q <= sub; q++) pre += __hip_atomic_load(&acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (pre >= in.maxOut) atomicMin((uint32_t *)cutPtr, sub * U + U - 1u);
+                    }
                 }
                 needPop = true;                                              // the DFS goes on in the same trip
                 continue;

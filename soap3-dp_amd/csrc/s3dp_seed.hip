@@ -13,7 +13,7 @@ using namespace s3i;
 // (alignment.cu:1839-1894) + the hit limit of hostKernelSingle (CPUfunctions.cpp:2843-2876: a seed with more than maxHitNum hits is
 // dropped), decodePositions (:1143-1219, sorted by strand, read, position) and singleMerge (:1102-1141, positions closer than
 // DPS_DIVIDE_GAP = 50 collapse into the first).  Everything runs on the device next to the resident reads; the seed batch is an
-// ordinary s3_batch.  PARITY UNPINNED (host code inside CUDA sources); tested against a restatement built on the pinned search oracle.
+// ordinary s3_batch.  Pinned through the reference's own seeding engines in the oracle harness (tests/test_gpu_dp_pipeline.py); also tested against a restatement built on the pinned search oracle.
 // ---------------------------------------------------------------------------------------------
 
 __global__ void seedPackKernel(uint32_t nSeeds, const SeedDesc *seeds, const uint32_t *queries, uint32_t wpq, uint32_t *seedQueries, uint32_t seedWpq,

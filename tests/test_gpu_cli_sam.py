@@ -154,7 +154,7 @@ def test_cli_sam_pairs_c3_shape(tmp_path, variant, opts):
 
 def test_cli_default_mode_single_reads_with_dp(tmp_path):
     """`soap3-dp single <index> <reads>` without -s: BWT stage at Soap3MisMatchAllow = 2 mismatches into .gout.1, the reads it leaves unaligned
-    through seeding + DP into .dpout.1.  The DP engines are unpinned: the check is semantic -- every read is reported once, the
+    through seeding + DP into .dpout.1.  (Property test kept from round 1; the record-for-record comparison with the reference's own engines is tests/test_gpu_dp_pipeline.py.)  The check is semantic -- every read is reported once, the
     damaged reads (indels, 5 substitutions) come back at their true place with a CIGAR of the expected shape."""
     import re
     import numpy as np

@@ -1,5 +1,5 @@
 """-m gpu: default DP for half-aligned pairs (s3_dp_half_end: window geometry + device packing + DP + CIGAR decode).
-The reference's engine is host code inside a CUDA source file and cannot be built here (parity unpinned); this test checks the
+Property test kept from round 1 (the record-for-record comparison with the reference's own engine is tests/test_gpu_dp_pipeline.py); it checks the
 semantics on simulated pairs whose second end carries a known insertion / deletion / substitutions: the end is found at the right
 place, and the CIGAR, applied to the reference, reproduces the read with exactly the reported score and edit distance."""
 import re

@@ -1,6 +1,6 @@
 """-m gpu: seeding for the DP stages (s3_seed_candidates: seed packing, exact + 1-mismatch seed search, hit limit, estimated positions,
 merge) against a restatement built here on the pinned search oracle; plus the semantic check that reads too damaged for the BWT stage
-get their true position among the candidates.  (The reference's seeding engine is host code inside CUDA sources: parity unpinned.)"""
+get their true position among the candidates.  (Kept from round 1; the reference's own seeding engines are compared in tests/test_gpu_dp_pipeline.py.)"""
 import ctypes as C
 
 import numpy as np
