@@ -457,7 +457,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
         if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
         {
-            static const unsigned blocksPerCu = (unsigned)envSize("S3DP_BLOCKS_PER_CU", S3_V2_WAVES_PER_SIMD);
+            // persistent grid: what is resident at once (4 blocks per CU), or less when several batches share the device (the streamed form: a
+            // narrower grid per batch lets the kernels of two batches run side by side and fill each other's tails)
+            static const unsigned blocksPerCuEnv = (unsigned)envSize("S3DP_BLOCKS_PER_CU", 0);
+            const unsigned blocksPerCu = blocksPerCuEnv ? blocksPerCuEnv : (b->blocksPerCu ? b->blocksPerCu : S3_V2_WAVES_PER_SIMD);
             hipError_t le = (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
             if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
             if (in.heavyLimit != 0xFFFFFFFFu) {

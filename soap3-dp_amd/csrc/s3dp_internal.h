@@ -57,6 +57,7 @@ struct s3_batch {
     size_t countCap = 0;                                       // entries of dItemCounts / dItemOffsets (items + units of the listed reads + 1)
     uint32_t mergeUnitBase = 0, mergeUnitsPerRead = 0;         // of the last search pass (0: no read was taken apart)
     uint32_t uniformLen = 0;
+    unsigned blocksPerCu = 0;                         // width of the persistent search grid (0: all that is resident at once)
     uint32_t *dKept = nullptr, *dOccCounts = nullptr, *dCeCounts = nullptr, *dTotalOcc = nullptr, *dWithError = nullptr;
     uint32_t *dHitOffsets = nullptr;
     s3::DevHit   *dHits = nullptr;

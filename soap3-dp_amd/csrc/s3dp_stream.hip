@@ -139,6 +139,8 @@ extern "C" int s3_stream_create(s3_index *ix, uint32_t maxReads, uint32_t wordPe
     for (Slot &s : st->slots) {
         int rc = s3_batch_create(ix, maxReads, wordPerQuery, &s.b);
         if (rc) { s3_stream_free(st); return rc; }
+        // the slots share the device: half-width search grids, so that the kernels of two batches are resident together (S3DP_STREAM_BLOCKS_PER_CU)
+        if (depth > 1) s.b->blocksPerCu = (unsigned)envSize("S3DP_STREAM_BLOCKS_PER_CU", 2);
 #define PIN(p, bytes) do { hipError_t e_ = hipHostMalloc((void **)&(p), (bytes), hipHostMallocDefault); \
         if (e_ != hipSuccess) { s3_stream_free(st); return fail(S3_ENOMEM, std::string("hipHostMalloc(stream staging): ") + hipGetErrorString(e_)); } } while (0)
         PIN(s.hQueries, roundUp * wordPerQuery * 4); PIN(s.hLens, roundUp * 4); PIN(s.hSeedLens, roundUp * 4);
