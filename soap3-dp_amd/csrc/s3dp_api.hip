@@ -418,9 +418,11 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     // S3DP_HEAVY=0 switches the second pass off (every read is walked by one lane: same results; reads in repeat families then hold the launch up);
-    // n > 1: list a read once it has reserved more than n candidates (default: 256)
+    // n > 1: list a read once it has reserved more than n candidates (default 1024); S3DP_HEAVY_RANK: ... or cost more than that many rank queries
+    // (default 4096: dead ends cost steps, not candidates)
     const size_t heavyEnv = envSize("S3DP_HEAVY", 1);                       // read per pass: tests switch it
-    in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : 256u);
+    in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : 1024u);
+    in.heavyRank = heavyEnv == 0 ? 0xFFFFFFFFu : (uint32_t)envSize("S3DP_HEAVY_RANK", heavyEnv > 1 && heavyEnv < 64 ? 64 : 4096);
     in.slotList = nullptr; in.slotCount = nullptr;
     // units of the second pass: first-mismatch positions of an item's first mismatch step, + 1 for "none" -- the longest such step over the cases
     // and over the read lengths this batch can hold (S3DP_UNITS=0: whole items)
@@ -509,7 +511,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     HIPCHK(hipMemsetAsync(b->dItemAcc, 0, (size_t)nHeavy * groups * 4, b->stream));
                     out.itemAcc = b->dItemAcc;
                     SearchIn in2 = in;
-                    in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu;
+                    in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu; in2.heavyRank = 0xFFFFFFFFu;
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
                     in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (check-and-extend and the scatter decode unit indices with them)
                     for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass

@@ -56,6 +56,7 @@ struct SearchIn {
     uint32_t        uniformLen;  // != 0: every active read has this length (model kept in LDS by the v2 kernel)
     uint32_t        earlyMinI;   // ... but only once this many characters are matched: a chance match of the lookup characters costs a step (one line) to drop,
                                  // a candidate three lines to verify
+    uint32_t        heavyRank;   // first pass: ... or that has cost more rank queries than this
     uint32_t        heavyLimit;  // first pass: a read that reserves more check-and-extend candidates than this is listed for the second pass
     const uint32_t *slotList;    // second pass (item mode: one work unit per item of a listed read): the listed slots ...
     const uint32_t *slotCount;   // ... and how many (device memory, written by the first pass)

@@ -145,6 +145,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     uint32_t cntIdx = 0, seq = 0, total = 0, rIdx = 0, loadOff = 0, slotIdx = 0, sub = 0;
     uint32_t readTotal = 0;                                                 // occurrences the read's finished items have for sure (the cut at maxOut runs across items)
     uint32_t readCand = 0;                                                  // check-and-extend candidates this read has reserved
+    uint32_t readRank = 0;                                                  // rank queries this read has cost so far (first pass)
     bool goHeavy = false;
     int Li = 0, nSteps = 0;
     uint32_t casIdx = 0;
@@ -364,7 +365,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         if (in.unitMode == 1u) out.itemCounts[slotIdx * groups + sub] = 0;
                     }
                     rIdx = in.active ? (off < 64u ? a0 : a1) : slotIdx;
-                    readTotal = 0; readCand = 0;
+                    readTotal = 0; readCand = 0; readRank = 0;
                     if constexpr (UNIFORM) Li = (int)in.uniformLen;
                     casIdx = sub >> 1; strand = sub & 1u;
                     nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
@@ -489,6 +490,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         // ---------- advance ----------
         bool doSettle = false, needPop = false;
         if (in.unitMode && (state == ST_STEP || state == ST_TRUNK) && unitInRead > d1) { state = ST_DONE; sp = 0; }    // behind the read's cut
+        // first pass: a read that has cost this many rank queries is heavy whatever it has found so far (dead ends cost steps, not candidates)
+        if (!in.unitMode && state == ST_STEP && readRank > in.heavyRank) { goHeavy = true; state = ST_DONE; sp = 0; }
         if (state == ST_STEP) {
             const S3Step stS = stepAt(s);
             const bool exact = ins >= stS.maxErr;
@@ -504,6 +507,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 oR = rankFromWords(qR, occA, myStage32[offR], myStage32[offR + 1u], myStage32[12u + (qR.fwd ? 1u : 0u)]);
             }
             nRank += 2;
+            readRank += 2;
             const int pos = stS.start + stS.dir * i;
             const uint32_t ch = readChar(pos);
             // child ranges: the active range advances by rank, the passive one shrinks by the occurrences of the larger symbols
