@@ -215,14 +215,28 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     emit(0, l, rr_, (uint32_t)(ins + occ));
                     total += rr_ - l + 1u;
                     if (in.unitMode) {
-                        if (total >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
-                        // ... and so do the items up to this one together (the running total of the item-wise walk, kept per item here): everything
-                        // behind this item's last unit then lies behind the cut
+                        // The running total of an item-wise walk, kept where the units of a read can all see it: per item (itemAcc) and, inside the item,
+                        // per position (the spare word of the trunk states: 1 + what the unit at that position holds for sure; the last unit's slot is
+                        // not a trunk state and starts from 0).  Everything in sequence order up to and including this unit that adds up to MaxOutputPerRead
+                        // puts the read's cut right behind this unit; the items up to this one adding up to it put it behind the item.
+                        const uint32_t cnt = rr_ - l + 1u;
                         uint32_t *acc = out.itemAcc + (size_t)(cutPtr - out.readCut) * groups;
-                        atomicAdd(&acc[sub], rr_ - l + 1u);
-                        uint32_t pre = 0;
-                        for (uint32_t q = 0; q <= sub; q++) pre += __hip_atomic_load(&acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (pre >= in.maxOut) atomicMin((uint32_t *)cutPtr, sub * U + U - 1u);
+                        atomicAdd(&acc[sub], cnt);
+                        uint32_t before = 0;
+                        for (uint32_t q = 0; q < sub; q++) before += __hip_atomic_load(&acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t mine = __hip_atomic_load(&acc[sub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (before + mine >= in.maxOut) atomicMin((uint32_t *)cutPtr, sub * U + U - 1u);
+                        if (U > 1u) {
+                            const uint32_t myPos = unitInRead - sub * U;
+                            uint4 *ts = out.trunkStates + (cntIdx - in.unitBase) - myPos;
+                            atomicAdd(&ts[myPos].w, cnt);
+                            uint32_t upTo = before;
+                            for (uint32_t q = 0; q <= myPos; q++) {
+                                const uint32_t w = __hip_atomic_load(&ts[q].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                upTo += q + 1u == U ? w : (w ? w - 1u : 0u);
+                            }
+                            if (upTo >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
+                        } else if (total >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
                     }
                 }
                 needPop = true;                                              // the DFS goes on in the same trip
