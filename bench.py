@@ -81,7 +81,13 @@ def _plant(codes, unit, copies, frac_lo, frac_hi, young_share, young_div, old_di
         else:
             dst = torch.randint(0, n - ulen - 1, (m,), generator=g, device=dev)
         flat = dst[:, None] + ar[None, :]
-        codes[flat[valid]] = piece[valid]
+        # copies of one call may overlap: the later copy wins, whatever order the device writes in (a plain indexed store with duplicate indices is
+        # not deterministic on the GPU, and every rank -- and every run that reuses the index files -- must see the SAME genome)
+        idx, vals = flat[valid], piece[valid]
+        idx, order = torch.sort(idx, stable=True)
+        last = torch.ones_like(idx, dtype=torch.bool)
+        last[:-1] = idx[1:] != idx[:-1]
+        codes[idx[last]] = vals[order[last]]
         done += m
 
 
@@ -144,6 +150,18 @@ def make_genome(n, seed, device, repeat_frac=0.0):
         codes[a:b] = torch.randint(0, 4, (b - a,), generator=g, device=device, dtype=torch.uint8)
     families = plant_repeats(codes, repeat_frac, seed + 1) if repeat_frac > 0 else {}
     return codes, families
+
+
+def genome_checksum(codes):
+    """position-weighted sum of the text (kept next to the index files of --index-dir: an index is only reused for the genome it was built from)"""
+    import torch
+    tot = 0
+    step = 1 << 28
+    for a in range(0, codes.numel(), step):
+        c = codes[a:a + step].to(torch.int64)
+        w = (torch.arange(a, a + c.numel(), device=codes.device, dtype=torch.int64) % 65521) + 1
+        tot = (tot + int((c * w).sum())) % (1 << 61)
+    return tot
 
 
 def make_reads(codes, n_reads, L, seed, device, mix=(0.55, 0.25, 0.12, 0.05, 0.03)):
@@ -407,16 +425,26 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     t0 = time.perf_counter()
     keep_dir = a.index_dir or index_dir
     prefix = os.path.join(keep_dir, "bench_%s_%d.index" % (label, a.genome_bp)) if keep_dir else None
-    if prefix and os.path.exists(prefix + ".sa") and a.index_dir:
+    gsum = genome_checksum(codes)
+    reuse = False
+    if prefix and a.index_dir and os.path.exists(prefix + ".sa") and os.path.exists(prefix + ".genome_sum"):
+        reuse = open(prefix + ".genome_sum").read().strip() == str(gsum)
+        if not reuse:
+            log("[%s] index files under %s belong to another genome: rebuilding" % (label, keep_dir))
+    if reuse:
         hi = s3dp.HostIndex.from_files(prefix)
     elif world > 1 or prefix:
         if rank == 0:
             os.makedirs(keep_dir, exist_ok=True)
             hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=True)
             hi.write_files(prefix, with_lkt=True)
+            with open(prefix + ".genome_sum", "w") as f:
+                f.write("%d\n" % gsum)
         if world > 1:
             dist.barrier()
             if rank != 0:
+                if open(prefix + ".genome_sum").read().strip() != str(gsum):
+                    raise SystemExit("bench.py: rank %d generated a different genome than rank 0" % rank)
                 hi = s3dp.HostIndex.from_files(prefix)
     else:
         hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=(rank == 0))

@@ -55,28 +55,36 @@ static int devAlloc(s3_index *ix, T **p, size_t count)
     return S3_OK;
 }
 
+namespace {
+struct DevTmp {                                    // a device allocation that lives as long as the scope (error returns included)
+    void *p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
 static int uploadHalf(s3_index *ix, const s3_bwt_desc &h, DevBwt *out, hipStream_t s)
 {
     if (!h.bwt || !h.occ) return fail(S3_EINVAL, "s3_index_upload: missing bwt/occ array");
     const size_t expectRecs = ((size_t)h.cumFreq[4] + 127) / 128 + 1;
     if (h.occRecs != expectRecs) return fail(S3_EINVAL, "s3_index_upload: occRecs does not match textLength");
-    uint32_t *tb = nullptr, *to = nullptr;
+    DevTmp tbHold, toHold;                         // staging of the file layout: gone when this returns, on every path
     uint4 *lines = nullptr;
-    HIPCHK(hipMalloc((void **)&tb, h.bwtWords * 4 + 16));
-    HIPCHK(hipMalloc((void **)&to, h.occRecs * 16));
+    HIPCHK(hipMalloc(&tbHold.p, h.bwtWords * 4 + 16));
+    HIPCHK(hipMalloc(&toHold.p, h.occRecs * 16));
+    uint32_t *tb = (uint32_t *)tbHold.p, *to = (uint32_t *)toHold.p;
     int rc = devAlloc(ix, &lines, h.occRecs * 4);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(tb, h.bwt, h.bwtWords * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(to, h.occ, h.occRecs * 16, hipMemcpyHostToDevice, s));
     launchRelayout(tb, h.bwtWords, to, h.occRecs, lines, s);
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipFree(tb));
-    HIPCHK(hipFree(to));
     out->lines = lines;
     out->inverseSa0 = h.inverseSa0;
     out->n = h.cumFreq[4];
     return S3_OK;
 }
+
+static int indexUploadBody(s3_index *ix, const s3_index_desc *desc, hipStream_t s);
 
 extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index **outp)
 {
@@ -89,8 +97,19 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     HIPCHK(hipSetDevice(device));
     s3_index *ix = new s3_index();
     ix->dev = device;
-    hipStream_t s;
-    HIPCHK(hipStreamCreate(&s));
+    hipStream_t s = nullptr;
+    hipError_t es = hipStreamCreate(&s);
+    if (es != hipSuccess) { delete ix; return fail(S3_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(es)); }
+    // whatever goes wrong below: the object, its device memory (up to 120 GB with the 16-mer tables) and the stream are released
+    const int rc = indexUploadBody(ix, desc, s);
+    (void)hipStreamDestroy(s);
+    if (rc) { s3_index_free(ix); return rc; }
+    *outp = ix;
+    return S3_OK;
+}
+
+static int indexUploadBody(s3_index *ix, const s3_index_desc *desc, hipStream_t s)
+{
     // S3DP_VERBOSE=1: where the upload's time goes (stderr)
     static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
     auto tUp = std::chrono::steady_clock::now();
@@ -103,15 +122,16 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     };
     int rc = uploadHalf(ix, desc->fwd, &ix->d.fwd, s);
     if (!rc) rc = uploadHalf(ix, desc->rev, &ix->d.rev, s);
-    if (rc) { s3_index_free(ix); return rc; }
+    if (rc) return rc;
     lap("BWT + occurrence, both");
     const uint32_t n = desc->textLength;
     uint32_t *sa = nullptr, *pac = nullptr, *lkt = nullptr, *rlkt = nullptr;
     const size_t ltWords = (size_t)1 << (2 * desc->lktSize);
     const size_t pacWords = desc->packedWords + 4;                     // + zero tail so 3-word windows never leave the buffer
     if ((rc = devAlloc(ix, &sa, (size_t)n + 1)) || (rc = devAlloc(ix, &pac, pacWords)) || (rc = devAlloc(ix, &lkt, ltWords)) ||
-        (rc = devAlloc(ix, &rlkt, ltWords))) { s3_index_free(ix); return rc; }
+        (rc = devAlloc(ix, &rlkt, ltWords))) return rc;
     const uint32_t saInterval = desc->saInterval > 1 ? desc->saInterval : 1;
+    DevTmp samplesHold;
     uint32_t *saSamples = nullptr;
     {
         // the suffix array in pieces: as one 12 GB copy from pageable memory it takes the runtime's staging path (3.4 GB/s measured); pieces of this size
@@ -119,8 +139,8 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
         const size_t entries = saInterval > 1 ? ((size_t)n + saInterval) / saInterval : (size_t)n + 1;
         uint32_t *dst = sa;
         if (saInterval > 1) {
-            HIPCHK(hipMalloc((void **)&saSamples, entries * 4));
-            dst = saSamples;
+            HIPCHK(hipMalloc(&samplesHold.p, entries * 4));
+            dst = saSamples = (uint32_t *)samplesHold.p;
         }
         const size_t total = entries * 4, pieceMb = envSize("S3DP_H2D_PIECE_MB", 128), piece = pieceMb ? pieceMb << 20 : total;
         for (size_t off = 0; off < total; off += piece)
@@ -130,7 +150,6 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
             launchSaExpand(ix->d.fwd, saSamples, saInterval, n, sa, s);
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(hipGetLastError());
-            (void)hipFree(saSamples);
         }
     }
     HIPCHK(hipMemsetAsync(pac, 0, pacWords * 4, s));
@@ -178,7 +197,7 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
                 break;
             }
             (void)hipGetLastError();
-            if (e != (int)hipErrorOutOfMemory) { s3_index_free(ix); return fail(S3_EHIP, std::string("long lookup tables: ") + hipGetErrorString((hipError_t)e)); }
+            if (e != (int)hipErrorOutOfMemory) { return fail(S3_EHIP, std::string("long lookup tables: ") + hipGetErrorString((hipError_t)e)); }
         }
     }
     lap("long lookup tables");
@@ -187,14 +206,12 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     for (int e = 0; e <= S3_MAX_MISMATCH; e++) {
         memset(host.data(), 0, host.size() * sizeof(S3Model));
         for (int L = 1; L <= S3_MAX_READ_LENGTH; L++) s3_model_build(L, e, &host[L]);
-        if ((rc = devAlloc(ix, &ix->models[e], host.size()))) { s3_index_free(ix); return rc; }
+        if ((rc = devAlloc(ix, &ix->models[e], host.size()))) return rc;
         HIPCHK(hipMemcpyAsync(ix->models[e], host.data(), host.size() * sizeof(S3Model), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
     }
     HIPCHK(hipStreamSynchronize(s));
     lap("model tables");
-    HIPCHK(hipStreamDestroy(s));
-    *outp = ix;
     return S3_OK;
 }
 
@@ -263,12 +280,14 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     if (recCap > 0xFFFFFF00ull) recCap = 0xFFFFFF00ull;
     if (occCap > 0xFFFFFF00ull) occCap = 0xFFFFFF00ull;
     b->recCap = (uint32_t)recCap; b->occCap = (uint32_t)occCap;
-    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    // from here on every error return goes through s3_batch_free
+#define HIPB(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { s3_batch_free(b); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    HIPB(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
     BA(dRecs, recCap); BA(dOrdered, recCap); b->ordCap = recCap;
-    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskEnd, 4); BA(dSum64, 2);
+    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dReadAcc, 2 * ((size_t)maxReads + 64)); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
     BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4); BA(dTrunk, 16); b->trunkCap = 16; BA(dItemAcc, 16); b->accCap = 16;
@@ -295,13 +314,14 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     }
     b->tempBytes = (t1 > t2 ? t1 : t2) + 256;
     if ((rc = balloc(b, &b->dTemp, b->tempBytes))) { s3_batch_free(b); return rc; }
-    HIPCHK(hipEventCreate(&b->evTotal[0])); HIPCHK(hipEventCreate(&b->evTotal[1]));
-    b->evSearch.resize(16);
-    for (auto &e : b->evSearch) HIPCHK(hipEventCreate(&e));
-    b->evCe.resize(16);
-    for (auto &e : b->evCe) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPB(hipEventCreate(&b->evTotal[0])); HIPB(hipEventCreate(&b->evTotal[1]));
+    b->evSearch.assign(256, nullptr);
+    for (auto &e : b->evSearch) HIPB(hipEventCreate(&e));
+    b->evCe.assign(256, nullptr);
+    for (auto &e : b->evCe) HIPB(hipEventCreate(&e));
+    HIPB(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    HIPB(hipStreamSynchronize(b->stream));
+#undef HIPB
     *outp = b;
     return S3_OK;
 }
@@ -410,9 +430,9 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             in.sStarPacked |= (uint32_t)sStar << (3 * c);
         }
     }
-    in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0;
+    in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0; in.itemLo = 0; in.itemSpan = 0;
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
-    unsigned long long counterSnap[8];
+    unsigned long long counterSnap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (b->counting) {
         HIPCHK(hipMemcpyAsync(counterSnap, b->dCounters, 64, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
@@ -457,14 +477,47 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         out.heavyFlags = b->dHeavyFlags; out.heavyList = b->dHeavyList; out.heavyCount = b->dHeavyCount; out.heavyIndex = b->dHeavyIndex;
         nHeavy = 0; nCount = (uint32_t)nItems;
         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-        if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2], b->stream));
+        // timing: one event pair per group of stepping launches / per check-and-extend launch (they alternate when the second pass runs in rounds)
+        auto mark = [&](std::vector<hipEvent_t> &ev, uint32_t &used, bool begin) -> hipError_t {
+            if ((size_t)used * 2 + 1 >= ev.size()) return hipSuccess;
+            const hipError_t e = hipEventRecord(ev[used * 2 + (begin ? 0 : 1)], b->stream);
+            if (!begin) used++;
+            return e;
+        };
+        HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
         {
             // persistent grid: what is resident at once (4 blocks per CU), or less when several batches share the device (the streamed form: a
             // narrower grid per batch lets the kernels of two batches run side by side and fill each other's tails)
             static const unsigned blocksPerCuEnv = (unsigned)envSize("S3DP_BLOCKS_PER_CU", 0);
             const unsigned blocksPerCu = blocksPerCuEnv ? blocksPerCuEnv : (b->blocksPerCu ? b->blocksPerCu : S3_V2_WAVES_PER_SIMD);
+            // S3DP_VERBOSE=1 with counters enabled: reads, listed reads, rank queries and milliseconds of every launch of this pass (stderr)
+            static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
+            unsigned long long rankSeen = counterSnap[0];
+            auto lapT = std::chrono::steady_clock::now();
+            auto lap = [&](const char *what, uint64_t units) {
+                if (!verbose || !b->counting) return;
+                unsigned long long c[2] = {0, 0};
+                (void)d2h(c, b->dCounters, 16, b->stream);
+                const auto now = std::chrono::steady_clock::now();
+                fprintf(stderr, "[s3dp] search mm=%u %-12s %10llu units %8.2f ms %12llu rank queries\n", modelMm, what, (unsigned long long)units,
+                        std::chrono::duration<double, std::milli>(now - lapT).count(), c[0] - rankSeen);
+                rankSeen = c[0]; lapT = now;
+            };
+            if (verbose && b->counting) { (void)hipStreamSynchronize(b->stream); lapT = std::chrono::steady_clock::now(); }
             hipError_t le = (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
             if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
+            lap("first pass", nActive);
+            HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
+            // check-and-extend takes the task records written since its last launch: dTaskRange = {first, end}; what it accepts is appended behind them
+            auto checkExtend = [&]() -> int {
+                HIPCHK(hipMemcpyAsync(b->dTaskRange + 1, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
+                HIPCHK(mark(b->evCe, b->evCeUsed, true));
+                launchCheckExtend(b->ix->d, in, out, b->dTaskRange, b->stream);
+                HIPCHK(mark(b->evCe, b->evCeUsed, false));
+                HIPCHK(hipMemcpyAsync(b->dTaskRange, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
+                return S3_OK;
+            };
+            HIPCHK(hipMemsetAsync(b->dTaskRange, 0, 8, b->stream));
             if (in.heavyLimit != 0xFFFFFFFFu) {
                 // second pass: the listed reads taken apart into units.  Their number sizes the count / offset arrays: one host round trip (the first
                 // pass is short: it drops a heavy read after a few hundred candidates)
@@ -492,14 +545,16 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     }
                     nCount = (uint32_t)(need - 1);
                     HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, (need - nItems) * 4, b->stream));
+                    // the listed reads count per unit from here on
+                    launchZeroListedCounts(b->dHeavyList, b->dHeavyCount, nHeavy, (uint32_t)groups, b->dItemCounts, b->stream);
                     // the trunk states: 16 B per (listed read, item, position)
                     const size_t nStates = (size_t)nHeavy * groups * U;
-                    if (U > 1 && nStates > b->trunkCap) {
+                    if (nStates > b->trunkCap) {
                         int rc = bgrow(b, &b->dTrunk, nStates + nStates / 4, 0);
                         if (rc) return rc;
                         b->trunkCap = nStates + nStates / 4;
                     }
-                    if (U > 1) HIPCHK(hipMemsetAsync(b->dTrunk, 0, nStates * sizeof(uint4), b->stream));
+                    HIPCHK(hipMemsetAsync(b->dTrunk, 0, nStates * sizeof(uint4), b->stream));
                     out.trunkStates = b->dTrunk;
                     out.readCut = b->dLongList;                                // (free until the merge kernels list their long reads)
                     HIPCHK(hipMemsetAsync(b->dLongList, 0xFF, (size_t)nHeavy * 4, b->stream));
@@ -510,24 +565,49 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     }
                     HIPCHK(hipMemsetAsync(b->dItemAcc, 0, (size_t)nHeavy * groups * 4, b->stream));
                     out.itemAcc = b->dItemAcc;
+                    // the running totals of the listed reads: [0, maxReads) now, [maxReads, 2 maxReads) as they stood when the round began
+                    uint32_t *accNow = b->dReadAcc, *accPrev = b->dReadAcc + b->maxReads;
+                    HIPCHK(hipMemsetAsync(accNow, 0, (size_t)nHeavy * 4, b->stream));
+                    out.readAcc = accNow; out.readAccPrev = accPrev;
                     SearchIn in2 = in;
                     in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu; in2.heavyRank = 0xFFFFFFFFu;
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
                     in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (check-and-extend and the scatter decode unit indices with them)
-                    for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass
-                        in2.unitMode = mode;
-                        HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-                        le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, b->stream);
-                        if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
+                    // ROUNDS.  The CPU path stops a read at MaxOutputPerRead occurrences, and most occurrences of a read inside a repeat family are
+                    // check-and-extend candidates: nobody knows how many of them hold until ceKernel has looked.  So the items of the listed reads are
+                    // can be searched in rounds of 1, 1, 2, 4, 8 ... items (S3DP_ROUNDS=1; default: all at once -- every round ends in the tail of its longest unit), check-and-extend after every round, and a read whose
+                    // running total -- certain occurrences + accepted candidates of all EARLIER rounds, nothing of the current one: units of one round
+                    // run side by side -- has reached the limit is closed: its later items lie behind the cut the merge will make, whatever they hold.
+                    static const bool rounds = envSize("S3DP_ROUNDS", 0) != 0;
+                    uint32_t lo = 0, size = 1, roundNo = 0;
+                    while (lo < (uint32_t)groups) {
+                        const uint32_t span = rounds ? std::min<uint32_t>(size, (uint32_t)groups - lo) : (uint32_t)groups;
+                        HIPCHK(hipMemcpyAsync(accPrev, accNow, (size_t)nHeavy * 4, hipMemcpyDeviceToDevice, b->stream));
+                        in2.itemLo = lo; in2.itemSpan = span;
+                        HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
+                        for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass
+                            in2.unitMode = mode;
+                            HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
+                            le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, b->stream);
+                            if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
+                            lap(mode == 1 ? "trunk pass" : "unit pass", (uint64_t)nHeavy * span * (mode == 1 ? 1 : U));
+                        }
+                        HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
+                        int rc = checkExtend();
+                        if (rc) return rc;
+                        lap("check-extend", 0);
+                        lo += span;
+                        if (roundNo++ > 0) size *= 2;
                     }
                 }
             }
-            // the task records end where the stepping kernel stopped writing; the check-and-extend kernel appends behind them
-            HIPCHK(hipMemcpyAsync(b->dTaskEnd, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
-            if (b->searchLaunches * 2 + 1 < b->evSearch.size()) HIPCHK(hipEventRecord(b->evSearch[b->searchLaunches * 2 + 1], b->stream));
-            if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2], b->stream));
-            launchCheckExtend(b->ix->d, in, out, b->dTaskEnd, b->stream);
-            if (b->ceLaunches * 2 + 1 < b->evCe.size()) HIPCHK(hipEventRecord(b->evCe[b->ceLaunches * 2 + 1], b->stream));
+            if (!nHeavy) {
+                int rc = checkExtend();
+                if (rc) return rc;
+                lap("check-extend", 0);
+            }
+            if (verbose && b->counting)
+                fprintf(stderr, "[s3dp] search mm=%u listed reads %u of %u, units per item %u\n", modelMm, nHeavy, nActive, in.unitsPerItem);
         }
         // offsets of the items in the ordered array (the scan runs before the host looks at the flags: one synchronisation per pass for both answers)
         HIPCHK(hipMemsetAsync(b->dItemCounts + nCount, 0, 4, b->stream));
@@ -556,7 +636,6 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     b->searchLaunches++;
-    b->ceLaunches++;
     {
         // sequence numbers include the rejected check-and-extend candidates: the ordered array can need more slots than there are records
         if (slots > b->ordCap) {
@@ -604,7 +683,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
     if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
     HIPCHK(hipSetDevice(b->ix->dev));
-    b->searchLaunches = 0; b->ceLaunches = 0;
+    b->searchLaunches = 0; b->evSearchUsed = 0; b->evCeUsed = 0;
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
     if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
@@ -663,7 +742,7 @@ extern "C" int s3_batch_last_timing(s3_batch *b, float *totalMs, float *searchMs
     HIPCHK(hipStreamSynchronize(b->stream));
     float t = 0, s = 0;
     HIPCHK(hipEventElapsedTime(&t, b->evTotal[0], b->evTotal[1]));
-    uint32_t timed = b->searchLaunches;
+    uint32_t timed = b->evSearchUsed;
     if (timed * 2 > b->evSearch.size()) timed = (uint32_t)(b->evSearch.size() / 2);
     for (uint32_t i = 0; i < timed; i++) {
         float x = 0;
@@ -682,7 +761,7 @@ extern "C" int s3_batch_last_ce_timing(s3_batch *b, float *ceMs, uint32_t *ceLau
     HIPCHK(hipSetDevice(b->ix->dev));
     HIPCHK(hipStreamSynchronize(b->stream));
     float s = 0;
-    uint32_t timed = b->ceLaunches;
+    uint32_t timed = b->evCeUsed;
     if (timed * 2 > b->evCe.size()) timed = (uint32_t)(b->evCe.size() / 2);
     for (uint32_t i = 0; i < timed; i++) {
         float x = 0;

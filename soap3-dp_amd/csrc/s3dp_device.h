@@ -64,11 +64,13 @@ struct SearchIn {
     uint32_t        unitsPerItem;  // second pass: first-mismatch positions an item is cut into, + 1 for "none" (1: whole items)
     uint32_t        unitBase;      // second pass: unit u counts its records in itemCounts[unitBase + u]
     uint32_t        sStarPacked;   // 3 bits per case: the first step that allows a mismatch (= nSteps: none)
+    uint32_t        itemLo, itemSpan; // second pass: the items [itemLo, itemLo + itemSpan) of every listed read are this launch's (a ROUND of the pass)
     uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_v2.hip)
 };
 
 #define S3_REC_TASK  (1u << 28)
 #define S3_REC_PASS2 0x80000000u            // in the item word: record written by the second pass (records of a listed read without it are stale)
+#define S3_TRUNK_VALID 0x80000000u          // trunkStates[].w: the trunk pass reached this position
 #define S3_REC_EARLY (1u << 29)              // task written inside the exact lookup step (single-suffix range): the rest of that step is verified too
 
 struct SearchOut {
@@ -84,7 +86,9 @@ struct SearchOut {
     uint32_t           *heavyIndex; // per listed slot: its place in heavyList
     uint32_t           *readCut;     // second pass, per listed read: the smallest unit (item * units + position) that holds maxOut occurrences by itself
     uint32_t           *itemAcc;     // second pass, per listed read and item: occurrences its units hold for sure (sums over the items give the cut too)
-    uint4              *trunkStates; // second pass: {l, r, rev l, valid} per (listed read, item, position), written by the trunk pass
+    uint4              *trunkStates; // second pass: {l, r, rev l, S3_TRUNK_VALID | certain occurrences of the unit} per (listed read, item, position)
+    uint32_t           *readAcc;     // second pass, per listed read: occurrences found so far -- certain ones and accepted check-and-extend candidates
+    const uint32_t     *readAccPrev; // ... its value when the round began: a read that had maxOut by then is closed (everything later is behind the cut)
 };
 
 struct DevHit { uint32_t a, b, meta; };       // binary-identical to s3_hit (kind, strand, nmis, cas bytes)
@@ -124,10 +128,11 @@ struct DpArgs {
 int launchDp(const DpArgs &a, hipStream_t s);        // returns a hipError_t
 
 void launchOrientReads(const uint32_t *queries, const uint32_t *lengths, uint32_t *readsT, uint32_t n, uint32_t wpq, uint32_t S, hipStream_t s);
+void launchZeroListedCounts(const uint32_t *heavyList, const uint32_t *heavyCount, uint32_t nHeavy, uint32_t groups, uint32_t *itemCounts, hipStream_t s);
 void launchSaExpand(const DevBwt &b, const uint32_t *samples, uint32_t interval, uint32_t n, uint32_t *sa, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
 int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
-void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskEnd, hipStream_t s);
+void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskRange, hipStream_t s);
 int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int
 void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s);
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,

@@ -72,8 +72,10 @@ extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLe
     DA(dPattern, (size_t)maxProblems * h->patternLen);
     DA(dTable, h->tableWords * maxProblems);
 #undef DA
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreate(&h->ev[0])); HIPCHK(hipEventCreate(&h->ev[1]));
+#define HIPD(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { s3_dp_free(h); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    HIPD(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPD(hipEventCreate(&h->ev[0])); HIPD(hipEventCreate(&h->ev[1]));
+#undef HIPD
     *outp = h;
     return S3_OK;
 }

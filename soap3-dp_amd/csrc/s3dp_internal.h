@@ -46,12 +46,13 @@ struct s3_batch {
     uint32_t fullUniformLen = 0;
     // search / ordering work buffers
     uint4    *dRecs = nullptr, *dOrdered = nullptr;
-    uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr, *dTaskEnd = nullptr;
+    uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr, *dTaskRange = nullptr;
     unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;
     unsigned long long *dSum64 = nullptr;            // 64-bit total next to a 32-bit scan (sum64Async): a wrapped total must not pass as a small one
     uint8_t  *dHeavyFlags = nullptr;                 // reads the first search pass listed for the exact pass (s3dp_search_v2.hip)
     uint32_t *dHeavyList = nullptr, *dHeavyCount = nullptr, *dHeavyIndex = nullptr;
     uint32_t *dLongList = nullptr, *dLongCount = nullptr;      // reads whose slice of the ordered array is walked by a whole wave (merge / decode)
+    uint32_t *dReadAcc = nullptr;                               // running totals of the listed reads, now and at the start of the round (2 x maxReads)
     uint32_t *dItemAcc = nullptr; size_t accCap = 0;            // per listed read and item: certain occurrences (second search pass)
     uint4 *dTrunk = nullptr; size_t trunkCap = 0;              // trunk states of the second search pass
     size_t countCap = 0;                                       // entries of dItemCounts / dItemOffsets (items + units of the listed reads + 1)
@@ -89,8 +90,8 @@ struct s3_batch {
     bool counting = false;
     hipEvent_t evTotal[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> evSearch, evCe;          // per launch of the stepping kernel / of the check-and-extend kernel
-    uint32_t ceLaunches = 0;
-    uint32_t searchLaunches = 0;
+    uint32_t evSearchUsed = 0, evCeUsed = 0;         // event pairs in use
+    uint32_t searchLaunches = 0;                     // search passes of the last call
     uint32_t occUsed = 0;
     uint64_t recordsTotal = 0;      // records of all search passes of the last call (read back when counters are enabled)
 };

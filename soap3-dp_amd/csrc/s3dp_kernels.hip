@@ -17,7 +17,9 @@
 //     (exclusive scan of per-item counts), no sort, no fixed answer slots.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "s3dp_model.h"
+#include <algorithm>
 #include "s3dp_device.h"
 
 namespace s3 {
@@ -504,6 +506,22 @@ __global__ void fillInvalidKernel(uint4 *ordered, const uint32_t *total, uint32_
 void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s)
 {
     hipLaunchKernelGGL(fillInvalidKernel, dim3(2048), dim3(256), 0, s, ordered, total, cap);
+}
+
+// the listed reads count per unit: what the first pass left in their items' own counters (or never wrote) is void
+__global__ void zeroListedCountsKernel(const uint32_t *heavyList, const uint32_t *heavyCount, uint32_t groups, uint32_t *itemCounts)
+{
+    const uint64_t total = (uint64_t)*heavyCount * groups;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (uint64_t)gridDim.x * blockDim.x)
+        itemCounts[(size_t)heavyList[k / groups] * groups + (uint32_t)(k % groups)] = 0;
+}
+
+void launchZeroListedCounts(const uint32_t *heavyList, const uint32_t *heavyCount, uint32_t nHeavy, uint32_t groups, uint32_t *itemCounts, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)nHeavy * groups;
+    if (!total) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(zeroListedCountsKernel, dim3(blocks), dim3(256), 0, s, heavyList, heavyCount, groups, itemCounts);
 }
 
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,

@@ -197,7 +197,7 @@ extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t
     if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
     HIPCHK(hipSetDevice(b->ix->dev));
     const uint32_t n = b->n;
-    b->searchLaunches = 0; b->ceLaunches = 0;
+    b->searchLaunches = 0; b->evSearchUsed = 0; b->evCeUsed = 0;
     b->occUsed = 0;
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
@@ -367,7 +367,7 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
     if (rc) return rc;
     const bool bestMode = reportType >= 3, mapq = !bestMode;
     const uint32_t n = b->n, nPairs = n / 2;
-    b->searchLaunches = 0; b->ceLaunches = 0;
+    b->searchLaunches = 0; b->evSearchUsed = 0; b->evCeUsed = 0;
     b->occUsed = 0;
     b->xaUsed = 0;
     b->recordsTotal = 0;

@@ -133,10 +133,11 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         __syncthreads();
     }
 
-    const unsigned long long nSlots = in.unitMode ? (unsigned long long)*in.slotCount * ((uint32_t)in.nCases * 2u) * (in.unitMode == 2u ? in.unitsPerItem - 1u : 1u)
-                                                  : in.nActive;            // second pass: listed reads x items (x positions)
     const uint32_t nCases = (uint32_t)in.nCases;
     const uint32_t groups = nCases * 2u;
+    // second pass: listed reads x the items of this round (x the units of an item: every position of the mismatch step + "none")
+    const uint32_t unitsPerReadHere = in.unitMode ? in.itemSpan * (in.unitMode == 2u ? in.unitsPerItem : 1u) : 1u;
+    const unsigned long long nSlots = in.unitMode ? (unsigned long long)*in.slotCount * unitsPerReadHere : in.nActive;
     uint32_t nRank = 0, nLt = 0;
 
     // ---- per-lane item + search state ---------------------------------------------------------------------
@@ -153,7 +154,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     int s = 0, i = 0, ins = 0, occ = 0;
     // unit mode
     const uint32_t U = in.unitMode ? in.unitsPerItem : 1u;
-    const uint32_t unitsPerItemHere = in.unitMode == 2u ? U - 1u : 1u;       // work units per item in this launch
+    const uint32_t unitsPerItemHere = in.unitMode == 2u ? U : 1u;            // work units per item in this launch
+    bool noCount = false;                                                   // unit mode: the lane found nothing to do (closed read, no trunk state): its counter is not its to write
     bool trunk = false;                                                     // the lane is still on the part of the item that all its units share
     uint32_t unitP = 0xFFFFFFFFu;                                           // position of the unit's first mismatch; 0xFFFFFFFF: none in the mismatch step
     int sStar = 0;                                                          // the first step of the case that allows a mismatch (nSteps: none)
@@ -222,6 +224,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         const uint32_t cnt = rr_ - l + 1u;
                         uint32_t *acc = out.itemAcc + (size_t)(cutPtr - out.readCut) * groups;
                         atomicAdd(&acc[sub], cnt);
+                        atomicAdd(&out.readAcc[cutPtr - out.readCut], cnt);     // (the rounds' running total: check-and-extend adds what it accepts)
                         uint32_t before = 0;
                         for (uint32_t q = 0; q < sub; q++) before += __hip_atomic_load(&acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const uint32_t mine = __hip_atomic_load(&acc[sub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -231,10 +234,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                             uint4 *ts = out.trunkStates + (cntIdx - in.unitBase) - myPos;
                             atomicAdd(&ts[myPos].w, cnt);
                             uint32_t upTo = before;
-                            for (uint32_t q = 0; q <= myPos; q++) {
-                                const uint32_t w = __hip_atomic_load(&ts[q].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                upTo += q + 1u == U ? w : (w ? w - 1u : 0u);
-                            }
+                            for (uint32_t q = 0; q <= myPos; q++) upTo += __hip_atomic_load(&ts[q].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~S3_TRUNK_VALID;
                             if (upTo >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
                         } else if (total >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
                     }
@@ -288,8 +288,10 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             if (ins >= st.minErr && alive) {
                 if (trunk && s == sStar) {
-                    if (unitP != 0xFFFFFFFFu) { state = ST_DONE; return; }   // past the last position of the mismatch step: the last unit goes on alone
-                    trunk = false;
+                    // past the last position of the mismatch step without a mismatch: the item's last unit ("none") goes on from here, in its turn
+                    if (in.unitMode == 1u) out.trunkStates[cntIdx - in.unitBase] = make_uint4(g.fl, g.fr, g.rl, S3_TRUNK_VALID);
+                    state = ST_DONE;
+                    return;
                 }
                 occ += ins; ins = 0; s++; i = 0;
                 continue;
@@ -315,7 +317,9 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 goHeavy = false;
                 sub = groups;
             } else {
-                out.itemCounts[cntIdx] = seq;
+                // (the "none" unit's counter is shared by the trunk lane, which may have handed the trunk itself to check-and-extend, and the unit
+                //  lane: a unit lane that wrote nothing -- closed, cut, no trunk state -- leaves the counter alone; it was zeroed before the pass)
+                if (!noCount && !(in.unitMode == 2u && seq == 0u)) out.itemCounts[cntIdx] = seq;
                 readTotal += total;
                 sub++;
                 if (in.unitMode) sub = groups;                              // second pass: one unit per turn
@@ -343,8 +347,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 else {
                     chunkCur = chunkBase = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots;
                     if (in.slotList) {
-                        sl0 = b + lane < nSlots ? in.slotList[(b + lane) / (groups * unitsPerItemHere)] : 0u;
-                        sl1 = b + 64u + lane < nSlots ? in.slotList[(b + 64u + lane) / (groups * unitsPerItemHere)] : 0u;
+                        sl0 = b + lane < nSlots ? in.slotList[(b + lane) / unitsPerReadHere] : 0u;
+                        sl1 = b + 64u + lane < nSlots ? in.slotList[(b + 64u + lane) / unitsPerReadHere] : 0u;
                         if (in.active) { act0 = in.active[sl0]; act1 = in.active[sl1]; }
                     } else if (in.active) {
                         act0 = b + lane < nSlots ? in.active[b + lane] : 0u;
@@ -366,17 +370,17 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     sub = 0;
                     cntIdx = slotIdx * groups;
                     trunk = false; unitP = 0xFFFFFFFFu;
+                    noCount = false;
                     if (in.unitMode) {
-                        const uint32_t item = slotIdx / unitsPerItemHere;  // = listed read * groups + (case, strand)
-                        sub = item % groups;
-                        unitP = in.unitMode == 2u ? slotIdx % unitsPerItemHere : 0xFFFFFFFFu;
-                        cntIdx = in.unitBase + item * U + (in.unitMode == 2u ? unitP : U - 1u);
-                        trunk = U > 1u;
-                        unitInRead = sub * U + (in.unitMode == 2u ? unitP : U - 1u);
-                        cutPtr = out.readCut + item / groups;
+                        const uint32_t listed = slotIdx / unitsPerReadHere, rem = slotIdx - listed * unitsPerReadHere;
+                        sub = in.itemLo + rem / unitsPerItemHere;
+                        const uint32_t p = in.unitMode == 2u ? rem % unitsPerItemHere : U - 1u;       // U - 1: the unit without a mismatch in the mismatch step
+                        unitP = p + 1u == U ? 0xFFFFFFFFu : p;
+                        cntIdx = in.unitBase + (listed * groups + sub) * U + p;
+                        trunk = U > 1u && !(in.unitMode == 2u && p + 1u == U);
+                        unitInRead = sub * U + p;
+                        cutPtr = out.readCut + listed;
                         slotIdx = off < 64u ? s0 : s1;
-                        // the listed read counts per unit now: what the first pass left in its items' own counters (or never wrote) is void
-                        if (in.unitMode == 1u) out.itemCounts[slotIdx * groups + sub] = 0;
                     }
                     rIdx = in.active ? (off < 64u ? a0 : a1) : slotIdx;
                     readTotal = 0; readCand = 0; readRank = 0;
@@ -463,6 +467,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             aP0 = src;
             if (2u * wpq - loadOff > 4) aP1 = src + 1;
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
+            if (in.unitMode) aD1 = out.readAccPrev + (cutPtr - out.readCut);
         } else if (state == ST_TRUNK) {
             aP0 = out.trunkStates + (cntIdx - in.unitBase);
             aD1 = cutPtr;
@@ -540,7 +545,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const bool onTrunkHere = trunk && s == sStar;                      // trunk pass: no mismatch is taken in this step ...
             const bool branchOnly = onTrunkHere && (uint32_t)i == unitP;        // ... unit pass, at the unit's position: only the mismatch children
             if (branchOnly) trunk = false;
-            else if (onTrunkHere && (uint32_t)i + 1u < U) out.trunkStates[(cntIdx - in.unitBase) - (U - 1u) + (uint32_t)i] = make_uint4(g.fl, g.fr, g.rl, 1u);
+            else if (onTrunkHere && (uint32_t)i + 1u < U) out.trunkStates[(cntIdx - in.unitBase) - (U - 1u) + (uint32_t)i] = make_uint4(g.fl, g.fr, g.rl, S3_TRUNK_VALID);
             if (!exact && !(onTrunkHere && !branchOnly)) {
                 const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
                 const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
@@ -567,8 +572,12 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         if (state == ST_RESUME) { doSettle = true; needPop = false; }          // the completed frame that had to wait: emit it now, then pop
         if (state == ST_TRUNK) {
             // the range the trunk pass held at this unit's position (.w = 0: the trunk never got there -- nothing to do)
-            if (p0.w == 0u) state = ST_DONE;
-            else { g.fl = p0.x; g.fr = p0.y; g.rl = p0.z; g.rr = p0.z + (p0.y - p0.x); s = sStar; i = (int)unitP; ins = 0; occ = 0; state = ST_STEP; }
+            if (!(p0.w & S3_TRUNK_VALID)) { state = ST_DONE; noCount = true; }
+            else {
+                g.fl = p0.x; g.fr = p0.y; g.rl = p0.z; g.rr = p0.z + (p0.y - p0.x); s = sStar; ins = 0; occ = 0;
+                if (unitP != 0xFFFFFFFFu) { i = (int)unitP; state = ST_STEP; }
+                else { i = (int)stepAt(sStar).len; doSettle = true; needPop = false; }      // the "none" unit: behind the step's last position
+            }
         } else
         if (state == ST_LOAD) {
             // word gi of the read's row in readsT (both orientations, wpq words each) -> LDS word (orientation * wl + w); words past wl are padding
@@ -582,6 +591,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             loadOff += 8;
             if constexpr (!UNIFORM) Li = (int)saVal;
             if (loadOff >= 2u * wpq) state = in.unitMode == 2u ? ST_TRUNK : ST_KEYS;
+            if (in.unitMode && d1 >= in.maxOut) { state = ST_DONE; noCount = true; }       // the read was closed by the rounds before this one
         } else if (state == ST_LT) {
             const S3Step st = stepAt(0);
             int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
@@ -636,9 +646,10 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 // One lane per task; the lanes of a wave walk their candidates in lockstep (k-th candidate of every task), accepted ones are appended to the
 // record stream with one atomic per wave and round.  Per candidate: SA value, then per remaining model step the text against the oriented read,
 // 16 characters at a time (XOR, fold, popcount), the step's error window checked as in the stepping kernel (BGS-HostAlgnmtAlgo2.cpp:86-169).
-__global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, SearchOut out, const uint32_t *taskEnd)
+__global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, SearchOut out, const uint32_t *taskRange)
 {
-    uint32_t nRec = *taskEnd;
+    const uint32_t firstRec = taskRange[0];                   // records [firstRec, nRec): what the stepping launches wrote since the last call
+    uint32_t nRec = taskRange[1];
     if (nRec > out.recCap) nRec = out.recCap;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t groups = (uint32_t)in.nCases * 2u;
@@ -646,17 +657,19 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t nSa = 0, nCe = 0;
     uint32_t recCur = 0, recEnd = 0;                          // wave-uniform: reserved block [recCur, recEnd)
-    for (uint64_t base = (uint64_t)waveId * 64u; base < nRec; base += (uint64_t)nWaves * 64u) {
+    for (uint64_t base = (uint64_t)firstRec + (uint64_t)waveId * 64u; base < nRec; base += (uint64_t)nWaves * 64u) {
         const uint64_t idx = base + lane;
         uint4 rec = make_uint4(0xFFFFFFFFu, 0, 0, 0);
         if (idx < nRec) rec = out.recs[idx];
         bool task = rec.x != 0xFFFFFFFFu && (rec.y & S3_REC_TASK);
         uint32_t item = rec.x & ~S3_REC_PASS2;
         uint32_t slotOf = item / groups;
+        uint32_t listed = 0xFFFFFFFFu, accepted = 0;
         if (task && (rec.x & S3_REC_PASS2)) {
             // second-pass records count in unit space: unit = heavy read * groups * U + item * U + position
             const uint32_t unit = item - in.unitBase, U = in.unitsPerItem;
-            slotOf = out.heavyList[unit / (groups * U)];
+            listed = unit / (groups * U);
+            slotOf = out.heavyList[listed];
             item = slotOf * groups + (unit / U) % groups;
         } else if (task && out.heavyFlags[slotOf]) task = false;                 // stale: the second pass searched this read again
         const bool early = task && (rec.y & S3_REC_EARLY);
@@ -743,6 +756,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                     if (recEnd > out.recCap || recEnd < b0) { recEnd = b0 < out.recCap ? out.recCap : b0; if (lane == 0) atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
                 }
                 if (hit) {
+                    accepted++;
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
                     if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(rec.x, ((rec.y & 0xFFFFFFu) + k) | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
                 }
@@ -750,6 +764,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 if (recCur > recEnd) recCur = recEnd;
             }
         }
+        if (accepted && listed != 0xFFFFFFFFu) atomicAdd(&out.readAcc[listed], accepted);      // the listed read's running total (closes it for later rounds)
     }
     for (uint32_t j = recCur + lane; j < recEnd; j += 64u) out.recs[j] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
     if (out.counters) {
@@ -763,7 +778,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
 int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
 {
     if (in.nActive == 0) return (int)hipSuccess;
-    uint64_t blocks = ((uint64_t)in.nActive * (in.unitMode ? (uint64_t)in.nCases * 2u * (in.unitMode == 2u ? in.unitsPerItem : 1u) : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    uint64_t blocks = ((uint64_t)in.nActive * (in.unitMode ? (uint64_t)in.itemSpan * (in.unitMode == 2u ? in.unitsPerItem : 1u) : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wLds * 256u);
     if (lds > 48u * 1024u) {
@@ -777,7 +792,7 @@ int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out,
     return (int)hipSuccess;
 }
 
-void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskEnd, hipStream_t s)
+void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskRange, hipStream_t s)
 {
     if (in.nActive == 0) return;
     // the waves split the task records statically: launch exactly the blocks that are resident at once (a partial second round would run on a
@@ -790,7 +805,7 @@ void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &
         if (const char *e = getenv("S3DP_CE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
         return (unsigned)(cus * perCu);
     }();
-    hipLaunchKernelGGL(ceKernel, dim3(blocks), dim3(256), 0, s, ix, in, out, taskEnd);
+    hipLaunchKernelGGL(ceKernel, dim3(blocks), dim3(256), 0, s, ix, in, out, taskRange);
 }
 
 }  // namespace s3

@@ -101,7 +101,7 @@ int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<
         for (uint32_t j = 1; j < nSeeds; j++) if (seeds[j].len != seeds[0].len) { b->uniformLen = 0; break; }
         b->fullUniformLen = b->uniformLen;
     }
-    b->searchLaunches = 0; b->ceLaunches = 0; b->occUsed = 0; b->recordsTotal = 0;
+    b->searchLaunches = 0; b->evSearchUsed = 0; b->evCeUsed = 0; b->occUsed = 0; b->recordsTotal = 0;
     SCHK(hipMemsetAsync(b->dFlags, 0, 4, st));
     SCHK(hipMemsetAsync(b->dOccStart, 0, (size_t)(nSeeds ? nSeeds : 1) * 4, st));
     SCHK(hipMemsetAsync(b->dOccCount, 0, ((size_t)nSeeds + 1) * 4, st));

@@ -105,6 +105,7 @@ bool loadIndex(const std::string &prefix, HostIndex &ix, std::string &err)
         std::string e2;
         if (slurpWords(prefix + ".lkt", 1, ix.lkt, &hdr, e2) && hdr[0] == 13 && ix.lkt.size() == ((size_t)1 << 26)) {
             if (!slurpWords(prefix + ".rev.lkt", 1, ix.rlkt, &hdr, err)) return false;
+            if (hdr[0] != 13 || ix.rlkt.size() != ((size_t)1 << 26)) { err = prefix + ".rev.lkt is not a 13-mer table of 2^26 entries"; return false; }
         } else {
             buildLookupTable(ix.pac, ix.n, false, ix.lkt);
             buildLookupTable(ix.pac, ix.n, true, ix.rlkt);

@@ -188,6 +188,8 @@ class HostIndex:
             if os.path.exists(prefix + ".lkt"):
                 lkt = np.fromfile(prefix + ".lkt", dtype=np.uint32)[1:]
                 rev_lkt = np.fromfile(prefix + ".rev.lkt", dtype=np.uint32)[1:]
+                if len(lkt) != 1 << 26 or len(rev_lkt) != 1 << 26:
+                    raise ValueError("%s.lkt / .rev.lkt are not 13-mer tables of 2^26 entries" % prefix)
             else:
                 lkt = build_lookup_table(self.codes)
                 rev_lkt = build_lookup_table(self.codes[::-1])
@@ -284,6 +286,7 @@ class Batch:
         self.index = index
         self.h = C.c_void_p()
         self.n = 0
+        self.wpq = wpq
         _chk(lib().s3_batch_create(index.h, max_reads, wpq, C.byref(self.h)))
 
     def close(self):
@@ -301,6 +304,9 @@ class Batch:
         queries = np.ascontiguousarray(queries, dtype=np.uint32)
         read_lengths = np.ascontiguousarray(read_lengths, dtype=np.uint32)
         self.n = len(read_lengths)
+        need = (self.n + 31) // 32 * 32 * self.wpq              # s3_batch_upload reads whole groups of 32 reads (include/s3dp.h)
+        if queries.size < need:
+            queries = np.concatenate([queries.ravel(), np.zeros(need - queries.size, dtype=np.uint32)])
         _chk(lib().s3_batch_upload(self.h, queries.ctypes.data, read_lengths.ctypes.data, self.n))
 
     def enable_counters(self, on=True):

@@ -1,7 +1,8 @@
-set -e
+# prints rc= per case instead of stopping at the first failure
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && rm -rf rb && mkdir rb && cd rb
-G=/root/repo/tests/golden
-B=/root/repo/soap3-dp_amd/soap3-dp
+G=$ROOT/tests/golden
+B=$ROOT/soap3-dp_amd/soap3-dp
 for h in 1 2 3 4; do $B pair $G/g4/index $G/g4/reads_1.fq $G/g4/reads_2.fq -u 500 -v 100 -L 100 -h $h -o p$h > p$h.log 2>&1; echo "pair -h $h rc=$? gout=$(grep -vc '^@' p$h.gout.1) dpout=$(grep -vc '^@' p$h.dpout.1) unpair=$(grep -vc '^@' p$h.unpair)"; done
 gzip -c $G/g4/reads_1.fq > r1.fq.gz; gzip -c $G/g4/reads_2.fq > r2.fq.gz
 $B pair $G/g4/index r1.fq.gz r2.fq.gz -u 500 -v 100 -L 100 -o pgz > pgz.log 2>&1; echo "gz rc=$?"; cmp <(grep -v '^@PG' pgz.gout.1 | sed 's/r1.fq.gz/X/g') <(grep -v '^@PG' p2.gout.1 | sed "s#$G/g4/reads_1.fq#X#g") && echo "gz == plain (gout)"
