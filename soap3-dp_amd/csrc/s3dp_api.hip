@@ -127,7 +127,8 @@ static int indexUploadBody(s3_index *ix, const s3_index_desc *desc, hipStream_t 
     const uint32_t n = desc->textLength;
     uint32_t *sa = nullptr, *pac = nullptr, *lkt = nullptr, *rlkt = nullptr;
     const size_t ltWords = (size_t)1 << (2 * desc->lktSize);
-    const size_t pacWords = desc->packedWords + 4;                     // + zero tail so 3-word windows never leave the buffer
+    // + zero tail: 3-word windows never leave the buffer, and the second search pass reads the text in whole 64-byte lines up to a read length past the end
+    const size_t pacWords = (desc->packedWords + 15) / 16 * 16 + 16 + S3_MAX_READ_LENGTH / 16;
     if ((rc = devAlloc(ix, &sa, (size_t)n + 1)) || (rc = devAlloc(ix, &pac, pacWords)) || (rc = devAlloc(ix, &lkt, ltWords)) ||
         (rc = devAlloc(ix, &rlkt, ltWords))) return rc;
     const uint32_t saInterval = desc->saInterval > 1 ? desc->saInterval : 1;
@@ -287,7 +288,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
     BA(dRecs, recCap); BA(dOrdered, recCap); b->ordCap = recCap;
-    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dReadAcc, 2 * ((size_t)maxReads + 64)); BA(dSum64, 2);
+    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
     BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4); BA(dTrunk, 16); b->trunkCap = 16; BA(dItemAcc, 16); b->accCap = 16;
@@ -430,7 +431,8 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             in.sStarPacked |= (uint32_t)sStar << (3 * c);
         }
     }
-    in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0; in.itemLo = 0; in.itemSpan = 0;
+    in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0;
+    in.ceGiveUp = (uint32_t)envSize("S3DP_CE_GIVE_UP", S3_CE_GIVE_UP);
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
     unsigned long long counterSnap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (b->counting) {
@@ -496,11 +498,11 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             auto lapT = std::chrono::steady_clock::now();
             auto lap = [&](const char *what, uint64_t units) {
                 if (!verbose || !b->counting) return;
-                unsigned long long c[2] = {0, 0};
-                (void)d2h(c, b->dCounters, 16, b->stream);
+                unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                (void)d2h(c, b->dCounters, 64, b->stream);
                 const auto now = std::chrono::steady_clock::now();
-                fprintf(stderr, "[s3dp] search mm=%u %-12s %10llu units %8.2f ms %12llu rank queries\n", modelMm, what, (unsigned long long)units,
-                        std::chrono::duration<double, std::milli>(now - lapT).count(), c[0] - rankSeen);
+                fprintf(stderr, "[s3dp] search mm=%u %-12s %10llu units %8.2f ms %12llu rank queries (cut: %llu skipped, %llu stopped, %llu own)\n", modelMm, what, (unsigned long long)units,
+                        std::chrono::duration<double, std::milli>(now - lapT).count(), c[0] - rankSeen, c[4], c[5], c[6]);
                 rankSeen = c[0]; lapT = now;
             };
             if (verbose && b->counting) { (void)hipStreamSynchronize(b->stream); lapT = std::chrono::steady_clock::now(); }
@@ -565,43 +567,22 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     }
                     HIPCHK(hipMemsetAsync(b->dItemAcc, 0, (size_t)nHeavy * groups * 4, b->stream));
                     out.itemAcc = b->dItemAcc;
-                    // the running totals of the listed reads: [0, maxReads) now, [maxReads, 2 maxReads) as they stood when the round began
-                    uint32_t *accNow = b->dReadAcc, *accPrev = b->dReadAcc + b->maxReads;
-                    HIPCHK(hipMemsetAsync(accNow, 0, (size_t)nHeavy * 4, b->stream));
-                    out.readAcc = accNow; out.readAccPrev = accPrev;
                     SearchIn in2 = in;
                     in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu; in2.heavyRank = 0xFFFFFFFFu;
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
-                    in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (check-and-extend and the scatter decode unit indices with them)
-                    // ROUNDS.  The CPU path stops a read at MaxOutputPerRead occurrences, and most occurrences of a read inside a repeat family are
-                    // check-and-extend candidates: nobody knows how many of them hold until ceKernel has looked.  So the items of the listed reads are
-                    // can be searched in rounds of 1, 1, 2, 4, 8 ... items (S3DP_ROUNDS=1; default: all at once -- every round ends in the tail of its longest unit), check-and-extend after every round, and a read whose
-                    // running total -- certain occurrences + accepted candidates of all EARLIER rounds, nothing of the current one: units of one round
-                    // run side by side -- has reached the limit is closed: its later items lie behind the cut the merge will make, whatever they hold.
-                    static const bool rounds = envSize("S3DP_ROUNDS", 0) != 0;
-                    uint32_t lo = 0, size = 1, roundNo = 0;
-                    while (lo < (uint32_t)groups) {
-                        const uint32_t span = rounds ? std::min<uint32_t>(size, (uint32_t)groups - lo) : (uint32_t)groups;
-                        HIPCHK(hipMemcpyAsync(accPrev, accNow, (size_t)nHeavy * 4, hipMemcpyDeviceToDevice, b->stream));
-                        in2.itemLo = lo; in2.itemSpan = span;
-                        HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
-                        for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass
-                            in2.unitMode = mode;
-                            HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-                            le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, b->stream);
-                            if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
-                            lap(mode == 1 ? "trunk pass" : "unit pass", (uint64_t)nHeavy * span * (mode == 1 ? 1 : U));
-                        }
-                        HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
-                        int rc = checkExtend();
-                        if (rc) return rc;
-                        lap("check-extend", 0);
-                        lo += span;
-                        if (roundNo++ > 0) size *= 2;
+                    in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (the scatter decodes unit indices with them)
+                    HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
+                    for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass
+                        in2.unitMode = mode;
+                        HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
+                        le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksPerCu, b->stream);
+                        if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
+                        lap(mode == 1 ? "trunk pass" : "unit pass", (uint64_t)nHeavy * groups * (mode == 1 ? 1 : U));
                     }
+                    HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
                 }
             }
-            if (!nHeavy) {
+            {
                 int rc = checkExtend();
                 if (rc) return rc;
                 lap("check-extend", 0);

@@ -64,12 +64,13 @@ struct SearchIn {
     uint32_t        unitsPerItem;  // second pass: first-mismatch positions an item is cut into, + 1 for "none" (1: whole items)
     uint32_t        unitBase;      // second pass: unit u counts its records in itemCounts[unitBase + u]
     uint32_t        sStarPacked;   // 3 bits per case: the first step that allows a mismatch (= nSteps: none)
-    uint32_t        itemLo, itemSpan; // second pass: the items [itemLo, itemLo + itemSpan) of every listed read are this launch's (a ROUND of the pass)
+    uint32_t        ceGiveUp;      // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel (S3_CE_GIVE_UP)
     uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_v2.hip)
 };
 
 #define S3_REC_TASK  (1u << 28)
 #define S3_REC_PASS2 0x80000000u            // in the item word: record written by the second pass (records of a listed read without it are stale)
+#define S3_CE_GIVE_UP 4u                     // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel
 #define S3_TRUNK_VALID 0x80000000u          // trunkStates[].w: the trunk pass reached this position
 #define S3_REC_EARLY (1u << 29)              // task written inside the exact lookup step (single-suffix range): the rest of that step is verified too
 
@@ -86,9 +87,7 @@ struct SearchOut {
     uint32_t           *heavyIndex; // per listed slot: its place in heavyList
     uint32_t           *readCut;     // second pass, per listed read: the smallest unit (item * units + position) that holds maxOut occurrences by itself
     uint32_t           *itemAcc;     // second pass, per listed read and item: occurrences its units hold for sure (sums over the items give the cut too)
-    uint4              *trunkStates; // second pass: {l, r, rev l, S3_TRUNK_VALID | certain occurrences of the unit} per (listed read, item, position)
-    uint32_t           *readAcc;     // second pass, per listed read: occurrences found so far -- certain ones and accepted check-and-extend candidates
-    const uint32_t     *readAccPrev; // ... its value when the round began: a read that had maxOut by then is closed (everything later is behind the cut)
+    uint4              *trunkStates; // second pass: {l, r, rev l, S3_TRUNK_VALID | occurrences of the unit} at [(item * units + position) * listed reads + read]
 };
 
 struct DevHit { uint32_t a, b, meta; };       // binary-identical to s3_hit (kind, strand, nmis, cas bytes)

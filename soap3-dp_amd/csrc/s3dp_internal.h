@@ -52,7 +52,6 @@ struct s3_batch {
     uint8_t  *dHeavyFlags = nullptr;                 // reads the first search pass listed for the exact pass (s3dp_search_v2.hip)
     uint32_t *dHeavyList = nullptr, *dHeavyCount = nullptr, *dHeavyIndex = nullptr;
     uint32_t *dLongList = nullptr, *dLongCount = nullptr;      // reads whose slice of the ordered array is walked by a whole wave (merge / decode)
-    uint32_t *dReadAcc = nullptr;                               // running totals of the listed reads, now and at the start of the round (2 x maxReads)
     uint32_t *dItemAcc = nullptr; size_t accCap = 0;            // per listed read and item: certain occurrences (second search pass)
     uint4 *dTrunk = nullptr; size_t trunkCap = 0;              // trunk states of the second search pass
     size_t countCap = 0;                                       // entries of dItemCounts / dItemOffsets (items + units of the listed reads + 1)

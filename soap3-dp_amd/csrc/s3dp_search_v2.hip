@@ -34,8 +34,9 @@ namespace s3 {
 
 namespace v2 {
 
-enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_TRUNK = 2, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6, ST_RESUME = 7 };
+enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_TRUNK = 2, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6, ST_RESUME = 7, ST_CE_SA = 8, ST_CE_TEXT = 9 };
 constexpr uint32_t ID_NONE = 0x7FFFFFFFu;
+constexpr uint32_t ID_TEXT = 0x40000000u;                 // cooperative line ids: bit 31 = reverse BWT, ID_TEXT | k = 64-byte line k of the packed text
 constexpr int STACK = 20;
 
 struct Frame { uint32_t fl, fr, rl, meta; };        // rr = rl + (fr - fl);  meta = s | i << 3 | ins << 14 | occ << 17
@@ -106,17 +107,22 @@ using namespace v2;
 // bound by its instruction count.  The record stream keeps the CPU path's order because accepted candidates are written under the reserved
 // numbers; rejected ones leave holes the ordering pass skips.  Not counting the candidates in `total` only delays the early stop at
 // MaxOutputPerRead: the per-read cut is applied again, exactly, when the records are merged.
-// in.unitMode: the second pass over the listed reads, two launches.
+// SECOND (template): the second pass over the listed reads, in.unitMode = 1 / 2, two launches.  Its lanes do check-and-extend THEMSELVES (states
+// ST_CE_SA / ST_CE_TEXT below) instead of writing task records: most occurrences of a read inside a repeat family are check-and-extend candidates,
+// and only a lane that knows which of them hold can stop where the CPU path stops -- at MaxOutputPerRead occurrences.  The units of a read start in
+// sequence order, spread over the launch (the work queue is ordered by item and position first, read last), every unit adds what it has found to
+// counters the other units of its read can see, and a unit that finds MaxOutputPerRead occurrences in front of it stops.
 //   1 (trunk pass): one lane per (listed read, item) walks the TRUNK of the item -- lookup step, exact steps, then the first mismatch step without
 //     taking a mismatch -- and writes the range it holds at every position of that step into out.trunkStates; it then goes on as the item's last
 //     unit (no mismatch in that step at all).  Whatever ends the trunk early (a range handed to check-and-extend, a dead range) ends it for all
 //     units: positions it never reached keep an invalid state.
 //   2 (unit pass): one lane per (listed read, item, position p): it loads the read and the trunk state of p, takes ONLY the mismatch children at p
 //     and is from there on an ordinary depth-first search.
-template <bool UNIFORM>
+template <bool UNIFORM, bool SECOND>
 __global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_V2_WAVES_PER_SIMD)
 searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 {
+    const uint32_t unitMode = SECOND ? in.unitMode : 0u;                    // (a constant 0 in the first pass: its code carries nothing of the second)
     extern __shared__ __align__(16) unsigned char shmem[];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t wpq = in.wpqLoad;                                        // words per orientation in readsT (stride, a power of two)
@@ -136,8 +142,11 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     const uint32_t nCases = (uint32_t)in.nCases;
     const uint32_t groups = nCases * 2u;
     // second pass: listed reads x the items of this round (x the units of an item: every position of the mismatch step + "none")
-    const uint32_t unitsPerReadHere = in.unitMode ? in.itemSpan * (in.unitMode == 2u ? in.unitsPerItem : 1u) : 1u;
-    const unsigned long long nSlots = in.unitMode ? (unsigned long long)*in.slotCount * unitsPerReadHere : in.nActive;
+    const uint32_t nListed = SECOND ? *in.slotCount : 0u;
+    const uint32_t unitsPerReadHere = unitMode ? groups * (unitMode == 2u ? in.unitsPerItem : 1u) : 1u;
+    const unsigned long long nSlots = unitMode ? (unsigned long long)nListed * unitsPerReadHere : in.nActive;
+    uint32_t nCutSkip = 0, nCutMid = 0, nOwnMax = 0;                       // (statistics: units skipped by the cut before their first step / stopped by it / stopped by their own total)
+    uint32_t nSaL = 0, nCeL = 0;                                           // second pass: suffix-array reads / compare windows of its own check-and-extend
     uint32_t nRank = 0, nLt = 0;
 
     // ---- per-lane item + search state ---------------------------------------------------------------------
@@ -153,8 +162,18 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     Range g = {0, 0, 0, 0};
     int s = 0, i = 0, ins = 0, occ = 0;
     // unit mode
-    const uint32_t U = in.unitMode ? in.unitsPerItem : 1u;
-    const uint32_t unitsPerItemHere = in.unitMode == 2u ? U : 1u;            // work units per item in this launch
+    const uint32_t U = unitMode ? in.unitsPerItem : 1u;
+    const uint32_t unitsPerItemHere = unitMode == 2u ? U : 1u;               // work units per item in this launch
+    uint32_t listed = 0;                                                    // the lane's read in the list
+    // check-and-extend of the second pass (one candidate at a time): candidates [ceL + ceK, ceL + ceN) of the suffix array are left; of the current
+    // one: text position of the read's first character, the model step being compared, characters of it done, mismatches so far
+    uint32_t ceL = 0, ceN = 0, ceK = 0, ceSa = 0, ceRp = 0;
+    int ceT = 0, ceII = 0, ceIns = 0, ceAcc = 0, ceOff = 0, ceMm = 0;
+    bool ceEarly = false;
+    // A unit whose candidates keep failing stops verifying them itself: after S3_CE_GIVE_UP rejections in a row it writes task records like the first
+    // pass (one trip per task instead of one or two per candidate; ceKernel verifies them, many lanes wide).  Knowing the count at once only pays
+    // where candidates hold -- inside young repeat families, whose reads reach MaxOutputPerRead --, and either way the merge applies the cut exactly.
+    uint32_t ceMiss = 0;
     bool noCount = false;                                                   // unit mode: the lane found nothing to do (closed read, no trunk state): its counter is not its to write
     bool trunk = false;                                                     // the lane is still on the part of the item that all its units share
     uint32_t unitP = 0xFFFFFFFFu;                                           // position of the unit's first mismatch; 0xFFFFFFFF: none in the mismatch step
@@ -197,6 +216,26 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         pendA = a; pendB = b;
         seq++;
     };
+    // The running total of an item-wise walk, kept where the units of a read can all see it: per item (itemAcc) and, inside the item, per position
+    // (the spare word of the trunk states: S3_TRUNK_VALID | what the unit at that position holds).  Everything in sequence order up to and including
+    // this unit that adds up to MaxOutputPerRead puts the read's cut right behind this unit; the items up to this one adding up to it put it
+    // behind the item.
+    auto tsAt = [&](uint32_t q) -> uint4 * { return out.trunkStates + ((size_t)sub * U + q) * nListed + listed; };
+    auto countCertain = [&](uint32_t cnt) {
+        uint32_t *acc = out.itemAcc + (size_t)listed * groups;
+        atomicAdd(&acc[sub], cnt);
+        uint32_t before = 0;
+        for (uint32_t q = 0; q < sub; q++) before += __hip_atomic_load(&acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t mine = __hip_atomic_load(&acc[sub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + mine >= in.maxOut) atomicMin((uint32_t *)cutPtr, sub * U + U - 1u);
+        if (U > 1u) {
+            const uint32_t myPos = unitInRead - sub * U;
+            atomicAdd(&tsAt(myPos)->w, cnt);
+            uint32_t upTo = before;
+            for (uint32_t q = 0; q <= myPos; q++) upTo += __hip_atomic_load(&tsAt(q)->w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~S3_TRUNK_VALID;
+            if (upTo >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
+        } else if (total >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
+    };
     // advance without memory until the lane needs ranks / SA / text or its item is finished
     auto settle = [&](bool needPop) {
         for (;;) {
@@ -216,28 +255,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     if (readTotal + total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - readTotal - total - 1u;
                     emit(0, l, rr_, (uint32_t)(ins + occ));
                     total += rr_ - l + 1u;
-                    if (in.unitMode) {
-                        // The running total of an item-wise walk, kept where the units of a read can all see it: per item (itemAcc) and, inside the item,
-                        // per position (the spare word of the trunk states: 1 + what the unit at that position holds for sure; the last unit's slot is
-                        // not a trunk state and starts from 0).  Everything in sequence order up to and including this unit that adds up to MaxOutputPerRead
-                        // puts the read's cut right behind this unit; the items up to this one adding up to it put it behind the item.
-                        const uint32_t cnt = rr_ - l + 1u;
-                        uint32_t *acc = out.itemAcc + (size_t)(cutPtr - out.readCut) * groups;
-                        atomicAdd(&acc[sub], cnt);
-                        atomicAdd(&out.readAcc[cutPtr - out.readCut], cnt);     // (the rounds' running total: check-and-extend adds what it accepts)
-                        uint32_t before = 0;
-                        for (uint32_t q = 0; q < sub; q++) before += __hip_atomic_load(&acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint32_t mine = __hip_atomic_load(&acc[sub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (before + mine >= in.maxOut) atomicMin((uint32_t *)cutPtr, sub * U + U - 1u);
-                        if (U > 1u) {
-                            const uint32_t myPos = unitInRead - sub * U;
-                            uint4 *ts = out.trunkStates + (cntIdx - in.unitBase) - myPos;
-                            atomicAdd(&ts[myPos].w, cnt);
-                            uint32_t upTo = before;
-                            for (uint32_t q = 0; q <= myPos; q++) upTo += __hip_atomic_load(&ts[q].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~S3_TRUNK_VALID;
-                            if (upTo >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
-                        } else if (total >= in.maxOut) atomicMin((uint32_t *)cutPtr, unitInRead);
-                    }
+                    if (unitMode) countCertain(rr_ - l + 1u);
                 }
                 needPop = true;                                              // the DFS goes on in the same trip
                 continue;
@@ -250,6 +268,9 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (i < lenEff && alive) {
                 const int pos = st.start + st.dir * i;
                 if ((g.fr - g.fl) < (uint32_t)st.ceThr && pos >= st.ceStart && pos <= st.ceEnd) {
+                    if constexpr (SECOND) {
+                        if (ceMiss < in.ceGiveUp) { ceL = g.fl; ceN = g.fr - g.fl + 1u; ceK = 0; ceEarly = false; state = ST_CE_SA; return; }   // the lane verifies them itself
+                    }
                     if (pendMeta >> 31) { state = ST_RESUME; return; }       // one record per lane and trip
                     pendMeta = 0x80000000u | seq | S3_REC_TASK;
                     pendA = g.fl;
@@ -271,6 +292,9 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         const uint32_t lim = in.earlyCe < (uint32_t)nx.ceThr ? in.earlyCe : (uint32_t)nx.ceThr;     // nx.ceThr >= 0 for every step
                         const int nxLenEff = nx.minErr > 1 ? nx.len - (nx.minErr - 1) : nx.len;                    // the next step must have a first position to stand on
                         if ((g.fr - g.fl) < lim && nxLenEff > 0 && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
+                            if constexpr (SECOND) {
+                                if (ceMiss < in.ceGiveUp) { ceL = g.fl; ceN = g.fr - g.fl + 1u; ceK = 0; ceEarly = true; state = ST_CE_SA; return; }
+                            }
                             if (pendMeta >> 31) { state = ST_RESUME; return; }
                             pendMeta = 0x80000000u | seq | S3_REC_TASK | S3_REC_EARLY;
                             pendA = g.fl;
@@ -289,7 +313,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (ins >= st.minErr && alive) {
                 if (trunk && s == sStar) {
                     // past the last position of the mismatch step without a mismatch: the item's last unit ("none") goes on from here, in its turn
-                    if (in.unitMode == 1u) out.trunkStates[cntIdx - in.unitBase] = make_uint4(g.fl, g.fr, g.rl, S3_TRUNK_VALID);
+                    if (unitMode == 1u) *tsAt(U - 1u) = make_uint4(g.fl, g.fr, g.rl, S3_TRUNK_VALID);
                     state = ST_DONE;
                     return;
                 }
@@ -319,10 +343,10 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             } else {
                 // (the "none" unit's counter is shared by the trunk lane, which may have handed the trunk itself to check-and-extend, and the unit
                 //  lane: a unit lane that wrote nothing -- closed, cut, no trunk state -- leaves the counter alone; it was zeroed before the pass)
-                if (!noCount && !(in.unitMode == 2u && seq == 0u)) out.itemCounts[cntIdx] = seq;
+                if (!noCount && !(unitMode == 2u && seq == 0u)) out.itemCounts[cntIdx] = seq;
                 readTotal += total;
                 sub++;
-                if (in.unitMode) sub = groups;                              // second pass: one unit per turn
+                if (unitMode) sub = groups;                                 // second pass: one unit per turn
                 else if (readTotal >= in.maxOut) {
                     // the per-read cut (mergeCountKernel) ends inside this item or before: what follows can never be kept
                     for (; sub < groups; sub++) out.itemCounts[slotIdx * groups + sub] = 0;
@@ -347,8 +371,8 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 else {
                     chunkCur = chunkBase = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots;
                     if (in.slotList) {
-                        sl0 = b + lane < nSlots ? in.slotList[(b + lane) / unitsPerReadHere] : 0u;
-                        sl1 = b + 64u + lane < nSlots ? in.slotList[(b + 64u + lane) / unitsPerReadHere] : 0u;
+                        sl0 = b + lane < nSlots ? in.slotList[(uint32_t)(b + lane) % nListed] : 0u;
+                        sl1 = b + 64u + lane < nSlots ? in.slotList[(uint32_t)(b + 64u + lane) % nListed] : 0u;
                         if (in.active) { act0 = in.active[sl0]; act1 = in.active[sl1]; }
                     } else if (in.active) {
                         act0 = b + lane < nSlots ? in.active[b + lane] : 0u;
@@ -371,13 +395,16 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     cntIdx = slotIdx * groups;
                     trunk = false; unitP = 0xFFFFFFFFu;
                     noCount = false;
-                    if (in.unitMode) {
-                        const uint32_t listed = slotIdx / unitsPerReadHere, rem = slotIdx - listed * unitsPerReadHere;
-                        sub = in.itemLo + rem / unitsPerItemHere;
-                        const uint32_t p = in.unitMode == 2u ? rem % unitsPerItemHere : U - 1u;       // U - 1: the unit without a mismatch in the mismatch step
+                    ceMiss = 0;
+                    if (unitMode) {
+                        // queue order: item first, then position, the read last -- the units of one read start far apart, in their sequence order
+                        const uint32_t rem = slotIdx / nListed;
+                        listed = slotIdx - rem * nListed;
+                        sub = rem / unitsPerItemHere;
+                        const uint32_t p = unitMode == 2u ? rem % unitsPerItemHere : U - 1u;          // U - 1: the unit without a mismatch in the mismatch step
                         unitP = p + 1u == U ? 0xFFFFFFFFu : p;
                         cntIdx = in.unitBase + (listed * groups + sub) * U + p;
-                        trunk = U > 1u && !(in.unitMode == 2u && p + 1u == U);
+                        trunk = U > 1u && !(unitMode == 2u && p + 1u == U);
                         unitInRead = sub * U + p;
                         cutPtr = out.readCut + listed;
                         slotIdx = off < 64u ? s0 : s1;
@@ -388,7 +415,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     casIdx = sub >> 1; strand = sub & 1u;
                     nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
                     sStar = (int)((in.sStarPacked >> (3u * casIdx)) & 7u);
-                    if (!in.unitMode) cntIdx += sub;
+                    if (!unitMode) cntIdx += sub;
                     seq = 0; total = 0; sp = 0; loadOff = 0;
                     hasItem = true;
                     state = ST_LOAD;
@@ -454,7 +481,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
             idA = kL | (dir < 0 ? 0u : 0x80000000u);
             needB = kR != kL;
-            if (in.unitMode) aD1 = cutPtr;
+            if (unitMode) aD1 = cutPtr;
             if (needB) {
                 const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
                 const bool fw = iR > (kR << 7);
@@ -467,9 +494,19 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             aP0 = src;
             if (2u * wpq - loadOff > 4) aP1 = src + 1;
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
-            if (in.unitMode) aD1 = out.readAccPrev + (cutPtr - out.readCut);
         } else if (state == ST_TRUNK) {
-            aP0 = out.trunkStates + (cntIdx - in.unitBase);
+            aP0 = tsAt(unitP == 0xFFFFFFFFu ? U - 1u : unitP);
+            aD1 = cutPtr;
+        } else if (SECOND && state == ST_CE_SA) {
+            aD0 = ix.sa + ceL + ceK;
+            aD1 = cutPtr;
+        } else if (SECOND && state == ST_CE_TEXT) {
+            // the 64-byte text line that holds the next character to compare; the next candidate's suffix-array entry rides along
+            const S3Step st = stepAt(ceT);
+            const int pos = st.start + st.dir * ceII;
+            const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end);
+            idA = ID_TEXT | ((ceRp + left + (uint32_t)ceOff) >> 8);
+            if (ceK + 1u < ceN) aD0 = ix.sa + ceL + ceK + 1u;
             aD1 = cutPtr;
         } else if (state == ST_LT) {
             const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
@@ -492,6 +529,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
         const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((32u + q4) * 4u), (int)idA);
         const uint32_t o3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((48u + q4) * 4u), (int)idA);
         auto lineAddr = [&](uint32_t o) -> const uint4 * {
+            if (SECOND && o != ID_NONE && (o >> 30) == 1u) return (const uint4 *)ix.pac + (size_t)(o & 0x3FFFFFFFu) * 4u + sub;
             const uint4 *base = (o >> 31) ? ix.rev.lines : ix.fwd.lines;
             return base + (o == ID_NONE ? (size_t)sub : (size_t)(o & 0x7FFFFFFFu) * 4u + sub);
         };
@@ -508,9 +546,12 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 
         // ---------- advance ----------
         bool doSettle = false, needPop = false;
-        if (in.unitMode && (state == ST_STEP || state == ST_TRUNK) && unitInRead > d1) { state = ST_DONE; sp = 0; }    // behind the read's cut
+        if (unitMode && (state == ST_STEP || state == ST_TRUNK || state == ST_CE_SA || state == ST_CE_TEXT) && unitInRead > d1) {    // behind the read's cut
+            if (state == ST_TRUNK) nCutSkip++; else nCutMid++;
+            state = ST_DONE; sp = 0;
+        }
         // first pass: a read that has cost this many rank queries is heavy whatever it has found so far (dead ends cost steps, not candidates)
-        if (!in.unitMode && state == ST_STEP && readRank > in.heavyRank) { goHeavy = true; state = ST_DONE; sp = 0; }
+        if (!unitMode && state == ST_STEP && readRank > in.heavyRank) { goHeavy = true; state = ST_DONE; sp = 0; }
         if (state == ST_STEP) {
             const S3Step stS = stepAt(s);
             const bool exact = ins >= stS.maxErr;
@@ -545,7 +586,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             const bool onTrunkHere = trunk && s == sStar;                      // trunk pass: no mismatch is taken in this step ...
             const bool branchOnly = onTrunkHere && (uint32_t)i == unitP;        // ... unit pass, at the unit's position: only the mismatch children
             if (branchOnly) trunk = false;
-            else if (onTrunkHere && (uint32_t)i + 1u < U) out.trunkStates[(cntIdx - in.unitBase) - (U - 1u) + (uint32_t)i] = make_uint4(g.fl, g.fr, g.rl, S3_TRUNK_VALID);
+            else if (onTrunkHere && (uint32_t)i + 1u < U) *tsAt((uint32_t)i) = make_uint4(g.fl, g.fr, g.rl, S3_TRUNK_VALID);
             if (!exact && !(onTrunkHere && !branchOnly)) {
                 const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
                 const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
@@ -590,8 +631,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             loadOff += 8;
             if constexpr (!UNIFORM) Li = (int)saVal;
-            if (loadOff >= 2u * wpq) state = in.unitMode == 2u ? ST_TRUNK : ST_KEYS;
-            if (in.unitMode && d1 >= in.maxOut) { state = ST_DONE; noCount = true; }       // the read was closed by the rounds before this one
+            if (loadOff >= 2u * wpq) state = unitMode == 2u ? ST_TRUNK : ST_KEYS;
         } else if (state == ST_LT) {
             const S3Step st = stepAt(0);
             int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
@@ -610,6 +650,87 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             s = 0; i = ll; ins = 0; occ = 0;
             doSettle = true;
         }
+        if constexpr (SECOND) {
+            // ---------- check-and-extend by the lane itself: per candidate its suffix-array entry, then the text under the rest of the model, one 64-byte
+            // line (256 characters) per trip, compared as ceKernel compares (XOR, fold, popcount); BGS-HostAlgnmtAlgo2.cpp:86-169 ----------
+            if (state == ST_CE_SA || state == ST_CE_TEXT) {
+                bool textHere = state == ST_CE_TEXT;                          // the line of this trip belongs to the current candidate
+                bool fresh = !textHere;                                       // the current candidate has not been set up yet
+                const bool haveNext = textHere && ceK + 1u < ceN;             // ... and the next candidate's entry came along
+                const uint32_t lineHere = idA & 0x3FFFFFFFu;
+                if (fresh) ceSa = saVal;
+                for (;;) {
+                    int verdict = 0;                                          // 1: accepted, -1: rejected, 0: needs a text line
+                    if (fresh) {
+                        const S3Step st0 = stepAt(s);
+                        ceRp = ceSa - (uint32_t)(st0.dir > 0 ? st0.lm0 : st0.lm0 - i);     // 32-bit wrap, as the reference
+                        ceT = s; ceII = i; ceIns = ins; ceAcc = occ; ceOff = 0; ceMm = 0;
+                        nSaL++;
+                        fresh = false;
+                    }
+                    for (;;) {
+                        const S3Step st = stepAt(ceT);
+                        const int pos = st.start + st.dir * ceII;
+                        const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end), right = (uint32_t)(pos < st.end ? st.end : pos);
+                        const uint32_t len = right - left + 1u;
+                        if (ceOff == 0) {
+                            // entering a step: its piece must lie inside the text
+                            if (ceEarly && ceT == s) {
+                                const long long rpS = (long long)ceSa - (long long)(st.dir > 0 ? st.lm0 : st.lm0 - i);
+                                if (rpS + (long long)left < 0 || rpS + (long long)right >= (long long)ix.n) { verdict = -1; break; }
+                            }
+                            if (ceRp + left > ix.n) { verdict = -1; break; }    // BGS-HostAlgnmtAlgo2.cpp:122-125
+                        }
+                        const uint32_t tpos = ceRp + left + (uint32_t)ceOff;
+                        if (!textHere || (tpos >> 8) != lineHere) break;        // that line is not here: next trip
+                        uint32_t todo = len - (uint32_t)ceOff;
+                        const uint32_t inLine = 256u - (tpos & 255u);
+                        if (todo > inLine) todo = inLine;
+                        for (uint32_t o = 0; o < todo; o += 16u) {
+                            const uint32_t c = todo - o > 16u ? 16u : todo - o;
+                            const uint32_t tp = (tpos + o) & 255u, w = tp >> 4, sh = (tp & 15u) * 2u;
+                            const uint32_t w0 = myStage32[w], w1 = w + 1u < 16u ? myStage32[w + 1u] : 0u;
+                            const uint32_t a_ = sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
+                            uint32_t x = a_ ^ readWindow((int)(left + (uint32_t)ceOff + o));
+                            x = (x | (x >> 1)) & 0x55555555u;
+                            if (c < 16u) x &= ~0u << (32u - 2u * c);
+                            ceMm += __popc(x);
+                        }
+                        nCeL += (todo + 31u) >> 5;
+                        ceOff += (int)todo;
+                        if ((uint32_t)ceOff < len) break;                          // the rest of the step lies in the next line
+                        const int tot = ceMm + ceIns;
+                        if (tot < st.minErr || tot > st.maxErr) { verdict = -1; break; }
+                        ceAcc += tot; ceT++; ceII = 0; ceIns = 0; ceOff = 0; ceMm = 0;
+                        if (ceT >= nSteps) { verdict = 1; break; }
+                    }
+                    if (verdict == 0) { state = ST_CE_TEXT; break; }
+                    if (verdict > 0) {
+                        // an occurrence: written under the unit's next sequence number (rejected candidates reserve nothing here)
+                        pendMeta = 0x80000000u | seq | (1u << 24) | ((uint32_t)ceAcc << 25);
+                        pendA = ceRp; pendB = ceRp;
+                        seq++; total++;
+                        countCertain(1u);
+                        ceMiss = 0;
+                    } else ceMiss++;
+                    ceK++;
+                    if (ceK >= ceN) { doSettle = true; needPop = true; break; }  // all candidates seen: the search goes on (settle sets the state)
+                    if (ceMiss >= in.ceGiveUp && !(pendMeta >> 31)) {
+                        // the rest of this range goes to ceKernel as a task (its candidates reserve their sequence numbers, as in the first pass)
+                        pendMeta = 0x80000000u | seq | S3_REC_TASK | (ceEarly ? S3_REC_EARLY : 0u);
+                        pendA = ceL + ceK;
+                        pendB = (ceN - ceK - 1u) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+                        seq += ceN - ceK;
+                        doSettle = true; needPop = true;
+                        break;
+                    }
+                    if (readTotal + total >= in.maxOut) { state = ST_DONE; sp = 0; nOwnMax++; break; }
+                    if (textHere && haveNext) { ceSa = saVal; fresh = true; textHere = false; continue; }   // set the next one up now; its text comes with the next trip
+                    state = ST_CE_SA;
+                    break;
+                }
+            }
+        }
         if (doSettle) settle(needPop);
         // ---------- write the parked records (convergent) ----------
         {
@@ -626,7 +747,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 }
                 if (pendMeta >> 31) {
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(in.unitMode ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(unitMode ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
                     pendMeta = 0;
                 }
                 recCur += np;
@@ -639,6 +760,13 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     if (out.counters) {
         atomicAdd(&out.counters[0], (unsigned long long)nRank);
         atomicAdd(&out.counters[1], (unsigned long long)nLt);
+        if constexpr (SECOND) {
+            atomicAdd(&out.counters[2], (unsigned long long)nSaL);
+            atomicAdd(&out.counters[3], (unsigned long long)nCeL);
+            atomicAdd(&out.counters[4], (unsigned long long)nCutSkip);
+            atomicAdd(&out.counters[5], (unsigned long long)nCutMid);
+            atomicAdd(&out.counters[6], (unsigned long long)nOwnMax);
+        }
     }
 }
 
@@ -664,12 +792,11 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         bool task = rec.x != 0xFFFFFFFFu && (rec.y & S3_REC_TASK);
         uint32_t item = rec.x & ~S3_REC_PASS2;
         uint32_t slotOf = item / groups;
-        uint32_t listed = 0xFFFFFFFFu, accepted = 0;
         if (task && (rec.x & S3_REC_PASS2)) {
-            // second-pass records count in unit space: unit = heavy read * groups * U + item * U + position
+            // second-pass records (units that gave up verifying their candidates themselves) count in unit space:
+            // unit = heavy read * groups * U + item * U + position
             const uint32_t unit = item - in.unitBase, U = in.unitsPerItem;
-            listed = unit / (groups * U);
-            slotOf = out.heavyList[listed];
+            slotOf = out.heavyList[unit / (groups * U)];
             item = slotOf * groups + (unit / U) % groups;
         } else if (task && out.heavyFlags[slotOf]) task = false;                 // stale: the second pass searched this read again
         const bool early = task && (rec.y & S3_REC_EARLY);
@@ -756,7 +883,6 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                     if (recEnd > out.recCap || recEnd < b0) { recEnd = b0 < out.recCap ? out.recCap : b0; if (lane == 0) atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
                 }
                 if (hit) {
-                    accepted++;
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
                     if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(rec.x, ((rec.y & 0xFFFFFFu) + k) | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
                 }
@@ -764,7 +890,6 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 if (recCur > recEnd) recCur = recEnd;
             }
         }
-        if (accepted && listed != 0xFFFFFFFFu) atomicAdd(&out.readAcc[listed], accepted);      // the listed read's running total (closes it for later rounds)
     }
     for (uint32_t j = recCur + lane; j < recEnd; j += 64u) out.recs[j] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
     if (out.counters) {
@@ -778,17 +903,23 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
 int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
 {
     if (in.nActive == 0) return (int)hipSuccess;
-    uint64_t blocks = ((uint64_t)in.nActive * (in.unitMode ? (uint64_t)in.itemSpan * (in.unitMode == 2u ? in.unitsPerItem : 1u) : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    uint64_t blocks = ((uint64_t)in.nActive * (in.unitMode ? (uint64_t)in.nCases * 2u * (in.unitMode == 2u ? in.unitsPerItem : 1u) : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wLds * 256u);
     if (lds > 48u * 1024u) {
         // more than the default dynamic LDS limit: without the attribute the launch itself fails later with a less useful error
-        hipError_t e = hipFuncSetAttribute((const void *)searchKernelV2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)searchKernelV2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)searchKernelV2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)searchKernelV2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)searchKernelV2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)searchKernelV2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    if (in.uniformLen) hipLaunchKernelGGL((searchKernelV2<true>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
-    else hipLaunchKernelGGL((searchKernelV2<false>), dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
+    const dim3 grid((unsigned)blocks), block(S3_SEARCH_BLOCK);
+    if (in.unitMode) {
+        if (in.uniformLen) hipLaunchKernelGGL((searchKernelV2<true, true>), grid, block, lds, s, ix, in, out);
+        else hipLaunchKernelGGL((searchKernelV2<false, true>), grid, block, lds, s, ix, in, out);
+    } else if (in.uniformLen) hipLaunchKernelGGL((searchKernelV2<true, false>), grid, block, lds, s, ix, in, out);
+    else hipLaunchKernelGGL((searchKernelV2<false, false>), grid, block, lds, s, ix, in, out);
     return (int)hipSuccess;
 }
 
