@@ -107,6 +107,11 @@ using namespace v2;
 // bound by its instruction count.  The record stream keeps the CPU path's order because accepted candidates are written under the reserved
 // numbers; rejected ones leave holes the ordering pass skips.  Not counting the candidates in `total` only delays the early stop at
 // MaxOutputPerRead: the per-read cut is applied again, exactly, when the records are merged.
+// in.unitMode = 3 (relay rounds): a unit that has cost more than in.unitBudget rank queries stops and leaves what it still had to do -- its position and
+// the frames of its depth-first stack, each an independent subtree, in sequence order -- in out.relay*; the next launch gives every such frame a
+// lane of its own (which may do the same again).  A frame counts its records in a slot of its own behind the units' slots; the host adds the
+// frames' totals to their unit's count before the scan and places every frame's slice right behind its parent's own records after it
+// (s3dp_kernels.hip::relayUpKernel / relayDownKernel): the order of the CPU path stays, the longest unit no longer sets the launch's length.
 // SECOND (template): the second pass over the listed reads, in.unitMode = 1 / 2, two launches.  Its lanes do check-and-extend THEMSELVES (states
 // ST_CE_SA / ST_CE_TEXT below) instead of writing task records: most occurrences of a read inside a repeat family are check-and-extend candidates,
 // and only a lane that knows which of them hold can stop where the CPU path stops -- at MaxOutputPerRead occurrences.  The units of a read start in
@@ -119,7 +124,7 @@ using namespace v2;
 //   2 (unit pass): one lane per (listed read, item, position p): it loads the read and the trunk state of p, takes ONLY the mismatch children at p
 //     and is from there on an ordinary depth-first search.
 template <bool UNIFORM, bool SECOND>
-__global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_V2_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(S3_SEARCH_BLOCK, SECOND ? S3_V2_WAVES_PER_SIMD_SECOND : S3_V2_WAVES_PER_SIMD)
 searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 {
     const uint32_t unitMode = SECOND ? in.unitMode : 0u;                    // (a constant 0 in the first pass: its code carries nothing of the second)
@@ -144,7 +149,9 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     // second pass: listed reads x the items of this round (x the units of an item: every position of the mismatch step + "none")
     const uint32_t nListed = SECOND ? *in.slotCount : 0u;
     const uint32_t unitsPerReadHere = unitMode ? groups * (unitMode == 2u ? in.unitsPerItem : 1u) : 1u;
-    const unsigned long long nSlots = unitMode ? (unsigned long long)nListed * unitsPerReadHere : in.nActive;
+    const unsigned long long nSlots = unitMode == 3u ? (unsigned long long)(in.relayEnd - in.relayBegin)
+                                      : unitMode ? (unsigned long long)nListed * unitsPerReadHere : in.nActive;
+    uint32_t unitTrips = 0, maxUnitTrips = 0; unsigned long long laneTrips = 0;   // (statistics)
     uint32_t nCutSkip = 0, nCutMid = 0, nOwnMax = 0;                       // (statistics: units skipped by the cut before their first step / stopped by it / stopped by their own total)
     uint32_t nSaL = 0, nCeL = 0;                                           // second pass: suffix-array reads / compare windows of its own check-and-extend
     uint32_t nRank = 0, nLt = 0;
@@ -174,6 +181,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     // pass (one trip per task instead of one or two per candidate; ceKernel verifies them, many lanes wide).  Knowing the count at once only pays
     // where candidates hold -- inside young repeat families, whose reads reach MaxOutputPerRead --, and either way the merge applies the cut exactly.
     uint32_t ceMiss = 0;
+    uint32_t unitRank = 0;                                                  // rank queries of this unit so far (relay: in.unitBudget)
     bool noCount = false;                                                   // unit mode: the lane found nothing to do (closed read, no trunk state): its counter is not its to write
     bool trunk = false;                                                     // the lane is still on the part of the item that all its units share
     uint32_t unitP = 0xFFFFFFFFu;                                           // position of the unit's first mismatch; 0xFFFFFFFF: none in the mismatch step
@@ -191,7 +199,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     bool padded = false;                                                    // the item's lookup range may hold an element that is no occurrence
     // wave-uniform work queue window
     uint64_t chunkCur = 0, chunkEnd = 0, chunkBase = 0;
-    uint32_t act0 = 0, act1 = 0, sl0 = 0, sl1 = 0;
+    uint32_t act0 = 0, act1 = 0, sl0 = 0, sl1 = 0, rl0 = 0, rl1 = 0;
     bool queueEmpty = false;
 
     auto stepAt = [&](int k) -> S3Step {
@@ -221,7 +229,13 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     // this unit that adds up to MaxOutputPerRead puts the read's cut right behind this unit; the items up to this one adding up to it put it
     // behind the item.
     auto tsAt = [&](uint32_t q) -> uint4 * { return out.trunkStates + ((size_t)sub * U + q) * nListed + listed; };
+    // (an accepted candidate is one occurrence: they are collected and booked S3_V2_COUNT_BATCH at a time, at the end of a range of candidates and at
+    //  the end of the unit -- the evaluation reads up to groups + U words)
+    uint32_t countPending = 0;
     auto countCertain = [&](uint32_t cnt) {
+        cnt += countPending;
+        countPending = 0;
+        if (cnt == 0) return;
         uint32_t *acc = out.itemAcc + (size_t)listed * groups;
         atomicAdd(&acc[sub], cnt);
         uint32_t before = 0;
@@ -343,6 +357,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             } else {
                 // (the "none" unit's counter is shared by the trunk lane, which may have handed the trunk itself to check-and-extend, and the unit
                 //  lane: a unit lane that wrote nothing -- closed, cut, no trunk state -- leaves the counter alone; it was zeroed before the pass)
+                if constexpr (SECOND) countCertain(0u);
                 if (!noCount && !(unitMode == 2u && seq == 0u)) out.itemCounts[cntIdx] = seq;
                 readTotal += total;
                 sub++;
@@ -370,7 +385,14 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 if (b >= nSlots) queueEmpty = true;
                 else {
                     chunkCur = chunkBase = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots;
-                    if (in.slotList) {
+                    if (SECOND && unitMode == 3u) {
+                        // relay round: the work items are the frames [relayBegin, relayEnd); their reads through the unit they belong to
+                        rl0 = b + lane < nSlots ? out.relayUnit[in.relayBegin + (uint32_t)(b + lane)] : 0xFFFFFFFFu;
+                        rl1 = b + 64u + lane < nSlots ? out.relayUnit[in.relayBegin + (uint32_t)(b + 64u + lane)] : 0xFFFFFFFFu;
+                        sl0 = rl0 != 0xFFFFFFFFu ? in.slotList[rl0 / (groups * U)] : 0u;
+                        sl1 = rl1 != 0xFFFFFFFFu ? in.slotList[rl1 / (groups * U)] : 0u;
+                        if (in.active) { act0 = in.active[sl0]; act1 = in.active[sl1]; }
+                    } else if (in.slotList) {
                         sl0 = b + lane < nSlots ? in.slotList[(uint32_t)(b + lane) % nListed] : 0u;
                         sl1 = b + 64u + lane < nSlots ? in.slotList[(uint32_t)(b + 64u + lane) % nListed] : 0u;
                         if (in.active) { act0 = in.active[sl0]; act1 = in.active[sl1]; }
@@ -389,14 +411,29 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)act1);
                 const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)sl0);
                 const uint32_t s1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)sl1);
+                uint32_t u0 = 0, u1 = 0;
+                if constexpr (SECOND) {
+                    u0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)rl0);
+                    u1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)rl1);
+                }
                 if (state == ST_DONE && rank < avail) {
                     slotIdx = (uint32_t)(chunkCur + rank);
                     sub = 0;
                     cntIdx = slotIdx * groups;
                     trunk = false; unitP = 0xFFFFFFFFu;
                     noCount = false;
-                    ceMiss = 0;
-                    if (unitMode) {
+                    ceMiss = 0; unitRank = 0; unitTrips = 0;
+                    if (SECOND && unitMode == 3u) {
+                        const uint32_t u = off < 64u ? u0 : u1;                 // the unit this frame belongs to (void entries: a group that did not fit)
+                        const uint32_t it = u / U;
+                        listed = it / groups;
+                        sub = it - listed * groups;
+                        cntIdx = in.extBase + in.relayBegin + slotIdx;
+                        unitInRead = sub * U + (u - it * U);
+                        cutPtr = out.readCut + listed;
+                        slotIdx = off < 64u ? s0 : s1;
+                        if (u == 0xFFFFFFFFu) { listed = 0; sub = 0; noCount = true; }
+                    } else if (unitMode) {
                         // queue order: item first, then position, the read last -- the units of one read start far apart, in their sequence order
                         const uint32_t rem = slotIdx / nListed;
                         listed = slotIdx - rem * nListed;
@@ -419,6 +456,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     seq = 0; total = 0; sp = 0; loadOff = 0;
                     hasItem = true;
                     state = ST_LOAD;
+                    if (SECOND && noCount) state = ST_DONE;                    // (a void relay entry)
                 }
                 chunkCur += nIdle < avail ? nIdle : avail;
             } else if (queueEmpty && idleMask == ~0ULL) break;                 // nothing left anywhere
@@ -495,7 +533,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (2u * wpq - loadOff > 4) aP1 = src + 1;
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
         } else if (state == ST_TRUNK) {
-            aP0 = tsAt(unitP == 0xFFFFFFFFu ? U - 1u : unitP);
+            aP0 = unitMode == 3u ? out.relayFrame + (cntIdx - in.extBase) : tsAt(unitP == 0xFFFFFFFFu ? U - 1u : unitP);
             aD1 = cutPtr;
         } else if (SECOND && state == ST_CE_SA) {
             aD0 = ix.sa + ceL + ceK;
@@ -546,9 +584,39 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
 
         // ---------- advance ----------
         bool doSettle = false, needPop = false;
+        if constexpr (SECOND) { if (state != ST_DONE) { unitTrips++; laneTrips++; if (unitTrips > maxUnitTrips) maxUnitTrips = unitTrips; } }
         if (unitMode && (state == ST_STEP || state == ST_TRUNK || state == ST_CE_SA || state == ST_CE_TEXT) && unitInRead > d1) {    // behind the read's cut
             if (state == ST_TRUNK) nCutSkip++; else nCutMid++;
             state = ST_DONE; sp = 0;
+        }
+        if constexpr (SECOND) {
+            // relay: over the budget -- the lane's position and its stack go to the next round, one lane per frame (sequence order: the position it
+            // stands on first, then the stack from the top)
+            // (only for a read that has found little so far: where occurrences come in, the read's cut is near and the ORDER of the search is what saves work)
+            bool relay = state == ST_STEP && unitRank > in.unitBudget && !trunk && unitMode >= 2u;
+            if (relay) {
+                const uint32_t *acc = out.itemAcc + (size_t)listed * groups;
+                uint32_t found = total;
+                for (uint32_t q = 0; q < groups; q++) found += __hip_atomic_load(&acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (found >= in.maxOut / 16u) { relay = false; unitRank = 0; }     // (asks again a budget later)
+            }
+            if (relay) {
+                const uint32_t n = (uint32_t)sp + 1u;
+                const uint32_t e0 = atomicAdd(out.relayCount, n);
+                if (e0 + n <= in.relayCap) {
+                    const uint32_t unit = (listed * groups + sub) * U + (unitInRead - sub * U);
+                    for (uint32_t j = 0; j < n; j++) {
+                        Frame f;
+                        if (j == 0) { f.fl = g.fl; f.fr = g.fr; f.rl = g.rl; f.meta = (uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17; }
+                        else f = stack[sp - (int)j];
+                        out.relayFrame[e0 + j] = make_uint4(f.fl, f.fr, f.rl, f.meta);
+                        out.relayUnit[e0 + j] = unit;
+                        out.relayParent[e0 + j] = cntIdx;
+                    }
+                    out.relayGroup[e0] = n << 24 | seq;                      // group head: siblings, and what the parent wrote itself
+                    state = ST_DONE; sp = 0;
+                } else unitRank = 0;                                        // no room: the lane goes on itself (and asks again a budget later)
+            }
         }
         // first pass: a read that has cost this many rank queries is heavy whatever it has found so far (dead ends cost steps, not candidates)
         if (!unitMode && state == ST_STEP && readRank > in.heavyRank) { goHeavy = true; state = ST_DONE; sp = 0; }
@@ -568,6 +636,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             nRank += 2;
             readRank += 2;
+            unitRank += 2;
             const int pos = stS.start + stS.dir * i;
             const uint32_t ch = readChar(pos);
             // child ranges: the active range advances by rank, the passive one shrinks by the occurrences of the larger symbols
@@ -611,6 +680,12 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (doSettle && !needPop) { g = gc; i++; }
         }
         if (state == ST_RESUME) { doSettle = true; needPop = false; }          // the completed frame that had to wait: emit it now, then pop
+        if (SECOND && state == ST_TRUNK && unitMode == 3u) {
+            // a relayed frame: what a pop would have found
+            Frame f; f.fl = p0.x; f.fr = p0.y; f.rl = p0.z; f.meta = p0.w;
+            stack[0] = f; sp = 1;
+            doSettle = true; needPop = true;
+        } else
         if (state == ST_TRUNK) {
             // the range the trunk pass held at this unit's position (.w = 0: the trunk never got there -- nothing to do)
             if (!(p0.w & S3_TRUNK_VALID)) { state = ST_DONE; noCount = true; }
@@ -631,7 +706,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             loadOff += 8;
             if constexpr (!UNIFORM) Li = (int)saVal;
-            if (loadOff >= 2u * wpq) state = unitMode == 2u ? ST_TRUNK : ST_KEYS;
+            if (loadOff >= 2u * wpq) state = unitMode >= 2u ? ST_TRUNK : ST_KEYS;
         } else if (state == ST_LT) {
             const S3Step st = stepAt(0);
             int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
@@ -654,6 +729,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             // ---------- check-and-extend by the lane itself: per candidate its suffix-array entry, then the text under the rest of the model, one 64-byte
             // line (256 characters) per trip, compared as ceKernel compares (XOR, fold, popcount); BGS-HostAlgnmtAlgo2.cpp:86-169 ----------
             if (state == ST_CE_SA || state == ST_CE_TEXT) {
+                unitRank++;                                                   // (a trip is a trip: the relay budget counts them all)
                 bool textHere = state == ST_CE_TEXT;                          // the line of this trip belongs to the current candidate
                 bool fresh = !textHere;                                       // the current candidate has not been set up yet
                 const bool haveNext = textHere && ceK + 1u < ceN;             // ... and the next candidate's entry came along
@@ -710,11 +786,11 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         pendMeta = 0x80000000u | seq | (1u << 24) | ((uint32_t)ceAcc << 25);
                         pendA = ceRp; pendB = ceRp;
                         seq++; total++;
-                        countCertain(1u);
+                        if (++countPending >= S3_V2_COUNT_BATCH) countCertain(0u);
                         ceMiss = 0;
                     } else ceMiss++;
                     ceK++;
-                    if (ceK >= ceN) { doSettle = true; needPop = true; break; }  // all candidates seen: the search goes on (settle sets the state)
+                    if (ceK >= ceN) { countCertain(0u); doSettle = true; needPop = true; break; }  // all candidates seen: the search goes on (settle sets the state)
                     if (ceMiss >= in.ceGiveUp && !(pendMeta >> 31)) {
                         // the rest of this range goes to ceKernel as a task (its candidates reserve their sequence numbers, as in the first pass)
                         pendMeta = 0x80000000u | seq | S3_REC_TASK | (ceEarly ? S3_REC_EARLY : 0u);
@@ -765,21 +841,26 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             atomicAdd(&out.counters[3], (unsigned long long)nCeL);
             atomicAdd(&out.counters[4], (unsigned long long)nCutSkip);
             atomicAdd(&out.counters[5], (unsigned long long)nCutMid);
-            atomicAdd(&out.counters[6], (unsigned long long)nOwnMax);
+            atomicAdd(&out.counters[6], laneTrips);
+            atomicMax(&out.counters[7], (unsigned long long)maxUnitTrips);
         }
     }
 }
 
-// ---- check-and-extend of the task records (SPLIT mode) --------------------------------------------------------------------------------
-// One lane per task; the lanes of a wave walk their candidates in lockstep (k-th candidate of every task), accepted ones are appended to the
-// record stream with one atomic per wave and round.  Per candidate: SA value, then per remaining model step the text against the oriented read,
-// 16 characters at a time (XOR, fold, popcount), the step's error window checked as in the stepping kernel (BGS-HostAlgnmtAlgo2.cpp:86-169).
+// ---- check-and-extend of the task records --------------------------------------------------------------------------------------------------
+// A wave takes 64 records at a time; the candidates of their tasks are numbered through (wave prefix sum of the task sizes, descriptors in LDS) and
+// dealt to the lanes 64 at a time -- one lane per CANDIDATE, whatever the sizes of the tasks (1 .. 256): a lane finds its task by bisection in the
+// prefix sums.  Accepted candidates are appended to the record stream with one atomic per wave and S3_V2_REC_BLOCK records.  Per candidate: SA
+// value, then per remaining model step the text against the oriented read, 16 characters at a time (XOR, fold, popcount), the step's error
+// window checked as in the stepping kernel (BGS-HostAlgnmtAlgo2.cpp:86-169).
 __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, SearchOut out, const uint32_t *taskRange)
 {
+    __shared__ uint4 sRec[4][64];                              // per wave: the task records of the batch ...
+    __shared__ uint32_t sStart[4][65], sRead[4][64];           // ... the number of their first candidate; the read a task belongs to
     const uint32_t firstRec = taskRange[0];                   // records [firstRec, nRec): what the stepping launches wrote since the last call
     uint32_t nRec = taskRange[1];
     if (nRec > out.recCap) nRec = out.recCap;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t groups = (uint32_t)in.nCases * 2u;
     const uint32_t S = in.wpqLoad;
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
@@ -795,31 +876,52 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         if (task && (rec.x & S3_REC_PASS2)) {
             // second-pass records (units that gave up verifying their candidates themselves) count in unit space:
             // unit = heavy read * groups * U + item * U + position
-            const uint32_t unit = item - in.unitBase, U = in.unitsPerItem;
+            const uint32_t U = in.unitsPerItem;
+            const uint32_t unit = item >= in.extBase ? out.relayUnit[item - in.extBase] : item - in.unitBase;      // (a relayed frame counts in a slot of its own)
             slotOf = out.heavyList[unit / (groups * U)];
             item = slotOf * groups + (unit / U) % groups;
         } else if (task && out.heavyFlags[slotOf]) task = false;                 // stale: the second pass searched this read again
-        const bool early = task && (rec.y & S3_REC_EARLY);
-        uint32_t size = 0, rIdx = 0, casIdx = 0, strand = 0;
-        int Li = 0, nSteps = 0, s0 = 0, i0 = 0, ins0 = 0, occ0 = 0;
-        if (task) {
-            size = (rec.w & 0xFFu) + 1u;
-            const uint32_t meta = rec.w >> 8;
-            s0 = (int)(meta & 7u); i0 = (int)((meta >> 3) & 0x7FFu); ins0 = (int)((meta >> 14) & 7u); occ0 = (int)((meta >> 17) & 7u);
-            const uint32_t slot = slotOf, sub = item % groups;
-            casIdx = sub >> 1; strand = sub & 1u;
-            rIdx = in.active ? in.active[slot] : slot;
-            Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
-            nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
+        const uint32_t size = task ? (rec.w & 0xFFu) + 1u : 0u;
+        // exclusive prefix sum of the sizes over the wave
+        uint32_t incl = size;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, (int)d);
+            if (lane >= d) incl += v;
         }
-        const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
-        const S3Case &cs = in.models[Li].cs[casIdx];
-        for (uint32_t k = 0; __ballot(k < size); k++) {
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        if (total == 0) continue;
+        __builtin_amdgcn_wave_barrier();
+        sRec[wv][lane] = make_uint4(rec.x, rec.y, rec.z, (rec.w & 0xFFFFFF00u) | (item % groups));     // (low byte: the (case, strand) of the item)
+        sStart[wv][lane] = incl - size;
+        if (lane == 63u) sStart[wv][64] = total;
+        sRead[wv][lane] = task ? (in.active ? in.active[slotOf] : slotOf) : 0u;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
+            const uint32_t c = c0 + lane;
             bool hit = false;
-            uint32_t rp = 0;
-            int acc = occ0;
-            if (k < size) {
-                const uint32_t sa = ix.sa[rec.z + k];
+            uint32_t rp = 0, recX = 0, seqK = 0;
+            int acc = 0;
+            if (c < total) {
+                // the task this candidate belongs to: the last one that starts at or before c (tasks of size 0 start where the next one starts)
+                uint32_t lo = 0, hi = 63u;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    if (sStart[wv][mid] <= c) lo = mid; else hi = mid - 1u;
+                }
+                const uint4 tr = sRec[wv][lo];
+                const uint32_t k = c - sStart[wv][lo];
+                const uint32_t meta = tr.w >> 8, sub = tr.w & 0xFFu;
+                const int s0 = (int)(meta & 7u), i0 = (int)((meta >> 3) & 0x7FFu), ins0 = (int)((meta >> 14) & 7u), occ0 = (int)((meta >> 17) & 7u);
+                const uint32_t casIdx = sub >> 1, strand = sub & 1u, rIdx = sRead[wv][lo];
+                const bool early = (tr.y & S3_REC_EARLY) != 0;
+                const int Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
+                const int nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
+                const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
+                const S3Case &cs = in.models[Li].cs[casIdx];
+                recX = tr.x; seqK = (tr.y & 0xFFFFFFu) + k;
+                acc = occ0;
+                const uint32_t sa = ix.sa[tr.z + k];
                 nSa++;
                 const S3Step st0 = cs.st[s0];
                 const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i0;
@@ -854,12 +956,12 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
 #pragma unroll
                         for (uint32_t j = 0; j < 8; j++) {
                             if (j * 16u < piece) {
-                                const uint32_t c = piece - j * 16u > 16u ? 16u : piece - j * 16u;
+                                const uint32_t cch = piece - j * 16u > 16u ? 16u : piece - j * 16u;
                                 const uint32_t a_ = tsh ? (tw[j] << tsh) | (tw[j + 1] >> (32u - tsh)) : tw[j];
                                 const uint32_t b_ = qsh ? (qw[j] << qsh) | (qw[j + 1] >> (32u - qsh)) : qw[j];
                                 uint32_t x = a_ ^ b_;
                                 x = (x | (x >> 1)) & 0x55555555u;
-                                if (c < 16u) x &= ~0u << (32u - 2u * c);
+                                if (cch < 16u) x &= ~0u << (32u - 2u * cch);
                                 mm += __popc(x);
                             }
                         }
@@ -884,7 +986,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 }
                 if (hit) {
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(rec.x, ((rec.y & 0xFFFFFFu) + k) | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
+                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(recX, seqK | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
                 }
                 recCur += np;
                 if (recCur > recEnd) recCur = recEnd;
@@ -904,6 +1006,7 @@ int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out,
 {
     if (in.nActive == 0) return (int)hipSuccess;
     uint64_t blocks = ((uint64_t)in.nActive * (in.unitMode ? (uint64_t)in.nCases * 2u * (in.unitMode == 2u ? in.unitsPerItem : 1u) : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    if (in.unitMode == 3u) blocks = ((uint64_t)(in.relayEnd - in.relayBegin) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wLds * 256u);
     if (lds > 48u * 1024u) {
