@@ -433,8 +433,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     }
     in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0;
     in.ceGiveUp = (uint32_t)envSize("S3DP_CE_GIVE_UP", S3_CE_GIVE_UP);
-    in.unitBudget = 0xFFFFFFFFu; in.relayBegin = in.relayEnd = in.relayCap = 0; in.extBase = 0xFFFFFFFFu;
-    std::vector<uint32_t> relayRounds;                                     // ends of the relay rounds of this pass (frames [previous end, end))
+    in.ceInlineMax = (uint32_t)envSize("S3DP_CE_INLINE_MAX", 128);
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
     unsigned long long counterSnap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (b->counting) {
@@ -480,7 +479,6 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         out.workHead = b->dWorkHead;
         out.heavyFlags = b->dHeavyFlags; out.heavyList = b->dHeavyList; out.heavyCount = b->dHeavyCount; out.heavyIndex = b->dHeavyIndex;
         nHeavy = 0; nCount = (uint32_t)nItems;
-        relayRounds.clear(); in.extBase = 0xFFFFFFFFu;
         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
         // timing: one event pair per group of stepping launches / per check-and-extend launch (they alternate when the second pass runs in rounds)
         auto mark = [&](std::vector<hipEvent_t> &ev, uint32_t &used, bool begin) -> hipError_t {
@@ -533,21 +531,9 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                 if (nHeavy) {
                     uint32_t U = unitsPerItem;
                     const uint64_t groups = (uint64_t)nCases * 2u;
-                    // relay: units over S3DP_UNIT_BUDGET rank queries (0, the default: never -- measured: a round lasts as long as its slowest lane, 4-5 us per trip, and ten rounds cost more than the tail they cut) hand what is left of them to further launches, at most
-                    // S3DP_RELAY_CAP frames per pass (default 4 M: 128 MB)
-                    const uint32_t unitBudget = (uint32_t)envSize("S3DP_UNIT_BUDGET", 0);     // read per pass: tests switch it
-                    const uint32_t relayCap = unitBudget ? (uint32_t)envSize("S3DP_RELAY_CAP", 4u << 20) : 0u;
-                    if (nItems + (uint64_t)nHeavy * groups * U + relayCap >= 0x7FFFFF00ull) U = 1;          // (unit indices share a word with a flag bit)
-                    if (nItems + (uint64_t)nHeavy * groups * U + relayCap >= 0x7FFFFF00ull) return fail(S3_EOVERFLOW, "too many heavy reads in one batch: use smaller batches");
-                    const size_t nUnitsEnd = nItems + (size_t)nHeavy * groups * U;            // count slots: the items, the units, one for the total, the relayed frames
-                    const size_t need = nUnitsEnd + 1 + relayCap;
-                    if (relayCap > b->relayCap) {
-                        int rc;
-                        if ((rc = bgrow(b, &b->dRelayFrame, relayCap, 0)) || (rc = bgrow(b, &b->dRelayUnit, relayCap, 0)) || (rc = bgrow(b, &b->dRelayParent, relayCap, 0)) ||
-                            (rc = bgrow(b, &b->dRelayGroup, relayCap, 0)) || (rc = bgrow(b, &b->dRelayChild, relayCap, 0))) return rc;
-                        if (!b->dRelayCount && (rc = balloc(b, &b->dRelayCount, 4))) return rc;
-                        b->relayCap = relayCap;
-                    }
+                    if (nItems + (uint64_t)nHeavy * groups * U >= 0x7FFFFF00ull) U = 1;          // (unit indices share a word with a flag bit)
+                    if (nItems + (uint64_t)nHeavy * groups * U >= 0x7FFFFF00ull) return fail(S3_EOVERFLOW, "too many heavy reads in one batch: use smaller batches");
+                    const size_t need = nItems + (size_t)nHeavy * groups * U + 1;
                     if (need > b->countCap) {
                         size_t cap = b->countCap;
                         while (cap < need) cap += cap / 2 + 1;
@@ -562,16 +548,8 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                         if (t1 + 256 > b->tempBytes) { if ((rc = bgrow(b, &b->dTemp, t1 + 256, 0))) return rc; b->tempBytes = t1 + 256; }
                         out.itemCounts = b->dItemCounts;
                     }
-                    nCount = (uint32_t)nUnitsEnd;
+                    nCount = (uint32_t)(need - 1);
                     HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, (need - nItems) * 4, b->stream));
-                    if (relayCap) {
-                        HIPCHK(hipMemsetAsync(b->dRelayCount, 0, 4, b->stream));
-                        HIPCHK(hipMemsetAsync(b->dRelayUnit, 0xFF, (size_t)relayCap * 4, b->stream));
-                        HIPCHK(hipMemsetAsync(b->dRelayGroup, 0, (size_t)relayCap * 4, b->stream));
-                        HIPCHK(hipMemsetAsync(b->dRelayChild, 0, (size_t)relayCap * 4, b->stream));
-                        out.relayCount = b->dRelayCount; out.relayFrame = b->dRelayFrame; out.relayUnit = b->dRelayUnit; out.relayParent = b->dRelayParent;
-                        out.relayGroup = b->dRelayGroup;
-                    }
                     // the listed reads count per unit from here on
                     launchZeroListedCounts(b->dHeavyList, b->dHeavyCount, nHeavy, (uint32_t)groups, b->dItemCounts, b->stream);
                     // the trunk states: 16 B per (listed read, item, position)
@@ -596,10 +574,6 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu; in2.heavyRank = 0xFFFFFFFFu;
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
                     in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (the scatter decodes unit indices with them)
-                    if (relayCap) {
-                        in2.unitBudget = unitBudget; in2.relayCap = relayCap;
-                        in2.extBase = in.extBase = (uint32_t)nUnitsEnd + 1u;
-                    }
                     HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
                     for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass
                         in2.unitMode = mode;
@@ -607,25 +581,6 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                         le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksSecond, b->stream);
                         if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
                         lap(mode == 1 ? "trunk pass" : "unit pass", (uint64_t)nHeavy * groups * (mode == 1 ? 1 : U));
-                    }
-                    if (relayCap && U > 1) {
-                        // relay rounds: what the over-budget units left behind, one lane per frame; the last round has no budget
-                        const int maxRounds = 12;
-                        uint32_t r0 = 0;
-                        for (int round = 0; round < maxRounds; round++) {
-                            uint32_t r1 = 0;
-                            HIPCHK(d2h(&r1, b->dRelayCount, 4, b->stream));
-                            if (r1 > relayCap) r1 = relayCap;
-                            if (r1 <= r0) break;
-                            relayRounds.push_back(r1);
-                            in2.unitMode = 3; in2.relayBegin = r0; in2.relayEnd = r1;
-                            in2.unitBudget = round + 1 == maxRounds ? 0xFFFFFFFFu : unitBudget;
-                            HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-                            le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksSecond, b->stream);
-                            if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (relay round): ") + hipGetErrorString(le));
-                            lap("relay round", r1 - r0);
-                            r0 = r1;
-                        }
                     }
                     HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
                 }
@@ -638,9 +593,6 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             if (verbose && b->counting)
                 fprintf(stderr, "[s3dp] search mm=%u listed reads %u of %u, units per item %u\n", modelMm, nHeavy, nActive, in.unitsPerItem);
         }
-        // relayed frames: their totals go into their units' counts (rounds backwards) ...
-        for (size_t k = relayRounds.size(); k-- > 0;)
-            launchRelayUp(k ? relayRounds[k - 1] : 0u, relayRounds[k], in.extBase, b->dRelayGroup, b->dRelayParent, b->dRelayChild, b->dItemCounts, b->stream);
         // offsets of the items in the ordered array (the scan runs before the host looks at the flags: one synchronisation per pass for both answers)
         HIPCHK(hipMemsetAsync(b->dItemCounts + nCount, 0, 4, b->stream));
         {
@@ -649,9 +601,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             int rc = sum64Async(b, b->dItemCounts, nCount);
             if (rc) return rc;
         }
-        // ... and every frame's slice lies behind its parent's own records (rounds forwards)
-        for (size_t k = 0; k < relayRounds.size(); k++)
-            launchRelayDown(k ? relayRounds[k - 1] : 0u, relayRounds[k], in.extBase, b->dRelayGroup, b->dRelayParent, b->dRelayChild, b->dItemCounts, b->dItemOffsets, b->stream);
+
         // a record that did not fit was dropped but counted: the ordering below must not run on such a pass.  Grow and search again.
         uint32_t flags = 0;
         HIPCHK(hipMemcpyAsync(&flags, b->dFlags, 4, hipMemcpyDeviceToHost, b->stream));
@@ -684,7 +634,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     }
     launchFillInvalid(b->dOrdered, b->dItemOffsets + nCount, b->ordCap, b->stream);
     launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->dHeavyFlags, b->dHeavyList, (uint32_t)nCases * 2u, in.unitBase, in.unitsPerItem,
-                  in.extBase, b->dRelayUnit, b->stream);
+                  b->stream);
     // what the merge / decode kernels need to find a read's slice of the ordered array (kept for the decode calls that follow this pass)
     b->mergeUnitBase = in.unitBase; b->mergeUnitsPerRead = nHeavy ? (uint32_t)nCases * 2u * in.unitsPerItem : 0u;
     // the long-read list of the merge kernels shares the buffer of the heavy list, which the scatter above still reads: a second list

@@ -66,9 +66,7 @@ struct SearchIn {
     uint32_t        unitsPerItem;  // second pass: first-mismatch positions an item is cut into, + 1 for "none" (1: whole items)
     uint32_t        unitBase;      // second pass: unit u counts its records in itemCounts[unitBase + u]
     uint32_t        sStarPacked;   // 3 bits per case: the first step that allows a mismatch (= nSteps: none)
-    uint32_t        unitBudget;    // second pass: rank queries after which a unit relays what is left of it to the next round (0xFFFFFFFF: never)
-    uint32_t        relayBegin, relayEnd, relayCap;   // unitMode 3: the relayed frames of this round; room in the relay arrays
-    uint32_t        extBase;       // count slot of relayed frame e: extBase + e (behind the units' slots; 0xFFFFFFFF: no relay)
+    uint32_t        ceInlineMax;   // second pass: occurrences a unit verifies itself before it hands the rest of its candidates to ceKernel
     uint32_t        ceGiveUp;      // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel (S3_CE_GIVE_UP)
     uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_v2.hip)
 };
@@ -92,11 +90,6 @@ struct SearchOut {
     uint32_t           *heavyIndex; // per listed slot: its place in heavyList
     uint32_t           *readCut;     // second pass, per listed read: the smallest unit (item * units + position) that holds maxOut occurrences by itself
     uint32_t           *itemAcc;     // second pass, per listed read and item: occurrences its units hold for sure (sums over the items give the cut too)
-    uint32_t           *relayCount;  // relayed frames so far
-    uint4              *relayFrame;  // {l, r, rev l, meta} as on the depth-first stack
-    uint32_t           *relayUnit;   // the unit ((listed read * groups + item) * units + position) a frame belongs to; 0xFFFFFFFF: void
-    uint32_t           *relayParent; // count slot of the lane that relayed it (a unit's or a frame's)
-    uint32_t           *relayGroup;  // first frame of a relaying lane: siblings << 24 | records the lane wrote itself
     uint4              *trunkStates; // second pass: {l, r, rev l, S3_TRUNK_VALID | occurrences of the unit} at [(item * units + position) * listed reads + read]
 };
 
@@ -145,10 +138,7 @@ void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &
 int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int
 void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s);
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,
-                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, uint32_t extBase, const uint32_t *relayUnit, hipStream_t s);
-void launchRelayUp(uint32_t r0, uint32_t r1, uint32_t extBase, const uint32_t *group, const uint32_t *parent, uint32_t *childTot, uint32_t *itemCounts, hipStream_t s);
-void launchRelayDown(uint32_t r0, uint32_t r1, uint32_t extBase, const uint32_t *group, const uint32_t *parent, const uint32_t *childTot, const uint32_t *itemCounts,
-                     uint32_t *itemOffsets, hipStream_t s);
+                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, hipStream_t s);
 void launchMergeCount(const MergeArgs &a, hipStream_t s);
 void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s);
 void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOffsets, uint32_t occBase, uint32_t occCap, uint32_t *occPos,

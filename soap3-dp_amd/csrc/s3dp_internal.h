@@ -53,9 +53,6 @@ struct s3_batch {
     uint32_t *dHeavyList = nullptr, *dHeavyCount = nullptr, *dHeavyIndex = nullptr;
     uint32_t *dLongList = nullptr, *dLongCount = nullptr;      // reads whose slice of the ordered array is walked by a whole wave (merge / decode)
     uint32_t *dItemAcc = nullptr; size_t accCap = 0;            // per listed read and item: certain occurrences (second search pass)
-    // relayed frames of over-budget units (allocated with the first second pass)
-    uint4 *dRelayFrame = nullptr; uint32_t *dRelayUnit = nullptr, *dRelayParent = nullptr, *dRelayGroup = nullptr, *dRelayChild = nullptr, *dRelayCount = nullptr;
-    uint32_t relayCap = 0;
     uint4 *dTrunk = nullptr; size_t trunkCap = 0;              // trunk states of the second search pass
     size_t countCap = 0;                                       // entries of dItemCounts / dItemOffsets (items + units of the listed reads + 1)
     uint32_t mergeUnitBase = 0, mergeUnitsPerRead = 0;         // of the last search pass (0: no read was taken apart)

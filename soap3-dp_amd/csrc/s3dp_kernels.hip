@@ -96,8 +96,7 @@ void launchSaExpand(const DevBwt &b, const uint32_t *samples, uint32_t interval,
 // ordering: records -> CSR by item (counting scatter; offsets = exclusive scan of itemCounts)
 // ---------------------------------------------------------------------------------------------
 __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered,
-                              const uint8_t *heavyFlags, const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem,
-                              uint32_t extBase, const uint32_t *relayUnit)
+                              const uint8_t *heavyFlags, const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem)
 {
     uint32_t n = *recCount;
     if (n > recCap) n = recCap;
@@ -108,7 +107,7 @@ __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint3
         if (r.x & S3_REC_PASS2) {
             // written by the second search pass (or by check-and-extend of its tasks): counted per unit; downstream the record carries its ITEM again
             at = r.x & ~S3_REC_PASS2;
-            const uint32_t unit = at >= extBase ? relayUnit[at - extBase] : at - unitBase;       // (a relayed frame counts in a slot of its own)
+            const uint32_t unit = at - unitBase;
             r.x = heavyList[unit / (groups * unitsPerItem)] * groups + (unit / unitsPerItem) % groups;
         } else if (heavyFlags[r.x / groups]) continue;                         // stale: the second pass searched this read again
         ordered[itemOffsets[at] + (r.y & 0xFFFFFFu)] = r;
@@ -525,54 +524,10 @@ void launchZeroListedCounts(const uint32_t *heavyList, const uint32_t *heavyCoun
     hipLaunchKernelGGL(zeroListedCountsKernel, dim3(blocks), dim3(256), 0, s, heavyList, heavyCount, groups, itemCounts);
 }
 
-// Relayed frames (s3dp_search_v2.hip, unitMode 3).  Before the scan: every group of frames adds what it holds -- own records and what its frames relayed in
-// turn -- to its parent (rounds in reverse order); after the scan: every group's frames are placed, in order, right behind the parent's own records
-// (rounds in forward order).
-__global__ void relayUpKernel(uint32_t r0, uint32_t r1, uint32_t extBase, const uint32_t *group, const uint32_t *parent, uint32_t *childTot, uint32_t *itemCounts)
-{
-    const uint32_t e = r0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= r1) return;
-    const uint32_t g = group[e];
-    if (!g) return;
-    const uint32_t n = g >> 24;
-    uint32_t tot = 0;
-    for (uint32_t j = 0; j < n; j++) tot += itemCounts[extBase + e + j] + childTot[e + j];
-    const uint32_t p = parent[e];
-    if (p >= extBase) childTot[p - extBase] = tot;
-    else atomicAdd(&itemCounts[p], tot);
-}
-
-__global__ void relayDownKernel(uint32_t r0, uint32_t r1, uint32_t extBase, const uint32_t *group, const uint32_t *parent, const uint32_t *childTot,
-                                const uint32_t *itemCounts, uint32_t *itemOffsets)
-{
-    const uint32_t e = r0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= r1) return;
-    const uint32_t g = group[e];
-    if (!g) return;
-    const uint32_t n = g >> 24;
-    uint32_t base = itemOffsets[parent[e]] + (g & 0xFFFFFFu);
-    for (uint32_t j = 0; j < n; j++) {
-        itemOffsets[extBase + e + j] = base;
-        base += itemCounts[extBase + e + j] + childTot[e + j];
-    }
-}
-
-void launchRelayUp(uint32_t r0, uint32_t r1, uint32_t extBase, const uint32_t *group, const uint32_t *parent, uint32_t *childTot, uint32_t *itemCounts, hipStream_t s)
-{
-    if (r1 > r0) hipLaunchKernelGGL(relayUpKernel, dim3((r1 - r0 + 255) / 256), dim3(256), 0, s, r0, r1, extBase, group, parent, childTot, itemCounts);
-}
-
-void launchRelayDown(uint32_t r0, uint32_t r1, uint32_t extBase, const uint32_t *group, const uint32_t *parent, const uint32_t *childTot, const uint32_t *itemCounts,
-                     uint32_t *itemOffsets, hipStream_t s)
-{
-    if (r1 > r0) hipLaunchKernelGGL(relayDownKernel, dim3((r1 - r0 + 255) / 256), dim3(256), 0, s, r0, r1, extBase, group, parent, childTot, itemCounts, itemOffsets);
-}
-
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,
-                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, uint32_t extBase, const uint32_t *relayUnit, hipStream_t s)
+                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, hipStream_t s)
 {
-    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, heavyFlags, heavyList, groups, unitBase, unitsPerItem,
-                       extBase, relayUnit);
+    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, heavyFlags, heavyList, groups, unitBase, unitsPerItem);
 }
 
 void launchMergeCount(const MergeArgs &a, hipStream_t s)

@@ -107,11 +107,6 @@ using namespace v2;
 // bound by its instruction count.  The record stream keeps the CPU path's order because accepted candidates are written under the reserved
 // numbers; rejected ones leave holes the ordering pass skips.  Not counting the candidates in `total` only delays the early stop at
 // MaxOutputPerRead: the per-read cut is applied again, exactly, when the records are merged.
-// in.unitMode = 3 (relay rounds): a unit that has cost more than in.unitBudget rank queries stops and leaves what it still had to do -- its position and
-// the frames of its depth-first stack, each an independent subtree, in sequence order -- in out.relay*; the next launch gives every such frame a
-// lane of its own (which may do the same again).  A frame counts its records in a slot of its own behind the units' slots; the host adds the
-// frames' totals to their unit's count before the scan and places every frame's slice right behind its parent's own records after it
-// (s3dp_kernels.hip::relayUpKernel / relayDownKernel): the order of the CPU path stays, the longest unit no longer sets the launch's length.
 // SECOND (template): the second pass over the listed reads, in.unitMode = 1 / 2, two launches.  Its lanes do check-and-extend THEMSELVES (states
 // ST_CE_SA / ST_CE_TEXT below) instead of writing task records: most occurrences of a read inside a repeat family are check-and-extend candidates,
 // and only a lane that knows which of them hold can stop where the CPU path stops -- at MaxOutputPerRead occurrences.  The units of a read start in
@@ -149,8 +144,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     // second pass: listed reads x the items of this round (x the units of an item: every position of the mismatch step + "none")
     const uint32_t nListed = SECOND ? *in.slotCount : 0u;
     const uint32_t unitsPerReadHere = unitMode ? groups * (unitMode == 2u ? in.unitsPerItem : 1u) : 1u;
-    const unsigned long long nSlots = unitMode == 3u ? (unsigned long long)(in.relayEnd - in.relayBegin)
-                                      : unitMode ? (unsigned long long)nListed * unitsPerReadHere : in.nActive;
+    const unsigned long long nSlots = unitMode ? (unsigned long long)nListed * unitsPerReadHere : in.nActive;
     uint32_t unitTrips = 0, maxUnitTrips = 0; unsigned long long laneTrips = 0;   // (statistics)
     uint32_t nCutSkip = 0, nCutMid = 0, nOwnMax = 0;                       // (statistics: units skipped by the cut before their first step / stopped by it / stopped by their own total)
     uint32_t nSaL = 0, nCeL = 0;                                           // second pass: suffix-array reads / compare windows of its own check-and-extend
@@ -180,8 +174,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     // A unit whose candidates keep failing stops verifying them itself: after S3_CE_GIVE_UP rejections in a row it writes task records like the first
     // pass (one trip per task instead of one or two per candidate; ceKernel verifies them, many lanes wide).  Knowing the count at once only pays
     // where candidates hold -- inside young repeat families, whose reads reach MaxOutputPerRead --, and either way the merge applies the cut exactly.
-    uint32_t ceMiss = 0;
-    uint32_t unitRank = 0;                                                  // rank queries of this unit so far (relay: in.unitBudget)
+    uint32_t ceMiss = 0, ceTaken = 0;
     bool noCount = false;                                                   // unit mode: the lane found nothing to do (closed read, no trunk state): its counter is not its to write
     bool trunk = false;                                                     // the lane is still on the part of the item that all its units share
     uint32_t unitP = 0xFFFFFFFFu;                                           // position of the unit's first mismatch; 0xFFFFFFFF: none in the mismatch step
@@ -199,7 +192,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     bool padded = false;                                                    // the item's lookup range may hold an element that is no occurrence
     // wave-uniform work queue window
     uint64_t chunkCur = 0, chunkEnd = 0, chunkBase = 0;
-    uint32_t act0 = 0, act1 = 0, sl0 = 0, sl1 = 0, rl0 = 0, rl1 = 0;
+    uint32_t act0 = 0, act1 = 0, sl0 = 0, sl1 = 0;
     bool queueEmpty = false;
 
     auto stepAt = [&](int k) -> S3Step {
@@ -385,14 +378,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 if (b >= nSlots) queueEmpty = true;
                 else {
                     chunkCur = chunkBase = b; chunkEnd = b + S3_V2_CHUNK < nSlots ? b + S3_V2_CHUNK : nSlots;
-                    if (SECOND && unitMode == 3u) {
-                        // relay round: the work items are the frames [relayBegin, relayEnd); their reads through the unit they belong to
-                        rl0 = b + lane < nSlots ? out.relayUnit[in.relayBegin + (uint32_t)(b + lane)] : 0xFFFFFFFFu;
-                        rl1 = b + 64u + lane < nSlots ? out.relayUnit[in.relayBegin + (uint32_t)(b + 64u + lane)] : 0xFFFFFFFFu;
-                        sl0 = rl0 != 0xFFFFFFFFu ? in.slotList[rl0 / (groups * U)] : 0u;
-                        sl1 = rl1 != 0xFFFFFFFFu ? in.slotList[rl1 / (groups * U)] : 0u;
-                        if (in.active) { act0 = in.active[sl0]; act1 = in.active[sl1]; }
-                    } else if (in.slotList) {
+                    if (in.slotList) {
                         sl0 = b + lane < nSlots ? in.slotList[(uint32_t)(b + lane) % nListed] : 0u;
                         sl1 = b + 64u + lane < nSlots ? in.slotList[(uint32_t)(b + 64u + lane) % nListed] : 0u;
                         if (in.active) { act0 = in.active[sl0]; act1 = in.active[sl1]; }
@@ -411,29 +397,14 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                 const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)act1);
                 const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)sl0);
                 const uint32_t s1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)sl1);
-                uint32_t u0 = 0, u1 = 0;
-                if constexpr (SECOND) {
-                    u0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)rl0);
-                    u1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((off & 63u) * 4u), (int)rl1);
-                }
                 if (state == ST_DONE && rank < avail) {
                     slotIdx = (uint32_t)(chunkCur + rank);
                     sub = 0;
                     cntIdx = slotIdx * groups;
                     trunk = false; unitP = 0xFFFFFFFFu;
                     noCount = false;
-                    ceMiss = 0; unitRank = 0; unitTrips = 0;
-                    if (SECOND && unitMode == 3u) {
-                        const uint32_t u = off < 64u ? u0 : u1;                 // the unit this frame belongs to (void entries: a group that did not fit)
-                        const uint32_t it = u / U;
-                        listed = it / groups;
-                        sub = it - listed * groups;
-                        cntIdx = in.extBase + in.relayBegin + slotIdx;
-                        unitInRead = sub * U + (u - it * U);
-                        cutPtr = out.readCut + listed;
-                        slotIdx = off < 64u ? s0 : s1;
-                        if (u == 0xFFFFFFFFu) { listed = 0; sub = 0; noCount = true; }
-                    } else if (unitMode) {
+                    ceMiss = 0; ceTaken = 0; unitTrips = 0;
+                    if (unitMode) {
                         // queue order: item first, then position, the read last -- the units of one read start far apart, in their sequence order
                         const uint32_t rem = slotIdx / nListed;
                         listed = slotIdx - rem * nListed;
@@ -456,7 +427,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                     seq = 0; total = 0; sp = 0; loadOff = 0;
                     hasItem = true;
                     state = ST_LOAD;
-                    if (SECOND && noCount) state = ST_DONE;                    // (a void relay entry)
                 }
                 chunkCur += nIdle < avail ? nIdle : avail;
             } else if (queueEmpty && idleMask == ~0ULL) break;                 // nothing left anywhere
@@ -533,7 +503,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (2u * wpq - loadOff > 4) aP1 = src + 1;
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
         } else if (state == ST_TRUNK) {
-            aP0 = unitMode == 3u ? out.relayFrame + (cntIdx - in.extBase) : tsAt(unitP == 0xFFFFFFFFu ? U - 1u : unitP);
+            aP0 = tsAt(unitP == 0xFFFFFFFFu ? U - 1u : unitP);
             aD1 = cutPtr;
         } else if (SECOND && state == ST_CE_SA) {
             aD0 = ix.sa + ceL + ceK;
@@ -589,35 +559,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (state == ST_TRUNK) nCutSkip++; else nCutMid++;
             state = ST_DONE; sp = 0;
         }
-        if constexpr (SECOND) {
-            // relay: over the budget -- the lane's position and its stack go to the next round, one lane per frame (sequence order: the position it
-            // stands on first, then the stack from the top)
-            // (only for a read that has found little so far: where occurrences come in, the read's cut is near and the ORDER of the search is what saves work)
-            bool relay = state == ST_STEP && unitRank > in.unitBudget && !trunk && unitMode >= 2u;
-            if (relay) {
-                const uint32_t *acc = out.itemAcc + (size_t)listed * groups;
-                uint32_t found = total;
-                for (uint32_t q = 0; q < groups; q++) found += __hip_atomic_load(&acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (found >= in.maxOut / 16u) { relay = false; unitRank = 0; }     // (asks again a budget later)
-            }
-            if (relay) {
-                const uint32_t n = (uint32_t)sp + 1u;
-                const uint32_t e0 = atomicAdd(out.relayCount, n);
-                if (e0 + n <= in.relayCap) {
-                    const uint32_t unit = (listed * groups + sub) * U + (unitInRead - sub * U);
-                    for (uint32_t j = 0; j < n; j++) {
-                        Frame f;
-                        if (j == 0) { f.fl = g.fl; f.fr = g.fr; f.rl = g.rl; f.meta = (uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17; }
-                        else f = stack[sp - (int)j];
-                        out.relayFrame[e0 + j] = make_uint4(f.fl, f.fr, f.rl, f.meta);
-                        out.relayUnit[e0 + j] = unit;
-                        out.relayParent[e0 + j] = cntIdx;
-                    }
-                    out.relayGroup[e0] = n << 24 | seq;                      // group head: siblings, and what the parent wrote itself
-                    state = ST_DONE; sp = 0;
-                } else unitRank = 0;                                        // no room: the lane goes on itself (and asks again a budget later)
-            }
-        }
         // first pass: a read that has cost this many rank queries is heavy whatever it has found so far (dead ends cost steps, not candidates)
         if (!unitMode && state == ST_STEP && readRank > in.heavyRank) { goHeavy = true; state = ST_DONE; sp = 0; }
         if (state == ST_STEP) {
@@ -636,7 +577,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             nRank += 2;
             readRank += 2;
-            unitRank += 2;
             const int pos = stS.start + stS.dir * i;
             const uint32_t ch = readChar(pos);
             // child ranges: the active range advances by rank, the passive one shrinks by the occurrences of the larger symbols
@@ -680,12 +620,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             if (doSettle && !needPop) { g = gc; i++; }
         }
         if (state == ST_RESUME) { doSettle = true; needPop = false; }          // the completed frame that had to wait: emit it now, then pop
-        if (SECOND && state == ST_TRUNK && unitMode == 3u) {
-            // a relayed frame: what a pop would have found
-            Frame f; f.fl = p0.x; f.fr = p0.y; f.rl = p0.z; f.meta = p0.w;
-            stack[0] = f; sp = 1;
-            doSettle = true; needPop = true;
-        } else
         if (state == ST_TRUNK) {
             // the range the trunk pass held at this unit's position (.w = 0: the trunk never got there -- nothing to do)
             if (!(p0.w & S3_TRUNK_VALID)) { state = ST_DONE; noCount = true; }
@@ -706,7 +640,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             }
             loadOff += 8;
             if constexpr (!UNIFORM) Li = (int)saVal;
-            if (loadOff >= 2u * wpq) state = unitMode >= 2u ? ST_TRUNK : ST_KEYS;
+            if (loadOff >= 2u * wpq) state = unitMode == 2u ? ST_TRUNK : ST_KEYS;
         } else if (state == ST_LT) {
             const S3Step st = stepAt(0);
             int ll = ix.ltSize > st.len ? st.len : ix.ltSize;
@@ -729,7 +663,6 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
             // ---------- check-and-extend by the lane itself: per candidate its suffix-array entry, then the text under the rest of the model, one 64-byte
             // line (256 characters) per trip, compared as ceKernel compares (XOR, fold, popcount); BGS-HostAlgnmtAlgo2.cpp:86-169 ----------
             if (state == ST_CE_SA || state == ST_CE_TEXT) {
-                unitRank++;                                                   // (a trip is a trip: the relay budget counts them all)
                 bool textHere = state == ST_CE_TEXT;                          // the line of this trip belongs to the current candidate
                 bool fresh = !textHere;                                       // the current candidate has not been set up yet
                 const bool haveNext = textHere && ceK + 1u < ceN;             // ... and the next candidate's entry came along
@@ -787,7 +720,9 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
                         pendA = ceRp; pendB = ceRp;
                         seq++; total++;
                         if (++countPending >= S3_V2_COUNT_BATCH) countCertain(0u);
-                        ceMiss = 0;
+                        // (a unit that has verified in.ceInlineMax occurrences itself has shown what it is worth to its read's cut: from there on its
+                        //  candidates go to ceKernel too -- a thousand of them one after the other is what a launch would wait for)
+                        ceMiss = ++ceTaken >= in.ceInlineMax ? in.ceGiveUp : 0u;
                     } else ceMiss++;
                     ceK++;
                     if (ceK >= ceN) { countCertain(0u); doSettle = true; needPop = true; break; }  // all candidates seen: the search goes on (settle sets the state)
@@ -877,7 +812,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
             // second-pass records (units that gave up verifying their candidates themselves) count in unit space:
             // unit = heavy read * groups * U + item * U + position
             const uint32_t U = in.unitsPerItem;
-            const uint32_t unit = item >= in.extBase ? out.relayUnit[item - in.extBase] : item - in.unitBase;      // (a relayed frame counts in a slot of its own)
+            const uint32_t unit = item - in.unitBase;
             slotOf = out.heavyList[unit / (groups * U)];
             item = slotOf * groups + (unit / U) % groups;
         } else if (task && out.heavyFlags[slotOf]) task = false;                 // stale: the second pass searched this read again
@@ -1006,7 +941,6 @@ int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out,
 {
     if (in.nActive == 0) return (int)hipSuccess;
     uint64_t blocks = ((uint64_t)in.nActive * (in.unitMode ? (uint64_t)in.nCases * 2u * (in.unitMode == 2u ? in.unitsPerItem : 1u) : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
-    if (in.unitMode == 3u) blocks = ((uint64_t)(in.relayEnd - in.relayBegin) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + 2u * in.wLds * 256u);
     if (lds > 48u * 1024u) {

@@ -522,10 +522,10 @@ int main(int argc, char **argv)
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     // The read files come in chunks (ReadChunker): a loader thread parses chunk i+1 -- with all host threads -- while chunk i is aligned and
     // chunk i-1 is formatted and written, as the reference's loader thread fills the next batch buffer (aio_thread.cpp:582, SOAP3-DP.cu:607-800).
-    // It starts before the index is read: neither needs the other.  S3DP_CHUNK_READS: reads per chunk (default 2 Mi single reads / 4 Mi paired).
+    // It starts before the index is read: neither needs the other.  S3DP_CHUNK_READS: reads per chunk (default 4 Mi: a search launch lasts as long as its longest unit, larger chunks amortise that).
     size_t chunkReadsEnv = 0;
     if (const char *e = getenv("S3DP_CHUNK_READS")) chunkReadsEnv = (size_t)strtoull(e, nullptr, 10);
-    const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : (paired ? (size_t)1 << 22 : (size_t)1 << 21)) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
+    const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : (size_t)1 << 22) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
     ReadChunker chunker;
     if (!chunker.open(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)) return die(err);
     struct ChunkQueue {

@@ -22,15 +22,13 @@ def dev_index(name):
 
 @pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120), ("g6", 100)])     # g6: the ends of the text, padded lookup keys (tools/simulate_edge_case.py)
 @pytest.mark.parametrize("mm", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("heavy", ["0", "1", "2", "2i", "2r", "2g"])
+@pytest.mark.parametrize("heavy", ["0", "1", "2", "2i", "2g"])
 def test_search_bit_exact_vs_reference_dump_and_oracle(monkeypatch, name, maxlen, mm, heavy):
     """heavy: S3DP_HEAVY -- 0: every read is walked by one lane; 1 (the default): a read that reserves more than 256 check-and-extend candidates
     leaves the first pass and is taken apart by a second launch of the kernel, one lane per (item, position of the first mismatch) unit; 2: every
     read with more than two candidates goes that way; 2i: the same with whole items as units (S3DP_UNITS=0).  The records must not depend on it."""
     monkeypatch.setenv("S3DP_HEAVY", heavy[0])
     monkeypatch.setenv("S3DP_UNITS", "0" if heavy.endswith("i") else "1")
-    if heavy.endswith("r"):                                 # units relay what is left of them after 8 rank queries (several relay rounds)
-        monkeypatch.setenv("S3DP_UNIT_BUDGET", "8")
     if heavy.endswith("g"):                                 # units never verify candidates themselves / always do
         monkeypatch.setenv("S3DP_CE_GIVE_UP", "0")
     reads = golden_reads(name)
@@ -98,12 +96,10 @@ def test_long_lookup_tables_do_not_change_results(monkeypatch, name, maxlen, ext
 
 
 @pytest.mark.parametrize("cap", [1, 3, 17])
-@pytest.mark.parametrize("heavy", ["0", "1", "3", "3i", "3r", "3g"])
+@pytest.mark.parametrize("heavy", ["0", "1", "3", "3i", "3g"])
 def test_max_output_truncation(monkeypatch, cap, heavy):
     monkeypatch.setenv("S3DP_HEAVY", heavy[0])
     monkeypatch.setenv("S3DP_UNITS", "0" if heavy.endswith("i") else "1")
-    if heavy.endswith("r"):
-        monkeypatch.setenv("S3DP_UNIT_BUDGET", "8")
     if heavy.endswith("g"):
         monkeypatch.setenv("S3DP_CE_GIVE_UP", "1000000")
     name, maxlen, mm = "g2", 120, 2
