@@ -90,7 +90,11 @@ __device__ __forceinline__ void pairSweep(const uint32_t *pos, const uint32_t *m
         const uint32_t gap = r.pos + patLen - 1u - l.pos + 1u;
         return lb <= gap && gap <= ub && l.strand == 1u && r.strand == 2u;
     };
-    auto beyond = [&](const Occ &l, const Occ &r) -> bool { return l.strand != r.strand && (uint32_t)(l.pos + ub) < (uint32_t)(r.pos + patLen - 1u); };
+    // The reference leaves the inner loop at the first occurrence of the OTHER strand that lies beyond the window (PEIsPairOutOfRange); one of the same
+    // strand never ends it, so two lists of thousands of same-strand occurrences (a read pair inside a tandem array) cost their product.  An occurrence
+    // beyond the window cannot match whatever its strand, and the lists are sorted by position: leaving at the first one beyond the window reports the
+    // same pairs in the same order.
+    auto beyond = [&](const Occ &l, const Occ &r) -> bool { return (uint64_t)l.pos + ub < (uint64_t)r.pos + patLen - 1u; };
     uint32_t i1 = 0, i2 = 0;
     while (i1 < n1 && i2 < n2) {
         const Occ o1 = get(b1 + i1), o2 = get(b2 + i2);
