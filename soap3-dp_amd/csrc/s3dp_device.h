@@ -114,6 +114,10 @@ struct MergeArgs {
 #define S3_MERGE_LONG 256u
 
 // semi-global DP (s3dp_dp.hip)
+// Traceback table of one 64-row chunk with T steps: H as int16, two steps per dword ([step / 2][lane], the even step in the low half), then one bit per
+// cell, 32 steps per dword ([step / 32][lane], step t at bit 31 - t % 32): 2.125 B per cell, every store a whole 256-byte row.
+static inline __host__ __device__ size_t dpTableXBase(uint32_t T) { return ((size_t)(T >> 1) + 1u) * 64u; }
+static inline __host__ __device__ size_t dpTableChunkWords(uint32_t T) { return dpTableXBase(T) + ((size_t)(T >> 5) + 1u) * 64u; }
 struct DpArgs {
     const uint32_t *dna, *dnaLengths, *reads, *readLengths;     // reference layouts (1-based, MSB first, 32-interleaved)
     const uint32_t *clipLt, *anchorLeft, *anchorRight;            // optional

@@ -55,6 +55,7 @@ struct LaneState {
     int upIn, fIn, dgIn, rIn;         // what this lane produced in the previous step (the lane above consumes it by DPP)
     int nb0, nb1, nb2, nr;            // boundary row + window character of the column lane 0 meets next (prefetched from LDS)
     int bS; uint32_t bT, bC;          // this row's maximum: score, step of its first occurrence, occurrences
+    uint32_t hHold, xBits;            // table words in the making: H of the even step; the last steps' extended-deletion bits
 };
 
 struct ChunkConst {
@@ -64,8 +65,8 @@ struct ChunkConst {
     bool rowClip, rowBest;
     const unsigned char *refLds;
     int *bnd;
-    uint16_t *tabH;                   // this chunk's part of the table: H[step][lane] ...
-    unsigned long long *tabX;         // ... and per step the lanes whose H came out of an extended deletion
+    uint32_t *tabH;                   // this chunk's part of the table: H of two steps per dword, [step / 2][lane] ...
+    uint32_t *tabX;                   // ... and "H came out of an extended deletion", 32 steps per dword, [step / 32][lane]
 };
 
 // one anti-diagonal step.  Lanes outside the table (column < 1 while RAMP, column > W, rows beyond the read) compute on garbage that no
@@ -97,9 +98,11 @@ __device__ __forceinline__ void dpStep(const ChunkConst &k, LaneState &s, uint32
     s.upIn = up; s.fIn = f; s.dgIn = dg; s.rIn = rS;
     // written once and read only by the traceback kernel: streaming stores keep the table out of the caches' way
     if (TABLE) {
-        __builtin_nontemporal_store((uint16_t)hSt, &k.tabH[(size_t)t * 64u + k.lane]);
-        const unsigned long long x = __ballot(hSt == k.ge + ePrevIn);
-        if (k.lane == 0u) __builtin_nontemporal_store(x, &k.tabX[t]);
+        // (t is uniform: the branches cost a scalar compare; every store is 64 dwords in a row)
+        s.xBits = (s.xBits << 1) | (hSt == k.ge + ePrevIn ? 1u : 0u);
+        if (t & 1u) __builtin_nontemporal_store(s.hHold | (uint32_t)hSt << 16, &k.tabH[(size_t)(t >> 1) * 64u + k.lane]);
+        else s.hHold = (uint32_t)hSt & 0xFFFFu;
+        if ((t & 31u) == 31u) __builtin_nontemporal_store(s.xBits, &k.tabX[(size_t)(t >> 5) * 64u + k.lane]);
     }
     if (BEST) {
         // columns jLo..W of the rows that may end the alignment; inside a row the columns come in increasing order, so the first maximum is the
@@ -124,9 +127,8 @@ __device__ __forceinline__ void chunkSweep(const DpArgs &a, uint32_t p, uint32_t
     k.go = a.gapOpen; k.ge = a.gapExtend; k.gi = k.go - k.ge; k.match = a.match; k.mismatch = a.mismatch;
     asm volatile("" : "+v"(k.match), "+v"(k.mismatch));              // the select between them wants vector registers: move once, not per step
     k.lane = threadIdx.x & 63u; k.W = W; k.refOffset = refOffset; k.aL = aL; k.refLds = refLds; k.bnd = bnd;
-    // per chunk: T steps of 64 int16 (T * 32 dwords), then T 64-bit words (T * 2 dwords)
-    k.tabH = TABLE ? (uint16_t *)(table + (size_t)c * T * 34u) : nullptr;
-    k.tabX = TABLE ? (unsigned long long *)(table + (size_t)c * T * 34u + (size_t)T * 32u) : nullptr;
+    k.tabH = TABLE ? table + (size_t)c * dpTableChunkWords(T) : nullptr;
+    k.tabX = TABLE ? table + (size_t)c * dpTableChunkWords(T) + dpTableXBase(T) : nullptr;
     const uint32_t i = (c << 6) + 1u + k.lane;                       // this lane's read row
     const bool rowOk = i <= L;
     k.rc = rowOk ? seqChar(a.reads, p, a.maxReadLength, i) : 0u;
@@ -141,6 +143,7 @@ __device__ __forceinline__ void chunkSweep(const DpArgs &a, uint32_t p, uint32_t
     else { const int up0 = k.gi + k.ge * ((int)i - (clipLt > 0 ? clipLt : 0)); s.hPrev = clampS(up0); s.ePrev = clampS(up0 + k.gi); }
     s.upIn = 0; s.fIn = 0; s.dgIn = 0; s.rIn = 0;
     s.bS = NEG_INF; s.bT = 0; s.bC = 0;
+    s.hHold = 0; s.xBits = 0;
     const uint32_t j1 = W ? 1u : 0u;
     s.nb0 = bnd[3u * j1]; s.nb1 = bnd[3u * j1 + 1u]; s.nb2 = bnd[3u * j1 + 2u]; s.nr = refLds[j1];
     const uint32_t steps = W + 63u;
@@ -148,6 +151,11 @@ __device__ __forceinline__ void chunkSweep(const DpArgs &a, uint32_t p, uint32_t
     for (; t <= 63u; t++) dpStep<TABLE, CLIP, BEST, true>(k, s, t);
     for (; t + 1u <= steps; t += 2u) { dpStep<TABLE, CLIP, BEST, false>(k, s, t); dpStep<TABLE, CLIP, BEST, false>(k, s, t + 1u); }
     if (t <= steps) dpStep<TABLE, CLIP, BEST, false>(k, s, t);
+    if (TABLE) {
+        // what the last steps left in the registers (steps is the last step taken)
+        if (!(steps & 1u)) __builtin_nontemporal_store(s.hHold, &k.tabH[(size_t)(steps >> 1) * 64u + k.lane]);
+        if ((steps & 31u) != 31u) __builtin_nontemporal_store(s.xBits << (31u - (steps & 31u)), &k.tabX[(size_t)(steps >> 5) * 64u + k.lane]);
+    }
     if (BEST && s.bC) bestMerge(best, s.bS, ((s.bT - k.lane) << 16) | i, s.bC);
 }
 
@@ -251,16 +259,17 @@ struct View {
         if (j == 0u) return clampS(i == 0u ? 0 : (i <= cl ? go : gi + ge * (int)(i - cl)));
         if (i == 0u) return (j + refOffset >= aL) ? NEG_INF : 0;
         const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
-        const uint16_t *h = (const uint16_t *)(table + (size_t)c * T * 34u);
-        return (int)(int16_t)h[(size_t)(j + k) * 64u + k];
+        const uint32_t t = j + k;                                    // the step that computed the cell
+        const uint32_t w = table[(size_t)c * dpTableChunkWords(T) + (size_t)(t >> 1) * 64u + k];
+        return (int)(int16_t)(uint16_t)((t & 1u) ? w >> 16 : w);
     }
     // did H(j, i) come out of an extended deletion, H(j,i) == gapExtend + E(j-1,i)?  (j >= 1; for j == 1 the previous column is the initial one)
     __device__ bool fromExtendedDeletion(uint32_t j, uint32_t i) const
     {
         if (i == 0u) return false;
         const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
-        const unsigned long long *x = (const unsigned long long *)(table + (size_t)c * T * 34u + (size_t)T * 32u);
-        return (x[j + k] >> k) & 1ull;
+        const uint32_t t = j + k;
+        return (table[(size_t)c * dpTableChunkWords(T) + dpTableXBase(T) + (size_t)(t >> 5) * 64u + k] >> (31u - (t & 31u))) & 1u;
     }
 };
 }  // namespace tb

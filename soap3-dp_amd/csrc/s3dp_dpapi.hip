@@ -64,7 +64,7 @@ extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLe
     h->maxTable = maxDPTableLength; h->patternLen = maxReadLength + maxDPTableLength; h->sc = *sc;
     const size_t rnd = ((size_t)maxProblems + 31) / 32 * 32;
     const size_t dnaW = rnd * ((maxDNALength + 15) / 16), rdW = rnd * ((maxReadLength + 15) / 16);
-    h->tableWords = (size_t)((maxReadLength + 63) / 64) * (maxDPTableLength + 64) * 34;      // per 64-row chunk and step: 64 int16 + one 64-bit word
+    h->tableWords = (size_t)((maxReadLength + 63) / 64) * dpTableChunkWords(maxDPTableLength + 64u);      // per 64-row chunk (s3dp_device.h)
     int rc;
 #define DA(p, c) if ((rc = dalloc(h, &h->p, (c)))) { s3_dp_free(h); return rc; }
     DA(dDna, dnaW); DA(dReads, rdW); DA(dDnaLen, rnd); DA(dReadLen, rnd); DA(dClipLt, rnd); DA(dClipRt, rnd); DA(dAL, rnd); DA(dAR, rnd);
