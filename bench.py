@@ -300,7 +300,9 @@ def extras(s3dp, ix, codes, dev, rank):
         ms = dp.timing()
         cells = float(k) * L * 499.0
         res["default_dp_half_end"] = {"problems": k, "read_len": L, "window": 499, "kernel_ms": ms, "GCUPS_kernel": cells / (ms / 1e3) / 1e9,
-                                      "wall_ms_incl_pack_decode": wall * 1e3, "aligned_by_dp": int((resd["whichFromDP"] < 2).sum())}
+                                      "engine_call_ms": getattr(dp, "last_call_ms", None),
+                                      "engine_call_is": "s3_dp_half_end: pack on the device, fill + traceback kernels, decode, CIGAR text; wall clock of the C call",
+                                      "wall_ms_incl_python_binding": wall * 1e3, "aligned_by_dp": int((resd["whichFromDP"] < 2).sum())}
     except Exception as e:
         res["default_dp_half_end"] = {"error": repr(e)}
     finally:

@@ -130,6 +130,7 @@ struct DpArgs {
     size_t          tableWordsPerProblem;
     uint32_t        n, maxDNALength, maxReadLength, maxDPTableLength, patternLen, ldsPerWave;
     int             match, mismatch, gapOpen, gapExtend, scheme;
+    uint32_t       *patMax;                                       // optional: longest pattern of the launch in bytes (atomicMax; zeroed by the caller)
 };
 int launchDp(const DpArgs &a, hipStream_t s);        // returns a hipError_t
 

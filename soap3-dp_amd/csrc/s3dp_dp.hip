@@ -337,6 +337,7 @@ __global__ void dpBacktrackKernel(DpArgs a)
     } else if (exitBy == CLIP_AFTER_INSERT) { put('I'); run('S', i - 1u); }
     else if (exitBy == CLIP_AFTER_MATCH) { put(refAt(j) == readAt(i) ? 'M' : 'm'); run('S', i - 1u); --j; }
     put(0);
+    if (a.patMax) atomicMax(a.patMax, out < a.patternLen ? out : a.patternLen);        // bytes of the longest pattern, terminator included: what the host fetches per row
     a.hitLocs[p] = v.refOffset + j;
 }
 

@@ -69,7 +69,7 @@ extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLe
 #define DA(p, c) if ((rc = dalloc(h, &h->p, (c)))) { s3_dp_free(h); return rc; }
     DA(dDna, dnaW); DA(dReads, rdW); DA(dDnaLen, rnd); DA(dReadLen, rnd); DA(dClipLt, rnd); DA(dClipRt, rnd); DA(dAL, rnd); DA(dAR, rnd);
     DA(dCut, rnd); DA(dScores, rnd); DA(dHit, rnd); DA(dStart, rnd); DA(dCnt, rnd); DA(dCols, rnd);
-    DA(dPattern, (size_t)maxProblems * h->patternLen);
+    DA(dPattern, (size_t)maxProblems * h->patternLen); DA(dPatMax, 4);
     DA(dTable, h->tableWords * maxProblems);
 #undef DA
 #define HIPD(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { s3_dp_free(h); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -77,6 +77,18 @@ extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLe
     HIPD(hipEventCreate(&h->ev[0])); HIPD(hipEventCreate(&h->ev[1]));
 #undef HIPD
     *outp = h;
+    return S3_OK;
+}
+
+int s3i::dpFetchPatterns(s3_dp *h, uint32_t n, std::vector<uint8_t> &pat, uint32_t &pitch)
+{
+    uint32_t mx = 0;
+    HIPCHK(d2h(&mx, h->dPatMax, 4, h->stream));                        // (synchronises the stream: the results queued before it have arrived too)
+    if (mx == 0 || mx > h->patternLen) mx = h->patternLen;
+    pitch = mx;
+    pat.resize((size_t)n * pitch);
+    if (n) HIPCHK(hipMemcpy2DAsync(pat.data(), pitch, h->dPattern, h->patternLen, pitch, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return S3_OK;
 }
 
@@ -148,7 +160,8 @@ int s3i::dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL,
     a.clipLt = hasClipLt ? h->dClipLt : nullptr; a.clipRt = hasClipRt ? h->dClipRt : nullptr;
     a.anchorLeft = hasAL ? h->dAL : nullptr; a.anchorRight = hasAR ? h->dAR : nullptr;
     a.cutoffs = h->dCut; a.scores = h->dScores; a.hitLocs = h->dHit; a.startOffsets = h->dStart; a.maxScoreCounts = h->dCnt; a.tableCols = h->dCols;
-    a.pattern = h->dPattern; a.table = h->dTable; a.tableWordsPerProblem = h->tableWords;
+    a.pattern = h->dPattern; a.table = h->dTable; a.tableWordsPerProblem = h->tableWords; a.patMax = h->dPatMax;
+    HIPCHK(hipMemsetAsync(h->dPatMax, 0, 4, h->stream));
     a.n = n; a.maxDNALength = h->maxDNA; a.maxReadLength = h->maxRead; a.maxDPTableLength = h->maxTable; a.patternLen = h->patternLen;
     a.ldsPerWave = (((h->maxDNA + 1u + 15u) & ~15u) + (h->maxDNA + 1u) * 12u + 15u) & ~15u;
     a.match = h->sc.matchScore; a.mismatch = h->sc.mismatchScore; a.gapOpen = h->sc.gapOpenScore; a.gapExtend = h->sc.gapExtendScore; a.scheme = h->scheme;
@@ -201,8 +214,14 @@ extern "C" int s3_dp_align(s3_dp *h, const uint32_t *packedDNA, const uint32_t *
     HIPCHK(hipMemcpyAsync(scores, h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(hitLocs, h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(maxScoreCounts, h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(pattern, h->dPattern, (size_t)n * h->patternLen, hipMemcpyDeviceToHost, s));
     if (clipRtSizes) HIPCHK(hipMemcpyAsync(clipRtSizes, h->dClipRt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    {
+        // of every pattern row only as many bytes as the longest pattern has (the rest of a row was never written)
+        uint32_t mx = 0;
+        HIPCHK(d2h(&mx, h->dPatMax, 4, s));
+        if (mx == 0 || mx > h->patternLen) mx = h->patternLen;
+        HIPCHK(hipMemcpy2DAsync(pattern, h->patternLen, h->dPattern, h->patternLen, mx, n, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(hipStreamSynchronize(s));
     h->timed = true;
     return S3_OK;
@@ -350,12 +369,12 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
         if (rc) return rc;
         std::vector<int32_t> scores(n);
         std::vector<uint32_t> hit(n), cnt(n);
-        std::vector<uint8_t> pat((size_t)n * h->patternLen);
+        std::vector<uint8_t> pat;
+        uint32_t pitch = 0;
         HIPCHK(hipMemcpyAsync(scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if ((rc = dpFetchPatterns(h, n, pat, pitch))) return rc;
         if ((rc = dpDump(h, n, true, true, true, true))) return rc;
         // algnmtCPUThread (:2329-2441)
         decodeParallel<s3_dp_half_result>(n, results, pool, [&](uint32_t id, std::vector<s3_dp_half_result> &results, std::string &pool) {
@@ -367,7 +386,7 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
             if (scores[id] >= cutoffThreshold[1 - alignedIsMate]) {
                 CigarEnc enc;
                 char last = 'N';
-                for (const uint8_t *p = pat.data() + (size_t)id * h->patternLen; *p != 0; p++) {
+                for (const uint8_t *p = pat.data() + (size_t)id * pitch; *p != 0; p++) {
                     if (*p == 'V') enc.append(last, (int)*(++p) - 1);
                     else { enc.append((char)*p, 1); last = (char)*p; }
                 }
@@ -510,19 +529,19 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
         if (rc) break;
         std::vector<int32_t> scores(n);
         std::vector<uint32_t> hit(n), cnt(n);
-        std::vector<uint8_t> pat((size_t)n * h->patternLen);
+        std::vector<uint8_t> pat;
+        uint32_t pitch = 0;
         ECHK(hipMemcpyAsync(scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         ECHK(hipMemcpyAsync(hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         ECHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        ECHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
-        ECHK(hipStreamSynchronize(s));
+        if ((rc = dpFetchPatterns(h, n, pat, pitch))) break;
 #undef ECHK
         if ((rc = dpDump(h, n, true, true, false, false))) break;
         decodeParallel<s3_dp_single_result>(n, results, pool, [&](uint32_t i, std::vector<s3_dp_single_result> &results, std::string &pool) {
             if (scores[i] < cutoffThreshold) return;
             CigarEnc enc;
             char last = 'N';
-            for (const uint8_t *p = pat.data() + (size_t)i * h->patternLen; *p != 0; p++) {
+            for (const uint8_t *p = pat.data() + (size_t)i * pitch; *p != 0; p++) {
                 if (*p == 'V') enc.append(last, (int)*(++p) - 1);
                 else { enc.append((char)*p, 1); last = (char)*p; }
             }
@@ -719,7 +738,7 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
         dCand = (DpCand *)q;
     }
 #define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipFree(dCand); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
-    struct Round { std::vector<int32_t> scores; std::vector<uint32_t> hit, cnt; std::vector<uint8_t> pat; };
+    struct Round { std::vector<int32_t> scores; std::vector<uint32_t> hit, cnt; std::vector<uint8_t> pat; uint32_t pitch = 0; };
     auto runRound = [&](const std::vector<DpCand> &cand, const std::vector<uint32_t> &dnaLens, const std::vector<uint32_t> &rdLens, const std::vector<int32_t> &cut,
                         const std::vector<uint32_t> &clipLt, const std::vector<uint32_t> &clipRt, const std::vector<uint32_t> &aL, const std::vector<uint32_t> &aR,
                         Round &R) -> int {
@@ -738,12 +757,11 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
                            wordsPerDNA, wordsPerRead, h->dDna, h->dReads);
         int rc2 = dpRun(h, n, true, true, true, true);
         if (rc2) return rc2;
-        R.scores.resize(n); R.hit.resize(n); R.cnt.resize(n); R.pat.resize((size_t)n * h->patternLen);
+        R.scores.resize(n); R.hit.resize(n); R.cnt.resize(n);
         ECHK(hipMemcpyAsync(R.scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         ECHK(hipMemcpyAsync(R.hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         ECHK(hipMemcpyAsync(R.cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        ECHK(hipMemcpyAsync(R.pat.data(), h->dPattern, R.pat.size(), hipMemcpyDeviceToHost, s));
-        ECHK(hipStreamSynchronize(s));
+        { const int rc3 = dpFetchPatterns(h, n, R.pat, R.pitch); if (rc3) return rc3; }
         return dpDump(h, n, true, true, true, true);
     };
     auto window = [&](uint32_t pos, uint32_t readLength, uint32_t &start, uint32_t &len) {
@@ -815,7 +833,7 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
             for (int lOr = 0; lOr < 2; lOr++) {
                 CigarEnc enc;
                 char last = 'N';
-                for (const uint8_t *p = rd[lOr]->pat.data() + (size_t)idx[lOr] * h->patternLen; *p != 0; p++) {
+                for (const uint8_t *p = rd[lOr]->pat.data() + (size_t)idx[lOr] * rd[lOr]->pitch; *p != 0; p++) {
                     if (*p == 'V') enc.append(last, (int)*(++p) - 1);
                     else { enc.append((char)*p, 1); last = (char)*p; }
                 }

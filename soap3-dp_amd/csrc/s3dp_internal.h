@@ -106,6 +106,7 @@ struct s3_dp {
     int32_t *dCut = nullptr, *dScores = nullptr;
     uint32_t *dHit = nullptr, *dStart = nullptr, *dCnt = nullptr, *dCols = nullptr, *dTable = nullptr;
     unsigned char *dPattern = nullptr;
+    uint32_t *dPatMax = nullptr;           // longest pattern of the last launch (bytes with the terminator)
     size_t tableWords = 0;
     bool timed = false;
     std::vector<uint32_t> dumpClipRt;      // S3DP_DUMP_DP: the right clips as the packer set them (the kernel overwrites them)
@@ -178,6 +179,9 @@ int seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<SeedD
 int sum64Async(s3_batch *b, const uint32_t *counts, uint32_t n);
 // DP (s3dp_dpapi.hip): launch the DP kernels on what is in the aligner's device buffers
 int dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR);
+// the patterns of the last dpRun, one row of `pitch` bytes per problem (pitch = the longest pattern with its terminator, not the aligner's patternLen:
+// a pattern is a few dozen bytes, the row it is written into eight hundred)
+int dpFetchPatterns(s3_dp *h, uint32_t n, std::vector<uint8_t> &pat, uint32_t &pitch);
 // S3DP_DUMP_DP=<file> (tests): the problems of the last dpRun with their results, and stage separators
 int dpDump(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR);
 void dpDumpNote(const char *line);

@@ -6,6 +6,7 @@ here: if the library or a HIP device is missing the calls raise.
 """
 import ctypes as C
 import os
+import time
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -550,8 +551,10 @@ class DpAligner:
                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         cut = (C.c_int * 2)(*cutoffs)
         res, n, pool = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        t0 = time.perf_counter()
         _chk(f(self.h, batch.h, read_lengths.ctypes.data, occ.ctypes.data, len(occ), insert_low, insert_high, cut, clip_left, clip_right,
                C.byref(res), C.byref(n), C.byref(pool)))
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3       # the engine itself (pack, kernels, decode, CIGAR text); what follows is this binding
         out = np.frombuffer(C.string_at(res, n.value * HALF_RESULT_DTYPE.itemsize), dtype=HALF_RESULT_DTYPE).copy() if n.value else np.zeros(0, HALF_RESULT_DTYPE)
         cigars = []
         for r in out:

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="host threads (0 = all)")
     ap.add_argument("--repeat-frac", type=float, default=0.0, help="share of the genome planted with GRCh38-like repeat families (bench.py's generator)")
     ap.add_argument("--devices", default="", help="-c argument of the command line (e.g. 0,0: two members on one GPU)")
+    ap.add_argument("--devnull", type=int, default=0, help="single reads: a second run with the SAM written to /dev/null")
     ap.add_argument("--pairs", type=int, default=0, help="paired-end default mode (DP stages on) with this many 2 x read-len pairs instead of single reads")
     a = ap.parse_args()
     import torch
@@ -97,6 +98,24 @@ def main():
            # the command line streams: reading, aligning and writing overlap inside "Alignment + output time" (it starts when the index is resident)
            # (the loader runs ahead while the index is read; the pipeline cannot be faster than its slower stage, so the larger of the two times counts)
            "reads_per_s_reads_in_sam_out": N / (max(ph.get("Alignment + output time", 0), float(m.group(1)) if m else 0.0) or wall)}
+    # the same run with the SAM going to /dev/null: what the program does when the file system does not set the pace
+    if a.devnull:
+        for f in os.listdir(work):
+            if f.startswith("out.gout."):
+                os.remove(os.path.join(work, f))
+        for k in (1,) if not a.devices else range(1, len(a.devices.split(",")) + 1):
+            os.symlink("/dev/null", os.path.join(work, "out.gout.%d" % k))
+        t = time.time()
+        out2 = subprocess.run([exe, "single", os.path.join(work, "g.index"), fq, "-L", str(L), "-s", str(a.mismatch), "-b", "2", "-o", os.path.join(work, "out")] +
+                              (["-c", a.devices] if a.devices else []), capture_output=True, text=True, env=env)
+        wall2 = time.time() - t
+        if out2.returncode == 0:
+            ph2 = {k: float(v) for k, v in re.findall(r"\[Main\] (Loading time|Read load time|Alignment \+ output time|Total elapsed time) :\s+([0-9.]+)", out2.stdout)}
+            res["sam_to_dev_null"] = {"wall_s_total": wall2, "phases_s": ph2,
+                                      "reads_per_s_reads_in_sam_out": N / max(ph2.get("Alignment + output time", wall2), ph2.get("Read load time", 0))}
+    if not a.workdir:
+        import shutil
+        shutil.rmtree(work, ignore_errors=True)
     print(json.dumps(res))
 
 
@@ -167,6 +186,9 @@ def pairs_mode(a, codes, work, rng, t_index):
            "sam_bytes": sum(os.path.getsize(os.path.join(work, "out." + e)) for e in ("gout.1", "dpout.1", "unpair")),
            "pairs_per_s_wall_incl_index_load": N / wall,
            "pairs_per_s_reads_in_sam_out": N / (ph.get("Read load time", 0) + ph.get("Alignment + output time", 0) or wall)}
+    if not a.workdir:
+        import shutil
+        shutil.rmtree(work, ignore_errors=True)
     print(json.dumps(res))
 
 

@@ -36,9 +36,7 @@ if want dp; then      # DP kernel: GCUPS, kernel stats, counters on 4096 problem
   rm -rf /tmp/prof_dp
   S3DP_BENCH_DP_PROBLEMS=4096 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/prof_dp -o dp -- python3 tools/bench_dp.py > /dev/null 2> $OUT/dp_pmc_sq.log
   f=$(find /tmp/prof_dp -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 tools/pmc_summary.py "$f" dpFillKernel > $OUT/dp_pmc_sq.txt && tail -3 $OUT/dp_pmc_sq.txt
-  rm -rf /tmp/prof_dp
-  S3DP_BENCH_DP_PROBLEMS=4096 timeout 600 rocprofv3 --pmc WRITE_SIZE FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_dp -o dp -- python3 tools/bench_dp.py > /dev/null 2> $OUT/dp_pmc_mem.log
-  f=$(find /tmp/prof_dp -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 tools/pmc_summary.py "$f" dpFillKernel > $OUT/dp_pmc_mem.txt && tail -3 $OUT/dp_pmc_mem.txt
+  # (WRITE_SIZE and FETCH_SIZE do not fit one pass -- 2 + 3 of the 4 TCC slots: rocprofv3 aborts; the table traffic is algorithmic: 2.125 B per cell)
 fi
 if want e2e; then     # the command line, FASTQ in -> SAM out, GRCh38 scale: uniform genome (round 1's workload), repeat-rich genome, two members on one GPU
   timeout 900 python3 tools/bench_e2e.py --genome-bp 3100000000 --reads 20000000 > $OUT/e2e_se_uniform.json 2> $OUT/e2e_se_uniform.log; echo "e2e uniform rc=$?"; cat $OUT/e2e_se_uniform.json | cut -c1-600
