@@ -68,7 +68,12 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
 {
     const int T = hostThreads();
     const uint32_t per = (count + (uint32_t)T - 1) / (uint32_t)T;
-    std::vector<std::string> buf((size_t)T);
+    // the buffers live as long as the calling thread: a chunk of 4 Mi reads is more than a gigabyte of SAM, and touching that much fresh memory from all
+    // host threads at once for every chunk is page faults on one address space's lock
+    thread_local std::vector<std::string> keptBuffers;
+    std::vector<std::string> &buf = keptBuffers;              // (the workers below must see THIS thread's buffers, not their own thread-local ones)
+    if (buf.size() < (size_t)T) buf.resize((size_t)T);
+    for (auto &b : buf) b.clear();
     std::vector<uint64_t> al((size_t)T, 0);
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back([&, t] {
