@@ -37,7 +37,7 @@ FLEXOBJ := $(addprefix $(OBJ)/flex_,$(addsuffix .o,$(FLEX)))
 SAMOBJ  := $(addprefix $(OBJ)/sam_,$(addsuffix .o,$(SAMT)))
 HOSTOBJ := $(addprefix $(OBJ)/host_,$(addsuffix .o,$(HOST)))
 
-all: $(OUT)/soap3-dp-builder $(OUT)/BGS-Build $(OUT)/ref_harness $(OUT)/libdpref.so
+all: $(OUT)/soap3-dp-builder $(OUT)/BGS-Build $(OUT)/ref_harness $(OUT)/libdpref.so $(OUT)/ref_bam2sam
 
 $(OBJ):
 	mkdir -p $(OBJ)
@@ -123,6 +123,10 @@ $(OBJ)/dp_header_lines.inc: $(REF)/DV-DPfunctions.h | $(OBJ)
 	sed -n -e '/^#define DP_THREADS_PER_BLOCK/p' -e '/^typedef unsigned char uchar;/p' -e '/^typedef unsigned int uint;/p' -e '/^#define MC_CeilDivide16/p' $< > $@
 $(OUT)/libdpref.so: oracle/ref_dp_driver.hip $(OBJ)/dp_device.inc $(OBJ)/dp_header_lines.inc
 	$(HIPCC) -O2 -std=c++17 -fPIC -shared --offload-arch=gfx950 -ffp-contract=off -Ioracle -o $@ $<
+
+# BAM reader for the tests: the reference's samtools decodes what `soap3-dp -bam` wrote (oracle/ref_bam2sam.c is ours)
+$(OUT)/ref_bam2sam: oracle/ref_bam2sam.c $(SAMOBJ)
+	$(CC) $(SAMFLG) -I$(REF)/samtools-0.1.18 $< $(SAMOBJ) -lz -lm -o $@
 
 clean:
 	rm -rf $(OUT)

@@ -1,5 +1,6 @@
 // s3_host.cpp -- index files, read files and SAM records for the drop-in `soap3-dp` program (see s3_host.h).
 #include "s3_host.h"
+#include "s3_bam.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -618,6 +619,7 @@ SamWriter::SamWriter(const HostIndex &ix_, const SamOptions &o, std::string *sk)
 void SamWriter::put(const std::string &line)
 {
     if (sink) sink->append(line);
+    else if (bamFileOf(out)) { if (!bamWriteLines(out, line.data(), line.size())) { fprintf(stderr, "write error on the output file\n"); exit(1); } }
     else fwrite(line.data(), 1, line.size(), out);
     nRecords++;
 }
@@ -625,9 +627,11 @@ void SamWriter::put(const std::string &line)
 void SamWriter::header()
 {
     // SAMOutputHeaderConstruct (SAM.cpp:82-137); the @PG line names this program
-    fprintf(out, "@HD\tVN:1.3\tSO:unsorted\n@RG\tID:%s\tSM:%s\t%s\n", opt.readGroup.c_str(), opt.sampleName.c_str(), opt.readGrpOption.c_str());
-    for (int i = 0; i < ix.numOfSeq; i++) fprintf(out, "@SQ\tSN:%s\tLN:%u\n", ix.seqName[i].c_str(), ix.actualEnd[i] - ix.actualStart[i]);
-    fprintf(out, "@PG\tID:SOAP3-dp\tPN:SOAP3-dp\tVN:%s\n", s3_version());
+    std::string h = "@HD\tVN:1.3\tSO:unsorted\n@RG\tID:" + opt.readGroup + "\tSM:" + opt.sampleName + "\t" + opt.readGrpOption + "\n";
+    for (int i = 0; i < ix.numOfSeq; i++) h += "@SQ\tSN:" + ix.seqName[i] + "\tLN:" + std::to_string(ix.actualEnd[i] - ix.actualStart[i]) + "\n";
+    h += std::string("@PG\tID:SOAP3-dp\tPN:SOAP3-dp\tVN:") + s3_version() + "\n";
+    if (bamFileOf(out)) { if (!bamWriteHeader(out, h)) { fprintf(stderr, "write error on the output file\n"); exit(1); } }
+    else fwrite(h.data(), 1, h.size(), out);
 }
 
 uint32_t SamWriter::chrAndPos(uint32_t ambPos, uint64_t &tp, uint32_t &chr) const

@@ -1,7 +1,7 @@
 // soap3-dp -- drop-in command line for the alignment path (single-end and paired-end, DP stages on or off), same arguments, .ini keys and index files as
 // the reference program (SOAP3-DP.cu main, IniParam.cpp:237-767), driving the MI355X kernels through the C-ABI of libs3dp.so.
 //
-//   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
+//   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2] [-bam] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
 //   soap3-dp pair   <index prefix> <reads 1> <reads 2> [-u maxInsert] [-v minInsert] [-s k] [the same options]
 // Without -s the DP stages are on (the reference's default): single reads the BWT stage leaves unaligned go through seeding + semi-global DP
 // and are written to <prefix>.dpout.1; pairs without a proper pairing go through the default DP (mate rescue next to an aligned end) or the deep
@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <memory>
 #include "s3_host.h"
+#include "s3_bam.h"
 
 using namespace s3host;
 
@@ -75,6 +76,7 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
     if (buf.size() < (size_t)T) buf.resize((size_t)T);
     for (auto &b : buf) b.clear();
     std::vector<uint64_t> al((size_t)T, 0);
+    const BamFile *bam = bamFileOf(out);
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back([&, t] {
         const uint32_t lo = (uint32_t)t * per, hi = lo + per < count ? lo + per : count;
@@ -82,9 +84,17 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
         buf[(size_t)t].reserve((size_t)(hi - lo) * 320);
         SamWriter w(hix, so, &buf[(size_t)t]);
         for (uint32_t k = lo; k < hi; k++) one(w, k, al[(size_t)t]);
+        if (bam) {
+            // -bam: this thread's records as BAM, in BGZF blocks of their own (blocks are independent: the parts are written behind each other)
+            std::string raw, err;
+            if (!samTextToBam(bam->refNames, buf[(size_t)t].data(), buf[(size_t)t].size(), raw, err)) { fprintf(stderr, "BAM output: %s\n", err.c_str()); exit(1); }
+            buf[(size_t)t].clear();
+            if (!bgzfCompress(raw.data(), raw.size(), buf[(size_t)t], bam->level)) { fprintf(stderr, "BAM output: compression failed\n"); exit(1); }
+        }
     });
     for (auto &x : th) x.join();
     // the buffers go to the file at their final offsets, a few writers at a time
+    if (!bamFlush(out)) { fprintf(stderr, "write error on the output file\n"); exit(1); }
     fflush(out);
     const int fd = fileno(out);
     std::vector<long long> off((size_t)T + 1, 0);
@@ -487,13 +497,14 @@ int main(int argc, char **argv)
     std::vector<int> devices(1, 0);                                            // -c: the reference takes one GPU id (SOAP3-DP.cu:219-220); here also a list "0,1,2"
     bool enableDP = true, skipSoap3 = false;
     std::string prefix = queryFile, readGroup, sampleName, readGrpOption;
-    bool printMDNM = false;
+    bool printMDNM = false, outputBam = false;
     for (int i = paired ? 5 : 4; i < argc; i++) {
         const std::string a = argv[i];
         auto need = [&](const char *what) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "Please specify %s after '%s'\n", what, a.c_str()); exit(1); } return argv[++i]; };
         if (a == "-L" || a == "-l") maxReadLength = atoi(need("the length"));
         else if (a == "-h") alignmentType = atoi(need("the output option"));
         else if (a == "-b") outputFormat = atoi(need("the output file format"));
+        else if (a == "-bam") outputBam = true;                              // isOutputBinary: samopen(.., "wb") instead of "wh" (SOAP3-DP.cu:413-416)
         else if (a == "-o") prefix = need("the output prefix");
         else if (a == "-c") {
             devices.clear();
@@ -630,6 +641,11 @@ int main(int argc, char **argv)
     const std::string outName = prefix + ".gout." + fileNo;
     FILE *out = fopen(outName.c_str(), "w");
     if (!out) return dieJoin("Could not open the output file " + outName);
+    // -bam: the same records as BAM (s3_bam.h); the header's reference dictionary is the index's
+    std::vector<uint32_t> refLengths;
+    for (int i = 0; i < hix.numOfSeq; i++) refLengths.push_back(hix.actualEnd[i] - hix.actualStart[i]);
+    auto asBam = [&](FILE *f) { if (outputBam) bamRegister(f, hix.seqName, refLengths, -1); };
+    asBam(out);
     SamOptions so;
     so.readGroup = readGroup; so.sampleName = sampleName; so.readGrpOption = readGrpOption; so.alignmentType = alignmentType;
     so.minMAPQ = ini.minMAPQ; so.maxMAPQ = ini.maxMAPQ; so.bwaLikeScore = ini.bwaLike; so.printMDNM = printMDNM;
@@ -647,6 +663,7 @@ int main(int argc, char **argv)
         const std::string dpName = prefix + ".dpout." + fileNo;
         dpOut = fopen(dpName.c_str(), "w");
         if (!dpOut) return dieJoin("Could not open the output file " + dpName);
+        asBam(dpOut);
         SamWriter dpHdr(hix, so, dpOut);
         dpHdr.header();
         s3_dp_ini di{ini.dpScoreThreshold, ini.maxFrontLenClipped, ini.maxEndLenClipped};
@@ -678,6 +695,7 @@ int main(int argc, char **argv)
             const std::string upName = prefix + (member == 0 ? ".unpair" : ".unpair." + fileNo);
             unpairOut = fopen(upName.c_str(), "w");
             if (!unpairOut) return dieJoin("Could not open the output file " + upName);
+            asBam(unpairOut);
             SamWriter upHdr(hix, so, unpairOut);
             upHdr.header();
         }
@@ -853,11 +871,12 @@ int main(int argc, char **argv)
             for (uint32_t k : todo) if (!doneFlag[k]) w.unaligned(rs, first + k);
         }
     }
-    fclose(out);
+    auto closeOut = [&](FILE *f) { if (!bamClose(f)) { fprintf(stderr, "write error on the output file\n"); exit(1); } fclose(f); };
+    closeOut(out);
     if (dpOut) {
-        fclose(dpOut);
+        closeOut(dpOut);
         if (paired) {
-            fclose(unpairOut);
+            closeOut(unpairOut);
             dpAlignedReads = 2 * (defaultDpPairs + newDefaultPairs + deepDpPairs);
             s3_dp_free(dpHalf);
         }

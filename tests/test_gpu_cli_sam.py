@@ -494,3 +494,48 @@ def test_cli_pairs_longer_than_150_bases_skip_the_bwt_stage(tmp_path):
         fa, fb = (pr[0x80], pr[0x40]) if swap else (pr[0x40], pr[0x80])
         good += bool(int(fa[1]) & 2 and fa[2] == ch and abs(int(fa[3]) - lp) <= 4 and abs(int(fb[3]) - rp) <= 4 and int(fb[1]) & 16)
     assert good >= 0.85 * len(truth), (good, len(truth))
+
+
+REF_BAM2SAM = os.path.join(ROOT, "oracle", "_ref", "ref_bam2sam")
+
+
+def _decoded(path):
+    out = subprocess.run([REF_BAM2SAM, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    return out.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BAM2SAM), reason="the reference's samtools is not built (oracle/ref.mk)")
+@pytest.mark.parametrize("chunk", ["", "192"])
+def test_cli_bam_single_reads(tmp_path, chunk):
+    """`-bam` (the reference's isOutputBinary: samopen "wb", SOAP3-DP.cu:413): the file the command line writes, read back by the REFERENCE's samtools,
+    is line for line the SAM file of the same run without -bam (streamed single-end path: records compressed in pieces by all host threads)."""
+    name = "g2"
+    shutil.copyfile(os.path.join(GOLDEN, name, "reads.fq"), tmp_path / "r.fq")
+    env = dict(os.environ)
+    if chunk:
+        env["S3DP_CHUNK_READS"] = chunk
+    texts = {}
+    for mode in ("sam", "bam"):
+        out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), "r.fq", "-L", "120", "-s", "4", "-b", "2", "-o", mode] + (["-bam"] if mode == "bam" else []),
+                             cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        texts[mode] = open(tmp_path / (mode + ".gout.1")).read() if mode == "sam" else _decoded(str(tmp_path / "bam.gout.1"))
+    assert texts["bam"].splitlines() == texts["sam"].splitlines()
+    assert os.path.getsize(tmp_path / "bam.gout.1") < os.path.getsize(tmp_path / "sam.gout.1")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BAM2SAM), reason="the reference's samtools is not built (oracle/ref.mk)")
+def test_cli_bam_pairs_with_dp(tmp_path):
+    """-bam on the paired-end default mode: all three files (.gout.1, .dpout.1, .unpair), DP stages on"""
+    name = "g4"
+    texts = {}
+    for mode in ("sam", "bam"):
+        out = subprocess.run([BIN, "pair", os.path.join(GOLDEN, name, "index"), os.path.join(GOLDEN, name, "reads_1.fq"), os.path.join(GOLDEN, name, "reads_2.fq"),
+                              "-u", "500", "-v", "100", "-L", "100", "-o", mode] + (["-bam"] if mode == "bam" else []), cwd=tmp_path, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        for ext in ("gout.1", "dpout.1", "unpair"):
+            p = str(tmp_path / (mode + "." + ext))
+            texts[(mode, ext)] = open(p).read() if mode == "sam" else _decoded(p)
+    for ext in ("gout.1", "dpout.1", "unpair"):
+        assert texts[("bam", ext)].splitlines() == texts[("sam", ext)].splitlines(), ext

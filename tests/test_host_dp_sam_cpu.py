@@ -16,7 +16,7 @@ TOOL = os.path.join(ROOT, "tests", "tools", "dp_sam")
 
 
 def tool():
-    src = [os.path.join(ROOT, "tests", "tools", "dp_sam.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host.cpp"),
+    src = [os.path.join(ROOT, "tests", "tools", "dp_sam.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_bam.cpp"),
            os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host_dp.cpp")]
     if not os.path.exists(TOOL) or os.path.getmtime(TOOL) < max(os.path.getmtime(s) for s in src):
         lib = os.path.join(ROOT, "soap3-dp_amd")
@@ -44,7 +44,7 @@ PAIR_TOOL = os.path.join(ROOT, "tests", "tools", "dp_pair_sam")
 
 def pair_tool():
     host = os.path.join(ROOT, "soap3-dp_amd", "host")
-    src = [os.path.join(ROOT, "tests", "tools", "dp_pair_sam.cpp")] + [os.path.join(host, f) for f in ("s3_host.cpp", "s3_host_dp.cpp", "s3_host_dp_pair.cpp")]
+    src = [os.path.join(ROOT, "tests", "tools", "dp_pair_sam.cpp")] + [os.path.join(host, f) for f in ("s3_host.cpp", "s3_bam.cpp", "s3_host_dp.cpp", "s3_host_dp_pair.cpp")]
     if not os.path.exists(PAIR_TOOL) or os.path.getmtime(PAIR_TOOL) < max(os.path.getmtime(s) for s in src + [os.path.join(host, "s3_host.h")]):
         lib = os.path.join(ROOT, "soap3-dp_amd")
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", PAIR_TOOL] + src + ["-L" + lib, "-ls3dp", "-lz", "-lm", "-Wl,-rpath," + lib])

@@ -19,7 +19,7 @@ _built = {}
 def tool():
     if "ok" not in _built:
         s3o.build()
-        src = [os.path.join(ROOT, "tests", "tools", "oracle_sam.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host.cpp")]
+        src = [os.path.join(ROOT, "tests", "tools", "oracle_sam.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_bam.cpp")]
         osrc = [os.path.join(ROOT, "oracle", f) for f in ("s3_oracle.c", "s3_oracle_pe.c")]
         objs = []
         for c in osrc:

@@ -14,7 +14,7 @@ TOOL = "/tmp/s3dp_chunk_reads"
 
 @pytest.fixture(scope="module")
 def tool():
-    src = [os.path.join(ROOT, "tests", "tools", "chunk_reads.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host.cpp"),
+    src = [os.path.join(ROOT, "tests", "tools", "chunk_reads.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_bam.cpp"),
            os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host_dp.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host_dp_pair.cpp")]
     lib = os.path.join(ROOT, "soap3-dp_amd")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", TOOL] + src + ["-L" + lib, "-ls3dp", "-lz", "-lm", "-Wl,-rpath," + lib])
