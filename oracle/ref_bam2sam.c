@@ -1,6 +1,6 @@
 /* ref_bam2sam.c -- test infrastructure: reads a BAM file with the REFERENCE's samtools-0.1.18 (objects built by oracle/ref.mk from
  * /root/reference/samtools-0.1.18) and prints it as SAM text with the header, the way the reference's own SAM output is written (samopen "wh").
- * Used by tests/test_host_bam_cpu.py to check that what `soap3-dp -bam` writes is the same set of records as its SAM output.
+ * Used by tests/test_host_bam_cpu.py to check that what `soap3-dp -b 3` writes is the same set of records as its SAM output.
  *   ref_bam2sam in.bam > out.sam */
 #include <stdio.h>
 #include "sam.h"

@@ -1,4 +1,4 @@
-// s3_bam.h -- BAM output of the command line (`-bam`): the reference hands every record to samtools (samopen(.., "wb"), SOAP3-DP.cu:414; samwrite), which
+// s3_bam.h -- BAM output of the command line (`-b 3`): the reference hands every record to samtools (samopen(.., "wb"), SOAP3-DP.cu:414; samwrite), which
 // writes BAM instead of SAM text.  Here the records exist as SAM text (s3_host.cpp::SamWriter); this file turns SAM lines into BAM records and BAM
 // bytes into BGZF blocks (SAM/BAM specification 1.3, as samtools-0.1.18 implements it: bam.h, bgzf.c).  BGZF blocks are independent, so every host
 // thread compresses its own part of a chunk and the parts are written behind each other.

@@ -1,7 +1,7 @@
 // soap3-dp -- drop-in command line for the alignment path (single-end and paired-end, DP stages on or off), same arguments, .ini keys and index files as
 // the reference program (SOAP3-DP.cu main, IniParam.cpp:237-767), driving the MI355X kernels through the C-ABI of libs3dp.so.
 //
-//   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2] [-bam] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
+//   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2|3] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
 //   soap3-dp pair   <index prefix> <reads 1> <reads 2> [-u maxInsert] [-v minInsert] [-s k] [the same options]
 // Without -s the DP stages are on (the reference's default): single reads the BWT stage leaves unaligned go through seeding + semi-global DP
 // and are written to <prefix>.dpout.1; pairs without a proper pairing go through the default DP (mate rescue next to an aligned end) or the deep
@@ -85,7 +85,7 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
         SamWriter w(hix, so, &buf[(size_t)t]);
         for (uint32_t k = lo; k < hi; k++) one(w, k, al[(size_t)t]);
         if (bam) {
-            // -bam: this thread's records as BAM, in BGZF blocks of their own (blocks are independent: the parts are written behind each other)
+            // -b 3: this thread's records as BAM, in BGZF blocks of their own (blocks are independent: the parts are written behind each other)
             std::string raw, err;
             if (!samTextToBam(bam->refNames, buf[(size_t)t].data(), buf[(size_t)t].size(), raw, err)) { fprintf(stderr, "BAM output: %s\n", err.c_str()); exit(1); }
             buf[(size_t)t].clear();
@@ -503,8 +503,11 @@ int main(int argc, char **argv)
         auto need = [&](const char *what) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "Please specify %s after '%s'\n", what, a.c_str()); exit(1); } return argv[++i]; };
         if (a == "-L" || a == "-l") maxReadLength = atoi(need("the length"));
         else if (a == "-h") alignmentType = atoi(need("the output option"));
-        else if (a == "-b") outputFormat = atoi(need("the output file format"));
-        else if (a == "-bam") outputBam = true;                              // isOutputBinary: samopen(.., "wb") instead of "wh" (SOAP3-DP.cu:413-416)
+        else if (a == "-b") {
+            // 2 = SAM through the samtools API; 3 = BAM: the same API with isOutputBinary (IniParam.cpp:598-604; samopen(.., "wb"), SOAP3-DP.cu:413-416)
+            outputFormat = atoi(need("the output file format"));
+            if (outputFormat == 3) { outputFormat = 2; outputBam = true; }
+        } else if (a == "-bam" || a == "-BAM") return die("BAM read input (-bam) is not built: FASTA / FASTQ, plain or gzip");
         else if (a == "-o") prefix = need("the output prefix");
         else if (a == "-c") {
             devices.clear();
@@ -527,7 +530,7 @@ int main(int argc, char **argv)
             if (i + 1 < argc && argv[i + 1][0] >= '0' && argv[i + 1][0] <= '9') numMismatch = atoi(argv[++i]);
         } else return die("unknown option " + a);
     }
-    if (outputFormat != 2) return die("only SAM output (-b 2) is built");
+    if (outputFormat != 2) return die("only SAM (-b 2) and BAM (-b 3) output are built");
     if (alignmentType < 1 || alignmentType > 4) return die("The output option should be 1, 2, 3 or 4");
     if (maxReadLength > S3_MAX_READ_LENGTH) return die("The length should not be greater than 1024");
     if (readGroup.empty()) readGroup = queryFile;
@@ -641,7 +644,7 @@ int main(int argc, char **argv)
     const std::string outName = prefix + ".gout." + fileNo;
     FILE *out = fopen(outName.c_str(), "w");
     if (!out) return dieJoin("Could not open the output file " + outName);
-    // -bam: the same records as BAM (s3_bam.h); the header's reference dictionary is the index's
+    // -b 3: the same records as BAM (s3_bam.h); the header's reference dictionary is the index's
     std::vector<uint32_t> refLengths;
     for (int i = 0; i < hix.numOfSeq; i++) refLengths.push_back(hix.actualEnd[i] - hix.actualStart[i]);
     auto asBam = [&](FILE *f) { if (outputBam) bamRegister(f, hix.seqName, refLengths, -1); };

@@ -508,8 +508,8 @@ def _decoded(path):
 @pytest.mark.skipif(not os.path.exists(REF_BAM2SAM), reason="the reference's samtools is not built (oracle/ref.mk)")
 @pytest.mark.parametrize("chunk", ["", "192"])
 def test_cli_bam_single_reads(tmp_path, chunk):
-    """`-bam` (the reference's isOutputBinary: samopen "wb", SOAP3-DP.cu:413): the file the command line writes, read back by the REFERENCE's samtools,
-    is line for line the SAM file of the same run without -bam (streamed single-end path: records compressed in pieces by all host threads)."""
+    """`-b 3` (the reference's isOutputBinary: samopen "wb", SOAP3-DP.cu:413): the file the command line writes, read back by the REFERENCE's samtools,
+    is line for line the SAM file of the same run with -b 2 (streamed single-end path: records compressed in pieces by all host threads)."""
     name = "g2"
     shutil.copyfile(os.path.join(GOLDEN, name, "reads.fq"), tmp_path / "r.fq")
     env = dict(os.environ)
@@ -517,7 +517,7 @@ def test_cli_bam_single_reads(tmp_path, chunk):
         env["S3DP_CHUNK_READS"] = chunk
     texts = {}
     for mode in ("sam", "bam"):
-        out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), "r.fq", "-L", "120", "-s", "4", "-b", "2", "-o", mode] + (["-bam"] if mode == "bam" else []),
+        out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), "r.fq", "-L", "120", "-s", "4", "-b", "3" if mode == "bam" else "2", "-o", mode],
                              cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         texts[mode] = open(tmp_path / (mode + ".gout.1")).read() if mode == "sam" else _decoded(str(tmp_path / "bam.gout.1"))
@@ -527,12 +527,12 @@ def test_cli_bam_single_reads(tmp_path, chunk):
 
 @pytest.mark.skipif(not os.path.exists(REF_BAM2SAM), reason="the reference's samtools is not built (oracle/ref.mk)")
 def test_cli_bam_pairs_with_dp(tmp_path):
-    """-bam on the paired-end default mode: all three files (.gout.1, .dpout.1, .unpair), DP stages on"""
+    """-b 3 on the paired-end default mode: all three files (.gout.1, .dpout.1, .unpair), DP stages on"""
     name = "g4"
     texts = {}
     for mode in ("sam", "bam"):
         out = subprocess.run([BIN, "pair", os.path.join(GOLDEN, name, "index"), os.path.join(GOLDEN, name, "reads_1.fq"), os.path.join(GOLDEN, name, "reads_2.fq"),
-                              "-u", "500", "-v", "100", "-L", "100", "-o", mode] + (["-bam"] if mode == "bam" else []), cwd=tmp_path, capture_output=True, text=True, timeout=900)
+                              "-u", "500", "-v", "100", "-L", "100", "-o", mode] + (["-b", "3"] if mode == "bam" else []), cwd=tmp_path, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         for ext in ("gout.1", "dpout.1", "unpair"):
             p = str(tmp_path / (mode + "." + ext))

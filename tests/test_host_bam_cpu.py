@@ -1,4 +1,4 @@
-"""`soap3-dp -bam`: the records the command line writes as SAM, written as BAM by soap3-dp_amd/host/s3_bam.cpp, must come back from the REFERENCE's
+"""`soap3-dp -b 3`: the records the command line writes as SAM, written as BAM by soap3-dp_amd/host/s3_bam.cpp, must come back from the REFERENCE's
 samtools (oracle/_ref/ref_bam2sam, built from /root/reference/samtools-0.1.18 by oracle/ref.mk) as the same SAM text -- header and every record.
 The inputs are the golden SAM files the reference itself wrote (single-end, long reads, pairs, DP stages on)."""
 import gzip

@@ -1,4 +1,4 @@
-// sam2bam.cpp -- test tool: a SAM file through the command line's BAM writer (soap3-dp_amd/host/s3_bam.cpp), the way `soap3-dp -bam` uses it:
+// sam2bam.cpp -- test tool: a SAM file through the command line's BAM writer (soap3-dp_amd/host/s3_bam.cpp), the way `soap3-dp -b 3` uses it:
 // header block, records in pieces (whole lines) compressed on their own, end-of-file block.     sam2bam in.sam out.bam [bytes per piece]
 #include <stdio.h>
 #include <stdlib.h>
