@@ -175,38 +175,62 @@ void bamHeaderBytes(const std::string &headerText, const std::vector<std::string
     }
 }
 
+namespace {
+// one deflate state per thread and level, reset per block: deflateInit2 allocates a quarter of a megabyte -- per 64 KB block and from every host
+// thread at once that is an mmap / munmap pair on one address space for every block
+struct Deflater {
+    z_stream zs;
+    int level = -100;
+    bool live = false;
+    ~Deflater() { if (live) deflateEnd(&zs); }
+    bool ready(int lv)
+    {
+        if (live && lv == level) return deflateReset(&zs) == Z_OK;
+        if (live) { deflateEnd(&zs); live = false; }
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, lv, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        live = true; level = lv;
+        return true;
+    }
+};
+}  // namespace
+
+// one block of at most 0xff00 bytes (len == 0: the empty block that marks the end of a BAM file -- never written in the middle: samtools stops there)
+static bool bgzfBlock(const char *data, size_t len, std::string &out, int level)
+{
+    thread_local Deflater df;
+    thread_local std::vector<unsigned char> bufV(65536 + 1024);
+    unsigned char *buf = bufV.data();
+    if (!df.ready(level)) return false;
+    z_stream &zs = df.zs;
+    zs.next_in = (Bytef *)data; zs.avail_in = (uInt)len;
+    zs.next_out = buf + 18; zs.avail_out = (uInt)(bufV.size() - 18 - 8);
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    if (rc != Z_STREAM_END) return false;                               // (incompressible data of 0xff00 bytes still fits: deflate's stored blocks add 5 bytes per 64 KB)
+    const size_t total = clen + 18 + 8;
+    static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    memcpy(buf, hdr, 16);
+    buf[16] = (unsigned char)((total - 1) & 0xFF); buf[17] = (unsigned char)((total - 1) >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)data, (uInt)len);
+    unsigned char *tail = buf + 18 + clen;
+    tail[0] = (unsigned char)crc; tail[1] = (unsigned char)(crc >> 8); tail[2] = (unsigned char)(crc >> 16); tail[3] = (unsigned char)(crc >> 24);
+    tail[4] = (unsigned char)len; tail[5] = (unsigned char)(len >> 8); tail[6] = (unsigned char)(len >> 16); tail[7] = (unsigned char)(len >> 24);
+    out.append((const char *)buf, total);
+    return true;
+}
+
 bool bgzfCompress(const char *data, size_t n, std::string &out, int level)
 {
     const size_t kBlock = 0xff00;                                           // bgzf.c: DEFAULT_BLOCK_SIZE 64 KB, filled to 0xff00
-    unsigned char buf[65536 + 1024];
-    for (size_t off = 0; off < n || (n == 0 && off == 0); off += kBlock) {
-        const size_t len = n - off < kBlock ? n - off : kBlock;
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-        zs.next_in = (Bytef *)(data + off); zs.avail_in = (uInt)len;
-        zs.next_out = buf + 18; zs.avail_out = sizeof buf - 18 - 8;
-        const int rc = deflate(&zs, Z_FINISH);
-        const size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        if (rc != Z_STREAM_END) return false;                               // (incompressible data of 0xff00 bytes still fits: deflate's stored blocks add 5 bytes per 64 KB)
-        const size_t total = clen + 18 + 8;
-        static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-        memcpy(buf, hdr, 16);
-        buf[16] = (unsigned char)((total - 1) & 0xFF); buf[17] = (unsigned char)((total - 1) >> 8);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)(data + off), (uInt)len);
-        unsigned char *tail = buf + 18 + clen;
-        tail[0] = (unsigned char)crc; tail[1] = (unsigned char)(crc >> 8); tail[2] = (unsigned char)(crc >> 16); tail[3] = (unsigned char)(crc >> 24);
-        tail[4] = (unsigned char)len; tail[5] = (unsigned char)(len >> 8); tail[6] = (unsigned char)(len >> 16); tail[7] = (unsigned char)(len >> 24);
-        out.append((const char *)buf, total);
-        if (n == 0) break;
-    }
-    return true;
+    for (size_t off = 0; off < n; off += kBlock)
+        if (!bgzfBlock(data + off, n - off < kBlock ? n - off : kBlock, out, level)) return false;
+    return true;                                                            // (nothing in, nothing out)
 }
 
 const std::string &bgzfEofBlock()
 {
-    static const std::string eof = [] { std::string s; bgzfCompress("", 0, s, -1); return s; }();
+    static const std::string eof = [] { std::string s; bgzfBlock("", 0, s, -1); return s; }();
     return eof;
 }
 

@@ -663,18 +663,34 @@ int SamWriter::chrAndPosChecked(uint32_t readLen, uint32_t ambPos, uint64_t &tp,
     return aligned;
 }
 
+// decimal digits appended without a temporary string (the records are made of a dozen small numbers each)
+static inline void appendUInt(std::string &s, unsigned long long v)
+{
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    const size_t at = s.size();
+    s.resize(at + (size_t)n);
+    for (int k = 0; k < n; k++) s[at + (size_t)k] = tmp[n - 1 - k];
+}
+
 void SamWriter::seqAndQual(const ReadSet &rs, uint32_t r, bool negative, std::string &line) const
 {
     const uint32_t L = rs.lengths[r];
     const uint8_t *c = &rs.codes[(size_t)r * rs.maxReadLength];
     const char *q = &rs.quals[(size_t)r * rs.maxReadLength];
     static const char dna[] = "ACGT";
-    if (!negative) for (uint32_t i = 0; i < L; i++) line.push_back(dna[c[i]]);
-    else for (uint32_t i = 0; i < L; i++) line.push_back(dna[3 - c[L - 1 - i]]);
-    line.push_back('\t');
-    if (L && (unsigned char)q[negative ? L - 1 : 0] == 0xff) line.push_back('*');
-    else if (!negative) for (uint32_t i = 0; i < L; i++) line.push_back((char)(q[i] + 33));
-    else for (uint32_t i = 0; i < L; i++) line.push_back((char)(q[L - 1 - i] + 33));
+    const bool noQual = L && (unsigned char)q[negative ? L - 1 : 0] == 0xff;
+    const size_t at = line.size();
+    line.resize(at + L + 1 + (noQual ? 1 : L));
+    char *o = &line[at];
+    if (!negative) for (uint32_t i = 0; i < L; i++) o[i] = dna[c[i]];
+    else for (uint32_t i = 0; i < L; i++) o[i] = dna[3 - c[L - 1 - i]];
+    o[L] = '\t';
+    o += L + 1;
+    if (noQual) o[0] = '*';
+    else if (!negative) for (uint32_t i = 0; i < L; i++) o[i] = (char)(q[i] + 33);
+    else for (uint32_t i = 0; i < L; i++) o[i] = (char)(q[L - 1 - i] + 33);
 }
 
 void SamWriter::unaligned(const ReadSet &rs, uint32_t r)
@@ -765,11 +781,11 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
             xa += ix.seqName[ch - 1];
             xa.push_back(',');
             xa.push_back(strand[k] == 2 ? '-' : '+');
-            xa += std::to_string((unsigned long long)tp);
+            appendUInt(xa, tp);
             xa.push_back(',');
-            xa += std::to_string(readLen);
+            appendUInt(xa, readLen);
             xa += "M,";
-            xa += std::to_string((unsigned)mis[k]);
+            appendUInt(xa, mis[k]);
             xa.push_back(';');
             if (mis[k] > bestMis) secBestHitNum++;
         }
@@ -779,7 +795,11 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
     const uint8_t *codes = &rs.codes[(size_t)r * rs.maxReadLength];
     const char *quals = &rs.quals[(size_t)r * rs.maxReadLength];
     // bestMis == 9999 cannot reach here: a hit is always chosen
-    const int mdLen = mdString(ix, codes, quals, fullLen, pos[best], negative, (int)mis[best], boundTrim, md, avgQual);
+    // (the MD string: printed with -p, its mismatch letters counted for a trimmed read, its qualities averaged for the non-BWA MAPQ -- otherwise nobody
+    //  looks at it, and it costs a walk over the read against the text)
+    int mdLen = 0;
+    if (opt.printMDNM || !opt.bwaLikeScore || (boundTrim && mis[best]))
+        mdLen = mdString(ix, codes, quals, fullLen, pos[best], negative, (int)mis[best], boundTrim, md, avgQual);
     uint32_t outMis = mis[best];
     if (boundTrim && outMis) {                                            // :5706-5712
         outMis = 0;
@@ -801,24 +821,28 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
         } else mapq = opt.minMAPQ;
     }
     (void)mdLen;
-    std::string line = rs.names[r];
-    line.push_back('\t');
-    line += std::to_string(negative ? 16 : 0);
-    line.push_back('\t');
+    std::string &line = scratch;                                          // (kept between records: no allocation per record)
+    line.clear();
+    line += rs.names[r];
+    line += negative ? "\t16\t" : "\t0\t";
     line += ix.seqName[bestChr - 1];
     line.push_back('\t');
-    line += std::to_string((unsigned long long)bestTP);
+    appendUInt(line, bestTP);
     line.push_back('\t');
-    line += std::to_string(mapq);
+    appendUInt(line, (unsigned)mapq);
     line.push_back('\t');
-    if (!newCigar.empty()) line += newCigar; else { line += std::to_string(fullLen); line.push_back('M'); }
+    if (!newCigar.empty()) line += newCigar; else { appendUInt(line, fullLen); line.push_back('M'); }
     line += "\t*\t0\t0\t";
     seqAndQual(rs, r, negative, line);
-    line += "\tRG:Z:" + opt.readGroup;
-    if (opt.printMDNM) line += "\tNM:i:" + std::to_string(outMis);
-    line += "\tX0:i:" + std::to_string(bestHitNum) + "\tX1:i:" + std::to_string(secBestHitNum) + "\tXM:i:" + std::to_string(outMis) + "\tXO:i:0\tXG:i:0";
-    if (opt.printMDNM && !md.empty()) line += "\tMD:Z:" + md;
-    if (nOcc > 1 && !xa.empty()) line += "\tXA:Z:" + xa;
+    line += "\tRG:Z:";
+    line += opt.readGroup;
+    if (opt.printMDNM) { line += "\tNM:i:"; appendUInt(line, outMis); }
+    line += "\tX0:i:"; appendUInt(line, (unsigned)bestHitNum);
+    line += "\tX1:i:"; appendUInt(line, (unsigned)secBestHitNum);
+    line += "\tXM:i:"; appendUInt(line, outMis);
+    line += "\tXO:i:0\tXG:i:0";
+    if (opt.printMDNM && !md.empty()) { line += "\tMD:Z:"; line += md; }
+    if (nOcc > 1 && !xa.empty()) { line += "\tXA:Z:"; line += xa; }
     line.push_back('\n');
     put(line);
 }

@@ -156,6 +156,7 @@ private:
     SamOptions opt;
     FILE *out;
     std::string *sink = nullptr;
+    std::string scratch;                                 // the record being built (kept: no allocation per record)
     void put(const std::string &line);
     int gLogN[256];
     uint64_t nRecords = 0;

@@ -1,5 +1,5 @@
 // sam2bam.cpp -- test tool: a SAM file through the command line's BAM writer (soap3-dp_amd/host/s3_bam.cpp), the way `soap3-dp -b 3` uses it:
-// header block, records in pieces (whole lines) compressed on their own, end-of-file block.     sam2bam in.sam out.bam [bytes per piece]
+// header block, records in pieces (whole lines) compressed on their own, end-of-file block.     sam2bam in.sam out.bam [bytes per piece [zlib level]]
 #include <stdio.h>
 #include <stdlib.h>
 #include <fstream>
@@ -15,6 +15,7 @@ int main(int argc, char **argv)
     ss << in.rdbuf();
     const std::string all = ss.str();
     const size_t piece = argc > 3 ? (size_t)atol(argv[3]) : 100000;
+    const int level = argc > 4 ? atoi(argv[4]) : -1;
     // header text and reference dictionary from the @SQ lines
     std::string header;
     std::vector<std::string> names;
@@ -33,7 +34,7 @@ int main(int argc, char **argv)
     }
     FILE *out = fopen(argv[2], "wb");
     if (!out) return 1;
-    bamRegister(out, names, lens, -1);
+    bamRegister(out, names, lens, level);
     if (!bamWriteHeader(out, header)) return 1;
     // half of the body through the buffered single-record path, half as independently compressed pieces (the parallel formatter's way)
     const size_t half = all.find('\n', pos + (all.size() - pos) / 2);
@@ -49,7 +50,7 @@ int main(int argc, char **argv)
         e = e == std::string::npos ? all.size() : e + 1;
         std::string raw, z, err;
         if (!samTextToBam(names, all.data() + cur, e - cur, raw, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
-        if (!bgzfCompress(raw.data(), raw.size(), z, -1)) return 1;
+        if (!bgzfCompress(raw.data(), raw.size(), z, level)) return 1;
         fwrite(z.data(), 1, z.size(), out);
         cur = e;
     }

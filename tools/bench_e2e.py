@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="host threads (0 = all)")
     ap.add_argument("--repeat-frac", type=float, default=0.0, help="share of the genome planted with GRCh38-like repeat families (bench.py's generator)")
     ap.add_argument("--devices", default="", help="-c argument of the command line (e.g. 0,0: two members on one GPU)")
+    ap.add_argument("--bam", type=int, default=0, help="single reads: -b 3 (BAM output) instead of -b 2")
     ap.add_argument("--devnull", type=int, default=0, help="single reads: a second run with the SAM written to /dev/null")
     ap.add_argument("--pairs", type=int, default=0, help="paired-end default mode (DP stages on) with this many 2 x read-len pairs instead of single reads")
     a = ap.parse_args()
@@ -81,7 +82,7 @@ def main():
         env["S3DP_HOST_THREADS"] = str(a.threads)
     exe = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
     t = time.time()
-    out = subprocess.run([exe, "single", os.path.join(work, "g.index"), fq, "-L", str(L), "-s", str(a.mismatch), "-b", "2", "-o", os.path.join(work, "out")] +
+    out = subprocess.run([exe, "single", os.path.join(work, "g.index"), fq, "-L", str(L), "-s", str(a.mismatch), "-b", "3" if a.bam else "2", "-o", os.path.join(work, "out")] +
                          (["-c", a.devices] if a.devices else []), capture_output=True, text=True, env=env)
     wall = time.time() - t
     if out.returncode != 0:
@@ -91,7 +92,7 @@ def main():
     aligned = int(re.search(r"Overall number of reads aligned: (\d+)", out.stdout).group(1))
     sam_bytes = sum(os.path.getsize(os.path.join(work, f)) for f in os.listdir(work) if f.startswith("out.gout."))
     m = re.search(r"\[Main\] Read load time :\s+([0-9.]+) seconds \(loader", out.stdout)
-    res = {"genome_bp": a.genome_bp, "repeat_frac": a.repeat_frac, "devices": a.devices or "0", "loader_thread_s": float(m.group(1)) if m else None, "reads": N, "read_len": L, "max_mismatch": a.mismatch, "host_threads": a.threads or os.cpu_count(),
+    res = {"output": "BAM (-b 3)" if a.bam else "SAM (-b 2)", "genome_bp": a.genome_bp, "repeat_frac": a.repeat_frac, "devices": a.devices or "0", "loader_thread_s": float(m.group(1)) if m else None, "reads": N, "read_len": L, "max_mismatch": a.mismatch, "host_threads": a.threads or os.cpu_count(),
            "index_build_and_write_s": t_index, "fastq_write_s": t_reads, "wall_s_total": wall, "phases_s": ph, "aligned_reads": aligned,
            "sam_bytes": sam_bytes, "fastq_bytes": os.path.getsize(fq),
            "reads_per_s_wall_incl_index_load": N / wall,
