@@ -496,10 +496,104 @@ bool ReadChunker::open(const std::string &file1, const std::string &file2, uint3
     return true;
 }
 
+bool ReadChunker::openBam(const std::string &file, bool paired, uint32_t maxReadLength_, int qualityConstant_, int maxLenReadName_, std::string &err)
+{
+    maxReadLength = maxReadLength_; qualityConstant = qualityConstant_; maxLenReadName = maxLenReadName_;
+    bam = true; bamPaired = paired;
+    files.clear();
+    files.emplace_back(new File());
+    File &X = *files[0];
+    X.name = file;
+    X.gz = gzopen(file.c_str(), "r");                                   // (BGZF is a series of gzip members: zlib reads across them)
+    if (!X.gz) { err = "cannot open " + file; return false; }
+    gzbuffer(X.gz, 1 << 20);
+    auto rd = [&](void *p, unsigned n) { return gzread(X.gz, p, n) == (int)n; };
+    char magic[4];
+    int32_t lText = 0, nRef = 0;
+    if (!rd(magic, 4) || memcmp(magic, "BAM\1", 4) != 0) { err = file + " is not a BAM file"; return false; }
+    if (!rd(&lText, 4) || lText < 0) { err = "bad BAM header in " + file; return false; }
+    std::vector<char> skip((size_t)lText + 1);
+    if (lText && !rd(skip.data(), (unsigned)lText)) { err = "bad BAM header in " + file; return false; }
+    if (!rd(&nRef, 4) || nRef < 0) { err = "bad BAM header in " + file; return false; }
+    for (int i = 0; i < nRef; i++) {
+        int32_t lName = 0, lRef = 0;
+        if (!rd(&lName, 4) || lName < 0) { err = "bad BAM header in " + file; return false; }
+        skip.resize((size_t)lName + 1);
+        if ((lName && !rd(skip.data(), (unsigned)lName)) || !rd(&lRef, 4)) { err = "bad BAM header in " + file; return false; }
+    }
+    return true;
+}
+
+bool ReadChunker::nextBam(uint32_t maxReads, ReadSet &rs, std::string &err)
+{
+    File &X = *files[0];
+    if (bamPaired) maxReads &= ~1u;
+    if (maxReads == 0) { err = "ReadChunker::next: bad chunk size"; return false; }
+    unsigned char charMap[256];
+    fillCharMap(charMap);
+    uint32_t w = 1;
+    while (w < maxReadLength) w *= 2;
+    const uint32_t wpq = w / 16 ? w / 16 : 1;
+    // the records of the chunk, raw (their number is not known before they are read)
+    std::vector<std::vector<unsigned char>> recs;
+    while (recs.size() < maxReads && !X.eof) {
+        int32_t blockSize = 0;
+        const int got = gzread(X.gz, &blockSize, 4);
+        if (got == 0) { X.eof = true; break; }
+        if (got != 4 || blockSize < 32) { err = "truncated BAM record in " + X.name; return false; }
+        std::vector<unsigned char> b((size_t)blockSize);
+        if (gzread(X.gz, b.data(), (unsigned)blockSize) != blockSize) { err = "truncated BAM record in " + X.name; return false; }
+        recs.push_back(std::move(b));
+    }
+    uint32_t n = (uint32_t)recs.size();
+    if (bamPaired) n &= ~1u;                                            // (a last read without its mate is dropped, as a shorter second file would drop it)
+    if (n == 0) return false;
+    allocateReads(rs, n, true, wpq, maxReadLength);
+    static const char nt16[] = "=ACMGRSVTWYHKDBN";
+    const int T = hostThreads();
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t] {
+        for (uint32_t r = (uint32_t)t; r < n; r += (uint32_t)T) {
+            const unsigned char *b = recs[r].data();
+            const size_t size = recs[r].size();
+            uint32_t v[8];
+            memcpy(v, b, 32);
+            const uint32_t lName = v[2] & 0xFFu, flag = v[3] >> 16, nCigar = v[3] & 0xFFFFu, lSeq = v[4];
+            const size_t seqAt = 32 + (size_t)lName + 4 * (size_t)nCigar, qualAt = seqAt + (lSeq + 1) / 2;
+            if (qualAt + lSeq > size) continue;                        // a broken record: an empty read
+            const char *nm = (const char *)b + 32;
+            size_t nl = lName ? lName - 1 : 0;
+            if (nl > (size_t)maxLenReadName - 1) nl = (size_t)maxLenReadName - 1;
+            rs.names[r].assign(nm, nl);
+            const bool fwd = !(flag & 16u);
+            const uint32_t L = lSeq > maxReadLength ? maxReadLength : lSeq;
+            rs.lengths[r] = L;
+            uint32_t *dst = rs.queries.data() + ((size_t)r / 32) * 32 * wpq + r % 32;
+            uint8_t *cd = &rs.codes[(size_t)r * maxReadLength];
+            char *qd = &rs.quals[(size_t)r * maxReadLength];
+            for (uint32_t i = 0; i < L; i++) {
+                const uint32_t k = fwd ? i : lSeq - 1 - i;              // the read as sequenced: a reverse-strand record is turned back
+                const unsigned char ch = (unsigned char)nt16[(b[seqAt + k / 2] >> (k & 1u ? 0 : 4)) & 15u];
+                // (the reference indexes its four-entry complement table with the CHARACTER here, QueryParser.cpp:132 -- out of bounds; the evident intent:
+                //  the complement of A / C / G / T, anything else stays what it is, N -> G as everywhere)
+                const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+                const uint8_t code = fwd || !acgt ? charMap[ch] : (uint8_t)(3 - charMap[ch]);
+                dst[(i / 16) * 32] |= (uint32_t)code << (2 * (i % 16));
+                cd[i] = code;
+                const unsigned char q = b[qualAt + k];
+                qd[i] = q == 0xFF ? (char)0xFF : (char)((int)q + 33 - qualityConstant);
+            }
+        }
+    });
+    for (auto &x : th) x.join();
+    return true;
+}
+
 bool ReadChunker::next(uint32_t maxReads, ReadSet &rs, std::string &err)
 {
     err.clear();
     rs = ReadSet();
+    if (bam) return nextBam(maxReads, rs, err);
     const size_t F = files.size();
     if (F == 2) maxReads &= ~1u;
     const uint32_t perFile = F == 2 ? maxReads / 2 : maxReads;

@@ -67,10 +67,15 @@ public:
     ~ReadChunker();
     bool open(const std::string &file1, const std::string &file2 /* empty: single reads */, uint32_t maxReadLength, int qualityConstant, int maxLenReadName,
               std::string &err);
+    // reads from ONE BAM file (the reference's -bam: loadBAMReads, QueryParser.cpp:27-171): every record is a read -- for pairs the mates follow each
+    // other --, a record with the reverse-strand flag is taken back to the read as sequenced (reverse complement, qualities reversed)
+    bool openBam(const std::string &file, bool paired, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, std::string &err);
     bool next(uint32_t maxReads, ReadSet &rs, std::string &err);
 private:
     struct File;
     std::vector<std::unique_ptr<File>> files;
+    bool bam = false, bamPaired = false;
+    bool nextBam(uint32_t maxReads, ReadSet &rs, std::string &err);
     uint32_t maxReadLength = 0;
     int qualityConstant = 33, maxLenReadName = 64;
 };

@@ -1,7 +1,7 @@
 // soap3-dp -- drop-in command line for the alignment path (single-end and paired-end, DP stages on or off), same arguments, .ini keys and index files as
 // the reference program (SOAP3-DP.cu main, IniParam.cpp:237-767), driving the MI355X kernels through the C-ABI of libs3dp.so.
 //
-//   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2|3] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
+//   soap3-dp single <index prefix> <reads.fa|fq[.gz]> [-L maxReadLen] [-s k] [-h 1..4] [-b 2|3] [-bam] [-o prefix] [-c gpu] [-D rg] [-A sample] [-R opts] [-p]
 //   soap3-dp pair   <index prefix> <reads 1> <reads 2> [-u maxInsert] [-v minInsert] [-s k] [the same options]
 // Without -s the DP stages are on (the reference's default): single reads the BWT stage leaves unaligned go through seeding + semi-global DP
 // and are written to <prefix>.dpout.1; pairs without a proper pairing go through the default DP (mate rescue next to an aligned end) or the deep
@@ -488,17 +488,20 @@ int main(int argc, char **argv)
     if (argc < 4) return die("usage: soap3-dp single <index> <reads> [options]\n       soap3-dp pair <index> <reads 1> <reads 2> [-u max insert] [-v min insert] [options]");
     const bool paired = strcmp(argv[1], "pair") == 0;
     if (!paired && strcmp(argv[1], "single") != 0) return die("the first argument must be 'single' or 'pair'");
-    if (paired && argc < 5) return die("pair mode needs two read files");
+    // -bam: the reads come from ONE BAM file, the mates of a pair behind each other (isReadBAM, IniParam.cpp:449-459)
+    bool readBam = false;
+    for (int i = 2; i < argc; i++) if (!strcmp(argv[i], "-bam") || !strcmp(argv[i], "-BAM")) readBam = true;
+    if (paired && !readBam && argc < 5) return die("pair mode needs two read files");
     Ini ini;
     parseIni(std::string(argv[0]) + ".ini", ini);
-    const std::string indexName = argv[2], queryFile = argv[3], queryFile2 = paired ? argv[4] : "";
+    const std::string indexName = argv[2], queryFile = argv[3], queryFile2 = paired && !readBam ? argv[4] : "";
     int insertHigh = 500, insertLow = 1;                                       // IniParam.cpp:482-483
     int maxReadLength = 120, numMismatch = -1, alignmentType = 2, outputFormat = 2;             // DEFAULT_MAX_READ_LEN, all-best, SAM
     std::vector<int> devices(1, 0);                                            // -c: the reference takes one GPU id (SOAP3-DP.cu:219-220); here also a list "0,1,2"
     bool enableDP = true, skipSoap3 = false;
     std::string prefix = queryFile, readGroup, sampleName, readGrpOption;
     bool printMDNM = false, outputBam = false;
-    for (int i = paired ? 5 : 4; i < argc; i++) {
+    for (int i = paired && !readBam ? 5 : 4; i < argc; i++) {
         const std::string a = argv[i];
         auto need = [&](const char *what) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "Please specify %s after '%s'\n", what, a.c_str()); exit(1); } return argv[++i]; };
         if (a == "-L" || a == "-l") maxReadLength = atoi(need("the length"));
@@ -507,7 +510,7 @@ int main(int argc, char **argv)
             // 2 = SAM through the samtools API; 3 = BAM: the same API with isOutputBinary (IniParam.cpp:598-604; samopen(.., "wb"), SOAP3-DP.cu:413-416)
             outputFormat = atoi(need("the output file format"));
             if (outputFormat == 3) { outputFormat = 2; outputBam = true; }
-        } else if (a == "-bam" || a == "-BAM") return die("BAM read input (-bam) is not built: FASTA / FASTQ, plain or gzip");
+        } else if (a == "-bam" || a == "-BAM") { /* seen above */ }
         else if (a == "-o") prefix = need("the output prefix");
         else if (a == "-c") {
             devices.clear();
@@ -546,7 +549,8 @@ int main(int argc, char **argv)
     if (const char *e = getenv("S3DP_CHUNK_READS")) chunkReadsEnv = (size_t)strtoull(e, nullptr, 10);
     const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : (size_t)1 << 22) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
     ReadChunker chunker;
-    if (!chunker.open(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)) return die(err);
+    if (readBam ? !chunker.openBam(queryFile, paired, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)
+                : !chunker.open(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)) return die(err);
     struct ChunkQueue {
         std::mutex mu;
         std::condition_variable cv;

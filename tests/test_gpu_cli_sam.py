@@ -539,3 +539,48 @@ def test_cli_bam_pairs_with_dp(tmp_path):
             texts[(mode, ext)] = open(p).read() if mode == "sam" else _decoded(p)
     for ext in ("gout.1", "dpout.1", "unpair"):
         assert texts[("bam", ext)].splitlines() == texts[("sam", ext)].splitlines(), ext
+
+
+def _fastq_to_unaligned_bam(fq, bam, tmp_path, flags=(4,)):
+    """the reads of a FASTQ file as unaligned BAM records (the product's BAM writer through tests/tools/sam2bam)"""
+    host = os.path.join(ROOT, "soap3-dp_amd", "host")
+    exe = os.path.join(ROOT, "tests", "tools", "sam2bam")
+    src = [os.path.join(ROOT, "tests", "tools", "sam2bam.cpp"), os.path.join(host, "s3_bam.cpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + host, "-o", exe] + src + ["-lz"])
+    sam = str(bam) + ".sam"
+    with open(sam, "w") as g:
+        g.write("@HD\tVN:1.3\tSO:unsorted\n@SQ\tSN:x\tLN:1000\n")
+        files = [open(f).read().split("\n") for f in fq]
+        n = (len(files[0]) - 1) // 4
+        for i in range(n):
+            for k, lines in enumerate(files):
+                nm = lines[4 * i][1:].split()[0]
+                if len(nm) > 2 and nm[-2] == "/":                      # BAM names carry no mate suffix (the text loader strips it: QueryParser's FASTQ path)
+                    nm = nm[:-2]
+                g.write("%s\t%d\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (nm, flags[k % len(flags)], lines[4 * i + 1], lines[4 * i + 3]))
+    subprocess.check_call([exe, sam, str(bam)])
+
+
+def test_cli_bam_input_single_and_pairs(tmp_path):
+    """-bam (the reference's isReadBAM): reads from one BAM file -- same SAM records as from the FASTQ files the BAM was made of"""
+    name = "g2"
+    shutil.copyfile(os.path.join(GOLDEN, name, "reads.fq"), tmp_path / "r.fq")
+    _fastq_to_unaligned_bam([tmp_path / "r.fq"], tmp_path / "r.bam", tmp_path)
+    recs = {}
+    for mode, args in (("fq", ["r.fq"]), ("bam", ["r.bam", "-bam"])):
+        out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index")] + args + ["-L", "120", "-s", "4", "-b", "2", "-D", "rg", "-o", mode], cwd=tmp_path,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        recs[mode] = sam_records(open(tmp_path / (mode + ".gout.1")).read())[1]
+    assert recs["bam"] == recs["fq"] and len(recs["fq"]) > 1000
+    name = "g4"
+    f1, f2 = os.path.join(GOLDEN, name, "reads_1.fq"), os.path.join(GOLDEN, name, "reads_2.fq")
+    _fastq_to_unaligned_bam([f1, f2], tmp_path / "p.bam", tmp_path, flags=(77, 141))
+    texts = {}
+    for mode, args in (("pfq", [f1, f2]), ("pbam", ["p.bam", "-bam"])):
+        out = subprocess.run([BIN, "pair", os.path.join(GOLDEN, name, "index")] + args + ["-u", "500", "-v", "100", "-L", "100", "-s", "3", "-D", "rg", "-o", mode], cwd=tmp_path,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        texts[mode] = [l for l in open(tmp_path / (mode + ".gout.1")).read().split("\n") if l and not l.startswith("@PG")]
+    assert texts["pbam"] == texts["pfq"] and len(texts["pfq"]) > 1000

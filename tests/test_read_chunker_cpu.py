@@ -83,3 +83,48 @@ def test_golden_reads_through_the_chunker(tool, tmp_path):
     whole, _ = dump(tool, 1 << 30, 100, [os.path.join(GOLDEN, "g4", "reads_1.fq"), os.path.join(GOLDEN, "g4", "reads_2.fq")], tmp_path, "g4_whole")
     got, c = dump(tool, 512, 100, [os.path.join(GOLDEN, "g4", "reads_1.fq"), os.path.join(GOLDEN, "g4", "reads_2.fq")], tmp_path, "g4_512")
     assert got == whole and c == 5
+
+
+def _sam2bam():
+    host = os.path.join(ROOT, "soap3-dp_amd", "host")
+    exe = os.path.join(ROOT, "tests", "tools", "sam2bam")
+    src = [os.path.join(ROOT, "tests", "tools", "sam2bam.cpp"), os.path.join(host, "s3_bam.cpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + host, "-o", exe] + src + ["-lz"])
+    return exe
+
+
+_COMP = str.maketrans("ACGTN", "TGCAN")
+
+
+def test_bam_input_gives_the_reads_of_the_fastq(tool, tmp_path):
+    """-bam (loadBAMReads, QueryParser.cpp:27): the reads of a BAM file are the reads of the FASTQ it was made from, whatever the chunk size; a record
+    that carries the reverse-strand flag holds the reverse complement and is turned back.  (The BAM is written by the product's own BAM writer, which
+    tests/test_host_bam_cpu.py pins against the reference's samtools.)"""
+    rng = np.random.default_rng(11)
+    fq = tmp_path / "a.fq"
+    write_fastq(fq, 2500, rng, 30, 100)
+    sam = tmp_path / "a.sam"
+    with open(fq) as f, open(sam, "w") as g:
+        g.write("@HD\tVN:1.3\tSO:unsorted\n@SQ\tSN:chr1\tLN:1000\n")
+        lines = f.read().split("\n")
+        for i in range(0, len(lines) - 3, 4):
+            name, seq, qual = lines[i][1:].split()[0], lines[i + 1], lines[i + 3]
+            if (i // 4) % 3 == 1:                                   # an "aligned to the reverse strand" record: sequence and qualities as on the reference strand
+                g.write("%s\t16\tchr1\t5\t30\t%dM\t*\t0\t0\t%s\t%s\n" % (name, len(seq), seq.translate(_COMP)[::-1], qual[::-1]))
+            else:
+                g.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (name, seq, qual))
+    bam = tmp_path / "a.bam"
+    subprocess.check_call([_sam2bam(), str(sam), str(bam)])
+    whole, _ = dump(tool, 1 << 30, 100, [fq], tmp_path, "fq")
+    for chunk in (1 << 30, 1000, 64):
+        got, c = dump(tool, chunk, 100, ["bam:" + str(bam)], tmp_path, "bam%d" % chunk)
+        assert c == (2500 + chunk - 1) // chunk
+        assert len(got) == len(whole)
+        for a, b in zip(whole, got):
+            # (the FASTQ name keeps "/1"; N is read as G on both paths: charMap)
+            assert a.split(" ")[1:] == b.split(" ")[1:], (a[:80], b[:80])
+            assert a.split(" ")[0].split("/")[0] == b.split(" ")[0].split("/")[0]
+    # pairs: the mates behind each other in one file; an odd record at the end is dropped
+    got, _ = dump(tool, 1000, 100, ["bampair:" + str(bam)], tmp_path, "bampair")
+    assert [l.split(" ")[1:] for l in got if l] == [l.split(" ")[1:] for l in whole if l][:2500]

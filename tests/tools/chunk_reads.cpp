@@ -14,7 +14,11 @@ int main(int argc, char **argv)
     FILE *out = fopen(argv[3], "w");
     ReadChunker c;
     std::string err;
-    if (!c.open(argv[4], argc > 5 ? argv[5] : "", L, 33, 64, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    // a file argument "bam:<file>" / "bampair:<file>": reads (pairs) from one BAM file
+    const std::string f1 = argv[4];
+    const bool ok = f1.compare(0, 4, "bam:") == 0 ? c.openBam(f1.substr(4), false, L, 33, 64, err)
+                  : f1.compare(0, 8, "bampair:") == 0 ? c.openBam(f1.substr(8), true, L, 33, 64, err) : c.open(f1, argc > 5 ? argv[5] : "", L, 33, 64, err);
+    if (!ok) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     ReadSet rs;
     unsigned chunks = 0;
     while (c.next(chunk, rs, err)) {
