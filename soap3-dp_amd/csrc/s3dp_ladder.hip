@@ -42,13 +42,22 @@ __global__ void stateAllKernel(uint32_t n, const uint32_t *totalOcc, uint8_t *st
     if (i < n) state[i] = totalOcc[i] > 0 ? 1 : 0;
 }
 
+// read-ordered copy of the occurrence lists.  A wave takes 64 reads; lists of up to 8 entries are copied by their own lane, longer ones by the whole
+// wave, entry k by lane k % 64 (a read inside a repeat family holds a thousand entries: one lane per read left the launch waiting for those lanes).
 __global__ void gatherOccKernel(uint32_t n, const uint32_t *occStart, const uint32_t *outOffsets, const uint32_t *pos, const uint32_t *meta,
                                 uint32_t *outPos, uint32_t *outMeta)
 {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const uint32_t cnt = outOffsets[r + 1] - outOffsets[r], src = occStart[r], dst = outOffsets[r];
-    for (uint32_t k = 0; k < cnt; k++) { outPos[dst + k] = pos[src + k]; outMeta[dst + k] = meta[src + k]; }
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    uint32_t cnt = 0, src = 0, dst = 0;
+    if (r < n) { cnt = outOffsets[r + 1] - outOffsets[r]; src = occStart[r]; dst = outOffsets[r]; }
+    if (cnt <= 8u) for (uint32_t k = 0; k < cnt; k++) { outPos[dst + k] = pos[src + k]; outMeta[dst + k] = meta[src + k]; }
+    unsigned long long big = __ballot(cnt > 8u);
+    while (big) {
+        const int l = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t c = (uint32_t)__shfl((int)cnt, l), s0 = (uint32_t)__shfl((int)src, l), d0 = (uint32_t)__shfl((int)dst, l);
+        for (uint32_t k = lane; k < c; k += 64u) { outPos[d0 + k] = pos[s0 + k]; outMeta[d0 + k] = meta[s0 + k]; }
+    }
 }
 
 void s3i::launchIota(uint32_t *p, uint32_t n, hipStream_t s)
