@@ -303,7 +303,18 @@ __global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix
                 const uint32_t strand = ((r.x % groups) & 1u) + 1u;
                 const uint32_t meta = strand | nmis << 8;
                 if (kind) { occPos[o + preKind] = r.z; occMeta[o + preKind] = meta; }
-                else for (uint32_t q = 0; q < c; q++) { occPos[oSa + preSa + q] = ix.sa[r.z + q]; occMeta[oSa + preSa + q] = meta | 0x10000u; }
+                else if (c <= 8u) for (uint32_t q = 0; q < c; q++) { occPos[oSa + preSa + q] = ix.sa[r.z + q]; occMeta[oSa + preSa + q] = meta | 0x10000u; }
+            }
+            // an SA range of more than a few suffixes (up to maxOut identical copies) is expanded by the whole wave, suffix q by lane q % 64
+            {
+                unsigned long long big = __ballot(incl && !kind && c > 8u);
+                const uint32_t strandB = ((r.x % groups) & 1u) + 1u, metaB = strandB | nmis << 8 | 0x10000u, dstB = oSa + preSa;
+                while (big) {
+                    const int l = __ffsll((long long)big) - 1;
+                    big &= big - 1;
+                    const uint32_t z = (uint32_t)__shfl((int)r.z, l), cc = (uint32_t)__shfl((int)c, l), d = (uint32_t)__shfl((int)dstB, l), m = (uint32_t)__shfl((int)metaB, l);
+                    for (uint32_t q = lane; q < cc; q += 64u) { occPos[d + q] = ix.sa[z + q]; occMeta[d + q] = m; }
+                }
             }
             o += nKind; oSa += nSa;
             total = total + sum > a.maxOut ? a.maxOut : total + sum;
