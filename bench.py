@@ -321,6 +321,12 @@ def cpu_baseline(hi, q, lens, wpq, mm, max_out, budget_s):
     import threading
     import s3o
     cores = os.cpu_count() or 1
+    try:                                                    # the container's CPU quota, when it has one: threads beyond it only take turns
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
     oix = s3o.Index(host_index=hi)
     n_all = len(lens)
     block = 256

@@ -95,6 +95,10 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     if (!desc->sa || !desc->packedDNA || !desc->lkt || !desc->revLkt) return fail(S3_EINVAL, "sa, packedDNA and both lookup tables are required");
     if (desc->lktSize < 1 || desc->lktSize > 15) return fail(S3_EINVAL, "bad lookup table size");
     HIPCHK(hipSetDevice(device));
+    // S3DP_BLOCKING_SYNC=1: host threads that wait for the device sleep instead of spinning -- under a CPU quota (a container granted sixteen CPUs) every
+    // spinning waiter is a CPU the parser and the formatter do not get.  Has to be said before the device's context exists: failure is ignored.
+    if (const char *e = getenv("S3DP_BLOCKING_SYNC")) if (*e == '1') (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    (void)hipGetLastError();
     s3_index *ix = new s3_index();
     ix->dev = device;
     hipStream_t s = nullptr;

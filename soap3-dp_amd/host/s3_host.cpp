@@ -178,10 +178,32 @@ s3_index_desc HostIndex::desc() const
 // ------------------------------------------------------------------------------------------------
 // The whole file is inflated into memory, cut into one piece per host thread at record boundaries, and the pieces are parsed in
 // parallel (count pass, then fill pass straight into the packed arrays).  S3DP_HOST_THREADS overrides the thread count.
+// CPUs the process may actually use: the hardware's, cut to the control group's quota (a container that shows 256 processors and grants sixteen runs
+// 256 threads at a sixteenth of the speed each -- and stalls all of them whenever the quota of a period is spent)
+static int cpuAllowance()
+{
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    auto fromQuota = [&](double quota, double period) { if (quota > 0 && period > 0) { const int c = (int)((quota + period - 1) / period); if (c >= 1 && c < hw) hw = c; } };
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                      // cgroup v2: "<quota|max> <period>"
+        char q[64] = {0};
+        double period = 0;
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) fromQuota(atof(q), period);
+        fclose(f);
+    } else {
+        double quota = -1, period = 0;                                          // cgroup v1
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lf", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lf", &period) != 1) period = 0; fclose(g); }
+        fromQuota(quota, period);
+    }
+    return hw;
+}
+
 int hostThreads()
 {
+    static const int allowed = cpuAllowance();
     const char *e = getenv("S3DP_HOST_THREADS");
-    int t = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    int t = e && *e ? atoi(e) : allowed;
     if (t < 1) t = 1;
     if (t > 256) t = 256;
     return t;
