@@ -483,11 +483,20 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
 
 static int die(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); return 1; }
 
-int main(int argc, char **argv)
+// what the jobs of one program run share: the index in host memory and on the devices (single-multi / pair-multi load it once, SOAP3-DP.cu:869-1140)
+struct SharedIndex {
+    HostIndex hix;
+    s3_group *grp = nullptr;
+    std::vector<int> devices;
+    bool loaded = false;
+};
+
+static int runJob(int argc, char **argv, SharedIndex &shared)
 {
-    if (argc < 4) return die("usage: soap3-dp single <index> <reads> [options]\n       soap3-dp pair <index> <reads 1> <reads 2> [-u max insert] [-v min insert] [options]");
+    if (argc < 4) return die("usage: soap3-dp single <index> <reads> [options]\n       soap3-dp pair <index> <reads 1> <reads 2> [-u max insert] [-v min insert] [options]\n"
+                             "       soap3-dp single-multi <index> <list file> [options]\n       soap3-dp pair-multi <index> <list file> [options]");
     const bool paired = strcmp(argv[1], "pair") == 0;
-    if (!paired && strcmp(argv[1], "single") != 0) return die("the first argument must be 'single' or 'pair'");
+    if (!paired && strcmp(argv[1], "single") != 0) return die("the first argument must be 'single', 'pair', 'single-multi' or 'pair-multi'");
     // -bam: the reads come from ONE BAM file, the mates of a pair behind each other (isReadBAM, IniParam.cpp:449-459)
     bool readBam = false;
     for (int i = 2; i < argc; i++) if (!strcmp(argv[i], "-bam") || !strcmp(argv[i], "-BAM")) readBam = true;
@@ -539,7 +548,7 @@ int main(int argc, char **argv)
     if (readGroup.empty()) readGroup = queryFile;
     if (sampleName.empty()) sampleName = "default";
     std::string err;
-    HostIndex hix;
+    HostIndex &hix = shared.hix;
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     // The read files come in chunks (ReadChunker): a loader thread parses chunk i+1 -- with all host threads -- while chunk i is aligned and
@@ -584,17 +593,21 @@ int main(int argc, char **argv)
     };
     // (a failure below leaves through exit(): the loader thread must not outlive main's locals silently)
     auto dieJoin = [&](const std::string &m) -> int { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); return 1; };
-    printf("[Main] loading index into host...\n");
-    if (!loadIndex(indexName, hix, err)) return dieJoin(err);
-    printf("[Main] Finished loading index into host.\n[Main] Loading time : %9.4f seconds\n", since(t0));
-    printf("[Main] Reference sequence length : %u\n", hix.n);
-    // the index is replicated: one copy per device, uploaded at the same time (s3_group_create); the read chunks are dealt to the devices as they
-    // come free, each device writes its own set of output files (as the reference writes one .gout.N per CPU thread, SOAP3-DP.cu:251-258)
-    s3_group *grp = nullptr;
-    s3_index_desc d = hix.desc();
-    if (s3_group_create(devices.data(), (int)devices.size(), &d, &grp) != S3_OK) return dieJoin(s3_last_error());
+    if (!shared.loaded) {
+        printf("[Main] loading index into host...\n");
+        if (!loadIndex(indexName, hix, err)) return dieJoin(err);
+        printf("[Main] Finished loading index into host.\n[Main] Loading time : %9.4f seconds\n", since(t0));
+        printf("[Main] Reference sequence length : %u\n", hix.n);
+        // the index is replicated: one copy per device, uploaded at the same time (s3_group_create); the read chunks are dealt to the devices as they
+        // come free, each device writes its own set of output files (as the reference writes one .gout.N per CPU thread, SOAP3-DP.cu:251-258)
+        s3_index_desc d = hix.desc();
+        if (s3_group_create(devices.data(), (int)devices.size(), &d, &shared.grp) != S3_OK) return dieJoin(s3_last_error());
+        shared.devices = devices;
+        shared.loaded = true;
+        printf("[Main] Finished copying index into device (GPU).\n");
+    } else devices = shared.devices;                                           // (later jobs of a list run on the devices the index is on)
+    s3_group *grp = shared.grp;
     const int nMembers = (int)devices.size();
-    printf("[Main] Finished copying index into device (GPU).\n");
     std::unique_ptr<ReadSet> chunk = nextChunk();
     if (!chunk) {
         if (!loaded.err.empty()) return dieJoin(loaded.err);
@@ -926,8 +939,59 @@ int main(int argc, char **argv)
     printf("[Main] Read load time : %9.4f seconds (loader thread, overlapped)\n", loaded.seconds);
     loader.join();
     if (!loaded.err.empty()) return die(loaded.err);
-    s3_group_free(grp);
     FILE *done = fopen((prefix + ".done").c_str(), "w");
     if (done) fclose(done);
     return 0;
+}
+
+// single / pair: one job.  single-multi / pair-multi <index> <list file> [options]: one job per line of the list, the index loaded once
+// (loadMultiInputFile, IniParam.cpp:28-170; README.md "Multiple sets of ..."): columns separated by tabs --
+//   single-multi: read file, output prefix [, read group ID, sample name [, read group options]]
+//   pair-multi:   read file 1, read file 2, minimum insert, maximum insert, output prefix [, read group ID, sample name [, options]]
+//   with -bam a pair is ONE file: read file, minimum insert, maximum insert, output prefix, ...
+int main(int argc, char **argv)
+{
+    SharedIndex shared;
+    int rc = 0;
+    const bool multi = argc >= 2 && (!strcmp(argv[1], "single-multi") || !strcmp(argv[1], "pair-multi"));
+    if (!multi) rc = runJob(argc, argv, shared);
+    else {
+        if (argc < 4) return die("usage: soap3-dp single-multi|pair-multi <index> <list file> [options]");
+        const bool paired = !strcmp(argv[1], "pair-multi");
+        bool readBam = false;
+        for (int i = 4; i < argc; i++) if (!strcmp(argv[i], "-bam") || !strcmp(argv[i], "-BAM")) readBam = true;
+        FILE *f = fopen(argv[3], "r");
+        if (!f) return die(std::string("cannot open the list file ") + argv[3]);
+        std::vector<std::vector<std::string>> lines;
+        char buf[8192];
+        while (fgets(buf, sizeof buf, f)) {
+            std::vector<std::string> cols;
+            std::string cur;
+            for (const char *p = buf; *p && *p != '\n' && *p != '\r'; p++) { if (*p == '\t') { cols.push_back(cur); cur.clear(); } else cur.push_back(*p); }
+            cols.push_back(cur);
+            while (!cols.empty() && cols.back().empty()) cols.pop_back();
+            if (!cols.empty()) lines.push_back(cols);
+        }
+        fclose(f);
+        for (size_t ln = 0; ln < lines.size() && rc == 0; ln++) {
+            const std::vector<std::string> &c = lines[ln];
+            const size_t nFiles = paired && !readBam ? 2 : 1, need = nFiles + (paired ? 2 : 0) + 1;
+            if (c.size() < need) return die("line " + std::to_string(ln + 1) + " of " + argv[3] + ": too few columns");
+            std::vector<std::string> a = {argv[0], paired ? "pair" : "single", argv[2]};
+            for (size_t k = 0; k < nFiles; k++) a.push_back(c[k]);
+            for (int i = 4; i < argc; i++) a.push_back(argv[i]);               // the options of the command line hold for every job
+            size_t k = nFiles;
+            if (paired) { a.push_back("-v"); a.push_back(c[k++]); a.push_back("-u"); a.push_back(c[k++]); }
+            a.push_back("-o"); a.push_back(c[k++]);
+            if (k < c.size()) { a.push_back("-D"); a.push_back(c[k++]); }
+            if (k < c.size()) { a.push_back("-A"); a.push_back(c[k++]); }
+            if (k < c.size()) { a.push_back("-R"); a.push_back(c[k++]); }
+            std::vector<char *> av;
+            for (std::string &x : a) av.push_back(&x[0]);
+            printf("[Main] ---- job %zu of %zu: %s\n", ln + 1, lines.size(), c[0].c_str());
+            rc = runJob((int)av.size(), av.data(), shared);
+        }
+    }
+    if (shared.grp) s3_group_free(shared.grp);
+    return rc;
 }

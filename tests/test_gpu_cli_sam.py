@@ -584,3 +584,32 @@ def test_cli_bam_input_single_and_pairs(tmp_path):
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         texts[mode] = [l for l in open(tmp_path / (mode + ".gout.1")).read().split("\n") if l and not l.startswith("@PG")]
     assert texts["pbam"] == texts["pfq"] and len(texts["pfq"]) > 1000
+
+
+def test_cli_multi_modes(tmp_path):
+    """single-multi / pair-multi (loadMultiInputFile, IniParam.cpp:28): one job per line of a tab-separated list, the index loaded once -- every job's
+    files equal those of the same job run on its own"""
+    g2, g4 = os.path.join(GOLDEN, "g2"), os.path.join(GOLDEN, "g4")
+    shutil.copyfile(os.path.join(g2, "reads.fq"), tmp_path / "a.fq")
+    with open(tmp_path / "list.txt", "w") as f:
+        f.write("a.fq\tm1\trgA\tsampleA\n")
+        f.write("a.fq\tm2\n")
+
+    def run(args):
+        out = subprocess.run([BIN] + args, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        return out.stdout
+    log = run(["single-multi", os.path.join(g2, "index"), "list.txt", "-L", "120", "-s", "4", "-b", "2"])
+    assert log.count("Finished copying index into device") == 1 and log.count("---- job") == 2
+    run(["single", os.path.join(g2, "index"), "a.fq", "-L", "120", "-s", "4", "-b", "2", "-D", "rgA", "-A", "sampleA", "-o", "s1"])
+    run(["single", os.path.join(g2, "index"), "a.fq", "-L", "120", "-s", "4", "-b", "2", "-o", "s2"])
+    strip = lambda t: [l for l in t.split("\n") if not l.startswith("@PG")]
+    assert strip(open(tmp_path / "m1.gout.1").read()) == strip(open(tmp_path / "s1.gout.1").read())
+    assert strip(open(tmp_path / "m2.gout.1").read()) == strip(open(tmp_path / "s2.gout.1").read())
+    assert "SM:sampleA" in open(tmp_path / "m1.gout.1").read()
+    f1, f2 = os.path.join(g4, "reads_1.fq"), os.path.join(g4, "reads_2.fq")
+    with open(tmp_path / "plist.txt", "w") as f:
+        f.write("%s\t%s\t100\t500\tpm1\trgP\tsP\n" % (f1, f2))
+    run(["pair-multi", os.path.join(g4, "index"), "plist.txt", "-L", "100", "-s", "3"])
+    run(["pair", os.path.join(g4, "index"), f1, f2, "-L", "100", "-s", "3", "-u", "500", "-v", "100", "-D", "rgP", "-A", "sP", "-o", "ps1"])
+    assert strip(open(tmp_path / "pm1.gout.1").read()) == strip(open(tmp_path / "ps1.gout.1").read())
