@@ -322,9 +322,9 @@ def cpu_baseline(hi, q, lens, wpq, mm, max_out, budget_s):
     import s3o
     cores = os.cpu_count() or 1
     try:                                                    # the container's CPU quota, when it has one: threads beyond it only take turns
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            cores = max(1, min(cores, -(-int(q) // int(per))))
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
     except (OSError, ValueError):
         pass
     oix = s3o.Index(host_index=hi)

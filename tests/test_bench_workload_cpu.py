@@ -32,3 +32,31 @@ def test_truth_check_on_a_repeat_rich_genome():
     bad[: len(bad) // 2] += 1
     t2 = bench.truth_check(ph, off, bad, st, mis, tpos.numpy(), tstrand.numpy(), tsub.numpy().astype(np.int64), 1000)
     assert not t2["ok"] and t2["true_place_missing"] > 0
+
+
+def test_cpu_baseline_leg_runs_with_and_without_a_cpu_quota(monkeypatch):
+    """bench.cpu_baseline (the "port" leg): a bounded sample on every core the process may use -- the hardware's, cut to the control group's quota"""
+    import builtins
+    import io
+    dev = torch.device("cpu")
+    codes, _ = bench.make_genome(400_000, 3, dev, 0.0)
+    L, n = 100, 1024
+    reads2d, _, _, _ = bench.make_reads(codes, n, L, 9, dev)
+    wpq = s3dp.word_per_query(L)
+    q = bench.pack_on_device(reads2d, wpq)
+    lens = np.full(n, L, dtype=np.uint32)
+    hi = builder.build_host_index(codes.numpy(), device="cpu")
+    real_open = builtins.open
+    for text, want in (("200000 100000\n", 2), ("max 100000\n", None), (None, None)):
+        def fake(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                if text is None:
+                    raise OSError("no such file")
+                return io.StringIO(text)
+            return real_open(path, *a, **k)
+        monkeypatch.setattr(builtins, "open", fake)
+        r = bench.cpu_baseline(hi, q, lens, wpq, 4, 1000, 2.0)
+        monkeypatch.setattr(builtins, "open", real_open)
+        assert r["value"] > 0 and r["rank_queries_per_read"] > 0
+        if want:
+            assert r["cores"] == want
