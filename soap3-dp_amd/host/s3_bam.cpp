@@ -59,9 +59,12 @@ inline uint8_t nt16(char c)
 
 bool samTextToBam(const std::vector<std::string> &refNames, const char *text, size_t n, std::string &raw, std::string &err)
 {
-    // reference name -> index; a handful of names: a small map built per call is cheap next to the lines
+    // reference name -> index: the last answer first (consecutive records mostly name the same sequence), then the map -- looked up with a key kept
+    // between records, so a lookup allocates nothing
     std::unordered_map<std::string, int> ref;
     for (size_t i = 0; i < refNames.size(); i++) ref.emplace(refNames[i], (int)i);
+    int lastId = -1;
+    std::string key;
     const char *cur = text, *const endAll = text + n;
     std::vector<uint32_t> cigar;
     while (cur < endAll) {
@@ -79,8 +82,12 @@ bool samTextToBam(const std::vector<std::string> &refNames, const char *text, si
         }
         auto refId = [&](const Field &f) -> int {
             if (f.n == 1 && f.p[0] == '*') return -1;
-            const auto it = ref.find(std::string(f.p, f.n));
-            return it == ref.end() ? -1 : it->second;
+            if (lastId >= 0 && refNames[(size_t)lastId].size() == f.n && memcmp(refNames[(size_t)lastId].data(), f.p, f.n) == 0) return lastId;
+            key.assign(f.p, f.n);
+            const auto it = ref.find(key);
+            if (it == ref.end()) return -1;
+            lastId = it->second;
+            return lastId;
         };
         const int tid = refId(rname);
         const int mtid = (rnext.n == 1 && rnext.p[0] == '=') ? tid : refId(rnext);
@@ -121,9 +128,17 @@ bool samTextToBam(const std::vector<std::string> &refNames, const char *text, si
         raw.append(qname.p, qname.n);
         raw.push_back('\0');
         for (uint32_t c : cigar) put32(raw, c);
-        for (uint32_t k = 0; k < lseq; k += 2) raw.push_back((char)(nt16(seq.p[k]) << 4 | (k + 1 < lseq ? nt16(seq.p[k + 1]) : 0)));
-        if (qual.n == 1 && qual.p[0] == '*' && lseq != 1) raw.append(lseq, (char)0xFF);
-        else for (uint32_t k = 0; k < lseq; k++) raw.push_back((char)((k < qual.n ? qual.p[k] : '!') - 33));
+        {
+            // sequence (two bases per byte) and qualities written in place
+            const size_t sb = (lseq + 1) / 2, at2 = raw.size();
+            raw.resize(at2 + sb + lseq);
+            char *o = &raw[at2];
+            for (uint32_t k = 0; k + 1 < lseq; k += 2) o[k >> 1] = (char)(nt16(seq.p[k]) << 4 | nt16(seq.p[k + 1]));
+            if (lseq & 1u) o[lseq >> 1] = (char)(nt16(seq.p[lseq - 1]) << 4);
+            o += sb;
+            if (qual.n == 1 && qual.p[0] == '*' && lseq != 1) memset(o, 0xFF, lseq);
+            else for (uint32_t k = 0; k < lseq; k++) o[k] = (char)((k < qual.n ? qual.p[k] : '!') - 33);
+        }
         // optional fields TAG:TYPE:VALUE (sam_read1's rules for the integer width, bam_import.c)
         Field t;
         while (p <= eol && nextField(p, eol, t)) {
