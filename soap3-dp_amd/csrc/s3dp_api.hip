@@ -2,6 +2,7 @@
 // k-mismatch search call and the single-end all-best ladder.  Host logic only; kernels are in
 // s3dp_kernels.hip.  No CPU fallback exists: without a HIP device every entry point fails.
 #include <hipcub/hipcub.hpp>
+#include <atomic>
 #include <chrono>
 #include "s3dp_internal.h"
 
@@ -261,6 +262,13 @@ int s3i::growOccurrences(s3_batch *b, uint64_t need)
     return S3_OK;
 }
 
+bool s3i::growRefused()
+{
+    static std::atomic<long> left{[] { const char *e = getenv("S3DP_TEST_FAIL_GROW"); return e ? atol(e) : 0L; }()};
+    if (left.load() <= 0) return false;
+    return left.fetch_sub(1) == 1;
+}
+
 size_t s3i::envSize(const char *name, size_t dflt)
 {
     const char *v = getenv(name);
@@ -292,7 +300,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
     BA(dRecs, recCap); BA(dOrdered, recCap); b->ordCap = recCap;
-    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, 8); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
+    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, S3_NUM_COUNTERS); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
     BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4); BA(dTrunk, 16); b->trunkCap = 16; BA(dItemAcc, 16); b->accCap = 16;
@@ -324,7 +332,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     for (auto &e : b->evSearch) HIPB(hipEventCreate(&e));
     b->evCe.assign(256, nullptr);
     for (auto &e : b->evCe) HIPB(hipEventCreate(&e));
-    HIPB(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    HIPB(hipMemsetAsync(b->dCounters, 0, S3_NUM_COUNTERS * 8, b->stream));
     HIPB(hipStreamSynchronize(b->stream));
 #undef HIPB
     *outp = b;
@@ -347,6 +355,7 @@ extern "C" void s3_batch_free(s3_batch *b)
 extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint32_t *readLengths, uint32_t n)
 {
     if (!b || !queries || !readLengths) return fail(S3_EINVAL, "s3_batch_upload: null argument");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     if (n > b->maxReads) return fail(S3_EINVAL, "s3_batch_upload: n exceeds batch capacity");
     for (uint32_t i = 0; i < n; i++)
         if (readLengths[i] < 16 || readLengths[i] > S3_MAX_READ_LENGTH || readLengths[i] > b->wpq * 16u)
@@ -371,6 +380,7 @@ extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint3
 extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLengths)
 {
     if (!b) return fail(S3_EINVAL, "null batch");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     HIPCHK(hipSetDevice(b->ix->dev));
     if (!seedLengths) {
         if (b->longMode) {
@@ -399,6 +409,7 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
 extern "C" int s3_batch_enable_counters(s3_batch *b, int on)
 {
     if (!b) return fail(S3_EINVAL, "null batch");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     b->counting = on != 0;
     return S3_OK;
 }
@@ -406,6 +417,7 @@ extern "C" int s3_batch_enable_counters(s3_batch *b, int on)
 // search + order + merge for `nActive` slots.  Leaves per-slot results in dTotalOcc / dWithError / dKept / ...
 int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint32_t modelMm, uint32_t maxOut)
 {
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     const int nCases = s3_num_cases((int)modelMm);
     const size_t nItems = (size_t)nActive * nCases * 2;
     SearchIn in{};
@@ -418,9 +430,9 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     {
         // S3DP_EARLY_CE=0: ranges walk their exact lookup step to the end, as the CPU path does (same results, more rank queries); n: ranges of up to n
         // suffixes leave it for check-and-extend at once (default 1)
-        static const uint32_t early = (uint32_t)envSize("S3DP_EARLY_CE", 1);                    // largest range (suffixes) handed over early
+        const uint32_t early = (uint32_t)envSize("S3DP_EARLY_CE", 1);                           // largest range (suffixes) handed over early
         in.earlyCe = b->ix->d.ltSize <= 13 ? early : 0u;                       // the list of padded keys (DevIndex::padBack / padBi) holds twelve per table
-        static const uint32_t earlyMin = (uint32_t)envSize("S3DP_EARLY_MIN", 0);
+        const uint32_t earlyMin = (uint32_t)envSize("S3DP_EARLY_MIN", 0);
         in.earlyMinI = earlyMin;
     }
     {
@@ -439,9 +451,9 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.ceGiveUp = (uint32_t)envSize("S3DP_CE_GIVE_UP", S3_CE_GIVE_UP);
     in.ceInlineMax = (uint32_t)envSize("S3DP_CE_INLINE_MAX", 128);
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
-    unsigned long long counterSnap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long counterSnap[S3_NUM_COUNTERS] = {};
     if (b->counting) {
-        HIPCHK(hipMemcpyAsync(counterSnap, b->dCounters, 64, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipMemcpyAsync(counterSnap, b->dCounters, S3_NUM_COUNTERS * 8, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     // S3DP_HEAVY=0 switches the second pass off (every read is walked by one lane: same results; reads in repeat families then hold the launch up);
@@ -481,8 +493,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
         out.counters = b->counting ? b->dCounters : nullptr;
         out.workHead = b->dWorkHead;
+        out.cutDummy = b->dFlags + 2;
         out.heavyFlags = b->dHeavyFlags; out.heavyList = b->dHeavyList; out.heavyCount = b->dHeavyCount; out.heavyIndex = b->dHeavyIndex;
         nHeavy = 0; nCount = (uint32_t)nItems;
+        b->scatterDyn = ScatterDyn{nullptr, nullptr, 0, 0};
         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
         // timing: one event pair per group of stepping launches / per check-and-extend launch (they alternate when the second pass runs in rounds)
         auto mark = [&](std::vector<hipEvent_t> &ev, uint32_t &used, bool begin) -> hipError_t {
@@ -495,7 +509,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         {
             // persistent grid: what is resident at once (4 blocks per CU), or less when several batches share the device (the streamed form: a
             // narrower grid per batch lets the kernels of two batches run side by side and fill each other's tails)
-            static const unsigned blocksPerCuEnv = (unsigned)envSize("S3DP_BLOCKS_PER_CU", 0);
+            const unsigned blocksPerCuEnv = (unsigned)envSize("S3DP_BLOCKS_PER_CU", 0);
             const unsigned blocksPerCu = blocksPerCuEnv ? blocksPerCuEnv : (b->blocksPerCu ? b->blocksPerCu : S3_V2_WAVES_PER_SIMD);
             const unsigned blocksSecond = std::min<unsigned>(blocksPerCu, S3_V2_WAVES_PER_SIMD_SECOND);     // (the second-pass instantiation holds more registers)
             // S3DP_VERBOSE=1 with counters enabled: reads, listed reads, rank queries and milliseconds of every launch of this pass (stderr)
@@ -537,7 +551,14 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     const uint64_t groups = (uint64_t)nCases * 2u;
                     if (nItems + (uint64_t)nHeavy * groups * U >= 0x7FFFFF00ull) U = 1;          // (unit indices share a word with a flag bit)
                     if (nItems + (uint64_t)nHeavy * groups * U >= 0x7FFFFF00ull) return fail(S3_EOVERFLOW, "too many heavy reads in one batch: use smaller batches");
-                    const size_t need = nItems + (size_t)nHeavy * groups * U + 1;
+                    // the unit pass (s3dp_unit.hip; S3DP_UNIT_KERNEL=v2: the searchKernelV2 instantiation it replaced) lets idle lanes adopt frames of busy ones
+                    // once the queue is empty: every adopted frame counts its records in a counter of its own behind the units' (S3DP_UNIT_NODES of them, 0: none)
+                    const bool unitKernelV2 = [] { const char *e = getenv("S3DP_UNIT_KERNEL"); return e && !strcmp(e, "v2"); }();
+                    const bool newUnitPass = U > 1 && !unitKernelV2;
+                    size_t dynCap = newUnitPass ? envSize("S3DP_UNIT_NODES", 1u << 23) : 0;
+                    const size_t nStatic = nItems + (size_t)nHeavy * groups * U + 1;
+                    if (nStatic + dynCap >= 0x7FFFFF00ull) dynCap = 0;
+                    const size_t need = nStatic + dynCap;
                     if (need > b->countCap) {
                         size_t cap = b->countCap;
                         while (cap < need) cap += cap / 2 + 1;
@@ -552,8 +573,8 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                         if (t1 + 256 > b->tempBytes) { if ((rc = bgrow(b, &b->dTemp, t1 + 256, 0))) return rc; b->tempBytes = t1 + 256; }
                         out.itemCounts = b->dItemCounts;
                     }
-                    nCount = (uint32_t)(need - 1);
-                    HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, (need - nItems) * 4, b->stream));
+                    nCount = (uint32_t)(nStatic - 1);
+                    HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, (nStatic - nItems) * 4, b->stream));
                     // the listed reads count per unit from here on
                     launchZeroListedCounts(b->dHeavyList, b->dHeavyCount, nHeavy, (uint32_t)groups, b->dItemCounts, b->stream);
                     // the trunk states: 16 B per (listed read, item, position)
@@ -579,13 +600,49 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
                     in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (the scatter decodes unit indices with them)
                     HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
+                    const unsigned blocksUnit = std::min<unsigned>(blocksPerCu, S3_UNIT_WAVES_PER_SIMD);
+                    if (newUnitPass) {
+                        // what the unit-pass kernel needs besides: the listed reads' numbers, its stack, the chains of adopted frames
+                        int rc;
+                        if (nHeavy > b->listedCap) {
+                            if ((rc = bgrow(b, &b->dListedRead, (size_t)nHeavy + nHeavy / 4 + 64, 0))) { b->listedCap = 0; return rc; }
+                            b->listedCap = (size_t)nHeavy + nHeavy / 4 + 64;
+                        }
+                        const size_t waves = unitPassMaxWaves(256u * blocksUnit);
+                        if (waves > b->unitStackWaves) {
+                            if ((rc = bgrow(b, &b->dUnitStack, waves * S3_UNIT_STACK * 64u, 0))) { b->unitStackWaves = 0; return rc; }
+                            b->unitStackWaves = waves;
+                        }
+                        const size_t nChain = (size_t)nHeavy * groups * U + 1 + dynCap;
+                        if (nChain > b->chainCap) {
+                            if ((rc = bgrow(b, &b->dChainNext, nChain + nChain / 4, 0))) { b->chainCap = 0; return rc; }
+                            b->chainCap = nChain + nChain / 4;
+                        }
+                        if (dynCap > b->dynCap) {
+                            b->dynCap = 0;
+                            if ((rc = bgrow(b, &b->dDynOwner, dynCap, 0)) || (rc = bgrow(b, &b->dDynLocal, dynCap, 0))) return rc;
+                            b->dynCap = dynCap;
+                        }
+                        if (!b->dDynUsed && (rc = balloc(b, &b->dDynUsed, 4))) return rc;
+                        HIPCHK(hipMemsetAsync(b->dChainNext, 0, ((size_t)nHeavy * groups * U + 1) * 4, b->stream));
+                        HIPCHK(hipMemsetAsync(b->dDynUsed, 0, 4, b->stream));
+                        out.listedRead = b->dListedRead; out.unitStack = b->dUnitStack; out.chainNext = b->dChainNext;
+                        out.dynOwner = b->dDynOwner; out.dynLocal = b->dDynLocal; out.dynUsed = b->dDynUsed;
+                        out.dynBase = (uint32_t)nStatic; out.dynCap = (uint32_t)dynCap;
+                        launchListedReads(b->dHeavyList, b->dHeavyCount, active, b->dListedRead, nHeavy, b->stream);
+                    }
                     for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass
                         in2.unitMode = mode;
                         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-                        le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksSecond, b->stream);
+                        if (mode == 2u && newUnitPass) le = (hipError_t)launchUnitPass(b->ix->d, in2, out, 256u * blocksUnit, b->stream);
+                        else le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksSecond, b->stream);
                         if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
                         lap(mode == 1 ? "trunk pass" : "unit pass", (uint64_t)nHeavy * groups * (mode == 1 ? 1 : U));
                     }
+                    // the counters of adopted frames become part of their units' totals before anything is scanned (check-and-extend fills reserved
+                    // sequence numbers: it changes no count)
+                    if (newUnitPass && dynCap) launchUnitChains(out, (uint32_t)nItems, (uint32_t)((size_t)nHeavy * groups * U), b->stream);
+                    b->scatterDyn = ScatterDyn{b->dDynOwner, b->dDynLocal, out.dynBase, out.dynCap};
                     HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
                 }
             }
@@ -621,7 +678,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         if (rc) return rc;
         flags &= ~S3_FLAG_REC_OVERFLOW;
         HIPCHK(hipMemcpyAsync(b->dFlags, &flags, 4, hipMemcpyHostToDevice, b->stream));
-        if (b->counting) HIPCHK(hipMemcpyAsync(b->dCounters, counterSnap, 64, hipMemcpyHostToDevice, b->stream));
+        if (b->counting) HIPCHK(hipMemcpyAsync(b->dCounters, counterSnap, S3_NUM_COUNTERS * 8, hipMemcpyHostToDevice, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     b->searchLaunches++;
@@ -638,7 +695,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     }
     launchFillInvalid(b->dOrdered, b->dItemOffsets + nCount, b->ordCap, b->stream);
     launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->dHeavyFlags, b->dHeavyList, (uint32_t)nCases * 2u, in.unitBase, in.unitsPerItem,
-                  b->stream);
+                  b->scatterDyn, b->stream);
     // what the merge / decode kernels need to find a read's slice of the ordered array (kept for the decode calls that follow this pass)
     b->mergeUnitBase = in.unitBase; b->mergeUnitsPerRead = nHeavy ? (uint32_t)nCases * 2u * in.unitsPerItem : 0u;
     // the long-read list of the merge kernels shares the buffer of the heavy list, which the scatter above still reads: a second list
@@ -669,13 +726,14 @@ int s3i::checkFlags(s3_batch *b)
 extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOutputPerRead)
 {
     if (!b) return fail(S3_EINVAL, "null batch");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
     if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
     HIPCHK(hipSetDevice(b->ix->dev));
     b->searchLaunches = 0; b->evSearchUsed = 0; b->evCeUsed = 0;
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
-    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_NUM_COUNTERS * 8, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
     int rc = searchPass(b, nullptr, b->n, numMismatch, maxOutputPerRead);
     if (rc) return rc;
@@ -697,6 +755,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
 extern "C" int s3_batch_sync(s3_batch *b)
 {
     if (!b) return fail(S3_EINVAL, "null batch");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     HIPCHK(hipSetDevice(b->ix->dev));
     HIPCHK(hipStreamSynchronize(b->stream));
     return checkFlags(b);
@@ -706,6 +765,7 @@ extern "C" int s3_batch_fetch_hits(s3_batch *b, uint64_t *hitOffsets, s3_hit *hi
                                    uint64_t *nHitsOut)
 {
     if (!b || b->lastKind != 1) return fail(S3_EINVAL, "s3_batch_fetch_hits: no search result pending");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     int rc = s3_batch_sync(b);
     if (rc) return rc;
     const uint32_t n = b->n;
@@ -727,6 +787,7 @@ extern "C" int s3_batch_fetch_hits(s3_batch *b, uint64_t *hitOffsets, s3_hit *hi
 extern "C" int s3_batch_last_timing(s3_batch *b, float *totalMs, float *searchMs, uint32_t *searchLaunches)
 {
     if (!b || b->lastKind == 0) return fail(S3_EINVAL, "no timed call");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     HIPCHK(hipSetDevice(b->ix->dev));
     HIPCHK(hipStreamSynchronize(b->stream));
     float t = 0, s = 0;
@@ -747,6 +808,7 @@ extern "C" int s3_batch_last_timing(s3_batch *b, float *totalMs, float *searchMs
 extern "C" int s3_batch_last_ce_timing(s3_batch *b, float *ceMs, uint32_t *ceLaunches)
 {
     if (!b || b->lastKind == 0) return fail(S3_EINVAL, "no timed call");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     HIPCHK(hipSetDevice(b->ix->dev));
     HIPCHK(hipStreamSynchronize(b->stream));
     float s = 0;
@@ -765,6 +827,7 @@ extern "C" int s3_batch_last_ce_timing(s3_batch *b, float *ceMs, uint32_t *ceLau
 extern "C" int s3_batch_counters(s3_batch *b, s3_counters *out)
 {
     if (!b || !out) return fail(S3_EINVAL, "null argument");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     HIPCHK(hipSetDevice(b->ix->dev));
     unsigned long long c[8] = {0};
     HIPCHK(hipStreamSynchronize(b->stream));

@@ -11,6 +11,13 @@
 #define S3_V2_COUNT_BATCH 32u             // second pass: accepted candidates a unit books at a time
 #define S3_V2_REC_BLOCK 256u              // record slots a wave reserves with one atomic
 #define S3_V2_MODEL_BYTES 1104u           // sizeof(S3Model) rounded up to 16
+#define S3_UNIT_WAVES_PER_SIMD 4          // register budget of the unit-pass kernel (s3dp_unit.hip)
+#define S3_UNIT_CHUNK 64u                 // units a wave of the unit pass takes from the work queue at a time (one per lane: tested before they start)
+#define S3_UNIT_STACK 32u                 // depth-first frames per lane of the unit pass (a ring in global memory; a power of two)
+#define S3_UNIT_RDY_BYTES 1536u            // LDS per wave of the unit pass for its tested units (6 words x 64)
+#define S3_UNIT_ADOPT_IDLE 32u             // idle lanes of a wave before frames are adopted
+#define S3_UNIT_NODE_BLOCK 256u           // sub-unit counters a wave of the unit pass reserves with one atomic
+#define S3_NUM_COUNTERS 16                 // 64-bit tallies of a batch (SearchOut::counters)
 #define S3_FLAG_STACK_OVERFLOW 1u
 #define S3_FLAG_REC_OVERFLOW   2u
 #define S3_FLAG_OCC_OVERFLOW   4u
@@ -88,9 +95,22 @@ struct SearchOut {
     uint8_t            *heavyFlags; // per slot: listed for the second pass (zeroed before every first pass)
     uint32_t           *heavyList, *heavyCount;
     uint32_t           *heavyIndex; // per listed slot: its place in heavyList
+    uint32_t           *cutDummy;    // a scratch word: where a lane's cut pointer points while it has no listed read
     uint32_t           *readCut;     // second pass, per listed read: the smallest unit (item * units + position) that holds maxOut occurrences by itself
     uint32_t           *itemAcc;     // second pass, per listed read and item: occurrences its units hold for sure (sums over the items give the cut too)
     uint4              *trunkStates; // second pass: {l, r, rev l, S3_TRUNK_VALID | occurrences of the unit} at [(item * units + position) * listed reads + read]
+    // unit pass (s3dp_unit.hip)
+    const uint32_t     *listedRead;  // per listed read: its index in readsT / readLengths
+    uint4              *unitStack;   // depth-first frames: [wave of the grid][S3_UNIT_STACK][64 lanes]
+    // A lane with nothing left to take adopts the OLDEST frame of a busy lane of its wave (the subtree that lane would have searched last).  The frame's
+    // records count from zero in a counter of their own (a "node": itemCounts[dynBase + k]); chainNext links the counters in sequence order -- a node is
+    // inserted right behind the counter of the lane that gave the frame away --, dynOwner names the unit the chain started from, and unitChainKernel
+    // turns the chains into offsets (dynLocal) before the counting scatter runs.
+    uint32_t           *chainNext;   // per counter (units and nodes): the counter whose records follow (0: none)
+    uint32_t           *dynOwner;    // per node: the unit (index into itemCounts) at the head of its chain
+    uint32_t           *dynUsed;     // nodes handed out so far (may run past dynCap: the excess was never used)
+    uint32_t           *dynLocal;    // per node: where its records start inside the total of its chain (unitChainKernel)
+    uint32_t            dynBase, dynCap; // nodes count in itemCounts[dynBase + k], k < dynCap (0: no adoption)
 };
 
 struct DevHit { uint32_t a, b, meta; };       // binary-identical to s3_hit (kind, strand, nmis, cas bytes)
@@ -139,11 +159,16 @@ void launchZeroListedCounts(const uint32_t *heavyList, const uint32_t *heavyCoun
 void launchSaExpand(const DevBwt &b, const uint32_t *samples, uint32_t interval, uint32_t n, uint32_t *sa, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
 int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
+int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);     // s3dp_unit.hip; returns a hipError_t
+unsigned unitPassMaxWaves(unsigned maxBlocks);                                        // waves of the widest unit-pass grid (sizes SearchOut::unitStack)
+void launchListedReads(const uint32_t *heavyList, const uint32_t *heavyCount, const uint32_t *active, uint32_t *listedRead, uint32_t nHeavy, hipStream_t s);
+void launchUnitChains(const SearchOut &out, uint32_t unitBase, uint32_t nUnits, hipStream_t s);
 void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskRange, hipStream_t s);
 int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int
 void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s);
+struct ScatterDyn { const uint32_t *owner, *local; uint32_t base, cap; };          // the counters of adopted frames (SearchOut::dynOwner / dynLocal / dynBase / dynCap)
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,
-                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, hipStream_t s);
+                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, ScatterDyn dyn, hipStream_t s);
 void launchMergeCount(const MergeArgs &a, hipStream_t s);
 void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s);
 void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOffsets, uint32_t occBase, uint32_t occCap, uint32_t *occPos,

@@ -54,7 +54,13 @@ struct s3_batch {
     uint32_t *dLongList = nullptr, *dLongCount = nullptr;      // reads whose slice of the ordered array is walked by a whole wave (merge / decode)
     uint32_t *dItemAcc = nullptr; size_t accCap = 0;            // per listed read and item: certain occurrences (second search pass)
     uint4 *dTrunk = nullptr; size_t trunkCap = 0;              // trunk states of the second search pass
-    size_t countCap = 0;                                       // entries of dItemCounts / dItemOffsets (items + units of the listed reads + 1)
+    size_t countCap = 0;                                       // entries of dItemCounts / dItemOffsets (items + units of the listed reads + 1 + the counters of adopted frames)
+    // unit pass (s3dp_unit.hip)
+    uint32_t *dListedRead = nullptr; size_t listedCap = 0;     // per listed read: its index in readsT
+    uint4 *dUnitStack = nullptr; size_t unitStackWaves = 0;    // depth-first frames of the unit-pass grid
+    uint32_t *dChainNext = nullptr; size_t chainCap = 0;       // per unit and per adopted frame: the counter that follows
+    uint32_t *dDynOwner = nullptr, *dDynLocal = nullptr, *dDynUsed = nullptr; size_t dynCap = 0;
+    s3::ScatterDyn scatterDyn{nullptr, nullptr, 0, 0};         // of the last search pass
     uint32_t mergeUnitBase = 0, mergeUnitsPerRead = 0;         // of the last search pass (0: no read was taken apart)
     uint32_t uniformLen = 0;
     unsigned blocksPerCu = 0;                         // width of the persistent search grid (0: all that is resident at once)
@@ -84,6 +90,7 @@ struct s3_batch {
     size_t    sortItems = 0, sortTempBytes = 0;
     std::vector<void *> allocs;
     // state of the last call
+    bool failed = false;           // a buffer was lost while growing (bgrow): every later call on this batch returns S3_ENOMEM
     int lastKind = 0;              // 1 = search, 2 = align (single), 3 = align (pairs)
     uint32_t lastNumCases = 0;
     bool counting = false;
@@ -126,32 +133,51 @@ inline int balloc(s3_batch *b, T **p, size_t count)
     return S3_OK;
 }
 
-// replace a batch buffer by a larger one, keeping the first `keep` elements
+bool growRefused();                                           // s3dp_api.hip
+
+// replace a batch buffer by a larger one, keeping the first `keep` elements.  On failure the batch is left in a state every later call refuses
+// (s3_batch::failed): the callers keep their capacities next to the pointers, and a freed buffer under an old capacity would be a wild launch.
 template <class T>
 inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
 {
     void *q = nullptr;
     if (!keep) {
-        // nothing to carry over: the old buffer goes first, so that the two never stand side by side (the ordering buffer of a batch of reads from
-        // repeat families is tens of gigabytes)
+        // nothing to carry over.  Try to allocate next to the old buffer; when that does not fit (the ordering buffer of a batch of reads from repeat
+        // families is tens of gigabytes) the old buffer goes first.
         hipError_t e0 = hipStreamSynchronize(b->stream);
-        if (e0 == hipSuccess) e0 = hipFree(*p);
-        if (e0 != hipSuccess) return fail(S3_EHIP, std::string("grow (free): ") + hipGetErrorString(e0));
-        for (auto &a : b->allocs) if (a == (void *)*p) a = nullptr;
-        *p = nullptr;
-        e0 = hipMalloc(&q, newCount * sizeof(T));
-        if (e0 != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch grow, ") + std::to_string(newCount * sizeof(T) >> 20) + " MB): " + hipGetErrorString(e0));
-        b->allocs.push_back(q);
+        if (e0 != hipSuccess) return fail(S3_EHIP, std::string("grow (sync): ") + hipGetErrorString(e0));
+        const bool refuse = growRefused();                        // (tests: S3DP_TEST_FAIL_GROW=n makes the n-th growth of the process find the device full)
+        e0 = refuse ? hipErrorOutOfMemory : hipMalloc(&q, newCount * sizeof(T));
+        if (e0 != hipSuccess) {
+            (void)hipGetLastError();
+            q = nullptr;
+            e0 = hipFree(*p);
+            if (e0 != hipSuccess) { b->failed = true; return fail(S3_EHIP, std::string("grow (free): ") + hipGetErrorString(e0)); }
+            for (auto &a : b->allocs) if (a == (void *)*p) a = nullptr;
+            *p = nullptr;
+            e0 = refuse ? hipErrorOutOfMemory : hipMalloc(&q, newCount * sizeof(T));
+            if (e0 != hipSuccess) {
+                (void)hipGetLastError();
+                b->failed = true;                                     // the old buffer is gone and there is no new one
+                return fail(S3_ENOMEM, std::string("hipMalloc(batch grow, ") + std::to_string(newCount * sizeof(T) >> 20) + " MB): " + hipGetErrorString(e0) +
+                                           "; the batch is unusable from here on: free it and create a smaller one");
+            }
+            b->allocs.push_back(q);
+            *p = (T *)q;
+            return S3_OK;
+        }
+        bool placed = false;
+        for (auto &a : b->allocs) if (*p && a == (void *)*p) { a = q; placed = true; }
+        if (!placed) b->allocs.push_back(q);
+        (void)hipFree(*p);
         *p = (T *)q;
         return S3_OK;
     }
     hipError_t e = hipMalloc(&q, newCount * sizeof(T));
-    if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch grow, ") + std::to_string(newCount * sizeof(T) >> 20) + " MB): " + hipGetErrorString(e));
-    if (keep) {
-        e = hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, b->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-        if (e != hipSuccess) { (void)hipFree(q); return fail(S3_EHIP, std::string("grow copy: ") + hipGetErrorString(e)); }
-    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(S3_ENOMEM, std::string("hipMalloc(batch grow, ") + std::to_string(newCount * sizeof(T) >> 20) + " MB): " + hipGetErrorString(e)); }
+    e = hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) { (void)hipFree(q); return fail(S3_EHIP, std::string("grow copy: ") + hipGetErrorString(e)); }
     for (auto &a : b->allocs) if (a == (void *)*p) a = q;
     (void)hipFree(*p);
     *p = (T *)q;

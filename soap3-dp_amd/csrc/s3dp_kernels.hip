@@ -96,7 +96,7 @@ void launchSaExpand(const DevBwt &b, const uint32_t *samples, uint32_t interval,
 // ordering: records -> CSR by item (counting scatter; offsets = exclusive scan of itemCounts)
 // ---------------------------------------------------------------------------------------------
 __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered,
-                              const uint8_t *heavyFlags, const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem)
+                              const uint8_t *heavyFlags, const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, ScatterDyn dyn)
 {
     uint32_t n = *recCount;
     if (n > recCap) n = recCap;
@@ -107,8 +107,16 @@ __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint3
         if (r.x & S3_REC_PASS2) {
             // written by the second search pass (or by check-and-extend of its tasks): counted per unit; downstream the record carries its ITEM again
             at = r.x & ~S3_REC_PASS2;
+            uint32_t inChain = 0;
+            if (dyn.cap && at >= dyn.base) {
+                // counted by an adopted frame (s3dp_unit.hip): its records sit inside the slice of the unit its chain started from
+                inChain = dyn.local[at - dyn.base];
+                at = dyn.owner[at - dyn.base];
+            }
             const uint32_t unit = at - unitBase;
             r.x = heavyList[unit / (groups * unitsPerItem)] * groups + (unit / unitsPerItem) % groups;
+            ordered[itemOffsets[at] + inChain + (r.y & 0xFFFFFFu)] = r;
+            continue;
         } else if (heavyFlags[r.x / groups]) continue;                         // stale: the second pass searched this read again
         ordered[itemOffsets[at] + (r.y & 0xFFFFFFu)] = r;
     }
@@ -536,9 +544,9 @@ void launchZeroListedCounts(const uint32_t *heavyList, const uint32_t *heavyCoun
 }
 
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,
-                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, hipStream_t s)
+                   const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, ScatterDyn dyn, hipStream_t s)
 {
-    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, heavyFlags, heavyList, groups, unitBase, unitsPerItem);
+    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, heavyFlags, heavyList, groups, unitBase, unitsPerItem, dyn);
 }
 
 void launchMergeCount(const MergeArgs &a, hipStream_t s)

@@ -202,6 +202,7 @@ extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t
     if (reportType < 1 || reportType > 4) return fail(S3_EINVAL, "reportType must be 1..4");
     const bool bestMode = reportType >= 3, allValid = reportType == 1;
     if (!b) return fail(S3_EINVAL, "null batch");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
     if (maxOutputPerRead == 0 || maxOutputPerRead > 0xFFFFFFu) return fail(S3_EINVAL, "maxOutputPerRead must be 1..16777215");
     HIPCHK(hipSetDevice(b->ix->dev));
@@ -210,7 +211,7 @@ extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t
     b->occUsed = 0;
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
-    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_NUM_COUNTERS * 8, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
     HIPCHK(hipMemsetAsync(b->dPhase, 0, n, b->stream));
     HIPCHK(hipMemsetAsync(b->dFinalWithError, 0, (size_t)n * 32, b->stream));
@@ -281,6 +282,7 @@ extern "C" int s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *
                                          uint8_t *occMis, size_t occCap, uint64_t *nOccOut)
 {
     if (!b || b->lastKind != 2) return fail(S3_EINVAL, "s3_batch_fetch_alignments: no alignment result pending");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     int rc = s3_batch_sync(b);
     if (rc) return rc;
     const uint32_t n = b->n;
@@ -366,6 +368,7 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
                                    uint32_t peMaxOutputPerPair)
 {
     if (!b) return fail(S3_EINVAL, "null batch");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     if (reportType < 1 || reportType > 4) return fail(S3_EINVAL, "reportType must be 1..4");
     if (numMismatch > S3_MAX_MISMATCH) return fail(S3_EINVAL, "numMismatch must be 0..4");
     if (maxHitsPerEnd == 0 || maxHitsPerEnd > 0xFFFFFFu) return fail(S3_EINVAL, "maxHitsPerEnd must be 1..16777215");
@@ -381,7 +384,7 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
     b->xaUsed = 0;
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
-    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, 64, b->stream));
+    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_NUM_COUNTERS * 8, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
     HIPCHK(hipMemsetAsync(b->dPhase, 0, n ? n : 1, b->stream));
     HIPCHK(hipMemsetAsync(b->dFinalWithError, 0, (size_t)(n ? n : 1) * 32, b->stream));
@@ -500,6 +503,7 @@ extern "C" int s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t
                                     uint64_t *occOffsets, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis, size_t occCap, uint64_t *nOccOut)
 {
     if (!b || b->lastKind != 3) return fail(S3_EINVAL, "s3_batch_fetch_pairs: no paired-end result pending");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     int rc = s3_batch_sync(b);
     if (rc) return rc;
     static_assert(sizeof(s3_pair_result) == sizeof(DevPair) && sizeof(s3_pair_xa) == sizeof(DevPairXa), "pair layouts");
@@ -537,6 +541,7 @@ extern "C" int s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t
 extern "C" int s3_batch_fetch_pair_origins(s3_batch *b, uint8_t *fromSaRange, size_t cap)
 {
     if (!b || b->lastKind != 3 || !fromSaRange) return fail(S3_EINVAL, "s3_batch_fetch_pair_origins: no paired-end result pending");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     int rc = s3_batch_sync(b);
     if (rc) return rc;
     uint32_t total = 0;

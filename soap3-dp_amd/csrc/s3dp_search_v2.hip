@@ -29,69 +29,9 @@
 #include <stdint.h>
 #include "s3dp_device.h"
 #include "s3dp_model.h"
+#include "s3dp_search_common.h"
 
 namespace s3 {
-
-namespace v2 {
-
-enum : uint32_t { ST_DONE = 0, ST_STEP = 1, ST_TRUNK = 2, ST_LOAD = 4, ST_LT = 5, ST_KEYS = 6, ST_RESUME = 7, ST_CE_SA = 8, ST_CE_TEXT = 9 };
-constexpr uint32_t ID_NONE = 0x7FFFFFFFu;
-constexpr uint32_t ID_TEXT = 0x40000000u;                 // cooperative line ids: bit 31 = reverse BWT, ID_TEXT | k = 64-byte line k of the packed text
-constexpr int STACK = 20;
-
-struct Frame { uint32_t fl, fr, rl, meta; };        // rr = rl + (fr - fl);  meta = s | i << 3 | ins << 14 | occ << 17
-
-__device__ __forceinline__ uint64_t hiMask(uint32_t nChars) { return nChars >= 32 ? ~0ULL : (nChars == 0 ? 0ULL : (~0ULL << (64 - 2 * nChars))); }
-__device__ __forceinline__ uint64_t loMask(uint32_t nChars) { return nChars >= 32 ? ~0ULL : ((1ULL << (2 * nChars)) - 1ULL); }
-__device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
-__device__ __forceinline__ uint32_t pairRev(uint32_t x)   // reverse the order of the 16 2-bit characters of a word
-{
-    x = __brev(x);
-    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
-}
-
-// mask of the first n (0..16) characters of an MSB-first word, on the even bit of every character
-__device__ __forceinline__ uint32_t topChars(uint32_t n)
-{
-    const uint32_t t = 2u * n;
-    return (t >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> t)) & 0x55555555u;
-}
-
-// Rank of all four symbols at index i from the line of sample k = (i + 63) >> 7 (layout: relayoutKernel, s3dp_kernels.hip):
-//   occ  = line[0]; half = the two words of the half-block that hold the counted characters; sub = line[3].x (before) / .y (after).
-// d = |i - 128 k| <= 64 characters next to the sample are counted; the first 32 of them come precounted in `sub`, so at most two
-// words go through the popcount.  32-bit VALU only.
-struct RankSel { uint32_t d, n; bool fwd, far; };     // far: d > 32 -> words z,w of the half + precounts, else words x,y
-__device__ __forceinline__ RankSel rankSel(uint32_t i)
-{
-    const uint32_t p = ((i + 63u) >> 7) << 7;
-    RankSel r;
-    r.fwd = i > p;
-    r.d = r.fwd ? i - p : p - i;
-    r.far = r.d > 32u;
-    r.n = r.far ? r.d - 32u : r.d;
-    return r;
-}
-__device__ __forceinline__ uint4 rankFromWords(const RankSel &q, uint4 occ, uint32_t wa, uint32_t wb, uint32_t sub)
-{
-    const uint32_t n0 = q.n < 16u ? q.n : 16u, n1 = q.n - n0;
-    const uint32_t m0 = topChars(n0), m1 = topChars(n1);
-    const uint32_t la = wa & m0, ha = (wa >> 1) & m0, ba = la & ha;
-    const uint32_t lb = wb & m1, hb = (wb >> 1) & m1, bb = lb & hb;
-    uint32_t c3 = __popc(ba) + __popc(bb);
-    uint32_t c2 = __popc(ha ^ ba) + __popc(hb ^ bb);
-    uint32_t c1 = __popc(la ^ ba) + __popc(lb ^ bb);
-    if (q.far) { c1 += sub & 0xFFu; c2 += (sub >> 8) & 0xFFu; c3 += (sub >> 16) & 0xFFu; }
-    const uint32_t c0 = q.d - c1 - c2 - c3;
-    uint4 v = occ;
-    if (q.fwd) { v.x += c0; v.y += c1; v.z += c2; v.w += c3; }
-    else { v.x -= c0; v.y -= c1; v.z -= c2; v.w -= c3; }
-    return v;
-}
-
-struct Range { uint32_t fl, fr, rl, rr; };
-
-}  // namespace v2
 
 using namespace v2;
 
@@ -184,7 +124,7 @@ searchKernelV2(DevIndex ix, SearchIn in, SearchOut out)
     // pass reads that word along with its rank lines and stops when it finds itself behind it -- what the single lane of an item-wise walk gets from
     // its running total.
     uint32_t unitInRead = 0;
-    const uint32_t *cutPtr = (const uint32_t *)ix.pac;
+    const uint32_t *cutPtr = out.cutDummy;                                  // (a word of the batch nobody reads: a stray atomicMin must never land in the index)
     uint32_t strand = 0;
     Frame stack[STACK];
     int sp = 0;
@@ -812,6 +752,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
             // second-pass records (units that gave up verifying their candidates themselves) count in unit space:
             // unit = heavy read * groups * U + item * U + position
             const uint32_t U = in.unitsPerItem;
+            if (out.dynCap && item >= out.dynBase) item = out.dynOwner[item - out.dynBase];      // counted by an adopted frame: the unit its chain started from
             const uint32_t unit = item - in.unitBase;
             slotOf = out.heavyList[unit / (groups * U)];
             item = slotOf * groups + (unit / U) % groups;

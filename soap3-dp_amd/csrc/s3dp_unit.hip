@@ -1,0 +1,710 @@
+// s3dp_unit.hip -- the UNIT PASS of the 2BWT k-mismatch search for gfx950: the listed ("heavy") reads of a search pass, taken apart.
+//
+// What a unit is, and why the units of an item in position order ARE the CPU path's record order, is told in s3dp_search_v2.hip (which still runs the
+// first pass and the trunk pass).  This file is the kernel that searches the units: one lane per (listed read, item, position p of the item's first
+// mismatch).  It used to be an instantiation of searchKernelV2 and carried everything that kernel can do -- read loading for both strands, lookup
+// tables, key building, trunk bookkeeping, ten unconditional loads per lane and trip, the depth-first stack in scratch memory whose pops stalled
+// the wave in the middle of a trip -- at 153 registers and three waves per SIMD, and a launch lasted as long as its longest unit.  Here:
+//
+//   * a wave takes 64 queue slots at a time and TESTS them before any lane starts one: the slots of a chunk are consecutive listed reads at one
+//     (item, position), so their trunk states, cut words and read numbers are three coalesced loads; units without a trunk state or behind their
+//     read's cut (half of them) never occupy a lane.  The queue is worked through a two-stage pipeline inside the trips' single wait: the atomic
+//     on the queue head one trip, the loads of the chunk the next;
+//   * a unit needs ONE strand of its read in LDS (a single trip);
+//   * the step descriptor of the model step a lane is in sits in four registers;
+//   * the depth-first stack is a ring of frames in global memory, [frame][lane] so that the lanes of a wave write whole lines, with the TOP frame
+//     always in registers: a push is a store nobody waits for, a pop takes the register copy, and the frame below it is fetched with the next
+//     trip's rank lines;
+//   * the read's cut word is read when a lane pops (and while it verifies candidates), not on every trip;
+//   * occurrences are booked S3_V2_COUNT_BATCH at a time (the evaluation of the cut reads up to groups + U words);
+//   * loads are issued only by the lanes whose state needs them;
+//   * and the tail: once the queue is empty, an idle lane ADOPTS the oldest frame of a busy lane of its wave -- the subtree that lane would have
+//     searched last.  Its records count from zero in a counter of their own that is linked right behind the giver's counter (SearchOut::chainNext);
+//     unitChainKernel turns the chains into offsets and the counting scatter places the records exactly where the single lane would have put
+//     them.  A unit of ten thousand trips becomes a few hundred trips of a whole wave; the order of the records does not change.
+//
+// Results are bit-identical to the old unit pass (S3DP_UNIT_KERNEL=v2 runs that one) and so to the CPU path: BGS-HostAlgnmtAlgo2.cpp:933-1071
+// (order), :86-169 (check-and-extend), DV-Kernel.cu:437-955 (what the reference's own kernels do per step).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <algorithm>
+#include "s3dp_device.h"
+#include "s3dp_model.h"
+#include "s3dp_search_common.h"
+
+namespace s3 {
+
+using namespace v2;
+
+namespace unit {
+enum : uint32_t { U_IDLE = 0, U_STEP = 1, U_LOAD = 2, U_ADOPT = 3, U_POPWAIT = 4, U_CE_SA = 5, U_CE_TEXT = 6, U_RESUME = 7, U_DONE = 8 };
+
+// the model step a lane is in, as the five words of S3Step with the check-and-extend threshold moved into the (unused) type byte
+struct StepC {
+    uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ int start() const { return (int)(int16_t)(w0 & 0xFFFFu); }
+    __device__ __forceinline__ int end() const { return (int)w0 >> 16; }
+    __device__ __forceinline__ int ceStart() const { return (int)(int16_t)(w1 & 0xFFFFu); }
+    __device__ __forceinline__ int ceEnd() const { return (int)w1 >> 16; }
+    __device__ __forceinline__ int lm0() const { return (int)(int16_t)(w2 & 0xFFFFu); }
+    __device__ __forceinline__ int len() const { return (int)w2 >> 16; }
+    __device__ __forceinline__ int dir() const { return (int)(int8_t)(w3 & 0xFFu); }
+    __device__ __forceinline__ int ceThr() const { return (int)((w3 >> 8) & 0xFFu); }
+    __device__ __forceinline__ int minErr() const { return (int)((w3 >> 16) & 0xFFu); }
+    __device__ __forceinline__ int maxErr() const { return (int)(w3 >> 24); }
+};
+__device__ __forceinline__ StepC packStep(const uint32_t *p)
+{
+    StepC c;
+    c.w0 = p[0]; c.w1 = p[1]; c.w2 = p[2];
+    c.w3 = (p[3] & 0xFFFF00FFu) | ((p[4] & 0xFFu) << 8);
+    return c;
+}
+}  // namespace unit
+
+using namespace unit;
+
+// COUNT: with the statistics of s3_batch_enable_counters (rank queries, trips, longest unit ...): ten more registers, measurement runs only
+template <bool UNIFORM, bool COUNT>
+__global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_UNIT_WAVES_PER_SIMD)
+unitKernel(DevIndex ix, SearchIn in, SearchOut out)
+{
+    extern __shared__ __align__(16) unsigned char shmem[];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t wpq = in.wpqLoad;                                        // words per orientation in readsT
+    const uint32_t wl = in.wLds;                                            // words of the searched strand kept in LDS
+    const uint32_t waveBytes = 4096u + S3_UNIT_RDY_BYTES + wl * 256u;
+    unsigned char *wbase = shmem + S3_V2_MODEL_BYTES + wv * waveBytes;
+    uint4 *stage = (uint4 *)wbase;                                          // [64 owners][4 x 16 B]; between trips: the mailboxes of an adoption
+    uint32_t *rdy = (uint32_t *)(wbase + 4096u);                            // tested units waiting for a lane: rdy[field * 64 + k], k < rdyCount
+    uint32_t *ro = (uint32_t *)(wbase + 4096u + S3_UNIT_RDY_BYTES);         // the unit's strand of its read, MSB first: ro[w * 64 + lane]
+    uint32_t *myStage32 = (uint32_t *)(stage + lane * 4u);
+
+    if (UNIFORM) {
+        const uint32_t *src = (const uint32_t *)&in.models[in.uniformLen];
+        for (uint32_t k = threadIdx.x; k < sizeof(S3Model) / 4; k += blockDim.x) ((uint32_t *)shmem)[k] = src[k];
+        __syncthreads();
+    }
+
+    const uint32_t groups = (uint32_t)in.nCases * 2u;
+    const uint32_t nListed = *in.slotCount;
+    const uint32_t U = in.unitsPerItem;
+    const uint32_t nSlots = nListed * groups * U;                           // (< 2^31: s3dp_api.hip)
+    uint4 *stk = out.unitStack + (size_t)(blockIdx.x * (S3_SEARCH_BLOCK / 64u) + wv) * S3_UNIT_STACK * 64u;     // frame d of lane k: stk[(d % S3_UNIT_STACK) * 64 + k]
+    const uint32_t giveUp = in.ceGiveUp < 0xFFFFu ? in.ceGiveUp : 0xFFFFu, inlineMax = in.ceInlineMax < 0xFFFFu ? in.ceInlineMax : 0xFFFFu;
+
+    // ---- statistics (COUNT) ----
+    uint32_t nRank = 0, nSaL = 0, nCeL = 0, nCutSkip = 0, nCutMid = 0, unitTrips = 0, maxUnitTrips = 0, nAdopt = 0;
+    unsigned long long laneTrips = 0;
+
+    // ---- per-lane state ----
+    uint32_t state = U_IDLE;
+    uint32_t fl = 0, fr = 0, rl = 0;                                        // the range (rr = rl + fr - fl)
+    int s = 0, i = 0, ins = 0, occ = 0;
+    StepC sc = {0, 0, 0, 0};
+    int Li = UNIFORM ? (int)in.uniformLen : 0;
+    uint32_t subN = 0;                                                      // item (case * 2 + strand) | number of steps of the case << 8
+    uint32_t listed = 0, unitInRead = 0;
+    uint32_t cntIdx = 0, seq = 0, total = 0;
+    bool first = false;                                                     // the unit's first step: only the mismatch children at its position
+    uint32_t sp = 0, sb = 0;                                                // frames [sb, sp) of the ring are the lane's stack
+    uint4 tos = make_uint4(0, 0, 0, 0);                                     // copy of frame sp - 1 ...
+    bool tosValid = false;                                                  // ... when this is set
+    uint32_t aux = 0;                                                       // U_LOAD: the read's number in readsT; U_ADOPT: where the frame lies
+    uint32_t loadOff = 0;
+    // check-and-extend by the lane: candidates [ceL + ceK, ceL + ceN) of the suffix array are left; of the current one: suffix-array value, text position
+    // of the read's first character, and (packed) the model step being compared, characters of it done, mismatches so far
+    uint32_t ceL = 0, ceSa = 0, ceRp = 0;
+    uint32_t ceNK = 0;                                                      // ceN | ceK << 8
+    uint32_t ceWhere = 0;                                                   // ceT | ceII << 3 | ceIns << 14 | ceAcc << 17
+    uint32_t ceProg = 0;                                                    // ceOff | ceMm << 16
+    uint32_t ceHist = 0;                                                    // rejected candidates in a row | occurrences verified by the lane << 16
+    uint32_t pendMeta = 0, pendA = 0, pendB = 0;
+    uint32_t countPending = 0;
+    // ---- wave-uniform ----
+    uint32_t recCur = 0, recEnd = 0;                                        // reserved record block
+    uint32_t nodeCur = 0, nodeEnd = 0;                                      // reserved sub-unit counters
+    bool queueEmpty = false, basePending = false, noNodes = out.dynCap == 0u;
+    uint32_t pendBase = 0;
+    uint32_t rdyCount = 0, rdyTaken = 0;
+
+#define casIdx (((subN) & 0xFFu) >> 1)
+#define subIdx ((subN) & 0xFFu)
+#define nSteps ((int)((subN) >> 8))
+    auto stepPtr = [&](int k) -> const uint32_t * {
+        if constexpr (UNIFORM) return (const uint32_t *)&((const S3Model *)shmem)->cs[casIdx].st[k];
+        else return (const uint32_t *)&in.models[Li].cs[casIdx].st[k];
+    };
+    auto stepAt = [&](int k) -> S3Step {
+        if constexpr (UNIFORM) return ((const S3Model *)shmem)->cs[casIdx].st[k];
+        else return in.models[Li].cs[casIdx].st[k];
+    };
+    auto oword = [&](uint32_t w) -> uint32_t { return w < wl ? ro[w * 64u + lane] : 0u; };
+    auto readChar = [&](int pos) -> uint32_t { return (ro[((uint32_t)pos >> 4) * 64u + lane] >> (30u - 2u * ((uint32_t)pos & 15u))) & 3u; };
+    auto readWindow = [&](int p0) -> uint32_t {
+        const uint32_t w = (uint32_t)p0 >> 4, sh = ((uint32_t)p0 & 15u) * 2u;
+        const uint32_t a = oword(w), b2 = oword(w + 1u);
+        return sh ? (a << sh) | (b2 >> (32u - sh)) : a;
+    };
+    auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
+        pendMeta = 0x80000000u | seq | (kind << 24) | (nmis << 25);
+        pendA = a; pendB = b;
+        seq++;
+    };
+    auto push = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t meta) {
+        const uint4 f = make_uint4(a, b, c, meta);
+        stk[(sp & (S3_UNIT_STACK - 1u)) * 64u + lane] = f;
+        sp++;
+        tos = f; tosValid = true;
+    };
+    auto loadStepCache = [&]() { sc = packStep(stepPtr(s)); };
+
+    // advance without memory until the lane needs ranks / SA / text / its next frame, or its unit is finished
+    auto settle = [&](bool needPop) {
+        for (;;) {
+            if (total >= in.maxOut) { state = U_DONE; return; }
+            if (needPop) {
+                if (sp == sb) { state = U_DONE; return; }
+                if (!tosValid) { state = U_POPWAIT; return; }               // the frame comes with the next trip's loads
+                fl = tos.x; fr = tos.y; rl = tos.z;
+                const uint32_t m = tos.w;
+                s = (int)(m & 7u); i = (int)((m >> 3) & 0x7FFu); ins = (int)((m >> 14) & 7u); occ = (int)((m >> 17) & 7u);
+                sp--; tosValid = false;
+                needPop = false;
+                if (s < nSteps) loadStepCache();
+            }
+            if (s >= nSteps) {                                               // SRA_STEP_TYPE_COMPLETE
+                uint32_t l = fl, rr_ = fr;
+                if (rr_ >= l) {
+                    if (pendMeta >> 31) { state = U_RESUME; return; }        // one record per lane and trip: this frame waits for the next trip
+                    if (total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - total - 1u;
+                    emit(0, l, rr_, (uint32_t)(ins + occ));
+                    total += rr_ - l + 1u;
+                    countPending += rr_ - l + 1u;
+                }
+                needPop = true;
+                continue;
+            }
+            const bool exact = ins >= sc.maxErr();
+            int lenEff = sc.len();
+            if (!exact && sc.minErr() > ins + 1) lenEff -= sc.minErr() - ins - 1;
+            const bool alive = fl <= fr;
+            if (i < lenEff && alive) {
+                const int pos = sc.start() + sc.dir() * i;
+                if ((fr - fl) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd()) {
+                    if ((ceHist & 0xFFFFu) < giveUp) { ceL = fl; ceNK = fr - fl + 1u; state = U_CE_SA; return; }      // the lane verifies them itself
+                    if (pendMeta >> 31) { state = U_RESUME; return; }
+                    pendMeta = 0x80000000u | seq | S3_REC_TASK;
+                    pendA = fl;
+                    pendB = (fr - fl) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+                    seq += fr - fl + 1u;
+                    needPop = true;
+                    continue;
+                }
+                state = U_STEP;
+                return;
+            }
+            if (ins >= sc.minErr() && alive) {
+                occ += ins; ins = 0; s++; i = 0;
+                if (s < nSteps) loadStepCache();
+                continue;
+            }
+            needPop = true;
+        }
+    };
+
+    for (;;) {
+        // ---------- retire finished units (their occurrences were booked at the end of the trip that finished them) ----------
+        if (state == U_DONE) {
+            if (seq != 0u || cntIdx >= out.dynBase) out.itemCounts[cntIdx] = seq;      // (a unit that wrote nothing leaves the counter alone: the trunk lane may own it)
+            state = U_IDLE;
+        }
+        // ---------- idle lanes take tested units ----------
+        unsigned long long idleMask = __ballot(state == U_IDLE);
+        if (idleMask && rdyTaken < rdyCount) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+            const uint32_t e = rdyTaken + rank, avail = rdyCount - rdyTaken;
+            if (state == U_IDLE && rank < avail) {
+                fl = rdy[e]; fr = rdy[64u + e]; rl = rdy[128u + e];
+                listed = rdy[192u + e]; unitInRead = rdy[256u + e]; aux = rdy[320u + e];
+                const uint32_t sub = unitInRead / U, p = unitInRead - sub * U;
+                const uint32_t cas = sub >> 1;
+                subN = sub | ((in.nStepsPacked >> (3u * cas)) & 7u) << 8;
+                s = (int)((in.sStarPacked >> (3u * cas)) & 7u);
+                cntIdx = in.unitBase + listed * groups * U + unitInRead;
+                first = p + 1u != U;
+                i = (int)p;                                                 // (the unit without a mismatch in this step: behind the step's last position, set when the step is known)
+                ins = 0; occ = 0; seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
+                ceHist = 0; countPending = 0;
+                if constexpr (COUNT) unitTrips = 0;
+                loadOff = 0;
+                state = U_LOAD;
+            }
+            const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+            rdyTaken += nIdle < avail ? nIdle : avail;
+            idleMask = __ballot(state == U_IDLE);
+        }
+        // ---------- the queue: what this trip does for it ----------
+        const bool stageA = !queueEmpty && !basePending;                    // take the next chunk's number (lane 0's atomic rides with this trip's loads)
+        const bool stageB = basePending && rdyTaken >= rdyCount;            // load and test the chunk
+        if (queueEmpty && !basePending && rdyTaken >= rdyCount && idleMask) {
+            if (idleMask == ~0ULL) break;                                   // nothing left anywhere
+            // ---------- adoption: idle lanes take the oldest frames of busy lanes ----------
+            // (only once half of the wave is idle: a lane that finishes a little before its neighbours is no tail, and every adopted frame takes a counter)
+            const bool canGive = state != U_IDLE && state != U_LOAD && state != U_ADOPT && sp > sb;
+            const unsigned long long giveMask = __ballot(canGive);
+            uint32_t nPairs = (uint32_t)__popcll(giveMask);
+            const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+            if (nIdle < nPairs) nPairs = nIdle;
+            if (nIdle < S3_UNIT_ADOPT_IDLE) nPairs = 0;
+            if (nPairs && !noNodes) {
+                if (nodeCur + nPairs > nodeEnd) {
+                    // (what is left of the old block is dropped: a few counters nobody uses)
+                    uint32_t b0 = 0;
+                    if (lane == 0) b0 = atomicAdd(out.dynUsed, S3_UNIT_NODE_BLOCK);
+                    b0 = (uint32_t)__shfl((int)b0, 0);
+                    nodeCur = b0 < out.dynCap ? b0 : out.dynCap;
+                    nodeEnd = b0 + S3_UNIT_NODE_BLOCK < out.dynCap ? b0 + S3_UNIT_NODE_BLOCK : out.dynCap;
+                    if (nodeEnd < nodeCur) nodeEnd = nodeCur;
+                    if (nodeEnd == nodeCur) noNodes = true;                   // the counters are used up: from here on every lane finishes what it has
+                }
+                if (nodeEnd - nodeCur < nPairs) nPairs = nodeEnd - nodeCur;
+            } else nPairs = 0;
+            if (nPairs) {
+                const uint32_t gRank = __builtin_amdgcn_mbcnt_hi((uint32_t)(giveMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)giveMask, 0u));
+                const uint32_t iRank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+                if (canGive && gRank < nPairs) {
+                    const uint32_t node = nodeCur + gRank, newCnt = out.dynBase + node;
+                    // the new counter follows the giver's: whatever the giver still finds comes before the frame it gives away.  (Only the lane that
+                    // owns a counter writes its link, so it reads back what it wrote.)
+                    uint32_t *myLink = out.chainNext + (cntIdx - in.unitBase);
+                    const uint32_t after = *myLink;
+                    out.chainNext[newCnt - in.unitBase] = after;
+                    *myLink = newCnt;
+                    out.dynOwner[node] = in.unitBase + listed * groups * U + unitInRead;
+                    stage[gRank * 2u] = make_uint4(lane | (sb & (S3_UNIT_STACK - 1u)) << 8, listed, unitInRead, subN);
+                    stage[gRank * 2u + 1u] = make_uint4(newCnt, (uint32_t)Li, 0u, 0u);
+                    sb++;
+                    if (sb == sp) tosValid = false;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (state == U_IDLE && iRank < nPairs) {
+                    const uint4 m0 = stage[iRank * 2u], m1 = stage[iRank * 2u + 1u];
+                    const uint32_t giver = m0.x & 63u;
+                    aux = ((m0.x >> 8) & (S3_UNIT_STACK - 1u)) * 64u + giver;
+                    listed = m0.y; unitInRead = m0.z; subN = m0.w;
+                    cntIdx = m1.x;
+                    if constexpr (!UNIFORM) Li = (int)m1.y;
+                    for (uint32_t w = 0; w < wl; w++) ro[w * 64u + lane] = ro[w * 64u + giver];
+                    first = false;
+                    seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
+                    ceHist = 0; countPending = 0;
+                    if constexpr (COUNT) { unitTrips = 0; nAdopt++; }
+                    state = U_ADOPT;
+                }
+                nodeCur += nPairs;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+
+        // ---------- what does this lane need?  Addresses only: every lane issues the same loads, back to back, with no branch between them (a load
+        // inside a branch makes the compiler wait for it at the join); a lane that needs nothing reads a cache-hot dummy ----------
+        uint32_t idA = ID_NONE, iL = 0, iR = 0;
+        bool needB = false;
+        int dir = 0;
+        const uint4 *dummy16 = (const uint4 *)ix.pac;
+        const uint4 *aP0 = dummy16, *aP1 = dummy16, *aPT = dummy16;
+        const uint32_t *aD0 = ix.pac, *aCut = ix.pac;
+        if (state == U_STEP) {
+            dir = sc.dir();
+            const uint32_t inv = dir < 0 ? ix.fwd.inverseSa0 : ix.rev.inverseSa0;
+            const uint32_t rr = rl + (fr - fl);
+            iL = dir < 0 ? fl : rl;
+            iR = (dir < 0 ? fr : rr) + 1u;
+            iL -= (iL > inv);
+            iR -= (iR > inv);
+            const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
+            idA = kL | (dir < 0 ? 0u : 0x80000000u);
+            needB = kR != kL;
+            if (needB) {
+                const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
+                const bool fw = iR > (kR << 7);
+                aP0 = line;
+                aP1 = line + (fw ? 2 : 1);
+                aD0 = (const uint32_t *)(line + 3) + (fw ? 1 : 0);
+            }
+        } else if (state == U_CE_TEXT) {
+            const int ceT = (int)(ceWhere & 7u), ceII = (int)((ceWhere >> 3) & 0x7FFu);
+            const S3Step st = stepAt(ceT);
+            const int pos = st.start + st.dir * ceII;
+            const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end);
+            idA = ID_TEXT | ((ceRp + left + (ceProg & 0xFFFFu)) >> 8);
+            if ((ceNK >> 8) + 1u < (ceNK & 0xFFu)) aD0 = ix.sa + ceL + (ceNK >> 8) + 1u;     // the next candidate's suffix-array entry rides along
+        } else if (state == U_CE_SA) {
+            aD0 = ix.sa + ceL + (ceNK >> 8);
+        } else if (state == U_LOAD) {
+            const uint4 *src = (const uint4 *)(in.readsT + (size_t)aux * 2u * wpq + (size_t)(subN & 1u) * wpq + loadOff);
+            aP0 = src;
+            if (wpq - loadOff > 4u) aP1 = src + 1;
+            if constexpr (!UNIFORM) aD0 = in.readLengths + aux;
+        } else if (state == U_ADOPT) {
+            aP0 = stk + aux;
+        }
+        const bool running = state == U_STEP || state == U_POPWAIT || state == U_CE_SA || state == U_CE_TEXT || state == U_RESUME;
+        const bool wantTos = running && !tosValid && sp > sb;
+        const bool wantCut = wantTos || state == U_CE_SA || state == U_CE_TEXT || state == U_ADOPT;
+        if (wantTos) aPT = stk + ((sp - 1u) & (S3_UNIT_STACK - 1u)) * 64u + lane;
+        if (wantCut) aCut = out.readCut + listed;
+        // ---------- issue: the cooperative lines (4 adjacent lanes fetch the 4 x 16 B of one owner's line; owners without a request: line 0), then what
+        // single lanes need ----------
+        const uint32_t q16 = lane & 3u, q4 = lane >> 2;
+        const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((q4) * 4u), (int)idA);
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u + q4) * 4u), (int)idA);
+        const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((32u + q4) * 4u), (int)idA);
+        const uint32_t o3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((48u + q4) * 4u), (int)idA);
+        auto lineAddr = [&](uint32_t o) -> const uint4 * {
+            if (o != ID_NONE && (o >> 30) == 1u) return (const uint4 *)ix.pac + (size_t)(o & 0x3FFFFFFFu) * 4u + q16;
+            const uint4 *base = (o >> 31) ? ix.rev.lines : ix.fwd.lines;
+            return base + (o == ID_NONE ? (size_t)q16 : (size_t)(o & 0x7FFFFFFFu) * 4u + q16);
+        };
+        const uint4 va0 = *lineAddr(o0), va1 = *lineAddr(o1), va2 = *lineAddr(o2), va3 = *lineAddr(o3);
+        const uint4 p0 = *aP0, p1 = *aP1, pT = *aPT;
+        const uint32_t d0 = *aD0;
+        const uint32_t dCut = __hip_atomic_load(aCut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the queue (wave-uniform branches; what they load is read under the same conditions further down)
+        unsigned long long qBase = 0;
+        uint4 cTs;
+        uint32_t cCut, cRidx, cListed = 0, cRem = 0;
+        bool cIn = false;
+        if (stageA && lane == 0) qBase = atomicAdd(out.workHead, (unsigned long long)S3_UNIT_CHUNK);
+        if (stageB) {
+            const uint32_t slot = pendBase + lane;
+            cIn = slot < nSlots;
+            const uint32_t slotC = cIn ? slot : 0u;
+            cRem = slotC / nListed;
+            cListed = slotC - cRem * nListed;
+            cTs = out.trunkStates[slotC];                                    // tsAt(p) of (item, position) = slot / nListed, read = slot % nListed
+            cCut = __hip_atomic_load(out.readCut + cListed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cRidx = out.listedRead[cListed];
+        }
+        // ---------- stage the cooperative lines in LDS (owner slot = 64 B) ----------
+        stage[(q4) * 4u + q16] = va0;
+        stage[(16u + q4) * 4u + q16] = va1;
+        stage[(32u + q4) * 4u + q16] = va2;
+        stage[(48u + q4) * 4u + q16] = va3;
+        const uint32_t saVal = d0;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------- the queue's results ----------
+        if (stageA) {
+            const unsigned long long b = (unsigned long long)__shfl((long long)qBase, 0);
+            if (b >= nSlots) queueEmpty = true;
+            else { pendBase = (uint32_t)b; basePending = true; }
+        }
+        if (stageB) {
+            // units with a trunk state that are not behind their read's cut, packed to the front of the wave's list
+            const bool live = cIn && (cTs.w & S3_TRUNK_VALID) && !(cRem > cCut);
+            const unsigned long long lm = __ballot(live);
+            if (live) {
+                const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                rdy[k] = cTs.x; rdy[64u + k] = cTs.y; rdy[128u + k] = cTs.z;
+                rdy[192u + k] = cListed; rdy[256u + k] = cRem; rdy[320u + k] = cRidx;
+            }
+            rdyCount = (uint32_t)__popcll(lm); rdyTaken = 0;
+            basePending = false;
+            if constexpr (COUNT) nCutSkip += (cIn && (cTs.w & S3_TRUNK_VALID) && !live) ? 1u : 0u;
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---------- advance ----------
+        bool doSettle = false, needPop = false;
+        if constexpr (COUNT) { if (state != U_IDLE) { unitTrips++; laneTrips++; if (unitTrips > maxUnitTrips) maxUnitTrips = unitTrips; } }
+        if (wantTos) { tos = pT; tosValid = true; }
+        if (wantCut && unitInRead > dCut && state != U_ADOPT) {                  // behind the read's cut
+            if constexpr (COUNT) nCutMid++;
+            state = U_DONE; sp = sb; tosValid = false;
+        }
+        if (state == U_STEP) {
+            const bool exact = ins >= sc.maxErr();
+            const RankSel qL = rankSel(iL), qR = rankSel(iR);
+            const uint4 occA = stage[lane * 4u];
+            // own line in LDS as words: [0..3] counts, [4..7] half before (reversed), [8..11] half after, [12] / [13] precounts
+            const uint32_t offL = (qL.fwd ? 8u : 4u) + (qL.far ? 2u : 0u);
+            const uint4 oL = rankFromWords(qL, occA, myStage32[offL], myStage32[offL + 1u], myStage32[12u + (qL.fwd ? 1u : 0u)]);
+            uint4 oR;
+            if (needB) oR = rankFromWords(qR, p0, qR.far ? p1.z : p1.x, qR.far ? p1.w : p1.y, d0);
+            else {
+                const uint32_t offR = (qR.fwd ? 8u : 4u) + (qR.far ? 2u : 0u);
+                oR = rankFromWords(qR, occA, myStage32[offR], myStage32[offR + 1u], myStage32[12u + (qR.fwd ? 1u : 0u)]);
+            }
+            if constexpr (COUNT) nRank += 2;
+            const int pos = sc.start() + dir * i;
+            const uint32_t ch = readChar(pos);
+            // child ranges: the active range advances by rank, the passive one shrinks by the occurrences of the larger symbols
+            const uint32_t e1 = oR.y - oL.y, e2 = oR.z - oL.z, e3 = oR.w - oL.w;
+            const uint32_t base = dir < 0 ? rl + (fr - fl) : fr;
+            // a child as a frame {fl, fr, rl}: active range [al, ar], passive range ending `oc` (the occurrences of larger symbols) below `base`
+            auto childFl = [&](uint32_t al, uint32_t ar, uint32_t oc) -> uint32_t { return dir < 0 ? al : base - oc - (ar - al); };
+            auto childFr = [&](uint32_t al, uint32_t ar, uint32_t oc) -> uint32_t { return dir < 0 ? ar : base - oc; };
+            auto childRl = [&](uint32_t al, uint32_t ar, uint32_t oc) -> uint32_t { return dir < 0 ? base - oc - (ar - al) : al; };
+            const uint32_t cAl = sel4(oL, ch) + 1u, cAr = sel4(oR, ch);
+            const uint32_t cOc = ch == 0 ? e1 + e2 + e3 : ch == 1 ? e2 + e3 : ch == 2 ? e3 : 0u;
+            const uint32_t gFl = childFl(cAl, cAr, cOc), gFr = childFr(cAl, cAr, cOc), gRl = childRl(cAl, cAr, cOc);
+            doSettle = true;
+            const bool branchOnly = first;                                     // the unit's position: only the mismatch children (the continuation belongs to the later units)
+            first = false;
+            if (!exact) {
+                const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
+                const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
+                if (a0 || a1 || a2 || a3) {
+                    if (sp - sb + 4u > S3_UNIT_STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = U_DONE; sp = sb; tosValid = false; doSettle = false; }
+                    else {
+                        const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
+                        const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
+                        if (!branchOnly) push(gFl, gFr, gRl, mCont);
+                        if (a3) push(childFl(oL.w + 1u, oR.w, 0u), childFr(oL.w + 1u, oR.w, 0u), childRl(oL.w + 1u, oR.w, 0u), mKid);
+                        if (a2) push(childFl(oL.z + 1u, oR.z, e3), childFr(oL.z + 1u, oR.z, e3), childRl(oL.z + 1u, oR.z, e3), mKid);
+                        if (a1) push(childFl(oL.y + 1u, oR.y, e2 + e3), childFr(oL.y + 1u, oR.y, e2 + e3), childRl(oL.y + 1u, oR.y, e2 + e3), mKid);
+                        if (a0) push(childFl(oL.x + 1u, oR.x, e1 + e2 + e3), childFr(oL.x + 1u, oR.x, e1 + e2 + e3), childRl(oL.x + 1u, oR.x, e1 + e2 + e3), mKid);
+                        needPop = true;                                        // (the frame pushed last is in `tos`: the pop takes it from there)
+                    }
+                } else if (branchOnly) needPop = true;                         // no child alive: the unit is empty
+            } else if (branchOnly) needPop = true;
+            if (doSettle && !needPop) { fl = gFl; fr = gFr; rl = gRl; i++; }
+        } else if (state == U_RESUME) { doSettle = true; needPop = false; }
+        else if (state == U_POPWAIT) { doSettle = true; needPop = true; }
+        else if (state == U_ADOPT) {
+            fl = p0.x; fr = p0.y; rl = p0.z;
+            s = (int)(p0.w & 7u); i = (int)((p0.w >> 3) & 0x7FFu); ins = (int)((p0.w >> 14) & 7u); occ = (int)((p0.w >> 17) & 7u);
+            if (s < nSteps) loadStepCache();
+            if (unitInRead > dCut) { state = U_DONE; if constexpr (COUNT) nCutMid++; }
+            else { doSettle = true; needPop = false; }
+        } else if (state == U_LOAD) {
+            const uint32_t vals[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t w = loadOff + k;
+                if (w < wl) ro[w * 64u + lane] = vals[k];
+            }
+            loadOff += 8;
+            if constexpr (!UNIFORM) Li = (int)saVal;
+            if (loadOff >= wl || loadOff >= wpq) {
+                loadStepCache();
+                if (first) state = U_STEP;
+                else { i = sc.len(); doSettle = true; needPop = false; }         // the unit without a mismatch in this step: behind its last position
+            }
+        }
+        // ---------- check-and-extend by the lane itself (see searchKernelV2; BGS-HostAlgnmtAlgo2.cpp:86-169) ----------
+        if (state == U_CE_SA || state == U_CE_TEXT) {
+            bool textHere = state == U_CE_TEXT;                               // the line of this trip belongs to the current candidate
+            bool fresh = !textHere;                                           // the current candidate has not been set up yet
+            const uint32_t ceN = ceNK & 0xFFu;
+            uint32_t ceK = ceNK >> 8;
+            const bool haveNext = textHere && ceK + 1u < ceN;                 // ... and the next candidate's entry came along
+            const uint32_t lineHere = idA & 0x3FFFFFFFu;
+            int ceT = (int)(ceWhere & 7u), ceII = (int)((ceWhere >> 3) & 0x7FFu), ceIns = (int)((ceWhere >> 14) & 7u), ceAcc = (int)((ceWhere >> 17) & 0x7Fu);
+            int ceOff = (int)(ceProg & 0xFFFFu), ceMm = (int)(ceProg >> 16);
+            uint32_t ceMiss = ceHist & 0xFFFFu, ceTaken = ceHist >> 16;
+            if (fresh) ceSa = saVal;
+            for (;;) {
+                int verdict = 0;                                              // 1: accepted, -1: rejected, 0: needs a text line
+                if (fresh) {
+                    ceRp = ceSa - (uint32_t)(sc.dir() > 0 ? sc.lm0() : sc.lm0() - i);     // 32-bit wrap, as the reference
+                    ceT = s; ceII = i; ceIns = ins; ceAcc = occ; ceOff = 0; ceMm = 0;
+                    if constexpr (COUNT) nSaL++;
+                    fresh = false;
+                }
+                for (;;) {
+                    const S3Step st = stepAt(ceT);
+                    const int pos = st.start + st.dir * ceII;
+                    const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end), right = (uint32_t)(pos < st.end ? st.end : pos);
+                    const uint32_t len = right - left + 1u;
+                    if (ceOff == 0 && ceRp + left > ix.n) { verdict = -1; break; }          // BGS-HostAlgnmtAlgo2.cpp:122-125
+                    const uint32_t tpos = ceRp + left + (uint32_t)ceOff;
+                    if (!textHere || (tpos >> 8) != lineHere) break;          // that line is not here: next trip
+                    uint32_t todo = len - (uint32_t)ceOff;
+                    const uint32_t inLine = 256u - (tpos & 255u);
+                    if (todo > inLine) todo = inLine;
+                    for (uint32_t o = 0; o < todo; o += 16u) {
+                        const uint32_t c = todo - o > 16u ? 16u : todo - o;
+                        const uint32_t tp = (tpos + o) & 255u, w = tp >> 4, sh = (tp & 15u) * 2u;
+                        const uint32_t t0 = myStage32[w], t1 = w + 1u < 16u ? myStage32[w + 1u] : 0u;
+                        const uint32_t a_ = sh ? (t0 << sh) | (t1 >> (32u - sh)) : t0;
+                        uint32_t x = a_ ^ readWindow((int)(left + (uint32_t)ceOff + o));
+                        x = (x | (x >> 1)) & 0x55555555u;
+                        if (c < 16u) x &= ~0u << (32u - 2u * c);
+                        ceMm += __popc(x);
+                    }
+                    if constexpr (COUNT) nCeL += (todo + 31u) >> 5;
+                    ceOff += (int)todo;
+                    if ((uint32_t)ceOff < len) break;                          // the rest of the step lies in the next line
+                    const int tot = ceMm + ceIns;
+                    if (tot < st.minErr || tot > st.maxErr) { verdict = -1; break; }
+                    ceAcc += tot; ceT++; ceII = 0; ceIns = 0; ceOff = 0; ceMm = 0;
+                    if (ceT >= nSteps) { verdict = 1; break; }
+                }
+                if (verdict == 0) { state = U_CE_TEXT; break; }
+                if (verdict > 0) {
+                    // an occurrence: written under the unit's next sequence number (rejected candidates reserve nothing here)
+                    pendMeta = 0x80000000u | seq | (1u << 24) | ((uint32_t)ceAcc << 25);
+                    pendA = ceRp; pendB = ceRp;
+                    seq++; total++;
+                    countPending++;
+                    // (a unit that has verified in.ceInlineMax occurrences itself has shown what it is worth to its read's cut: from there on its
+                    //  candidates go to ceKernel -- a thousand of them one after the other is what a launch would wait for)
+                    if (ceTaken < 0xFFFFu) ceTaken++;
+                    ceMiss = ceTaken >= inlineMax ? giveUp : 0u;
+                } else if (ceMiss < 0xFFFFu) ceMiss++;
+                ceK++;
+                if (ceK >= ceN) { doSettle = true; needPop = true; break; }    // all candidates seen: the search goes on (settle sets the state)
+                if (ceMiss >= giveUp && !(pendMeta >> 31)) {
+                    // the rest of this range goes to ceKernel as a task (its candidates reserve their sequence numbers, as in the first pass)
+                    pendMeta = 0x80000000u | seq | S3_REC_TASK;
+                    pendA = ceL + ceK;
+                    pendB = (ceN - ceK - 1u) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+                    seq += ceN - ceK;
+                    doSettle = true; needPop = true;
+                    break;
+                }
+                if (total >= in.maxOut) { state = U_DONE; sp = sb; tosValid = false; break; }
+                if (textHere && haveNext) { ceSa = saVal; fresh = true; textHere = false; continue; }   // set the next one up now; its text comes with the next trip
+                state = U_CE_SA;
+                break;
+            }
+            ceNK = ceN | ceK << 8;
+            ceWhere = (uint32_t)ceT | (uint32_t)ceII << 3 | (uint32_t)ceIns << 14 | (uint32_t)ceAcc << 17;
+            ceProg = (uint32_t)ceOff | (uint32_t)ceMm << 16;
+            ceHist = ceMiss | ceTaken << 16;
+        }
+        if (doSettle) settle(needPop);
+        // ---------- book the occurrences the unit holds for sure, where the other units of its read can see them: per item (itemAcc) and per position
+        // (the spare word of the trunk states), S3_V2_COUNT_BATCH at a time and when the unit ends.  Everything in sequence order up to and including this
+        // unit that adds up to MaxOutputPerRead puts the read's cut behind this unit; the items up to this one adding up to it put it behind the item
+        // (see searchKernelV2::countCertain) ----------
+        if (countPending >= S3_V2_COUNT_BATCH || (state == U_DONE && countPending)) {
+            const uint32_t cnt = countPending, sub = subIdx;
+            countPending = 0;
+            uint32_t *cutPtr = out.readCut + listed;
+            uint32_t *acc = out.itemAcc + (size_t)listed * groups;
+            atomicAdd(&acc[sub], cnt);
+            uint32_t before = 0;
+            for (uint32_t q = 0; q < sub; q++) before += __hip_atomic_load(&acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t mine = __hip_atomic_load(&acc[sub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + mine >= in.maxOut) atomicMin(cutPtr, sub * U + U - 1u);
+            const uint32_t myPos = unitInRead - sub * U;
+            uint4 *ts0 = out.trunkStates + (size_t)sub * U * nListed + listed;                 // position q of this item and read: ts0[q * nListed]
+            atomicAdd(&ts0[(size_t)myPos * nListed].w, cnt);
+            uint32_t upTo = before;
+            for (uint32_t q = 0; q <= myPos; q++) upTo += __hip_atomic_load(&ts0[(size_t)q * nListed].w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~S3_TRUNK_VALID;
+            if (upTo >= in.maxOut) atomicMin(cutPtr, unitInRead);
+        }
+        // ---------- write the parked records (convergent) ----------
+        {
+            const unsigned long long pm = __ballot((pendMeta >> 31) != 0);
+            if (pm) {
+                const uint32_t np = (uint32_t)__popcll(pm);
+                if (recCur + np > recEnd) {
+                    for (uint32_t k = recCur + lane; k < recEnd; k += 64u) out.recs[k] = make_uint4(0xFFFFFFFFu, 0, 0, 0);   // unused tail
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(out.recCount, S3_V2_REC_BLOCK);
+                    b = (uint32_t)__shfl((int)b, 0);
+                    recCur = b; recEnd = b + S3_V2_REC_BLOCK;
+                    if (recEnd > out.recCap || recEnd < b) { recEnd = b < out.recCap ? out.recCap : b; atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
+                }
+                if (pendMeta >> 31) {
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(cntIdx | S3_REC_PASS2, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                    pendMeta = 0;
+                }
+                recCur += np;
+                if (recCur > recEnd) recCur = recEnd;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef casIdx
+#undef subIdx
+#undef nSteps
+    for (uint32_t k = recCur + lane; k < recEnd; k += 64u) out.recs[k] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+    if constexpr (COUNT) {
+        if (out.counters) {
+            atomicAdd(&out.counters[0], (unsigned long long)nRank);
+            atomicAdd(&out.counters[2], (unsigned long long)nSaL);
+            atomicAdd(&out.counters[3], (unsigned long long)nCeL);
+            atomicAdd(&out.counters[4], (unsigned long long)nCutSkip);
+            atomicAdd(&out.counters[5], (unsigned long long)nCutMid);
+            atomicAdd(&out.counters[6], laneTrips);
+            atomicMax(&out.counters[7], (unsigned long long)maxUnitTrips);
+            atomicAdd(&out.counters[8], (unsigned long long)nAdopt);
+        }
+    }
+}
+
+// per listed read: its index in readsT / readLengths (what the first pass had in its `active` indirection)
+__global__ void listedReadsKernel(const uint32_t *heavyList, const uint32_t *heavyCount, const uint32_t *active, uint32_t *listedRead)
+{
+    const uint32_t n = *heavyCount;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t slot = heavyList[k];
+        listedRead[k] = active ? active[slot] : slot;
+    }
+}
+
+// The counters of adopted frames, chained behind the units they came from: a unit's count becomes the total of its chain, every node gets its place
+// inside that total (what comes before it in sequence order).  One lane per unit with a chain; chains are short.
+__global__ void unitChainKernel(SearchOut out, uint32_t unitBase, uint32_t nUnits)
+{
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nUnits; u += gridDim.x * blockDim.x) {
+        uint32_t node = out.chainNext[u];
+        if (!node) continue;
+        uint32_t off = out.itemCounts[unitBase + u];
+        while (node) {
+            out.dynLocal[node - out.dynBase] = off;
+            off += out.itemCounts[node];
+            node = out.chainNext[node - unitBase];
+        }
+        out.itemCounts[unitBase + u] = off;
+    }
+}
+
+unsigned unitPassMaxWaves(unsigned maxBlocks) { return maxBlocks * (S3_SEARCH_BLOCK / 64u); }
+
+int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
+{
+    if (in.nActive == 0) return (int)hipSuccess;
+    uint64_t blocks = ((uint64_t)in.nActive * (uint64_t)in.nCases * 2u * in.unitsPerItem + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    if (blocks > maxBlocks) blocks = maxBlocks;
+    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + S3_UNIT_RDY_BYTES + in.wLds * 256u);
+    const bool count = out.counters != nullptr;
+    const void *fn = in.uniformLen ? (count ? (const void *)unitKernel<true, true> : (const void *)unitKernel<true, false>)
+                                   : (count ? (const void *)unitKernel<false, true> : (const void *)unitKernel<false, false>);
+    if (lds > 48u * 1024u) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const dim3 grid((unsigned)blocks), block(S3_SEARCH_BLOCK);
+    if (in.uniformLen) {
+        if (count) hipLaunchKernelGGL((unitKernel<true, true>), grid, block, lds, s, ix, in, out);
+        else hipLaunchKernelGGL((unitKernel<true, false>), grid, block, lds, s, ix, in, out);
+    } else {
+        if (count) hipLaunchKernelGGL((unitKernel<false, true>), grid, block, lds, s, ix, in, out);
+        else hipLaunchKernelGGL((unitKernel<false, false>), grid, block, lds, s, ix, in, out);
+    }
+    return (int)hipSuccess;
+}
+
+void launchListedReads(const uint32_t *heavyList, const uint32_t *heavyCount, const uint32_t *active, uint32_t *listedRead, uint32_t nHeavy, hipStream_t s)
+{
+    if (!nHeavy) return;
+    hipLaunchKernelGGL(listedReadsKernel, dim3((nHeavy + 255u) / 256u), dim3(256), 0, s, heavyList, heavyCount, active, listedRead);
+}
+
+void launchUnitChains(const SearchOut &out, uint32_t unitBase, uint32_t nUnits, hipStream_t s)
+{
+    if (!nUnits || !out.dynCap) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)nUnits + 255u) / 256u, 8192u);
+    hipLaunchKernelGGL(unitChainKernel, dim3(blocks), dim3(256), 0, s, out, unitBase, nUnits);
+}
+
+}  // namespace s3

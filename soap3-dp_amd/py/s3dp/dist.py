@@ -30,7 +30,7 @@ def reduce_counters(counters, device=None):
     """sum the per-rank counter dict over all ranks (no-op without an initialised process group)"""
     import torch
     import torch.distributed as dist
-    vec = torch.tensor([float(counters.get(k, 0)) for k in COUNTER_KEYS], dtype=torch.float64, device=device)
+    vec = torch.tensor([int(counters.get(k, 0)) for k in COUNTER_KEYS], dtype=torch.int64, device=device)      # (64-bit integers: rank-query counts pass 2^53)
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     return {k: int(v) for k, v in zip(COUNTER_KEYS, vec.tolist())}

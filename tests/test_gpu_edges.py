@@ -109,3 +109,48 @@ def test_text_boundaries_and_homopolymers(world):
     assert counts[6] == 7 and counts[7] == 7                 # all-A / all-T: the hit limit cuts the list
     for rt in (1, 3, 4):
         compare(ix, oix, reads, 100, 3, report_type=rt)
+
+
+def test_a_batch_that_lost_a_buffer_while_growing_refuses_further_calls():
+    """bgrow frees the old buffer before the larger one exists when both do not fit; if the second allocation fails too the batch has a null
+    buffer under an old capacity.  It must answer every later call with S3_ENOMEM instead of launching kernels on it (S3DP_TEST_FAIL_GROW=1: the first
+    growth of the process finds the device full; a tiny record floor forces that growth)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, "soap3-dp_amd/py"); sys.path.insert(0, "tests")
+import s3dp
+from conftest import golden_reads, host_index
+reads = golden_reads("g2")
+q, lens, wpq = s3dp.pack_reads(reads, 120)
+ix = s3dp.Index(host_index("g2"))
+b = s3dp.Batch(ix, len(reads), wpq)
+b.upload(q, lens)
+errs = []
+for k in range(3):
+    try:
+        b.search(2, 1000)
+        errs.append("ok")
+    except s3dp.S3Error as e:
+        errs.append(str(e))
+assert "unusable" in errs[0] or "hipMalloc" in errs[0], errs
+assert all("lost a buffer" in e for e in errs[1:]), errs
+try:
+    b.upload(q, lens)
+    raise SystemExit("upload on a failed batch succeeded")
+except s3dp.S3Error as e:
+    assert "lost a buffer" in str(e)
+b.close()
+b2 = s3dp.Batch(ix, len(reads), wpq)          # the growth hook is spent: a fresh batch works, and grows
+b2.upload(q, lens)
+b2.search(2, 1000)
+hits, offs, tot, werr = b2.fetch_hits()
+assert len(hits) > 4096
+print("refused-ok", len(hits))
+'''
+    env = dict(os.environ, S3DP_TEST_FAIL_GROW="1", S3DP_REC_FLOOR="16", S3DP_REC_PER_READ="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "refused-ok" in r.stdout, r.stdout + r.stderr

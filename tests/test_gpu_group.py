@@ -130,3 +130,45 @@ def test_distributed_path_with_world_size_one(tmp_path):
     oix = s3o.Index(host_index=host_index("g1"))
     phase, werr, offs, pos, strand, mis, st = oix.align_single_allbest(q, lens, wpq, 2, 1000)
     assert tot["reads"] == 600 and tot["readsAligned"] == int((phase > 0).sum()) and tot["alignments"] == int(offs[-1])
+
+
+
+def test_group_on_two_devices_runs_the_rccl_allreduce():
+    """With two or more devices visible: s3_group_create on devices [0, 1] and the real ncclAllReduce between them (one-GPU boxes skip this; the
+    two-members-on-one-device tests above cover everything but the collective itself)."""
+    if s3dp.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    hi = host_index("g1")
+    g = s3dp.Group(hi, [0, 1])
+    big = (1 << 60) + 12345                                  # would not survive a trip through float64
+    a = g.allreduce(np.array([[1, big, 7], [10, 1, 70]], dtype=np.uint64))
+    assert a.tolist() == [[11, big + 1, 77], [11, big + 1, 77]]
+    reads = golden_reads("g1")[:256]
+    q, lens, wpq = s3dp.pack_reads(reads, 100)
+    res = []
+    for k in range(2):
+        b = s3dp.Batch(g.index(k), len(reads), wpq)
+        b.upload(q, lens)
+        b.align_single_allbest(2, 1000)
+        res.append(b.fetch_alignments())
+        b.close()
+    for x, y in zip(res[0], res[1]):
+        assert (x == y).all()
+    g.close()
+
+
+def test_cli_on_two_devices(tmp_path):
+    """soap3-dp -c 0,1 with two real devices: the union of the two members' files is the reference's golden output"""
+    if s3dp.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    shutil.copy(os.path.join(GOLDEN, "g1", "reads.fq"), tmp_path / "g1.fq")
+    env = dict(os.environ, S3DP_CHUNK_READS="256")
+    out = subprocess.run([BIN, "single", os.path.join(GOLDEN, "g1", "index"), "g1.fq", "-L", "100", "-s", "4", "-b", "2", "-c", "0,1", "-o", "out"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    ref_h, ref = records(gzip.open(os.path.join(GOLDEN, "g1", "sam_s4.sam.gz"), "rt").read())
+    hdrs, mine = union(tmp_path, ["out.gout.1", "out.gout.2"])
+    assert all(h == ref_h for h in hdrs) and mine == ref
+    m = re.search(r"Overall number of reads aligned: (\d+)", out.stdout)
+    aligned = sum(1 for l in ref.elements() if int(l.split("\t")[1]) & 4 == 0)
+    assert m and int(m.group(1)) == aligned                                   # summed by ncclAllReduce between the two devices

@@ -62,12 +62,59 @@ def test_search_bit_exact_vs_reference_dump_and_oracle(monkeypatch, name, maxlen
     b.close()
 
 
+KNOBS = [
+    {"S3DP_EARLY_CE": "0"},                                  # the exact lookup step is walked to its end, as the CPU path walks it
+    {"S3DP_EARLY_CE": "4", "S3DP_EARLY_MIN": "17"},
+    {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8"},             # nearly every read is listed by its rank queries
+    {"S3DP_HEAVY": "2", "S3DP_CE_INLINE_MAX": "1"},          # units hand their candidates to ceKernel after the first they verified
+    {"S3DP_HEAVY": "2", "S3DP_CE_INLINE_MAX": "1000000", "S3DP_CE_GIVE_UP": "1000000"},
+    {"S3DP_HEAVY": "2", "S3DP_UNIT_KERNEL": "v2"},           # the searchKernelV2 instantiation the unit-pass kernel replaced
+    {"S3DP_HEAVY": "2", "S3DP_UNIT_NODES": "0"},             # no adoption of frames: every unit is searched by one lane
+    {"S3DP_HEAVY": "2", "S3DP_UNIT_NODES": "300"},           # the counters of adopted frames run out on the way
+    {"S3DP_HEAVY": "2", "S3DP_BLOCKS_PER_CU": "1", "S3DP_CE_BLOCKS_PER_CU": "1"},
+]
+
+
+@pytest.mark.parametrize("knobs", KNOBS, ids=lambda k: ",".join("%s=%s" % (a[5:], b) for a, b in k.items()))
+@pytest.mark.parametrize("name,maxlen,mm", [("g2", 120, 2), ("g2", 120, 4), ("g1", 100, 3)])
+def test_search_knobs_do_not_change_results(monkeypatch, name, maxlen, mm, knobs):
+    """Every tuning knob of the search (thresholds of the heavy-read machinery, early check-and-extend, grid widths, the unit-pass kernel and its
+    adoption of frames) at an extreme value: records, order and tallies stay the oracle's.  With S3DP_EARLY_CE=0 and one lane per read the kernels'
+    rank-query count EQUALS the oracle's."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    if "S3DP_HEAVY" not in knobs:
+        monkeypatch.setenv("S3DP_HEAVY", "0")
+    reads = golden_reads(name)
+    q, lens, wpq = s3dp.pack_reads(reads, maxlen)
+    b = s3dp.Batch(dev_index(name), len(reads), wpq)
+    b.upload(q, lens)
+    b.enable_counters(True)
+    b.search(mm, 1000)
+    hits, offs, tot, werr = b.fetch_hits()
+    oix = s3o.Index(host_index=host_index(name))
+    ohits, ooffs, otot, owerr, st = oix.search(q, lens, wpq, mm, max_out=1000)
+    assert (offs == ooffs).all() and hits.tobytes() == ohits.tobytes()
+    assert (tot == otot).all() and (werr == owerr).all()
+    c = b.counters()
+    if knobs.get("S3DP_EARLY_CE") == "0":
+        assert c["rankQueries"] == st.rankQueries
+    b.enable_counters(False)
+    b.search(mm, 7)                                          # and with a tight MaxOutputPerRead, uncounted kernels
+    hits, offs, tot, werr = b.fetch_hits()
+    ohits, ooffs, otot, owerr, st = oix.search(q, lens, wpq, mm, max_out=7)
+    assert (offs == ooffs).all() and hits.tobytes() == ohits.tobytes()
+    assert (tot == otot).all() and (werr == owerr).all()
+    oix.close()
+    b.close()
+
+
 @pytest.mark.parametrize("extra", [1, 2, 3])
 @pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
 def test_long_lookup_tables_do_not_change_results(monkeypatch, name, maxlen, extra):
-    monkeypatch.setenv("S3DP_HEAVY", "0")                   # the rank-query comparison below is for a single pass over every read
     """S3DP_LT_EXTRA: 14- / 15- / 16-mer tables built in HBM at upload (the state after the 13-mer lookup plus one / two / three exact steps).  Records, their
     order and the per-read tallies must stay bit-identical to the oracle for every mismatch budget; only the number of rank queries drops."""
+    monkeypatch.setenv("S3DP_HEAVY", "0")                   # the rank-query comparison below is for a single pass over every read
     monkeypatch.setenv("S3DP_LT_EXTRA", str(extra))
     ix = s3dp.Index(host_index(name))
     assert s3dp.lib().s3_index_lookup_chars(ix.h) == 13 + extra
