@@ -214,7 +214,9 @@ class HostIndex:
             hdr = [h["inverseSa0"]] + [int(x) for x in h["cum"][1:5]]
             words(prefix + mid + ".bwt", hdr, h["bwt"])
             words(prefix + mid + ".fmv.gpu", hdr, h["occ"])
-        words(prefix + ".sa", [self.fwd["inverseSa0"]] + [int(x) for x in self.fwd["cum"][1:5]] + [getattr(self, "sa_interval", 1)], self.sa)
+        sa_file = np.array(self.sa, dtype=np.uint32, copy=True)
+        sa_file[0] = n                                            # on disk entry 0 is the suffix '$' = n; readers force it to -1 (BWT.c:286)
+        words(prefix + ".sa", [self.fwd["inverseSa0"]] + [int(x) for x in self.fwd["cum"][1:5]] + [getattr(self, "sa_interval", 1)], sa_file)
         # packed text: 4 characters per byte, first one in the top bits; then one (partial or empty) byte and the count n % 4
         pw = np.ascontiguousarray(self.pac, dtype=">u4")
         raw = pw.view(np.uint8)[: n // 4 + 1].copy()

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-2 measurement set for the GPU box (run through gpurun from the repository root; writes small summaries under gpurun_out/r02_final/, which
+# Measurement set (rounds 2 and 3) for the GPU box (run through gpurun from the repository root; writes small summaries under gpurun_out/r02_final/, which
 # are then copied into profiles/).  Every step has its own timeout; the benchmark index is built once and kept as files under /tmp.
 #   tools/run_profiles.sh [bench|stats|pmc|dp|e2e|pairs ...]     (default: all)
 set -u
-OUT=gpurun_out/r02_final
+OUT=${S3DP_PROFILE_OUT:-gpurun_out/r03}
 IX=/tmp/s3dp_ix
 mkdir -p $OUT $IX
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
@@ -19,17 +19,17 @@ fi
 if want stats; then   # kernel stats of the timed passes (rocprofv3 --kernel-trace --stats)
   rm -rf /tmp/prof_stats
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python3 bench.py $QUICK --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.log
-  echo "stats rc=$?"; f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_bench.csv && grep "s3::" $OUT/kernel_stats_bench.csv | head -12 | cut -c1-160
+  echo "stats rc=$?"; f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_bench.csv && grep "s3::" $OUT/kernel_stats_bench.csv | head -16 | cut -c1-160
 fi
 if want pmc; then     # HBM traffic of the search kernels: FETCH_SIZE in its own pass, one ladder (4 phases), no warm-up
   rm -rf /tmp/prof_pmc
   timeout 1200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_pmc -o pmc -- python3 bench.py $QUICK --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_fetch.log
   echo "pmc rc=$?"; f=$(find /tmp/prof_pmc -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python3 tools/pmc_summary.py "$f" searchKernelV2 > $OUT/pmc_fetch_search.txt; python3 tools/pmc_summary.py "$f" ceKernel > $OUT/pmc_fetch_ce.txt; tail -4 $OUT/pmc_fetch_search.txt; fi
+  if [ -n "$f" ]; then python3 tools/pmc_summary.py "$f" searchKernelV2 > $OUT/pmc_fetch_search.txt; python3 tools/pmc_summary.py "$f" unitKernel > $OUT/pmc_fetch_unit.txt; python3 tools/pmc_summary.py "$f" ceKernel > $OUT/pmc_fetch_ce.txt; tail -4 $OUT/pmc_fetch_unit.txt; fi
   rm -rf /tmp/prof_pmc
   timeout 1200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/prof_pmc -o pmc -- python3 bench.py $QUICK --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_sq.log
   echo "pmc sq rc=$?"; f=$(find /tmp/prof_pmc -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python3 tools/pmc_summary.py "$f" searchKernelV2 > $OUT/pmc_sq_search.txt; python3 tools/pmc_summary.py "$f" ceKernel > $OUT/pmc_sq_ce.txt; tail -4 $OUT/pmc_sq_search.txt; fi
+  if [ -n "$f" ]; then python3 tools/pmc_summary.py "$f" searchKernelV2 > $OUT/pmc_sq_search.txt; python3 tools/pmc_summary.py "$f" unitKernel > $OUT/pmc_sq_unit.txt; python3 tools/pmc_summary.py "$f" ceKernel > $OUT/pmc_sq_ce.txt; tail -4 $OUT/pmc_sq_unit.txt; fi
 fi
 if want dp; then      # DP kernel: GCUPS, kernel stats, counters on 4096 problems per shape
   timeout 600 python3 tools/bench_dp.py > $OUT/dp_gcups.jsonl 2> $OUT/dp_gcups.log; echo "dp rc=$?"; cat $OUT/dp_gcups.jsonl | cut -c1-220
