@@ -345,12 +345,20 @@ int  s3_dp_align(s3_dp *h, const uint32_t *packedDNA, const uint32_t *DNALengths
                  const uint32_t *clipLtSizes, uint32_t *clipRtSizes, const uint32_t *anchorLeftLocs, const uint32_t *anchorRightLocs,
                  int32_t *scores, uint32_t *hitLocs, uint32_t *maxScoreCounts, uint8_t *pattern);
 int  s3_dp_last_timing(s3_dp *h, float *ms);      /* device time of the last s3_dp_align (fill + backtrack), HIP events */
+/* running totals of an aligner since s3_dp_create, over every launch of its kernels (s3_dp_align and the engines s3_dp_half_end / _deep /
+ * _new_default / _single_end): device milliseconds, problems, cells (read length x window length per problem) -- what a giga-cell-updates
+ * figure is made of; the reference's TimeRecorder (DV-DPfunctions.h:446-747) plays this part, unused in its release build */
+int  s3_dp_totals(s3_dp *h, double *kernelMs, uint64_t *problems, uint64_t *cells);
 void s3_dp_free(s3_dp *h);
 
 /* measurement aid, not part of the alignment path: rate of random 64-byte-line gathers on this device
  * (the practical ceiling of a rank-query stream).  Reports the average kernel time and lines read per launch. */
 int  s3_probe_gather(int device, size_t tableBytes, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,
                      int repeats, float *msOut, uint64_t *linesOut);
+
+/* measurement aid: streaming bandwidth of this device with an own copy kernel (16-byte loads and stores, grid-stride): bytes READ PLUS WRITTEN per
+ * second is the denominator of the roofline fraction (bench.py).  Reports the average time of one copy of `bytes`. */
+int  s3_probe_copy(int device, size_t bytes, int repeats, float *msOut);
 
 int  s3_device_count(void);
 const char *s3_last_error(void);

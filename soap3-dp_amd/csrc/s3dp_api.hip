@@ -514,20 +514,35 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             const unsigned blocksSecond = std::min<unsigned>(blocksPerCu, S3_V2_WAVES_PER_SIMD_SECOND);     // (the second-pass instantiation holds more registers)
             // S3DP_VERBOSE=1 with counters enabled: reads, listed reads, rank queries and milliseconds of every launch of this pass (stderr)
             static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
-            unsigned long long rankSeen = counterSnap[0], tripsSeen = counterSnap[6];
+            unsigned long long rankSeen = counterSnap[0], tripsSeen = counterSnap[6], wavesSeen = counterSnap[9], adoptSeen = counterSnap[8], saSeen = counterSnap[2], ceSeen = counterSnap[3];
             auto lapT = std::chrono::steady_clock::now();
             auto lap = [&](const char *what, uint64_t units) {
                 if (!verbose || !b->counting) return;
-                unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                (void)d2h(c, b->dCounters, 64, b->stream);
+                unsigned long long c[S3_NUM_COUNTERS] = {};
+                (void)d2h(c, b->dCounters, S3_NUM_COUNTERS * 8, b->stream);
                 const auto now = std::chrono::steady_clock::now();
-                fprintf(stderr, "[s3dp] search mm=%u %-12s %10llu units %8.2f ms %12llu rank queries (second pass so far: cut %llu + %llu units, %llu lane trips, longest unit %llu trips)\n",
-                        modelMm, what, (unsigned long long)units, std::chrono::duration<double, std::milli>(now - lapT).count(), c[0] - rankSeen, c[4], c[5], c[6] - tripsSeen, c[7]);
-                rankSeen = c[0]; tripsSeen = c[6]; lapT = now;
+                fprintf(stderr, "[s3dp] search mm=%u %-12s %10llu units %8.2f ms %12llu rank queries (second pass so far: cut %llu + %llu units, %llu lane trips, longest unit %llu trips; "
+                                "unit kernel: %llu wave trips, %llu frames adopted; %llu suffix-array reads, %llu compare windows)\n",
+                        modelMm, what, (unsigned long long)units, std::chrono::duration<double, std::milli>(now - lapT).count(), c[0] - rankSeen, c[4], c[5], c[6] - tripsSeen, c[7],
+                        c[9] - wavesSeen, c[8] - adoptSeen, c[2] - saSeen, c[3] - ceSeen);
+                rankSeen = c[0]; tripsSeen = c[6]; wavesSeen = c[9]; adoptSeen = c[8]; saSeen = c[2]; ceSeen = c[3]; lapT = now;
                 (void)hipMemsetAsync(b->dCounters + 7, 0, 8, b->stream);
             };
             if (verbose && b->counting) { (void)hipStreamSynchronize(b->stream); lapT = std::chrono::steady_clock::now(); }
-            hipError_t le = (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream);
+            // the depth-first stacks of the first-pass and unit-pass kernels: a ring of frames per lane of the widest grid
+            const unsigned blocksFirst = std::min<unsigned>(blocksPerCu, S3_FIRST_WAVES_PER_SIMD), blocksUnit = std::min<unsigned>(blocksPerCu, S3_UNIT_WAVES_PER_SIMD);
+            {
+                const size_t waves = unitPassMaxWaves(256u * std::max(blocksFirst, blocksUnit));
+                if (waves > b->unitStackWaves) {
+                    int rc = bgrow(b, &b->dUnitStack, waves * S3_UNIT_STACK * 64u, 0);
+                    if (rc) { b->unitStackWaves = 0; return rc; }
+                    b->unitStackWaves = waves;
+                }
+                out.unitStack = b->dUnitStack;
+            }
+            const bool firstKernelV2 = [] { const char *e = getenv("S3DP_FIRST_KERNEL"); return e && !strcmp(e, "v2"); }();   // (the searchKernelV2 instantiation s3dp_first.hip replaced)
+            hipError_t le = firstKernelV2 ? (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream)
+                                          : (hipError_t)launchFirstPass(b->ix->d, in, out, 256u * blocksFirst, b->stream);
             if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
             lap("first pass", nActive);
             HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
@@ -600,18 +615,12 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
                     in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (the scatter decodes unit indices with them)
                     HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
-                    const unsigned blocksUnit = std::min<unsigned>(blocksPerCu, S3_UNIT_WAVES_PER_SIMD);
                     if (newUnitPass) {
                         // what the unit-pass kernel needs besides: the listed reads' numbers, its stack, the chains of adopted frames
                         int rc;
                         if (nHeavy > b->listedCap) {
                             if ((rc = bgrow(b, &b->dListedRead, (size_t)nHeavy + nHeavy / 4 + 64, 0))) { b->listedCap = 0; return rc; }
                             b->listedCap = (size_t)nHeavy + nHeavy / 4 + 64;
-                        }
-                        const size_t waves = unitPassMaxWaves(256u * blocksUnit);
-                        if (waves > b->unitStackWaves) {
-                            if ((rc = bgrow(b, &b->dUnitStack, waves * S3_UNIT_STACK * 64u, 0))) { b->unitStackWaves = 0; return rc; }
-                            b->unitStackWaves = waves;
                         }
                         const size_t nChain = (size_t)nHeavy * groups * U + 1 + dynCap;
                         if (nChain > b->chainCap) {
@@ -858,6 +867,37 @@ extern "C" int s3_bwt_search(s3_index *ix, const uint32_t *queries, const uint32
     *hitOffsets = off; *hits = h;
     if (totalOcc) *totalOcc = tot; else free(tot);
     if (withError) *withError = we; else free(we);
+    return S3_OK;
+}
+
+// measurement aid (bench.py's roofline denominator): streaming copy bandwidth of the device with an own 16-byte copy kernel
+extern "C" int s3_probe_copy(int device, size_t bytes, int repeats, float *msOut)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(S3_ENODEV, "no HIP device available");
+    HIPCHK(hipSetDevice(device));
+    const size_t n16 = bytes / 16;
+    if (n16 == 0 || repeats < 1) return fail(S3_EINVAL, "bad probe arguments");
+    uint4 *src = nullptr, *dst = nullptr;
+    HIPCHK(hipMalloc((void **)&src, n16 * 16));
+    if (hipMalloc((void **)&dst, n16 * 16) != hipSuccess) { (void)hipFree(src); return fail(S3_ENOMEM, "s3_probe_copy: hipMalloc"); }
+    HIPCHK(hipMemset(src, 1, n16 * 16));
+    HIPCHK(hipMemset(dst, 2, n16 * 16));
+    hipStream_t s;
+    hipEvent_t e0, e1;
+    HIPCHK(hipStreamCreate(&s));
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    launchCopyProbe(src, dst, n16, s);                                                             // warm-up
+    HIPCHK(hipEventRecord(e0, s));
+    for (int r = 0; r < repeats; r++) launchCopyProbe(src, dst, n16, s);
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (msOut) *msOut = ms / repeats;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    (void)hipFree(src); (void)hipFree(dst);
     return S3_OK;
 }
 

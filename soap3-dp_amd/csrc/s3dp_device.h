@@ -11,6 +11,8 @@
 #define S3_V2_COUNT_BATCH 32u             // second pass: accepted candidates a unit books at a time
 #define S3_V2_REC_BLOCK 256u              // record slots a wave reserves with one atomic
 #define S3_V2_MODEL_BYTES 1104u           // sizeof(S3Model) rounded up to 16
+#define S3_FIRST_WAVES_PER_SIMD 4         // register budget of the first-pass kernel (s3dp_first.hip)
+#define S3_FIRST_RDY_BYTES 512u            // LDS per wave of the first pass for the reads waiting for a lane (2 words x 64)
 #define S3_UNIT_WAVES_PER_SIMD 4          // register budget of the unit-pass kernel (s3dp_unit.hip)
 #define S3_UNIT_CHUNK 64u                 // units a wave of the unit pass takes from the work queue at a time (one per lane: tested before they start)
 #define S3_UNIT_STACK 32u                 // depth-first frames per lane of the unit pass (a ring in global memory; a power of two)
@@ -159,6 +161,7 @@ void launchZeroListedCounts(const uint32_t *heavyList, const uint32_t *heavyCoun
 void launchSaExpand(const DevBwt &b, const uint32_t *samples, uint32_t interval, uint32_t n, uint32_t *sa, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
 int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
+int launchFirstPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);    // s3dp_first.hip; returns a hipError_t
 int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);     // s3dp_unit.hip; returns a hipError_t
 unsigned unitPassMaxWaves(unsigned maxBlocks);                                        // waves of the widest unit-pass grid (sizes SearchOut::unitStack)
 void launchListedReads(const uint32_t *heavyList, const uint32_t *heavyCount, const uint32_t *active, uint32_t *listedRead, uint32_t nHeavy, hipStream_t s);
@@ -227,6 +230,7 @@ void launchPairStats(const PairSweepArgs &a, hipStream_t s);
 void launchPairEmit(const PairSweepArgs &a, const uint32_t *xaOffsets, uint32_t xaBase, DevPairXa *xa, hipStream_t s);
 void launchPairGatherXa(uint32_t nPairs, const uint32_t *xaStart, const uint32_t *outOffsets, const DevPairXa *xa, DevPairXa *out, hipStream_t s);
 
+void launchCopyProbe(const uint4 *src, uint4 *dst, size_t n16, hipStream_t s);
 void launchGatherProbe(const uint4 *table, uint64_t nLines, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,
                        uint32_t *sink, hipStream_t s);
 

@@ -69,12 +69,13 @@ extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLe
 #define DA(p, c) if ((rc = dalloc(h, &h->p, (c)))) { s3_dp_free(h); return rc; }
     DA(dDna, dnaW); DA(dReads, rdW); DA(dDnaLen, rnd); DA(dReadLen, rnd); DA(dClipLt, rnd); DA(dClipRt, rnd); DA(dAL, rnd); DA(dAR, rnd);
     DA(dCut, rnd); DA(dScores, rnd); DA(dHit, rnd); DA(dStart, rnd); DA(dCnt, rnd); DA(dCols, rnd);
-    DA(dPattern, (size_t)maxProblems * h->patternLen); DA(dPatMax, 4);
+    DA(dPattern, (size_t)maxProblems * h->patternLen); DA(dPatMax, 4); DA(dCells, 2);
     DA(dTable, h->tableWords * maxProblems);
 #undef DA
 #define HIPD(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { s3_dp_free(h); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
     HIPD(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPD(hipEventCreate(&h->ev[0])); HIPD(hipEventCreate(&h->ev[1]));
+    HIPD(hipMemset(h->dCells, 0, 8));
 #undef HIPD
     *outp = h;
     return S3_OK;
@@ -169,9 +170,33 @@ int s3i::dpDump(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL
 }
 
 // launch the DP kernels on what is in the aligner's device buffers
+// cells of a launch (read length x window length per problem), summed into the aligner's running total
+__global__ void dpCellsKernel(uint32_t n, const uint32_t *dnaLen, const uint32_t *readLen, unsigned long long *total)
+{
+    unsigned long long c = 0;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) c += (unsigned long long)dnaLen[k] * readLen[k];
+    for (int d = 32; d; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(total, c);
+}
+
+// the device time of the last launch joins the running total (its events are about to be recorded again)
+static int dpFoldTiming(s3_dp *h)
+{
+    if (!h->timed || h->folded) return S3_OK;
+    float ms = 0;
+    HIPCHK(hipEventSynchronize(h->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    h->totalMs += ms;
+    h->folded = true;
+    return S3_OK;
+}
+
 int s3i::dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR)
 {
     hipStream_t s = h->stream;
+    { int rc = dpFoldTiming(h); if (rc) return rc; }
+    h->totalProblems += n;
+    if (n) hipLaunchKernelGGL(dpCellsKernel, dim3(std::min<uint32_t>((n + 255u) / 256u, 1024u)), dim3(256), 0, s, n, h->dDnaLen, h->dReadLen, h->dCells);
     DpArgs a{};
     a.dna = h->dDna; a.dnaLengths = h->dDnaLen; a.reads = h->dReads; a.readLengths = h->dReadLen;
     a.clipLt = hasClipLt ? h->dClipLt : nullptr; a.clipRt = hasClipRt ? h->dClipRt : nullptr;
@@ -194,7 +219,7 @@ int s3i::dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL,
     }
     HIPCHK(hipEventRecord(h->ev[1], s));
     HIPCHK(hipGetLastError());
-    h->timed = true;
+    h->timed = true; h->folded = false;
     return S3_OK;
 }
 
@@ -881,6 +906,20 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
     memcpy(cp, pool.data(), pool.size());
     if (tm) { memcpy(tm, tooMany.data(), nPairs); *tooManyHitsOut = tm; }
     *resultsOut = out; *nResultsOut = results.size(); *cigarPoolOut = cp;
+    return S3_OK;
+}
+
+extern "C" int s3_dp_totals(s3_dp *h, double *kernelMs, uint64_t *problems, uint64_t *cells)
+{
+    if (!h) return fail(S3_EINVAL, "null aligner");
+    HIPCHK(hipSetDevice(h->dev));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    { int rc = dpFoldTiming(h); if (rc) return rc; }
+    unsigned long long c = 0;
+    HIPCHK(hipMemcpy(&c, h->dCells, 8, hipMemcpyDeviceToHost));
+    if (kernelMs) *kernelMs = h->totalMs;
+    if (problems) *problems = h->totalProblems;
+    if (cells) *cells = c;
     return S3_OK;
 }
 

@@ -115,7 +115,10 @@ struct s3_dp {
     unsigned char *dPattern = nullptr;
     uint32_t *dPatMax = nullptr;           // longest pattern of the last launch (bytes with the terminator)
     size_t tableWords = 0;
-    bool timed = false;
+    bool timed = false, folded = true;
+    double totalMs = 0;                    // device time of every launch since the aligner was made (s3_dp_totals) ...
+    uint64_t totalProblems = 0;            // ... the problems of those launches ...
+    unsigned long long *dCells = nullptr;  // ... and their cells (device counter)
     std::vector<uint32_t> dumpClipRt;      // S3DP_DUMP_DP: the right clips as the packer set them (the kernel overwrites them)
 };
 

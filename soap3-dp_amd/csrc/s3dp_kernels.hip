@@ -587,6 +587,26 @@ void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *
 // ---------------------------------------------------------------------------------------------
 namespace s3 {
 
+// streaming copy, 16 bytes per lane and load, four independent loads in flight per lane
+typedef uint32_t s3_v4u __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) copyProbeKernel(const s3_v4u *__restrict__ src, s3_v4u *__restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const s3_v4u a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const s3_v4u c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+void launchCopyProbe(const uint4 *src, uint4 *dst, size_t n16, hipStream_t s)
+{
+    hipLaunchKernelGGL(copyProbeKernel, dim3(256 * 16), dim3(256), 0, s, (const s3_v4u *)src, (s3_v4u *)dst, n16);
+}
+
 template <int ILP>
 __global__ void __launch_bounds__(256) gatherProbeKernel(const uint4 *table, uint64_t nLines, uint32_t itersPerLane, int loadsPerLine, int dependent,
                                                          uint32_t *sink)

@@ -67,6 +67,29 @@ __device__ __forceinline__ uint4 rankFromWords(const RankSel &q, uint4 occ, uint
 
 struct Range { uint32_t fl, fr, rl, rr; };
 
+// the model step a lane is in, as the five words of S3Step with the check-and-extend threshold moved into the (unused) type byte
+struct StepC {
+    uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ int start() const { return (int)(int16_t)(w0 & 0xFFFFu); }
+    __device__ __forceinline__ int end() const { return (int)w0 >> 16; }
+    __device__ __forceinline__ int ceStart() const { return (int)(int16_t)(w1 & 0xFFFFu); }
+    __device__ __forceinline__ int ceEnd() const { return (int)w1 >> 16; }
+    __device__ __forceinline__ int lm0() const { return (int)(int16_t)(w2 & 0xFFFFu); }
+    __device__ __forceinline__ int len() const { return (int)w2 >> 16; }
+    __device__ __forceinline__ int dir() const { return (int)(int8_t)(w3 & 0xFFu); }
+    __device__ __forceinline__ int ceThr() const { return (int)((w3 >> 8) & 0xFFu); }
+    __device__ __forceinline__ int minErr() const { return (int)((w3 >> 16) & 0xFFu); }
+    __device__ __forceinline__ int maxErr() const { return (int)(w3 >> 24); }
+};
+__device__ __forceinline__ StepC packStep(const uint32_t *p)
+{
+    StepC c;
+    c.w0 = p[0]; c.w1 = p[1]; c.w2 = p[2];
+    c.w3 = (p[3] & 0xFFFF00FFu) | ((p[4] & 0xFFu) << 8);
+    return c;
+}
+
+
 }  // namespace v2
 
 }  // namespace s3

@@ -754,8 +754,11 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
             const uint32_t U = in.unitsPerItem;
             if (out.dynCap && item >= out.dynBase) item = out.dynOwner[item - out.dynBase];      // counted by an adopted frame: the unit its chain started from
             const uint32_t unit = item - in.unitBase;
-            slotOf = out.heavyList[unit / (groups * U)];
+            const uint32_t listed = unit / (groups * U);
+            slotOf = out.heavyList[listed];
             item = slotOf * groups + (unit / U) % groups;
+            // a task of a unit behind its read's cut: the units in front of it hold MaxOutputPerRead occurrences for sure, the merge never gets here
+            if (out.readCut && unit - listed * groups * U > out.readCut[listed]) task = false;
         } else if (task && out.heavyFlags[slotOf]) task = false;                 // stale: the second pass searched this read again
         const uint32_t size = task ? (rec.w & 0xFFu) + 1u : 0u;
         // exclusive prefix sum of the sizes over the wave

@@ -40,27 +40,6 @@ using namespace v2;
 namespace unit {
 enum : uint32_t { U_IDLE = 0, U_STEP = 1, U_LOAD = 2, U_ADOPT = 3, U_POPWAIT = 4, U_CE_SA = 5, U_CE_TEXT = 6, U_RESUME = 7, U_DONE = 8 };
 
-// the model step a lane is in, as the five words of S3Step with the check-and-extend threshold moved into the (unused) type byte
-struct StepC {
-    uint32_t w0, w1, w2, w3;
-    __device__ __forceinline__ int start() const { return (int)(int16_t)(w0 & 0xFFFFu); }
-    __device__ __forceinline__ int end() const { return (int)w0 >> 16; }
-    __device__ __forceinline__ int ceStart() const { return (int)(int16_t)(w1 & 0xFFFFu); }
-    __device__ __forceinline__ int ceEnd() const { return (int)w1 >> 16; }
-    __device__ __forceinline__ int lm0() const { return (int)(int16_t)(w2 & 0xFFFFu); }
-    __device__ __forceinline__ int len() const { return (int)w2 >> 16; }
-    __device__ __forceinline__ int dir() const { return (int)(int8_t)(w3 & 0xFFu); }
-    __device__ __forceinline__ int ceThr() const { return (int)((w3 >> 8) & 0xFFu); }
-    __device__ __forceinline__ int minErr() const { return (int)((w3 >> 16) & 0xFFu); }
-    __device__ __forceinline__ int maxErr() const { return (int)(w3 >> 24); }
-};
-__device__ __forceinline__ StepC packStep(const uint32_t *p)
-{
-    StepC c;
-    c.w0 = p[0]; c.w1 = p[1]; c.w2 = p[2];
-    c.w3 = (p[3] & 0xFFFF00FFu) | ((p[4] & 0xFFu) << 8);
-    return c;
-}
 }  // namespace unit
 
 using namespace unit;
@@ -96,11 +75,14 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 
     // ---- statistics (COUNT) ----
     uint32_t nRank = 0, nSaL = 0, nCeL = 0, nCutSkip = 0, nCutMid = 0, unitTrips = 0, maxUnitTrips = 0, nAdopt = 0;
-    unsigned long long laneTrips = 0;
+    unsigned long long laneTrips = 0, waveTrips = 0;
 
     // ---- per-lane state ----
     uint32_t state = U_IDLE;
-    uint32_t fl = 0, fr = 0, rl = 0;                                        // the range (rr = rl + fr - fl)
+    // The range, seen from the direction of the step the lane is in: the ACTIVE range [aL, aR] is the one the step's rank queries move (the forward
+    // range in a backward step, the reverse range in a forward step), the passive one ends at pR and has the same size.  Frames on the stack are
+    // kept the same way (their step says which way round); the roles swap when a step of the other direction begins.
+    uint32_t aL = 0, aR = 0, pR = 0;
     int s = 0, i = 0, ins = 0, occ = 0;
     StepC sc = {0, 0, 0, 0};
     int Li = UNIFORM ? (int)in.uniformLen : 0;
@@ -159,6 +141,9 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         tos = f; tosValid = true;
     };
     auto loadStepCache = [&]() { sc = packStep(stepPtr(s)); };
+    // first and last element of the FORWARD range (what records, tasks and the suffix array speak of); sc is the step the range was last moved by
+    auto fwdL = [&]() -> uint32_t { return sc.dir() < 0 ? aL : pR - (aR - aL); };
+    auto fwdR = [&]() -> uint32_t { return sc.dir() < 0 ? aR : pR; };
 
     // advance without memory until the lane needs ranks / SA / text / its next frame, or its unit is finished
     auto settle = [&](bool needPop) {
@@ -167,7 +152,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (needPop) {
                 if (sp == sb) { state = U_DONE; return; }
                 if (!tosValid) { state = U_POPWAIT; return; }               // the frame comes with the next trip's loads
-                fl = tos.x; fr = tos.y; rl = tos.z;
+                aL = tos.x; aR = tos.y; pR = tos.z;
                 const uint32_t m = tos.w;
                 s = (int)(m & 7u); i = (int)((m >> 3) & 0x7FFu); ins = (int)((m >> 14) & 7u); occ = (int)((m >> 17) & 7u);
                 sp--; tosValid = false;
@@ -175,8 +160,8 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 if (s < nSteps) loadStepCache();
             }
             if (s >= nSteps) {                                               // SRA_STEP_TYPE_COMPLETE
-                uint32_t l = fl, rr_ = fr;
-                if (rr_ >= l) {
+                uint32_t l = fwdL(), rr_ = fwdR();
+                if (aR >= aL) {
                     if (pendMeta >> 31) { state = U_RESUME; return; }        // one record per lane and trip: this frame waits for the next trip
                     if (total + (rr_ - l + 1u) > in.maxOut) rr_ = l + in.maxOut - total - 1u;
                     emit(0, l, rr_, (uint32_t)(ins + occ));
@@ -189,16 +174,16 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             const bool exact = ins >= sc.maxErr();
             int lenEff = sc.len();
             if (!exact && sc.minErr() > ins + 1) lenEff -= sc.minErr() - ins - 1;
-            const bool alive = fl <= fr;
+            const bool alive = aL <= aR;
             if (i < lenEff && alive) {
                 const int pos = sc.start() + sc.dir() * i;
-                if ((fr - fl) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd()) {
-                    if ((ceHist & 0xFFFFu) < giveUp) { ceL = fl; ceNK = fr - fl + 1u; state = U_CE_SA; return; }      // the lane verifies them itself
+                if ((aR - aL) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd()) {
+                    if ((ceHist & 0xFFFFu) < giveUp) { ceL = fwdL(); ceNK = aR - aL + 1u; state = U_CE_SA; return; }      // the lane verifies them itself
                     if (pendMeta >> 31) { state = U_RESUME; return; }
                     pendMeta = 0x80000000u | seq | S3_REC_TASK;
-                    pendA = fl;
-                    pendB = (fr - fl) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
-                    seq += fr - fl + 1u;
+                    pendA = fwdL();
+                    pendB = (aR - aL) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+                    seq += aR - aL + 1u;
                     needPop = true;
                     continue;
                 }
@@ -207,7 +192,11 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             }
             if (ins >= sc.minErr() && alive) {
                 occ += ins; ins = 0; s++; i = 0;
-                if (s < nSteps) loadStepCache();
+                if (s < nSteps) {
+                    const int was = sc.dir();
+                    loadStepCache();
+                    if (sc.dir() != was) { const uint32_t oldR = aR; aL = pR - (aR - aL); aR = pR; pR = oldR; }      // the other index moves from here on
+                }
                 continue;
             }
             needPop = true;
@@ -226,7 +215,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
             const uint32_t e = rdyTaken + rank, avail = rdyCount - rdyTaken;
             if (state == U_IDLE && rank < avail) {
-                fl = rdy[e]; fr = rdy[64u + e]; rl = rdy[128u + e];
+                aL = rdy[e]; aR = rdy[64u + e]; pR = rdy[128u + e];          // the trunk state {l, r, rev l}: turned the step's way when the step is known
                 listed = rdy[192u + e]; unitInRead = rdy[256u + e]; aux = rdy[320u + e];
                 const uint32_t sub = unitInRead / U, p = unitInRead - sub * U;
                 const uint32_t cas = sub >> 1;
@@ -310,22 +299,22 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 
         // ---------- what does this lane need?  Addresses only: every lane issues the same loads, back to back, with no branch between them (a load
         // inside a branch makes the compiler wait for it at the join); a lane that needs nothing reads a cache-hot dummy ----------
-        uint32_t idA = ID_NONE, iL = 0, iR = 0;
+        uint32_t iL = 0, iR = 0, textLine = 0;
         bool needB = false;
         int dir = 0;
         const uint4 *dummy16 = (const uint4 *)ix.pac;
+        const uint4 *ownLine = ix.fwd.lines;                                    // the 64-byte line this lane wants fetched by its quad (nothing: line 0)
         const uint4 *aP0 = dummy16, *aP1 = dummy16, *aPT = dummy16;
         const uint32_t *aD0 = ix.pac, *aCut = ix.pac;
         if (state == U_STEP) {
             dir = sc.dir();
             const uint32_t inv = dir < 0 ? ix.fwd.inverseSa0 : ix.rev.inverseSa0;
-            const uint32_t rr = rl + (fr - fl);
-            iL = dir < 0 ? fl : rl;
-            iR = (dir < 0 ? fr : rr) + 1u;
+            iL = aL;
+            iR = aR + 1u;
             iL -= (iL > inv);
             iR -= (iR > inv);
             const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
-            idA = kL | (dir < 0 ? 0u : 0x80000000u);
+            ownLine = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kL * 4u;
             needB = kR != kL;
             if (needB) {
                 const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
@@ -339,7 +328,8 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             const S3Step st = stepAt(ceT);
             const int pos = st.start + st.dir * ceII;
             const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end);
-            idA = ID_TEXT | ((ceRp + left + (ceProg & 0xFFFFu)) >> 8);
+            textLine = (ceRp + left + (ceProg & 0xFFFFu)) >> 8;
+            ownLine = (const uint4 *)ix.pac + (size_t)textLine * 4u;
             if ((ceNK >> 8) + 1u < (ceNK & 0xFFu)) aD0 = ix.sa + ceL + (ceNK >> 8) + 1u;     // the next candidate's suffix-array entry rides along
         } else if (state == U_CE_SA) {
             aD0 = ix.sa + ceL + (ceNK >> 8);
@@ -356,19 +346,16 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         const bool wantCut = wantTos || state == U_CE_SA || state == U_CE_TEXT || state == U_ADOPT;
         if (wantTos) aPT = stk + ((sp - 1u) & (S3_UNIT_STACK - 1u)) * 64u + lane;
         if (wantCut) aCut = out.readCut + listed;
-        // ---------- issue: the cooperative lines (4 adjacent lanes fetch the 4 x 16 B of one owner's line; owners without a request: line 0), then what
-        // single lanes need ----------
+        // ---------- issue: the cooperative lines (4 adjacent lanes fetch the 4 x 16 B of one owner's line: the owner's address travels by ds_bpermute,
+        // two words), then what single lanes need ----------
         const uint32_t q16 = lane & 3u, q4 = lane >> 2;
-        const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((q4) * 4u), (int)idA);
-        const uint32_t o1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((16u + q4) * 4u), (int)idA);
-        const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((32u + q4) * 4u), (int)idA);
-        const uint32_t o3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((48u + q4) * 4u), (int)idA);
-        auto lineAddr = [&](uint32_t o) -> const uint4 * {
-            if (o != ID_NONE && (o >> 30) == 1u) return (const uint4 *)ix.pac + (size_t)(o & 0x3FFFFFFFu) * 4u + q16;
-            const uint4 *base = (o >> 31) ? ix.rev.lines : ix.fwd.lines;
-            return base + (o == ID_NONE ? (size_t)q16 : (size_t)(o & 0x7FFFFFFFu) * 4u + q16);
+        const uint32_t ownLo = (uint32_t)(uintptr_t)ownLine, ownHi = (uint32_t)((uintptr_t)ownLine >> 32);
+        auto quadLine = [&](uint32_t owner) -> const uint4 * {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownLo);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownHi);
+            return (const uint4 *)(((uintptr_t)hi << 32) | lo) + q16;
         };
-        const uint4 va0 = *lineAddr(o0), va1 = *lineAddr(o1), va2 = *lineAddr(o2), va3 = *lineAddr(o3);
+        const uint4 va0 = *quadLine(q4), va1 = *quadLine(16u + q4), va2 = *quadLine(32u + q4), va3 = *quadLine(48u + q4);
         const uint4 p0 = *aP0, p1 = *aP1, pT = *aPT;
         const uint32_t d0 = *aD0;
         const uint32_t dCut = __hip_atomic_load(aCut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -419,7 +406,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 
         // ---------- advance ----------
         bool doSettle = false, needPop = false;
-        if constexpr (COUNT) { if (state != U_IDLE) { unitTrips++; laneTrips++; if (unitTrips > maxUnitTrips) maxUnitTrips = unitTrips; } }
+        if constexpr (COUNT) { waveTrips++; if (state != U_IDLE) { unitTrips++; laneTrips++; if (unitTrips > maxUnitTrips) maxUnitTrips = unitTrips; } }
         if (wantTos) { tos = pT; tosValid = true; }
         if (wantCut && unitInRead > dCut && state != U_ADOPT) {                  // behind the read's cut
             if constexpr (COUNT) nCutMid++;
@@ -443,39 +430,39 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             const uint32_t ch = readChar(pos);
             // child ranges: the active range advances by rank, the passive one shrinks by the occurrences of the larger symbols
             const uint32_t e1 = oR.y - oL.y, e2 = oR.z - oL.z, e3 = oR.w - oL.w;
-            const uint32_t base = dir < 0 ? rl + (fr - fl) : fr;
-            // a child as a frame {fl, fr, rl}: active range [al, ar], passive range ending `oc` (the occurrences of larger symbols) below `base`
-            auto childFl = [&](uint32_t al, uint32_t ar, uint32_t oc) -> uint32_t { return dir < 0 ? al : base - oc - (ar - al); };
-            auto childFr = [&](uint32_t al, uint32_t ar, uint32_t oc) -> uint32_t { return dir < 0 ? ar : base - oc; };
-            auto childRl = [&](uint32_t al, uint32_t ar, uint32_t oc) -> uint32_t { return dir < 0 ? base - oc - (ar - al) : al; };
-            const uint32_t cAl = sel4(oL, ch) + 1u, cAr = sel4(oR, ch);
             const uint32_t cOc = ch == 0 ? e1 + e2 + e3 : ch == 1 ? e2 + e3 : ch == 2 ? e3 : 0u;
-            const uint32_t gFl = childFl(cAl, cAr, cOc), gFr = childFr(cAl, cAr, cOc), gRl = childRl(cAl, cAr, cOc);
+            const uint32_t gAl = sel4(oL, ch) + 1u, gAr = sel4(oR, ch), gPr = pR - cOc;         // the continuation (the read's own character)
             doSettle = true;
             const bool branchOnly = first;                                     // the unit's position: only the mismatch children (the continuation belongs to the later units)
             first = false;
+            bool taken = false;                                                // the lane goes on in a mismatch child
             if (!exact) {
                 const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
                 const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
                 if (a0 || a1 || a2 || a3) {
                     if (sp - sb + 4u > S3_UNIT_STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = U_DONE; sp = sb; tosValid = false; doSettle = false; }
                     else {
+                        // depth-first, children in ascending order, the continuation last: the lane goes on in the smallest child that is alive, the
+                        // others wait on the stack (pushed in descending order), the continuation below them
                         const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
                         const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
-                        if (!branchOnly) push(gFl, gFr, gRl, mCont);
-                        if (a3) push(childFl(oL.w + 1u, oR.w, 0u), childFr(oL.w + 1u, oR.w, 0u), childRl(oL.w + 1u, oR.w, 0u), mKid);
-                        if (a2) push(childFl(oL.z + 1u, oR.z, e3), childFr(oL.z + 1u, oR.z, e3), childRl(oL.z + 1u, oR.z, e3), mKid);
-                        if (a1) push(childFl(oL.y + 1u, oR.y, e2 + e3), childFr(oL.y + 1u, oR.y, e2 + e3), childRl(oL.y + 1u, oR.y, e2 + e3), mKid);
-                        if (a0) push(childFl(oL.x + 1u, oR.x, e1 + e2 + e3), childFr(oL.x + 1u, oR.x, e1 + e2 + e3), childRl(oL.x + 1u, oR.x, e1 + e2 + e3), mKid);
-                        needPop = true;                                        // (the frame pushed last is in `tos`: the pop takes it from there)
+                        const uint32_t kid = a0 ? 0u : a1 ? 1u : a2 ? 2u : 3u;
+                        if (!branchOnly) push(gAl, gAr, gPr, mCont);
+                        if (a3 && kid != 3u) push(oL.w + 1u, oR.w, pR, mKid);
+                        if (a2 && kid != 2u) push(oL.z + 1u, oR.z, pR - e3, mKid);
+                        if (a1 && kid != 1u) push(oL.y + 1u, oR.y, pR - (e2 + e3), mKid);
+                        const uint32_t kOc = kid == 0u ? e1 + e2 + e3 : kid == 1u ? e2 + e3 : kid == 2u ? e3 : 0u;
+                        aL = sel4(oL, kid) + 1u; aR = sel4(oR, kid); pR = pR - kOc;
+                        ins++; i++;
+                        taken = true;
                     }
                 } else if (branchOnly) needPop = true;                         // no child alive: the unit is empty
             } else if (branchOnly) needPop = true;
-            if (doSettle && !needPop) { fl = gFl; fr = gFr; rl = gRl; i++; }
+            if (doSettle && !needPop && !taken) { aL = gAl; aR = gAr; pR = gPr; i++; }
         } else if (state == U_RESUME) { doSettle = true; needPop = false; }
         else if (state == U_POPWAIT) { doSettle = true; needPop = true; }
         else if (state == U_ADOPT) {
-            fl = p0.x; fr = p0.y; rl = p0.z;
+            aL = p0.x; aR = p0.y; pR = p0.z;
             s = (int)(p0.w & 7u); i = (int)((p0.w >> 3) & 0x7FFu); ins = (int)((p0.w >> 14) & 7u); occ = (int)((p0.w >> 17) & 7u);
             if (s < nSteps) loadStepCache();
             if (unitInRead > dCut) { state = U_DONE; if constexpr (COUNT) nCutMid++; }
@@ -491,6 +478,12 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if constexpr (!UNIFORM) Li = (int)saVal;
             if (loadOff >= wl || loadOff >= wpq) {
                 loadStepCache();
+                {
+                    // the trunk state {l, r, rev l} the step's way round
+                    const uint32_t l = aL, r = aR, rvl = pR;
+                    if (sc.dir() < 0) pR = rvl + (r - l);
+                    else { aL = rvl; aR = rvl + (r - l); pR = r; }
+                }
                 if (first) state = U_STEP;
                 else { i = sc.len(); doSettle = true; needPop = false; }         // the unit without a mismatch in this step: behind its last position
             }
@@ -502,7 +495,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             const uint32_t ceN = ceNK & 0xFFu;
             uint32_t ceK = ceNK >> 8;
             const bool haveNext = textHere && ceK + 1u < ceN;                 // ... and the next candidate's entry came along
-            const uint32_t lineHere = idA & 0x3FFFFFFFu;
+            const uint32_t lineHere = textLine;
             int ceT = (int)(ceWhere & 7u), ceII = (int)((ceWhere >> 3) & 0x7FFu), ceIns = (int)((ceWhere >> 14) & 7u), ceAcc = (int)((ceWhere >> 17) & 0x7Fu);
             int ceOff = (int)(ceProg & 0xFFFFu), ceMm = (int)(ceProg >> 16);
             uint32_t ceMiss = ceHist & 0xFFFFu, ceTaken = ceHist >> 16;
@@ -637,6 +630,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             atomicAdd(&out.counters[6], laneTrips);
             atomicMax(&out.counters[7], (unsigned long long)maxUnitTrips);
             atomicAdd(&out.counters[8], (unsigned long long)nAdopt);
+            if (lane == 0) atomicAdd(&out.counters[9], waveTrips);
         }
     }
 }

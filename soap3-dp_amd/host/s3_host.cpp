@@ -735,7 +735,7 @@ SamWriter::SamWriter(const HostIndex &ix_, const SamOptions &o, std::string *sk)
 void SamWriter::put(const std::string &line)
 {
     if (sink) sink->append(line);
-    else if (bamFileOf(out)) { if (!bamWriteLines(out, line.data(), line.size())) { fprintf(stderr, "write error on the output file\n"); exit(1); } }
+    else if (bamFileOf(out)) { if (!bamWriteLines(out, line.data(), line.size())) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); } }
     else fwrite(line.data(), 1, line.size(), out);
     nRecords++;
 }
@@ -746,7 +746,7 @@ void SamWriter::header()
     std::string h = "@HD\tVN:1.3\tSO:unsorted\n@RG\tID:" + opt.readGroup + "\tSM:" + opt.sampleName + "\t" + opt.readGrpOption + "\n";
     for (int i = 0; i < ix.numOfSeq; i++) h += "@SQ\tSN:" + ix.seqName[i] + "\tLN:" + std::to_string(ix.actualEnd[i] - ix.actualStart[i]) + "\n";
     h += std::string("@PG\tID:SOAP3-dp\tPN:SOAP3-dp\tVN:") + s3_version() + "\n";
-    if (bamFileOf(out)) { if (!bamWriteHeader(out, h)) { fprintf(stderr, "write error on the output file\n"); exit(1); } }
+    if (bamFileOf(out)) { if (!bamWriteHeader(out, h)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); } }
     else fwrite(h.data(), 1, h.size(), out);
 }
 

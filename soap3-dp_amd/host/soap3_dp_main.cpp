@@ -87,14 +87,14 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
         if (bam) {
             // -b 3: this thread's records as BAM, in BGZF blocks of their own (blocks are independent: the parts are written behind each other)
             std::string raw, err;
-            if (!samTextToBam(bam->refNames, buf[(size_t)t].data(), buf[(size_t)t].size(), raw, err)) { fprintf(stderr, "BAM output: %s\n", err.c_str()); exit(1); }
+            if (!samTextToBam(bam->refNames, buf[(size_t)t].data(), buf[(size_t)t].size(), raw, err)) { fprintf(stderr, "BAM output: %s\n", err.c_str()); fflush(stdout); fflush(stderr); _exit(1); }
             buf[(size_t)t].clear();
-            if (!bgzfCompress(raw.data(), raw.size(), buf[(size_t)t], bam->level)) { fprintf(stderr, "BAM output: compression failed\n"); exit(1); }
+            if (!bgzfCompress(raw.data(), raw.size(), buf[(size_t)t], bam->level)) { fprintf(stderr, "BAM output: compression failed\n"); fflush(stdout); fflush(stderr); _exit(1); }
         }
     });
     for (auto &x : th) x.join();
     // the buffers go to the file at their final offsets, a few writers at a time
-    if (!bamFlush(out)) { fprintf(stderr, "write error on the output file\n"); exit(1); }
+    if (!bamFlush(out)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); }
     fflush(out);
     const int fd = fileno(out);
     std::vector<long long> off((size_t)T + 1, 0);
@@ -115,7 +115,7 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
         }
     });
     for (auto &x : wr) x.join();
-    if (bad) { fprintf(stderr, "write error on the output file\n"); exit(1); }
+    if (bad) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); }
     fseeko(out, (off_t)off[(size_t)T], SEEK_SET);
 }
 
@@ -196,6 +196,19 @@ static bool singleDpRuns(const HostIndex &hix, const SamOptions &so, FILE *paral
 
 static std::mutex g_pairStageMu;                                 // (several devices run the stages at once)
 static double g_pairStageSeconds[5] = {0, 0, 0, 0, 0};          // routing, default DP, new default DP, deep DP, single-end DP of the leftovers
+static double g_deviceMs[4] = {0, 0, 0, 0};                        // device time: BWT stages (ladder), their search kernels; DP kernels; (spare)
+static uint64_t g_dpProblems = 0, g_dpCells = 0;
+static void addDeviceMs(int k, double ms) { std::lock_guard<std::mutex> g(g_pairStageMu); g_deviceMs[k] += ms; }
+static void addBatchTiming(s3_batch *b)
+{
+    float tot = 0, search = 0; uint32_t launches = 0;
+    if (s3_batch_last_timing(b, &tot, &search, &launches) == S3_OK) { addDeviceMs(0, tot); addDeviceMs(1, search); }
+}
+static void addDpTotals(s3_dp *h)
+{
+    double ms = 0; uint64_t pr = 0, cells = 0;
+    if (h && s3_dp_totals(h, &ms, &pr, &cells) == S3_OK) { std::lock_guard<std::mutex> g(g_pairStageMu); g_deviceMs[2] += ms; g_dpProblems += pr; g_dpCells += cells; }
+}
 static double pairStageSeconds(int k) { std::lock_guard<std::mutex> g(g_pairStageMu); return g_pairStageSeconds[k]; }
 
 // ---- DP stages of a paired-end batch (soap3_dp_pair_align after the BWT ladder, alignment.cu:2021-2420) --------------------------------------
@@ -493,6 +506,7 @@ struct SharedIndex {
 
 static int runJob(int argc, char **argv, SharedIndex &shared)
 {
+    { std::lock_guard<std::mutex> g(g_pairStageMu); for (double &x : g_pairStageSeconds) x = 0; for (double &x : g_deviceMs) x = 0; g_dpProblems = g_dpCells = 0; }   // (per job: the *-multi modes run several)
     if (argc < 4) return die("usage: soap3-dp single <index> <reads> [options]\n       soap3-dp pair <index> <reads 1> <reads 2> [-u max insert] [-v min insert] [options]\n"
                              "       soap3-dp single-multi <index> <list file> [options]\n       soap3-dp pair-multi <index> <list file> [options]");
     const bool paired = strcmp(argv[1], "pair") == 0;
@@ -817,6 +831,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 if (s3_batch_align_pair(b, (uint32_t)numMismatch, ini.maxHitsEachEndForPairing, alignmentType, (uint32_t)insertLow, (uint32_t)insertHigh,
                                         ini.peMaxOutputPerPair) != S3_OK) return dieJoin(s3_last_error());
                 if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, ooff.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return dieJoin(s3_last_error());
+                addBatchTiming(b);
                 xa.resize(nXa ? nXa : 1); pos.resize(nOcc ? nOcc : 1); strand.resize(nOcc ? nOcc : 1); mis.resize(nOcc ? nOcc : 1); fromSa.resize(nOcc ? nOcc : 1);
                 if (s3_batch_fetch_pairs(b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK)
                     return dieJoin(s3_last_error());
@@ -855,6 +870,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         std::vector<uint64_t> offs((size_t)cnt + 1);
         uint64_t nOcc = 0;
         if (s3_batch_fetch_alignments(b, phase.data(), nullptr, offs.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return dieJoin(s3_last_error());
+        addBatchTiming(b);
         std::vector<uint32_t> pos(nOcc ? nOcc : 1);
         std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
         if (s3_batch_fetch_alignments(b, nullptr, nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK) return dieJoin(s3_last_error());
@@ -893,16 +909,18 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             for (uint32_t k : todo) if (!doneFlag[k]) w.unaligned(rs, first + k);
         }
     }
-    auto closeOut = [&](FILE *f) { if (!bamClose(f)) { fprintf(stderr, "write error on the output file\n"); exit(1); } fclose(f); };
+    auto closeOut = [&](FILE *f) { if (!bamClose(f)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); } fclose(f); };
     closeOut(out);
     if (dpOut) {
         closeOut(dpOut);
         if (paired) {
             closeOut(unpairOut);
             dpAlignedReads = 2 * (defaultDpPairs + newDefaultPairs + deepDpPairs);
+            addDpTotals(dpHalf);
             s3_dp_free(dpHalf);
         }
         aligned += dpAlignedReads;
+        addDpTotals(dp);
         s3_dp_free(dp);
         s3_batch_free(seedBatch);
     }
@@ -932,6 +950,11 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                    (unsigned long long)counters[C_LEFTOVER], dpStageSeconds, pairStageSeconds(0), pairStageSeconds(1), pairStageSeconds(2), pairStageSeconds(3), pairStageSeconds(4));
         else printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)counters[C_DP_READS]);
     }
+    // device time of the run (HIP events): the BWT stages with their search kernels, and every launch of the DP kernels with the cells they filled
+    printf("[Main] Device time : BWT stages %.1f ms (search kernels %.1f ms)", g_deviceMs[0], g_deviceMs[1]);
+    if (enableDP) printf(", DP kernels %.1f ms, %llu problems, %llu cells, %.1f GCUPS", g_deviceMs[2], (unsigned long long)g_dpProblems, (unsigned long long)g_dpCells,
+                         g_deviceMs[2] > 0 ? (double)g_dpCells / (g_deviceMs[2] * 1e-3) / 1e9 : 0.0);
+    printf("\n");
     if (nMembers > 1) printf("[Main] Devices: %d (index replicated, chunks of %u reads dealt as the devices come free, counters summed by one all-reduce)\n", nMembers, chunkReads);
     printf("[Main] Alignment + output time : %9.4f seconds\n[Main] Total elapsed time : %9.4f seconds\n", since(tAlign), since(t0));
     printf("[Main] Overall number of reads aligned: %llu\n", (unsigned long long)aligned);
