@@ -44,6 +44,35 @@ REPEAT_FAMILIES = (
 )
 
 
+# Other repeat models (--repeat-model), to see that the thresholds of the heavy-read machinery (S3DP_HEAVY, S3DP_HEAVY_RANK, S3DP_CE_GIVE_UP ...) are not
+# tuned to one genome: "young" -- three times the share of young, near-identical copies (reads that hit MaxOutputPerRead everywhere); "old" -- hardly any
+# young copies and older ones further from their consensus (many dead ends, few hits); "satellite-heavy" -- 15 % tandem arrays and fewer dispersed copies.
+REPEAT_MODELS = {
+    "grch38-like": REPEAT_FAMILIES,
+    "young": (
+        ("sine_alu_like", 0.10, 300, (0.85, 1.0), 0.45, (0.002, 0.01), (0.05, 0.15)),
+        ("line_l1_like", 0.17, 6000, (0.03, 1.0), 0.15, (0.002, 0.01), (0.03, 0.15)),
+        ("mid_families", 0.15, 0, (0.3, 1.0), 0.30, (0.005, 0.02), (0.02, 0.12)),
+        ("segmental_duplications", 0.05, -1, (1.0, 1.0), 1.0, (0.002, 0.01), (0.002, 0.01)),
+        ("satellites", 0.03, 171, (1.0, 1.0), 1.0, (0.005, 0.02), (0.005, 0.02)),
+    ),
+    "old": (
+        ("sine_alu_like", 0.10, 300, (0.85, 1.0), 0.02, (0.01, 0.03), (0.10, 0.20)),
+        ("line_l1_like", 0.17, 6000, (0.03, 1.0), 0.01, (0.01, 0.03), (0.08, 0.20)),
+        ("mid_families", 0.15, 0, (0.3, 1.0), 0.02, (0.02, 0.04), (0.08, 0.18)),
+        ("segmental_duplications", 0.05, -1, (1.0, 1.0), 1.0, (0.02, 0.05), (0.02, 0.05)),
+        ("satellites", 0.03, 171, (1.0, 1.0), 1.0, (0.03, 0.08), (0.03, 0.08)),
+    ),
+    "satellite-heavy": (
+        ("sine_alu_like", 0.08, 300, (0.85, 1.0), 0.15, (0.005, 0.02), (0.05, 0.15)),
+        ("line_l1_like", 0.12, 6000, (0.03, 1.0), 0.05, (0.005, 0.02), (0.03, 0.15)),
+        ("mid_families", 0.10, 0, (0.3, 1.0), 0.10, (0.01, 0.03), (0.02, 0.12)),
+        ("segmental_duplications", 0.05, -1, (1.0, 1.0), 1.0, (0.005, 0.02), (0.005, 0.02)),
+        ("satellites", 0.15, 171, (1.0, 1.0), 1.0, (0.005, 0.03), (0.005, 0.03)),
+    ),
+}
+
+
 def _plant(codes, unit, copies, frac_lo, frac_hi, young_share, young_div, old_div, g, tandem=0):
     """write `copies` mutated (and half of them reverse-complemented) copies of `unit` at random places; copies are 3'-anchored pieces of the
     unit (LINE-like truncation); tandem > 0: arrays of `tandem` units in a row instead of dispersed copies"""
@@ -91,7 +120,7 @@ def _plant(codes, unit, copies, frac_lo, frac_hi, young_share, young_div, old_di
         done += m
 
 
-def plant_repeats(codes, repeat_frac, seed):
+def plant_repeats(codes, repeat_frac, seed, model="grch38-like"):
     """overwrite about repeat_frac of `codes` with copies of repeat families (REPEAT_FAMILIES); returns the per-family copy counts"""
     import torch
     dev = codes.device
@@ -100,7 +129,7 @@ def plant_repeats(codes, repeat_frac, seed):
     g.manual_seed(seed)
     scale = repeat_frac / 0.5
     report = {}
-    for name, share, ulen, (flo, fhi), yshare, ydiv, odiv in REPEAT_FAMILIES:
+    for name, share, ulen, (flo, fhi), yshare, ydiv, odiv in REPEAT_MODELS[model]:
         budget = int(n * share * scale)
         if budget <= 0:
             continue
@@ -139,7 +168,7 @@ def plant_repeats(codes, repeat_frac, seed):
     return report
 
 
-def make_genome(n, seed, device, repeat_frac=0.0):
+def make_genome(n, seed, device, repeat_frac=0.0, model="grch38-like"):
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -148,7 +177,7 @@ def make_genome(n, seed, device, repeat_frac=0.0):
     for a in range(0, n, step):
         b = min(n, a + step)
         codes[a:b] = torch.randint(0, 4, (b - a,), generator=g, device=device, dtype=torch.uint8)
-    families = plant_repeats(codes, repeat_frac, seed + 1) if repeat_frac > 0 else {}
+    families = plant_repeats(codes, repeat_frac, seed + 1, model) if repeat_frac > 0 else {}
     return codes, families
 
 
@@ -244,36 +273,269 @@ def make_pairs(codes, n_pairs, L, seed, device):
     return out
 
 
-def extras(s3dp, ix, codes, dev, rank):
-    """secondary figures (not the headline metric): BASELINE configs[2] shapes -- 2 x 150 bp pairs through the paired-end BWT stage, and the
-    semi-global DP kernel on default-DP windows"""
+def make_pairs_c3(codes, n_pairs, L, seed, device, indel_frac=0.10):
+    """BASELINE.json configs[2]: 2 x L pairs, insert ~ N(350, 40) clipped to [L + 1, 500], '+/-' orientation, 0-4 substitutions per end
+    (55/25/12/5/3 %), and `indel_frac` of the MATES carry one 1-8 base indel (a deletion skips reference bases, an insertion adds random ones): such a
+    mate has no <= 4-mismatch hit, its pair is half-aligned and goes to the default DP.  Returns the reads (2 n x L codes, mates adjacent) and the truth:
+    leftmost reference position of either mate (0-based, of the mate as simulated: first file = row 2p), its strand, whether it carries an indel."""
     import torch
-    res = {}
-    L, n_pairs = 150, 2_000_000
-    reads2d = make_pairs(codes, n_pairs, L, 4242, dev)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n = codes.numel()
+    ins = torch.clamp(torch.round(torch.randn(n_pairs, generator=g, device=device) * 40 + 350), L + 1, 500).to(torch.int64)
+    start = torch.randint(0, n - 700, (n_pairs,), generator=g, device=device)
+    ar = torch.arange(L, device=device)
+    probs = torch.tensor((0.55, 0.25, 0.12, 0.05, 0.03), device=device)
+    ends, left_pos, has_indel = [], [], []
+    for base in (start, start + ins - L):                                   # the left mate, the right mate (both read off the forward strand here)
+        k = torch.randint(1, 9, (n_pairs,), generator=g, device=device)
+        is_del = torch.rand(n_pairs, generator=g, device=device) < 0.5
+        hit = torch.rand(n_pairs, generator=g, device=device) < indel_frac
+        c = torch.randint(30, L - 30, (n_pairs,), generator=g, device=device)
+        j = ar[None, :].expand(n_pairs, L)
+        # deletion of k at c: read[j] = ref[j] (j < c), ref[j + k] (j >= c);  insertion of k at c: ref[j] (j < c), random (c <= j < c + k), ref[j - k] (j >= c + k)
+        off = torch.where(is_del[:, None], (j >= c[:, None]) * k[:, None], -((j >= (c + k)[:, None]) * k[:, None]))
+        off = torch.where(hit[:, None], off, torch.zeros_like(off))
+        seg = codes[base[:, None] + j + off]
+        rnd = torch.randint(0, 4, (n_pairs, L), generator=g, device=device, dtype=torch.uint8)
+        inserted = hit[:, None] & ~is_del[:, None] & (j >= c[:, None]) & (j < (c + k)[:, None])
+        seg = torch.where(inserted, rnd, seg)
+        nsub = torch.multinomial(probs, n_pairs, replacement=True, generator=g)
+        kth = torch.topk(torch.rand((n_pairs, L), generator=g, device=device), 4, dim=1).indices
+        delta = torch.randint(1, 4, (n_pairs, 4), generator=g, device=device, dtype=torch.uint8)
+        for t in range(4):
+            rows = torch.nonzero(nsub > t).squeeze(1)
+            seg[rows, kth[rows, t]] = (seg[rows, kth[rows, t]] + delta[rows, t]) % 4
+        ends.append(seg)
+        left_pos.append(base)
+        has_indel.append(hit)
+    a, bb = ends[0], 3 - torch.flip(ends[1], [1])
+    swap = torch.rand(n_pairs, generator=g, device=device) < 0.5
+    out = torch.empty((2 * n_pairs, L), dtype=torch.uint8, device=device)
+    out[0::2] = torch.where(swap[:, None], bb, a)
+    out[1::2] = torch.where(swap[:, None], a, bb)
+    pos = torch.empty(2 * n_pairs, dtype=torch.int64, device=device)
+    pos[0::2] = torch.where(swap, left_pos[1], left_pos[0])
+    pos[1::2] = torch.where(swap, left_pos[0], left_pos[1])
+    strand = torch.empty(2 * n_pairs, dtype=torch.uint8, device=device)       # 0: read off the forward strand, 1: reverse complement
+    strand[0::2] = swap.to(torch.uint8)
+    strand[1::2] = (~swap).to(torch.uint8)
+    indel = torch.empty(2 * n_pairs, dtype=torch.bool, device=device)
+    indel[0::2] = torch.where(swap, has_indel[1], has_indel[0])
+    indel[1::2] = torch.where(swap, has_indel[0], has_indel[1])
+    return out, pos.cpu().numpy(), strand.cpu().numpy(), indel.cpu().numpy()
+
+
+def write_fastq_pairs(reads2d_np, L, path1, path2):
+    """the two FASTQ files of a pair set, records of fixed width (names are the pair numbers, qualities 'I'), built as byte matrices"""
+    n_pairs = reads2d_np.shape[0] // 2
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    names = np.char.zfill(np.arange(n_pairs).astype("U9"), 9).astype("S9")
+    name_bytes = np.frombuffer(names.tobytes(), dtype=np.uint8).reshape(n_pairs, 9)
+    for path, rows in ((path1, reads2d_np[0::2]), (path2, reads2d_np[1::2])):
+        rec = np.empty((n_pairs, 1 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
+        rec[:, 0] = ord("@")
+        rec[:, 1:10] = name_bytes
+        rec[:, 10] = ord("\n")
+        rec[:, 11:11 + L] = letters[rows]
+        rec[:, 11 + L:14 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, 14 + L:14 + 2 * L] = ord("I")
+        rec[:, 14 + 2 * L] = ord("\n")
+        rec.tofile(path)
+
+
+def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False):
+    """BASELINE.json configs[2] as far as one GPU and the time budget of a default run go: n_pairs 2 x 150 bp pairs on the benchmark genome,
+    `pair -u 500 -v 1`, DP stages ON, end to end through the drop-in command line (the DP stages are driven by its host code), plus the resident BWT
+    stage of the same pairs through the library with the oracle check on a sample.  Reports pairs/s, the stages' wall and device times, the BWT stage's
+    algorithmic bytes against its kernels' time, the DP kernels' GCUPS against the vector-ALU peak, and a truth check of the SAM files."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    import torch
+    import s3o
+    L = 150
+    res = {"pairs": n_pairs, "read_len": L, "options": "pair -L 150 -u 500 -v 1 (default mode: BWT ladder + default / new default / deep / single-end DP)",
+           "mixture": "insert N(350, 40) in [151, 500]; 0-4 substitutions per mate (55/25/12/5/3 %); 10 % of the mates carry a 1-8 base indel"}
+    reads2d, tpos, tstrand, tindel = make_pairs_c3(codes, n_pairs, L, 31337, dev)
     wpq = s3dp.word_per_query(L)
     q = pack_on_device(reads2d, wpq)
+    reads_np = reads2d.cpu().numpy()
     del reads2d
+    torch.cuda.empty_cache()
     lens = np.full(2 * n_pairs, L, dtype=np.uint32)
+    # ---- the BWT stage, resident (what the command line's first stage does per chunk), with counters and the oracle on a sample ----
     b = s3dp.Batch(ix, 2 * n_pairs, wpq)
     try:
         b.upload(q, lens)
+        b.enable_counters(True)
         b.align_pair(3, 8000, 2, 1, 500, 1000)
         b.sync()
+        cnt = b.counters()
+        b.enable_counters(False)
+        dev_ms = search_ms = ce_ms = 0.0
         t0 = time.perf_counter()
         for _ in range(2):
             b.align_pair(3, 8000, 2, 1, 500, 1000)
             b.sync()
+            tot, s_ms, _k = b.timing()
+            dev_ms += tot
+            search_ms += s_ms
+            ce_ms += b.ce_timing()[0]
         dt = (time.perf_counter() - t0) / 2
         pairs = b.fetch_pairs()[0]
-        res["paired_end_2x150_bwt_stage"] = {"pairs": n_pairs, "ms_per_pass": dt * 1e3, "M_pairs_per_s": n_pairs / dt / 1e6,
-                                              "properly_paired": int((pairs["phase"] > 0).sum()),
-                                              "options": "pair -L 150 -s 3 -h 2 -u 500 -v 1 (DP stages off)"}
-    except Exception as e:
-        res["paired_end_2x150_bwt_stage"] = {"error": repr(e)}
+        bytes_bwt = 32.0 * cnt["rankQueries"] + 16.0 * cnt["ltLookups"] + 4.0 * cnt["saReads"] + 16.0 * cnt["ceWindows"] + 2 * n_pairs * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
+        kern_s = (search_ms + ce_ms) / 2 / 1e3
+        res["bwt_stage_resident"] = {"ms_per_pass": dt * 1e3, "device_ms_per_pass": dev_ms / 2, "search_kernels_ms_per_pass": (search_ms + ce_ms) / 2,
+                                     "M_pairs_per_s": n_pairs / dt / 1e6, "properly_paired": int((pairs["phase"] > 0).sum()),
+                                     "rank_queries": int(cnt["rankQueries"]), "algorithmic_bytes": bytes_bwt,
+                                     "roofline": {"bound": "hbm", "achieved": bytes_bwt / kern_s / 1e9 if kern_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": bytes_bwt / kern_s / 1e9 / HBM_PEAK_GBS if kern_s > 0 else 0.0}}
+        m = 1024
+        oix = s3o.Index(host_index=hi)
+        want = oix.align_pair(q[:m * 2 // 32 * 32 * wpq], lens[:2 * m], wpq, 3, 8000, 2, 1, 500, 1000)
+        oix.close()
+        got = pairs[:m]
+        hit = want[0]["phase"] > 0
+        ok = (got["phase"] == want[0]["phase"]).all() and all((got[f][hit] == want[0][f][hit]).all() for f in ("bestA1", "bestA2", "bestS1", "bestS2", "bestM1", "bestM2", "numPairs"))
+        res["oracle_check"] = {"pairs": m, "what": "the BWT stage's pair results (phase, best pairing, strands, mismatches, number of pairings) against the CPU oracle", "bit_exact": bool(ok)}
     finally:
         b.close()
+    # ---- end to end: the command line with the DP stages on ----
+    work = workdir or tempfile.mkdtemp(prefix="s3dp_c3_", dir="/tmp")
+    try:
+        t0 = time.perf_counter()
+        prefix = os.path.join(work, "g.index")
+        hi.write_files(prefix, with_lkt=True)
+        f1, f2 = os.path.join(work, "r1.fq"), os.path.join(work, "r2.fq")
+        write_fastq_pairs(reads_np, L, f1, f2)
+        res["setup_s"] = time.perf_counter() - t0
+        exe = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
+        t0 = time.perf_counter()
+        out = subprocess.run([exe, "pair", prefix, f1, f2, "-L", str(L), "-u", "500", "-v", "1", "-b", "2", "-o", os.path.join(work, "out")], capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        if out.returncode != 0:
+            raise RuntimeError("soap3-dp pair failed: " + out.stderr[-500:])
+        txt = out.stdout
+        if echo:
+            log("command line said:\n" + txt + out.stderr)
+        ph = {k: float(v) for k, v in re.findall(r"\[Main\] (Loading time|Read load time|Alignment \+ output time|Total elapsed time|DP stages time) :\s+([0-9.]+)", txt)}
+        counts = {k: int(v) for k, v in re.findall(r"\[Main\] (Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|"
+                                                   r"Pairs left without a proper pairing|Overall number of reads aligned): (\d+)", txt)}
+        stage = re.search(r"DP stages time :\s+[0-9.]+ seconds \((.*)\)", txt)
+        devl = re.search(r"Device time : BWT stages ([0-9.]+) ms \(search kernels ([0-9.]+) ms\), DP kernels ([0-9.]+) ms, (\d+) problems, (\d+) cells, ([0-9.]+) GCUPS", txt)
+        align_s = ph.get("Alignment + output time", wall)
+        e2e = {"wall_s": wall, "phases_s": ph, "counts": counts, "dp_stage_seconds": stage.group(1) if stage else None,
+               "M_pairs_per_s_reads_in_sam_out": n_pairs / max(align_s, ph.get("Read load time", 0.0)) / 1e6}
+        ch = re.search(r"Chunk loop time : alignment calls ([0-9.]+), fetching results ([0-9.]+), formatting \+ writing ([0-9.]+), DP stages ([0-9.]+)", txt)
+        if ch:
+            e2e["chunk_loop_s"] = {"alignment_calls": float(ch.group(1)), "fetching_results": float(ch.group(2)), "formatting_and_writing": float(ch.group(3)), "dp_stages": float(ch.group(4))}
+        if devl:
+            dp_ms, cells = float(devl.group(3)), int(devl.group(5))
+            e2e["device_ms"] = {"bwt_stages": float(devl.group(1)), "bwt_search_kernels": float(devl.group(2)), "dp_kernels": dp_ms}
+            # vector-ALU peak for the DP's cell update: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s; the fill kernel spends about 21 vector
+            # instructions per 64-cell step (DESIGN.md 3.4) -> a ceiling of about 1870 G cell updates per second
+            e2e["dp"] = {"problems": int(devl.group(4)), "cells": cells, "GCUPS": cells / (dp_ms / 1e3) / 1e9 if dp_ms > 0 else 0.0,
+                         "valu_ceiling_GCUPS": 256 * 4 * 16 * 2.4 / 21.0, "frac_of_valu_ceiling": (cells / (dp_ms / 1e3) / 1e9) / (256 * 4 * 16 * 2.4 / 21.0) if dp_ms > 0 else 0.0}
+        res["end_to_end"] = e2e
+        # ---- truth check of the three SAM files: where did every mate land? ----
+        import pandas as pd
+        seen = np.zeros(2 * n_pairs, dtype=bool)
+        at_truth = np.zeros(2 * n_pairs, dtype=bool)
+        mapped = np.zeros(2 * n_pairs, dtype=bool)
+        by_file = {}
+        for name in ("out.gout.1", "out.dpout.1", "out.unpair"):
+            p = os.path.join(work, name)
+            if not os.path.exists(p) or os.path.getsize(p) == 0:
+                continue
+            cut = subprocess.run("grep -v '^@' %s | cut -f1,2,4" % p, shell=True, capture_output=True)
+            if not cut.stdout:
+                continue
+            import io
+            df = pd.read_csv(io.BytesIO(cut.stdout), sep="\t", header=None, names=["q", "flag", "pos"], dtype={"q": np.int64, "flag": np.int64, "pos": np.int64})
+            prim = df[(df.flag & 0x900) == 0]
+            row = prim.q.values * 2 + ((prim.flag.values & 0x80) != 0)
+            isMapped = (prim.flag.values & 4) == 0
+            good = isMapped & (np.abs(prim.pos.values - 1 - tpos[row]) <= 12) & ((((prim.flag.values & 0x10) != 0).astype(np.uint8)) == tstrand[row])
+            seen[row] = True
+            mapped[row] |= isMapped
+            at_truth[row] |= good
+            by_file[name] = {"records": int(len(df)), "mates": int(len(prim)), "mates_mapped": int(isMapped.sum()), "mates_at_simulated_place": int(good.sum())}
+        both = at_truth[0::2] & at_truth[1::2]
+        res["truth_check"] = {"pairs": n_pairs, "mates_reported": int(seen.sum()), "mates_mapped": int(mapped.sum()), "mates_at_simulated_place": int(at_truth.sum()),
+                              "pairs_with_both_mates_at_simulated_place": int(both.sum()),
+                              "mates_with_indel": int(tindel.sum()), "mates_with_indel_at_simulated_place": int((at_truth & tindel).sum()),
+                              "by_file": by_file,
+                              "is": "primary record of every mate against the simulated place (tolerance 12 bases for clips and indels at the ends, strand must match); "
+                                    "on a genome that is half repeats a mate inside a repeat family has equally good places elsewhere, so this is a rate, "
+                                    "not a pass / fail -- all mates must be reported",
+                              "ok": bool(seen.all())}
+    finally:
+        if not workdir:
+            shutil.rmtree(work, ignore_errors=True)
+    return res
+
+
+def se150_leg(s3dp, ix, hi, codes, dev, n_reads):
+    """SURVEY.md 8d's second read shape: 150 bp single-end reads, the same all-best ladder, kernel-only reads/s (resident batch, device time)"""
+    import torch
+    import s3o
+    L = 150
+    reads2d, tpos, tstrand, tsub = make_reads(codes, n_reads, L, 515, dev)
+    wpq = s3dp.word_per_query(L)
+    q = pack_on_device(reads2d, wpq)
+    del reads2d
     torch.cuda.empty_cache()
+    lens = np.full(n_reads, L, dtype=np.uint32)
+    b = s3dp.Batch(ix, n_reads, wpq)
+    try:
+        b.upload(q, lens)
+        b.align_single_allbest(4, 1000)
+        b.sync()
+        dev_ms = search_ms = ce_ms = 0.0
+        t0 = time.perf_counter()
+        for _ in range(2):
+            b.align_single_allbest(4, 1000)
+            b.sync()
+            tot, s_ms, _k = b.timing()
+            dev_ms += tot
+            search_ms += s_ms
+            ce_ms += b.ce_timing()[0]
+        dt = (time.perf_counter() - t0) / 2
+        phase, werr, offs, pos, strand, mis = b.fetch_alignments()
+        m = 512
+        oix = s3o.Index(host_index=hi)
+        oph, owe, ooff, opos, ostr, omis, _ = oix.align_single_allbest(q, lens, wpq, 4, 1000, first=0, count=m)
+        oix.close()
+        ok = (phase[:m] == oph).all() and (offs[:m + 1] == ooff).all() and (pos[:int(ooff[-1])] == opos).all() and (mis[:int(ooff[-1])] == omis).all()
+        return {"reads": n_reads, "read_len": L, "ms_per_step": dt * 1e3, "device_ms_per_step": dev_ms / 2, "search_kernels_ms_per_step": (search_ms + ce_ms) / 2,
+                "M_reads_per_s": n_reads / dt / 1e6, "M_reads_per_s_kernel_only": n_reads / ((search_ms + ce_ms) / 2 / 1e3) / 1e6,
+                "aligned_reads": int((phase > 0).sum()), "oracle_check": {"reads": m, "bit_exact": bool(ok)},
+                "options": "single -L 150 -s 4 -h 2 (DP off), same substitution mixture as the headline"}
+    finally:
+        b.close()
+
+
+def extras(s3dp, ix, hi, codes, dev, rank, a):
+    """secondary figures (not the headline metric): BASELINE configs[2] -- 2 x 150 bp pairs with the DP stages on (c3_pairs), 150 bp single-end reads
+    (se_150bp), and the semi-global DP kernel on default-DP windows"""
+    import torch
+    res = {}
+    L = 150
+    wpq = s3dp.word_per_query(L)
+    if a.c3_pairs > 0:
+        try:
+            res["c3_pairs"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs)
+        except Exception as e:
+            res["c3_pairs"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    if a.se150_reads > 0:
+        try:
+            res["se_150bp"] = se150_leg(s3dp, ix, hi, codes, dev, a.se150_reads)
+        except Exception as e:
+            res["se_150bp"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     # DP kernel: 150 bp reads against 648-column windows cut from the genome at the reads' places (default-DP shape), device time
     n_dp = 32768
     occ = np.zeros(n_dp, dtype=s3dp.OCC_DTYPE)
@@ -479,7 +741,10 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     import torch
     from s3dp import dist as sd
     t0 = time.perf_counter()
-    codes, families = make_genome(a.genome_bp, 1, dev, repeat_frac)
+    model = getattr(a, "repeat_model", "grch38-like")
+    codes, families = make_genome(a.genome_bp, 1, dev, repeat_frac, model)
+    if repeat_frac > 0 and model != "grch38-like":
+        label = label + "-" + model
     log("[%s] genome %d bp (repeat_frac %.2f) generated in %.1f s" % (label, a.genome_bp, repeat_frac, time.perf_counter() - t0))
     t0 = time.perf_counter()
     reads2d, tpos, tstrand, tsub = make_reads(codes, a.reads, a.read_len, 2026 + rank, dev)
@@ -637,7 +902,7 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
             "strict_is": "SURVEY.md 8d unextended: 32 B x rank queries + packed reads + 12 B x records",
             "traffic_unit": "bytes per launch pair (FETCH_SIZE of both kernels, profiles/pmc_traffic.json)",
             "algorithmic_bytes_per_launch": bytes_step / n_launch,
-            "kernel": "s3::searchKernelV2 + s3::ceKernel", "launches_per_step": n_launch,
+            "kernel": "s3::firstKernel + s3::unitKernel + s3::ceKernel (the stepping kernels and the check-and-extend kernel: the halves of one search pass)", "launches_per_step": n_launch,
             "kernel_ms_per_step": (search_ms + ce_ms) / max(1, a.steps),
             "stepping_kernel_ms_per_step": search_ms / max(1, a.steps),
             "check_extend_kernel_ms_per_step": ce_ms / max(1, a.steps), "device_ms_per_step": dev_ms / max(1, a.steps),
@@ -655,7 +920,7 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
                                     "frac": lines / peaks["random_Glines_per_s"]}
     out = {"value": value, "ms_per_step": dt / a.steps * 1e3,
            "config": {"workload": label, "genome_bp": a.genome_bp, "reads_per_gpu": a.reads, "read_len": a.read_len, "max_mismatch": a.mismatch,
-                      "max_output_per_read": a.max_out, "repeat_frac": repeat_frac, "repeat_families": families,
+                      "max_output_per_read": a.max_out, "repeat_frac": repeat_frac, "repeat_model": model if repeat_frac > 0 else None, "repeat_families": families,
                       "parallelism": "reads sharded x%d, index replicated" % world,
                       "lookup_chars": int(s3dp.lib().s3_index_lookup_chars(ix.h))},
            "roofline": roof, "aligned_reads": tot["readsAligned"], "occurrences": tot["alignments"],
@@ -695,6 +960,7 @@ def main():
     ap.add_argument("--mismatch", type=int, default=4)
     ap.add_argument("--max-out", type=int, default=1000)
     ap.add_argument("--repeat-frac", type=float, default=0.5, help="share of the genome planted with repeat families (GRCh38 is about one half)")
+    ap.add_argument("--repeat-model", default="grch38-like", choices=sorted(REPEAT_MODELS), help="which repeat structure is planted (robustness runs; the headline is grch38-like)")
     ap.add_argument("--uniform", type=int, default=1, help="N = 1 only: also run the repeat-free genome of round 1 (reported under extras)")
     ap.add_argument("--streaming", type=int, default=1, help="also time the streamed form (uploads and downloads inside the timed region)")
     ap.add_argument("--stream-batch", type=int, default=1 << 22, help="reads per streamed batch (the reference reads 1 Mi at a time, SOAP3-DP.cu:394; a launch here lasts as long as its longest unit, so larger batches pay)")
@@ -702,6 +968,8 @@ def main():
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle after the run")
     ap.add_argument("--index-dir", default=None, help="keep / reuse the index files of the benchmark genome in this directory")
     ap.add_argument("--build-only", type=int, default=0, help="stop after the index files are written (with --index-dir)")
+    ap.add_argument("--c3-pairs", type=int, default=1_000_000, help="extras: 2 x 150 bp pairs through the command line with the DP stages on (0: skip)")
+    ap.add_argument("--se150-reads", type=int, default=2_000_000, help="extras: 150 bp single-end reads, kernel-only rate (0: skip)")
     ap.add_argument("--exact-rank", type=int, default=1, help="count the reference algorithm's rank queries on this input with one walk-mode device pass")
     ap.add_argument("--extras", type=int, default=1, help="after the timed region (N = 1): paired-end 2x150 BWT stage and DP kernel throughput")
     a = ap.parse_args()
@@ -748,7 +1016,7 @@ def main():
     if rank == 0:
         if world == 1 and a.extras:
             try:
-                out["extras"] = extras(s3dp, keep["ix"], keep["codes"], dev, rank)
+                out["extras"] = extras(s3dp, keep["ix"], keep["hi"], keep["codes"], dev, rank, a)
             except Exception as e:                                      # secondary figures must never cost the headline line
                 out["extras"] = {"error": repr(e)}
     keep["ix"].close()

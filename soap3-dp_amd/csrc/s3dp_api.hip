@@ -457,11 +457,12 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     // S3DP_HEAVY=0 switches the second pass off (every read is walked by one lane: same results; reads in repeat families then hold the launch up);
-    // n > 1: list a read once it has reserved more than n candidates (default 1024); S3DP_HEAVY_RANK: ... or cost more than that many rank queries
-    // (default 4096: dead ends cost steps, not candidates)
+    // n > 1: list a read once it has reserved more than n candidates (default 2048); S3DP_HEAVY_RANK: ... or cost more than that many rank queries
+    // (default 1024: dead ends cost steps, not candidates).  Round 3, with the unit pass twice as fast: 2048 / 1024 / give-up 2 is 6 % faster than round 2's
+    // 1024 / 4096 / 4 on the benchmark genome and no slower on the other repeat models (profiles/r03_threshold_sweeps.txt)
     const size_t heavyEnv = envSize("S3DP_HEAVY", 1);                       // read per pass: tests switch it
-    in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : 1024u);
-    in.heavyRank = heavyEnv == 0 ? 0xFFFFFFFFu : (uint32_t)envSize("S3DP_HEAVY_RANK", heavyEnv > 1 && heavyEnv < 64 ? 64 : 4096);
+    in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : 2048u);
+    in.heavyRank = heavyEnv == 0 ? 0xFFFFFFFFu : (uint32_t)envSize("S3DP_HEAVY_RANK", heavyEnv > 1 && heavyEnv < 64 ? 64 : 1024);
     in.slotList = nullptr; in.slotCount = nullptr;
     // units of the second pass: first-mismatch positions of an item's first mismatch step, + 1 for "none" -- the longest such step over the cases
     // and over the read lengths this batch can hold (S3DP_UNITS=0: whole items)
@@ -510,11 +511,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             // persistent grid: what is resident at once (4 blocks per CU), or less when several batches share the device (the streamed form: a
             // narrower grid per batch lets the kernels of two batches run side by side and fill each other's tails)
             const unsigned blocksPerCuEnv = (unsigned)envSize("S3DP_BLOCKS_PER_CU", 0);
-            const unsigned blocksPerCu = blocksPerCuEnv ? blocksPerCuEnv : (b->blocksPerCu ? b->blocksPerCu : S3_V2_WAVES_PER_SIMD);
-            const unsigned blocksSecond = std::min<unsigned>(blocksPerCu, S3_V2_WAVES_PER_SIMD_SECOND);     // (the second-pass instantiation holds more registers)
+            const unsigned blocksPerCu = blocksPerCuEnv ? blocksPerCuEnv : (b->blocksPerCu ? b->blocksPerCu : S3_FIRST_WAVES_PER_SIMD);
             // S3DP_VERBOSE=1 with counters enabled: reads, listed reads, rank queries and milliseconds of every launch of this pass (stderr)
             static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
-            unsigned long long rankSeen = counterSnap[0], tripsSeen = counterSnap[6], wavesSeen = counterSnap[9], adoptSeen = counterSnap[8], saSeen = counterSnap[2], ceSeen = counterSnap[3];
+            unsigned long long rankSeen = counterSnap[0], tripsSeen = counterSnap[6], wavesSeen = counterSnap[9], adoptSeen = counterSnap[8], saSeen = counterSnap[2], ceSeen = counterSnap[3], accSeen = counterSnap[10];
             auto lapT = std::chrono::steady_clock::now();
             auto lap = [&](const char *what, uint64_t units) {
                 if (!verbose || !b->counting) return;
@@ -522,10 +522,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                 (void)d2h(c, b->dCounters, S3_NUM_COUNTERS * 8, b->stream);
                 const auto now = std::chrono::steady_clock::now();
                 fprintf(stderr, "[s3dp] search mm=%u %-12s %10llu units %8.2f ms %12llu rank queries (second pass so far: cut %llu + %llu units, %llu lane trips, longest unit %llu trips; "
-                                "unit kernel: %llu wave trips, %llu frames adopted; %llu suffix-array reads, %llu compare windows)\n",
+                                "unit kernel: %llu wave trips, %llu frames adopted; %llu suffix-array reads, %llu compare windows, %llu candidates accepted by ceKernel)\n",
                         modelMm, what, (unsigned long long)units, std::chrono::duration<double, std::milli>(now - lapT).count(), c[0] - rankSeen, c[4], c[5], c[6] - tripsSeen, c[7],
-                        c[9] - wavesSeen, c[8] - adoptSeen, c[2] - saSeen, c[3] - ceSeen);
-                rankSeen = c[0]; tripsSeen = c[6]; wavesSeen = c[9]; adoptSeen = c[8]; saSeen = c[2]; ceSeen = c[3]; lapT = now;
+                        c[9] - wavesSeen, c[8] - adoptSeen, c[2] - saSeen, c[3] - ceSeen, c[10] - accSeen);
+                rankSeen = c[0]; tripsSeen = c[6]; wavesSeen = c[9]; adoptSeen = c[8]; saSeen = c[2]; ceSeen = c[3]; accSeen = c[10]; lapT = now;
                 (void)hipMemsetAsync(b->dCounters + 7, 0, 8, b->stream);
             };
             if (verbose && b->counting) { (void)hipStreamSynchronize(b->stream); lapT = std::chrono::steady_clock::now(); }
@@ -540,9 +540,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                 }
                 out.unitStack = b->dUnitStack;
             }
-            const bool firstKernelV2 = [] { const char *e = getenv("S3DP_FIRST_KERNEL"); return e && !strcmp(e, "v2"); }();   // (the searchKernelV2 instantiation s3dp_first.hip replaced)
-            hipError_t le = firstKernelV2 ? (hipError_t)launchSearchV2(b->ix->d, in, out, 256u * blocksPerCu, b->stream)
-                                          : (hipError_t)launchFirstPass(b->ix->d, in, out, 256u * blocksFirst, b->stream);
+            hipError_t le = (hipError_t)launchFirstPass(b->ix->d, in, out, 256u * blocksFirst, b->stream);
             if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
             lap("first pass", nActive);
             HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
@@ -566,10 +564,9 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     const uint64_t groups = (uint64_t)nCases * 2u;
                     if (nItems + (uint64_t)nHeavy * groups * U >= 0x7FFFFF00ull) U = 1;          // (unit indices share a word with a flag bit)
                     if (nItems + (uint64_t)nHeavy * groups * U >= 0x7FFFFF00ull) return fail(S3_EOVERFLOW, "too many heavy reads in one batch: use smaller batches");
-                    // the unit pass (s3dp_unit.hip; S3DP_UNIT_KERNEL=v2: the searchKernelV2 instantiation it replaced) lets idle lanes adopt frames of busy ones
-                    // once the queue is empty: every adopted frame counts its records in a counter of its own behind the units' (S3DP_UNIT_NODES of them, 0: none)
-                    const bool unitKernelV2 = [] { const char *e = getenv("S3DP_UNIT_KERNEL"); return e && !strcmp(e, "v2"); }();
-                    const bool newUnitPass = U > 1 && !unitKernelV2;
+                    // the unit pass (s3dp_unit.hip) lets idle lanes adopt frames of busy ones once the queue is empty: every adopted frame counts its
+                    // records in a counter of its own behind the units' (S3DP_UNIT_NODES of them, 0: none)
+                    const bool newUnitPass = U > 1;
                     size_t dynCap = newUnitPass ? envSize("S3DP_UNIT_NODES", 1u << 23) : 0;
                     const size_t nStatic = nItems + (size_t)nHeavy * groups * U + 1;
                     if (nStatic + dynCap >= 0x7FFFFF00ull) dynCap = 0;
@@ -615,13 +612,19 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
                     in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (the scatter decodes unit indices with them)
                     HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
-                    if (newUnitPass) {
-                        // what the unit-pass kernel needs besides: the listed reads' numbers, its stack, the chains of adopted frames
+                    {
+                        // the listed reads' numbers in readsT (trunk pass and unit pass)
                         int rc;
                         if (nHeavy > b->listedCap) {
                             if ((rc = bgrow(b, &b->dListedRead, (size_t)nHeavy + nHeavy / 4 + 64, 0))) { b->listedCap = 0; return rc; }
                             b->listedCap = (size_t)nHeavy + nHeavy / 4 + 64;
                         }
+                        out.listedRead = b->dListedRead;
+                        launchListedReads(b->dHeavyList, b->dHeavyCount, active, b->dListedRead, nHeavy, b->stream);
+                    }
+                    if (newUnitPass) {
+                        // what the unit-pass kernel needs besides: the chains of adopted frames
+                        int rc;
                         const size_t nChain = (size_t)nHeavy * groups * U + 1 + dynCap;
                         if (nChain > b->chainCap) {
                             if ((rc = bgrow(b, &b->dChainNext, nChain + nChain / 4, 0))) { b->chainCap = 0; return rc; }
@@ -635,16 +638,15 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                         if (!b->dDynUsed && (rc = balloc(b, &b->dDynUsed, 4))) return rc;
                         HIPCHK(hipMemsetAsync(b->dChainNext, 0, ((size_t)nHeavy * groups * U + 1) * 4, b->stream));
                         HIPCHK(hipMemsetAsync(b->dDynUsed, 0, 4, b->stream));
-                        out.listedRead = b->dListedRead; out.unitStack = b->dUnitStack; out.chainNext = b->dChainNext;
+                        out.chainNext = b->dChainNext;
                         out.dynOwner = b->dDynOwner; out.dynLocal = b->dDynLocal; out.dynUsed = b->dDynUsed;
                         out.dynBase = (uint32_t)nStatic; out.dynCap = (uint32_t)dynCap;
-                        launchListedReads(b->dHeavyList, b->dHeavyCount, active, b->dListedRead, nHeavy, b->stream);
                     }
                     for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass
                         in2.unitMode = mode;
                         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
-                        if (mode == 2u && newUnitPass) le = (hipError_t)launchUnitPass(b->ix->d, in2, out, 256u * blocksUnit, b->stream);
-                        else le = (hipError_t)launchSearchV2(b->ix->d, in2, out, 256u * blocksSecond, b->stream);
+                        if (mode == 2u) le = (hipError_t)launchUnitPass(b->ix->d, in2, out, 256u * blocksUnit, b->stream);
+                        else le = (hipError_t)launchTrunkPass(b->ix->d, in2, out, 256u * blocksFirst, b->stream);
                         if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
                         lap(mode == 1 ? "trunk pass" : "unit pass", (uint64_t)nHeavy * groups * (mode == 1 ? 1 : U));
                     }

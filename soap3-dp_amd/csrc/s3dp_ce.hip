@@ -1,0 +1,192 @@
+// s3dp_ce.hip -- check-and-extend of the 2BWT k-mismatch search for gfx950 (BGS-HostAlgnmtAlgo2.cpp:36-176): the stepping kernels (s3dp_first.hip: first
+// pass and trunk pass; s3dp_unit.hip: unit pass) do not walk a small SA range inside a model's check window: they write a TASK record (range, where the
+// search stands in the model) into the record stream, reserve one sequence number per candidate and go on.  This kernel verifies the candidates -- suffix-
+// array value, then the text under the rest of the model against the oriented read, 16 characters per XOR / fold / popcount -- and appends the accepted
+// ones under their reserved numbers, so the record stream keeps the CPU path's order; rejected candidates leave holes the ordering pass skips.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include "s3dp_device.h"
+#include "s3dp_model.h"
+#include "s3dp_search_common.h"
+
+namespace s3 {
+
+using namespace v2;
+
+// ---- check-and-extend of the task records --------------------------------------------------------------------------------------------------
+// A wave takes 64 records at a time; the candidates of their tasks are numbered through (wave prefix sum of the task sizes, descriptors in LDS) and
+// dealt to the lanes 64 at a time -- one lane per CANDIDATE, whatever the sizes of the tasks (1 .. 256): a lane finds its task by bisection in the
+// prefix sums.  Accepted candidates are appended to the record stream with one atomic per wave and S3_V2_REC_BLOCK records.  Per candidate: SA
+// value, then per remaining model step the text against the oriented read, 16 characters at a time (XOR, fold, popcount), the step's error
+// window checked as in the stepping kernel (BGS-HostAlgnmtAlgo2.cpp:86-169).
+__global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, SearchOut out, const uint32_t *taskRange)
+{
+    __shared__ uint4 sRec[4][64];                              // per wave: the task records of the batch ...
+    __shared__ uint32_t sStart[4][65], sRead[4][64];           // ... the number of their first candidate; the read a task belongs to
+    const uint32_t firstRec = taskRange[0];                   // records [firstRec, nRec): what the stepping launches wrote since the last call
+    uint32_t nRec = taskRange[1];
+    if (nRec > out.recCap) nRec = out.recCap;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t groups = (uint32_t)in.nCases * 2u;
+    const uint32_t S = in.wpqLoad;
+    const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t nSa = 0, nCe = 0, nAcc = 0;
+    uint32_t recCur = 0, recEnd = 0;                          // wave-uniform: reserved block [recCur, recEnd)
+    for (uint64_t base = (uint64_t)firstRec + (uint64_t)waveId * 64u; base < nRec; base += (uint64_t)nWaves * 64u) {
+        const uint64_t idx = base + lane;
+        uint4 rec = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+        if (idx < nRec) rec = out.recs[idx];
+        bool task = rec.x != 0xFFFFFFFFu && (rec.y & S3_REC_TASK);
+        uint32_t item = rec.x & ~S3_REC_PASS2;
+        uint32_t slotOf = item / groups;
+        if (task && (rec.x & S3_REC_PASS2)) {
+            // second-pass records (units that gave up verifying their candidates themselves) count in unit space:
+            // unit = heavy read * groups * U + item * U + position
+            const uint32_t U = in.unitsPerItem;
+            if (out.dynCap && item >= out.dynBase) item = out.dynOwner[item - out.dynBase];      // counted by an adopted frame: the unit its chain started from
+            const uint32_t unit = item - in.unitBase;
+            const uint32_t listed = unit / (groups * U);
+            slotOf = out.heavyList[listed];
+            item = slotOf * groups + (unit / U) % groups;
+            // a task of a unit behind its read's cut: the units in front of it hold MaxOutputPerRead occurrences for sure, the merge never gets here
+            if (out.readCut && unit - listed * groups * U > out.readCut[listed]) task = false;
+        } else if (task && out.heavyFlags[slotOf]) task = false;                 // stale: the second pass searched this read again
+        const uint32_t size = task ? (rec.w & 0xFFu) + 1u : 0u;
+        // exclusive prefix sum of the sizes over the wave
+        uint32_t incl = size;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, (int)d);
+            if (lane >= d) incl += v;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        if (total == 0) continue;
+        __builtin_amdgcn_wave_barrier();
+        sRec[wv][lane] = make_uint4(rec.x, rec.y, rec.z, (rec.w & 0xFFFFFF00u) | (item % groups));     // (low byte: the (case, strand) of the item)
+        sStart[wv][lane] = incl - size;
+        if (lane == 63u) sStart[wv][64] = total;
+        sRead[wv][lane] = task ? (in.active ? in.active[slotOf] : slotOf) : 0u;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
+            const uint32_t c = c0 + lane;
+            bool hit = false;
+            uint32_t rp = 0, recX = 0, seqK = 0;
+            int acc = 0;
+            if (c < total) {
+                // the task this candidate belongs to: the last one that starts at or before c (tasks of size 0 start where the next one starts)
+                uint32_t lo = 0, hi = 63u;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    if (sStart[wv][mid] <= c) lo = mid; else hi = mid - 1u;
+                }
+                const uint4 tr = sRec[wv][lo];
+                const uint32_t k = c - sStart[wv][lo];
+                const uint32_t meta = tr.w >> 8, sub = tr.w & 0xFFu;
+                const int s0 = (int)(meta & 7u), i0 = (int)((meta >> 3) & 0x7FFu), ins0 = (int)((meta >> 14) & 7u), occ0 = (int)((meta >> 17) & 7u);
+                const uint32_t casIdx = sub >> 1, strand = sub & 1u, rIdx = sRead[wv][lo];
+                const bool early = (tr.y & S3_REC_EARLY) != 0;
+                const int Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
+                const int nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
+                const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
+                const S3Case &cs = in.models[Li].cs[casIdx];
+                recX = tr.x; seqK = (tr.y & 0xFFFFFFu) + k;
+                acc = occ0;
+                const uint32_t sa = ix.sa[tr.z + k];
+                nSa++;
+                const S3Step st0 = cs.st[s0];
+                const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i0;
+                rp = sa - (uint32_t)leftAlign;                                   // 32-bit wrap, as the reference
+                int t = s0, ii = i0, insCur = ins0;
+                hit = true;
+                while (t < nSteps) {
+                    const S3Step st = cs.st[t];
+                    const int pos = st.start + st.dir * ii;
+                    const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end), right = (uint32_t)(pos < st.end ? st.end : pos);
+                    const uint32_t len = right - left + 1u;
+                    if (early && t == s0) {
+                        // what is left of the exact lookup step: the walk this replaces matches real text only
+                        const long long rpS = (long long)sa - (long long)leftAlign;
+                        if (rpS + (long long)left < 0 || rpS + (long long)right >= (long long)ix.n) { hit = false; break; }
+                    }
+                    if (rp + left > ix.n) { hit = false; break; }                // BGS-HostAlgnmtAlgo2.cpp:122-125
+                    const uint32_t tpos = rp + left;
+                    int mm = 0;
+                    // 128 characters at a time: all text and read words of the piece are requested before the first is used
+                    for (uint32_t o0 = 0; o0 < len; o0 += 128u) {
+                        const uint32_t piece = len - o0 > 128u ? 128u : len - o0;
+                        const uint32_t tp0 = tpos + o0, tw0 = tp0 >> 4, tsh = (tp0 & 15u) * 2u;
+                        const uint32_t qp0 = left + o0, qw0 = qp0 >> 4, qsh = (qp0 & 15u) * 2u;
+                        uint32_t tw[9], qw[9];
+#pragma unroll
+                        for (uint32_t j = 0; j < 9; j++) {
+                            const uint32_t need = j * 16u < piece + 16u;              // word j + the one behind it for the shift
+                            tw[j] = (need && tw0 + j < ix.pacWords) ? ix.pac[tw0 + j] : 0u;
+                            qw[j] = (need && qw0 + j < S) ? rd[qw0 + j] : 0u;
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; j++) {
+                            if (j * 16u < piece) {
+                                const uint32_t cch = piece - j * 16u > 16u ? 16u : piece - j * 16u;
+                                const uint32_t a_ = tsh ? (tw[j] << tsh) | (tw[j + 1] >> (32u - tsh)) : tw[j];
+                                const uint32_t b_ = qsh ? (qw[j] << qsh) | (qw[j + 1] >> (32u - qsh)) : qw[j];
+                                uint32_t x = a_ ^ b_;
+                                x = (x | (x >> 1)) & 0x55555555u;
+                                if (cch < 16u) x &= ~0u << (32u - 2u * cch);
+                                mm += __popc(x);
+                            }
+                        }
+                    }
+                    nCe += (len + 31u) >> 5;
+                    const int tot = mm + insCur;
+                    if (tot < st.minErr || tot > st.maxErr) { hit = false; break; }
+                    acc += tot; t++; ii = 0; insCur = 0;
+                }
+            }
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                // accepted candidates go into a block of record slots the wave reserved with one atomic (as the stepping kernel does)
+                const uint32_t np = (uint32_t)__popcll(hm);
+                if (recCur + np > recEnd) {
+                    for (uint32_t j = recCur + lane; j < recEnd; j += 64u) out.recs[j] = make_uint4(0xFFFFFFFFu, 0, 0, 0);   // unused tail
+                    uint32_t b0 = 0;
+                    if (lane == 0) b0 = atomicAdd(out.recCount, S3_V2_REC_BLOCK);
+                    b0 = (uint32_t)__shfl((int)b0, 0);
+                    recCur = b0; recEnd = b0 + S3_V2_REC_BLOCK;
+                    if (recEnd > out.recCap || recEnd < b0) { recEnd = b0 < out.recCap ? out.recCap : b0; if (lane == 0) atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
+                }
+                if (hit) {
+                    nAcc++;
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(recX, seqK | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
+                }
+                recCur += np;
+                if (recCur > recEnd) recCur = recEnd;
+            }
+        }
+    }
+    for (uint32_t j = recCur + lane; j < recEnd; j += 64u) out.recs[j] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+    if (out.counters) {
+        atomicAdd(&out.counters[2], (unsigned long long)nSa);
+        atomicAdd(&out.counters[3], (unsigned long long)nCe);
+        atomicAdd(&out.counters[10], (unsigned long long)nAcc);
+    }
+}
+
+void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskRange, hipStream_t s)
+{
+    if (in.nActive == 0) return;
+    // the waves split the task records statically: launch exactly the blocks that are resident at once (a partial second round would run on a
+    // third of the chip while the rest idles).  S3DP_CE_BLOCKS_PER_CU overrides the occupancy the runtime reports.
+    static const unsigned blocks = [] {
+        int dev = 0, cus = 256, perCu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, ceKernel, 256, 0) != hipSuccess || perCu < 1) perCu = 6;
+        if (const char *e = getenv("S3DP_CE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
+        return (unsigned)(cus * perCu);
+    }();
+    hipLaunchKernelGGL(ceKernel, dim3(blocks), dim3(256), 0, s, ix, in, out, taskRange);
+}
+
+}  // namespace s3

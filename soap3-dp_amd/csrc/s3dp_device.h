@@ -5,9 +5,6 @@
 #include "s3dp_model.h"
 
 #define S3_SEARCH_BLOCK 256
-#define S3_V2_WAVES_PER_SIMD 4            // register budget of the v2 search kernel (512 / 4 -> 128 VGPRs, no spills in the loop)
-#define S3_V2_WAVES_PER_SIMD_SECOND 3     // ... of its second-pass instantiation (check-and-extend states on top: 170 VGPRs, no spills)
-#define S3_V2_CHUNK 128u                  // reads a wave takes from the work queue at a time
 #define S3_V2_COUNT_BATCH 32u             // second pass: accepted candidates a unit books at a time
 #define S3_V2_REC_BLOCK 256u              // record slots a wave reserves with one atomic
 #define S3_V2_MODEL_BYTES 1104u           // sizeof(S3Model) rounded up to 16
@@ -71,18 +68,18 @@ struct SearchIn {
     uint32_t        heavyLimit;  // first pass: a read that reserves more check-and-extend candidates than this is listed for the second pass
     const uint32_t *slotList;    // second pass (item mode: one work unit per item of a listed read): the listed slots ...
     const uint32_t *slotCount;   // ... and how many (device memory, written by the first pass)
-    uint32_t        unitMode;      // 0: first pass (a unit = a read); 1: trunk pass over the listed reads' items; 2: unit pass (s3dp_search_v2.hip)
+    uint32_t        unitMode;      // 0: first pass (a unit = a read); 1: trunk pass over the listed reads' items; 2: unit pass (s3dp_first.hip, s3dp_unit.hip)
     uint32_t        unitsPerItem;  // second pass: first-mismatch positions an item is cut into, + 1 for "none" (1: whole items)
     uint32_t        unitBase;      // second pass: unit u counts its records in itemCounts[unitBase + u]
     uint32_t        sStarPacked;   // 3 bits per case: the first step that allows a mismatch (= nSteps: none)
     uint32_t        ceInlineMax;   // second pass: occurrences a unit verifies itself before it hands the rest of its candidates to ceKernel
     uint32_t        ceGiveUp;      // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel (S3_CE_GIVE_UP)
-    uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_v2.hip)
+    uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_common.h)
 };
 
 #define S3_REC_TASK  (1u << 28)
 #define S3_REC_PASS2 0x80000000u            // in the item word: record written by the second pass (records of a listed read without it are stale)
-#define S3_CE_GIVE_UP 4u                     // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel
+#define S3_CE_GIVE_UP 2u                     // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel
 #define S3_TRUNK_VALID 0x80000000u          // trunkStates[].w: the trunk pass reached this position
 #define S3_REC_EARLY (1u << 29)              // task written inside the exact lookup step (single-suffix range): the rest of that step is verified too
 
@@ -160,8 +157,8 @@ void launchOrientReads(const uint32_t *queries, const uint32_t *lengths, uint32_
 void launchZeroListedCounts(const uint32_t *heavyList, const uint32_t *heavyCount, uint32_t nHeavy, uint32_t groups, uint32_t *itemCounts, hipStream_t s);
 void launchSaExpand(const DevBwt &b, const uint32_t *samples, uint32_t interval, uint32_t n, uint32_t *sa, hipStream_t s);
 void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, size_t occRecs, uint4 *lines, hipStream_t s);
-int launchSearchV2(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);
 int launchFirstPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);    // s3dp_first.hip; returns a hipError_t
+int launchTrunkPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);    // s3dp_first.hip, the trunk-pass role
 int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);     // s3dp_unit.hip; returns a hipError_t
 unsigned unitPassMaxWaves(unsigned maxBlocks);                                        // waves of the widest unit-pass grid (sizes SearchOut::unitStack)
 void launchListedReads(const uint32_t *heavyList, const uint32_t *heavyCount, const uint32_t *active, uint32_t *listedRead, uint32_t nHeavy, hipStream_t s);

@@ -8,11 +8,11 @@
 //   * the read is loaded in both orientations (two trips for 100 bases) and its items run back to back in the lane;
 //   * an item starts from the longest lookup table the index holds: the 13-mer tables of the file format (with the range reconciliation of
 //     BWTExactModelForward_Lookup2, BGS-HostAlgnmtAlgo2.cpp:349-356) or the 14- / 15- / 16-mer tables built in HBM at upload;
-//   * check-and-extend is not done here: a small range inside the check window becomes a TASK record for ceKernel (s3dp_search_v2.hip) with one
+//   * check-and-extend is not done here: a small range inside the check window becomes a TASK record for ceKernel (s3dp_ce.hip) with one
 //     sequence number reserved per candidate; a single suffix left inside the exact lookup step is handed over at once (S3_REC_EARLY);
 //   * a read that reserves more candidates than in.heavyLimit, or costs more rank queries than in.heavyRank, is a HEAVY read: the lane lists it
 //     for the second pass (trunk pass + unit pass) and drops it.
-// Results are bit-identical to searchKernelV2<., false>, which this kernel replaces (S3DP_FIRST_KERNEL=v2 runs that one), and so to the CPU path.
+// The whole story of the search is told in s3dp_search_common.h.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -30,7 +30,12 @@ enum : uint32_t { F_IDLE = 0, F_STEP = 1, F_LOAD = 2, F_KEYS = 3, F_LT = 4, F_PO
 }
 using namespace first;
 
-template <bool UNIFORM, bool COUNT>
+// TRUNK: the trunk pass over the listed reads (in.slotCount of them): a slot is ONE (listed read, item); the lane walks the item's trunk -- lookup step,
+// exact steps, then the first step that allows a mismatch WITHOUT taking one -- and leaves the range it holds at every position of that step, and
+// behind its last one, in out.trunkStates: the unit pass starts from them.  Whatever ends the trunk early (a range handed to check-and-extend, a dead
+// range) ends it for every unit: positions it never reached keep no state.  Its records (tasks for ceKernel) count in the counter of the item's last
+// unit.  With in.unitsPerItem == 1 (no mismatch step to cut the item at: exact-match models; or S3DP_UNITS=0) the lane searches the whole item.
+template <bool UNIFORM, bool COUNT, bool TRUNK>
 __global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_FIRST_WAVES_PER_SIMD)
 firstKernel(DevIndex ix, SearchIn in, SearchOut out)
 {
@@ -52,7 +57,12 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     }
 
     const uint32_t groups = (uint32_t)in.nCases * 2u;
-    const uint32_t nSlots = in.nActive;
+    const uint32_t nListed = TRUNK ? *in.slotCount : 0u;
+    const uint32_t U = TRUNK ? in.unitsPerItem : 1u;
+    const bool onTrunk = TRUNK && U > 1u;                                   // the item is cut into units: the lane stays on the trunk
+    const uint32_t nSlots = TRUNK ? nListed * groups : in.nActive;
+    uint32_t listed = 0;                                                    // (TRUNK) the lane's read in the list
+    int sStar = 0;                                                          // (TRUNK) the first step of the case that allows a mismatch
     uint4 *stk = out.unitStack + (size_t)(blockIdx.x * (S3_SEARCH_BLOCK / 64u) + wv) * S3_UNIT_STACK * 64u;     // frame d of lane k: stk[(d % S3_UNIT_STACK) * 64 + k]
 
     uint32_t nRank = 0, nLt = 0;                                            // (COUNT)
@@ -113,6 +123,12 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     auto loadStepCache = [&]() { sc = packStep(stepPtr(s)); };
     auto fwdL = [&]() -> uint32_t { return sc.dir() < 0 ? aL : pR - (aR - aL); };
     auto fwdR = [&]() -> uint32_t { return sc.dir() < 0 ? aR : pR; };
+    // (TRUNK) the range at position q of the mismatch step, as {l, r, rev l}
+    auto leaveState = [&](uint32_t q) {
+        const uint32_t size = aR - aL;
+        const uint32_t fl = sc.dir() < 0 ? aL : pR - size, fr = sc.dir() < 0 ? aR : pR, rl = sc.dir() < 0 ? pR - size : aL;
+        out.trunkStates[((size_t)subIdx * U + q) * nListed + listed] = make_uint4(fl, fr, rl, S3_TRUNK_VALID);
+    };
     // a small range inside the check window, or a single suffix inside the lookup step: one task record, a sequence number per candidate
     auto task = [&](uint32_t flags) {
         pendMeta = 0x80000000u | seq | S3_REC_TASK | flags;
@@ -156,13 +172,13 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                 if ((aR - aL) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd()) {
                     if (pendMeta >> 31) { state = F_RESUME; return; }
                     task(0u);
-                    if (readCand > in.heavyLimit) { goHeavy = true; state = F_DONE; return; }
+                    if (!TRUNK && readCand > in.heavyLimit) { goHeavy = true; state = F_DONE; return; }
                     needPop = true;
                     continue;
                 }
                 // Few suffixes left inside the exact lookup step: walking the rest of the step can only keep or lose each of them, in the same relative
                 // order, and the next step hands them to check-and-extend at its first position anyway.  Hand them over now; the task also verifies what is
-                // left of this step, inside the text (searchKernelV2 tells the whole story).  Not for ranges that may hold a padded table element.
+                // left of this step, inside the text (s3dp_search_common.h tells the whole story).  Not for ranges that may hold a padded table element.
                 if (in.earlyCe && s == 0 && i >= (int)in.earlyMinI && sc.ceThr() == 0 && nSteps > 1 && !padded) {
                     const S3Step nx = stepAt(1);
                     const uint32_t lim = in.earlyCe < (uint32_t)nx.ceThr ? in.earlyCe : (uint32_t)nx.ceThr;
@@ -170,7 +186,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                     if ((aR - aL) < lim && nxLenEff > 0 && nx.start >= nx.ceStart && nx.start <= nx.ceEnd) {
                         if (pendMeta >> 31) { state = F_RESUME; return; }
                         task(S3_REC_EARLY);
-                        if (readCand > in.heavyLimit) { goHeavy = true; state = F_DONE; return; }
+                        if (!TRUNK && readCand > in.heavyLimit) { goHeavy = true; state = F_DONE; return; }
                         needPop = true;
                         continue;
                     }
@@ -179,6 +195,12 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                 return;
             }
             if (ins >= sc.minErr() && alive) {
+                if (onTrunk && s == sStar) {
+                    // past the last position of the mismatch step without a mismatch: the item's last unit ("none") goes on from here, in its turn
+                    leaveState(U - 1u);
+                    state = F_DONE;
+                    return;
+                }
                 occ += ins; ins = 0; s++; i = 0;
                 if (s < nSteps) {
                     const int was = sc.dir();
@@ -204,6 +226,9 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                 pendMeta = 0;
                 goHeavy = false;
                 sub = groups;
+            } else if constexpr (TRUNK) {
+                out.itemCounts[cntIdx] = seq;
+                sub = groups;                                               // one item per turn
             } else {
                 out.itemCounts[cntIdx] = seq;
                 readTotal += total;
@@ -230,6 +255,14 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                 slotIdx = rdy[e]; rIdx = rdy[64u + e];
                 subN = ((in.nStepsPacked) & 7u) << 8;
                 cntIdx = slotIdx * groups;
+                if constexpr (TRUNK) {
+                    // queue order: item first, the read last (slot = item * listed reads + read)
+                    const uint32_t sub = slotIdx / nListed, cas = sub >> 1;
+                    listed = slotIdx - sub * nListed;
+                    subN = sub | ((in.nStepsPacked >> (3u * cas)) & 7u) << 8;
+                    sStar = (int)((in.sStarPacked >> (3u * cas)) & 7u);
+                    cntIdx = in.unitBase + (listed * groups + sub) * U + (U - 1u);
+                }
                 readTotal = 0; readCand = 0; readRank = 0; goHeavy = false;
                 seq = 0; total = 0; sp = 0; tosValid = false; loadOff = 0;
                 state = F_LOAD;
@@ -349,7 +382,8 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         if (stageB) {
             const uint32_t slot = pendBase + lane;
             cIn = slot < nSlots;
-            cRidx = cIn ? (in.active ? in.active[slot] : slot) : 0u;
+            if constexpr (TRUNK) cRidx = cIn ? out.listedRead[slot % nListed] : 0u;
+            else cRidx = cIn ? (in.active ? in.active[slot] : slot) : 0u;
         }
         stage[(q4) * 4u + q16] = va0;
         stage[(16u + q4) * 4u + q16] = va1;
@@ -375,7 +409,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         bool doSettle = false, needPop = false;
         if (wantTos) { tos = pT; tosValid = true; }
         // a read that has cost this many rank queries is heavy whatever it has found so far (dead ends cost steps, not candidates)
-        if (state == F_STEP && readRank > in.heavyRank) { goHeavy = true; state = F_DONE; sp = 0; tosValid = false; }
+        if (!TRUNK && state == F_STEP && readRank > in.heavyRank) { goHeavy = true; state = F_DONE; sp = 0; tosValid = false; }
         if (state == F_STEP) {
             const bool exact = ins >= sc.maxErr();
             const RankSel qL = rankSel(iL), qR = rankSel(iR);
@@ -397,7 +431,9 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             const uint32_t gAl = sel4(oL, ch) + 1u, gAr = sel4(oR, ch), gPr = pR - cOc;         // the continuation (the read's own character)
             doSettle = true;
             bool taken = false;
-            if (!exact) {
+            const bool trunkHere = onTrunk && s == sStar;                      // no mismatch is taken in this step: the units take them
+            if (trunkHere && (uint32_t)i + 1u < U) leaveState((uint32_t)i);
+            if (!exact && !trunkHere) {
                 const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
                 const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
                 if (a0 || a1 || a2 || a3) {
@@ -470,7 +506,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                 }
                 if (pendMeta >> 31) {
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(TRUNK ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
                     pendMeta = 0;
                 }
                 recCur += np;
@@ -492,28 +528,34 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     }
 }
 
-int launchFirstPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
+// trunk = false: first pass, one slot per read of in.nActive; true: trunk pass, one slot per (listed read, item) -- the kernel reads the number of listed
+// reads from device memory (in.slotCount); in.nActive then bounds the grid.  Returns a hipError_t.
+template <bool TRUNK>
+static int launchFirstOrTrunk(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
 {
     if (in.nActive == 0) return (int)hipSuccess;
-    uint64_t blocks = ((uint64_t)in.nActive + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
+    uint64_t blocks = ((uint64_t)in.nActive * (TRUNK ? (uint64_t)in.nCases * 2u : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + S3_FIRST_RDY_BYTES + 2u * in.wLds * 256u);
     const bool count = out.counters != nullptr;
-    const void *fn = in.uniformLen ? (count ? (const void *)firstKernel<true, true> : (const void *)firstKernel<true, false>)
-                                   : (count ? (const void *)firstKernel<false, true> : (const void *)firstKernel<false, false>);
+    const void *fn = in.uniformLen ? (count ? (const void *)firstKernel<true, true, TRUNK> : (const void *)firstKernel<true, false, TRUNK>)
+                                   : (count ? (const void *)firstKernel<false, true, TRUNK> : (const void *)firstKernel<false, false, TRUNK>);
     if (lds > 48u * 1024u) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     const dim3 grid((unsigned)blocks), block(S3_SEARCH_BLOCK);
     if (in.uniformLen) {
-        if (count) hipLaunchKernelGGL((firstKernel<true, true>), grid, block, lds, s, ix, in, out);
-        else hipLaunchKernelGGL((firstKernel<true, false>), grid, block, lds, s, ix, in, out);
+        if (count) hipLaunchKernelGGL((firstKernel<true, true, TRUNK>), grid, block, lds, s, ix, in, out);
+        else hipLaunchKernelGGL((firstKernel<true, false, TRUNK>), grid, block, lds, s, ix, in, out);
     } else {
-        if (count) hipLaunchKernelGGL((firstKernel<false, true>), grid, block, lds, s, ix, in, out);
-        else hipLaunchKernelGGL((firstKernel<false, false>), grid, block, lds, s, ix, in, out);
+        if (count) hipLaunchKernelGGL((firstKernel<false, true, TRUNK>), grid, block, lds, s, ix, in, out);
+        else hipLaunchKernelGGL((firstKernel<false, false, TRUNK>), grid, block, lds, s, ix, in, out);
     }
     return (int)hipSuccess;
 }
+
+int launchFirstPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s) { return launchFirstOrTrunk<false>(ix, in, out, maxBlocks, s); }
+int launchTrunkPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s) { return launchFirstOrTrunk<true>(ix, in, out, maxBlocks, s); }
 
 }  // namespace s3

@@ -4,6 +4,7 @@
 // while reads are aligned.  The one exchange step is the sum of the alignment counters at the end (the `[Main] Overall ...` numbers of
 // SOAP3-DP.cu:816-830): one ncclAllReduce over the group's devices (RCCL, xGMI between the GPUs of a node).
 #include <rccl/rccl.h>
+#include <future>
 #include <thread>
 #include "s3dp_internal.h"
 
@@ -13,11 +14,18 @@ struct s3_group {
     std::vector<int> devices;
     std::vector<s3_index *> indexes;
     bool distinct = true;                    // RCCL needs one communicator rank per DISTINCT device
+    // the communicators of a group of several distinct devices are made while the index is uploaded (ncclCommInitAll takes seconds: at the end of a
+    // run it would be the longest single step of a short job); a group of one device has nothing to exchange and never makes one
+    std::vector<ncclComm_t> comm;
+    std::future<ncclResult_t> commReady;
+    bool commMade = false;
 };
 
 extern "C" void s3_group_free(s3_group *g)
 {
     if (!g) return;
+    if (g->commReady.valid()) g->commMade = g->commReady.get() == ncclSuccess;
+    if (g->commMade) for (ncclComm_t c : g->comm) (void)ncclCommDestroy(c);
     for (s3_index *ix : g->indexes) if (ix) s3_index_free(ix);
     delete g;
 }
@@ -29,6 +37,10 @@ extern "C" int s3_group_create(const int *devices, int nDevices, const s3_index_
     g->devices.assign(devices, devices + nDevices);
     g->indexes.assign((size_t)nDevices, nullptr);
     for (int a = 0; a < nDevices; a++) for (int b = a + 1; b < nDevices; b++) if (devices[a] == devices[b]) g->distinct = false;
+    if (g->distinct && nDevices > 1) {
+        g->comm.assign((size_t)nDevices, nullptr);
+        g->commReady = std::async(std::launch::async, [g] { return ncclCommInitAll(g->comm.data(), (int)g->devices.size(), g->devices.data()); });
+    }
     // the index is replicated: one upload per member, all at once (each is bound by its own PCIe link and its own table kernels)
     std::vector<int> rc((size_t)nDevices, S3_OK);
     std::vector<std::string> err((size_t)nDevices);
@@ -55,6 +67,7 @@ extern "C" int s3_group_allreduce(s3_group *g, uint64_t *counters, int nCounters
 {
     if (!g || !counters || nCounters < 1 || nCounters > 1024) return fail(S3_EINVAL, "s3_group_allreduce: bad argument");
     const int n = (int)g->devices.size();
+    if (n == 1) return S3_OK;                                                 // one member: its counters are the sums
     if (!g->distinct) {
         // members that share a device (a test on one GPU) cannot be ranks of one communicator: their sum is taken here
         std::vector<uint64_t> sum((size_t)nCounters, 0);
@@ -62,7 +75,13 @@ extern "C" int s3_group_allreduce(s3_group *g, uint64_t *counters, int nCounters
         for (int k = 0; k < n; k++) for (int c = 0; c < nCounters; c++) counters[(size_t)k * nCounters + c] = sum[(size_t)c];
         return S3_OK;
     }
-    std::vector<ncclComm_t> comm((size_t)n);
+    if (g->commReady.valid()) {
+        const ncclResult_t ci = g->commReady.get();
+        if (ci != ncclSuccess) return fail(S3_EHIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(ci));
+        g->commMade = true;
+    }
+    if (!g->commMade) return fail(S3_EHIP, "s3_group_allreduce: the group has no communicators");
+    std::vector<ncclComm_t> &comm = g->comm;
     std::vector<hipStream_t> st((size_t)n, nullptr);
     std::vector<uint64_t *> buf((size_t)n, nullptr);
     int rc = S3_OK;
@@ -75,8 +94,6 @@ extern "C" int s3_group_allreduce(s3_group *g, uint64_t *counters, int nCounters
         }
     };
 #define GCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { msg = std::string(#x) + ": " + hipGetErrorString(e_); rc = S3_EHIP; } } while (0)
-    const ncclResult_t ci = ncclCommInitAll(comm.data(), n, g->devices.data());
-    if (ci != ncclSuccess) return fail(S3_EHIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(ci));
     for (int k = 0; k < n && rc == S3_OK; k++) {
         GCHK(hipSetDevice(g->devices[(size_t)k]));
         if (rc == S3_OK) GCHK(hipStreamCreateWithFlags(&st[(size_t)k], hipStreamNonBlocking));
@@ -96,7 +113,6 @@ extern "C" int s3_group_allreduce(s3_group *g, uint64_t *counters, int nCounters
         if (rc == S3_OK) GCHK(hipStreamSynchronize(st[(size_t)k]));
     }
 #undef GCHK
-    for (int k = 0; k < n; k++) (void)ncclCommDestroy(comm[(size_t)k]);
     cleanup();
     return rc == S3_OK ? S3_OK : fail(rc, msg);
 }

@@ -49,7 +49,7 @@ struct s3_batch {
     uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr, *dTaskRange = nullptr;
     unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;
     unsigned long long *dSum64 = nullptr;            // 64-bit total next to a 32-bit scan (sum64Async): a wrapped total must not pass as a small one
-    uint8_t  *dHeavyFlags = nullptr;                 // reads the first search pass listed for the exact pass (s3dp_search_v2.hip)
+    uint8_t  *dHeavyFlags = nullptr;                 // reads the first search pass listed for the exact pass (s3dp_first.hip)
     uint32_t *dHeavyList = nullptr, *dHeavyCount = nullptr, *dHeavyIndex = nullptr;
     uint32_t *dLongList = nullptr, *dLongCount = nullptr;      // reads whose slice of the ordered array is walked by a whole wave (merge / decode)
     uint32_t *dItemAcc = nullptr; size_t accCap = 0;            // per listed read and item: certain occurrences (second search pass)

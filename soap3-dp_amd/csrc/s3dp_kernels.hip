@@ -1,5 +1,5 @@
 // s3dp_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X) around the 2BWT search: index re-layout, read orientation, long lookup
-// tables, record ordering, per-read merge, SA decode.  The search itself is s3dp_search_v2.hip.
+// tables, record ordering, per-read merge, SA decode.  The search itself is s3dp_first.hip / s3dp_unit.hip / s3dp_ce.hip.
 //
 // What is computed is fixed by the reference's CPU path (BGS-HostAlgnmtAlgo2.cpp driven by the
 // SRA2BWTMdl.c case tables): same cases, same DFS order, same lookup-table start, same

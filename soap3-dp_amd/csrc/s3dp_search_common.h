@@ -1,5 +1,41 @@
-// s3dp_search_common.h -- what the search kernels share (s3dp_search_v2.hip: first pass, trunk pass, check-and-extend kernel; s3dp_unit.hip: unit
-// pass): state numbers, cooperative line ids, DFS frames and the rank arithmetic on the 64-byte rank lines (layout: relayoutKernel, s3dp_kernels.hip).
+// s3dp_search_common.h -- what the search kernels share: s3dp_first.hip (first pass, trunk pass), s3dp_unit.hip (unit pass), s3dp_ce.hip
+// (check-and-extend kernel): cooperative line ids, DFS frames, the model step of a lane in registers, and the rank arithmetic on the 64-byte rank
+// lines (layout: relayoutKernel, s3dp_kernels.hip).
+//
+// THE SEARCH, in one place.  Same results, record for record, as the reference CPU path (BGS-HostAlgnmtAlgo2.cpp); different machine mapping.
+//   * Measurement on MI355X (tools/hbm_probe.py) shows that a rank-query stream is bound by the number of vector-memory REQUESTS, not by DRAM bytes:
+//     two 16-B lane loads into the same 64-B line cost as much as two lines.  So a rank query is ONE coalesced 64-B request: the index is re-laid
+//     out at upload into one line per 128 BWT characters (counts, the half-block before the sample reversed, the half-block after it, precounts), 4
+//     adjacent lanes load the 4 x 16 B of one owner's line (the owner's address travels by ds_bpermute), the line is staged in LDS and read back
+//     by its owner -- "Occ/rank tables staged through LDS for coalesced HBM reads".
+//   * The grids are persistent; a lane runs a flat state machine and takes new work from a queue when it is done.  Every trip of the loop first
+//     ISSUES all memory operations of all lanes (rank lines, lookup entries, read words, the next stack frame) without a branch in between, waits
+//     ONCE, then every lane advances its own search (pure ALU + LDS) until it needs memory again.
+//   * Work item of the first pass = a read: its (case, strand) items in the CPU path's order, each from the longest lookup table the index holds.
+//     Check-and-extend (a small SA range inside a model's check window is verified against the text instead of walked) runs in its own kernel:
+//     the stepping lane writes a TASK record, reserves one sequence number per candidate and goes on; accepted candidates are written under the
+//     reserved numbers, so the record stream keeps the CPU path's order; rejected ones leave holes the ordering pass skips.
+//   * EARLY check-and-extend: the first step of every case is an exact walk of 20-60 characters, and behind the lookup table almost every range
+//     is ONE suffix wide; a lane that finds a single suffix inside the lookup step hands it over at once (S3_REC_EARLY) when the next step would
+//     start check-and-extend at its first position anyway; the task also verifies what is left of the lookup step, inside the text.  Exact steps
+//     map a range onto a range order-preservingly, so survivors come out in the order the CPU path emits them.  Ranges that may hold a padded
+//     lookup-table element (DevIndex::padBack / padBi) are walked, as the CPU path walks them.
+//   * HEAVY reads.  A read inside a repeat family with 10^5 copies has a 4-mismatch neighbourhood of 10^5 rank queries: one lane per read leaves
+//     the chip idle behind a few lanes.  A read that reserves more candidates than in.heavyLimit or costs more rank queries than in.heavyRank
+//     leaves the first pass (listed), and the SECOND pass takes the listed reads apart: its work unit is the part of ONE (read, case, strand)
+//     item's search tree whose FIRST mismatch sits at one given position of the first step that allows mismatches (or that has none there).  The
+//     depth-first order of the CPU path visits exactly these subtrees one after the other (at every position: the mismatch children first,
+//     ascending, then the continuation), so the units of an item, numbered by position, ARE its sequence order: each unit counts its records from
+//     zero and the counting scatter puts them behind each other -- a thousand lanes per heavy read, no sort.  The TRUNK pass (one lane per listed
+//     read and item) walks the item without taking a mismatch in that step and leaves the range it holds at every position; the UNIT pass (one
+//     lane per read, item and position) starts from those.
+//   * THE CUT.  The CPU path stops a read at MaxOutputPerRead occurrences.  The lanes of the unit pass verify their candidates themselves (up to a
+//     point: after in.ceGiveUp rejections in a row, or in.ceInlineMax verified occurrences, a unit writes task records like the first pass), book
+//     what they hold for sure in counters the units of their read share (itemAcc per item, the spare word of the trunk states per position), and
+//     everything in sequence order up to a unit that adds up to MaxOutputPerRead puts the read's cut behind that unit (SearchOut::readCut); a lane
+//     that finds itself behind its read's cut stops.  The merge applies the cut exactly either way.
+//   * THE TAIL.  Once the queue is empty, an idle lane of the unit pass adopts the oldest frame of a busy lane of its wave; the frame's records
+//     count in a counter of their own chained behind the giver's (SearchOut::chainNext) -- s3dp_unit.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,8 +1,8 @@
 // s3dp_unit.hip -- the UNIT PASS of the 2BWT k-mismatch search for gfx950: the listed ("heavy") reads of a search pass, taken apart.
 //
-// What a unit is, and why the units of an item in position order ARE the CPU path's record order, is told in s3dp_search_v2.hip (which still runs the
+// What a unit is, and why the units of an item in position order ARE the CPU path's record order, is told in s3dp_search_common.h (s3dp_first.hip runs the
 // first pass and the trunk pass).  This file is the kernel that searches the units: one lane per (listed read, item, position p of the item's first
-// mismatch).  It used to be an instantiation of searchKernelV2 and carried everything that kernel can do -- read loading for both strands, lookup
+// mismatch).  Until round 3 it was an instantiation of the one search kernel and carried everything that kernel could do -- read loading for both strands, lookup
 // tables, key building, trunk bookkeeping, ten unconditional loads per lane and trip, the depth-first stack in scratch memory whose pops stalled
 // the wave in the middle of a trip -- at 153 registers and three waves per SIMD, and a launch lasted as long as its longest unit.  Here:
 //
@@ -23,7 +23,7 @@
 //     unitChainKernel turns the chains into offsets and the counting scatter places the records exactly where the single lane would have put
 //     them.  A unit of ten thousand trips becomes a few hundred trips of a whole wave; the order of the records does not change.
 //
-// Results are bit-identical to the old unit pass (S3DP_UNIT_KERNEL=v2 runs that one) and so to the CPU path: BGS-HostAlgnmtAlgo2.cpp:933-1071
+// Results are bit-identical to the CPU path: BGS-HostAlgnmtAlgo2.cpp:933-1071
 // (order), :86-169 (check-and-extend), DV-Kernel.cu:437-955 (what the reference's own kernels do per step).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -488,7 +488,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 else { i = sc.len(); doSettle = true; needPop = false; }         // the unit without a mismatch in this step: behind its last position
             }
         }
-        // ---------- check-and-extend by the lane itself (see searchKernelV2; BGS-HostAlgnmtAlgo2.cpp:86-169) ----------
+        // ---------- check-and-extend by the lane itself (BGS-HostAlgnmtAlgo2.cpp:86-169: per candidate its suffix-array entry, then the text under the rest of the model, one 64-byte line = 256 characters per trip, compared as ceKernel compares) ----------
         if (state == U_CE_SA || state == U_CE_TEXT) {
             bool textHere = state == U_CE_TEXT;                               // the line of this trip belongs to the current candidate
             bool fresh = !textHere;                                           // the current candidate has not been set up yet
@@ -574,7 +574,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         // ---------- book the occurrences the unit holds for sure, where the other units of its read can see them: per item (itemAcc) and per position
         // (the spare word of the trunk states), S3_V2_COUNT_BATCH at a time and when the unit ends.  Everything in sequence order up to and including this
         // unit that adds up to MaxOutputPerRead puts the read's cut behind this unit; the items up to this one adding up to it put it behind the item
-        // (see searchKernelV2::countCertain) ----------
+        // (s3dp_search_common.h, "the cut") ----------
         if (countPending >= S3_V2_COUNT_BATCH || (state == U_DONE && countPending)) {
             const uint32_t cnt = countPending, sub = subIdx;
             countPending = 0;

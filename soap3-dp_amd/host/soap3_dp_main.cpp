@@ -196,6 +196,10 @@ static bool singleDpRuns(const HostIndex &hix, const SamOptions &so, FILE *paral
 
 static std::mutex g_pairStageMu;                                 // (several devices run the stages at once)
 static double g_pairStageSeconds[5] = {0, 0, 0, 0, 0};          // routing, default DP, new default DP, deep DP, single-end DP of the leftovers
+static double g_chunkSeconds[4] = {0, 0, 0, 0};                    // wall clock inside the chunk loop: alignment call, fetch of the results, formatting + writing, DP stages
+static void addChunkSeconds(int k, double sec) { std::lock_guard<std::mutex> g(g_pairStageMu); g_chunkSeconds[k] += sec; }
+static double g_streamSeconds[6] = {0, 0, 0, 0, 0, 0};             // streamed single reads: waiting for the loader, for a free slot, copying a chunk in; writer: waiting for results, formatting + writing
+static void addStreamSeconds(int k, double sec) { std::lock_guard<std::mutex> g(g_pairStageMu); g_streamSeconds[k] += sec; }
 static double g_deviceMs[4] = {0, 0, 0, 0};                        // device time: BWT stages (ladder), their search kernels; DP kernels; (spare)
 static uint64_t g_dpProblems = 0, g_dpCells = 0;
 static void addDeviceMs(int k, double ms) { std::lock_guard<std::mutex> g(g_pairStageMu); g_deviceMs[k] += ms; }
@@ -506,7 +510,7 @@ struct SharedIndex {
 
 static int runJob(int argc, char **argv, SharedIndex &shared)
 {
-    { std::lock_guard<std::mutex> g(g_pairStageMu); for (double &x : g_pairStageSeconds) x = 0; for (double &x : g_deviceMs) x = 0; g_dpProblems = g_dpCells = 0; }   // (per job: the *-multi modes run several)
+    { std::lock_guard<std::mutex> g(g_pairStageMu); for (double &x : g_pairStageSeconds) x = 0; for (double &x : g_deviceMs) x = 0; for (double &x : g_chunkSeconds) x = 0; for (double &x : g_streamSeconds) x = 0; g_dpProblems = g_dpCells = 0; }   // (per job: the *-multi modes run several)
     if (argc < 4) return die("usage: soap3-dp single <index> <reads> [options]\n       soap3-dp pair <index> <reads 1> <reads 2> [-u max insert] [-v min insert] [options]\n"
                              "       soap3-dp single-multi <index> <list file> [options]\n       soap3-dp pair-multi <index> <list file> [options]");
     const bool paired = strcmp(argv[1], "pair") == 0;
@@ -672,6 +676,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         while (w < (uint32_t)maxReadLength) w *= 2;
         chunk->wpq = w / 16 ? w / 16 : 1; chunk->maxReadLength = (uint32_t)maxReadLength;
     }
+    static const bool verboseTimeline = getenv("S3DP_VERBOSE") != nullptr;
+    auto mark = [&](const char *what) { if (verboseTimeline) fprintf(stderr, "[s3dp] member %d: %-44s at %8.3f s after the index was resident\n", member, what, since(tAlign)); };
+    mark("first chunk in hand");
     const std::string outName = prefix + ".gout." + fileNo;
     FILE *out = fopen(outName.c_str(), "w");
     if (!out) return dieJoin("Could not open the output file " + outName);
@@ -743,6 +750,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         s3_stream *st = nullptr;
         const uint32_t cap = chunk->n == chunkReads ? chunkReads : (chunk->n ? chunk->n : 1);
         if (s3_stream_create(ix, cap, chunk->wpq, 3, &st) != S3_OK) return dieJoin(s3_last_error());
+        mark("stream created");
         struct InFlight { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<ReadSet>> q; bool done = false; } fl;
         std::string werr;
         std::thread writer([&] {
@@ -758,8 +766,11 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 fl.cv.notify_all();
                 const ReadSet &rs = *rsP;
                 s3_stream_result res;
+                const auto tN = std::chrono::steady_clock::now();
                 if (s3_stream_next(st, &res) != S3_OK) { werr = s3_last_error(); fprintf(stderr, "%s\n", werr.c_str()); fflush(stderr); _exit(1); }
                 const uint32_t cnt = res.n;
+                addStreamSeconds(3, since(tN));
+                const auto tFm = std::chrono::steady_clock::now();
                 parallelFormat(hix, so, out, cnt, [&](SamWriter &w, uint32_t k, uint64_t &al) {
                     const size_t o = res.occOffsets[k], m = res.occOffsets[k + 1] - res.occOffsets[k];
                     uint8_t sbuf[64], mbuf[64];
@@ -776,15 +787,20 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                     if (m) al++;
                     w.singleEnd(rs, k, res.occPos + o, sp, mp, m, maxReadLength > 120 ? (rs.lengths[k] > 120 ? 100u : rs.lengths[k]) : 0u);
                 }, aligned);
+                addStreamSeconds(4, since(tFm));
                 if (s3_stream_release(st) != S3_OK) { fprintf(stderr, "%s\n", s3_last_error()); fflush(stderr); _exit(1); }
             }
         });
         while (chunk && chunk->n) {
             uint32_t *q = nullptr, *l = nullptr, *sl = nullptr;
+            const auto tAq = std::chrono::steady_clock::now();
             if (s3_stream_acquire(st, &q, &l, &sl) != S3_OK) return dieJoin(s3_last_error());
+            addStreamSeconds(1, since(tAq));
             const uint32_t cnt = chunk->n;
+            const auto tCp = std::chrono::steady_clock::now();
             memcpy(q, chunk->queries.data(), chunk->queries.size() * 4);
             memcpy(l, chunk->lengths.data(), (size_t)cnt * 4);
+            addStreamSeconds(2, since(tCp));
             // reads longer than 120 bases: only the first 100 are searched, the rest is verified on the device (alignment.cu:2473-2491)
             if (maxReadLength > 120) for (uint32_t k = 0; k < cnt; k++) sl[k] = chunk->lengths[k] > 120 ? 100u : chunk->lengths[k];
             if (s3_stream_submit(st, cnt, maxReadLength > 120, (uint32_t)numMismatch, ini.maxOutputPerRead, alignmentType, nullptr) != S3_OK) return dieJoin(s3_last_error());
@@ -794,7 +810,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 fl.q.push_back(std::move(chunk));
             }
             fl.cv.notify_all();
+            const auto tLd = std::chrono::steady_clock::now();
             chunk = nextChunk();
+            addStreamSeconds(0, since(tLd));
         }
         {
             std::lock_guard<std::mutex> g(fl.mu);
@@ -802,13 +820,17 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         }
         fl.cv.notify_all();
         writer.join();
+        mark("stream loop done");
         s3_stream_free(st);
+        mark("stream freed");
         if (!loaded.err.empty()) return dieJoin(loaded.err);
         chunk.reset();
     }
+    mark("DP aligners and seed batch created");
     s3_batch *b = nullptr;
     const uint32_t maxBatch = chunkReads;
     if (chunk && s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : (chunk->n ? chunk->n : 1), chunk->wpq, &b) != S3_OK) return dieJoin(s3_last_error());
+    mark("batch created");
     for (; chunk && chunk->n; chunk = nextChunk()) {
         ReadSet &rs = *chunk;
         const uint32_t first = 0, cnt = rs.n;
@@ -828,15 +850,21 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             if (skipSoap3) {
                 for (s3_pair_result &x : pr) { memset(&x, 0, sizeof x); x.min1 = x.min2 = 255; }     // no BWT stage: nothing paired, no hits
             } else {
+                const auto tA = std::chrono::steady_clock::now();
                 if (s3_batch_align_pair(b, (uint32_t)numMismatch, ini.maxHitsEachEndForPairing, alignmentType, (uint32_t)insertLow, (uint32_t)insertHigh,
                                         ini.peMaxOutputPerPair) != S3_OK) return dieJoin(s3_last_error());
+                if (s3_batch_sync(b) != S3_OK) return dieJoin(s3_last_error());
+                addChunkSeconds(0, since(tA));
+                const auto tF = std::chrono::steady_clock::now();
                 if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, ooff.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return dieJoin(s3_last_error());
                 addBatchTiming(b);
                 xa.resize(nXa ? nXa : 1); pos.resize(nOcc ? nOcc : 1); strand.resize(nOcc ? nOcc : 1); mis.resize(nOcc ? nOcc : 1); fromSa.resize(nOcc ? nOcc : 1);
                 if (s3_batch_fetch_pairs(b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK)
                     return dieJoin(s3_last_error());
                 if (enableDP && s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return dieJoin(s3_last_error());
+                addChunkSeconds(1, since(tF));
             }
+            const auto tW = std::chrono::steady_clock::now();
             parallelFormat(hix, so, out, np, [&](SamWriter &w, uint32_t p, uint64_t &al) {
                 const uint32_t r1 = first + 2 * p, r2 = r1 + 1;
                 if (pr[p].phase) {
@@ -850,12 +878,14 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                                    ini.maxHitsEachEndForPairing);
                 }
             }, aligned);
+            addChunkSeconds(2, since(tW));
             if (enableDP) {
                 PairDpCtx c{hix, so, rs, ini, b, seedBatch, dp, dpHalf, dpOut, unpairOut, first, cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
                 std::string e2;
                 const auto tDp = std::chrono::steady_clock::now();
                 if (!pairDpStages(c, pr, ooff, pos, strand, mis, fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) return dieJoin(e2);
                 dpStageSeconds += since(tDp);
+                addChunkSeconds(3, since(tDp));
             }
             continue;
         }
@@ -913,6 +943,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     closeOut(out);
     if (dpOut) {
         closeOut(dpOut);
+        mark("chunk loop done");
         if (paired) {
             closeOut(unpairOut);
             dpAlignedReads = 2 * (defaultDpPairs + newDefaultPairs + deepDpPairs);
@@ -925,6 +956,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         s3_batch_free(seedBatch);
     }
     if (b) s3_batch_free(b);
+    mark("aligners and batches freed");
     uint64_t *C = counters.data() + (size_t)member * C_COUNTERS;
     C[C_ALIGNED] = aligned; C[C_READS] = totalReads; C[C_DP_READS] = dpAlignedReads; C[C_DEFAULT_DP] = defaultDpPairs; C[C_NEW_DEFAULT_DP] = newDefaultPairs;
     C[C_DEEP_DP] = deepDpPairs; C[C_LEFTOVER] = leftoverPairs;
@@ -951,6 +983,10 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         else printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)counters[C_DP_READS]);
     }
     // device time of the run (HIP events): the BWT stages with their search kernels, and every launch of the DP kernels with the cells they filled
+    if (!paired && !enableDP) printf("[Main] Stream loop time : feeder waited %.3f for the loader, %.3f for a free slot, copied chunks in %.3f; writer waited %.3f for results, formatted + wrote %.3f seconds\n",
+                                     g_streamSeconds[0], g_streamSeconds[1], g_streamSeconds[2], g_streamSeconds[3], g_streamSeconds[4]);
+    if (paired) printf("[Main] Chunk loop time : alignment calls %.3f, fetching results %.3f, formatting + writing %.3f, DP stages %.3f seconds\n", g_chunkSeconds[0], g_chunkSeconds[1],
+                       g_chunkSeconds[2], g_chunkSeconds[3]);
     printf("[Main] Device time : BWT stages %.1f ms (search kernels %.1f ms)", g_deviceMs[0], g_deviceMs[1]);
     if (enableDP) printf(", DP kernels %.1f ms, %llu problems, %llu cells, %.1f GCUPS", g_deviceMs[2], (unsigned long long)g_dpProblems, (unsigned long long)g_dpCells,
                          g_deviceMs[2] > 0 ? (double)g_dpCells / (g_deviceMs[2] * 1e-3) / 1e9 : 0.0);

@@ -66,7 +66,7 @@ def test_cli_pairs_with_dp_on_two_members(tmp_path):
 
 def test_group_allreduce():
     hi = host_index("g1")
-    g = s3dp.Group(hi, [0])                                                    # one member: ncclCommInitAll + ncclAllReduce over one rank
+    g = s3dp.Group(hi, [0])                                                    # one member: nothing to exchange, the counters are the sums
     a = g.allreduce(np.array([[3, 5, 7]], dtype=np.uint64))
     assert a.tolist() == [[3, 5, 7]]
     assert g.member_of_batch(5) == 0

@@ -68,7 +68,6 @@ KNOBS = [
     {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8"},             # nearly every read is listed by its rank queries
     {"S3DP_HEAVY": "2", "S3DP_CE_INLINE_MAX": "1"},          # units hand their candidates to ceKernel after the first they verified
     {"S3DP_HEAVY": "2", "S3DP_CE_INLINE_MAX": "1000000", "S3DP_CE_GIVE_UP": "1000000"},
-    {"S3DP_HEAVY": "2", "S3DP_UNIT_KERNEL": "v2"},           # the searchKernelV2 instantiation the unit-pass kernel replaced
     {"S3DP_HEAVY": "2", "S3DP_UNIT_NODES": "0"},             # no adoption of frames: every unit is searched by one lane
     {"S3DP_HEAVY": "2", "S3DP_UNIT_NODES": "300"},           # the counters of adopted frames run out on the way
     {"S3DP_HEAVY": "2", "S3DP_BLOCKS_PER_CU": "1", "S3DP_CE_BLOCKS_PER_CU": "1"},

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Sum rocprofv3 --pmc counters per dispatch for kernels whose name contains a pattern (default: searchKernelV2)."""
+"""Sum rocprofv3 --pmc counters per dispatch for kernels whose name contains a pattern (default: firstKernel)."""
 import collections
 import csv
 import sys
 
-path, pat = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "searchKernelV2")
+path, pat = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "firstKernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 order = []
 for r in csv.DictReader(open(path)):

@@ -25,11 +25,11 @@ if want pmc; then     # HBM traffic of the search kernels: FETCH_SIZE in its own
   rm -rf /tmp/prof_pmc
   timeout 1200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_pmc -o pmc -- python3 bench.py $QUICK --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_fetch.log
   echo "pmc rc=$?"; f=$(find /tmp/prof_pmc -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python3 tools/pmc_summary.py "$f" searchKernelV2 > $OUT/pmc_fetch_search.txt; python3 tools/pmc_summary.py "$f" unitKernel > $OUT/pmc_fetch_unit.txt; python3 tools/pmc_summary.py "$f" ceKernel > $OUT/pmc_fetch_ce.txt; tail -4 $OUT/pmc_fetch_unit.txt; fi
+  if [ -n "$f" ]; then python3 tools/pmc_summary.py "$f" firstKernel > $OUT/pmc_fetch_first.txt; python3 tools/pmc_summary.py "$f" unitKernel > $OUT/pmc_fetch_unit.txt; python3 tools/pmc_summary.py "$f" ceKernel > $OUT/pmc_fetch_ce.txt; tail -4 $OUT/pmc_fetch_unit.txt; fi
   rm -rf /tmp/prof_pmc
   timeout 1200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/prof_pmc -o pmc -- python3 bench.py $QUICK --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_sq.log
   echo "pmc sq rc=$?"; f=$(find /tmp/prof_pmc -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python3 tools/pmc_summary.py "$f" searchKernelV2 > $OUT/pmc_sq_search.txt; python3 tools/pmc_summary.py "$f" unitKernel > $OUT/pmc_sq_unit.txt; python3 tools/pmc_summary.py "$f" ceKernel > $OUT/pmc_sq_ce.txt; tail -4 $OUT/pmc_sq_unit.txt; fi
+  if [ -n "$f" ]; then python3 tools/pmc_summary.py "$f" firstKernel > $OUT/pmc_sq_first.txt; python3 tools/pmc_summary.py "$f" unitKernel > $OUT/pmc_sq_unit.txt; python3 tools/pmc_summary.py "$f" ceKernel > $OUT/pmc_sq_ce.txt; tail -4 $OUT/pmc_sq_unit.txt; fi
 fi
 if want dp; then      # DP kernel: GCUPS, kernel stats, counters on 4096 problems per shape
   timeout 600 python3 tools/bench_dp.py > $OUT/dp_gcups.jsonl 2> $OUT/dp_gcups.log; echo "dp rc=$?"; cat $OUT/dp_gcups.jsonl | cut -c1-220
