@@ -846,7 +846,7 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
             if not ((ph == phase[first:first + m]).all() and (of.astype(np.int64) == (offs[first:first + m + 1].astype(np.int64) - lo)).all() and
                     (po == pos[lo:hi]).all() and (sr == strand[lo:hi]).all() and (mi == mis[lo:hi]).all()):
                 mism.append(first)
-        streamed = s3dp.stream_bench(ix, q, lens, wpq, a.mismatch, a.max_out, a.stream_batch, a.steps, check=chk)
+        streamed = s3dp.stream_bench(ix, q, lens, wpq, a.mismatch, a.max_out, a.stream_batch, a.steps, depth=a.stream_depth, check=chk)
         if mism:
             raise SystemExit("bench.py: streamed results differ from the resident batch's (batches at reads %r)" % mism[:5])
         streamed["same_results_as_resident"] = True
@@ -964,6 +964,7 @@ def main():
     ap.add_argument("--uniform", type=int, default=1, help="N = 1 only: also run the repeat-free genome of round 1 (reported under extras)")
     ap.add_argument("--streaming", type=int, default=1, help="also time the streamed form (uploads and downloads inside the timed region)")
     ap.add_argument("--stream-batch", type=int, default=1 << 22, help="reads per streamed batch (the reference reads 1 Mi at a time, SOAP3-DP.cu:394; a launch here lasts as long as its longest unit, so larger batches pay)")
+    ap.add_argument("--stream-depth", type=int, default=3, help="batches in flight in the streamed form")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle after the run")
     ap.add_argument("--index-dir", default=None, help="keep / reuse the index files of the benchmark genome in this directory")

@@ -164,12 +164,14 @@ void s3_stream_free(s3_stream *st);
 
 /* ---- several devices -------------------------------------------------------------------------------------------------------------
  * The reference takes ONE device (`-c <id>`, SOAP3-DP.cu:219-220, README.md:523-536).  The path shards by reads, so a group of devices each holds
- * the whole index (s3_group_create uploads it to every member at once) and aligns its own batches -- s3_group_member_of_batch deals batch i to
- * member i mod n; a batch holds whole pairs, mates stay together (CPUfunctions.cpp:1982,2029).  Batches, streams and DP aligners are created on
+ * the whole index (s3_group_create uploads it to every member at once) and aligns its own batches -- s3_group_member_of_batch is the
+ * static deal (batch i to member i mod n) for callers that want a reproducible assignment; the `soap3-dp -c a,b` command line instead hands a chunk to
+ * whichever member is free (which member's files a read lands in then depends on timing: the UNION of the members' files is the result, as the reference's
+ * .gout.N files are the union over its CPU threads).  A batch holds whole pairs, mates stay together (CPUfunctions.cpp:1982,2029).  Batches, streams and DP aligners are created on
  * s3_group_index(g, k) like on any index.  The single exchange step is the sum of the counters at the end (the `[Main] Overall ...` numbers,
  * SOAP3-DP.cu:816-830): s3_group_allreduce takes nMembers rows of nCounters values and leaves the column sums in every row, computed by one
- * ncclAllReduce over the members' devices (RCCL; members that share a device -- a test on one GPU -- are summed on the host instead, RCCL needs
- * distinct devices).  Output: one set of files per member, as the reference writes one .gout.N per CPU thread (SOAP3-DP.cu:251-258). */
+ * ncclAllReduce over the members' devices (RCCL; the communicators are made while the index uploads; a group of one member has nothing to exchange and
+ * makes none; members that share a device -- a test on one GPU -- are summed on the host instead, RCCL needs distinct devices).  Output: one set of files per member, as the reference writes one .gout.N per CPU thread (SOAP3-DP.cu:251-258). */
 typedef struct s3_group s3_group;
 int  s3_group_create(const int *devices, int nDevices, const s3_index_desc *desc, s3_group **out);
 int  s3_group_size(const s3_group *g);

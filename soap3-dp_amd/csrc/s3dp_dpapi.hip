@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <hipcub/hipcub.hpp>
 #include <thread>
+#include <chrono>
 #include "s3dp_internal.h"
 
 using namespace s3;
@@ -86,15 +87,96 @@ __global__ void dpGatherPatternsKernel(uint32_t n, const unsigned char *rows, ui
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (uint64_t)n * pitch) return;
     const uint32_t p = (uint32_t)(k / pitch), o = (uint32_t)(k - (uint64_t)p * pitch);
-    tight[k] = rows[(size_t)p * rowPitch + o];
+    // (the last byte of a row is always the terminator: a pattern that filled its whole row -- the traceback drops the terminator then -- must not
+    //  run the decoders' loops into the next row)
+    tight[k] = o + 1u == pitch ? (unsigned char)0 : rows[(size_t)p * rowPitch + o];
+}
+
+// ---- decode of the traceback on the device (CigarStringEncoder, edit-distance counts: DV-DPfunctions.cu:2363-2403, :3768-3818) -----------
+// One lane per problem reads the pattern the traceback left (reversed string of M m D I S and 'V'<n> run markers) and writes a DECODED ROW into the
+// problem's part of the traceback table, which nobody needs any more:  [int32 insertions][int32 deletions][int32 soft clips][int32 gap penalty]
+// [CIGAR text, 0-terminated].  The CIGAR text is what the engines' host code used to build per problem: runs of equal operations merged in pattern
+// order, printed from the last run to the first (the pattern is reversed), a zero-length run separating what it stands between.
+__global__ void dpDecodeKernel(uint32_t n, const unsigned char *pattern, uint32_t patternLen, const int32_t *scores, const int32_t *cutoffs, int gapOpen, int gapExtend,
+                               uint32_t *table, size_t tableWordsPerProblem, uint32_t *rowMax)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t *base = table + (size_t)p * tableWordsPerProblem;
+    int32_t *hdr = (int32_t *)base;
+    char *text = (char *)(base + 4);
+    uint32_t *runs = base + 4 + (2u * patternLen + 8u) / 4u + 1u;             // (a run of one operation prints as two characters: the text never outgrows 2 x pattern)
+    hdr[0] = hdr[1] = hdr[2] = hdr[3] = 0;
+    text[0] = 0;
+    if (scores[p] < cutoffs[p]) return;
+    const unsigned char *pat = pattern + (size_t)p * patternLen;
+    uint32_t nRuns = 0;
+    int lastType = 'N', lastCnt = 0, last = 'N';
+    auto append = [&](int type, int cnt) {
+        if (lastType == type) lastCnt += cnt;
+        else { if (lastCnt > 0) runs[nRuns++] = (uint32_t)lastType << 24 | (uint32_t)lastCnt; lastType = type; lastCnt = cnt; }
+    };
+    for (uint32_t k = 0; k < patternLen && pat[k] != 0; k++) {
+        if (pat[k] == 'V') { k++; if (k < patternLen) append(last, (int)pat[k] - 1); }
+        else { append((int)pat[k], 1); last = (int)pat[k]; }
+    }
+    append('N', 0);
+    uint32_t o = 0;
+    int nI = 0, nD = 0, nS = 0, gap = 0;
+    for (uint32_t r = nRuns; r-- > 0;) {
+        const int type = (int)(runs[r] >> 24), cnt = (int)(runs[r] & 0xFFFFFFu);
+        char dig[12];
+        int nd = 0, v = cnt;
+        do { dig[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (nd) text[o++] = dig[--nd];
+        text[o++] = (char)type;
+        if (type == 'I') { nI += cnt; gap += gapOpen + (cnt - 1) * gapExtend; }
+        else if (type == 'D') { nD += cnt; gap += gapOpen + (cnt - 1) * gapExtend; }
+        else if (type == 'S') nS += cnt;
+    }
+    text[o] = 0;
+    hdr[0] = nI; hdr[1] = nD; hdr[2] = nS; hdr[3] = gap;
+    atomicMax(rowMax, 16u + o + 1u);
+}
+
+__global__ void dpGatherRowsKernel(uint32_t n, const uint32_t *table, size_t tableWordsPerProblem, unsigned char *tight, uint32_t pitch)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (uint64_t)n * pitch) return;
+    const uint32_t p = (uint32_t)(k / pitch), o = (uint32_t)(k - (uint64_t)p * pitch);
+    tight[k] = o + 1u == pitch ? (unsigned char)0 : ((const unsigned char *)(table + (size_t)p * tableWordsPerProblem))[o];
+}
+
+// the decoded rows of the last dpRun, `pitch` bytes each (see dpDecodeKernel).  A problem below its cutoff has an empty text.
+int s3i::dpFetchDecoded(s3_dp *h, uint32_t n, std::vector<uint8_t> &rows, uint32_t &pitch)
+{
+    if (h->tableWords * 4u < 64u + 8u * (size_t)h->patternLen) return fail(S3_EINVAL, "dpFetchDecoded: the aligner's table is too small to decode in");
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemsetAsync(h->dPatMax, 0, 4, s));
+    if (n) hipLaunchKernelGGL(dpDecodeKernel, dim3((n + 63) / 64), dim3(64), 0, s, n, h->dPattern, h->patternLen, h->dScores, h->dCut, h->sc.gapOpenScore, h->sc.gapExtendScore,
+                              h->dTable, h->tableWords, h->dPatMax);
+    uint32_t mx = 0;
+    HIPCHK(d2h(&mx, h->dPatMax, 4, s));
+    if (mx < 20u) mx = 20u;
+    pitch = ((mx + 3u) & ~3u) + 4u;
+    rows.resize((size_t)n * pitch);
+    if (n) {
+        if ((size_t)n * pitch > (size_t)h->maxProblems * h->patternLen) return fail(S3_EINVAL, "dpFetchDecoded: no room to gather the rows");
+        const uint64_t total = (uint64_t)n * pitch;
+        hipLaunchKernelGGL(dpGatherRowsKernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, n, h->dTable, h->tableWords, h->dPattern, pitch);     // (the patterns are spent)
+        HIPCHK(hipMemcpyAsync(rows.data(), h->dPattern, (size_t)total, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return S3_OK;
 }
 
 int s3i::dpFetchPatterns(s3_dp *h, uint32_t n, std::vector<uint8_t> &pat, uint32_t &pitch)
 {
     uint32_t mx = 0;
     HIPCHK(d2h(&mx, h->dPatMax, 4, h->stream));                        // (synchronises the stream: the results queued before it have arrived too)
-    if (mx == 0 || mx > h->patternLen) mx = h->patternLen;
-    pitch = (mx + 3u) & ~3u;
+    if (mx > h->patternLen) mx = h->patternLen;
+    if (mx == 0) mx = 1;                                               // no problem of the launch reached its cutoff: nobody reads a pattern
+    pitch = ((mx + 3u) & ~3u) + 4u;                                    // (room for the forced terminator behind the longest pattern)
     if (pitch > h->patternLen) pitch = h->patternLen;
     pat.resize((size_t)n * pitch);
     if (n) {
@@ -312,33 +394,17 @@ __global__ void dpPackKernel(uint32_t n, const DpCand *cand, const uint32_t *tex
 
 namespace {
 // CigarStringEncoder (DV-DPfunctions.h:548-597): runs are collected in traceback order and written out reversed
-struct CigarEnc {
-    std::vector<std::pair<char, int>> runs;
-    char lastType = 'N';
-    int lastCnt = 0;
-    int count[128];
-    int gapPenalty = 0;
-    std::string text;
-    void append(char type, int cnt)
+// a decoded row (dpDecodeKernel): the counts the engines need and the CIGAR text
+struct DecodedRow {
+    int nI, nD, nS, gapPenalty;
+    const char *text;
+    DecodedRow(const std::vector<uint8_t> &rows, uint32_t pitch, uint32_t id)
     {
-        if (lastType == type) lastCnt += cnt;
-        else { runs.emplace_back(lastType, lastCnt); lastType = type; lastCnt = cnt; }
-    }
-    void encode(int gapOpen, int gapExtend)
-    {
-        memset(count, 0, sizeof count);
-        gapPenalty = 0;
-        append('N', 0);
-        for (size_t i = runs.size(); i-- > 1;) {
-            const char type = runs[i].first;
-            const int cnt = runs[i].second;
-            if (cnt > 0) {
-                text += std::to_string(cnt);
-                text.push_back(type);
-                count[(int)type] += cnt;
-                if (type == 'I' || type == 'D') gapPenalty += gapOpen + (cnt - 1) * gapExtend;
-            }
-        }
+        const uint8_t *r = rows.data() + (size_t)id * pitch;
+        int32_t hdr[4];
+        memcpy(hdr, r, 16);
+        nI = hdr[0]; nD = hdr[1]; nS = hdr[2]; gapPenalty = hdr[3];
+        text = (const char *)r + 16;
     }
 };
 }  // namespace
@@ -410,8 +476,8 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
         HIPCHK(hipMemcpyAsync(scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        if ((rc = dpFetchPatterns(h, n, pat, pitch))) return rc;
         if ((rc = dpDump(h, n, true, true, true, true))) return rc;
+        if ((rc = dpFetchDecoded(h, n, pat, pitch))) return rc;
         // algnmtCPUThread (:2329-2441)
         decodeParallel<s3_dp_half_result>(n, results, pool, [&](uint32_t id, std::vector<s3_dp_half_result> &results, std::string &pool) {
             s3_dp_half_result r{};
@@ -420,23 +486,17 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
             r.cigarOffset = 0xFFFFFFFFu;
             uint32_t dpPos;
             if (scores[id] >= cutoffThreshold[1 - alignedIsMate]) {
-                CigarEnc enc;
-                char last = 'N';
-                for (const uint8_t *p = pat.data() + (size_t)id * pitch; *p != 0; p++) {
-                    if (*p == 'V') enc.append(last, (int)*(++p) - 1);
-                    else { enc.append((char)*p, 1); last = (char)*p; }
-                }
-                enc.encode(h->sc.gapOpenScore, h->sc.gapExtendScore);
+                const DecodedRow enc(pat, pitch, id);
                 r.cigarOffset = (uint32_t)pool.size();
                 pool += enc.text;
                 pool.push_back('\0');
-                const int L = (int)rdLens[id] - enc.count['I'] - enc.count['S'];
+                const int L = (int)rdLens[id] - enc.nI - enc.nS;
                 const int numMis = (L * h->sc.matchScore + enc.gapPenalty - scores[id]) / (h->sc.matchScore - h->sc.mismatchScore);
-                r.editdist = (uint32_t)(enc.count['I'] + enc.count['D'] + numMis);
+                r.editdist = (uint32_t)(enc.nI + enc.nD + numMis);
                 r.whichFromDP = (uint8_t)(1 - alignedIsMate);
                 dpPos = startLocs[id] + hit[id];
                 if (dpPos < refer[id].pos) r.insertSize = refer[id].pos - dpPos + readLengths[alignedID];
-                else r.insertSize = dpPos - refer[id].pos + rdLens[id] + (uint32_t)enc.count['D'] - (uint32_t)enc.count['I'] - (uint32_t)enc.count['S'];
+                else r.insertSize = dpPos - refer[id].pos + rdLens[id] + (uint32_t)enc.nD - (uint32_t)enc.nI - (uint32_t)enc.nS;
                 r.num_sameScore = cnt[id];
             } else { r.whichFromDP = 2; dpPos = 0xFFFFFFFFu; }
             const uint8_t dpStrand = (uint8_t)(leftOrRight[id] == 0 ? leftLeg : rightLeg);
@@ -570,23 +630,17 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
         ECHK(hipMemcpyAsync(scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         ECHK(hipMemcpyAsync(hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         ECHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        if ((rc = dpFetchPatterns(h, n, pat, pitch))) break;
 #undef ECHK
         if ((rc = dpDump(h, n, true, true, false, false))) break;
+        if ((rc = dpFetchDecoded(h, n, pat, pitch))) break;
         decodeParallel<s3_dp_single_result>(n, results, pool, [&](uint32_t i, std::vector<s3_dp_single_result> &results, std::string &pool) {
             if (scores[i] < cutoffThreshold) return;
-            CigarEnc enc;
-            char last = 'N';
-            for (const uint8_t *p = pat.data() + (size_t)i * pitch; *p != 0; p++) {
-                if (*p == 'V') enc.append(last, (int)*(++p) - 1);
-                else { enc.append((char)*p, 1); last = (char)*p; }
-            }
-            enc.encode(h->sc.gapOpenScore, h->sc.gapExtendScore);
+            const DecodedRow enc(pat, pitch, i);
             s3_dp_single_result r{};
             r.readID = cand[i].readId; r.strand = (uint8_t)cand[i].strand; r.algnmt = cand[i].start + hit[i]; r.score = scores[i];
-            const int L = (int)rdLens[i] - enc.count['I'] - enc.count['S'];
+            const int L = (int)rdLens[i] - enc.nI - enc.nS;
             const int numMis = (L * h->sc.matchScore + enc.gapPenalty - scores[i]) / (h->sc.matchScore - h->sc.mismatchScore);
-            r.editdist = (uint32_t)(enc.count['I'] + enc.count['D'] + numMis);
+            r.editdist = (uint32_t)(enc.nI + enc.nD + numMis);
             r.num_sameScore = cnt[i];
             r.cigarOffset = (uint32_t)pool.size();
             pool += enc.text;
@@ -662,6 +716,11 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
 {
     if (!h || !b || !seedBatch || !readLengths || (!pairFirstReads && nPairs) || !cutoffThreshold || !resultsOut || !nResultsOut || !cigarPoolOut)
         return fail(S3_EINVAL, "s3_dp_deep: null argument");
+    // S3DP_VERBOSE: where a call's time goes (stderr)
+    static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
+    auto tLap = std::chrono::steady_clock::now();
+    double lapMs[6] = {0, 0, 0, 0, 0, 0};                                     // seeds listed, seeds searched, positions sorted + merged, DP rounds, decode, rest
+    auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); lapMs[k] += std::chrono::duration<double, std::milli>(now - tLap).count(); tLap = now; };
     // new default DP: the end whose hits are given is not seeded (packSeedsOneSide seeds the mate of the pair's FIRST occurrence, DV-DPfunctions.cu:2756-2776)
     std::vector<uint8_t> givenEnd(nPairs, 255);
     for (size_t i = 0; i < nGiven; i++) {
@@ -692,8 +751,12 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
     }
     std::vector<uint64_t> keys;
     std::vector<uint8_t> status;
-    int rc = seedSearchKeys(b, seedBatch, seeds, maxHitNum, 30, keys, status);
+    uint64_t *dKeys = nullptr;
+    uint32_t nKeys = 0;
+    lap(0);
+    int rc = seedSearchKeys(b, seedBatch, seeds, maxHitNum, 30, keys, status, &dKeys, &nKeys);
     if (rc) return rc;
+    lap(1);
     // a pair with a seed dropped for too many hits is flagged (tooManyHitFlags, :2940-2944)
     std::vector<uint8_t> tooMany(nPairs, 0);
     if (tooManyHitsOut) {
@@ -701,65 +764,19 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
         for (size_t k = 0; k < nPairs; k++)
             for (; j < seeds.size() && (seeds[j].keyHi & 0x3FFFFFFFu) == pairFirstReads[k]; j++) if (status[j] == 4) tooMany[k] = 1;
     }
-    // four sorted runs: [end][strand], entries = (pair's first read, position)
-    struct Pos { uint32_t id, pos; };
-    std::vector<Pos> arr[2][2];
-    for (uint64_t key : keys) {
-        const uint32_t hi = (uint32_t)(key >> 32);
-        arr[hi >> 31][(hi >> 30) & 1u].push_back(Pos{hi & 0x3FFFFFFFu, (uint32_t)key});
-    }
-    if (nGiven) {
-        // the given hits stand in front of the seed hits (decodePositions :2896-2899) and everything is sorted by (pair, position) again
-        for (size_t i = 0; i < nGiven; i++) {
-            if (given[i].strand < 1 || given[i].strand > 2) return fail(S3_EINVAL, "s3_dp_new_default: bad strand");
-            arr[given[i].readID & 1u][given[i].strand - 1].push_back(Pos{given[i].readID & ~1u, given[i].pos});
-        }
-        for (int e = 0; e < 2; e++)
-            for (int st2 = 0; st2 < 2; st2++)
-                std::stable_sort(arr[e][st2].begin(), arr[e][st2].end(), [](const Pos &x, const Pos &y) { return x.id != y.id ? x.id < y.id : x.pos < y.pos; });
-    }
-    // ---- pairEndMerge: left = '+' hits of one end (compressed by DP2_DIVIDE_GAP), right = '-' hits of the other end --------------------
-    std::vector<PairCand> cands;
-    auto merge = [&](std::vector<Pos> &left, const std::vector<Pos> &right, uint32_t leftIsMate) {
-        size_t li = 0, ri = 0;
-        while (li < left.size() && ri < right.size()) {
-            if (left[li].id < right[ri].id) { li++; continue; }
-            if (right[ri].id < left[li].id) { ri++; continue; }
-            const uint32_t id = left[li].id;
-            size_t le = li, re = ri;
-            while (le < left.size() && left[le].id == id) le++;
-            while (re < right.size() && right[re].id == id) re++;
-            // MC_Compress on the left run
-            size_t w = li;
-            uint32_t prev = left[li].pos;
-            for (size_t p = li + 1; p < le; p++) if (prev + 50u < left[p].pos) { left[++w] = left[p]; prev = left[p].pos; }
-            const size_t lend = w + 1;
-            const int readLength = (int)readLengths[id];                            // readLengths[readID] with the pair's first read, as the reference
-            const int margin = readLength > 100 ? readLength >> 2 : 25;            // DP2_MARGIN
-            int lengthLow = insertLow - readLength - margin;
-            if (lengthLow < 0) lengthLow = 0;
-            const int lengthHigh = insertHigh - readLength + margin;
-            size_t lp = li, rp = ri;
-            while (lp < lend && rp < re) {
-                const uint32_t readLoc = left[lp].pos, mateLoc = right[rp].pos;
-                if (readLoc + (uint32_t)lengthLow > mateLoc) rp++;
-                else if (readLoc + (uint32_t)lengthHigh < mateLoc) lp++;
-                else { cands.push_back(PairCand{{readLoc, mateLoc}, id + leftIsMate}); lp++; }
-            }
-            li = le; ri = re;
-        }
-    };
-    merge(arr[0][leftLeg - 1], arr[1][rightLeg - 1], 0);                            // read left, mate right
-    merge(arr[1][leftLeg - 1], arr[0][rightLeg - 1], 1);                            // mate left, read right
-    std::stable_sort(cands.begin(), cands.end(), [](const PairCand &x, const PairCand &y) { return x.readIDLeft < y.readIDLeft; });
+    for (size_t i = 0; i < nGiven; i++) if (given[i].strand < 1 || given[i].strand > 2) { (void)hipFree(dKeys); return fail(S3_EINVAL, "s3_dp_new_default: bad strand"); }
+    // ---- pairEndMerge on the device (s3dp_seed.hip): the positions never come to the host; the candidates do, ordered by the left read --------------------
+    std::vector<PairCandHost> candsDev;
+    std::vector<uint32_t> perPair;
+    rc = pairMergeOnDevice(b, dKeys, nKeys, given, nGiven, pairFirstReads, nPairs, insertLow, insertHigh, candsDev, perPair);
+    (void)hipFree(dKeys);
+    if (rc) return rc;
+    std::vector<PairCand> cands(candsDev.size());
+    for (size_t i = 0; i < candsDev.size(); i++) cands[i] = PairCand{{candsDev[i].pos[0], candsDev[i].pos[1]}, candsDev[i].readIDLeft};
     // bit 1 of the per-pair flag: the pair has candidates (alignFlags of performSeeding, :3110-3121 -- only pairs WITHOUT candidates are
     // seeded again in round 2 or handed on as unseeded)
-    if (tooManyHitsOut)
-        for (const PairCand &c : cands) {
-            const uint32_t even = c.readIDLeft & ~1u;
-            const uint32_t *it = std::lower_bound(pairFirstReads, pairFirstReads + nPairs, even);
-            if (it != pairFirstReads + nPairs && *it == even) tooMany[(size_t)(it - pairFirstReads)] |= 2;
-        }
+    if (tooManyHitsOut) for (size_t k = 0; k < nPairs; k++) if (perPair[k]) tooMany[k] |= 2;
+    lap(2);
     // ---- two DP rounds per batch of candidates ---------------------------------------------------------------------------------------
     HIPCHK(hipSetDevice(h->dev));
     const uint32_t fullDNALength = b->ix->d.n;
@@ -797,8 +814,8 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
         ECHK(hipMemcpyAsync(R.scores.data(), h->dScores, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         ECHK(hipMemcpyAsync(R.hit.data(), h->dHit, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         ECHK(hipMemcpyAsync(R.cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        { const int rc3 = dpFetchPatterns(h, n, R.pat, R.pitch); if (rc3) return rc3; }
-        return dpDump(h, n, true, true, true, true);
+        { const int rc3 = dpDump(h, n, true, true, true, true); if (rc3) return rc3; }
+        return dpFetchDecoded(h, n, R.pat, R.pitch);
     };
     auto window = [&](uint32_t pos, uint32_t readLength, uint32_t &start, uint32_t &len) {
         const uint32_t margin = readLength > 100 ? readLength >> 2 : 25;
@@ -855,6 +872,7 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
         }
         if (rc) break;
         if (m && (rc = runRound(candR, dnaR, rdR, cutR, clipLtR, clipRtR, aLR, aRR, RR))) break;
+        lap(3);
         // DP2CPUAlgnThread: both ends above their cutoffs
         decodeParallel<s3_dp_deep_result>(m, results, pool, [&](uint32_t k, std::vector<s3_dp_deep_result> &results, std::string &pool) {
             const uint32_t i = sel[k];
@@ -867,18 +885,12 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
             std::string cig[2];
             int editdist[2], DIS[2];
             for (int lOr = 0; lOr < 2; lOr++) {
-                CigarEnc enc;
-                char last = 'N';
-                for (const uint8_t *p = rd[lOr]->pat.data() + (size_t)idx[lOr] * rd[lOr]->pitch; *p != 0; p++) {
-                    if (*p == 'V') enc.append(last, (int)*(++p) - 1);
-                    else { enc.append((char)*p, 1); last = (char)*p; }
-                }
-                enc.encode(h->sc.gapOpenScore, h->sc.gapExtendScore);
+                const DecodedRow enc(rd[lOr]->pat, rd[lOr]->pitch, idx[lOr]);
                 cig[lOr] = enc.text;
-                const int L = (int)rdR[k] - enc.count['I'] - enc.count['S'];
+                const int L = (int)rdR[k] - enc.nI - enc.nS;
                 const int numMis = (L * h->sc.matchScore + enc.gapPenalty - rd[lOr]->scores[idx[lOr]]) / (h->sc.matchScore - h->sc.mismatchScore);
-                editdist[lOr] = enc.count['I'] + enc.count['D'] + numMis;
-                DIS[lOr] = enc.count['D'] - enc.count['I'] - enc.count['S'];
+                editdist[lOr] = enc.nI + enc.nD + numMis;
+                DIS[lOr] = enc.nD - enc.nI - enc.nS;
             }
             const uint32_t posOf[2] = {startL[i] + RL.hit[i], startR[k] + RR.hit[k]};
             s3_dp_deep_result r{};
@@ -894,6 +906,7 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
             r.cigarOffset_2 = (uint32_t)pool.size(); pool += cig[mateSide]; pool.push_back('\0');
             results.push_back(r);
         }, [](s3_dp_deep_result &r, uint32_t base) { r.cigarOffset_1 += base; r.cigarOffset_2 += base; });
+        lap(4);
     }
 #undef ECHK
     (void)hipFree(dCand);
@@ -905,6 +918,11 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
     memcpy(out, results.data(), results.size() * sizeof(s3_dp_deep_result));
     memcpy(cp, pool.data(), pool.size());
     if (tm) { memcpy(tm, tooMany.data(), nPairs); *tooManyHitsOut = tm; }
+    lap(5);
+    if (verbose)
+        fprintf(stderr, "[s3dp] deep DP stage %d: %zu pairs, %zu given hits, %zu seeds, %zu positions, %zu candidates, %zu results: seeds listed %.1f ms, searched %.1f, sorted + merged %.1f, "
+                        "DP rounds %.1f, decode %.1f, rest %.1f\n", stage, nPairs, nGiven, seeds.size(), (size_t)nKeys, cands.size(), results.size(), lapMs[0], lapMs[1], lapMs[2], lapMs[3],
+                lapMs[4], lapMs[5]);
     *resultsOut = out; *nResultsOut = results.size(); *cigarPoolOut = cp;
     return S3_OK;
 }

@@ -203,7 +203,12 @@ void launchStateAll(uint32_t n, const uint32_t *totalOcc, uint8_t *state, hipStr
 // seeding (s3dp_seed.hip)
 struct SeedDesc { uint32_t readId, off, len, keyHi; };   // seed of read `readId` at `off`; keyHi = the upper key bits its hits sort by
 int seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<SeedDesc> &seeds, uint32_t maxHitNum, uint32_t strandBit,
-                   std::vector<uint64_t> &keysSorted, std::vector<uint8_t> &seedStatus);
+                   std::vector<uint64_t> &keysSorted, std::vector<uint8_t> &seedStatus, uint64_t **devKeysOut = nullptr, uint32_t *nKeysOut = nullptr);
+// pairEndMerge on the device (s3dp_seed.hip): the sorted position keys of both ends (device; plus `given` occurrences, new default DP) -> the pairs of
+// (left, right) positions inside the insert window, ordered by the left read; perPair[k] = candidates of pairFirstReads[k] (both orientations)
+struct PairCandHost { uint32_t pos[2]; uint32_t readIDLeft; };
+int pairMergeOnDevice(s3_batch *b, uint64_t *dKeys, uint32_t nKeys, const s3_occ *given, size_t nGiven, const uint32_t *pairFirstReads, size_t nPairs, int insertLow,
+                      int insertHigh, std::vector<PairCandHost> &cands, std::vector<uint32_t> &perPair);
 // enqueue the 64-bit sum of counts[0, n) into b->dSum64 (uses b->dTemp: call it after the scan that shares the scratch was enqueued, same stream)
 int sum64Async(s3_batch *b, const uint32_t *counts, uint32_t n);
 // DP (s3dp_dpapi.hip): launch the DP kernels on what is in the aligner's device buffers
@@ -211,6 +216,8 @@ int dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool
 // the patterns of the last dpRun, one row of `pitch` bytes per problem (pitch = the longest pattern with its terminator, not the aligner's patternLen:
 // a pattern is a few dozen bytes, the row it is written into eight hundred)
 int dpFetchPatterns(s3_dp *h, uint32_t n, std::vector<uint8_t> &pat, uint32_t &pitch);
+// the same decoded on the device: per problem [int32 insertions, deletions, soft clips, gap penalty][CIGAR text, 0-terminated] (dpDecodeKernel, s3dp_dpapi.hip)
+int dpFetchDecoded(s3_dp *h, uint32_t n, std::vector<uint8_t> &rows, uint32_t &pitch);
 // S3DP_DUMP_DP=<file> (tests): the problems of the last dpRun with their results, and stage separators
 int dpDump(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL, bool hasAR);
 void dpDumpNote(const char *line);

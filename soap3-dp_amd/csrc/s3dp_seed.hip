@@ -63,9 +63,87 @@ __global__ void seedKeysKernel(uint32_t nSeeds, const SeedDesc *seeds, const uin
     }
 }
 
-// Search the seeds and return their hits as sorted 64-bit keys: (keyHi | strand bit) << 32 | estimated read position.
+// ---- candidate merges on the device --------------------------------------------------------------------------------------------
+// singleMerge (DV-DPfunctions.cu:1102-1141): inside one (strand, read) run of the sorted keys the first position is kept, then every position more than
+// DPS_DIVIDE_GAP = 50 beyond the last KEPT one -- a chain along the run, so the lane that finds itself at the head of a run walks it (runs are a few
+// seeds' worth of hits); a counting walk, a scan, a writing walk.
+__global__ void singleMergeKernel(const uint64_t *keys, uint32_t n, const uint32_t *offsets, uint32_t *counts, s3_seed_candidate *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t run = keys[i] >> 32;
+    if (i && (keys[i - 1] >> 32) == run) { if (!out) counts[i] = 0; return; }
+    uint32_t prev = (uint32_t)keys[i], kept = 1;
+    const uint32_t at = out ? offsets[i] : 0u;
+    if (out) out[at] = s3_seed_candidate{(uint32_t)(run & 0x7FFFFFFFu), prev, (uint8_t)((run >> 31) ? 2 : 1), {0, 0, 0}};
+    for (uint32_t k = i + 1; k < n && (keys[k] >> 32) == run; k++) {
+        const uint32_t cur = (uint32_t)keys[k];
+        if ((uint64_t)prev + 50u < cur) {
+            if (out) out[at + kept] = s3_seed_candidate{(uint32_t)(run & 0x7FFFFFFFu), cur, (uint8_t)((run >> 31) ? 2 : 1), {0, 0, 0}};
+            kept++; prev = cur;
+        }
+    }
+    if (!out) counts[i] = kept;
+}
+
+// pairEndMerge (DV-DPfunctions.cu:2780-2883) for one orientation: the '+' positions of one end (the LEFT run: keys [l0, l1)) against the '-' positions of the
+// other end (the RIGHT run: keys [r0, r1)), both sorted by (pair, position), a key = (... | pair's first read) << 32 | position.  Per pair: the left positions
+// compressed by DP2_DIVIDE_GAP (a position more than 50 beyond the last KEPT one is kept), then the reference's two-pointer sweep -- a left position takes the
+// first right position at or beyond readLoc + lengthLow (the right pointer never goes back: the bounds rise with the left positions) if that is not beyond
+// readLoc + lengthHigh.  The lane at the head of a pair's left run walks it.  out == NULL: count into counts[2 * pairRank + leftIsMate]; else write behind
+// offsets[...].  pairRank = the pair's place in pairFirstReads (ascending), so the candidates come out sorted by the left read, as the reference sorts them.
+struct PairCandDev { uint32_t posLeft, posRight, readIDLeft; };
+__global__ void pairMergeKernel(const uint64_t *keys, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1, uint32_t leftIsMate, const uint32_t *readLengths,
+                                const uint32_t *pairFirstReads, uint32_t nPairs, int insertLow, int insertHigh, uint32_t *counts, const uint32_t *offsets, PairCandDev *out)
+{
+    const uint32_t i = l0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= l1) return;
+    const uint32_t id = (uint32_t)(keys[i] >> 32) & 0x3FFFFFFFu;
+    if (i > l0 && ((uint32_t)(keys[i - 1] >> 32) & 0x3FFFFFFFu) == id) return;
+    // the pair's right run
+    uint32_t lo = r0, hi = r1;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (((uint32_t)(keys[mid] >> 32) & 0x3FFFFFFFu) < id) lo = mid + 1; else hi = mid; }
+    uint32_t rp = lo;
+    if (rp >= r1 || ((uint32_t)(keys[rp] >> 32) & 0x3FFFFFFFu) != id) return;
+    uint32_t a = 0, b = nPairs;
+    while (a < b) { const uint32_t mid = (a + b) >> 1; if (pairFirstReads[mid] < id) a = mid + 1; else b = mid; }
+    const uint32_t slot = 2u * a + leftIsMate;
+    const int readLength = (int)readLengths[id];                                    // readLengths[readID] with the pair's first read, as the reference
+    const int margin = readLength > 100 ? readLength >> 2 : 25;                    // DP2_MARGIN
+    int lengthLow = insertLow - readLength - margin;
+    if (lengthLow < 0) lengthLow = 0;
+    const int lengthHigh = insertHigh - readLength + margin;
+    uint32_t n = 0;
+    const uint32_t at = out ? offsets[slot] : 0u;
+    uint32_t prev = 0;
+    bool first = true;
+    for (uint32_t lp = i; lp < l1 && ((uint32_t)(keys[lp] >> 32) & 0x3FFFFFFFu) == id; lp++) {
+        const uint32_t readLoc = (uint32_t)keys[lp];
+        if (!first && !(prev + 50u < readLoc)) continue;                            // MC_Compress
+        first = false; prev = readLoc;
+        while (rp < r1 && ((uint32_t)(keys[rp] >> 32) & 0x3FFFFFFFu) == id && readLoc + (uint32_t)lengthLow > (uint32_t)keys[rp]) rp++;
+        if (rp >= r1 || ((uint32_t)(keys[rp] >> 32) & 0x3FFFFFFFu) != id) break;   // the right run is used up: nothing pairs with the later left positions either
+        const uint32_t mateLoc = (uint32_t)keys[rp];
+        if (readLoc + (uint32_t)lengthHigh < mateLoc) continue;
+        if (out) out[at + n] = PairCandDev{readLoc, mateLoc, id + leftIsMate};
+        n++;
+    }
+    if (!out) counts[slot] = n;
+}
+
+// keys of occurrences given from outside (the new default DP: the BWT stage's hits of one end), in the format of the seed keys
+__global__ void givenKeysKernel(const s3_occ *occ, uint32_t n, uint64_t *keys)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t hi = (occ[i].readID & 1u) << 31 | (occ[i].strand == 2 ? 1u << 30 : 0u) | (occ[i].readID & ~1u);
+    keys[i] = (uint64_t)hi << 32 | occ[i].pos;
+}
+
+// Search the seeds and return their hits as sorted 64-bit keys: (keyHi | strand bit) << 32 | estimated read position.  devKeysOut != NULL: the sorted keys
+// stay on the device (the caller frees *devKeysOut with hipFree) and keysOut stays empty.
 int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<SeedDesc> &seeds, uint32_t maxHitNum, uint32_t strandBit,
-                        std::vector<uint64_t> &keysOut, std::vector<uint8_t> &statusOut)
+                        std::vector<uint64_t> &keysOut, std::vector<uint8_t> &statusOut, uint64_t **devKeysOut, uint32_t *nKeysOut)
 {
     HIPCHK(hipSetDevice(reads->ix->dev));
     const uint32_t nSeeds = (uint32_t)seeds.size();
@@ -84,7 +162,7 @@ int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<
         tmp.push_back(*p);
         return S3_OK;
     };
-    auto cleanup = [&]() { for (void *p : tmp) (void)hipFree(p); };
+    auto cleanup = [&]() { for (void *p : tmp) if (p) (void)hipFree(p); };
     int rc;
     if ((rc = talloc((void **)&dSeeds, (size_t)nSeeds * sizeof(SeedDesc))) || (rc = talloc((void **)&dRetry, nSeeds)) || (rc = talloc((void **)&dStatus, nSeeds))) { cleanup(); return rc; }
 #define SCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -139,15 +217,112 @@ int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<
         hipLaunchKernelGGL(seedKeysKernel, dim3((nSeeds + 255) / 256), dim3(256), 0, st, nSeeds, dSeeds, reads->dLens, b->dOccStart, b->dOccCount, b->dOutOffsets,
                            b->dOccPos, b->dOccMeta, strandBit, dKeys);
         SCHK(hipcub::DeviceRadixSort::SortKeys(dSortTmp, sortBytes, dKeys, dKeysOut, (int)total, 0, 64, st));
-        keysOut.resize(total);
-        SCHK(hipMemcpyAsync(keysOut.data(), dKeysOut, (size_t)total * 8, hipMemcpyDeviceToHost, st));
+        if (devKeysOut) {
+            for (void *&p : tmp) if (p == (void *)dKeysOut) p = nullptr;        // handed to the caller
+            *devKeysOut = dKeysOut;
+        } else {
+            keysOut.resize(total);
+            SCHK(hipMemcpyAsync(keysOut.data(), dKeysOut, (size_t)total * 8, hipMemcpyDeviceToHost, st));
+        }
         SCHK(hipStreamSynchronize(st));
-    }
+    } else if (devKeysOut) *devKeysOut = nullptr;
+    if (nKeysOut) *nKeysOut = total;
     statusOut.resize(nSeeds);
     if (nSeeds) SCHK(d2h(statusOut.data(), dStatus, nSeeds, st));
 #undef SCHK
     cleanup();
     return checkFlags(b);
+}
+
+__global__ void runBoundsKernel(const uint64_t *keys, uint32_t n, uint32_t *bounds)
+{
+    const uint32_t t = threadIdx.x;                                            // 3 lanes: first key with (end, strand) bits >= 1, 2, 3
+    if (t >= 3) return;
+    const uint64_t want = (uint64_t)(t + 1u) << 62;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+    bounds[t] = lo;
+}
+
+int s3i::pairMergeOnDevice(s3_batch *b, uint64_t *dKeys, uint32_t nKeys, const s3_occ *given, size_t nGiven, const uint32_t *pairFirstReads, size_t nPairs, int insertLow,
+                           int insertHigh, std::vector<PairCandHost> &cands, std::vector<uint32_t> &perPair)
+{
+    static_assert(sizeof(PairCandHost) == sizeof(PairCandDev), "candidate layouts");
+    cands.clear();
+    perPair.assign(nPairs, 0);
+    hipStream_t st = b->stream;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *p : tmp) if (p) (void)hipFree(p); };
+    auto talloc = [&](void **p, size_t bytes) -> int {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e != hipSuccess) { cleanup(); return fail(S3_ENOMEM, std::string("hipMalloc(pair merge): ") + hipGetErrorString(e)); }
+        tmp.push_back(*p);
+        return S3_OK;
+    };
+#define PCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    int rc;
+    uint64_t *keys = dKeys;
+    uint32_t n = nKeys;
+    if (nGiven) {
+        // the given occurrences join the seed positions: one list sorted by (end, strand, pair, position) again (decodePositions, DV-DPfunctions.cu:2896-2899)
+        if (nGiven + (size_t)nKeys >= 0xFFFFFFF0ull) { cleanup(); return fail(S3_EOVERFLOW, "pair merge: too many positions"); }
+        s3_occ *dOcc = nullptr;
+        uint64_t *all = nullptr, *sorted = nullptr;
+        char *sortTmp = nullptr;
+        const uint32_t m = (uint32_t)(nKeys + nGiven);
+        size_t sortBytes = 0;
+        PCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, sortBytes, all, sorted, (int)m, 0, 64, st));
+        if ((rc = talloc((void **)&dOcc, nGiven * sizeof(s3_occ))) || (rc = talloc((void **)&all, (size_t)m * 8)) || (rc = talloc((void **)&sorted, (size_t)m * 8)) ||
+            (rc = talloc((void **)&sortTmp, sortBytes))) return rc;
+        PCHK(hipMemcpyAsync(dOcc, given, nGiven * sizeof(s3_occ), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(givenKeysKernel, dim3((unsigned)((nGiven + 255) / 256)), dim3(256), 0, st, dOcc, (uint32_t)nGiven, all);
+        if (nKeys) PCHK(hipMemcpyAsync(all + nGiven, dKeys, (size_t)nKeys * 8, hipMemcpyDeviceToDevice, st));
+        PCHK(hipcub::DeviceRadixSort::SortKeys(sortTmp, sortBytes, all, sorted, (int)m, 0, 64, st));
+        keys = sorted; n = m;
+    }
+    if (n == 0 || nPairs == 0) { cleanup(); return S3_OK; }
+    uint32_t *dBounds = nullptr, *dPairs = nullptr, *dCounts = nullptr, *dOffsets = nullptr;
+    char *scanTmp = nullptr;
+    const uint32_t nSlots = (uint32_t)(2 * nPairs);
+    size_t tb = 0;
+    PCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dCounts, dOffsets, (int)(nSlots + 1), st));
+    if ((rc = talloc((void **)&dBounds, 16)) || (rc = talloc((void **)&dPairs, nPairs * 4)) || (rc = talloc((void **)&dCounts, ((size_t)nSlots + 1) * 4)) ||
+        (rc = talloc((void **)&dOffsets, ((size_t)nSlots + 1) * 4)) || (rc = talloc((void **)&scanTmp, tb + 16))) return rc;
+    PCHK(hipMemcpyAsync(dPairs, pairFirstReads, nPairs * 4, hipMemcpyHostToDevice, st));
+    PCHK(hipMemsetAsync(dCounts, 0, ((size_t)nSlots + 1) * 4, st));
+    hipLaunchKernelGGL(runBoundsKernel, dim3(1), dim3(64), 0, st, keys, n, dBounds);
+    uint32_t bnd[3] = {0, 0, 0};
+    PCHK(hipMemcpyAsync(bnd, dBounds, 12, hipMemcpyDeviceToHost, st));
+    PCHK(hipStreamSynchronize(st));
+    // runs: [end 0 '+'] [end 0 '-'] [end 1 '+'] [end 1 '-'];  orientation 0: end 0 '+' (left) against end 1 '-' (right);  1: end 1 '+' against end 0 '-'
+    const uint32_t runLo[4] = {0, bnd[0], bnd[1], bnd[2]}, runHi[4] = {bnd[0], bnd[1], bnd[2], n};
+    auto launch = [&](uint32_t o, const uint32_t *offs, PairCandDev *out) {
+        const uint32_t l = o ? 2u : 0u, r = o ? 1u : 3u;
+        const uint32_t cnt = runHi[l] - runLo[l];
+        if (!cnt || runHi[r] == runLo[r]) return;
+        hipLaunchKernelGGL(pairMergeKernel, dim3((cnt + 255) / 256), dim3(256), 0, st, keys, runLo[l], runHi[l], runLo[r], runHi[r], o, b->dLens, dPairs, (uint32_t)nPairs,
+                           insertLow, insertHigh, dCounts, offs, out);
+    };
+    launch(0, nullptr, nullptr);
+    launch(1, nullptr, nullptr);
+    PCHK(hipcub::DeviceScan::ExclusiveSum(scanTmp, tb, dCounts, dOffsets, (int)(nSlots + 1), st));
+    std::vector<uint32_t> offs((size_t)nSlots + 1);
+    PCHK(hipMemcpyAsync(offs.data(), dOffsets, ((size_t)nSlots + 1) * 4, hipMemcpyDeviceToHost, st));
+    PCHK(hipStreamSynchronize(st));
+    const uint32_t total = offs[nSlots];
+    for (size_t k = 0; k < nPairs; k++) perPair[k] = offs[2 * k + 2] - offs[2 * k];
+    if (total) {
+        PairCandDev *dOut = nullptr;
+        if ((rc = talloc((void **)&dOut, (size_t)total * sizeof(PairCandDev)))) return rc;
+        launch(0, dOffsets, dOut);
+        launch(1, dOffsets, dOut);
+        cands.resize(total);
+        PCHK(hipMemcpyAsync(cands.data(), dOut, (size_t)total * sizeof(PairCandDev), hipMemcpyDeviceToHost, st));
+        PCHK(hipStreamSynchronize(st));
+    }
+#undef PCHK
+    cleanup();
+    return S3_OK;
 }
 
 extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *readIDs, size_t nReadIDs, int stage,
@@ -169,21 +344,39 @@ extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const ui
     }
     std::vector<uint64_t> keys;
     std::vector<uint8_t> status;
-    int rc = seedSearchKeys(reads, seedBatch, seeds, maxHitNum, 31, keys, status);
+    uint64_t *dKeys = nullptr;
+    uint32_t nKeys = 0;
+    int rc = seedSearchKeys(reads, seedBatch, seeds, maxHitNum, 31, keys, status, &dKeys, &nKeys);
     if (rc) return rc;
-    // singleMerge (DV-DPfunctions.cu:1102-1141): within one (strand, read) run the first position is kept, then every position more than
-    // DPS_DIVIDE_GAP = 50 beyond the last kept one
+    // singleMerge on the device: count per run head, scan, write; the candidates come over, not the positions
     std::vector<s3_seed_candidate> out;
-    for (size_t i = 0; i < keys.size();) {
-        const uint64_t run = keys[i] >> 32;
-        uint32_t prev = (uint32_t)keys[i];
-        out.push_back(s3_seed_candidate{(uint32_t)(run & 0x7FFFFFFFu), prev, (uint8_t)((run >> 31) ? 2 : 1), {0, 0, 0}});
-        size_t k = i + 1;
-        for (; k < keys.size() && (keys[k] >> 32) == run; k++) {
-            const uint32_t cur = (uint32_t)keys[k];
-            if ((uint64_t)prev + 50u < cur) { out.push_back(s3_seed_candidate{(uint32_t)(run & 0x7FFFFFFFu), cur, (uint8_t)((run >> 31) ? 2 : 1), {0, 0, 0}}); prev = cur; }
+    if (nKeys) {
+        hipStream_t st = seedBatch->stream;
+        uint32_t *dCounts = nullptr, *dOffsets = nullptr;
+        s3_seed_candidate *dOut = nullptr;
+        char *dTmp = nullptr;
+        size_t tb = 0;
+        auto freeAll = [&]() { (void)hipFree(dKeys); (void)hipFree(dCounts); (void)hipFree(dOffsets); (void)hipFree(dOut); (void)hipFree(dTmp); };
+#define MCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { freeAll(); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+        MCHK(hipMalloc((void **)&dCounts, ((size_t)nKeys + 1) * 4));
+        MCHK(hipMalloc((void **)&dOffsets, ((size_t)nKeys + 1) * 4));
+        MCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dCounts, dOffsets, (int)(nKeys + 1), st));
+        MCHK(hipMalloc((void **)&dTmp, tb + 16));
+        MCHK(hipMemsetAsync(dCounts + nKeys, 0, 4, st));
+        hipLaunchKernelGGL(singleMergeKernel, dim3((nKeys + 255) / 256), dim3(256), 0, st, dKeys, nKeys, nullptr, dCounts, (s3_seed_candidate *)nullptr);
+        MCHK(hipcub::DeviceScan::ExclusiveSum(dTmp, tb, dCounts, dOffsets, (int)(nKeys + 1), st));
+        uint32_t total = 0;
+        MCHK(hipMemcpyAsync(&total, dOffsets + nKeys, 4, hipMemcpyDeviceToHost, st));
+        MCHK(hipStreamSynchronize(st));
+        if (total) {
+            MCHK(hipMalloc((void **)&dOut, (size_t)total * sizeof(s3_seed_candidate)));
+            hipLaunchKernelGGL(singleMergeKernel, dim3((nKeys + 255) / 256), dim3(256), 0, st, dKeys, nKeys, dOffsets, dCounts, dOut);
+            out.resize(total);
+            MCHK(hipMemcpyAsync(out.data(), dOut, (size_t)total * sizeof(s3_seed_candidate), hipMemcpyDeviceToHost, st));
+            MCHK(hipStreamSynchronize(st));
         }
-        i = k;
+#undef MCHK
+        freeAll();
     }
     const size_t nSeeds = status.size();
     s3_seed_candidate *c = (s3_seed_candidate *)malloc(out.size() * sizeof(s3_seed_candidate) + 1);

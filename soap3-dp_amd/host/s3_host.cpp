@@ -7,6 +7,9 @@
 #include <zlib.h>
 #include <fcntl.h>
 #include <unistd.h>
+#ifdef __SSSE3__
+#include <tmmintrin.h>
+#endif
 #include <sys/stat.h>
 #include <algorithm>
 #include <atomic>
@@ -790,6 +793,8 @@ static inline void appendUInt(std::string &s, unsigned long long v)
     for (int k = 0; k < n; k++) s[at + (size_t)k] = tmp[n - 1 - k];
 }
 
+// sequence and quality columns: 2-bit codes -> letters (reverse-complemented for the reverse strand), qualities + 33 (reversed likewise).  Sixteen
+// characters per step where the CPU has byte shuffles: these two columns are two thirds of a record, and the formatter shares sixteen CPUs with the loader.
 void SamWriter::seqAndQual(const ReadSet &rs, uint32_t r, bool negative, std::string &line) const
 {
     const uint32_t L = rs.lengths[r];
@@ -800,13 +805,34 @@ void SamWriter::seqAndQual(const ReadSet &rs, uint32_t r, bool negative, std::st
     const size_t at = line.size();
     line.resize(at + L + 1 + (noQual ? 1 : L));
     char *o = &line[at];
-    if (!negative) for (uint32_t i = 0; i < L; i++) o[i] = dna[c[i]];
-    else for (uint32_t i = 0; i < L; i++) o[i] = dna[3 - c[L - 1 - i]];
+    uint32_t i = 0;
+#ifdef __SSSE3__
+    {
+        const __m128i lut = _mm_setr_epi8('A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T', 'A', 'C', 'G', 'T');
+        const __m128i lutRc = _mm_setr_epi8('T', 'G', 'C', 'A', 'T', 'G', 'C', 'A', 'T', 'G', 'C', 'A', 'T', 'G', 'C', 'A');
+        const __m128i rev = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+        const __m128i three = _mm_set1_epi8(3);
+        if (!negative) for (; i + 16 <= L; i += 16) _mm_storeu_si128((__m128i *)(o + i), _mm_shuffle_epi8(lut, _mm_and_si128(_mm_loadu_si128((const __m128i *)(c + i)), three)));
+        else for (; i + 16 <= L; i += 16)
+            _mm_storeu_si128((__m128i *)(o + i), _mm_shuffle_epi8(lutRc, _mm_shuffle_epi8(_mm_and_si128(_mm_loadu_si128((const __m128i *)(c + L - 16 - i)), three), rev)));
+    }
+#endif
+    if (!negative) for (; i < L; i++) o[i] = dna[c[i]];
+    else for (; i < L; i++) o[i] = dna[3 - c[L - 1 - i]];
     o[L] = '\t';
     o += L + 1;
-    if (noQual) o[0] = '*';
-    else if (!negative) for (uint32_t i = 0; i < L; i++) o[i] = (char)(q[i] + 33);
-    else for (uint32_t i = 0; i < L; i++) o[i] = (char)(q[L - 1 - i] + 33);
+    if (noQual) { o[0] = '*'; return; }
+    i = 0;
+#ifdef __SSSE3__
+    {
+        const __m128i rev = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+        const __m128i add = _mm_set1_epi8(33);
+        if (!negative) for (; i + 16 <= L; i += 16) _mm_storeu_si128((__m128i *)(o + i), _mm_add_epi8(_mm_loadu_si128((const __m128i *)(q + i)), add));
+        else for (; i + 16 <= L; i += 16) _mm_storeu_si128((__m128i *)(o + i), _mm_add_epi8(_mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(q + L - 16 - i)), rev), add));
+    }
+#endif
+    if (!negative) for (; i < L; i++) o[i] = (char)(q[i] + 33);
+    else for (; i < L; i++) o[i] = (char)(q[L - 1 - i] + 33);
 }
 
 void SamWriter::unaligned(const ReadSet &rs, uint32_t r)
@@ -937,8 +963,9 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
         } else mapq = opt.minMAPQ;
     }
     (void)mdLen;
-    std::string &line = scratch;                                          // (kept between records: no allocation per record)
-    line.clear();
+    // (the record is built where it goes: at the end of the thread's buffer when there is one, in a kept string otherwise -- no allocation, no copy)
+    std::string &line = sink ? *sink : scratch;
+    if (!sink) line.clear();
     line += rs.names[r];
     line += negative ? "\t16\t" : "\t0\t";
     line += ix.seqName[bestChr - 1];
@@ -960,7 +987,7 @@ void SamWriter::singleEnd(const ReadSet &rs, uint32_t r, const uint32_t *pos, co
     if (opt.printMDNM && !md.empty()) { line += "\tMD:Z:"; line += md; }
     if (nOcc > 1 && !xa.empty()) { line += "\tXA:Z:"; line += xa; }
     line.push_back('\n');
-    put(line);
+    if (sink) nRecords++; else put(line);
 }
 
 void SamWriter::singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_t strand, uint8_t mis)

@@ -20,6 +20,8 @@
 #include <future>
 #include <vector>
 #include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <condition_variable>
 #include <memory>
@@ -63,16 +65,49 @@ static void parseIni(const std::string &file, Ini &ini)
     fclose(f);
 }
 
-// SAM records of `count` units (reads or pairs) formatted by all host threads, each into its own buffer, written in unit order
+// SAM records of `count` units (reads or pairs) formatted by all host threads, each into its own buffer, written in unit order.  The buffers of a
+// call go to the file in the background -- a few pwrite streams at their final offsets -- while the next call formats into a second set: formatting
+// 4 Mi reads takes all host threads about half a second and writing their 1.3 GB about as long, and the two used to take turns.  Per output file: two
+// generations of buffers and the write that is still under way (drained before the file is closed: drainOutput).
+struct OutState {
+    std::vector<std::string> buf[2];
+    std::thread pending[2];
+    int gen = 0;
+};
+static std::mutex g_outMu;
+static std::map<FILE *, std::unique_ptr<OutState>> g_outStates;
+static OutState &outState(FILE *f)
+{
+    std::lock_guard<std::mutex> g(g_outMu);
+    std::unique_ptr<OutState> &p = g_outStates[f];
+    if (!p) p.reset(new OutState());
+    return *p;
+}
+static void drainOutput(FILE *f)                                              // before anything else touches the file, and before it is closed
+{
+    std::unique_ptr<OutState> st;
+    {
+        std::lock_guard<std::mutex> g(g_outMu);
+        auto it = g_outStates.find(f);
+        if (it == g_outStates.end()) return;
+        st = std::move(it->second);
+        g_outStates.erase(it);
+    }
+    for (std::thread &t : st->pending) if (t.joinable()) t.join();
+}
+
 template <class F>
 static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out, uint32_t count, F &&one, uint64_t &aligned)
 {
     const int T = hostThreads();
     const uint32_t per = (count + (uint32_t)T - 1) / (uint32_t)T;
-    // the buffers live as long as the calling thread: a chunk of 4 Mi reads is more than a gigabyte of SAM, and touching that much fresh memory from all
+    // the buffers live as long as the output file: a chunk of 4 Mi reads is more than a gigabyte of SAM, and touching that much fresh memory from all
     // host threads at once for every chunk is page faults on one address space's lock
-    thread_local std::vector<std::string> keptBuffers;
-    std::vector<std::string> &buf = keptBuffers;              // (the workers below must see THIS thread's buffers, not their own thread-local ones)
+    OutState &os = outState(out);
+    const int gen = os.gen;
+    os.gen ^= 1;
+    if (os.pending[gen].joinable()) os.pending[gen].join();                   // the write of the call before the last one used these buffers
+    std::vector<std::string> &buf = os.buf[gen];
     if (buf.size() < (size_t)T) buf.resize((size_t)T);
     for (auto &b : buf) b.clear();
     std::vector<uint64_t> al((size_t)T, 0);
@@ -93,30 +128,33 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
         }
     });
     for (auto &x : th) x.join();
-    // the buffers go to the file at their final offsets, a few writers at a time
+    // the buffers go to the file at their final offsets, a few writers at a time; the file position moves behind them at once, so whatever is
+    // written through the FILE next (records of stages that do not come through here) lands behind this call's records
     if (!bamFlush(out)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); }
     fflush(out);
     const int fd = fileno(out);
     std::vector<long long> off((size_t)T + 1, 0);
     off[0] = (long long)ftello(out);
     for (int t = 0; t < T; t++) { off[(size_t)t + 1] = off[(size_t)t] + (long long)buf[(size_t)t].size(); aligned += al[(size_t)t]; }
-    const int W = T < 8 ? T : 8;
-    std::vector<std::thread> wr;
-    std::atomic<bool> bad(false);
-    for (int w = 0; w < W; w++) wr.emplace_back([&, w] {
-        for (int t = w; t < T; t += W) {
-            const std::string &b = buf[(size_t)t];
-            size_t done = 0;
-            while (done < b.size()) {
-                const ssize_t k = pwrite(fd, b.data() + done, b.size() - done, (off_t)(off[(size_t)t] + (long long)done));
-                if (k <= 0) { bad = true; return; }
-                done += (size_t)k;
-            }
-        }
-    });
-    for (auto &x : wr) x.join();
-    if (bad) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); }
     fseeko(out, (off_t)off[(size_t)T], SEEK_SET);
+    os.pending[gen] = std::thread([fd, T, off, &buf] {
+        const int W = T < 8 ? T : 8;
+        std::vector<std::thread> wr;
+        std::atomic<bool> bad(false);
+        for (int w = 0; w < W; w++) wr.emplace_back([&, w] {
+            for (int t = w; t < T; t += W) {
+                const std::string &b = buf[(size_t)t];
+                size_t done = 0;
+                while (done < b.size()) {
+                    const ssize_t k = pwrite(fd, b.data() + done, b.size() - done, (off_t)(off[(size_t)t] + (long long)done));
+                    if (k <= 0) { bad = true; return; }
+                    done += (size_t)k;
+                }
+            }
+        });
+        for (auto &x : wr) x.join();
+        if (bad) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); }
+    });
 }
 
 // ---- single-end DP of a list of reads (DPForUnalignSingle2, DV-DPForSingleReads.cu): seeding in batches of at most 256 Ki seeds, DP at the candidates;
@@ -266,33 +304,52 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         for (const s3_occ &x : v) if (x.mismatchCount <= mn + (mapqMode ? 1 : 0)) v[w++] = x;
         v.resize(w);
     };
-    std::vector<s3_occ> h1, h2;
     std::vector<std::vector<s3_occ>> kept(c.cnt);                                // keepSoap3Results: what the BWT stage leaves of a read for the later stages
-    for (uint32_t p = 0; p < np; p++) {
-        if (pr[p].phase) continue;
-        const uint32_t r1 = 2 * p, r2 = r1 + 1;
-        const size_t n1 = ooff[r1 + 1] - ooff[r1], n2 = ooff[r2 + 1] - ooff[r2];
-        if (n1 == 0 && n2 == 0) { deepPairs.push_back(r1); continue; }
-        if (n1 == 0 || n2 == 0) {
-            const int e = n1 ? 0 : 1;
-            endHits(e ? r2 : r1, true, h1);
-            if (h1.size() > maxHit[e]) retainBest(h1);
-            kept[e ? r2 : r1] = h1;
-            if (h1.size() <= maxHit[e]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; }
-            else newOcc.insert(newOcc.end(), h1.begin(), h1.end());
-            continue;
-        }
-        endHits(r1, false, h1); endHits(r2, false, h2);
-        if (h1.size() > maxHit[0]) retainBest(h1);
-        if (h2.size() > maxHit[1]) retainBest(h2);
-        kept[r1] = h1; kept[r2] = h2;
-        if (h1.size() <= maxHit[0] && h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; }
-        else if (h1.size() < h2.size()) {
-            if (h1.size() <= maxHit[0]) { dpOcc.insert(dpOcc.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else newOcc.insert(newOcc.end(), h1.begin(), h1.end());
-            otherOcc.insert(otherOcc.end(), h2.begin(), h2.end());
-        } else {
-            if (h2.size() <= maxHit[1]) { dpOcc.insert(dpOcc.end(), h2.begin(), h2.end()); inDefault[p] = 1; } else newOcc.insert(newOcc.end(), h2.begin(), h2.end());
-            otherOcc.insert(otherOcc.end(), h1.begin(), h1.end());
+    {
+        // the pairs are routed by all host threads, a contiguous range of pairs each, and the ranges' lists joined in pair order (a pair inside a repeat
+        // family brings thousands of hits per end: the loop moves tens of millions of entries per chunk)
+        struct Part { std::vector<s3_occ> dp, nw, other; std::vector<uint32_t> deep; };
+        const int T = std::max(1, std::min(hostThreads(), 32));
+        std::vector<Part> parts((size_t)T);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back([&, t] {
+            Part &P = parts[(size_t)t];
+            std::vector<s3_occ> h1, h2;
+            const uint32_t lo = (uint32_t)((uint64_t)np * t / T), hi = (uint32_t)((uint64_t)np * (t + 1) / T);
+            for (uint32_t p = lo; p < hi; p++) {
+                if (pr[p].phase) continue;
+                const uint32_t r1 = 2 * p, r2 = r1 + 1;
+                const size_t n1 = ooff[r1 + 1] - ooff[r1], n2 = ooff[r2 + 1] - ooff[r2];
+                if (n1 == 0 && n2 == 0) { P.deep.push_back(r1); continue; }
+                if (n1 == 0 || n2 == 0) {
+                    const int e = n1 ? 0 : 1;
+                    endHits(e ? r2 : r1, true, h1);
+                    if (h1.size() > maxHit[e]) retainBest(h1);
+                    kept[e ? r2 : r1] = h1;
+                    if (h1.size() <= maxHit[e]) { P.dp.insert(P.dp.end(), h1.begin(), h1.end()); inDefault[p] = 1; }
+                    else P.nw.insert(P.nw.end(), h1.begin(), h1.end());
+                    continue;
+                }
+                endHits(r1, false, h1); endHits(r2, false, h2);
+                if (h1.size() > maxHit[0]) retainBest(h1);
+                if (h2.size() > maxHit[1]) retainBest(h2);
+                kept[r1] = h1; kept[r2] = h2;
+                if (h1.size() <= maxHit[0] && h2.size() <= maxHit[1]) { P.dp.insert(P.dp.end(), h1.begin(), h1.end()); P.dp.insert(P.dp.end(), h2.begin(), h2.end()); inDefault[p] = 1; }
+                else if (h1.size() < h2.size()) {
+                    if (h1.size() <= maxHit[0]) { P.dp.insert(P.dp.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else P.nw.insert(P.nw.end(), h1.begin(), h1.end());
+                    P.other.insert(P.other.end(), h2.begin(), h2.end());
+                } else {
+                    if (h2.size() <= maxHit[1]) { P.dp.insert(P.dp.end(), h2.begin(), h2.end()); inDefault[p] = 1; } else P.nw.insert(P.nw.end(), h2.begin(), h2.end());
+                    P.other.insert(P.other.end(), h1.begin(), h1.end());
+                }
+            }
+        });
+        for (auto &x : th) x.join();
+        for (const Part &P : parts) {
+            dpOcc.insert(dpOcc.end(), P.dp.begin(), P.dp.end());
+            newOcc.insert(newOcc.end(), P.nw.begin(), P.nw.end());
+            otherOcc.insert(otherOcc.end(), P.other.begin(), P.other.end());
+            deepPairs.insert(deepPairs.end(), P.deep.begin(), P.deep.end());
         }
     }
     if (const char *dump = getenv("S3DP_DUMP_ROUTING")) {                        // the routing, for tests/test_gpu_cli_sam.py (format: oracle/ref_harness.cpp)
@@ -571,10 +628,11 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     // The read files come in chunks (ReadChunker): a loader thread parses chunk i+1 -- with all host threads -- while chunk i is aligned and
     // chunk i-1 is formatted and written, as the reference's loader thread fills the next batch buffer (aio_thread.cpp:582, SOAP3-DP.cu:607-800).
-    // It starts before the index is read: neither needs the other.  S3DP_CHUNK_READS: reads per chunk (default 4 Mi: a search launch lasts as long as its longest unit, larger chunks amortise that).
+    // It starts before the index is read: neither needs the other.  S3DP_CHUNK_READS: reads per chunk (default 1 Mi, the reference's own batch (SOAP3-DP.cu:394): since the unit pass
+    // shares the tail of a launch among the lanes of a wave, a small chunk costs no more per read than a large one, and three of them fill the pipeline four times sooner).
     size_t chunkReadsEnv = 0;
     if (const char *e = getenv("S3DP_CHUNK_READS")) chunkReadsEnv = (size_t)strtoull(e, nullptr, 10);
-    const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : (size_t)1 << 22) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
+    const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : (size_t)1 << 20) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
     ReadChunker chunker;
     if (readBam ? !chunker.openBam(queryFile, paired, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)
                 : !chunker.open(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)) return die(err);
@@ -939,7 +997,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             for (uint32_t k : todo) if (!doneFlag[k]) w.unaligned(rs, first + k);
         }
     }
-    auto closeOut = [&](FILE *f) { if (!bamClose(f)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); } fclose(f); };
+    auto closeOut = [&](FILE *f) { drainOutput(f); if (!bamClose(f)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); } fclose(f); };
     closeOut(out);
     if (dpOut) {
         closeOut(dpOut);
