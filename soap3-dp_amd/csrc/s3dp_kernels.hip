@@ -184,10 +184,13 @@ __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
         readSlice(a, slot, groups, beg, end);
         uint32_t total = 0, nRec = 0, nOcc = 0, nCe = 0;                      // nRec / nOcc / nCe / we: per-lane partial sums
         uint32_t we[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // (the next 64 entries are on their way while these are worked on: a step is a dependent kilobyte load otherwise)
+        uint4 rNext = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+        if (beg + lane < end) rNext = a.ordered[beg + lane];
         for (uint32_t base = beg; base < end && total < a.maxOut; base += 64u) {
-            const uint32_t i = base + lane;
-            uint4 r = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-            if (i < end) r = a.ordered[i];
+            const uint4 r = rNext;
+            rNext = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+            if (base + 64u + lane < end) rNext = a.ordered[base + 64u + lane];
             const bool valid = r.x != 0xFFFFFFFFu;
             const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
             // a range is never longer than maxOut can use: clamp before the prefix sum (32-bit)
@@ -291,10 +294,13 @@ __global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix
         if ((uint64_t)occBase + occOffsets[slot + 1] > occCap) { if (lane == 0) atomicOr(flags, S3_FLAG_OCC_OVERFLOW); continue; }
         uint32_t o = occBase + occOffsets[slot], oSa = o + a.ceCounts[slot];  // wave-uniform cursors: check-and-extend hits / expanded SA ranges
         uint32_t total = 0;
+        // (the next 64 entries are on their way while these are worked on: a step is a dependent kilobyte load otherwise)
+        uint4 rNext = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+        if (beg + lane < end) rNext = a.ordered[beg + lane];
         for (uint32_t base = beg; base < end && total < a.maxOut; base += 64u) {
-            const uint32_t i = base + lane;
-            uint4 r = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-            if (i < end) r = a.ordered[i];
+            const uint4 r = rNext;
+            rNext = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+            if (base + 64u + lane < end) rNext = a.ordered[base + 64u + lane];
             const bool valid = r.x != 0xFFFFFFFFu;
             const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
             uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;

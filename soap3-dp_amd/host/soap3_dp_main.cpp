@@ -773,10 +773,11 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         int scheme = 1, tableLen = 0, patLen = 0;
         s3_dp_config(maxRL, maxDNA, 1, &scheme, &tableLen, &patLen);
         s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
-        // problems per DP launch: the traceback tables of one launch stay under 24 GB (7 MB per problem at 1024 bases)
+        // problems per DP launch: the traceback tables of one launch stay under 8 GB (a device allocation costs about 20 ms per GB, twice per run; ten
+        // thousand problems fill the chip as well as thirty thousand do)
         auto problems = [&](int rl, int tl) -> uint32_t {
             const double perProblem = (double)((rl + 63) / 64) * (tl + 64) * 64 * 4;
-            const double n = 24e9 / perProblem;
+            const double n = 8e9 / perProblem;
             return n >= 32768 ? 32768u : n < 256 ? 256u : (uint32_t)n;
         };
         if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &dp) != S3_OK) return dieJoin(s3_last_error());

@@ -10,6 +10,10 @@ writers -- compiled from /root/reference by oracle/ref.mk, behind the reference'
     as the packers built them, and score / start / tie count / op string as the decode stage received them.  (Compared as sets, and the
     product may submit fewer: the reference's packRight (DV-DPfunctions.cu:3420-3472) leaves the slot of a candidate whose left end failed as
     it is, so that unchanged left problem runs a second time with the right ends; the product does not submit it again.)
+Record ORDER inside a file is not compared, and cannot be: the reference writes .gout per host thread and phase, .dpout per DP stage (default DP, new
+default DP, deep DP rounds) through its output threads, the product per chunk of the input and stage -- the same records come in a different interleaving
+by construction (with S3DP_CHUNK_READS every chunk writes its own stages behind each other).  What order could break is pinned elsewhere: the records of one
+READ (primary first, XA lists in hit order) are inside the compared lines, and the order of a read's hits is compared list for list in test_gpu_parity.py.
 g7 is BASELINE config C3's shape (2 x 150 bp, -u 500 -v 1); dp_long (2 x 200 bp) skips the BWT stage; dp_se* are single reads."""
 import gzip
 import os

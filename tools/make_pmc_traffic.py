@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from rocprofv3 --pmc FETCH_SIZE counter files of `bench.py --steps 1 --warmup 0` runs (one counted ladder + one timed
+ladder: the second half of every search kernel's dispatches is the timed step).  FETCH_SIZE comes in kilobytes (MI355X_MICROARCH.md); 64-byte requests.
+    tools/make_pmc_traffic.py <commit> <repeat_frac>=<counter_collection.csv> ...   > profiles/pmc_traffic.json"""
+import collections
+import csv
+import json
+import sys
+
+KERNELS = ("firstKernel", "unitKernel", "ceKernel")
+
+
+def fetch_of_last_ladder(path):
+    per = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != "FETCH_SIZE":
+            continue
+        k = next((k for k in KERNELS if k in r["Kernel_Name"]), None)
+        if k is None:
+            continue
+        per.setdefault(k, collections.OrderedDict()).setdefault(r["Dispatch_Id"], 0.0)
+        per[k][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    out = {}
+    for k, d in per.items():
+        vals = list(d.values())
+        half = vals[len(vals) // 2:]
+        out[k] = {"launches": len(half), "bytes": sum(half) * 1024.0}
+    return out
+
+
+def main():
+    commit = sys.argv[1]
+    workloads = []
+    for arg in sys.argv[2:]:
+        frac, path = arg.split("=", 1)
+        f = fetch_of_last_ladder(path)
+        workloads.append({"genome_bp": 3100000000, "reads_per_gpu": 10000000, "read_len": 100, "max_mismatch": 4, "max_output_per_read": 1000,
+                          "repeat_frac": float(frac), "fetch_bytes_per_step": sum(v["bytes"] for v in f.values()), "launches_per_step": 4,
+                          "per_kernel": f})
+    print(json.dumps({"_comment": "HBM bytes fetched by the search kernels (s3::firstKernel: first pass + trunk pass, s3::unitKernel: unit pass, s3::ceKernel: "
+                                  "check-and-extend) in one timed ladder of bench.py, rocprofv3 --pmc FETCH_SIZE in its own pass (KB x 1024; 64-byte requests), "
+                                  "default configuration; tools/run_profiles.sh + tools/make_pmc_traffic.py",
+                      "commit": commit, "workloads": workloads}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

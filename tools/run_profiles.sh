@@ -8,10 +8,10 @@ IX=/tmp/s3dp_ix
 mkdir -p $OUT $IX
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 STEPS="${*:-bench stats pmc dp e2e pairs}"
-QUICK="--index-dir $IX --uniform 0 --extras 0 --streaming 0 --cpu-budget 0 --check 0"
+QUICK="--index-dir $IX --uniform 0 --extras 0 --streaming 0 --cpu-budget 0 --check 0 --exact-rank 0 --repeat-frac ${S3DP_PROFILE_REPEAT_FRAC:-0.5}"
 want() { case " $STEPS " in *" $1 "*) return 0;; esac; return 1; }
 
-timeout 900 python3 bench.py --index-dir $IX --build-only 1 > /dev/null 2> $OUT/index_build.log; echo "index build rc=$?"
+timeout 900 python3 bench.py --index-dir $IX --repeat-frac ${S3DP_PROFILE_REPEAT_FRAC:-0.5} --build-only 1 > /dev/null 2> $OUT/index_build.log; echo "index build rc=$?"
 
 if want bench; then   # the default run, as the driver runs it
   timeout 1500 python3 bench.py --index-dir $IX --steps 5 > $OUT/bench.json 2> $OUT/bench.log; echo "bench rc=$?"; grep "resident:\|streamed:" $OUT/bench.log
@@ -25,6 +25,7 @@ if want pmc; then     # HBM traffic of the search kernels: FETCH_SIZE in its own
   rm -rf /tmp/prof_pmc
   timeout 1200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_pmc -o pmc -- python3 bench.py $QUICK --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_fetch.log
   echo "pmc rc=$?"; f=$(find /tmp/prof_pmc -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && cp "$f" /tmp/pmc_fetch_${S3DP_PROFILE_REPEAT_FRAC:-0.5}.csv
   if [ -n "$f" ]; then python3 tools/pmc_summary.py "$f" firstKernel > $OUT/pmc_fetch_first.txt; python3 tools/pmc_summary.py "$f" unitKernel > $OUT/pmc_fetch_unit.txt; python3 tools/pmc_summary.py "$f" ceKernel > $OUT/pmc_fetch_ce.txt; tail -4 $OUT/pmc_fetch_unit.txt; fi
   rm -rf /tmp/prof_pmc
   timeout 1200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/prof_pmc -o pmc -- python3 bench.py $QUICK --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_sq.log
