@@ -182,12 +182,17 @@ def pairs_mode(a, codes, work, rng, t_index):
     if out.returncode != 0:
         print(out.stdout[-2000:], out.stderr[-2000:], file=sys.stderr)
         raise SystemExit(1)
+    if os.environ.get("S3DP_VERBOSE"):
+        print(out.stdout, out.stderr, file=sys.stderr)
     ph = {k: float(v) for k, v in re.findall(r"\[Main\] (Loading time|Read load time|Alignment \+ output time|Total elapsed time|DP stages time) :\s+([0-9.]+)", out.stdout)}
+    ch = re.search(r"\[Main\] Chunk loop time : (.*)", out.stdout)
+    dv = re.search(r"\[Main\] Device time : (.*)", out.stdout)
     counts = {k: int(v) for k, v in re.findall(r"\[Main\] (Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|"
                                                r"Pairs left without a proper pairing|Overall number of reads aligned): (\d+)", out.stdout)}
     stage = re.search(r"DP stages time :\s+[0-9.]+ seconds \((.*)\)", out.stdout)
     res = {"mode": "pair, DP stages on", "dp_stage_seconds": stage.group(1) if stage else None, "genome_bp": a.genome_bp, "pairs": N, "read_len": L, "host_threads": a.threads or os.cpu_count(),
            "pair_mix": {"bwt": 0.90, "one_end_indel": 0.06, "both_ends_indel": 0.03, "random_mate": 0.01},
+           "chunk_loop": ch.group(1) if ch else None, "device_time": dv.group(1) if dv else None,
            "index_build_and_write_s": t_index, "fastq_write_s": t_reads, "wall_s_total": wall, "phases_s": ph, "counts": counts,
            "sam_bytes": sum(os.path.getsize(os.path.join(work, "out." + e)) for e in ("gout.1", "dpout.1", "unpair")),
            "pairs_per_s_wall_incl_index_load": N / wall,
