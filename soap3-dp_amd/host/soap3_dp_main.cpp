@@ -771,7 +771,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         s3_dp_stage_parameters(S3_STAGE_SINGLE_DP, detectedReadLength, &di, &dpPar);      // getParameterForSingleDP on the detected length (alignment.cu:2580)
         const int maxRL = (maxReadLength / 4 + 1) * 4, margin = maxReadLength > 100 ? maxReadLength >> 2 : 25, maxDNA = maxRL + 2 * margin + 8;   // DV-DPfunctions.cu:1580
         int scheme = 1, tableLen = 0, patLen = 0;
-        s3_dp_config(maxRL, maxDNA, 1, &scheme, &tableLen, &patLen);
+        // SemiGlobalAligner::decideConfiguration (DV-DPfunctions.cu:568-612) takes scheme 1 (one table over the whole window) whenever 64 blocks of full
+        // tables fit the device, which on 288 GB they always do.  S3DP_DP_SCHEME=2 asks for what the reference does on a device too small for that: scheme 2
+        // (score pass over the window, table of L + L/2 + 8 columns) wherever the window is at least three read lengths (coefConf[0]), scheme 1 elsewhere.
+        const int askScheme = getenv("S3DP_DP_SCHEME") && atoi(getenv("S3DP_DP_SCHEME")) == 2 ? 2 : 1;
+        auto wantScheme = [&](int rl, int dna) { return askScheme == 2 && dna >= rl * 3 ? 2 : 1; };
+        s3_dp_config(maxRL, maxDNA, wantScheme(maxRL, maxDNA), &scheme, &tableLen, &patLen);
         s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
         // problems per DP launch: the traceback tables of one launch stay under 8 GB (a device allocation costs about 20 ms per GB, twice per run; ten
         // thousand problems fill the chip as well as thirty thousand do)
@@ -785,7 +790,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         if (paired) {
             // default DP (half-aligned pairs): HalfEndAlignmentEngine::performAlignment sizes, DV-DPfunctions.cu:2221-2224
             const int maxDNAHalf = insertHigh - insertLow + maxReadLength + 1;
-            s3_dp_config(maxRL, maxDNAHalf, 1, &scheme, &tableLen, &patLen);
+            s3_dp_config(maxRL, maxDNAHalf, wantScheme(maxRL, maxDNAHalf), &scheme, &tableLen, &patLen);
             if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &dpHalf) != S3_OK) return dieJoin(s3_last_error());
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength, &di, &halfPar[0]);
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength2, &di, &halfPar[1]);

@@ -180,6 +180,9 @@ dprun() {  # outdir tag index mode(single|pair) reads... -- options
 )
 dprun $OUT/g7 h2  pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2
 dprun $OUT/g7 h2p pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2 -p
+# the same run as the reference decides it on a SMALL device (decideConfiguration's scheme 2, DV-DPfunctions.cu:600-612: score pass over the whole window,
+# table of L + L/2 + 8 columns): the default DP's 650-column windows take it (>= 3 x read length), the deep DP's 224-column windows do not
+REFDP_SCHEME=2 dprun $OUT/g7 h2s2 pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2
 dprun $OUT/g7 h1  pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2 -h 1
 dprun $OUT/g7 h3  pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2 -h 3
 dprun $OUT/g7 h4  pair g7.fa.index g7_1.fq g7_2.fq -L 150 -u 500 -v 1 -b 2 -h 4
