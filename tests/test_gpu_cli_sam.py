@@ -57,6 +57,31 @@ def test_cli_sam_matches_reference_cpu_path(tmp_path, name, maxlen, variant, opt
     assert os.path.exists(tmp_path / "out.done")
 
 
+PROCESS_KNOBS = [
+    {"S3DP_VERBOSE": "1"},                                            # the timeline and per-launch laps go to stderr / stdout lines, never into the SAM file
+    {"S3DP_BLOCKING_SYNC": "1"},                                      # host threads sleep while they wait for the device
+    {"S3DP_H2D_PIECE_MB": "1"}, {"S3DP_H2D_PIECE_MB": "0"},           # index upload in 1 MB pieces / in one piece
+    {"S3DP_STREAM_BLOCKS_PER_CU": "1", "S3DP_CHUNK_READS": "192"},    # grid widths of the batches that share the device
+    {"S3DP_STREAM_BLOCKS_PER_CU": "8", "S3DP_CHUNK_READS": "192"},
+    {"S3DP_HOST_THREADS": "1", "S3DP_CHUNK_READS": "192"},
+]
+
+
+@pytest.mark.parametrize("knobs", PROCESS_KNOBS, ids=lambda k: ",".join("%s=%s" % (a[5:], b) for a, b in k.items()))
+def test_cli_process_knobs_do_not_change_the_sam_file(tmp_path, knobs):
+    """Knobs read once per process (device flags, upload piece size, stream grid widths, verbosity, host threads): same records as the reference's CPU path"""
+    name, maxlen, variant, opts = "g2", 120, "s4", ["-s", "4"]
+    shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), tmp_path / (name + ".fq"))
+    out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", str(maxlen)] + opts + ["-b", "2", "-o", "out"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600, env=dict(os.environ, **knobs))
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    mine_h, mine = sam_records(open(tmp_path / "out.gout.1").read())
+    ref_h, ref = sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_%s.sam.gz" % variant), "rt").read())
+    assert mine_h == ref_h and mine == ref
+    if "S3DP_VERBOSE" in knobs:
+        assert "[s3dp]" in out.stderr                                   # the timeline was printed
+
+
 @pytest.mark.parametrize("variant,opts", [("s4", ["-s", "4"]), ("h1_s2p", ["-s", "2", "-h", "1", "-p"])])
 def test_cli_sam_at_the_ends_of_the_text(tmp_path, variant, opts):
     """fixture g6: reads that hug or overhang the ends of the text and a sequence boundary (boundary trimming, soft clips, padded lookup keys)"""
@@ -523,6 +548,15 @@ def test_cli_bam_single_reads(tmp_path, chunk):
         texts[mode] = open(tmp_path / (mode + ".gout.1")).read() if mode == "sam" else _decoded(str(tmp_path / "bam.gout.1"))
     assert texts["bam"].splitlines() == texts["sam"].splitlines()
     assert os.path.getsize(tmp_path / "bam.gout.1") < os.path.getsize(tmp_path / "sam.gout.1")
+    # S3DP_BAM_LEVEL: zlib's level 9 and its default (-1, what samtools uses) hold the same records in fewer bytes than level 1
+    sizes = {}
+    for level in ("9", "-1", "0"):
+        out = subprocess.run([BIN, "single", os.path.join(GOLDEN, name, "index"), "r.fq", "-L", "120", "-s", "4", "-b", "3", "-o", "bam" + level],
+                             cwd=tmp_path, capture_output=True, text=True, timeout=600, env=dict(env, S3DP_BAM_LEVEL=level))
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert _decoded(str(tmp_path / ("bam%s.gout.1" % level))).splitlines() == texts["sam"].splitlines()
+        sizes[level] = os.path.getsize(tmp_path / ("bam%s.gout.1" % level))
+    assert sizes["9"] <= os.path.getsize(tmp_path / "bam.gout.1") < sizes["0"] and sizes["-1"] <= os.path.getsize(tmp_path / "bam.gout.1")
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BAM2SAM), reason="the reference's samtools is not built (oracle/ref.mk)")
