@@ -617,7 +617,7 @@ bool ReadChunker::nextBam(uint32_t maxReads, ReadSet &rs, std::string &err)
 bool ReadChunker::next(uint32_t maxReads, ReadSet &rs, std::string &err)
 {
     err.clear();
-    rs = ReadSet();
+    rs.n = 0;                                                            // (a recycled set keeps its arrays: allocateReads sizes and zeroes them again)
     if (bam) return nextBam(maxReads, rs, err);
     const size_t F = files.size();
     if (F == 2) maxReads &= ~1u;

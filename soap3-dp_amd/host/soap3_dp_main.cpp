@@ -644,9 +644,22 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         std::string err;
         double seconds = 0;
     } loaded;
+    // chunks that have been written out come back here: a chunk of 1 Mi reads is 230 MB in five arrays, and giving them back to the system and asking for
+    // them again cost a munmap in the writer thread and sixty thousand page faults in the loader per chunk
+    struct { std::mutex mu; std::vector<std::unique_ptr<ReadSet>> free; } pool;
+    auto recycle = [&](std::unique_ptr<ReadSet> rs) {
+        if (!rs) return;
+        std::lock_guard<std::mutex> g(pool.mu);
+        if (pool.free.size() < 8) pool.free.push_back(std::move(rs));
+    };
     std::thread loader([&] {
         for (;;) {
-            std::unique_ptr<ReadSet> rs(new ReadSet());
+            std::unique_ptr<ReadSet> rs;
+            {
+                std::lock_guard<std::mutex> g(pool.mu);
+                if (!pool.free.empty()) { rs = std::move(pool.free.back()); pool.free.pop_back(); }
+            }
+            if (!rs) rs.reset(new ReadSet());
             std::string e;
             const auto t = std::chrono::steady_clock::now();
             const bool ok = chunker.next(chunkReads, *rs, e);
@@ -853,6 +866,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 }, aligned);
                 addStreamSeconds(4, since(tFm));
                 if (s3_stream_release(st) != S3_OK) { fprintf(stderr, "%s\n", s3_last_error()); fflush(stderr); _exit(1); }
+                recycle(std::move(rsP));
             }
         });
         while (chunk && chunk->n) {
@@ -895,7 +909,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     const uint32_t maxBatch = chunkReads;
     if (chunk && s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : (chunk->n ? chunk->n : 1), chunk->wpq, &b) != S3_OK) return dieJoin(s3_last_error());
     mark("batch created");
-    for (; chunk && chunk->n; chunk = nextChunk()) {
+    for (; chunk && chunk->n; recycle(std::move(chunk)), chunk = nextChunk()) {
         ReadSet &rs = *chunk;
         const uint32_t first = 0, cnt = rs.n;
         totalReads += cnt;
