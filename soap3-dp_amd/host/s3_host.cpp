@@ -266,17 +266,23 @@ size_t parseRecord(const TextView &all, size_t p, bool fq, uint32_t maxReadLengt
 }
 }  // namespace
 
-// sizes the arrays of `rs` for n reads and writes the zeros that are content (bits are OR-ed into the packed words, bytes behind a read's end stay 0),
-// slice by slice with all threads
-static void allocateReads(ReadSet &rs, uint32_t n, bool fq, uint32_t wpq, uint32_t maxReadLength)
+// sizes the arrays of `rs` for n reads.  zeroContent (the BAM path, whose records OR their bits into the packed words): the zeros that are content are
+// written here, slice by slice with all threads; the text path writes every word and every byte of a read's rows itself (fillRead), which saved three
+// passes over 230 MB per chunk of 1 Mi reads.
+static void allocateReads(ReadSet &rs, uint32_t n, bool fq, uint32_t wpq, uint32_t maxReadLength, bool zeroContent)
 {
     rs.maxReadLength = maxReadLength; rs.wpq = wpq; rs.isFastq = fq; rs.n = n;
     const size_t roundUp = ((size_t)n + 31) / 32 * 32;
     rs.queries.resize(roundUp * wpq);
-    rs.lengths.assign(n, 0);
-    rs.names.assign(n, std::string());
+    rs.lengths.resize(n);
+    rs.names.resize(n);
     rs.codes.resize((size_t)n * maxReadLength);
     rs.quals.resize((size_t)n * maxReadLength);
+    if (!zeroContent) {
+        // the packed words of the reads that pad the last group of 32
+        for (size_t r = n; r < roundUp; r++) for (uint32_t w = 0; w < wpq; w++) rs.queries[(r / 32) * 32 * wpq + r % 32 + (size_t)32 * w] = 0;
+        return;
+    }
     const int T = hostThreads();
     auto zero = [&](void *base, size_t bytes) {
         std::vector<std::thread> z;
@@ -368,6 +374,95 @@ struct ReadChunker::File {
 };
 
 namespace {
+// ---- the record form every sequencer writes: header line, ONE sequence line, '+' line, quality line --------------------------------------------------
+// parseRecord walks a record byte by byte (0.9 us per 100-base read on one core: the loader set the pace of the command line).  A record of the
+// four-line form is taken line by line instead (memchr) and yields exactly what parseRecord yields -- same name, same characters, same position
+// behind it, whatever the length of the quality line --; anything else (FASTA, wrapped sequences, a sequence line holding '>', '@' or '+', a record cut
+// by the end of the buffer) is left to parseRecord.  S3DP_GENERIC_PARSER=1 switches the short cut off (tests compare the two).
+struct FastRec { const char *name, *nameEnd, *seq, *qual; uint32_t nuc, nq; size_t next; };
+
+static bool genericParserOnly()
+{
+    static const bool v = [] { const char *e = getenv("S3DP_GENERIC_PARSER"); return e && *e == '1'; }();
+    return v;
+}
+
+static inline bool hasStopChar(const char *s, size_t n)
+{
+    size_t i = 0;
+#ifdef __SSSE3__
+    const __m128i gt = _mm_set1_epi8('>'), at = _mm_set1_epi8('@'), pl = _mm_set1_epi8('+');
+    for (; i + 16 <= n; i += 16) {
+        const __m128i x = _mm_loadu_si128((const __m128i *)(s + i));
+        if (_mm_movemask_epi8(_mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(x, gt), _mm_cmpeq_epi8(x, at)), _mm_cmpeq_epi8(x, pl)))) return true;
+    }
+#endif
+    for (; i < n; i++) if (s[i] == '>' || s[i] == '@' || s[i] == '+') return true;
+    return false;
+}
+
+static inline bool fastqRecord(const TextView &all, size_t p, FastRec &R)
+{
+    const char *b = all.p, *end = all.p + all.size();
+    const char *e1 = (const char *)memchr(b + p + 1, '\n', (size_t)(end - (b + p + 1)));
+    if (!e1) return false;
+    const char *s = e1 + 1;
+    const char *e2 = (const char *)memchr(s, '\n', (size_t)(end - s));
+    if (!e2 || e2 == s || e2 + 1 >= end || e2[1] != '+') return false;
+    if ((size_t)(e2 - s) > 0xFFFFFFFFu || hasStopChar(s, (size_t)(e2 - s))) return false;
+    const char *e3 = (const char *)memchr(e2 + 1, '\n', (size_t)(end - (e2 + 1)));
+    if (!e3) return false;
+    const char *qs = e3 + 1;
+    R.name = b + p + 1; R.nameEnd = e1; R.seq = s; R.qual = qs;
+    R.nuc = (uint32_t)(e2 - s);
+    const size_t lim = std::min<size_t>(R.nuc, (size_t)(end - qs));
+    const char *nl = lim ? (const char *)memchr(qs, '\n', lim) : nullptr;
+    R.nq = (uint32_t)(nl ? (size_t)(nl - qs) : lim);
+    R.next = (size_t)(qs - b) + R.nq;
+    return true;
+}
+
+// the name as parseRecord takes it: up to the first blank, at most maxLenReadName - 1 characters, a trailing "/x" dropped
+static inline void fastName(const FastRec &R, int maxLenReadName, std::string &name)
+{
+    const char *e = R.name;
+    while (e < R.nameEnd && *e != ' ' && *e != '\t') e++;
+    size_t n = (size_t)(e - R.name);
+    const size_t cap = maxLenReadName > 1 ? (size_t)(maxLenReadName - 1) : 0;
+    if (n > cap) n = cap;
+    if (n >= 2 && R.name[n - 2] == '/') n -= 2;
+    name.assign(R.name, n);
+}
+
+// one read into its rows and packed words; every byte of the rows and every one of the wpq words is written
+static inline void fillRead(const char *seq, uint32_t len, const char *qual, uint32_t nq, uint32_t maxReadLength, uint32_t wpq, const unsigned char *charMap,
+                            int qualityConstant, uint32_t *dst, uint8_t *cd, char *qd)
+{
+    for (uint32_t i = 0; i < len; i++) cd[i] = charMap[(unsigned char)seq[i]];
+    memset(cd + len, 0, maxReadLength - len);
+    const uint32_t k = nq < len ? nq : len;
+    for (uint32_t i = 0; i < k; i++) qd[i] = (char)(qual[i] - qualityConstant);
+    memset(qd + k, 0, maxReadLength - k);
+    uint32_t w = 0;
+#ifdef __SSSE3__
+    {
+        // sixteen 2-bit codes -> one word, first character in the lowest bits: c0 + 4 c1 per byte pair, + 16 (..) per pair of those, bytes gathered
+        const __m128i m1 = _mm_set1_epi16(0x0401), m2 = _mm_set1_epi32(0x00100001);
+        const __m128i gather = _mm_setr_epi8(0, 4, 8, 12, (char)0x80, (char)0x80, (char)0x80, (char)0x80, (char)0x80, (char)0x80, (char)0x80, (char)0x80, (char)0x80, (char)0x80,
+                                             (char)0x80, (char)0x80);
+        for (; w < wpq && 16u * w + 16u <= maxReadLength; w++) {
+            const __m128i x = _mm_loadu_si128((const __m128i *)(cd + 16u * w));
+            dst[(size_t)w * 32] = (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi8(_mm_madd_epi16(_mm_maddubs_epi16(x, m1), m2), gather));
+        }
+    }
+#endif
+    for (; w < wpq; w++) {
+        uint32_t word = 0;
+        for (uint32_t j = 0, i = 16u * w; j < 16u && i < len; j++, i++) word |= (uint32_t)cd[i] << (2u * j);
+        dst[(size_t)w * 32] = word;
+    }
+}
+
 // what one file contributes to a chunk: the text region, its pieces (one per thread) with their record counts
 struct Region {
     TextView all;
@@ -414,6 +509,7 @@ bool scanRegion(Region &R, uint32_t maxReads, uint32_t maxReadLength, int maxLen
     }
     for (int t = 0; t < T; t++) R.pieces[(size_t)t].end = t + 1 < T ? R.pieces[(size_t)t + 1].beg : N;
     std::atomic<bool> anyBad(false);
+    const bool fast = R.fq && !genericParserOnly();
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back([&, t] {
         Piece &P = R.pieces[(size_t)t];
@@ -423,6 +519,8 @@ bool scanRegion(Region &R, uint32_t maxReads, uint32_t maxReadLength, int maxLen
         while (p < P.end) {
             while (p < P.end && all[p] != '>' && all[p] != '@') p++;
             if (p >= P.end) break;
+            FastRec fr;
+            if (fast && fastqRecord(all, p, fr)) { c++; p = fr.next; continue; }
             p = parseRecord(all, p, R.fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] { c++; }, false, name, seq, q, bad);
         }
         P.count = c;
@@ -458,6 +556,8 @@ void cutRegion(Region &R, uint32_t m, uint32_t maxReadLength, int maxLenReadName
         while (p < P.end && c < m - P.first) {
             while (p < P.end && all[p] != '>' && all[p] != '@') p++;
             if (p >= P.end) break;
+            FastRec fr;
+            if (R.fq && !genericParserOnly() && fastqRecord(all, p, fr)) { c++; p = fr.next; continue; }
             p = parseRecord(all, p, R.fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] { c++; }, false, name, seq, q, bad);
         }
         while (p < P.end && !isRecordStart(all, R.fq, p)) p++;
@@ -474,6 +574,7 @@ void fillRegion(const Region &R, ReadSet &rs, uint32_t stride, uint32_t offset, 
 {
     const TextView &all = R.all;
     const uint32_t wpq = rs.wpq;
+    const bool fast = R.fq && !genericParserOnly();
     std::vector<std::thread> th;
     for (size_t t = 0; t < R.pieces.size(); t++) th.emplace_back([&, t] {
         const Piece &P = R.pieces[t];
@@ -483,6 +584,20 @@ void fillRegion(const Region &R, ReadSet &rs, uint32_t stride, uint32_t offset, 
         while (p < P.end) {
             while (p < P.end && all[p] != '>' && all[p] != '@') p++;
             if (p >= P.end) break;
+            FastRec fr;
+            if (fast && fastqRecord(all, p, fr)) {
+                if (r < R.n) {
+                    const size_t rd = (size_t)stride * r + offset;
+                    fastName(fr, maxLenReadName, rs.names[rd]);
+                    const uint32_t len = fr.nuc < maxReadLength ? fr.nuc : maxReadLength;
+                    rs.lengths[rd] = len;
+                    fillRead(fr.seq, len, fr.qual, fr.nq, maxReadLength, wpq, charMap, qualityConstant, rs.queries.data() + (rd / 32) * 32 * wpq + rd % 32,
+                             &rs.codes[rd * maxReadLength], &rs.quals[rd * maxReadLength]);
+                }
+                r++;
+                p = fr.next;
+                continue;
+            }
             p = parseRecord(all, p, R.fq, maxReadLength, maxLenReadName, charMap, qualityConstant, [&] {
                 if (r < R.n) {
                     const size_t rd = (size_t)stride * r + offset;
@@ -491,6 +606,9 @@ void fillRegion(const Region &R, ReadSet &rs, uint32_t stride, uint32_t offset, 
                     uint32_t *dst = rs.queries.data() + (rd / 32) * 32 * wpq + rd % 32;
                     uint8_t *cd = &rs.codes[rd * maxReadLength];
                     char *qd = &rs.quals[rd * maxReadLength];
+                    for (uint32_t w = 0; w < wpq; w++) dst[(size_t)w * 32] = 0;
+                    memset(cd, 0, maxReadLength);
+                    memset(qd, 0, maxReadLength);
                     for (size_t i = 0; i < seq.size(); i++) {
                         dst[(i / 16) * 32] |= (uint32_t)seq[i] << (2 * (i % 16));
                         cd[i] = seq[i];
@@ -573,7 +691,7 @@ bool ReadChunker::nextBam(uint32_t maxReads, ReadSet &rs, std::string &err)
     uint32_t n = (uint32_t)recs.size();
     if (bamPaired) n &= ~1u;                                            // (a last read without its mate is dropped, as a shorter second file would drop it)
     if (n == 0) return false;
-    allocateReads(rs, n, true, wpq, maxReadLength);
+    allocateReads(rs, n, true, wpq, maxReadLength, true);
     static const char nt16[] = "=ACMGRSVTWYHKDBN";
     const int T = hostThreads();
     std::vector<std::thread> th;
@@ -677,7 +795,7 @@ bool ReadChunker::next(uint32_t maxReads, ReadSet &rs, std::string &err)
     for (size_t f = 0; f < F; f++) m = std::min(m, regs[f].n);
     if (m == 0) return false;                                           // end of the input (the reference stops at the shorter file of a pair)
     for (size_t f = 0; f < F; f++) cutRegion(regs[f], m, maxReadLength, maxLenReadName, qualityConstant, charMap);
-    allocateReads(rs, (uint32_t)F * m, regs[0].fq, wpq, maxReadLength);
+    allocateReads(rs, (uint32_t)F * m, regs[0].fq, wpq, maxReadLength, false);
     if (F == 2) {
         std::thread second([&] { fillRegion(regs[1], rs, 2, 1, maxReadLength, maxLenReadName, qualityConstant, charMap); });
         fillRegion(regs[0], rs, 2, 0, maxReadLength, maxLenReadName, qualityConstant, charMap);
@@ -700,7 +818,7 @@ bool loadSingleReads(const std::string &file, uint32_t maxReadLength, int qualit
         if (!err.empty()) return false;
         uint32_t w = 1;
         while (w < maxReadLength) w *= 2;
-        allocateReads(rs, 0, false, w / 16 ? w / 16 : 1, maxReadLength);
+        allocateReads(rs, 0, false, w / 16 ? w / 16 : 1, maxReadLength, true);
     }
     return true;
 }
@@ -715,7 +833,7 @@ bool loadPairReads(const std::string &file1, const std::string &file2, uint32_t 
         if (!err.empty()) return false;
         uint32_t w = 1;
         while (w < maxReadLength) w *= 2;
-        allocateReads(rs, 0, false, w / 16 ? w / 16 : 1, maxReadLength);
+        allocateReads(rs, 0, false, w / 16 ? w / 16 : 1, maxReadLength, true);
     }
     return true;
 }

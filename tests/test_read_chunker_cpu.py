@@ -17,13 +17,15 @@ def tool():
     src = [os.path.join(ROOT, "tests", "tools", "chunk_reads.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_bam.cpp"),
            os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host_dp.cpp"), os.path.join(ROOT, "soap3-dp_amd", "host", "s3_host_dp_pair.cpp")]
     lib = os.path.join(ROOT, "soap3-dp_amd")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", TOOL] + src + ["-L" + lib, "-ls3dp", "-lz", "-lm", "-Wl,-rpath," + lib])
+    subprocess.check_call(["g++", "-O2", "-mssse3", "-std=c++17", "-pthread", "-o", TOOL] + src + ["-L" + lib, "-ls3dp", "-lz", "-lm", "-Wl,-rpath," + lib])
     return TOOL
 
 
-def dump(tool, chunk, L, files, tmp_path, tag, threads="8"):
+def dump(tool, chunk, L, files, tmp_path, tag, threads="8", generic=False):
     out = tmp_path / ("dump_%s.txt" % tag)
     env = dict(os.environ, S3DP_HOST_THREADS=threads)
+    if generic:
+        env["S3DP_GENERIC_PARSER"] = "1"
     r = subprocess.run([tool, str(chunk), str(L), str(out)] + [str(f) for f in files], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr
     return open(out).read().split("\n"), int(r.stderr.split()[0])
@@ -56,6 +58,58 @@ def test_chunk_size_does_not_change_the_reads(tool, tmp_path):
         g.write(f.read())
     got, _ = dump(tool, 700, 100, [gzf], tmp_path, "gz")
     assert got == whole
+
+
+def test_line_by_line_parser_equals_the_general_one(tool, tmp_path):
+    """Four-line FASTQ records are taken line by line (memchr, SIMD packing); everything else goes through the byte-by-byte parser that follows the
+    reference's reader.  Both must make the same reads of every file: S3DP_GENERIC_PARSER=1 switches the short cut off."""
+    rng = np.random.default_rng(23)
+    recs = []
+    for i in range(4000):
+        L = int(rng.integers(1, 131))
+        seq = "".join("ACGTNacgtnUuRY"[int(x)] for x in rng.integers(0, 14, size=L))
+        q = "".join(chr(33 + int(x)) for x in rng.integers(0, 60, size=L))
+        name = "r%d" % i
+        kind = i % 16
+        if kind == 1: name += "/1"
+        elif kind == 2: name += "/2 trailing words"
+        elif kind == 3: name += "\ttabbed"
+        elif kind == 4: name = name + "x" * 80                       # longer than MaxLenReadName
+        elif kind == 5: name = name + "y" * 61 + "/1"                # "/1" falls behind the name limit
+        plus = "+" if kind != 6 else "+" + name
+        if kind == 7: q = "@" + q[1:]
+        elif kind == 8: q = q + "IIII"                               # quality line longer than the sequence
+        elif kind == 9 and L > 3: q = q[:L // 2]                     # ... and shorter
+        elif kind == 10 and L > 3: q = "@" + q[1:L // 2]
+        if kind == 11 and L > 20:
+            seq = seq[:L // 2] + "\n" + seq[L // 2:]                  # wrapped sequence: the general parser's business
+        nl = "\r\n" if kind == 13 else "\n"
+        recs.append("@%s%s%s%s%s%s%s%s" % (name, nl, seq, nl, plus, nl, q, nl))
+    text = "".join(recs)
+    for tag, body in (("nl", text), ("no_final_newline", text[:-1]), ("blank_lines", text.replace("@r100\n", "\n\n@r100\n"))):
+        fq = tmp_path / (tag + ".fq")
+        with open(fq, "w", newline="") as f:
+            f.write(body)
+        for L in (100, 130):
+            gen, _ = dump(tool, 1 << 30, L, [fq], tmp_path, tag + "_gen%d" % L, generic=True)
+            assert len([l for l in gen if l]) >= 3900
+            for chunk, thr in ((1 << 30, "8"), (257, "5"), (1000, "1")):
+                got, _ = dump(tool, chunk, L, [fq], tmp_path, tag + "_fast%d_%d" % (L, chunk), thr)
+                assert got == gen, "the line-by-line parser differs (%s, L = %d, chunks of %d)" % (tag, L, chunk)
+    # a character the general parser stops at inside a sequence line (it ends the sequence there): such a record is not the line-by-line parser's
+    odd = tmp_path / "odd.fq"
+    with open(odd, "w") as f:
+        f.write("@a\nACGTACGTACGTACGTACGT+ACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIII\n@b\nACG>T\n+\nIIIII\n@c\nACGT\n+\nIIII\n")
+    gen, _ = dump(tool, 1 << 30, 100, [odd], tmp_path, "odd_gen", generic=True)
+    got, _ = dump(tool, 1 << 30, 100, [odd], tmp_path, "odd_fast")
+    assert got == gen and gen[0].split(" ")[:2] == ["a", "20"] and gen[1].split(" ")[:2] == ["b", "3"]
+    # pairs through both
+    f1, f2 = tmp_path / "q_1.fq", tmp_path / "q_2.fq"
+    write_fastq(f1, 900, rng, 50, 100, at_quals=True)
+    write_fastq(f2, 900, rng, 90, 100)
+    gen, _ = dump(tool, 500, 100, [f1, f2], tmp_path, "q_gen", generic=True)
+    got, _ = dump(tool, 500, 100, [f1, f2], tmp_path, "q_fast")
+    assert got == gen
 
 
 def test_fasta_and_pairs(tool, tmp_path):
