@@ -148,6 +148,8 @@ struct DpArgs {
     uint32_t       *table;                                        // per problem and 64-row chunk: (maxDPTableLength + 64) steps x 64 int16 H, then one 64-bit word per step
     size_t          tableWordsPerProblem;
     uint32_t        n, maxDNALength, maxReadLength, maxDPTableLength, patternLen, ldsPerWave;
+    uint32_t        ldsPerWavePair, first;                        // LDS of a wave that sweeps two problems (20 B per column); first problem of a launch of dpFillKernel
+    int             pairMode;                                     // 0: one problem per wavefront whatever the scores (S3DP_DP_PAIRED=0)
     int             match, mismatch, gapOpen, gapExtend, scheme;
     uint32_t       *patMax;                                       // optional: longest pattern of the launch in bytes (atomicMax; zeroed by the caller)
 };

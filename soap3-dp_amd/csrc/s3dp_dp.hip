@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) dpFillKernel(DpArgs a)
     extern __shared__ __align__(16) unsigned char sh[];
     // the wavefront number is uniform: saying so keeps the problem's lengths, clips, anchors and loop counters in scalar registers
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + wv;                // 1, 2 or 4 problems per block: what the windows leave room for in LDS
+    const uint32_t p = a.first + blockIdx.x * (blockDim.x >> 6) + wv;      // 1, 2 or 4 problems per block: what the windows leave room for in LDS
     if (p >= a.n) return;
     const uint32_t perWave = a.ldsPerWave;
     unsigned char *refLds = sh + wv * perWave;
@@ -241,6 +241,255 @@ __global__ void __launch_bounds__(256) dpFillKernel(DpArgs a)
         if (a.clipRt) a.clipRt[p] = found ? L - row : 0u;
     }
 }
+
+// ---- two problems per wavefront ---------------------------------------------------------------------------------------------------------------------------
+// Every value of the recurrence fits 16 bits: stored cells are clamped to [-32000, 32767] by the reference itself, and the running values of a column stay
+// within -32000 + 2 gapOpen + mismatch + gapExtend ... L x match (dpPairable checks the scores).  So a wave sweeps TWO problems at once, problem 2q in the low
+// half and problem 2q + 1 in the high half of every register, with the packed 16-bit instructions of the vector ALU (v_pk_add_i16, v_pk_max_i16,
+// v_pk_mad_i16 / _u16, v_pk_min_u16): one instruction per step and lane serves two cells.  Both problems take the steps of the longer window and the
+// chunks of the longer read; cells outside a problem's own table compute on values no cell inside consumes, as before.  What has no packed form is written
+// as arithmetic on the halves: "equal" is min_u16(a ^ b, 1), a select is a bit-field insert under a mask made of that.  The table each problem gets is the one
+// the one-problem kernel writes, bit for bit (two steps per dword, 32 steps of bits per dword): the traceback and everything behind it do not know.
+// Scheme 1 only (scheme 2 and score ranges beyond 16 bits: dpFillKernel).
+namespace dp2 {
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t bitsOf(s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s2 asS2(uint32_t v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ s2 both(int lo, int hi) { s2 r; r.x = (short)lo; r.y = (short)hi; return r; }
+__device__ __forceinline__ s2 pmax(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+// (the compiler turns min(x, 1) on halves into two compares, two selects and a byte permute, and a multiply-add on halves likewise: the three packed
+//  instructions that do them in one are asked for by name)
+__device__ __forceinline__ uint32_t pkMinU16(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pkMadI16(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ uint32_t pkMadU16(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// per half: 0 where the half is zero, 1 elsewhere
+__device__ __forceinline__ uint32_t nonZero01(uint32_t x) { return pkMinU16(x, 0x00010001u); }
+// per half: 0xFFFF where the half of x is non-zero / negative
+__device__ __forceinline__ uint32_t nonZeroMask(uint32_t x) { const s2 z = {0, 0}; return bitsOf(z - asS2(nonZero01(x))); }
+__device__ __forceinline__ uint32_t negativeMask(uint32_t x) { const s2 sh = {15, 15}; return bitsOf(asS2(x) >> sh); }
+__device__ __forceinline__ uint32_t pick(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }          // v_bfi_b32
+__device__ __forceinline__ uint32_t shr1From(uint32_t first, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false); }
+
+constexpr uint32_t NEVER2 = 0x80008000u;             // -32768 in both halves: below every value of the recurrence
+constexpr uint32_t ONE2 = 0x00010001u;
+
+struct Lane2 {
+    s2 hPrev, ePrev, upIn, fIn, dgIn;                // as LaneState, both problems; dgIn carries the diagonal PLUS the match score
+    uint32_t rIn;
+    uint4 nb;                                        // the column lane 0 meets next: boundary row (x, y, z) and window characters (w)
+    uint32_t initPrev;                               // CLIP: the initial row at the column this lane had one step ago
+    s2 bS; uint32_t bT, bC; s2 j2;                   // BEST: maximum, its step, its count -- 16 bits each per problem; j2 = this lane's column in both halves
+    uint32_t hHold, xBits, xHold;                    // table words in the making
+};
+
+struct Const2 {
+    s2 go, ge, gi, mt, dM, negInf;                   // mt = match, dM = mismatch - match
+    uint32_t rc, lane, W;                            // W = the longer window
+    uint32_t clipMask, notBest;                      // per half: 0xFFFF where the row lies in the free left clip; 0x8000 where it cannot hold the maximum
+    s2 jLo, Wown;                                    // per problem: first column that may hold the maximum, last column of its own window
+    uint4 *col;                                      // LDS: boundary row + window characters per column
+    const uint32_t *initRow;                         // LDS: H(j, 0) of both problems per column (entry 0 = 0: what the diagonal of column 1 sees)
+    uint32_t *tabH[2], *tabX[2];
+};
+
+template <bool CLIP, bool BEST, bool RAMP>
+__device__ __forceinline__ void dpStep2(const Const2 &k, Lane2 &s, uint32_t t)
+{
+    const s2 upS = asS2(shr1From(s.nb.x, bitsOf(s.upIn))), fS = asS2(shr1From(s.nb.y, bitsOf(s.fIn))), dgS = asS2(shr1From(s.nb.z, bitsOf(s.dgIn)));
+    const uint32_t rS = shr1From(s.nb.w, s.rIn);
+    const uint32_t jn = t + 1u < k.W ? t + 1u : k.W;                  // uniform
+    s.nb = k.col[jn];
+    const s2 prevR = s.hPrev;
+    const s2 geE = k.ge + s.ePrev;
+    s2 gapped = pmax(k.go + prevR, geE);
+    const s2 eSt = pmax(gapped, k.negInf);
+    s2 f = pmax(k.ge + fS, k.go + upS);
+    gapped = pmax(f, gapped);
+    const s2 diag = asS2(pkMadI16(nonZero01(rS ^ k.rc), bitsOf(k.dM), bitsOf(dgS)));      // the diagonal came down with the match score added
+    const s2 up = pmax(gapped, diag);
+    const s2 hSt = pmax(up, k.negInf);
+    s2 dg = prevR;
+    if (CLIP) {
+        const int jc = (int)(t - k.lane);
+        const uint32_t initJ = k.initRow[jc < 0 ? 0 : (jc > (int)k.W ? (int)k.W : jc)];
+        f = pmax(f, asS2(pick(k.clipMask, bitsOf(asS2(initJ) + k.gi), NEVER2)));
+        dg = pmax(dg, asS2(pick(k.clipMask, s.initPrev, NEVER2)));
+        s.initPrev = initJ;
+    }
+    if (RAMP) { const bool started = t > k.lane; s.hPrev = started ? hSt : s.hPrev; s.ePrev = started ? eSt : s.ePrev; }
+    else { s.hPrev = hSt; s.ePrev = eSt; }
+    s.upIn = up; s.fIn = f; s.dgIn = dg + k.mt; s.rIn = rS;
+    {
+        // the bit kept is the complement of the one-problem kernel's ("H did NOT come out of an extended deletion"); the words are complemented when stored
+        s.xBits = pkMadU16(s.xBits, 0x00020002u, nonZero01(bitsOf(hSt) ^ bitsOf(geE)));
+        const uint32_t h2 = bitsOf(hSt);
+        if (t & 1u) {
+            __builtin_nontemporal_store((s.hHold & 0xFFFFu) | (h2 << 16), &k.tabH[0][(size_t)(t >> 1) * 64u + k.lane]);
+            __builtin_nontemporal_store((s.hHold >> 16) | (h2 & 0xFFFF0000u), &k.tabH[1][(size_t)(t >> 1) * 64u + k.lane]);
+        } else s.hHold = h2;
+        if ((t & 15u) == 15u) {
+            if (t & 16u) {
+                __builtin_nontemporal_store(~((s.xHold << 16) | (s.xBits & 0xFFFFu)), &k.tabX[0][(size_t)(t >> 5) * 64u + k.lane]);
+                __builtin_nontemporal_store(~((s.xHold & 0xFFFF0000u) | (s.xBits >> 16)), &k.tabX[1][(size_t)(t >> 5) * 64u + k.lane]);
+            } else s.xHold = s.xBits;
+        }
+    }
+    if (BEST) {
+        // a cell counts where the row may end the alignment and jLo <= column <= the problem's own window; elsewhere its candidate is below everything
+        const uint32_t outMask = negativeMask(bitsOf(s.j2 - k.jLo) | bitsOf(k.Wown - s.j2) | k.notBest);
+        const s2 cand = asS2(pick(outMask, NEVER2, bitsOf(up)));
+        const s2 m = pmax(cand, s.bS);
+        const uint32_t gt = nonZeroMask(bitsOf(m) ^ bitsOf(s.bS));
+        const uint32_t eq = ONE2 - nonZero01(bitsOf(cand) ^ bitsOf(s.bS));
+        s.bC = pick(gt, ONE2, s.bC + eq);
+        s.bT = pick(gt, t * ONE2, s.bT);
+        s.bS = m;
+        s.j2 = s.j2 + asS2(ONE2);
+    }
+    if (!RAMP) {
+        // the chunk's last row becomes the boundary of the next chunk; lane 0 fetched this column 64 steps ago
+        if (k.lane == 63u) { uint4 *c = &k.col[t - 63u]; c->x = bitsOf(up); c->y = bitsOf(f); c->z = bitsOf(s.dgIn); }
+    }
+}
+
+struct Problem2 { uint32_t p[2], L[2], W[2], aL[2], aR[2]; int clipLt[2], clipRtLoc[2]; };
+
+template <bool CLIP, bool BEST>
+__device__ __forceinline__ void chunkSweep2(const DpArgs &a, const Problem2 &q, uint32_t c, uint32_t Wmax, uint4 *col, const uint32_t *initRow, Best best[2])
+{
+    Const2 k;
+    const int go = a.gapOpen, ge = a.gapExtend, gi = go - ge;
+    k.go = both(go, go); k.ge = both(ge, ge); k.gi = both(gi, gi); k.mt = both(a.match, a.match); k.dM = both(a.mismatch - a.match, a.mismatch - a.match);
+    k.negInf = both(NEG_INF, NEG_INF);
+    k.lane = threadIdx.x & 63u; k.W = Wmax; k.col = col; k.initRow = initRow;
+    const uint32_t T = a.maxDPTableLength + 64u;
+    const uint32_t i = (c << 6) + 1u + k.lane;                       // this lane's read row
+    uint32_t rc[2], clipM[2], notB[2];
+    int jLo[2], h0[2], e0[2];
+    for (int h = 0; h < 2; h++) {
+        uint32_t *table = a.table + (size_t)q.p[h] * a.tableWordsPerProblem + (size_t)c * dpTableChunkWords(T);
+        k.tabH[h] = table; k.tabX[h] = table + dpTableXBase(T);
+        const bool rowOk = i <= q.L[h];
+        rc[h] = rowOk ? seqChar(a.reads, q.p[h], a.maxReadLength, i) : 0u;
+        jLo[h] = max(1, (int)q.aR[h]);                               // first column that may hold the maximum (right anchor; no start offset in scheme 1)
+        const bool rowBest = BEST && rowOk && (int)i >= q.clipRtLoc[h] && (int)q.W[h] - jLo[h] >= 0;
+        notB[h] = rowBest ? 0u : 0x8000u;
+        clipM[h] = CLIP && (int)i <= q.clipLt[h] ? 0xFFFFu : 0u;
+        // column 0 of this row (:165-183)
+        if ((int)i <= q.clipLt[h]) { h0[h] = clampS(go); e0[h] = clampS(go + gi); }
+        else { const int up0 = gi + ge * ((int)i - (q.clipLt[h] > 0 ? q.clipLt[h] : 0)); h0[h] = clampS(up0); e0[h] = clampS(up0 + gi); }
+    }
+    k.rc = rc[0] | rc[1] << 16; k.clipMask = clipM[0] | clipM[1] << 16; k.notBest = notB[0] | notB[1] << 16;
+    k.jLo = both(jLo[0], jLo[1]); k.Wown = both((int)q.W[0], (int)q.W[1]);
+    Lane2 s;
+    s.hPrev = both(h0[0], h0[1]); s.ePrev = both(e0[0], e0[1]);
+    s.upIn = both(0, 0); s.fIn = both(0, 0); s.dgIn = both(0, 0); s.rIn = 0; s.initPrev = 0;
+    s.bS = both(NEG_INF, NEG_INF); s.bT = 0; s.bC = 0;
+    s.j2 = both(1 - (int)k.lane, 1 - (int)k.lane);                   // the column of step 1
+    s.hHold = 0; s.xBits = 0; s.xHold = 0;
+    s.nb = col[Wmax ? 1u : 0u];
+    const uint32_t steps = Wmax + 63u;
+    uint32_t t = 1;
+    for (; t <= 63u; t++) dpStep2<CLIP, BEST, true>(k, s, t);
+    for (; t + 1u <= steps; t += 2u) { dpStep2<CLIP, BEST, false>(k, s, t); dpStep2<CLIP, BEST, false>(k, s, t + 1u); }
+    if (t <= steps) dpStep2<CLIP, BEST, false>(k, s, t);
+    // what the last steps left in the registers (steps is the last step taken)
+    for (int h = 0; h < 2; h++) {
+        const uint32_t sh = h ? 16u : 0u;
+        if (!(steps & 1u)) __builtin_nontemporal_store((s.hHold >> sh) & 0xFFFFu, &k.tabH[h][(size_t)(steps >> 1) * 64u + k.lane]);
+        const uint32_t r = steps & 31u;
+        if (r != 31u) {
+            // the bits of steps (steps & ~31) .. steps: the first sixteen wait in xHold once there are more, the rest sit at the low end of xBits
+            const uint32_t cur = (((s.xBits >> sh) & 0xFFFFu) << (15u - (r & 15u))) & 0xFFFFu, held = (s.xHold >> sh) & 0xFFFFu;
+            const uint32_t w = r >= 16u ? (held << 16) | cur : cur << 16;
+            __builtin_nontemporal_store(~w, &k.tabX[h][(size_t)(steps >> 5) * 64u + k.lane]);
+        }
+        if (BEST) {
+            const uint32_t cnt = (s.bC >> sh) & 0xFFFFu, at = (s.bT >> sh) & 0xFFFFu;
+            const int score = (int)(short)((bitsOf(s.bS) >> sh) & 0xFFFFu);
+            if (cnt) bestMerge(best[h], score, ((at - k.lane) << 16) | i, cnt);
+        }
+    }
+}
+
+}  // namespace dp2
+
+using namespace dp2;
+
+__global__ void __launch_bounds__(256) dpFillPairKernel(DpArgs a)
+{
+    extern __shared__ __align__(16) unsigned char sh[];
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    const uint32_t p0 = 2u * (blockIdx.x * (blockDim.x >> 6) + wv);
+    if (p0 + 1u >= a.n) return;                                          // whole pairs only: an odd last problem is dpFillKernel's (launchDp)
+    Problem2 q;
+    for (int h = 0; h < 2; h++) {
+        const uint32_t p = p0 + (uint32_t)h;
+        q.p[h] = p; q.L[h] = a.readLengths[p]; q.W[h] = a.dnaLengths[p];
+        q.aL[h] = a.anchorLeft ? a.anchorLeft[p] : a.maxDNALength; q.aR[h] = a.anchorRight ? a.anchorRight[p] : 0u;
+        q.clipLt[h] = (int)(a.clipLt ? a.clipLt[p] : 0u);
+        q.clipRtLoc[h] = (int)(q.L[h] - (a.clipRt ? a.clipRt[p] : 0u));
+    }
+    uint4 *col = (uint4 *)(sh + (size_t)wv * a.ldsPerWavePair);
+    uint32_t *initRow = (uint32_t *)(col + (a.maxDNALength + 1u));
+    const uint32_t Wmax = q.W[0] > q.W[1] ? q.W[0] : q.W[1], Lmax = q.L[0] > q.L[1] ? q.L[0] : q.L[1];
+    const int gi = a.gapOpen - a.gapExtend;
+    // row 0 of both problems: H[j][0] = init(j), running open = init + gi, diagonal for row 1 = init(j-1) (+ match, see Lane2::dgIn), the window characters
+    for (uint32_t j = lane; j <= Wmax; j += 64u) {
+        uint32_t v[4] = {0, 0, 0, 0}, ini = 0;
+        for (int h = 0; h < 2; h++) {
+            const int init = (j >= q.aL[h]) ? NEG_INF : 0;
+            const int prevInit = (j <= 1u) ? 0 : ((j - 1u >= q.aL[h]) ? NEG_INF : 0);
+            const uint32_t ch = (j >= 1u && j <= q.W[h]) ? seqChar(a.dna, q.p[h], a.maxDNALength, j) : 0u;
+            const uint32_t sh16 = h ? 16u : 0u;
+            v[0] |= ((uint32_t)init & 0xFFFFu) << sh16; v[1] |= ((uint32_t)(init + gi) & 0xFFFFu) << sh16; v[2] |= ((uint32_t)(prevInit + a.match) & 0xFFFFu) << sh16;
+            v[3] |= ch << sh16;
+            ini |= ((uint32_t)init & 0xFFFFu) << sh16;
+        }
+        col[j] = make_uint4(v[0], v[1], v[2], v[3]);
+        initRow[j] = j ? ini : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    Best best[2];
+    for (int h = 0; h < 2; h++) { best[h].score = NEG_INF; best[h].key = 0xFFFFFFFFu; best[h].count = 0; }
+    const uint32_t chunks = (Lmax + 63u) >> 6;
+    for (uint32_t c = 0; c < chunks; c++) {
+        // wave-uniform: does the chunk touch the free left clip / hold rows that may end the alignment -- of either problem?
+        const bool clip = q.clipLt[0] > (int)(c << 6) || q.clipLt[1] > (int)(c << 6);
+        const bool mayEnd = (int)((c << 6) + 64u) >= q.clipRtLoc[0] || (int)((c << 6) + 64u) >= q.clipRtLoc[1];
+        if (clip) {
+            if (mayEnd) chunkSweep2<true, true>(a, q, c, Wmax, col, initRow, best);
+            else chunkSweep2<true, false>(a, q, c, Wmax, col, initRow, best);
+        } else {
+            if (mayEnd) chunkSweep2<false, true>(a, q, c, Wmax, col, initRow, best);
+            else chunkSweep2<false, false>(a, q, c, Wmax, col, initRow, best);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int h = 0; h < 2; h++) {
+        Best &b = best[h];
+        for (int off = 32; off > 0; off >>= 1) {
+            const int s2v = __shfl_xor(b.score, off);
+            const uint32_t k2 = (uint32_t)__shfl_xor((int)b.key, off), c2 = (uint32_t)__shfl_xor((int)b.count, off);
+            bestMerge(b, s2v, k2, c2);
+        }
+        if (lane == 0) {
+            const uint32_t p = q.p[h];
+            const bool found = b.count && b.score > NEG_INF;              // ties with the initial -32000 only count (:228-236)
+            const uint32_t hitPos = found ? b.key >> 16 : 0u, row = found ? b.key & 0xFFFFu : 0u;
+            a.startOffsets[p] = 0u;
+            a.hitLocs[p] = hitPos;
+            a.scores[p] = b.score;
+            a.maxScoreCounts[p] = b.count;
+            a.tableCols[p] = q.W[h];
+            if (a.clipRt) a.clipRt[p] = found ? q.L[h] - row : 0u;
+        }
+    }
+}
+
 
 // Traceback (what GPUBacktrack computes, DV-DPfunctions.cu:316-512): from the maximum back to the read's first aligned base.
 // The reference's walk decides every move by comparing table VALUES, in a fixed priority -- match/mismatch, then a deletion that opens here, then
@@ -341,23 +590,51 @@ __global__ void dpBacktrackKernel(DpArgs a)
     a.hitLocs[p] = v.refOffset + j;
 }
 
-// returns a hipError_t (hipErrorInvalidValue: a window that does not fit into LDS even with one problem per block)
-int launchDp(const DpArgs &a, hipStream_t s)
+// may the launch's problems go two to a wavefront (dpFillPairKernel)?  Scheme 1, every value of the recurrence within 16 bits, the paired rows in LDS
+static bool dpPairable(const DpArgs &a)
 {
-    if (!a.n) return (int)hipSuccess;
-    // a wave keeps its window and the boundary row of its pass in LDS (ldsPerWave bytes); blocks hold 4 waves while that fits into the CU's 160 KB,
-    // then 2, then 1 (windows up to about 12,000 columns)
+    if (!a.pairMode || a.scheme != 1 || a.n < 2u) return false;
+    if (a.match < 0 || a.match > 250 || a.mismatch > 0 || a.mismatch < -250 || a.gapOpen > 0 || a.gapOpen < -250 || a.gapExtend > 0 || a.gapExtend < -250) return false;
+    if ((long long)a.maxReadLength * a.match > 30000) return false;
+    if (-2 * a.gapOpen - a.gapExtend - a.mismatch > 700) return false;
+    if (a.maxDNALength > 12000u || (size_t)a.ldsPerWavePair > 160u * 1024u) return false;
+    return true;
+}
+
+// returns a hipError_t (hipErrorInvalidValue: a window that does not fit into LDS even with one problem per block)
+int launchDp(const DpArgs &a0, hipStream_t s)
+{
+    if (!a0.n) return (int)hipSuccess;
+    DpArgs a = a0;
     const size_t kLdsMax = 160u * 1024u;
-    uint32_t waves = 4;
-    while (waves > 1 && (size_t)a.ldsPerWave * waves > kLdsMax) waves >>= 1;
-    const size_t lds = (size_t)a.ldsPerWave * waves;
-    if (lds > kLdsMax) return (int)hipErrorInvalidValue;
-    if (lds > 48u * 1024u) {
-        // above the default limit for dynamic LDS: without the attribute the launch fails (and only shows at the next synchronisation)
-        const hipError_t e = hipFuncSetAttribute((const void *)dpFillKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+    a.first = 0;
+    if (dpPairable(a)) {
+        uint32_t waves = 4;
+        while (waves > 1 && (size_t)a.ldsPerWavePair * waves > kLdsMax) waves >>= 1;
+        const size_t lds = (size_t)a.ldsPerWavePair * waves;
+        if (lds > 48u * 1024u) {
+            const hipError_t e = hipFuncSetAttribute((const void *)dpFillPairKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        const uint32_t pairs = a.n >> 1;
+        hipLaunchKernelGGL(dpFillPairKernel, dim3((pairs + waves - 1u) / waves), dim3(64u * waves), lds, s, a);
+        a.first = pairs << 1;                                              // an odd last problem on its own
     }
-    hipLaunchKernelGGL(dpFillKernel, dim3((a.n + waves - 1u) / waves), dim3(64u * waves), lds, s, a);
+    if (a.first < a.n) {
+        // a wave keeps its window and the boundary row of its pass in LDS (ldsPerWave bytes); blocks hold 4 waves while that fits into the CU's 160 KB,
+        // then 2, then 1 (windows up to about 12,000 columns)
+        uint32_t waves = 4;
+        while (waves > 1 && (size_t)a.ldsPerWave * waves > kLdsMax) waves >>= 1;
+        const size_t lds = (size_t)a.ldsPerWave * waves;
+        if (lds > kLdsMax) return (int)hipErrorInvalidValue;
+        if (lds > 48u * 1024u) {
+            // above the default limit for dynamic LDS: without the attribute the launch fails (and only shows at the next synchronisation)
+            const hipError_t e = hipFuncSetAttribute((const void *)dpFillKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(dpFillKernel, dim3((a.n - a.first + waves - 1u) / waves), dim3(64u * waves), lds, s, a);
+    }
+    a.first = 0;
     hipLaunchKernelGGL(dpBacktrackKernel, dim3((a.n + 63u) / 64u), dim3(64), 0, s, a);
     return (int)hipSuccess;
 }

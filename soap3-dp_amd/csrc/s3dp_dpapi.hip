@@ -288,6 +288,9 @@ int s3i::dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL,
     HIPCHK(hipMemsetAsync(h->dPatMax, 0, 4, h->stream));
     a.n = n; a.maxDNALength = h->maxDNA; a.maxReadLength = h->maxRead; a.maxDPTableLength = h->maxTable; a.patternLen = h->patternLen;
     a.ldsPerWave = (((h->maxDNA + 1u + 15u) & ~15u) + (h->maxDNA + 1u) * 12u + 15u) & ~15u;
+    a.ldsPerWavePair = ((h->maxDNA + 1u) * 20u + 15u) & ~15u;
+    a.first = 0;
+    { const char *e = getenv("S3DP_DP_PAIRED"); a.pairMode = !(e && *e == '0'); }
     a.match = h->sc.matchScore; a.mismatch = h->sc.mismatchScore; a.gapOpen = h->sc.gapOpenScore; a.gapExtend = h->sc.gapExtendScore; a.scheme = h->scheme;
     if ((size_t)a.ldsPerWave > 160 * 1024) return fail(S3_EINVAL, "s3_dp_align: maxDNALength too large for the LDS-resident window");
     if (dpDumpFile()) {

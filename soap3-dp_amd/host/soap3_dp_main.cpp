@@ -96,9 +96,16 @@ static void drainOutput(FILE *f)                                              //
     for (std::thread &t : st->pending) if (t.joinable()) t.join();
 }
 
+// where a call of parallelFormat spends its time (summed over the run, printed with S3DP_VERBOSE): waiting for the write that still holds its buffers,
+// the formatting threads (wall, and the sum over the threads), the rest
+static std::mutex g_fmtMu;
+static double g_fmtSeconds[4] = {0, 0, 0, 0};
+
 template <class F>
 static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out, uint32_t count, F &&one, uint64_t &aligned)
 {
+    const auto tEnter = std::chrono::steady_clock::now();
+    auto secondsSince = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     const int T = hostThreads();
     const uint32_t per = (count + (uint32_t)T - 1) / (uint32_t)T;
     // the buffers live as long as the output file: a chunk of 4 Mi reads is more than a gigabyte of SAM, and touching that much fresh memory from all
@@ -107,6 +114,9 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
     const int gen = os.gen;
     os.gen ^= 1;
     if (os.pending[gen].joinable()) os.pending[gen].join();                   // the write of the call before the last one used these buffers
+    const double waited = secondsSince(tEnter);
+    const auto tWork = std::chrono::steady_clock::now();
+    std::vector<double> busy((size_t)T, 0);
     std::vector<std::string> &buf = os.buf[gen];
     if (buf.size() < (size_t)T) buf.resize((size_t)T);
     for (auto &b : buf) b.clear();
@@ -116,6 +126,8 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
     for (int t = 0; t < T; t++) th.emplace_back([&, t] {
         const uint32_t lo = (uint32_t)t * per, hi = lo + per < count ? lo + per : count;
         if (lo >= hi) return;
+        const auto tMine = std::chrono::steady_clock::now();
+        struct Stop { double &d; std::chrono::steady_clock::time_point t0; ~Stop() { d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } stop{busy[(size_t)t], tMine};
         buf[(size_t)t].reserve((size_t)(hi - lo) * 320);
         SamWriter w(hix, so, &buf[(size_t)t]);
         for (uint32_t k = lo; k < hi; k++) one(w, k, al[(size_t)t]);
@@ -128,6 +140,12 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
         }
     });
     for (auto &x : th) x.join();
+    {
+        double sum = 0;
+        for (double b : busy) sum += b;
+        std::lock_guard<std::mutex> g(g_fmtMu);
+        g_fmtSeconds[0] += waited; g_fmtSeconds[1] += secondsSince(tWork); g_fmtSeconds[2] += sum; g_fmtSeconds[3] += 1;
+    }
     // the buffers go to the file at their final offsets, a few writers at a time; the file position moves behind them at once, so whatever is
     // written through the FILE next (records of stages that do not come through here) lands behind this call's records
     if (!bamFlush(out)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); }
@@ -1061,6 +1079,11 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         else printf("[Main] Number of reads aligned by DP: %llu\n", (unsigned long long)counters[C_DP_READS]);
     }
     // device time of the run (HIP events): the BWT stages with their search kernels, and every launch of the DP kernels with the cells they filled
+    if (getenv("S3DP_VERBOSE")) {
+        std::lock_guard<std::mutex> g(g_fmtMu);
+        fprintf(stderr, "[s3dp] formatter: %.0f calls, waited %.3f s for buffers still being written, formatting threads %.3f s of wall clock (%.3f s summed over %d threads)\n",
+                g_fmtSeconds[3], g_fmtSeconds[0], g_fmtSeconds[1], g_fmtSeconds[2], hostThreads());
+    }
     if (!paired && !enableDP) printf("[Main] Stream loop time : feeder waited %.3f for the loader, %.3f for a free slot, copied chunks in %.3f; writer waited %.3f for results, formatted + wrote %.3f seconds\n",
                                      g_streamSeconds[0], g_streamSeconds[1], g_streamSeconds[2], g_streamSeconds[3], g_streamSeconds[4]);
     if (paired) printf("[Main] Chunk loop time : alignment calls %.3f, fetching results %.3f, formatting + writing %.3f, DP stages %.3f seconds\n", g_chunkSeconds[0], g_chunkSeconds[1],

@@ -42,3 +42,33 @@ def test_dp_without_optional_arrays():
     osc, ohit, ocnt, opat, _, _ = s3o.dp_align(P["dna"], P["dna_len"], 160, al.max_table, P["reads"], P["read_len"], 100, P["cutoffs"], scheme=1, scores=SC)
     assert (sc == osc).all() and (hit == ohit).all() and (cnt == ocnt).all()
     al.close()
+
+
+# (score set, what it exercises): the reference's defaults; larger penalties; a penalty beyond what the paired kernel accepts (the launch falls back to one
+# problem per wavefront)
+SCORE_SETS = [((1, -2, -3, -1), "defaults"), ((2, -3, -5, -2), "larger"), ((5, -4, -12, -3), "larger still"), ((1, -260, -3, -1), "outside the paired range")]
+
+
+@pytest.mark.parametrize("scores,what", SCORE_SETS, ids=[w for _, w in SCORE_SETS])
+@pytest.mark.parametrize("n", [1, 2, 201])
+def test_two_problems_per_wavefront_equal_one(monkeypatch, scores, what, n):
+    """dpFillPairKernel sweeps two problems in the 16-bit halves of a wave's registers (scheme 1, scores within range): same scores, start columns, tie
+    counts, right clips and traceback strings as the one-problem kernel (S3DP_DP_PAIRED=0) and as the CPU restatement -- neighbours of different read
+    length and window, an odd problem at the end, chunk-boundary lengths, clips into the second chunk."""
+    max_read, max_dna = 200, 420
+    P = make_problems(n, max_read, max_dna, 77 + n, lengths=[63, 150, 64, 65, 30, 127, 128, 129, 191, 192, 193, 100], clip_max=90)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("S3DP_DP_PAIRED", mode)
+        al = s3dp.DpAligner(n, max_read, max_dna, scheme=1, scores=scores)
+        out[mode] = al.align(P["dna"], P["dna_len"], P["reads"], P["read_len"], P["cutoffs"], clip_lt=P["clip_lt"], clip_rt=P["clip_rt"], anchor_lt=P["a_lt"],
+                             anchor_rt=P["a_rt"])
+        al.close()
+    orc = s3o.dp_align(P["dna"], P["dna_len"], max_dna, max_dna, P["reads"], P["read_len"], max_read, P["cutoffs"], scheme=1, scores=scores,
+                       clip_lt=P["clip_lt"], clip_rt=P["clip_rt"], anchor_lt=P["a_lt"], anchor_rt=P["a_rt"])
+    for mode in ("1", "0"):
+        sc, hit, cnt, pat, crt = out[mode]
+        assert (sc == orc[0]).all() and (hit == orc[1]).all() and (cnt == orc[2]).all() and (crt == orc[4]).all(), "S3DP_DP_PAIRED=" + mode
+        for t in np.nonzero(sc >= P["cutoffs"])[0]:
+            a, b = bytes(pat[t]), bytes(orc[3][t])
+            assert a[:a.index(0) + 1] == b[:b.index(0) + 1], (mode, t)
