@@ -258,7 +258,7 @@ static bool singleDpRuns(const HostIndex &hix, const SamOptions &so, FILE *paral
 
 static std::mutex g_pairStageMu;                                 // (several devices run the stages at once)
 static double g_pairStageSeconds[5] = {0, 0, 0, 0, 0};          // routing, default DP, new default DP, deep DP, single-end DP of the leftovers
-static double g_chunkSeconds[4] = {0, 0, 0, 0};                    // wall clock inside the chunk loop: alignment call, fetch of the results, formatting + writing, DP stages
+static double g_chunkSeconds[6] = {0, 0, 0, 0, 0, 0};              // wall clock inside the chunk loop: alignment call, fetch of the results, formatting + writing, DP stages (on their own thread), waiting for them, upload
 static void addChunkSeconds(int k, double sec) { std::lock_guard<std::mutex> g(g_pairStageMu); g_chunkSeconds[k] += sec; }
 static double g_streamSeconds[6] = {0, 0, 0, 0, 0, 0};             // streamed single reads: waiting for the loader, for a free slot, copying a chunk in; writer: waiting for results, formatting + writing
 static void addStreamSeconds(int k, double sec) { std::lock_guard<std::mutex> g(g_pairStageMu); g_streamSeconds[k] += sec; }
@@ -933,12 +933,61 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     const uint32_t maxBatch = chunkReads;
     if (chunk && s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : (chunk->n ? chunk->n : 1), chunk->wpq, &b) != S3_OK) return dieJoin(s3_last_error());
     mark("batch created");
-    for (; chunk && chunk->n; recycle(std::move(chunk)), chunk = nextChunk()) {
+    // ---- pairs with the DP stages on: the stages of chunk k run on a thread of their own while this one uploads, searches and writes the paired
+    // records of chunk k + 1 -- two batches take turns (the DP packers read a chunk's reads where the search left them); the stages are host work around
+    // a quarter second of kernels per ten million pairs and used to run between two chunks' searches ------------------------------------------------
+    struct PairJob {
+        std::unique_ptr<ReadSet> rs; s3_batch *b = nullptr; uint32_t cnt = 0;
+        std::vector<s3_pair_result> pr; std::vector<uint64_t> ooff; std::vector<uint32_t> pos; std::vector<uint8_t> strand, mis, fromSa;
+    };
+    struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<PairJob>> q; uint64_t submitted = 0, done = 0; bool stop = false; } dpq;
+    s3_batch *pairBatch[2] = {b, nullptr};
+    std::thread dpWorker;
+    const bool pipelinedDp = paired && enableDP && chunk && chunk->n;
+    if (pipelinedDp) {
+        if (s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : chunk->n, chunk->wpq, &pairBatch[1]) != S3_OK) return dieJoin(s3_last_error());
+        dpWorker = std::thread([&] {
+            for (;;) {
+                std::unique_ptr<PairJob> j;
+                {
+                    std::unique_lock<std::mutex> lk(dpq.mu);
+                    dpq.cv.wait(lk, [&] { return !dpq.q.empty() || dpq.stop; });
+                    if (dpq.q.empty()) return;
+                    j = std::move(dpq.q.front());
+                    dpq.q.pop_front();
+                }
+                PairDpCtx c{hix, so, *j->rs, ini, j->b, seedBatch, dp, dpHalf, dpOut, unpairOut, 0u, j->cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
+                std::string e2;
+                const auto tDp = std::chrono::steady_clock::now();
+                if (!pairDpStages(c, j->pr, j->ooff, j->pos, j->strand, j->mis, j->fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) {
+                    fflush(stdout); fprintf(stderr, "%s\n", e2.c_str()); fflush(stderr); _exit(1);
+                }
+                dpStageSeconds += since(tDp);
+                addChunkSeconds(3, since(tDp));
+                recycle(std::move(j->rs));
+                j.reset();
+                { std::lock_guard<std::mutex> g(dpq.mu); dpq.done++; }
+                dpq.cv.notify_all();
+            }
+        });
+    }
+    uint64_t chunkNo = 0;
+    for (; chunk && chunk->n; recycle(std::move(chunk)), chunk = nextChunk(), chunkNo++) {
         ReadSet &rs = *chunk;
         const uint32_t first = 0, cnt = rs.n;
         totalReads += cnt;
         (void)maxBatch;
+        if (pipelinedDp) {
+            // this chunk's batch was the batch of the chunk before the last: its DP stages must be through
+            b = pairBatch[chunkNo & 1];
+            const auto tWt = std::chrono::steady_clock::now();
+            std::unique_lock<std::mutex> lk(dpq.mu);
+            dpq.cv.wait(lk, [&] { return chunkNo < 2 || dpq.done + 2 > chunkNo; });
+            addChunkSeconds(4, since(tWt));
+        }
+        const auto tUp = std::chrono::steady_clock::now();
         if (s3_batch_upload(b, rs.queries.data() + (size_t)first * rs.wpq, rs.lengths.data() + first, cnt) != S3_OK) return dieJoin(s3_last_error());
+        addChunkSeconds(5, since(tUp));
         // reads longer than 120 bases: only the first 100 are searched, the rest is verified on the device (alignment.cu:2473-2491)
         if (paired) {
             // pairs keep to the whole read (seedLengths is NULL for pairs, alignment.cu:1965-2013); DP stages are off (-s)
@@ -982,12 +1031,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             }, aligned);
             addChunkSeconds(2, since(tW));
             if (enableDP) {
-                PairDpCtx c{hix, so, rs, ini, b, seedBatch, dp, dpHalf, dpOut, unpairOut, first, cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
-                std::string e2;
-                const auto tDp = std::chrono::steady_clock::now();
-                if (!pairDpStages(c, pr, ooff, pos, strand, mis, fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) return dieJoin(e2);
-                dpStageSeconds += since(tDp);
-                addChunkSeconds(3, since(tDp));
+                std::unique_ptr<PairJob> j(new PairJob());
+                j->b = b; j->cnt = cnt;
+                j->pr.swap(pr); j->ooff.swap(ooff); j->pos.swap(pos); j->strand.swap(strand); j->mis.swap(mis); j->fromSa.swap(fromSa);
+                j->rs = std::move(chunk);                                          // (the loop's recycle() gets nothing: the worker gives the set back)
+                { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); dpq.submitted++; }
+                dpq.cv.notify_all();
             }
             continue;
         }
@@ -1041,6 +1090,13 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             for (uint32_t k : todo) if (!doneFlag[k]) w.unaligned(rs, first + k);
         }
     }
+    if (dpWorker.joinable()) {
+        { std::lock_guard<std::mutex> g(dpq.mu); dpq.stop = true; }
+        dpq.cv.notify_all();
+        dpWorker.join();
+        b = pairBatch[0];
+        s3_batch_free(pairBatch[1]);
+    }
     auto closeOut = [&](FILE *f) { drainOutput(f); if (!bamClose(f)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); } fclose(f); };
     closeOut(out);
     if (dpOut) {
@@ -1092,8 +1148,8 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     }
     if (!paired && !enableDP) printf("[Main] Stream loop time : feeder waited %.3f for the loader, %.3f for a free slot, copied chunks in %.3f; writer waited %.3f for results, formatted + wrote %.3f seconds\n",
                                      g_streamSeconds[0], g_streamSeconds[1], g_streamSeconds[2], g_streamSeconds[3], g_streamSeconds[4]);
-    if (paired) printf("[Main] Chunk loop time : alignment calls %.3f, fetching results %.3f, formatting + writing %.3f, DP stages %.3f seconds\n", g_chunkSeconds[0], g_chunkSeconds[1],
-                       g_chunkSeconds[2], g_chunkSeconds[3]);
+    if (paired) printf("[Main] Chunk loop time : alignment calls %.3f, fetching results %.3f, formatting + writing %.3f, DP stages %.3f seconds (on a thread of their own; the loop waited %.3f for them), uploads %.3f\n",
+                       g_chunkSeconds[0], g_chunkSeconds[1], g_chunkSeconds[2], g_chunkSeconds[3], g_chunkSeconds[4], g_chunkSeconds[5]);
     printf("[Main] Device time : BWT stages %.1f ms (search kernels %.1f ms)", g_deviceMs[0], g_deviceMs[1]);
     if (enableDP) printf(", DP kernels %.1f ms, %llu problems, %llu cells, %.1f GCUPS", g_deviceMs[2], (unsigned long long)g_dpProblems, (unsigned long long)g_dpCells,
                          g_deviceMs[2] > 0 ? (double)g_dpCells / (g_deviceMs[2] * 1e-3) / 1e9 : 0.0);
