@@ -706,21 +706,6 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     };
     // (a failure below leaves through exit(): the loader thread must not outlive main's locals silently)
     auto dieJoin = [&](const std::string &m) -> int { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); return 1; };
-    if (!shared.loaded) {
-        printf("[Main] loading index into host...\n");
-        if (!loadIndex(indexName, hix, err)) return dieJoin(err);
-        printf("[Main] Finished loading index into host.\n[Main] Loading time : %9.4f seconds\n", since(t0));
-        printf("[Main] Reference sequence length : %u\n", hix.n);
-        // the index is replicated: one copy per device, uploaded at the same time (s3_group_create); the read chunks are dealt to the devices as they
-        // come free, each device writes its own set of output files (as the reference writes one .gout.N per CPU thread, SOAP3-DP.cu:251-258)
-        s3_index_desc d = hix.desc();
-        if (s3_group_create(devices.data(), (int)devices.size(), &d, &shared.grp) != S3_OK) return dieJoin(s3_last_error());
-        shared.devices = devices;
-        shared.loaded = true;
-        printf("[Main] Finished copying index into device (GPU).\n");
-    } else devices = shared.devices;                                           // (later jobs of a list run on the devices the index is on)
-    s3_group *grp = shared.grp;
-    const int nMembers = (int)devices.size();
     std::unique_ptr<ReadSet> chunk = nextChunk();
     if (!chunk) {
         if (!loaded.err.empty()) return dieJoin(loaded.err);
@@ -751,6 +736,58 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         else if (paired && (detectedReadLength <= 50 || detectedReadLength2 <= 50)) numMismatch = 1;   // SOAP3-DP.cu:663-666
         if (!enableDP && numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;
     }
+    // the DP aligners' traceback tables are a few gigabytes per device (20 ms per GB to allocate): made while the index is read and uploaded
+    struct PreDp { s3_dp *dp = nullptr, *dpHalf = nullptr; std::string err; };
+    const std::vector<int> &dpDevices = shared.loaded ? shared.devices : devices;
+    std::vector<PreDp> preDp(dpDevices.size());
+    std::vector<std::thread> preDpThreads;
+    auto dpShapes = [&](int &maxRL, int &maxDNA, int &maxDNAHalf) {
+        maxRL = (maxReadLength / 4 + 1) * 4;
+        const int margin = maxReadLength > 100 ? maxReadLength >> 2 : 25;
+        maxDNA = maxRL + 2 * margin + 8;                                      // DV-DPfunctions.cu:1580
+        maxDNAHalf = insertHigh - insertLow + maxReadLength + 1;              // HalfEndAlignmentEngine::performAlignment, DV-DPfunctions.cu:2221-2224
+    };
+    if (enableDP)
+        for (size_t m = 0; m < dpDevices.size(); m++) preDpThreads.emplace_back([&, m] {
+            int maxRL, maxDNA, maxDNAHalf;
+            dpShapes(maxRL, maxDNA, maxDNAHalf);
+            // SemiGlobalAligner::decideConfiguration (DV-DPfunctions.cu:568-612) takes scheme 1 (one table over the whole window) whenever 64 blocks of full
+            // tables fit the device, which on 288 GB they always do.  S3DP_DP_SCHEME=2 asks for what the reference does on a device too small for that: scheme 2
+            // (score pass over the window, table of L + L/2 + 8 columns) wherever the window is at least three read lengths (coefConf[0]), scheme 1 elsewhere.
+            const int askScheme = getenv("S3DP_DP_SCHEME") && atoi(getenv("S3DP_DP_SCHEME")) == 2 ? 2 : 1;
+            auto wantScheme = [&](int rl, int dna) { return askScheme == 2 && dna >= rl * 3 ? 2 : 1; };
+            // problems per DP launch: the traceback tables of one launch stay under 8 GB (ten thousand problems fill the chip as well as thirty thousand do)
+            auto problems = [&](int rl, int tl) -> uint32_t {
+                const double perProblem = (double)((rl + 63) / 64) * (tl + 64) * 64 * 4;
+                const double n = 8e9 / perProblem;
+                return n >= 32768 ? 32768u : n < 256 ? 256u : (uint32_t)n;
+            };
+            int scheme = 1, tableLen = 0, patLen = 0;
+            s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
+            s3_dp_config(maxRL, maxDNA, wantScheme(maxRL, maxDNA), &scheme, &tableLen, &patLen);
+            if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &preDp[m].dp) != S3_OK) { preDp[m].err = s3_last_error(); return; }
+            if (paired) {
+                s3_dp_config(maxRL, maxDNAHalf, wantScheme(maxRL, maxDNAHalf), &scheme, &tableLen, &patLen);
+                if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &preDp[m].dpHalf) != S3_OK) preDp[m].err = s3_last_error();
+            }
+        });
+    if (!shared.loaded) {
+        printf("[Main] loading index into host...\n");
+        if (!loadIndex(indexName, hix, err)) return dieJoin(err);
+        printf("[Main] Finished loading index into host.\n[Main] Loading time : %9.4f seconds\n", since(t0));
+        printf("[Main] Reference sequence length : %u\n", hix.n);
+        // the index is replicated: one copy per device, uploaded at the same time (s3_group_create); the read chunks are dealt to the devices as they
+        // come free, each device writes its own set of output files (as the reference writes one .gout.N per CPU thread, SOAP3-DP.cu:251-258)
+        s3_index_desc d = hix.desc();
+        if (s3_group_create(devices.data(), (int)devices.size(), &d, &shared.grp) != S3_OK) return dieJoin(s3_last_error());
+        shared.devices = devices;
+        shared.loaded = true;
+        printf("[Main] Finished copying index into device (GPU).\n");
+    } else devices = shared.devices;                                           // (later jobs of a list run on the devices the index is on)
+    s3_group *grp = shared.grp;
+    const int nMembers = (int)devices.size();
+    for (std::thread &t : preDpThreads) t.join();
+    for (const PreDp &x : preDp) if (!x.err.empty()) return dieJoin(x.err);
     const auto tAlign = std::chrono::steady_clock::now();
     // the first chunk goes back to the head of the queue: the members take their chunks from there
     if (chunk->n) { std::lock_guard<std::mutex> g(loaded.mu); loaded.q.push_front(std::move(chunk)); }
@@ -759,7 +796,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     std::vector<uint64_t> counters((size_t)nMembers * C_COUNTERS, 0);
     std::vector<double> memberDpSeconds((size_t)nMembers, 0);
     auto runMember = [&](int member) -> int {
-    const int device = s3_group_device(grp, member);
+    (void)s3_group_device;                                                      // (the DP aligners were made on dpDevices[member], the same device)
     s3_index *ix = s3_group_index(grp, member);
     const std::string fileNo = std::to_string(member + 1);
     double dpStageSeconds = 0;
@@ -806,29 +843,10 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         dpHdr.header();
         s3_dp_ini di{ini.dpScoreThreshold, ini.maxFrontLenClipped, ini.maxEndLenClipped};
         s3_dp_stage_parameters(S3_STAGE_SINGLE_DP, detectedReadLength, &di, &dpPar);      // getParameterForSingleDP on the detected length (alignment.cu:2580)
-        const int maxRL = (maxReadLength / 4 + 1) * 4, margin = maxReadLength > 100 ? maxReadLength >> 2 : 25, maxDNA = maxRL + 2 * margin + 8;   // DV-DPfunctions.cu:1580
-        int scheme = 1, tableLen = 0, patLen = 0;
-        // SemiGlobalAligner::decideConfiguration (DV-DPfunctions.cu:568-612) takes scheme 1 (one table over the whole window) whenever 64 blocks of full
-        // tables fit the device, which on 288 GB they always do.  S3DP_DP_SCHEME=2 asks for what the reference does on a device too small for that: scheme 2
-        // (score pass over the window, table of L + L/2 + 8 columns) wherever the window is at least three read lengths (coefConf[0]), scheme 1 elsewhere.
-        const int askScheme = getenv("S3DP_DP_SCHEME") && atoi(getenv("S3DP_DP_SCHEME")) == 2 ? 2 : 1;
-        auto wantScheme = [&](int rl, int dna) { return askScheme == 2 && dna >= rl * 3 ? 2 : 1; };
-        s3_dp_config(maxRL, maxDNA, wantScheme(maxRL, maxDNA), &scheme, &tableLen, &patLen);
-        s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
-        // problems per DP launch: the traceback tables of one launch stay under 8 GB (a device allocation costs about 20 ms per GB, twice per run; ten
-        // thousand problems fill the chip as well as thirty thousand do)
-        auto problems = [&](int rl, int tl) -> uint32_t {
-            const double perProblem = (double)((rl + 63) / 64) * (tl + 64) * 64 * 4;
-            const double n = 8e9 / perProblem;
-            return n >= 32768 ? 32768u : n < 256 ? 256u : (uint32_t)n;
-        };
-        if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &dp) != S3_OK) return dieJoin(s3_last_error());
+        dp = preDp[(size_t)member].dp;                                        // made while the index was loaded (above)
         if (s3_batch_create(ix, 262144 + 64, 8, &seedBatch) != S3_OK) return dieJoin(s3_last_error());
         if (paired) {
-            // default DP (half-aligned pairs): HalfEndAlignmentEngine::performAlignment sizes, DV-DPfunctions.cu:2221-2224
-            const int maxDNAHalf = insertHigh - insertLow + maxReadLength + 1;
-            s3_dp_config(maxRL, maxDNAHalf, wantScheme(maxRL, maxDNAHalf), &scheme, &tableLen, &patLen);
-            if (s3_dp_create(device, problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &dpHalf) != S3_OK) return dieJoin(s3_last_error());
+            dpHalf = preDp[(size_t)member].dpHalf;                            // default DP (half-aligned pairs)
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength, &di, &halfPar[0]);
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength2, &di, &halfPar[1]);
             for (int e = 0; e < 2; e++) {
