@@ -18,6 +18,10 @@ import time
 
 import numpy as np
 
+# the HIP runtime maps its streams onto four hardware queues unless told otherwise: batches in flight on their own streams then wait for each other
+# where no dependency exists (libs3dp.so asks for sixteen itself; here torch may bring the runtime up first)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "soap3-dp_amd", "py"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -846,14 +850,19 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
             if not ((ph == phase[first:first + m]).all() and (of.astype(np.int64) == (offs[first:first + m + 1].astype(np.int64) - lo)).all() and
                     (po == pos[lo:hi]).all() and (sr == strand[lo:hi]).all() and (mi == mis[lo:hi]).all()):
                 mism.append(first)
-        streamed = s3dp.stream_bench(ix, q, lens, wpq, a.mismatch, a.max_out, a.stream_batch, a.steps, depth=a.stream_depth, check=chk)
-        if mism:
-            raise SystemExit("bench.py: streamed results differ from the resident batch's (batches at reads %r)" % mism[:5])
-        streamed["same_results_as_resident"] = True
-        streamed["M_reads_per_s"] = sd.reduce_counters({"reads": int(streamed["reads"])}, device=dev)["reads"] / \
-            sd.max_over_ranks(streamed["seconds"], device=dev) / 1e6
-        streamed["vs_resident"] = streamed["M_reads_per_s"] / value
-        log("[%s] streamed: %.2f M reads/s (%.2f of resident)" % (label, streamed["M_reads_per_s"], streamed["vs_resident"]))
+        def one_stream(batch_reads, depth):
+            st = s3dp.stream_bench(ix, q, lens, wpq, a.mismatch, a.max_out, batch_reads, a.steps, depth=depth, check=chk)
+            if mism:
+                raise SystemExit("bench.py: streamed results differ from the resident batch's (batches at reads %r)" % mism[:5])
+            st["same_results_as_resident"] = True
+            st["M_reads_per_s"] = sd.reduce_counters({"reads": int(st["reads"])}, device=dev)["reads"] / sd.max_over_ranks(st["seconds"], device=dev) / 1e6
+            st["vs_resident"] = st["M_reads_per_s"] / value
+            log("[%s] streamed, %d reads per batch, %d in flight: %.2f M reads/s (%.2f of resident)" % (label, batch_reads, depth, st["M_reads_per_s"], st["vs_resident"]))
+            return st
+        streamed = one_stream(a.stream_batch, a.stream_depth)
+        if a.stream_batch != 1 << 20 and a.reads >= 4 << 20:
+            # the reference's own batch (1 Mi reads, SOAP3-DP.cu:394), which is also the command line's chunk: six batches in flight
+            streamed["batches_of_1Mi"] = one_stream(1 << 20, 6)
 
     # ---- roofline of the search (stepping kernel + check-and-extend kernel: the two halves of one search pass) ----------------
     # algorithmic bytes: SURVEY.md 8d's formula (strict), and the same extended by what the lookup tables and check-and-extend read: 16 B per lookup

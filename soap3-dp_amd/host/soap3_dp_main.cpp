@@ -868,7 +868,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     if (!paired && !enableDP) {
         s3_stream *st = nullptr;
         const uint32_t cap = chunk->n == chunkReads ? chunkReads : (chunk->n ? chunk->n : 1);
-        if (s3_stream_create(ix, cap, chunk->wpq, 3, &st) != S3_OK) return dieJoin(s3_last_error());
+        // six batches in flight (S3DP_STREAM_DEPTH): a batch of 1 Mi reads leaves the device idle between its launches and at their tails, the others fill in
+        const int streamDepth = getenv("S3DP_STREAM_DEPTH") && atoi(getenv("S3DP_STREAM_DEPTH")) > 0 ? atoi(getenv("S3DP_STREAM_DEPTH")) : 6;
+        if (s3_stream_create(ix, cap, chunk->wpq, streamDepth, &st) != S3_OK) return dieJoin(s3_last_error());
         mark("stream created");
         struct InFlight { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<ReadSet>> q; bool done = false; } fl;
         std::string werr;

@@ -56,6 +56,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise S3Error("libs3dp.so is not built (run `make -C soap3-dp_amd` or __graft_entry__.build())")
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # (see s3dp_api.hip: hardware queues for the streams of the batches in flight)
         L = C.CDLL(LIB_PATH)
         L.s3_last_error.restype = C.c_char_p
         L.s3_version.restype = C.c_char_p
