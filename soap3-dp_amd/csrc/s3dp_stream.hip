@@ -31,7 +31,7 @@ struct Slot {
     float deviceMs = 0;
     int rc = S3_OK;
     std::string err;
-    enum { FREE, ACQUIRED, QUEUED, DONE } state = FREE;
+    enum { FREE, ACQUIRED, QUEUED, DONE, UNBORN, FAILED } state = UNBORN;     // UNBORN: its buffers are still being made (s3_stream_create's helper thread)
     std::thread worker;
 };
 }  // namespace
@@ -45,6 +45,8 @@ struct s3_stream {
     uint64_t nextTicket = 0, nextResult = 0;      // tickets are handed out in submission order; results are returned in that order
     int acquired = -1;                            // slot handed to the caller by s3_stream_acquire and not yet submitted
     bool quit = false;
+    std::thread maker;                            // makes the slots behind the first one while the first batches are under way
+    std::string makerErr;
 };
 
 static int growOut(Slot &s, size_t need)
@@ -111,6 +113,7 @@ static void workerLoop(s3_stream *st, int k)
 extern "C" void s3_stream_free(s3_stream *st)
 {
     if (!st) return;
+    if (st->maker.joinable()) st->maker.join();
     {
         std::unique_lock<std::mutex> lk(st->mu);
         // let queued batches finish: their workers hold device work
@@ -136,20 +139,46 @@ extern "C" int s3_stream_create(s3_index *ix, uint32_t maxReads, uint32_t wordPe
     st->ix = ix; st->maxReads = maxReads; st->wpq = wordPerQuery;
     st->slots.resize((size_t)depth);
     const size_t roundUp = ((size_t)maxReads + 31) / 32 * 32;
-    for (Slot &s : st->slots) {
+    // a slot = a batch on the device + pinned staging on the host: 0.04 to 0.2 s each (pinning touches every page).  The first slot is made here; the
+    // others by a helper thread while the first batches are under way -- s3_stream_acquire waits for a slot that is not there yet as it waits for a busy one.
+    auto makeSlot = [ix, maxReads, wordPerQuery, depth, roundUp](Slot &s) -> int {
+        HIPCHK(hipSetDevice(ix->dev));
         int rc = s3_batch_create(ix, maxReads, wordPerQuery, &s.b);
-        if (rc) { s3_stream_free(st); return rc; }
+        if (rc) return rc;
         // the slots share the device: half-width search grids, so that the kernels of two batches are resident together (S3DP_STREAM_BLOCKS_PER_CU)
         if (depth > 1) s.b->blocksPerCu = (unsigned)envSize("S3DP_STREAM_BLOCKS_PER_CU", 2);
 #define PIN(p, bytes) do { hipError_t e_ = hipHostMalloc((void **)&(p), (bytes), hipHostMallocDefault); \
-        if (e_ != hipSuccess) { s3_stream_free(st); return fail(S3_ENOMEM, std::string("hipHostMalloc(stream staging): ") + hipGetErrorString(e_)); } } while (0)
+        if (e_ != hipSuccess) return fail(S3_ENOMEM, std::string("hipHostMalloc(stream staging): ") + hipGetErrorString(e_)); } while (0)
         PIN(s.hQueries, roundUp * wordPerQuery * 4); PIN(s.hLens, roundUp * 4); PIN(s.hSeedLens, roundUp * 4);
         PIN(s.hPhase, roundUp); PIN(s.hWithError, roundUp * 32); PIN(s.hOffsets, (roundUp + 1) * 4);
 #undef PIN
-        int rc2 = growOut(s, (size_t)maxReads * 4 + 65536);
-        if (rc2) { s3_stream_free(st); return rc2; }
+        return growOut(s, (size_t)maxReads * 4 + 65536);
+    };
+    {
+        const int rc = makeSlot(st->slots[0]);
+        if (rc) { const std::string keep = s3_last_error(); s3_stream_free(st); return fail(rc, keep); }
+        st->slots[0].state = Slot::FREE;
     }
     for (int k = 0; k < depth; k++) st->slots[(size_t)k].worker = std::thread(workerLoop, st, k);
+    if (depth > 1)
+        st->maker = std::thread([st, makeSlot, depth] {
+            for (int k = 1; k < depth; k++) {
+                Slot &s = st->slots[(size_t)k];
+                const int rc = makeSlot(s);
+                {
+                    std::lock_guard<std::mutex> g(st->mu);
+                    if (rc) { s.state = Slot::FAILED; s.rc = rc; st->makerErr = s3_last_error(); }
+                    else s.state = Slot::FREE;
+                }
+                st->cv.notify_all();
+                if (rc) {
+                    std::lock_guard<std::mutex> g(st->mu);
+                    for (int j = k + 1; j < depth; j++) { st->slots[(size_t)j].state = Slot::FAILED; st->slots[(size_t)j].rc = rc; }
+                    st->cv.notify_all();
+                    return;
+                }
+            }
+        });
     *outp = st;
     return S3_OK;
 }
@@ -162,7 +191,8 @@ extern "C" int s3_stream_acquire(s3_stream *st, uint32_t **queries, uint32_t **r
     // slots are used round-robin, so that results can be handed back in submission order without bookkeeping
     const int k = (int)(st->nextTicket % st->slots.size());
     Slot &s = st->slots[(size_t)k];
-    st->cv.wait(lk, [&] { return s.state == Slot::FREE; });
+    st->cv.wait(lk, [&] { return s.state == Slot::FREE || s.state == Slot::FAILED; });
+    if (s.state == Slot::FAILED) return fail(s.rc ? s.rc : S3_ENOMEM, "s3_stream_acquire: a slot of the stream could not be made: " + st->makerErr);
     s.state = Slot::ACQUIRED;
     st->acquired = k;
     *queries = s.hQueries; *readLengths = s.hLens;
