@@ -869,8 +869,10 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     if (!paired && !enableDP) {
         s3_stream *st = nullptr;
         const uint32_t cap = chunk->n == chunkReads ? chunkReads : (chunk->n ? chunk->n : 1);
-        // six batches in flight (S3DP_STREAM_DEPTH): a batch of 1 Mi reads leaves the device idle between its launches and at their tails, the others fill in
-        const int streamDepth = getenv("S3DP_STREAM_DEPTH") && atoi(getenv("S3DP_STREAM_DEPTH")) > 0 ? atoi(getenv("S3DP_STREAM_DEPTH")) : 6;
+        // three batches in flight (S3DP_STREAM_DEPTH).  The library alone runs 1 Mi-read batches faster six deep (0.85 of the resident rate against 0.75,
+        // bench.py's streamed figure); behind the loader and the formatter three are faster (20 M reads, repeat-rich genome: 1.6 s against 2.2; uniform:
+        // 0.87 against 1.1 -- profiles/r03_e2e_depth_queues.txt)
+        const int streamDepth = getenv("S3DP_STREAM_DEPTH") && atoi(getenv("S3DP_STREAM_DEPTH")) > 0 ? atoi(getenv("S3DP_STREAM_DEPTH")) : 3;
         if (s3_stream_create(ix, cap, chunk->wpq, streamDepth, &st) != S3_OK) return dieJoin(s3_last_error());
         mark("stream created");
         struct InFlight { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<ReadSet>> q; bool done = false; } fl;

@@ -1,0 +1,20 @@
+#!/bin/bash
+# single reads through the command line on one set of files: stream depth x hardware queues, two runs each (run through gpurun from the repository root)
+# tools/e2e_matrix.sh <genome_bp> <repeat_frac>
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+G=${1:-3100000000}; R=${2:-0.5}
+O=gpurun_out/r03k; mkdir -p $O
+W=/tmp/e2e_w; rm -rf $W
+python3 tools/bench_e2e.py --genome-bp $G --reads 20000000 --repeat-frac $R --workdir $W > $O/e2e_base_$R.json 2> $O/e2e_base_$R.log
+run() {
+  local tag=$1; shift
+  for k in 1 2; do
+    rm -f $W/out.gout.1
+    env "$@" soap3-dp_amd/soap3-dp single $W/g.index $W/reads.fq -L 100 -s 4 -b 2 -o $W/out 2>&1 | grep "Alignment + output" | sed "s/^/$tag run $k: /"
+  done
+}
+run d3_q4 S3DP_STREAM_DEPTH=3 GPU_MAX_HW_QUEUES=4
+run d3_q16 S3DP_STREAM_DEPTH=3 GPU_MAX_HW_QUEUES=16
+run d4_q16 S3DP_STREAM_DEPTH=4 GPU_MAX_HW_QUEUES=16
+run d6_q16 S3DP_STREAM_DEPTH=6 GPU_MAX_HW_QUEUES=16
+run d6_q4 S3DP_STREAM_DEPTH=6 GPU_MAX_HW_QUEUES=4
