@@ -328,7 +328,13 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         for (const s3_occ &x : v) if (x.mismatchCount <= mn + (mapqMode ? 1 : 0)) v[w++] = x;
         v.resize(w);
     };
-    std::vector<std::vector<s3_occ>> kept(c.cnt);                                // keepSoap3Results: what the BWT stage leaves of a read for the later stages
+    // keepSoap3Results: what the BWT stage leaves of a read for the later stages.  Lists exist for the ends of the pairs without a proper pairing only (a
+    // tenth of a chunk): a vector per READ of the chunk was 2 Mi constructors and destructors per chunk, a fifth of a second per ten million pairs
+    std::vector<uint32_t> keptSlot(np, 0xFFFFFFFFu);
+    uint32_t nUnpaired = 0;
+    for (uint32_t p = 0; p < np; p++) if (!pr[p].phase) keptSlot[p] = nUnpaired++;
+    std::vector<std::vector<s3_occ>> keptLists((size_t)2 * nUnpaired);
+    auto kept = [&](uint32_t r) -> std::vector<s3_occ> & { return keptLists[(size_t)2 * keptSlot[r >> 1] + (r & 1u)]; };
     {
         // the pairs are routed by all host threads, a contiguous range of pairs each, and the ranges' lists joined in pair order (a pair inside a repeat
         // family brings thousands of hits per end: the loop moves tens of millions of entries per chunk)
@@ -349,7 +355,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
                     const int e = n1 ? 0 : 1;
                     endHits(e ? r2 : r1, true, h1);
                     if (h1.size() > maxHit[e]) retainBest(h1);
-                    kept[e ? r2 : r1] = h1;
+                    kept(e ? r2 : r1) = h1;
                     if (h1.size() <= maxHit[e]) { P.dp.insert(P.dp.end(), h1.begin(), h1.end()); inDefault[p] = 1; }
                     else P.nw.insert(P.nw.end(), h1.begin(), h1.end());
                     continue;
@@ -357,7 +363,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
                 endHits(r1, false, h1); endHits(r2, false, h2);
                 if (h1.size() > maxHit[0]) retainBest(h1);
                 if (h2.size() > maxHit[1]) retainBest(h2);
-                kept[r1] = h1; kept[r2] = h2;
+                kept(r1) = h1; kept(r2) = h2;
                 if (h1.size() <= maxHit[0] && h2.size() <= maxHit[1]) { P.dp.insert(P.dp.end(), h1.begin(), h1.end()); P.dp.insert(P.dp.end(), h2.begin(), h2.end()); inDefault[p] = 1; }
                 else if (h1.size() < h2.size()) {
                     if (h1.size() <= maxHit[0]) { P.dp.insert(P.dp.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else P.nw.insert(P.nw.end(), h1.begin(), h1.end());
@@ -551,28 +557,31 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
     for (uint32_t r1 : deepPairs) if (!deepDone[r1 / 2]) left.push_back(r1);
     std::vector<uint8_t> viaDP(c.cnt, 0);
     for (uint32_t r1 : left) {
-        const bool no1 = kept[r1].empty(), no2 = kept[r1 + 1].empty();
+        const bool no1 = kept(r1).empty(), no2 = kept(r1 + 1).empty();
         if (no1) { viaDP[r1] = 1; todo.push_back(r1); }
         if (no2 || !no1) { viaDP[r1 + 1] = 1; todo.push_back(r1 + 1); }
     }
-    std::vector<std::vector<DpHit>> own(c.cnt);
+    std::vector<uint32_t> leftSlot(np, 0xFFFFFFFFu);                             // (likewise: lists for the ends of the leftover pairs only)
+    for (size_t lk = 0; lk < left.size(); lk++) leftSlot[left[lk] >> 1] = (uint32_t)lk;
+    std::vector<std::vector<DpHit>> ownLists(2 * left.size());
+    auto own = [&](uint32_t r) -> std::vector<DpHit> & { return ownLists[(size_t)2 * leftSlot[r >> 1] + (r & 1u)]; };
     // a read with DP hits on both strands reaches the reference's store as two entries and breaks its pairing by position in the list
     // (outputSingleResultForPairEnds :1106-1112 prints an error); here the two runs are one list
     if (!singleDpRuns(c.hix, c.so, nullptr, c.b, c.seedBatch, c.dp, lens, todo, c.singlePar, moduleType, [&](SamWriter &, uint32_t k, std::vector<DpHit> &hits) {
-            own[k].insert(own[k].end(), hits.begin(), hits.end());
+            own(k).insert(own(k).end(), hits.begin(), hits.end());
         }, err)) return false;
     parallelFormat(c.hix, c.so, c.unpairOut, (uint32_t)left.size(), [&](SamWriter &up, uint32_t lk, uint64_t &al) {
         const uint32_t r1 = left[lk];
         for (uint32_t r = r1; r < r1 + 2; r++) {
             if (viaDP[r]) continue;
             const int L = (int)lens[r];
-            for (const s3_occ &x : kept[r]) {                                      // inputSoap3AnsToArray, PEAlgnmt.cpp:1180
+            for (const s3_occ &x : kept(r)) {                                      // inputSoap3AnsToArray, PEAlgnmt.cpp:1180
                 DpHit h{x.pos, x.strand, L * c.so.dpMatchScore + (int)x.mismatchCount * c.so.dpMismatchScore, (int)x.mismatchCount, std::to_string(L) + "M"};
                 h.fromDP = false;
-                own[r].push_back(h);
+                own(r).push_back(h);
             }
         }
-        up.unpairedDP(c.rs, c.first + r1, own[r1].data(), own[r1].size(), own[r1 + 1].data(), own[r1 + 1].size(), c.singlePar.cutoffThreshold);
+        up.unpairedDP(c.rs, c.first + r1, own(r1).data(), own(r1).size(), own(r1 + 1).data(), own(r1 + 1).size(), c.singlePar.cutoffThreshold);
         al++;
     }, leftoverPairs);
     lap(4);
