@@ -887,7 +887,6 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         struct InFlight { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<ReadSet>> q; bool done = false; } fl;
         std::string werr;
         std::thread writer([&] {
-            RawVec<uint32_t> keepOffsets, keepPos, keepMeta;
             for (;;) {
                 std::unique_ptr<ReadSet> rsP;
                 {
@@ -905,26 +904,6 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 const uint32_t cnt = res.n;
                 addStreamSeconds(3, since(tN));
                 const auto tFm = std::chrono::steady_clock::now();
-                // the occurrence lists are copied out of the slot's staging and the slot is given back BEFORE the records are formatted: a slot that waits
-                // for the formatter is a batch less on the device (three slots, one of them always waiting here: the device ran two batches deep)
-                {
-                    const size_t nOccHere = res.occOffsets[cnt];
-                    keepOffsets.resize((size_t)cnt + 1); keepPos.resize(nOccHere ? nOccHere : 1); keepMeta.resize(nOccHere ? nOccHere : 1);
-                    const int T = hostThreads();
-                    std::vector<std::thread> cp;
-                    for (int t = 0; t < T; t++) cp.emplace_back([&, t] {
-                        auto part = [&](const uint32_t *src, uint32_t *dst, size_t n) {
-                            const size_t lo = n * (size_t)t / (size_t)T, hi = n * (size_t)(t + 1) / (size_t)T;
-                            if (hi > lo) memcpy(dst + lo, src + lo, (hi - lo) * 4);
-                        };
-                        part(res.occOffsets, keepOffsets.data(), (size_t)cnt + 1);
-                        part(res.occPos, keepPos.data(), nOccHere);
-                        part(res.occMeta, keepMeta.data(), nOccHere);
-                    });
-                    for (auto &x : cp) x.join();
-                    res.occOffsets = keepOffsets.data(); res.occPos = keepPos.data(); res.occMeta = keepMeta.data();
-                    if (s3_stream_release(st) != S3_OK) { fprintf(stderr, "%s\n", s3_last_error()); fflush(stderr); _exit(1); }
-                }
                 parallelFormat(hix, so, out, cnt, [&](SamWriter &w, uint32_t k, uint64_t &al) {
                     const size_t o = res.occOffsets[k], m = res.occOffsets[k + 1] - res.occOffsets[k];
                     uint8_t sbuf[64], mbuf[64];
@@ -942,6 +921,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                     w.singleEnd(rs, k, res.occPos + o, sp, mp, m, maxReadLength > 120 ? (rs.lengths[k] > 120 ? 100u : rs.lengths[k]) : 0u);
                 }, aligned);
                 addStreamSeconds(4, since(tFm));
+                if (s3_stream_release(st) != S3_OK) { fprintf(stderr, "%s\n", s3_last_error()); fflush(stderr); _exit(1); }
                 recycle(std::move(rsP));
             }
         });
