@@ -903,6 +903,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 if (s3_stream_next(st, &res) != S3_OK) { werr = s3_last_error(); fprintf(stderr, "%s\n", werr.c_str()); fflush(stderr); _exit(1); }
                 const uint32_t cnt = res.n;
                 addStreamSeconds(3, since(tN));
+                if (res.batch) addBatchTiming(res.batch);                       // (device time of the batch's ladder: batches in flight share the device, the sum is above the wall clock)
                 const auto tFm = std::chrono::steady_clock::now();
                 parallelFormat(hix, so, out, cnt, [&](SamWriter &w, uint32_t k, uint64_t &al) {
                     const size_t o = res.occOffsets[k], m = res.occOffsets[k + 1] - res.occOffsets[k];

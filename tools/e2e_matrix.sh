@@ -10,9 +10,13 @@ run() {
   local tag=$1; shift
   for k in 1 2; do
     rm -f $W/out.gout.1
-    env "$@" soap3-dp_amd/soap3-dp single $W/g.index $W/reads.fq -L 100 -s 4 -b 2 -o $W/out 2>&1 | grep "Alignment + output" | sed "s/^/$tag run $k: /"
+    env "$@" soap3-dp_amd/soap3-dp single $W/g.index $W/reads.fq -L 100 -s 4 -b 2 -o $W/out 2>&1 | grep "Alignment + output\|Device time\|Stream loop" | sed "s/^/$tag run $k: /"
   done
 }
+if [ -n "$3" ]; then
+  for t in $3; do run threads$t S3DP_HOST_THREADS=$t; done
+  exit 0
+fi
 run d3_q4 S3DP_STREAM_DEPTH=3 GPU_MAX_HW_QUEUES=4
 run d3_q16 S3DP_STREAM_DEPTH=3 GPU_MAX_HW_QUEUES=16
 run d4_q16 S3DP_STREAM_DEPTH=4 GPU_MAX_HW_QUEUES=16
