@@ -292,7 +292,9 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     b->ix = ix; b->maxReads = maxReads; b->wpq = wordPerQuery;
     const size_t roundUp = ((size_t)maxReads + 31) / 32 * 32;
     b->maxItems = (size_t)maxReads * 20;                               // 10 cases x 2 strands at 4 mismatches
-    const size_t recPerRead = envSize("S3DP_REC_PER_READ", 6), occPerRead = envSize("S3DP_OCC_PER_READ", 12);
+    // (32 record slots and 40 occurrences per read to begin with: a repeat-rich genome needs about that, and a batch that outgrows its buffers in the middle
+    //  of a run pays a hipMalloc + hipFree -- a device-wide synchronisation -- and the repeat of its pass; 0.9 GB per 1 Mi reads is nothing of 288 GB)
+    const size_t recPerRead = envSize("S3DP_REC_PER_READ", 32), occPerRead = envSize("S3DP_OCC_PER_READ", 40);
     // every wave of the persistent search grid may hold one partly filled block of record slots: that is the floor.  Both buffers
     // grow on demand (growRecords / growOccurrences); the sizes here only avoid regrowth in the common case.
     const size_t recFloor = envSize("S3DP_REC_FLOOR", 65536 + (size_t)S3_V2_REC_BLOCK * 8192);

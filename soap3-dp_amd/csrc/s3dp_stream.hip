@@ -152,7 +152,9 @@ extern "C" int s3_stream_create(s3_index *ix, uint32_t maxReads, uint32_t wordPe
         PIN(s.hQueries, roundUp * wordPerQuery * 4); PIN(s.hLens, roundUp * 4); PIN(s.hSeedLens, roundUp * 4);
         PIN(s.hPhase, roundUp); PIN(s.hWithError, roundUp * 32); PIN(s.hOffsets, (roundUp + 1) * 4);
 #undef PIN
-        return growOut(s, (size_t)maxReads * 4 + 65536);
+        // pinned space for the occurrence lists: S3DP_STREAM_OCC_PER_READ entries per read to begin with (default 4; pinning more up front was measured slower than growing); a list that outgrows it costs a
+        // hipHostFree + hipHostMalloc of twice the size in the middle of a run (pinning touches every page: tens of milliseconds per 100 MB)
+        return growOut(s, (size_t)maxReads * envSize("S3DP_STREAM_OCC_PER_READ", 4) + 65536);
     };
     {
         const int rc = makeSlot(st->slots[0]);

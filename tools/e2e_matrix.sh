@@ -13,6 +13,13 @@ run() {
     env "$@" soap3-dp_amd/soap3-dp single $W/g.index $W/reads.fq -L 100 -s 4 -b 2 -o $W/out 2>&1 | grep "Alignment + output\|Device time\|Stream loop" | sed "s/^/$tag run $k: /"
   done
 }
+if [ "$3" = "buffers" ]; then
+  run default A=1
+  run big S3DP_REC_PER_READ=64 S3DP_OCC_PER_READ=48
+  run pinned40 S3DP_STREAM_OCC_PER_READ=40
+  run pinned40_big S3DP_STREAM_OCC_PER_READ=40 S3DP_REC_PER_READ=64 S3DP_OCC_PER_READ=48
+  exit 0
+fi
 if [ -n "$3" ]; then
   for t in $3; do run threads$t S3DP_HOST_THREADS=$t; done
   exit 0
