@@ -36,7 +36,10 @@ if want dp; then      # DP kernel: GCUPS, kernel stats, counters on 4096 problem
   timeout 600 python3 tools/bench_dp.py > $OUT/dp_gcups.jsonl 2> $OUT/dp_gcups.log; echo "dp rc=$?"; cat $OUT/dp_gcups.jsonl | cut -c1-220
   rm -rf /tmp/prof_dp
   S3DP_BENCH_DP_PROBLEMS=4096 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/prof_dp -o dp -- python3 tools/bench_dp.py > /dev/null 2> $OUT/dp_pmc_sq.log
-  f=$(find /tmp/prof_dp -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 tools/pmc_summary.py "$f" dpFillKernel > $OUT/dp_pmc_sq.txt && tail -3 $OUT/dp_pmc_sq.txt
+  f=$(find /tmp/prof_dp -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 tools/pmc_summary.py "$f" dpFill > $OUT/dp_pmc_sq.txt && tail -3 $OUT/dp_pmc_sq.txt
+  rm -rf /tmp/prof_dp2
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dp2 -o dp -- python3 tools/bench_dp.py > /dev/null 2> $OUT/dp_stats.log
+  f=$(find /tmp/prof_dp2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/dp_kernel_stats.csv && head -6 $OUT/dp_kernel_stats.csv | cut -c1-60,100-200
   # (WRITE_SIZE and FETCH_SIZE do not fit one pass -- 2 + 3 of the 4 TCC slots: rocprofv3 aborts; the table traffic is algorithmic: 2.125 B per cell)
 fi
 if want e2e; then     # the command line, FASTQ in -> SAM out, GRCh38 scale: uniform genome (round 1's workload), repeat-rich genome, two members on one GPU
