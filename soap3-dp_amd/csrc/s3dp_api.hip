@@ -7,6 +7,8 @@
 #include "s3dp_internal.h"
 
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 using namespace s3;
 using namespace s3i;
 
@@ -19,6 +21,89 @@ int s3i::fail(int code, const std::string &msg) { g_err = msg; return code; }
 // The variable is read when the runtime comes up, i.e. at the first HIP call: asking for it when this library is loaded is early enough unless the host
 // process used HIP before (then it had its chance to set it).  A value the user set is left alone.
 __attribute__((constructor)) static void s3dpRuntimeDefaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
+// ---- scratch cache of the DP / seeding engines (s3dp_internal.h) -------------------------------------------------------------------------------------
+namespace {
+struct ScratchBlock { void *p; size_t bytes; hipStream_t lastStream; int device; };
+struct ScratchCache {
+    std::mutex mu;
+    std::vector<ScratchBlock> freeBlocks;                      // cached, by device
+    std::map<void *, ScratchBlock> live;                       // handed out
+    size_t cachedBytes = 0;
+} g_scratch;
+size_t scratchClass(size_t bytes) { size_t c = 65536; while (c < bytes) c <<= 1; return c; }
+}  // namespace
+
+hipError_t s3i::scratchAlloc(void **p, size_t bytes, hipStream_t stream)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const size_t want = scratchClass(bytes ? bytes : 1);
+    ScratchBlock got{nullptr, 0, nullptr, dev};
+    {
+        std::lock_guard<std::mutex> g(g_scratch.mu);
+        for (size_t i = 0; i < g_scratch.freeBlocks.size(); i++) {
+            const ScratchBlock &b = g_scratch.freeBlocks[i];
+            if (b.device == dev && b.bytes == want) { got = b; g_scratch.freeBlocks.erase(g_scratch.freeBlocks.begin() + (long)i); g_scratch.cachedBytes -= want; break; }
+        }
+    }
+    if (got.p) {
+        if (got.lastStream && got.lastStream != stream && (e = hipStreamSynchronize(got.lastStream)) != hipSuccess) return e;
+    } else {
+        if ((e = hipMalloc(&got.p, want)) != hipSuccess) {
+            s3i::scratchTrim(dev);                              // the cache may hold what is missing
+            if ((e = hipMalloc(&got.p, want)) != hipSuccess) return e;
+        }
+        got.bytes = want;
+    }
+    got.lastStream = stream;
+    {
+        std::lock_guard<std::mutex> g(g_scratch.mu);
+        g_scratch.live[got.p] = got;
+    }
+    *p = got.p;
+    return hipSuccess;
+}
+
+void s3i::scratchFree(void *p, hipStream_t stream)
+{
+    if (!p) return;
+    ScratchBlock b{nullptr, 0, nullptr, 0};
+    bool giveBack = false;
+    {
+        std::lock_guard<std::mutex> g(g_scratch.mu);
+        auto it = g_scratch.live.find(p);
+        if (it == g_scratch.live.end()) giveBack = true;        // not ours: plain hipMalloc memory
+        else {
+            b = it->second;
+            g_scratch.live.erase(it);
+            b.lastStream = stream;
+            if (g_scratch.cachedBytes + b.bytes > ((size_t)8 << 30)) giveBack = true;
+            else { g_scratch.freeBlocks.push_back(b); g_scratch.cachedBytes += b.bytes; }
+        }
+    }
+    if (giveBack) (void)hipFree(p);
+}
+
+void s3i::scratchStreamGone(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> g(g_scratch.mu);
+    for (ScratchBlock &b : g_scratch.freeBlocks) if (b.lastStream == stream) b.lastStream = nullptr;
+}
+
+void s3i::scratchTrim(int device)
+{
+    std::vector<ScratchBlock> mine;
+    {
+        std::lock_guard<std::mutex> g(g_scratch.mu);
+        for (size_t i = 0; i < g_scratch.freeBlocks.size();) {
+            if (g_scratch.freeBlocks[i].device == device) { mine.push_back(g_scratch.freeBlocks[i]); g_scratch.cachedBytes -= g_scratch.freeBlocks[i].bytes; g_scratch.freeBlocks.erase(g_scratch.freeBlocks.begin() + (long)i); }
+            else i++;
+        }
+    }
+    for (const ScratchBlock &b : mine) (void)hipFree(b.p);
+}
 
 namespace {
 struct U32ToU64 { __host__ __device__ unsigned long long operator()(const uint32_t &x) const { return (unsigned long long)x; } };
@@ -233,6 +318,7 @@ extern "C" void s3_index_free(s3_index *ix)
 {
     if (!ix) return;
     (void)hipSetDevice(ix->dev);
+    s3i::scratchTrim(ix->dev);
     for (void *p : ix->allocs) (void)hipFree(p);
     delete ix;
 }
@@ -353,7 +439,7 @@ extern "C" void s3_batch_free(s3_batch *b)
 {
     if (!b) return;
     (void)hipSetDevice(b->ix->dev);
-    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); s3i::scratchStreamGone(b->stream); }
     for (void *p : b->allocs) (void)hipFree(p);
     for (auto e : b->evSearch) if (e) (void)hipEventDestroy(e);
     for (auto e : b->evCe) if (e) (void)hipEventDestroy(e);

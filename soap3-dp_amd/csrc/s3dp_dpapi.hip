@@ -29,7 +29,7 @@ extern "C" void s3_dp_free(s3_dp *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->dev);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); scratchStreamGone(h->stream); }
     for (void *p : h->allocs) (void)hipFree(p);
     for (auto e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -518,7 +518,7 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
     };
     {
         void *q = nullptr;
-        hipError_t e = hipMalloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64);
+        hipError_t e = scratchAlloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64, h->stream);
         if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp candidates): ") + hipGetErrorString(e));
         dCand = (DpCand *)q;
     }
@@ -560,7 +560,7 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
         if (cand.size() + 1 > h->maxProblems) rc = flush();
     }
     if (rc == S3_OK) rc = flush();
-    (void)hipFree(dCand);
+    scratchFree(dCand, h->stream);
     if (rc) return rc;
     s3_dp_half_result *out = (s3_dp_half_result *)malloc(results.size() * sizeof(s3_dp_half_result) + 1);
     char *cp = (char *)malloc(pool.size() + 1);
@@ -587,7 +587,7 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
     DpCand *dCand = nullptr;
     {
         void *q = nullptr;
-        hipError_t e = hipMalloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64);
+        hipError_t e = scratchAlloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64, h->stream);
         if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp candidates): ") + hipGetErrorString(e));
         dCand = (DpCand *)q;
     }
@@ -614,7 +614,7 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
         }
         if (rc) break;
         hipStream_t s = h->stream;
-#define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipFree(dCand); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+#define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { scratchFree(dCand, h->stream); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
         ECHK(hipMemcpyAsync(dCand, cand.data(), (size_t)n * sizeof(DpCand), hipMemcpyHostToDevice, s));
         ECHK(hipMemcpyAsync(h->dDnaLen, dnaLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         ECHK(hipMemcpyAsync(h->dReadLen, rdLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
@@ -651,7 +651,7 @@ extern "C" int s3_dp_single_end(s3_dp *h, s3_batch *b, const uint32_t *readLengt
             results.push_back(r);
         }, [](s3_dp_single_result &r, uint32_t base) { r.cigarOffset += base; });
     }
-    (void)hipFree(dCand);
+    scratchFree(dCand, h->stream);
     if (rc) return rc;
     s3_dp_single_result *out = (s3_dp_single_result *)malloc(results.size() * sizeof(s3_dp_single_result) + 1);
     char *cp = (char *)malloc(pool.size() + 1);
@@ -767,12 +767,12 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
         for (size_t k = 0; k < nPairs; k++)
             for (; j < seeds.size() && (seeds[j].keyHi & 0x3FFFFFFFu) == pairFirstReads[k]; j++) if (status[j] == 4) tooMany[k] = 1;
     }
-    for (size_t i = 0; i < nGiven; i++) if (given[i].strand < 1 || given[i].strand > 2) { (void)hipFree(dKeys); return fail(S3_EINVAL, "s3_dp_new_default: bad strand"); }
+    for (size_t i = 0; i < nGiven; i++) if (given[i].strand < 1 || given[i].strand > 2) { scratchFree(dKeys, seedBatch->stream); return fail(S3_EINVAL, "s3_dp_new_default: bad strand"); }
     // ---- pairEndMerge on the device (s3dp_seed.hip): the positions never come to the host; the candidates do, ordered by the left read --------------------
     std::vector<PairCandHost> candsDev;
     std::vector<uint32_t> perPair;
     rc = pairMergeOnDevice(b, dKeys, nKeys, given, nGiven, pairFirstReads, nPairs, insertLow, insertHigh, candsDev, perPair);
-    (void)hipFree(dKeys);
+    scratchFree(dKeys, seedBatch->stream);
     if (rc) return rc;
     std::vector<PairCand> cands(candsDev.size());
     for (size_t i = 0; i < candsDev.size(); i++) cands[i] = PairCand{{candsDev[i].pos[0], candsDev[i].pos[1]}, candsDev[i].readIDLeft};
@@ -789,11 +789,11 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
     DpCand *dCand = nullptr;
     {
         void *q = nullptr;
-        hipError_t e = hipMalloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64);
+        hipError_t e = scratchAlloc(&q, (size_t)h->maxProblems * sizeof(DpCand) + 64, h->stream);
         if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp candidates): ") + hipGetErrorString(e));
         dCand = (DpCand *)q;
     }
-#define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipFree(dCand); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+#define ECHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { scratchFree(dCand, h->stream); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
     struct Round { std::vector<int32_t> scores; std::vector<uint32_t> hit, cnt; std::vector<uint8_t> pat; uint32_t pitch = 0; };
     auto runRound = [&](const std::vector<DpCand> &cand, const std::vector<uint32_t> &dnaLens, const std::vector<uint32_t> &rdLens, const std::vector<int32_t> &cut,
                         const std::vector<uint32_t> &clipLt, const std::vector<uint32_t> &clipRt, const std::vector<uint32_t> &aL, const std::vector<uint32_t> &aR,
@@ -912,7 +912,7 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
         lap(4);
     }
 #undef ECHK
-    (void)hipFree(dCand);
+    scratchFree(dCand, h->stream);
     if (rc) return rc;
     s3_dp_deep_result *out = (s3_dp_deep_result *)malloc(results.size() * sizeof(s3_dp_deep_result) + 1);
     char *cp = (char *)malloc(pool.size() + 1);

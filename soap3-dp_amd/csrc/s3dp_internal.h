@@ -19,6 +19,16 @@ inline hipError_t d2h(void *dst, const void *src, size_t bytes, hipStream_t s)
     return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
 int fail(int code, const std::string &msg);               // records the message for s3_last_error and returns `code`
+
+// Scratch memory of the DP and seeding engines.  Every engine call needs a dozen device buffers whose sizes depend on its input; hipMalloc costs tens of
+// microseconds, hipFree a DEVICE-WIDE synchronisation -- forty of each per chunk of pairs, on a thread that runs beside another chunk's search.  scratchAlloc
+// hands out blocks of a per-device cache (sizes rounded up to powers of two from 64 KB), scratchFree puts them back; nothing is given to the driver until the
+// cache holds more than 8 GB or the index of the device is freed (scratchTrim).  A block comes back with the stream it was last used on: whoever takes it for
+// another stream waits for that stream first -- what hipFree's synchronisation used to guarantee.
+hipError_t scratchAlloc(void **p, size_t bytes, hipStream_t stream);
+void scratchFree(void *p, hipStream_t stream);
+void scratchTrim(int device);
+void scratchStreamGone(hipStream_t stream);               // the owner of `stream` has synchronised it and is about to destroy it: cached blocks forget it
 }
 #define HIPCHK(x)                                                                                          \
     do {                                                                                                   \

@@ -141,7 +141,7 @@ __global__ void givenKeysKernel(const s3_occ *occ, uint32_t n, uint64_t *keys)
 }
 
 // Search the seeds and return their hits as sorted 64-bit keys: (keyHi | strand bit) << 32 | estimated read position.  devKeysOut != NULL: the sorted keys
-// stay on the device (the caller frees *devKeysOut with hipFree) and keysOut stays empty.
+// stay on the device (the caller gives *devKeysOut back with scratchFree) and keysOut stays empty.
 int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<SeedDesc> &seeds, uint32_t maxHitNum, uint32_t strandBit,
                         std::vector<uint64_t> &keysOut, std::vector<uint8_t> &statusOut, uint64_t **devKeysOut, uint32_t *nKeysOut)
 {
@@ -157,12 +157,12 @@ int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<
     char *dSortTmp = nullptr;
     std::vector<void *> tmp;
     auto talloc = [&](void **p, size_t bytes) -> int {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        hipError_t e = scratchAlloc(p, bytes ? bytes : 16, st);
         if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(seeding): ") + hipGetErrorString(e));
         tmp.push_back(*p);
         return S3_OK;
     };
-    auto cleanup = [&]() { for (void *p : tmp) if (p) (void)hipFree(p); };
+    auto cleanup = [&]() { for (void *p : tmp) if (p) scratchFree(p, st); };
     int rc;
     if ((rc = talloc((void **)&dSeeds, (size_t)nSeeds * sizeof(SeedDesc))) || (rc = talloc((void **)&dRetry, nSeeds)) || (rc = talloc((void **)&dStatus, nSeeds))) { cleanup(); return rc; }
 #define SCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -252,9 +252,9 @@ int s3i::pairMergeOnDevice(s3_batch *b, uint64_t *dKeys, uint32_t nKeys, const s
     perPair.assign(nPairs, 0);
     hipStream_t st = b->stream;
     std::vector<void *> tmp;
-    auto cleanup = [&]() { for (void *p : tmp) if (p) (void)hipFree(p); };
+    auto cleanup = [&]() { for (void *p : tmp) if (p) scratchFree(p, st); };
     auto talloc = [&](void **p, size_t bytes) -> int {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        hipError_t e = scratchAlloc(p, bytes ? bytes : 16, st);
         if (e != hipSuccess) { cleanup(); return fail(S3_ENOMEM, std::string("hipMalloc(pair merge): ") + hipGetErrorString(e)); }
         tmp.push_back(*p);
         return S3_OK;
@@ -356,12 +356,12 @@ extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const ui
         s3_seed_candidate *dOut = nullptr;
         char *dTmp = nullptr;
         size_t tb = 0;
-        auto freeAll = [&]() { (void)hipFree(dKeys); (void)hipFree(dCounts); (void)hipFree(dOffsets); (void)hipFree(dOut); (void)hipFree(dTmp); };
+        auto freeAll = [&]() { scratchFree(dKeys, st); scratchFree(dCounts, st); scratchFree(dOffsets, st); scratchFree(dOut, st); scratchFree(dTmp, st); };
 #define MCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { freeAll(); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
-        MCHK(hipMalloc((void **)&dCounts, ((size_t)nKeys + 1) * 4));
-        MCHK(hipMalloc((void **)&dOffsets, ((size_t)nKeys + 1) * 4));
+        MCHK(scratchAlloc((void **)&dCounts, ((size_t)nKeys + 1) * 4, st));
+        MCHK(scratchAlloc((void **)&dOffsets, ((size_t)nKeys + 1) * 4, st));
         MCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, dCounts, dOffsets, (int)(nKeys + 1), st));
-        MCHK(hipMalloc((void **)&dTmp, tb + 16));
+        MCHK(scratchAlloc((void **)&dTmp, tb + 16, st));
         MCHK(hipMemsetAsync(dCounts + nKeys, 0, 4, st));
         hipLaunchKernelGGL(singleMergeKernel, dim3((nKeys + 255) / 256), dim3(256), 0, st, dKeys, nKeys, nullptr, dCounts, (s3_seed_candidate *)nullptr);
         MCHK(hipcub::DeviceScan::ExclusiveSum(dTmp, tb, dCounts, dOffsets, (int)(nKeys + 1), st));
@@ -369,7 +369,7 @@ extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const ui
         MCHK(hipMemcpyAsync(&total, dOffsets + nKeys, 4, hipMemcpyDeviceToHost, st));
         MCHK(hipStreamSynchronize(st));
         if (total) {
-            MCHK(hipMalloc((void **)&dOut, (size_t)total * sizeof(s3_seed_candidate)));
+            MCHK(scratchAlloc((void **)&dOut, (size_t)total * sizeof(s3_seed_candidate), st));
             hipLaunchKernelGGL(singleMergeKernel, dim3((nKeys + 255) / 256), dim3(256), 0, st, dKeys, nKeys, dOffsets, dCounts, dOut);
             out.resize(total);
             MCHK(hipMemcpyAsync(out.data(), dOut, (size_t)total * sizeof(s3_seed_candidate), hipMemcpyDeviceToHost, st));
