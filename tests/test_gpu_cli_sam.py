@@ -64,6 +64,10 @@ PROCESS_KNOBS = [
     {"S3DP_STREAM_BLOCKS_PER_CU": "1", "S3DP_CHUNK_READS": "192"},    # grid widths of the batches that share the device
     {"S3DP_STREAM_BLOCKS_PER_CU": "8", "S3DP_CHUNK_READS": "192"},
     {"S3DP_HOST_THREADS": "1", "S3DP_CHUNK_READS": "192"},
+    {"S3DP_STREAM_DEPTH": "1", "S3DP_CHUNK_READS": "192"},            # batches in flight
+    {"S3DP_STREAM_DEPTH": "6", "S3DP_CHUNK_READS": "192"},
+    {"GPU_MAX_HW_QUEUES": "2", "S3DP_CHUNK_READS": "192"},            # the HIP runtime's variable (the library asks for 16 unless it is set)
+    {"S3DP_GENERIC_PARSER": "1"},                                     # every record through the general parser
 ]
 
 

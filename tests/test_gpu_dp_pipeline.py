@@ -71,6 +71,8 @@ CASES = [
     ("g7_h2p", "g7", "h2p", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2", "-p"]),
     # the small-device decision of SemiGlobalAligner::decideConfiguration (scheme 2 on the 650-column windows of the default DP; S3DP_DP_SCHEME=2)
     ("g7_h2_scheme2", "g7", "h2s2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]),
+    # the same run with one DP problem per wavefront (S3DP_DP_PAIRED=0): the paired fill kernel and the one-problem kernel write the same tables
+    ("g7_h2_unpaired_dp", "g7", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]),
     ("g7_h1", "g7", "h1", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2", "-h", "1"]),
     ("g7_h3", "g7", "h3", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2", "-h", "3"]),
     ("g7_h4", "g7", "h4", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2", "-h", "4"]),
@@ -96,6 +98,8 @@ def test_dp_pipeline_matches_the_reference_engines(tmp_path, case, gdir, tag, mo
         shutil.copy(os.path.join(GOLDEN, gdir, r), tmp_path / n)
         names.append(n)
     env = dict(os.environ, S3DP_DUMP_DP=str(tmp_path / "problems.txt"))
+    if case.endswith("_unpaired_dp"):
+        env["S3DP_DP_PAIRED"] = "0"
     if case.endswith("_scheme2"):
         env["S3DP_DP_SCHEME"] = "2"
     if case.endswith("_chunked"):

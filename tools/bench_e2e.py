@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--devices", default="", help="-c argument of the command line (e.g. 0,0: two members on one GPU)")
     ap.add_argument("--bam", type=int, default=0, help="single reads: -b 3 (BAM output) instead of -b 2")
     ap.add_argument("--devnull", type=int, default=0, help="single reads: a second run with the SAM written to /dev/null")
+    ap.add_argument("--default-mode", type=int, default=0, help="single reads: the reference's default mode -- BWT stage at Soap3MisMatchAllow mismatches, the reads it leaves through seeding + DP (.dpout.1)")
     ap.add_argument("--pairs", type=int, default=0, help="paired-end default mode (DP stages on) with this many 2 x read-len pairs instead of single reads")
     a = ap.parse_args()
     import torch
@@ -82,7 +83,7 @@ def main():
         env["S3DP_HOST_THREADS"] = str(a.threads)
     exe = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
     t = time.time()
-    out = subprocess.run([exe, "single", os.path.join(work, "g.index"), fq, "-L", str(L), "-s", str(a.mismatch), "-b", "3" if a.bam else "2", "-o", os.path.join(work, "out")] +
+    out = subprocess.run([exe, "single", os.path.join(work, "g.index"), fq, "-L", str(L)] + ([] if a.default_mode else ["-s", str(a.mismatch)]) + ["-b", "3" if a.bam else "2", "-o", os.path.join(work, "out")] +
                          (["-c", a.devices] if a.devices else []), capture_output=True, text=True, env=env)
     wall = time.time() - t
     if out.returncode != 0:
@@ -96,7 +97,7 @@ def main():
     sl = re.search(r"\[Main\] Stream loop time : (.*)", out.stdout)
     dv = re.search(r"\[Main\] Device time : (.*)", out.stdout)
     m = re.search(r"\[Main\] Read load time :\s+([0-9.]+) seconds \(loader", out.stdout)
-    res = {"output": "BAM (-b 3)" if a.bam else "SAM (-b 2)", "genome_bp": a.genome_bp, "repeat_frac": a.repeat_frac, "devices": a.devices or "0", "loader_thread_s": float(m.group(1)) if m else None, "reads": N, "read_len": L, "max_mismatch": a.mismatch, "host_threads": a.threads or os.cpu_count(),
+    res = {"mode": "default (DP on)" if a.default_mode else "-s %d (DP off)" % a.mismatch, "output": "BAM (-b 3)" if a.bam else "SAM (-b 2)", "genome_bp": a.genome_bp, "repeat_frac": a.repeat_frac, "devices": a.devices or "0", "loader_thread_s": float(m.group(1)) if m else None, "reads": N, "read_len": L, "max_mismatch": a.mismatch, "host_threads": a.threads or os.cpu_count(),
            "index_build_and_write_s": t_index, "fastq_write_s": t_reads, "wall_s_total": wall, "phases_s": ph, "aligned_reads": aligned,
            "stream_loop": sl.group(1) if sl else None, "device_time": dv.group(1) if dv else None,
            "sam_bytes": sam_bytes, "fastq_bytes": os.path.getsize(fq),
