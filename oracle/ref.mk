@@ -37,7 +37,7 @@ FLEXOBJ := $(addprefix $(OBJ)/flex_,$(addsuffix .o,$(FLEX)))
 SAMOBJ  := $(addprefix $(OBJ)/sam_,$(addsuffix .o,$(SAMT)))
 HOSTOBJ := $(addprefix $(OBJ)/host_,$(addsuffix .o,$(HOST)))
 
-all: $(OUT)/soap3-dp-builder $(OUT)/BGS-Build $(OUT)/ref_harness $(OUT)/libdpref.so $(OUT)/ref_bam2sam
+all: $(OUT)/soap3-dp-builder $(OUT)/BGS-Build $(OUT)/ref_harness $(OUT)/libdpref.so $(OUT)/ref_bam2sam $(OUT)/ref_sam2bam
 
 $(OBJ):
 	mkdir -p $(OBJ)
@@ -126,6 +126,10 @@ $(OUT)/libdpref.so: oracle/ref_dp_driver.hip $(OBJ)/dp_device.inc $(OBJ)/dp_head
 
 # BAM reader for the tests: the reference's samtools decodes what `soap3-dp -bam` wrote (oracle/ref_bam2sam.c is ours)
 $(OUT)/ref_bam2sam: oracle/ref_bam2sam.c $(SAMOBJ)
+	$(CC) $(SAMFLG) -I$(REF)/samtools-0.1.18 $< $(SAMOBJ) -lz -lm -o $@
+
+# BAM writer for the fixtures of the `-bam` input (oracle/ref_sam2bam.c is ours; the library is the reference's)
+$(OUT)/ref_sam2bam: oracle/ref_sam2bam.c $(SAMOBJ)
 	$(CC) $(SAMFLG) -I$(REF)/samtools-0.1.18 $< $(SAMOBJ) -lz -lm -o $@
 
 clean:

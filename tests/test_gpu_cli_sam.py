@@ -624,6 +624,29 @@ def test_cli_bam_input_single_and_pairs(tmp_path):
     assert texts["pbam"] == texts["pfq"] and len(texts["pfq"]) > 1000
 
 
+def test_cli_bam_input_written_by_the_reference_library(tmp_path):
+    """-bam on BAM files written by the REFERENCE's samtools library (tests/golden/bam/, made by tests/golden/make_bam_fixtures.py: the reads of g2 with every
+    third record reverse-complemented under flag 16, the pairs of g4 with flags 77 / 141): the SAM records of the FASTQ run, i.e. the reference's golden
+    records"""
+    bam = os.path.join(GOLDEN, "bam")
+    out = subprocess.run([BIN, "single", os.path.join(GOLDEN, "g2", "index"), os.path.join(bam, "se.bam"), "-bam", "-L", "120", "-s", "4", "-b", "2", "-o", "se"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    mine = sam_records(open(tmp_path / "se.gout.1").read())[1]
+    ref = sam_records(gzip.open(os.path.join(GOLDEN, "g2", "sam_s4.sam.gz"), "rt").read())[1]
+    import re
+    strip = lambda rec: {k: re.sub(r"\tRG:Z:[^\t]*", "", v) for k, v in rec.items()}
+    assert strip(mine) == strip(ref) and len(ref) == 1500                    # (the read group is the query file's name: it differs, nothing else does)
+    f1, f2 = os.path.join(GOLDEN, "g4", "reads_1.fq"), os.path.join(GOLDEN, "g4", "reads_2.fq")
+    texts = {}
+    for mode, args in (("pfq", [f1, f2]), ("pbam", [os.path.join(bam, "pe.bam"), "-bam"])):
+        out = subprocess.run([BIN, "pair", os.path.join(GOLDEN, "g4", "index")] + args + ["-u", "500", "-v", "100", "-L", "100", "-s", "3", "-D", "rg", "-o", mode], cwd=tmp_path,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        texts[mode] = [l for l in open(tmp_path / (mode + ".gout.1")).read().split("\n") if l and not l.startswith("@PG")]
+    assert texts["pbam"] == texts["pfq"] and len(texts["pfq"]) > 1000
+
+
 def test_cli_multi_modes(tmp_path):
     """single-multi / pair-multi (loadMultiInputFile, IniParam.cpp:28): one job per line of a tab-separated list, the index loaded once -- every job's
     files equal those of the same job run on its own"""

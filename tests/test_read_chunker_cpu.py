@@ -182,3 +182,23 @@ def test_bam_input_gives_the_reads_of_the_fastq(tool, tmp_path):
     # pairs: the mates behind each other in one file; an odd record at the end is dropped
     got, _ = dump(tool, 1000, 100, ["bampair:" + str(bam)], tmp_path, "bampair")
     assert [l.split(" ")[1:] for l in got if l] == [l.split(" ")[1:] for l in whole if l][:2500]
+
+
+def test_bam_files_written_by_the_reference_library(tool, tmp_path):
+    """tests/golden/bam/*.bam were written by the REFERENCE's samtools-0.1.18 (oracle/ref_sam2bam.c over its library, tests/golden/make_bam_fixtures.py) from the
+    reads of g2 (every third record flagged as aligned to the reverse strand: sequence reverse-complemented, qualities reversed) and the pairs of g4: the
+    loader gives the reads of the FASTQ files, whatever the chunk size.  (The test above feeds it BAM files of the product's own writer.)"""
+    bam = os.path.join(GOLDEN, "bam")
+    whole, _ = dump(tool, 1 << 30, 120, [os.path.join(GOLDEN, "g2", "reads.fq")], tmp_path, "g2fq")
+    n = len([l for l in whole if l])
+    assert n == 1500
+    for chunk in (1 << 30, 512, 64):
+        got, c = dump(tool, chunk, 120, ["bam:" + os.path.join(bam, "se.bam")], tmp_path, "g2bam%d" % chunk)
+        assert c == (n + chunk - 1) // chunk
+        assert [l.split(" ")[1:] for l in got] == [l.split(" ")[1:] for l in whole]
+        assert [l.split(" ")[0].split("/")[0] for l in got if l] == [l.split(" ")[0].split("/")[0] for l in whole if l]
+    wholep, _ = dump(tool, 1 << 30, 100, [os.path.join(GOLDEN, "g4", "reads_1.fq"), os.path.join(GOLDEN, "g4", "reads_2.fq")], tmp_path, "g4fq")
+    for chunk in (1 << 30, 500):
+        got, _ = dump(tool, chunk, 100, ["bampair:" + os.path.join(bam, "pe.bam")], tmp_path, "g4bam%d" % chunk)
+        assert [l.split(" ")[1:] for l in got] == [l.split(" ")[1:] for l in wholep]
+        assert [l.split(" ")[0].split("/")[0] for l in got if l] == [l.split(" ")[0].split("/")[0] for l in wholep if l]
