@@ -203,4 +203,6 @@ if [ -z "${S3_FIXTURE_ONLY:-}" ]; then
 ( cd $W && $REF/ref_harness models models.txt && gzip -9n < models.txt > $OUT/models.txt.gz )
 ( cd $W && $REF/ref_harness dpparams $INI dpparams.txt && gzip -9n < dpparams.txt > $OUT/dpparams.txt.gz )
 fi
+# BAM files for the `-bam` input tests, written by the reference's samtools library (oracle/_ref/ref_sam2bam)
+if [ -z "${S3_FIXTURE_OUT:-}" ]; then python $ROOT/tests/golden/make_bam_fixtures.py; fi
 du -sh $OUT
