@@ -424,10 +424,13 @@ __global__ void __launch_bounds__(256) dpFillPairKernel(DpArgs a)
     extern __shared__ __align__(16) unsigned char sh[];
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const uint32_t p0 = 2u * (blockIdx.x * (blockDim.x >> 6) + wv);
-    if (p0 + 1u >= a.n) return;                                          // whole pairs only: an odd last problem is dpFillKernel's (launchDp)
+    if (p0 >= a.n) return;
+    // an odd last problem sits in both halves: the same values go to the same places twice (a launch of its own for it cost a whole sweep of one wave,
+    // 0.15-0.4 ms, on every call of the engines)
+    const uint32_t twin = p0 + 1u >= a.n ? 0u : 1u;
     Problem2 q;
     for (int h = 0; h < 2; h++) {
-        const uint32_t p = p0 + (uint32_t)h;
+        const uint32_t p = p0 + (uint32_t)h * twin;
         q.p[h] = p; q.L[h] = a.readLengths[p]; q.W[h] = a.dnaLengths[p];
         q.aL[h] = a.anchorLeft ? a.anchorLeft[p] : a.maxDNALength; q.aR[h] = a.anchorRight ? a.anchorRight[p] : 0u;
         q.clipLt[h] = (int)(a.clipLt ? a.clipLt[p] : 0u);
@@ -593,7 +596,7 @@ __global__ void dpBacktrackKernel(DpArgs a)
 // may the launch's problems go two to a wavefront (dpFillPairKernel)?  Scheme 1, every value of the recurrence within 16 bits, the paired rows in LDS
 static bool dpPairable(const DpArgs &a)
 {
-    if (!a.pairMode || a.scheme != 1 || a.n < 2u) return false;
+    if (!a.pairMode || a.scheme != 1) return false;
     if (a.match < 0 || a.match > 250 || a.mismatch > 0 || a.mismatch < -250 || a.gapOpen > 0 || a.gapOpen < -250 || a.gapExtend > 0 || a.gapExtend < -250) return false;
     if ((long long)a.maxReadLength * a.match > 30000) return false;
     if (-2 * a.gapOpen - a.gapExtend - a.mismatch > 700) return false;
@@ -616,9 +619,9 @@ int launchDp(const DpArgs &a0, hipStream_t s)
             const hipError_t e = hipFuncSetAttribute((const void *)dpFillPairKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        const uint32_t pairs = a.n >> 1;
+        const uint32_t pairs = (a.n + 1u) >> 1;
         hipLaunchKernelGGL(dpFillPairKernel, dim3((pairs + waves - 1u) / waves), dim3(64u * waves), lds, s, a);
-        a.first = pairs << 1;                                              // an odd last problem on its own
+        a.first = a.n;
     }
     if (a.first < a.n) {
         // a wave keeps its window and the boundary row of its pass in LDS (ldsPerWave bytes); blocks hold 4 waves while that fits into the CU's 160 KB,
