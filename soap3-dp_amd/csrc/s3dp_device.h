@@ -150,6 +150,7 @@ struct DpArgs {
     uint32_t        n, maxDNALength, maxReadLength, maxDPTableLength, patternLen, ldsPerWave;
     uint32_t        ldsPerWavePair, first;                        // LDS of a wave that sweeps two problems (20 B per column); first problem of a launch of dpFillKernel
     int             pairMode;                                     // 0: one problem per wavefront whatever the scores (S3DP_DP_PAIRED=0)
+    int             fuseMode, fuseTraceback;                      // the paired fill kernel goes on to walk its two tables (S3DP_DP_FUSED=0: dpBacktrackKernel as a launch of its own); set per launch
     int             match, mismatch, gapOpen, gapExtend, scheme;
     uint32_t       *patMax;                                       // optional: longest pattern of the launch in bytes (atomicMax; zeroed by the caller)
 };

@@ -242,6 +242,104 @@ __global__ void __launch_bounds__(256) dpFillKernel(DpArgs a)
     }
 }
 
+// Traceback (what GPUBacktrack computes, DV-DPfunctions.cu:316-512): from the maximum back to the read's first aligned base.
+// The reference's walk decides every move by comparing table VALUES, in a fixed priority -- match/mismatch, then a deletion that opens here, then
+// one that extends, then (inside the left-clip allowance) the two ways out, then an insertion that opens, else one that extends -- and inside a gap
+// it follows the gap's own score downwards until the gap is seen to open.  The same decisions are taken here from H alone plus the one bit per
+// cell the fill kernel recorded; the walk is organised as "where am I, what does the cell say" (View) and three small movers, one lane per
+// problem (a walk is a chain of dependent reads: 64 problems per wave is what hides its latency).
+namespace tb {
+struct View {
+    const DpArgs &a; uint32_t p, T, refOffset, aL, cl;
+    const uint32_t *table;
+    int go, ge, gi;
+    // H(j, i) as the table holds it; column 0 and row 0 are never stored: they are the initial conditions (:165-198)
+    __device__ int H(uint32_t j, uint32_t i) const
+    {
+        if (j == 0u) return clampS(i == 0u ? 0 : (i <= cl ? go : gi + ge * (int)(i - cl)));
+        if (i == 0u) return (j + refOffset >= aL) ? NEG_INF : 0;
+        const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
+        const uint32_t t = j + k;                                    // the step that computed the cell
+        const uint32_t w = table[(size_t)c * dpTableChunkWords(T) + (size_t)(t >> 1) * 64u + k];
+        return (int)(int16_t)(uint16_t)((t & 1u) ? w >> 16 : w);
+    }
+    // did H(j, i) come out of an extended deletion, H(j,i) == gapExtend + E(j-1,i)?  (j >= 1; for j == 1 the previous column is the initial one)
+    __device__ bool fromExtendedDeletion(uint32_t j, uint32_t i) const
+    {
+        if (i == 0u) return false;
+        const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
+        const uint32_t t = j + k;
+        return (table[(size_t)c * dpTableChunkWords(T) + dpTableXBase(T) + (size_t)(t >> 5) * 64u + k] >> (31u - (t & 31u))) & 1u;
+    }
+};
+}  // namespace tb
+
+// the walk of problem p by the calling lane; score / hitLoc / startOffset / clipRt: what the fill left for p (handed over in registers where the fill kernel
+// itself goes on to walk, read back from the arrays in dpBacktrackKernel)
+__device__ __forceinline__ void dpBacktrackOne(const DpArgs &a, uint32_t p, int score, uint32_t hitLoc, uint32_t startOffset, uint32_t clipRt)
+{
+    unsigned char *pat = a.pattern + (size_t)p * a.patternLen;
+    pat[0] = 0;
+    if (score < a.cutoffs[p]) return;
+    const uint32_t L = a.readLengths[p];
+    const tb::View v{a, p, a.maxDPTableLength + 64u, startOffset, a.anchorLeft ? a.anchorLeft[p] : a.maxDNALength, a.clipLt ? a.clipLt[p] : 0u,
+                     a.table + (size_t)p * a.tableWordsPerProblem, a.gapOpen, a.gapExtend, a.gapOpen - a.gapExtend};
+    uint32_t out = 0;
+    auto put = [&](uint32_t x) { if (out < a.patternLen) pat[out] = (unsigned char)x; ++out; };
+    auto run = [&](char op, uint32_t n) { put((uint32_t)op); put('V'); put(n); };       // 'V'<n>: n - 1 more of the op before (decoded by the engines)
+    uint32_t i = L - clipRt, j = hitLoc;                                                 // read position, window column (1-based, 0 = before the first)
+    if (clipRt) run('S', clipRt);
+    auto readAt = [&](uint32_t q) { return seqChar(a.reads, p, a.maxReadLength, q); };
+    auto refAt = [&](uint32_t q) { return seqChar(a.dna, p, a.maxDNALength, v.refOffset + q); };
+    auto rowInit = [&](uint32_t q) -> int { return (v.refOffset + q >= v.aL) ? NEG_INF : 0; };     // H(q, 0)
+    enum Exit { NONE, CLIP_AFTER_MATCH, CLIP_AFTER_INSERT } exitBy = NONE;
+    int cur = v.H(j, i);
+    while (i > 0u && j > 0u && exitBy == NONE) {
+        const bool same = refAt(j) == readAt(i);
+        const int sub = same ? a.match : a.mismatch;
+        int nxt;
+        if (cur == sub + (nxt = v.H(j - 1u, i - 1u))) { put(same ? 'M' : 'm'); --j; --i; cur = nxt; continue; }
+        if (cur == v.go + (nxt = v.H(j - 1u, i))) { put('D'); --j; cur = nxt; continue; }
+        if (v.fromExtendedDeletion(j, i)) {
+            // inside a deletion: its score falls by gapExtend per base until the column where it opened out of H
+            put('D'); --j;
+            int gap = (int16_t)(cur - v.ge);
+            for (;;) {
+                if (!(i > 0u && j > 0u)) { cur = gap; break; }
+                put('D'); --j;
+                if (gap == v.go + (nxt = v.H(j, i))) { cur = nxt; break; }
+                gap = (int16_t)(gap - v.ge);
+            }
+            continue;
+        }
+        if (i <= v.cl + 1u) {                                                              // the read's start may be clipped away from here
+            if (cur == rowInit(j - 1u) + sub && j >= 1u) { exitBy = CLIP_AFTER_MATCH; break; }
+            if (cur == rowInit(j) + v.go) { exitBy = CLIP_AFTER_INSERT; break; }
+        }
+        if (cur == v.go + (nxt = v.H(j, i - 1u))) { put('I'); --i; cur = nxt; continue; }
+        // inside an insertion: likewise, along the read
+        put('I'); --i;
+        int gap = (int16_t)(cur - v.ge);
+        for (;;) {
+            if (!(i > 0u && j > 0u)) { cur = gap; break; }
+            if (i <= v.cl + 1u && gap == rowInit(j) + v.go) { cur = gap; exitBy = CLIP_AFTER_INSERT; break; }
+            put('I'); --i;
+            if (gap == v.go + (nxt = v.H(j, i))) { cur = nxt; break; }
+            gap = (int16_t)(gap - v.ge);
+        }
+    }
+    if (j == 0u) {
+        // ran off the window's left edge: what is left of the read is clipped as far as allowed, the rest counts as inserted
+        const uint32_t clipped = v.cl < i ? v.cl : i;
+        if (clipped < i) run('I', i - clipped);
+        run('S', clipped);
+    } else if (exitBy == CLIP_AFTER_INSERT) { put('I'); run('S', i - 1u); }
+    else if (exitBy == CLIP_AFTER_MATCH) { put(refAt(j) == readAt(i) ? 'M' : 'm'); run('S', i - 1u); --j; }
+    put(0);
+    if (a.patMax) atomicMax(a.patMax, out < a.patternLen ? out : a.patternLen);        // bytes of the longest pattern, terminator included: what the host fetches per row
+    a.hitLocs[p] = v.refOffset + j;
+}
+
 // ---- two problems per wavefront ---------------------------------------------------------------------------------------------------------------------------
 // Every value of the recurrence fits 16 bits: stored cells are clamped to [-32000, 32767] by the reference itself, and the running values of a column stay
 // within -32000 + 2 gapOpen + mismatch + gapExtend ... L x match (dpPairable checks the scores).  So a wave sweeps TWO problems at once, problem 2q in the low
@@ -472,6 +570,7 @@ __global__ void __launch_bounds__(256) dpFillPairKernel(DpArgs a)
         }
         __builtin_amdgcn_wave_barrier();
     }
+    uint32_t hitPosOf[2], clipRtOf[2];
     for (int h = 0; h < 2; h++) {
         Best &b = best[h];
         for (int off = 32; off > 0; off >>= 1) {
@@ -479,118 +578,37 @@ __global__ void __launch_bounds__(256) dpFillPairKernel(DpArgs a)
             const uint32_t k2 = (uint32_t)__shfl_xor((int)b.key, off), c2 = (uint32_t)__shfl_xor((int)b.count, off);
             bestMerge(b, s2v, k2, c2);
         }
+        const bool found = b.count && b.score > NEG_INF;                  // ties with the initial -32000 only count (:228-236)
+        const uint32_t hitPos = found ? b.key >> 16 : 0u, row = found ? b.key & 0xFFFFu : 0u;
+        hitPosOf[h] = hitPos;
+        clipRtOf[h] = a.clipRt ? (found ? q.L[h] - row : 0u) : 0u;
         if (lane == 0) {
             const uint32_t p = q.p[h];
-            const bool found = b.count && b.score > NEG_INF;              // ties with the initial -32000 only count (:228-236)
-            const uint32_t hitPos = found ? b.key >> 16 : 0u, row = found ? b.key & 0xFFFFu : 0u;
             a.startOffsets[p] = 0u;
             a.hitLocs[p] = hitPos;
             a.scores[p] = b.score;
             a.maxScoreCounts[p] = b.count;
             a.tableCols[p] = q.W[h];
-            if (a.clipRt) a.clipRt[p] = found ? q.L[h] - row : 0u;
+            if (a.clipRt) a.clipRt[p] = clipRtOf[h];
         }
+    }
+    if (a.fuseTraceback) {
+        // The traceback is a chain of dependent loads, one lane per problem: as a kernel of its own it took a quarter of the fill's time on the engines' small
+        // launches, with the device nearly empty.  Here lanes 0 and 1 of the wave walk the two tables the wave has just written while the other waves of
+        // the launch are still filling theirs: the walk's latency hides behind their arithmetic.  (The fence makes the wave's own table stores visible to
+        // its loads; nobody else reads or writes these tables.)
+        __threadfence();
+        if (lane < 1u + twin)
+            dpBacktrackOne(a, lane ? q.p[1] : q.p[0], lane ? best[1].score : best[0].score, lane ? hitPosOf[1] : hitPosOf[0], 0u, lane ? clipRtOf[1] : clipRtOf[0]);
     }
 }
 
-
-// Traceback (what GPUBacktrack computes, DV-DPfunctions.cu:316-512): from the maximum back to the read's first aligned base.
-// The reference's walk decides every move by comparing table VALUES, in a fixed priority -- match/mismatch, then a deletion that opens here, then
-// one that extends, then (inside the left-clip allowance) the two ways out, then an insertion that opens, else one that extends -- and inside a gap
-// it follows the gap's own score downwards until the gap is seen to open.  The same decisions are taken here from H alone plus the one bit per
-// cell the fill kernel recorded; the walk is organised as "where am I, what does the cell say" (View) and three small movers, one lane per
-// problem (a walk is a chain of dependent reads: 64 problems per wave is what hides its latency).
-namespace tb {
-struct View {
-    const DpArgs &a; uint32_t p, T, refOffset, aL, cl;
-    const uint32_t *table;
-    int go, ge, gi;
-    // H(j, i) as the table holds it; column 0 and row 0 are never stored: they are the initial conditions (:165-198)
-    __device__ int H(uint32_t j, uint32_t i) const
-    {
-        if (j == 0u) return clampS(i == 0u ? 0 : (i <= cl ? go : gi + ge * (int)(i - cl)));
-        if (i == 0u) return (j + refOffset >= aL) ? NEG_INF : 0;
-        const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
-        const uint32_t t = j + k;                                    // the step that computed the cell
-        const uint32_t w = table[(size_t)c * dpTableChunkWords(T) + (size_t)(t >> 1) * 64u + k];
-        return (int)(int16_t)(uint16_t)((t & 1u) ? w >> 16 : w);
-    }
-    // did H(j, i) come out of an extended deletion, H(j,i) == gapExtend + E(j-1,i)?  (j >= 1; for j == 1 the previous column is the initial one)
-    __device__ bool fromExtendedDeletion(uint32_t j, uint32_t i) const
-    {
-        if (i == 0u) return false;
-        const uint32_t c = (i - 1u) >> 6, k = (i - 1u) & 63u;
-        const uint32_t t = j + k;
-        return (table[(size_t)c * dpTableChunkWords(T) + dpTableXBase(T) + (size_t)(t >> 5) * 64u + k] >> (31u - (t & 31u))) & 1u;
-    }
-};
-}  // namespace tb
 
 __global__ void dpBacktrackKernel(DpArgs a)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.n) return;
-    unsigned char *pat = a.pattern + (size_t)p * a.patternLen;
-    pat[0] = 0;
-    if (a.scores[p] < a.cutoffs[p]) return;
-    const uint32_t L = a.readLengths[p];
-    const tb::View v{a, p, a.maxDPTableLength + 64u, a.startOffsets[p], a.anchorLeft ? a.anchorLeft[p] : a.maxDNALength, a.clipLt ? a.clipLt[p] : 0u,
-                     a.table + (size_t)p * a.tableWordsPerProblem, a.gapOpen, a.gapExtend, a.gapOpen - a.gapExtend};
-    const uint32_t clipRt = a.clipRt ? a.clipRt[p] : 0u;
-    uint32_t out = 0;
-    auto put = [&](uint32_t x) { if (out < a.patternLen) pat[out] = (unsigned char)x; ++out; };
-    auto run = [&](char op, uint32_t n) { put((uint32_t)op); put('V'); put(n); };       // 'V'<n>: n - 1 more of the op before (decoded by the engines)
-    uint32_t i = L - clipRt, j = a.hitLocs[p];                                           // read position, window column (1-based, 0 = before the first)
-    if (clipRt) run('S', clipRt);
-    auto readAt = [&](uint32_t q) { return seqChar(a.reads, p, a.maxReadLength, q); };
-    auto refAt = [&](uint32_t q) { return seqChar(a.dna, p, a.maxDNALength, v.refOffset + q); };
-    auto rowInit = [&](uint32_t q) -> int { return (v.refOffset + q >= v.aL) ? NEG_INF : 0; };     // H(q, 0)
-    enum Exit { NONE, CLIP_AFTER_MATCH, CLIP_AFTER_INSERT } exitBy = NONE;
-    int cur = v.H(j, i);
-    while (i > 0u && j > 0u && exitBy == NONE) {
-        const bool same = refAt(j) == readAt(i);
-        const int sub = same ? a.match : a.mismatch;
-        int nxt;
-        if (cur == sub + (nxt = v.H(j - 1u, i - 1u))) { put(same ? 'M' : 'm'); --j; --i; cur = nxt; continue; }
-        if (cur == v.go + (nxt = v.H(j - 1u, i))) { put('D'); --j; cur = nxt; continue; }
-        if (v.fromExtendedDeletion(j, i)) {
-            // inside a deletion: its score falls by gapExtend per base until the column where it opened out of H
-            put('D'); --j;
-            int gap = (int16_t)(cur - v.ge);
-            for (;;) {
-                if (!(i > 0u && j > 0u)) { cur = gap; break; }
-                put('D'); --j;
-                if (gap == v.go + (nxt = v.H(j, i))) { cur = nxt; break; }
-                gap = (int16_t)(gap - v.ge);
-            }
-            continue;
-        }
-        if (i <= v.cl + 1u) {                                                              // the read's start may be clipped away from here
-            if (cur == rowInit(j - 1u) + sub && j >= 1u) { exitBy = CLIP_AFTER_MATCH; break; }
-            if (cur == rowInit(j) + v.go) { exitBy = CLIP_AFTER_INSERT; break; }
-        }
-        if (cur == v.go + (nxt = v.H(j, i - 1u))) { put('I'); --i; cur = nxt; continue; }
-        // inside an insertion: likewise, along the read
-        put('I'); --i;
-        int gap = (int16_t)(cur - v.ge);
-        for (;;) {
-            if (!(i > 0u && j > 0u)) { cur = gap; break; }
-            if (i <= v.cl + 1u && gap == rowInit(j) + v.go) { cur = gap; exitBy = CLIP_AFTER_INSERT; break; }
-            put('I'); --i;
-            if (gap == v.go + (nxt = v.H(j, i))) { cur = nxt; break; }
-            gap = (int16_t)(gap - v.ge);
-        }
-    }
-    if (j == 0u) {
-        // ran off the window's left edge: what is left of the read is clipped as far as allowed, the rest counts as inserted
-        const uint32_t clipped = v.cl < i ? v.cl : i;
-        if (clipped < i) run('I', i - clipped);
-        run('S', clipped);
-    } else if (exitBy == CLIP_AFTER_INSERT) { put('I'); run('S', i - 1u); }
-    else if (exitBy == CLIP_AFTER_MATCH) { put(refAt(j) == readAt(i) ? 'M' : 'm'); run('S', i - 1u); --j; }
-    put(0);
-    if (a.patMax) atomicMax(a.patMax, out < a.patternLen ? out : a.patternLen);        // bytes of the longest pattern, terminator included: what the host fetches per row
-    a.hitLocs[p] = v.refOffset + j;
+    dpBacktrackOne(a, p, a.scores[p], a.hitLocs[p], a.startOffsets[p], a.clipRt ? a.clipRt[p] : 0u);
 }
 
 // may the launch's problems go two to a wavefront (dpFillPairKernel)?  Scheme 1, every value of the recurrence within 16 bits, the paired rows in LDS
@@ -620,7 +638,9 @@ int launchDp(const DpArgs &a0, hipStream_t s)
             if (e != hipSuccess) return (int)e;
         }
         const uint32_t pairs = (a.n + 1u) >> 1;
+        a.fuseTraceback = a.fuseMode;
         hipLaunchKernelGGL(dpFillPairKernel, dim3((pairs + waves - 1u) / waves), dim3(64u * waves), lds, s, a);
+        if (a.fuseTraceback) return (int)hipSuccess;
         a.first = a.n;
     }
     if (a.first < a.n) {
