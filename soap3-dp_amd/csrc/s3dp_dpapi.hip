@@ -291,7 +291,7 @@ int s3i::dpRun(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL,
     a.ldsPerWavePair = ((h->maxDNA + 1u) * 20u + 15u) & ~15u;
     a.first = 0;
     { const char *e = getenv("S3DP_DP_PAIRED"); a.pairMode = !(e && *e == '0'); }
-    { const char *e = getenv("S3DP_DP_FUSED"); a.fuseMode = !(e && *e == '0'); a.fuseTraceback = 0; }
+    { const char *e = getenv("S3DP_DP_FUSED"); a.fuseMode = e && *e == '1'; a.fuseTraceback = 0; }     // (measured slower on full launches: off unless asked for)
     a.match = h->sc.matchScore; a.mismatch = h->sc.mismatchScore; a.gapOpen = h->sc.gapOpenScore; a.gapExtend = h->sc.gapExtendScore; a.scheme = h->scheme;
     if ((size_t)a.ldsPerWave > 160 * 1024) return fail(S3_EINVAL, "s3_dp_align: maxDNALength too large for the LDS-resident window");
     if (dpDumpFile()) {

@@ -58,15 +58,16 @@ def test_two_problems_per_wavefront_equal_one(monkeypatch, scores, what, n):
     max_read, max_dna = 200, 420
     P = make_problems(n, max_read, max_dna, 77 + n, lengths=[63, 150, 64, 65, 30, 127, 128, 129, 191, 192, 193, 100], clip_max=90)
     out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("S3DP_DP_PAIRED", mode)
+    for mode in ("1", "0", "fused"):
+        monkeypatch.setenv("S3DP_DP_PAIRED", "0" if mode == "0" else "1")
+        monkeypatch.setenv("S3DP_DP_FUSED", "1" if mode == "fused" else "0")   # the paired kernel walking its own tables (measured slower, off by default)
         al = s3dp.DpAligner(n, max_read, max_dna, scheme=1, scores=scores)
         out[mode] = al.align(P["dna"], P["dna_len"], P["reads"], P["read_len"], P["cutoffs"], clip_lt=P["clip_lt"], clip_rt=P["clip_rt"], anchor_lt=P["a_lt"],
                              anchor_rt=P["a_rt"])
         al.close()
     orc = s3o.dp_align(P["dna"], P["dna_len"], max_dna, max_dna, P["reads"], P["read_len"], max_read, P["cutoffs"], scheme=1, scores=scores,
                        clip_lt=P["clip_lt"], clip_rt=P["clip_rt"], anchor_lt=P["a_lt"], anchor_rt=P["a_rt"])
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "fused"):
         sc, hit, cnt, pat, crt = out[mode]
         assert (sc == orc[0]).all() and (hit == orc[1]).all() and (cnt == orc[2]).all() and (crt == orc[4]).all(), "S3DP_DP_PAIRED=" + mode
         for t in np.nonzero(sc >= P["cutoffs"])[0]:
