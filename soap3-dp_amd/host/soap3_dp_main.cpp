@@ -972,11 +972,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     struct PairJob {
         std::unique_ptr<ReadSet> rs; s3_batch *b = nullptr; uint32_t cnt = 0;
         std::vector<s3_pair_result> pr; std::vector<uint64_t> ooff; std::vector<uint32_t> pos; std::vector<uint8_t> strand, mis, fromSa;
+        std::vector<uint32_t> todo; bool hadSeedLengths = false;                  // single reads (default mode): the reads the BWT stage left without a hit
     };
     struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<PairJob>> q; uint64_t submitted = 0, done = 0; bool stop = false; } dpq;
     s3_batch *pairBatch[2] = {b, nullptr};
     std::thread dpWorker;
-    const bool pipelinedDp = paired && enableDP && chunk && chunk->n;
+    const bool pipelinedDp = enableDP && chunk && chunk->n;                      // (pairs and, in the default mode, single reads)
     if (pipelinedDp) {
         if (s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : chunk->n, chunk->wpq, &pairBatch[1]) != S3_OK) return dieJoin(s3_last_error());
         dpWorker = std::thread([&] {
@@ -989,11 +990,28 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                     j = std::move(dpq.q.front());
                     dpq.q.pop_front();
                 }
-                PairDpCtx c{hix, so, *j->rs, ini, j->b, seedBatch, dp, dpHalf, dpOut, unpairOut, 0u, j->cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
                 std::string e2;
                 const auto tDp = std::chrono::steady_clock::now();
-                if (!pairDpStages(c, j->pr, j->ooff, j->pos, j->strand, j->mis, j->fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) {
-                    fflush(stdout); fprintf(stderr, "%s\n", e2.c_str()); fflush(stderr); _exit(1);
+                auto fatal = [&](const std::string &m) { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); };
+                if (paired) {
+                    PairDpCtx c{hix, so, *j->rs, ini, j->b, seedBatch, dp, dpHalf, dpOut, unpairOut, 0u, j->cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
+                    if (!pairDpStages(c, j->pr, j->ooff, j->pos, j->strand, j->mis, j->fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) fatal(e2);
+                } else {
+                    // DPForUnalignSingle2 (DV-DPForSingleReads.cu): seeding in batches of at most 256 Ki seeds, DP at the candidates, one record per run of
+                    // results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776), the rest as unaligned records
+                    const ReadSet &rs = *j->rs;
+                    if (j->hadSeedLengths && s3_batch_set_seed_lengths(j->b, nullptr) != S3_OK) fatal(s3_last_error());
+                    std::vector<uint8_t> doneFlag(j->cnt, 0);
+                    // a read with DP hits on both strands comes as two runs (two records, as in the reference): its flag may be set by two threads at once,
+                    // to the same value; the count of aligned reads is taken from the flags afterwards
+                    if (!singleDpRuns(hix, so, dpOut, j->b, seedBatch, dp, rs.lengths.data(), j->todo, dpPar, alignmentType, [&](SamWriter &w, uint32_t k, std::vector<DpHit> &hits) {
+                            w.singleDP(rs, k, hits.data(), hits.size(), dpPar.cutoffThreshold);
+                            doneFlag[k] = 1;
+                        }, e2)) fatal(e2);
+                    for (uint32_t k : j->todo) dpAlignedReads += doneFlag[k];
+                    SamWriter w(hix, so, dpOut);
+                    for (uint32_t k : j->todo) if (!doneFlag[k]) w.unaligned(rs, k);
+                    w.flush();
                 }
                 dpStageSeconds += since(tDp);
                 addChunkSeconds(3, since(tDp));
@@ -1102,25 +1120,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             w.singleEnd(rs, first + k, pos.data() + o, strand.data() + o, mis.data() + o, m, seeds.empty() ? 0u : seeds[k]);
         }, aligned);
         if (enableDP) {
-            // DPForUnalignSingle2 (DV-DPForSingleReads.cu): seeding in batches of at most 256 Ki seeds, DP at the candidates, one record per run of
-            // results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776), the rest as unaligned records
-            if (!seeds.empty() && s3_batch_set_seed_lengths(b, nullptr) != S3_OK) return dieJoin(s3_last_error());
-            std::vector<uint32_t> todo;
-            for (uint32_t k = 0; k < cnt; k++) if (offs[k + 1] == offs[k]) todo.push_back(k);
-            std::vector<uint8_t> doneFlag(cnt, 0);
-            const uint32_t *lens = rs.lengths.data() + first;
-            {
-                // a read with DP hits on both strands comes as two runs (two records, as in the reference): its flag may be set by two threads at once,
-                // to the same value; the count of aligned reads is taken from the flags afterwards
-                std::string e2;
-                if (!singleDpRuns(hix, so, dpOut, b, seedBatch, dp, lens, todo, dpPar, alignmentType, [&](SamWriter &w, uint32_t k, std::vector<DpHit> &hits) {
-                        w.singleDP(rs, first + k, hits.data(), hits.size(), dpPar.cutoffThreshold);
-                        doneFlag[k] = 1;
-                    }, e2)) return dieJoin(e2);
-                for (uint32_t k : todo) dpAlignedReads += doneFlag[k];
-            }
-            SamWriter w(hix, so, dpOut);
-            for (uint32_t k : todo) if (!doneFlag[k]) w.unaligned(rs, first + k);
+            std::unique_ptr<PairJob> j(new PairJob());
+            j->b = b; j->cnt = cnt; j->hadSeedLengths = !seeds.empty();
+            for (uint32_t k = 0; k < cnt; k++) if (offs[k + 1] == offs[k]) j->todo.push_back(k);
+            j->rs = std::move(chunk);                                              // (the loop's recycle() gets nothing: the worker gives the set back)
+            { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); dpq.submitted++; }
+            dpq.cv.notify_all();
         }
     }
     if (dpWorker.joinable()) {
