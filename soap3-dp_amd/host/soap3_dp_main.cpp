@@ -805,7 +805,6 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     std::vector<uint64_t> counters((size_t)nMembers * C_COUNTERS, 0);
     std::vector<double> memberDpSeconds((size_t)nMembers, 0);
     auto runMember = [&](int member) -> int {
-    (void)s3_group_device;                                                      // (the DP aligners were made on dpDevices[member], the same device)
     s3_index *ix = s3_group_index(grp, member);
     const std::string fileNo = std::to_string(member + 1);
     double dpStageSeconds = 0;
