@@ -418,21 +418,29 @@ struct DecodedRow {
 template <class R, class Fn, class Fix>
 static void decodeParallel(uint32_t n, std::vector<R> &results, std::string &pool, Fn &&fn, Fix &&fix)
 {
+    // (eight threads: the boxes show 256 processors and grant sixteen, and these calls run beside the command line's own pools; a part's vector and string
+    //  sit on cache lines of their own -- neighbouring headers updated by neighbouring threads cost more than the threads brought)
     unsigned T = std::thread::hardware_concurrency();
-    if (T > 32) T = 32;
+    if (T > 8) T = 8;
     if (T < 2 || n < 4096) { for (uint32_t id = 0; id < n; id++) fn(id, results, pool); return; }
-    struct Part { std::vector<R> res; std::string pool; };
+    struct alignas(128) Part { std::vector<R> res; std::string pool; };
     std::vector<Part> parts(T);
     std::vector<std::thread> th;
     for (unsigned t = 0; t < T; t++)
         th.emplace_back([&, t] {
             const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+            parts[t].res.reserve(hi - lo);
+            parts[t].pool.reserve((size_t)(hi - lo) * 16);
             for (uint32_t id = lo; id < hi; id++) fn(id, parts[t].res, parts[t].pool);
         });
     for (auto &x : th) x.join();
+    size_t total = results.size(), chars = pool.size();
+    for (unsigned t = 0; t < T; t++) { total += parts[t].res.size(); chars += parts[t].pool.size(); }
+    results.reserve(total); pool.reserve(chars);
     for (unsigned t = 0; t < T; t++) {
         const uint32_t base = (uint32_t)pool.size();
-        for (R &r : parts[t].res) { fix(r, base); results.push_back(r); }
+        for (R &r : parts[t].res) fix(r, base);
+        results.insert(results.end(), parts[t].res.begin(), parts[t].res.end());
         pool += parts[t].pool;
     }
 }
@@ -455,11 +463,21 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
     std::vector<uint8_t> leftOrRight;
     std::vector<s3_occ> refer;
     DpCand *dCand = nullptr;
+    {
+        const size_t cap = std::min<size_t>(h->maxProblems, 2 * nOcc + 2);
+        cand.reserve(cap); dnaLens.reserve(cap); rdLens.reserve(cap); clipLt.reserve(cap); clipRt.reserve(cap); aL.reserve(cap); aR.reserve(cap); startLocs.reserve(cap);
+        cut.reserve(cap); leftOrRight.reserve(cap); refer.reserve(cap);
+    }
     const uint32_t wordsPerDNA = (h->maxDNA + 15) / 16, wordsPerRead = (h->maxRead + 15) / 16;
+    static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
+    auto tLap = std::chrono::steady_clock::now();
+    double lapMs[6] = {0, 0, 0, 0, 0, 0};                                    // candidate lists, uploads + pack, kernels, fetch, records, (rest)
+    auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); lapMs[k] += std::chrono::duration<double, std::milli>(now - tLap).count(); tLap = now; };
     auto flush = [&]() -> int {
         const uint32_t n = (uint32_t)cand.size();
         if (!n) return S3_OK;
         hipStream_t s = h->stream;
+        lap(0);
         HIPCHK(hipMemcpyAsync(dCand, cand.data(), (size_t)n * sizeof(DpCand), hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(h->dDnaLen, dnaLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(h->dReadLen, rdLens.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
@@ -473,6 +491,8 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
                            wordsPerDNA, wordsPerRead, h->dDna, h->dReads);
         int rc = dpRun(h, n, true, true, true, true);
         if (rc) return rc;
+        if (verbose) { HIPCHK(hipStreamSynchronize(s)); }
+        lap(1);
         std::vector<int32_t> scores(n);
         std::vector<uint32_t> hit(n), cnt(n);
         std::vector<uint8_t> pat;
@@ -482,6 +502,7 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
         HIPCHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         if ((rc = dpDump(h, n, true, true, true, true))) return rc;
         if ((rc = dpFetchDecoded(h, n, pat, pitch))) return rc;
+        lap(3);
         // algnmtCPUThread (:2329-2441)
         decodeParallel<s3_dp_half_result>(n, results, pool, [&](uint32_t id, std::vector<s3_dp_half_result> &results, std::string &pool) {
             s3_dp_half_result r{};
@@ -515,6 +536,7 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
         }, [](s3_dp_half_result &r, uint32_t base) { if (r.cigarOffset != 0xFFFFFFFFu) r.cigarOffset += base; });
         cand.clear(); dnaLens.clear(); rdLens.clear(); clipLt.clear(); clipRt.clear(); aL.clear(); aR.clear(); startLocs.clear(); cut.clear();
         leftOrRight.clear(); refer.clear();
+        lap(4);
         return S3_OK;
     };
     {
@@ -563,6 +585,8 @@ extern "C" int s3_dp_half_end(s3_dp *h, s3_batch *b, const uint32_t *readLengths
     if (rc == S3_OK) rc = flush();
     scratchFree(dCand, h->stream);
     if (rc) return rc;
+    if (verbose) fprintf(stderr, "[s3dp] default DP call: %zu results: candidate lists %.2f ms, uploads + pack + kernels (synchronised) %.2f, fetch of scores and decoded rows %.2f, records %.2f\n",
+                         results.size(), lapMs[0], lapMs[1], lapMs[3], lapMs[4]);
     s3_dp_half_result *out = (s3_dp_half_result *)malloc(results.size() * sizeof(s3_dp_half_result) + 1);
     char *cp = (char *)malloc(pool.size() + 1);
     if (!out || !cp) { free(out); free(cp); return fail(S3_ENOMEM, "s3_dp_half_end: out of host memory"); }
