@@ -63,3 +63,52 @@ def test_pairs_equal_the_oracle_at_scale(workload):
     assert mine[0] == ref[0] and set(mine[1]) == set(ref[1]) and len(ref[1]) >= 40000
     bad = [k for k in ref[1] if ref[1][k] != mine[1][k]]
     assert not bad, "%d of %d records differ, first:\n%s\n%s" % (len(bad), len(ref[1]), ref[1][bad[0]], mine[1][bad[0]])
+
+
+REF_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref/ref_harness is not built (make -f oracle/ref.mk where /root/reference exists)")
+@pytest.mark.parametrize("mode", ["pair", "single"])
+def test_dp_stages_equal_the_reference_engines_at_scale(tmp_path, mode):
+    """The DP stages ON, against the REFERENCE's own pipeline run at test time: oracle/_ref/ref_harness is the reference's host code (BWT ladder by its CPU twin,
+    routing, the DP engines' packers / seeding / merges / decode / OutputBuffer::ready / record writers compiled from /root/reference by oracle/ref.mk; the two DP
+    kernels behind them are the restatement that tests/test_gpu_dp_reference.py holds bit-identical to the reference's device code).  30,000 pairs 2 x 150 bp
+    (config C3's options; a tenth of the mates with an indel, a twentieth of the pairs damaged in both mates) -- twenty times fixture g7 -- and 40,000 single
+    reads: the three SAM files (two for single reads) must hold the same records."""
+    from test_gpu_dp_pipeline import by_read, records
+    w = tmp_path
+    sim = os.path.join(ROOT, "tools", "simulate.py")
+    ini = os.path.join(ROOT, "soap3-dp_amd", "host", "soap3-dp.ini")
+    if mode == "pair":
+        subprocess.check_call([sys.executable, sim, "--genome-len", "2000000", "--chroms", "3", "--n-runs", "4", "--repeats", "16", "--genome-seed", "55", "--fasta", str(w / "g.fa"),
+                               "--pairs", "30000", "--read-len", "150", "--read-seed", "5", "--fastq", str(w / "r_1.fq"), "--fastq2", str(w / "r_2.fq"),
+                               "--indel-frac", "0.10", "--damaged-frac", "0.05"])
+        files, opts = ["r_1.fq", "r_2.fq"], ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]
+    else:
+        subprocess.check_call([sys.executable, sim, "--genome-len", "2000000", "--chroms", "3", "--n-runs", "4", "--repeats", "16", "--genome-seed", "55", "--fasta", str(w / "g.fa"),
+                               "--reads", "40000", "--read-len", "100", "--read-seed", "6", "--fastq", str(w / "r_1.fq"), "--mix", "30", "20", "15", "15", "10", "10"])
+        files, opts = ["r_1.fq"], ["-L", "100", "-b", "2"]
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "soap3-dp_amd", "py"))
+    subprocess.check_call([sys.executable, "-m", "s3dp.fasta", str(w / "g.fa")], env=env, cwd=w)
+    ref = subprocess.run([REF_HARNESS, "sam", ini, mode, "g.fa.index"] + files + opts + ["-o", "ref"], cwd=w, capture_output=True, text=True, timeout=1800)
+    assert ref.returncode == 0, ref.stdout[-2000:] + ref.stderr[-2000:]
+    out = subprocess.run([BIN, mode, "g.fa.index"] + files + opts + ["-o", "mine"], cwd=w, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, S3DP_CHUNK_READS="16384"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    problems, seen = [], 0
+    for kind in ("gout.1", "dpout.1", "unpair"):
+        rp, mp = w / ("ref." + kind), w / ("mine." + kind)
+        if not os.path.exists(rp):
+            continue
+        ref_h, refc = records(open(rp).read())
+        mine_h, minec = records(open(mp).read()) if os.path.exists(mp) else ([], {})
+        seen += sum(refc.values())
+        if mine_h != ref_h:
+            problems.append("%s: header differs" % kind)
+        if minec != refc:
+            rb, mb = by_read(refc), by_read(minec)
+            diff = [k for k in set(rb) | set(mb) if sorted(rb.get(k, [])) != sorted(mb.get(k, []))]
+            problems.append("%s: %d of %d reads differ, e.g.\nREF  %s\nMINE %s" % (kind, len(diff), len(rb), rb.get(diff[0]), mb.get(diff[0])))
+    assert not problems, "; ".join(problems)
+    assert seen >= (60000 if mode == "pair" else 40000)
