@@ -119,4 +119,4 @@ def test_dp_stages_equal_the_reference_engines_at_scale(tmp_path, mode, extra):
             diff = [k for k in set(rb) | set(mb) if sorted(rb.get(k, [])) != sorted(mb.get(k, []))]
             problems.append("%s: %d of %d reads differ, e.g.\nREF  %s\nMINE %s" % (kind, len(diff), len(rb), rb.get(diff[0]), mb.get(diff[0])))
     assert not problems, "; ".join(problems)
-    assert seen >= (60000 if mode == "pair" else 40000) or "-h" in extra   # (unique best writes no record... it does: every read gets one; kept loose for -h 3)
+    assert seen >= (60000 if mode == "pair" else 40000)                    # every read has its record in one of the files
