@@ -120,3 +120,44 @@ def test_dp_stages_equal_the_reference_engines_at_scale(tmp_path, mode, extra):
             problems.append("%s: %d of %d reads differ, e.g.\nREF  %s\nMINE %s" % (kind, len(diff), len(rb), rb.get(diff[0]), mb.get(diff[0])))
     assert not problems, "; ".join(problems)
     assert seen >= (60000 if mode == "pair" else 40000)                    # every read has its record in one of the files
+
+
+@pytest.mark.parametrize("tag,opts", [("s3", ["-s", "3"]), ("h1_s2p", ["-s", "2", "-h", "1", "-p"])])
+def test_long_reads_equal_the_oracle_at_scale(workload, tmp_path, tag, opts):
+    """long-read mode (reads above 120 bases: the first 100 are searched, the rest verified on the device): 30,000 reads of 130-220 bases.  (Reads above 120 bases only:
+    the reference mixes up seed lengths when a run holds both kinds)"""
+    w = workload
+    sim = os.path.join(ROOT, "tools", "simulate.py")
+    subprocess.check_call([sys.executable, sim, "--genome-len", "3000000", "--chroms", "4", "--n-runs", "6", "--repeats", "24", "--genome-seed", "101", "--fasta", str(tmp_path / "g.fa"),
+                           "--reads", "30000", "--read-len", "220", "--var-len", "130", "220", "--read-seed", "11", "--fastq", str(w / "long.fq")])
+    env = dict(os.environ, S3DP_CHUNK_READS="8192")
+    out = subprocess.run([BIN, "single", "g.fa.index", "long.fq", "-L", "220"] + opts + ["-b", "2", "-o", "gpu_long_" + tag], cwd=w, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    ora = subprocess.run([oracle_tool(), "single", "g.fa.index", "long.fq", "-L", "220"] + opts + ["-o", "cpu_long_" + tag], cwd=w, capture_output=True, text=True, timeout=1800)
+    assert ora.returncode == 0, ora.stderr[-2000:]
+    mine_h, mine = sam_records(open(w / ("gpu_long_%s.gout.1" % tag)).read())
+    ref_h, ref = sam_records(open(w / ("cpu_long_%s.gout.1" % tag)).read())
+    assert mine_h == ref_h and len(ref) == 30000 and set(mine) == set(ref)
+    bad = [k for k in ref if ref[k] != mine[k]]
+    assert not bad, "%d of %d records differ, first:\n%s\n%s" % (len(bad), len(ref), ref[bad[0]], mine[bad[0]])
+
+
+def test_two_members_on_one_device_at_scale(workload):
+    """`-c 0,0`: two members of a group on the one GPU, chunks dealt to whichever is free, a set of output files each -- the union of the two files is the
+    oracle's file"""
+    w = workload
+    env = dict(os.environ, S3DP_CHUNK_READS="10000")
+    out = subprocess.run([BIN, "single", "g.fa.index", "se.fq", "-L", "100", "-s", "4", "-b", "2", "-c", "0,0", "-o", "gpu_two"], cwd=w, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    if not os.path.exists(w / "cpu_se_s4.gout.1"):
+        ora = subprocess.run([oracle_tool(), "single", "g.fa.index", "se.fq", "-L", "100", "-s", "4", "-o", "cpu_se_s4"], cwd=w, capture_output=True, text=True, timeout=1800)
+        assert ora.returncode == 0, ora.stderr[-2000:]
+    ref = sam_records(open(w / "cpu_se_s4.gout.1").read())[1]
+    mine = {}
+    for k in (1, 2):
+        part = sam_records(open(w / ("gpu_two.gout.%d" % k)).read())[1]
+        assert not (set(part) & set(mine))
+        mine.update(part)
+    assert len(mine) == len(ref) == 150000
+    bad = [k for k in ref if ref[k] != mine.get(k)]
+    assert not bad, "%d records differ, first:\n%s\n%s" % (len(bad), ref[bad[0]], mine.get(bad[0]))
