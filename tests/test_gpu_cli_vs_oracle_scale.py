@@ -161,3 +161,24 @@ def test_two_members_on_one_device_at_scale(workload):
     assert len(mine) == len(ref) == 150000
     bad = [k for k in ref if ref[k] != mine.get(k)]
     assert not bad, "%d records differ, first:\n%s\n%s" % (len(bad), ref[bad[0]], mine.get(bad[0]))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "soap3-dp-builder")), reason="the reference builder is not built (oracle/ref.mk)")
+def test_gpu_built_index_equals_the_reference_tools_at_scale(workload, tmp_path):
+    """the index files `python -m s3dp.fasta` builds on the GPU for the 3 Mbp genome of this module (four sequences, N runs, repeat families: the suffix sort
+    needs several rounds of prefix doubling) against the files the REFERENCE's soap3-dp-builder + BGS-Build write for the same FASTA file, run here: byte for
+    byte, the lookup tables included (the fixtures of tests/test_fasta_front_end.py are a tenth of this size)."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "soap3-dp_amd", "py"))
+    from s3dp import fasta
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    shutil.copy(os.path.join(refdir, "soap3-dp-builder.ini"), tmp_path / "soap3-dp-builder.ini")
+    shutil.copy(workload / "g.fa", tmp_path / "g.fa")
+    subprocess.check_call([os.path.join(refdir, "soap3-dp-builder"), "g.fa"], cwd=tmp_path, stdout=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(refdir, "BGS-Build"), "g.fa.index"], cwd=tmp_path, stdout=subprocess.DEVNULL)
+    seed = int(open(tmp_path / "g.fa.index.ann").readline().split()[2])          # (the reference stamps a seed into the first line; it decides nothing else)
+    out = str(tmp_path / "mine")
+    fasta.build_index_files(str(workload / "g.fa"), out, device="cuda", seed=seed, with_lkt=True)
+    for ext in (".ann", ".amb", ".tra", ".pac", ".bwt", ".rev.bwt", ".fmv.gpu", ".rev.fmv.gpu", ".sa", ".lkt", ".rev.lkt"):
+        a, b = open(out + ext, "rb").read(), open(str(tmp_path / "g.fa.index") + ext, "rb").read()
+        assert a == b, "%s differs from the reference tools' file (%d / %d bytes)" % (ext, len(a), len(b))
