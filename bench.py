@@ -414,6 +414,7 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False):
         hi.write_files(prefix, with_lkt=True)
         f1, f2 = os.path.join(work, "r1.fq"), os.path.join(work, "r2.fq")
         write_fastq_pairs(reads_np, L, f1, f2)
+        os.sync()                                                          # (files written a moment ago: their write-back is not the program's time)
         res["setup_s"] = time.perf_counter() - t0
         exe = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
         t0 = time.perf_counter()

@@ -77,7 +77,8 @@ def main():
             for i in range(b0, min(N, b0 + block)):
                 parts.append(b"@r%d\n" % i + letters[i].tobytes() + b"\n+\n" + qual + b"\n")
             f.write(b"".join(parts))
-    t_reads = time.time() - t
+    os.sync()                                  # (the index and read files were written seconds ago: with gigabytes of them still dirty in the page cache the
+    t_reads = time.time() - t                  #  program's first pinned allocations wait for the write-back -- up to a second that is the harness's, not the program's)
     env = dict(os.environ)
     if a.threads:
         env["S3DP_HOST_THREADS"] = str(a.threads)
@@ -171,7 +172,8 @@ def pairs_mode(a, codes, work, rng, t_index):
             fh[tag - 1].write(b"".join(b"@p%d/%d\n" % (b0 + i, tag) + txt[i].tobytes() + b"\n+\n" + qual + b"\n" for i in range(n)))
     for f in fh:
         f.close()
-    t_reads = time.time() - t
+    os.sync()                                  # (the index and read files were written seconds ago: with gigabytes of them still dirty in the page cache the
+    t_reads = time.time() - t                  #  program's first pinned allocations wait for the write-back -- up to a second that is the harness's, not the program's)
     env = dict(os.environ)
     if a.threads:
         env["S3DP_HOST_THREADS"] = str(a.threads)
