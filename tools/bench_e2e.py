@@ -52,6 +52,13 @@ def main():
     hi = builder.build_host_index(codes, device=dev)
     hi.write_files(os.path.join(work, "g.index"), with_lkt=True)
     t_index = time.time() - t
+    # this process built the index on the GPU and is about to start the command line as a child: what torch's allocator still caches of the build (tens of
+    # gigabytes) would be missing from the child's HBM -- it sizes its lookup tables by what is free
+    del hi
+    if dev != "cpu":
+        torch.cuda.empty_cache()
+        free, total = torch.cuda.mem_get_info()
+        print("[bench_e2e] HBM free before the command line starts: %.1f of %.1f GB" % (free / 1e9, total / 1e9), file=sys.stderr)
     if a.pairs:
         return pairs_mode(a, codes, work, rng, t_index)
     # reads: uniform start, strand 50/50, 0-4 substitutions (55/25/12/5/3 %), quality 'I'
