@@ -417,6 +417,10 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False):
         os.sync()                                                          # (files written a moment ago: their write-back is not the program's time)
         res["setup_s"] = time.perf_counter() - t0
         exe = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
+        # (the command line runs as a child BESIDE this process's resident index: what torch's allocator caches on top of that would be missing from the
+        #  child's HBM, and it sizes its lookup tables by what is free)
+        import torch
+        torch.cuda.empty_cache()
         t0 = time.perf_counter()
         out = subprocess.run([exe, "pair", prefix, f1, f2, "-L", str(L), "-u", "500", "-v", "1", "-b", "2", "-o", os.path.join(work, "out")], capture_output=True, text=True)
         wall = time.perf_counter() - t0
@@ -429,6 +433,7 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False):
         counts = {k: int(v) for k, v in re.findall(r"\[Main\] (Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|"
                                                    r"Pairs left without a proper pairing|Overall number of reads aligned): (\d+)", txt)}
         stage = re.search(r"DP stages time :\s+[0-9.]+ seconds \((.*)\)", txt)
+        ltc = re.search(r"Lookup tables in device memory : (\d+) characters", txt)
         devl = re.search(r"Device time : BWT stages ([0-9.]+) ms \(search kernels ([0-9.]+) ms\), DP kernels ([0-9.]+) ms, (\d+) problems, (\d+) cells, ([0-9.]+) GCUPS", txt)
         align_s = ph.get("Alignment + output time", wall)
         e2e = {"wall_s": wall, "phases_s": ph, "counts": counts, "dp_stage_seconds": stage.group(1) if stage else None,
@@ -439,10 +444,12 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False):
         if devl:
             dp_ms, cells = float(devl.group(3)), int(devl.group(5))
             e2e["device_ms"] = {"bwt_stages": float(devl.group(1)), "bwt_search_kernels": float(devl.group(2)), "dp_kernels": dp_ms}
-            # vector-ALU peak for the DP's cell update: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s; the fill kernel spends about 21 vector
-            # instructions per 64-cell step -> a ceiling of about 1870 G cell updates per second
+            # vector-ALU peak for the DP's cell update: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s; the paired fill kernel spends about 31 vector
+            # instructions per step of 64 lanes x 2 cells = 15.5 per 64 cells -> a ceiling of about 2540 G cell updates per second
             e2e["dp"] = {"problems": int(devl.group(4)), "cells": cells, "GCUPS": cells / (dp_ms / 1e3) / 1e9 if dp_ms > 0 else 0.0,
-                         "valu_ceiling_GCUPS": 256 * 4 * 16 * 2.4 / 21.0, "frac_of_valu_ceiling": (cells / (dp_ms / 1e3) / 1e9) / (256 * 4 * 16 * 2.4 / 21.0) if dp_ms > 0 else 0.0}
+                         "valu_ceiling_GCUPS": 256 * 4 * 16 * 2.4 / 15.5, "frac_of_valu_ceiling": (cells / (dp_ms / 1e3) / 1e9) / (256 * 4 * 16 * 2.4 / 15.5) if dp_ms > 0 else 0.0}
+        if ltc:
+            e2e["lookup_chars"] = int(ltc.group(1))
         res["end_to_end"] = e2e
         # ---- truth check of the three SAM files: where did every mate land? ----
         import pandas as pd

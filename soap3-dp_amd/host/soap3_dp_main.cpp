@@ -792,6 +792,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         shared.devices = devices;
         shared.loaded = true;
         printf("[Main] Finished copying index into device (GPU).\n");
+        // (the long lookup tables are sized by the HBM that is free: 16-mers want 103 GB; a run beside another process's allocations may get 15- or 14-mers --
+        //  the same records, more rank queries per read)
+        printf("[Main] Lookup tables in device memory : %d characters\n", s3_index_lookup_chars(s3_group_index(shared.grp, 0)));
     } else devices = shared.devices;                                           // (later jobs of a list run on the devices the index is on)
     s3_group *grp = shared.grp;
     const int nMembers = (int)devices.size();

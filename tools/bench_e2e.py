@@ -103,11 +103,12 @@ def main():
     aligned = int(re.search(r"Overall number of reads aligned: (\d+)", out.stdout).group(1))
     sam_bytes = sum(os.path.getsize(os.path.join(work, f)) for f in os.listdir(work) if f.startswith("out.gout."))
     sl = re.search(r"\[Main\] Stream loop time : (.*)", out.stdout)
+    ltc = re.search(r"Lookup tables in device memory : (\d+) characters", out.stdout)
     dv = re.search(r"\[Main\] Device time : (.*)", out.stdout)
     m = re.search(r"\[Main\] Read load time :\s+([0-9.]+) seconds \(loader", out.stdout)
     res = {"mode": "default (DP on)" if a.default_mode else "-s %d (DP off)" % a.mismatch, "output": "BAM (-b 3)" if a.bam else "SAM (-b 2)", "genome_bp": a.genome_bp, "repeat_frac": a.repeat_frac, "devices": a.devices or "0", "loader_thread_s": float(m.group(1)) if m else None, "reads": N, "read_len": L, "max_mismatch": a.mismatch, "host_threads": a.threads or os.cpu_count(),
            "index_build_and_write_s": t_index, "fastq_write_s": t_reads, "wall_s_total": wall, "phases_s": ph, "aligned_reads": aligned,
-           "stream_loop": sl.group(1) if sl else None, "device_time": dv.group(1) if dv else None,
+           "stream_loop": sl.group(1) if sl else None, "device_time": dv.group(1) if dv else None, "lookup_chars": int(ltc.group(1)) if ltc else None,
            "sam_bytes": sam_bytes, "fastq_bytes": os.path.getsize(fq),
            "reads_per_s_wall_incl_index_load": N / wall,
            # the command line streams: reading, aligning and writing overlap inside "Alignment + output time" (it starts when the index is resident)
