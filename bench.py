@@ -348,7 +348,7 @@ def write_fastq_pairs(reads2d_np, L, path1, path2):
         rec.tofile(path)
 
 
-def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False):
+def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cli=False):
     """BASELINE.json configs[2] as far as one GPU and the time budget of a default run go: n_pairs 2 x 150 bp pairs on the benchmark genome,
     `pair -u 500 -v 1`, DP stages ON, end to end through the drop-in command line (the DP stages are driven by its host code), plus the resident BWT
     stage of the same pairs through the library with the oracle check on a sample.  Reports pairs/s, the stages' wall and device times, the BWT stage's
@@ -406,87 +406,94 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False):
         res["oracle_check"] = {"pairs": m, "what": "the BWT stage's pair results (phase, best pairing, strands, mismatches, number of pairings) against the CPU oracle", "bit_exact": bool(ok)}
     finally:
         b.close()
-    # ---- end to end: the command line with the DP stages on ----
-    work = workdir or tempfile.mkdtemp(prefix="s3dp_c3_", dir="/tmp")
-    try:
-        t0 = time.perf_counter()
-        prefix = os.path.join(work, "g.index")
-        hi.write_files(prefix, with_lkt=True)
-        f1, f2 = os.path.join(work, "r1.fq"), os.path.join(work, "r2.fq")
-        write_fastq_pairs(reads_np, L, f1, f2)
-        os.sync()                                                          # (files written a moment ago: their write-back is not the program's time)
-        res["setup_s"] = time.perf_counter() - t0
-        exe = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
-        # (the command line runs as a child BESIDE this process's resident index: what torch's allocator caches on top of that would be missing from the
-        #  child's HBM, and it sizes its lookup tables by what is free)
-        import torch
-        torch.cuda.empty_cache()
-        t0 = time.perf_counter()
-        out = subprocess.run([exe, "pair", prefix, f1, f2, "-L", str(L), "-u", "500", "-v", "1", "-b", "2", "-o", os.path.join(work, "out")], capture_output=True, text=True)
-        wall = time.perf_counter() - t0
-        if out.returncode != 0:
-            raise RuntimeError("soap3-dp pair failed: " + out.stderr[-500:])
-        txt = out.stdout
-        if echo:
-            log("command line said:\n" + txt + out.stderr)
-        ph = {k: float(v) for k, v in re.findall(r"\[Main\] (Loading time|Read load time|Alignment \+ output time|Total elapsed time|DP stages time) :\s+([0-9.]+)", txt)}
-        counts = {k: int(v) for k, v in re.findall(r"\[Main\] (Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|"
-                                                   r"Pairs left without a proper pairing|Overall number of reads aligned): (\d+)", txt)}
-        stage = re.search(r"DP stages time :\s+[0-9.]+ seconds \((.*)\)", txt)
-        ltc = re.search(r"Lookup tables in device memory : (\d+) characters", txt)
-        devl = re.search(r"Device time : BWT stages ([0-9.]+) ms \(search kernels ([0-9.]+) ms\), DP kernels ([0-9.]+) ms, (\d+) problems, (\d+) cells, ([0-9.]+) GCUPS", txt)
-        align_s = ph.get("Alignment + output time", wall)
-        e2e = {"wall_s": wall, "phases_s": ph, "counts": counts, "dp_stage_seconds": stage.group(1) if stage else None,
-               "M_pairs_per_s_reads_in_sam_out": n_pairs / max(align_s, ph.get("Read load time", 0.0)) / 1e6}
-        ch = re.search(r"Chunk loop time : alignment calls ([0-9.]+), fetching results ([0-9.]+), formatting \+ writing ([0-9.]+), DP stages ([0-9.]+)", txt)
-        if ch:
-            e2e["chunk_loop_s"] = {"alignment_calls": float(ch.group(1)), "fetching_results": float(ch.group(2)), "formatting_and_writing": float(ch.group(3)), "dp_stages": float(ch.group(4))}
-        if devl:
-            dp_ms, cells = float(devl.group(3)), int(devl.group(5))
-            e2e["device_ms"] = {"bwt_stages": float(devl.group(1)), "bwt_search_kernels": float(devl.group(2)), "dp_kernels": dp_ms}
-            # vector-ALU peak for the DP's cell update: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s; the paired fill kernel spends about 31 vector
-            # instructions per step of 64 lanes x 2 cells = 15.5 per 64 cells -> a ceiling of about 2540 G cell updates per second
-            e2e["dp"] = {"problems": int(devl.group(4)), "cells": cells, "GCUPS": cells / (dp_ms / 1e3) / 1e9 if dp_ms > 0 else 0.0,
-                         "valu_ceiling_GCUPS": 256 * 4 * 16 * 2.4 / 15.5, "frac_of_valu_ceiling": (cells / (dp_ms / 1e3) / 1e9) / (256 * 4 * 16 * 2.4 / 15.5) if dp_ms > 0 else 0.0}
-        if ltc:
-            e2e["lookup_chars"] = int(ltc.group(1))
-        res["end_to_end"] = e2e
-        # ---- truth check of the three SAM files: where did every mate land? ----
-        import pandas as pd
-        seen = np.zeros(2 * n_pairs, dtype=bool)
-        at_truth = np.zeros(2 * n_pairs, dtype=bool)
-        mapped = np.zeros(2 * n_pairs, dtype=bool)
-        by_file = {}
-        for name in ("out.gout.1", "out.dpout.1", "out.unpair"):
-            p = os.path.join(work, name)
-            if not os.path.exists(p) or os.path.getsize(p) == 0:
-                continue
-            cut = subprocess.run("grep -v '^@' %s | cut -f1,2,4" % p, shell=True, capture_output=True)
-            if not cut.stdout:
-                continue
-            import io
-            df = pd.read_csv(io.BytesIO(cut.stdout), sep="\t", header=None, names=["q", "flag", "pos"], dtype={"q": np.int64, "flag": np.int64, "pos": np.int64})
-            prim = df[(df.flag & 0x900) == 0]
-            row = prim.q.values * 2 + ((prim.flag.values & 0x80) != 0)
-            isMapped = (prim.flag.values & 4) == 0
-            good = isMapped & (np.abs(prim.pos.values - 1 - tpos[row]) <= 12) & ((((prim.flag.values & 0x10) != 0).astype(np.uint8)) == tstrand[row])
-            seen[row] = True
-            mapped[row] |= isMapped
-            at_truth[row] |= good
-            by_file[name] = {"records": int(len(df)), "mates": int(len(prim)), "mates_mapped": int(isMapped.sum()), "mates_at_simulated_place": int(good.sum())}
-        both = at_truth[0::2] & at_truth[1::2]
-        res["truth_check"] = {"pairs": n_pairs, "mates_reported": int(seen.sum()), "mates_mapped": int(mapped.sum()), "mates_at_simulated_place": int(at_truth.sum()),
-                              "pairs_with_both_mates_at_simulated_place": int(both.sum()),
-                              "mates_with_indel": int(tindel.sum()), "mates_with_indel_at_simulated_place": int((at_truth & tindel).sum()),
-                              "by_file": by_file,
-                              "is": "primary record of every mate against the simulated place (tolerance 12 bases for clips and indels at the ends, strand must match); "
-                                    "on a genome that is half repeats a mate inside a repeat family has equally good places elsewhere, so this is a rate, "
-                                    "not a pass / fail -- all mates must be reported",
-                              "ok": bool(seen.all())}
-    finally:
-        if not workdir:
-            shutil.rmtree(work, ignore_errors=True)
-    return res
+    # (the command-line part is a function of its own: bench.py's main run calls it after its own resident index is closed -- two copies of a 120 GB index
+    #  on one GPU made the child's start-up and teardown a second longer than when it has the device to itself, which is how it is used)
+    def cli_part():
+        # ---- end to end: the command line with the DP stages on ----
+        work = workdir or tempfile.mkdtemp(prefix="s3dp_c3_", dir="/tmp")
+        try:
+            t0 = time.perf_counter()
+            prefix = os.path.join(work, "g.index")
+            hi.write_files(prefix, with_lkt=True)
+            f1, f2 = os.path.join(work, "r1.fq"), os.path.join(work, "r2.fq")
+            write_fastq_pairs(reads_np, L, f1, f2)
+            os.sync()                                                          # (files written a moment ago: their write-back is not the program's time)
+            res["setup_s"] = time.perf_counter() - t0
+            exe = os.path.join(ROOT, "soap3-dp_amd", "soap3-dp")
+            # (the command line runs as a child BESIDE this process's resident index: what torch's allocator caches on top of that would be missing from the
+            #  child's HBM, and it sizes its lookup tables by what is free)
+            import torch
+            torch.cuda.empty_cache()
+            t0 = time.perf_counter()
+            out = subprocess.run([exe, "pair", prefix, f1, f2, "-L", str(L), "-u", "500", "-v", "1", "-b", "2", "-o", os.path.join(work, "out")], capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if out.returncode != 0:
+                raise RuntimeError("soap3-dp pair failed: " + out.stderr[-500:])
+            txt = out.stdout
+            if echo:
+                log("command line said:\n" + txt + out.stderr)
+            ph = {k: float(v) for k, v in re.findall(r"\[Main\] (Loading time|Read load time|Alignment \+ output time|Total elapsed time|DP stages time) :\s+([0-9.]+)", txt)}
+            counts = {k: int(v) for k, v in re.findall(r"\[Main\] (Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|"
+                                                       r"Pairs left without a proper pairing|Overall number of reads aligned): (\d+)", txt)}
+            stage = re.search(r"DP stages time :\s+[0-9.]+ seconds \((.*)\)", txt)
+            ltc = re.search(r"Lookup tables in device memory : (\d+) characters", txt)
+            devl = re.search(r"Device time : BWT stages ([0-9.]+) ms \(search kernels ([0-9.]+) ms\), DP kernels ([0-9.]+) ms, (\d+) problems, (\d+) cells, ([0-9.]+) GCUPS", txt)
+            align_s = ph.get("Alignment + output time", wall)
+            e2e = {"wall_s": wall, "phases_s": ph, "counts": counts, "dp_stage_seconds": stage.group(1) if stage else None,
+                   "M_pairs_per_s_reads_in_sam_out": n_pairs / max(align_s, ph.get("Read load time", 0.0)) / 1e6}
+            ch = re.search(r"Chunk loop time : alignment calls ([0-9.]+), fetching results ([0-9.]+), formatting \+ writing ([0-9.]+), DP stages ([0-9.]+)", txt)
+            if ch:
+                e2e["chunk_loop_s"] = {"alignment_calls": float(ch.group(1)), "fetching_results": float(ch.group(2)), "formatting_and_writing": float(ch.group(3)), "dp_stages": float(ch.group(4))}
+            if devl:
+                dp_ms, cells = float(devl.group(3)), int(devl.group(5))
+                e2e["device_ms"] = {"bwt_stages": float(devl.group(1)), "bwt_search_kernels": float(devl.group(2)), "dp_kernels": dp_ms}
+                # vector-ALU peak for the DP's cell update: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s; the paired fill kernel spends about 31 vector
+                # instructions per step of 64 lanes x 2 cells = 15.5 per 64 cells -> a ceiling of about 2540 G cell updates per second
+                e2e["dp"] = {"problems": int(devl.group(4)), "cells": cells, "GCUPS": cells / (dp_ms / 1e3) / 1e9 if dp_ms > 0 else 0.0,
+                             "valu_ceiling_GCUPS": 256 * 4 * 16 * 2.4 / 15.5, "frac_of_valu_ceiling": (cells / (dp_ms / 1e3) / 1e9) / (256 * 4 * 16 * 2.4 / 15.5) if dp_ms > 0 else 0.0}
+            if ltc:
+                e2e["lookup_chars"] = int(ltc.group(1))
+            res["end_to_end"] = e2e
+            # ---- truth check of the three SAM files: where did every mate land? ----
+            import pandas as pd
+            seen = np.zeros(2 * n_pairs, dtype=bool)
+            at_truth = np.zeros(2 * n_pairs, dtype=bool)
+            mapped = np.zeros(2 * n_pairs, dtype=bool)
+            by_file = {}
+            for name in ("out.gout.1", "out.dpout.1", "out.unpair"):
+                p = os.path.join(work, name)
+                if not os.path.exists(p) or os.path.getsize(p) == 0:
+                    continue
+                cut = subprocess.run("grep -v '^@' %s | cut -f1,2,4" % p, shell=True, capture_output=True)
+                if not cut.stdout:
+                    continue
+                import io
+                df = pd.read_csv(io.BytesIO(cut.stdout), sep="\t", header=None, names=["q", "flag", "pos"], dtype={"q": np.int64, "flag": np.int64, "pos": np.int64})
+                prim = df[(df.flag & 0x900) == 0]
+                row = prim.q.values * 2 + ((prim.flag.values & 0x80) != 0)
+                isMapped = (prim.flag.values & 4) == 0
+                good = isMapped & (np.abs(prim.pos.values - 1 - tpos[row]) <= 12) & ((((prim.flag.values & 0x10) != 0).astype(np.uint8)) == tstrand[row])
+                seen[row] = True
+                mapped[row] |= isMapped
+                at_truth[row] |= good
+                by_file[name] = {"records": int(len(df)), "mates": int(len(prim)), "mates_mapped": int(isMapped.sum()), "mates_at_simulated_place": int(good.sum())}
+            both = at_truth[0::2] & at_truth[1::2]
+            res["truth_check"] = {"pairs": n_pairs, "mates_reported": int(seen.sum()), "mates_mapped": int(mapped.sum()), "mates_at_simulated_place": int(at_truth.sum()),
+                                  "pairs_with_both_mates_at_simulated_place": int(both.sum()),
+                                  "mates_with_indel": int(tindel.sum()), "mates_with_indel_at_simulated_place": int((at_truth & tindel).sum()),
+                                  "by_file": by_file,
+                                  "is": "primary record of every mate against the simulated place (tolerance 12 bases for clips and indels at the ends, strand must match); "
+                                        "on a genome that is half repeats a mate inside a repeat family has equally good places elsewhere, so this is a rate, "
+                                        "not a pass / fail -- all mates must be reported",
+                                  "ok": bool(seen.all())}
+        finally:
+            if not workdir:
+                shutil.rmtree(work, ignore_errors=True)
+    
+        return res
+    if defer_cli:
+        return res, cli_part
+    return cli_part()
 
 
 def se150_leg(s3dp, ix, hi, codes, dev, n_reads):
@@ -538,7 +545,7 @@ def extras(s3dp, ix, hi, codes, dev, rank, a):
     wpq = s3dp.word_per_query(L)
     if a.c3_pairs > 0:
         try:
-            res["c3_pairs"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs)
+            res["c3_pairs"], res["_c3_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs, defer_cli=True)
         except Exception as e:
             res["c3_pairs"] = {"error": repr(e)}
         torch.cuda.empty_cache()
@@ -1042,6 +1049,14 @@ def main():
     import gc
     gc.collect()
     torch.cuda.empty_cache()
+    c3_cli = out.get("extras", {}).pop("_c3_cli", None) if isinstance(out.get("extras"), dict) else None
+    if c3_cli is not None:
+        try:
+            c3_cli()                                                    # fills extras.c3_pairs.end_to_end and .truth_check
+        except Exception as e:
+            out["extras"]["c3_pairs"]["end_to_end"] = {"error": repr(e)}
+        gc.collect()
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and a.uniform and a.repeat_frac > 0:
         try:
             a2 = argparse.Namespace(**vars(a))
