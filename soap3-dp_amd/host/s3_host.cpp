@@ -1152,22 +1152,29 @@ void SamWriter::singleAnswer(const ReadSet &rs, uint32_t r, uint32_t pos, uint8_
 
 void SamWriter::emit(const ReadSet &rs, const Rec &c)
 {
-    std::string line = rs.names[c.r];
-    line.push_back('\t'); line += std::to_string(c.flag);
-    line.push_back('\t'); line += c.tid < 0 ? std::string("*") : ix.seqName[c.tid];
-    line.push_back('\t'); line += std::to_string(c.pos0 + 1);
-    line.push_back('\t'); line += std::to_string(c.mapq);
-    line.push_back('\t'); line += c.cigar.empty() ? std::string("*") : c.cigar;
+    // (built where it goes -- at the end of the thread's buffer, or in the kept string -- without temporaries: as singleEnd builds its records)
+    std::string &line = sink ? *sink : scratch;
+    if (!sink) line.clear();
+    line += rs.names[c.r];
+    line.push_back('\t'); appendUInt(line, (unsigned)c.flag);
+    line.push_back('\t'); if (c.tid < 0) line.push_back('*'); else line += ix.seqName[c.tid];
+    line.push_back('\t'); appendUInt(line, (unsigned long long)(c.pos0 + 1));
+    line.push_back('\t'); appendUInt(line, (unsigned)c.mapq);
+    line.push_back('\t'); if (c.cigar.empty()) line.push_back('*'); else line += c.cigar;
     line.push_back('\t');
-    if (c.mtid < 0) line += "*";
-    else if (c.tid >= 0 && c.mtid == c.tid) line += "=";
+    if (c.mtid < 0) line.push_back('*');
+    else if (c.tid >= 0 && c.mtid == c.tid) line.push_back('=');
     else line += ix.seqName[c.mtid];
-    line.push_back('\t'); line += std::to_string(c.mpos0 + 1);
-    line.push_back('\t'); line += std::to_string(c.isize);
+    line.push_back('\t'); appendUInt(line, (unsigned long long)(c.mpos0 + 1));
+    line.push_back('\t');
+    if (c.isize < 0) { line.push_back('-'); appendUInt(line, (unsigned long long)(-c.isize)); } else appendUInt(line, (unsigned long long)c.isize);
     line.push_back('\t');
     seqAndQual(rs, c.r, c.negative, line);
-    line += "\tRG:Z:" + opt.readGroup + c.tags + "\n";
-    put(line);
+    line += "\tRG:Z:";
+    line += opt.readGroup;
+    line += c.tags;
+    line.push_back('\n');
+    if (sink) nRecords++; else put(line);
 }
 
 int bwaLikeSingle(int x0, int x1, const int *gLogN)                // bwaLikeSingleQualScore, BGS-IO.cpp:2310
@@ -1207,8 +1214,12 @@ void SamWriter::properPair(const ReadSet &rs, uint32_t r1, uint32_t r2, const s3
     const int trim2 = chrAndPosChecked(len2, P.bestA2, tp2, chr2, &cig2);
     const bool neg1 = P.bestS1 == 2, neg2 = P.bestS2 == 2;
     int avg1 = 20, avg2 = 20;
-    mdString(ix, &rs.codes[(size_t)r1 * rs.maxReadLength], &rs.quals[(size_t)r1 * rs.maxReadLength], len1, P.bestA1, neg1, P.bestM1, trim1, md1, avg1);
-    mdString(ix, &rs.codes[(size_t)r2 * rs.maxReadLength], &rs.quals[(size_t)r2 * rs.maxReadLength], len2, P.bestA2, neg2, P.bestM2, trim2, md2, avg2);
+    // (the MD string: printed with -p, its mismatch letters counted for a trimmed read, its qualities averaged for the non-BWA MAPQ -- otherwise nobody looks at
+    //  it, and it costs a walk over the read against the text; as in singleEnd)
+    if (opt.printMDNM || !opt.bwaLikeScore || (trim1 && P.bestM1))
+        mdString(ix, &rs.codes[(size_t)r1 * rs.maxReadLength], &rs.quals[(size_t)r1 * rs.maxReadLength], len1, P.bestA1, neg1, P.bestM1, trim1, md1, avg1);
+    if (opt.printMDNM || !opt.bwaLikeScore || (trim2 && P.bestM2))
+        mdString(ix, &rs.codes[(size_t)r2 * rs.maxReadLength], &rs.quals[(size_t)r2 * rs.maxReadLength], len2, P.bestA2, neg2, P.bestM2, trim2, md2, avg2);
     int mis1 = P.bestM1, mis2 = P.bestM2;
     if (trim1 && mis1) { mis1 = 0; for (char c : md1) mis1 += c > '9'; }
     if (trim2 && mis2) { mis2 = 0; for (char c : md2) mis2 += c > '9'; }
