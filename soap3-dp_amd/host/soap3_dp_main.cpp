@@ -187,6 +187,20 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
 // (all-best + SAM runs it as all-valid, alignment.cu:2563): sorted by position, one result per position; then best-only for -h 3 / 4 --------------
 // parallelOut != NULL: the runs of a batch are handed to `emit` by all host threads at once, each with a writer whose records land in parallelOut in run
 // order; NULL: one call after the other (the writer argument is then a dummy that must not be used).
+// number of seeds of a read of a given length in a DP stage (s3_seed_positions, asked per read when the seed batches are cut): the answer depends on the
+// stage and the length only, and a chunk asks a hundred thousand times
+static int seedCountOf(int stage, int readLength)
+{
+    thread_local int cachedStage = -1, cachedLength = -1, cachedCount = 0;
+    if (stage != cachedStage || readLength != cachedLength) {
+        int sl = 0, sp[128];
+        cachedCount = 0;
+        s3_seed_positions(stage, readLength, &sl, sp, &cachedCount);
+        cachedStage = stage; cachedLength = readLength;
+    }
+    return cachedCount;
+}
+
 template <class Emit>
 static bool singleDpRuns(const HostIndex &hix, const SamOptions &so, FILE *parallelOut, s3_batch *b, s3_batch *seedBatch, s3_dp *dp, const uint32_t *lens,
                          const std::vector<uint32_t> &todo, const s3_dp_stage_params &dpPar, int alignmentType, Emit &&emit, std::string &err)
@@ -195,8 +209,7 @@ static bool singleDpRuns(const HostIndex &hix, const SamOptions &so, FILE *paral
     while (at < todo.size()) {
         size_t end = at, nSeeds = 0;
         while (end < todo.size()) {
-            int sl = 0, num = 0, sp[128];
-            s3_seed_positions(S3_STAGE_SINGLE_DP, (int)lens[todo[end]], &sl, sp, &num);
+            const int num = seedCountOf(S3_STAGE_SINGLE_DP, (int)lens[todo[end]]);
             if (nSeeds + (size_t)num > 262144) break;
             nSeeds += (size_t)num;
             end++;
@@ -532,9 +545,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             for (size_t at = 0; at < todo.size();) {
                 size_t m = 0, nSeeds = 0;                                         // as many pairs as the seed batch holds seeds for
                 while (at + m < todo.size()) {
-                    int sl = 0, n1 = 0, n2 = 0, sp[128];
-                    s3_seed_positions(stageId, (int)lens[todo[at + m]], &sl, sp, &n1);
-                    s3_seed_positions(stageId, (int)lens[todo[at + m] + 1], &sl, sp, &n2);
+                    const int n1 = seedCountOf(stageId, (int)lens[todo[at + m]]), n2 = seedCountOf(stageId, (int)lens[todo[at + m] + 1]);
                     if (nSeeds + (size_t)(n1 + n2) > 262144) break;
                     nSeeds += (size_t)(n1 + n2);
                     m++;
