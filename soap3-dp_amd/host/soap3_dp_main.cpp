@@ -162,7 +162,8 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
     for (int t = 0; t < T; t++) { off[(size_t)t + 1] = off[(size_t)t] + (long long)buf[(size_t)t].s.size(); aligned += al[(size_t)t]; }
     fseeko(out, (off_t)off[(size_t)T], SEEK_SET);
     os.pending[gen] = std::thread([fd, T, off, &buf] {
-        const int W = T < 8 ? T : 8;
+        static const int maxWriters = getenv("S3DP_WRITE_THREADS") && atoi(getenv("S3DP_WRITE_THREADS")) > 0 ? atoi(getenv("S3DP_WRITE_THREADS")) : 8;
+        const int W = T < maxWriters ? T : maxWriters;
         std::vector<std::thread> wr;
         std::atomic<bool> bad(false);
         for (int w = 0; w < W; w++) wr.emplace_back([&, w] {

@@ -13,6 +13,10 @@ run() {
     env "$@" soap3-dp_amd/soap3-dp single $W/g.index $W/reads.fq -L 100 -s 4 -b 2 -o $W/out 2>&1 | grep "Alignment + output\|Device time\|Stream loop" | sed "s/^/$tag run $k: /"
   done
 }
+if [ "$3" = "writers" ]; then
+  for t in 8 16 4 8 16; do run writers$t S3DP_WRITE_THREADS=$t; done
+  exit 0
+fi
 if [ "$3" = "buffers" ]; then
   run default A=1
   run big S3DP_REC_PER_READ=64 S3DP_OCC_PER_READ=48
