@@ -438,7 +438,23 @@ static inline void fastName(const FastRec &R, int maxLenReadName, std::string &n
 static inline void fillRead(const char *seq, uint32_t len, const char *qual, uint32_t nq, uint32_t maxReadLength, uint32_t wpq, const unsigned char *charMap,
                             int qualityConstant, uint32_t *dst, uint8_t *cd, char *qd)
 {
-    for (uint32_t i = 0; i < len; i++) cd[i] = charMap[(unsigned char)seq[i]];
+    uint32_t i0 = 0;
+#ifdef __SSSE3__
+    {
+        // the character table of fillCharMap in registers: case folded by clearing bit 5 (a letter and its lower-case form are the only two bytes that fold
+        // onto it), C -> 1, G / N -> 2, T / U -> 3, everything else 0
+        const __m128i fold = _mm_set1_epi8((char)0xDF), one = _mm_set1_epi8(1), two = _mm_set1_epi8(2), three = _mm_set1_epi8(3);
+        const __m128i cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cN = _mm_set1_epi8('N'), cT = _mm_set1_epi8('T'), cU = _mm_set1_epi8('U');
+        for (; i0 + 16 <= len; i0 += 16) {
+            const __m128i x = _mm_and_si128(_mm_loadu_si128((const __m128i *)(seq + i0)), fold);
+            const __m128i c = _mm_and_si128(_mm_cmpeq_epi8(x, cC), one);
+            const __m128i g = _mm_and_si128(_mm_or_si128(_mm_cmpeq_epi8(x, cG), _mm_cmpeq_epi8(x, cN)), two);
+            const __m128i t = _mm_and_si128(_mm_or_si128(_mm_cmpeq_epi8(x, cT), _mm_cmpeq_epi8(x, cU)), three);
+            _mm_storeu_si128((__m128i *)(cd + i0), _mm_or_si128(_mm_or_si128(c, g), t));
+        }
+    }
+#endif
+    for (uint32_t i = i0; i < len; i++) cd[i] = charMap[(unsigned char)seq[i]];
     memset(cd + len, 0, maxReadLength - len);
     const uint32_t k = nq < len ? nq : len;
     for (uint32_t i = 0; i < k; i++) qd[i] = (char)(qual[i] - qualityConstant);
