@@ -197,9 +197,7 @@ int s3i::dpFetchPatterns(s3_dp *h, uint32_t n, std::vector<uint8_t> &pat, uint32
 //   P <readLen> <windowLen> <clipLt> <clipRt> <anchorL> <anchorR> <cutoff> <read> <window> | <score> <hitLoc> <ties> <ops>
 static FILE *dpDumpFile()
 {
-    static FILE *f = nullptr;
-    static bool tried = false;
-    if (!tried) { const char *p = getenv("S3DP_DUMP_DP"); f = p && *p ? fopen(p, "w") : nullptr; tried = true; }
+    static FILE *f = [] { const char *p = getenv("S3DP_DUMP_DP"); return p && *p ? fopen(p, "w") : (FILE *)nullptr; }();     // (opened once, whichever thread comes first)
     return f;
 }
 
@@ -231,6 +229,7 @@ int s3i::dpDump(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL
     HIPCHK(hipMemcpyAsync(cnt.data(), h->dCnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(pat.data(), h->dPattern, pat.size(), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    flockfile(f);                                                       // (two aligners may dump at once: the command line runs two DP stage threads)
     for (uint32_t t = 0; t < n; t++) {
         const size_t rb = (size_t)(t >> 5) * (wR << 5) + (t & 31), db = (size_t)(t >> 5) * (wD << 5) + (t & 31);
         fprintf(f, "P %u %u %u %u %u %u %d ", rl[t], dl[t], cl[t], hasClipRt && t < h->dumpClipRt.size() ? h->dumpClipRt[t] : 0u, al[t], ar[t], cut[t]);
@@ -248,6 +247,7 @@ int s3i::dpDump(s3_dp *h, uint32_t n, bool hasClipLt, bool hasClipRt, bool hasAL
         fputc('\n', f);
     }
     fflush(f);
+    funlockfile(f);
     return S3_OK;
 }
 

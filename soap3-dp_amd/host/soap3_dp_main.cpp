@@ -73,6 +73,7 @@ static void parseIni(const std::string &file, Ini &ini)
 //  appending a dozen fields per record to neighbouring strings ran at a quarter of their speed -- 0.28 us per record per thread with the padding, 1.24 without)
 struct alignas(128) OutBuffer { std::string s; };
 struct OutState {
+    std::mutex use;                                   // one formatting call (or direct writer) per file at a time: two DP workers share .dpout / .unpair
     std::vector<OutBuffer> buf[2];
     std::thread pending[2];
     int gen = 0;
@@ -114,6 +115,7 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
     // the buffers live as long as the output file: a chunk of 4 Mi reads is more than a gigabyte of SAM, and touching that much fresh memory from all
     // host threads at once for every chunk is page faults on one address space's lock
     OutState &os = outState(out);
+    std::lock_guard<std::mutex> oneAtATime(os.use);
     const int gen = os.gen;
     os.gen ^= 1;
     if (os.pending[gen].joinable()) os.pending[gen].join();                   // the write of the call before the last one used these buffers
@@ -758,7 +760,8 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         if (!enableDP && numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;
     }
     // the DP aligners' traceback tables are a few gigabytes per device (20 ms per GB to allocate): made while the index is read and uploaded
-    struct PreDp { s3_dp *dp = nullptr, *dpHalf = nullptr; std::string err; };
+    constexpr int kDpWorkers = 2;                                             // DP stage threads per device (each with its own aligners and seed batch)
+    struct PreDp { s3_dp *dp[kDpWorkers] = {nullptr, nullptr}, *dpHalf[kDpWorkers] = {nullptr, nullptr}; std::string err; };
     const std::vector<int> &dpDevices = shared.loaded ? shared.devices : devices;
     std::vector<PreDp> preDp(dpDevices.size());
     std::vector<std::thread> preDpThreads;
@@ -786,10 +789,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             int scheme = 1, tableLen = 0, patLen = 0;
             s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
             s3_dp_config(maxRL, maxDNA, wantScheme(maxRL, maxDNA), &scheme, &tableLen, &patLen);
-            if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &preDp[m].dp) != S3_OK) { preDp[m].err = s3_last_error(); return; }
+            for (int w = 0; w < kDpWorkers; w++)
+                if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &preDp[m].dp[w]) != S3_OK) { preDp[m].err = s3_last_error(); return; }
             if (paired) {
                 s3_dp_config(maxRL, maxDNAHalf, wantScheme(maxRL, maxDNAHalf), &scheme, &tableLen, &patLen);
-                if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &preDp[m].dpHalf) != S3_OK) preDp[m].err = s3_last_error();
+                for (int w = 0; w < kDpWorkers; w++)
+                    if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &preDp[m].dpHalf[w]) != S3_OK) { preDp[m].err = s3_last_error(); return; }
             }
         });
     if (!shared.loaded) {
@@ -851,10 +856,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     SamWriter sam(hix, so, out);
     sam.header();
     FILE *dpOut = nullptr;
-    s3_dp *dp = nullptr;
-    s3_batch *seedBatch = nullptr;
+    s3_dp *dpSet[kDpWorkers] = {nullptr, nullptr}, *halfSet[kDpWorkers] = {nullptr, nullptr};    // one set of aligners and one seed batch per DP stage thread
+    s3_batch *seedSet[kDpWorkers] = {nullptr, nullptr};
     s3_dp_stage_params dpPar{}, halfPar[2] = {}, deepPar[2][2] = {}, newPar[2] = {};
-    s3_dp *dpHalf = nullptr;
     FILE *unpairOut = nullptr;
     uint64_t dpAlignedReads = 0, defaultDpPairs = 0, newDefaultPairs = 0, deepDpPairs = 0, leftoverPairs = 0;
     if (enableDP) {
@@ -866,10 +870,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         dpHdr.header();
         s3_dp_ini di{ini.dpScoreThreshold, ini.maxFrontLenClipped, ini.maxEndLenClipped};
         s3_dp_stage_parameters(S3_STAGE_SINGLE_DP, detectedReadLength, &di, &dpPar);      // getParameterForSingleDP on the detected length (alignment.cu:2580)
-        dp = preDp[(size_t)member].dp;                                        // made while the index was loaded (above)
-        if (s3_batch_create(ix, 262144 + 64, 8, &seedBatch) != S3_OK) return dieJoin(s3_last_error());
+        for (int w = 0; w < kDpWorkers; w++) {                                // (the aligners were made while the index was loaded, above)
+            dpSet[w] = preDp[(size_t)member].dp[w];
+            if (s3_batch_create(ix, 262144 + 64, 8, &seedSet[w]) != S3_OK) return dieJoin(s3_last_error());
+        }
         if (paired) {
-            dpHalf = preDp[(size_t)member].dpHalf;                            // default DP (half-aligned pairs)
+            for (int w = 0; w < kDpWorkers; w++) halfSet[w] = preDp[(size_t)member].dpHalf[w];
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength, &di, &halfPar[0]);
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength2, &di, &halfPar[1]);
             for (int e = 0; e < 2; e++) {
@@ -988,13 +994,24 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         std::vector<s3_pair_result> pr; std::vector<uint64_t> ooff; std::vector<uint32_t> pos; std::vector<uint8_t> strand, mis, fromSa;
         std::vector<uint32_t> todo; bool hadSeedLengths = false;                  // single reads (default mode): the reads the BWT stage left without a hit
     };
-    struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<PairJob>> q; uint64_t submitted = 0, done = 0; bool stop = false; } dpq;
-    s3_batch *pairBatch[2] = {b, nullptr};
-    std::thread dpWorker;
+    struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<PairJob>> q; std::vector<s3_batch *> freeBatches; bool stop = false; } dpq;
+    std::vector<s3_batch *> stageBatches;                                         // the batches that take turns: one under the search, one with each DP stage thread
+    std::thread dpWorkers[kDpWorkers];
+    uint64_t workerCounts[kDpWorkers][5] = {};                                    // per DP stage thread: reads aligned by the single-end DP, default / new default / deep DP pairs, leftovers
+    double workerSeconds[kDpWorkers] = {};
     const bool pipelinedDp = enableDP && chunk && chunk->n;                      // (pairs and, in the default mode, single reads)
     if (pipelinedDp) {
-        if (s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : chunk->n, chunk->wpq, &pairBatch[1]) != S3_OK) return dieJoin(s3_last_error());
-        dpWorker = std::thread([&] {
+        stageBatches.push_back(b);
+        for (int w = 0; w < kDpWorkers; w++) {
+            s3_batch *nb = nullptr;
+            if (s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : chunk->n, chunk->wpq, &nb) != S3_OK) return dieJoin(s3_last_error());
+            stageBatches.push_back(nb);
+        }
+        dpq.freeBatches = stageBatches;
+        for (int wk = 0; wk < kDpWorkers; wk++) dpWorkers[wk] = std::thread([&, wk] {
+            s3_dp *dpW = dpSet[wk], *halfW = halfSet[wk];
+            s3_batch *seedW = seedSet[wk];
+            uint64_t *cntW = workerCounts[wk];
             for (;;) {
                 std::unique_ptr<PairJob> j;
                 {
@@ -1008,8 +1025,8 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 const auto tDp = std::chrono::steady_clock::now();
                 auto fatal = [&](const std::string &m) { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); };
                 if (paired) {
-                    PairDpCtx c{hix, so, *j->rs, ini, j->b, seedBatch, dp, dpHalf, dpOut, unpairOut, 0u, j->cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
-                    if (!pairDpStages(c, j->pr, j->ooff, j->pos, j->strand, j->mis, j->fromSa, defaultDpPairs, newDefaultPairs, deepDpPairs, leftoverPairs, e2)) fatal(e2);
+                    PairDpCtx c{hix, so, *j->rs, ini, j->b, seedW, dpW, halfW, dpOut, unpairOut, 0u, j->cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
+                    if (!pairDpStages(c, j->pr, j->ooff, j->pos, j->strand, j->mis, j->fromSa, cntW[1], cntW[2], cntW[3], cntW[4], e2)) fatal(e2);
                 } else {
                     // DPForUnalignSingle2 (DV-DPForSingleReads.cu): seeding in batches of at most 256 Ki seeds, DP at the candidates, one record per run of
                     // results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776), the rest as unaligned records
@@ -1018,20 +1035,23 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                     std::vector<uint8_t> doneFlag(j->cnt, 0);
                     // a read with DP hits on both strands comes as two runs (two records, as in the reference): its flag may be set by two threads at once,
                     // to the same value; the count of aligned reads is taken from the flags afterwards
-                    if (!singleDpRuns(hix, so, dpOut, j->b, seedBatch, dp, rs.lengths.data(), j->todo, dpPar, alignmentType, [&](SamWriter &w, uint32_t k, std::vector<DpHit> &hits) {
+                    if (!singleDpRuns(hix, so, dpOut, j->b, seedW, dpW, rs.lengths.data(), j->todo, dpPar, alignmentType, [&](SamWriter &w, uint32_t k, std::vector<DpHit> &hits) {
                             w.singleDP(rs, k, hits.data(), hits.size(), dpPar.cutoffThreshold);
                             doneFlag[k] = 1;
                         }, e2)) fatal(e2);
-                    for (uint32_t k : j->todo) dpAlignedReads += doneFlag[k];
+                    for (uint32_t k : j->todo) cntW[0] += doneFlag[k];
+                    // (records written through the FILE: under the file's lock, like a formatting call -- the other DP stage thread writes there too)
+                    std::lock_guard<std::mutex> oneAtATime(outState(dpOut).use);
                     SamWriter w(hix, so, dpOut);
                     for (uint32_t k : j->todo) if (!doneFlag[k]) w.unaligned(rs, k);
                     w.flush();
                 }
-                dpStageSeconds += since(tDp);
+                workerSeconds[wk] += since(tDp);
                 addChunkSeconds(3, since(tDp));
                 recycle(std::move(j->rs));
+                s3_batch *back = j->b;
                 j.reset();
-                { std::lock_guard<std::mutex> g(dpq.mu); dpq.done++; }
+                { std::lock_guard<std::mutex> g(dpq.mu); dpq.freeBatches.push_back(back); }
                 dpq.cv.notify_all();
             }
         });
@@ -1043,11 +1063,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         totalReads += cnt;
         (void)maxBatch;
         if (pipelinedDp) {
-            // this chunk's batch was the batch of the chunk before the last: its DP stages must be through
-            b = pairBatch[chunkNo & 1];
+            // a batch whose chunk is through its DP stages (or has not been used yet)
             const auto tWt = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> lk(dpq.mu);
-            dpq.cv.wait(lk, [&] { return chunkNo < 2 || dpq.done + 2 > chunkNo; });
+            dpq.cv.wait(lk, [&] { return !dpq.freeBatches.empty(); });
+            b = dpq.freeBatches.back();
+            dpq.freeBatches.pop_back();
             addChunkSeconds(4, since(tWt));
         }
         const auto tUp = std::chrono::steady_clock::now();
@@ -1100,7 +1121,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 j->b = b; j->cnt = cnt;
                 j->pr.swap(pr); j->ooff.swap(ooff); j->pos.swap(pos); j->strand.swap(strand); j->mis.swap(mis); j->fromSa.swap(fromSa);
                 j->rs = std::move(chunk);                                          // (the loop's recycle() gets nothing: the worker gives the set back)
-                { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); dpq.submitted++; }
+                { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); }
                 dpq.cv.notify_all();
             }
             continue;
@@ -1138,16 +1159,21 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             j->b = b; j->cnt = cnt; j->hadSeedLengths = !seeds.empty();
             for (uint32_t k = 0; k < cnt; k++) if (offs[k + 1] == offs[k]) j->todo.push_back(k);
             j->rs = std::move(chunk);                                              // (the loop's recycle() gets nothing: the worker gives the set back)
-            { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); dpq.submitted++; }
+            { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); }
             dpq.cv.notify_all();
         }
     }
-    if (dpWorker.joinable()) {
+    if (pipelinedDp) {
         { std::lock_guard<std::mutex> g(dpq.mu); dpq.stop = true; }
         dpq.cv.notify_all();
-        dpWorker.join();
-        b = pairBatch[0];
-        s3_batch_free(pairBatch[1]);
+        for (std::thread &t : dpWorkers) if (t.joinable()) t.join();
+        for (int w = 0; w < kDpWorkers; w++) {
+            dpAlignedReads += workerCounts[w][0]; defaultDpPairs += workerCounts[w][1]; newDefaultPairs += workerCounts[w][2]; deepDpPairs += workerCounts[w][3];
+            leftoverPairs += workerCounts[w][4];
+            dpStageSeconds += workerSeconds[w];
+        }
+        b = stageBatches[0];
+        for (size_t k = 1; k < stageBatches.size(); k++) s3_batch_free(stageBatches[k]);
     }
     auto closeOut = [&](FILE *f) { drainOutput(f); if (!bamClose(f)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); } fclose(f); };
     closeOut(out);
@@ -1158,13 +1184,10 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         if (paired) {
             closeOut(unpairOut);
             dpAlignedReads = 2 * (defaultDpPairs + newDefaultPairs + deepDpPairs);
-            addDpTotals(dpHalf);
-            s3_dp_free(dpHalf);
+            for (int w = 0; w < kDpWorkers; w++) { addDpTotals(halfSet[w]); s3_dp_free(halfSet[w]); }
         }
         aligned += dpAlignedReads;
-        addDpTotals(dp);
-        s3_dp_free(dp);
-        s3_batch_free(seedBatch);
+        for (int w = 0; w < kDpWorkers; w++) { addDpTotals(dpSet[w]); s3_dp_free(dpSet[w]); s3_batch_free(seedSet[w]); }
     }
     if (b) s3_batch_free(b);
     mark("aligners and batches freed");
