@@ -760,7 +760,10 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         if (!enableDP && numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;
     }
     // the DP aligners' traceback tables are a few gigabytes per device (20 ms per GB to allocate): made while the index is read and uploaded
-    constexpr int kDpWorkers = 2;                                             // DP stage threads per device (each with its own aligners and seed batch)
+    constexpr int kDpWorkers = 2;                                             // at most: DP stage threads per device (each with its own aligners and seed batch)
+    // one by default: on the boxes that grant sixteen CPUs a second one only takes CPU time from the formatter and the loader (10 M pairs: 1.45-1.51 s
+    // with two against 1.38-1.43 s with one); S3DP_DP_THREADS=2 for hosts with cores to spare
+    const int nDpWorkers = getenv("S3DP_DP_THREADS") && atoi(getenv("S3DP_DP_THREADS")) >= 2 ? 2 : 1;
     struct PreDp { s3_dp *dp[kDpWorkers] = {nullptr, nullptr}, *dpHalf[kDpWorkers] = {nullptr, nullptr}; std::string err; };
     const std::vector<int> &dpDevices = shared.loaded ? shared.devices : devices;
     std::vector<PreDp> preDp(dpDevices.size());
@@ -789,11 +792,11 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             int scheme = 1, tableLen = 0, patLen = 0;
             s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
             s3_dp_config(maxRL, maxDNA, wantScheme(maxRL, maxDNA), &scheme, &tableLen, &patLen);
-            for (int w = 0; w < kDpWorkers; w++)
+            for (int w = 0; w < nDpWorkers; w++)
                 if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &preDp[m].dp[w]) != S3_OK) { preDp[m].err = s3_last_error(); return; }
             if (paired) {
                 s3_dp_config(maxRL, maxDNAHalf, wantScheme(maxRL, maxDNAHalf), &scheme, &tableLen, &patLen);
-                for (int w = 0; w < kDpWorkers; w++)
+                for (int w = 0; w < nDpWorkers; w++)
                     if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &preDp[m].dpHalf[w]) != S3_OK) { preDp[m].err = s3_last_error(); return; }
             }
         });
@@ -870,12 +873,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         dpHdr.header();
         s3_dp_ini di{ini.dpScoreThreshold, ini.maxFrontLenClipped, ini.maxEndLenClipped};
         s3_dp_stage_parameters(S3_STAGE_SINGLE_DP, detectedReadLength, &di, &dpPar);      // getParameterForSingleDP on the detected length (alignment.cu:2580)
-        for (int w = 0; w < kDpWorkers; w++) {                                // (the aligners were made while the index was loaded, above)
+        for (int w = 0; w < nDpWorkers; w++) {                                // (the aligners were made while the index was loaded, above)
             dpSet[w] = preDp[(size_t)member].dp[w];
             if (s3_batch_create(ix, 262144 + 64, 8, &seedSet[w]) != S3_OK) return dieJoin(s3_last_error());
         }
         if (paired) {
-            for (int w = 0; w < kDpWorkers; w++) halfSet[w] = preDp[(size_t)member].dpHalf[w];
+            for (int w = 0; w < nDpWorkers; w++) halfSet[w] = preDp[(size_t)member].dpHalf[w];
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength, &di, &halfPar[0]);
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength2, &di, &halfPar[1]);
             for (int e = 0; e < 2; e++) {
@@ -1002,13 +1005,13 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     const bool pipelinedDp = enableDP && chunk && chunk->n;                      // (pairs and, in the default mode, single reads)
     if (pipelinedDp) {
         stageBatches.push_back(b);
-        for (int w = 0; w < kDpWorkers; w++) {
+        for (int w = 0; w < nDpWorkers; w++) {
             s3_batch *nb = nullptr;
             if (s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : chunk->n, chunk->wpq, &nb) != S3_OK) return dieJoin(s3_last_error());
             stageBatches.push_back(nb);
         }
         dpq.freeBatches = stageBatches;
-        for (int wk = 0; wk < kDpWorkers; wk++) dpWorkers[wk] = std::thread([&, wk] {
+        for (int wk = 0; wk < nDpWorkers; wk++) dpWorkers[wk] = std::thread([&, wk] {
             s3_dp *dpW = dpSet[wk], *halfW = halfSet[wk];
             s3_batch *seedW = seedSet[wk];
             uint64_t *cntW = workerCounts[wk];
@@ -1167,7 +1170,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         { std::lock_guard<std::mutex> g(dpq.mu); dpq.stop = true; }
         dpq.cv.notify_all();
         for (std::thread &t : dpWorkers) if (t.joinable()) t.join();
-        for (int w = 0; w < kDpWorkers; w++) {
+        for (int w = 0; w < nDpWorkers; w++) {
             dpAlignedReads += workerCounts[w][0]; defaultDpPairs += workerCounts[w][1]; newDefaultPairs += workerCounts[w][2]; deepDpPairs += workerCounts[w][3];
             leftoverPairs += workerCounts[w][4];
             dpStageSeconds += workerSeconds[w];
@@ -1184,10 +1187,10 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         if (paired) {
             closeOut(unpairOut);
             dpAlignedReads = 2 * (defaultDpPairs + newDefaultPairs + deepDpPairs);
-            for (int w = 0; w < kDpWorkers; w++) { addDpTotals(halfSet[w]); s3_dp_free(halfSet[w]); }
+            for (int w = 0; w < nDpWorkers; w++) { addDpTotals(halfSet[w]); s3_dp_free(halfSet[w]); }
         }
         aligned += dpAlignedReads;
-        for (int w = 0; w < kDpWorkers; w++) { addDpTotals(dpSet[w]); s3_dp_free(dpSet[w]); s3_batch_free(seedSet[w]); }
+        for (int w = 0; w < nDpWorkers; w++) { addDpTotals(dpSet[w]); s3_dp_free(dpSet[w]); s3_batch_free(seedSet[w]); }
     }
     if (b) s3_batch_free(b);
     mark("aligners and batches freed");

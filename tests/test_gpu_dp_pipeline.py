@@ -86,6 +86,9 @@ CASES = [
     # the same input in chunks of 1024 / 512 reads (the command line streams its input: S3DP_CHUNK_READS): nothing may depend on the chunking
     ("g7_h2_chunked", "g7", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]),
     ("g7_se_chunked", "g7", "se", "single", ("reads_1.fq",), ["-L", "150", "-b", "2"]),
+    # ... and with two DP stage threads taking the chunks in turns (S3DP_DP_THREADS=2: two sets of aligners, one writer per output file at a time)
+    ("g7_h2_chunked_two_dp_threads", "g7", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]),
+    ("g7_se_chunked_two_dp_threads", "g7", "se", "single", ("reads_1.fq",), ["-L", "150", "-b", "2"]),
 ]
 
 
@@ -102,6 +105,9 @@ def test_dp_pipeline_matches_the_reference_engines(tmp_path, case, gdir, tag, mo
         env["S3DP_DP_PAIRED"] = "0"
     if case.endswith("_scheme2"):
         env["S3DP_DP_SCHEME"] = "2"
+    if case.endswith("_two_dp_threads"):
+        env["S3DP_DP_THREADS"] = "2"
+        env["S3DP_CHUNK_READS"] = "512"
     if case.endswith("_chunked"):
         env["S3DP_CHUNK_READS"] = "1024" if mode == "pair" else "512"
     out = subprocess.run([BIN, mode, os.path.join(GOLDEN, gdir, "index")] + names + opts + ["-o", "out"], cwd=tmp_path, capture_output=True, text=True,
