@@ -798,7 +798,7 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
             if rank != 0:
                 if open(prefix + ".genome_sum").read().strip() != str(gsum):
                     raise SystemExit("bench.py: rank %d generated a different genome than rank 0" % rank)
-                hi = s3dp.HostIndex.from_files(prefix)
+                hi = s3dp.HostIndex.from_files(prefix, shared=True)       # one set of pages per node, not one copy per rank
     else:
         hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=(rank == 0))
     torch.cuda.empty_cache()
@@ -973,6 +973,70 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     return out, dict(ix=ix, hi=hi, codes=codes, q=q, lens=lens, wpq=wpq)
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this same script, one per GPU, as CHILD processes of
+    torch.distributed.run (the reference's model is one process per GPU, SOAP3-DP.cu:219-220, README.md:523-536), pass their stderr through, print
+    rank 0's JSON line, return their exit code.  This process only counts the devices (torch.cuda.device_count() does not initialise the HIP runtime
+    on this image) and waits: a process that has touched a GPU is never replaced by another program."""
+    import socket
+    import subprocess
+    if not a.launch_selftest:
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            print("bench.py: --gpus %d but this node shows %d HIP device%s" % (a.gpus, have, "" if have == 1 else "s"), file=sys.stderr)
+            return 2
+    with socket.socket() as sk:                                         # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [x for x in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in p.stdout:                                                 # rank 0 prints ONE JSON line; anything else on stdout goes to stderr
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks ended without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def launch_selftest_rank(a):
+    """one rank of `bench.py --gpus N --launch-selftest 1` (CPU, gloo): the N > 1 path's plumbing -- environment from the launcher, process group,
+    the shard bounds, the counters' reduce, barrier + max-over-ranks timing, ONE line from rank 0 -- around a stand-in for the timed region"""
+    import torch.distributed as dist
+    from s3dp import dist as sd
+    world, rank, local = sd.world()
+    if a.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE is %d" % (a.gpus, world), file=sys.stderr)
+        return 2
+    dist.init_process_group(backend="gloo")
+    total = a.reads * world                                             # weak scaling: a.reads per rank
+    lo, hi = sd.shard_bounds(total, rank, world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))                                       # (the slowest rank sets the time)
+    dist.barrier()
+    dt = sd.max_over_ranks(time.perf_counter() - t0)
+    tot = sd.reduce_counters({"reads": hi - lo, "readsAligned": hi - lo, "alignments": (hi - lo) * 2})
+    if rank == 0:
+        print(json.dumps({"metric": "launch selftest (no alignment done)", "value": tot["reads"] / dt / 1e6, "unit": "M reads/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "u32", "data": "none", "config": {"workload": "launch selftest"}, "selftest": True,
+                          "reads": tot["reads"], "alignments": tot["alignments"], "max_seconds": dt}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -997,7 +1061,14 @@ def main():
     ap.add_argument("--se150-reads", type=int, default=2_000_000, help="extras: 150 bp single-end reads, kernel-only rate (0: skip)")
     ap.add_argument("--exact-rank", type=int, default=1, help="count the reference algorithm's rank queries on this input with one walk-mode device pass")
     ap.add_argument("--extras", type=int, default=1, help="after the timed region (N = 1): paired-end 2x150 BWT stage and DP kernel throughput")
+    ap.add_argument("--launch-selftest", type=int, default=0, help="N > 1 plumbing only, no GPU: the ranks shard a count, reduce it over gloo and print the line "
+                                                                    "(tests/test_bench_launcher_cpu.py)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))                               # this process becomes the launcher: it never touches a GPU
+    if a.launch_selftest:
+        raise SystemExit(launch_selftest_rank(a))
 
     import torch
     import s3dp
@@ -1007,7 +1078,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (for N > 1 launch one rank per GPU with torch.distributed.run)" % (a.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (bench.py --gpus N starts its own ranks when no launcher has set WORLD_SIZE)" % (a.gpus, world))
     if not torch.cuda.is_available() or s3dp.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     torch.cuda.set_device(local)

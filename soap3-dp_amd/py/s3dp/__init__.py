@@ -169,6 +169,22 @@ def pack_text_words(codes):
     return (padded.reshape(words, 16) << sh).sum(axis=1, dtype=np.uint64).astype(np.uint32)
 
 
+def pac_words_from_file(path, n=None):
+    """the packed text words of pack_text_words() straight from a .pac file: its bytes hold 4 characters each, first one in the top bits, so four
+    bytes read big-endian ARE one word of 16 characters (TextConverter.c:666-720); the unused bits of the last byte are cleared by the writer"""
+    raw = np.fromfile(path, dtype=np.uint8)
+    m = (len(raw) - 2) * 4 + int(raw[-1])
+    if n is not None:
+        assert m == n
+    nwords = (m + 63) // 64 * 4 + 8
+    buf = np.zeros(nwords * 4, dtype=np.uint8)
+    k = (m + 3) // 4
+    buf[:k] = raw[:k]
+    if m % 4:
+        buf[k - 1] &= (0xFF << (2 * (4 - m % 4))) & 0xFF
+    return buf.view(">u4").astype(np.uint32)
+
+
 class HostIndex:
     """host arrays of one 2BWT + GPU-2BWT index in the file layouts"""
 
@@ -176,36 +192,50 @@ class HostIndex:
         self.keep = []
 
     @classmethod
-    def from_files(cls, prefix, lkt=None, rev_lkt=None):
+    def from_files(cls, prefix, lkt=None, rev_lkt=None, shared=False):
+        """shared=True: the big arrays are private copy-on-write mappings of the files (np.memmap mode 'c') instead of copies in this process's
+        heap -- N ranks of one node that load the same files then share ONE set of pages in the page cache (a GRCh38-scale index is 17 GB per
+        private copy), as the reference's share-index mode does (IndexHandler.cpp:176-192); the packed text comes from the .pac bytes directly and
+        the unpacked characters (`codes`, which only builders and tests use) are not materialised."""
         self = cls()
 
+        def words(path):
+            return np.memmap(path, dtype=np.uint32, mode="c") if shared else np.fromfile(path, dtype=np.uint32)
+
         def half(mid):
-            raw = np.fromfile(prefix + mid + ".bwt", dtype=np.uint32)
-            occ = np.fromfile(prefix + mid + ".fmv.gpu", dtype=np.uint32)
+            raw = words(prefix + mid + ".bwt")
+            occ = words(prefix + mid + ".fmv.gpu")
             assert (raw[:5] == occ[:5]).all(), "header mismatch between .bwt and .fmv.gpu"
-            return dict(inverseSa0=int(raw[0]), cum=[0] + [int(x) for x in raw[1:5]], bwt=np.ascontiguousarray(raw[5:]),
-                        occ=np.ascontiguousarray(occ[5:]))
+            return dict(inverseSa0=int(raw[0]), cum=[0] + [int(x) for x in raw[1:5]], bwt=raw[5:] if shared else np.ascontiguousarray(raw[5:]),
+                        occ=occ[5:] if shared else np.ascontiguousarray(occ[5:]))
         self.fwd = half("")
         self.rev = half(".rev")
         self.n = self.fwd["cum"][4]
-        sa = np.fromfile(prefix + ".sa", dtype=np.uint32)
+        sa = words(prefix + ".sa")
         self.sa_interval = int(sa[5])                            # SaValueFreq: 1 = full array, k = every k-th entry (BWT.c:254-255)
-        self.sa = np.ascontiguousarray(sa[6:6 + (self.n + self.sa_interval) // self.sa_interval]).copy()
-        self.sa[0] = 0xFFFFFFFF                                   # BWT.c:286
-        self.codes = unpack_pac(prefix + ".pac")
-        assert len(self.codes) == self.n
-        self.pac = pack_text_words(self.codes)
+        self.sa = sa[6:6 + (self.n + self.sa_interval) // self.sa_interval]
+        if not shared:
+            self.sa = np.ascontiguousarray(self.sa).copy()
+        self.sa[0] = 0xFFFFFFFF                                   # BWT.c:286 (shared: the one page this touches becomes private)
+        if shared:
+            self.codes = None
+            self.pac = pac_words_from_file(prefix + ".pac", self.n)
+        else:
+            self.codes = unpack_pac(prefix + ".pac")
+            assert len(self.codes) == self.n
+            self.pac = pack_text_words(self.codes)
         if lkt is None:
             if os.path.exists(prefix + ".lkt"):
-                lkt = np.fromfile(prefix + ".lkt", dtype=np.uint32)[1:]
-                rev_lkt = np.fromfile(prefix + ".rev.lkt", dtype=np.uint32)[1:]
+                lkt = words(prefix + ".lkt")[1:]
+                rev_lkt = words(prefix + ".rev.lkt")[1:]
                 if len(lkt) != 1 << 26 or len(rev_lkt) != 1 << 26:
                     raise ValueError("%s.lkt / .rev.lkt are not 13-mer tables of 2^26 entries" % prefix)
             else:
-                lkt = build_lookup_table(self.codes)
-                rev_lkt = build_lookup_table(self.codes[::-1])
-        self.lkt = np.ascontiguousarray(lkt)
-        self.rev_lkt = np.ascontiguousarray(rev_lkt)
+                codes = self.codes if self.codes is not None else unpack_pac(prefix + ".pac")
+                lkt = build_lookup_table(codes)
+                rev_lkt = build_lookup_table(codes[::-1])
+        self.lkt = lkt if shared else np.ascontiguousarray(lkt)
+        self.rev_lkt = rev_lkt if shared else np.ascontiguousarray(rev_lkt)
         self.lkt_size = 13
         return self
 

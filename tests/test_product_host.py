@@ -54,3 +54,21 @@ def test_no_device_means_loud_failure():
     with pytest.raises(s3dp.S3Error) as e:
         s3dp.Index(host_index("g1"))
     assert "no HIP device" in str(e.value)
+
+
+def test_shared_index_mapping_equals_the_private_copy():
+    """HostIndex.from_files(shared=True) maps the files copy-on-write (ranks of a node share the pages) and must describe the same index"""
+    import numpy as np
+    import s3dp
+    from conftest import GOLDEN, host_index
+    for g in ("g1", "g6"):
+        a = host_index(g)
+        b = s3dp.HostIndex.from_files(os.path.join(GOLDEN, g, "index"), lkt=a.lkt, rev_lkt=a.rev_lkt, shared=True)
+        assert a.n == b.n and a.sa_interval == b.sa_interval and b.codes is None
+        assert np.array_equal(a.pac, b.pac) and np.array_equal(a.sa, b.sa)
+        for h in ("fwd", "rev"):
+            ha, hb = getattr(a, h), getattr(b, h)
+            assert ha["inverseSa0"] == hb["inverseSa0"] and ha["cum"] == hb["cum"]
+            assert np.array_equal(ha["bwt"], hb["bwt"]) and np.array_equal(ha["occ"], hb["occ"])
+        da, db = a.desc(), b.desc()
+        assert da.fwd.bwtWords == db.fwd.bwtWords and da.packedWords == db.packedWords and da.textLength == db.textLength
