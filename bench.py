@@ -370,9 +370,13 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
     torch.cuda.empty_cache()
     lens = np.full(2 * n_pairs, L, dtype=np.uint32)
     # ---- the BWT stage, resident (what the command line's first stage does per chunk), with counters and the oracle on a sample ----
+    # (on at most 1 Mi pairs: one search pass numbers its records with 32 bits, and twenty million 150-base reads of a genome that is half repeats pass
+    #  2^32 of them -- the command line works in chunks of 512 Ki pairs)
+    n_all, n_pairs = n_pairs, min(n_pairs, 1 << 20)
+    res["bwt_stage_resident_pairs"] = n_pairs
     b = s3dp.Batch(ix, 2 * n_pairs, wpq)
     try:
-        b.upload(q, lens)
+        b.upload(q[:(2 * n_pairs + 31) // 32 * 32 * wpq], lens[:2 * n_pairs])
         b.enable_counters(True)
         b.align_pair(3, 8000, 2, 1, 500, 1000)
         b.sync()
@@ -406,6 +410,7 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
         res["oracle_check"] = {"pairs": m, "what": "the BWT stage's pair results (phase, best pairing, strands, mismatches, number of pairings) against the CPU oracle", "bit_exact": bool(ok)}
     finally:
         b.close()
+    n_pairs = n_all
     # (the command-line part is a function of its own: bench.py's main run calls it after its own resident index is closed -- two copies of a 120 GB index
     #  on one GPU made the child's start-up and teardown a second longer than when it has the device to itself, which is how it is used)
     def cli_part():

@@ -144,7 +144,10 @@ int  s3_batch_fetch_alignments(s3_batch *b, uint8_t *phase, uint32_t *withError 
  *                       (for the DP stages)
  *   s3_stream_release   gives the oldest slot back
  * One thread may drive all four calls as long as it never holds more than `depth` unreleased batches; or a producer thread acquires / submits
- * while a consumer thread takes results.  Results come back in submission order. */
+ * while a consumer thread takes results.  Results come back in submission order.
+ * Host requirement: batches in flight run on their own HIP streams; the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues
+ * (default 4), and streams that share a queue run in order.  A host that keeps more than two batches in flight should set GPU_MAX_HW_QUEUES=16 in its
+ * environment BEFORE its first HIP call (the soap3-dp executable and the Python binding do); the library does not change its host's environment. */
 typedef struct s3_stream s3_stream;
 typedef struct {
     uint64_t        ticket;

@@ -18,9 +18,8 @@ int s3i::fail(int code, const std::string &msg) { g_err = msg; return code; }
 // The HIP runtime spreads a process's streams over FOUR hardware queues by default (GPU_MAX_HW_QUEUES); streams that share a queue run in order.  A
 // streamed run keeps up to six batches in flight, each with a kernel stream and copy streams: on four queues a batch's kernels waited behind another
 // batch's although nothing connected them -- 1 Mi-read batches reached 0.75 of the resident rate, 0.58 with four in flight; with sixteen queues 0.85.
-// The variable is read when the runtime comes up, i.e. at the first HIP call: asking for it when this library is loaded is early enough unless the host
-// process used HIP before (then it had its chance to set it).  A value the user set is left alone.
-__attribute__((constructor)) static void s3dpRuntimeDefaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// The variable is read when the runtime comes up, i.e. at the first HIP call, and it belongs to the HOST PROGRAM: the soap3-dp executable, the Python
+// binding and bench.py set it (unless the user did) before their first HIP call; the library does not change its host's environment (include/s3dp.h).
 
 // ---- scratch cache of the DP / seeding engines (s3dp_internal.h) -------------------------------------------------------------------------------------
 namespace {

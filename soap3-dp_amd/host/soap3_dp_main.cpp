@@ -833,7 +833,15 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     double dpStageSeconds = 0;
     std::unique_ptr<ReadSet> chunk = nextChunk();
     if (!chunk) {
-        if (member > 0) return 0;                                              // fewer chunks than devices: nothing for this one (member 0 still writes the headers)
+        if (member > 0) {                                                      // fewer chunks than devices: nothing for this one (member 0 still writes the headers)
+            // its aligners were made while the index loaded: several GB of traceback tables per device that no later job would ever free
+            for (int w = 0; w < kDpWorkers; w++) {
+                if (preDp[(size_t)member].dp[w]) s3_dp_free(preDp[(size_t)member].dp[w]);
+                if (preDp[(size_t)member].dpHalf[w]) s3_dp_free(preDp[(size_t)member].dpHalf[w]);
+                preDp[(size_t)member].dp[w] = preDp[(size_t)member].dpHalf[w] = nullptr;
+            }
+            return 0;
+        }
         chunk.reset(new ReadSet());
         uint32_t w = 1;
         while (w < (uint32_t)maxReadLength) w *= 2;
@@ -1252,6 +1260,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
 //   with -bam a pair is ONE file: read file, minimum insert, maximum insert, output prefix, ...
 int main(int argc, char **argv)
 {
+    // sixteen hardware queues instead of the HIP runtime's four, before its first call (s3dp_api.hip: batches in flight on their own streams otherwise wait
+    // for each other); a value the user set is left alone
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     SharedIndex shared;
     int rc = 0;
     const bool multi = argc >= 2 && (!strcmp(argv[1], "single-multi") || !strcmp(argv[1], "pair-multi"));
