@@ -277,11 +277,14 @@ def make_pairs(codes, n_pairs, L, seed, device):
     return out
 
 
-def make_pairs_c3(codes, n_pairs, L, seed, device, indel_frac=0.10):
+def make_pairs_c3(codes, n_pairs, L, seed, device, indel_frac=0.10, both_frac=0.0):
     """BASELINE.json configs[2]: 2 x L pairs, insert ~ N(350, 40) clipped to [L + 1, 500], '+/-' orientation, 0-4 substitutions per end
     (55/25/12/5/3 %), and `indel_frac` of the MATES carry one 1-8 base indel (a deletion skips reference bases, an insertion adds random ones): such a
-    mate has no <= 4-mismatch hit, its pair is half-aligned and goes to the default DP.  Returns the reads (2 n x L codes, mates adjacent) and the truth:
-    leftmost reference position of either mate (0-based, of the mate as simulated: first file = row 2p), its strand, whether it carries an indel."""
+    mate has no <= 4-mismatch hit, its pair is half-aligned and goes to the default DP.  both_frac (BASELINE.json configs[4], SURVEY.md 8d "C5"): that
+    share of the PAIRS is damaged in BOTH mates -- each mate gets an indel or, with equal probability, 5-8 substitutions -- so neither end has a BWT hit
+    and the pair goes to the deep DP (DV-DPForBothUnalign.cu).  Returns the reads (2 n x L codes, mates adjacent) and the truth:
+    leftmost reference position of either mate (0-based, of the mate as simulated: first file = row 2p), its strand, whether it carries an indel,
+    whether its pair is one of the both-damaged ones."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -290,11 +293,17 @@ def make_pairs_c3(codes, n_pairs, L, seed, device, indel_frac=0.10):
     start = torch.randint(0, n - 700, (n_pairs,), generator=g, device=device)
     ar = torch.arange(L, device=device)
     probs = torch.tensor((0.55, 0.25, 0.12, 0.05, 0.03), device=device)
+    both = torch.rand(n_pairs, generator=g, device=device) < both_frac if both_frac > 0 else torch.zeros(n_pairs, dtype=torch.bool, device=device)
     ends, left_pos, has_indel = [], [], []
     for base in (start, start + ins - L):                                   # the left mate, the right mate (both read off the forward strand here)
         k = torch.randint(1, 9, (n_pairs,), generator=g, device=device)
         is_del = torch.rand(n_pairs, generator=g, device=device) < 0.5
         hit = torch.rand(n_pairs, generator=g, device=device) < indel_frac
+        many = torch.zeros(n_pairs, dtype=torch.bool, device=device)
+        if both_frac > 0:                                                   # a both-damaged pair: this mate gets an indel, or 5-8 substitutions
+            by_indel = torch.rand(n_pairs, generator=g, device=device) < 0.5
+            hit = torch.where(both, by_indel, hit)
+            many = both & ~by_indel
         c = torch.randint(30, L - 30, (n_pairs,), generator=g, device=device)
         j = ar[None, :].expand(n_pairs, L)
         # deletion of k at c: read[j] = ref[j] (j < c), ref[j + k] (j >= c);  insertion of k at c: ref[j] (j < c), random (c <= j < c + k), ref[j - k] (j >= c + k)
@@ -305,11 +314,15 @@ def make_pairs_c3(codes, n_pairs, L, seed, device, indel_frac=0.10):
         inserted = hit[:, None] & ~is_del[:, None] & (j >= c[:, None]) & (j < (c + k)[:, None])
         seg = torch.where(inserted, rnd, seg)
         nsub = torch.multinomial(probs, n_pairs, replacement=True, generator=g)
-        kth = torch.topk(torch.rand((n_pairs, L), generator=g, device=device), 4, dim=1).indices
-        delta = torch.randint(1, 4, (n_pairs, 4), generator=g, device=device, dtype=torch.uint8)
-        for t in range(4):
+        top = 8 if both_frac > 0 else 4
+        if both_frac > 0:
+            nsub = torch.where(many, torch.randint(5, 9, (n_pairs,), generator=g, device=device), nsub)
+        kth = torch.topk(torch.rand((n_pairs, L), generator=g, device=device), top, dim=1).indices
+        delta = torch.randint(1, 4, (n_pairs, top), generator=g, device=device, dtype=torch.uint8)
+        for t in range(top):
             rows = torch.nonzero(nsub > t).squeeze(1)
             seg[rows, kth[rows, t]] = (seg[rows, kth[rows, t]] + delta[rows, t]) % 4
+        del kth, delta
         ends.append(seg)
         left_pos.append(base)
         has_indel.append(hit)
@@ -327,7 +340,7 @@ def make_pairs_c3(codes, n_pairs, L, seed, device, indel_frac=0.10):
     indel = torch.empty(2 * n_pairs, dtype=torch.bool, device=device)
     indel[0::2] = torch.where(swap, has_indel[1], has_indel[0])
     indel[1::2] = torch.where(swap, has_indel[0], has_indel[1])
-    return out, pos.cpu().numpy(), strand.cpu().numpy(), indel.cpu().numpy()
+    return out, pos.cpu().numpy(), strand.cpu().numpy(), indel.cpu().numpy(), both.cpu().numpy()
 
 
 def write_fastq_pairs(reads2d_np, L, path1, path2):
@@ -348,7 +361,7 @@ def write_fastq_pairs(reads2d_np, L, path1, path2):
         rec.tofile(path)
 
 
-def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cli=False):
+def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cli=False, both_frac=0.0, resident=True, index_prefix=None):
     """BASELINE.json configs[2] as far as one GPU and the time budget of a default run go: n_pairs 2 x 150 bp pairs on the benchmark genome,
     `pair -u 500 -v 1`, DP stages ON, end to end through the drop-in command line (the DP stages are driven by its host code), plus the resident BWT
     stage of the same pairs through the library with the oracle check on a sample.  Reports pairs/s, the stages' wall and device times, the BWT stage's
@@ -361,22 +374,28 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
     import s3o
     L = 150
     res = {"pairs": n_pairs, "read_len": L, "options": "pair -L 150 -u 500 -v 1 (default mode: BWT ladder + default / new default / deep / single-end DP)",
-           "mixture": "insert N(350, 40) in [151, 500]; 0-4 substitutions per mate (55/25/12/5/3 %); 10 % of the mates carry a 1-8 base indel"}
-    reads2d, tpos, tstrand, tindel = make_pairs_c3(codes, n_pairs, L, 31337, dev)
+           "mixture": "insert N(350, 40) in [151, 500]; 0-4 substitutions per mate (55/25/12/5/3 %); 10 % of the mates carry a 1-8 base indel" +
+                      ("; %.0f %% of the PAIRS damaged in both mates (an indel or 5-8 substitutions each): deep DP (BASELINE.json configs[4])" % (100 * both_frac) if both_frac > 0 else "")}
+    reads2d, tpos, tstrand, tindel, tboth = make_pairs_c3(codes, n_pairs, L, 31337 if both_frac == 0 else 31338, dev, both_frac=both_frac)
     wpq = s3dp.word_per_query(L)
-    q = pack_on_device(reads2d, wpq)
+    n_res = min(n_pairs, 1 << 20) if resident else 0
+    q = pack_on_device(reads2d[:2 * n_res], wpq) if n_res else None
     reads_np = reads2d.cpu().numpy()
     del reads2d
     torch.cuda.empty_cache()
     lens = np.full(2 * n_pairs, L, dtype=np.uint32)
+    if not resident:
+        ix = None
     # ---- the BWT stage, resident (what the command line's first stage does per chunk), with counters and the oracle on a sample ----
     # (on at most 1 Mi pairs: one search pass numbers its records with 32 bits, and twenty million 150-base reads of a genome that is half repeats pass
     #  2^32 of them -- the command line works in chunks of 512 Ki pairs)
-    n_all, n_pairs = n_pairs, min(n_pairs, 1 << 20)
+    n_all, n_pairs = n_pairs, n_res
     res["bwt_stage_resident_pairs"] = n_pairs
-    b = s3dp.Batch(ix, 2 * n_pairs, wpq)
+    b = s3dp.Batch(ix, 2 * n_pairs, wpq) if resident else None
     try:
-        b.upload(q[:(2 * n_pairs + 31) // 32 * 32 * wpq], lens[:2 * n_pairs])
+        if not resident:
+            raise StopIteration
+        b.upload(q, lens[:2 * n_pairs])
         b.enable_counters(True)
         b.align_pair(3, 8000, 2, 1, 500, 1000)
         b.sync()
@@ -393,13 +412,18 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
             ce_ms += b.ce_timing()[0]
         dt = (time.perf_counter() - t0) / 2
         pairs = b.fetch_pairs()[0]
-        bytes_bwt = 32.0 * cnt["rankQueries"] + 16.0 * cnt["ltLookups"] + 4.0 * cnt["saReads"] + 16.0 * cnt["ceWindows"] + 2 * n_pairs * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
+        # SURVEY.md 8d's formula with 12 B per reported occurrence (strict) and the same extended by what lookup tables and check-and-extend read
+        # (the hit term is left out of the strict figure here: the stage's output is pairings, its occurrence lists stay on the device)
+        bytes_strict = 32.0 * cnt["rankQueries"] + 2 * n_pairs * (4.0 * wpq + 4.0)
+        bytes_bwt = bytes_strict + 12.0 * cnt["records"] + 16.0 * cnt["ltLookups"] + 4.0 * cnt["saReads"] + 16.0 * cnt["ceWindows"]
         kern_s = (search_ms + ce_ms) / 2 / 1e3
         res["bwt_stage_resident"] = {"ms_per_pass": dt * 1e3, "device_ms_per_pass": dev_ms / 2, "search_kernels_ms_per_pass": (search_ms + ce_ms) / 2,
                                      "M_pairs_per_s": n_pairs / dt / 1e6, "properly_paired": int((pairs["phase"] > 0).sum()),
                                      "rank_queries": int(cnt["rankQueries"]), "algorithmic_bytes": bytes_bwt,
-                                     "roofline": {"bound": "hbm", "achieved": bytes_bwt / kern_s / 1e9 if kern_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                  "frac": bytes_bwt / kern_s / 1e9 / HBM_PEAK_GBS if kern_s > 0 else 0.0}}
+                                     "roofline": {"bound": "hbm", "achieved": bytes_strict / kern_s / 1e9 if kern_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": bytes_strict / kern_s / 1e9 / HBM_PEAK_GBS if kern_s > 0 else 0.0,
+                                                  "is": "SURVEY.md 8d unextended without the hit term: 32 B x rank queries + packed reads, over the search kernels' time",
+                                                  "frac_extended": bytes_bwt / kern_s / 1e9 / HBM_PEAK_GBS if kern_s > 0 else 0.0}}
         m = 1024
         oix = s3o.Index(host_index=hi)
         want = oix.align_pair(q[:m * 2 // 32 * 32 * wpq], lens[:2 * m], wpq, 3, 8000, 2, 1, 500, 1000)
@@ -408,8 +432,11 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
         hit = want[0]["phase"] > 0
         ok = (got["phase"] == want[0]["phase"]).all() and all((got[f][hit] == want[0][f][hit]).all() for f in ("bestA1", "bestA2", "bestS1", "bestS2", "bestM1", "bestM2", "numPairs"))
         res["oracle_check"] = {"pairs": m, "what": "the BWT stage's pair results (phase, best pairing, strands, mismatches, number of pairings) against the CPU oracle", "bit_exact": bool(ok)}
+    except StopIteration:
+        res.pop("bwt_stage_resident_pairs", None)
     finally:
-        b.close()
+        if b is not None:
+            b.close()
     n_pairs = n_all
     # (the command-line part is a function of its own: bench.py's main run calls it after its own resident index is closed -- two copies of a 120 GB index
     #  on one GPU made the child's start-up and teardown a second longer than when it has the device to itself, which is how it is used)
@@ -418,8 +445,9 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
         work = workdir or tempfile.mkdtemp(prefix="s3dp_c3_", dir="/tmp")
         try:
             t0 = time.perf_counter()
-            prefix = os.path.join(work, "g.index")
-            hi.write_files(prefix, with_lkt=True)
+            prefix = index_prefix or os.path.join(work, "g.index")
+            if not os.path.exists(prefix + ".sa"):                              # (legs that share an index directory write the files once)
+                hi.write_files(prefix, with_lkt=True)
             f1, f2 = os.path.join(work, "r1.fq"), os.path.join(work, "r2.fq")
             write_fastq_pairs(reads_np, L, f1, f2)
             os.sync()                                                          # (files written a moment ago: their write-back is not the program's time)
@@ -486,6 +514,7 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
             res["truth_check"] = {"pairs": n_pairs, "mates_reported": int(seen.sum()), "mates_mapped": int(mapped.sum()), "mates_at_simulated_place": int(at_truth.sum()),
                                   "pairs_with_both_mates_at_simulated_place": int(both.sum()),
                                   "mates_with_indel": int(tindel.sum()), "mates_with_indel_at_simulated_place": int((at_truth & tindel).sum()),
+                                  "pairs_damaged_in_both_mates": int(tboth.sum()), "of_those_with_both_mates_at_simulated_place": int((both & tboth).sum()),
                                   "by_file": by_file,
                                   "is": "primary record of every mate against the simulated place (tolerance 12 bases for clips and indels at the ends, strand must match); "
                                         "on a genome that is half repeats a mate inside a repeat family has equally good places elsewhere, so this is a rate, "
@@ -548,11 +577,22 @@ def extras(s3dp, ix, hi, codes, dev, rank, a):
     res = {}
     L = 150
     wpq = s3dp.word_per_query(L)
+    import tempfile
+    shared = tempfile.mkdtemp(prefix="s3dp_bench_ix_", dir="/tmp") if (a.c3_pairs > 0 or a.c5_pairs > 0) else None
+    res["_index_dir"] = shared
     if a.c3_pairs > 0:
         try:
-            res["c3_pairs"], res["_c3_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs, defer_cli=True)
+            res["c3_pairs"], res["_c3_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs, defer_cli=True, index_prefix=os.path.join(shared, "g.index"))
         except Exception as e:
             res["c3_pairs"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    if a.c5_pairs > 0:
+        # BASELINE.json configs[4] on one GPU: the C3 mixture plus 5 % of the pairs damaged in both mates (deep DP, DV-DPForBothUnalign.cu), command line only
+        try:
+            res["c5_pairs"], res["_c5_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c5_pairs, defer_cli=True, both_frac=0.05, resident=False,
+                                                      index_prefix=os.path.join(shared, "g.index"))
+        except Exception as e:
+            res["c5_pairs"] = {"error": repr(e)}
         torch.cuda.empty_cache()
     if a.se150_reads > 0:
         try:
@@ -1062,7 +1102,8 @@ def main():
     ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle after the run")
     ap.add_argument("--index-dir", default=None, help="keep / reuse the index files of the benchmark genome in this directory")
     ap.add_argument("--build-only", type=int, default=0, help="stop after the index files are written (with --index-dir)")
-    ap.add_argument("--c3-pairs", type=int, default=1_000_000, help="extras: 2 x 150 bp pairs through the command line with the DP stages on (0: skip)")
+    ap.add_argument("--c3-pairs", type=int, default=10_000_000, help="extras: BASELINE.json configs[2] -- 2 x 150 bp pairs through the command line with the DP stages on (0: skip)")
+    ap.add_argument("--c5-pairs", type=int, default=2_000_000, help="extras: configs[4]'s mixture (5 %% of the pairs damaged in both mates: deep DP) through the command line (0: skip)")
     ap.add_argument("--se150-reads", type=int, default=2_000_000, help="extras: 150 bp single-end reads, kernel-only rate (0: skip)")
     ap.add_argument("--exact-rank", type=int, default=1, help="count the reference algorithm's rank queries on this input with one walk-mode device pass")
     ap.add_argument("--extras", type=int, default=1, help="after the timed region (N = 1): paired-end 2x150 BWT stage and DP kernel throughput")
@@ -1125,14 +1166,20 @@ def main():
     import gc
     gc.collect()
     torch.cuda.empty_cache()
-    c3_cli = out.get("extras", {}).pop("_c3_cli", None) if isinstance(out.get("extras"), dict) else None
-    if c3_cli is not None:
-        try:
-            c3_cli()                                                    # fills extras.c3_pairs.end_to_end and .truth_check
-        except Exception as e:
-            out["extras"]["c3_pairs"]["end_to_end"] = {"error": repr(e)}
-        gc.collect()
-        torch.cuda.empty_cache()
+    ex = out.get("extras") if isinstance(out.get("extras"), dict) else {}
+    shared_ix = ex.pop("_index_dir", None)
+    for key, leg in (("_c3_cli", "c3_pairs"), ("_c5_cli", "c5_pairs")):
+        cli = ex.pop(key, None)
+        if cli is not None:
+            try:
+                cli()                                                   # fills extras.<leg>.end_to_end and .truth_check
+            except Exception as e:
+                ex[leg]["end_to_end"] = {"error": repr(e)}
+            gc.collect()
+            torch.cuda.empty_cache()
+    if shared_ix:
+        import shutil
+        shutil.rmtree(shared_ix, ignore_errors=True)
     if rank == 0 and world == 1 and a.uniform and a.repeat_frac > 0:
         try:
             a2 = argparse.Namespace(**vars(a))

@@ -309,6 +309,40 @@ int  s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t *xaOffset
  * (HalfEndOccStream::fetchNextOcc, DV-DPfunctions.cu:1901-1960), while the lists here hold the check-and-extend hits first. */
 int  s3_batch_fetch_pair_origins(s3_batch *b, uint8_t *fromSaRange, size_t cap);
 
+/* ---- routing of the pairs the BWT ladder left without a proper pairing, on the device (round 4) ------------------------------------------------------
+ * Replaces the needProceedDP branch of hostKernel (CPUfunctions.cpp:2153-2262, 2444-2543) that decides, pair by pair, which DP stage gets which of the two
+ * ends' hit lists: a list longer than the stage's hit limit keeps its best (keepSecondBest: and second-best) stratum (retainAllBest /
+ * retainAllBestAndSecBest, SAList.cpp:140,290); no hits at all -> deep DP; hits on one end -> that end's list, SA ranges before check-and-extend hits
+ * (HalfEndOccStream::fetchNextOcc, DV-DPfunctions.cu:1901-1960), to the default DP or -- still above maxHitNum -- to the new default DP; hits on both ends
+ * -> both lists to the default DP when both are within the limit, else the shorter one (the second end's when equal) to the default / new default DP and
+ * the other one kept for the unpaired output only.  Call it after s3_batch_align_pair on the same batch; the three lists (entries grouped by read, reads
+ * ascending) stay on the device:
+ *   s3_batch_fetch_routing    per pair the S3_ROUTE_* bits; any of the three lists (NULL: not wanted)
+ *   s3_batch_fetch_kept       the kept lists of selected reads (what the unpaired output of a pair that every stage failed on prints): offsets[nReads + 1]
+ *                             and the entries behind each other, malloc'ed (s3_free)
+ *   s3_dp_new_default_routed  s3_dp_new_default on the new-default list where it lies (it never comes to the host)
+ * maxHitNum[e]: the default DP's hit limit for end e (s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP)).  Pinned: the routing of the reference's own hostKernel
+ * (tests/test_gpu_cli_sam.py::test_cli_pair_dp_routing_matches_the_reference, fixtures g4 / g5). */
+#define S3_ROUTE_UNPAIRED      1     /* the ladder found no proper pairing (every other bit implies this one) */
+#define S3_ROUTE_DEEP          2     /* no hit on either end: deep DP */
+#define S3_ROUTE_DEFAULT       4     /* the pair has entries in the default-DP list */
+#define S3_ROUTE_NEW_DEFAULT   8     /* the pair has entries in the new-default-DP list ... */
+#define S3_ROUTE_GIVEN_END_2  16     /* ... and they are its SECOND end's hits */
+typedef struct {
+    uint64_t nDefault, nNewDefault, nOther;                         /* entries of the three lists */
+    uint32_t nUnpaired, nDeepPairs, nDefaultPairs, nNewDefaultPairs;
+} s3_pair_routing;
+int  s3_batch_route_pairs(s3_batch *b, const uint32_t maxHitNum[2], int keepSecondBest, s3_pair_routing *out);
+/* the result of a ladder that was not run (pairs of reads above 150 bases skip the BWT stage, SOAP3-DP.cu:658-662): no pairing, no occurrence; routing it
+ * sends every pair to the deep DP */
+int  s3_batch_no_pair_result(s3_batch *b);
+int  s3_batch_fetch_routing(s3_batch *b, uint8_t *pairRoute /* n / 2 */, s3_occ *defaultOcc, size_t defaultCap, s3_occ *newDefaultOcc, size_t newDefaultCap,
+                            s3_occ *otherOcc, size_t otherCap);
+int  s3_batch_fetch_kept(s3_batch *b, const uint32_t *reads, size_t nReads, uint64_t *offsets, s3_occ **occ, uint64_t *nOcc);
+int  s3_dp_new_default_routed(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, uint32_t maxHitNum, int insertLow, int insertHigh,
+                              const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_deep_result **results, size_t *nResults,
+                              char **cigarPool, uint8_t **pairFlags, uint32_t **pairFirstReads, size_t *nPairs);
+
 int  s3_batch_sync(s3_batch *b);
 /* device time of the work enqueued by the last search/align call, measured with HIP events on the batch stream;
  * searchMs = time inside the BWT-search kernels only. */

@@ -23,12 +23,15 @@ int s3i::fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 // ---- scratch cache of the DP / seeding engines (s3dp_internal.h) -------------------------------------------------------------------------------------
 namespace {
-struct ScratchBlock { void *p; size_t bytes; hipStream_t lastStream; int device; };
+// A cached block remembers its last use as an EVENT recorded on the stream that used it (round 4; it used to remember the stream handle, and a taker on
+// another thread could synchronise a stream its owner was destroying): whoever takes the block for another stream makes that stream wait for the event
+// -- on the device, the host does not block -- and an event outlives its stream.
+struct ScratchBlock { void *p; size_t bytes; hipStream_t lastStream; hipEvent_t done; int device; };
 struct ScratchCache {
     std::mutex mu;
     std::vector<ScratchBlock> freeBlocks;                      // cached, by device
     std::map<void *, ScratchBlock> live;                       // handed out
-    size_t cachedBytes = 0;
+    std::map<int, size_t> cachedBytes;                         // per device
 } g_scratch;
 size_t scratchClass(size_t bytes) { size_t c = 65536; while (c < bytes) c <<= 1; return c; }
 }  // namespace
@@ -39,16 +42,16 @@ hipError_t s3i::scratchAlloc(void **p, size_t bytes, hipStream_t stream)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const size_t want = scratchClass(bytes ? bytes : 1);
-    ScratchBlock got{nullptr, 0, nullptr, dev};
+    ScratchBlock got{nullptr, 0, nullptr, nullptr, dev};
     {
         std::lock_guard<std::mutex> g(g_scratch.mu);
         for (size_t i = 0; i < g_scratch.freeBlocks.size(); i++) {
             const ScratchBlock &b = g_scratch.freeBlocks[i];
-            if (b.device == dev && b.bytes == want) { got = b; g_scratch.freeBlocks.erase(g_scratch.freeBlocks.begin() + (long)i); g_scratch.cachedBytes -= want; break; }
+            if (b.device == dev && b.bytes == want) { got = b; g_scratch.freeBlocks.erase(g_scratch.freeBlocks.begin() + (long)i); g_scratch.cachedBytes[dev] -= want; break; }
         }
     }
     if (got.p) {
-        if (got.lastStream && got.lastStream != stream && (e = hipStreamSynchronize(got.lastStream)) != hipSuccess) return e;
+        if (got.done && got.lastStream != stream && (e = hipStreamWaitEvent(stream, got.done, 0)) != hipSuccess) return e;
     } else {
         if ((e = hipMalloc(&got.p, want)) != hipSuccess) {
             s3i::scratchTrim(dev);                              // the cache may hold what is missing
@@ -68,8 +71,8 @@ hipError_t s3i::scratchAlloc(void **p, size_t bytes, hipStream_t stream)
 void s3i::scratchFree(void *p, hipStream_t stream)
 {
     if (!p) return;
-    ScratchBlock b{nullptr, 0, nullptr, 0};
-    bool giveBack = false;
+    ScratchBlock b{nullptr, 0, nullptr, nullptr, 0};
+    bool giveBack = false, ours = false;
     {
         std::lock_guard<std::mutex> g(g_scratch.mu);
         auto it = g_scratch.live.find(p);
@@ -77,16 +80,28 @@ void s3i::scratchFree(void *p, hipStream_t stream)
         else {
             b = it->second;
             g_scratch.live.erase(it);
-            b.lastStream = stream;
-            if (g_scratch.cachedBytes + b.bytes > ((size_t)8 << 30)) giveBack = true;
-            else { g_scratch.freeBlocks.push_back(b); g_scratch.cachedBytes += b.bytes; }
+            ours = true;
         }
     }
-    if (giveBack) (void)hipFree(p);
+    if (ours) {
+        // the block's last use, as an event on the stream that used it (recorded outside the lock: nobody else knows the block at this point)
+        hipError_t e = b.done ? hipSuccess : hipEventCreateWithFlags(&b.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(b.done, stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(stream); if (b.done) { (void)hipEventDestroy(b.done); b.done = nullptr; } }
+        b.lastStream = stream;
+        std::lock_guard<std::mutex> g(g_scratch.mu);
+        if (g_scratch.cachedBytes[b.device] + b.bytes > ((size_t)8 << 30)) giveBack = true;       // (per device)
+        else { g_scratch.freeBlocks.push_back(b); g_scratch.cachedBytes[b.device] += b.bytes; }
+    }
+    if (giveBack) {
+        if (ours && b.done) (void)hipEventDestroy(b.done);
+        (void)hipFree(p);
+    }
 }
 
 void s3i::scratchStreamGone(hipStream_t stream)
 {
+    // (the owner has synchronised `stream`: the events recorded on it are complete and stay valid; only the handle must not be compared again)
     std::lock_guard<std::mutex> g(g_scratch.mu);
     for (ScratchBlock &b : g_scratch.freeBlocks) if (b.lastStream == stream) b.lastStream = nullptr;
 }
@@ -97,11 +112,11 @@ void s3i::scratchTrim(int device)
     {
         std::lock_guard<std::mutex> g(g_scratch.mu);
         for (size_t i = 0; i < g_scratch.freeBlocks.size();) {
-            if (g_scratch.freeBlocks[i].device == device) { mine.push_back(g_scratch.freeBlocks[i]); g_scratch.cachedBytes -= g_scratch.freeBlocks[i].bytes; g_scratch.freeBlocks.erase(g_scratch.freeBlocks.begin() + (long)i); }
+            if (g_scratch.freeBlocks[i].device == device) { mine.push_back(g_scratch.freeBlocks[i]); g_scratch.cachedBytes[device] -= g_scratch.freeBlocks[i].bytes; g_scratch.freeBlocks.erase(g_scratch.freeBlocks.begin() + (long)i); }
             else i++;
         }
     }
-    for (const ScratchBlock &b : mine) (void)hipFree(b.p);
+    for (const ScratchBlock &b : mine) { if (b.done) (void)hipEventDestroy(b.done); (void)hipFree(b.p); }
 }
 
 namespace {

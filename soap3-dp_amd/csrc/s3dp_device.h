@@ -220,6 +220,11 @@ struct PairSweepArgs {
     DevPair        *pairs;
     uint32_t       *bestIdx, *xaCount;           // per slot-pair
     uint32_t       *xaStart, *xaCountOut;        // per pair (global index)
+    // pairs with long lists (more than heavyMin entries on both ends together) are listed by pairStatsKernel and taken by one wave each
+    uint32_t        heavyMin, regionBase;
+    uint32_t       *heavyList, *heavyCount;      // slots of the listed pairs
+    uint32_t       *bestRank, *bestLocal;        // per slot-pair: the optimal pair as (rank of its left leg, number of the partner)
+    uint32_t       *scratchW, *scratchR;         // one word each per occurrence of the phase's region (index - regionBase)
 };
 void launchPairExpand(uint32_t nPairs, const uint32_t *activePairs, uint32_t *readList, hipStream_t s);
 void launchPairClassify(const PairClassifyArgs &a, hipStream_t s);

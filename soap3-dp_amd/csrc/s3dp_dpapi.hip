@@ -704,7 +704,8 @@ struct PairCand { uint32_t pos[2]; uint32_t readIDLeft; };
 // shared by the deep DP (both ends seeded) and the new default DP (one end's positions given by the BWT stage, only its mate seeded)
 static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *pairFirstReads, size_t nPairs, int stage,
                     uint32_t maxHitNum, int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight,
-                    s3_dp_deep_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut, uint8_t **tooManyHitsOut, const s3_occ *given, size_t nGiven);
+                    s3_dp_deep_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut, uint8_t **tooManyHitsOut, const s3_occ *given, size_t nGiven,
+                    const uint8_t *givenEndOnDevice = nullptr);
 
 extern "C" int s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *pairFirstReads, size_t nPairs, int stage,
                           uint32_t maxHitNum, int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight,
@@ -738,9 +739,35 @@ extern "C" int s3_dp_new_default(s3_dp *h, s3_batch *b, s3_batch *seedBatch, con
     return S3_OK;
 }
 
+// The same with the aligned ends' hits where s3_batch_route_pairs left them on the device: the list never comes to the host (11 M entries per chunk of 512 Ki
+// pairs on a genome that is half repeats: 0.11 s to upload, as much again to walk on the host)
+extern "C" int s3_dp_new_default_routed(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, uint32_t maxHitNum, int insertLow, int insertHigh,
+                                        const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_deep_result **resultsOut, size_t *nResultsOut,
+                                        char **cigarPoolOut, uint8_t **pairFlagsOut, uint32_t **pairFirstReadsOut, size_t *nPairsOut)
+{
+    if (!b || !b->routed) return fail(S3_EINVAL, "s3_dp_new_default_routed: call s3_batch_route_pairs first");
+    std::vector<uint32_t> pairs;
+    std::vector<uint8_t> givenEnd;
+    for (uint32_t p = 0; p < b->n / 2; p++)
+        if (b->hPairRoute[p] & S3_ROUTE_NEW_DEFAULT) { pairs.push_back(2 * p); givenEnd.push_back((b->hPairRoute[p] & S3_ROUTE_GIVEN_END_2) ? 1 : 0); }
+    const s3_occ *dGiven = (const s3_occ *)(b->dRouteOcc + (size_t)(b->n ? b->hRouteOffs[b->n] : 0u) * 3);
+    int rc = deepImpl(h, b, seedBatch, readLengths, pairs.data(), pairs.size(), S3_STAGE_NEW_DEFAULT_DP, maxHitNum, insertLow, insertHigh, cutoffThreshold, softClipLeft,
+                      softClipRight, resultsOut, nResultsOut, cigarPoolOut, pairFlagsOut, dGiven, (size_t)b->routing.nNewDefault, givenEnd.data());
+    if (rc) return rc;
+    if (pairFirstReadsOut) {
+        uint32_t *p = (uint32_t *)malloc(pairs.size() * 4 + 4);
+        if (!p) return fail(S3_ENOMEM, "s3_dp_new_default_routed: out of host memory");
+        memcpy(p, pairs.data(), pairs.size() * 4);
+        *pairFirstReadsOut = p;
+    }
+    if (nPairsOut) *nPairsOut = pairs.size();
+    return S3_OK;
+}
+
 static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *readLengths, const uint32_t *pairFirstReads, size_t nPairs, int stage,
                     uint32_t maxHitNum, int insertLow, int insertHigh, const int cutoffThreshold[2], int softClipLeft, int softClipRight,
-                    s3_dp_deep_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut, uint8_t **tooManyHitsOut, const s3_occ *given, size_t nGiven)
+                    s3_dp_deep_result **resultsOut, size_t *nResultsOut, char **cigarPoolOut, uint8_t **tooManyHitsOut, const s3_occ *given, size_t nGiven,
+                    const uint8_t *givenEndOnDevice)
 {
     if (!h || !b || !seedBatch || !readLengths || (!pairFirstReads && nPairs) || !cutoffThreshold || !resultsOut || !nResultsOut || !cigarPoolOut)
         return fail(S3_EINVAL, "s3_dp_deep: null argument");
@@ -750,13 +777,19 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
     double lapMs[6] = {0, 0, 0, 0, 0, 0};                                     // seeds listed, seeds searched, positions sorted + merged, DP rounds, decode, rest
     auto lap = [&](int k) { const auto now = std::chrono::steady_clock::now(); lapMs[k] += std::chrono::duration<double, std::milli>(now - tLap).count(); tLap = now; };
     // new default DP: the end whose hits are given is not seeded (packSeedsOneSide seeds the mate of the pair's FIRST occurrence, DV-DPfunctions.cu:2756-2776)
+    // (givenEndOnDevice: `given` is a device pointer and the given end of every pair comes with it)
+    const bool givenOnDevice = givenEndOnDevice != nullptr;
     std::vector<uint8_t> givenEnd(nPairs, 255);
-    for (size_t i = 0; i < nGiven; i++) {
-        const uint32_t even = given[i].readID & ~1u;
-        const uint32_t *it = std::lower_bound(pairFirstReads, pairFirstReads + nPairs, even);
-        if (it == pairFirstReads + nPairs || *it != even) return fail(S3_EINVAL, "s3_dp_new_default: occurrence of a pair that is not listed");
-        uint8_t &g = givenEnd[(size_t)(it - pairFirstReads)];
-        if (g == 255) g = (uint8_t)(given[i].readID & 1u);
+    if (givenOnDevice) givenEnd.assign(givenEndOnDevice, givenEndOnDevice + nPairs);
+    else {
+        const uint32_t *it = pairFirstReads;                                    // (the occurrences are grouped by pair, pairs ascending: the search resumes where it was)
+        for (size_t i = 0; i < nGiven; i++) {
+            const uint32_t even = given[i].readID & ~1u;
+            if (it == pairFirstReads + nPairs || *it != even) it = std::lower_bound(pairFirstReads, pairFirstReads + nPairs, even);
+            if (it == pairFirstReads + nPairs || *it != even) return fail(S3_EINVAL, "s3_dp_new_default: occurrence of a pair that is not listed");
+            uint8_t &g = givenEnd[(size_t)(it - pairFirstReads)];
+            if (g == 255) g = (uint8_t)(given[i].readID & 1u);
+        }
     }
     if (b->ix != seedBatch->ix || b == seedBatch || h->dev != b->ix->dev) return fail(S3_EINVAL, "s3_dp_deep: batches / aligner do not belong together");
     const int leftLeg = 1, rightLeg = 2;
@@ -792,11 +825,12 @@ static int deepImpl(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *
         for (size_t k = 0; k < nPairs; k++)
             for (; j < seeds.size() && (seeds[j].keyHi & 0x3FFFFFFFu) == pairFirstReads[k]; j++) if (status[j] == 4) tooMany[k] = 1;
     }
-    for (size_t i = 0; i < nGiven; i++) if (given[i].strand < 1 || given[i].strand > 2) { scratchFree(dKeys, seedBatch->stream); return fail(S3_EINVAL, "s3_dp_new_default: bad strand"); }
+    if (!givenOnDevice)
+        for (size_t i = 0; i < nGiven; i++) if (given[i].strand < 1 || given[i].strand > 2) { scratchFree(dKeys, seedBatch->stream); return fail(S3_EINVAL, "s3_dp_new_default: bad strand"); }
     // ---- pairEndMerge on the device (s3dp_seed.hip): the positions never come to the host; the candidates do, ordered by the left read --------------------
     std::vector<PairCandHost> candsDev;
     std::vector<uint32_t> perPair;
-    rc = pairMergeOnDevice(b, dKeys, nKeys, given, nGiven, pairFirstReads, nPairs, insertLow, insertHigh, candsDev, perPair);
+    rc = pairMergeOnDevice(b, dKeys, nKeys, given, nGiven, givenOnDevice, pairFirstReads, nPairs, insertLow, insertHigh, candsDev, perPair);
     scratchFree(dKeys, seedBatch->stream);
     if (rc) return rc;
     std::vector<PairCand> cands(candsDev.size());

@@ -93,11 +93,20 @@ struct s3_batch {
     uint32_t *dReadList = nullptr, *dPairActive[2] = {nullptr, nullptr}, *dBestIdx = nullptr, *dXaCount = nullptr, *dXaOffsets = nullptr;
     uint32_t *dXaStart = nullptr, *dXaCountOut = nullptr, *dXaOutOffsets = nullptr, *dOccCountIn = nullptr, *dSegBegin = nullptr, *dSegEnd = nullptr;
     s3::DevPairXa *dXa = nullptr, *dXaOut = nullptr;
+    uint32_t *dPairHeavyList = nullptr, *dPairHeavyCount = nullptr, *dBestRank = nullptr, *dBestLocal = nullptr;   // pairs with long lists (s3dp_pair.hip)
     uint32_t xaCap = 0, xaUsed = 0;
     uint64_t *dSortKeys[2] = {nullptr, nullptr};
     uint32_t *dSortMeta = nullptr;
     char     *dSortTemp = nullptr;
     size_t    sortItems = 0, sortTempBytes = 0;
+    // routing of the unpaired pairs (s3dp_route.hip; allocated by the first s3_batch_route_pairs)
+    uint32_t *dRouteKept = nullptr, *dRouteCounts = nullptr, *dRouteOffs = nullptr, *dRouteOcc = nullptr;
+    uint8_t  *dRouteThr = nullptr, *dRoute = nullptr, *dPairRoute = nullptr;
+    char     *dRouteTemp = nullptr; size_t routeTempBytes = 0, routeCap = 0;
+    bool routed = false;
+    s3_pair_routing routing{};
+    std::vector<uint8_t> hPairRoute;               // host copies of the last routing: per pair the S3_ROUTE_* bits ...
+    std::vector<uint32_t> hRouteOffs;              // ... and where every read's entries start in each of the three lists ([3][n] + 1)
     std::vector<void *> allocs;
     // state of the last call
     bool failed = false;           // a buffer was lost while growing (bgrow): every later call on this batch returns S3_ENOMEM
@@ -217,8 +226,9 @@ int seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<SeedD
 // pairEndMerge on the device (s3dp_seed.hip): the sorted position keys of both ends (device; plus `given` occurrences, new default DP) -> the pairs of
 // (left, right) positions inside the insert window, ordered by the left read; perPair[k] = candidates of pairFirstReads[k] (both orientations)
 struct PairCandHost { uint32_t pos[2]; uint32_t readIDLeft; };
-int pairMergeOnDevice(s3_batch *b, uint64_t *dKeys, uint32_t nKeys, const s3_occ *given, size_t nGiven, const uint32_t *pairFirstReads, size_t nPairs, int insertLow,
-                      int insertHigh, std::vector<PairCandHost> &cands, std::vector<uint32_t> &perPair);
+// (givenOnDevice: `given` is a device pointer -- the new default DP's list where s3_batch_route_pairs left it)
+int pairMergeOnDevice(s3_batch *b, uint64_t *dKeys, uint32_t nKeys, const s3_occ *given, size_t nGiven, bool givenOnDevice, const uint32_t *pairFirstReads, size_t nPairs,
+                      int insertLow, int insertHigh, std::vector<PairCandHost> &cands, std::vector<uint32_t> &perPair);
 // enqueue the 64-bit sum of counts[0, n) into b->dSum64 (uses b->dTemp: call it after the scan that shares the scratch was enqueued, same stream)
 int sum64Async(s3_batch *b, const uint32_t *counts, uint32_t n);
 // DP (s3dp_dpapi.hip): launch the DP kernels on what is in the aligner's device buffers

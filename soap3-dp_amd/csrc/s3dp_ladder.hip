@@ -333,6 +333,7 @@ static int ensurePairBuffers(s3_batch *b)
     BA(dPairActive[0], maxPairs); BA(dPairActive[1], maxPairs); BA(dBestIdx, maxPairs); BA(dXaCount, maxPairs + 1); BA(dXaOffsets, maxPairs + 1);
     BA(dXaStart, maxPairs); BA(dXaCountOut, maxPairs + 1); BA(dXaOutOffsets, maxPairs + 1); BA(dOccCountIn, maxReads + 2);
     BA(dSegBegin, maxReads + 2); BA(dSegEnd, maxReads + 2);
+    BA(dPairHeavyList, maxPairs); BA(dPairHeavyCount, 4); BA(dBestRank, maxPairs); BA(dBestLocal, maxPairs);
     b->xaCap = (uint32_t)(maxPairs + 65536);
     BA(dXa, b->xaCap); BA(dXaOut, b->xaCap);
 #undef BA
@@ -382,6 +383,7 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
     b->searchLaunches = 0; b->evSearchUsed = 0; b->evCeUsed = 0;
     b->occUsed = 0;
     b->xaUsed = 0;
+    b->routed = false;
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
     if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_NUM_COUNTERS * 8, b->stream));
@@ -453,6 +455,11 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
         sw.occStart = b->dOccStart; sw.occCount = b->dOccCount; sw.occCountIn = b->dOccCountIn; sw.occPos = b->dOccPos; sw.occMeta = b->dOccMeta;
         sw.readLengths = b->dLens; sw.insertLow = insertLow; sw.insertHigh = insertHigh; sw.peMaxOutputPerPair = peMaxOutputPerPair; sw.mm = mm;
         sw.terminal = terminal; sw.pairs = b->dPairs; sw.bestIdx = b->dBestIdx; sw.xaCount = b->dXaCount; sw.xaStart = b->dXaStart; sw.xaCountOut = b->dXaCountOut;
+        // pairs with more than S3DP_PAIR_HEAVY entries on both ends together: one wave per pair (s3dp_pair.hip); 0xFFFFFFFF = every pair by its own lane
+        static const uint32_t heavyMin = (uint32_t)envSize("S3DP_PAIR_HEAVY", 48);
+        sw.heavyMin = items ? heavyMin : 0xFFFFFFFFu; sw.regionBase = regionBase; sw.heavyList = b->dPairHeavyList; sw.heavyCount = b->dPairHeavyCount;
+        sw.bestRank = b->dBestRank; sw.bestLocal = b->dBestLocal; sw.scratchW = (uint32_t *)b->dSortKeys[0]; sw.scratchR = (uint32_t *)b->dSortKeys[1];
+        HIPCHK(hipMemsetAsync(b->dPairHeavyCount, 0, 4, b->stream));
         launchPairStats(sw, b->stream);
         HIPCHK(hipMemsetAsync(b->dXaCount + nA, 0, 4, b->stream));
         size_t tb = b->tempBytes;
@@ -499,6 +506,28 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
     return S3_OK;
 }
 
+// The paired-end result of a ladder that was not run: every pair without a proper pairing, no occurrence on either end.  (Pairs of reads above 150 bases skip
+// the BWT stage, SOAP3-DP.cu:658-662, alignment.cu:1928-1944: the DP stages then find every pair routed to the deep DP.)
+extern "C" int s3_batch_no_pair_result(s3_batch *b)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
+    if (b->n & 1u) return fail(S3_EINVAL, "s3_batch_no_pair_result: the batch must hold an even number of reads");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    int rc = ensurePairBuffers(b);
+    if (rc) return rc;
+    const uint32_t n = b->n, nPairs = n / 2;
+    b->searchLaunches = 0; b->evSearchUsed = 0; b->evCeUsed = 0; b->occUsed = 0; b->xaUsed = 0; b->recordsTotal = 0; b->routed = false;
+    HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
+    HIPCHK(hipMemsetAsync(b->dOutOffsets, 0, ((size_t)n + 1) * 4, b->stream));
+    HIPCHK(hipMemsetAsync(b->dXaOutOffsets, 0, ((size_t)nPairs + 1) * 4, b->stream));
+    if (nPairs) hipLaunchKernelGGL(pairInitKernel, dim3((nPairs + 255) / 256), dim3(256), 0, b->stream, nPairs, b->dPairs);
+    HIPCHK(hipEventRecord(b->evTotal[1], b->stream));
+    HIPCHK(hipGetLastError());
+    b->lastKind = 3;
+    return S3_OK;
+}
+
 extern "C" int s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t *xaOffsets, s3_pair_xa *xa, size_t xaCap, uint64_t *nXaOut,
                                     uint64_t *occOffsets, uint32_t *occPos, uint8_t *occStrand, uint8_t *occMis, size_t occCap, uint64_t *nOccOut)
 {
@@ -518,6 +547,7 @@ extern "C" int s3_batch_fetch_pairs(s3_batch *b, s3_pair_result *pairs, uint64_t
         if (nXa > xaCap) return fail(S3_EOVERFLOW, "s3_batch_fetch_pairs: pair list array too small");
         if (nXa) HIPCHK(d2h(xa, b->dXaOut, nXa * sizeof(DevPairXa), b->stream));
     }
+    if (!occOffsets && !occPos && !occStrand && !occMis && !nOccOut) return S3_OK;   // (a caller that routes the unpaired pairs on the device takes no lists)
     std::vector<uint32_t> ooff((size_t)n + 1);
     HIPCHK(d2h(ooff.data(), b->dOutOffsets, ((size_t)n + 1) * 4, b->stream));
     const uint64_t total = ooff[n];

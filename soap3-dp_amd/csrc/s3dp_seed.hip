@@ -244,8 +244,8 @@ __global__ void runBoundsKernel(const uint64_t *keys, uint32_t n, uint32_t *boun
     bounds[t] = lo;
 }
 
-int s3i::pairMergeOnDevice(s3_batch *b, uint64_t *dKeys, uint32_t nKeys, const s3_occ *given, size_t nGiven, const uint32_t *pairFirstReads, size_t nPairs, int insertLow,
-                           int insertHigh, std::vector<PairCandHost> &cands, std::vector<uint32_t> &perPair)
+int s3i::pairMergeOnDevice(s3_batch *b, uint64_t *dKeys, uint32_t nKeys, const s3_occ *given, size_t nGiven, bool givenOnDevice, const uint32_t *pairFirstReads,
+                           size_t nPairs, int insertLow, int insertHigh, std::vector<PairCandHost> &cands, std::vector<uint32_t> &perPair)
 {
     static_assert(sizeof(PairCandHost) == sizeof(PairCandDev), "candidate layouts");
     cands.clear();
@@ -272,10 +272,10 @@ int s3i::pairMergeOnDevice(s3_batch *b, uint64_t *dKeys, uint32_t nKeys, const s
         const uint32_t m = (uint32_t)(nKeys + nGiven);
         size_t sortBytes = 0;
         PCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, sortBytes, all, sorted, (int)m, 0, 64, st));
-        if ((rc = talloc((void **)&dOcc, nGiven * sizeof(s3_occ))) || (rc = talloc((void **)&all, (size_t)m * 8)) || (rc = talloc((void **)&sorted, (size_t)m * 8)) ||
+        if ((!givenOnDevice && (rc = talloc((void **)&dOcc, nGiven * sizeof(s3_occ)))) || (rc = talloc((void **)&all, (size_t)m * 8)) || (rc = talloc((void **)&sorted, (size_t)m * 8)) ||
             (rc = talloc((void **)&sortTmp, sortBytes))) return rc;
-        PCHK(hipMemcpyAsync(dOcc, given, nGiven * sizeof(s3_occ), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(givenKeysKernel, dim3((unsigned)((nGiven + 255) / 256)), dim3(256), 0, st, dOcc, (uint32_t)nGiven, all);
+        if (!givenOnDevice) PCHK(hipMemcpyAsync(dOcc, given, nGiven * sizeof(s3_occ), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(givenKeysKernel, dim3((unsigned)((nGiven + 255) / 256)), dim3(256), 0, st, givenOnDevice ? given : dOcc, (uint32_t)nGiven, all);
         if (nKeys) PCHK(hipMemcpyAsync(all + nGiven, dKeys, (size_t)nKeys * 8, hipMemcpyDeviceToDevice, st));
         PCHK(hipcub::DeviceRadixSort::SortKeys(sortTmp, sortBytes, all, sorted, (int)m, 0, 64, st));
         keys = sorted; n = m;

@@ -298,6 +298,7 @@ struct PairDpCtx {
     const HostIndex &hix; const SamOptions &so; const ReadSet &rs; const Ini &ini;
     s3_batch *b, *seedBatch; s3_dp *dp, *dpHalf; FILE *dpOut, *unpairOut;
     uint32_t first, cnt; int alignmentType, insertLow, insertHigh;
+    s3_pair_routing routing; uint64_t chunkNo, readBase;      // of the chunk: the device-side routing's counts; its number and its first read in the input (routing dump)
     const s3_dp_stage_params *halfPar; const s3_dp_stage_params (*deepPar)[2]; const s3_dp_stage_params &singlePar; const s3_dp_stage_params *newPar;
 };
 
@@ -306,8 +307,7 @@ struct PairDpCtx {
 // (DPForUnalignPairs2: seeding round 1, round 2 for the pairs that only lost seeds to the hit limit, PairEndAlignmentEngine ->
 // outputDeepDPResult2), and for the pairs every stage failed on the single-end DP of their ends (DPForUnalignSingle2 + outputSingleResultForPairEnds)
 // into <prefix>.unpair; pairs with an end aligned to too many places for the default DP go through the new default DP first (newSemiGlobalDP).
-static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &pr, const std::vector<uint64_t> &ooff, const std::vector<uint32_t> &pos,
-                         const std::vector<uint8_t> &strand, const std::vector<uint8_t> &mis, const std::vector<uint8_t> &fromSa, uint64_t &defaultDpPairs,
+static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &pr, uint64_t &defaultDpPairs,
                          uint64_t &newDefaultPairs, uint64_t &deepDpPairs, uint64_t &leftoverPairs, std::string &err)
 {
     const uint32_t np = c.cnt / 2;
@@ -317,94 +317,25 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
         { std::lock_guard<std::mutex> g(g_pairStageMu); g_pairStageSeconds[k] += std::chrono::duration<double>(now - tStage).count(); }
         tStage = now;
     };
-    const bool mapqMode = c.alignmentType == 1 || c.alignmentType == 2;
     const int moduleType = c.alignmentType == 2 ? 1 : c.alignmentType;          // all-best + SAM runs the DP module as all-valid (alignment.cu:2023-2030)
-    const uint32_t maxHit[2] = {(uint32_t)c.halfPar[0].maxHitNum, (uint32_t)c.halfPar[1].maxHitNum};
     const uint32_t *lens = c.rs.lengths.data() + c.first;
-    std::vector<s3_occ> otherOcc;                                                // otherSoap3Result: kept for the unpaired output only
-    std::vector<s3_occ> dpOcc, newOcc;                                          // input of the default DP / of the new default DP
+    // The routing itself (which list of which end goes to which stage, cut at the stage's hit limit) ran on the device behind the ladder
+    // (s3_batch_route_pairs, called by the chunk loop): here come one byte per pair and the default DP's list; the new default DP's list -- the thousands of
+    // hits of ends inside repeat families -- stays where it is, the kept lists of the few pairs every stage fails on are fetched at the end.
+    std::vector<uint8_t> route(np ? np : 1, 0);
+    std::vector<s3_occ> dpOcc((size_t)c.routing.nDefault);
+    if (s3_batch_fetch_routing(c.b, route.data(), dpOcc.data(), dpOcc.size(), nullptr, 0, nullptr, 0) != S3_OK) { err = s3_last_error(); return false; }
     std::vector<uint32_t> deepPairs;                                             // first read (batch index) of the pairs for the deep DP
-    std::vector<uint8_t> inDefault(np, 0);
-    // an end's hits in the order the reference hands them on: half-aligned pairs keep SA ranges and check-and-extend hits apart and the DP input
-    // stream reads the SA ranges first; with hits on both ends everything was merged and sorted by position for the pairing attempt
-    auto endHits = [&](uint32_t r, bool saFirst, std::vector<s3_occ> &out) {
-        out.clear();
-        const size_t o = ooff[r], n = ooff[r + 1] - o;
-        for (int pass = saFirst ? 0 : 1; pass < 2; pass++)
-            for (size_t k = 0; k < n; k++) {
-                if (saFirst && (fromSa[o + k] != 0) != (pass == 0)) continue;
-                s3_occ x{}; x.readID = r; x.pos = pos[o + k]; x.strand = strand[o + k]; x.mismatchCount = mis[o + k];
-                out.push_back(x);
-            }
-    };
-    auto retainBest = [&](std::vector<s3_occ> &v) {                              // retainAllBestAndSecBest / retainAllBest, SAList.cpp:140,290
-        uint8_t mn = 255;
-        for (const s3_occ &x : v) mn = std::min(mn, x.mismatchCount);
-        size_t w = 0;
-        for (const s3_occ &x : v) if (x.mismatchCount <= mn + (mapqMode ? 1 : 0)) v[w++] = x;
-        v.resize(w);
-    };
-    // keepSoap3Results: what the BWT stage leaves of a read for the later stages.  Lists exist for the ends of the pairs without a proper pairing only (a
-    // tenth of a chunk): a vector per READ of the chunk was 2 Mi constructors and destructors per chunk, a fifth of a second per ten million pairs
-    std::vector<uint32_t> keptSlot(np, 0xFFFFFFFFu);
-    uint32_t nUnpaired = 0;
-    for (uint32_t p = 0; p < np; p++) if (!pr[p].phase) keptSlot[p] = nUnpaired++;
-    std::vector<std::vector<s3_occ>> keptLists((size_t)2 * nUnpaired);
-    auto kept = [&](uint32_t r) -> std::vector<s3_occ> & { return keptLists[(size_t)2 * keptSlot[r >> 1] + (r & 1u)]; };
-    {
-        // the pairs are routed by all host threads, a contiguous range of pairs each, and the ranges' lists joined in pair order (a pair inside a repeat
-        // family brings thousands of hits per end: the loop moves tens of millions of entries per chunk)
-        struct alignas(128) Part { std::vector<s3_occ> dp, nw, other; std::vector<uint32_t> deep; };      // (a cache line pair each: see OutBuffer)
-        const int T = std::max(1, std::min(hostThreads(), 32));
-        std::vector<Part> parts((size_t)T);
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++) th.emplace_back([&, t] {
-            Part &P = parts[(size_t)t];
-            std::vector<s3_occ> h1, h2;
-            const uint32_t lo = (uint32_t)((uint64_t)np * t / T), hi = (uint32_t)((uint64_t)np * (t + 1) / T);
-            for (uint32_t p = lo; p < hi; p++) {
-                if (pr[p].phase) continue;
-                const uint32_t r1 = 2 * p, r2 = r1 + 1;
-                const size_t n1 = ooff[r1 + 1] - ooff[r1], n2 = ooff[r2 + 1] - ooff[r2];
-                if (n1 == 0 && n2 == 0) { P.deep.push_back(r1); continue; }
-                if (n1 == 0 || n2 == 0) {
-                    const int e = n1 ? 0 : 1;
-                    endHits(e ? r2 : r1, true, h1);
-                    if (h1.size() > maxHit[e]) retainBest(h1);
-                    kept(e ? r2 : r1) = h1;
-                    if (h1.size() <= maxHit[e]) { P.dp.insert(P.dp.end(), h1.begin(), h1.end()); inDefault[p] = 1; }
-                    else P.nw.insert(P.nw.end(), h1.begin(), h1.end());
-                    continue;
-                }
-                endHits(r1, false, h1); endHits(r2, false, h2);
-                if (h1.size() > maxHit[0]) retainBest(h1);
-                if (h2.size() > maxHit[1]) retainBest(h2);
-                kept(r1) = h1; kept(r2) = h2;
-                if (h1.size() <= maxHit[0] && h2.size() <= maxHit[1]) { P.dp.insert(P.dp.end(), h1.begin(), h1.end()); P.dp.insert(P.dp.end(), h2.begin(), h2.end()); inDefault[p] = 1; }
-                else if (h1.size() < h2.size()) {
-                    if (h1.size() <= maxHit[0]) { P.dp.insert(P.dp.end(), h1.begin(), h1.end()); inDefault[p] = 1; } else P.nw.insert(P.nw.end(), h1.begin(), h1.end());
-                    P.other.insert(P.other.end(), h2.begin(), h2.end());
-                } else {
-                    if (h2.size() <= maxHit[1]) { P.dp.insert(P.dp.end(), h2.begin(), h2.end()); inDefault[p] = 1; } else P.nw.insert(P.nw.end(), h2.begin(), h2.end());
-                    P.other.insert(P.other.end(), h1.begin(), h1.end());
-                }
-            }
-        });
-        for (auto &x : th) x.join();
-        for (const Part &P : parts) {
-            dpOcc.insert(dpOcc.end(), P.dp.begin(), P.dp.end());
-            newOcc.insert(newOcc.end(), P.nw.begin(), P.nw.end());
-            otherOcc.insert(otherOcc.end(), P.other.begin(), P.other.end());
-            deepPairs.insert(deepPairs.end(), P.deep.begin(), P.deep.end());
-        }
-    }
+    for (uint32_t p = 0; p < np; p++) if (route[p] & S3_ROUTE_DEEP) deepPairs.push_back(2 * p);
     if (const char *dump = getenv("S3DP_DUMP_ROUTING")) {                        // the routing, for tests/test_gpu_cli_sam.py (format: oracle/ref_harness.cpp)
-        FILE *f = fopen(dump, c.first ? "a" : "w");
+        std::vector<s3_occ> newOcc((size_t)c.routing.nNewDefault), otherOcc((size_t)c.routing.nOther);
+        if (s3_batch_fetch_routing(c.b, nullptr, nullptr, 0, newOcc.data(), newOcc.size(), otherOcc.data(), otherOcc.size()) != S3_OK) { err = s3_last_error(); return false; }
+        FILE *f = fopen(dump, c.first || c.chunkNo ? "a" : "w");
         if (f) {
             const std::vector<s3_occ> *lists[3] = {&dpOcc, &newOcc, &otherOcc};
             for (int l = 0; l < 3; l++)
-                for (const s3_occ &x : *lists[l]) fprintf(f, "%c %u %d %d %u\n", "DNO"[l], c.first + x.readID, (int)x.strand, (int)x.mismatchCount, x.pos);
-            for (uint32_t r1 : deepPairs) fprintf(f, "U %u\n", c.first + r1);
+                for (const s3_occ &x : *lists[l]) fprintf(f, "%c %llu %d %d %u\n", "DNO"[l], (unsigned long long)(c.readBase + x.readID), (int)x.strand, (int)x.mismatchCount, x.pos);
+            for (uint32_t r1 : deepPairs) fprintf(f, "U %llu\n", (unsigned long long)(c.readBase + r1));
             fclose(f);
         }
     }
@@ -466,7 +397,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             }
         }, defaultDpPairs);
         s3_free(res); s3_free(pool);
-        for (uint32_t p = 0; p < np; p++) if (inDefault[p] && !done[p]) deepPairs.push_back(2 * p);
+        for (uint32_t p = 0; p < np; p++) if ((route[p] & S3_ROUTE_DEFAULT) && !done[p]) deepPairs.push_back(2 * p);
         std::sort(deepPairs.begin(), deepPairs.end());
     }
     // deep-DP results of a run of pairs -> records (DP2OutputThread :3846-3858: OutputBuffer::ready(), then outputDeepDPResult2)
@@ -518,14 +449,14 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
     };
     lap(1);
     // ---- new default DP (the reference runs it before the default DP; the stages are independent of each other) ----
-    if (!newOcc.empty()) {
+    if (c.routing.nNewDefault) {
         s3_dp_deep_result *res = nullptr;
         size_t nRes = 0, nNewPairs = 0;
         char *pool = nullptr;
         uint32_t *newPairs = nullptr;
         const int cut[2] = {c.newPar[0].cutoffThreshold, c.newPar[1].cutoffThreshold};
-        if (s3_dp_new_default(c.dp, c.b, c.seedBatch, lens, newOcc.data(), newOcc.size(), (uint32_t)c.newPar[0].maxHitNum, c.insertLow, c.insertHigh, cut,
-                              c.newPar[0].softClipLeft, c.newPar[0].softClipRight, &res, &nRes, &pool, nullptr, &newPairs, &nNewPairs) != S3_OK) { err = s3_last_error(); return false; }
+        if (s3_dp_new_default_routed(c.dp, c.b, c.seedBatch, lens, (uint32_t)c.newPar[0].maxHitNum, c.insertLow, c.insertHigh, cut,
+                                     c.newPar[0].softClipLeft, c.newPar[0].softClipRight, &res, &nRes, &pool, nullptr, &newPairs, &nNewPairs) != S3_OK) { err = s3_last_error(); return false; }
         deepRecords(res, nRes, pool, newDefaultPairs);
         for (size_t k = 0; k < nNewPairs; k++) if (!deepDone[newPairs[k] / 2]) deepPairs.push_back(newPairs[k]);   // passUnalignedToDeepDP
         std::sort(deepPairs.begin(), deepPairs.end());
@@ -569,6 +500,20 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
     //      with hits the FIRST end keeps them, the second end keeps its own only when the first had none) ----
     std::vector<uint32_t> left, todo;
     for (uint32_t r1 : deepPairs) if (!deepDone[r1 / 2]) left.push_back(r1);
+    // keepSoap3Results: what the BWT stage left of the leftover pairs' ends (the lists as they were routed, cut at the hit limit)
+    std::vector<uint32_t> leftReads;
+    for (uint32_t r1 : left) { leftReads.push_back(r1); leftReads.push_back(r1 + 1); }
+    std::vector<uint64_t> keptOff(leftReads.size() + 1, 0);
+    s3_occ *keptOcc = nullptr;
+    if (!leftReads.empty() && s3_batch_fetch_kept(c.b, leftReads.data(), leftReads.size(), keptOff.data(), &keptOcc, nullptr) != S3_OK) { err = s3_last_error(); return false; }
+    struct KeptFree { s3_occ *&p; ~KeptFree() { if (p) s3_free(p); } } keptFree{keptOcc};
+    std::vector<uint32_t> keptSlot(np, 0xFFFFFFFFu);
+    for (size_t lk = 0; lk < left.size(); lk++) keptSlot[left[lk] >> 1] = (uint32_t)lk;
+    struct KeptView { const s3_occ *b, *e; const s3_occ *begin() const { return b; } const s3_occ *end() const { return e; } bool empty() const { return b == e; } };
+    auto kept = [&](uint32_t r) -> KeptView {
+        const size_t i = (size_t)2 * keptSlot[r >> 1] + (r & 1u);
+        return KeptView{keptOcc + keptOff[i], keptOcc + keptOff[i + 1]};
+    };
     std::vector<uint8_t> viaDP(c.cnt, 0);
     for (uint32_t r1 : left) {
         const bool no1 = kept(r1).empty(), no2 = kept(r1 + 1).empty();
@@ -1002,7 +947,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     // a quarter second of kernels per ten million pairs and used to run between two chunks' searches ------------------------------------------------
     struct PairJob {
         std::unique_ptr<ReadSet> rs; s3_batch *b = nullptr; uint32_t cnt = 0;
-        std::vector<s3_pair_result> pr; std::vector<uint64_t> ooff; std::vector<uint32_t> pos; std::vector<uint8_t> strand, mis, fromSa;
+        std::vector<s3_pair_result> pr; s3_pair_routing routing{}; uint64_t chunkNo = 0, readBase = 0;
         std::vector<uint32_t> todo; bool hadSeedLengths = false;                  // single reads (default mode): the reads the BWT stage left without a hit
     };
     struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<PairJob>> q; std::vector<s3_batch *> freeBatches; bool stop = false; } dpq;
@@ -1036,8 +981,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 const auto tDp = std::chrono::steady_clock::now();
                 auto fatal = [&](const std::string &m) { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); };
                 if (paired) {
-                    PairDpCtx c{hix, so, *j->rs, ini, j->b, seedW, dpW, halfW, dpOut, unpairOut, 0u, j->cnt, alignmentType, insertLow, insertHigh, halfPar, deepPar, dpPar, newPar};
-                    if (!pairDpStages(c, j->pr, j->ooff, j->pos, j->strand, j->mis, j->fromSa, cntW[1], cntW[2], cntW[3], cntW[4], e2)) fatal(e2);
+                    PairDpCtx c{hix, so, *j->rs, ini, j->b, seedW, dpW, halfW, dpOut, unpairOut, 0u, j->cnt, alignmentType, insertLow, insertHigh, j->routing, j->chunkNo,
+                                j->readBase, halfPar, deepPar, dpPar, newPar};
+                    if (!pairDpStages(c, j->pr, cntW[1], cntW[2], cntW[3], cntW[4], e2)) fatal(e2);
                 } else {
                     // DPForUnalignSingle2 (DV-DPForSingleReads.cu): seeding in batches of at most 256 Ki seeds, DP at the candidates, one record per run of
                     // results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776), the rest as unaligned records
@@ -1094,9 +1040,27 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             uint64_t nXa = 0, nOcc = 0;
             std::vector<s3_pair_xa> xa(1);
             std::vector<uint32_t> pos(1);
-            std::vector<uint8_t> strand(1), mis(1), fromSa(1);
+            std::vector<uint8_t> strand(1), mis(1);
+            s3_pair_routing routing{};
+            const bool mapqMode = alignmentType == 1 || alignmentType == 2;
+            const uint32_t routeMaxHit[2] = {(uint32_t)halfPar[0].maxHitNum, (uint32_t)halfPar[1].maxHitNum};
             if (skipSoap3) {
-                for (s3_pair_result &x : pr) { memset(&x, 0, sizeof x); x.min1 = x.min2 = 255; }     // no BWT stage: nothing paired, no hits
+                // no BWT stage: nothing paired, no hits -- an empty ladder result (numMismatch 0 over nothing would still search; the batch is told directly)
+                for (s3_pair_result &x : pr) { memset(&x, 0, sizeof x); x.min1 = x.min2 = 255; }
+                if (s3_batch_no_pair_result(b) != S3_OK || s3_batch_route_pairs(b, routeMaxHit, mapqMode, &routing) != S3_OK) return dieJoin(s3_last_error());
+            } else if (enableDP) {
+                // DP stages on: the occurrence lists of the unpaired pairs stay on the device -- routed there (s3dp_route.hip), read there by the DP stages
+                const auto tA = std::chrono::steady_clock::now();
+                if (s3_batch_align_pair(b, (uint32_t)numMismatch, ini.maxHitsEachEndForPairing, alignmentType, (uint32_t)insertLow, (uint32_t)insertHigh,
+                                        ini.peMaxOutputPerPair) != S3_OK) return dieJoin(s3_last_error());
+                if (s3_batch_route_pairs(b, routeMaxHit, mapqMode, &routing) != S3_OK) return dieJoin(s3_last_error());
+                addChunkSeconds(0, since(tA));
+                const auto tF = std::chrono::steady_clock::now();
+                if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != S3_OK) return dieJoin(s3_last_error());
+                addBatchTiming(b);
+                xa.resize(nXa ? nXa : 1);
+                if (nXa && s3_batch_fetch_pairs(b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != S3_OK) return dieJoin(s3_last_error());
+                addChunkSeconds(1, since(tF));
             } else {
                 const auto tA = std::chrono::steady_clock::now();
                 if (s3_batch_align_pair(b, (uint32_t)numMismatch, ini.maxHitsEachEndForPairing, alignmentType, (uint32_t)insertLow, (uint32_t)insertHigh,
@@ -1106,10 +1070,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 const auto tF = std::chrono::steady_clock::now();
                 if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, ooff.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return dieJoin(s3_last_error());
                 addBatchTiming(b);
-                xa.resize(nXa ? nXa : 1); pos.resize(nOcc ? nOcc : 1); strand.resize(nOcc ? nOcc : 1); mis.resize(nOcc ? nOcc : 1); fromSa.resize(nOcc ? nOcc : 1);
+                xa.resize(nXa ? nXa : 1); pos.resize(nOcc ? nOcc : 1); strand.resize(nOcc ? nOcc : 1); mis.resize(nOcc ? nOcc : 1);
                 if (s3_batch_fetch_pairs(b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK)
                     return dieJoin(s3_last_error());
-                if (enableDP && s3_batch_fetch_pair_origins(b, fromSa.data(), fromSa.size()) != S3_OK) return dieJoin(s3_last_error());
                 addChunkSeconds(1, since(tF));
             }
             const auto tW = std::chrono::steady_clock::now();
@@ -1130,7 +1093,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             if (enableDP) {
                 std::unique_ptr<PairJob> j(new PairJob());
                 j->b = b; j->cnt = cnt;
-                j->pr.swap(pr); j->ooff.swap(ooff); j->pos.swap(pos); j->strand.swap(strand); j->mis.swap(mis); j->fromSa.swap(fromSa);
+                j->pr.swap(pr); j->routing = routing; j->chunkNo = chunkNo; j->readBase = totalReads - cnt;
                 j->rs = std::move(chunk);                                          // (the loop's recycle() gets nothing: the worker gives the set back)
                 { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); }
                 dpq.cv.notify_all();
