@@ -443,6 +443,7 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
     def cli_part():
         # ---- end to end: the command line with the DP stages on ----
         work = workdir or tempfile.mkdtemp(prefix="s3dp_c3_", dir="/tmp")
+        os.makedirs(work, exist_ok=True)
         try:
             t0 = time.perf_counter()
             prefix = index_prefix or os.path.join(work, "g.index")
@@ -685,6 +686,145 @@ def cpu_baseline(hi, q, lens, wpq, mm, max_out, budget_s):
             "reads_per_s_per_core": total / dt / cores, "rank_queries_per_read": ranks / max(1, total)}
 
 
+def cpu_reference_leg(n_reads=200_000):
+    """The reference's OWN CPU path timed beside the port (cpu_baseline.kind "reference"): oracle/_ref/ref_harness -- the reference's hostKernel
+    (CPUfunctions.cpp:1498: every (read, case) resolved by its CPU twin BGS-HostAlgnmtAlgo2.cpp, occurrences decoded, SAM records written), compiled from the
+    reference's sources by oracle/ref.mk -- on a simulated 3 Mbp genome with repeat families and N runs indexed by the reference's own builder
+    (oracle/_ref/soap3-dp-builder + BGS-Build; GRCh38-scale files would take the reference builder hours), `single -L 100 -s 4 -b 2`, one CPU thread; and
+    the port (oracle/s3_oracle.c, what cpu_baseline times on the headline workload) on the same reads and the same index files, one thread: the ratio
+    calibrates the port.  None when the prebuilt reference binaries are not there."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    import s3dp
+    import s3o
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    need = [os.path.join(ref, x) for x in ("ref_harness", "soap3-dp-builder", "BGS-Build", "soap3-dp-builder.ini")]
+    if not all(os.path.exists(x) for x in need):
+        return None
+    w = tempfile.mkdtemp(prefix="s3dp_refcpu_", dir="/tmp")
+    try:
+        sim = os.path.join(ROOT, "tools", "simulate.py")
+        subprocess.check_call([sys.executable, sim, "--genome-len", "3000000", "--chroms", "4", "--n-runs", "6", "--repeats", "24", "--genome-seed", "101", "--fasta",
+                               os.path.join(w, "g.fa"), "--reads", str(n_reads), "--read-len", "100", "--read-seed", "7", "--fastq", os.path.join(w, "se.fq")],
+                              stdout=subprocess.DEVNULL)
+        shutil.copy(os.path.join(ref, "soap3-dp-builder.ini"), os.path.join(w, "soap3-dp-builder.ini"))
+        subprocess.check_call([os.path.join(ref, "soap3-dp-builder"), "g.fa"], cwd=w, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(ref, "BGS-Build"), "g.fa.index"], cwd=w, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        ini = os.path.join(ROOT, "soap3-dp_amd", "host", "soap3-dp.ini")
+        out = subprocess.run([os.path.join(ref, "ref_harness"), "sam", ini, "single", "g.fa.index", "se.fq", "-L", "100", "-s", "4", "-b", "2", "-o", "ref"], cwd=w,
+                             capture_output=True, text=True, env=dict(os.environ, REF_HARNESS_TIMING="1"), timeout=1200)
+        m = re.search(r"\[ref_harness\] hostKernel: ([0-9.]+) seconds in (\d+) passes over (\d+) reads", out.stderr + out.stdout)
+        if out.returncode != 0 or not m:
+            return {"error": "ref_harness failed: " + (out.stderr or out.stdout)[-300:]}
+        ref_s = float(m.group(1))
+        hi = s3dp.HostIndex.from_files(os.path.join(w, "g.fa.index"))
+        reads = s3o.read_fastq(os.path.join(w, "se.fq"))
+        q, lens, wpq = s3dp.pack_reads(reads, 100)
+        oix = s3o.Index(host_index=hi)
+        t0 = time.perf_counter()
+        res = oix.align_single_allbest(q, lens, wpq, 4, 1000)
+        port_s = time.perf_counter() - t0
+        oix.close()
+        return {"kind": "reference", "what": "oracle/_ref/ref_harness: the reference's hostKernel (CPUfunctions.cpp:1498) compiled from /root/reference by oracle/ref.mk, "
+                                             "wall clock inside hostKernel summed over the ladder's passes, one CPU thread",
+                "sample": "%d simulated 100 bp reads (tools/simulate.py, read seed 7) on a 3 Mbp genome with repeat families and N runs (genome seed 101), index files by the "
+                          "reference's soap3-dp-builder + BGS-Build, single -L 100 -s 4 -b 2" % n_reads,
+                "cores": 1, "value": n_reads / ref_s / 1e6, "unit": "M reads/s", "seconds": ref_s,
+                "port_same_input": {"kind": "port", "cores": 1, "value": n_reads / port_s / 1e6, "unit": "M reads/s", "seconds": port_s,
+                                    "what": "oracle/s3_oracle.c (ladder + decode, no SAM text) on the same reads and index files, one thread",
+                                    "occurrences": int(res[2][-1])},
+                "port_over_reference": ref_s / port_s}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(w, ignore_errors=True)
+
+
+def select_packed(q, wpq, rows):
+    """the packed words of reads `rows` (a multiple of 32 of them) as a batch of their own: the layout interleaves 32 reads word by word"""
+    m = len(rows)
+    assert m % 32 == 0
+    q3 = q.reshape(-1, wpq, 32)
+    return np.ascontiguousarray(q3[rows // 32, :, rows % 32].reshape(m // 32, 32, wpq).transpose(0, 2, 1)).ravel()
+
+
+def stratified_oracle_check(hi, q, lens, wpq, mm, max_out, phase, werr, offs, pos, strand, mis, want, budget_s):
+    """oracle check where the machinery is: reads whose occurrence list was CUT at MaxOutputPerRead (the cut follows the CPU path's search order: units,
+    adoption and the running total must all agree with it), reads with hundreds of occurrences below the cut (listed as heavy, taken apart into units),
+    reads with a handful, and the first reads of the batch -- a quarter of `want` each, in blocks of 32 on every granted core until `budget_s` seconds
+    are used (a read in a repeat family costs the oracle milliseconds).  Bit-exact: phase, WithError, occurrence count, every (position, strand,
+    mismatches) in order."""
+    import concurrent.futures as cf
+    import s3o
+    n = len(lens)
+    counts = np.diff(offs.astype(np.int64))
+    quarter = max(32, want // 4 // 32 * 32)
+    strata = (("cut_at_max_output", np.nonzero(counts >= max_out)[0]), ("hundreds_of_occurrences", np.nonzero((counts >= 100) & (counts < max_out))[0]),
+              ("two_to_99_occurrences", np.nonzero((counts >= 2) & (counts < 100))[0]), ("first_reads", np.arange(min(n, quarter))))
+    rng = np.random.default_rng(4)
+    chosen, tags = [], {}
+    for tag, idx in strata:
+        if tag != "first_reads" and len(idx) > quarter:
+            idx = np.sort(rng.choice(idx, size=quarter, replace=False))
+        idx = idx[:len(idx) // 32 * 32]
+        tags[tag] = len(idx)
+        chosen.append(idx)
+    rows = np.concatenate(chosen) if chosen else np.zeros(0, dtype=np.int64)
+    if not len(rows):
+        return {"reads": 0, "bit_exact": True, "strata": tags}
+    sel = select_packed(q, wpq, rows)
+    ls = np.ascontiguousarray(lens[rows])
+    oix = s3o.Index(host_index=hi)
+    cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    # the strata take turns, so that a run cut short by the budget still covers all of them
+    per = [[] for _ in strata]
+    at = 0
+    for k, idx in enumerate(chosen):
+        per[k] = list(range(at, at + len(idx), 32))
+        at += len(idx)
+    import itertools
+    order = [b for tup in itertools.zip_longest(*per) for b in tup if b is not None]
+    t0 = time.perf_counter()
+    deadline = t0 + budget_s
+    bad, done = [], []
+
+    def work(b0):
+        if time.perf_counter() > deadline:
+            return
+        oph, owe, ooff, opos, ostr, omis, _ = oix.align_single_allbest(sel, ls, wpq, mm, max_out, first=b0, count=32)
+        for j in range(32):
+            r = int(rows[b0 + j])
+            lo, hi_ = int(offs[r]), int(offs[r + 1])
+            o0, o1 = int(ooff[j]), int(ooff[j + 1])
+            if not (phase[r] == oph[j] and (werr[r] == owe[j]).all() and hi_ - lo == o1 - o0 and (pos[lo:hi_] == opos[o0:o1]).all() and
+                    (strand[lo:hi_] == ostr[o0:o1]).all() and (mis[lo:hi_] == omis[o0:o1]).all()):
+                bad.append(r)
+        done.append(b0)
+
+    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(work, order))
+    oix.close()
+    checked = np.zeros(len(rows), dtype=bool)
+    for b0 in done:
+        checked[b0:b0 + 32] = True
+    by = {}
+    at = 0
+    for (tag, _), idx in zip(strata, chosen):
+        by[tag] = {"chosen": int(len(idx)), "checked": int(checked[at:at + len(idx)].sum())}
+        at += len(idx)
+    return {"reads": int(checked.sum()), "bit_exact": not bad, "differing_reads": [int(x) for x in bad[:8]], "strata": by, "seconds": time.perf_counter() - t0,
+            "what": "reads chosen where the heavy-read machinery works (cut at MaxOutputPerRead / hundreds of occurrences / a few / the first reads), against the CPU oracle: "
+                    "phase, WithError, every occurrence in order"}
+
+
 def truth_check(phase, offs, pos, strand, mis, tpos, tstrand, tsub, max_out):
     """The simulated place of every read against what the ladder reported.  All-best reports the best stratum only, cut at MaxOutputPerRead,
     so for every read with at most 4 substitutions: it must be aligned; unless its list was cut at MaxOutputPerRead (the cut follows the search
@@ -911,7 +1051,7 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
                     (po == pos[lo:hi]).all() and (sr == strand[lo:hi]).all() and (mi == mis[lo:hi]).all()):
                 mism.append(first)
         def one_stream(batch_reads, depth):
-            st = s3dp.stream_bench(ix, q, lens, wpq, a.mismatch, a.max_out, batch_reads, a.steps, depth=depth, check=chk)
+            st = s3dp.stream_bench(ix, q, lens, wpq, a.mismatch, a.max_out, batch_reads, min(a.steps, 5), depth=depth, check=chk)
             if mism:
                 raise SystemExit("bench.py: streamed results differ from the resident batch's (batches at reads %r)" % mism[:5])
             st["same_results_as_resident"] = True
@@ -944,8 +1084,10 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
         n_rank = min(n_rank, float(walk["rank_queries"]))
     elif cpu and cpu["rank_queries_per_read"] * a.reads < n_rank:
         n_rank = cpu["rank_queries_per_read"] * a.reads
-    bytes_strict = 32.0 * n_rank + a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"]
-    bytes_step = bytes_strict + 16.0 * cnt["ltLookups"] + 4.0 * cnt["saReads"] + 16.0 * cnt["ceWindows"]
+    # headline (nothing added): 32 B per rank query of the reference algorithm + the packed reads + 12 B per OUTPUT hit (the occurrences the
+    # ladder reports); the extended figure, a named secondary: 12 B per internal record instead and what lookup tables and check-and-extend read
+    bytes_strict = 32.0 * n_rank + a.reads * (4.0 * wpq + 4.0) + 12.0 * n_occ
+    bytes_step = 32.0 * n_rank + a.reads * (4.0 * wpq + 4.0) + 12.0 * cnt["records"] + 16.0 * cnt["ltLookups"] + 4.0 * cnt["saReads"] + 16.0 * cnt["ceWindows"]
     search_s_per_step = (search_ms + ce_ms) / 1e3 / max(1, a.steps)
     achieved = bytes_step / search_s_per_step / 1e9 if search_s_per_step > 0 else 0.0
     achieved_strict = bytes_strict / search_s_per_step / 1e9 if search_s_per_step > 0 else 0.0
@@ -962,15 +1104,25 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
         traffic = None
     n_launch = max(1, launches // max(1, a.steps))
     peak = HBM_PEAK_GBS
-    roof = {"bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak, "traffic": traffic,
+    traffic_commit = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic_commit = json.load(f).get("commit")
+    except (OSError, ValueError):
+        pass
+    roof = {"bound": "hbm", "achieved": achieved_strict, "peak": peak, "unit": "GB/s", "frac": achieved_strict / peak, "traffic": traffic,
+            "achieved_is": "SURVEY.md 8d, nothing added: (32 B x rank queries of the reference algorithm on this input + packed reads + 12 B x reported occurrences) per step "
+                           "/ time inside the search kernels per step",
             "peak_is": "HBM3E peak of the MI355X (MI355X_MICROARCH.md); peak_measured: the best device-to-device copy on this GPU at the start of the run "
                        "(own 16-byte copy kernel and torch copy, read + write bytes)",
-            "peak_measured": peaks["copy_GBps"], "frac_of_measured": achieved / peaks["copy_GBps"],
-            "peak_spec": HBM_PEAK_GBS, "frac_of_spec": achieved / HBM_PEAK_GBS,
-            "achieved_strict": achieved_strict, "frac_strict": achieved_strict / peak,
-            "strict_is": "SURVEY.md 8d unextended: 32 B x rank queries + packed reads + 12 B x records",
-            "traffic_unit": "bytes per launch pair (FETCH_SIZE of both kernels, profiles/pmc_traffic.json)",
-            "algorithmic_bytes_per_launch": bytes_step / n_launch,
+            "peak_measured": peaks["copy_GBps"], "frac_of_measured": achieved_strict / peaks["copy_GBps"],
+            "peak_spec": HBM_PEAK_GBS, "frac_of_spec": achieved_strict / HBM_PEAK_GBS,
+            "achieved_extended": achieved, "frac_extended": achieved / peak,
+            "extended_is": "secondary: 12 B per internal record instead of per reported occurrence, + 16 B per lookup-table entry + 4 B per suffix-array entry + 16 B per 32-character compare window",
+            "traffic_unit": "bytes per launch pair (FETCH_SIZE of the search kernels from a separate rocprofv3 --pmc pass, profiles/pmc_traffic.json: a committed measurement of this workload, "
+                            "not taken by this run)",
+            "traffic_measured_at_commit": traffic_commit if traffic else None,
+            "algorithmic_bytes_per_launch": bytes_strict / n_launch, "algorithmic_bytes_per_launch_extended": bytes_step / n_launch,
             "kernel": "s3::firstKernel + s3::unitKernel + s3::ceKernel (the stepping kernels and the check-and-extend kernel: the halves of one search pass)", "launches_per_step": n_launch,
             "kernel_ms_per_step": (search_ms + ce_ms) / max(1, a.steps),
             "stepping_kernel_ms_per_step": search_ms / max(1, a.steps),
@@ -997,20 +1149,18 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     if streamed:
         out["streamed"] = streamed
     if cpu:
+        if a.cpu_reference:
+            t0 = time.perf_counter()
+            cpu["reference"] = cpu_reference_leg(a.cpu_reference)
+            log("[%s] reference CPU path timed beside the port in %.1f s: %r" % (label, time.perf_counter() - t0,
+                                                                                 {k: v for k, v in (cpu["reference"] or {}).items() if k in ("value", "port_over_reference", "error")}))
         out["cpu_baseline"] = cpu
     if rank == 0:
         out["truth_check"] = truth_check(phase, offs, pos, strand, mis, tpos, tstrand, tsub, a.max_out)
         if a.check > 0:
-            import s3o
-            oix = s3o.Index(host_index=hi)
-            m = min(a.check, a.reads) // 32 * 32
-            oph, owe, ooff, opos, ostr, omis, _ = oix.align_single_allbest(q, lens, wpq, a.mismatch, a.max_out, first=0, count=m)
-            ok = (phase[:m] == oph).all() and (werr[:m] == owe).all() and (offs[:m + 1] == ooff).all() and \
-                (pos[:int(ooff[-1])] == opos).all() and (strand[:int(ooff[-1])] == ostr).all() and (mis[:int(ooff[-1])] == omis).all()
-            out["oracle_check"] = {"reads": m, "bit_exact": bool(ok)}
-            oix.close()
-            if not ok:
-                raise SystemExit("bench.py: HIP result differs from the CPU oracle (%s)" % label)
+            out["oracle_check"] = stratified_oracle_check(hi, q, lens, wpq, a.mismatch, a.max_out, phase, werr, offs, pos, strand, mis, min(a.check, a.reads), a.check_budget)
+            if not out["oracle_check"]["bit_exact"]:
+                raise SystemExit("bench.py: HIP result differs from the CPU oracle (%s): reads %r" % (label, out["oracle_check"]["differing_reads"]))
         if not out["truth_check"]["ok"]:
             raise SystemExit("bench.py: truth check failed (%s): %r" % (label, out["truth_check"]))
     if not a.streaming:
@@ -1099,13 +1249,17 @@ def main():
     ap.add_argument("--stream-batch", type=int, default=1 << 22, help="reads per streamed batch (the reference reads 1 Mi at a time, SOAP3-DP.cu:394; a launch here lasts as long as its longest unit, so larger batches pay)")
     ap.add_argument("--stream-depth", type=int, default=3, help="batches in flight in the streamed form")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
-    ap.add_argument("--check", type=int, default=2048, help="reads verified against the oracle after the run")
+    ap.add_argument("--cpu-reference", type=int, default=200_000, help="reads of the leg that times the reference's own CPU path (oracle/_ref/ref_harness) beside the port (0: skip)")
+    ap.add_argument("--check", type=int, default=4096, help="reads verified against the oracle after the run (a quarter each: cut at MaxOutputPerRead, hundreds of occurrences, a few, the first reads)")
+    ap.add_argument("--check-budget", type=float, default=20.0, help="seconds the oracle check may take (it stops taking new blocks of 32 reads after that)")
     ap.add_argument("--index-dir", default=None, help="keep / reuse the index files of the benchmark genome in this directory")
     ap.add_argument("--build-only", type=int, default=0, help="stop after the index files are written (with --index-dir)")
     ap.add_argument("--c3-pairs", type=int, default=10_000_000, help="extras: BASELINE.json configs[2] -- 2 x 150 bp pairs through the command line with the DP stages on (0: skip)")
     ap.add_argument("--c5-pairs", type=int, default=2_000_000, help="extras: configs[4]'s mixture (5 %% of the pairs damaged in both mates: deep DP) through the command line (0: skip)")
     ap.add_argument("--se150-reads", type=int, default=2_000_000, help="extras: 150 bp single-end reads, kernel-only rate (0: skip)")
     ap.add_argument("--exact-rank", type=int, default=1, help="count the reference algorithm's rank queries on this input with one walk-mode device pass")
+    ap.add_argument("--robustness", default="young", help="extras: comma-separated repeat models (young, old, satellite-heavy) run at --robustness-reads reads each ('' = none)")
+    ap.add_argument("--robustness-reads", type=int, default=2_000_000)
     ap.add_argument("--extras", type=int, default=1, help="after the timed region (N = 1): paired-end 2x150 BWT stage and DP kernel throughput")
     ap.add_argument("--launch-selftest", type=int, default=0, help="N > 1 plumbing only, no GPU: the ranks shard a count, reduce it over gloo and print the line "
                                                                     "(tests/test_bench_launcher_cpu.py)")
@@ -1190,6 +1344,26 @@ def main():
             out.setdefault("extras", {})["uniform_genome"] = ures
         except Exception as e:
             out.setdefault("extras", {})["uniform_genome"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and a.repeat_frac > 0 and a.robustness:
+        # robustness of the heavy-read machinery's thresholds: other repeat structures of the same size at a reduced read count (own genome, own index each)
+        out.setdefault("extras", {})["repeat_models"] = {}
+        for model in [m for m in a.robustness.split(",") if m and m != a.repeat_model]:
+            try:
+                a3 = argparse.Namespace(**vars(a))
+                a3.repeat_model, a3.reads, a3.streaming, a3.exact_rank, a3.check = model, min(a.reads, a.robustness_reads), 0, 0, min(a.check, 2048)
+                a3.steps, a3.warmup, a3.check_budget = min(a.steps, 3), 1, min(a.check_budget, 10.0)
+                mres, mkeep = run_workload(a3, s3dp, builder, dev, local, rank, world, dist, peaks, a.repeat_frac, "repeat-rich", want_cpu=False)
+                mkeep["ix"].close()
+                mkeep.clear()
+                out["extras"]["repeat_models"][model] = {"M_reads_per_s": mres["value"], "ms_per_step": mres["ms_per_step"], "reads": a3.reads,
+                                                         "truth_check": mres.get("truth_check"), "oracle_check": mres.get("oracle_check"),
+                                                         "rank_queries_per_read": mres["rank_queries_per_read"], "occurrences": mres["occurrences"],
+                                                         "kernel_ms_per_step": mres["roofline"]["kernel_ms_per_step"], "frac": mres["roofline"]["frac"],
+                                                         "repeat_families": mres["config"]["repeat_families"]}
+            except Exception as e:
+                out["extras"]["repeat_models"][model] = {"error": repr(e)}
+            gc.collect()
+            torch.cuda.empty_cache()
     if rank == 0:
         out["wall_s_total"] = time.perf_counter() - t_all
         print(json.dumps(out), flush=True)

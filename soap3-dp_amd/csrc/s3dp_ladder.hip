@@ -456,7 +456,7 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
         sw.readLengths = b->dLens; sw.insertLow = insertLow; sw.insertHigh = insertHigh; sw.peMaxOutputPerPair = peMaxOutputPerPair; sw.mm = mm;
         sw.terminal = terminal; sw.pairs = b->dPairs; sw.bestIdx = b->dBestIdx; sw.xaCount = b->dXaCount; sw.xaStart = b->dXaStart; sw.xaCountOut = b->dXaCountOut;
         // pairs with more than S3DP_PAIR_HEAVY entries on both ends together: one wave per pair (s3dp_pair.hip); 0xFFFFFFFF = every pair by its own lane
-        static const uint32_t heavyMin = (uint32_t)envSize("S3DP_PAIR_HEAVY", 48);
+        const uint32_t heavyMin = (uint32_t)envSize("S3DP_PAIR_HEAVY", 48);      // (read per call: tests/test_gpu_parity.py switches it)
         sw.heavyMin = items ? heavyMin : 0xFFFFFFFFu; sw.regionBase = regionBase; sw.heavyList = b->dPairHeavyList; sw.heavyCount = b->dPairHeavyCount;
         sw.bestRank = b->dBestRank; sw.bestLocal = b->dBestLocal; sw.scratchW = (uint32_t *)b->dSortKeys[0]; sw.scratchR = (uint32_t *)b->dSortKeys[1];
         HIPCHK(hipMemsetAsync(b->dPairHeavyCount, 0, 4, b->stream));

@@ -706,9 +706,13 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     }
     // the DP aligners' traceback tables are a few gigabytes per device (20 ms per GB to allocate): made while the index is read and uploaded
     constexpr int kDpWorkers = 2;                                             // at most: DP stage threads per device (each with its own aligners and seed batch)
-    // one by default: on the boxes that grant sixteen CPUs a second one only takes CPU time from the formatter and the loader (10 M pairs: 1.45-1.51 s
-    // with two against 1.38-1.43 s with one); S3DP_DP_THREADS=2 for hosts with cores to spare
-    const int nDpWorkers = getenv("S3DP_DP_THREADS") && atoi(getenv("S3DP_DP_THREADS")) >= 2 ? 2 : 1;
+    // two by default (S3DP_DP_THREADS=1 for one).  A stage thread's work is a chain of small launches and fetches, each of which waits behind the search
+    // kernels of the chunk loop -- persistent waves that hold the device for tens of milliseconds at a time: one thread needed 5.1 s for the stages of 10 M
+    // pairs while the chunk loop needed 3.5 s; two threads on alternate chunks hide each other's waits (10 M pairs: 5.1 -> 4.1 s).  Round 3 found no gain in
+    // a second thread because the stages were host work then (routing of the hit lists: on the device since round 4) and the box grants sixteen CPUs.
+    // With two threads the records of different chunks reach .dpout / .unpair in the order the threads finish (the reference's own output threads write
+    // in no fixed order either, SOAP3-DP.cu:251-258): the SET of records is the result; S3DP_DP_THREADS=1 gives a reproducible file order.
+    const int nDpWorkers = getenv("S3DP_DP_THREADS") && atoi(getenv("S3DP_DP_THREADS")) == 1 ? 1 : 2;
     struct PreDp { s3_dp *dp[kDpWorkers] = {nullptr, nullptr}, *dpHalf[kDpWorkers] = {nullptr, nullptr}; std::string err; };
     const std::vector<int> &dpDevices = shared.loaded ? shared.devices : devices;
     std::vector<PreDp> preDp(dpDevices.size());

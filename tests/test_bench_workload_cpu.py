@@ -32,6 +32,21 @@ def test_truth_check_on_a_repeat_rich_genome():
     bad[: len(bad) // 2] += 1
     t2 = bench.truth_check(ph, off, bad, st, mis, tpos.numpy(), tstrand.numpy(), tsub.numpy().astype(np.int64), 1000)
     assert not t2["ok"] and t2["true_place_missing"] > 0
+    # the stratified oracle check (bench.py's oracle_check): with MaxOutputPerRead 5 this genome has reads in every stratum; the oracle's own lists pass,
+    # a changed occurrence of a read whose list was cut is found
+    oix = s3o.Index(host_index=hi)
+    ph, we, off, pos, st, mis, _ = oix.align_single_allbest(q, lens, wpq, 4, 5, first=0, count=n)
+    oix.close()
+    c = bench.stratified_oracle_check(hi, q, lens, wpq, 4, 5, ph, we, off, pos, st, mis, 512, 60.0)
+    assert c["bit_exact"] and c["reads"] >= 128, c
+    assert c["strata"]["cut_at_max_output"]["checked"] >= 32 and c["strata"]["first_reads"]["checked"] >= 32, c
+    counts = np.diff(off.astype(np.int64))
+    cut = np.nonzero(counts >= 5)[0]
+    bad = pos.copy()
+    for r in cut:
+        bad[int(off[r]) + 3] ^= 1
+    c2 = bench.stratified_oracle_check(hi, q, lens, wpq, 4, 5, ph, we, off, bad, st, mis, 512, 60.0)
+    assert not c2["bit_exact"] and set(c2["differing_reads"]) <= set(int(x) for x in cut)
 
 
 def test_cpu_baseline_leg_runs_with_and_without_a_cpu_quota(monkeypatch):

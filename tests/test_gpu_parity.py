@@ -314,6 +314,86 @@ def test_pair_small_caps():
     b.close()
 
 
+def test_pairs_inside_repeat_families_long_lists():
+    """Pairs whose ends lie in a dispersed repeat family (600 near-identical copies) or in a tandem array: hundreds to thousands of hits per end, thousands
+    of valid pairings.  Such pairs are taken by one wave each (pairStatsHeavyKernel / pairEmitHeavyKernel, s3dp_pair.hip) instead of one lane's serial
+    sweep: the optimal pair, its index, the statistics, the "suboptimal" sum and the XA list in pairing order must equal the oracle's sweep
+    (PEMappingCore / PEStatsPEPairList, PEAlgnmt.cpp:201-291,777-832) -- with every pair on the wave path (S3DP_PAIR_HEAVY=0), with none (4294967295)
+    and with the default threshold."""
+    rng = np.random.default_rng(77)
+    n, L = 400_000, 100
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    unit = rng.integers(0, 4, size=700, dtype=np.uint8)
+    for c in range(600):                                      # dispersed family: copies 0.3 % from the consensus
+        at = 1000 + c * 500 + int(rng.integers(0, 40))
+        cp = unit.copy()
+        flip = rng.random(700) < 0.003
+        cp[flip] = (cp[flip] + rng.integers(1, 4, size=int(flip.sum()))) % 4
+        codes[at:at + 450] = cp[:450] if c % 3 else cp[250:700]
+    sat = rng.integers(0, 4, size=171, dtype=np.uint8)
+    for c in range(400):                                      # tandem array, 1 % divergence
+        cp = sat.copy()
+        flip = rng.random(171) < 0.01
+        cp[flip] = (cp[flip] + rng.integers(1, 4, size=int(flip.sum()))) % 4
+        codes[320_000 + c * 171:320_000 + (c + 1) * 171] = cp
+    hi = builder.build_host_index(codes, device="cpu")
+    ix = s3dp.Index(hi)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+    reads = []
+    for k in range(256):
+        where = k % 4
+        if where == 0:
+            start = 1000 + int(rng.integers(0, 600)) * 500 + int(rng.integers(0, 60))
+        elif where == 1:
+            start = 320_000 + int(rng.integers(0, 171 * 396))
+        elif where == 2:
+            start = int(rng.integers(0, n - 600))
+        else:
+            start = 1000 + int(rng.integers(0, 590)) * 500 + 200
+        ins = int(rng.integers(210, 420))
+        a = codes[start:start + L].copy()
+        bb = comp[codes[start + ins - L:start + ins][::-1]]
+        for rd in (a, bb):
+            for _ in range(int(rng.integers(0, 3))):
+                j = int(rng.integers(0, L))
+                rd[j] = (rd[j] + 1 + int(rng.integers(0, 3))) % 4
+        pair = [bytes(b"ACGT"[c] for c in a), bytes(b"ACGT"[c] for c in bb)]
+        if k % 5 == 0:
+            pair.reverse()
+        reads += pair
+    q, lens, wpq = s3dp.pack_reads(reads, L)
+    oix = s3o.Index(host_index=hi)
+    b = s3dp.Batch(ix, len(reads), wpq)
+    b.upload(q, lens)
+    keep = os.environ.get("S3DP_PAIR_HEAVY")
+    try:
+        for report_type, mm, pe_max in ((2, 2, 1000), (1, 2, 7), (4, 1, 1000)):
+            want = oix.align_pair(q, lens, wpq, mm, 8000, report_type, 150, 500, pe_max)
+            assert (want[0]["numPairs"] > 200).sum() > 10, "the workload should hold pairs with hundreds of pairings"
+            for heavy in ("0", "4294967295", None):
+                if heavy is None:
+                    os.environ.pop("S3DP_PAIR_HEAVY", None)
+                else:
+                    os.environ["S3DP_PAIR_HEAVY"] = heavy
+                b.align_pair(mm, 8000, report_type, 150, 500, pe_max)
+                got = b.fetch_pairs()
+                for f in got[0].dtype.names:
+                    if f == "pad":
+                        continue
+                    bad = np.nonzero(got[0][f] != want[0][f])[0]
+                    assert len(bad) == 0, "S3DP_PAIR_HEAVY=%s -h %d: pair field %s differs at pair %d: %s vs %s" % (heavy, report_type, f, bad[0], got[0][bad[0]], want[0][bad[0]])
+                for k in range(1, 7):
+                    assert len(got[k]) == len(want[k]) and (got[k] == want[k]).all(), "S3DP_PAIR_HEAVY=%s -h %d: output array %d differs" % (heavy, report_type, k)
+    finally:
+        if keep is None:
+            os.environ.pop("S3DP_PAIR_HEAVY", None)
+        else:
+            os.environ["S3DP_PAIR_HEAVY"] = keep
+    oix.close()
+    b.close()
+    ix.close()
+
+
 @pytest.mark.parametrize("seed", [3, 4])
 def test_text_ends_and_padded_lookup_keys_stress(seed):
     """A tiny genome searched with reads that hug or overhang its ends with runs of A -- the 13-mers the lookup tables count for the last / first text
