@@ -618,6 +618,9 @@ static bool dpPairable(const DpArgs &a)
     if (a.match < 0 || a.match > 250 || a.mismatch > 0 || a.mismatch < -250 || a.gapOpen > 0 || a.gapOpen < -250 || a.gapExtend > 0 || a.gapExtend < -250) return false;
     if ((long long)a.maxReadLength * a.match > 30000) return false;
     if (-2 * a.gapOpen - a.gapExtend - a.mismatch > 700) return false;
+    // (the window bound also bounds the 16-bit counters of the maximum tracking: a lane's tie count of one chunk grows by at most one per step, at most
+    //  window + 63 steps, and the step number itself sits in a 16-bit half; the rows' counts are added up in 32 bits (bestMerge), so W x (clipRt + 1) ties --
+    //  a homopolymer window -- pass 65,535 without harm: tests/test_gpu_dp.py::test_tie_counts_beyond_16_bits_in_the_paired_kernel)
     if (a.maxDNALength > 12000u || (size_t)a.ldsPerWavePair > 160u * 1024u) return false;
     return true;
 }

@@ -73,3 +73,38 @@ def test_two_problems_per_wavefront_equal_one(monkeypatch, scores, what, n):
         for t in np.nonzero(sc >= P["cutoffs"])[0]:
             a, b = bytes(pat[t]), bytes(orc[3][t])
             assert a[:a.index(0) + 1] == b[:b.index(0) + 1], (mode, t)
+
+
+def test_tie_counts_beyond_16_bits_in_the_paired_kernel(monkeypatch):
+    """The paired fill kernel keeps a row's tie count in a 16-bit half (one increment per step at most: at most window + 63 per lane and chunk, which is why
+    dpPairable refuses windows above 12,000 columns) and adds the rows' counts up in 32 bits.  Forced here: match score 0 on homopolymer windows of 3,000
+    columns with right clips up to the whole read -- every cell of every row that may end the alignment ties at the maximum, W x (clipRt + 1) = hundreds of
+    thousands of ties, far beyond 65,535 -- and the count must equal the one-problem kernel's and the CPU restatement's."""
+    max_read, max_dna, n = 200, 3000, 6
+    scores = (0, -2, -3, -1)
+    rng = np.random.default_rng(5)
+    dna, reads, clip_rt = [], [], []
+    for t in range(n):
+        L = (100, 150, 64, 190, 129, 65)[t]
+        base = t % 4
+        win = np.full(max_dna - 7 * t, base, dtype=np.uint8)
+        rd = np.full(L, base, dtype=np.uint8)
+        if t == 4:
+            win[1500] = (base + 1) % 4                     # one foreign character: the ties split around it
+        dna.append(win); reads.append(rd); clip_rt.append(L - 1 if t != 2 else 40)
+    P = dict(dna=s3dp.pack_dp_sequences(dna, max_dna), dna_len=np.array([len(x) for x in dna], dtype=np.uint32),
+             reads=s3dp.pack_dp_sequences(reads, max_read), read_len=np.array([len(x) for x in reads], dtype=np.uint32),
+             clip_lt=np.zeros(n, dtype=np.uint32), clip_rt=np.array(clip_rt, dtype=np.uint32), cutoffs=np.full(n, -5, dtype=np.int32))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("S3DP_DP_PAIRED", mode)
+        monkeypatch.setenv("S3DP_DP_FUSED", "0")
+        al = s3dp.DpAligner(n, max_read, max_dna, scheme=1, scores=scores)
+        out[mode] = al.align(P["dna"], P["dna_len"], P["reads"], P["read_len"], P["cutoffs"], clip_lt=P["clip_lt"], clip_rt=P["clip_rt"])
+        al.close()
+    orc = s3o.dp_align(P["dna"], P["dna_len"], max_dna, max_dna, P["reads"], P["read_len"], max_read, P["cutoffs"], scheme=1, scores=scores,
+                       clip_lt=P["clip_lt"], clip_rt=P["clip_rt"])
+    assert (orc[2] > 65535).sum() >= 4, orc[2]
+    for mode in ("1", "0"):
+        sc, hit, cnt, pat, crt = out[mode]
+        assert (sc == orc[0]).all() and (hit == orc[1]).all() and (cnt == orc[2]).all() and (crt == orc[4]).all(), ("S3DP_DP_PAIRED=" + mode, cnt, orc[2])
