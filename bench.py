@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "soap3-dp_amd", "py"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+COLL_DEV = []               # [None] when the ranks share ONE GPU over gloo (S3DP_BENCH_SHARE_GPU=1, a test of the N > 1 path on a one-GPU box): collectives on CPU tensors
 
 
 def log(*a):
@@ -1030,10 +1031,10 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
         launches += k
     barrier()
     dt = time.perf_counter() - t0
-    dt = sd.max_over_ranks(dt, device=dev)
+    dt = sd.max_over_ranks(dt, device=COLL_DEV[0] if COLL_DEV else dev)
     # the only collective of the path: the final reduce of the counters (RCCL all-reduce)
     tot = sd.reduce_counters({"reads": a.reads, "readsAligned": aligned, "alignments": n_occ, "rankQueries": cnt["rankQueries"],
-                              "records": cnt["records"]}, device=dev)
+                              "records": cnt["records"]}, device=COLL_DEV[0] if COLL_DEV else dev)
     value = tot["reads"] * a.steps / dt / 1e6
     log("[%s] resident: %.2f M reads/s, %.1f ms per step (stepping %.1f ms, check-and-extend %.1f ms, device %.1f ms); %.0f rank queries per read" %
         (label, value, dt / a.steps * 1e3, search_ms / a.steps, ce_ms / a.steps, dev_ms / a.steps, cnt["rankQueries"] / a.reads))
@@ -1055,7 +1056,7 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
             if mism:
                 raise SystemExit("bench.py: streamed results differ from the resident batch's (batches at reads %r)" % mism[:5])
             st["same_results_as_resident"] = True
-            st["M_reads_per_s"] = sd.reduce_counters({"reads": int(st["reads"])}, device=dev)["reads"] / sd.max_over_ranks(st["seconds"], device=dev) / 1e6
+            st["M_reads_per_s"] = sd.reduce_counters({"reads": int(st["reads"])}, device=COLL_DEV[0] if COLL_DEV else dev)["reads"] / sd.max_over_ranks(st["seconds"], device=COLL_DEV[0] if COLL_DEV else dev) / 1e6
             st["vs_resident"] = st["M_reads_per_s"] / value
             log("[%s] streamed, %d reads per batch, %d in flight: %.2f M reads/s (%.2f of resident)" % (label, batch_reads, depth, st["M_reads_per_s"], st["vs_resident"]))
             return st
@@ -1175,7 +1176,7 @@ def launch_ranks(a):
     on this image) and waits: a process that has touched a GPU is never replaced by another program."""
     import socket
     import subprocess
-    if not a.launch_selftest:
+    if not a.launch_selftest and os.environ.get("S3DP_BENCH_SHARE_GPU") != "1":
         import torch
         have = torch.cuda.device_count()
         if have < a.gpus:
@@ -1281,6 +1282,13 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (bench.py --gpus N starts its own ranks when no launcher has set WORLD_SIZE)" % (a.gpus, world))
     if not torch.cuda.is_available() or s3dp.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    # S3DP_BENCH_SHARE_GPU=1 (test aid, tests/test_gpu_group.py): every rank on device 0, gloo instead of RCCL (RCCL wants one device per rank) -- the
+    # whole N > 1 path of this file (index built once per node and mapped by the other ranks, barriers, max-over-ranks timing, the counters' reduce) on a
+    # box with ONE GPU; the figures of such a run mean nothing
+    share = os.environ.get("S3DP_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
+        COLL_DEV.append(None)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -1289,7 +1297,10 @@ def main():
         import tempfile
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
         box = [tempfile.mkdtemp(prefix="s3dp_bench_") if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         index_dir = box[0]

@@ -1017,6 +1017,54 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             }
         });
     }
+    // ---- pairs with the DP stages on: a third stage between the search and the DP stages.  The chunk loop uploads, searches and routes; the POST thread
+    // fetches the chunk's pairings, formats and writes the properly paired records and hands the chunk to the DP stage threads -- a quarter second of host
+    // work per ten million pairs during which the device used to wait for the next chunk's search (round 4) ------------------------------------------------
+    struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<PairJob>> q; bool stop = false; } postq;
+    std::thread postThread;
+    uint64_t postAligned = 0;
+    const bool postOn = pipelinedDp && paired && !skipSoap3 && !(getenv("S3DP_POST_THREAD") && atoi(getenv("S3DP_POST_THREAD")) == 0);
+    if (postOn) {
+        s3_batch *nb = nullptr;                                                   // (one more batch takes turns: the one the post thread holds)
+        if (s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : chunk->n, chunk->wpq, &nb) != S3_OK) return dieJoin(s3_last_error());
+        stageBatches.push_back(nb);
+        { std::lock_guard<std::mutex> g(dpq.mu); dpq.freeBatches.push_back(nb); }
+        postThread = std::thread([&] {
+            auto fatal = [&](const std::string &m) { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); };
+            for (;;) {
+                std::unique_ptr<PairJob> j;
+                {
+                    std::unique_lock<std::mutex> lk(postq.mu);
+                    postq.cv.wait(lk, [&] { return !postq.q.empty() || postq.stop; });
+                    if (postq.q.empty()) return;
+                    j = std::move(postq.q.front());
+                    postq.q.pop_front();
+                }
+                const ReadSet &rs = *j->rs;
+                const uint32_t np = j->cnt / 2;
+                std::vector<s3_pair_result> &pr = j->pr;
+                pr.resize(np ? np : 1);
+                std::vector<uint64_t> xoff((size_t)np + 1, 0);
+                std::vector<s3_pair_xa> xa(1);
+                uint64_t nXa = 0;
+                const auto tF = std::chrono::steady_clock::now();
+                if (s3_batch_fetch_pairs(j->b, pr.data(), xoff.data(), nullptr, 0, &nXa, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != S3_OK) fatal(s3_last_error());
+                addBatchTiming(j->b);
+                xa.resize(nXa ? nXa : 1);
+                if (nXa && s3_batch_fetch_pairs(j->b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != S3_OK) fatal(s3_last_error());
+                addChunkSeconds(1, since(tF));
+                const auto tW = std::chrono::steady_clock::now();
+                parallelFormat(hix, so, out, np, [&](SamWriter &w, uint32_t p, uint64_t &al) {
+                    if (!pr[p].phase) return;                                      // goes to the DP stages
+                    if (!(alignmentType == 3 && pr[p].numMin != 1)) al += 2;
+                    w.properPair(rs, 2 * p, 2 * p + 1, pr[p], xa.data() + xoff[p], (size_t)(xoff[p + 1] - xoff[p]));
+                }, postAligned);
+                addChunkSeconds(2, since(tW));
+                { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); }
+                dpq.cv.notify_all();
+            }
+        });
+    }
     uint64_t chunkNo = 0;
     for (; chunk && chunk->n; recycle(std::move(chunk)), chunk = nextChunk(), chunkNo++) {
         ReadSet &rs = *chunk;
@@ -1059,6 +1107,14 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                                         ini.peMaxOutputPerPair) != S3_OK) return dieJoin(s3_last_error());
                 if (s3_batch_route_pairs(b, routeMaxHit, mapqMode, &routing) != S3_OK) return dieJoin(s3_last_error());
                 addChunkSeconds(0, since(tA));
+                if (postOn) {
+                    std::unique_ptr<PairJob> j(new PairJob());
+                    j->b = b; j->cnt = cnt; j->routing = routing; j->chunkNo = chunkNo; j->readBase = totalReads - cnt;
+                    j->rs = std::move(chunk);                                      // (the loop's recycle() gets nothing: the DP stage thread gives the set back)
+                    { std::lock_guard<std::mutex> g(postq.mu); postq.q.push_back(std::move(j)); }
+                    postq.cv.notify_all();
+                    continue;
+                }
                 const auto tF = std::chrono::steady_clock::now();
                 if (s3_batch_fetch_pairs(b, pr.data(), xoff.data(), nullptr, 0, &nXa, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != S3_OK) return dieJoin(s3_last_error());
                 addBatchTiming(b);
@@ -1140,6 +1196,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); }
             dpq.cv.notify_all();
         }
+    }
+    if (postThread.joinable()) {
+        { std::lock_guard<std::mutex> g(postq.mu); postq.stop = true; }
+        postq.cv.notify_all();
+        postThread.join();
+        aligned += postAligned;
     }
     if (pipelinedDp) {
         { std::lock_guard<std::mutex> g(dpq.mu); dpq.stop = true; }

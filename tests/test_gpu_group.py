@@ -133,6 +133,27 @@ def test_distributed_path_with_world_size_one(tmp_path):
 
 
 
+def test_bench_py_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it: the script spawns its ranks, rank 0 builds the index once and writes the files,
+    rank 1 maps them (HostIndex.from_files(shared=True)), both align their own shard, the counters are reduced, ONE line comes back.  On a one-GPU box the
+    two ranks share device 0 over gloo (S3DP_BENCH_SHARE_GPU=1; RCCL wants a device per rank): everything of the N > 1 path but the RCCL transport."""
+    import json
+    env = dict(os.environ, S3DP_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genome-bp", "60000000", "--reads", "200000", "--steps", "2", "--warmup", "1",
+                          "--cpu-budget", "0", "--check", "256", "--exact-rank", "0", "--stream-batch", "65536", "--extras", "0", "--uniform", "0", "--robustness", ""],
+                         capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    assert res["aligned_reads"] == 400000                              # both shards, summed by the all-reduce
+    assert res["truth_check"]["ok"] and res["oracle_check"]["bit_exact"]
+    assert res["streamed"]["same_results_as_resident"]
+
+
 def test_group_on_two_devices_runs_the_rccl_allreduce():
     """With two or more devices visible: s3_group_create on devices [0, 1] and the real ncclAllReduce between them (one-GPU boxes skip this; the
     two-members-on-one-device tests above cover everything but the collective itself)."""
