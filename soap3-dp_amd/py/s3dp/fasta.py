@@ -8,7 +8,8 @@ Behaviour that decides text positions, and so every SAM coordinate (kept exactly
     byte is a character: A C G T in either case are kept, anything else (N, IUPAC codes, '\\r', blanks ...) is ambiguous (HSP.c:855-895);
   * a run of fewer than 10 ambiguous characters becomes that many 'G'; a run of 10 or more is REMOVED from the text and recorded; a run ends at an
     unambiguous character, at '>' or at the end of the file (line breaks inside a run do not end it);
-  * `-U` (MaskLowerCase) turns lower-case letters into 'N' first.
+  * `-U` (MaskLowerCase): a lower-case letter OPENS a run of ambiguous characters; only real ambiguity codes extend one (HSP.c:849-870), so a
+    soft-masked stretch becomes 'G's, base by base, and is not removed.
 The removed runs and the sequence boundaries go into the translate table (.tra) that turns text positions back into (sequence, offset): entries
 sorted by start, a 2^18-sampled grid of how many entries start before each grid cell, and the sequences' real offsets -- including the reference's
 way of computing a run's length from the CUMULATIVE count of discarded characters (HSP.c:886-887, :959): file formats are what other tools read.
@@ -84,8 +85,20 @@ def parse_fasta(src, seed=0, mask_lower_case=False):
         ambiguous = code == 255
         seq_start, actual_start = total, total + discarded
         if ambiguous.any():
-            d = np.diff(np.concatenate(([0], ambiguous.view(np.int8), [0])))
-            rs, re_ = np.flatnonzero(d == 1), np.flatnonzero(d == -1)          # runs [rs, re_)
+            if mask_lower_case:
+                # -U as the reference applies it (HSP.c:849-870): the mask turns a lower-case letter into an ambiguous character where a run may START
+                # (the outer loop); the loop that counts the run tests the UNMASKED map, where a / c / g / t are ordinary bases and end it.  So a masked
+                # base opens a run of its own -- one 'G' unless real ambiguity codes follow it -- and only N / IUPAC characters (either case) extend a run.
+                extends = _CODE[chunk] == 255
+                prev = np.concatenate(([False], ambiguous[:-1]))
+                start = ambiguous & (~extends | ~prev)
+                rs = np.flatnonzero(start)
+                brk = np.flatnonzero(start | ~ambiguous)                        # where a run cannot continue into
+                nxt_brk = np.searchsorted(brk, rs, side="right")
+                re_ = np.where(nxt_brk < brk.size, brk[np.minimum(nxt_brk, brk.size - 1)], chunk.size)
+            else:
+                d = np.diff(np.concatenate(([0], ambiguous.view(np.int8), [0])))
+                rs, re_ = np.flatnonzero(d == 1), np.flatnonzero(d == -1)      # runs [rs, re_)
             rlen = re_ - rs
             remove = rlen >= 10
             keep = np.ones(chunk.size, dtype=bool)

@@ -53,18 +53,32 @@ def cases():
     body = "".join(parts) + rnd(rng, 300)
     pad = (-sum(1 for c in body if c in "ACGT")) % 4
     out["f4"] = ">only\n" + wrap(body + rnd(rng, pad), 73)
+    # f5 (built with -U, MaskLowerCase): soft-masked stretches, a masked base in front of a long run of N (the run swallows it), masked bases in front of nine
+    # N and behind them, lower-case n runs, mixed-case stretches, IUPAC codes -- a masked letter opens a run, only real ambiguity codes extend one (HSP.c:849-870)
+    def low(n):
+        return rnd(rng, n).lower()
+    v1 = (rnd(rng, 300) + low(25) + rnd(rng, 200) + "N" * 15 + rnd(rng, 100) + "a" + "N" * 12 + rnd(rng, 50) + "NNNN" + rnd(rng, 40) + low(3) + "N" * 9 + "g" +
+          rnd(rng, 60))
+    v2 = rnd(rng, 120) + "n" * 11 + rnd(rng, 80) + "".join("acgtn"[c] for c in rng.integers(0, 5, size=40)) + rnd(rng, 100) + "RYK" + rnd(rng, 30) + "t" + "n" * 9 + rnd(rng, 21)
+    out["f5"] = ">m1 soft-masked\n" + wrap(v1) + ">m2\n" + wrap(v2, 47)
     return out
+
+
+MASKED = {"f5"}                                   # built with the reference builder's -U
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
     for name, text in cases().items():
+        if only and name not in only:
+            continue
         with tempfile.TemporaryDirectory() as td:
             fa = os.path.join(td, name + ".fa")
             with open(fa, "w", newline="") as f:
                 f.write(text)
             shutil.copy(os.path.join(REF, "soap3-dp-builder.ini"), td)
-            subprocess.check_call([os.path.join(REF, "soap3-dp-builder"), name + ".fa"], cwd=td, stdout=subprocess.DEVNULL)
+            subprocess.check_call([os.path.join(REF, "soap3-dp-builder"), name + ".fa"] + (["-U"] if name in MASKED else []), cwd=td, stdout=subprocess.DEVNULL)
             keep = [".ann", ".amb", ".tra", ".pac"]
             if name == "f1":
                 subprocess.check_call([os.path.join(REF, "BGS-Build"), name + ".fa.index"], cwd=td, stdout=subprocess.DEVNULL)

@@ -12,7 +12,8 @@ from s3dp import fasta
 from conftest import GOLDEN
 
 CASES = [("fasta/f1.fa", "fasta/f1.index"), ("fasta/f2.fa", "fasta/f2.index"), ("fasta/f3.fa", "fasta/f3.index"), ("fasta/f4.fa", "fasta/f4.index"),
-         ("g1/genome.fa", "g1/index")]
+         ("g1/genome.fa", "g1/index"), ("fasta/f5.fa", "fasta/f5.index")]
+MASKED = {"fasta/f5.fa"}                          # built by the reference builder with -U (MaskLowerCase)
 
 
 def ref_seed(prefix):
@@ -22,7 +23,7 @@ def ref_seed(prefix):
 @pytest.mark.parametrize("fa,prefix", CASES)
 def test_annotation_translate_and_packed_text_match_the_reference_builder(tmp_path, fa, prefix):
     prefix = os.path.join(GOLDEN, prefix)
-    p = fasta.parse_fasta(os.path.join(GOLDEN, fa), seed=ref_seed(prefix))
+    p = fasta.parse_fasta(os.path.join(GOLDEN, fa), seed=ref_seed(prefix), mask_lower_case=fa in MASKED)
     fasta.write_annotation_files(p, str(tmp_path / "x"))
     for ext in (".ann", ".amb", ".tra"):
         assert open(str(tmp_path / "x") + ext, "rb").read() == open(prefix + ext, "rb").read(), ext
@@ -45,10 +46,17 @@ def test_cases_cover_the_parser_branches():
 
 
 def test_mask_lower_case():
+    """-U as the reference builder applies it (HSP.c:849-870): a masked letter opens a run of ambiguous characters, only real ambiguity codes extend one --
+    a soft-masked stretch becomes 'G' base by base and stays in the text; fixture f5 is the reference builder's own output with -U"""
     p = fasta.parse_fasta(b">x\nACGTacgtacgtacgtACGT\n", mask_lower_case=True)
-    assert p.n == 8 and p.amb == [(4, 15)]
-    q = fasta.parse_fasta(b">x\nACGTacgtACGT\n", mask_lower_case=True)
-    assert q.codes.tolist() == [0, 1, 2, 3, 2, 2, 2, 2, 0, 1, 2, 3]
+    assert p.n == 20 and p.amb == [] and p.codes.tolist() == [0, 1, 2, 3] + [2] * 12 + [0, 1, 2, 3]
+    q = fasta.parse_fasta(b">x\nACGTaNNNNNNNNNNNNACGTcgNNNNNNNNNtACGT\n", mask_lower_case=True)
+    # 'a' + 12 N: one run of 13, removed; 'c': a run of one, G; 'g' + 9 N: a run of ten, removed; 't': a run of one, G
+    assert q.n == 14 and q.amb == [(4, 16), (9, 31)] and q.codes.tolist() == [0, 1, 2, 3, 0, 1, 2, 3, 2, 2, 0, 1, 2, 3]
+    prefix = os.path.join(GOLDEN, "fasta/f5.index")
+    f5 = fasta.parse_fasta(os.path.join(GOLDEN, "fasta/f5.fa"), mask_lower_case=True)
+    assert fasta.pac_bytes(f5.codes) == open(prefix + ".pac", "rb").read()
+    assert len(f5.amb) >= 4
     with pytest.raises(ValueError):
         fasta.parse_fasta(b"ACGT\n")
 

@@ -2,7 +2,7 @@
 # round 4: the default bench line as the driver runs it, with a summary of the new legs (run through gpurun from the repository root)
 O=gpurun_out/${1:-r04e}
 mkdir -p $O
-/usr/bin/time -v python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.log; echo rc=$?
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.log; echo rc=$?
 tail -5 $O/bench.log; grep "^\[bench\]" $O/bench.log | cut -c1-300 | tail -40
 python3 - $O/bench.json <<'PY'
 import json, sys
