@@ -1251,7 +1251,7 @@ def main():
     ap.add_argument("--stream-depth", type=int, default=3, help="batches in flight in the streamed form")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU-baseline work (0 = skip)")
     ap.add_argument("--cpu-reference", type=int, default=200_000, help="reads of the leg that times the reference's own CPU path (oracle/_ref/ref_harness) beside the port (0: skip)")
-    ap.add_argument("--check", type=int, default=4096, help="reads verified against the oracle after the run (a quarter each: cut at MaxOutputPerRead, hundreds of occurrences, a few, the first reads)")
+    ap.add_argument("--check", type=int, default=16384, help="reads verified against the oracle after the run (a quarter each: cut at MaxOutputPerRead, hundreds of occurrences, a few, the first reads)")
     ap.add_argument("--check-budget", type=float, default=20.0, help="seconds the oracle check may take (it stops taking new blocks of 32 reads after that)")
     ap.add_argument("--index-dir", default=None, help="keep / reuse the index files of the benchmark genome in this directory")
     ap.add_argument("--build-only", type=int, default=0, help="stop after the index files are written (with --index-dir)")
@@ -1260,7 +1260,7 @@ def main():
     ap.add_argument("--se150-reads", type=int, default=2_000_000, help="extras: 150 bp single-end reads, kernel-only rate (0: skip)")
     ap.add_argument("--exact-rank", type=int, default=1, help="count the reference algorithm's rank queries on this input with one walk-mode device pass")
     ap.add_argument("--robustness", default="young", help="extras: comma-separated repeat models (young, old, satellite-heavy) run at --robustness-reads reads each ('' = none)")
-    ap.add_argument("--robustness-reads", type=int, default=2_000_000)
+    ap.add_argument("--robustness-reads", type=int, default=10_000_000, help="reads of a robustness leg (the headline's count: a smaller batch pays more for the tails of its launches and would not compare)")
     ap.add_argument("--extras", type=int, default=1, help="after the timed region (N = 1): paired-end 2x150 BWT stage and DP kernel throughput")
     ap.add_argument("--launch-selftest", type=int, default=0, help="N > 1 plumbing only, no GPU: the ranks shard a count, reduce it over gloo and print the line "
                                                                     "(tests/test_bench_launcher_cpu.py)")

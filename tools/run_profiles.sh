@@ -3,12 +3,12 @@
 # are then copied into profiles/).  Every step has its own timeout; the benchmark index is built once and kept as files under /tmp.
 #   tools/run_profiles.sh [bench|stats|pmc|dp|e2e|pairs ...]     (default: all)
 set -u
-OUT=${S3DP_PROFILE_OUT:-gpurun_out/r03}
+OUT=${S3DP_PROFILE_OUT:-gpurun_out/r04}
 IX=/tmp/s3dp_ix
 mkdir -p $OUT $IX
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 STEPS="${*:-bench stats pmc dp e2e pairs}"
-QUICK="--index-dir $IX --uniform 0 --extras 0 --streaming 0 --cpu-budget 0 --check 0 --exact-rank 0 --repeat-frac ${S3DP_PROFILE_REPEAT_FRAC:-0.5}"
+QUICK="--index-dir $IX --uniform 0 --extras 0 --streaming 0 --cpu-budget 0 --check 0 --exact-rank 0 --robustness= --cpu-reference 0 --repeat-frac ${S3DP_PROFILE_REPEAT_FRAC:-0.5}"
 want() { case " $STEPS " in *" $1 "*) return 0;; esac; return 1; }
 
 timeout 900 python3 bench.py --index-dir $IX --repeat-frac ${S3DP_PROFILE_REPEAT_FRAC:-0.5} --build-only 1 > /dev/null 2> $OUT/index_build.log; echo "index build rc=$?"
