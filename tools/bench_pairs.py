@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--index-dir", default=None)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--mismatch", type=int, default=3)
+    ap.add_argument("--counters", type=int, default=1, help="0: no counted pass (profiling runs: the counted pass launches the COUNT instantiations of the kernels)")
     a = ap.parse_args()
     import torch
     import bench
@@ -47,11 +48,13 @@ def main():
     lens = np.full(2 * a.pairs, L, dtype=np.uint32)
     b = s3dp.Batch(ix, 2 * a.pairs, wpq)
     b.upload(q, lens)
-    b.enable_counters(True)
-    b.align_pair(a.mismatch, 8000, 2, 1, 500, 1000)
-    b.sync()
-    cnt = b.counters()
-    b.enable_counters(False)
+    cnt = {}
+    if a.counters:
+        b.enable_counters(True)
+        b.align_pair(a.mismatch, 8000, 2, 1, 500, 1000)
+        b.sync()
+        cnt = b.counters()
+        b.enable_counters(False)
     b.align_pair(a.mismatch, 8000, 2, 1, 500, 1000)
     b.sync()
     t0 = time.perf_counter()
