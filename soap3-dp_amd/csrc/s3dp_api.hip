@@ -409,7 +409,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
-    BA(dRecs, recCap); BA(dOrdered, recCap); b->ordCap = recCap;
+    BA(dRecs, recCap); BA(dOrdered, recCap); BA(dOrdValid, recCap); b->ordCap = recCap;
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, S3_NUM_COUNTERS); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
@@ -811,18 +811,21 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             if (slots > cap) return fail(S3_EOVERFLOW, "ordering buffer overflow at the 32-bit limit");
             int rc = bgrow(b, &b->dOrdered, cap, 0);
             if (rc) return rc;
+            if ((rc = bgrow(b, &b->dOrdValid, cap, 0))) return rc;
             b->ordCap = (uint32_t)cap;
         }
     }
-    launchFillInvalid(b->dOrdered, b->dItemOffsets + nCount, b->ordCap, b->stream);
-    launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->dHeavyFlags, b->dHeavyList, (uint32_t)nCases * 2u, in.unitBase, in.unitsPerItem,
+    // nine in ten sequence numbers belong to rejected check-and-extend candidates: the holes are a zero BYTE each (they used to be 16-byte entries written
+    // by a fill pass and read back by merge and decode: 31 GB per ladder of the benchmark, three times)
+    if (slots) HIPCHK(hipMemsetAsync(b->dOrdValid, 0, slots, b->stream));
+    launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->dOrdValid, b->dHeavyFlags, b->dHeavyList, (uint32_t)nCases * 2u, in.unitBase, in.unitsPerItem,
                   b->scatterDyn, b->stream);
     // what the merge / decode kernels need to find a read's slice of the ordered array (kept for the decode calls that follow this pass)
     b->mergeUnitBase = in.unitBase; b->mergeUnitsPerRead = nHeavy ? (uint32_t)nCases * 2u * in.unitsPerItem : 0u;
     // the long-read list of the merge kernels shares the buffer of the heavy list, which the scatter above still reads: a second list
     
     MergeArgs m{};
-    m.nActive = nActive; m.nCases = (uint32_t)nCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
+    m.nActive = nActive; m.nCases = (uint32_t)nCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered; m.valid = b->dOrdValid;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     m.longList = b->dLongList; m.longCount = b->dLongCount;
     m.heavyFlags = b->mergeUnitsPerRead ? b->dHeavyFlags : nullptr; m.heavyIndex = b->dHeavyIndex; m.unitBase = b->mergeUnitBase; m.unitsPerRead = b->mergeUnitsPerRead;
@@ -863,7 +866,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     size_t tb = b->tempBytes;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dKept, b->dHitOffsets, (int)(b->n + 1), b->stream));
     MergeArgs m{};
-    m.nActive = b->n; m.nCases = b->lastNumCases; m.maxOut = maxOutputPerRead; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered;
+    m.nActive = b->n; m.nCases = b->lastNumCases; m.maxOut = maxOutputPerRead; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered; m.valid = b->dOrdValid;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     m.heavyFlags = b->mergeUnitsPerRead ? b->dHeavyFlags : nullptr; m.heavyIndex = b->dHeavyIndex; m.unitBase = b->mergeUnitBase; m.unitsPerRead = b->mergeUnitsPerRead;
     if (!b->dHits) { int rc2 = balloc(b, &b->dHits, b->recCap); if (rc2) return rc2; }

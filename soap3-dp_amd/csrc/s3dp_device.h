@@ -118,6 +118,7 @@ struct MergeArgs {
     uint32_t        nActive, nCases, maxOut;
     const uint32_t *itemOffsets;
     const uint4    *ordered;
+    const uint8_t  *valid;        // one byte per slot of `ordered`: 1 = a record was scattered there (the rest: sequence numbers of rejected check-and-extend candidates)
     uint32_t       *keptRecs, *occCounts, *ceCounts, *totalOcc, *withError;
     const uint8_t  *decodeMask;   // optional per-slot state; only slots with state == decodeWant are decoded
     uint8_t         decodeWant;
@@ -168,9 +169,8 @@ void launchListedReads(const uint32_t *heavyList, const uint32_t *heavyCount, co
 void launchUnitChains(const SearchOut &out, uint32_t unitBase, uint32_t nUnits, hipStream_t s);
 void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskRange, hipStream_t s);
 int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int
-void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s);
 struct ScatterDyn { const uint32_t *owner, *local; uint32_t base, cap; };          // the counters of adopted frames (SearchOut::dynOwner / dynLocal / dynBase / dynCap)
-void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,
+void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, uint8_t *valid, const uint8_t *heavyFlags,
                    const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, ScatterDyn dyn, hipStream_t s);
 void launchMergeCount(const MergeArgs &a, hipStream_t s);
 void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s);

@@ -95,7 +95,7 @@ void launchSaExpand(const DevBwt &b, const uint32_t *samples, uint32_t interval,
 // ---------------------------------------------------------------------------------------------
 // ordering: records -> CSR by item (counting scatter; offsets = exclusive scan of itemCounts)
 // ---------------------------------------------------------------------------------------------
-__global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered,
+__global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, uint8_t *valid,
                               const uint8_t *heavyFlags, const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, ScatterDyn dyn)
 {
     uint32_t n = *recCount;
@@ -115,10 +115,12 @@ __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint3
             }
             const uint32_t unit = at - unitBase;
             r.x = heavyList[unit / (groups * unitsPerItem)] * groups + (unit / unitsPerItem) % groups;
-            ordered[itemOffsets[at] + inChain + (r.y & 0xFFFFFFu)] = r;
+            const uint32_t dst = itemOffsets[at] + inChain + (r.y & 0xFFFFFFu);
+            ordered[dst] = r; valid[dst] = 1;
             continue;
         } else if (heavyFlags[r.x / groups]) continue;                         // stale: the second pass searched this read again
-        ordered[itemOffsets[at] + (r.y & 0xFFFFFFu)] = r;
+        const uint32_t dst = itemOffsets[at] + (r.y & 0xFFFFFFu);
+        ordered[dst] = r; valid[dst] = 1;
     }
 }
 
@@ -145,8 +147,8 @@ __global__ void mergeCountKernel(MergeArgs a)
     uint32_t total = 0, nRec = 0, nOcc = 0, nCe = 0;
     uint32_t we[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = beg; i < end && total < a.maxOut; i++) {
+        if (!a.valid[i]) continue;                                          // sequence number of a rejected check-and-extend candidate
         const uint4 r = a.ordered[i];
-        if (r.x == 0xFFFFFFFFu) continue;                                   // sequence number of a rejected check-and-extend candidate
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
         uint32_t cnt = kind ? 1u : r.w - r.z + 1u;
         if (total + cnt > a.maxOut) cnt = a.maxOut - total;
@@ -171,8 +173,24 @@ __device__ __forceinline__ uint32_t waveExclusiveSum(uint32_t v, uint32_t lane, 
     return inc - v;
 }
 
-// mergeCountKernel for the listed (long) reads: one wave per read, 64 entries of its slice per step -- the holes of rejected check-and-extend
-// candidates (nine in ten entries of a read inside a repeat family) cost a coalesced load instead of a turn of a serial loop
+// The long kernels walk a read's slice S3_LONG_STEPS x 64 slots per trip: the validity bytes of the trip are loaded first (and those of the next trip are
+// already on their way), then the 16-byte entries of the slots that hold a record -- one in ten -- all issued before the first is used; the 64-slot steps
+// of the trip are then worked through in order.  (Round 3 loaded 64 sixteen-byte entries per step, holes included, one step ahead: 2 us per step, latency.)
+#define S3_LONG_STEPS 8u
+struct LongTrip { uint32_t v[S3_LONG_STEPS]; };
+__device__ __forceinline__ LongTrip loadTripValid(const MergeArgs &a, uint32_t base, uint32_t end, uint32_t lane)
+{
+    LongTrip t;
+#pragma unroll
+    for (uint32_t u = 0; u < S3_LONG_STEPS; u++) {
+        const uint32_t pos = base + 64u * u + lane;
+        t.v[u] = pos < end ? (uint32_t)a.valid[pos] : 0u;                   // (base < end <= the array's length: a slot beyond `end` is not touched)
+    }
+    return t;
+}
+
+// mergeCountKernel for the listed (long) reads: one wave per read -- the holes of rejected check-and-extend
+// candidates (nine in ten entries of a read inside a repeat family) cost a byte of a coalesced load instead of a turn of a serial loop
 __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -184,33 +202,36 @@ __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
         readSlice(a, slot, groups, beg, end);
         uint32_t total = 0, nRec = 0, nOcc = 0, nCe = 0;                      // nRec / nOcc / nCe / we: per-lane partial sums
         uint32_t we[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        // (the next 64 entries are on their way while these are worked on: a step is a dependent kilobyte load otherwise)
-        uint4 rNext = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-        if (beg + lane < end) rNext = a.ordered[beg + lane];
-        for (uint32_t base = beg; base < end && total < a.maxOut; base += 64u) {
-            const uint4 r = rNext;
-            rNext = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-            if (base + 64u + lane < end) rNext = a.ordered[base + 64u + lane];
-            const bool valid = r.x != 0xFFFFFFFFu;
-            const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
-            // a range is never longer than maxOut can use: clamp before the prefix sum (32-bit)
-            uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;
-            if (cnt > a.maxOut) cnt = a.maxOut;
-            uint32_t sum = 0;
-            const uint32_t pre = waveExclusiveSum(cnt, lane, sum);
-            const bool incl = valid && total + pre < a.maxOut;
-            uint32_t c = 0;
-            if (incl) { c = cnt; if (total + pre + c > a.maxOut) c = a.maxOut - total - pre; }
+        LongTrip next = loadTripValid(a, beg, end, lane);
+        for (uint32_t base = beg; base < end && total < a.maxOut; base += 64u * S3_LONG_STEPS) {
+            const LongTrip cur = next;
+            if (base + 64u * S3_LONG_STEPS < end) next = loadTripValid(a, base + 64u * S3_LONG_STEPS, end, lane);
+            uint4 rr[S3_LONG_STEPS];
 #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) we[k] += nmis == k ? c : 0u;
-            nRec += incl ? 1u : 0u; nOcc += c; nCe += incl ? kind : 0u;
-            total = total + sum > a.maxOut ? a.maxOut : total + sum;
+            for (uint32_t u = 0; u < S3_LONG_STEPS; u++) rr[u] = a.ordered[cur.v[u] ? base + 64u * u + lane : beg];     // (a lane without a record reads a line the wave has)
+#pragma unroll
+            for (uint32_t u = 0; u < S3_LONG_STEPS; u++) {
+                if (total >= a.maxOut) break;
+                const uint4 r = rr[u];
+                const bool valid = cur.v[u] != 0u;
+                const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
+                // a range is never longer than maxOut can use: clamp before the prefix sum (32-bit)
+                uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;
+                if (cnt > a.maxOut) cnt = a.maxOut;
+                uint32_t sum = 0;
+                const uint32_t pre = waveExclusiveSum(cnt, lane, sum);
+                const bool incl = valid && total + pre < a.maxOut;
+                uint32_t c = 0;
+                if (incl) { c = cnt; if (total + pre + c > a.maxOut) c = a.maxOut - total - pre; }
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) we[k] += nmis == k ? c : 0u;
+                nRec += incl ? 1u : 0u; nOcc += c; nCe += incl ? kind : 0u;
+                total = total + sum > a.maxOut ? a.maxOut : total + sum;
+            }
         }
-        uint32_t dummy = 0;
         (void)waveExclusiveSum(nRec, lane, nRec); (void)waveExclusiveSum(nOcc, lane, nOcc); (void)waveExclusiveSum(nCe, lane, nCe);
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) (void)waveExclusiveSum(we[k], lane, we[k]);
-        (void)dummy;
         if (lane == 0) {
             a.keptRecs[slot] = nRec; a.occCounts[slot] = nOcc; a.ceCounts[slot] = nCe; a.totalOcc[slot] = total;
             for (int k = 0; k < 8; k++) a.withError[(size_t)slot * 8 + k] = we[k];
@@ -230,8 +251,8 @@ __global__ void mergeFillKernel(MergeArgs a, const uint32_t *hitOffsets, DevHit 
     uint32_t total = 0;
     DevHit *dst = hits + hitOffsets[slot];
     for (uint32_t k = 0, i = beg; k < n; i++) {
+        if (!a.valid[i]) continue;
         const uint4 r = a.ordered[i];
-        if (r.x == 0xFFFFFFFFu) continue;
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
         const uint32_t grp = r.x % groups;
         uint32_t lo = r.z, hi = r.w;
@@ -262,8 +283,8 @@ __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffset
     if ((uint64_t)occBase + occOffsets[slot + 1] > occCap) { atomicOr(flags, S3_FLAG_OCC_OVERFLOW); return; }
     uint32_t total = 0;
     for (uint32_t k = 0, i = beg; k < n; i++) {
+        if (!a.valid[i]) continue;
         const uint4 r = a.ordered[i];
-        if (r.x == 0xFFFFFFFFu) continue;
         k++;
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
         const uint32_t strand = ((r.x % groups) & 1u) + 1u;
@@ -294,14 +315,18 @@ __global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix
         if ((uint64_t)occBase + occOffsets[slot + 1] > occCap) { if (lane == 0) atomicOr(flags, S3_FLAG_OCC_OVERFLOW); continue; }
         uint32_t o = occBase + occOffsets[slot], oSa = o + a.ceCounts[slot];  // wave-uniform cursors: check-and-extend hits / expanded SA ranges
         uint32_t total = 0;
-        // (the next 64 entries are on their way while these are worked on: a step is a dependent kilobyte load otherwise)
-        uint4 rNext = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-        if (beg + lane < end) rNext = a.ordered[beg + lane];
-        for (uint32_t base = beg; base < end && total < a.maxOut; base += 64u) {
-            const uint4 r = rNext;
-            rNext = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-            if (base + 64u + lane < end) rNext = a.ordered[base + 64u + lane];
-            const bool valid = r.x != 0xFFFFFFFFu;
+        LongTrip next = loadTripValid(a, beg, end, lane);
+        for (uint32_t base0 = beg; base0 < end && total < a.maxOut; base0 += 64u * S3_LONG_STEPS) {
+          const LongTrip cur = next;
+          if (base0 + 64u * S3_LONG_STEPS < end) next = loadTripValid(a, base0 + 64u * S3_LONG_STEPS, end, lane);
+          uint4 rr[S3_LONG_STEPS];
+#pragma unroll
+          for (uint32_t u = 0; u < S3_LONG_STEPS; u++) rr[u] = a.ordered[cur.v[u] ? base0 + 64u * u + lane : beg];
+#pragma unroll
+          for (uint32_t u = 0; u < S3_LONG_STEPS; u++) {
+            if (total >= a.maxOut) break;
+            const uint4 r = rr[u];
+            const bool valid = cur.v[u] != 0u;
             const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
             uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;
             if (cnt > a.maxOut) cnt = a.maxOut;
@@ -332,6 +357,7 @@ __global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix
             }
             o += nKind; oSa += nSa;
             total = total + sum > a.maxOut ? a.maxOut : total + sum;
+          }
         }
     }
 }
@@ -521,18 +547,6 @@ int launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hip
     return 0;
 }
 
-__global__ void fillInvalidKernel(uint4 *ordered, const uint32_t *total, uint32_t cap)
-{
-    uint32_t n = *total;
-    if (n > cap) n = cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) ordered[i] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-}
-
-void launchFillInvalid(uint4 *ordered, const uint32_t *total, uint32_t cap, hipStream_t s)
-{
-    hipLaunchKernelGGL(fillInvalidKernel, dim3(2048), dim3(256), 0, s, ordered, total, cap);
-}
-
 // the listed reads count per unit: what the first pass left in their items' own counters (or never wrote) is void
 __global__ void zeroListedCountsKernel(const uint32_t *heavyList, const uint32_t *heavyCount, uint32_t groups, uint32_t *itemCounts)
 {
@@ -549,10 +563,10 @@ void launchZeroListedCounts(const uint32_t *heavyList, const uint32_t *heavyCoun
     hipLaunchKernelGGL(zeroListedCountsKernel, dim3(blocks), dim3(256), 0, s, heavyList, heavyCount, groups, itemCounts);
 }
 
-void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, const uint8_t *heavyFlags,
+void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, uint8_t *valid, const uint8_t *heavyFlags,
                    const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, ScatterDyn dyn, hipStream_t s)
 {
-    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, heavyFlags, heavyList, groups, unitBase, unitsPerItem, dyn);
+    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, valid, heavyFlags, heavyList, groups, unitBase, unitsPerItem, dyn);
 }
 
 void launchMergeCount(const MergeArgs &a, hipStream_t s)
