@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_UNIT_WAVES_PER_SIMD)
 unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 {
     extern __shared__ __align__(16) unsigned char shmem[];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (the wave number is uniform: said so, its addresses stay scalar)
     const uint32_t wpq = in.wpqLoad;                                        // words per orientation in readsT
     const uint32_t wl = in.wLds;                                            // words of the searched strand kept in LDS
     const uint32_t waveBytes = 4096u + S3_UNIT_RDY_BYTES + wl * 256u;
