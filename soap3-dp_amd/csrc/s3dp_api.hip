@@ -571,8 +571,12 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     // (default 1024: dead ends cost steps, not candidates).  Round 3, with the unit pass twice as fast: 2048 / 1024 / give-up 2 is 6 % faster than round 2's
     // 1024 / 4096 / 4 on the benchmark genome and no slower on the other repeat models (profiles/r03_threshold_sweeps.txt)
     const size_t heavyEnv = envSize("S3DP_HEAVY", 1);                       // read per pass: tests switch it
-    in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : 2048u);
-    in.heavyRank = heavyEnv == 0 ? 0xFFFFFFFFu : (uint32_t)envSize("S3DP_HEAVY_RANK", heavyEnv > 1 && heavyEnv < 64 ? 64 : 1024);
+    // (defaults by the size of the batch: what a read costs before it is listed is a floor under the duration of a first pass -- 1024 rank queries are 2.3 ms --
+    //  which the ladder of ten million reads does not feel and the ladder of one million does: 1 Mi-read batch 81.2 -> 75.9 ms per ladder with 1024 / 512,
+    //  tools/r4_small_sweep.sh; the 10 M batch is best at 2048 / 1024, profiles/r03_threshold_sweeps.txt)
+    const bool smallPass = b->n <= (2u << 20);                                // (by the BATCH: the later phases of a large batch are small passes and still best at 2048 / 1024)
+    in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : (smallPass ? 1024u : 2048u));
+    in.heavyRank = heavyEnv == 0 ? 0xFFFFFFFFu : (uint32_t)envSize("S3DP_HEAVY_RANK", heavyEnv > 1 && heavyEnv < 64 ? 64 : (smallPass ? 512 : 1024));
     in.slotList = nullptr; in.slotCount = nullptr;
     // units of the second pass: first-mismatch positions of an item's first mismatch step, + 1 for "none" -- the longest such step over the cases
     // and over the read lengths this batch can hold (S3DP_UNITS=0: whole items)
