@@ -246,7 +246,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             uint32_t nPairs = (uint32_t)__popcll(giveMask);
             const uint32_t nIdle = (uint32_t)__popcll(idleMask);
             if (nIdle < nPairs) nPairs = nIdle;
-            if (nIdle < S3_UNIT_ADOPT_IDLE) nPairs = 0;
+            if (nIdle < in.adoptIdle) nPairs = 0;
             if (nPairs && !noNodes) {
                 if (nodeCur + nPairs > nodeEnd) {
                     // (what is left of the old block is dropped: a few counters nobody uses)

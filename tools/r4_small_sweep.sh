@@ -26,9 +26,10 @@ print("%s reads %d: %.2f M reads/s, %.1f ms per step (stepping %.1f, ce %.1f)" %
 PY
 }
 run TAG=default
-run TAG=rank512 S3DP_HEAVY_RANK=512
-run TAG=rank256 S3DP_HEAVY_RANK=256
-run TAG=rank512_heavy1024 S3DP_HEAVY_RANK=512 S3DP_HEAVY=1024
-run TAG=rank256_heavy512 S3DP_HEAVY_RANK=256 S3DP_HEAVY=512
-run TAG=giveup4 S3DP_CE_GIVE_UP=4
-run TAG=adoptnodes0 S3DP_UNIT_NODES=0
+run TAG=idle16 S3DP_ADOPT_IDLE=16
+run TAG=idle8 S3DP_ADOPT_IDLE=8
+run TAG=idle4 S3DP_ADOPT_IDLE=4
+run TAG=idle1 S3DP_ADOPT_IDLE=1
+run TAG=10M_default N_READS=10000000
+run TAG=10M_idle8 N_READS=10000000 S3DP_ADOPT_IDLE=8
+run TAG=10M_idle1 N_READS=10000000 S3DP_ADOPT_IDLE=1
