@@ -400,6 +400,9 @@ int  s3_probe_gather(int device, size_t tableBytes, uint32_t blocks, uint32_t it
 int  s3_probe_copy(int device, size_t bytes, int repeats, float *msOut);
 
 int  s3_device_count(void);
+/* the host NUMA node device `device` is attached to (-1 if the system does not say): where a host program keeps the threads and buffers that feed it.
+ * (No counterpart in the reference, which leaves placement to the operating system; soap3_dp_main.cpp binds to it unless S3DP_NUMA_BIND=0.) */
+int  s3_device_host_node(int device, int *node);
 const char *s3_last_error(void);
 const char *s3_version(void);
 

@@ -95,48 +95,138 @@ struct ValidateArgs {
     uint8_t *selFlags;
 };
 
+// The filter restated so that a list can be shared by a wave.  The reference's loop keeps, in list order, the hits with seed mismatches >= minSeedMis and
+// seed + extension mismatches <= maxMis -- in the best modes only those with the FEWEST total (a smaller total empties what was kept so far), and it
+// stops once the smallest possible total (minSeedMis) has maxHit entries; the list is cut at maxHit afterwards.  Whatever the order of events, what
+// remains is: the qualifying hits (best modes: those whose total equals the list's minimum), in list order, the first maxHit of them.  So: one sweep
+// that counts every hit's mismatches (kept in bits 16..23 of its meta word) and takes the minimum, one sweep that compacts in order.
+// The extension is compared sixteen characters at a time: the read's tail from its packed words (LSB-first characters), the text window from two packed
+// words (MSB-first characters) -- read as a number that window IS the reversed sequence, which is what the reverse strand compares against (complemented);
+// for the forward strand its character order is turned around (bit reversal, then the two bits of each character swapped back).
+struct TailCompare {
+    const uint32_t *rd;           // the read's first packed word (32-interleaved layout)
+    const uint32_t *text;
+    uint32_t wpq, textWords, textLength, readLen, seedLen, ext;
+    int maxMis;
+    __device__ __forceinline__ uint32_t readWord(uint32_t q0) const       // characters q0 .. q0+15 of the read, LSB-first
+    {
+        const uint32_t w = q0 >> 4, sh = (q0 & 15u) * 2u;
+        const uint32_t lo = w < wpq ? rd[(size_t)w * 32u] : 0u, hi = w + 1u < wpq ? rd[(size_t)(w + 1u) * 32u] : 0u;
+        return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+    }
+    __device__ __forceinline__ uint32_t textWord(long long s) const       // characters s .. s+15 of the text, MSB-first (positions outside the text read as 0)
+    {
+        const long long w = s >> 4;                                        // (arithmetic shift: s may be negative for the last, partial window of a reverse hit)
+        const uint32_t sh = (uint32_t)(s & 15) * 2u;
+        const uint32_t hi = (w >= 0 && w < (long long)textWords) ? text[w] : 0u, lo = (w + 1 >= 0 && w + 1 < (long long)textWords) ? text[w + 1] : 0u;
+        return sh ? (hi << sh) | (lo >> (32u - sh)) : hi;
+    }
+    // seed + extension mismatches of one seed hit, 0xFF when it does not qualify
+    __device__ __forceinline__ uint32_t total(uint32_t pos, uint32_t meta, int minSeedMis) const
+    {
+        const uint32_t strand = meta & 0xFFu;
+        const int seedMis = (int)((meta >> 8) & 0xFFu);
+        if (seedMis < minSeedMis) return 0xFFu;
+        const bool fwd = strand == 1u && (uint64_t)pos + readLen <= textLength, rev = strand == 2u && pos >= ext;
+        if (!fwd && !rev) return 0xFFu;
+        int mis = seedMis;
+        for (uint32_t k = 0; k < ext && mis <= maxMis; k += 16u) {
+            const uint32_t left = ext - k, mask = left >= 16u ? 0x55555555u : ((1u << (2u * left)) - 1u) & 0x55555555u;
+            const uint32_t r = readWord(seedLen + k);
+            uint32_t x;
+            if (fwd) {
+                uint32_t t = __brev(textWord((long long)pos + seedLen + k));
+                t = ((t >> 1) & 0x55555555u) | ((t & 0x55555555u) << 1);
+                x = r ^ t;
+            } else {
+                x = r ^ ~textWord((long long)pos - 16 - (long long)k);
+            }
+            mis += __popc((x | (x >> 1)) & mask);
+        }
+        return mis <= maxMis ? (uint32_t)mis : 0xFFu;
+    }
+};
+
+#define S3_VALIDATE_OWN 8u          // lists up to this long stay with their read's lane; longer ones are taken by the whole wave, one after the other
+
 __global__ void validateKernel(ValidateArgs a)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= a.nActive || a.state[slot] != a.want) return;
-    const uint32_t r = a.active ? a.active[slot] : slot;
-    const uint32_t readLen = a.lens[r], seedLen = a.seedLens[r];
-    const uint32_t base = a.occBase + a.occOffsets[slot];
-    const uint32_t cnt = a.occOffsets[slot + 1] - a.occOffsets[slot];
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool mine = slot < a.nActive && a.state[slot] == a.want;
+    uint32_t r = 0, readLen = 0, seedLen = 0, base = 0, cnt = 0;
+    if (mine) {
+        r = a.active ? a.active[slot] : slot;
+        readLen = a.lens[r]; seedLen = a.seedLens[r];
+        base = a.occBase + a.occOffsets[slot];
+        cnt = a.occOffsets[slot + 1] - a.occOffsets[slot];
+    }
+    const bool extend = mine && readLen > seedLen;
+    int maxMisAll = 0;
     uint32_t out = cnt;
-    if (readLen > seedLen) {
-        const uint32_t ext = readLen - seedLen;
-        int maxMis = (int)ceil(0.02 * (double)readLen);                  // MISMATCH_RATIO_FOR_LONG, CPUfunctions.cpp:1819
-        if (a.needMapq) maxMis *= 2;
-        int pre = maxMis;
-        const uint32_t *rd = a.queries + (size_t)(r >> 5) * 32u * a.wpq + (r & 31u);
-        auto readChar = [&](uint32_t q) -> uint32_t { return (rd[(size_t)(q >> 4) * 32u] >> ((q & 15u) * 2u)) & 3u; };
-        auto textChar = [&](uint64_t p) -> uint32_t { return (a.text[p >> 4] >> (2u * (15u - (uint32_t)(p & 15u)))) & 3u; };
+    auto compareOf = [&](uint32_t rr, uint32_t rl, uint32_t sl) {
+        TailCompare c;
+        c.rd = a.queries + (size_t)(rr >> 5) * 32u * a.wpq + (rr & 31u);
+        c.text = a.text; c.wpq = a.wpq; c.textLength = a.textLength; c.textWords = (a.textLength + 15u) / 16u;
+        c.readLen = rl; c.seedLen = sl; c.ext = rl - sl;
+        int m = (int)ceil(0.02 * (double)rl);                            // MISMATCH_RATIO_FOR_LONG, CPUfunctions.cpp:1819
+        if (a.needMapq) m *= 2;
+        c.maxMis = m;
+        return c;
+    };
+    (void)maxMisAll;
+    if (extend && cnt <= S3_VALIDATE_OWN) {
+        const TailCompare c = compareOf(r, readLen, seedLen);
+        uint32_t tot[S3_VALIDATE_OWN], best = 0xFFu;
+        #pragma unroll
+        for (uint32_t i = 0; i < S3_VALIDATE_OWN; i++) {
+            tot[i] = 0xFFu;
+            if (i < cnt) { tot[i] = c.total(a.occPos[base + i], a.occMeta[base + i], a.minSeedMis); best = tot[i] < best ? tot[i] : best; }
+        }
         out = 0;
-        for (uint32_t i = 0; i < cnt; i++) {
-            const uint32_t pos = a.occPos[base + i], meta = a.occMeta[base + i];
-            const uint32_t strand = meta & 0xFFu;
-            const int seedMis = (int)((meta >> 8) & 0xFFu);
-            if (seedMis < a.minSeedMis) continue;
-            int mis = maxMis + 1;
-            if (strand == 1u && (uint64_t)pos + readLen <= a.textLength) {
-                mis = 0;
-                for (uint32_t t = 0; t < ext; t++) mis += readChar(seedLen + t) != textChar((uint64_t)pos + seedLen + t);
-            }
-            if (strand == 2u && pos >= ext) {
-                mis = 0;
-                for (uint32_t t = 0; t < ext; t++) mis += (3u - readChar(readLen - 1u - t)) != textChar((uint64_t)pos - ext + t);
-            }
-            const int tot = mis + seedMis;
-            if (tot > maxMis) continue;
-            if (a.onlyBest && tot > pre) continue;
-            if (a.onlyBest && tot < pre) { out = 0; pre = tot; }
-            a.occPos[base + out] = strand == 1u ? pos : pos - ext;
-            a.occMeta[base + out] = strand | (uint32_t)tot << 8;
+        #pragma unroll
+        for (uint32_t i = 0; i < S3_VALIDATE_OWN; i++) {
+            if (i >= cnt || tot[i] == 0xFFu || (a.onlyBest && tot[i] != best) || out >= a.maxHit) continue;
+            const uint32_t pos = a.occPos[base + i], strand = a.occMeta[base + i] & 0xFFu;
+            a.occPos[base + out] = strand == 1u ? pos : pos - c.ext;       // (out <= i: entry i has been read by now)
+            a.occMeta[base + out] = strand | tot[i] << 8;
             out++;
-            if (pre == a.minSeedMis && out >= a.maxHit) break;
         }
     }
+    unsigned long long big = __ballot(extend && cnt > S3_VALIDATE_OWN);
+    while (big) {
+        const int l = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t rr = (uint32_t)__shfl((int)r, l), rl = (uint32_t)__shfl((int)readLen, l), sl = (uint32_t)__shfl((int)seedLen, l);
+        const uint32_t b0 = (uint32_t)__shfl((int)base, l), c0 = (uint32_t)__shfl((int)cnt, l);
+        const TailCompare c = compareOf(rr, rl, sl);
+        uint32_t best = 0xFFu;
+        for (uint32_t k = lane; k < c0; k += 64u) {
+            const uint32_t meta = a.occMeta[b0 + k];
+            const uint32_t t = c.total(a.occPos[b0 + k], meta, a.minSeedMis);
+            a.occMeta[b0 + k] = (meta & 0xFFFFu) | t << 16;
+            best = t < best ? t : best;
+        }
+        for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d); best = o < best ? o : best; }
+        uint32_t kept = 0;
+        for (uint32_t k0 = 0; k0 < c0 && kept < a.maxHit; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            uint32_t pos = 0, meta = 0xFF0000u;
+            if (k < c0) { pos = a.occPos[b0 + k]; meta = a.occMeta[b0 + k]; }
+            const uint32_t t = meta >> 16;
+            const bool keep = t != 0xFFu && (!a.onlyBest || t == best);
+            const unsigned long long m = __ballot(keep);
+            const uint32_t at = kept + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            // (a kept entry lands at or before its own place, and every lane of the wave has read this round's entries before any of them is written)
+            if (keep && at < a.maxHit) {
+                const uint32_t strand = meta & 0xFFu;
+                a.occPos[b0 + at] = strand == 1u ? pos : pos - c.ext;
+                a.occMeta[b0 + at] = strand | t << 8;
+            }
+            kept += (uint32_t)__popcll(m);
+        }
+        if ((int)lane == l) out = kept;
+    }
+    if (!mine) return;
     if (out > a.maxHit) out = a.maxHit;                                  // origHitLimit, CPUfunctions.cpp:1838
     a.outOccCount[r] = out;
     if (out == 0) {

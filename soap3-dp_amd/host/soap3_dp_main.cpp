@@ -16,6 +16,7 @@
 #include <atomic>
 #include <chrono>
 #include <unistd.h>
+#include <sched.h>
 #include <thread>
 #include <future>
 #include <vector>
@@ -549,6 +550,55 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
 
 static int die(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); return 1; }
 
+// ---- placement: the calling thread (and every thread it starts afterwards) goes to the CPUs of the host NUMA node(s) the given devices hang off, so that
+// the chunk buffers, the pinned staging buffers and the threads that fill them sit on the device's side of the socket link.  Measured on a two-socket host
+// (2 x 64 cores, MI355X on node 0), ten million 2 x 150 pairs: 4.03-4.17 s with the threads wherever the scheduler put them, 3.63-3.83 s on either single
+// node -- what costs is a run spread over both.  An affinity the caller already narrowed (taskset, a cgroup) is only ever narrowed further; a system that
+// does not tell the node is left alone; S3DP_NUMA_BIND=0 turns this off.  (The reference leaves placement to the operating system.)
+static bool cpusOfNode(int node, cpu_set_t &set)
+{
+    CPU_ZERO(&set);
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    char text[4096] = {0};
+    const bool got = fgets(text, sizeof text, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    for (const char *q = text; *q && *q != '\n';) {                           // "0-63,128-191"
+        char *e = nullptr;
+        const long lo = strtol(q, &e, 10);
+        if (e == q) return false;
+        long hi = lo;
+        if (*e == '-') { q = e + 1; hi = strtol(q, &e, 10); if (e == q) return false; }
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; c++) CPU_SET((int)c, &set);
+        q = *e == ',' ? e + 1 : e;
+    }
+    return CPU_COUNT(&set) > 0;
+}
+static void bindNearDevices(const int *devices, int nDevices)
+{
+    if (const char *e = getenv("S3DP_NUMA_BIND")) if (atoi(e) == 0) return;
+    // (what the program was started with, taken once: a second job of a *-multi run, or a member on another node, is placed within that, not within
+    //  what an earlier call left the main thread with)
+    static cpu_set_t have;
+    static const bool known = sched_getaffinity(0, sizeof have, &have) == 0;
+    if (!known) return;
+    cpu_set_t want;
+    CPU_ZERO(&want);
+    for (int k = 0; k < nDevices; k++) {
+        int node = -1;
+        cpu_set_t c;
+        if (s3_device_host_node(devices[k], &node) != S3_OK || node < 0 || !cpusOfNode(node, c)) return;
+        CPU_OR(&want, &want, &c);
+    }
+    CPU_AND(&want, &want, &have);
+    if (CPU_COUNT(&want) == 0) return;
+    if (sched_setaffinity(0, sizeof want, &want) == 0 && getenv("S3DP_VERBOSE"))
+        fprintf(stderr, "[s3dp] host threads on the %d CPUs of the device's NUMA node (of %d)\n", CPU_COUNT(&want), CPU_COUNT(&have));
+}
+
 // what the jobs of one program run share: the index in host memory and on the devices (single-multi / pair-multi load it once, SOAP3-DP.cu:869-1140)
 struct SharedIndex {
     HostIndex hix;
@@ -614,6 +664,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     if (maxReadLength > S3_MAX_READ_LENGTH) return die("The length should not be greater than 1024");
     if (readGroup.empty()) readGroup = queryFile;
     if (sampleName.empty()) sampleName = "default";
+    bindNearDevices(devices.data(), (int)devices.size());                       // before the loader thread and the index buffers
     std::string err;
     HostIndex &hix = shared.hix;
     const auto t0 = std::chrono::steady_clock::now();
@@ -777,6 +828,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     std::vector<uint64_t> counters((size_t)nMembers * C_COUNTERS, 0);
     std::vector<double> memberDpSeconds((size_t)nMembers, 0);
     auto runMember = [&](int member) -> int {
+    if (nMembers > 1) bindNearDevices(&devices[(size_t)member], 1);           // (each member's threads to its own device's node)
     s3_index *ix = s3_group_index(grp, member);
     const std::string fileNo = std::to_string(member + 1);
     double dpStageSeconds = 0;
@@ -1197,6 +1249,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             dpq.cv.notify_all();
         }
     }
+    mark("last chunk searched");
     if (postThread.joinable()) {
         { std::lock_guard<std::mutex> g(postq.mu); postq.stop = true; }
         postq.cv.notify_all();
@@ -1212,11 +1265,13 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             leftoverPairs += workerCounts[w][4];
             dpStageSeconds += workerSeconds[w];
         }
+        mark("DP stage threads done");
         b = stageBatches[0];
         for (size_t k = 1; k < stageBatches.size(); k++) s3_batch_free(stageBatches[k]);
     }
     auto closeOut = [&](FILE *f) { drainOutput(f); if (!bamClose(f)) { fprintf(stderr, "write error on the output file\n"); fflush(stdout); fflush(stderr); _exit(1); } fclose(f); };
     closeOut(out);
+    mark("first output file closed");
     if (streamFreer.joinable()) { streamFreer.join(); mark("stream freed"); }
     if (dpOut) {
         closeOut(dpOut);

@@ -235,6 +235,74 @@ def test_long_read_mode_matches_oracle(report_type, mm):
     b.close()
 
 
+@pytest.mark.parametrize("report_type,mm,max_out", [(2, 2, 1000), (1, 2, 1000), (2, 3, 40), (3, 2, 1000), (4, 2, 5)])
+def test_long_read_mode_inside_repeat_families(report_type, mm, max_out):
+    """150-base reads (-L 150: the first 100 bases searched without a hit limit, the other 50 verified on the device) from a dispersed family of 600
+    near-identical copies and a tandem array: the seed lists hold hundreds of hits, which the verification (validateKernel, s3dp_ladder.hip) shares
+    among the lanes of a wave; lists of up to eight hits stay with one lane.  What is kept, its order, the shift of reverse hits to the read's leftmost
+    base, the cut at the hit limit and the best modes' "fewest mismatches only" must equal the reference's serial filter (validateAlignments,
+    CPUfunctions.cpp:1129-1222) -- at a hit limit above and below the list lengths, and with reads hanging over both ends of the text."""
+    rng = np.random.default_rng(78)
+    n, L = 300_000, 150
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    unit = rng.integers(0, 4, size=700, dtype=np.uint8)
+    for c in range(550):                                      # dispersed family: the seeds' side 0.3 % from the consensus, the far side 3 %
+        at = 1000 + c * 500 + int(rng.integers(0, 40))
+        cp = unit.copy()
+        rate = np.where(np.arange(700) % 300 < 150, 0.003, 0.03)
+        flip = rng.random(700) < rate
+        cp[flip] = (cp[flip] + rng.integers(1, 4, size=int(flip.sum()))) % 4
+        codes[at:at + 450] = cp[:450]
+    sat = rng.integers(0, 4, size=171, dtype=np.uint8)
+    for c in range(100):                                      # tandem array at the very end of the text, 1 % divergence
+        cp = sat.copy()
+        flip = rng.random(171) < 0.01
+        cp[flip] = (cp[flip] + rng.integers(1, 4, size=int(flip.sum()))) % 4
+        codes[n - (c + 1) * 171:n - c * 171] = cp
+    codes[:171 * 3] = np.tile(sat, 3)                          # and three units at the very start
+    hi = builder.build_host_index(codes, device="cpu")
+    ix = s3dp.Index(hi)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+    reads = []
+    for k in range(384):
+        where = k % 4
+        if where == 0:
+            start = 1000 + int(rng.integers(0, 550)) * 500 + int(rng.integers(0, 250))
+        elif where == 1:
+            start = n - 171 * 100 + int(rng.integers(0, 171 * 100 - L))
+        elif where == 2:
+            start = int(rng.integers(0, n - L))
+        else:
+            start = int(rng.integers(0, 171 * 3 - L)) if k % 8 == 3 else n - L - int(rng.integers(0, 171))
+        rd = codes[start:start + L].copy()
+        for _ in range(int(rng.integers(0, 4))):
+            j = int(rng.integers(0, L))
+            rd[j] = (rd[j] + 1 + int(rng.integers(0, 3))) % 4
+        if k % 3 == 0:
+            rd = comp[rd[::-1]]
+        reads.append(bytes(b"ACGT"[c] for c in rd))
+    q, lens, wpq = s3dp.pack_reads(reads, L)
+    seeds = np.where(lens > 120, 100, lens).astype(np.uint32)
+    b = s3dp.Batch(ix, len(reads), wpq)
+    b.upload(q, lens)
+    b.set_seed_lengths(seeds)
+    b.align_single(mm, max_out, report_type)
+    phase, werr, offs, pos, strand, mis = b.fetch_alignments()
+    oix = s3o.Index(host_index=hi)
+    ophase, owerr, ooffs, opos, ostrand, omis, st = oix.align_single_allbest(q, lens, wpq, mm, max_out, report_type=report_type, seed_lengths=seeds)
+    nhit = ooffs[1:] - ooffs[:-1]
+    if max_out >= 1000 and report_type <= 2:
+        assert (nhit > 64).sum() > 20, "the workload should hold reads with lists longer than a wave"
+    assert (nhit > 0).sum() > 200 and ((nhit > 0) & (nhit <= 8)).sum() > 50
+    assert (phase == ophase).all()
+    bad = np.nonzero((offs[1:] - offs[:-1]) != nhit)[0]
+    assert len(bad) == 0, "read %d keeps %d hits, the oracle %d" % (bad[0], (offs[1:] - offs[:-1])[bad[0]], nhit[bad[0]])
+    assert (pos == opos).all() and (strand == ostrand).all() and (mis == omis).all()
+    oix.close()
+    b.close()
+    ix.close()
+
+
 def test_buffers_grow_instead_of_overflowing(monkeypatch):
     """record and occurrence buffers start tiny (env) and must grow transparently: same result as the oracle"""
     monkeypatch.setenv("S3DP_REC_PER_READ", "0")
