@@ -1005,6 +1005,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         std::unique_ptr<ReadSet> rs; s3_batch *b = nullptr; uint32_t cnt = 0;
         std::vector<s3_pair_result> pr; s3_pair_routing routing{}; uint64_t chunkNo = 0, readBase = 0;
         std::vector<uint32_t> todo; bool hadSeedLengths = false;                  // single reads (default mode): the reads the BWT stage left without a hit
+        std::vector<uint32_t> seeds;                                              // single reads above 120 bases: the searched length of every read
     };
     struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<PairJob>> q; std::vector<s3_batch *> freeBatches; bool stop = false; } dpq;
     std::vector<s3_batch *> stageBatches;                                         // the batches that take turns: one under the search, one with each DP stage thread
@@ -1075,7 +1076,38 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<PairJob>> q; bool stop = false; } postq;
     std::thread postThread;
     uint64_t postAligned = 0;
-    const bool postOn = pipelinedDp && paired && !skipSoap3 && !(getenv("S3DP_POST_THREAD") && atoi(getenv("S3DP_POST_THREAD")) == 0);
+    const bool postOn = pipelinedDp && !skipSoap3 && !(getenv("S3DP_POST_THREAD") && atoi(getenv("S3DP_POST_THREAD")) == 0);
+    // single reads: what follows the search of a chunk -- the hits fetched, the records of the reads that have some formatted and written, the others listed
+    // for the DP stage (`todo`, DP on).  Called by the chunk loop, or by the post thread while the loop searches the next chunk.
+    auto finishSingle = [&](s3_batch *bb, const ReadSet &rs, uint32_t cnt, const std::vector<uint32_t> &seeds, uint64_t &al, std::vector<uint32_t> *todo, std::string &e) -> bool {
+        std::vector<uint8_t> phase(cnt);
+        std::vector<uint64_t> offs((size_t)cnt + 1);
+        uint64_t nOcc = 0;
+        const auto tF = std::chrono::steady_clock::now();
+        if (s3_batch_fetch_alignments(bb, phase.data(), nullptr, offs.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) { e = s3_last_error(); return false; }
+        addBatchTiming(bb);
+        std::vector<uint32_t> pos(nOcc ? nOcc : 1);
+        std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
+        if (s3_batch_fetch_alignments(bb, nullptr, nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK) { e = s3_last_error(); return false; }
+        addChunkSeconds(1, since(tF));
+        const auto tW = std::chrono::steady_clock::now();
+        parallelFormat(hix, so, out, cnt, [&](SamWriter &w, uint32_t k, uint64_t &a1) {
+            const size_t o = offs[k], m = offs[k + 1] - offs[k];
+            if (alignmentType >= 3) {
+                // unique best: exactly one hit, otherwise a no-answer record; random best: the first hit (hostKernel, CPUfunctions.cpp:1861-1930)
+                if (m == 0 && enableDP) return;                                   // goes to the DP stage
+                if (m == 0 || (alignmentType == 3 && m > 1)) w.unaligned(rs, k);
+                else { a1++; w.singleAnswer(rs, k, pos[o], strand[o], mis[o]); }
+                return;
+            }
+            if (m) a1++;
+            else if (enableDP) return;                                            // goes to the DP stage
+            w.singleEnd(rs, k, pos.data() + o, strand.data() + o, mis.data() + o, m, seeds.empty() ? 0u : seeds[k]);
+        }, al);
+        addChunkSeconds(2, since(tW));
+        if (todo) for (uint32_t k = 0; k < cnt; k++) if (offs[k + 1] == offs[k]) todo->push_back(k);
+        return true;
+    };
     if (postOn) {
         s3_batch *nb = nullptr;                                                   // (one more batch takes turns: the one the post thread holds)
         if (s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : chunk->n, chunk->wpq, &nb) != S3_OK) return dieJoin(s3_last_error());
@@ -1093,6 +1125,13 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                     postq.q.pop_front();
                 }
                 const ReadSet &rs = *j->rs;
+                if (!paired) {
+                    std::string e2;
+                    if (!finishSingle(j->b, rs, j->cnt, j->seeds, postAligned, &j->todo, e2)) fatal(e2);
+                    { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); }
+                    dpq.cv.notify_all();
+                    continue;
+                }
                 const uint32_t np = j->cnt / 2;
                 std::vector<s3_pair_result> &pr = j->pr;
                 pr.resize(np ? np : 1);
@@ -1218,32 +1257,24 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             for (uint32_t k = 0; k < cnt; k++) seeds[k] = rs.lengths[first + k] > 120 ? 100u : rs.lengths[first + k];
             if (s3_batch_set_seed_lengths(b, seeds.data()) != S3_OK) return dieJoin(s3_last_error());
         }
+        const auto tA = std::chrono::steady_clock::now();
         if (s3_batch_align_single(b, (uint32_t)numMismatch, ini.maxOutputPerRead, alignmentType) != S3_OK) return dieJoin(s3_last_error());
-        std::vector<uint8_t> phase(cnt);
-        std::vector<uint64_t> offs((size_t)cnt + 1);
-        uint64_t nOcc = 0;
-        if (s3_batch_fetch_alignments(b, phase.data(), nullptr, offs.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) return dieJoin(s3_last_error());
-        addBatchTiming(b);
-        std::vector<uint32_t> pos(nOcc ? nOcc : 1);
-        std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
-        if (s3_batch_fetch_alignments(b, nullptr, nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK) return dieJoin(s3_last_error());
-        parallelFormat(hix, so, out, cnt, [&](SamWriter &w, uint32_t k, uint64_t &al) {
-            const size_t o = offs[k], m = offs[k + 1] - offs[k];
-            if (alignmentType >= 3) {
-                // unique best: exactly one hit, otherwise a no-answer record; random best: the first hit (hostKernel, CPUfunctions.cpp:1861-1930)
-                if (m == 0 && enableDP) return;                                   // goes to the DP stage
-                if (m == 0 || (alignmentType == 3 && m > 1)) w.unaligned(rs, first + k);
-                else { al++; w.singleAnswer(rs, first + k, pos[o], strand[o], mis[o]); }
-                return;
-            }
-            if (m) al++;
-            else if (enableDP) return;                                            // goes to the DP stage
-            w.singleEnd(rs, first + k, pos.data() + o, strand.data() + o, mis.data() + o, m, seeds.empty() ? 0u : seeds[k]);
-        }, aligned);
-        if (enableDP) {
+        if (postOn) {
+            // DP on: the post thread fetches and writes this chunk's hits while the next chunk is searched (the search returns with its last kernels still
+            // under way: the wait for them is the post thread's)
+            addChunkSeconds(0, since(tA));
             std::unique_ptr<PairJob> j(new PairJob());
+            j->b = b; j->cnt = cnt; j->hadSeedLengths = !seeds.empty(); j->seeds.swap(seeds);
+            j->rs = std::move(chunk);                                              // (the loop's recycle() gets nothing: the DP stage thread gives the set back)
+            { std::lock_guard<std::mutex> g(postq.mu); postq.q.push_back(std::move(j)); }
+            postq.cv.notify_all();
+            continue;
+        }
+        std::unique_ptr<PairJob> j(enableDP ? new PairJob() : nullptr);
+        std::string e2;
+        if (!finishSingle(b, rs, cnt, seeds, aligned, j ? &j->todo : nullptr, e2)) return dieJoin(e2);
+        if (j) {
             j->b = b; j->cnt = cnt; j->hadSeedLengths = !seeds.empty();
-            for (uint32_t k = 0; k < cnt; k++) if (offs[k + 1] == offs[k]) j->todo.push_back(k);
             j->rs = std::move(chunk);                                              // (the loop's recycle() gets nothing: the worker gives the set back)
             { std::lock_guard<std::mutex> g(dpq.mu); dpq.q.push_back(std::move(j)); }
             dpq.cv.notify_all();
