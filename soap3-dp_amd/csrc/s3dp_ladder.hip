@@ -93,6 +93,7 @@ struct ValidateArgs {
     uint8_t *outPhase;
     uint32_t *outOccCount;
     uint8_t *selFlags;
+    uint32_t *bigList, *bigCount; // slots whose list is longer than S3_VALIDATE_OWN: left to validateBigKernel, one wave per list
 };
 
 // The filter restated so that a list can be shared by a wave.  The reference's loop keeps, in list order, the hits with seed mismatches >= minSeedMis and
@@ -147,11 +148,11 @@ struct TailCompare {
     }
 };
 
-#define S3_VALIDATE_OWN 8u          // lists up to this long stay with their read's lane; longer ones are taken by the whole wave, one after the other
+#define S3_VALIDATE_OWN 8u          // lists up to this long stay with their read's lane; longer ones are taken by a whole wave each (validateBigKernel)
 
 __global__ void validateKernel(ValidateArgs a)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     const bool mine = slot < a.nActive && a.state[slot] == a.want;
     uint32_t r = 0, readLen = 0, seedLen = 0, base = 0, cnt = 0;
     if (mine) {
@@ -161,7 +162,6 @@ __global__ void validateKernel(ValidateArgs a)
         cnt = a.occOffsets[slot + 1] - a.occOffsets[slot];
     }
     const bool extend = mine && readLen > seedLen;
-    int maxMisAll = 0;
     uint32_t out = cnt;
     auto compareOf = [&](uint32_t rr, uint32_t rl, uint32_t sl) {
         TailCompare c;
@@ -173,7 +173,6 @@ __global__ void validateKernel(ValidateArgs a)
         c.maxMis = m;
         return c;
     };
-    (void)maxMisAll;
     if (extend && cnt <= S3_VALIDATE_OWN) {
         const TailCompare c = compareOf(r, readLen, seedLen);
         uint32_t tot[S3_VALIDATE_OWN], best = 0xFFu;
@@ -192,27 +191,59 @@ __global__ void validateKernel(ValidateArgs a)
             out++;
         }
     }
-    unsigned long long big = __ballot(extend && cnt > S3_VALIDATE_OWN);
-    while (big) {
-        const int l = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const uint32_t rr = (uint32_t)__shfl((int)r, l), rl = (uint32_t)__shfl((int)readLen, l), sl = (uint32_t)__shfl((int)seedLen, l);
-        const uint32_t b0 = (uint32_t)__shfl((int)base, l), c0 = (uint32_t)__shfl((int)cnt, l);
-        const TailCompare c = compareOf(rr, rl, sl);
-        uint32_t best = 0xFFu;
-        for (uint32_t k = lane; k < c0; k += 64u) {
-            const uint32_t meta = a.occMeta[b0 + k];
-            const uint32_t t = c.total(a.occPos[b0 + k], meta, a.minSeedMis);
-            a.occMeta[b0 + k] = (meta & 0xFFFFu) | t << 16;
-            best = t < best ? t : best;
+    if (extend && cnt > S3_VALIDATE_OWN) { a.bigList[atomicAdd(a.bigCount, 1u)] = slot; return; }
+    if (!mine) return;
+    if (out > a.maxHit) out = a.maxHit;                                  // origHitLimit, CPUfunctions.cpp:1838
+    a.outOccCount[r] = out;
+    if (out == 0) {
+        a.outPhase[r] = 0;
+        if (a.carryOn) a.selFlags[slot] = 1;
+    }
+}
+
+// the long lists, one wave per list (a wave that kept the long lists of its own 64 reads left the launch waiting for the waves with several
+// thousand-hit reads among theirs: 27 ms per million reads on the repeat-rich genome)
+__global__ void validateBigKernel(ValidateArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u, nBig = *a.bigCount;
+    const uint32_t nWaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nBig; w += nWaves) {
+        const uint32_t slot = a.bigList[w];
+        const uint32_t r = a.active ? a.active[slot] : slot;
+        const uint32_t b0 = a.occBase + a.occOffsets[slot], c0 = a.occOffsets[slot + 1] - a.occOffsets[slot];
+        TailCompare c;
+        c.rd = a.queries + (size_t)(r >> 5) * 32u * a.wpq + (r & 31u);
+        c.text = a.text; c.wpq = a.wpq; c.textLength = a.textLength; c.textWords = (a.textLength + 15u) / 16u;
+        c.readLen = a.lens[r]; c.seedLen = a.seedLens[r]; c.ext = c.readLen - c.seedLen;
+        c.maxMis = (int)ceil(0.02 * (double)c.readLen);                  // MISMATCH_RATIO_FOR_LONG, CPUfunctions.cpp:1819
+        if (a.needMapq) c.maxMis *= 2;
+        // All-valid / all-best reports keep every qualifying hit: one sweep, left as soon as the hit limit is reached -- a read inside a satellite array
+        // comes with millions of seed hits (the search runs without a limit in this mode) of which the first thousand that qualify are the answer.
+        // Best modes need the list's minimum first; that sweep ends early too once the smallest possible total (minSeedMis) has filled the limit.
+        uint32_t best = 0xFFu, kept = 0;
+        if (a.onlyBest) {
+            uint32_t atFloor = 0;
+            for (uint32_t k0 = 0; k0 < c0 && atFloor < a.maxHit; k0 += 64u) {
+                const uint32_t k = k0 + lane;
+                uint32_t t = 0xFFu;
+                if (k < c0) {
+                    const uint32_t meta = a.occMeta[b0 + k];
+                    t = c.total(a.occPos[b0 + k], meta, a.minSeedMis);
+                    a.occMeta[b0 + k] = (meta & 0xFFFFu) | t << 16;
+                }
+                best = t < best ? t : best;
+                atFloor += (uint32_t)__popcll(__ballot((int)t == a.minSeedMis));
+            }
+            for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d); best = o < best ? o : best; }
         }
-        for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d); best = o < best ? o : best; }
-        uint32_t kept = 0;
+        // (best modes: entries behind the point where the first sweep stopped carry no total -- by then `kept` has reached the limit, see above)
         for (uint32_t k0 = 0; k0 < c0 && kept < a.maxHit; k0 += 64u) {
             const uint32_t k = k0 + lane;
-            uint32_t pos = 0, meta = 0xFF0000u;
-            if (k < c0) { pos = a.occPos[b0 + k]; meta = a.occMeta[b0 + k]; }
-            const uint32_t t = meta >> 16;
+            uint32_t pos = 0, meta = 0xFF0000u, t = 0xFFu;
+            if (k < c0) {
+                pos = a.occPos[b0 + k]; meta = a.occMeta[b0 + k];
+                t = a.onlyBest ? meta >> 16 : c.total(pos, meta, a.minSeedMis);
+            }
             const bool keep = t != 0xFFu && (!a.onlyBest || t == best);
             const unsigned long long m = __ballot(keep);
             const uint32_t at = kept + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -224,14 +255,14 @@ __global__ void validateKernel(ValidateArgs a)
             }
             kept += (uint32_t)__popcll(m);
         }
-        if ((int)lane == l) out = kept;
-    }
-    if (!mine) return;
-    if (out > a.maxHit) out = a.maxHit;                                  // origHitLimit, CPUfunctions.cpp:1838
-    a.outOccCount[r] = out;
-    if (out == 0) {
-        a.outPhase[r] = 0;
-        if (a.carryOn) a.selFlags[slot] = 1;
+        if (lane == 0) {
+            if (kept > a.maxHit) kept = a.maxHit;                        // origHitLimit, CPUfunctions.cpp:1838
+            a.outOccCount[r] = kept;
+            if (kept == 0) {
+                a.outPhase[r] = 0;
+                if (a.carryOn) a.selFlags[slot] = 1;
+            }
+        }
     }
 }
 
@@ -277,7 +308,11 @@ int s3i::decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive,
         v.text = b->ix->d.pac; v.textLength = b->ix->d.n;
         v.onlyBest = lg.onlyBest; v.minSeedMis = lg.minSeedMis; v.needMapq = lg.needMapq; v.maxHit = lg.maxHit; v.carryOn = lg.carryOn;
         v.outPhase = b->dPhase; v.outOccCount = b->dOccCount; v.selFlags = b->dSelFlags;
+        v.bigList = b->dLongList; v.bigCount = b->dLongCount;                // (the merge kernels' list of long reads: read for the last time by the decode above)
+        HIPCHK(hipMemsetAsync(b->dLongCount, 0, 4, b->stream));
         hipLaunchKernelGGL(validateKernel, dim3((nActive + 255) / 256), dim3(256), 0, b->stream, v);
+        const unsigned bigBlocks = nActive / 4 + 1 < 4096u ? nActive / 4 + 1 : 4096u;                    // four lists per block at a time
+        hipLaunchKernelGGL(validateBigKernel, dim3(bigBlocks), dim3(256), 0, b->stream, v);
     }
     b->occUsed += added;
     return S3_OK;
