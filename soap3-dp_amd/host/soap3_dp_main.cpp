@@ -549,6 +549,12 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
 }
 
 static int die(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); return 1; }
+// what a user can do about a chunk whose hit lists outgrow the device
+static std::string withHint(const std::string &m)
+{
+    if (m.find("out of memory") == std::string::npos && m.find("2^32") == std::string::npos) return m;
+    return m + "\n(the hit lists of one chunk of reads do not fit: run with fewer reads per chunk -- S3DP_CHUNK_READS=262144 or less -- or a lower hit limit)";
+}
 
 // ---- placement: the calling thread (and every thread it starts afterwards) goes to the CPUs of the host NUMA node(s) the given devices hang off, so that
 // the chunk buffers, the pinned staging buffers and the threads that fill them sit on the device's side of the socket link.  Measured on a two-socket host
@@ -675,7 +681,11 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     // shares the tail of a launch among the lanes of a wave, a small chunk costs no more per read than a large one, and three of them fill the pipeline four times sooner).
     size_t chunkReadsEnv = 0;
     if (const char *e = getenv("S3DP_CHUNK_READS")) chunkReadsEnv = (size_t)strtoull(e, nullptr, 10);
-    const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : (size_t)1 << 20) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
+    // (all valid alignments of reads above 120 bases: the 100-base seeds are searched without a hit limit, a read inside a repeat family brings thousands
+    //  of hits, and four batches of 1 Mi such reads grew past the HBM the index leaves on the 3.1 Gbp repeat-rich genome; a quarter of the chunk is also
+    //  the faster one there: 1.95 s against 2.44 s per 1 Mi reads)
+    const size_t chunkDefault = (alignmentType == 1 && maxReadLength > 120) ? (size_t)1 << 18 : (size_t)1 << 20;
+    const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : chunkDefault) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
     ReadChunker chunker;
     if (readBam ? !chunker.openBam(queryFile, paired, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)
                 : !chunker.open(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)) return die(err);
@@ -724,7 +734,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         return r;
     };
     // (a failure below leaves through exit(): the loader thread must not outlive main's locals silently)
-    auto dieJoin = [&](const std::string &m) -> int { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); return 1; };
+    auto dieJoin = [&](const std::string &m) -> int { fflush(stdout); fprintf(stderr, "%s\n", withHint(m).c_str()); fflush(stderr); _exit(1); return 1; };
     std::unique_ptr<ReadSet> chunk = nextChunk();
     if (!chunk) {
         if (!loaded.err.empty()) return dieJoin(loaded.err);
@@ -1036,7 +1046,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 }
                 std::string e2;
                 const auto tDp = std::chrono::steady_clock::now();
-                auto fatal = [&](const std::string &m) { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); };
+                auto fatal = [&](const std::string &m) { fflush(stdout); fprintf(stderr, "%s\n", withHint(m).c_str()); fflush(stderr); _exit(1); };
                 if (paired) {
                     PairDpCtx c{hix, so, *j->rs, ini, j->b, seedW, dpW, halfW, dpOut, unpairOut, 0u, j->cnt, alignmentType, insertLow, insertHigh, j->routing, j->chunkNo,
                                 j->readBase, halfPar, deepPar, dpPar, newPar};
@@ -1114,7 +1124,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         stageBatches.push_back(nb);
         { std::lock_guard<std::mutex> g(dpq.mu); dpq.freeBatches.push_back(nb); }
         postThread = std::thread([&] {
-            auto fatal = [&](const std::string &m) { fflush(stdout); fprintf(stderr, "%s\n", m.c_str()); fflush(stderr); _exit(1); };
+            auto fatal = [&](const std::string &m) { fflush(stdout); fprintf(stderr, "%s\n", withHint(m).c_str()); fflush(stderr); _exit(1); };
             for (;;) {
                 std::unique_ptr<PairJob> j;
                 {
