@@ -362,7 +362,7 @@ def write_fastq_pairs(reads2d_np, L, path1, path2):
         rec.tofile(path)
 
 
-def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cli=False, both_frac=0.0, resident=True, index_prefix=None):
+def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cli=False, both_frac=0.0, resident=True, index_prefix=None, single_too=False):
     """BASELINE.json configs[2] as far as one GPU and the time budget of a default run go: n_pairs 2 x 150 bp pairs on the benchmark genome,
     `pair -u 500 -v 1`, DP stages ON, end to end through the drop-in command line (the DP stages are driven by its host code), plus the resident BWT
     stage of the same pairs through the library with the oracle check on a sample.  Reports pairs/s, the stages' wall and device times, the BWT stage's
@@ -551,6 +551,28 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
                                         "on a genome that is half repeats a mate inside a repeat family has equally good places elsewhere, so this is a rate, "
                                         "not a pass / fail -- all mates must be reported",
                                   "ok": bool(seen.all())}
+            if single_too:
+                # ---- the first mates alone as single reads in the DEFAULT mode (DP stage on; above 120 bases: 100-base seeds verified on the device) -- the
+                # reference's everyday single-end call, which no other leg runs at this size on this genome (58 s for 10 M reads until the end of round 4)
+                try:
+                    for name in ("out.gout.1", "out.dpout.1", "out.unpair"):
+                        if os.path.exists(os.path.join(work, name)):
+                            os.remove(os.path.join(work, name))
+                    os.sync()
+                    t0 = time.perf_counter()
+                    se = subprocess.run([exe, "single", prefix, f1, "-L", str(L), "-b", "2", "-o", os.path.join(work, "se")], capture_output=True, text=True)
+                    se_wall = time.perf_counter() - t0
+                    if se.returncode != 0:
+                        raise RuntimeError("soap3-dp single failed: " + se.stderr[-500:])
+                    sph = {k: float(v) for k, v in re.findall(r"\[Main\] (Loading time|Read load time|Alignment \+ output time|Total elapsed time) :\s+([0-9.]+)", se.stdout)}
+                    sal = re.search(r"Overall number of reads aligned: (\d+)", se.stdout)
+                    sdp = re.search(r"Number of reads aligned by DP: (\d+)", se.stdout)
+                    s_align = sph.get("Alignment + output time", se_wall)
+                    res["single_default_mode"] = {"reads": n_pairs, "read_len": L, "options": "single -L %d (default mode: BWT stage with 100-base seeds + single-end DP)" % L,
+                                                  "wall_s": se_wall, "phases_s": sph, "M_reads_per_s_reads_in_sam_out": n_pairs / max(s_align, sph.get("Read load time", 0.0)) / 1e6,
+                                                  "reads_aligned": int(sal.group(1)) if sal else None, "reads_aligned_by_dp": int(sdp.group(1)) if sdp else None}
+                except Exception as e:
+                    res["single_default_mode"] = {"error": repr(e)}
         finally:
             if not workdir:
                 shutil.rmtree(work, ignore_errors=True)
@@ -613,7 +635,7 @@ def extras(s3dp, ix, hi, codes, dev, rank, a):
     res["_index_dir"] = shared
     if a.c3_pairs > 0:
         try:
-            res["c3_pairs"], res["_c3_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs, defer_cli=True, index_prefix=os.path.join(shared, "g.index"))
+            res["c3_pairs"], res["_c3_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs, defer_cli=True, index_prefix=os.path.join(shared, "g.index"), single_too=True)
         except Exception as e:
             res["c3_pairs"] = {"error": repr(e)}
         torch.cuda.empty_cache()
