@@ -1086,7 +1086,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     struct { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<PairJob>> q; bool stop = false; } postq;
     std::thread postThread;
     uint64_t postAligned = 0;
-    const bool postOn = pipelinedDp && !skipSoap3 && !(getenv("S3DP_POST_THREAD") && atoi(getenv("S3DP_POST_THREAD")) == 0);
+    const bool postWanted = !skipSoap3 && !(getenv("S3DP_POST_THREAD") && atoi(getenv("S3DP_POST_THREAD")) == 0);
+    // pairs with the DP stages off (-s): no DP stage threads, but the same hand-over -- two batches take turns between the chunk loop (upload, search,
+    // pairing) and the post thread (fetch, format, write), which gives its batch back itself
+    const bool postOnly = postWanted && paired && !enableDP && chunk && chunk->n;
+    const bool postOn = (pipelinedDp && postWanted) || postOnly;
+    if (postOnly) { stageBatches.push_back(b); dpq.freeBatches = stageBatches; }
     // single reads: what follows the search of a chunk -- the hits fetched, the records of the reads that have some formatted and written, the others listed
     // for the DP stage (`todo`, DP on).  Called by the chunk loop, or by the post thread while the loop searches the next chunk.
     auto finishSingle = [&](s3_batch *bb, const ReadSet &rs, uint32_t cnt, const std::vector<uint32_t> &seeds, uint64_t &al, std::vector<uint32_t> *todo, std::string &e) -> bool {
@@ -1148,6 +1153,39 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 std::vector<uint64_t> xoff((size_t)np + 1, 0);
                 std::vector<s3_pair_xa> xa(1);
                 uint64_t nXa = 0;
+                if (!enableDP) {
+                    // DP stages off: the pairs without a proper pairing are written with their ends' own hits
+                    std::vector<uint64_t> ooff((size_t)j->cnt + 1, 0);
+                    uint64_t nOcc = 0;
+                    const auto tF0 = std::chrono::steady_clock::now();
+                    if (s3_batch_fetch_pairs(j->b, pr.data(), xoff.data(), nullptr, 0, &nXa, ooff.data(), nullptr, nullptr, nullptr, 0, &nOcc) != S3_OK) fatal(s3_last_error());
+                    addBatchTiming(j->b);
+                    xa.resize(nXa ? nXa : 1);
+                    std::vector<uint32_t> pos(nOcc ? nOcc : 1);
+                    std::vector<uint8_t> strand(nOcc ? nOcc : 1), mis(nOcc ? nOcc : 1);
+                    if (s3_batch_fetch_pairs(j->b, nullptr, nullptr, xa.data(), xa.size(), nullptr, nullptr, pos.data(), strand.data(), mis.data(), pos.size(), nullptr) != S3_OK)
+                        fatal(s3_last_error());
+                    addChunkSeconds(1, since(tF0));
+                    const auto tW0 = std::chrono::steady_clock::now();
+                    parallelFormat(hix, so, out, np, [&](SamWriter &w, uint32_t p, uint64_t &al) {
+                        const uint32_t r1 = 2 * p, r2 = r1 + 1;
+                        if (pr[p].phase) {
+                            if (!(alignmentType == 3 && pr[p].numMin != 1)) al += 2;
+                            w.properPair(rs, r1, r2, pr[p], xa.data() + xoff[p], (size_t)(xoff[p + 1] - xoff[p]));
+                        } else {
+                            const size_t o1 = ooff[2 * p], n1 = ooff[2 * p + 1] - o1, o2 = ooff[2 * p + 1], n2 = ooff[2 * p + 2] - o2;
+                            w.improperPair(rs, r1, r2, pos.data() + o1, strand.data() + o1, mis.data() + o1, n1, pos.data() + o2, strand.data() + o2, mis.data() + o2, n2,
+                                           ini.maxHitsEachEndForPairing);
+                        }
+                    }, postAligned);
+                    addChunkSeconds(2, since(tW0));
+                    recycle(std::move(j->rs));
+                    s3_batch *back = j->b;
+                    j.reset();
+                    { std::lock_guard<std::mutex> g(dpq.mu); dpq.freeBatches.push_back(back); }
+                    dpq.cv.notify_all();
+                    continue;
+                }
                 const auto tF = std::chrono::steady_clock::now();
                 if (s3_batch_fetch_pairs(j->b, pr.data(), xoff.data(), nullptr, 0, &nXa, nullptr, nullptr, nullptr, nullptr, 0, nullptr) != S3_OK) fatal(s3_last_error());
                 addBatchTiming(j->b);
@@ -1172,7 +1210,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         const uint32_t first = 0, cnt = rs.n;
         totalReads += cnt;
         (void)maxBatch;
-        if (pipelinedDp) {
+        if (pipelinedDp || postOnly) {
             // a batch whose chunk is through its DP stages (or has not been used yet)
             const auto tWt = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> lk(dpq.mu);
@@ -1226,6 +1264,15 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                 const auto tA = std::chrono::steady_clock::now();
                 if (s3_batch_align_pair(b, (uint32_t)numMismatch, ini.maxHitsEachEndForPairing, alignmentType, (uint32_t)insertLow, (uint32_t)insertHigh,
                                         ini.peMaxOutputPerPair) != S3_OK) return dieJoin(s3_last_error());
+                if (postOnly) {
+                    addChunkSeconds(0, since(tA));
+                    std::unique_ptr<PairJob> j(new PairJob());
+                    j->b = b; j->cnt = cnt;
+                    j->rs = std::move(chunk);                                      // (the loop's recycle() gets nothing: the post thread gives the set back)
+                    { std::lock_guard<std::mutex> g(postq.mu); postq.q.push_back(std::move(j)); }
+                    postq.cv.notify_all();
+                    continue;
+                }
                 if (s3_batch_sync(b) != S3_OK) return dieJoin(s3_last_error());
                 addChunkSeconds(0, since(tA));
                 const auto tF = std::chrono::steady_clock::now();
@@ -1296,6 +1343,10 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         postq.cv.notify_all();
         postThread.join();
         aligned += postAligned;
+    }
+    if (postOnly) {
+        b = stageBatches[0];
+        for (size_t k = 1; k < stageBatches.size(); k++) s3_batch_free(stageBatches[k]);
     }
     if (pipelinedDp) {
         { std::lock_guard<std::mutex> g(dpq.mu); dpq.stop = true; }
