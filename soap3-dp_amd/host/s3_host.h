@@ -15,9 +15,21 @@ namespace s3host {
 
 struct Translate { uint32_t startPos, chrID, correction; };
 
+// vector whose resize() leaves new elements uninitialised: the big per-read arrays are sized once and then filled (and, where zeros are part of the
+// content, zeroed) by all host threads, which also spreads the page faults
+template <class T> struct DefaultInit : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInit<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+using BigWords = std::vector<uint32_t, DefaultInit<uint32_t>>;   // file payloads of gigabytes: sized, then filled by all host threads (no zero fill first)
+
 struct HostIndex {
     // search structures (file payloads, headers stripped)
-    std::vector<uint32_t> bwt, occ, rbwt, rocc, sa, pac, lkt, rlkt;
+    BigWords bwt, occ, rbwt, rocc, sa;
+    std::vector<uint32_t> pac, lkt, rlkt;
     uint32_t inverseSa0 = 0, rInverseSa0 = 0, cum[5] = {0, 0, 0, 0, 0}, rcum[5] = {0, 0, 0, 0, 0};
     uint32_t n = 0;
     uint32_t saInterval = 1;                             // SaValueFreq of the .sa file (1: full suffix array)
@@ -37,15 +49,6 @@ bool loadIndex(const std::string &prefix, HostIndex &ix, std::string &err);
 int hostThreads();                                       // S3DP_HOST_THREADS or the hardware concurrency (1..256)
 void buildLookupTable(const std::vector<uint32_t> &pacWords, uint32_t n, bool reversed, std::vector<uint32_t> &table);
 
-// vector whose resize() leaves new elements uninitialised: the big per-read arrays are sized once and then filled (and, where zeros are part of the
-// content, zeroed) by all host threads, which also spreads the page faults
-template <class T> struct DefaultInit : std::allocator<T> {
-    template <class U> struct rebind { using other = DefaultInit<U>; };
-    template <class U, class... A> void construct(U *p, A &&...a)
-    {
-        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
-    }
-};
 template <class T> using RawVec = std::vector<T, DefaultInit<T>>;
 
 struct ReadSet {

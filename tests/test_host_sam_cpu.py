@@ -32,8 +32,8 @@ def tool():
     return TOOL
 
 
-def run(tmp_path, args):
-    out = subprocess.run([tool()] + args + ["-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+def run(tmp_path, args, env=None):
+    out = subprocess.run([tool()] + args + ["-o", "out"], cwd=tmp_path, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     return open(tmp_path / "out.gout.1").read()
 
@@ -50,6 +50,16 @@ def compare(mine, ref):
 def test_single_end_sam(tmp_path, name, maxlen, variant, opts):
     shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), tmp_path / (name + ".fq"))
     text = run(tmp_path, ["single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", str(maxlen)] + opts)
+    compare(sam_records(text), sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_%s.sam.gz" % variant), "rt").read()))
+
+
+def test_index_files_read_in_pieces_by_all_host_threads(tmp_path):
+    """the loader reads an index file's payload at its final place with one pread stream per host thread (64 MiB and more each); here in pieces of 4 KiB on
+    eight threads, so that the fixture's small files are split too: same records as the golden SAM"""
+    name, maxlen, (variant, opts) = "g2", 120, VARIANTS[0]
+    shutil.copy(os.path.join(GOLDEN, name, "reads.fq"), tmp_path / (name + ".fq"))
+    env = dict(os.environ, S3DP_LOAD_PIECE="4096", S3DP_HOST_THREADS="8")
+    text = run(tmp_path, ["single", os.path.join(GOLDEN, name, "index"), name + ".fq", "-L", str(maxlen)] + opts, env=env)
     compare(sam_records(text), sam_records(gzip.open(os.path.join(GOLDEN, name, "sam_%s.sam.gz" % variant), "rt").read()))
 
 
