@@ -496,6 +496,7 @@ extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint3
     HIPCHK(hipStreamSynchronize(b->stream));
     b->n = n;
     b->lastKind = 0;
+    b->sortedIdsValid = false;
     b->uniformLen = n ? readLengths[0] : 0;
     for (uint32_t i = 1; i < n; i++) if (readLengths[i] != readLengths[0]) { b->uniformLen = 0; break; }
     b->fullUniformLen = b->uniformLen;
@@ -516,6 +517,7 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
             HIPCHK(hipStreamSynchronize(b->stream));
         }
         b->longMode = false; b->uniformLen = b->fullUniformLen;
+        b->sortedIdsValid = false;
         return S3_OK;
     }
     const uint32_t n = b->n;
@@ -530,6 +532,7 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
     b->uniformLen = n ? seedLengths[0] : 0;
     for (uint32_t i = 1; i < n; i++) if (seedLengths[i] != seedLengths[0]) { b->uniformLen = 0; break; }
     b->longMode = true;
+    b->sortedIdsValid = false;
     b->lastKind = 0;
     return S3_OK;
 }
@@ -539,6 +542,32 @@ extern "C" int s3_batch_enable_counters(s3_batch *b, int on)
     if (!b) return fail(S3_EINVAL, "null batch");
     if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     b->counting = on != 0;
+    return S3_OK;
+}
+
+// slots (nullptr: 0 .. n-1) ordered by the first 32 characters of their reads; the ordered slots are left in b->dOrderVals[1] (s3dp_unit.hip, "LOCALITY")
+int s3i::orderByReadPrefix(s3_batch *b, const uint32_t *slots, uint32_t n, const uint32_t *active, uint32_t stride, uint32_t words)
+{
+    if (n > b->orderCap) {
+        const size_t cap = (size_t)n + n / 4 + 1024;
+        int rc;
+        b->orderCap = 0;
+        for (int k = 0; k < 2; k++) {
+            if (b->dOrderKeys[k]) { if ((rc = bgrow(b, &b->dOrderKeys[k], cap, 0))) return rc; } else if ((rc = balloc(b, &b->dOrderKeys[k], cap))) return rc;
+            if (b->dOrderVals[k]) { if ((rc = bgrow(b, &b->dOrderVals[k], cap, 0))) return rc; } else if ((rc = balloc(b, &b->dOrderVals[k], cap))) return rc;
+        }
+        b->orderCap = cap;
+    }
+    size_t tb = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dOrderKeys[0], b->dOrderKeys[1], b->dOrderVals[0], b->dOrderVals[1], (int)n, 0, 64, b->stream));
+    if (tb + 256 > b->tempBytes) {
+        int rc = bgrow(b, &b->dTemp, tb + 256, 0);
+        if (rc) { b->tempBytes = 0; return rc; }
+        b->tempBytes = tb + 256;
+    }
+    launchListedKeys(slots, n, active, b->dReadsT, stride, words, b->dOrderKeys[0], b->dOrderVals[0], b->stream);
+    tb = b->tempBytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dTemp, tb, b->dOrderKeys[0], b->dOrderKeys[1], b->dOrderVals[0], b->dOrderVals[1], (int)n, 0, 64, b->stream));
     return S3_OK;
 }
 
@@ -648,6 +677,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             // S3DP_VERBOSE=1 with counters enabled: reads, listed reads, rank queries and milliseconds of every launch of this pass (stderr)
             static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
             unsigned long long rankSeen = counterSnap[0], tripsSeen = counterSnap[6], wavesSeen = counterSnap[9], adoptSeen = counterSnap[8], saSeen = counterSnap[2], ceSeen = counterSnap[3], accSeen = counterSnap[10];
+            unsigned long long dSeen[5] = {counterSnap[11], counterSnap[12], counterSnap[13], counterSnap[14], counterSnap[15]};
             auto lapT = std::chrono::steady_clock::now();
             auto lap = [&](const char *what, uint64_t units) {
                 if (!verbose || !b->counting) return;
@@ -658,6 +688,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                                 "unit kernel: %llu wave trips, %llu frames adopted; %llu suffix-array reads, %llu compare windows, %llu candidates accepted by ceKernel)\n",
                         modelMm, what, (unsigned long long)units, std::chrono::duration<double, std::milli>(now - lapT).count(), c[0] - rankSeen, c[4], c[5], c[6] - tripsSeen, c[7],
                         c[9] - wavesSeen, c[8] - adoptSeen, c[2] - saSeen, c[3] - ceSeen, c[10] - accSeen);
+                if (c[9] - wavesSeen)
+                    fprintf(stderr, "[s3dp]   unit kernel paths: %llu wave trips with a lane in check-and-extend (%llu lane trips), %llu stepping lane trips, %llu lane pops, %llu wave trips that book\n",
+                            c[11] - dSeen[0], c[12] - dSeen[1], c[13] - dSeen[2], c[15] - dSeen[4], c[14] - dSeen[3]);
+                dSeen[0] = c[11]; dSeen[1] = c[12]; dSeen[2] = c[13]; dSeen[3] = c[14]; dSeen[4] = c[15];
                 rankSeen = c[0]; tripsSeen = c[6]; wavesSeen = c[9]; adoptSeen = c[8]; saSeen = c[2]; ceSeen = c[3]; accSeen = c[10]; lapT = now;
                 (void)hipMemsetAsync(b->dCounters + 7, 0, 8, b->stream);
             };
@@ -719,6 +753,12 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                         out.itemCounts = b->dItemCounts;
                     }
                     nCount = (uint32_t)(nStatic - 1);
+                    // family-mates next to each other in the list (s3dp_unit.hip, "LOCALITY"; S3DP_SORT_LISTED=0: the order the first pass listed them in)
+                    if (nHeavy > 1 && envSize("S3DP_SORT_LISTED", 1) != 0) {
+                        int rc = orderByReadPrefix(b, b->dHeavyList, nHeavy, active, 2u * in.wpqLoad, in.wLds);
+                        if (rc) return rc;
+                        launchListedPlace(b->dOrderVals[1], nHeavy, b->dHeavyList, b->dHeavyIndex, b->stream);
+                    }
                     HIPCHK(hipMemsetAsync(b->dItemCounts + nItems, 0, (nStatic - nItems) * 4, b->stream));
                     // the listed reads count per unit from here on
                     launchZeroListedCounts(b->dHeavyList, b->dHeavyCount, nHeavy, (uint32_t)groups, b->dItemCounts, b->stream);

@@ -167,6 +167,10 @@ int launchTrunkPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out
 int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);     // s3dp_unit.hip; returns a hipError_t
 unsigned unitPassMaxWaves(unsigned maxBlocks);                                        // waves of the widest unit-pass grid (sizes SearchOut::unitStack)
 void launchListedReads(const uint32_t *heavyList, const uint32_t *heavyCount, const uint32_t *active, uint32_t *listedRead, uint32_t nHeavy, hipStream_t s);
+// the order of the listed reads (s3dp_unit.hip, "LOCALITY"): keys = the first 32 characters of read active[slots[k]] (slots == nullptr: k), vals = the slot
+void launchListedKeys(const uint32_t *slots, uint32_t n, const uint32_t *active, const uint32_t *readsT, uint32_t stride, uint32_t words, unsigned long long *keys,
+                      uint32_t *vals, hipStream_t s);
+void launchListedPlace(const uint32_t *sortedSlots, uint32_t n, uint32_t *heavyList, uint32_t *heavyIndex, hipStream_t s);
 void launchUnitChains(const SearchOut &out, uint32_t unitBase, uint32_t nUnits, hipStream_t s);
 void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskRange, hipStream_t s);
 int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int

@@ -71,6 +71,8 @@ struct s3_batch {
     uint4 *dUnitStack = nullptr; size_t unitStackWaves = 0;    // depth-first frames of the unit-pass grid
     uint32_t *dChainNext = nullptr; size_t chainCap = 0;       // per unit and per adopted frame: the counter that follows
     uint32_t *dDynOwner = nullptr, *dDynLocal = nullptr, *dDynUsed = nullptr; size_t dynCap = 0;
+    unsigned long long *dOrderKeys[2] = {nullptr, nullptr}; uint32_t *dOrderVals[2] = {nullptr, nullptr}; size_t orderCap = 0;   // sort buffers: order of the listed reads / of the batch
+    uint32_t *dSortedIds = nullptr; bool sortedIdsValid = false; // the batch's reads in the order of their first characters (single-end ladders start from it)
     s3::ScatterDyn scatterDyn{nullptr, nullptr, 0, 0};         // of the last search pass
     uint32_t mergeUnitBase = 0, mergeUnitsPerRead = 0;         // of the last search pass (0: no read was taken apart)
     uint32_t uniformLen = 0;
@@ -215,6 +217,8 @@ size_t envSize(const char *name, size_t dflt);
 // search + order + merge for `nActive` slots (s3dp_api.hip); per-slot results land in dTotalOcc / dWithError / dKept / ...
 int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint32_t modelMm, uint32_t maxOut);
 int checkFlags(s3_batch *b);
+// slots[0, n) (nullptr: 0 .. n-1) in the order of the first 32 characters of the reads behind them, into b->dOrderVals[1] (s3dp_api.hip)
+int orderByReadPrefix(s3_batch *b, const uint32_t *slots, uint32_t n, const uint32_t *active, uint32_t stride, uint32_t words);
 // ladders (s3dp_ladder.hip)
 struct LongArgs { bool on; int onlyBest, minSeedMis, needMapq; uint32_t maxHit; int carryOn; };
 int decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive, uint8_t want, uint8_t phase, uint32_t maxOut, uint8_t selectWhen, const LongArgs &lg);

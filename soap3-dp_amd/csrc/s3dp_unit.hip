@@ -76,6 +76,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     // ---- statistics (COUNT) ----
     uint32_t nRank = 0, nSaL = 0, nCeL = 0, nCutSkip = 0, nCutMid = 0, unitTrips = 0, maxUnitTrips = 0, nAdopt = 0;
     unsigned long long laneTrips = 0, waveTrips = 0;
+    uint32_t dCeWave = 0, dCeLane = 0, dStepLane = 0, dBookWave = 0, dPopLane = 0;     // (COUNT) how often the rare paths run, and for how many lanes
 
     // ---- per-lane state ----
     uint32_t state = U_IDLE;
@@ -489,6 +490,13 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             }
         }
         // ---------- check-and-extend by the lane itself (BGS-HostAlgnmtAlgo2.cpp:86-169: per candidate its suffix-array entry, then the text under the rest of the model, one 64-byte line = 256 characters per trip, compared as ceKernel compares) ----------
+        if constexpr (COUNT) {
+            const unsigned long long cm = __ballot(state == U_CE_SA || state == U_CE_TEXT);
+            dCeWave += cm ? 1u : 0u;
+            dCeLane += (state == U_CE_SA || state == U_CE_TEXT) ? 1u : 0u;
+            dStepLane += state == U_STEP ? 1u : 0u;
+            dPopLane += (doSettle && needPop) || state == U_POPWAIT ? 1u : 0u;
+        }
         if (state == U_CE_SA || state == U_CE_TEXT) {
             bool textHere = state == U_CE_TEXT;                               // the line of this trip belongs to the current candidate
             bool fresh = !textHere;                                           // the current candidate has not been set up yet
@@ -575,6 +583,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         // (the spare word of the trunk states), S3_V2_COUNT_BATCH at a time and when the unit ends.  Everything in sequence order up to and including this
         // unit that adds up to MaxOutputPerRead puts the read's cut behind this unit; the items up to this one adding up to it put it behind the item
         // (s3dp_search_common.h, "the cut") ----------
+        if constexpr (COUNT) dBookWave += __ballot(countPending >= S3_V2_COUNT_BATCH || (state == U_DONE && countPending)) ? 1u : 0u;
         if (countPending >= S3_V2_COUNT_BATCH || (state == U_DONE && countPending)) {
             const uint32_t cnt = countPending, sub = subIdx;
             countPending = 0;
@@ -631,6 +640,11 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             atomicMax(&out.counters[7], (unsigned long long)maxUnitTrips);
             atomicAdd(&out.counters[8], (unsigned long long)nAdopt);
             if (lane == 0) atomicAdd(&out.counters[9], waveTrips);
+            if (lane == 0) atomicAdd(&out.counters[11], (unsigned long long)dCeWave);
+            atomicAdd(&out.counters[12], (unsigned long long)dCeLane);
+            atomicAdd(&out.counters[13], (unsigned long long)dStepLane);
+            if (lane == 0) atomicAdd(&out.counters[14], (unsigned long long)dBookWave);
+            atomicAdd(&out.counters[15], (unsigned long long)dPopLane);
         }
     }
 }
@@ -642,6 +656,33 @@ __global__ void listedReadsKernel(const uint32_t *heavyList, const uint32_t *hea
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const uint32_t slot = heavyList[k];
         listedRead[k] = active ? active[slot] : slot;
+    }
+}
+
+// LOCALITY (round 5).  The first pass lists heavy reads in the order its lanes give up on them: neighbours in the list have nothing in common, so the 64
+// units a wave takes -- consecutive listed reads at one (item, position) -- walk 64 unrelated subtrees: every rank query its own line from HBM, every lane
+// in its own state.  Reads out of the same place of the same repeat family walk nearly the same subtree.  So the list is put in the order of the reads'
+// first 32 characters before the trunk pass: family-mates become neighbours, ask for the same rank lines in the same trip (one request to L2 instead of
+// sixty-four to HBM) and branch the same way.  Units are numbered by (listed read, item, position) and every consumer finds a read through heavyIndex:
+// the order of the list is nobody's business, the records come out where they came out before.
+__global__ void listedKeysKernel(const uint32_t *slots, uint32_t n, const uint32_t *active, const uint32_t *readsT, uint32_t stride, uint32_t words,
+                                 unsigned long long *keys, uint32_t *vals)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t slot = slots ? slots[k] : k;
+        const uint32_t r = active ? active[slot] : slot;
+        const uint32_t *w = readsT + (size_t)r * stride;
+        keys[k] = (unsigned long long)w[0] << 32 | (words > 1u ? w[1] : 0u);
+        vals[k] = slot;
+    }
+}
+
+__global__ void listedPlaceKernel(const uint32_t *sortedSlots, uint32_t n, uint32_t *heavyList, uint32_t *heavyIndex)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t slot = sortedSlots[k];
+        heavyList[k] = slot;
+        heavyIndex[slot] = k;
     }
 }
 
@@ -692,6 +733,21 @@ void launchListedReads(const uint32_t *heavyList, const uint32_t *heavyCount, co
 {
     if (!nHeavy) return;
     hipLaunchKernelGGL(listedReadsKernel, dim3((nHeavy + 255u) / 256u), dim3(256), 0, s, heavyList, heavyCount, active, listedRead);
+}
+
+void launchListedKeys(const uint32_t *slots, uint32_t n, const uint32_t *active, const uint32_t *readsT, uint32_t stride, uint32_t words, unsigned long long *keys,
+                      uint32_t *vals, hipStream_t s)
+{
+    if (!n) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)n + 255u) / 256u, 8192u);
+    hipLaunchKernelGGL(listedKeysKernel, dim3(blocks), dim3(256), 0, s, slots, n, active, readsT, stride, words, keys, vals);
+}
+
+void launchListedPlace(const uint32_t *sortedSlots, uint32_t n, uint32_t *heavyList, uint32_t *heavyIndex, hipStream_t s)
+{
+    if (!n) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)n + 255u) / 256u, 8192u);
+    hipLaunchKernelGGL(listedPlaceKernel, dim3(blocks), dim3(256), 0, s, sortedSlots, n, heavyList, heavyIndex);
 }
 
 void launchUnitChains(const SearchOut &out, uint32_t unitBase, uint32_t nUnits, hipStream_t s)
