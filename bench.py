@@ -362,7 +362,8 @@ def write_fastq_pairs(reads2d_np, L, path1, path2):
         rec.tofile(path)
 
 
-def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cli=False, both_frac=0.0, resident=True, index_prefix=None, single_too=False):
+def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cli=False, both_frac=0.0, resident=True, index_prefix=None, single_too=False,
+           seed_offset=0, device_no=None, host_threads=None, truth=True):
     """BASELINE.json configs[2] as far as one GPU and the time budget of a default run go: n_pairs 2 x 150 bp pairs on the benchmark genome,
     `pair -u 500 -v 1`, DP stages ON, end to end through the drop-in command line (the DP stages are driven by its host code), plus the resident BWT
     stage of the same pairs through the library with the oracle check on a sample.  Reports pairs/s, the stages' wall and device times, the BWT stage's
@@ -377,7 +378,7 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
     res = {"pairs": n_pairs, "read_len": L, "options": "pair -L 150 -u 500 -v 1 (default mode: BWT ladder + default / new default / deep / single-end DP)",
            "mixture": "insert N(350, 40) in [151, 500]; 0-4 substitutions per mate (55/25/12/5/3 %); 10 % of the mates carry a 1-8 base indel" +
                       ("; %.0f %% of the PAIRS damaged in both mates (an indel or 5-8 substitutions each): deep DP (BASELINE.json configs[4])" % (100 * both_frac) if both_frac > 0 else "")}
-    reads2d, tpos, tstrand, tindel, tboth = make_pairs_c3(codes, n_pairs, L, 31337 if both_frac == 0 else 31338, dev, both_frac=both_frac)
+    reads2d, tpos, tstrand, tindel, tboth = make_pairs_c3(codes, n_pairs, L, (31337 if both_frac == 0 else 31338) + seed_offset, dev, both_frac=both_frac)
     wpq = s3dp.word_per_query(L)
     n_res = min(n_pairs, 1 << 20) if resident else 0
     q = pack_on_device(reads2d[:2 * n_res], wpq) if n_res else None
@@ -489,7 +490,10 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
             import torch
             torch.cuda.empty_cache()
             t0 = time.perf_counter()
-            out = subprocess.run([exe, "pair", prefix, f1, f2, "-L", str(L), "-u", "500", "-v", "1", "-b", "2", "-o", os.path.join(work, "out")], capture_output=True, text=True)
+            # (a rank of an N > 1 run: its own device, its share of the host's threads -- one process per GPU, SOAP3-DP.cu:219-220)
+            cli_env = dict(os.environ, S3DP_HOST_THREADS=str(host_threads)) if host_threads else None
+            out = subprocess.run([exe, "pair", prefix, f1, f2, "-L", str(L), "-u", "500", "-v", "1", "-b", "2", "-o", os.path.join(work, "out")] +
+                                 (["-c", str(device_no)] if device_no is not None else []), capture_output=True, text=True, env=cli_env)
             wall = time.perf_counter() - t0
             if out.returncode != 0:
                 raise RuntimeError("soap3-dp pair failed: " + out.stderr[-500:])
@@ -518,6 +522,8 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
             if ltc:
                 e2e["lookup_chars"] = int(ltc.group(1))
             res["end_to_end"] = e2e
+            if not truth:
+                return res
             # ---- truth check of the three SAM files: where did every mate land? ----
             import pandas as pd
             seen = np.zeros(2 * n_pairs, dtype=bool)
@@ -621,6 +627,75 @@ def se150_leg(s3dp, ix, hi, codes, dev, n_reads):
                 "options": "single -L 150 -s 4 -h 2 (DP off), same substitution mixture as the headline"}
     finally:
         b.close()
+
+
+def granted_cpus():
+    """CPUs this process may use: the hardware's, cut to the control group's quota and to the affinity mask"""
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def c4_leg(s3dp, hi, codes, dev, local, rank, world, dist, a, index_prefix, coll_dev):
+    """BASELINE.json configs[3] on N GPUs of one node: every rank takes its own shard of a.c4_pairs 2 x 150 bp pairs (own seed) through the drop-in command
+    line on ITS device -- one process per GPU over its shard, the reference's model (SOAP3-DP.cu:219-220, README.md:523-536) --, index replicated, host
+    threads divided by the number of ranks; the ranks start together (barrier), the job's time is the slowest rank's, its counts are the sums of the shards'
+    (`[Main] Number of pairs ...`, SOAP3-DP.cu:816-830), reduced over RCCL."""
+    from s3dp import dist as sd
+    import torch
+    threads = max(2, granted_cpus() // world)
+    share = os.environ.get("S3DP_BENCH_SHARE_GPU") == "1"
+    err, leg, cli = None, {}, None
+    try:                                                                # (a rank that fails must still reach the barrier and the collectives below)
+        leg, cli = c3_leg(s3dp, None, hi, codes, dev, a.c4_pairs, defer_cli=True, resident=False, index_prefix=index_prefix, seed_offset=7919 * (rank + 1),
+                          device_no=0 if share else local, host_threads=threads, truth=(rank == 0))
+    except Exception as e:
+        err = repr(e)
+    torch.cuda.empty_cache()
+    dist.barrier()
+    t0 = time.perf_counter()
+    try:
+        if cli is not None:
+            cli()
+    except Exception as e:
+        err = repr(e)
+    wall = time.perf_counter() - t0
+    e2e = leg.get("end_to_end") or {}
+    if "error" in e2e:
+        err = e2e["error"]
+    align_s = (e2e.get("phases_s") or {}).get("Alignment + output time", 0.0) if not err else 0.0
+    counts = dict((e2e.get("counts") or {})) if not err else {}
+    mine = {"pairs": a.c4_pairs if not err else 0, "failed": 1 if err else 0,
+            "aligned_reads": counts.get("Overall number of reads aligned", 0), "pairs_default_dp": counts.get("Number of pairs aligned by DP", 0),
+            "pairs_new_default_dp": counts.get("Number of pairs aligned by new default DP", 0), "pairs_deep_dp": counts.get("Number of pairs aligned by deep DP", 0),
+            "pairs_left": counts.get("Pairs left without a proper pairing", 0), "align_ms": int(align_s * 1e3), "wall_ms": int(wall * 1e3)}
+    sums, per_rank = sd.sum_dict_over_ranks(mine, device=coll_dev)
+    slowest = sd.max_over_ranks(align_s, device=coll_dev)
+    slowest_wall = sd.max_over_ranks(wall, device=coll_dev)
+    if rank != 0:
+        return None
+    res = {"pairs_per_gpu": a.c4_pairs, "gpus": world, "host_threads_per_rank": threads, "options": leg.get("options"), "mixture": leg.get("mixture"),
+           "what": "every rank: its own shard through `soap3-dp pair ... -c <its device>` (FASTQ in, three SAM files out, every DP stage on), started together; "
+                   "seconds = the slowest rank's alignment + output time (index load apart, as in the C3 leg); counts = sums over the ranks",
+           "end_to_end": {"phases_s": {"Alignment + output time": slowest, "Loading time": (e2e.get("phases_s") or {}).get("Loading time")}, "wall_s": slowest_wall,
+                          "M_pairs_per_s_reads_in_sam_out": sums["pairs"] / slowest / 1e6 if slowest > 0 else 0.0,
+                          "counts": {k: v for k, v in sums.items() if k not in ("align_ms", "wall_ms")},
+                          "per_device": [{"M_pairs_per_s": r["pairs"] / (r["align_ms"] / 1e3) / 1e6 if r["align_ms"] else 0.0, **r} for r in per_rank],
+                          "counts_sum_equals_sum_of_shards": all(sums[k] == sum(r[k] for r in per_rank) for k in sums),
+                          "rank0": {k: e2e.get(k) for k in ("device_ms", "dp", "chunk_loop_s", "dp_stage_seconds", "lookup_chars")}},
+           "truth_check": dict(leg.get("truth_check") or {}, of="rank 0's shard")}
+    if sums["failed"]:
+        res["end_to_end"]["error"] = "%d rank(s) failed: %s" % (sums["failed"], err)
+    return res
 
 
 def extras(s3dp, ix, hi, codes, dev, rank, a):
@@ -1059,6 +1134,7 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     b.align_single_allbest(a.mismatch, a.max_out)
     b.sync()
     cnt = b.counters()
+    kcnt = b.kernel_stats()                     # the same tallies per kernel (first pass, trunk pass, unit pass, check-and-extend)
     phase, werr, offs, pos, strand, mis = b.fetch_alignments()
     aligned = int((phase > 0).sum())
     n_occ = int(offs[-1])
@@ -1072,10 +1148,13 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     t0 = time.perf_counter()
     search_ms = ce_ms = dev_ms = 0.0
     launches = 0
+    kms = {k: 0.0 for k in ("first", "trunk", "unit", "ce")}
     for _ in range(a.steps):
         b.align_single_allbest(a.mismatch, a.max_out)
         b.sync()
         tot_ms, s_ms, k = b.timing()        # HIP events on the batch stream
+        for name, st in b.kernel_stats().items():
+            kms[name] += st["ms"]
         search_ms += s_ms
         dev_ms += tot_ms
         ce_ms += b.ce_timing()[0]
@@ -1156,6 +1235,27 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
         traffic = None
     n_launch = max(1, launches // max(1, a.steps))
     peak = HBM_PEAK_GBS
+    # per kernel: what IT issued (counted pass), its own duration (HIP events around its launches, timed steps), its fetched bytes (the committed
+    # FETCH_SIZE pass, split by kernel name) -- so that the dominant kernel's fraction can be recomputed from this line alone
+    per_kernel, traffic_roles = {}, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            for w in json.load(f)["workloads"]:
+                if traffic is not None and w.get("repeat_frac") == repeat_frac and w.get("reads_per_gpu") == a.reads:
+                    traffic_roles = w.get("per_role")
+    except (OSError, ValueError, KeyError):
+        traffic_roles = None
+    for name in ("first", "trunk", "unit", "ce"):
+        kc, ms = kcnt[name], kms[name] / max(1, a.steps)
+        b8d = 32.0 * kc["rankQueries"] + (a.reads * (4.0 * wpq + 4.0) if name == "first" else 0.0)
+        bext = b8d + 16.0 * kc["ltLookups"] + 4.0 * kc["saReads"] + 16.0 * kc["ceWindows"]
+        fetched = traffic_roles[name]["bytes"] if traffic_roles and name in traffic_roles else None
+        per_kernel[name] = {"ms_per_step": ms, "launches_per_step": kc["launches"], "rank_queries": kc["rankQueries"], "lt_lookups": kc["ltLookups"],
+                            "sa_reads": kc["saReads"], "ce_windows": kc["ceWindows"], "algorithmic_bytes": b8d, "algorithmic_bytes_extended": bext,
+                            "achieved_GBps": b8d / ms / 1e6 if ms > 0 else 0.0, "frac": b8d / ms / 1e6 / peak if ms > 0 else 0.0,
+                            "frac_extended": bext / ms / 1e6 / peak if ms > 0 else 0.0, "fetched_bytes": fetched,
+                            "fetched_GBps": fetched / ms / 1e6 if fetched and ms > 0 else None,
+                            "fetched_Glines_per_s": fetched / 64.0 / ms / 1e6 if fetched and ms > 0 else None}
     traffic_commit = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -1184,7 +1284,14 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
             "rank_queries_algorithmic_is": ("min(what the timed kernels issued, what the kernels issue when they walk every read like the CPU path: "
                                             "one device pass over all reads, counted)") if walk is not None and walk["usable"] else
                                            "min(what the kernels issued, the CPU restatement's count scaled from its sample)",
-            "walk_mode_pass": walk}
+            "walk_mode_pass": walk,
+            "per_kernel": per_kernel,
+            "per_kernel_is": "first = s3::firstKernel (first pass), trunk = s3::firstKernel (trunk-pass role), unit = s3::unitKernel, ce = s3::ceKernel; counts: what the kernel "
+                             "issued in the counted pass; algorithmic_bytes = 32 B x its rank queries (+ the packed reads for the first pass), SURVEY.md 8d without the hit "
+                             "term (12 B x reported occurrences belong to the whole pass); _extended adds 16 B per lookup entry, 4 B per suffix-array entry, 16 B per "
+                             "32-character compare window (all of ceKernel's work); ms = HIP events around the kernel's own launches, mean over the timed steps; "
+                             "fetched_bytes = FETCH_SIZE of its dispatches in the committed rocprofv3 pass (profiles/pmc_traffic.json)",
+            "dominant_kernel": max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])}
     if traffic:
         # the path is made of random accesses with 4-32 B payloads; the GPU moves 64 B per access (tools/hbm_probe.py), so the rate of fetched
         # 64-byte lines against the probe measured in this run is what tells how busy the memory system is
@@ -1217,7 +1324,7 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
             raise SystemExit("bench.py: truth check failed (%s): %r" % (label, out["truth_check"]))
     if not a.streaming:
         b.close()
-    return out, dict(ix=ix, hi=hi, codes=codes, q=q, lens=lens, wpq=wpq)
+    return out, dict(ix=ix, hi=hi, codes=codes, q=q, lens=lens, wpq=wpq, prefix=prefix)
 
 
 def launch_ranks(a):
@@ -1284,6 +1391,65 @@ def launch_selftest_rank(a):
     return 0
 
 
+def summary_of(out):
+    """the figures a reader of the stored tail needs: headline, per-kernel roofline of the dominant kernel, C3 / C5 legs, robustness legs"""
+    def g(d, *path, default=None):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+    roof = out.get("roofline", {})
+    pk = roof.get("per_kernel") or {}
+    sm = {"headline_M_reads_per_s": out.get("value"), "ms_per_step": out.get("ms_per_step"), "n_gpus": out.get("n_gpus"), "roofline_frac": roof.get("frac"),
+          "per_kernel": {k: {f: v.get(f) for f in ("ms_per_step", "rank_queries", "sa_reads", "ce_windows", "algorithmic_bytes", "fetched_bytes", "frac")} for k, v in pk.items()}}
+    lines = ["headline: %.2f M reads/s, %.1f ms per step, roofline.frac %.4f (8d bytes over the search kernels' time)" %
+             (out.get("value") or 0.0, out.get("ms_per_step") or 0.0, roof.get("frac") or 0.0)]
+    if pk:
+        lines.append("per kernel (ms per step | rank queries | 8d bytes | fetched bytes | frac of 8 TB/s): " + "; ".join(
+            "%s %.1f | %.3g | %.3g | %s | %.3f" % (k, v["ms_per_step"], v["rank_queries"], v["algorithmic_bytes"],
+                                                    ("%.3g" % v["fetched_bytes"]) if v.get("fetched_bytes") else "-", v["frac"]) for k, v in pk.items()))
+    ex = out.get("extras") if isinstance(out.get("extras"), dict) else {}
+    for key, tag in (("c3_pairs", "C3"), ("c5_pairs", "C5"), ("c4_pairs", "C4")):
+        leg = ex.get(key)
+        if not isinstance(leg, dict):
+            continue
+        e2e = leg.get("end_to_end") or {}
+        if "error" in leg or "error" in e2e or not e2e:
+            lines.append("%s: %s" % (tag, (leg.get("error") or e2e.get("error") or "no end-to-end figure")[:200]))
+            continue
+        pairs = g(leg, "truth_check", "pairs", default=0) or 0
+        secs = g(e2e, "phases_s", "Alignment + output time", default=e2e.get("wall_s"))
+        rec = {"pairs": pairs, "seconds": secs, "M_pairs_per_s": e2e.get("M_pairs_per_s_reads_in_sam_out"), "loading_s": g(e2e, "phases_s", "Loading time"),
+               "bwt_stage_frac": g(leg, "bwt_stage_resident", "roofline", "frac"), "dp_GCUPS": g(e2e, "dp", "GCUPS"), "dp_isolated_GCUPS": g(leg, "dp_isolated", "GCUPS"),
+               "device_ms": e2e.get("device_ms"), "counts": e2e.get("counts"),
+               "both_mates_at_simulated_place": g(leg, "truth_check", "pairs_with_both_mates_at_simulated_place")}
+        if "per_device" in e2e:
+            rec["per_device"] = e2e["per_device"]
+        sm[key] = rec
+        lines.append("%s: %d pairs %.2f s = %.2f M pairs/s (FASTQ in, SAM out; index load %.2f s apart), BWT frac %s, DP %s GCUPS in the run%s" %
+                     (tag, pairs, secs or 0.0, rec["M_pairs_per_s"] or 0.0, rec["loading_s"] or 0.0,
+                      ("%.3f" % rec["bwt_stage_frac"]) if rec["bwt_stage_frac"] else "-", ("%.0f" % rec["dp_GCUPS"]) if rec["dp_GCUPS"] else "-",
+                      (", %.0f isolated" % rec["dp_isolated_GCUPS"]) if rec["dp_isolated_GCUPS"] else ""))
+        sd = leg.get("single_default_mode")
+        if isinstance(sd, dict) and "M_reads_per_s_reads_in_sam_out" in sd:
+            sm[key + "_single_default_mode"] = {"reads": sd["reads"], "M_reads_per_s": sd["M_reads_per_s_reads_in_sam_out"], "wall_s": sd["wall_s"]}
+            lines.append("%s first mates, single -L %d default mode: %.2f M reads/s FASTQ in, SAM out" % (tag, sd["read_len"], sd["M_reads_per_s_reads_in_sam_out"]))
+    for model, r in (ex.get("repeat_models") or {}).items():
+        if isinstance(r, dict) and "M_reads_per_s" in r:
+            sm.setdefault("repeat_models", {})[model] = {"M_reads_per_s": r["M_reads_per_s"], "ms_per_step": r["ms_per_step"]}
+            lines.append("repeat model %s: %.2f M reads/s (%.1f ms per step)" % (model, r["M_reads_per_s"], r["ms_per_step"]))
+    u = ex.get("uniform_genome")
+    if isinstance(u, dict) and "value" in u:
+        sm["uniform_genome_M_reads_per_s"] = u["value"]
+        lines.append("uniform genome: %.1f M reads/s" % u["value"])
+    st = out.get("streamed")
+    if isinstance(st, dict):
+        sm["streamed_vs_resident"] = {"4Mi_x3": st.get("vs_resident"), "1Mi_x6": g(st, "batches_of_1Mi", "vs_resident")}
+    sm["lines"] = ["[summary] " + ln for ln in lines]
+    return sm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1307,7 +1473,8 @@ def main():
     ap.add_argument("--index-dir", default=None, help="keep / reuse the index files of the benchmark genome in this directory")
     ap.add_argument("--build-only", type=int, default=0, help="stop after the index files are written (with --index-dir)")
     ap.add_argument("--c3-pairs", type=int, default=10_000_000, help="extras: BASELINE.json configs[2] -- 2 x 150 bp pairs through the command line with the DP stages on (0: skip)")
-    ap.add_argument("--c5-pairs", type=int, default=2_000_000, help="extras: configs[4]'s mixture (5 %% of the pairs damaged in both mates: deep DP) through the command line (0: skip)")
+    ap.add_argument("--c5-pairs", type=int, default=10_000_000, help="extras: configs[4]'s mixture (5 %% of the pairs damaged in both mates: deep DP) through the command line (0: skip)")
+    ap.add_argument("--c4-pairs", type=int, default=10_000_000, help="N > 1: BASELINE.json configs[3] -- pairs PER GPU, every rank's shard through the command line on its own device (0: skip)")
     ap.add_argument("--se150-reads", type=int, default=2_000_000, help="extras: 150 bp single-end reads, kernel-only rate (0: skip)")
     ap.add_argument("--exact-rank", type=int, default=1, help="count the reference algorithm's rank queries on this input with one walk-mode device pass")
     ap.add_argument("--robustness", default="young", help="extras: comma-separated repeat models (young, old, satellite-heavy) run at --robustness-reads reads each ('' = none)")
@@ -1378,8 +1545,20 @@ def main():
             except Exception as e:                                      # secondary figures must never cost the headline line
                 out["extras"] = {"error": repr(e)}
     keep["ix"].close()
-    keep.clear()
     import gc
+    if world > 1 and a.c4_pairs > 0 and keep.get("prefix"):
+        # the paired workload on N GPUs (BASELINE.json configs[3]): every rank's shard through the command line on its own device, after the ranks have freed
+        # their resident indexes (the children bring their own)
+        keep.pop("q", None)
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            c4 = c4_leg(s3dp, keep["hi"], keep["codes"], dev, local, rank, world, dist, a, keep["prefix"], COLL_DEV[0] if COLL_DEV else dev)
+        except Exception as e:
+            c4 = {"error": repr(e)}
+        if rank == 0:
+            out.setdefault("extras", {})["c4_pairs"] = c4
+    keep.clear()
     gc.collect()
     torch.cuda.empty_cache()
     ex = out.get("extras") if isinstance(out.get("extras"), dict) else {}
@@ -1428,6 +1607,11 @@ def main():
             torch.cuda.empty_cache()
     if rank == 0:
         out["wall_s_total"] = time.perf_counter() - t_all
+        # The line is tens of kilobytes; whoever stores only its tail (and the tail of stderr) must still find the round's figures: a compact summary as the
+        # LAST key of the line, and the same as the last lines of stderr.
+        out["summary"] = summary_of(out)
+        for ln in out["summary"]["lines"]:
+            log(ln)
         print(json.dumps(out), flush=True)
     if index_dir and rank == 0:
         import shutil

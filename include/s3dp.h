@@ -351,6 +351,12 @@ int  s3_batch_last_timing(s3_batch *b, float *totalMs, float *searchMs, uint32_t
  * is kept inside the search kernel, S3DP_CE=inline) */
 int  s3_batch_last_ce_timing(s3_batch *b, float *ceMs, uint32_t *ceLaunches);
 int  s3_batch_counters(s3_batch *b, s3_counters *out);      /* device-side tallies of the last call (if enabled) */
+/* The same per KERNEL of the search passes of the last call -- out[0] first pass (s3::firstKernel), out[1] trunk pass (s3::firstKernel, trunk role), out[2] unit
+ * pass (s3::unitKernel), out[3] check-and-extend (s3::ceKernel) -- with each kernel's device time from HIP events around its launches on the batch's stream, so
+ * that a kernel's algorithmic bytes (32 B per rank query ...) can be priced against ITS duration (bench.py roofline.per_kernel).  Measurement
+ * aid; no counterpart in the reference (its kernels are timed by the CUDA profiler). */
+typedef struct { float ms; uint32_t launches; uint64_t rankQueries, ltLookups, saReads, ceWindows; } s3_kernel_stats;
+int  s3_batch_kernel_stats(s3_batch *b, s3_kernel_stats out[4]);
 int  s3_batch_enable_counters(s3_batch *b, int on);
 
 /* one-shot convenience (host in, host out), mirrors the call shape of perform_round1_alignment:

@@ -51,7 +51,13 @@ hipError_t s3i::scratchAlloc(void **p, size_t bytes, hipStream_t stream)
         }
     }
     if (got.p) {
-        if (got.done && got.lastStream != stream && (e = hipStreamWaitEvent(stream, got.done, 0)) != hipSuccess) return e;
+        if (got.done && got.lastStream != stream && (e = hipStreamWaitEvent(stream, got.done, 0)) != hipSuccess) {
+            // the block is in no list at this point: back to the cache as it was (its event still stands for its last use), not lost
+            std::lock_guard<std::mutex> g(g_scratch.mu);
+            g_scratch.freeBlocks.push_back(got);
+            g_scratch.cachedBytes[dev] += want;
+            return e;
+        }
     } else {
         if ((e = hipMalloc(&got.p, want)) != hipSuccess) {
             s3i::scratchTrim(dev);                              // the cache may hold what is missing
@@ -428,7 +434,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
     BA(dRecs, recCap); BA(dOrdered, recCap); BA(dOrdValid, recCap); b->ordCap = recCap;
-    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, S3_NUM_COUNTERS); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
+    BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, S3_COUNTER_WORDS); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
     BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4); BA(dTrunk, 16); b->trunkCap = 16; BA(dItemAcc, 16); b->accCap = 16;
@@ -456,11 +462,12 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     b->tempBytes = (t1 > t2 ? t1 : t2) + 256;
     if ((rc = balloc(b, &b->dTemp, b->tempBytes))) { s3_batch_free(b); return rc; }
     HIPB(hipEventCreate(&b->evTotal[0])); HIPB(hipEventCreate(&b->evTotal[1]));
-    b->evSearch.assign(256, nullptr);
+    b->evSearch.assign(512, nullptr);
+    b->evSearchRole.assign(256, 0);
     for (auto &e : b->evSearch) HIPB(hipEventCreate(&e));
     b->evCe.assign(256, nullptr);
     for (auto &e : b->evCe) HIPB(hipEventCreate(&e));
-    HIPB(hipMemsetAsync(b->dCounters, 0, S3_NUM_COUNTERS * 8, b->stream));
+    HIPB(hipMemsetAsync(b->dCounters, 0, S3_COUNTER_WORDS * 8, b->stream));
     HIPB(hipStreamSynchronize(b->stream));
 #undef HIPB
     *outp = b;
@@ -609,10 +616,11 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.adoptIdle = (uint32_t)envSize("S3DP_ADOPT_IDLE", S3_UNIT_ADOPT_IDLE);
     in.ceInlineMax = (uint32_t)envSize("S3DP_CE_INLINE_MAX", 128);
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
-    unsigned long long counterSnap[S3_NUM_COUNTERS] = {};
+    unsigned long long counterSnapAll[S3_COUNTER_WORDS] = {}, counterSnap[S3_NUM_COUNTERS] = {};   // per kernel role; summed over the roles
     if (b->counting) {
-        HIPCHK(hipMemcpyAsync(counterSnap, b->dCounters, S3_NUM_COUNTERS * 8, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipMemcpyAsync(counterSnapAll, b->dCounters, S3_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
+        for (int r = 0; r < S3_NUM_ROLES; r++) for (int k = 0; k < S3_NUM_COUNTERS; k++) counterSnap[k] += counterSnapAll[r * S3_NUM_COUNTERS + k];
     }
     // S3DP_HEAVY=0 switches the second pass off (every read is walked by one lane: same results; reads in repeat families then hold the launch up);
     // n > 1: list a read once it has reserved more than n candidates (default 2048); S3DP_HEAVY_RANK: ... or cost more than that many rank queries
@@ -662,13 +670,17 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         b->scatterDyn = ScatterDyn{nullptr, nullptr, 0, 0};
         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
         // timing: one event pair per group of stepping launches / per check-and-extend launch (they alternate when the second pass runs in rounds)
-        auto mark = [&](std::vector<hipEvent_t> &ev, uint32_t &used, bool begin) -> hipError_t {
+        // (role: which kernel the pair brackets -- 0 first pass, 1 trunk pass, 2 unit pass, 3 check-and-extend: s3_batch_kernel_stats)
+        auto mark = [&](std::vector<hipEvent_t> &ev, uint32_t &used, bool begin, uint8_t role) -> hipError_t {
             if ((size_t)used * 2 + 1 >= ev.size()) return hipSuccess;
             const hipError_t e = hipEventRecord(ev[used * 2 + (begin ? 0 : 1)], b->stream);
+            if (&ev == &b->evSearch) b->evSearchRole[used] = role;
             if (!begin) used++;
             return e;
         };
-        HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
+        auto countersOf = [&](int role) { return b->counting ? b->dCounters + role * S3_NUM_COUNTERS : nullptr; };
+        out.counters = countersOf(0);
+        HIPCHK(mark(b->evSearch, b->evSearchUsed, true, 0));
         {
             // persistent grid: what is resident at once (4 blocks per CU), or less when several batches share the device (the streamed form: a
             // narrower grid per batch lets the kernels of two batches run side by side and fill each other's tails)
@@ -681,8 +693,9 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             auto lapT = std::chrono::steady_clock::now();
             auto lap = [&](const char *what, uint64_t units) {
                 if (!verbose || !b->counting) return;
-                unsigned long long c[S3_NUM_COUNTERS] = {};
-                (void)d2h(c, b->dCounters, S3_NUM_COUNTERS * 8, b->stream);
+                unsigned long long call[S3_COUNTER_WORDS] = {}, c[S3_NUM_COUNTERS] = {};
+                (void)d2h(call, b->dCounters, S3_COUNTER_WORDS * 8, b->stream);
+                for (int r = 0; r < S3_NUM_ROLES; r++) for (int k = 0; k < S3_NUM_COUNTERS; k++) c[k] += call[r * S3_NUM_COUNTERS + k];
                 const auto now = std::chrono::steady_clock::now();
                 fprintf(stderr, "[s3dp] search mm=%u %-12s %10llu units %8.2f ms %12llu rank queries (second pass so far: cut %llu + %llu units, %llu lane trips, longest unit %llu trips; "
                                 "unit kernel: %llu wave trips, %llu frames adopted; %llu suffix-array reads, %llu compare windows, %llu candidates accepted by ceKernel)\n",
@@ -693,7 +706,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                             c[11] - dSeen[0], c[12] - dSeen[1], c[13] - dSeen[2], c[15] - dSeen[4], c[14] - dSeen[3]);
                 dSeen[0] = c[11]; dSeen[1] = c[12]; dSeen[2] = c[13]; dSeen[3] = c[14]; dSeen[4] = c[15];
                 rankSeen = c[0]; tripsSeen = c[6]; wavesSeen = c[9]; adoptSeen = c[8]; saSeen = c[2]; ceSeen = c[3]; accSeen = c[10]; lapT = now;
-                (void)hipMemsetAsync(b->dCounters + 7, 0, 8, b->stream);
+                for (int r = 0; r < S3_NUM_ROLES; r++) (void)hipMemsetAsync(b->dCounters + r * S3_NUM_COUNTERS + 7, 0, 8, b->stream);
             };
             if (verbose && b->counting) { (void)hipStreamSynchronize(b->stream); lapT = std::chrono::steady_clock::now(); }
             // the depth-first stacks of the first-pass and unit-pass kernels: a ring of frames per lane of the widest grid
@@ -710,13 +723,14 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             hipError_t le = (hipError_t)launchFirstPass(b->ix->d, in, out, 256u * blocksFirst, b->stream);
             if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel: cannot raise the dynamic LDS limit: ") + hipGetErrorString(le));
             lap("first pass", nActive);
-            HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
+            HIPCHK(mark(b->evSearch, b->evSearchUsed, false, 0));
             // check-and-extend takes the task records written since its last launch: dTaskRange = {first, end}; what it accepts is appended behind them
             auto checkExtend = [&]() -> int {
                 HIPCHK(hipMemcpyAsync(b->dTaskRange + 1, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
-                HIPCHK(mark(b->evCe, b->evCeUsed, true));
+                HIPCHK(mark(b->evCe, b->evCeUsed, true, 3));
+                out.counters = countersOf(3);
                 launchCheckExtend(b->ix->d, in, out, b->dTaskRange, b->stream);
-                HIPCHK(mark(b->evCe, b->evCeUsed, false));
+                HIPCHK(mark(b->evCe, b->evCeUsed, false, 3));
                 HIPCHK(hipMemcpyAsync(b->dTaskRange, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
                 return S3_OK;
             };
@@ -784,7 +798,6 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     in2.slotList = b->dHeavyList; in2.slotCount = b->dHeavyCount; in2.heavyLimit = 0xFFFFFFFFu; in2.heavyRank = 0xFFFFFFFFu;
                     in2.unitsPerItem = U; in2.unitBase = (uint32_t)nItems;
                     in.unitsPerItem = U; in.unitBase = (uint32_t)nItems;       // (the scatter decodes unit indices with them)
-                    HIPCHK(mark(b->evSearch, b->evSearchUsed, true));
                     {
                         // the listed reads' numbers in readsT (trunk pass and unit pass)
                         int rc;
@@ -818,16 +831,18 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     for (uint32_t mode = 1; mode <= (U > 1 ? 2u : 1u); mode++) {   // trunk pass, then unit pass
                         in2.unitMode = mode;
                         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
+                        out.counters = countersOf((int)mode);
+                        HIPCHK(mark(b->evSearch, b->evSearchUsed, true, (uint8_t)mode));
                         if (mode == 2u) le = (hipError_t)launchUnitPass(b->ix->d, in2, out, 256u * blocksUnit, b->stream);
                         else le = (hipError_t)launchTrunkPass(b->ix->d, in2, out, 256u * blocksFirst, b->stream);
                         if (le != hipSuccess) return fail(S3_EHIP, std::string("search kernel (second pass): ") + hipGetErrorString(le));
+                        HIPCHK(mark(b->evSearch, b->evSearchUsed, false, (uint8_t)mode));
                         lap(mode == 1 ? "trunk pass" : "unit pass", (uint64_t)nHeavy * groups * (mode == 1 ? 1 : U));
                     }
                     // the counters of adopted frames become part of their units' totals before anything is scanned (check-and-extend fills reserved
                     // sequence numbers: it changes no count)
                     if (newUnitPass && dynCap) launchUnitChains(out, (uint32_t)nItems, (uint32_t)((size_t)nHeavy * groups * U), b->stream);
                     b->scatterDyn = ScatterDyn{b->dDynOwner, b->dDynLocal, out.dynBase, out.dynCap};
-                    HIPCHK(mark(b->evSearch, b->evSearchUsed, false));
                 }
             }
             {
@@ -862,7 +877,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         if (rc) return rc;
         flags &= ~S3_FLAG_REC_OVERFLOW;
         HIPCHK(hipMemcpyAsync(b->dFlags, &flags, 4, hipMemcpyHostToDevice, b->stream));
-        if (b->counting) HIPCHK(hipMemcpyAsync(b->dCounters, counterSnap, S3_NUM_COUNTERS * 8, hipMemcpyHostToDevice, b->stream));
+        if (b->counting) HIPCHK(hipMemcpyAsync(b->dCounters, counterSnapAll, S3_COUNTER_WORDS * 8, hipMemcpyHostToDevice, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     b->searchLaunches++;
@@ -920,7 +935,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     b->searchLaunches = 0; b->evSearchUsed = 0; b->evCeUsed = 0;
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
-    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_NUM_COUNTERS * 8, b->stream));
+    if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_COUNTER_WORDS * 8, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
     int rc = searchPass(b, nullptr, b->n, numMismatch, maxOutputPerRead);
     if (rc) return rc;
@@ -1011,14 +1026,47 @@ extern "C" int s3_batch_last_ce_timing(s3_batch *b, float *ceMs, uint32_t *ceLau
     return S3_OK;
 }
 
+// per kernel of the search passes of the last call: its device time (HIP events around its launches) and, with counters enabled, its own tallies
+extern "C" int s3_batch_kernel_stats(s3_batch *b, s3_kernel_stats *out)
+{
+    if (!b || !out || b->lastKind == 0) return fail(S3_EINVAL, "s3_batch_kernel_stats: no timed call");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int r = 0; r < S3_NUM_ROLES; r++) out[r] = s3_kernel_stats{};
+    uint32_t timed = b->evSearchUsed;
+    if (timed * 2 > b->evSearch.size()) timed = (uint32_t)(b->evSearch.size() / 2);
+    for (uint32_t i = 0; i < timed; i++) {
+        float x = 0;
+        HIPCHK(hipEventElapsedTime(&x, b->evSearch[2 * i], b->evSearch[2 * i + 1]));
+        const int r = b->evSearchRole[i] < 3 ? b->evSearchRole[i] : 0;
+        out[r].ms += x; out[r].launches++;
+    }
+    timed = b->evCeUsed;
+    if (timed * 2 > b->evCe.size()) timed = (uint32_t)(b->evCe.size() / 2);
+    for (uint32_t i = 0; i < timed; i++) {
+        float x = 0;
+        HIPCHK(hipEventElapsedTime(&x, b->evCe[2 * i], b->evCe[2 * i + 1]));
+        out[3].ms += x; out[3].launches++;
+    }
+    unsigned long long call[S3_COUNTER_WORDS] = {0};
+    HIPCHK(d2h(call, b->dCounters, S3_COUNTER_WORDS * 8, b->stream));
+    for (int r = 0; r < S3_NUM_ROLES; r++) {
+        const unsigned long long *c = call + r * S3_NUM_COUNTERS;
+        out[r].rankQueries = c[0]; out[r].ltLookups = c[1]; out[r].saReads = c[2]; out[r].ceWindows = c[3];
+    }
+    return S3_OK;
+}
+
 extern "C" int s3_batch_counters(s3_batch *b, s3_counters *out)
 {
     if (!b || !out) return fail(S3_EINVAL, "null argument");
     if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
     HIPCHK(hipSetDevice(b->ix->dev));
-    unsigned long long c[8] = {0};
+    unsigned long long call[S3_COUNTER_WORDS] = {0}, c[8] = {0};
     HIPCHK(hipStreamSynchronize(b->stream));
-    HIPCHK(d2h(c, b->dCounters, 64, b->stream));
+    HIPCHK(d2h(call, b->dCounters, S3_COUNTER_WORDS * 8, b->stream));
+    for (int r = 0; r < S3_NUM_ROLES; r++) for (int k = 0; k < 8; k++) c[k] += call[r * S3_NUM_COUNTERS + k];
     out->rankQueries = c[0]; out->ltLookups = c[1]; out->saReads = c[2]; out->ceWindows = c[3];
     out->records = b->recordsTotal;
     return S3_OK;

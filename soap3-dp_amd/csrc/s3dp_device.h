@@ -16,7 +16,9 @@
 #define S3_UNIT_RDY_BYTES 1536u            // LDS per wave of the unit pass for its tested units (6 words x 64)
 #define S3_UNIT_ADOPT_IDLE 32u             // idle lanes of a wave before frames are adopted
 #define S3_UNIT_NODE_BLOCK 256u           // sub-unit counters a wave of the unit pass reserves with one atomic
-#define S3_NUM_COUNTERS 16                 // 64-bit tallies of a batch (SearchOut::counters)
+#define S3_NUM_COUNTERS 16                 // 64-bit tallies of a kernel (SearchOut::counters)
+#define S3_NUM_ROLES 4                     // ... kept per kernel of a search pass: first pass, trunk pass, unit pass, check-and-extend (s3_batch_kernel_stats)
+#define S3_COUNTER_WORDS (S3_NUM_COUNTERS * S3_NUM_ROLES)
 #define S3_FLAG_STACK_OVERFLOW 1u
 #define S3_FLAG_REC_OVERFLOW   2u
 #define S3_FLAG_OCC_OVERFLOW   4u

@@ -118,6 +118,7 @@ struct s3_batch {
     bool counting = false;
     hipEvent_t evTotal[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> evSearch, evCe;          // per launch of the stepping kernel / of the check-and-extend kernel
+    std::vector<uint8_t> evSearchRole;               // per pair of evSearch: 0 first pass, 1 trunk pass, 2 unit pass
     uint32_t evSearchUsed = 0, evCeUsed = 0;         // event pairs in use
     uint32_t searchLaunches = 0;                     // search passes of the last call
     uint32_t occUsed = 0;

@@ -186,10 +186,11 @@ extern "C" int s3_batch_route_pairs(s3_batch *b, const uint32_t maxHitNum[2], in
     b->hRouteOffs.assign(3 * (size_t)n + 1, 0);
     if (!np) { b->routed = true; return S3_OK; }
     int rc;
-    if (!b->dRouteKept) {
+    if (!b->dRouteTemp) {                                                    // (the LAST buffer of the chain: a chain that failed half-way is tried again, not trusted)
         const size_t m = b->maxReads + 2;
-        if ((rc = balloc(b, &b->dRouteKept, m)) || (rc = balloc(b, &b->dRouteThr, m)) || (rc = balloc(b, &b->dRoute, m)) || (rc = balloc(b, &b->dPairRoute, m / 2 + 1)) ||
-            (rc = balloc(b, &b->dRouteCounts, 3 * m + 1)) || (rc = balloc(b, &b->dRouteOffs, 3 * m + 1))) return rc;
+        if ((!b->dRouteKept && (rc = balloc(b, &b->dRouteKept, m))) || (!b->dRouteThr && (rc = balloc(b, &b->dRouteThr, m))) || (!b->dRoute && (rc = balloc(b, &b->dRoute, m))) ||
+            (!b->dPairRoute && (rc = balloc(b, &b->dPairRoute, m / 2 + 1))) || (!b->dRouteCounts && (rc = balloc(b, &b->dRouteCounts, 3 * m + 1))) ||
+            (!b->dRouteOffs && (rc = balloc(b, &b->dRouteOffs, 3 * m + 1)))) return rc;
         size_t tb = 0;
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, b->dRouteCounts, b->dRouteOffs, (int)(3 * m + 1), b->stream));
         if ((rc = balloc(b, &b->dRouteTemp, tb + 16))) return rc;

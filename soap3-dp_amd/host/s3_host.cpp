@@ -13,6 +13,7 @@
 #include <sys/stat.h>
 #include <algorithm>
 #include <atomic>
+#include <sched.h>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -240,7 +241,12 @@ static int cpuAllowance()
 
 int hostThreads()
 {
-    static const int allowed = cpuAllowance();
+    static const int quota = cpuAllowance();
+    // ... and to the CPUs the thread may run on NOW: the command line binds itself to the device's NUMA node after its first calls here, and a run under
+    // taskset starts narrowed -- threads beyond the affinity mask only take turns
+    int allowed = quota;
+    cpu_set_t have;
+    if (sched_getaffinity(0, sizeof have, &have) == 0) { const int c = CPU_COUNT(&have); if (c >= 1 && c < allowed) allowed = c; }
     const char *e = getenv("S3DP_HOST_THREADS");
     int t = e && *e ? atoi(e) : allowed;
     if (t < 1) t = 1;

@@ -773,7 +773,8 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     // a second thread because the stages were host work then (routing of the hit lists: on the device since round 4) and the box grants sixteen CPUs.
     // With two threads the records of different chunks reach .dpout / .unpair in the order the threads finish (the reference's own output threads write
     // in no fixed order either, SOAP3-DP.cu:251-258): the SET of records is the result; S3DP_DP_THREADS=1 gives a reproducible file order.
-    const int nDpWorkers = getenv("S3DP_DP_THREADS") && atoi(getenv("S3DP_DP_THREADS")) == 1 ? 1 : 2;
+    // (S3DP_DUMP_ROUTING, the tests' routing dump, is appended chunk by chunk by the stage thread: one thread, or chunk 1 could write before chunk 0 truncates the file)
+    const int nDpWorkers = (getenv("S3DP_DP_THREADS") && atoi(getenv("S3DP_DP_THREADS")) == 1) || getenv("S3DP_DUMP_ROUTING") ? 1 : 2;
     struct PreDp { s3_dp *dp[kDpWorkers] = {nullptr, nullptr}, *dpHalf[kDpWorkers] = {nullptr, nullptr}; std::string err; };
     const std::vector<int> &dpDevices = shared.loaded ? shared.devices : devices;
     std::vector<PreDp> preDp(dpDevices.size());

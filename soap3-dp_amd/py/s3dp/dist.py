@@ -36,6 +36,22 @@ def reduce_counters(counters, device=None):
     return {k: int(v) for k, v in zip(COUNTER_KEYS, vec.tolist())}
 
 
+def sum_dict_over_ranks(d, device=None):
+    """sum a dict of integers over all ranks, and gather every rank's own values: returns (sums, per_rank list of dicts).  The paired leg of bench.py:
+    every rank's command line reports its shard's counts (the `[Main] Number of pairs ...` lines, SOAP3-DP.cu:816-830); the job's are their sums."""
+    import torch
+    import torch.distributed as dist
+    keys = sorted(d)
+    vec = torch.tensor([int(d[k]) for k in keys], dtype=torch.int64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return dict(d), [dict(d)]
+    ws = dist.get_world_size()
+    parts = [torch.zeros_like(vec) for _ in range(ws)]
+    dist.all_gather(parts, vec)
+    dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    return {k: int(v) for k, v in zip(keys, vec.tolist())}, [{k: int(v) for k, v in zip(keys, p.tolist())} for p in parts]
+
+
 def max_over_ranks(x, device=None):
     import torch
     import torch.distributed as dist

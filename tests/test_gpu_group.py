@@ -142,7 +142,8 @@ def test_bench_py_starts_two_ranks_itself():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genome-bp", "60000000", "--reads", "200000", "--steps", "2", "--warmup", "1",
-                          "--cpu-budget", "0", "--check", "256", "--exact-rank", "0", "--stream-batch", "65536", "--extras", "0", "--uniform", "0", "--robustness", ""],
+                          "--cpu-budget", "0", "--check", "256", "--exact-rank", "0", "--stream-batch", "65536", "--extras", "0", "--uniform", "0", "--robustness", "",
+                          "--c4-pairs", "40000"],
                          capture_output=True, text=True, env=env, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.split("\n") if l.strip()]
@@ -152,6 +153,16 @@ def test_bench_py_starts_two_ranks_itself():
     assert res["aligned_reads"] == 400000                              # both shards, summed by the all-reduce
     assert res["truth_check"]["ok"] and res["oracle_check"]["bit_exact"]
     assert res["streamed"]["same_results_as_resident"]
+    # the paired leg of an N > 1 run (BASELINE configs[3]): every rank's shard through the command line, counts summed over the ranks
+    c4 = res["extras"]["c4_pairs"]
+    e2e = c4["end_to_end"]
+    assert "error" not in e2e, e2e
+    assert c4["gpus"] == 2 and e2e["counts"]["pairs"] == 80000 and e2e["counts"]["failed"] == 0
+    assert len(e2e["per_device"]) == 2 and all(r["pairs"] == 40000 and r["aligned_reads"] > 70000 for r in e2e["per_device"])
+    assert e2e["counts_sum_equals_sum_of_shards"] and e2e["counts"]["aligned_reads"] == sum(r["aligned_reads"] for r in e2e["per_device"])
+    assert e2e["per_device"][0]["aligned_reads"] != e2e["per_device"][1]["aligned_reads"]          # (own shards: own seeds)
+    assert e2e["M_pairs_per_s_reads_in_sam_out"] > 0 and c4["truth_check"]["ok"]
+    assert any(l.startswith("[summary] C4:") for l in res["summary"]["lines"])
 
 
 def test_group_on_two_devices_runs_the_rccl_allreduce():

@@ -28,8 +28,9 @@ phase, werr, offs, pos, strand, mis, st = ix.align_single_allbest(q, lens, wpq, 
 c = {"reads": len(mine), "readsAligned": int((phase > 0).sum()), "alignments": int(offs[-1]), "rankQueries": st.rankQueries, "records": st.hits}
 tot = sd.reduce_counters(c)
 t = sd.max_over_ranks(1.0 + rank)
+sums, per_rank = sd.sum_dict_over_ranks({"pairs": 10 + rank, "aligned_reads": (1 << 40) + 7 * rank, "failed": 0})    # (the paired leg's shard counts)
 if rank == 0:
-    print("RESULT " + json.dumps({"tot": tot, "tmax": t, "lo_hi": [lo, hi]}))
+    print("RESULT " + json.dumps({"tot": tot, "tmax": t, "lo_hi": [lo, hi], "sums": sums, "per_rank": per_rank}))
 dist.destroy_process_group()
 '''
 
@@ -56,6 +57,8 @@ def test_two_ranks_shard_and_reduce(tmp_path):
     assert res["tot"]["alignments"] == int(offs[-1])
     assert res["tot"]["rankQueries"] == st.rankQueries
     assert res["tmax"] == 2.0
+    assert res["sums"] == {"pairs": 21, "aligned_reads": (1 << 41) + 7, "failed": 0}
+    assert res["per_rank"] == [{"pairs": 10, "aligned_reads": 1 << 40, "failed": 0}, {"pairs": 11, "aligned_reads": (1 << 40) + 7, "failed": 0}]
 
 
 def test_shard_bounds_cover_everything_and_keep_pairs():

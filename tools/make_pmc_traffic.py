@@ -10,8 +10,20 @@ import sys
 KERNELS = ("firstKernel", "unitKernel", "ceKernel")
 
 
+def role_of(name):
+    """first / trunk (the two roles of s3::firstKernel: its last template argument) / unit / ce"""
+    if "unitKernel" in name:
+        return "unit"
+    if "ceKernel" in name:
+        return "ce"
+    if "firstKernel" in name:
+        args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name else []
+        return "trunk" if len(args) >= 3 and args[2] == "true" else "first"
+    return None
+
+
 def fetch_of_last_ladder(path):
-    per = collections.OrderedDict()
+    per, roles = collections.OrderedDict(), collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != "FETCH_SIZE":
             continue
@@ -20,12 +32,20 @@ def fetch_of_last_ladder(path):
             continue
         per.setdefault(k, collections.OrderedDict()).setdefault(r["Dispatch_Id"], 0.0)
         per[k][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        ro = role_of(r["Kernel_Name"])
+        roles.setdefault(ro, collections.OrderedDict()).setdefault(r["Dispatch_Id"], 0.0)
+        roles[ro][r["Dispatch_Id"]] += float(r["Counter_Value"])
     out = {}
     for k, d in per.items():
         vals = list(d.values())
         half = vals[len(vals) // 2:]
         out[k] = {"launches": len(half), "bytes": sum(half) * 1024.0}
-    return out
+    by_role = {}
+    for k, d in roles.items():
+        vals = list(d.values())
+        half = vals[len(vals) // 2:]
+        by_role[k] = {"launches": len(half), "bytes": sum(half) * 1024.0}
+    return out, by_role
 
 
 def main():
@@ -33,10 +53,10 @@ def main():
     workloads = []
     for arg in sys.argv[2:]:
         frac, path = arg.split("=", 1)
-        f = fetch_of_last_ladder(path)
+        f, by_role = fetch_of_last_ladder(path)
         workloads.append({"genome_bp": 3100000000, "reads_per_gpu": 10000000, "read_len": 100, "max_mismatch": 4, "max_output_per_read": 1000,
                           "repeat_frac": float(frac), "fetch_bytes_per_step": sum(v["bytes"] for v in f.values()), "launches_per_step": 4,
-                          "per_kernel": f})
+                          "per_kernel": f, "per_role": by_role})
     print(json.dumps({"_comment": "HBM bytes fetched by the search kernels (s3::firstKernel: first pass + trunk pass, s3::unitKernel: unit pass, s3::ceKernel: "
                                   "check-and-extend) in one timed ladder of bench.py, rocprofv3 --pmc FETCH_SIZE in its own pass (KB x 1024; 64-byte requests), "
                                   "default configuration; tools/run_profiles.sh + tools/make_pmc_traffic.py",
