@@ -614,6 +614,9 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0;
     in.ceGiveUp = (uint32_t)envSize("S3DP_CE_GIVE_UP", S3_CE_GIVE_UP);
     in.adoptIdle = (uint32_t)envSize("S3DP_ADOPT_IDLE", S3_UNIT_ADOPT_IDLE);
+    in.takeMin = (uint32_t)envSize("S3DP_TAKE_MIN", S3_UNIT_TAKE_MIN);
+    if (in.takeMin < 1u) in.takeMin = 1u;
+    if (in.takeMin > 64u) in.takeMin = 64u;
     in.ceInlineMax = (uint32_t)envSize("S3DP_CE_INLINE_MAX", 128);
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
     unsigned long long counterSnapAll[S3_COUNTER_WORDS] = {}, counterSnap[S3_NUM_COUNTERS] = {};   // per kernel role; summed over the roles

@@ -348,10 +348,11 @@ extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t
     const uint32_t searchLimit = b->longMode ? 0xFFFFFFFFu : maxOutputPerRead;
     const uint32_t *active = nullptr;
     uint32_t nActive = n;
-    // The ladder starts from the reads in the order of their first 32 characters (S3DP_SORT_READS=0: in input order): the 64 reads a wave of the first pass
-    // takes are then neighbours in sequence space (batches too small to fill the device are left alone) -- family-mates of a repeat walk the same rank lines in the same trips -- and every later phase inherits
-    // the order (the next phase's list is a stable selection).  Results are per read: their order in the output does not change.
-    const size_t sortFrom = envSize("S3DP_SORT_READS", 4096);            // batches of at least this many reads (0: never; 1: always -- the tests)
+    // S3DP_SORT_READS=n: batches of n reads and more start the ladder from the reads in the order of their first 32 characters -- the 64 reads a wave of the
+    // first pass takes are then neighbours in sequence space, family-mates of a repeat walk the same rank lines in the same trips -- and every later phase
+    // inherits the order (the next phase's list is a stable selection).  Results are per read: their order in the output does not change.  OFF by default:
+    // measured on the benchmark genome (profiles/README_r05.md) the first passes fetch a fifth fewer bytes and take the same time.
+    const size_t sortFrom = envSize("S3DP_SORT_READS", 0);               // (0: never; 1: always -- the tests)
     if (sortFrom && n >= sortFrom) {
         if (!b->sortedIdsValid) {
             int rc;

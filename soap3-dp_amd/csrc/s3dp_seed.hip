@@ -93,42 +93,109 @@ __global__ void singleMergeKernel(const uint64_t *keys, uint32_t n, const uint32
 // readLoc + lengthHigh.  The lane at the head of a pair's left run walks it.  out == NULL: count into counts[2 * pairRank + leftIsMate]; else write behind
 // offsets[...].  pairRank = the pair's place in pairFirstReads (ascending), so the candidates come out sorted by the left read, as the reference sorts them.
 struct PairCandDev { uint32_t posLeft, posRight, readIDLeft; };
+#define S3_PAIRMERGE_WAVE 24u       // left runs longer than this are walked by the whole wave of their head lane (S3DP_PAIRMERGE_WAVE; 0xFFFFFFFF: never)
+// A pair whose end sits in a repeat family comes with thousands of positions (the new default DP's given hits: up to the hit limit per end), and the lane at
+// the head of such a run kept 63 lanes and the launch waiting while it made two dependent loads per position.  The sweep is not as serial as it looks: which
+// left positions survive the compression is a chain (the next kept one is the first more than 50 beyond the last kept one) -- solved for 64 sorted
+// positions at a time in registers with a ballot per kept position --, and a kept position's partner is the lower bound of readLoc + lengthLow in the right
+// run (what the never-returning right pointer arrives at), found by every kept lane on its own.  Candidates leave in left order through a ballot prefix.
 __global__ void pairMergeKernel(const uint64_t *keys, uint32_t l0, uint32_t l1, uint32_t r0, uint32_t r1, uint32_t leftIsMate, const uint32_t *readLengths,
-                                const uint32_t *pairFirstReads, uint32_t nPairs, int insertLow, int insertHigh, uint32_t *counts, const uint32_t *offsets, PairCandDev *out)
+                                const uint32_t *pairFirstReads, uint32_t nPairs, int insertLow, int insertHigh, uint32_t waveMin, uint32_t *counts,
+                                const uint32_t *offsets, PairCandDev *out)
 {
-    const uint32_t i = l0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= l1) return;
-    const uint32_t id = (uint32_t)(keys[i] >> 32) & 0x3FFFFFFFu;
-    if (i > l0 && ((uint32_t)(keys[i - 1] >> 32) & 0x3FFFFFFFu) == id) return;
-    // the pair's right run
-    uint32_t lo = r0, hi = r1;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (((uint32_t)(keys[mid] >> 32) & 0x3FFFFFFFu) < id) lo = mid + 1; else hi = mid; }
-    uint32_t rp = lo;
-    if (rp >= r1 || ((uint32_t)(keys[rp] >> 32) & 0x3FFFFFFFu) != id) return;
-    uint32_t a = 0, b = nPairs;
-    while (a < b) { const uint32_t mid = (a + b) >> 1; if (pairFirstReads[mid] < id) a = mid + 1; else b = mid; }
-    const uint32_t slot = 2u * a + leftIsMate;
-    const int readLength = (int)readLengths[id];                                    // readLengths[readID] with the pair's first read, as the reference
-    const int margin = readLength > 100 ? readLength >> 2 : 25;                    // DP2_MARGIN
-    int lengthLow = insertLow - readLength - margin;
-    if (lengthLow < 0) lengthLow = 0;
-    const int lengthHigh = insertHigh - readLength + margin;
-    uint32_t n = 0;
-    const uint32_t at = out ? offsets[slot] : 0u;
-    uint32_t prev = 0;
-    bool first = true;
-    for (uint32_t lp = i; lp < l1 && ((uint32_t)(keys[lp] >> 32) & 0x3FFFFFFFu) == id; lp++) {
-        const uint32_t readLoc = (uint32_t)keys[lp];
-        if (!first && !(prev + 50u < readLoc)) continue;                            // MC_Compress
-        first = false; prev = readLoc;
-        while (rp < r1 && ((uint32_t)(keys[rp] >> 32) & 0x3FFFFFFFu) == id && readLoc + (uint32_t)lengthLow > (uint32_t)keys[rp]) rp++;
-        if (rp >= r1 || ((uint32_t)(keys[rp] >> 32) & 0x3FFFFFFFu) != id) break;   // the right run is used up: nothing pairs with the later left positions either
-        const uint32_t mateLoc = (uint32_t)keys[rp];
-        if (readLoc + (uint32_t)lengthHigh < mateLoc) continue;
-        if (out) out[at + n] = PairCandDev{readLoc, mateLoc, id + leftIsMate};
-        n++;
+    const uint32_t i = l0 + blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    auto idOf = [&](uint32_t k) -> uint32_t { return (uint32_t)(keys[k] >> 32) & 0x3FFFFFFFu; };
+    uint32_t id = 0, rp = 0, slot = 0, at = 0;
+    int lengthLow = 0, lengthHigh = 0;
+    bool head = false;
+    if (i < l1) {
+        id = idOf(i);
+        head = !(i > l0 && idOf(i - 1) == id);
     }
-    if (!out) counts[slot] = n;
+    if (head) {
+        // the pair's right run
+        uint32_t lo = r0, hi = r1;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (idOf(mid) < id) lo = mid + 1; else hi = mid; }
+        rp = lo;
+        head = rp < r1 && idOf(rp) == id;
+    }
+    bool big = false;
+    if (head) {
+        uint32_t a = 0, b = nPairs;
+        while (a < b) { const uint32_t mid = (a + b) >> 1; if (pairFirstReads[mid] < id) a = mid + 1; else b = mid; }
+        slot = 2u * a + leftIsMate;
+        const int readLength = (int)readLengths[id];                                // readLengths[readID] with the pair's first read, as the reference
+        const int margin = readLength > 100 ? readLength >> 2 : 25;                // DP2_MARGIN
+        lengthLow = insertLow - readLength - margin;
+        if (lengthLow < 0) lengthLow = 0;
+        lengthHigh = insertHigh - readLength + margin;
+        at = out ? offsets[slot] : 0u;
+        big = waveMin != 0xFFFFFFFFu && (uint64_t)i + waveMin < l1 && idOf(i + waveMin) == id;
+    }
+    if (head && !big) {
+        uint32_t n = 0, prev = 0;
+        bool first = true;
+        for (uint32_t lp = i; lp < l1 && idOf(lp) == id; lp++) {
+            const uint32_t readLoc = (uint32_t)keys[lp];
+            if (!first && !(prev + 50u < readLoc)) continue;                        // MC_Compress
+            first = false; prev = readLoc;
+            while (rp < r1 && idOf(rp) == id && readLoc + (uint32_t)lengthLow > (uint32_t)keys[rp]) rp++;
+            if (rp >= r1 || idOf(rp) != id) break;                                 // the right run is used up: nothing pairs with the later left positions either
+            const uint32_t mateLoc = (uint32_t)keys[rp];
+            if (readLoc + (uint32_t)lengthHigh < mateLoc) continue;
+            if (out) out[at + n] = PairCandDev{readLoc, mateLoc, id + leftIsMate};
+            n++;
+        }
+        if (!out) counts[slot] = n;
+    }
+    // the long runs of this wave's heads, one after the other, by all of its lanes
+    unsigned long long todo = __ballot(head && big);
+    while (todo) {
+        const int h = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t hId = (uint32_t)__shfl((int)id, h), hI = (uint32_t)__shfl((int)i, h), hAt = (uint32_t)__shfl((int)at, h), hSlot = (uint32_t)__shfl((int)slot, h);
+        const uint32_t hLow = (uint32_t)__shfl(lengthLow, h), hHigh = (uint32_t)__shfl(lengthHigh, h);
+        uint32_t rLo = (uint32_t)__shfl((int)rp, h);
+        // ends of the two runs (upper bounds of the pair's id)
+        uint32_t lo = hI, hi = l1;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (idOf(mid) <= hId) lo = mid + 1; else hi = mid; }
+        const uint32_t lEnd = lo;
+        lo = rLo; hi = r1;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (idOf(mid) <= hId) lo = mid + 1; else hi = mid; }
+        const uint32_t rHi = lo;
+        uint32_t n = 0, prev = 0;
+        bool first = true;
+        for (uint32_t c0 = hI; c0 < lEnd; c0 += 64u) {
+            const uint32_t k = c0 + lane;
+            const bool in = k < lEnd;
+            const uint32_t readLoc = in ? (uint32_t)keys[k] : 0u;
+            // the chain of kept positions inside these 64: the qualifying lanes are a suffix (the positions ascend), its first lane is kept
+            bool kept = false;
+            unsigned long long after = ~0ULL;                                       // lanes behind the last kept one
+            for (;;) {
+                const unsigned long long q = __ballot(in && (first || prev + 50u < readLoc)) & after;
+                if (!q) break;
+                const int w = __ffsll((long long)q) - 1;
+                if ((int)lane == w) kept = true;
+                prev = (uint32_t)__shfl((int)readLoc, w);
+                first = false;
+                after = w == 63 ? 0ULL : ~0ULL << (w + 1);
+            }
+            // the partner: the first right position at or beyond readLoc + lengthLow, if it is not beyond readLoc + lengthHigh
+            uint32_t mateLoc = 0;
+            bool cand = false;
+            if (kept) {
+                uint32_t a = rLo, b = rHi;
+                const uint32_t want = readLoc + hLow;
+                while (a < b) { const uint32_t mid = (a + b) >> 1; if ((uint32_t)keys[mid] < want) a = mid + 1; else b = mid; }
+                if (a < rHi) { mateLoc = (uint32_t)keys[a]; cand = !(readLoc + hHigh < mateLoc); }
+            }
+            const unsigned long long cm = __ballot(cand);
+            if (cand && out) out[hAt + n + (uint32_t)__popcll(cm & ((1ULL << lane) - 1ULL))] = PairCandDev{readLoc, mateLoc, hId + leftIsMate};
+            n += (uint32_t)__popcll(cm);
+        }
+        if (!out && (int)lane == h) counts[hSlot] = n;
+    }
 }
 
 // keys of occurrences given from outside (the new default DP: the BWT stage's hits of one end), in the format of the seed keys
@@ -296,12 +363,13 @@ int s3i::pairMergeOnDevice(s3_batch *b, uint64_t *dKeys, uint32_t nKeys, const s
     PCHK(hipStreamSynchronize(st));
     // runs: [end 0 '+'] [end 0 '-'] [end 1 '+'] [end 1 '-'];  orientation 0: end 0 '+' (left) against end 1 '-' (right);  1: end 1 '+' against end 0 '-'
     const uint32_t runLo[4] = {0, bnd[0], bnd[1], bnd[2]}, runHi[4] = {bnd[0], bnd[1], bnd[2], n};
+    const uint32_t waveMin = (uint32_t)envSize("S3DP_PAIRMERGE_WAVE", S3_PAIRMERGE_WAVE);      // (read per call: the tests switch it)
     auto launch = [&](uint32_t o, const uint32_t *offs, PairCandDev *out) {
         const uint32_t l = o ? 2u : 0u, r = o ? 1u : 3u;
         const uint32_t cnt = runHi[l] - runLo[l];
         if (!cnt || runHi[r] == runLo[r]) return;
         hipLaunchKernelGGL(pairMergeKernel, dim3((cnt + 255) / 256), dim3(256), 0, st, keys, runLo[l], runHi[l], runLo[r], runHi[r], o, b->dLens, dPairs, (uint32_t)nPairs,
-                           insertLow, insertHigh, dCounts, offs, out);
+                           insertLow, insertHigh, waveMin, dCounts, offs, out);
     };
     launch(0, nullptr, nullptr);
     launch(1, nullptr, nullptr);

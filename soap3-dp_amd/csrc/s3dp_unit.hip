@@ -212,13 +212,17 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         }
         // ---------- idle lanes take tested units ----------
         unsigned long long idleMask = __ballot(state == U_IDLE);
-        if (idleMask && rdyTaken < rdyCount) {
+        // (starting units is a divergent path of some two hundred instructions, and two or three lanes of a wave finish a unit on EVERY trip: the idle lanes
+        //  wait until in.takeMin of them can start together -- or nothing else is running, or the queue is empty and waiting would only stretch the tail)
+        if (idleMask && rdyTaken < rdyCount && ((uint32_t)__popcll(idleMask) >= in.takeMin || queueEmpty)) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
             const uint32_t e = rdyTaken + rank, avail = rdyCount - rdyTaken;
             if (state == U_IDLE && rank < avail) {
                 aL = rdy[e]; aR = rdy[64u + e]; pR = rdy[128u + e];          // the trunk state {l, r, rev l}: turned the step's way when the step is known
-                listed = rdy[192u + e]; unitInRead = rdy[256u + e]; aux = rdy[320u + e];
-                const uint32_t sub = unitInRead / U, p = unitInRead - sub * U;
+                listed = rdy[192u + e]; aux = rdy[320u + e];
+                const uint32_t sp_ = rdy[256u + e];                          // item | position << 8 (the division is made once per chunk, where the chunk is tested)
+                const uint32_t sub = sp_ & 0xFFu, p = sp_ >> 8;
+                unitInRead = sub * U + p;
                 const uint32_t cas = sub >> 1;
                 subN = sub | ((in.nStepsPacked >> (3u * cas)) & 7u) << 8;
                 s = (int)((in.sStarPacked >> (3u * cas)) & 7u);
@@ -363,14 +367,17 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         // the queue (wave-uniform branches; what they load is read under the same conditions further down)
         unsigned long long qBase = 0;
         uint4 cTs;
-        uint32_t cCut, cRidx, cListed = 0, cRem = 0;
+        uint32_t cCut, cRidx, cListed = 0, cRem = 0, rem0 = 0;
         bool cIn = false;
         if (stageA && lane == 0) qBase = atomicAdd(out.workHead, (unsigned long long)S3_UNIT_CHUNK);
         if (stageB) {
             const uint32_t slot = pendBase + lane;
             cIn = slot < nSlots;
             const uint32_t slotC = cIn ? slot : 0u;
-            cRem = slotC / nListed;
+            // (a chunk of 64 consecutive slots holds at most two values of slot / nListed: the division is made once, on the chunk's first slot, in scalar registers)
+            rem0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pendBase) / nListed;
+            const uint32_t brk = (rem0 + 1u) * nListed;
+            cRem = rem0 + (slotC >= brk ? 1u : 0u) + (nListed < 64u && slotC >= brk ? (slotC - brk) / nListed : 0u);
             cListed = slotC - cRem * nListed;
             cTs = out.trunkStates[slotC];                                    // tsAt(p) of (item, position) = slot / nListed, read = slot % nListed
             cCut = __hip_atomic_load(out.readCut + cListed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -397,7 +404,10 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (live) {
                 const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
                 rdy[k] = cTs.x; rdy[64u + k] = cTs.y; rdy[128u + k] = cTs.z;
-                rdy[192u + k] = cListed; rdy[256u + k] = cRem; rdy[320u + k] = cRidx;
+                const uint32_t sub0 = rem0 / U;                                  // (scalar: of the chunk's first slot) ...
+                uint32_t cSub = sub0, cP = cRem - sub0 * U;                       // ... corrected per lane: cRem - rem0 is 0 or 1 unless the list is shorter than a chunk
+                while (cP >= U) { cP -= U; cSub++; }
+                rdy[192u + k] = cListed; rdy[256u + k] = cSub | cP << 8; rdy[320u + k] = cRidx;
             }
             rdyCount = (uint32_t)__popcll(lm); rdyTaken = 0;
             basePending = false;

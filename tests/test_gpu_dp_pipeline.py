@@ -89,6 +89,12 @@ CASES = [
     # ... and with two DP stage threads taking the chunks in turns (S3DP_DP_THREADS=2: two sets of aligners, one writer per output file at a time)
     ("g7_h2_chunked_two_dp_threads", "g7", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]),
     ("g7_se_chunked_two_dp_threads", "g7", "se", "single", ("reads_1.fq",), ["-L", "150", "-b", "2"]),
+    # pairEndMerge: every left run walked by the whole wave of its head lane (S3DP_PAIRMERGE_WAVE=0) / every run by its head lane alone (round 5: runs
+    # above 24 positions go to the wave by default); g5 holds the pairs whose ends sit in repeat families above the hit limit (new default DP)
+    ("g7_h2_merge_by_wave", "g7", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]),
+    ("g5_h2_merge_by_wave", "g5", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "100", "-u", "500", "-v", "100", "-b", "2"]),
+    ("g4_h2_merge_by_wave", "g4", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "100", "-u", "500", "-v", "100", "-b", "2"]),
+    ("g5_h2_merge_by_lane", "g5", "h2", "pair", ("reads_1.fq", "reads_2.fq"), ["-L", "100", "-u", "500", "-v", "100", "-b", "2"]),
 ]
 
 
@@ -108,6 +114,10 @@ def test_dp_pipeline_matches_the_reference_engines(tmp_path, case, gdir, tag, mo
     if case.endswith("_two_dp_threads"):
         env["S3DP_DP_THREADS"] = "2"
         env["S3DP_CHUNK_READS"] = "512"
+    if case.endswith("_merge_by_wave"):
+        env["S3DP_PAIRMERGE_WAVE"] = "0"
+    if case.endswith("_merge_by_lane"):
+        env["S3DP_PAIRMERGE_WAVE"] = str(0xFFFFFFFF)
     if case.endswith("_chunked"):
         env["S3DP_CHUNK_READS"] = "1024" if mode == "pair" else "512"
     out = subprocess.run([BIN, mode, os.path.join(GOLDEN, gdir, "index")] + names + opts + ["-o", "out"], cwd=tmp_path, capture_output=True, text=True,
