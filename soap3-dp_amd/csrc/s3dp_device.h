@@ -130,6 +130,7 @@ struct MergeArgs {
     // reads whose slice of the ordered array is longer than S3_MERGE_LONG entries (repeat families: mostly holes of rejected candidates) are listed by
     // mergeCountKernel and walked by a whole wave each (mergeCountLongKernel / decodeLongKernel) instead of one lane
     uint32_t       *longList, *longCount;
+    uint32_t       *dealt;        // optional: the word the waves of a long kernel draw their reads from (zeroed before the launch); nullptr: fixed deal
     // reads the second search pass took apart count their records per unit: their slice of the ordered array starts at
     // itemOffsets[unitBase + heavyIndex[slot] * unitsPerRead] and is unitsPerRead offsets long
     const uint8_t  *heavyFlags;
@@ -137,6 +138,7 @@ struct MergeArgs {
     uint32_t        unitBase, unitsPerRead;
 };
 #define S3_MERGE_LONG 256u
+#define S3_LONG_DEAL_DEFAULT 0            // the long kernels' reads dealt through a counter (S3DP_LONG_DEAL)
 
 // semi-global DP (s3dp_dp.hip)
 // Traceback table of one 64-row chunk with T steps: H as int16, two steps per dword ([step / 2][lane], the even step in the low half), then one bit per

@@ -189,6 +189,19 @@ __device__ __forceinline__ LongTrip loadTripValid(const MergeArgs &a, uint32_t b
     return t;
 }
 
+// Which listed read a wave of the long kernels takes next.  dealt == nullptr: a fixed deal, read waveId + k * nWaves (`strided` is that index).  Otherwise
+// the reads are dealt as the waves come free: ONE lane draws a number from the counter, every lane of the wave gets it (a wave that walks a read of ten
+// thousand slots no longer holds up the reads the fixed deal gave it besides).  Round 4 tried this, saw the ladder hang twice on the GPU box and took it out
+// unexplained; this form is what the explanation (profiles/README_r05.md) leaves standing: the counter is a word of its own per kernel, zeroed on the stream
+// right before the launch that draws from it, and the draw is unconditional for the whole wave (no lane leaves the loop on a number another lane holds).
+__device__ __forceinline__ uint32_t nextLongRead(uint32_t *dealt, uint32_t strided, uint32_t waveId, uint32_t lane)
+{
+    if (!dealt) return strided ? strided : waveId;
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(dealt, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // mergeCountKernel for the listed (long) reads: one wave per read -- the holes of rejected check-and-extend
 // candidates (nine in ten entries of a read inside a repeat family) cost a byte of a coalesced load instead of a turn of a serial loop
 __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
@@ -196,7 +209,7 @@ __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t nLong = *a.longCount, groups = a.nCases * 2u;
-    for (uint32_t idx = waveId; idx < nLong; idx += nWaves) {
+    for (uint32_t idx = nextLongRead(a.dealt, 0, waveId, lane); idx < nLong; idx = nextLongRead(a.dealt, idx + nWaves, waveId, lane)) {
         const uint32_t slot = a.longList[idx];
         uint32_t beg, end;
         readSlice(a, slot, groups, beg, end);
@@ -307,7 +320,7 @@ __global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t nLong = *a.longCount, groups = a.nCases * 2u;
-    for (uint32_t idx = waveId; idx < nLong; idx += nWaves) {
+    for (uint32_t idx = nextLongRead(a.dealt, 0, waveId, lane); idx < nLong; idx = nextLongRead(a.dealt, idx + nWaves, waveId, lane)) {
         const uint32_t slot = a.longList[idx];
         if (a.decodeMask && a.decodeMask[slot] != a.decodeWant) continue;
         uint32_t beg, end;
@@ -569,12 +582,21 @@ void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap,
     hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, valid, heavyFlags, heavyList, groups, unitBase, unitsPerItem, dyn);
 }
 
+// S3DP_LONG_DEAL=1: the long kernels deal their reads through a counter (nextLongRead); 0: fixed deal
+static bool longDealing()
+{
+    const char *e = getenv("S3DP_LONG_DEAL");
+    return e ? atoi(e) != 0 : S3_LONG_DEAL_DEFAULT;
+}
+
 void launchMergeCount(const MergeArgs &a, hipStream_t s)
 {
     if (!a.nActive) return;
-    if (a.longList) (void)hipMemsetAsync(a.longCount, 0, 4, s);
+    if (a.longList) (void)hipMemsetAsync(a.longCount, 0, 8, s);                // the count, and the word mergeCountLongKernel's waves draw their reads from
     hipLaunchKernelGGL(mergeCountKernel, dim3((a.nActive + 127) / 128), dim3(128), 0, s, a);
-    if (a.longList) hipLaunchKernelGGL(mergeCountLongKernel, dim3(2048), dim3(256), 0, s, a);
+    MergeArgs d = a;
+    d.dealt = longDealing() ? a.longCount + 1 : nullptr;
+    if (a.longList) hipLaunchKernelGGL(mergeCountLongKernel, dim3(2048), dim3(256), 0, s, d);
 }
 
 void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s)
@@ -588,7 +610,10 @@ void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOff
 {
     if (!a.nActive) return;
     hipLaunchKernelGGL(decodeKernel, dim3((a.nActive + 127) / 128), dim3(128), 0, s, a, ix, occOffsets, occBase, occCap, occPos, occMeta, flags);
-    if (a.longList) hipLaunchKernelGGL(decodeLongKernel, dim3(2048), dim3(256), 0, s, a, ix, occOffsets, occBase, occCap, occPos, occMeta, flags);
+    MergeArgs d = a;
+    d.dealt = longDealing() && a.longList ? a.longCount + 2 : nullptr;
+    if (d.dealt) (void)hipMemsetAsync(d.dealt, 0, 4, s);                        // (a pass may be decoded more than once: zeroed per launch, not per pass)
+    if (a.longList) hipLaunchKernelGGL(decodeLongKernel, dim3(2048), dim3(256), 0, s, d, ix, occOffsets, occBase, occCap, occPos, occMeta, flags);
 }
 
 void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *withError, uint32_t mm, uint32_t allowSpecial, uint8_t *state,

@@ -1215,7 +1215,10 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             // a batch whose chunk is through its DP stages (or has not been used yet)
             const auto tWt = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> lk(dpq.mu);
-            dpq.cv.wait(lk, [&] { return !dpq.freeBatches.empty(); });
+            // (S3DP_SERIAL=1, a measurement aid: the next chunk's search starts when every earlier chunk is through all of its stages -- one host thread's
+            //  kernels on the device at a time, so that a kernel trace shows each kernel's own duration and not its wait behind another thread's)
+            static const bool serialStages = getenv("S3DP_SERIAL") && atoi(getenv("S3DP_SERIAL")) == 1;
+            dpq.cv.wait(lk, [&] { return serialStages ? dpq.freeBatches.size() == stageBatches.size() : !dpq.freeBatches.empty(); });
             b = dpq.freeBatches.back();
             dpq.freeBatches.pop_back();
             addChunkSeconds(4, since(tWt));

@@ -72,8 +72,9 @@ REF_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 
 
 @pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref/ref_harness is not built (make -f oracle/ref.mk where /root/reference exists)")
-@pytest.mark.parametrize("mode,extra", [("pair", []), ("pair", ["-h", "1"]), ("pair", ["-h", "3"]), ("pair", ["-h", "4", "-p"]), ("single", []), ("single", ["-h", "1", "-p"])],
-                         ids=["pair", "pair_h1", "pair_h3", "pair_h4p", "single", "single_h1p"])
+@pytest.mark.parametrize("mode,extra", [("pair", []), ("pair", ["-h", "1"]), ("pair", ["-h", "3"]), ("pair", ["-h", "4", "-p"]), ("single", []), ("single", ["-h", "1", "-p"]),
+                                        ("pair", ["families"])],
+                         ids=["pair", "pair_h1", "pair_h3", "pair_h4p", "single", "single_h1p", "pair_every_route"])
 def test_dp_stages_equal_the_reference_engines_at_scale(tmp_path, mode, extra):
     """The DP stages ON, against the REFERENCE's own pipeline run at test time: oracle/_ref/ref_harness is the reference's host code (BWT ladder by its CPU twin,
     routing, the DP engines' packers / seeding / merges / decode / OutputBuffer::ready / record writers compiled from /root/reference by oracle/ref.mk; the two DP
@@ -84,7 +85,18 @@ def test_dp_stages_equal_the_reference_engines_at_scale(tmp_path, mode, extra):
     w = tmp_path
     sim = os.path.join(ROOT, "tools", "simulate.py")
     ini = os.path.join(ROOT, "soap3-dp_amd", "host", "soap3-dp.ini")
-    if mode == "pair":
+    families = extra == ["families"]
+    if families:
+        # EVERY route of the DP stages populated (round 5): a 3 Mbp genome with a young family of 600 copies (0.4 % apart) -- an end inside it comes with
+        # hundreds of BWT hits, above the default DP's hit limit: 700 pairs go through the NEW DEFAULT DP (given hits of one end, long merge runs), 9,000
+        # through the default DP, 7,700 through the deep DP, 7,400 ends through the single-end DP; every record of every route against the reference engines
+        extra = []
+        subprocess.check_call([sys.executable, sim, "--genome-len", "3000000", "--chroms", "3", "--n-runs", "4", "--repeats", "16", "--genome-seed", "55", "--fasta", str(w / "g.fa"),
+                               "--family-copies", "600", "--family-len", "700", "--family-div", "0.004",
+                               "--pairs", "30000", "--read-len", "150", "--read-seed", "5", "--fastq", str(w / "r_1.fq"), "--fastq2", str(w / "r_2.fq"),
+                               "--indel-frac", "0.10", "--damaged-frac", "0.05"])
+        files, opts = ["r_1.fq", "r_2.fq"], ["-L", "150", "-u", "500", "-v", "1", "-b", "2"]
+    elif mode == "pair":
         subprocess.check_call([sys.executable, sim, "--genome-len", "2000000", "--chroms", "3", "--n-runs", "4", "--repeats", "16", "--genome-seed", "55", "--fasta", str(w / "g.fa"),
                                "--pairs", "30000", "--read-len", "150", "--read-seed", "5", "--fastq", str(w / "r_1.fq"), "--fastq2", str(w / "r_2.fq"),
                                "--indel-frac", "0.10", "--damaged-frac", "0.05"])
@@ -120,6 +132,14 @@ def test_dp_stages_equal_the_reference_engines_at_scale(tmp_path, mode, extra):
             problems.append("%s: %d of %d reads differ, e.g.\nREF  %s\nMINE %s" % (kind, len(diff), len(rb), rb.get(diff[0]), mb.get(diff[0])))
     assert not problems, "; ".join(problems)
     assert seen >= (60000 if mode == "pair" else 40000)                    # every read has its record in one of the files
+    if families:
+        import re
+        got = {k: int(v) for k, v in re.findall(r"\[Main\] (Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|"
+                                                r"Pairs left without a proper pairing): (\d+)", out.stdout)}
+        want = {k: int(v) for k, v in re.findall(r"\[harness\] (new default DP|default DP|deep DP): \d+ pairs in, (\d+) aligned", ref.stdout + ref.stderr)}
+        assert got["Number of pairs aligned by new default DP"] == want["new default DP"] >= 300, (got, want)
+        assert got["Number of pairs aligned by DP"] == want["default DP"] >= 4000 and got["Number of pairs aligned by deep DP"] == want["deep DP"] >= 1000, (got, want)
+        assert got["Pairs left without a proper pairing"] >= 1000, got
 
 
 @pytest.mark.parametrize("tag,opts", [("s3", ["-s", "3"]), ("h1_s2p", ["-s", "2", "-h", "1", "-p"])])

@@ -15,7 +15,7 @@ for a, b in zip(b"ACGTN", b"TGCAN"):
     COMP[a] = b
 
 
-def make_genome(total_len, n_chrom=3, n_runs=4, seed=1, repeats=0, repeat_len=300):
+def make_genome(total_len, n_chrom=3, n_runs=4, seed=1, repeats=0, repeat_len=300, family_copies=0, family_len=600, family_div=0.02):
     rng = np.random.default_rng(seed)
     lens = np.full(n_chrom, total_len // n_chrom)
     lens[-1] += total_len - lens.sum()
@@ -36,6 +36,18 @@ def make_genome(total_len, n_chrom=3, n_runs=4, seed=1, repeats=0, repeat_len=30
             for p in rng.integers(0, repeat_len, size=nsub):
                 seg2[p] = ALPHA[rng.integers(0, 4)]
             chroms[cj][dst:dst + repeat_len] = seg2
+    # one large family (own generator: genomes made without it stay what they were): family_copies copies of a random unit, every base of a copy replaced
+    # with probability family_div -- reads inside it come with hundreds of hits (the hit limits of the DP stages, the new default DP, long merge runs)
+    if family_copies:
+        frng = np.random.default_rng(seed + 7777)
+        unit = ALPHA[frng.integers(0, 4, size=family_len)].copy()
+        for _c in range(family_copies):
+            cj = frng.integers(0, n_chrom)
+            dst = frng.integers(0, len(chroms[cj]) - family_len)
+            cp = unit.copy()
+            hit = frng.random(family_len) < family_div
+            cp[hit] = ALPHA[frng.integers(0, 4, size=int(hit.sum()))]
+            chroms[cj][dst:dst + family_len] = cp
     # N runs: half long (>=10), half short (<10)
     for k in range(n_runs):
         ci = rng.integers(0, n_chrom)
@@ -182,6 +194,9 @@ def main():
     ap.add_argument("--n-runs", type=int, default=4)
     ap.add_argument("--repeats", type=int, default=0)
     ap.add_argument("--genome-seed", type=int, default=1)
+    ap.add_argument("--family-copies", type=int, default=0, help="plant one large repeat family with this many copies")
+    ap.add_argument("--family-len", type=int, default=600)
+    ap.add_argument("--family-div", type=float, default=0.02, help="per-base divergence of a copy from the family's unit")
     ap.add_argument("--fasta", required=True)
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--read-len", type=int, default=100)
@@ -197,7 +212,7 @@ def main():
     ap.add_argument("--indel-frac", type=float, default=0.0, help="pairs: share with a 1-8 base indel in one mate")
     ap.add_argument("--damaged-frac", type=float, default=0.0, help="pairs: share with an indel or 5-8 substitutions in both mates")
     a = ap.parse_args()
-    chroms = make_genome(a.genome_len, a.chroms, a.n_runs, a.genome_seed, a.repeats)
+    chroms = make_genome(a.genome_len, a.chroms, a.n_runs, a.genome_seed, a.repeats, family_copies=a.family_copies, family_len=a.family_len, family_div=a.family_div)
     write_fasta(a.fasta, chroms)
     if a.reads:
         reads, truth = make_reads(chroms, a.reads, a.read_len, a.read_seed, var_len=a.var_len, **({"mix": tuple(a.mix)} if a.mix else {}))
