@@ -388,9 +388,23 @@ int s3i::growOccurrences(s3_batch *b, uint64_t need)
     int rc;
     if ((rc = bgrow(b, &b->dOccPos, cap, b->occUsed))) return rc;
     if ((rc = bgrow(b, &b->dOccMeta, cap, b->occUsed))) return rc;
+    b->occCap = (uint32_t)cap;
+    return S3_OK;
+}
+
+// the read-ordered copy of the final lists (dOutPos / dOutMeta) is sized by what the ladder KEEPS, not by what its passes decoded on the way: in long-read
+// mode the seed search runs without a hit limit and a read inside a satellite array decodes a hundred times what the verification keeps of it
+int s3i::ensureOutLists(s3_batch *b, uint64_t need)
+{
+    if (need <= b->outCap) return S3_OK;
+    if (need > kMaxEntries) return fail(S3_EOVERFLOW, "occurrence lists overflow at the 32-bit limit");
+    size_t cap = need + need / 4 + 65536;
+    if (cap > kMaxEntries) cap = kMaxEntries;
+    int rc;
+    b->outCap = 0;
     if ((rc = bgrow(b, &b->dOutPos, cap, 0))) return rc;
     if ((rc = bgrow(b, &b->dOutMeta, cap, 0))) return rc;
-    b->occCap = (uint32_t)cap;
+    b->outCap = cap;
     return S3_OK;
 }
 
@@ -447,7 +461,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     BA(dOccOffsets, (size_t)maxReads + 1); BA(dMasked, (size_t)maxReads + 1);
     BA(dOccPos, occCap); BA(dOccMeta, occCap);
     BA(dPhase, maxReads); BA(dFinalWithError, (size_t)maxReads * 8); BA(dOccStart, maxReads); BA(dOccCount, (size_t)maxReads + 1);
-    BA(dOutOffsets, (size_t)maxReads + 1); BA(dOutPos, occCap); BA(dOutMeta, occCap);
+    BA(dOutOffsets, (size_t)maxReads + 1); BA(dOutPos, occCap); BA(dOutMeta, occCap); b->outCap = occCap;
 #undef BA
     // scan / select scratch sized for the largest problem
     size_t t1 = 0, t2 = 0;
@@ -713,7 +727,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             };
             if (verbose && b->counting) { (void)hipStreamSynchronize(b->stream); lapT = std::chrono::steady_clock::now(); }
             // the depth-first stacks of the first-pass and unit-pass kernels: a ring of frames per lane of the widest grid
-            const unsigned blocksFirst = std::min<unsigned>(blocksPerCu, S3_FIRST_WAVES_PER_SIMD), blocksUnit = std::min<unsigned>(blocksPerCu, S3_UNIT_WAVES_PER_SIMD);
+            const unsigned blocksFirst = std::min<unsigned>(blocksPerCu, S3_FIRST_WAVES_PER_SIMD), blocksUnit = blocksPerCuEnv || b->blocksPerCu ? std::min<unsigned>(blocksPerCu, unitWavesPerSimd()) : unitWavesPerSimd();
             {
                 const size_t waves = unitPassMaxWaves(256u * std::max(blocksFirst, blocksUnit));
                 if (waves > b->unitStackWaves) {

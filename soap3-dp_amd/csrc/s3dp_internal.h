@@ -88,7 +88,7 @@ struct s3_batch {
     uint32_t *dOccPos = nullptr, *dOccMeta = nullptr;
     uint8_t  *dPhase = nullptr;
     uint32_t *dFinalWithError = nullptr, *dOccStart = nullptr, *dOccCount = nullptr;
-    uint32_t *dOutOffsets = nullptr, *dOutPos = nullptr, *dOutMeta = nullptr;
+    uint32_t *dOutOffsets = nullptr, *dOutPos = nullptr, *dOutMeta = nullptr; size_t outCap = 0;   // read-ordered final lists (ensureOutLists)
     // paired-end ladder (allocated by the first s3_batch_align_pair)
     bool pairReady = false;
     s3::DevPair  *dPairs = nullptr;
@@ -214,6 +214,7 @@ inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
 static const size_t kMaxEntries = 0xFFFFFF00ull;         // record / occurrence indices are 32 bit
 int growRecords(s3_batch *b);
 int growOccurrences(s3_batch *b, uint64_t need);
+int ensureOutLists(s3_batch *b, uint64_t need);
 size_t envSize(const char *name, size_t dflt);
 // search + order + merge for `nActive` slots (s3dp_api.hip); per-slot results land in dTotalOcc / dWithError / dKept / ...
 int searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint32_t modelMm, uint32_t maxOut);

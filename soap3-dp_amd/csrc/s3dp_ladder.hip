@@ -406,6 +406,13 @@ extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t
     // read-ordered CSR of the occurrences
     size_t tb = b->tempBytes;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dOccCount, b->dOutOffsets, (int)(n + 1), b->stream));
+    {
+        uint32_t kept = 0;
+        HIPCHK(hipMemcpyAsync(&kept, b->dOutOffsets + n, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        int rc = ensureOutLists(b, kept);
+        if (rc) return rc;
+    }
     if (n) hipLaunchKernelGGL(gatherOccKernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, n, b->dOccStart, b->dOutOffsets, b->dOccPos, b->dOccMeta,
                               b->dOutPos, b->dOutMeta);
     HIPCHK(hipEventRecord(b->evTotal[1], b->stream));
@@ -636,6 +643,12 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
     // read-ordered CSR of the occurrence lists of the pairs without a proper pairing, pair-ordered CSR of the XA pairs
     size_t tb = b->tempBytes;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dOccCount, b->dOutOffsets, (int)(n + 1), b->stream));
+    {
+        uint32_t kept = 0;
+        HIPCHK(hipMemcpyAsync(&kept, b->dOutOffsets + n, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if ((rc = ensureOutLists(b, kept))) return rc;
+    }
     if (n) hipLaunchKernelGGL(gatherOccKernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, n, b->dOccStart, b->dOutOffsets, b->dOccPos, b->dOccMeta,
                               b->dOutPos, b->dOutMeta);
     tb = b->tempBytes;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: the paired command line on the 10 M C3 pairs -- plain timings, then under rocprofv3 --kernel-trace --stats with the stages of the chunks
 # SERIALISED (S3DP_SERIAL=1 S3DP_DP_THREADS=1: one host thread's kernels on the device at a time), so that the kernel table shows own durations
+ulimit -c 0
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-r05c}; mkdir -p $O /tmp/s3dp_ix
 timeout 400 python3 bench.py --index-dir /tmp/s3dp_ix --build-only 1 > /dev/null 2> $O/index_build.log; echo "index rc=$?"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5: the single-end command line (FASTQ in, SAM out) on the repeat-rich 3.1 Gbp genome: chunk size x stream depth, results kept in files
+ulimit -c 0
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-r05e}; mkdir -p $O
 W=/tmp/e2e_w; rm -rf $W

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: counters of the search kernels of one bench ladder, each set in its own rocprofv3 pass (no tracing domains beside --pmc); run through gpurun
 #   tools/ladder_pmc.sh <outdir> [env settings, comma separated]
+ulimit -c 0
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-r05p}; mkdir -p $O /tmp/s3dp_ix
 envs=""; [ -n "$2" ] && envs=$(echo "$2" | tr ',' ' ')

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: the ladder with and without the two orderings (listed reads / the batch), per-launch statistics of the counted pass; run through gpurun
 #   tools/r5_ab.sh <outdir> "<env settings A>" "<env settings B>" ...      (each setting list: VAR=val,VAR=val or "base")
+ulimit -c 0
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-r05a}; shift
 mkdir -p $O /tmp/s3dp_ix

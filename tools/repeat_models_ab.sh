@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5: the two orderings on the other repeat models (own genome and index each); run through gpurun:  tools/repeat_models_ab.sh <outdir> model [model ...]
+ulimit -c 0
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-r05m}; shift; mkdir -p $O
 Q="--uniform 0 --extras 0 --streaming 0 --cpu-budget 0 --check 0 --exact-rank 0 --robustness= --cpu-reference 0"
