@@ -266,7 +266,122 @@ __global__ void validateBigKernel(ValidateArgs a)
     }
 }
 
+// ---- long-read mode inside repeats: the decode in slices (round 5) ----------------------------------------------------------------------------------
+// The seed search of long-read mode runs without a hit limit (CPUfunctions.cpp:1655-1656): a read inside a satellite array decodes hundreds of thousands of
+// seed hits of which the verification keeps MaxOutputPerRead.  Decoding a whole pass at once needed 16 bytes per DECODED hit -- 1 Mi such reads beside a
+// 120 GB index ran out of HBM.  Above S3DP_LONG_BUDGET decoded hits (default 2^28) a pass is worked off in slices of slots: a slice's hits are decoded into
+// scratch lists, verified there, and only what is kept moves behind the batch's final lists.
+__global__ void sliceMaskKernel(uint32_t n, uint32_t s0, uint32_t s1, const uint8_t *state, uint8_t want, const uint32_t *occCounts, uint32_t *masked, uint8_t *sliceState)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { masked[i] = 0; return; }
+    const bool in = i >= s0 && i < s1 && state[i] == want;
+    masked[i] = in ? occCounts[i] : 0u;
+    sliceState[i] = in ? want : (uint8_t)0xFF;
+}
+
+__global__ void sliceKeptKernel(uint32_t n, const uint32_t *active, const uint8_t *sliceState, uint8_t want, const uint32_t *outOccCount, uint32_t *kept)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    kept[i] = (i < n && sliceState[i] == want) ? outOccCount[active ? active[i] : i] : 0u;
+}
+
+__global__ void sliceStartsKernel(uint32_t n, const uint32_t *active, const uint8_t *sliceState, uint8_t want, const uint32_t *keptOffsets, uint32_t finalBase, uint32_t *outOccStart)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && sliceState[i] == want) outOccStart[active ? active[i] : i] = finalBase + keptOffsets[i];
+}
+
 // decode + publish the slots whose state == want; the occurrence region is appended at *dOccBase
+
+// (called by decodeAndPublish behind its mask kernel -- which has set the selection flags -- and its count of the pass's hits)
+static int decodeSliced(s3_batch *b, const uint32_t *active, uint32_t nActive, uint8_t want, uint8_t phase, uint32_t maxOut, const LongArgs &lg)
+{
+    const size_t budget = envSize("S3DP_LONG_BUDGET", (size_t)1 << 28);
+    std::vector<uint32_t> counts(nActive);
+    std::vector<uint8_t> state(nActive);
+    HIPCHK(d2h(counts.data(), b->dOccCounts, (size_t)nActive * 4, b->stream));
+    HIPCHK(d2h(state.data(), b->dState, nActive, b->stream));
+    // slices of slots whose decoded hits fit the budget (a read with more than that by itself is a slice of its own)
+    std::vector<std::pair<uint32_t, uint32_t>> slices;
+    uint64_t biggest = 0;
+    for (uint32_t s0 = 0; s0 < nActive;) {
+        uint64_t sum = 0;
+        uint32_t s1 = s0;
+        while (s1 < nActive) {
+            const uint64_t c = state[s1] == want ? counts[s1] : 0u;
+            if (s1 > s0 && sum + c > budget) break;
+            sum += c; s1++;
+        }
+        if (sum >= kMaxEntries) return fail(S3_EOVERFLOW, "a single read with more than 2^32 seed hits (long-read mode)");
+        if (sum) slices.push_back({s0, s1});
+        biggest = std::max(biggest, sum);
+        s0 = s1;
+    }
+    hipStream_t st = b->stream;
+    uint32_t *sPos = nullptr, *sMeta = nullptr, *dKeptCnt = nullptr, *dKeptOff = nullptr, *dBig = nullptr;
+    uint8_t *dSlice = nullptr;
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *p : tmp) scratchFree(p, st); };
+    auto talloc = [&](void **p, size_t bytes) -> int {
+        const hipError_t e = scratchAlloc(p, bytes ? bytes : 16, st);
+        if (e != hipSuccess) { cleanup(); return fail(S3_ENOMEM, std::string("hipMalloc(long-read slices): ") + hipGetErrorString(e)); }
+        tmp.push_back(*p);
+        return S3_OK;
+    };
+    int rc;
+    if ((rc = talloc((void **)&sPos, (size_t)biggest * 4)) || (rc = talloc((void **)&sMeta, (size_t)biggest * 4)) || (rc = talloc((void **)&dKeptCnt, ((size_t)nActive + 1) * 4)) ||
+        (rc = talloc((void **)&dKeptOff, ((size_t)nActive + 1) * 4)) || (rc = talloc((void **)&dBig, ((size_t)nActive + 4) * 4)) || (rc = talloc((void **)&dSlice, (size_t)nActive + 16))) return rc;
+#define LCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    const unsigned g = (nActive + 1 + 255) / 256;
+    // phase and mismatch tallies of the resolved reads (the list starts and counts it writes are replaced slice by slice below)
+    hipLaunchKernelGGL(publishKernel, dim3((nActive + 255) / 256), dim3(256), 0, st, nActive, active, b->dState, want, phase, b->dWithError, b->dOccOffsets, 0u, b->dPhase,
+                       b->dFinalWithError, b->dOccStart, b->dOccCount);
+    for (const auto &sl : slices) {
+        hipLaunchKernelGGL(sliceMaskKernel, dim3(g), dim3(256), 0, st, nActive, sl.first, sl.second, b->dState, want, b->dOccCounts, b->dMasked, dSlice);
+        size_t tb = b->tempBytes;
+        LCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dMasked, b->dOccOffsets, (int)(nActive + 1), st));
+        MergeArgs m{};
+        m.nActive = nActive; m.nCases = b->lastNumCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered; m.valid = b->dOrdValid;
+        m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
+        m.decodeMask = dSlice; m.decodeWant = want;
+        m.longList = b->dLongList; m.longCount = b->dLongCount;
+        m.heavyFlags = b->mergeUnitsPerRead ? b->dHeavyFlags : nullptr; m.heavyIndex = b->dHeavyIndex; m.unitBase = b->mergeUnitBase; m.unitsPerRead = b->mergeUnitsPerRead;
+        launchDecode(m, b->ix->d, b->dOccOffsets, 0u, (uint32_t)biggest, sPos, sMeta, b->dFlags, st);
+        ValidateArgs v{};
+        v.nActive = nActive; v.active = active; v.state = dSlice; v.want = want; v.occOffsets = b->dOccOffsets; v.occBase = 0;
+        v.occPos = sPos; v.occMeta = sMeta; v.queries = b->dQueries; v.wpq = b->wpq; v.lens = b->dLens; v.seedLens = b->dSeedLens;
+        v.text = b->ix->d.pac; v.textLength = b->ix->d.n;
+        v.onlyBest = lg.onlyBest; v.minSeedMis = lg.minSeedMis; v.needMapq = lg.needMapq; v.maxHit = lg.maxHit; v.carryOn = lg.carryOn;
+        v.outPhase = b->dPhase; v.outOccCount = b->dOccCount; v.selFlags = b->dSelFlags;
+        v.bigList = dBig + 4; v.bigCount = dBig;                              // (a list of its own: the merge kernels' list of long reads is read again by the next slice's decode)
+        LCHK(hipMemsetAsync(dBig, 0, 4, st));
+        hipLaunchKernelGGL(validateKernel, dim3((nActive + 255) / 256), dim3(256), 0, st, v);
+        const unsigned bigBlocks = nActive / 4 + 1 < 4096u ? nActive / 4 + 1 : 4096u;
+        hipLaunchKernelGGL(validateBigKernel, dim3(bigBlocks), dim3(256), 0, st, v);
+        // what the verification kept moves behind the batch's final lists
+        hipLaunchKernelGGL(sliceKeptKernel, dim3(g), dim3(256), 0, st, nActive, active, dSlice, want, b->dOccCount, dKeptCnt);
+        tb = b->tempBytes;
+        LCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, dKeptCnt, dKeptOff, (int)(nActive + 1), st));
+        uint32_t kept = 0;
+        LCHK(hipMemcpyAsync(&kept, dKeptOff + nActive, 4, hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));
+        if ((uint64_t)b->occUsed + kept >= kMaxEntries) { cleanup(); return fail(S3_EOVERFLOW, "more than 2^32 occurrences in one batch: use smaller batches or a smaller hit limit"); }
+        if ((uint64_t)b->occUsed + kept > b->occCap && (rc = growOccurrences(b, (uint64_t)b->occUsed + kept))) { cleanup(); return rc; }
+        if (kept)
+            hipLaunchKernelGGL(gatherOccKernel, dim3((nActive + 255) / 256), dim3(256), 0, st, nActive, b->dOccOffsets, dKeptOff, sPos, sMeta, b->dOccPos + b->occUsed,
+                               b->dOccMeta + b->occUsed);
+        hipLaunchKernelGGL(sliceStartsKernel, dim3((nActive + 255) / 256), dim3(256), 0, st, nActive, active, dSlice, want, dKeptOff, b->occUsed, b->dOccStart);
+        b->occUsed += kept;
+    }
+#undef LCHK
+    const hipError_t e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) return fail(S3_EHIP, std::string("long-read slices: ") + hipGetErrorString(e));
+    return S3_OK;
+}
 
 int s3i::decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive, uint8_t want, uint8_t phase, uint32_t maxOut, uint8_t selectWhen,
                             const LongArgs &lg)
@@ -285,6 +400,7 @@ int s3i::decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive,
     HIPCHK(hipMemcpyAsync(&added, b->dOccOffsets + nActive, 4, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipMemcpyAsync(&added64, b->dSum64, 8, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    if (lg.on && added64 > envSize("S3DP_LONG_BUDGET", (size_t)1 << 28)) return decodeSliced(b, active, nActive, want, phase, maxOut, lg);
     if (added64 != added || added64 + b->occUsed >= 0xFFFFFF00ull)
         return fail(S3_EOVERFLOW, "more than 2^32 occurrences in one batch (" + std::to_string(added64 + b->occUsed) + "): use smaller batches or a smaller hit limit");
     if ((uint64_t)b->occUsed + added > b->occCap) {

@@ -235,13 +235,18 @@ def test_long_read_mode_matches_oracle(report_type, mm):
     b.close()
 
 
-@pytest.mark.parametrize("report_type,mm,max_out", [(2, 2, 1000), (1, 2, 1000), (2, 3, 40), (3, 2, 1000), (4, 2, 5)])
-def test_long_read_mode_inside_repeat_families(report_type, mm, max_out):
+@pytest.mark.parametrize("report_type,mm,max_out,budget", [(2, 2, 1000, 0), (1, 2, 1000, 0), (2, 3, 40, 0), (3, 2, 1000, 0), (4, 2, 5, 0),
+                                                          (1, 2, 1000, 700), (2, 3, 40, 5000), (3, 2, 1000, 1), (4, 2, 5, 20000)])
+def test_long_read_mode_inside_repeat_families(monkeypatch, report_type, mm, max_out, budget):
     """150-base reads (-L 150: the first 100 bases searched without a hit limit, the other 50 verified on the device) from a dispersed family of 600
     near-identical copies and a tandem array: the seed lists hold hundreds of hits, which the verification (validateKernel, s3dp_ladder.hip) shares
     among the lanes of a wave; lists of up to eight hits stay with one lane.  What is kept, its order, the shift of reverse hits to the read's leftmost
     base, the cut at the hit limit and the best modes' "fewest mismatches only" must equal the reference's serial filter (validateAlignments,
     CPUfunctions.cpp:1129-1222) -- at a hit limit above and below the list lengths, and with reads hanging over both ends of the text."""
+    if budget:
+        # round 5: a pass that decodes more seed hits than S3DP_LONG_BUDGET works them off in slices of reads (scratch lists, only the kept hits stay): at
+        # 700 / 5000 / 20000 hits per slice, and with every read a slice of its own, nothing may change
+        monkeypatch.setenv("S3DP_LONG_BUDGET", str(budget))
     rng = np.random.default_rng(78)
     n, L = 300_000, 150
     codes = rng.integers(0, 4, size=n, dtype=np.uint8)
