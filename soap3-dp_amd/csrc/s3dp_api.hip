@@ -727,7 +727,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             };
             if (verbose && b->counting) { (void)hipStreamSynchronize(b->stream); lapT = std::chrono::steady_clock::now(); }
             // the depth-first stacks of the first-pass and unit-pass kernels: a ring of frames per lane of the widest grid
-            const unsigned blocksFirst = std::min<unsigned>(blocksPerCu, S3_FIRST_WAVES_PER_SIMD), blocksUnit = blocksPerCuEnv || b->blocksPerCu ? std::min<unsigned>(blocksPerCu, unitWavesPerSimd()) : unitWavesPerSimd();
+            const unsigned blocksFirst = std::min<unsigned>(blocksPerCu, S3_FIRST_WAVES_PER_SIMD), blocksUnit = std::min<unsigned>(blocksPerCu, S3_UNIT_WAVES_PER_SIMD);
             {
                 const size_t waves = unitPassMaxWaves(256u * std::max(blocksFirst, blocksUnit));
                 if (waves > b->unitStackWaves) {

@@ -171,7 +171,6 @@ void launchRelayout(const uint32_t *bwt, size_t bwtWords, const uint32_t *occ, s
 int launchFirstPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);    // s3dp_first.hip; returns a hipError_t
 int launchTrunkPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);    // s3dp_first.hip, the trunk-pass role
 int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s);     // s3dp_unit.hip; returns a hipError_t
-unsigned unitWavesPerSimd();                                                          // 4, or 5 with S3DP_UNIT_WAVES=5 (s3dp_unit.hip)
 unsigned unitPassMaxWaves(unsigned maxBlocks);                                        // waves of the widest unit-pass grid (sizes SearchOut::unitStack)
 void launchListedReads(const uint32_t *heavyList, const uint32_t *heavyCount, const uint32_t *active, uint32_t *listedRead, uint32_t nHeavy, hipStream_t s);
 // the order of the listed reads (s3dp_unit.hip, "LOCALITY"): keys = the first 32 characters of read active[slots[k]] (slots == nullptr: k), vals = the slot

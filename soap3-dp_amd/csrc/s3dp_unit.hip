@@ -45,9 +45,10 @@ enum : uint32_t { U_IDLE = 0, U_STEP = 1, U_LOAD = 2, U_ADOPT = 3, U_POPWAIT = 4
 using namespace unit;
 
 // COUNT: with the statistics of s3_batch_enable_counters (rank queries, trips, longest unit ...): ten more registers, measurement runs only
-// WAVES: waves per SIMD the register budget is cut for (4: 128 registers; 5: 96 registers and a few spills -- S3DP_UNIT_WAVES=5, an experiment of round 5)
-template <bool UNIFORM, bool COUNT, int WAVES = S3_UNIT_WAVES_PER_SIMD>
-__global__ void __launch_bounds__(S3_SEARCH_BLOCK, WAVES)
+// (four waves per SIMD = 128 registers.  Five -- 96 registers, 29 dwords of the lane state spilled, 154 KB of LDS per CU -- was tried in round 5:
+//  the unit passes of a ladder 149 -> 187 ms, profiles/README_r05.md)
+template <bool UNIFORM, bool COUNT>
+__global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_UNIT_WAVES_PER_SIMD)
 unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 {
     extern __shared__ __align__(16) unsigned char shmem[];
@@ -717,13 +718,6 @@ __global__ void unitChainKernel(SearchOut out, uint32_t unitBase, uint32_t nUnit
 
 unsigned unitPassMaxWaves(unsigned maxBlocks) { return maxBlocks * (S3_SEARCH_BLOCK / 64u); }
 
-// S3DP_UNIT_WAVES=5: the unit pass at five waves per SIMD (96 registers, some of the state spilled) instead of four
-unsigned unitWavesPerSimd()
-{
-    const char *e = getenv("S3DP_UNIT_WAVES");
-    return e && atoi(e) == 5 ? 5u : (unsigned)S3_UNIT_WAVES_PER_SIMD;
-}
-
 int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s)
 {
     if (in.nActive == 0) return (int)hipSuccess;
@@ -731,19 +725,14 @@ int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out,
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + S3_UNIT_RDY_BYTES + in.wLds * 256u);
     const bool count = out.counters != nullptr;
-    const bool five = unitWavesPerSimd() == 5u && !count;
-    const void *fn = five ? (in.uniformLen ? (const void *)unitKernel<true, false, 5> : (const void *)unitKernel<false, false, 5>)
-                   : in.uniformLen ? (count ? (const void *)unitKernel<true, true> : (const void *)unitKernel<true, false>)
+    const void *fn = in.uniformLen ? (count ? (const void *)unitKernel<true, true> : (const void *)unitKernel<true, false>)
                                    : (count ? (const void *)unitKernel<false, true> : (const void *)unitKernel<false, false>);
     if (lds > 48u * 1024u) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     const dim3 grid((unsigned)blocks), block(S3_SEARCH_BLOCK);
-    if (five) {
-        if (in.uniformLen) hipLaunchKernelGGL((unitKernel<true, false, 5>), grid, block, lds, s, ix, in, out);
-        else hipLaunchKernelGGL((unitKernel<false, false, 5>), grid, block, lds, s, ix, in, out);
-    } else if (in.uniformLen) {
+    if (in.uniformLen) {
         if (count) hipLaunchKernelGGL((unitKernel<true, true>), grid, block, lds, s, ix, in, out);
         else hipLaunchKernelGGL((unitKernel<true, false>), grid, block, lds, s, ix, in, out);
     } else {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: unit-pass variants (S3DP_TAKE_MIN ...) on the bench ladder, timed steps only; tools/r5_unit_ab.sh <outdir> cfg [cfg ...]   (cfg: VAR=val,VAR=val | base)
+# round 5: unit-pass variants (S3DP_TAKE_MIN ...) on the bench ladder, timed steps only; tools/ladder_ab.sh <outdir> cfg [cfg ...]   (cfg: VAR=val,VAR=val | base)
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-r05u}; shift; mkdir -p $O /tmp/s3dp_ix
