@@ -1431,10 +1431,12 @@ def summary_of(out):
         if "error" in leg or "error" in e2e or not e2e:
             lines.append("%s: %s" % (tag, (leg.get("error") or e2e.get("error") or "no end-to-end figure")[:200]))
             continue
-        pairs = g(leg, "truth_check", "pairs", default=0) or 0
+        pairs = g(e2e, "counts", "pairs") or g(leg, "truth_check", "pairs", default=0) or 0      # (C4: the sum over the ranks)
         secs = g(e2e, "phases_s", "Alignment + output time", default=e2e.get("wall_s"))
         rec = {"pairs": pairs, "seconds": secs, "M_pairs_per_s": e2e.get("M_pairs_per_s_reads_in_sam_out"), "loading_s": g(e2e, "phases_s", "Loading time"),
-               "bwt_stage_frac": g(leg, "bwt_stage_resident", "roofline", "frac"), "dp_GCUPS": g(e2e, "dp", "GCUPS"), "dp_isolated_GCUPS": g(leg, "dp_isolated", "GCUPS"),
+               "bwt_stage_frac": g(leg, "bwt_stage_resident", "roofline", "frac"), "dp_GCUPS": g(e2e, "dp", "GCUPS") or g(e2e, "rank0", "dp", "GCUPS"),
+               # the same default-DP problems through the engine ALONE (no search kernels beside it): extras.default_dp_half_end
+               "dp_isolated_GCUPS": g(ex, "default_dp_half_end", "GCUPS_kernel") if key == "c3_pairs" else None,
                "device_ms": e2e.get("device_ms"), "counts": e2e.get("counts"),
                "both_mates_at_simulated_place": g(leg, "truth_check", "pairs_with_both_mates_at_simulated_place")}
         if "per_device" in e2e:
