@@ -3,7 +3,7 @@
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-r05e}; mkdir -p $O
-W=/tmp/e2e_w; rm -rf $W
+W=/tmp/e2e_w; rm -rf $W /tmp/c3w /tmp/s3dp_ix /tmp/prof_*          # (the boxes' /tmp holds about two sets of index files and one run's output)
 python3 tools/bench_e2e.py --genome-bp 3100000000 --reads 20000000 --repeat-frac 0.5 --workdir $W > $O/e2e_se_repeat.json 2> $O/e2e_se_repeat.log; cut -c1-600 $O/e2e_se_repeat.json; echo
 run() {
   local tag=$1; shift
@@ -16,3 +16,4 @@ run default A=1
 rm -f $W/out.gout.1; ln -s /dev/null $W/out.gout.1
 run devnull_default A=1
 rm -f $W/out.gout.1
+rm -rf $W
