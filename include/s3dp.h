@@ -343,6 +343,10 @@ int  s3_dp_new_default_routed(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const 
                               const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_deep_result **results, size_t *nResults,
                               char **cigarPool, uint8_t **pairFlags, uint32_t **pairFirstReads, size_t *nPairs);
 
+/* A batch whose work runs BESIDE another batch's search (the seed batches of the DP stage threads, SOAP3Wrapper::seeding, DV-DPfunctions.h:212-229: in the
+ * reference seeding and search share the one GPU one after the other): background != 0 moves its stream to the device's lowest priority, so that its kernels
+ * take what the persistent search kernels leave; 0 moves it back.  The aligners of s3_dp_create are background work by construction.  Call it on an idle batch. */
+int  s3_batch_set_background(s3_batch *b, int background);
 int  s3_batch_sync(s3_batch *b);
 /* device time of the work enqueued by the last search/align call, measured with HIP events on the batch stream;
  * searchMs = time inside the BWT-search kernels only. */

@@ -558,6 +558,26 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
     return S3_OK;
 }
 
+// background batches (the seed batches of the command line's DP stage threads): their stream gets the lowest priority of the device, or the default again
+extern "C" int s3_batch_set_background(s3_batch *b, int background)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
+    HIPCHK(hipSetDevice(b->ix->dev));
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) return S3_OK;     // (a device without priorities: nothing to do)
+    const char *e = getenv("S3DP_DP_PRIORITY");
+    if (e && atoi(e) == 0) return S3_OK;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    hipStream_t s = nullptr;
+    if (background) HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+    else HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    s3i::scratchStreamGone(b->stream);
+    (void)hipStreamDestroy(b->stream);
+    b->stream = s;
+    return S3_OK;
+}
+
 extern "C" int s3_batch_enable_counters(s3_batch *b, int on)
 {
     if (!b) return fail(S3_EINVAL, "null batch");

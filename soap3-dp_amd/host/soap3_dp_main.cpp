@@ -895,7 +895,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         s3_dp_stage_parameters(S3_STAGE_SINGLE_DP, detectedReadLength, &di, &dpPar);      // getParameterForSingleDP on the detected length (alignment.cu:2580)
         for (int w = 0; w < nDpWorkers; w++) {                                // (the aligners were made while the index was loaded, above)
             dpSet[w] = preDp[(size_t)member].dp[w];
-            if (s3_batch_create(ix, 262144 + 64, 8, &seedSet[w]) != S3_OK) return dieJoin(s3_last_error());
+            if (s3_batch_create(ix, 262144 + 64, 8, &seedSet[w]) != S3_OK || s3_batch_set_background(seedSet[w], 1) != S3_OK) return dieJoin(s3_last_error());
         }
         if (paired) {
             for (int w = 0; w < nDpWorkers; w++) halfSet[w] = preDp[(size_t)member].dpHalf[w];
