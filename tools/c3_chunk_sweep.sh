@@ -12,7 +12,9 @@ OPT="-L 150 -u 500 -v 1 -b 2"
 run() { local tag=$1; shift; env "$@" timeout 200 $CLI /tmp/c3w/r1.fq /tmp/c3w/r2.fq $OPT -o /tmp/c3w/outp > $O/run_$tag.txt 2>&1; echo "$tag rc=$? $(grep 'Alignment + output' $O/run_$tag.txt) | $(grep 'Device time' $O/run_$tag.txt | cut -c1-120)"; }
 rm -rf /tmp/e2e_w /tmp/prof_*
 run c1m A=1
+run c1m_prio0 S3DP_DP_PRIORITY=0
 run c2m S3DP_CHUNK_READS=2097152
+run c2m_prio0 S3DP_CHUNK_READS=2097152 S3DP_DP_PRIORITY=0
 run c4m S3DP_CHUNK_READS=4194304
 run c1m_b3 S3DP_BLOCKS_PER_CU=3
 run c2m_b3 S3DP_CHUNK_READS=2097152 S3DP_BLOCKS_PER_CU=3
