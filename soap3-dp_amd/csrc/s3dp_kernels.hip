@@ -284,30 +284,47 @@ __global__ void mergeFillKernel(MergeArgs a, const uint32_t *hitOffsets, DevHit 
 __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffsets, uint32_t occBase, uint32_t occCap, uint32_t *occPos,
                              uint32_t *occMeta, uint32_t *flags)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= a.nActive) return;
-    if (a.decodeMask && a.decodeMask[slot] != a.decodeWant) return;
+    // One lane per read walks the read's slice.  An SA range of more than 16 suffixes -- a read inside a repeat with identical copies holds ONE record for a
+    // thousand occurrences (8,000 in the paired ladder) -- is expanded by the whole wave, suffix q by lane q % 64: consecutive suffix-array entries, whole
+    // lines, instead of a thousand dependent 4-byte loads in one lane while 63 wait (round 5: 121 ms of a 10 M-pair run were this loop).  So the walk is
+    // wave-synchronous: every lane takes one slot of its slice per turn, nobody leaves before all are through.
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
     const uint32_t groups = a.nCases * 2u;
-    uint32_t beg, end;
-    readSlice(a, slot, groups, beg, end);
-    if (a.longList && end - beg > S3_MERGE_LONG) return;                   // decodeLongKernel's
-    const uint32_t n = a.keptRecs[slot];
-    uint32_t o = occBase + occOffsets[slot], oSa = o + a.ceCounts[slot];
-    if ((uint64_t)occBase + occOffsets[slot + 1] > occCap) { atomicOr(flags, S3_FLAG_OCC_OVERFLOW); return; }
-    uint32_t total = 0;
-    for (uint32_t k = 0, i = beg; k < n; i++) {
-        if (!a.valid[i]) continue;
-        const uint4 r = a.ordered[i];
-        k++;
+    bool mine = slot < a.nActive && !(a.decodeMask && a.decodeMask[slot] != a.decodeWant);
+    uint32_t beg = 0, end = 0, n = 0, o = 0, oSa = 0;
+    if (mine) {
+        readSlice(a, slot, groups, beg, end);
+        if (a.longList && end - beg > S3_MERGE_LONG) mine = false;                     // decodeLongKernel's
+    }
+    if (mine && (uint64_t)occBase + occOffsets[slot + 1] > occCap) { atomicOr(flags, S3_FLAG_OCC_OVERFLOW); mine = false; }
+    if (mine) { n = a.keptRecs[slot]; o = occBase + occOffsets[slot]; oSa = o + a.ceCounts[slot]; }
+    uint32_t total = 0, k = 0, i = beg;
+    while (__any(mine && k < n)) {
+        const bool turn = mine && k < n;
+        const bool have = turn && a.valid[i] != 0;
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (have) r = a.ordered[i];
+        if (turn) i++;
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
-        const uint32_t strand = ((r.x % groups) & 1u) + 1u;
-        const uint32_t meta = strand | nmis << 8;
-        if (kind) { occPos[o] = r.z; occMeta[o] = meta; o++; total++; }
-        else {
-            uint32_t cnt = r.w - r.z + 1u;
-            if (total + cnt > a.maxOut) cnt = a.maxOut - total;
-            for (uint32_t q = 0; q < cnt; q++) { occPos[oSa] = ix.sa[r.z + q]; occMeta[oSa] = meta | 0x10000u; oSa++; }   // bit 16: came out of an SA range
-            total += cnt;
+        const uint32_t meta = (((r.x % groups) & 1u) + 1u) | nmis << 8;
+        uint32_t cnt = 0, dst = 0;
+        if (have) {
+            k++;
+            if (kind) { occPos[o] = r.z; occMeta[o] = meta; o++; total++; }
+            else {
+                cnt = r.w - r.z + 1u;
+                if (total + cnt > a.maxOut) cnt = a.maxOut - total;
+                dst = oSa;
+                if (cnt <= 16u) for (uint32_t q = 0; q < cnt; q++) { occPos[dst + q] = ix.sa[r.z + q]; occMeta[dst + q] = meta | 0x10000u; }   // bit 16: came out of an SA range
+                oSa += cnt; total += cnt;
+            }
+        }
+        unsigned long long big = __ballot(have && !kind && cnt > 16u);
+        while (big) {
+            const int l = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const uint32_t z = (uint32_t)__shfl((int)r.z, l), cc = (uint32_t)__shfl((int)cnt, l), d = (uint32_t)__shfl((int)dst, l), m = (uint32_t)__shfl((int)meta, l) | 0x10000u;
+            for (uint32_t q = lane; q < cc; q += 64u) { occPos[d + q] = ix.sa[z + q]; occMeta[d + q] = m; }
         }
     }
 }
