@@ -215,6 +215,7 @@ struct PairSortArgs {
     uint32_t       *occPos, *occMeta;
     uint64_t       *keys;
     uint32_t       *segBegin, *segEnd;
+    uint32_t        idxBits;                     // bits of a hit's place in its list (lists hold at most maxHitsPerEnd hits): the sort keys are position << idxBits | place
 };
 struct PairSweepArgs {
     uint32_t        nPairs;

@@ -703,6 +703,8 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
         PairSortArgs sa{};
         sa.nPairs = nA; sa.activePairs = active; sa.pairNext = b->dPairNext; sa.occStart = b->dOccStart; sa.occCount = b->dOccCount;
         sa.regionBase = regionBase; sa.occPos = b->dOccPos; sa.occMeta = b->dOccMeta; sa.segBegin = b->dSegBegin; sa.segEnd = b->dSegEnd;
+        sa.idxBits = 1;
+        while ((1ull << sa.idxBits) <= (unsigned long long)maxHitsPerEnd) sa.idxBits++;          // (a list holds at most maxHitsPerEnd <= 2^24 - 1 hits)
         if (items) {
             rc = ensureSortBuffers(b, items, (int)(2 * nA));
             if (rc) return rc;
@@ -710,7 +712,7 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
             launchPairSortKeys(sa, b->stream);
             size_t tb = b->sortTempBytes;
             HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(b->dSortTemp, tb, b->dSortKeys[0], b->dSortKeys[1], b->dOccMeta + regionBase, b->dSortMeta,
-                                                               (int)items, (int)(2 * nA), b->dSegBegin, b->dSegEnd, 0, 64, b->stream));
+                                                               (int)items, (int)(2 * nA), b->dSegBegin, b->dSegEnd, 0, (int)(32u + sa.idxBits), b->stream));
             launchPairSortBack(sa, b->dSortKeys[1], b->dSortMeta, b->stream);
         }
         launchPairSnapshotCounts(nA, active, b->dOccCount, b->dOccCountIn, b->stream);

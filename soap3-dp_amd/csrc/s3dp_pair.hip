@@ -68,13 +68,15 @@ __global__ void pairSortKeysKernel(PairSortArgs a)
         a.segBegin[s] = on ? beg : 0u;
         a.segEnd[s] = on ? beg + cnt : 0u;
     }
-    if (cnt <= 8u) for (uint32_t k = 0; k < cnt; k++) a.keys[beg + k] = (uint64_t)a.occPos[a.regionBase + beg + k] << 32 | (beg + k);
+    // key = position, then the hit's place in its own list (unique keys: the order of the reference's stable sort) -- in 32 + idxBits bits, which is what the
+    // radix sort is told to look at (a list holds at most maxHitsPerEnd hits: 13 bits in the command line, where 64-bit keys cost a quarter more passes)
+    if (cnt <= 8u) for (uint32_t k = 0; k < cnt; k++) a.keys[beg + k] = (uint64_t)a.occPos[a.regionBase + beg + k] << a.idxBits | k;
     unsigned long long big = __ballot(cnt > 8u);
     while (big) {
         const int l = __ffsll((long long)big) - 1;
         big &= big - 1;
         const uint32_t c = (uint32_t)__shfl((int)cnt, l), b0 = (uint32_t)__shfl((int)beg, l);
-        for (uint32_t k = lane; k < c; k += 64u) a.keys[b0 + k] = (uint64_t)a.occPos[a.regionBase + b0 + k] << 32 | (b0 + k);
+        for (uint32_t k = lane; k < c; k += 64u) a.keys[b0 + k] = (uint64_t)a.occPos[a.regionBase + b0 + k] << a.idxBits | k;
     }
 }
 
@@ -85,7 +87,7 @@ __global__ void pairSortBackKernel(PairSortArgs a, const uint64_t *keysSorted, c
     if (s < 2 * a.nPairs) { beg = a.segBegin[s]; cnt = a.segEnd[s] - beg; }
     if (cnt <= 8u)
         for (uint32_t k = beg; k < beg + cnt; k++) {
-            a.occPos[a.regionBase + k] = (uint32_t)(keysSorted[k] >> 32);
+            a.occPos[a.regionBase + k] = (uint32_t)(keysSorted[k] >> a.idxBits);
             a.occMeta[a.regionBase + k] = metaSorted[k];
         }
     unsigned long long big = __ballot(cnt > 8u);
@@ -94,7 +96,7 @@ __global__ void pairSortBackKernel(PairSortArgs a, const uint64_t *keysSorted, c
         big &= big - 1;
         const uint32_t c = (uint32_t)__shfl((int)cnt, l), b0 = (uint32_t)__shfl((int)beg, l);
         for (uint32_t k = b0 + lane; k < b0 + c; k += 64u) {
-            a.occPos[a.regionBase + k] = (uint32_t)(keysSorted[k] >> 32);
+            a.occPos[a.regionBase + k] = (uint32_t)(keysSorted[k] >> a.idxBits);
             a.occMeta[a.regionBase + k] = metaSorted[k];
         }
     }
