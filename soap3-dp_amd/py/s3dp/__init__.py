@@ -356,6 +356,12 @@ class Batch:
             queries = np.concatenate([queries.ravel(), np.zeros(need - queries.size, dtype=np.uint32)])
         _chk(lib().s3_batch_upload(self.h, queries.ctypes.data, read_lengths.ctypes.data, self.n))
 
+    def set_background(self, background=True):
+        """the batch's stream at the device's lowest priority (work that runs beside another batch's search), or back at the default"""
+        f = lib().s3_batch_set_background
+        f.argtypes = [C.c_void_p, C.c_int]
+        _chk(f(self.h, 1 if background else 0))
+
     def enable_counters(self, on=True):
         _chk(lib().s3_batch_enable_counters(self.h, 1 if on else 0))
 
