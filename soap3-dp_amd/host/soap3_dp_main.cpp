@@ -766,7 +766,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         if (!enableDP && numMismatch < 0) numMismatch = maxReadLength > 50 ? 3 : 2;
     }
     // the DP aligners' traceback tables are a few gigabytes per device (20 ms per GB to allocate): made while the index is read and uploaded
-    constexpr int kDpWorkers = 2;                                             // at most: DP stage threads per device (each with its own aligners and seed batch)
+    constexpr int kDpWorkers = 4;                                             // at most: DP stage threads per device (each with its own aligners and seed batch)
     // two by default (S3DP_DP_THREADS=1 for one).  A stage thread's work is a chain of small launches and fetches, each of which waits behind the search
     // kernels of the chunk loop -- persistent waves that hold the device for tens of milliseconds at a time: one thread needed 5.1 s for the stages of 10 M
     // pairs while the chunk loop needed 3.5 s; two threads on alternate chunks hide each other's waits (10 M pairs: 5.1 -> 4.1 s).  Round 3 found no gain in
@@ -774,8 +774,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     // With two threads the records of different chunks reach .dpout / .unpair in the order the threads finish (the reference's own output threads write
     // in no fixed order either, SOAP3-DP.cu:251-258): the SET of records is the result; S3DP_DP_THREADS=1 gives a reproducible file order.
     // (S3DP_DUMP_ROUTING, the tests' routing dump, is appended chunk by chunk by the stage thread: one thread, or chunk 1 could write before chunk 0 truncates the file)
-    const int nDpWorkers = (getenv("S3DP_DP_THREADS") && atoi(getenv("S3DP_DP_THREADS")) == 1) || getenv("S3DP_DUMP_ROUTING") ? 1 : 2;
-    struct PreDp { s3_dp *dp[kDpWorkers] = {nullptr, nullptr}, *dpHalf[kDpWorkers] = {nullptr, nullptr}; std::string err; };
+    const int dpThreadsEnv = getenv("S3DP_DP_THREADS") ? atoi(getenv("S3DP_DP_THREADS")) : 0;
+    const int nDpWorkers = getenv("S3DP_DUMP_ROUTING") ? 1 : (dpThreadsEnv >= 1 && dpThreadsEnv <= kDpWorkers ? dpThreadsEnv : 2);
+    struct PreDp { s3_dp *dp[kDpWorkers] = {}, *dpHalf[kDpWorkers] = {}; std::string err; };
     const std::vector<int> &dpDevices = shared.loaded ? shared.devices : devices;
     std::vector<PreDp> preDp(dpDevices.size());
     std::vector<std::thread> preDpThreads;
@@ -879,8 +880,8 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     SamWriter sam(hix, so, out);
     sam.header();
     FILE *dpOut = nullptr;
-    s3_dp *dpSet[kDpWorkers] = {nullptr, nullptr}, *halfSet[kDpWorkers] = {nullptr, nullptr};    // one set of aligners and one seed batch per DP stage thread
-    s3_batch *seedSet[kDpWorkers] = {nullptr, nullptr};
+    s3_dp *dpSet[kDpWorkers] = {}, *halfSet[kDpWorkers] = {};                 // one set of aligners and one seed batch per DP stage thread
+    s3_batch *seedSet[kDpWorkers] = {};
     s3_dp_stage_params dpPar{}, halfPar[2] = {}, deepPar[2][2] = {}, newPar[2] = {};
     FILE *unpairOut = nullptr;
     uint64_t dpAlignedReads = 0, defaultDpPairs = 0, newDefaultPairs = 0, deepDpPairs = 0, leftoverPairs = 0;
