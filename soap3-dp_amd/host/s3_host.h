@@ -74,6 +74,9 @@ public:
     // other --, a record with the reverse-strand flag is taken back to the read as sequenced (reverse complement, qualities reversed)
     bool openBam(const std::string &file, bool paired, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, std::string &err);
     bool next(uint32_t maxReads, ReadSet &rs, std::string &err);
+    // reads the input still holds, estimated from what is left of the first file and the bytes a read has taken so far (plain files: exact bytes; gzip: the
+    // compressed offset against the file's size; BAM or nothing read yet: -1 = unknown).  The command line sizes its chunks by it.
+    double remainingReads() const;
 private:
     struct File;
     std::vector<std::unique_ptr<File>> files;

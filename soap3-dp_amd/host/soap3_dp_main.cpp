@@ -686,6 +686,19 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     //  the faster one there: 1.95 s against 2.44 s per 1 Mi reads)
     const size_t chunkDefault = (alignmentType == 1 && maxReadLength > 120) ? (size_t)1 << 18 : (size_t)1 << 20;
     const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : chunkDefault) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
+    // LARGE CHUNKS FIRST (round 5).  The search kernels' cost per read falls with the size of the batch (the tails of their launches: ten million pairs cost
+    // 2.95 s of BWT stages in chunks of 1 Mi reads, 2.14 s in chunks of 2 Mi, 1.66 s in chunks of 4 Mi) -- but a run of few large chunks ends with the whole
+    // of its last chunk's DP stages and output behind the last search, and came out no faster.  So the input is taken in chunks of S3DP_CHUNK_BIG reads
+    // (default 4 Mi; 0: off) while plenty is left, and in chunks of the usual size at the end: the pipeline drains over a small chunk.  What is left is
+    // estimated from the files' sizes (ReadChunker::remainingReads); an explicit S3DP_CHUNK_READS fixes the size as before.
+    size_t chunkBigEnv = (size_t)4 << 20;
+    if (const char *e = getenv("S3DP_CHUNK_BIG")) chunkBigEnv = (size_t)strtoull(e, nullptr, 10);
+    const uint32_t chunkBig = chunkReadsEnv || chunkBigEnv <= chunkReads || (alignmentType == 1 && maxReadLength > 120) ? 0u : (uint32_t)(std::min<size_t>(chunkBigEnv, (size_t)1 << 23) / 64 * 64);
+    auto nextChunkSize = [&](const ReadChunker &ck) -> uint32_t {
+        if (!chunkBig) return chunkReads;
+        const double left = ck.remainingReads();
+        return left >= 0 && left < 1.5 * (double)chunkBig + 2.0 * (double)chunkReads ? chunkReads : chunkBig;   // (unknown = nothing read yet: the first chunk of a large file)
+    };
     ReadChunker chunker;
     if (readBam ? !chunker.openBam(queryFile, paired, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)
                 : !chunker.open(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)) return die(err);
@@ -715,7 +728,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             if (!rs) rs.reset(new ReadSet());
             std::string e;
             const auto t = std::chrono::steady_clock::now();
-            const bool ok = chunker.next(chunkReads, *rs, e);
+            const bool ok = chunker.next(nextChunkSize(chunker), *rs, e);
             std::unique_lock<std::mutex> lk(loaded.mu);
             loaded.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
             if (!ok) { loaded.err = e; loaded.done = true; loaded.cv.notify_all(); return; }
@@ -775,7 +788,8 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     // in no fixed order either, SOAP3-DP.cu:251-258): the SET of records is the result; S3DP_DP_THREADS=1 gives a reproducible file order.
     // (S3DP_DUMP_ROUTING, the tests' routing dump, is appended chunk by chunk by the stage thread: one thread, or chunk 1 could write before chunk 0 truncates the file)
     const int dpThreadsEnv = getenv("S3DP_DP_THREADS") ? atoi(getenv("S3DP_DP_THREADS")) : 0;
-    const int nDpWorkers = getenv("S3DP_DUMP_ROUTING") ? 1 : (dpThreadsEnv >= 1 && dpThreadsEnv <= kDpWorkers ? dpThreadsEnv : 2);
+    // (with large chunks a chunk's DP stages last longer than the search of the next one: three threads keep up with them)
+    const int nDpWorkers = getenv("S3DP_DUMP_ROUTING") ? 1 : (dpThreadsEnv >= 1 && dpThreadsEnv <= kDpWorkers ? dpThreadsEnv : (chunkBig ? 3 : 2));
     struct PreDp { s3_dp *dp[kDpWorkers] = {}, *dpHalf[kDpWorkers] = {}; std::string err; };
     const std::vector<int> &dpDevices = shared.loaded ? shared.devices : devices;
     std::vector<PreDp> preDp(dpDevices.size());
