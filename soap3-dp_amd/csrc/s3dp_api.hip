@@ -567,7 +567,7 @@ extern "C" int s3_batch_set_background(s3_batch *b, int background)
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) return S3_OK;     // (a device without priorities: nothing to do)
     const char *e = getenv("S3DP_DP_PRIORITY");
-    if (e && atoi(e) == 0) return S3_OK;
+    if (!(e && atoi(e) == 1)) return S3_OK;                          // (opt-in: measured without effect on the paired command line, s3dp_dpapi.hip)
     HIPCHK(hipStreamSynchronize(b->stream));
     hipStream_t s = nullptr;
     if (background) HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));

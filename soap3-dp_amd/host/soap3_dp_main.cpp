@@ -677,8 +677,11 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     // The read files come in chunks (ReadChunker): a loader thread parses chunk i+1 -- with all host threads -- while chunk i is aligned and
     // chunk i-1 is formatted and written, as the reference's loader thread fills the next batch buffer (aio_thread.cpp:582, SOAP3-DP.cu:607-800).
-    // It starts before the index is read: neither needs the other.  S3DP_CHUNK_READS: reads per chunk (default 1 Mi, the reference's own batch (SOAP3-DP.cu:394): since the unit pass
-    // shares the tail of a launch among the lanes of a wave, a small chunk costs no more per read than a large one, and three of them fill the pipeline four times sooner).
+    // It starts before the index is read: neither needs the other.  S3DP_CHUNK_READS: reads per chunk.  The default is 1 Mi, the reference's own batch
+    // (SOAP3-DP.cu:394), and it is the measured optimum of the whole program, not of the device: a ladder of 1 Mi reads costs the device 2.2 times as much per
+    // read as one of 10 M (13.7 against 30 M reads/s resident -- the tails of its launches), but twenty million reads in chunks of 1 / 2 / 4 Mi with three in
+    // flight take 1.41 / 1.62 / 2.06 s to /dev/null (gpurun_out/r05e2): with few chunks the first output waits for a long first search and the last chunk's
+    // formatting has nothing to hide behind.
     size_t chunkReadsEnv = 0;
     if (const char *e = getenv("S3DP_CHUNK_READS")) chunkReadsEnv = (size_t)strtoull(e, nullptr, 10);
     // (all valid alignments of reads above 120 bases: the 100-base seeds are searched without a hit limit, a read inside a repeat family brings thousands
@@ -689,9 +692,12 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     // LARGE CHUNKS FIRST (round 5).  The search kernels' cost per read falls with the size of the batch (the tails of their launches: ten million pairs cost
     // 2.95 s of BWT stages in chunks of 1 Mi reads, 2.14 s in chunks of 2 Mi, 1.66 s in chunks of 4 Mi) -- but a run of few large chunks ends with the whole
     // of its last chunk's DP stages and output behind the last search, and came out no faster.  So the input is taken in chunks of S3DP_CHUNK_BIG reads
-    // (default 4 Mi; 0: off) while plenty is left, and in chunks of the usual size at the end: the pipeline drains over a small chunk.  What is left is
+    // (0, the default: off) while plenty is left, and in chunks of the usual size at the end: the pipeline drains over a small chunk.  What is left is
     // estimated from the files' sizes (ReadChunker::remainingReads); an explicit S3DP_CHUNK_READS fixes the size as before.
-    size_t chunkBigEnv = (size_t)4 << 20;
+    // OFF by default: measured on the 10 M C3 pairs and on 20 M single reads with the outputs linked to /dev/null (tools/chunk_big_sweep.sh, gpurun_out/r05b):
+    // pairs 3.55 s without, 3.65-3.78 s with 4 Mi-read chunks and two to four DP stage threads -- the BWT stages fall from 2.74 to 2.0-2.2 s, the DP stages
+    // of the large chunks take what was won; single reads 1.41-1.46 s without, 1.70 / 2.1-2.2 s with 2 Mi / 4 Mi chunks (three slots in flight).
+    size_t chunkBigEnv = 0;
     if (const char *e = getenv("S3DP_CHUNK_BIG")) chunkBigEnv = (size_t)strtoull(e, nullptr, 10);
     const uint32_t chunkBig = chunkReadsEnv || chunkBigEnv <= chunkReads || (alignmentType == 1 && maxReadLength > 120) ? 0u : (uint32_t)(std::min<size_t>(chunkBigEnv, (size_t)1 << 23) / 64 * 64);
     auto nextChunkSize = [&](const ReadChunker &ck) -> uint32_t {
