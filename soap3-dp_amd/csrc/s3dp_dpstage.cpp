@@ -8,7 +8,7 @@
 
 extern "C" int s3_dp_stage_parameters(int stage, uint32_t L, const s3_dp_ini *ini, s3_dp_stage_params *o)
 {
-    if (!ini || !o || stage < S3_STAGE_SINGLE_DP || stage > S3_STAGE_DEEP_DP_ROUND1) return S3_EINVAL;
+    if (!ini || !o || stage < S3_STAGE_SINGLE_DP || stage > S3_STAGE_DEEP_DP_ROUND2) return S3_EINVAL;
     memset(o, 0, sizeof *o);
     // DPScoreThreshold=DEFAULT: 0.3 x read length, rounded up (DP_SCORE_THRESHOLD_RATIO, definitions.h:152)
     o->cutoffThreshold = ini->dpScoreThreshold < 0 ? (int)ceil(0.3 * (double)L) : ini->dpScoreThreshold;
@@ -23,7 +23,13 @@ extern "C" int s3_dp_stage_parameters(int stage, uint32_t L, const s3_dp_ini *in
         o->seedLength = L > 75 ? 26 : L > 50 ? 24 : 22;
         break;
     case S3_STAGE_DEEP_DP_ROUND1:
-        o->maxHitNum = L > 50 ? 100 : 150;
+    case S3_STAGE_DEEP_DP_ROUND2:
+        // round 2 (the pairs that lost a seed to round 1's hit limit) runs on round 1's parameter object with ONE field replaced: the hit limit of both
+        // ends becomes MAX_SEED_HITS_DEEP_DP_FOR_NORMAL_READ_2 = 1000 whatever the read length (DV-DPForBothUnalign.cu:137-139, definitions.h:179); its
+        // seeds come from getSeedPositions(STAGE_DEEP_DP_ROUND2) (s3_seed_positions).  Until round 5 this function refused the stage and the command line
+        // ran round 2 on a zeroed structure -- hit limit 0: every seed with a hit dropped -- which no fixture noticed because none held a seed with more than
+        // a hundred hits; the scale test with a 600-copy family does (tests/test_gpu_cli_vs_oracle_scale.py::...[pair_every_route]: 326 pairs).
+        o->maxHitNum = stage == S3_STAGE_DEEP_DP_ROUND2 ? 1000 : (L > 50 ? 100 : 150);
         o->seedLength = L > 150 ? 45 : L > 80 ? 26 : L > 60 ? 24 : L > 40 ? 22 : 20;
         o->sampleDist = (int)(o->seedLength * 0.5);
         o->tailTrimLen = 0;

@@ -924,8 +924,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             s3_dp_stage_parameters(S3_STAGE_DEFAULT_DP, detectedReadLength2, &di, &halfPar[1]);
             for (int e = 0; e < 2; e++) {
                 s3_dp_stage_parameters(S3_STAGE_NEW_DEFAULT_DP, e ? detectedReadLength2 : detectedReadLength, &di, &newPar[e]);
-                s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND1, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[0][e]);
-                s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND2, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[1][e]);
+                if (s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND1, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[0][e]) != S3_OK ||
+                    s3_dp_stage_parameters(S3_STAGE_DEEP_DP_ROUND2, e ? detectedReadLength2 : detectedReadLength, &di, &deepPar[1][e]) != S3_OK)
+                    return dieJoin("s3_dp_stage_parameters refused a deep-DP stage");
             }
             const std::string upName = prefix + (member == 0 ? ".unpair" : ".unpair." + fileNo);
             unpairOut = fopen(upName.c_str(), "w");

@@ -38,6 +38,12 @@ def test_stage_parameters_and_seed_positions_match_reference():
         elif kind == "deep":
             assert lib.s3_dp_stage_parameters(4, L, C.byref(ini), C.byref(p)) == 0
             assert [p.cutoffThreshold, p.maxHitNum, p.seedLength, p.sampleDist, p.tailTrimLen] == [int(f[4]), int(f[6]), int(f[8]), int(f[10]), int(f[12])], l
+            # round 2 of the deep DP runs on round 1's parameter object with the hit limit of both ends replaced by
+            # MAX_SEED_HITS_DEEP_DP_FOR_NORMAL_READ_2 = 1000 (DV-DPForBothUnalign.cu:137-139, definitions.h:179) -- whatever the read length
+            p2 = Params()
+            assert lib.s3_dp_stage_parameters(5, L, C.byref(ini), C.byref(p2)) == 0
+            assert [p2.cutoffThreshold, p2.maxHitNum, p2.seedLength, p2.sampleDist, p2.tailTrimLen, p2.softClipLeft, p2.softClipRight] == \
+                   [p.cutoffThreshold, 1000, p.seedLength, p.sampleDist, p.tailTrimLen, p.softClipLeft, p.softClipRight], l
         elif kind == "single":
             assert lib.s3_dp_stage_parameters(1, L, C.byref(ini), C.byref(p)) == 0
             assert [p.cutoffThreshold, p.maxHitNum, p.seedLength, p.singleDPSeedNum] == [int(f[4]), int(f[6]), int(f[8]), int(f[10])], l
