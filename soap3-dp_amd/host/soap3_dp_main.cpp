@@ -425,7 +425,11 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             if (res[q].cigarOffset_2 != 0xFFFFFFFFu) h.cigar2 = pool + res[q].cigarOffset_2;
             hits.push_back(h);
         }
-        std::stable_sort(hits.begin(), hits.end(), [](const DeepDpHit &x, const DeepDpHit &y) { return x.pos1 < y.pos1; });
+        // (std::sort, NOT a stable sort: OutputBuffer::arrayCopyNRemoveDuplicate sorts with std::sort by the first end's position alone and keeps the first
+        //  result of every position -- for more than sixteen results the survivor among results with equal first positions is whatever introsort leaves in
+        //  front, and the X0 / X1 counts and XA lists follow from it.  Same library, same comparator, same input order: same permutation.  Found by the
+        //  every-route scale test, where pairs come with hundreds of deep-DP results; the fixtures' lists are short enough for the insertion-sort branch.)
+        std::sort(hits.begin(), hits.end(), [](const DeepDpHit &x, const DeepDpHit &y) { return x.pos1 < y.pos1; });
         size_t u = 0;
         for (size_t q = 1; q < hits.size(); q++) if (hits[u].pos1 < hits[q].pos1) hits[++u] = hits[q];
         hits.resize(u + 1);
