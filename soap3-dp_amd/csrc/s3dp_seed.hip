@@ -182,13 +182,20 @@ __global__ void pairMergeKernel(const uint64_t *keys, uint32_t l0, uint32_t l1, 
                 after = w == 63 ? 0ULL : ~0ULL << (w + 1);
             }
             // the partner: the first right position at or beyond readLoc + lengthLow, if it is not beyond readLoc + lengthHigh
-            uint32_t mateLoc = 0;
+            // (the bounds rise with the left positions: the search starts where the previous 64 positions' first partner was found and gallops from there --
+            //  in a tandem array the partner moves a few entries per left position, and thirteen dependent loads become three)
+            uint32_t mateLoc = 0, a = rLo;
             bool cand = false;
             if (kept) {
-                uint32_t a = rLo, b = rHi;
                 const uint32_t want = readLoc + hLow;
+                uint32_t b = a, span = 1;
+                while (b < rHi && (uint32_t)keys[b] < want) { a = b + 1u; b = span < rHi - b ? b + span : rHi; span <<= 1; }
                 while (a < b) { const uint32_t mid = (a + b) >> 1; if ((uint32_t)keys[mid] < want) a = mid + 1; else b = mid; }
                 if (a < rHi) { mateLoc = (uint32_t)keys[a]; cand = !(readLoc + hHigh < mateLoc); }
+            }
+            {
+                const unsigned long long km = __ballot(kept);
+                if (km) rLo = (uint32_t)__shfl((int)a, __ffsll((long long)km) - 1);          // the lowest kept position's bound: no later one lies before it
             }
             const unsigned long long cm = __ballot(cand);
             if (cand && out) out[hAt + n + (uint32_t)__popcll(cm & ((1ULL << lane) - 1ULL))] = PairCandDev{readLoc, mateLoc, hId + leftIsMate};
