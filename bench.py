@@ -1415,13 +1415,15 @@ def summary_of(out):
     roof = out.get("roofline", {})
     pk = roof.get("per_kernel") or {}
     sm = {"headline_M_reads_per_s": out.get("value"), "ms_per_step": out.get("ms_per_step"), "n_gpus": out.get("n_gpus"), "roofline_frac": roof.get("frac"),
-          "per_kernel": {k: {f: v.get(f) for f in ("ms_per_step", "rank_queries", "sa_reads", "ce_windows", "algorithmic_bytes", "fetched_bytes", "frac")} for k, v in pk.items()}}
+          "per_kernel": {k: {f: v.get(f) for f in ("ms_per_step", "rank_queries", "sa_reads", "ce_windows", "algorithmic_bytes", "algorithmic_bytes_extended", "fetched_bytes",
+                                                    "frac", "frac_extended")} for k, v in pk.items()}}
     lines = ["headline: %.2f M reads/s, %.1f ms per step, roofline.frac %.4f (8d bytes over the search kernels' time)" %
              (out.get("value") or 0.0, out.get("ms_per_step") or 0.0, roof.get("frac") or 0.0)]
     if pk:
-        lines.append("per kernel (ms per step | rank queries | 8d bytes | fetched bytes | frac of 8 TB/s): " + "; ".join(
-            "%s %.1f | %.3g | %.3g | %s | %.3f" % (k, v["ms_per_step"], v["rank_queries"], v["algorithmic_bytes"],
-                                                    ("%.3g" % v["fetched_bytes"]) if v.get("fetched_bytes") else "-", v["frac"]) for k, v in pk.items()))
+        lines.append("per kernel (ms per step | rank queries | 8d bytes | fetched bytes | frac of 8 TB/s, extended): " + "; ".join(
+            "%s %.1f | %.3g | %.3g | %s | %.3f, %.3f" % (k, v["ms_per_step"], v["rank_queries"], v["algorithmic_bytes"],
+                                                          ("%.3g" % v["fetched_bytes"]) if v.get("fetched_bytes") else "-", v["frac"], v.get("frac_extended") or 0.0)
+            for k, v in pk.items()))
     ex = out.get("extras") if isinstance(out.get("extras"), dict) else {}
     for key, tag in (("c3_pairs", "C3"), ("c5_pairs", "C5"), ("c4_pairs", "C4")):
         leg = ex.get(key)

@@ -690,7 +690,7 @@ __global__ void listedKeysKernel(const uint32_t *slots, uint32_t n, const uint32
     }
 }
 
-__global__ void listedPlaceKernel(const uint32_t *sortedSlots, uint32_t n, uint32_t *heavyList, uint32_t *heavyIndex)
+__global__ void listedPutKernel(const uint32_t *sortedSlots, uint32_t n, uint32_t *heavyList, uint32_t *heavyIndex)
 {
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const uint32_t slot = sortedSlots[k];
@@ -760,7 +760,7 @@ void launchListedPlace(const uint32_t *sortedSlots, uint32_t n, uint32_t *heavyL
 {
     if (!n) return;
     const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)n + 255u) / 256u, 8192u);
-    hipLaunchKernelGGL(listedPlaceKernel, dim3(blocks), dim3(256), 0, s, sortedSlots, n, heavyList, heavyIndex);
+    hipLaunchKernelGGL(listedPutKernel, dim3(blocks), dim3(256), 0, s, sortedSlots, n, heavyList, heavyIndex);
 }
 
 void launchUnitChains(const SearchOut &out, uint32_t unitBase, uint32_t nUnits, hipStream_t s)

@@ -14,7 +14,7 @@ pass() {   # name, counters...
   timeout 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/prof_pmc -o pmc -- python3 bench.py $Q --steps 1 --warmup 0 > /dev/null 2> $O/pmc_$name.log; echo "pmc $name rc=$?"
   local f=$(find /tmp/prof_pmc -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
-    for k in first unit ce; do python3 tools/pmc_summary.py "$f" ${k}Kernel > $O/pmc_${name}_$k.txt; done
+    for k in first unit ce; do python3 tools/pmc_summary.py "$f" "s3::${k}Kernel" > $O/pmc_${name}_$k.txt; done
     tail -4 $O/pmc_${name}_unit.txt
     [ "$name" = fetch ] && cp "$f" /tmp/pmc_fetch_0.5.csv && python3 tools/make_pmc_traffic.py "${S3DP_COMMIT:-unknown}" 0.5=/tmp/pmc_fetch_0.5.csv > $O/pmc_traffic.json
   fi

@@ -14,7 +14,7 @@ def role_of(name):
     """first / trunk (the two roles of s3::firstKernel: its last template argument) / unit / ce"""
     if "unitKernel" in name:
         return "unit"
-    if "ceKernel" in name:
+    if "s3::ceKernel(" in name:
         return "ce"
     if "firstKernel" in name:
         args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name else []
@@ -27,7 +27,7 @@ def fetch_of_last_ladder(path):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != "FETCH_SIZE":
             continue
-        k = next((k for k in KERNELS if k in r["Kernel_Name"]), None)
+        k = next((k for k in KERNELS if ("s3::" + k) in r["Kernel_Name"]), None)
         if k is None:
             continue
         per.setdefault(k, collections.OrderedDict()).setdefault(r["Dispatch_Id"], 0.0)
