@@ -9,8 +9,8 @@ if [ ! -f /tmp/c3w/r1.fq ]; then
   timeout 400 python3 bench.py --index-dir /tmp/s3dp_ix --build-only 1 > /dev/null 2> $O/index_build.log; echo "index rc=$?"
   timeout 500 python3 tools/bench_c3.py --pairs ${PAIRS:-10000000} --index-dir /tmp/s3dp_ix --workdir /tmp/c3w > $O/c3.json 2> $O/c3.log; echo "c3 files rc=$?"
 fi
-ls -la /tmp/c3w | head; ln -sf /dev/null /tmp/c3w/h1.gout.1
-run() { local tag=$1; shift; env "$@" timeout 300 soap3-dp_amd/soap3-dp single /tmp/c3w/g.index /tmp/c3w/r1.fq -L 150 -h 1 -s 4 -b 2 -o /tmp/c3w/h1 > $O/h1_$tag.txt 2>&1
+ls -la /tmp/c3w | head; ln -sf /dev/null /tmp/c3w/h1.gout.1; ln -sf /dev/null /tmp/c3w/h1.dpout.1
+run() { local tag=$1; shift; env "$@" timeout 300 soap3-dp_amd/soap3-dp single /tmp/c3w/g.index /tmp/c3w/r1.fq -L 150 -h 1 -b 2 -o /tmp/c3w/h1 > $O/h1_$tag.txt 2>&1
         echo "$tag rc=$? $(grep 'Alignment + output' $O/h1_$tag.txt | tr -s ' ') | $(grep 'Device time' $O/h1_$tag.txt | cut -c8-90) | $(tail -1 $O/h1_$tag.txt | cut -c1-150)"; }
 run chunk256k A=1
 run chunk1m S3DP_CHUNK_READS=1048576
