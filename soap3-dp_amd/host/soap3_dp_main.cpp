@@ -689,8 +689,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     size_t chunkReadsEnv = 0;
     if (const char *e = getenv("S3DP_CHUNK_READS")) chunkReadsEnv = (size_t)strtoull(e, nullptr, 10);
     // (all valid alignments of reads above 120 bases: the 100-base seeds are searched without a hit limit, a read inside a repeat family brings thousands
-    //  of hits, and four batches of 1 Mi such reads grew past the HBM the index leaves on the 3.1 Gbp repeat-rich genome; a quarter of the chunk is also
-    //  the faster one there: 1.95 s against 2.44 s per 1 Mi reads)
+    //  of hits.  Until round 5 four batches of 1 Mi such reads grew past the HBM the index leaves on the 3.1 Gbp repeat-rich genome; the decode works in
+    //  slices now (S3DP_LONG_BUDGET) and 1 Mi / 2 Mi chunks run -- 8.8 / 12.1 s for ten million reads where a quarter of the chunk takes 6.7 s
+    //  (gpurun_out/r05h2): the small chunk stays the default of this mode because it is the faster one)
     const size_t chunkDefault = (alignmentType == 1 && maxReadLength > 120) ? (size_t)1 << 18 : (size_t)1 << 20;
     const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : chunkDefault) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
     // LARGE CHUNKS FIRST (round 5).  The search kernels' cost per read falls with the size of the batch (the tails of their launches: ten million pairs cost
