@@ -651,6 +651,12 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.takeMin = (uint32_t)envSize("S3DP_TAKE_MIN", S3_UNIT_TAKE_MIN);
     if (in.takeMin < 1u) in.takeMin = 1u;
     if (in.takeMin > 64u) in.takeMin = 64u;
+    in.fastTrips = (uint32_t)envSize("S3DP_FAST_TRIPS", S3_UNIT_FAST_TRIPS);
+    in.fastMin = (uint32_t)envSize("S3DP_FAST_MIN", S3_UNIT_FAST_MIN);
+    if (in.fastMin < 1u) in.fastMin = 1u;
+    in.firstFastTrips = (uint32_t)envSize("S3DP_FIRST_FAST_TRIPS", S3_FIRST_FAST_TRIPS);
+    in.firstFastMin = (uint32_t)envSize("S3DP_FIRST_FAST_MIN", S3_FIRST_FAST_MIN);
+    if (in.firstFastMin < 1u) in.firstFastMin = 1u;
     in.ceInlineMax = (uint32_t)envSize("S3DP_CE_INLINE_MAX", 128);
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
     unsigned long long counterSnapAll[S3_COUNTER_WORDS] = {}, counterSnap[S3_NUM_COUNTERS] = {};   // per kernel role; summed over the roles

@@ -16,6 +16,10 @@
 #define S3_UNIT_RDY_BYTES 1536u            // LDS per wave of the unit pass for its tested units (6 words x 64)
 #define S3_UNIT_ADOPT_IDLE 32u             // idle lanes of a wave before frames are adopted
 #define S3_UNIT_TAKE_MIN 8u                // idle lanes of a wave before they take their next units (S3DP_TAKE_MIN)
+#define S3_UNIT_FAST_TRIPS 7u              // step-only trips of a wave of the unit pass between two full trips, at most (S3DP_FAST_TRIPS; 0: none)
+#define S3_UNIT_FAST_MIN 32u               // ... made while this many of its lanes are stepping (S3DP_FAST_MIN)
+#define S3_FIRST_FAST_TRIPS 3u             // the same for the first pass and the trunk pass (S3DP_FIRST_FAST_TRIPS / S3DP_FIRST_FAST_MIN)
+#define S3_FIRST_FAST_MIN 40u
 #define S3_UNIT_NODE_BLOCK 256u           // sub-unit counters a wave of the unit pass reserves with one atomic
 #define S3_NUM_COUNTERS 16                 // 64-bit tallies of a kernel (SearchOut::counters)
 #define S3_NUM_ROLES 4                     // ... kept per kernel of a search pass: first pass, trunk pass, unit pass, check-and-extend (s3_batch_kernel_stats)
@@ -79,6 +83,8 @@ struct SearchIn {
     uint32_t        ceGiveUp;      // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel (S3_CE_GIVE_UP)
     uint32_t        adoptIdle;   // unit pass: idle lanes a wave needs before its busy lanes give frames away (S3_UNIT_ADOPT_IDLE)
     uint32_t        takeMin;     // unit pass: idle lanes a wave lets gather before they start their next units together (S3_UNIT_TAKE_MIN; 1: at once)
+    uint32_t        fastTrips, fastMin;  // unit pass: step-only trips between two full trips (S3_UNIT_FAST_TRIPS), made while fastMin lanes of the wave are stepping
+    uint32_t        firstFastTrips, firstFastMin;  // the same for the first pass and the trunk pass
     uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_common.h)
 };
 

@@ -213,6 +213,73 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         }
     };
 
+
+    // ---- the STEP of a lane, in two halves around the trip's wait (the full trips and the fast trips below share them; s3dp_unit.hip tells why) ----
+    auto stepAsk = [&](uint32_t &iL, uint32_t &iR, bool &needB, int &dir, const uint4 *&ownLine, const uint4 *&aP0, const uint4 *&aP1, const uint32_t *&aD0) {
+        dir = sc.dir();
+        const uint32_t inv = dir < 0 ? ix.fwd.inverseSa0 : ix.rev.inverseSa0;
+        iL = aL;
+        iR = aR + 1u;
+        iL -= (iL > inv);
+        iR -= (iR > inv);
+        const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
+        ownLine = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kL * 4u;
+        needB = kR != kL;
+        if (needB) {
+            const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
+            const bool fw = iR > (kR << 7);
+            aP0 = line;
+            aP1 = line + (fw ? 2 : 1);
+            aD0 = (const uint32_t *)(line + 3) + (fw ? 1 : 0);
+        }
+    };
+    auto stepTake = [&](uint32_t iL, uint32_t iR, bool needB, int dir, const uint4 &p0, const uint4 &p1, uint32_t d0, bool &doSettle, bool &needPop) {
+        const bool exact = ins >= sc.maxErr();
+        const RankSel qL = rankSel(iL), qR = rankSel(iR);
+        const uint4 occA = stage[lane * 4u];
+        const uint32_t offL = (qL.fwd ? 8u : 4u) + (qL.far ? 2u : 0u);
+        const uint4 oL = rankFromWords(qL, occA, myStage32[offL], myStage32[offL + 1u], myStage32[12u + (qL.fwd ? 1u : 0u)]);
+        uint4 oR;
+        if (needB) oR = rankFromWords(qR, p0, qR.far ? p1.z : p1.x, qR.far ? p1.w : p1.y, d0);
+        else {
+            const uint32_t offR = (qR.fwd ? 8u : 4u) + (qR.far ? 2u : 0u);
+            oR = rankFromWords(qR, occA, myStage32[offR], myStage32[offR + 1u], myStage32[12u + (qR.fwd ? 1u : 0u)]);
+        }
+        if constexpr (COUNT) nRank += 2;
+        readRank += 2;
+        const int pos = sc.start() + dir * i;
+        const uint32_t ch = readChar(pos);
+        const uint32_t e1 = oR.y - oL.y, e2 = oR.z - oL.z, e3 = oR.w - oL.w;
+        const uint32_t cOc = ch == 0 ? e1 + e2 + e3 : ch == 1 ? e2 + e3 : ch == 2 ? e3 : 0u;
+        const uint32_t gAl = sel4(oL, ch) + 1u, gAr = sel4(oR, ch), gPr = pR - cOc;         // the continuation (the read's own character)
+        doSettle = true;
+        bool taken = false;
+        const bool trunkHere = onTrunk && s == sStar;                      // no mismatch is taken in this step: the units take them
+        if (trunkHere && (uint32_t)i + 1u < U) leaveState((uint32_t)i);
+        if (!exact && !trunkHere) {
+            const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
+            const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
+            if (a0 || a1 || a2 || a3) {
+                if (sp + 4u > S3_UNIT_STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = F_DONE; sp = 0; tosValid = false; doSettle = false; }
+                else {
+                    // depth-first, children in ascending order, the continuation last: the lane goes on in the smallest child that is alive
+                    const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
+                    const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
+                    const uint32_t kid = a0 ? 0u : a1 ? 1u : a2 ? 2u : 3u;
+                    push(gAl, gAr, gPr, mCont);
+                    if (a3 && kid != 3u) push(oL.w + 1u, oR.w, pR, mKid);
+                    if (a2 && kid != 2u) push(oL.z + 1u, oR.z, pR - e3, mKid);
+                    if (a1 && kid != 1u) push(oL.y + 1u, oR.y, pR - (e2 + e3), mKid);
+                    const uint32_t kOc = kid == 0u ? e1 + e2 + e3 : kid == 1u ? e2 + e3 : kid == 2u ? e3 : 0u;
+                    aL = sel4(oL, kid) + 1u; aR = sel4(oR, kid); pR = pR - kOc;
+                    ins++; i++;
+                    taken = true;
+                }
+            }
+        }
+        if (doSettle && !taken) { aL = gAl; aR = gAr; pR = gPr; i++; }
+    };
+
     for (;;) {
         // ---------- retire finished items; the next (case, strand) of the same read, or the read is done ----------
         if (state == F_DONE) {
@@ -325,24 +392,8 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint4 *aP0 = dummy16, *aP1 = dummy16, *aPT = dummy16;
         const uint32_t *aD0 = ix.pac, *aD1 = ix.pac, *aD2 = ix.pac, *aD3 = ix.pac;
         const uint4 *ownLine = ix.fwd.lines;
-        if (state == F_STEP) {
-            dir = sc.dir();
-            const uint32_t inv = dir < 0 ? ix.fwd.inverseSa0 : ix.rev.inverseSa0;
-            iL = aL;
-            iR = aR + 1u;
-            iL -= (iL > inv);
-            iR -= (iR > inv);
-            const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
-            ownLine = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kL * 4u;
-            needB = kR != kL;
-            if (needB) {
-                const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
-                const bool fw = iR > (kR << 7);
-                aP0 = line;
-                aP1 = line + (fw ? 2 : 1);
-                aD0 = (const uint32_t *)(line + 3) + (fw ? 1 : 0);
-            }
-        } else if (state == F_LOAD) {
+        if (state == F_STEP) stepAsk(iL, iR, needB, dir, ownLine, aP0, aP1, aD0);
+        else if (state == F_LOAD) {
             const uint4 *src = (const uint4 *)(in.readsT + (size_t)rIdx * 2u * wpq + loadOff);   // wpq is a power of two
             aP0 = src;
             if (2u * wpq - loadOff > 4u) aP1 = src + 1;
@@ -410,52 +461,8 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         if (wantTos) { tos = pT; tosValid = true; }
         // a read that has cost this many rank queries is heavy whatever it has found so far (dead ends cost steps, not candidates)
         if (!TRUNK && state == F_STEP && readRank > in.heavyRank) { goHeavy = true; state = F_DONE; sp = 0; tosValid = false; }
-        if (state == F_STEP) {
-            const bool exact = ins >= sc.maxErr();
-            const RankSel qL = rankSel(iL), qR = rankSel(iR);
-            const uint4 occA = stage[lane * 4u];
-            const uint32_t offL = (qL.fwd ? 8u : 4u) + (qL.far ? 2u : 0u);
-            const uint4 oL = rankFromWords(qL, occA, myStage32[offL], myStage32[offL + 1u], myStage32[12u + (qL.fwd ? 1u : 0u)]);
-            uint4 oR;
-            if (needB) oR = rankFromWords(qR, p0, qR.far ? p1.z : p1.x, qR.far ? p1.w : p1.y, d0);
-            else {
-                const uint32_t offR = (qR.fwd ? 8u : 4u) + (qR.far ? 2u : 0u);
-                oR = rankFromWords(qR, occA, myStage32[offR], myStage32[offR + 1u], myStage32[12u + (qR.fwd ? 1u : 0u)]);
-            }
-            if constexpr (COUNT) nRank += 2;
-            readRank += 2;
-            const int pos = sc.start() + dir * i;
-            const uint32_t ch = readChar(pos);
-            const uint32_t e1 = oR.y - oL.y, e2 = oR.z - oL.z, e3 = oR.w - oL.w;
-            const uint32_t cOc = ch == 0 ? e1 + e2 + e3 : ch == 1 ? e2 + e3 : ch == 2 ? e3 : 0u;
-            const uint32_t gAl = sel4(oL, ch) + 1u, gAr = sel4(oR, ch), gPr = pR - cOc;         // the continuation (the read's own character)
-            doSettle = true;
-            bool taken = false;
-            const bool trunkHere = onTrunk && s == sStar;                      // no mismatch is taken in this step: the units take them
-            if (trunkHere && (uint32_t)i + 1u < U) leaveState((uint32_t)i);
-            if (!exact && !trunkHere) {
-                const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
-                const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
-                if (a0 || a1 || a2 || a3) {
-                    if (sp + 4u > S3_UNIT_STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = F_DONE; sp = 0; tosValid = false; doSettle = false; }
-                    else {
-                        // depth-first, children in ascending order, the continuation last: the lane goes on in the smallest child that is alive
-                        const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
-                        const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
-                        const uint32_t kid = a0 ? 0u : a1 ? 1u : a2 ? 2u : 3u;
-                        push(gAl, gAr, gPr, mCont);
-                        if (a3 && kid != 3u) push(oL.w + 1u, oR.w, pR, mKid);
-                        if (a2 && kid != 2u) push(oL.z + 1u, oR.z, pR - e3, mKid);
-                        if (a1 && kid != 1u) push(oL.y + 1u, oR.y, pR - (e2 + e3), mKid);
-                        const uint32_t kOc = kid == 0u ? e1 + e2 + e3 : kid == 1u ? e2 + e3 : kid == 2u ? e3 : 0u;
-                        aL = sel4(oL, kid) + 1u; aR = sel4(oR, kid); pR = pR - kOc;
-                        ins++; i++;
-                        taken = true;
-                    }
-                }
-            }
-            if (doSettle && !taken) { aL = gAl; aR = gAr; pR = gPr; i++; }
-        } else if (state == F_RESUME) { doSettle = true; needPop = false; }
+        if (state == F_STEP) stepTake(iL, iR, needB, dir, p0, p1, d0, doSettle, needPop);
+        else if (state == F_RESUME) { doSettle = true; needPop = false; }
         else if (state == F_POPWAIT) { doSettle = true; needPop = true; }
         else if (state == F_LOAD) {
             // word gi of the read's row in readsT (both orientations, wpq words each) -> LDS word (orientation * wl + w); words past wl are padding
@@ -514,6 +521,56 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             }
         }
         __builtin_amdgcn_wave_barrier();
+
+        // ---------- FAST TRIPS: while at least in.firstFastMin lanes of the wave are stepping, up to in.firstFastTrips trips that do nothing but step; a lane
+        // whose next move is anything else parks until the next full trip (s3dp_unit.hip, "FAST TRIPS").  A lane that has spent its read's rank budget
+        // stays out: the full trip lists its read ----------
+        for (uint32_t ft = 0; ft < in.firstFastTrips; ft++) {
+            const bool stepping = state == F_STEP && (TRUNK || readRank <= in.heavyRank);
+            if ((uint32_t)__popcll(__ballot(stepping)) < in.firstFastMin) break;
+            uint32_t iL = 0, iR = 0;
+            bool needB = false;
+            int dir = 0;
+            const uint4 *ownLine = ix.fwd.lines;
+            const uint4 *aP0 = (const uint4 *)ix.pac, *aP1 = (const uint4 *)ix.pac;
+            const uint32_t *aD0 = ix.pac;
+            if (stepping) stepAsk(iL, iR, needB, dir, ownLine, aP0, aP1, aD0);
+            const uint32_t q16 = lane & 3u, q4 = lane >> 2;
+            const uint32_t ownLo = (uint32_t)(uintptr_t)ownLine, ownHi = (uint32_t)((uintptr_t)ownLine >> 32);
+            auto quadLine = [&](uint32_t owner) -> const uint4 * {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownLo);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownHi);
+                return (const uint4 *)(((uintptr_t)hi << 32) | lo) + q16;
+            };
+            const uint4 va0 = *quadLine(q4), va1 = *quadLine(16u + q4), va2 = *quadLine(32u + q4), va3 = *quadLine(48u + q4);
+            const uint4 p0 = *aP0, p1 = *aP1;
+            const uint32_t d0 = *aD0;
+            stage[(q4) * 4u + q16] = va0;
+            stage[(16u + q4) * 4u + q16] = va1;
+            stage[(32u + q4) * 4u + q16] = va2;
+            stage[(48u + q4) * 4u + q16] = va3;
+            __builtin_amdgcn_wave_barrier();
+            if (stepping) {
+                bool doSettle = false, needPop = false;
+                stepTake(iL, iR, needB, dir, p0, p1, d0, doSettle, needPop);
+                if (doSettle) {
+                    // settle()'s way back to F_STEP, and nothing else of it
+                    bool go = false;
+                    if (!needPop) {
+                        const bool exact = ins >= sc.maxErr();
+                        int lenEff = sc.len();
+                        if (!exact && sc.minErr() > ins + 1) lenEff -= sc.minErr() - ins - 1;
+                        if (i < lenEff && aL <= aR) {
+                            const int pos = sc.start() + sc.dir() * i;
+                            go = !((aR - aL) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd());
+                            if (in.earlyCe && s == 0 && (aR - aL) < in.earlyCe) go = false;     // (the early hand-over is settle()'s business)
+                        }
+                    }
+                    state = go ? F_STEP : needPop ? F_POPWAIT : F_RESUME;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 #undef casIdx
 #undef subIdx

@@ -206,6 +206,78 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         }
     };
 
+
+    // ---- the STEP of a lane, in two halves around the trip's wait (the slow trips and the fast trips below share them) ----
+    // what a stepping lane asks for: its two rank indices, the line of the left one (fetched by its quad) and -- when the right one lies in another line -- the
+    // three pieces of that line it reads itself
+    auto stepAsk = [&](uint32_t &iL, uint32_t &iR, bool &needB, int &dir, const uint4 *&ownLine, const uint4 *&aP0, const uint4 *&aP1, const uint32_t *&aD0) {
+        dir = sc.dir();
+        const uint32_t inv = dir < 0 ? ix.fwd.inverseSa0 : ix.rev.inverseSa0;
+        iL = aL;
+        iR = aR + 1u;
+        iL -= (iL > inv);
+        iR -= (iR > inv);
+        const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
+        ownLine = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kL * 4u;
+        needB = kR != kL;
+        if (needB) {
+            const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
+            const bool fw = iR > (kR << 7);
+            aP0 = line;
+            aP1 = line + (fw ? 2 : 1);
+            aD0 = (const uint32_t *)(line + 3) + (fw ? 1 : 0);
+        }
+    };
+    // the step itself, from the staged line: ranks, children, pushes.  Leaves doSettle / needPop for the lane's next move (doSettle false: the lane is done)
+    auto stepTake = [&](uint32_t iL, uint32_t iR, bool needB, int dir, const uint4 &p0, const uint4 &p1, uint32_t d0, bool &doSettle, bool &needPop) {
+        const bool exact = ins >= sc.maxErr();
+        const RankSel qL = rankSel(iL), qR = rankSel(iR);
+        const uint4 occA = stage[lane * 4u];
+        // own line in LDS as words: [0..3] counts, [4..7] half before (reversed), [8..11] half after, [12] / [13] precounts
+        const uint32_t offL = (qL.fwd ? 8u : 4u) + (qL.far ? 2u : 0u);
+        const uint4 oL = rankFromWords(qL, occA, myStage32[offL], myStage32[offL + 1u], myStage32[12u + (qL.fwd ? 1u : 0u)]);
+        uint4 oR;
+        if (needB) oR = rankFromWords(qR, p0, qR.far ? p1.z : p1.x, qR.far ? p1.w : p1.y, d0);
+        else {
+            const uint32_t offR = (qR.fwd ? 8u : 4u) + (qR.far ? 2u : 0u);
+            oR = rankFromWords(qR, occA, myStage32[offR], myStage32[offR + 1u], myStage32[12u + (qR.fwd ? 1u : 0u)]);
+        }
+        if constexpr (COUNT) nRank += 2;
+        const int pos = sc.start() + dir * i;
+        const uint32_t ch = readChar(pos);
+        // child ranges: the active range advances by rank, the passive one shrinks by the occurrences of the larger symbols
+        const uint32_t e1 = oR.y - oL.y, e2 = oR.z - oL.z, e3 = oR.w - oL.w;
+        const uint32_t cOc = ch == 0 ? e1 + e2 + e3 : ch == 1 ? e2 + e3 : ch == 2 ? e3 : 0u;
+        const uint32_t gAl = sel4(oL, ch) + 1u, gAr = sel4(oR, ch), gPr = pR - cOc;         // the continuation (the read's own character)
+        doSettle = true;
+        const bool branchOnly = first;                                     // the unit's position: only the mismatch children (the continuation belongs to the later units)
+        first = false;
+        bool taken = false;                                                // the lane goes on in a mismatch child
+        if (!exact) {
+            const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
+            const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
+            if (a0 || a1 || a2 || a3) {
+                if (sp - sb + 4u > S3_UNIT_STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = U_DONE; sp = sb; tosValid = false; doSettle = false; }
+                else {
+                    // depth-first, children in ascending order, the continuation last: the lane goes on in the smallest child that is alive, the
+                    // others wait on the stack (pushed in descending order), the continuation below them
+                    const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
+                    const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
+                    const uint32_t kid = a0 ? 0u : a1 ? 1u : a2 ? 2u : 3u;
+                    if (!branchOnly) push(gAl, gAr, gPr, mCont);
+                    if (a3 && kid != 3u) push(oL.w + 1u, oR.w, pR, mKid);
+                    if (a2 && kid != 2u) push(oL.z + 1u, oR.z, pR - e3, mKid);
+                    if (a1 && kid != 1u) push(oL.y + 1u, oR.y, pR - (e2 + e3), mKid);
+                    const uint32_t kOc = kid == 0u ? e1 + e2 + e3 : kid == 1u ? e2 + e3 : kid == 2u ? e3 : 0u;
+                    aL = sel4(oL, kid) + 1u; aR = sel4(oR, kid); pR = pR - kOc;
+                    ins++; i++;
+                    taken = true;
+                }
+            } else if (branchOnly) needPop = true;                         // no child alive: the unit is empty
+        } else if (branchOnly) needPop = true;
+        if (doSettle && !needPop && !taken) { aL = gAl; aR = gAr; pR = gPr; i++; }
+    };
+
     for (;;) {
         // ---------- retire finished units (their occurrences were booked at the end of the trip that finished them) ----------
         if (state == U_DONE) {
@@ -313,24 +385,8 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint4 *ownLine = ix.fwd.lines;                                    // the 64-byte line this lane wants fetched by its quad (nothing: line 0)
         const uint4 *aP0 = dummy16, *aP1 = dummy16, *aPT = dummy16;
         const uint32_t *aD0 = ix.pac, *aCut = ix.pac;
-        if (state == U_STEP) {
-            dir = sc.dir();
-            const uint32_t inv = dir < 0 ? ix.fwd.inverseSa0 : ix.rev.inverseSa0;
-            iL = aL;
-            iR = aR + 1u;
-            iL -= (iL > inv);
-            iR -= (iR > inv);
-            const uint32_t kL = (iL + 63u) >> 7, kR = (iR + 63u) >> 7;
-            ownLine = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kL * 4u;
-            needB = kR != kL;
-            if (needB) {
-                const uint4 *line = (dir < 0 ? ix.fwd.lines : ix.rev.lines) + (size_t)kR * 4u;
-                const bool fw = iR > (kR << 7);
-                aP0 = line;
-                aP1 = line + (fw ? 2 : 1);
-                aD0 = (const uint32_t *)(line + 3) + (fw ? 1 : 0);
-            }
-        } else if (state == U_CE_TEXT) {
+        if (state == U_STEP) stepAsk(iL, iR, needB, dir, ownLine, aP0, aP1, aD0);
+        else if (state == U_CE_TEXT) {
             const int ceT = (int)(ceWhere & 7u), ceII = (int)((ceWhere >> 3) & 0x7FFu);
             const S3Step st = stepAt(ceT);
             const int pos = st.start + st.dir * ceII;
@@ -426,54 +482,8 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if constexpr (COUNT) nCutMid++;
             state = U_DONE; sp = sb; tosValid = false;
         }
-        if (state == U_STEP) {
-            const bool exact = ins >= sc.maxErr();
-            const RankSel qL = rankSel(iL), qR = rankSel(iR);
-            const uint4 occA = stage[lane * 4u];
-            // own line in LDS as words: [0..3] counts, [4..7] half before (reversed), [8..11] half after, [12] / [13] precounts
-            const uint32_t offL = (qL.fwd ? 8u : 4u) + (qL.far ? 2u : 0u);
-            const uint4 oL = rankFromWords(qL, occA, myStage32[offL], myStage32[offL + 1u], myStage32[12u + (qL.fwd ? 1u : 0u)]);
-            uint4 oR;
-            if (needB) oR = rankFromWords(qR, p0, qR.far ? p1.z : p1.x, qR.far ? p1.w : p1.y, d0);
-            else {
-                const uint32_t offR = (qR.fwd ? 8u : 4u) + (qR.far ? 2u : 0u);
-                oR = rankFromWords(qR, occA, myStage32[offR], myStage32[offR + 1u], myStage32[12u + (qR.fwd ? 1u : 0u)]);
-            }
-            if constexpr (COUNT) nRank += 2;
-            const int pos = sc.start() + dir * i;
-            const uint32_t ch = readChar(pos);
-            // child ranges: the active range advances by rank, the passive one shrinks by the occurrences of the larger symbols
-            const uint32_t e1 = oR.y - oL.y, e2 = oR.z - oL.z, e3 = oR.w - oL.w;
-            const uint32_t cOc = ch == 0 ? e1 + e2 + e3 : ch == 1 ? e2 + e3 : ch == 2 ? e3 : 0u;
-            const uint32_t gAl = sel4(oL, ch) + 1u, gAr = sel4(oR, ch), gPr = pR - cOc;         // the continuation (the read's own character)
-            doSettle = true;
-            const bool branchOnly = first;                                     // the unit's position: only the mismatch children (the continuation belongs to the later units)
-            first = false;
-            bool taken = false;                                                // the lane goes on in a mismatch child
-            if (!exact) {
-                const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
-                const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
-                if (a0 || a1 || a2 || a3) {
-                    if (sp - sb + 4u > S3_UNIT_STACK) { atomicOr(out.flags, S3_FLAG_STACK_OVERFLOW); state = U_DONE; sp = sb; tosValid = false; doSettle = false; }
-                    else {
-                        // depth-first, children in ascending order, the continuation last: the lane goes on in the smallest child that is alive, the
-                        // others wait on the stack (pushed in descending order), the continuation below them
-                        const uint32_t mCont = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)ins << 14) | ((uint32_t)occ << 17);
-                        const uint32_t mKid = (uint32_t)s | ((uint32_t)(i + 1) << 3) | ((uint32_t)(ins + 1) << 14) | ((uint32_t)occ << 17);
-                        const uint32_t kid = a0 ? 0u : a1 ? 1u : a2 ? 2u : 3u;
-                        if (!branchOnly) push(gAl, gAr, gPr, mCont);
-                        if (a3 && kid != 3u) push(oL.w + 1u, oR.w, pR, mKid);
-                        if (a2 && kid != 2u) push(oL.z + 1u, oR.z, pR - e3, mKid);
-                        if (a1 && kid != 1u) push(oL.y + 1u, oR.y, pR - (e2 + e3), mKid);
-                        const uint32_t kOc = kid == 0u ? e1 + e2 + e3 : kid == 1u ? e2 + e3 : kid == 2u ? e3 : 0u;
-                        aL = sel4(oL, kid) + 1u; aR = sel4(oR, kid); pR = pR - kOc;
-                        ins++; i++;
-                        taken = true;
-                    }
-                } else if (branchOnly) needPop = true;                         // no child alive: the unit is empty
-            } else if (branchOnly) needPop = true;
-            if (doSettle && !needPop && !taken) { aL = gAl; aR = gAr; pR = gPr; i++; }
-        } else if (state == U_RESUME) { doSettle = true; needPop = false; }
+        if (state == U_STEP) stepTake(iL, iR, needB, dir, p0, p1, d0, doSettle, needPop);
+        else if (state == U_RESUME) { doSettle = true; needPop = false; }
         else if (state == U_POPWAIT) { doSettle = true; needPop = true; }
         else if (state == U_ADOPT) {
             aL = p0.x; aR = p0.y; pR = p0.z;
@@ -637,6 +647,59 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             }
         }
         __builtin_amdgcn_wave_barrier();
+
+        // ---------- FAST TRIPS (round 5).  The trip above carries every path of the state machine, and with 64 lanes some lane needs every one of them on
+        // nearly every trip: ~890 vector instructions per trip at 26 active lanes of 64 (profiles/README_r05.md), of which the step itself is a third -- the
+        // pass is bound by vector issue, not by its lines.  So while at least in.fastMin lanes of the wave are stepping, up to in.fastTrips trips that do
+        // NOTHING BUT STEP follow: the stepping lanes' lines, the one wait, ranks, children, pushes, and the test whether the lane's next move is a
+        // step again.  A lane whose next move is anything else -- pop, record, step boundary, check-and-extend, end of the unit -- parks in U_RESUME /
+        // U_POPWAIT and makes it in the next full trip, together with the other lanes parked meanwhile: the rare paths run for many lanes at a time
+        // instead of two or three.  A lane is nobody else's business (the cut and the booking are order-free), so the records do not change. ----------
+        for (uint32_t ft = 0; ft < in.fastTrips; ft++) {
+            if ((uint32_t)__popcll(__ballot(state == U_STEP)) < in.fastMin) break;
+            uint32_t iL = 0, iR = 0;
+            bool needB = false;
+            int dir = 0;
+            const uint4 *ownLine = ix.fwd.lines;
+            const uint4 *aP0 = (const uint4 *)ix.pac, *aP1 = (const uint4 *)ix.pac;
+            const uint32_t *aD0 = ix.pac;
+            if (state == U_STEP) stepAsk(iL, iR, needB, dir, ownLine, aP0, aP1, aD0);
+            const uint32_t q16 = lane & 3u, q4 = lane >> 2;
+            const uint32_t ownLo = (uint32_t)(uintptr_t)ownLine, ownHi = (uint32_t)((uintptr_t)ownLine >> 32);
+            auto quadLine = [&](uint32_t owner) -> const uint4 * {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownLo);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownHi);
+                return (const uint4 *)(((uintptr_t)hi << 32) | lo) + q16;
+            };
+            const uint4 va0 = *quadLine(q4), va1 = *quadLine(16u + q4), va2 = *quadLine(32u + q4), va3 = *quadLine(48u + q4);
+            const uint4 p0 = *aP0, p1 = *aP1;
+            const uint32_t d0 = *aD0;
+            stage[(q4) * 4u + q16] = va0;
+            stage[(16u + q4) * 4u + q16] = va1;
+            stage[(32u + q4) * 4u + q16] = va2;
+            stage[(48u + q4) * 4u + q16] = va3;
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (COUNT) { waveTrips++; if (state != U_IDLE) { unitTrips++; laneTrips++; if (unitTrips > maxUnitTrips) maxUnitTrips = unitTrips; } dStepLane += state == U_STEP ? 1u : 0u; }
+            if (state == U_STEP) {
+                bool doSettle = false, needPop = false;
+                stepTake(iL, iR, needB, dir, p0, p1, d0, doSettle, needPop);
+                if (doSettle) {
+                    // settle()'s way back to U_STEP, and nothing else of it
+                    bool go = false;
+                    if (!needPop) {
+                        const bool exact = ins >= sc.maxErr();
+                        int lenEff = sc.len();
+                        if (!exact && sc.minErr() > ins + 1) lenEff -= sc.minErr() - ins - 1;
+                        if (i < lenEff && aL <= aR) {
+                            const int pos = sc.start() + sc.dir() * i;
+                            go = !((aR - aL) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd());
+                        }
+                    }
+                    state = go ? U_STEP : needPop ? U_POPWAIT : U_RESUME;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 #undef casIdx
 #undef subIdx
