@@ -447,7 +447,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
-    BA(dRecs, recCap); BA(dOrdered, recCap); BA(dOrdValid, recCap); b->ordCap = recCap;
+    BA(dRecs, recCap); BA(dOrdered, recCap); BA(dOrdValid, recCap + 8); b->ordCap = recCap;     // (+ 8: the long merge / decode kernels read the bytes eight at a time)
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, S3_COUNTER_WORDS); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
@@ -732,7 +732,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             // S3DP_VERBOSE=1 with counters enabled: reads, listed reads, rank queries and milliseconds of every launch of this pass (stderr)
             static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
             unsigned long long rankSeen = counterSnap[0], tripsSeen = counterSnap[6], wavesSeen = counterSnap[9], adoptSeen = counterSnap[8], saSeen = counterSnap[2], ceSeen = counterSnap[3], accSeen = counterSnap[10];
-            unsigned long long dSeen[5] = {counterSnap[11], counterSnap[12], counterSnap[13], counterSnap[14], counterSnap[15]};
+            unsigned long long dSeen[8] = {counterSnap[11], counterSnap[12], counterSnap[13], counterSnap[14], counterSnap[15], counterSnap[16], counterSnap[17], counterSnap[18]};
             auto lapT = std::chrono::steady_clock::now();
             auto lap = [&](const char *what, uint64_t units) {
                 if (!verbose || !b->counting) return;
@@ -747,7 +747,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                 if (c[9] - wavesSeen)
                     fprintf(stderr, "[s3dp]   unit kernel paths: %llu wave trips with a lane in check-and-extend (%llu lane trips), %llu stepping lane trips, %llu lane pops, %llu wave trips that book\n",
                             c[11] - dSeen[0], c[12] - dSeen[1], c[13] - dSeen[2], c[15] - dSeen[4], c[14] - dSeen[3]);
-                dSeen[0] = c[11]; dSeen[1] = c[12]; dSeen[2] = c[13]; dSeen[3] = c[14]; dSeen[4] = c[15];
+                if (c[16] - dSeen[5])
+                    fprintf(stderr, "[s3dp]   unit kernel fast trips: %llu of the wave trips (%llu stepping lane trips in them); %llu lane trips parked at a full trip\n",
+                            c[16] - dSeen[5], c[17] - dSeen[6], c[18] - dSeen[7]);
+                dSeen[0] = c[11]; dSeen[1] = c[12]; dSeen[2] = c[13]; dSeen[3] = c[14]; dSeen[4] = c[15]; dSeen[5] = c[16]; dSeen[6] = c[17]; dSeen[7] = c[18];
                 rankSeen = c[0]; tripsSeen = c[6]; wavesSeen = c[9]; adoptSeen = c[8]; saSeen = c[2]; ceSeen = c[3]; accSeen = c[10]; lapT = now;
                 for (int r = 0; r < S3_NUM_ROLES; r++) (void)hipMemsetAsync(b->dCounters + r * S3_NUM_COUNTERS + 7, 0, 8, b->stream);
             };
@@ -932,7 +935,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             if (slots > cap) return fail(S3_EOVERFLOW, "ordering buffer overflow at the 32-bit limit");
             int rc = bgrow(b, &b->dOrdered, cap, 0);
             if (rc) return rc;
-            if ((rc = bgrow(b, &b->dOrdValid, cap, 0))) return rc;
+            if ((rc = bgrow(b, &b->dOrdValid, cap + 8, 0))) return rc;
             b->ordCap = (uint32_t)cap;
         }
     }

@@ -3,6 +3,9 @@
 // search stands in the model) into the record stream, reserve one sequence number per candidate and go on.  This kernel verifies the candidates -- suffix-
 // array value, then the text under the rest of the model against the oriented read, 16 characters per XOR / fold / popcount -- and appends the accepted
 // ones under their reserved numbers, so the record stream keeps the CPU path's order; rejected candidates leave holes the ordering pass skips.
+// (Round 5 tried the text a second time in OVERLAPPING 64-byte lines -- line k = the 256 characters from 128 k on, so that no window straddles two lines:
+//  1.0 text lines per candidate instead of 1.4 -- and the kernel got SLOWER, 72.4 -> 78.2 ms per ladder: twice the text's bytes halve what the 256 MB
+//  of last-level cache hold of it, and that costs more than the second lines did.  profiles/README_r05.md.)
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>

@@ -21,7 +21,7 @@
 #define S3_FIRST_FAST_TRIPS 3u             // the same for the first pass and the trunk pass (S3DP_FIRST_FAST_TRIPS / S3DP_FIRST_FAST_MIN)
 #define S3_FIRST_FAST_MIN 40u
 #define S3_UNIT_NODE_BLOCK 256u           // sub-unit counters a wave of the unit pass reserves with one atomic
-#define S3_NUM_COUNTERS 16                 // 64-bit tallies of a kernel (SearchOut::counters)
+#define S3_NUM_COUNTERS 20                 // 64-bit tallies of a kernel (SearchOut::counters)
 #define S3_NUM_ROLES 4                     // ... kept per kernel of a search pass: first pass, trunk pass, unit pass, check-and-extend (s3_batch_kernel_stats)
 #define S3_COUNTER_WORDS (S3_NUM_COUNTERS * S3_NUM_ROLES)
 #define S3_FLAG_STACK_OVERFLOW 1u

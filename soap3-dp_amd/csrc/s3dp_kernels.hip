@@ -173,20 +173,35 @@ __device__ __forceinline__ uint32_t waveExclusiveSum(uint32_t v, uint32_t lane, 
     return inc - v;
 }
 
-// The long kernels walk a read's slice S3_LONG_STEPS x 64 slots per trip: the validity bytes of the trip are loaded first (and those of the next trip are
-// already on their way), then the 16-byte entries of the slots that hold a record -- one in ten -- all issued before the first is used; the 64-slot steps
-// of the trip are then worked through in order.  (Round 3 loaded 64 sixteen-byte entries per step, holes included, one step ahead: 2 us per step, latency.)
-#define S3_LONG_STEPS 8u
-struct LongTrip { uint32_t v[S3_LONG_STEPS]; };
-__device__ __forceinline__ LongTrip loadTripValid(const MergeArgs &a, uint32_t base, uint32_t end, uint32_t lane)
+// The long kernels walk a read's slice 512 slots per trip, and only the slots that hold a record get a lane: nine in ten slots of a read inside a repeat
+// family are the sequence numbers of rejected check-and-extend candidates.  A lane reads the validity bytes of EIGHT consecutive slots as one 8-byte word
+// (the next trip's are already on their way), the wave numbers the records of the trip through (one prefix sum over the lanes' counts) and writes their slot
+// numbers to LDS in order; then 64 RECORDS at a time -- not 64 slots -- are loaded and go through the prefix sums of the cut.  (Round 3 loaded 64 sixteen-byte
+// entries per step, holes included; rounds 4-5 walked the trip in eight steps of 64 slots, a prefix-sum round each, for the four or five records a step held.)
+#define S3_LONG_TRIP 512u
+__device__ __forceinline__ uint2 loadTripValid(const MergeArgs &a, uint32_t tb, uint32_t end, uint32_t lane)
 {
-    LongTrip t;
-#pragma unroll
-    for (uint32_t u = 0; u < S3_LONG_STEPS; u++) {
-        const uint32_t pos = base + 64u * u + lane;
-        t.v[u] = pos < end ? (uint32_t)a.valid[pos] : 0u;                   // (base < end <= the array's length: a slot beyond `end` is not touched)
+    const uint32_t pos = tb + 8u * lane;                                       // (tb is a multiple of 8 and the array 8-byte aligned with 8 bytes to spare: s3dp_api.hip)
+    return pos < end ? *(const uint2 *)(a.valid + pos) : make_uint2(0u, 0u);
+}
+// the trip's records, in slot order: their slot numbers in idx[0 .. V), V returned (wave-uniform)
+__device__ __forceinline__ uint32_t tripRecords(uint2 v, uint32_t tb, uint32_t beg, uint32_t end, uint32_t lane, uint32_t *idx)
+{
+    const uint32_t pos = tb + 8u * lane;
+    auto nz = [](uint32_t x) -> uint32_t { x |= x >> 4; x |= x >> 2; x |= x >> 1; x &= 0x01010101u; return ((x * 0x01020408u) >> 24) & 0xFu; };   // bit q: byte q is not zero
+    uint32_t bits = nz(v.x) | nz(v.y) << 4;
+    if (pos < beg) bits = beg - pos >= 8u ? 0u : bits & (0xFFu << (beg - pos));
+    if (pos >= end) bits = 0u;
+    else if (end - pos < 8u) bits &= (1u << (end - pos)) - 1u;
+    uint32_t V = 0;
+    uint32_t k = waveExclusiveSum((uint32_t)__popc(bits), lane, V);
+    while (bits) {
+        const uint32_t q = (uint32_t)__ffs((int)bits) - 1u;
+        bits &= bits - 1u;
+        idx[k++] = pos + q;
     }
-    return t;
+    __builtin_amdgcn_wave_barrier();
+    return V;
 }
 
 // Which listed read a wave of the long kernels takes next.  dealt == nullptr: a fixed deal, read waveId + k * nWaves (`strided` is that index).  Otherwise
@@ -206,27 +221,26 @@ __device__ __forceinline__ uint32_t nextLongRead(uint32_t *dealt, uint32_t strid
 // candidates (nine in ten entries of a read inside a repeat family) cost a byte of a coalesced load instead of a turn of a serial loop
 __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
 {
+    __shared__ uint32_t sIdx[4][S3_LONG_TRIP];
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *idx = sIdx[threadIdx.x >> 6];
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t nLong = *a.longCount, groups = a.nCases * 2u;
-    for (uint32_t idx = nextLongRead(a.dealt, 0, waveId, lane); idx < nLong; idx = nextLongRead(a.dealt, idx + nWaves, waveId, lane)) {
-        const uint32_t slot = a.longList[idx];
+    for (uint32_t li = nextLongRead(a.dealt, 0, waveId, lane); li < nLong; li = nextLongRead(a.dealt, li + nWaves, waveId, lane)) {
+        const uint32_t slot = a.longList[li];
         uint32_t beg, end;
         readSlice(a, slot, groups, beg, end);
         uint32_t total = 0, nRec = 0, nOcc = 0, nCe = 0;                      // nRec / nOcc / nCe / we: per-lane partial sums
         uint32_t we[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        LongTrip next = loadTripValid(a, beg, end, lane);
-        for (uint32_t base = beg; base < end && total < a.maxOut; base += 64u * S3_LONG_STEPS) {
-            const LongTrip cur = next;
-            if (base + 64u * S3_LONG_STEPS < end) next = loadTripValid(a, base + 64u * S3_LONG_STEPS, end, lane);
-            uint4 rr[S3_LONG_STEPS];
-#pragma unroll
-            for (uint32_t u = 0; u < S3_LONG_STEPS; u++) rr[u] = a.ordered[cur.v[u] ? base + 64u * u + lane : beg];     // (a lane without a record reads a line the wave has)
-#pragma unroll
-            for (uint32_t u = 0; u < S3_LONG_STEPS; u++) {
-                if (total >= a.maxOut) break;
-                const uint4 r = rr[u];
-                const bool valid = cur.v[u] != 0u;
+        const uint32_t tb0 = beg & ~7u;
+        uint2 next = loadTripValid(a, tb0, end, lane);
+        for (uint32_t tb = tb0; tb < end && total < a.maxOut; tb += S3_LONG_TRIP) {
+            const uint2 cur = next;
+            if (tb + S3_LONG_TRIP < end) next = loadTripValid(a, tb + S3_LONG_TRIP, end, lane);
+            const uint32_t V = tripRecords(cur, tb, beg, end, lane, idx);
+            for (uint32_t r0 = 0; r0 < V && total < a.maxOut; r0 += 64u) {
+                const bool valid = r0 + lane < V;
+                const uint4 r = a.ordered[valid ? idx[r0 + lane] : beg];             // (a lane without a record reads a line the wave has)
                 const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
                 // a range is never longer than maxOut can use: clamp before the prefix sum (32-bit)
                 uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;
@@ -241,6 +255,7 @@ __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
                 nRec += incl ? 1u : 0u; nOcc += c; nCe += incl ? kind : 0u;
                 total = total + sum > a.maxOut ? a.maxOut : total + sum;
             }
+            __builtin_amdgcn_wave_barrier();
         }
         (void)waveExclusiveSum(nRec, lane, nRec); (void)waveExclusiveSum(nOcc, lane, nOcc); (void)waveExclusiveSum(nCe, lane, nCe);
 #pragma unroll
@@ -334,29 +349,28 @@ __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffset
 __global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffsets, uint32_t occBase, uint32_t occCap, uint32_t *occPos,
                                                         uint32_t *occMeta, uint32_t *flags)
 {
+    __shared__ uint32_t sIdx[4][S3_LONG_TRIP];
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *idx = sIdx[threadIdx.x >> 6];
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t nLong = *a.longCount, groups = a.nCases * 2u;
-    for (uint32_t idx = nextLongRead(a.dealt, 0, waveId, lane); idx < nLong; idx = nextLongRead(a.dealt, idx + nWaves, waveId, lane)) {
-        const uint32_t slot = a.longList[idx];
+    for (uint32_t li = nextLongRead(a.dealt, 0, waveId, lane); li < nLong; li = nextLongRead(a.dealt, li + nWaves, waveId, lane)) {
+        const uint32_t slot = a.longList[li];
         if (a.decodeMask && a.decodeMask[slot] != a.decodeWant) continue;
         uint32_t beg, end;
         readSlice(a, slot, groups, beg, end);
         if ((uint64_t)occBase + occOffsets[slot + 1] > occCap) { if (lane == 0) atomicOr(flags, S3_FLAG_OCC_OVERFLOW); continue; }
         uint32_t o = occBase + occOffsets[slot], oSa = o + a.ceCounts[slot];  // wave-uniform cursors: check-and-extend hits / expanded SA ranges
         uint32_t total = 0;
-        LongTrip next = loadTripValid(a, beg, end, lane);
-        for (uint32_t base0 = beg; base0 < end && total < a.maxOut; base0 += 64u * S3_LONG_STEPS) {
-          const LongTrip cur = next;
-          if (base0 + 64u * S3_LONG_STEPS < end) next = loadTripValid(a, base0 + 64u * S3_LONG_STEPS, end, lane);
-          uint4 rr[S3_LONG_STEPS];
-#pragma unroll
-          for (uint32_t u = 0; u < S3_LONG_STEPS; u++) rr[u] = a.ordered[cur.v[u] ? base0 + 64u * u + lane : beg];
-#pragma unroll
-          for (uint32_t u = 0; u < S3_LONG_STEPS; u++) {
-            if (total >= a.maxOut) break;
-            const uint4 r = rr[u];
-            const bool valid = cur.v[u] != 0u;
+        const uint32_t tb0 = beg & ~7u;
+        uint2 next = loadTripValid(a, tb0, end, lane);
+        for (uint32_t tb = tb0; tb < end && total < a.maxOut; tb += S3_LONG_TRIP) {
+          const uint2 cur = next;
+          if (tb + S3_LONG_TRIP < end) next = loadTripValid(a, tb + S3_LONG_TRIP, end, lane);
+          const uint32_t V = tripRecords(cur, tb, beg, end, lane, idx);
+          for (uint32_t r0 = 0; r0 < V && total < a.maxOut; r0 += 64u) {
+            const bool valid = r0 + lane < V;
+            const uint4 r = a.ordered[valid ? idx[r0 + lane] : beg];
             const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
             uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;
             if (cnt > a.maxOut) cnt = a.maxOut;
@@ -388,6 +402,7 @@ __global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix
             o += nKind; oSa += nSa;
             total = total + sum > a.maxOut ? a.maxOut : total + sum;
           }
+          __builtin_amdgcn_wave_barrier();
         }
     }
 }
