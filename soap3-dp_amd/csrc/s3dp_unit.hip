@@ -278,38 +278,41 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         if (doSettle && !needPop && !taken) { aL = gAl; aR = gAr; pR = gPr; i++; }
     };
 
-    // ---- the LOAD of a lane that took a unit: its strand of the read into LDS, eight words per trip, then the unit's first move (both kinds of trip) ----
-    auto loadAsk = [&](const uint4 *&aP0, const uint4 *&aP1, const uint32_t *&aD0) {
-        const uint4 *src = (const uint4 *)(in.readsT + (size_t)aux * 2u * wpq + (size_t)(subN & 1u) * wpq + loadOff);
-        aP0 = src;
-        if (wpq - loadOff > 4u) aP1 = src + 1;
-        if constexpr (!UNIFORM) aD0 = in.readLengths + aux;
-    };
-    auto loadTake = [&](const uint4 &p0, const uint4 &p1, uint32_t d0, bool &doSettle, bool &needPop) {
-        const uint32_t vals[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-#pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t w = loadOff + k;
-            if (w < wl) ro[w * 64u + lane] = vals[k];
-        }
-        loadOff += 8;
-        if constexpr (!UNIFORM) Li = (int)d0;
-        if (loadOff >= wl || loadOff >= wpq) {
-            loadStepCache();
-            {
-                // the trunk state {l, r, rev l} the step's way round
-                const uint32_t l = aL, r = aR, rvl = pR;
-                if (sc.dir() < 0) pR = rvl + (r - l);
-                else { aL = rvl; aR = rvl + (r - l); pR = r; }
-            }
-            if (first) state = U_STEP;
-            else { i = sc.len(); doSettle = true; needPop = false; }         // the unit without a mismatch in this step: behind its last position
-        }
-    };
-
     for (;;) {
-        // (finished units were retired and the idle lanes given their next units at the end of the previous full trip, below)
+        // ---------- retire finished units (their occurrences were booked at the end of the trip that finished them) ----------
+        if (state == U_DONE) {
+            if (seq != 0u || cntIdx >= out.dynBase) out.itemCounts[cntIdx] = seq;      // (a unit that wrote nothing leaves the counter alone: the trunk lane may own it)
+            state = U_IDLE;
+        }
+        // ---------- idle lanes take tested units ----------
         unsigned long long idleMask = __ballot(state == U_IDLE);
+        // (starting units is a divergent path of some two hundred instructions, and two or three lanes of a wave finish a unit on EVERY trip: the idle lanes
+        //  wait until in.takeMin of them can start together -- or nothing else is running, or the queue is empty and waiting would only stretch the tail)
+        if (idleMask && rdyTaken < rdyCount && ((uint32_t)__popcll(idleMask) >= in.takeMin || queueEmpty)) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+            const uint32_t e = rdyTaken + rank, avail = rdyCount - rdyTaken;
+            if (state == U_IDLE && rank < avail) {
+                aL = rdy[e]; aR = rdy[64u + e]; pR = rdy[128u + e];          // the trunk state {l, r, rev l}: turned the step's way when the step is known
+                listed = rdy[192u + e]; aux = rdy[320u + e];
+                const uint32_t sp_ = rdy[256u + e];                          // item | position << 8 (the division is made once per chunk, where the chunk is tested)
+                const uint32_t sub = sp_ & 0xFFu, p = sp_ >> 8;
+                unitInRead = sub * U + p;
+                const uint32_t cas = sub >> 1;
+                subN = sub | ((in.nStepsPacked >> (3u * cas)) & 7u) << 8;
+                s = (int)((in.sStarPacked >> (3u * cas)) & 7u);
+                cntIdx = in.unitBase + listed * groups * U + unitInRead;
+                first = p + 1u != U;
+                i = (int)p;                                                 // (the unit without a mismatch in this step: behind the step's last position, set when the step is known)
+                ins = 0; occ = 0; seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
+                ceHist = 0; countPending = 0;
+                if constexpr (COUNT) unitTrips = 0;
+                loadOff = 0;
+                state = U_LOAD;
+            }
+            const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+            rdyTaken += nIdle < avail ? nIdle : avail;
+            idleMask = __ballot(state == U_IDLE);
+        }
         // ---------- the queue: what this trip does for it ----------
         const bool stageA = !queueEmpty && !basePending;                    // take the next chunk's number (lane 0's atomic rides with this trip's loads)
         const bool stageB = basePending && rdyTaken >= rdyCount;            // load and test the chunk
@@ -393,8 +396,12 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if ((ceNK >> 8) + 1u < (ceNK & 0xFFu)) aD0 = ix.sa + ceL + (ceNK >> 8) + 1u;     // the next candidate's suffix-array entry rides along
         } else if (state == U_CE_SA) {
             aD0 = ix.sa + ceL + (ceNK >> 8);
-        } else if (state == U_LOAD) loadAsk(aP0, aP1, aD0);
-        else if (state == U_ADOPT) {
+        } else if (state == U_LOAD) {
+            const uint4 *src = (const uint4 *)(in.readsT + (size_t)aux * 2u * wpq + (size_t)(subN & 1u) * wpq + loadOff);
+            aP0 = src;
+            if (wpq - loadOff > 4u) aP1 = src + 1;
+            if constexpr (!UNIFORM) aD0 = in.readLengths + aux;
+        } else if (state == U_ADOPT) {
             aP0 = stk + aux;
         }
         const bool running = state == U_STEP || state == U_POPWAIT || state == U_CE_SA || state == U_CE_TEXT || state == U_RESUME;
@@ -484,7 +491,27 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (s < nSteps) loadStepCache();
             if (unitInRead > dCut) { state = U_DONE; if constexpr (COUNT) nCutMid++; }
             else { doSettle = true; needPop = false; }
-        } else if (state == U_LOAD) loadTake(p0, p1, saVal, doSettle, needPop);
+        } else if (state == U_LOAD) {
+            const uint32_t vals[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t w = loadOff + k;
+                if (w < wl) ro[w * 64u + lane] = vals[k];
+            }
+            loadOff += 8;
+            if constexpr (!UNIFORM) Li = (int)saVal;
+            if (loadOff >= wl || loadOff >= wpq) {
+                loadStepCache();
+                {
+                    // the trunk state {l, r, rev l} the step's way round
+                    const uint32_t l = aL, r = aR, rvl = pR;
+                    if (sc.dir() < 0) pR = rvl + (r - l);
+                    else { aL = rvl; aR = rvl + (r - l); pR = r; }
+                }
+                if (first) state = U_STEP;
+                else { i = sc.len(); doSettle = true; needPop = false; }         // the unit without a mismatch in this step: behind its last position
+            }
+        }
         // ---------- check-and-extend by the lane itself (BGS-HostAlgnmtAlgo2.cpp:86-169: per candidate its suffix-array entry, then the text under the rest of the model, one 64-byte line = 256 characters per trip, compared as ceKernel compares) ----------
         if constexpr (COUNT) {
             const unsigned long long cm = __ballot(state == U_CE_SA || state == U_CE_TEXT);
@@ -622,51 +649,20 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---------- retire finished units (their occurrences were booked above) and give the idle lanes their next units -- HERE, at the end of the full trip
-        // and not at the top of the next one: the fast trips in between load the new units' reads (U_LOAD), so a lane that ends a unit in this trip's settle
-        // is stepping its next unit two trips later instead of waiting for two more full trips (a unit is 27 steps: the turnover was a third of its time) ----------
-        if (state == U_DONE) {
-            if (seq != 0u || cntIdx >= out.dynBase) out.itemCounts[cntIdx] = seq;      // (a unit that wrote nothing leaves the counter alone: the trunk lane may own it)
-            state = U_IDLE;
-        }
-        // ---------- idle lanes take tested units ----------
-        unsigned long long idleNow = __ballot(state == U_IDLE);
-        // (starting units is a divergent path of some two hundred instructions, and two or three lanes of a wave finish a unit on EVERY trip: the idle lanes
-        //  wait until in.takeMin of them can start together -- or nothing else is running, or the queue is empty and waiting would only stretch the tail)
-        if (idleNow && rdyTaken < rdyCount && ((uint32_t)__popcll(idleNow) >= in.takeMin || queueEmpty)) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleNow >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleNow, 0u));
-            const uint32_t e = rdyTaken + rank, avail = rdyCount - rdyTaken;
-            if (state == U_IDLE && rank < avail) {
-                aL = rdy[e]; aR = rdy[64u + e]; pR = rdy[128u + e];          // the trunk state {l, r, rev l}: turned the step's way when the step is known
-                listed = rdy[192u + e]; aux = rdy[320u + e];
-                const uint32_t sp_ = rdy[256u + e];                          // item | position << 8 (the division is made once per chunk, where the chunk is tested)
-                const uint32_t sub = sp_ & 0xFFu, p = sp_ >> 8;
-                unitInRead = sub * U + p;
-                const uint32_t cas = sub >> 1;
-                subN = sub | ((in.nStepsPacked >> (3u * cas)) & 7u) << 8;
-                s = (int)((in.sStarPacked >> (3u * cas)) & 7u);
-                cntIdx = in.unitBase + listed * groups * U + unitInRead;
-                first = p + 1u != U;
-                i = (int)p;                                                 // (the unit without a mismatch in this step: behind the step's last position, set when the step is known)
-                ins = 0; occ = 0; seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
-                ceHist = 0; countPending = 0;
-                if constexpr (COUNT) unitTrips = 0;
-                loadOff = 0;
-                state = U_LOAD;
-            }
-            const uint32_t nIdle = (uint32_t)__popcll(idleNow);
-            rdyTaken += nIdle < avail ? nIdle : avail;
-        }
-
         // ---------- FAST TRIPS (round 5).  The trip above carries every path of the state machine, and with 64 lanes some lane needs every one of them on
         // nearly every trip: ~890 vector instructions per trip at 26 active lanes of 64 (profiles/README_r05.md), of which the step itself is a third -- the
         // pass is bound by vector issue, not by its lines.  So while at least in.fastMin lanes of the wave are stepping, up to in.fastTrips trips that do
-        // NOTHING BUT STEP follow (and load the reads of the units just taken): the stepping lanes' lines, the one wait, ranks, children, pushes, and the
-        // test whether the lane's next move is a step again.  A lane whose next move is anything else -- pop, record, step boundary, check-and-extend, end of the unit -- parks in U_RESUME /
+        // NOTHING BUT STEP follow: the stepping lanes' lines, the one wait, ranks, children, pushes, and the test whether the lane's next move is a
+        // step again.  A lane whose next move is anything else -- pop, record, step boundary, check-and-extend, end of the unit -- parks in U_RESUME /
         // U_POPWAIT and makes it in the next full trip, together with the other lanes parked meanwhile: the rare paths run for many lanes at a time
         // instead of two or three.  A lane is nobody else's business (the cut and the booking are order-free), so the records do not change. ----------
+        // (What a fast trip carries is what it costs: its ~330 vector instructions are half of what the four waves of a SIMD can issue inside one memory
+        //  latency.  Round 5 measured three richer variants, all bit-exact: the reads of newly taken units loaded in the fast trips with retirement at the end
+        //  of the full trip (unit passes of a ladder 128.3 -> 130.4 ms), settle() and the frame under a popped one in the fast trips (parked lane trips
+        //  250 M -> 67 M, wave trips -11 %, but 3.9 -> 5.3 us per fast trip: 155 ms), fast trips for any stepping lane once the queue is empty (+11 ms:
+        //  frames are adopted in full trips only).  profiles/README_r05.md.)
         for (uint32_t ft = 0; ft < in.fastTrips; ft++) {
-            if ((uint32_t)__popcll(__ballot(state == U_STEP || state == U_LOAD)) < in.fastMin) break;
+            if ((uint32_t)__popcll(__ballot(state == U_STEP)) < in.fastMin) break;
             uint32_t iL = 0, iR = 0;
             bool needB = false;
             int dir = 0;
@@ -674,7 +670,6 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             const uint4 *aP0 = (const uint4 *)ix.pac, *aP1 = (const uint4 *)ix.pac;
             const uint32_t *aD0 = ix.pac;
             if (state == U_STEP) stepAsk(iL, iR, needB, dir, ownLine, aP0, aP1, aD0);
-            else if (state == U_LOAD) loadAsk(aP0, aP1, aD0);
             const uint32_t q16 = lane & 3u, q4 = lane >> 2;
             const uint32_t ownLo = (uint32_t)(uintptr_t)ownLine, ownHi = (uint32_t)((uintptr_t)ownLine >> 32);
             auto quadLine = [&](uint32_t owner) -> const uint4 * {
@@ -691,11 +686,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             stage[(48u + q4) * 4u + q16] = va3;
             __builtin_amdgcn_wave_barrier();
             if constexpr (COUNT) { waveTrips++; dFastWave++; if (state != U_IDLE) { unitTrips++; laneTrips++; if (unitTrips > maxUnitTrips) maxUnitTrips = unitTrips; } dStepLane += state == U_STEP ? 1u : 0u; dFastLane += state == U_STEP ? 1u : 0u; }
-            if (state == U_LOAD) {
-                bool doSettle = false, needPop = false;
-                loadTake(p0, p1, d0, doSettle, needPop);
-                if (doSettle) state = U_RESUME;                                    // (the unit without a mismatch in its step: settle() knows what comes next)
-            } else if (state == U_STEP) {
+            if (state == U_STEP) {
                 bool doSettle = false, needPop = false;
                 stepTake(iL, iR, needB, dir, p0, p1, d0, doSettle, needPop);
                 if (doSettle) {
