@@ -450,7 +450,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     BA(dRecs, recCap); BA(dOrdered, recCap); BA(dOrdValid, recCap + 8); b->ordCap = recCap;     // (+ 8: the long merge / decode kernels read the bytes eight at a time)
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, S3_COUNTER_WORDS); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
-    BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
+    BA(dWasHeavy, (size_t)maxReads + 64); BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
     BA(dLongList, (size_t)maxReads + 64); BA(dLongCount, 4); BA(dTrunk, 16); b->trunkCap = 16; BA(dItemAcc, 16); b->accCap = 16;
     b->countCap = b->maxItems + 1;
     BA(dKept, (size_t)maxReads + 1); BA(dOccCounts, (size_t)maxReads + 1); BA(dCeCounts, (size_t)maxReads + 1); BA(dTotalOcc, (size_t)maxReads + 1);
@@ -515,6 +515,7 @@ extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint3
     HIPCHK(hipMemcpyAsync(b->dLens, readLengths, (size_t)n * 4, hipMemcpyHostToDevice, b->stream));
     launchOrientReads(b->dQueries, b->dLens, b->dReadsT, n, b->wpq, b->wpq, b->stream);
     HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemsetAsync(b->dWasHeavy, 0, b->maxReads, b->stream));
     b->n = n;
     b->lastKind = 0;
     b->sortedIdsValid = false;
@@ -676,6 +677,8 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     const bool smallPass = b->n <= (2u << 20);                                // (by the BATCH: the later phases of a large batch are small passes and still best at 2048 / 1024)
     in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : (smallPass ? 1024u : 2048u));
     in.heavyRank = heavyEnv == 0 ? 0xFFFFFFFFu : (uint32_t)envSize("S3DP_HEAVY_RANK", heavyEnv > 1 && heavyEnv < 64 ? 64 : (smallPass ? 512 : 1024));
+    in.heavyLevel = modelMm + 1u;
+    static const bool heavyMemo = envSize("S3DP_HEAVY_MEMO", 1) != 0;       // a read listed in one phase of a ladder is listed at once in the next (s3dp_first.hip, F_LOAD)
     in.slotList = nullptr; in.slotCount = nullptr;
     // units of the second pass: first-mismatch positions of an item's first mismatch step, + 1 for "none" -- the longest such step over the cases
     // and over the read lengths this batch can hold (S3DP_UNITS=0: whole items)
@@ -709,6 +712,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         out.workHead = b->dWorkHead;
         out.cutDummy = b->dFlags + 2;
         out.heavyFlags = b->dHeavyFlags; out.heavyList = b->dHeavyList; out.heavyCount = b->dHeavyCount; out.heavyIndex = b->dHeavyIndex;
+        out.wasHeavy = in.heavyLimit != 0xFFFFFFFFu && modelMm > 0 && heavyMemo ? b->dWasHeavy : nullptr;
         nHeavy = 0; nCount = (uint32_t)nItems;
         b->scatterDyn = ScatterDyn{nullptr, nullptr, 0, 0};
         HIPCHK(hipMemsetAsync(b->dWorkHead, 0, 8, b->stream));
@@ -983,6 +987,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
     if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_COUNTER_WORDS * 8, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
+    HIPCHK(hipMemsetAsync(b->dWasHeavy, 0, b->maxReads, b->stream));
     int rc = searchPass(b, nullptr, b->n, numMismatch, maxOutputPerRead);
     if (rc) return rc;
     // hits in the ABI format

@@ -27,12 +27,20 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
 {
     __shared__ uint4 sRec[4][64];                              // per wave: the task records of the batch ...
     __shared__ uint32_t sStart[4][65], sRead[4][64];           // ... the number of their first candidate; the read a task belongs to
+    // ... and the tasks' reads, their searched strand, S words each (launchCheckExtend sizes it; not for reads of more than 256 bases): a candidate's read words
+    // come out of LDS.  What the kernel is bound by, next to the lines it fetches, is the number of lines its wave-instructions TOUCH -- the vector cache
+    // looks up one line per lane and clock --, and until round 5 a candidate asked for its window word by word: up to nine 4-byte loads from the text and
+    // nine from the read per model step, 27 load instructions per round of 64 candidates.  Now: the text in two or three aligned 16-byte pieces, the read
+    // from LDS -- 6 to 8.
+    extern __shared__ __align__(16) uint32_t sRd[];
     const uint32_t firstRec = taskRange[0];                   // records [firstRec, nRec): what the stepping launches wrote since the last call
     uint32_t nRec = taskRange[1];
     if (nRec > out.recCap) nRec = out.recCap;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t groups = (uint32_t)in.nCases * 2u;
     const uint32_t S = in.wpqLoad;
+    const bool staged = S >= 4u && S <= 16u;                   // (S is a power of two)
+    uint32_t *myRd = sRd + (size_t)wv * 64u * S;
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t nSa = 0, nCe = 0, nAcc = 0;
     uint32_t recCur = 0, recEnd = 0;                          // wave-uniform: reserved block [recCur, recEnd)
@@ -69,7 +77,13 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         sRec[wv][lane] = make_uint4(rec.x, rec.y, rec.z, (rec.w & 0xFFFFFF00u) | (item % groups));     // (low byte: the (case, strand) of the item)
         sStart[wv][lane] = incl - size;
         if (lane == 63u) sStart[wv][64] = total;
-        sRead[wv][lane] = task ? (in.active ? in.active[slotOf] : slotOf) : 0u;
+        const uint32_t myRead = task ? (in.active ? in.active[slotOf] : slotOf) : 0u;
+        sRead[wv][lane] = myRead;
+        if (staged && task) {
+            const uint4 *src = (const uint4 *)(in.readsT + (size_t)myRead * 2u * S + (size_t)((item % groups) & 1u) * S);
+            uint4 *dst = (uint4 *)(myRd + lane * S);
+            for (uint32_t k = 0; k < S / 4u; k++) dst[k] = src[k];
+        }
         __builtin_amdgcn_wave_barrier();
         for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
             const uint32_t c = c0 + lane;
@@ -92,6 +106,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 const int Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
                 const int nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
                 const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
+                const uint32_t *rdL = myRd + lo * S;
                 const S3Case &cs = in.models[Li].cs[casIdx];
                 recX = tr.x; seqK = (tr.y & 0xFFFFFFu) + k;
                 acc = occ0;
@@ -121,11 +136,25 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                         const uint32_t tp0 = tpos + o0, tw0 = tp0 >> 4, tsh = (tp0 & 15u) * 2u;
                         const uint32_t qp0 = left + o0, qw0 = qp0 >> 4, qsh = (qp0 & 15u) * 2u;
                         uint32_t tw[9], qw[9];
+                        {
+                            // the text words tw0 .. tw0 + jmax out of the aligned 16-byte pieces that hold them (the text ends in a zero tail longer than a
+                            // piece: s3dp_api.hip), the first one at word `off` of the first piece
+                            const uint32_t jmax = (piece + 15u) >> 4, off = tw0 & 3u, lastW = off + jmax;     // lastW <= 11
+                            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 *tc = (const u32x4 *)ix.pac + (tw0 >> 2);
+                            u32x4 c0 = tc[0], c1 = {0u, 0u, 0u, 0u}, c2 = {0u, 0u, 0u, 0u};
+                            if (lastW >= 4u) c1 = tc[1];
+                            if (lastW >= 8u) c2 = tc[2];
+                            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));          // (whole pieces: left alone the compiler asks for them word by word again)
+                            const uint32_t W[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+#pragma unroll
+                            for (uint32_t j = 0; j < 9; j++) tw[j] = off == 0u ? W[j] : off == 1u ? W[j + 1] : off == 2u ? W[j + 2] : W[j + 3];
+                        }
 #pragma unroll
                         for (uint32_t j = 0; j < 9; j++) {
                             const uint32_t need = j * 16u < piece + 16u;              // word j + the one behind it for the shift
-                            tw[j] = (need && tw0 + j < ix.pacWords) ? ix.pac[tw0 + j] : 0u;
-                            qw[j] = (need && qw0 + j < S) ? rd[qw0 + j] : 0u;
+                            if (!need) tw[j] = 0u;
+                            qw[j] = (need && qw0 + j < S) ? (staged ? rdL[qw0 + j] : rd[qw0 + j]) : 0u;
                         }
 #pragma unroll
                         for (uint32_t j = 0; j < 8; j++) {
@@ -185,11 +214,12 @@ void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &
         int dev = 0, cus = 256, perCu = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, ceKernel, 256, 0) != hipSuccess || perCu < 1) perCu = 6;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, ceKernel, 256, 16384) != hipSuccess || perCu < 1) perCu = 5;
         if (const char *e = getenv("S3DP_CE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
         return (unsigned)(cus * perCu);
     }();
-    hipLaunchKernelGGL(ceKernel, dim3(blocks), dim3(256), 0, s, ix, in, out, taskRange);
+    const size_t lds = in.wpqLoad >= 4u && in.wpqLoad <= 16u ? (size_t)4u * 64u * in.wpqLoad * 4u : 0u;      // the tasks' reads (ceKernel::sRd)
+    hipLaunchKernelGGL(ceKernel, dim3(blocks), dim3(256), lds, s, ix, in, out, taskRange);
 }
 
 }  // namespace s3

@@ -72,6 +72,7 @@ struct SearchIn {
     uint32_t        earlyMinI;   // ... but only once this many characters are matched: a chance match of the lookup characters costs a step (one line) to drop,
                                  // a candidate three lines to verify
     uint32_t        heavyRank;   // first pass: ... or that has cost more rank queries than this
+    uint32_t        heavyLevel;  // first pass: mismatch budget of this pass + 1 (what SearchOut::wasHeavy remembers; a read listed at a level <= this one is listed at once)
     uint32_t        heavyLimit;  // first pass: a read that reserves more check-and-extend candidates than this is listed for the second pass
     const uint32_t *slotList;    // second pass (item mode: one work unit per item of a listed read): the listed slots ...
     const uint32_t *slotCount;   // ... and how many (device memory, written by the first pass)
@@ -90,7 +91,10 @@ struct SearchIn {
 
 #define S3_REC_TASK  (1u << 28)
 #define S3_REC_PASS2 0x80000000u            // in the item word: record written by the second pass (records of a listed read without it are stale)
-#define S3_CE_GIVE_UP 2u                     // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel
+// second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel.  0 since the fast trips of round 5: a unit verifies nothing
+// itself -- a lane in check-and-extend moves in full trips only, one trip in five, and sits out the fast ones (10 M reads: 284.3 -> 278.9 ms per step against
+// 2, `young` 23.9 -> 24.6 M reads/s, satellite-heavy 14.2 -> 14.4; round 3 had chosen 2 with every trip a full one)
+#define S3_CE_GIVE_UP 0u
 #define S3_TRUNK_VALID 0x80000000u          // trunkStates[].w: the trunk pass reached this position
 #define S3_REC_EARLY (1u << 29)              // task written inside the exact lookup step (single-suffix range): the rest of that step is verified too
 
@@ -105,6 +109,7 @@ struct SearchOut {
     uint8_t            *heavyFlags; // per slot: listed for the second pass (zeroed before every first pass)
     uint32_t           *heavyList, *heavyCount;
     uint32_t           *heavyIndex; // per listed slot: its place in heavyList
+    uint8_t            *wasHeavy;   // per READ of the batch (not slot): SearchIn::heavyLevel of the pass that listed it, kept over the phases of a ladder (nullptr: off)
     uint32_t           *cutDummy;    // a scratch word: where a lane's cut pointer points while it has no listed read
     uint32_t           *readCut;     // second pass, per listed read: the smallest unit (item * units + position) that holds maxOut occurrences by itself
     uint32_t           *itemAcc;     // second pass, per listed read and item: occurrences its units hold for sure (sums over the items give the cut too)

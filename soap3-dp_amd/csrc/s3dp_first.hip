@@ -289,6 +289,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (goHeavy) {
                 // this read goes to the second pass: whatever it wrote so far is ignored there (scatter / check-and-extend test the flag)
                 out.heavyFlags[slotIdx] = 1;
+                if (out.wasHeavy) out.wasHeavy[rIdx] = (uint8_t)in.heavyLevel;  // remembered for the ladder's next phases (see F_LOAD)
                 const uint32_t at = atomicAdd(out.heavyCount, 1u);
                 out.heavyList[at] = slotIdx;
                 out.heavyIndex[slotIdx] = at;
@@ -400,6 +401,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             aP0 = src;
             if (2u * wpq - loadOff > 4u) aP1 = src + 1;
             if constexpr (!UNIFORM) aD0 = in.readLengths + rIdx;
+            if (!TRUNK && out.wasHeavy && loadOff == 0u) aD1 = (const uint32_t *)(out.wasHeavy + (rIdx & ~3u));
         } else if (state == F_LT) {
             const bool bidir = stepAt(0).type != S3_T_BACK_LOOKUP;
             if (ltB == 0xFFFFFFFFu) {
@@ -467,6 +469,16 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         else if (state == F_RESUME) { doSettle = true; needPop = false; }
         else if (state == F_POPWAIT) { doSettle = true; needPop = true; }
         else if (state == F_LOAD) {
+            // A read that was listed at this mismatch budget or a smaller one in an earlier phase of the ladder is listed at once: a read inside a repeat family
+            // that found nothing with two mismatches comes back with three, and would spend its rank budget again -- 512 trips of one lane -- before the first
+            // pass gives it up (a sixth of the first passes' rank queries, and their tails).  Which reads are listed is nobody's business: the second pass
+            // searches them from scratch.
+            if (!TRUNK && out.wasHeavy && loadOff == 0u) {
+                const uint32_t h = (d1 >> (8u * (rIdx & 3u))) & 0xFFu;
+                if (h && h <= in.heavyLevel) { goHeavy = true; state = F_DONE; }
+            }
+        }
+        if (state == F_LOAD) {
             // word gi of the read's row in readsT (both orientations, wpq words each) -> LDS word (orientation * wl + w); words past wl are padding
             const uint32_t vals[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
@@ -498,6 +510,9 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (!bidir) { aL = fl; aR = fr; pR = rr; } else { aL = rl; aR = rr; pR = fr; }
             s = 0; i = ll; ins = 0; occ = 0;
             doSettle = true;
+            // (Listing a read at once when one of its lookup strings has thousands of occurrences -- it WILL cost its rank budget, and what it does until then
+            //  is thrown away -- was measured in round 5, thresholds 1 Ki .. 64 Ki occurrences: the first passes of a ladder 48.7 -> 38-41 ms, the unit passes
+            //  128 -> 159-297 ms.  A read that only brushes a repeat costs the second pass far more than it costs a lane here.)
         }
         if (doSettle) settle(needPop);
         // ---------- write the parked records (convergent) ----------

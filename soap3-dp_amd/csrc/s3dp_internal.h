@@ -60,6 +60,7 @@ struct s3_batch {
     uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr, *dTaskRange = nullptr;
     unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;
     unsigned long long *dSum64 = nullptr;            // 64-bit total next to a 32-bit scan (sum64Async): a wrapped total must not pass as a small one
+    uint8_t  *dWasHeavy = nullptr;                   // per read: the mismatch budget + 1 at which a first pass listed it (reset when the reads change and when a ladder starts)
     uint8_t  *dHeavyFlags = nullptr;                 // reads the first search pass listed for the exact pass (s3dp_first.hip)
     uint32_t *dHeavyList = nullptr, *dHeavyCount = nullptr, *dHeavyIndex = nullptr;
     uint32_t *dLongList = nullptr, *dLongCount = nullptr;      // reads whose slice of the ordered array is walked by a whole wave (merge / decode)
