@@ -678,7 +678,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.heavyLimit = heavyEnv == 0 ? 0xFFFFFFFFu : (heavyEnv > 1 ? (uint32_t)heavyEnv : (smallPass ? 1024u : 2048u));
     in.heavyRank = heavyEnv == 0 ? 0xFFFFFFFFu : (uint32_t)envSize("S3DP_HEAVY_RANK", heavyEnv > 1 && heavyEnv < 64 ? 64 : (smallPass ? 512 : 1024));
     in.heavyLevel = modelMm + 1u;
-    static const bool heavyMemo = envSize("S3DP_HEAVY_MEMO", 1) != 0;       // a read listed in one phase of a ladder is listed at once in the next (s3dp_first.hip, F_LOAD)
+    const bool heavyMemo = envSize("S3DP_HEAVY_MEMO", 1) != 0;              // a read listed in one phase of a ladder is listed at once in the next (s3dp_first.hip, F_LOAD)
     in.slotList = nullptr; in.slotCount = nullptr;
     // units of the second pass: first-mismatch positions of an item's first mismatch step, + 1 for "none" -- the longest such step over the cases
     // and over the read lengths this batch can hold (S3DP_UNITS=0: whole items)

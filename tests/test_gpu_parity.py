@@ -71,6 +71,10 @@ KNOBS = [
     {"S3DP_HEAVY": "2", "S3DP_UNIT_NODES": "0"},             # no adoption of frames: every unit is searched by one lane
     {"S3DP_HEAVY": "2", "S3DP_UNIT_NODES": "300"},           # the counters of adopted frames run out on the way
     {"S3DP_HEAVY": "2", "S3DP_BLOCKS_PER_CU": "1", "S3DP_CE_BLOCKS_PER_CU": "1"},
+    # round 5: every trip that leaves a stepping lane is followed by trips that only step (the fixtures never gather the 32 stepping lanes of the default)
+    {"S3DP_HEAVY": "2", "S3DP_FAST_MIN": "1", "S3DP_FAST_TRIPS": "3", "S3DP_FIRST_FAST_MIN": "1", "S3DP_FIRST_FAST_TRIPS": "3"},
+    {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8", "S3DP_FAST_MIN": "2", "S3DP_FAST_TRIPS": "15", "S3DP_FIRST_FAST_MIN": "2", "S3DP_FIRST_FAST_TRIPS": "15", "S3DP_CE_GIVE_UP": "2"},
+    {"S3DP_HEAVY": "2", "S3DP_FAST_TRIPS": "0", "S3DP_FIRST_FAST_TRIPS": "0", "S3DP_CE_GIVE_UP": "2"},     # none at all, units verify candidates (rounds 3-4)
 ]
 
 
@@ -166,9 +170,16 @@ def test_max_output_truncation(monkeypatch, cap, heavy):
 
 @pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
 @pytest.mark.parametrize("mm", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("heavy", ["1", "2"])
+@pytest.mark.parametrize("heavy", ["1", "2", "2m", "2f"])
 def test_allbest_ladder_matches_oracle(monkeypatch, name, maxlen, mm, heavy):
-    monkeypatch.setenv("S3DP_HEAVY", heavy)
+    """heavy 2: nearly every read is listed for the second pass -- and, listed in one phase, listed at once in the next (the ladder's memory of its heavy
+    reads, round 5); 2m: without that memory; 2f: with fast trips behind every trip that leaves a stepping lane"""
+    monkeypatch.setenv("S3DP_HEAVY", heavy[0])
+    if heavy.endswith("m"):
+        monkeypatch.setenv("S3DP_HEAVY_MEMO", "0")
+    if heavy.endswith("f"):
+        for k in ("S3DP_FAST_MIN", "S3DP_FIRST_FAST_MIN"):
+            monkeypatch.setenv(k, "1")
     reads = golden_reads(name)
     q, lens, wpq = s3dp.pack_reads(reads, maxlen)
     b = s3dp.Batch(dev_index(name), len(reads), wpq)
