@@ -133,6 +133,20 @@ __device__ __forceinline__ void readSlice(const MergeArgs &a, uint32_t slot, uin
     } else { beg = a.itemOffsets[slot * groups]; end = a.itemOffsets[slot * groups + groups]; }
 }
 
+// The validity bytes of the eight slots from w0 on (w0 a multiple of 8; the array is 8-byte aligned with 8 bytes to spare: s3dp_api.hip) as a bit mask,
+// bit q = slot w0 + q holds a record; slots outside [lo, hi) masked out.  One 8-byte load where a walk slot by slot makes eight 1-byte loads -- and a load
+// instruction costs the vector cache a clock per lane whatever its width.
+__device__ __forceinline__ uint32_t validBits8(const uint8_t *valid, uint32_t w0, uint32_t lo, uint32_t hi)
+{
+    const uint2 v = *(const uint2 *)(valid + w0);
+    auto nz = [](uint32_t x) -> uint32_t { x |= x >> 4; x |= x >> 2; x |= x >> 1; x &= 0x01010101u; return ((x * 0x01020408u) >> 24) & 0xFu; };   // bit q: byte q is not zero
+    uint32_t bits = nz(v.x) | nz(v.y) << 4;
+    if (w0 < lo) bits = lo - w0 >= 8u ? 0u : bits & (0xFFu << (lo - w0));
+    if (w0 >= hi) bits = 0u;
+    else if (hi - w0 < 8u) bits &= (1u << (hi - w0)) - 1u;
+    return bits;
+}
+
 // Per read: walk the items in the CPU path's order (case 0 '+', case 0 '-', case 1 '+', ...), apply the
 // MaxOutputPerRead truncation across items (TotalOccurrences is per read: CPUfunctions.cpp:1246, the cut is
 // BGS-HostAlgnmtAlgo2.cpp:1612-1615 / :160-163), tally WithError[], and count what survives.
@@ -146,13 +160,17 @@ __global__ void mergeCountKernel(MergeArgs a)
     if (a.longList && end - beg > S3_MERGE_LONG) { a.longList[atomicAdd(a.longCount, 1u)] = slot; return; }   // a wave's job (mergeCountLongKernel)
     uint32_t total = 0, nRec = 0, nOcc = 0, nCe = 0;
     uint32_t we[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = beg; i < end && total < a.maxOut; i++) {
-        if (!a.valid[i]) continue;                                          // sequence number of a rejected check-and-extend candidate
-        const uint4 r = a.ordered[i];
-        const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
-        uint32_t cnt = kind ? 1u : r.w - r.z + 1u;
-        if (total + cnt > a.maxOut) cnt = a.maxOut - total;
-        total += cnt; we[nmis] += cnt; nRec++; nOcc += cnt; nCe += kind;
+    for (uint32_t w0 = beg & ~7u; w0 < end && total < a.maxOut; w0 += 8u) {
+        uint32_t bits = validBits8(a.valid, w0, beg, end);                   // (a slot without a record: the sequence number of a rejected check-and-extend candidate)
+        while (bits && total < a.maxOut) {
+            const uint32_t i = w0 + (uint32_t)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            const uint4 r = a.ordered[i];
+            const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
+            uint32_t cnt = kind ? 1u : r.w - r.z + 1u;
+            if (total + cnt > a.maxOut) cnt = a.maxOut - total;
+            total += cnt; we[nmis] += cnt; nRec++; nOcc += cnt; nCe += kind;
+        }
     }
     a.keptRecs[slot] = nRec;
     a.occCounts[slot] = nOcc;
@@ -314,12 +332,23 @@ __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffset
     if (mine && (uint64_t)occBase + occOffsets[slot + 1] > occCap) { atomicOr(flags, S3_FLAG_OCC_OVERFLOW); mine = false; }
     if (mine) { n = a.keptRecs[slot]; o = occBase + occOffsets[slot]; oSa = o + a.ceCounts[slot]; }
     uint32_t total = 0, k = 0, i = beg;
+    uint32_t w0 = beg & ~7u, bits = 0;                                        // the validity bits of the eight slots from w0 on that are still to be looked at
+    bool loaded = false;
     while (__any(mine && k < n)) {
         const bool turn = mine && k < n;
-        const bool have = turn && a.valid[i] != 0;
+        // a turn either fetches the next eight validity bytes (one load) or takes the next record they show
+        if (turn && !bits) {
+            if (loaded) w0 += 8u;
+            bits = validBits8(a.valid, w0, beg, end);
+            loaded = true;
+        }
+        const bool have = turn && bits != 0u;
         uint4 r = make_uint4(0, 0, 0, 0);
-        if (have) r = a.ordered[i];
-        if (turn) i++;
+        if (have) {
+            i = w0 + (uint32_t)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            r = a.ordered[i];
+        }
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
         const uint32_t meta = (((r.x % groups) & 1u) + 1u) | nmis << 8;
         uint32_t cnt = 0, dst = 0;

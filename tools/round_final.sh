@@ -18,6 +18,7 @@ for w in $WHAT; do
     rm -rf /tmp/prof_stats
     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python3 bench.py $Q --steps 3 --warmup 1 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.log; echo "stats rc=$?"
     f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_bench.csv && grep "s3::" $O/kernel_stats_bench.csv | head -14 | cut -c1-150
+    t=$(find /tmp/prof_stats -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python3 tools/ladder_breakdown.py "$t" > $O/ladder_breakdown.txt 2>&1 && head -30 $O/ladder_breakdown.txt
     rm -rf /tmp/prof_stats ;;
   pmc)
     S3DP_COMMIT=$(cat .commit 2>/dev/null | head -c 12) tools/ladder_pmc.sh $(basename $O) ;;
