@@ -65,7 +65,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     int sStar = 0;                                                          // (TRUNK) the first step of the case that allows a mismatch
     uint4 *stk = out.unitStack + (size_t)(blockIdx.x * (S3_SEARCH_BLOCK / 64u) + wv) * S3_UNIT_STACK * 64u;     // frame d of lane k: stk[(d % S3_UNIT_STACK) * 64 + k]
 
-    uint32_t nRank = 0, nLt = 0;                                            // (COUNT)
+    uint32_t nRank = 0, nLt = 0, nWaveTrips = 0, nLaneTrips = 0, nStepLane = 0, nFastWave = 0, nFastLane = 0, nParked = 0;     // (COUNT)
 
     // ---- per-lane state ----
     uint32_t state = F_IDLE;
@@ -462,6 +462,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
 
         // ---------- advance ----------
         bool doSettle = false, needPop = false;
+        if constexpr (COUNT) { nWaveTrips++; nLaneTrips += state != F_IDLE ? 1u : 0u; nStepLane += state == F_STEP ? 1u : 0u; nParked += state == F_RESUME || state == F_POPWAIT ? 1u : 0u; }
         if (wantTos) { tos = pT; tosValid = true; }
         // a read that has cost this many rank queries is heavy whatever it has found so far (dead ends cost steps, not candidates)
         if (!TRUNK && state == F_STEP && readRank > in.heavyRank) { goHeavy = true; state = F_DONE; sp = 0; tosValid = false; }
@@ -567,6 +568,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             stage[(32u + q4) * 4u + q16] = va2;
             stage[(48u + q4) * 4u + q16] = va3;
             __builtin_amdgcn_wave_barrier();
+            if constexpr (COUNT) { nWaveTrips++; nFastWave++; nLaneTrips += state != F_IDLE ? 1u : 0u; nStepLane += stepping ? 1u : 0u; nFastLane += stepping ? 1u : 0u; }
             if (stepping) {
                 bool doSettle = false, needPop = false;
                 stepTake(iL, iR, needB, dir, p0, p1, d0, doSettle, needPop);
@@ -598,6 +600,12 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         if (out.counters) {
             atomicAdd(&out.counters[0], (unsigned long long)nRank);
             atomicAdd(&out.counters[1], (unsigned long long)nLt);
+            atomicAdd(&out.counters[6], (unsigned long long)nLaneTrips);
+            if (lane == 0) atomicAdd(&out.counters[9], (unsigned long long)nWaveTrips);
+            atomicAdd(&out.counters[13], (unsigned long long)nStepLane);
+            if (lane == 0) atomicAdd(&out.counters[16], (unsigned long long)nFastWave);
+            atomicAdd(&out.counters[17], (unsigned long long)nFastLane);
+            atomicAdd(&out.counters[18], (unsigned long long)nParked);
         }
     }
 }
