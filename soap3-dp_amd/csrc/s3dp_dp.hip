@@ -289,29 +289,8 @@ __device__ __forceinline__ void dpBacktrackOne(const DpArgs &a, uint32_t p, int 
     auto run = [&](char op, uint32_t n) { put((uint32_t)op); put('V'); put(n); };       // 'V'<n>: n - 1 more of the op before (decoded by the engines)
     uint32_t i = L - clipRt, j = hitLoc;                                                 // read position, window column (1-based, 0 = before the first)
     if (clipRt) run('S', clipRt);
-    // (the packed word a character came out of is kept: sixteen consecutive steps read the same one)
-    uint32_t rdWordAt = 0xFFFFFFFFu, rdWord = 0, rfWordAt = 0xFFFFFFFFu, rfWord = 0;
-    const uint32_t rdBase = (p >> 5) * (((a.maxReadLength + 15u) >> 4) << 5) + (p & 31u), rfBase = (p >> 5) * (((a.maxDNALength + 15u) >> 4) << 5) + (p & 31u);
-    auto readAt = [&](uint32_t q) -> uint32_t {
-        if ((q >> 4) != rdWordAt) { rdWordAt = q >> 4; rdWord = a.reads[rdBase + (rdWordAt << 5)]; }
-        return (rdWord >> ((15u - (q & 15u)) << 1)) & 3u;
-    };
-    auto refAt = [&](uint32_t q0) -> uint32_t {
-        const uint32_t q = v.refOffset + q0;
-        if ((q >> 4) != rfWordAt) { rfWordAt = q >> 4; rfWord = a.dna[rfBase + (rfWordAt << 5)]; }
-        return (rfWord >> ((15u - (q & 15u)) << 1)) & 3u;
-    };
-    // THE DIAGONAL AHEAD (round 5).  The walk is a chain of dependent table reads -- what the cell says decides which cell is read next -- and a launch lasts as
-    // long as one problem's chain: ~150 steps of a microsecond each.  But nine steps in ten are matches, and on the diagonal the next cells are known: the
-    // eight cells ahead, H(j-1-k, i-1-k), are read together (one latency) and consumed while the walk stays on the diagonal; a gap or a clip drops them.
-    int dg[8];
-    uint32_t dgN = 0;
-    auto fillDiag = [&](uint32_t j, uint32_t i) {
-        const uint32_t m = j < i ? j : i;
-        dgN = m < 8u ? m : 8u;
-#pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) dg[k] = k < dgN ? v.H(j - 1u - k, i - 1u - k) : 0;
-    };
+    auto readAt = [&](uint32_t q) { return seqChar(a.reads, p, a.maxReadLength, q); };
+    auto refAt = [&](uint32_t q) { return seqChar(a.dna, p, a.maxDNALength, v.refOffset + q); };
     auto rowInit = [&](uint32_t q) -> int { return (v.refOffset + q >= v.aL) ? NEG_INF : 0; };     // H(q, 0)
     enum Exit { NONE, CLIP_AFTER_MATCH, CLIP_AFTER_INSERT } exitBy = NONE;
     int cur = v.H(j, i);
@@ -319,15 +298,7 @@ __device__ __forceinline__ void dpBacktrackOne(const DpArgs &a, uint32_t p, int 
         const bool same = refAt(j) == readAt(i);
         const int sub = same ? a.match : a.mismatch;
         int nxt;
-        if (dgN == 0u) fillDiag(j, i);
-        if (cur == sub + (nxt = dg[0])) {
-            put(same ? 'M' : 'm'); --j; --i; cur = nxt;
-#pragma unroll
-            for (uint32_t k = 0; k + 1u < 8u; k++) dg[k] = dg[k + 1u];
-            dgN--;
-            continue;
-        }
-        dgN = 0u;                                                                        // off the diagonal: what was read ahead belongs to another path
+        if (cur == sub + (nxt = v.H(j - 1u, i - 1u))) { put(same ? 'M' : 'm'); --j; --i; cur = nxt; continue; }
         if (cur == v.go + (nxt = v.H(j - 1u, i))) { put('D'); --j; cur = nxt; continue; }
         if (v.fromExtendedDeletion(j, i)) {
             // inside a deletion: its score falls by gapExtend per base until the column where it opened out of H
