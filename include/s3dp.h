@@ -347,6 +347,11 @@ int  s3_dp_new_default_routed(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const 
  * reference seeding and search share the one GPU one after the other): background != 0 moves its stream to the device's lowest priority, so that its kernels
  * take what the persistent search kernels leave; 0 moves it back.  The aligners of s3_dp_create are background work by construction.  Call it on an idle batch. */
 int  s3_batch_set_background(s3_batch *b, int background);
+/* Width of this batch's persistent search grids in workgroups per compute unit (0: all that are resident at once, four).  The reference sizes its grids by the
+ * batch (alignment.cu:118-221, blocksNeeded); here the grids are persistent and as wide as the device, and a batch whose search shares the device with the DP
+ * stages of earlier chunks (SOAP3-DP.cu:394-800 runs them one after the other) leaves a workgroup per compute unit to their kernels: the paired command line
+ * with its DP stages on asks for three (10 M pairs: 3.40 -> 3.18 s, round 5).  S3DP_BLOCKS_PER_CU overrides it. */
+int  s3_batch_set_grid(s3_batch *b, unsigned blocksPerCu);
 int  s3_batch_sync(s3_batch *b);
 /* device time of the work enqueued by the last search/align call, measured with HIP events on the batch stream;
  * searchMs = time inside the BWT-search kernels only. */

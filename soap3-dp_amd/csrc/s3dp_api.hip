@@ -559,6 +559,14 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
     return S3_OK;
 }
 
+extern "C" int s3_batch_set_grid(s3_batch *b, unsigned blocksPerCu)
+{
+    if (!b) return fail(S3_EINVAL, "null batch");
+    if (blocksPerCu > 16u) return fail(S3_EINVAL, "s3_batch_set_grid: at most 16 workgroups per compute unit");
+    b->blocksPerCu = blocksPerCu;
+    return S3_OK;
+}
+
 // background batches (the seed batches of the command line's DP stage threads): their stream gets the lowest priority of the device, or the default again
 extern "C" int s3_batch_set_background(s3_batch *b, int background)
 {

@@ -800,7 +800,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     // (S3DP_DUMP_ROUTING, the tests' routing dump, is appended chunk by chunk by the stage thread: one thread, or chunk 1 could write before chunk 0 truncates the file)
     const int dpThreadsEnv = getenv("S3DP_DP_THREADS") ? atoi(getenv("S3DP_DP_THREADS")) : 0;
     // (with large chunks a chunk's DP stages last longer than the search of the next one: three threads keep up with them)
-    const int nDpWorkers = getenv("S3DP_DUMP_ROUTING") ? 1 : (dpThreadsEnv >= 1 && dpThreadsEnv <= kDpWorkers ? dpThreadsEnv : (chunkBig ? 3 : 2));
+    // (pairs: three since the search kernels of round 5 -- a chunk's search is over before two threads are through the stages of the two chunks before it;
+    //  10 M pairs, outputs to /dev/null: 3.40 -> 3.25 s with three threads, 3.18 s with a search grid that leaves a workgroup per compute unit to their kernels)
+    const int nDpWorkers = getenv("S3DP_DUMP_ROUTING") ? 1 : (dpThreadsEnv >= 1 && dpThreadsEnv <= kDpWorkers ? dpThreadsEnv : (chunkBig || paired ? 3 : 2));
     struct PreDp { s3_dp *dp[kDpWorkers] = {}, *dpHalf[kDpWorkers] = {}; std::string err; };
     const std::vector<int> &dpDevices = shared.loaded ? shared.devices : devices;
     std::vector<PreDp> preDp(dpDevices.size());
@@ -1059,6 +1061,8 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             stageBatches.push_back(nb);
         }
         dpq.freeBatches = stageBatches;
+        // the searches of a paired run share the device with the DP stages of the chunks before: their grids leave a workgroup per compute unit to the DP kernels
+        if (paired) for (s3_batch *sb : stageBatches) if (s3_batch_set_grid(sb, 3) != S3_OK) return dieJoin(s3_last_error());
         for (int wk = 0; wk < nDpWorkers; wk++) dpWorkers[wk] = std::thread([&, wk] {
             s3_dp *dpW = dpSet[wk], *halfW = halfSet[wk];
             s3_batch *seedW = seedSet[wk];
@@ -1154,6 +1158,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     if (postOn) {
         s3_batch *nb = nullptr;                                                   // (one more batch takes turns: the one the post thread holds)
         if (s3_batch_create(ix, chunk->n == chunkReads ? chunkReads : chunk->n, chunk->wpq, &nb) != S3_OK) return dieJoin(s3_last_error());
+        if (paired && pipelinedDp && s3_batch_set_grid(nb, 3) != S3_OK) return dieJoin(s3_last_error());
         stageBatches.push_back(nb);
         { std::lock_guard<std::mutex> g(dpq.mu); dpq.freeBatches.push_back(nb); }
         postThread = std::thread([&] {
