@@ -47,7 +47,8 @@ using namespace unit;
 // COUNT: with the statistics of s3_batch_enable_counters (rank queries, trips, longest unit ...): ten more registers, measurement runs only
 // (four waves per SIMD = 128 registers.  Five -- 96 registers, 29 dwords of the lane state spilled, 154 KB of LDS per CU -- was tried in round 5:
 //  the unit passes of a ladder 149 -> 187 ms, profiles/README_r05.md)
-template <bool UNIFORM, bool COUNT>
+// CEIN: units may verify candidates themselves (in.ceGiveUp > 0; the default since the fast trips is 0: the launch takes the kernel without that machinery)
+template <bool UNIFORM, bool COUNT, bool CEIN>
 __global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_UNIT_WAVES_PER_SIMD)
 unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 {
@@ -181,7 +182,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (i < lenEff && alive) {
                 const int pos = sc.start() + sc.dir() * i;
                 if ((aR - aL) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd()) {
-                    if ((ceHist & 0xFFFFu) < giveUp) { ceL = fwdL(); ceNK = aR - aL + 1u; state = U_CE_SA; return; }      // the lane verifies them itself
+                    if (CEIN && (ceHist & 0xFFFFu) < giveUp) { ceL = fwdL(); ceNK = aR - aL + 1u; state = U_CE_SA; return; }      // the lane verifies them itself
                     if (pendMeta >> 31) { state = U_RESUME; return; }
                     pendMeta = 0x80000000u | seq | S3_REC_TASK;
                     pendA = fwdL();
@@ -386,7 +387,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint4 *aP0 = dummy16, *aP1 = dummy16, *aPT = dummy16;
         const uint32_t *aD0 = ix.pac, *aCut = ix.pac;
         if (state == U_STEP) stepAsk(iL, iR, needB, dir, ownLine, aP0, aP1, aD0);
-        else if (state == U_CE_TEXT) {
+        else if (CEIN && state == U_CE_TEXT) {
             const int ceT = (int)(ceWhere & 7u), ceII = (int)((ceWhere >> 3) & 0x7FFu);
             const S3Step st = stepAt(ceT);
             const int pos = st.start + st.dir * ceII;
@@ -394,7 +395,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             textLine = (ceRp + left + (ceProg & 0xFFFFu)) >> 8;
             ownLine = (const uint4 *)ix.pac + (size_t)textLine * 4u;
             if ((ceNK >> 8) + 1u < (ceNK & 0xFFu)) aD0 = ix.sa + ceL + (ceNK >> 8) + 1u;     // the next candidate's suffix-array entry rides along
-        } else if (state == U_CE_SA) {
+        } else if (CEIN && state == U_CE_SA) {
             aD0 = ix.sa + ceL + (ceNK >> 8);
         } else if (state == U_LOAD) {
             const uint4 *src = (const uint4 *)(in.readsT + (size_t)aux * 2u * wpq + (size_t)(subN & 1u) * wpq + loadOff);
@@ -404,9 +405,10 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         } else if (state == U_ADOPT) {
             aP0 = stk + aux;
         }
-        const bool running = state == U_STEP || state == U_POPWAIT || state == U_CE_SA || state == U_CE_TEXT || state == U_RESUME;
+        const bool inCe = CEIN && (state == U_CE_SA || state == U_CE_TEXT);
+        const bool running = state == U_STEP || state == U_POPWAIT || inCe || state == U_RESUME;
         const bool wantTos = running && !tosValid && sp > sb;
-        const bool wantCut = wantTos || state == U_CE_SA || state == U_CE_TEXT || state == U_ADOPT;
+        const bool wantCut = wantTos || inCe || state == U_ADOPT;
         if (wantTos) aPT = stk + ((sp - 1u) & (S3_UNIT_STACK - 1u)) * 64u + lane;
         if (wantCut) aCut = out.readCut + listed;
         // ---------- issue: the cooperative lines (4 adjacent lanes fetch the 4 x 16 B of one owner's line: the owner's address travels by ds_bpermute,
@@ -514,14 +516,14 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         }
         // ---------- check-and-extend by the lane itself (BGS-HostAlgnmtAlgo2.cpp:86-169: per candidate its suffix-array entry, then the text under the rest of the model, one 64-byte line = 256 characters per trip, compared as ceKernel compares) ----------
         if constexpr (COUNT) {
-            const unsigned long long cm = __ballot(state == U_CE_SA || state == U_CE_TEXT);
+            const unsigned long long cm = __ballot(CEIN && (state == U_CE_SA || state == U_CE_TEXT));
             dCeWave += cm ? 1u : 0u;
-            dCeLane += (state == U_CE_SA || state == U_CE_TEXT) ? 1u : 0u;
+            dCeLane += (CEIN && (state == U_CE_SA || state == U_CE_TEXT)) ? 1u : 0u;
             dStepLane += state == U_STEP ? 1u : 0u;
             dPopLane += (doSettle && needPop) || state == U_POPWAIT ? 1u : 0u;
             dParked += state == U_RESUME || state == U_POPWAIT ? 1u : 0u;
         }
-        if (state == U_CE_SA || state == U_CE_TEXT) {
+        if (CEIN && (state == U_CE_SA || state == U_CE_TEXT)) {
             bool textHere = state == U_CE_TEXT;                               // the line of this trip belongs to the current candidate
             bool fresh = !textHere;                                           // the current candidate has not been set up yet
             const uint32_t ceN = ceNK & 0xFFu;
@@ -796,21 +798,16 @@ int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out,
     uint64_t blocks = ((uint64_t)in.nActive * (uint64_t)in.nCases * 2u * in.unitsPerItem + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + S3_UNIT_RDY_BYTES + in.wLds * 256u);
-    const bool count = out.counters != nullptr;
-    const void *fn = in.uniformLen ? (count ? (const void *)unitKernel<true, true> : (const void *)unitKernel<true, false>)
-                                   : (count ? (const void *)unitKernel<false, true> : (const void *)unitKernel<false, false>);
+    const bool count = out.counters != nullptr, cein = in.ceGiveUp != 0u;
+    using Kern = void (*)(DevIndex, SearchIn, SearchOut);
+    static const Kern kerns[8] = {unitKernel<false, false, false>, unitKernel<false, false, true>, unitKernel<false, true, false>, unitKernel<false, true, true>,
+                                  unitKernel<true, false, false>,  unitKernel<true, false, true>,  unitKernel<true, true, false>,  unitKernel<true, true, true>};
+    const Kern fn = kerns[(in.uniformLen ? 4 : 0) + (count ? 2 : 0) + (cein ? 1 : 0)];
     if (lds > 48u * 1024u) {
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    const dim3 grid((unsigned)blocks), block(S3_SEARCH_BLOCK);
-    if (in.uniformLen) {
-        if (count) hipLaunchKernelGGL((unitKernel<true, true>), grid, block, lds, s, ix, in, out);
-        else hipLaunchKernelGGL((unitKernel<true, false>), grid, block, lds, s, ix, in, out);
-    } else {
-        if (count) hipLaunchKernelGGL((unitKernel<false, true>), grid, block, lds, s, ix, in, out);
-        else hipLaunchKernelGGL((unitKernel<false, false>), grid, block, lds, s, ix, in, out);
-    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(S3_SEARCH_BLOCK), lds, s, ix, in, out);
     return (int)hipSuccess;
 }
 
