@@ -660,6 +660,11 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.takeMin = (uint32_t)envSize("S3DP_TAKE_MIN", S3_UNIT_TAKE_MIN);
     if (in.takeMin < 1u) in.takeMin = 1u;
     if (in.takeMin > 64u) in.takeMin = 64u;
+    in.pruneUnits = (uint32_t)envSize("S3DP_PRUNE_UNITS", 1);
+    in.tailAge = (uint32_t)envSize("S3DP_TAIL_AGE", S3_UNIT_TAIL_AGE);
+    in.giantAge = (uint32_t)envSize("S3DP_GIANT_AGE", S3_UNIT_GIANT_AGE);
+    in.giantIdle = (uint32_t)envSize("S3DP_GIANT_IDLE", S3_UNIT_GIANT_IDLE);
+    if (in.giantIdle < 1u) in.giantIdle = 1u;
     in.fastTrips = (uint32_t)envSize("S3DP_FAST_TRIPS", S3_UNIT_FAST_TRIPS);
     in.fastMin = (uint32_t)envSize("S3DP_FAST_MIN", S3_UNIT_FAST_MIN);
     if (in.fastMin < 1u) in.fastMin = 1u;
@@ -744,6 +749,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             // S3DP_VERBOSE=1 with counters enabled: reads, listed reads, rank queries and milliseconds of every launch of this pass (stderr)
             static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
             unsigned long long rankSeen = counterSnap[0], tripsSeen = counterSnap[6], wavesSeen = counterSnap[9], adoptSeen = counterSnap[8], saSeen = counterSnap[2], ceSeen = counterSnap[3], accSeen = counterSnap[10];
+            unsigned long long waveTicksSeen = counterSnap[19], wavesCountSeen = counterSnap[20];
             unsigned long long dSeen[8] = {counterSnap[11], counterSnap[12], counterSnap[13], counterSnap[14], counterSnap[15], counterSnap[16], counterSnap[17], counterSnap[18]};
             auto lapT = std::chrono::steady_clock::now();
             auto lap = [&](const char *what, uint64_t units) {
@@ -759,6 +765,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                 if (c[9] - wavesSeen)
                     fprintf(stderr, "[s3dp]   unit kernel paths: %llu wave trips with a lane in check-and-extend (%llu lane trips), %llu stepping lane trips, %llu lane pops, %llu wave trips that book\n",
                             c[11] - dSeen[0], c[12] - dSeen[1], c[13] - dSeen[2], c[15] - dSeen[4], c[14] - dSeen[3]);
+                if (c[20] - wavesCountSeen)
+                    fprintf(stderr, "[s3dp]   %llu waves, %.2f ms on average from their first instruction to their last (of the launch's time above: the rest is its tail and its launch)\n",
+                            c[20] - wavesCountSeen, (double)(c[19] - waveTicksSeen) * 1e-5 / (double)(c[20] - wavesCountSeen));
+                waveTicksSeen = c[19]; wavesCountSeen = c[20];
                 if (c[16] - dSeen[5])
                     fprintf(stderr, "[s3dp]   unit kernel fast trips: %llu of the wave trips (%llu stepping lane trips in them); %llu lane trips parked at a full trip\n",
                             c[16] - dSeen[5], c[17] - dSeen[6], c[18] - dSeen[7]);
@@ -806,7 +816,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                     // the unit pass (s3dp_unit.hip) lets idle lanes adopt frames of busy ones once the queue is empty: every adopted frame counts its
                     // records in a counter of its own behind the units' (S3DP_UNIT_NODES of them, 0: none)
                     const bool newUnitPass = U > 1;
-                    size_t dynCap = newUnitPass ? envSize("S3DP_UNIT_NODES", 1u << 23) : 0;
+                    size_t dynCap = newUnitPass ? envSize("S3DP_UNIT_NODES", 1u << 24) : 0;
                     const size_t nStatic = nItems + (size_t)nHeavy * groups * U + 1;
                     if (nStatic + dynCap >= 0x7FFFFF00ull) dynCap = 0;
                     const size_t need = nStatic + dynCap;

@@ -20,8 +20,11 @@
 #define S3_UNIT_FAST_MIN 32u               // ... made while this many of its lanes are stepping (S3DP_FAST_MIN)
 #define S3_FIRST_FAST_TRIPS 3u             // the same for the first pass and the trunk pass (S3DP_FIRST_FAST_TRIPS / S3DP_FIRST_FAST_MIN)
 #define S3_FIRST_FAST_MIN 40u
+#define S3_UNIT_GIANT_AGE 48u              // full trips on one unit that make a lane a giant whose frames its wave adopts before the queue is empty (S3DP_GIANT_AGE; 0: never)
+#define S3_UNIT_GIANT_IDLE 8u
+#define S3_UNIT_TAIL_AGE 0u
 #define S3_UNIT_NODE_BLOCK 256u           // sub-unit counters a wave of the unit pass reserves with one atomic
-#define S3_NUM_COUNTERS 20                 // 64-bit tallies of a kernel (SearchOut::counters)
+#define S3_NUM_COUNTERS 22                 // 64-bit tallies of a kernel (SearchOut::counters)
 #define S3_NUM_ROLES 4                     // ... kept per kernel of a search pass: first pass, trunk pass, unit pass, check-and-extend (s3_batch_kernel_stats)
 #define S3_COUNTER_WORDS (S3_NUM_COUNTERS * S3_NUM_ROLES)
 #define S3_FLAG_STACK_OVERFLOW 1u
@@ -84,6 +87,9 @@ struct SearchIn {
     uint32_t        ceGiveUp;      // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel (S3_CE_GIVE_UP)
     uint32_t        adoptIdle;   // unit pass: idle lanes a wave needs before its busy lanes give frames away (S3_UNIT_ADOPT_IDLE)
     uint32_t        takeMin;     // unit pass: idle lanes a wave lets gather before they start their next units together (S3_UNIT_TAKE_MIN; 1: at once)
+    uint32_t        pruneUnits;          // trunk pass: positions without a live mismatch child keep no state, i.e. start no unit (S3DP_PRUNE_UNITS=0: they do)
+    uint32_t        tailAge;             // unit pass, queue empty: full trips a lane must have spent on its unit before it gives frames away (S3DP_TAIL_AGE)
+    uint32_t        giantAge, giantIdle; // unit pass: full trips on one unit that make a lane a giant (0: never), idle lanes of its wave before they adopt its frames (S3DP_GIANT_AGE / _IDLE)
     uint32_t        fastTrips, fastMin;  // unit pass: step-only trips between two full trips (S3_UNIT_FAST_TRIPS), made while fastMin lanes of the wave are stepping
     uint32_t        firstFastTrips, firstFastMin;  // the same for the first pass and the trunk pass
     uint32_t        earlyCe;     // ranges of up to this many suffixes leave the exact lookup step for check-and-extend at once (0: never; s3dp_search_common.h)

@@ -65,6 +65,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     int sStar = 0;                                                          // (TRUNK) the first step of the case that allows a mismatch
     uint4 *stk = out.unitStack + (size_t)(blockIdx.x * (S3_SEARCH_BLOCK / 64u) + wv) * S3_UNIT_STACK * 64u;     // frame d of lane k: stk[(d % S3_UNIT_STACK) * 64 + k]
 
+    const unsigned long long tWave0 = COUNT ? wall_clock64() : 0ULL;        // (COUNT) the wave's own duration in 10 ns ticks
     uint32_t nRank = 0, nLt = 0, nWaveTrips = 0, nLaneTrips = 0, nStepLane = 0, nFastWave = 0, nFastLane = 0, nParked = 0;     // (COUNT)
 
     // ---- per-lane state ----
@@ -255,7 +256,13 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         doSettle = true;
         bool taken = false;
         const bool trunkHere = onTrunk && s == sStar;                      // no mismatch is taken in this step: the units take them
-        if (trunkHere && (uint32_t)i + 1u < U) leaveState((uint32_t)i);
+        if (trunkHere && (uint32_t)i + 1u < U) {
+            // A position none of whose mismatch children is alive keeps no state: its unit would load its read, make this very step, find nothing and retire --
+            // five trips of a lane for nothing, and with three and four mismatches most units are of that kind (round 5).  The ranks are the ones the unit would
+            // compute: same range, same position, same character.
+            const bool anyKid = (ch != 0 && oL.x + 1u <= oR.x) || (ch != 1 && oL.y + 1u <= oR.y) || (ch != 2 && oL.z + 1u <= oR.z) || (ch != 3 && oL.w + 1u <= oR.w);
+            if (anyKid || !in.pruneUnits) leaveState((uint32_t)i);
+        }
         if (!exact && !trunkHere) {
             const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
             const bool a2 = ch != 2 && oL.z + 1u <= oR.z, a3 = ch != 3 && oL.w + 1u <= oR.w;
@@ -606,6 +613,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (lane == 0) atomicAdd(&out.counters[16], (unsigned long long)nFastWave);
             atomicAdd(&out.counters[17], (unsigned long long)nFastLane);
             atomicAdd(&out.counters[18], (unsigned long long)nParked);
+            if (lane == 0) { atomicAdd(&out.counters[19], wall_clock64() - tWave0); atomicAdd(&out.counters[20], 1ULL); }
         }
     }
 }

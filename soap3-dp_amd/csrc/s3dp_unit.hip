@@ -76,6 +76,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     uint4 *stk = out.unitStack + (size_t)(blockIdx.x * (S3_SEARCH_BLOCK / 64u) + wv) * S3_UNIT_STACK * 64u;     // frame d of lane k: stk[(d % S3_UNIT_STACK) * 64 + k]
     const uint32_t giveUp = in.ceGiveUp < 0xFFFFu ? in.ceGiveUp : 0xFFFFu, inlineMax = in.ceInlineMax < 0xFFFFu ? in.ceInlineMax : 0xFFFFu;
 
+    const unsigned long long tWave0 = COUNT ? wall_clock64() : 0ULL;        // (COUNT) the wave's own duration in 10 ns ticks, summed over the grid: how much of a launch is its tail
     // ---- statistics (COUNT) ----
     uint32_t nRank = 0, nSaL = 0, nCeL = 0, nCutSkip = 0, nCutMid = 0, unitTrips = 0, maxUnitTrips = 0, nAdopt = 0;
     unsigned long long laneTrips = 0, waveTrips = 0;
@@ -108,6 +109,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     uint32_t ceHist = 0;                                                    // rejected candidates in a row | occurrences verified by the lane << 16
     uint32_t pendMeta = 0, pendA = 0, pendB = 0;
     uint32_t countPending = 0;
+    uint32_t age = 0;                                                       // full trips the lane has spent on its unit (a GIANT: more than in.giantAge)
     // ---- wave-uniform ----
     uint32_t recCur = 0, recEnd = 0;                                        // reserved record block
     uint32_t nodeCur = 0, nodeEnd = 0;                                      // reserved sub-unit counters
@@ -305,7 +307,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 first = p + 1u != U;
                 i = (int)p;                                                 // (the unit without a mismatch in this step: behind the step's last position, set when the step is known)
                 ins = 0; occ = 0; seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
-                ceHist = 0; countPending = 0;
+                ceHist = 0; countPending = 0; age = 0;
                 if constexpr (COUNT) unitTrips = 0;
                 loadOff = 0;
                 state = U_LOAD;
@@ -315,18 +317,32 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             idleMask = __ballot(state == U_IDLE);
         }
         // ---------- the queue: what this trip does for it ----------
-        const bool stageA = !queueEmpty && !basePending;                    // take the next chunk's number (lane 0's atomic rides with this trip's loads)
+        // GIANTS.  A unit is a few dozen steps; one in a million is ten thousand (the longest unit of the benchmark's phase 2: 13,000 trips of ONE lane, 60 ms --
+        // the length of the whole launch), and until the queue was empty nobody helped it.  A lane that has been on its unit for more than in.giantAge full trips
+        // and has frames to give is a giant: its wave takes no further chunks from the queue (the other waves take them), and as its lanes run out of units they
+        // adopt the giant's oldest frames -- the mechanism of the tail, started while the rest of the device still has work (unit passes 115.9 -> 111.2 ms).
+        // (Measured beside it and left out: records parked in LDS next to the one in registers, so that a lane with two or three task records need not wait
+        //  a full trip per record -- 113.6 / 114.0 / 114.5 ms with 0 / 1 / 2 slots; trunk positions without a live mismatch child keeping no state: 111.0 / 111.2.)
+        if (state != U_IDLE) age++;
+        const bool canGive = state != U_IDLE && state != U_LOAD && state != U_ADOPT && sp > sb;
+        const unsigned long long giantMask = in.giantAge && !noNodes ? __ballot(canGive && age > in.giantAge) : 0ULL;      // (no counters left for adopted frames: no giants)
+        const bool tail = queueEmpty && !basePending && rdyTaken >= rdyCount;
+        const bool early = !tail && giantMask && !basePending && rdyTaken >= rdyCount;
+        const bool stageA = !queueEmpty && !basePending && !giantMask;      // take the next chunk's number (lane 0's atomic rides with this trip's loads)
         const bool stageB = basePending && rdyTaken >= rdyCount;            // load and test the chunk
-        if (queueEmpty && !basePending && rdyTaken >= rdyCount && idleMask) {
-            if (idleMask == ~0ULL) break;                                   // nothing left anywhere
+        if ((tail || early) && idleMask) {
+            if (tail && idleMask == ~0ULL) break;                           // nothing left anywhere
             // ---------- adoption: idle lanes take the oldest frames of busy lanes ----------
-            // (only once half of the wave is idle: a lane that finishes a little before its neighbours is no tail, and every adopted frame takes a counter)
-            const bool canGive = state != U_IDLE && state != U_LOAD && state != U_ADOPT && sp > sb;
-            const unsigned long long giveMask = __ballot(canGive);
+            // (in the tail only once half of the wave is idle: a lane that finishes a little before its neighbours is no tail, and every adopted frame takes a
+            //  counter; from a giant: as soon as in.giantIdle lanes are free)
+            // (in.tailAge: full trips a giver of the tail must have spent on its unit.  0: measured, round 5 -- with three and four mismatches a pass makes 8 M
+            //  adoptions in 8 M wave trips, and asking the givers for 3 / 8 / 16 / 32 full trips first made the unit passes 111.3 / 112.5 / 114.7 / 121.0 ms (111.0))
+            const bool gives = tail ? (canGive && age > in.tailAge) : (canGive && age > in.giantAge);
+            const unsigned long long giveMask = tail ? __ballot(gives) : giantMask;
             uint32_t nPairs = (uint32_t)__popcll(giveMask);
             const uint32_t nIdle = (uint32_t)__popcll(idleMask);
             if (nIdle < nPairs) nPairs = nIdle;
-            if (nIdle < in.adoptIdle) nPairs = 0;
+            if (nIdle < (tail ? in.adoptIdle : in.giantIdle)) nPairs = 0;
             if (nPairs && !noNodes) {
                 if (nodeCur + nPairs > nodeEnd) {
                     // (what is left of the old block is dropped: a few counters nobody uses)
@@ -343,7 +359,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (nPairs) {
                 const uint32_t gRank = __builtin_amdgcn_mbcnt_hi((uint32_t)(giveMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)giveMask, 0u));
                 const uint32_t iRank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
-                if (canGive && gRank < nPairs) {
+                if (gives && gRank < nPairs) {
                     const uint32_t node = nodeCur + gRank, newCnt = out.dynBase + node;
                     // the new counter follows the giver's: whatever the giver still finds comes before the frame it gives away.  (Only the lane that
                     // owns a counter writes its link, so it reads back what it wrote.)
@@ -368,7 +384,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                     for (uint32_t w = 0; w < wl; w++) ro[w * 64u + lane] = ro[w * 64u + giver];
                     first = false;
                     seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
-                    ceHist = 0; countPending = 0;
+                    ceHist = 0; countPending = 0; age = 0;
                     if constexpr (COUNT) { unitTrips = 0; nAdopt++; }
                     state = U_ADOPT;
                 }
@@ -732,6 +748,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (lane == 0) atomicAdd(&out.counters[16], (unsigned long long)dFastWave);
             atomicAdd(&out.counters[17], (unsigned long long)dFastLane);
             atomicAdd(&out.counters[18], (unsigned long long)dParked);
+            if (lane == 0) { atomicAdd(&out.counters[19], wall_clock64() - tWave0); atomicAdd(&out.counters[20], 1ULL); }
         }
     }
 }

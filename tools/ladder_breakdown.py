@@ -20,3 +20,8 @@ for r in rows[a:b]:
 print("ladder window %.2f ms, kernels %.2f ms" % ((t1 - t0) / 1e6, busy / 1e6))
 for name, d in acc.most_common(40):
     print("%8.3f ms  %4d  %s" % (d / 1e6, calls[name], name))
+print("the search kernels' launches in order (ms):")
+for r in rows[a:b]:
+    n = r["Kernel_Name"]
+    if "firstKernel" in n or "unitKernel" in n or "ceKernel" in n:
+        print("  %8.3f  %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, n.split("(")[0][-44:]))
