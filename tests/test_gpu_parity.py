@@ -75,6 +75,9 @@ KNOBS = [
     {"S3DP_HEAVY": "2", "S3DP_FAST_MIN": "1", "S3DP_FAST_TRIPS": "3", "S3DP_FIRST_FAST_MIN": "1", "S3DP_FIRST_FAST_TRIPS": "3"},
     {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8", "S3DP_FAST_MIN": "2", "S3DP_FAST_TRIPS": "15", "S3DP_FIRST_FAST_MIN": "2", "S3DP_FIRST_FAST_TRIPS": "15", "S3DP_CE_GIVE_UP": "2"},
     {"S3DP_HEAVY": "2", "S3DP_FAST_TRIPS": "0", "S3DP_FIRST_FAST_TRIPS": "0", "S3DP_CE_GIVE_UP": "2"},     # none at all, units verify candidates (rounds 3-4)
+    # every lane with a frame to give is a giant after its first full trip: frames are adopted while the queue still has work
+    {"S3DP_HEAVY": "2", "S3DP_GIANT_AGE": "1", "S3DP_GIANT_IDLE": "1", "S3DP_FAST_MIN": "4"},
+    {"S3DP_HEAVY": "2", "S3DP_GIANT_AGE": "0", "S3DP_PRUNE_UNITS": "0", "S3DP_TAIL_AGE": "2"},
 ]
 
 
