@@ -472,6 +472,8 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         if constexpr (COUNT) { nWaveTrips++; nLaneTrips += state != F_IDLE ? 1u : 0u; nStepLane += state == F_STEP ? 1u : 0u; nParked += state == F_RESUME || state == F_POPWAIT ? 1u : 0u; }
         if (wantTos) { tos = pT; tosValid = true; }
         // a read that has cost this many rank queries is heavy whatever it has found so far (dead ends cost steps, not candidates)
+        // (a quarter of the budget once the queue is empty -- against the launch's tail -- was measured in round 5: 260 k listed reads instead of 155 k in the
+        //  first phase, for the queue is empty while 262 k reads are still under way: 253.5 -> 291.9 ms per step)
         if (!TRUNK && state == F_STEP && readRank > in.heavyRank) { goHeavy = true; state = F_DONE; sp = 0; tosValid = false; }
         if (state == F_STEP) stepTake(iL, iR, needB, dir, p0, p1, d0, doSettle, needPop);
         else if (state == F_RESUME) { doSettle = true; needPop = false; }

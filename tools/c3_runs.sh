@@ -1,5 +1,5 @@
 #!/bin/bash
-# the paired command line on the 10 M C3 pairs (files of tools/c3_profile.sh / c3_chunk_sweep.sh reused when present) under environment settings, outputs to /dev/null:
+# the paired command line on the 10 M C3 pairs (files of tools/c3_profile.sh / c3_runs.sh reused when present) under environment settings, outputs to /dev/null:
 #   tools/c3_runs.sh <outdir> tag[:VAR=val,VAR=val] ...         (every run twice; the lines give "Alignment + output" and the device times)
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
