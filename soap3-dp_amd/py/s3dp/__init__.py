@@ -362,6 +362,12 @@ class Batch:
         f.argtypes = [C.c_void_p, C.c_int]
         _chk(f(self.h, 1 if background else 0))
 
+    def set_grid(self, blocks_per_cu):
+        """width of this batch's persistent search grids in workgroups per compute unit (0: all that are resident at once) -- s3_batch_set_grid"""
+        f = lib().s3_batch_set_grid
+        f.argtypes = [C.c_void_p, C.c_uint]
+        _chk(f(self.h, int(blocks_per_cu)))
+
     def enable_counters(self, on=True):
         _chk(lib().s3_batch_enable_counters(self.h, 1 if on else 0))
 

@@ -115,6 +115,27 @@ def test_search_knobs_do_not_change_results(monkeypatch, name, maxlen, mm, knobs
     b.close()
 
 
+def test_search_grid_width_does_not_change_results(monkeypatch):
+    """s3_batch_set_grid: the paired command line narrows its search grids to leave room for the DP kernels; one workgroup per compute unit, three, and all again"""
+    monkeypatch.setenv("S3DP_HEAVY", "2")
+    reads = golden_reads("g2")
+    q, lens, wpq = s3dp.pack_reads(reads, 120)
+    b = s3dp.Batch(dev_index("g2"), len(reads), wpq)
+    b.upload(q, lens)
+    oix = s3o.Index(host_index=host_index("g2"))
+    ohits, ooffs, otot, owerr, st = oix.search(q, lens, wpq, 3, max_out=1000)
+    for width in (1, 3, 0):
+        b.set_grid(width)
+        b.search(3, 1000)
+        hits, offs, tot, werr = b.fetch_hits()
+        assert (offs == ooffs).all() and hits.tobytes() == ohits.tobytes()
+        assert (tot == otot).all() and (werr == owerr).all()
+    with pytest.raises(s3dp.S3Error):
+        b.set_grid(17)
+    oix.close()
+    b.close()
+
+
 @pytest.mark.parametrize("extra", [1, 2, 3])
 @pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120)])
 def test_long_lookup_tables_do_not_change_results(monkeypatch, name, maxlen, extra):
