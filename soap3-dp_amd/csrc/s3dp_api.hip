@@ -654,7 +654,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
             in.sStarPacked |= (uint32_t)sStar << (3 * c);
         }
     }
-    in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0;
+    in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0; in.unitGroup = 1;
     in.ceGiveUp = (uint32_t)envSize("S3DP_CE_GIVE_UP", S3_CE_GIVE_UP);
     in.adoptIdle = (uint32_t)envSize("S3DP_ADOPT_IDLE", S3_UNIT_ADOPT_IDLE);
     in.takeMin = (uint32_t)envSize("S3DP_TAKE_MIN", S3_UNIT_TAKE_MIN);
@@ -712,7 +712,11 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                 if (lenEff > longest) longest = lenEff;
             }
         }
-        if (ok && longest > 0) unitsPerItem = (uint32_t)longest + 1u;
+        // (round 5: a unit is a GROUP of consecutive positions -- a unit per position is seven steps long with three and four mismatches, and starting it costs
+        //  as much as walking it; s3dp_unit.hip, "GROUPS")
+        in.unitGroup = (uint32_t)envSize("S3DP_UNIT_GROUP", S3_UNIT_GROUP);
+        if (in.unitGroup < 1u) in.unitGroup = 1u;
+        if (ok && longest > 0) unitsPerItem = ((uint32_t)longest + in.unitGroup - 1u) / in.unitGroup + 1u;
     }
     uint32_t nHeavy = 0, nCount = (uint32_t)nItems;                         // entries of itemCounts in use: the items, then the units of the listed reads
     for (;;) {

@@ -23,6 +23,7 @@
 #define S3_UNIT_GIANT_AGE 48u              // full trips on one unit that make a lane a giant whose frames its wave adopts before the queue is empty (S3DP_GIANT_AGE; 0: never)
 #define S3_UNIT_GIANT_IDLE 8u
 #define S3_UNIT_TAIL_AGE 0u
+#define S3_UNIT_GROUP 2u                   // first-mismatch positions per unit of the second pass (S3DP_UNIT_GROUP)
 #define S3_UNIT_NODE_BLOCK 256u           // sub-unit counters a wave of the unit pass reserves with one atomic
 #define S3_NUM_COUNTERS 22                 // 64-bit tallies of a kernel (SearchOut::counters)
 #define S3_NUM_ROLES 4                     // ... kept per kernel of a search pass: first pass, trunk pass, unit pass, check-and-extend (s3_batch_kernel_stats)
@@ -80,7 +81,8 @@ struct SearchIn {
     const uint32_t *slotList;    // second pass (item mode: one work unit per item of a listed read): the listed slots ...
     const uint32_t *slotCount;   // ... and how many (device memory, written by the first pass)
     uint32_t        unitMode;      // 0: first pass (a unit = a read); 1: trunk pass over the listed reads' items; 2: unit pass (s3dp_first.hip, s3dp_unit.hip)
-    uint32_t        unitsPerItem;  // second pass: first-mismatch positions an item is cut into, + 1 for "none" (1: whole items)
+    uint32_t        unitsPerItem;  // second pass: units an item is cut into -- GROUPS of unitGroup consecutive first-mismatch positions, + 1 for "none" (1: whole items)
+    uint32_t        unitGroup;     // second pass: consecutive positions per unit (S3DP_UNIT_GROUP; 1: one unit per position, as until round 5)
     uint32_t        unitBase;      // second pass: unit u counts its records in itemCounts[unitBase + u]
     uint32_t        sStarPacked;   // 3 bits per case: the first step that allows a mismatch (= nSteps: none)
     uint32_t        ceInlineMax;   // second pass: occurrences a unit verifies itself before it hands the rest of its candidates to ceKernel

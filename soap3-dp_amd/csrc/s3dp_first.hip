@@ -256,7 +256,11 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         doSettle = true;
         bool taken = false;
         const bool trunkHere = onTrunk && s == sStar;                      // no mismatch is taken in this step: the units take them
-        if (trunkHere && (uint32_t)i + 1u < U) {
+        if (trunkHere && in.unitGroup > 1u) {
+            // a unit is a group of in.unitGroup positions: the state is left where a group begins (the unit walks the trunk's path through its group itself)
+            const uint32_t g = (uint32_t)i / in.unitGroup;
+            if (g + 1u < U && (uint32_t)i == g * in.unitGroup) leaveState(g);
+        } else if (trunkHere && (uint32_t)i + 1u < U) {
             // A position none of whose mismatch children is alive keeps no state: its unit would load its read, make this very step, find nothing and retire --
             // five trips of a lane for nothing, and with three and four mismatches most units are of that kind (round 5).  The ranks are the ones the unit would
             // compute: same range, same position, same character.

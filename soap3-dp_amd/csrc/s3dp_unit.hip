@@ -94,7 +94,13 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     uint32_t subN = 0;                                                      // item (case * 2 + strand) | number of steps of the case << 8
     uint32_t listed = 0, unitInRead = 0;
     uint32_t cntIdx = 0, seq = 0, total = 0;
-    bool first = false;                                                     // the unit's first step: only the mismatch children at its position
+    // GROUPS (round 5).  A unit is the part of an item's search tree whose first mismatch sits in ONE GROUP of in.unitGroup consecutive positions of the first
+    // mismatch step: the lane starts from the trunk's state at the group's first position and walks the trunk's own path -- no mismatch yet -- through the group,
+    // taking the mismatch children at every position (children first, ascending, then the continuation: the CPU path's order) and DROPPING the continuation at
+    // the group's last position, where the next unit begins.  On that path it is in the trunk's footsteps: where the trunk handed its range to check-and-extend
+    // and ended, the unit ends too, silently -- the record is the trunk's.  (Until round 5 a group was one position: seven steps per unit with three and four
+    // mismatches, and loading the read, repeating the trunk's step and retiring cost as much as the walk.)
+    uint32_t groupEnd = 0;                                                  // first position behind the unit's group (0: the unit "none", behind the step's last position)
     uint32_t sp = 0, sb = 0;                                                // frames [sb, sp) of the ring are the lane's stack
     uint4 tos = make_uint4(0, 0, 0, 0);                                     // copy of frame sp - 1 ...
     bool tosValid = false;                                                  // ... when this is set
@@ -120,6 +126,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 #define casIdx (((subN) & 0xFFu) >> 1)
 #define subIdx ((subN) & 0xFFu)
 #define nSteps ((int)((subN) >> 8))
+    auto sUnit = [&]() -> uint32_t { return (in.sStarPacked >> (3u * casIdx)) & 7u; };     // the step the item is cut at (its first step that allows a mismatch)
     auto stepPtr = [&](int k) -> const uint32_t * {
         if constexpr (UNIFORM) return (const uint32_t *)&((const S3Model *)shmem)->cs[casIdx].st[k];
         else return (const uint32_t *)&in.models[Li].cs[casIdx].st[k];
@@ -184,6 +191,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (i < lenEff && alive) {
                 const int pos = sc.start() + sc.dir() * i;
                 if ((aR - aL) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd()) {
+                    if (groupEnd != 0u && s == (int)sUnit() && ins == 0) { needPop = true; continue; }      // in the trunk's footsteps: the trunk wrote this task and ended here
                     if (CEIN && (ceHist & 0xFFFFu) < giveUp) { ceL = fwdL(); ceNK = aR - aL + 1u; state = U_CE_SA; return; }      // the lane verifies them itself
                     if (pendMeta >> 31) { state = U_RESUME; return; }
                     pendMeta = 0x80000000u | seq | S3_REC_TASK;
@@ -253,8 +261,10 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint32_t cOc = ch == 0 ? e1 + e2 + e3 : ch == 1 ? e2 + e3 : ch == 2 ? e3 : 0u;
         const uint32_t gAl = sel4(oL, ch) + 1u, gAr = sel4(oR, ch), gPr = pR - cOc;         // the continuation (the read's own character)
         doSettle = true;
-        const bool branchOnly = first;                                     // the unit's position: only the mismatch children (the continuation belongs to the later units)
-        first = false;
+        // on the trunk's path (no mismatch yet in the unit's step) at the group's last position, or at the step's last position for a first mismatch: only the
+        // mismatch children -- the continuation belongs to the next unit, or to the unit "none"
+        const int lenTrunk = sc.minErr() > 1 ? sc.len() - (sc.minErr() - 1) : sc.len();
+        const bool branchOnly = groupEnd != 0u && s == (int)sUnit() && ins == 0 && ((uint32_t)i + 1u >= groupEnd || i + 1 >= lenTrunk);
         bool taken = false;                                                // the lane goes on in a mismatch child
         if (!exact) {
             const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
@@ -304,8 +314,8 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 subN = sub | ((in.nStepsPacked >> (3u * cas)) & 7u) << 8;
                 s = (int)((in.sStarPacked >> (3u * cas)) & 7u);
                 cntIdx = in.unitBase + listed * groups * U + unitInRead;
-                first = p + 1u != U;
-                i = (int)p;                                                 // (the unit without a mismatch in this step: behind the step's last position, set when the step is known)
+                groupEnd = p + 1u != U ? (p + 1u) * in.unitGroup : 0u;
+                i = (int)(p * in.unitGroup);                                                 // (the unit without a mismatch in this step: behind the step's last position, set when the step is known)
                 ins = 0; occ = 0; seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
                 ceHist = 0; countPending = 0; age = 0;
                 if constexpr (COUNT) unitTrips = 0;
@@ -369,7 +379,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                     *myLink = newCnt;
                     out.dynOwner[node] = in.unitBase + listed * groups * U + unitInRead;
                     stage[gRank * 2u] = make_uint4(lane | (sb & (S3_UNIT_STACK - 1u)) << 8, listed, unitInRead, subN);
-                    stage[gRank * 2u + 1u] = make_uint4(newCnt, (uint32_t)Li, 0u, 0u);
+                    stage[gRank * 2u + 1u] = make_uint4(newCnt, (uint32_t)Li, groupEnd, 0u);     // (the frame may be the trunk path's continuation: the adopter must know where the group ends)
                     sb++;
                     if (sb == sp) tosValid = false;
                 }
@@ -382,7 +392,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                     cntIdx = m1.x;
                     if constexpr (!UNIFORM) Li = (int)m1.y;
                     for (uint32_t w = 0; w < wl; w++) ro[w * 64u + lane] = ro[w * 64u + giver];
-                    first = false;
+                    groupEnd = m1.z;
                     seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
                     ceHist = 0; countPending = 0; age = 0;
                     if constexpr (COUNT) { unitTrips = 0; nAdopt++; }
@@ -526,7 +536,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                     if (sc.dir() < 0) pR = rvl + (r - l);
                     else { aL = rvl; aR = rvl + (r - l); pR = r; }
                 }
-                if (first) state = U_STEP;
+                if (groupEnd) state = U_STEP;
                 else { i = sc.len(); doSettle = true; needPop = false; }         // the unit without a mismatch in this step: behind its last position
             }
         }

@@ -22,7 +22,7 @@ def dev_index(name):
 
 @pytest.mark.parametrize("name,maxlen", [("g1", 100), ("g2", 120), ("g6", 100)])     # g6: the ends of the text, padded lookup keys (tools/simulate_edge_case.py)
 @pytest.mark.parametrize("mm", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("heavy", ["0", "1", "2", "2i", "2g"])
+@pytest.mark.parametrize("heavy", ["0", "1", "2", "2i", "2g", "2p"])
 def test_search_bit_exact_vs_reference_dump_and_oracle(monkeypatch, name, maxlen, mm, heavy):
     """heavy: S3DP_HEAVY -- 0: every read is walked by one lane; 1 (the default): a read that reserves more than 256 check-and-extend candidates
     leaves the first pass and is taken apart by a second launch of the kernel, one lane per (item, position of the first mismatch) unit; 2: every
@@ -31,6 +31,8 @@ def test_search_bit_exact_vs_reference_dump_and_oracle(monkeypatch, name, maxlen
     monkeypatch.setenv("S3DP_UNITS", "0" if heavy.endswith("i") else "1")
     if heavy.endswith("g"):                                 # units never verify candidates themselves / always do
         monkeypatch.setenv("S3DP_CE_GIVE_UP", "0")
+    if heavy.endswith("p"):                                 # one first-mismatch position per unit (until round 5; the default is a group of four)
+        monkeypatch.setenv("S3DP_UNIT_GROUP", "1")
     reads = golden_reads(name)
     q, lens, wpq = s3dp.pack_reads(reads, maxlen)
     b = s3dp.Batch(dev_index(name), len(reads), wpq)
@@ -78,6 +80,11 @@ KNOBS = [
     # every lane with a frame to give is a giant after its first full trip: frames are adopted while the queue still has work
     {"S3DP_HEAVY": "2", "S3DP_GIANT_AGE": "1", "S3DP_GIANT_IDLE": "1", "S3DP_FAST_MIN": "4"},
     {"S3DP_HEAVY": "2", "S3DP_GIANT_AGE": "0", "S3DP_PRUNE_UNITS": "0", "S3DP_TAIL_AGE": "2"},
+    # units are groups of consecutive first-mismatch positions (default 4): one position per unit (until round 5), odd sizes, and one group for the whole step
+    {"S3DP_HEAVY": "2", "S3DP_UNIT_GROUP": "1"},
+    {"S3DP_HEAVY": "2", "S3DP_UNIT_GROUP": "3", "S3DP_GIANT_AGE": "1", "S3DP_GIANT_IDLE": "1", "S3DP_FAST_MIN": "2"},
+    {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8", "S3DP_UNIT_GROUP": "7"},
+    {"S3DP_HEAVY": "2", "S3DP_UNIT_GROUP": "200"},
 ]
 
 
