@@ -714,7 +714,9 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         }
         // (round 5: a unit is a GROUP of consecutive positions -- a unit per position is seven steps long with three and four mismatches, and starting it costs
         //  as much as walking it; s3dp_unit.hip, "GROUPS")
-        in.unitGroup = (uint32_t)envSize("S3DP_UNIT_GROUP", S3_UNIT_GROUP);
+        // Two for the single-end ladders (10 M x 100 bp: unit passes 111.4 -> 93.6 ms), one for the paired ladder and the seeds of the DP stages: the same
+        // pairs on the same box took 2.93 s with groups of two and 2.70 s with one position per unit (search kernels 1.36 against 1.19 s; README_r05 9.7)
+        in.unitGroup = (uint32_t)envSize("S3DP_UNIT_GROUP", b->unitGroup ? b->unitGroup : 1u);
         if (in.unitGroup < 1u) in.unitGroup = 1u;
         if (ok && longest > 0) unitsPerItem = ((uint32_t)longest + in.unitGroup - 1u) / in.unitGroup + 1u;
     }
@@ -1009,6 +1011,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
     if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_COUNTER_WORDS * 8, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
+    b->unitGroup = S3_UNIT_GROUP;
     HIPCHK(hipMemsetAsync(b->dWasHeavy, 0, b->maxReads, b->stream));
     int rc = searchPass(b, nullptr, b->n, numMismatch, maxOutputPerRead);
     if (rc) return rc;

@@ -77,6 +77,7 @@ struct s3_batch {
     s3::ScatterDyn scatterDyn{nullptr, nullptr, 0, 0};         // of the last search pass
     uint32_t mergeUnitBase = 0, mergeUnitsPerRead = 0;         // of the last search pass (0: no read was taken apart)
     uint32_t uniformLen = 0;
+    unsigned unitGroup = 1;                           // first-mismatch positions per unit of the second pass (SearchIn::unitGroup): set by the entry point -- single-end ladders 2, everything else 1
     unsigned blocksPerCu = 0;                         // width of the persistent search grid (0: all that is resident at once)
     uint32_t *dKept = nullptr, *dOccCounts = nullptr, *dCeCounts = nullptr, *dTotalOcc = nullptr, *dWithError = nullptr;
     uint32_t *dHitOffsets = nullptr;

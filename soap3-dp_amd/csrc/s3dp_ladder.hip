@@ -453,6 +453,7 @@ extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
     HIPCHK(hipMemsetAsync(b->dWasHeavy, 0, b->maxReads, b->stream));                  // the ladder's memory of the reads its first passes listed
+    b->unitGroup = S3_UNIT_GROUP;                                                       // units of the second pass: groups of two positions (searchPass)
     if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_COUNTER_WORDS * 8, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
     HIPCHK(hipMemsetAsync(b->dPhase, 0, n, b->stream));
@@ -652,6 +653,7 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
     b->recordsTotal = 0;
     HIPCHK(hipMemsetAsync(b->dFlags, 0, 4, b->stream));
     HIPCHK(hipMemsetAsync(b->dWasHeavy, 0, b->maxReads, b->stream));                  // the ladder's memory of the reads its first passes listed
+    b->unitGroup = 1;                                                                   // ... one position per unit for pairs (measured: searchPass)
     if (b->counting) HIPCHK(hipMemsetAsync(b->dCounters, 0, S3_COUNTER_WORDS * 8, b->stream));
     HIPCHK(hipEventRecord(b->evTotal[0], b->stream));
     HIPCHK(hipMemsetAsync(b->dPhase, 0, n ? n : 1, b->stream));

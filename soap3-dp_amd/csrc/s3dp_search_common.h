@@ -28,7 +28,9 @@
 //     ascending, then the continuation), so the units of an item, numbered by position, ARE its sequence order: each unit counts its records from
 //     zero and the counting scatter puts them behind each other -- a thousand lanes per heavy read, no sort.  The TRUNK pass (one lane per listed
 //     read and item) walks the item without taking a mismatch in that step and leaves the range it holds at every position; the UNIT pass (one
-//     lane per read, item and position) starts from those.
+//     lane per read, item and position) starts from those.  Since round 5 a unit is a GROUP of consecutive positions (two by default): the lane walks the
+//     trunk's path through its group -- writing nothing there: those records are the trunk's --, takes the mismatch children at every position and drops the
+//     continuation at the group's last one (s3dp_unit.hip, "GROUPS"): half the unit starts, the same order.
 //   * THE CUT.  The CPU path stops a read at MaxOutputPerRead occurrences.  The lanes of the unit pass verify their candidates themselves (up to a
 //     point: after in.ceGiveUp rejections in a row, or in.ceInlineMax verified occurrences, a unit writes task records like the first pass), book
 //     what they hold for sure in counters the units of their read share (itemAcc per item, the spare word of the trunk states per position), and
