@@ -1,8 +1,8 @@
 // s3dp_unit.hip -- the UNIT PASS of the 2BWT k-mismatch search for gfx950: the listed ("heavy") reads of a search pass, taken apart.
 //
 // What a unit is, and why the units of an item in position order ARE the CPU path's record order, is told in s3dp_search_common.h (s3dp_first.hip runs the
-// first pass and the trunk pass).  This file is the kernel that searches the units: one lane per (listed read, item, position p of the item's first
-// mismatch).  Until round 3 it was an instantiation of the one search kernel and carried everything that kernel could do -- read loading for both strands, lookup
+// first pass and the trunk pass).  This file is the kernel that searches the units: one lane per (listed read, item, GROUP of positions of the item's first
+// mismatch: two for single-end ladders, one for pairs -- "GROUPS" below).  Until round 3 it was an instantiation of the one search kernel and carried everything that kernel could do -- read loading for both strands, lookup
 // tables, key building, trunk bookkeeping, ten unconditional loads per lane and trip, the depth-first stack in scratch memory whose pops stalled
 // the wave in the middle of a trip -- at 153 registers and three waves per SIMD, and a launch lasted as long as its longest unit.  Here:
 //
@@ -21,7 +21,10 @@
 //   * and the tail: once the queue is empty, an idle lane ADOPTS the oldest frame of a busy lane of its wave -- the subtree that lane would have
 //     searched last.  Its records count from zero in a counter of their own that is linked right behind the giver's counter (SearchOut::chainNext);
 //     unitChainKernel turns the chains into offsets and the counting scatter places the records exactly where the single lane would have put
-//     them.  A unit of ten thousand trips becomes a few hundred trips of a whole wave; the order of the records does not change.
+//     them.  A unit of ten thousand trips becomes a few hundred trips of a whole wave; the order of the records does not change;
+//   * and since round 5: FAST TRIPS -- a full trip of the state machine is followed by up to seven trips that only step (the pass was bound by vector
+//     issue, two thirds of it the rare paths); GIANTS -- a lane long on its unit gives frames away before the queue is empty; units that verify no
+//     candidates themselves (the kernel is compiled without that machinery when in.ceGiveUp is 0: template parameter CEIN).
 //
 // Results are bit-identical to the CPU path: BGS-HostAlgnmtAlgo2.cpp:933-1071
 // (order), :86-169 (check-and-extend), DV-Kernel.cu:437-955 (what the reference's own kernels do per step).
