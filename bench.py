@@ -1466,6 +1466,96 @@ def summary_of(out):
     sm["lines"] = ["[summary] " + ln for ln in lines]
     return sm
 
+def _r(x, sig=6):
+    """numbers of the compact line: six significant digits are more than any of them is measured to"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+COMPACT_LIMIT = 8192                                                    # bytes; tests/test_bench_line_cpu.py holds the line to it
+
+
+def compact_line(out, full_path=None):
+    """The ONE stdout line.  The full object (tens of kilobytes: every leg's counts, checks and texts) goes to a side file and to stderr; the line the
+    driver parses carries the contract's keys, the roofline of the search kernels with every kernel's own counts, the CPU baseline and a summary of the
+    other legs -- and stays under COMPACT_LIMIT bytes whatever the legs add (a 27 KB line was stored unparsed)."""
+    def g(d, *path, default=None):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+    cfg = out.get("config") or {}
+    roof = out.get("roofline") or {}
+    cpu = out.get("cpu_baseline") or {}
+    sm = out.get("summary") or summary_of(out)
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    wl = cfg.get("workload") or ""
+    line["config"] = {"workload": wl if len(wl) <= 400 else wl[:397] + "...",
+                      **{k: cfg.get(k) for k in ("genome_bp", "reads_per_gpu", "read_len", "max_mismatch", "max_output_per_read", "repeat_frac", "repeat_model",
+                                                 "parallelism", "lookup_chars") if k in cfg}}
+    pk = {}
+    for k, v in (roof.get("per_kernel") or {}).items():
+        pk[k] = {f: v.get(f) for f in ("ms_per_step", "rank_queries", "rank_queries_needed", "sa_reads", "ce_windows", "algorithmic_bytes", "fetched_bytes", "frac",
+                                       "frac_extended") if v.get(f) is not None}
+    line["roofline"] = {"bound": roof.get("bound"), "achieved": roof.get("achieved"), "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": roof.get("frac"),
+                        "traffic": roof.get("traffic"),
+                        "kernel": "s3::firstKernel + s3::unitKernel + s3::ceKernel (one search pass; dominant: s3::%sKernel)" % (roof.get("dominant_kernel") or "unit"),
+                        "launches_per_step": roof.get("launches_per_step"), "kernel_ms_per_step": roof.get("kernel_ms_per_step"),
+                        "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch"),
+                        "rank_queries_algorithmic": roof.get("rank_queries_algorithmic"), "rank_queries_issued": roof.get("rank_queries_per_step"),
+                        "peak_measured": roof.get("peak_measured"), "frac_of_measured": roof.get("frac_of_measured"), "frac_extended": roof.get("frac_extended"),
+                        "traffic_measured_at_commit": roof.get("traffic_measured_at_commit"),
+                        "random_line_rate": roof.get("random_line_rate"), "per_kernel": pk}
+    ref = cpu.get("reference") if isinstance(cpu.get("reference"), dict) else None
+    line["cpu_baseline"] = {"value": cpu.get("value"), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                            "sample": (cpu.get("sample") or "")[:200], "reads_per_s_per_core": cpu.get("reads_per_s_per_core")}
+    if ref:
+        line["cpu_baseline"]["reference"] = {"value": ref.get("value"), "unit": ref.get("unit"), "cores": ref.get("cores"), "kind": ref.get("kind"),
+                                             "port_over_reference": ref.get("port_over_reference")} if "value" in ref else {"error": str(ref.get("error"))[:120]}
+    line["parity"] = {"truth_check_ok": g(out, "truth_check", "ok"), "oracle_check_reads": g(out, "oracle_check", "reads"),
+                      "oracle_check_bit_exact": g(out, "oracle_check", "bit_exact"), "streamed_same_as_resident": g(out, "streamed", "same_results_as_resident")}
+    line["occurrences"] = out.get("occurrences")
+    s2 = {}
+    for key in ("c3_pairs", "c5_pairs", "c4_pairs"):
+        leg = sm.get(key)
+        if isinstance(leg, dict):
+            s2[key] = {f: leg.get(f) for f in ("pairs", "seconds", "M_pairs_per_s", "bwt_stage_frac", "dp_GCUPS", "dp_isolated_GCUPS", "device_ms",
+                                               "both_mates_at_simulated_place", "dp_oracle_check") if leg.get(f) is not None}
+        else:
+            ex = g(out, "extras", key)
+            if isinstance(ex, dict):
+                s2[key] = {"error": str(ex.get("error") or g(ex, "end_to_end", "error") or "no end-to-end figure")[:160]}
+    for key in ("repeat_models", "uniform_genome_M_reads_per_s", "streamed_vs_resident", "c3_pairs_single_default_mode"):
+        if sm.get(key) is not None:
+            s2[key] = sm[key]
+    if isinstance(g(out, "extras", "error"), str):
+        s2["extras_error"] = out["extras"]["error"][:160]
+    line["summary"] = s2
+    line["wall_s_total"] = out.get("wall_s_total")
+    line["full_object"] = full_path
+    line = _r(line)
+    txt = json.dumps(line, separators=(",", ":"))
+    # a leg that grew must not cost the record: drop the least needed parts until the line fits
+    for drop in (("summary", "c3_pairs", "device_ms"), ("summary", "c5_pairs", "device_ms"), ("summary", "c4_pairs"), ("roofline", "random_line_rate"),
+                 ("summary", "c3_pairs_single_default_mode"), ("summary", "repeat_models"), ("summary",)):
+        if len(txt) < COMPACT_LIMIT:
+            break
+        d = line
+        for k in drop[:-1]:
+            d = d.get(k) if isinstance(d, dict) else None
+        if isinstance(d, dict):
+            d.pop(drop[-1], None)
+        txt = json.dumps(line, separators=(",", ":"))
+    return txt
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -1624,12 +1714,24 @@ def main():
             torch.cuda.empty_cache()
     if rank == 0:
         out["wall_s_total"] = time.perf_counter() - t_all
-        # The line is tens of kilobytes; whoever stores only its tail (and the tail of stderr) must still find the round's figures: a compact summary as the
-        # LAST key of the line, and the same as the last lines of stderr.
+        # The full object is tens of kilobytes: it goes to a side file (and to stderr); stdout gets ONE compact line (compact_line: under 8 KB) that the driver
+        # parses, and the summary's lines are the last lines of stderr.
         out["summary"] = summary_of(out)
+        full_path = os.environ.get("S3DP_BENCH_FULL", "bench_full.json")
+        full_txt = json.dumps(out)
+        try:
+            with open(full_path, "w") as f:
+                f.write(full_txt + "\n")
+            if os.path.isdir("gpurun_out"):
+                with open(os.path.join("gpurun_out", "bench_full.json"), "w") as f:
+                    f.write(full_txt + "\n")
+        except OSError as e:
+            log("could not write %s: %r" % (full_path, e))
+            full_path = None
+        sys.stderr.write("[bench-full] " + full_txt + "\n")
         for ln in out["summary"]["lines"]:
             log(ln)
-        print(json.dumps(out), flush=True)
+        print(compact_line(out, full_path), flush=True)
     if index_dir and rank == 0:
         import shutil
         dist.barrier()
