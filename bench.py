@@ -1151,6 +1151,17 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
     phase, werr, offs, pos, strand, mis = b.fetch_alignments()
     aligned = int((phase > 0).sum())
     n_occ = int(offs[-1])
+    # the same pass with ONE first-mismatch position per unit (S3DP_UNIT_GROUP=1; the single-end ladders take groups of two): what the trunk and unit passes
+    # need to issue -- a unit of a group walks the trunk's path through its group again, and `rank_queries_needed` must not credit those steps
+    kneed = None
+    if os.environ.get("S3DP_UNIT_GROUP") != "1":
+        os.environ["S3DP_UNIT_GROUP"] = "1"
+        try:
+            b.align_single_allbest(a.mismatch, a.max_out)
+            b.sync()
+            kneed = b.kernel_stats()
+        finally:
+            del os.environ["S3DP_UNIT_GROUP"]
     b.enable_counters(False)
 
     # ---- timed region: resident batch ----------------------------------------------------------------------
@@ -1263,12 +1274,35 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
         b8d = 32.0 * kc["rankQueries"] + (a.reads * (4.0 * wpq + 4.0) if name == "first" else 0.0)
         bext = b8d + 16.0 * kc["ltLookups"] + 4.0 * kc["saReads"] + 16.0 * kc["ceWindows"]
         fetched = traffic_roles[name]["bytes"] if traffic_roles and name in traffic_roles else None
-        per_kernel[name] = {"ms_per_step": ms, "launches_per_step": kc["launches"], "rank_queries": kc["rankQueries"], "lt_lookups": kc["ltLookups"],
+        # needed: the first pass without what it spent on reads it then listed (the second pass starts those over); trunk and unit pass with one position per
+        # unit (kneed); never more than issued.  `frac` is priced on the needed count, `frac_issued` on what the kernel issued.
+        need = kc["rankQueries"] - (kc.get("listedRankQueries", 0) if name == "first" else 0)
+        if kneed is not None and name in ("trunk", "unit"):
+            need = min(need, kneed[name]["rankQueries"])
+        b8d_issued = b8d
+        b8d = 32.0 * need + (a.reads * (4.0 * wpq + 4.0) if name == "first" else 0.0)
+        bext += b8d - b8d_issued
+        per_kernel[name] = {"ms_per_step": ms, "launches_per_step": kc["launches"], "rank_queries": kc["rankQueries"], "rank_queries_needed": need,
+                            "lt_lookups": kc["ltLookups"], "frac_issued": b8d_issued / ms / 1e6 / peak if ms > 0 else 0.0,
                             "sa_reads": kc["saReads"], "ce_windows": kc["ceWindows"], "algorithmic_bytes": b8d, "algorithmic_bytes_extended": bext,
                             "achieved_GBps": b8d / ms / 1e6 if ms > 0 else 0.0, "frac": b8d / ms / 1e6 / peak if ms > 0 else 0.0,
                             "frac_extended": bext / ms / 1e6 / peak if ms > 0 else 0.0, "fetched_bytes": fetched,
                             "fetched_GBps": fetched / ms / 1e6 if fetched and ms > 0 else None,
                             "fetched_Glines_per_s": fetched / 64.0 / ms / 1e6 if fetched and ms > 0 else None}
+    per_kernel["first"]["rank_queries_on_reads_then_listed"] = kcnt["first"].get("listedRankQueries", 0)
+    # where ceKernel's rejected candidates are decided (s3_kernel_stats.ceRejected; counted pass)
+    rej = kcnt["ce"].get("ceRejected")
+    if rej and sum(rej):
+        tot_rej = float(sum(rej))
+        hist = {}
+        for d, dn in enumerate(("backward_step", "forward_step")):
+            for bud, bn in enumerate(("budget_0", "budget_1", "budget_2_or_more")):
+                w = rej[(d * 3 + bud) * 3:(d * 3 + bud) * 3 + 3]
+                hist["%s.%s" % (dn, bn)] = {"within_32_adjacent_chars": w[0], "rest_of_that_step": w[1], "a_later_step": w[2]}
+        per_kernel["ce"]["rejected"] = {"candidates": kcnt["ce"]["saReads"], "accepted": kcnt["ce"].get("accepted", 0), "rejected": int(tot_rej),
+                                        "share_within_32_adjacent_chars": sum(rej[0::3]) / tot_rej,
+                                        "share_within_32_adjacent_chars_backward_steps_only": sum(rej[0:9:3]) / tot_rej,
+                                        "share_handed_over_in_backward_steps": sum(rej[0:9]) / tot_rej, "by_direction_and_budget": hist}
     traffic_commit = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -1302,7 +1336,9 @@ def run_workload(a, s3dp, builder, dev, local, rank, world, dist, peaks, repeat_
             "per_kernel_is": "first = s3::firstKernel (first pass), trunk = s3::firstKernel (trunk-pass role), unit = s3::unitKernel, ce = s3::ceKernel; counts: what the kernel "
                              "issued in the counted pass; algorithmic_bytes = 32 B x its rank queries (+ the packed reads for the first pass), SURVEY.md 8d without the hit "
                              "term (12 B x reported occurrences belong to the whole pass); _extended adds 16 B per lookup entry, 4 B per suffix-array entry, 16 B per "
-                             "32-character compare window (all of ceKernel's work); ms = HIP events around the kernel's own launches, mean over the timed steps; "
+                             "32-character compare window (all of ceKernel's work); rank_queries_needed: first pass -- without what it spent on reads it then listed; trunk / "
+                             "unit pass -- with one first-mismatch position per unit (a group's unit walks the trunk's path again); frac on needed, frac_issued on issued; "
+                             "ms = HIP events around the kernel's own launches, mean over the timed steps; "
                              "fetched_bytes = FETCH_SIZE of its dispatches in the committed rocprofv3 pass (profiles/pmc_traffic.json)",
             "dominant_kernel": max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])}
     if traffic:
@@ -1504,7 +1540,11 @@ def compact_line(out, full_path=None):
     pk = {}
     for k, v in (roof.get("per_kernel") or {}).items():
         pk[k] = {f: v.get(f) for f in ("ms_per_step", "rank_queries", "rank_queries_needed", "sa_reads", "ce_windows", "algorithmic_bytes", "fetched_bytes", "frac",
-                                       "frac_extended") if v.get(f) is not None}
+                                       "frac_issued", "frac_extended") if v.get(f) is not None}
+        rj = v.get("rejected")
+        if isinstance(rj, dict):
+            pk[k]["rejected"] = {f: rj.get(f) for f in ("candidates", "accepted", "share_within_32_adjacent_chars", "share_within_32_adjacent_chars_backward_steps_only",
+                                                         "share_handed_over_in_backward_steps")}
     line["roofline"] = {"bound": roof.get("bound"), "achieved": roof.get("achieved"), "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": roof.get("frac"),
                         "traffic": roof.get("traffic"),
                         "kernel": "s3::firstKernel + s3::unitKernel + s3::ceKernel (one search pass; dominant: s3::%sKernel)" % (roof.get("dominant_kernel") or "unit"),

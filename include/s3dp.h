@@ -343,10 +343,6 @@ int  s3_dp_new_default_routed(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const 
                               const int cutoffThreshold[2], int softClipLeft, int softClipRight, s3_dp_deep_result **results, size_t *nResults,
                               char **cigarPool, uint8_t **pairFlags, uint32_t **pairFirstReads, size_t *nPairs);
 
-/* A batch whose work runs BESIDE another batch's search (the seed batches of the DP stage threads, SOAP3Wrapper::seeding, DV-DPfunctions.h:212-229: in the
- * reference seeding and search share the one GPU one after the other): background != 0 moves its stream to the device's lowest priority, so that its kernels
- * take what the persistent search kernels leave; 0 moves it back.  The aligners of s3_dp_create are background work by construction.  Call it on an idle batch. */
-int  s3_batch_set_background(s3_batch *b, int background);
 /* Width of this batch's persistent search grids in workgroups per compute unit (0: all that are resident at once, four).  The reference sizes its grids by the
  * batch (alignment.cu:118-221, blocksNeeded); here the grids are persistent and as wide as the device, and a batch whose search shares the device with the DP
  * stages of earlier chunks (SOAP3-DP.cu:394-800 runs them one after the other) leaves a workgroup per compute unit to their kernels: the paired command line
@@ -364,7 +360,12 @@ int  s3_batch_counters(s3_batch *b, s3_counters *out);      /* device-side talli
  * pass (s3::unitKernel), out[3] check-and-extend (s3::ceKernel) -- with each kernel's device time from HIP events around its launches on the batch's stream, so
  * that a kernel's algorithmic bytes (32 B per rank query ...) can be priced against ITS duration (bench.py roofline.per_kernel).  Measurement
  * aid; no counterpart in the reference (its kernels are timed by the CUDA profiler). */
-typedef struct { float ms; uint32_t launches; uint64_t rankQueries, ltLookups, saReads, ceWindows; } s3_kernel_stats;
+/* listedRankQueries (first pass): rank queries spent on reads the pass then listed for the second pass -- thrown away, the second pass starts over.
+ * accepted, ceRejected (check-and-extend): candidates accepted, and where the rejected ones were decided -- ceRejected[(dir * 3 + budget) * 3 + where]: dir 0 the
+ * candidate was handed over in a backward step (the characters to compare lie to the LEFT of its suffix), 1 in a forward step; budget = mismatches it may still
+ * take in that step (0, 1, 2 and more); where 0 = the 32 characters next to the matched part alone exceed the budget, 1 = the rest of that step decides, 2 = a
+ * later step of the model. */
+typedef struct { float ms; uint32_t launches; uint64_t rankQueries, ltLookups, saReads, ceWindows, listedRankQueries, accepted, ceRejected[18]; } s3_kernel_stats;
 int  s3_batch_kernel_stats(s3_batch *b, s3_kernel_stats out[4]);
 int  s3_batch_enable_counters(s3_batch *b, int on);
 

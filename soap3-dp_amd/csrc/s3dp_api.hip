@@ -518,7 +518,6 @@ extern "C" int s3_batch_upload(s3_batch *b, const uint32_t *queries, const uint3
     HIPCHK(hipMemsetAsync(b->dWasHeavy, 0, b->maxReads, b->stream));
     b->n = n;
     b->lastKind = 0;
-    b->sortedIdsValid = false;
     b->uniformLen = n ? readLengths[0] : 0;
     for (uint32_t i = 1; i < n; i++) if (readLengths[i] != readLengths[0]) { b->uniformLen = 0; break; }
     b->fullUniformLen = b->uniformLen;
@@ -539,7 +538,6 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
             HIPCHK(hipStreamSynchronize(b->stream));
         }
         b->longMode = false; b->uniformLen = b->fullUniformLen;
-        b->sortedIdsValid = false;
         return S3_OK;
     }
     const uint32_t n = b->n;
@@ -554,7 +552,6 @@ extern "C" int s3_batch_set_seed_lengths(s3_batch *b, const uint32_t *seedLength
     b->uniformLen = n ? seedLengths[0] : 0;
     for (uint32_t i = 1; i < n; i++) if (seedLengths[i] != seedLengths[0]) { b->uniformLen = 0; break; }
     b->longMode = true;
-    b->sortedIdsValid = false;
     b->lastKind = 0;
     return S3_OK;
 }
@@ -564,26 +561,6 @@ extern "C" int s3_batch_set_grid(s3_batch *b, unsigned blocksPerCu)
     if (!b) return fail(S3_EINVAL, "null batch");
     if (blocksPerCu > 16u) return fail(S3_EINVAL, "s3_batch_set_grid: at most 16 workgroups per compute unit");
     b->blocksPerCu = blocksPerCu;
-    return S3_OK;
-}
-
-// background batches (the seed batches of the command line's DP stage threads): their stream gets the lowest priority of the device, or the default again
-extern "C" int s3_batch_set_background(s3_batch *b, int background)
-{
-    if (!b) return fail(S3_EINVAL, "null batch");
-    if (b->failed) return fail(S3_ENOMEM, "this batch lost a buffer while growing (out of device memory earlier): free it and create a smaller one");
-    HIPCHK(hipSetDevice(b->ix->dev));
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) return S3_OK;     // (a device without priorities: nothing to do)
-    const char *e = getenv("S3DP_DP_PRIORITY");
-    if (!(e && atoi(e) == 1)) return S3_OK;                          // (opt-in: measured without effect on the paired command line, s3dp_dpapi.hip)
-    HIPCHK(hipStreamSynchronize(b->stream));
-    hipStream_t s = nullptr;
-    if (background) HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
-    else HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    s3i::scratchStreamGone(b->stream);
-    (void)hipStreamDestroy(b->stream);
-    b->stream = s;
     return S3_OK;
 }
 
@@ -660,7 +637,6 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.takeMin = (uint32_t)envSize("S3DP_TAKE_MIN", S3_UNIT_TAKE_MIN);
     if (in.takeMin < 1u) in.takeMin = 1u;
     if (in.takeMin > 64u) in.takeMin = 64u;
-    in.pruneUnits = (uint32_t)envSize("S3DP_PRUNE_UNITS", 1);
     in.tailAge = (uint32_t)envSize("S3DP_TAIL_AGE", S3_UNIT_TAIL_AGE);
     in.giantAge = (uint32_t)envSize("S3DP_GIANT_AGE", S3_UNIT_GIANT_AGE);
     in.giantIdle = (uint32_t)envSize("S3DP_GIANT_IDLE", S3_UNIT_GIANT_IDLE);
@@ -1130,6 +1106,8 @@ extern "C" int s3_batch_kernel_stats(s3_batch *b, s3_kernel_stats *out)
     for (int r = 0; r < S3_NUM_ROLES; r++) {
         const unsigned long long *c = call + r * S3_NUM_COUNTERS;
         out[r].rankQueries = c[0]; out[r].ltLookups = c[1]; out[r].saReads = c[2]; out[r].ceWindows = c[3];
+        out[r].listedRankQueries = c[21]; out[r].accepted = c[10];
+        for (int k = 0; k < S3_CE_HIST_SLOTS; k++) out[r].ceRejected[k] = c[S3_CE_HIST_BASE + k];
     }
     return S3_OK;
 }

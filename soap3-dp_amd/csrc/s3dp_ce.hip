@@ -23,6 +23,13 @@ using namespace v2;
 // prefix sums.  Accepted candidates are appended to the record stream with one atomic per wave and S3_V2_REC_BLOCK records.  Per candidate: SA
 // value, then per remaining model step the text against the oriented read, 16 characters at a time (XOR, fold, popcount), the step's error
 // window checked as in the stepping kernel (BGS-HostAlgnmtAlgo2.cpp:86-169).
+// COUNT (counters enabled: measurement passes only): besides the tallies, WHERE the rejected candidates are decided (would a table
+// of the 32 characters next to every suffix -- one line per candidate instead of a suffix-array line and then a text line -- settle them?).  Per rejected
+// candidate: the direction of the step it was handed over in (backward: the characters to its LEFT, a table in suffix-array order would hold them; forward:
+// the characters behind the matched part, whose distance from the suffix's start differs from task to task), the mismatches it may still take in that
+// step (0 / 1 / 2 and more), and whether the 32 characters next to the matched part alone exceed them / the rest of that step decides / a later step does:
+// counters[S3_CE_HIST_BASE + (dir * 3 + budget) * 3 + where].
+template <bool COUNT>
 __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, SearchOut out, const uint32_t *taskRange)
 {
     __shared__ uint4 sRec[4][64];                              // per wave: the task records of the batch ...
@@ -43,6 +50,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
     uint32_t *myRd = sRd + (size_t)wv * 64u * S;
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t nSa = 0, nCe = 0, nAcc = 0;
+    uint32_t histW[S3_CE_HIST_SLOTS] = {};                    // (COUNT) wave-uniform
     uint32_t recCur = 0, recEnd = 0;                          // wave-uniform: reserved block [recCur, recEnd)
     for (uint64_t base = (uint64_t)firstRec + (uint64_t)waveId * 64u; base < nRec; base += (uint64_t)nWaves * 64u) {
         const uint64_t idx = base + lane;
@@ -90,6 +98,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
             bool hit = false;
             uint32_t rp = 0, recX = 0, seqK = 0;
             int acc = 0;
+            uint32_t histIdx = 0xFFFFFFFFu;                     // (COUNT) where this candidate was rejected
             if (c < total) {
                 // the task this candidate belongs to: the last one that starts at or before c (tasks of size 0 start where the next one starts)
                 uint32_t lo = 0, hi = 63u;
@@ -116,6 +125,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i0;
                 rp = sa - (uint32_t)leftAlign;                                   // 32-bit wrap, as the reference
                 int t = s0, ii = i0, insCur = ins0;
+                bool rejBound = false;
                 hit = true;
                 while (t < nSteps) {
                     const S3Step st = cs.st[t];
@@ -125,9 +135,9 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                     if (early && t == s0) {
                         // what is left of the exact lookup step: the walk this replaces matches real text only
                         const long long rpS = (long long)sa - (long long)leftAlign;
-                        if (rpS + (long long)left < 0 || rpS + (long long)right >= (long long)ix.n) { hit = false; break; }
+                        if (rpS + (long long)left < 0 || rpS + (long long)right >= (long long)ix.n) { hit = false; rejBound = true; break; }
                     }
-                    if (rp + left > ix.n) { hit = false; break; }                // BGS-HostAlgnmtAlgo2.cpp:122-125
+                    if (rp + left > ix.n) { hit = false; rejBound = true; break; }                // BGS-HostAlgnmtAlgo2.cpp:122-125
                     const uint32_t tpos = rp + left;
                     int mm = 0;
                     // 128 characters at a time: all text and read words of the piece are requested before the first is used
@@ -174,6 +184,32 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                     if (tot < st.minErr || tot > st.maxErr) { hit = false; break; }
                     acc += tot; t++; ii = 0; insCur = 0;
                 }
+                if constexpr (COUNT) {
+                    if (!hit) {
+                        uint32_t where = 2u;                                     // a later step
+                        if (t == s0) {
+                            where = 1u;                                          // the rest of the first compared step (or the text's end)
+                            const int pos = st0.start + st0.dir * i0;
+                            const uint32_t left = (uint32_t)(pos < st0.end ? pos : st0.end), right = (uint32_t)(pos < st0.end ? st0.end : pos);
+                            const uint32_t len = right - left + 1u, nAdj = len < 32u ? len : 32u;
+                            if (!rejBound && (st0.dir > 0 ? rp + left + nAdj <= ix.n : rp + right < ix.n)) {
+                                int m2 = 0;
+                                for (uint32_t q = 0; q < nAdj; q++) {
+                                    const uint32_t rpos = st0.dir > 0 ? left + q : right - q, tp = rp + rpos;
+                                    const uint32_t tc = (ix.pac[tp >> 4] >> (30u - 2u * (tp & 15u))) & 3u, rc = (rd[rpos >> 4] >> (30u - 2u * (rpos & 15u))) & 3u;
+                                    m2 += tc != rc ? 1 : 0;
+                                }
+                                if (m2 + ins0 > st0.maxErr) where = 0u;
+                            }
+                        }
+                        const int left0 = st0.maxErr - ins0;
+                        histIdx = ((st0.dir > 0 ? 1u : 0u) * 3u + (uint32_t)(left0 < 0 ? 0 : left0 > 2 ? 2 : left0)) * 3u + where;
+                    }
+                }
+            }
+            if constexpr (COUNT) {
+#pragma unroll
+                for (uint32_t k = 0; k < S3_CE_HIST_SLOTS; k++) histW[k] += (uint32_t)__popcll(__ballot(histIdx == k));
             }
             const unsigned long long hm = __ballot(hit);
             if (hm) {
@@ -202,6 +238,9 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         atomicAdd(&out.counters[2], (unsigned long long)nSa);
         atomicAdd(&out.counters[3], (unsigned long long)nCe);
         atomicAdd(&out.counters[10], (unsigned long long)nAcc);
+        if constexpr (COUNT) {
+            if (lane == 0) for (uint32_t k = 0; k < S3_CE_HIST_SLOTS; k++) if (histW[k]) atomicAdd(&out.counters[S3_CE_HIST_BASE + k], (unsigned long long)histW[k]);
+        }
     }
 }
 
@@ -214,12 +253,13 @@ void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &
         int dev = 0, cus = 256, perCu = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, ceKernel, 256, 16384) != hipSuccess || perCu < 1) perCu = 5;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, ceKernel<false>, 256, 16384) != hipSuccess || perCu < 1) perCu = 5;
         if (const char *e = getenv("S3DP_CE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
         return (unsigned)(cus * perCu);
     }();
     const size_t lds = in.wpqLoad >= 4u && in.wpqLoad <= 16u ? (size_t)4u * 64u * in.wpqLoad * 4u : 0u;      // the tasks' reads (ceKernel::sRd)
-    hipLaunchKernelGGL(ceKernel, dim3(blocks), dim3(256), lds, s, ix, in, out, taskRange);
+    if (out.counters) hipLaunchKernelGGL(ceKernel<true>, dim3(blocks), dim3(256), lds, s, ix, in, out, taskRange);
+    else hipLaunchKernelGGL(ceKernel<false>, dim3(blocks), dim3(256), lds, s, ix, in, out, taskRange);
 }
 
 }  // namespace s3

@@ -25,7 +25,9 @@
 #define S3_UNIT_TAIL_AGE 0u
 #define S3_UNIT_GROUP 2u                   // first-mismatch positions per unit of the second pass (S3DP_UNIT_GROUP)
 #define S3_UNIT_NODE_BLOCK 256u           // sub-unit counters a wave of the unit pass reserves with one atomic
-#define S3_NUM_COUNTERS 22                 // 64-bit tallies of a kernel (SearchOut::counters)
+#define S3_NUM_COUNTERS 40                 // 64-bit tallies of a kernel (SearchOut::counters); [21]: rank queries the first pass spent on reads it then listed; [22..39]: ceKernel's rejection histogram (s3dp_ce.hip)
+#define S3_CE_HIST_BASE 22
+#define S3_CE_HIST_SLOTS 18
 #define S3_NUM_ROLES 4                     // ... kept per kernel of a search pass: first pass, trunk pass, unit pass, check-and-extend (s3_batch_kernel_stats)
 #define S3_COUNTER_WORDS (S3_NUM_COUNTERS * S3_NUM_ROLES)
 #define S3_FLAG_STACK_OVERFLOW 1u
@@ -89,7 +91,6 @@ struct SearchIn {
     uint32_t        ceGiveUp;      // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel (S3_CE_GIVE_UP)
     uint32_t        adoptIdle;   // unit pass: idle lanes a wave needs before its busy lanes give frames away (S3_UNIT_ADOPT_IDLE)
     uint32_t        takeMin;     // unit pass: idle lanes a wave lets gather before they start their next units together (S3_UNIT_TAKE_MIN; 1: at once)
-    uint32_t        pruneUnits;          // trunk pass: positions without a live mismatch child keep no state, i.e. start no unit (S3DP_PRUNE_UNITS=0: they do)
     uint32_t        tailAge;             // unit pass, queue empty: full trips a lane must have spent on its unit before it gives frames away (S3DP_TAIL_AGE)
     uint32_t        giantAge, giantIdle; // unit pass: full trips on one unit that make a lane a giant (0: never), idle lanes of its wave before they adopt its frames (S3DP_GIANT_AGE / _IDLE)
     uint32_t        fastTrips, fastMin;  // unit pass: step-only trips between two full trips (S3_UNIT_FAST_TRIPS), made while fastMin lanes of the wave are stepping
@@ -149,7 +150,6 @@ struct MergeArgs {
     // reads whose slice of the ordered array is longer than S3_MERGE_LONG entries (repeat families: mostly holes of rejected candidates) are listed by
     // mergeCountKernel and walked by a whole wave each (mergeCountLongKernel / decodeLongKernel) instead of one lane
     uint32_t       *longList, *longCount;
-    uint32_t       *dealt;        // optional: the word the waves of a long kernel draw their reads from (zeroed before the launch); nullptr: fixed deal
     // reads the second search pass took apart count their records per unit: their slice of the ordered array starts at
     // itemOffsets[unitBase + heavyIndex[slot] * unitsPerRead] and is unitsPerRead offsets long
     const uint8_t  *heavyFlags;
@@ -157,7 +157,6 @@ struct MergeArgs {
     uint32_t        unitBase, unitsPerRead;
 };
 #define S3_MERGE_LONG 256u
-#define S3_LONG_DEAL_DEFAULT 0            // the long kernels' reads dealt through a counter (S3DP_LONG_DEAL)
 
 // semi-global DP (s3dp_dp.hip)
 // Traceback table of one 64-row chunk with T steps: H as int16, two steps per dword ([step / 2][lane], the even step in the low half), then one bit per

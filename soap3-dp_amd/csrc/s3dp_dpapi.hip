@@ -74,18 +74,9 @@ extern "C" int s3_dp_create(int device, uint32_t maxProblems, uint32_t maxReadLe
     DA(dTable, h->tableWords * maxProblems);
 #undef DA
 #define HIPD(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { s3_dp_free(h); return fail(S3_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
-    {
-        // The DP stages run beside the search of the next chunks (the command line's stage threads).  Their kernels are small and many; when they take CUs from
-        // the persistent search kernels, the search -- the critical path of a paired run -- pays for it: measured on ten million pairs, BWT stages 2.44 s and DP
-        // kernels 0.42 s one after the other, 3.00 s and 0.77 s side by side (profiles/README_r05.md).  So an aligner's stream has the LOWEST priority the device
-        // offers: its kernels take what the search leaves -- with S3DP_DP_PRIORITY=1.  Measured (ten million pairs, outputs to /dev/null, gpurun_out/r05k2 and
-        // r05b): 3.41 / 3.55 s with it, 3.42 s without, on boxes whose run-to-run spread is larger than that; so the default priority stays the default.
-        int least = 0, greatest = 0;
-        const char *e = getenv("S3DP_DP_PRIORITY");
-        const bool low = e && atoi(e) == 1 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
-        if (low) HIPD(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least));
-        else HIPD(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    }
+    // (The aligner's stream at the device's lowest priority -- its many small kernels run beside the persistent search kernels of the next chunks -- was measured
+    //  in round 5 on ten million pairs: 3.41 / 3.55 s with it, 3.42 s without.  Taken out in round 6.)
+    HIPD(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPD(hipEventCreate(&h->ev[0])); HIPD(hipEventCreate(&h->ev[1]));
     HIPD(hipMemset(h->dCells, 0, 8));
 #undef HIPD

@@ -66,6 +66,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     uint4 *stk = out.unitStack + (size_t)(blockIdx.x * (S3_SEARCH_BLOCK / 64u) + wv) * S3_UNIT_STACK * 64u;     // frame d of lane k: stk[(d % S3_UNIT_STACK) * 64 + k]
 
     const unsigned long long tWave0 = COUNT ? wall_clock64() : 0ULL;        // (COUNT) the wave's own duration in 10 ns ticks
+    unsigned long long nListedRank = 0;                                     // (COUNT) rank queries spent on reads that were then listed: thrown away, the second pass starts over
     uint32_t nRank = 0, nLt = 0, nWaveTrips = 0, nLaneTrips = 0, nStepLane = 0, nFastWave = 0, nFastLane = 0, nParked = 0;     // (COUNT)
 
     // ---- per-lane state ----
@@ -265,7 +266,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             // five trips of a lane for nothing, and with three and four mismatches most units are of that kind (round 5).  The ranks are the ones the unit would
             // compute: same range, same position, same character.
             const bool anyKid = (ch != 0 && oL.x + 1u <= oR.x) || (ch != 1 && oL.y + 1u <= oR.y) || (ch != 2 && oL.z + 1u <= oR.z) || (ch != 3 && oL.w + 1u <= oR.w);
-            if (anyKid || !in.pruneUnits) leaveState((uint32_t)i);
+            if (anyKid) leaveState((uint32_t)i);
         }
         if (!exact && !trunkHere) {
             const bool a0 = ch != 0 && oL.x + 1u <= oR.x, a1 = ch != 1 && oL.y + 1u <= oR.y;
@@ -300,6 +301,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (goHeavy) {
                 // this read goes to the second pass: whatever it wrote so far is ignored there (scatter / check-and-extend test the flag)
                 out.heavyFlags[slotIdx] = 1;
+                if constexpr (COUNT) nListedRank += readRank;
                 if (out.wasHeavy) out.wasHeavy[rIdx] = (uint8_t)in.heavyLevel;  // remembered for the ladder's next phases (see F_LOAD)
                 const uint32_t at = atomicAdd(out.heavyCount, 1u);
                 out.heavyList[at] = slotIdx;
@@ -620,6 +622,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             atomicAdd(&out.counters[17], (unsigned long long)nFastLane);
             atomicAdd(&out.counters[18], (unsigned long long)nParked);
             if (lane == 0) { atomicAdd(&out.counters[19], wall_clock64() - tWave0); atomicAdd(&out.counters[20], 1ULL); }
+            atomicAdd(&out.counters[21], nListedRank);
         }
     }
 }

@@ -73,7 +73,6 @@ struct s3_batch {
     uint32_t *dChainNext = nullptr; size_t chainCap = 0;       // per unit and per adopted frame: the counter that follows
     uint32_t *dDynOwner = nullptr, *dDynLocal = nullptr, *dDynUsed = nullptr; size_t dynCap = 0;
     unsigned long long *dOrderKeys[2] = {nullptr, nullptr}; uint32_t *dOrderVals[2] = {nullptr, nullptr}; size_t orderCap = 0;   // sort buffers: order of the listed reads / of the batch
-    uint32_t *dSortedIds = nullptr; bool sortedIdsValid = false; // the batch's reads in the order of their first characters (single-end ladders start from it)
     s3::ScatterDyn scatterDyn{nullptr, nullptr, 0, 0};         // of the last search pass
     uint32_t mergeUnitBase = 0, mergeUnitsPerRead = 0;         // of the last search pass (0: no read was taken apart)
     uint32_t uniformLen = 0;
@@ -120,7 +119,7 @@ struct s3_batch {
     bool counting = false;
     hipEvent_t evTotal[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> evSearch, evCe;          // per launch of the stepping kernel / of the check-and-extend kernel
-    std::vector<uint8_t> evSearchRole;               // per pair of evSearch: 0 first pass, 1 trunk pass, 2 unit pass
+    std::vector<uint8_t> evSearchRole;               // per pair of evSearch: 0 first pass, 1 trunk pass, 2 unit pass (3 = check-and-extend marks the pairs of evCe)
     uint32_t evSearchUsed = 0, evCeUsed = 0;         // event pairs in use
     uint32_t searchLaunches = 0;                     // search passes of the last call
     uint32_t occUsed = 0;

@@ -222,19 +222,9 @@ __device__ __forceinline__ uint32_t tripRecords(uint2 v, uint32_t tb, uint32_t b
     return V;
 }
 
-// Which listed read a wave of the long kernels takes next.  dealt == nullptr: a fixed deal, read waveId + k * nWaves (`strided` is that index).  Otherwise
-// the reads are dealt as the waves come free: ONE lane draws a number from the counter, every lane of the wave gets it (a wave that walks a read of ten
-// thousand slots no longer holds up the reads the fixed deal gave it besides).  Round 4 tried this, saw the ladder hang twice on the GPU box and took it out
-// unexplained; this form is what the explanation (profiles/README_r05.md) leaves standing: the counter is a word of its own per kernel, zeroed on the stream
-// right before the launch that draws from it, and the draw is unconditional for the whole wave (no lane leaves the loop on a number another lane holds).
-__device__ __forceinline__ uint32_t nextLongRead(uint32_t *dealt, uint32_t strided, uint32_t waveId, uint32_t lane)
-{
-    if (!dealt) return strided ? strided : waveId;
-    uint32_t v = 0;
-    if (lane == 0) v = atomicAdd(dealt, 1u);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
+// (The listed reads are dealt to the waves of the long kernels in a fixed order, read waveId + k * nWaves.  Dealing them through a counter as the waves come
+//  free was built twice: round 4 saw the ladder hang and took it out unexplained; round 5's form -- a counter word per kernel, zeroed right before the
+//  launch, drawn unconditionally by the whole wave -- ran green and 11 ms per ladder SLOWER (8,192 waves on one word), and was taken out in round 6.)
 // mergeCountKernel for the listed (long) reads: one wave per read -- the holes of rejected check-and-extend
 // candidates (nine in ten entries of a read inside a repeat family) cost a byte of a coalesced load instead of a turn of a serial loop
 __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
@@ -244,7 +234,7 @@ __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
     uint32_t *idx = sIdx[threadIdx.x >> 6];
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t nLong = *a.longCount, groups = a.nCases * 2u;
-    for (uint32_t li = nextLongRead(a.dealt, 0, waveId, lane); li < nLong; li = nextLongRead(a.dealt, li + nWaves, waveId, lane)) {
+    for (uint32_t li = waveId; li < nLong; li += nWaves) {
         const uint32_t slot = a.longList[li];
         uint32_t beg, end;
         readSlice(a, slot, groups, beg, end);
@@ -339,8 +329,9 @@ __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffset
         // a turn either fetches the next eight validity bytes (one load) or takes the next record they show
         if (turn && !bits) {
             if (loaded) w0 += 8u;
-            bits = validBits8(a.valid, w0, beg, end);
-            loaded = true;
+            // (a slice that holds fewer records than keptRecs says -- a stale pass decoded again -- must end the lane with an error, not spin the wave forever)
+            if (w0 >= end) { atomicOr(flags, S3_FLAG_OCC_OVERFLOW); mine = false; }
+            else { bits = validBits8(a.valid, w0, beg, end); loaded = true; }
         }
         const bool have = turn && bits != 0u;
         uint4 r = make_uint4(0, 0, 0, 0);
@@ -383,7 +374,7 @@ __global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix
     uint32_t *idx = sIdx[threadIdx.x >> 6];
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t nLong = *a.longCount, groups = a.nCases * 2u;
-    for (uint32_t li = nextLongRead(a.dealt, 0, waveId, lane); li < nLong; li = nextLongRead(a.dealt, li + nWaves, waveId, lane)) {
+    for (uint32_t li = waveId; li < nLong; li += nWaves) {
         const uint32_t slot = a.longList[li];
         if (a.decodeMask && a.decodeMask[slot] != a.decodeWant) continue;
         uint32_t beg, end;
@@ -643,21 +634,12 @@ void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap,
     hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, valid, heavyFlags, heavyList, groups, unitBase, unitsPerItem, dyn);
 }
 
-// S3DP_LONG_DEAL=1: the long kernels deal their reads through a counter (nextLongRead); 0: fixed deal
-static bool longDealing()
-{
-    const char *e = getenv("S3DP_LONG_DEAL");
-    return e ? atoi(e) != 0 : S3_LONG_DEAL_DEFAULT;
-}
-
 void launchMergeCount(const MergeArgs &a, hipStream_t s)
 {
     if (!a.nActive) return;
-    if (a.longList) (void)hipMemsetAsync(a.longCount, 0, 8, s);                // the count, and the word mergeCountLongKernel's waves draw their reads from
+    if (a.longList) (void)hipMemsetAsync(a.longCount, 0, 4, s);
     hipLaunchKernelGGL(mergeCountKernel, dim3((a.nActive + 127) / 128), dim3(128), 0, s, a);
-    MergeArgs d = a;
-    d.dealt = longDealing() ? a.longCount + 1 : nullptr;
-    if (a.longList) hipLaunchKernelGGL(mergeCountLongKernel, dim3(2048), dim3(256), 0, s, d);
+    if (a.longList) hipLaunchKernelGGL(mergeCountLongKernel, dim3(2048), dim3(256), 0, s, a);
 }
 
 void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s)
@@ -671,10 +653,7 @@ void launchDecode(const MergeArgs &a, const DevIndex &ix, const uint32_t *occOff
 {
     if (!a.nActive) return;
     hipLaunchKernelGGL(decodeKernel, dim3((a.nActive + 127) / 128), dim3(128), 0, s, a, ix, occOffsets, occBase, occCap, occPos, occMeta, flags);
-    MergeArgs d = a;
-    d.dealt = longDealing() && a.longList ? a.longCount + 2 : nullptr;
-    if (d.dealt) (void)hipMemsetAsync(d.dealt, 0, 4, s);                        // (a pass may be decoded more than once: zeroed per launch, not per pass)
-    if (a.longList) hipLaunchKernelGGL(decodeLongKernel, dim3(2048), dim3(256), 0, s, d, ix, occOffsets, occBase, occCap, occPos, occMeta, flags);
+    if (a.longList) hipLaunchKernelGGL(decodeLongKernel, dim3(2048), dim3(256), 0, s, a, ix, occOffsets, occBase, occCap, occPos, occMeta, flags);
 }
 
 void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *withError, uint32_t mm, uint32_t allowSpecial, uint8_t *state,

@@ -466,22 +466,8 @@ extern "C" int s3_batch_align_single(s3_batch *b, uint32_t numMismatch, uint32_t
     const uint32_t searchLimit = b->longMode ? 0xFFFFFFFFu : maxOutputPerRead;
     const uint32_t *active = nullptr;
     uint32_t nActive = n;
-    // S3DP_SORT_READS=n: batches of n reads and more start the ladder from the reads in the order of their first 32 characters -- the 64 reads a wave of the
-    // first pass takes are then neighbours in sequence space, family-mates of a repeat walk the same rank lines in the same trips -- and every later phase
-    // inherits the order (the next phase's list is a stable selection).  Results are per read: their order in the output does not change.  OFF by default:
-    // measured on the benchmark genome (profiles/README_r05.md) the first passes fetch a fifth fewer bytes and take the same time.
-    const size_t sortFrom = envSize("S3DP_SORT_READS", 0);               // (0: never; 1: always -- the tests)
-    if (sortFrom && n >= sortFrom) {
-        if (!b->sortedIdsValid) {
-            int rc;
-            if (!b->dSortedIds && (rc = balloc(b, &b->dSortedIds, (size_t)b->maxReads + 2))) return rc;
-            const uint32_t wLoad = (b->longMode && b->wpq > 8) ? 8u : b->wpq;
-            if ((rc = orderByReadPrefix(b, nullptr, n, nullptr, 2u * wLoad, wLoad))) return rc;
-            HIPCHK(hipMemcpyAsync(b->dSortedIds, b->dOrderVals[1], (size_t)n * 4, hipMemcpyDeviceToDevice, b->stream));
-            b->sortedIdsValid = true;
-        }
-        active = b->dSortedIds;
-    }
+    // (Starting the ladder from the reads in the order of their first 32 characters -- family-mates of a repeat as neighbours in the first pass's waves -- was
+    //  measured in round 5: a fifth fewer bytes fetched by the first passes, the same time.  Taken out in round 6; the LISTED reads are still ordered that way.)
     int pp = 0;
     for (uint32_t mm = first; mm <= last && nActive > 0; mm++) {
         const bool terminal = mm >= numMismatch;

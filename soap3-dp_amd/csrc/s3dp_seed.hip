@@ -250,7 +250,7 @@ int s3i::seedSearchKeys(s3_batch *reads, s3_batch *seedBatch, const std::vector<
         launchOrientReads(b->dQueries, b->dLens, b->dReadsT, nSeeds, b->wpq, b->wpq, st);
         SCHK(hipMemsetAsync(b->dWasHeavy, 0, b->maxReads, st));
         b->unitGroup = 1;
-        b->n = nSeeds; b->longMode = false; b->lastKind = 0; b->sortedIdsValid = false;
+        b->n = nSeeds; b->longMode = false; b->lastKind = 0;
         b->uniformLen = nSeeds ? seeds[0].len : 0;
         for (uint32_t j = 1; j < nSeeds; j++) if (seeds[j].len != seeds[0].len) { b->uniformLen = 0; break; }
         b->fullUniformLen = b->uniformLen;

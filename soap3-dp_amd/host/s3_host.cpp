@@ -352,7 +352,6 @@ struct ReadChunker::File {
     RawVec<char> buf;
     size_t used = 0, have = 0;            // buf[used, have) is text not yet handed out
     double bytesPerRead = 0;
-    uint64_t readsOut = 0;                // reads handed out so far (remainingReads of a gzip file)
 
     ~File() { if (fd >= 0) close(fd); if (gz) gzclose(gz); }
 
@@ -791,22 +790,6 @@ bool ReadChunker::nextBam(uint32_t maxReads, ReadSet &rs, std::string &err)
     return true;
 }
 
-double ReadChunker::remainingReads() const
-{
-    if (bam || files.empty()) return -1;
-    const File &X = *files[0];
-    if (X.bytesPerRead <= 0) return -1;
-    double perFile = -1;
-    if (X.fd >= 0) perFile = (double)((uint64_t)(X.have - X.used) + (X.size - X.pos)) / X.bytesPerRead;
-    else if (X.gz) {
-        struct stat sb;
-        const long long off = (long long)gzoffset(X.gz);
-        if (off > 0 && stat(X.name.c_str(), &sb) == 0 && (long long)sb.st_size >= off && X.readsOut > 0)
-            perFile = (double)X.readsOut * (double)((long long)sb.st_size - off) / (double)off + (double)(X.have - X.used) / X.bytesPerRead;
-    }
-    return perFile < 0 ? -1 : perFile * (double)files.size();
-}
-
 bool ReadChunker::next(uint32_t maxReads, ReadSet &rs, std::string &err)
 {
     err.clear();
@@ -880,7 +863,6 @@ bool ReadChunker::next(uint32_t maxReads, ReadSet &rs, std::string &err)
         File &X = *files[f];
         X.bytesPerRead = (double)regs[f].consumed / (double)m;
         X.used += regs[f].consumed;
-        X.readsOut += m;
     }
     return true;
 }

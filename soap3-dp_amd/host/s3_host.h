@@ -74,9 +74,6 @@ public:
     // other --, a record with the reverse-strand flag is taken back to the read as sequenced (reverse complement, qualities reversed)
     bool openBam(const std::string &file, bool paired, uint32_t maxReadLength, int qualityConstant, int maxLenReadName, std::string &err);
     bool next(uint32_t maxReads, ReadSet &rs, std::string &err);
-    // reads the input still holds, estimated from what is left of the first file and the bytes a read has taken so far (plain files: exact bytes; gzip: the
-    // compressed offset against the file's size; BAM or nothing read yet: -1 = unknown).  The command line sizes its chunks by it.
-    double remainingReads() const;
 private:
     struct File;
     std::vector<std::unique_ptr<File>> files;
@@ -109,6 +106,12 @@ struct DpHit { uint32_t pos; uint8_t strand; int score, editdist; std::string ci
 struct PairDpHit { uint32_t pos1, pos2; uint8_t strand1, strand2, whichFromDP; int score1, score2, editdist, insertSize, numSameScore; std::string cigar; };
 // one result of the deep DP (DeepDPAlignResult, PEAlgnmt.h:409): both ends from the DP
 struct DeepDpHit { uint32_t pos1, pos2; uint8_t strand1, strand2; int score1, score2, editdist1, editdist2, insertSize, numSame1, numSame2; std::string cigar1, cigar2; };
+// OutputBuffer::arrayCopyNRemoveDuplicate (OutputDPResult.cpp; called by OutputBuffer::ready()): a pair's deep-DP results sorted by the first end's position
+// ALONE, the first result of every position kept.  The reference sorts with std::sort, and so does this: among more than sixteen results the survivor of
+// several with equal first positions is whatever libstdc++'s introsort leaves in front (up to sixteen: insertion sort, i.e. the first in input order), and
+// X0 / X1 / XA follow from it.  Same library, same comparator, same input order: same survivor.  tests/test_host_dp_sam_cpu.py pins the survivors of a
+// 40-result case to a golden list, so that a toolchain whose sort permutes differently shows up in the CPU suite.
+void keepFirstResultPerPosition(std::vector<DeepDpHit> &hits);
 // what the BWT stage left for a read in hspaux->x0_array / x1_array / mismatch_array (CPUfunctions.cpp:2099-2103): X0, X1, fewest mismatches; zeros without a hit
 struct BwtEndStats { int x0 = 0, x1 = 0, mismatch = 0; };
 

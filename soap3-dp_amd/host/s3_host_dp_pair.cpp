@@ -332,6 +332,15 @@ void SamWriter::pairDP(const ReadSet &rs, uint32_t r1, const PairDpHit *H, size_
     pairRecords(rs, r1, e, bestInsert, xa);
 }
 
+void keepFirstResultPerPosition(std::vector<DeepDpHit> &hits)
+{
+    if (hits.empty()) return;
+    std::sort(hits.begin(), hits.end(), [](const DeepDpHit &x, const DeepDpHit &y) { return x.pos1 < y.pos1; });
+    size_t u = 0;
+    for (size_t q = 1; q < hits.size(); q++) if (hits[u].pos1 < hits[q].pos1) hits[++u] = hits[q];
+    hits.resize(u + 1);
+}
+
 void SamWriter::pairDeepDP(const ReadSet &rs, uint32_t r1, const DeepDpHit *H, size_t n, const BwtEndStats st[2])
 {
     EndView e[2];

@@ -425,14 +425,8 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
             if (res[q].cigarOffset_2 != 0xFFFFFFFFu) h.cigar2 = pool + res[q].cigarOffset_2;
             hits.push_back(h);
         }
-        // (std::sort, NOT a stable sort: OutputBuffer::arrayCopyNRemoveDuplicate sorts with std::sort by the first end's position alone and keeps the first
-        //  result of every position -- for more than sixteen results the survivor among results with equal first positions is whatever introsort leaves in
-        //  front, and the X0 / X1 counts and XA lists follow from it.  Same library, same comparator, same input order: same permutation.  Found by the
-        //  every-route scale test, where pairs come with hundreds of deep-DP results; the fixtures' lists are short enough for the insertion-sort branch.)
-        std::sort(hits.begin(), hits.end(), [](const DeepDpHit &x, const DeepDpHit &y) { return x.pos1 < y.pos1; });
-        size_t u = 0;
-        for (size_t q = 1; q < hits.size(); q++) if (hits[u].pos1 < hits[q].pos1) hits[++u] = hits[q];
-        hits.resize(u + 1);
+        // (std::sort, not a stable sort -- s3_host.h tells why; found by the every-route scale test, where pairs come with hundreds of deep-DP results)
+        keepFirstResultPerPosition(hits);
         if (moduleType != 1) {
             int best = hits[0].score1 + hits[0].score2;
             for (const DeepDpHit &h : hits) best = std::max(best, h.score1 + h.score2);
@@ -694,22 +688,9 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     //  (gpurun_out/r05h2): the small chunk stays the default of this mode because it is the faster one)
     const size_t chunkDefault = (alignmentType == 1 && maxReadLength > 120) ? (size_t)1 << 18 : (size_t)1 << 20;
     const uint32_t chunkReads = (uint32_t)((chunkReadsEnv ? chunkReadsEnv : chunkDefault) / 64 * 64 + (chunkReadsEnv && chunkReadsEnv < 64 ? 64 : 0));
-    // LARGE CHUNKS FIRST (round 5).  The search kernels' cost per read falls with the size of the batch (the tails of their launches: ten million pairs cost
-    // 2.95 s of BWT stages in chunks of 1 Mi reads, 2.14 s in chunks of 2 Mi, 1.66 s in chunks of 4 Mi) -- but a run of few large chunks ends with the whole
-    // of its last chunk's DP stages and output behind the last search, and came out no faster.  So the input is taken in chunks of S3DP_CHUNK_BIG reads
-    // (0, the default: off) while plenty is left, and in chunks of the usual size at the end: the pipeline drains over a small chunk.  What is left is
-    // estimated from the files' sizes (ReadChunker::remainingReads); an explicit S3DP_CHUNK_READS fixes the size as before.
-    // OFF by default: measured on the 10 M C3 pairs and on 20 M single reads with the outputs linked to /dev/null (tools/chunk_big_sweep.sh, gpurun_out/r05b):
-    // pairs 3.55 s without, 3.65-3.78 s with 4 Mi-read chunks and two to four DP stage threads -- the BWT stages fall from 2.74 to 2.0-2.2 s, the DP stages
-    // of the large chunks take what was won; single reads 1.41-1.46 s without, 1.70 / 2.1-2.2 s with 2 Mi / 4 Mi chunks (three slots in flight).
-    size_t chunkBigEnv = 0;
-    if (const char *e = getenv("S3DP_CHUNK_BIG")) chunkBigEnv = (size_t)strtoull(e, nullptr, 10);
-    const uint32_t chunkBig = chunkReadsEnv || chunkBigEnv <= chunkReads || (alignmentType == 1 && maxReadLength > 120) ? 0u : (uint32_t)(std::min<size_t>(chunkBigEnv, (size_t)1 << 23) / 64 * 64);
-    auto nextChunkSize = [&](const ReadChunker &ck) -> uint32_t {
-        if (!chunkBig) return chunkReads;
-        const double left = ck.remainingReads();
-        return left >= 0 && left < 1.5 * (double)chunkBig + 2.0 * (double)chunkReads ? chunkReads : chunkBig;   // (unknown = nothing read yet: the first chunk of a large file)
-    };
+    // (Large chunks first, small ones at the end -- the search kernels' cost per read falls with the batch, 2.95 / 2.14 / 1.66 s of BWT stages for ten million
+    //  pairs in chunks of 1 / 2 / 4 Mi reads -- was measured in round 5: pairs 3.55 s without, 3.65-3.78 s with; single reads 1.41 s without, 1.70-2.2 s with:
+    //  the DP stages and the output of the large chunks take what the search wins.  Taken out in round 6; profiles/README_r05.md section 6.)
     ReadChunker chunker;
     if (readBam ? !chunker.openBam(queryFile, paired, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)
                 : !chunker.open(queryFile, queryFile2, (uint32_t)maxReadLength, 33, ini.maxLenReadName, err)) return die(err);
@@ -739,7 +720,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             if (!rs) rs.reset(new ReadSet());
             std::string e;
             const auto t = std::chrono::steady_clock::now();
-            const bool ok = chunker.next(nextChunkSize(chunker), *rs, e);
+            const bool ok = chunker.next(chunkReads, *rs, e);
             std::unique_lock<std::mutex> lk(loaded.mu);
             loaded.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
             if (!ok) { loaded.err = e; loaded.done = true; loaded.cv.notify_all(); return; }
@@ -802,8 +783,10 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     // (with large chunks a chunk's DP stages last longer than the search of the next one: three threads keep up with them)
     // (pairs: three since the search kernels of round 5 -- a chunk's search is over before two threads are through the stages of the two chunks before it;
     //  10 M pairs, outputs to /dev/null: 3.40 -> 3.25 s with three threads, 3.18 s with a search grid that leaves a workgroup per compute unit to their kernels)
-    const int nDpWorkers = getenv("S3DP_DUMP_ROUTING") ? 1 : (dpThreadsEnv >= 1 && dpThreadsEnv <= kDpWorkers ? dpThreadsEnv : (chunkBig || paired ? 3 : 2));
-    struct PreDp { s3_dp *dp[kDpWorkers] = {}, *dpHalf[kDpWorkers] = {}; std::string err; };
+    int nDpWorkers = getenv("S3DP_DUMP_ROUTING") ? 1 : (dpThreadsEnv >= 1 && dpThreadsEnv <= kDpWorkers ? dpThreadsEnv : (paired ? 3 : 2));
+    // (every stage thread brings its own aligners -- up to 8 GB of traceback tables each, twice for pairs: when the device has no room for a second or a third
+    //  set beside a large index, the run goes on with the threads that got theirs: `workers`, the smallest count over the devices)
+    struct PreDp { s3_dp *dp[kDpWorkers] = {}, *dpHalf[kDpWorkers] = {}; int workers = 0; std::string err; };
     const std::vector<int> &dpDevices = shared.loaded ? shared.devices : devices;
     std::vector<PreDp> preDp(dpDevices.size());
     std::vector<std::thread> preDpThreads;
@@ -831,12 +814,25 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
             int scheme = 1, tableLen = 0, patLen = 0;
             s3_dp_scores sc{ini.matchScore, ini.mismatchScore, ini.gapOpenScore, ini.gapExtendScore};
             s3_dp_config(maxRL, maxDNA, wantScheme(maxRL, maxDNA), &scheme, &tableLen, &patLen);
-            for (int w = 0; w < nDpWorkers; w++)
-                if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &preDp[m].dp[w]) != S3_OK) { preDp[m].err = s3_last_error(); return; }
+            PreDp &P = preDp[m];
+            const int want = nDpWorkers;
+            P.workers = want;
+            for (int w = 0; w < want; w++)
+                if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNA, (uint32_t)tableLen, scheme, &sc, &P.dp[w]) != S3_OK) {
+                    if (w == 0) { P.err = s3_last_error(); return; }
+                    P.dp[w] = nullptr; P.workers = w;
+                    break;
+                }
             if (paired) {
                 s3_dp_config(maxRL, maxDNAHalf, wantScheme(maxRL, maxDNAHalf), &scheme, &tableLen, &patLen);
-                for (int w = 0; w < nDpWorkers; w++)
-                    if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &preDp[m].dpHalf[w]) != S3_OK) { preDp[m].err = s3_last_error(); return; }
+                for (int w = 0; w < P.workers; w++)
+                    if (s3_dp_create(dpDevices[m], problems(maxRL, tableLen), (uint32_t)maxRL, (uint32_t)maxDNAHalf, (uint32_t)tableLen, scheme, &sc, &P.dpHalf[w]) != S3_OK) {
+                        if (w == 0) { P.err = s3_last_error(); return; }
+                        P.dpHalf[w] = nullptr;
+                        for (int v = w; v < P.workers; v++) { if (P.dp[v]) s3_dp_free(P.dp[v]); P.dp[v] = nullptr; }
+                        P.workers = w;
+                        break;
+                    }
             }
         });
     if (!shared.loaded) {
@@ -859,6 +855,20 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
     const int nMembers = (int)devices.size();
     for (std::thread &t : preDpThreads) t.join();
     for (const PreDp &x : preDp) if (!x.err.empty()) return dieJoin(x.err);
+    if (enableDP) {
+        int got = nDpWorkers;
+        for (const PreDp &x : preDp) got = std::min(got, x.workers);
+        if (got < nDpWorkers) {
+            fprintf(stderr, "[Main] device memory for %d DP stage thread%s per device only (asked: %d)\n", got, got == 1 ? "" : "s", nDpWorkers);
+            for (PreDp &x : preDp)
+                for (int w = got; w < kDpWorkers; w++) {
+                    if (x.dp[w]) s3_dp_free(x.dp[w]);
+                    if (x.dpHalf[w]) s3_dp_free(x.dpHalf[w]);
+                    x.dp[w] = x.dpHalf[w] = nullptr;
+                }
+            nDpWorkers = got;
+        }
+    }
     const auto tAlign = std::chrono::steady_clock::now();
     // the first chunk goes back to the head of the queue: the members take their chunks from there
     if (chunk->n) { std::lock_guard<std::mutex> g(loaded.mu); loaded.q.push_front(std::move(chunk)); }
@@ -923,7 +933,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         s3_dp_stage_parameters(S3_STAGE_SINGLE_DP, detectedReadLength, &di, &dpPar);      // getParameterForSingleDP on the detected length (alignment.cu:2580)
         for (int w = 0; w < nDpWorkers; w++) {                                // (the aligners were made while the index was loaded, above)
             dpSet[w] = preDp[(size_t)member].dp[w];
-            if (s3_batch_create(ix, 262144 + 64, 8, &seedSet[w]) != S3_OK || s3_batch_set_background(seedSet[w], 1) != S3_OK) return dieJoin(s3_last_error());
+            if (s3_batch_create(ix, 262144 + 64, 8, &seedSet[w]) != S3_OK) return dieJoin(s3_last_error());
         }
         if (paired) {
             for (int w = 0; w < nDpWorkers; w++) halfSet[w] = preDp[(size_t)member].dpHalf[w];

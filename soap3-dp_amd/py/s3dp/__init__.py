@@ -42,12 +42,13 @@ class Counters(C.Structure):
 
 
 class KernelStats(C.Structure):
-    _fields_ = [("ms", C.c_float), ("launches", C.c_uint32), ("rankQueries", C.c_uint64), ("ltLookups", C.c_uint64), ("saReads", C.c_uint64), ("ceWindows", C.c_uint64)]
+    _fields_ = [("ms", C.c_float), ("launches", C.c_uint32), ("rankQueries", C.c_uint64), ("ltLookups", C.c_uint64), ("saReads", C.c_uint64), ("ceWindows", C.c_uint64),
+                ("listedRankQueries", C.c_uint64), ("accepted", C.c_uint64), ("ceRejected", C.c_uint64 * 18)]
 
 
 EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_index_lookup_chars", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
            "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_batch_fetch_pair_origins", "s3_batch_route_pairs", "s3_batch_no_pair_result", "s3_batch_fetch_routing", "s3_batch_fetch_kept", "s3_dp_new_default_routed", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_dp_single_end", "s3_dp_deep", "s3_dp_new_default", "s3_batch_fetch_alignments", "s3_batch_sync", "s3_batch_last_ce_timing",
-           "s3_batch_last_timing", "s3_batch_set_background", "s3_batch_set_grid", "s3_batch_kernel_stats", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
+           "s3_batch_last_timing", "s3_batch_set_grid", "s3_batch_kernel_stats", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_device_host_node", "s3_last_error", "s3_version", "s3_probe_gather", "s3_probe_copy", "s3_dp_totals",
            "s3_stream_create", "s3_stream_acquire", "s3_stream_submit", "s3_stream_next", "s3_stream_release", "s3_stream_free",
            "s3_group_create", "s3_group_size", "s3_group_device", "s3_group_index", "s3_group_member_of_batch", "s3_group_allreduce", "s3_group_free"]
@@ -356,12 +357,6 @@ class Batch:
             queries = np.concatenate([queries.ravel(), np.zeros(need - queries.size, dtype=np.uint32)])
         _chk(lib().s3_batch_upload(self.h, queries.ctypes.data, read_lengths.ctypes.data, self.n))
 
-    def set_background(self, background=True):
-        """the batch's stream at the device's lowest priority (work that runs beside another batch's search), or back at the default"""
-        f = lib().s3_batch_set_background
-        f.argtypes = [C.c_void_p, C.c_int]
-        _chk(f(self.h, 1 if background else 0))
-
     def set_grid(self, blocks_per_cu):
         """width of this batch's persistent search grids in workgroups per compute unit (0: all that are resident at once) -- s3_batch_set_grid"""
         f = lib().s3_batch_set_grid
@@ -480,7 +475,8 @@ class Batch:
         f = lib().s3_batch_kernel_stats
         f.argtypes = [C.c_void_p, C.POINTER(KernelStats)]
         _chk(f(self.h, arr))
-        return {name: {k: getattr(arr[i], k) for k, _ in KernelStats._fields_} for i, name in enumerate(("first", "trunk", "unit", "ce"))}
+        return {name: {k: (list(getattr(arr[i], k)) if k == "ceRejected" else getattr(arr[i], k)) for k, _ in KernelStats._fields_}
+                for i, name in enumerate(("first", "trunk", "unit", "ce"))}
 
     def counters(self):
         c = Counters()

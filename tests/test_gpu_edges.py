@@ -111,30 +111,6 @@ def test_text_boundaries_and_homopolymers(world):
         compare(ix, oix, reads, 100, 3, report_type=rt)
 
 
-def test_a_background_batch_gives_the_same_results(world):
-    """s3_batch_set_background: the batch's stream moves to the device's lowest priority (the seed batches of the command line's DP stage threads) and back;
-    results do not depend on it, and another batch of the default priority runs beside it"""
-    rng, codes, hi, ix, oix = world
-    n = len(codes)
-    reads = [seq(codes[s:s + 100]) for s in rng.integers(0, n - 100, size=300)] + [b"A" * 100, b"AC" * 50]
-    q, lens, wpq = s3dp.pack_reads(reads, 100)
-    want = oix.align_single_allbest(q, lens, wpq, 3, 1000, report_type=2)
-    bg, fg = s3dp.Batch(ix, len(reads), wpq), s3dp.Batch(ix, len(reads), wpq)
-    bg.set_background(True)
-    for b in (bg, fg):
-        b.upload(q, lens)
-    bg.align_single(3, 1000, 2)
-    fg.align_single(3, 1000, 2)
-    for b in (bg, fg):
-        got = b.fetch_alignments()
-        assert (got[0] == want[0]).all() and (got[2] == want[2]).all() and all((got[k] == want[k]).all() for k in (3, 4, 5))
-    bg.set_background(False)
-    bg.align_single(3, 1000, 2)
-    got = bg.fetch_alignments()
-    assert (got[2] == want[2]).all() and (got[3] == want[3]).all()
-    bg.close(); fg.close()
-
-
 def test_a_batch_that_lost_a_buffer_while_growing_refuses_further_calls():
     """bgrow frees the old buffer before the larger one exists when both do not fit; if the second allocation fails too the batch has a null
     buffer under an old capacity.  It must answer every later call with S3_ENOMEM instead of launching kernels on it (S3DP_TEST_FAIL_GROW=1: the first

@@ -133,12 +133,13 @@ def test_distributed_path_with_world_size_one(tmp_path):
 
 
 
-def test_bench_py_starts_two_ranks_itself():
+def test_bench_py_starts_two_ranks_itself(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it: the script spawns its ranks, rank 0 builds the index once and writes the files,
     rank 1 maps them (HostIndex.from_files(shared=True)), both align their own shard, the counters are reduced, ONE line comes back.  On a one-GPU box the
     two ranks share device 0 over gloo (S3DP_BENCH_SHARE_GPU=1; RCCL wants a device per rank): everything of the N > 1 path but the RCCL transport."""
     import json
-    env = dict(os.environ, S3DP_BENCH_SHARE_GPU="1")
+    full = str(tmp_path / "bench_full.json")
+    env = dict(os.environ, S3DP_BENCH_SHARE_GPU="1", S3DP_BENCH_FULL=full)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genome-bp", "60000000", "--reads", "200000", "--steps", "2", "--warmup", "1",
@@ -148,8 +149,11 @@ def test_bench_py_starts_two_ranks_itself():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.split("\n") if l.strip()]
     assert len(lines) == 1, out.stdout[-2000:]
-    res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    line = json.loads(lines[0])                                        # the compact line the driver parses; the full object is in the side file
+    assert len(lines[0]) < 8192 and line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["full_object"] == full
+    assert line["roofline"]["frac"] > 0 and line["parity"]["oracle_check_bit_exact"] and line["summary"]["c4_pairs"]["pairs"] == 80000
+    res = json.loads(open(full).read())
+    assert res["n_gpus"] == 2 and res["value"] == pytest.approx(line["value"], rel=1e-4)
     assert res["aligned_reads"] == 400000                              # both shards, summed by the all-reduce
     assert res["truth_check"]["ok"] and res["oracle_check"]["bit_exact"]
     assert res["streamed"]["same_results_as_resident"]

@@ -31,7 +31,7 @@ def test_search_bit_exact_vs_reference_dump_and_oracle(monkeypatch, name, maxlen
     monkeypatch.setenv("S3DP_UNITS", "0" if heavy.endswith("i") else "1")
     if heavy.endswith("g"):                                 # units never verify candidates themselves / always do
         monkeypatch.setenv("S3DP_CE_GIVE_UP", "0")
-    if heavy.endswith("p"):                                 # one first-mismatch position per unit (until round 5; the default is a group of four)
+    if heavy.endswith("p"):                                 # one first-mismatch position per unit (until round 5; the default: groups of two for the single-end ladders, one position for pairs)
         monkeypatch.setenv("S3DP_UNIT_GROUP", "1")
     reads = golden_reads(name)
     q, lens, wpq = s3dp.pack_reads(reads, maxlen)
@@ -79,8 +79,8 @@ KNOBS = [
     {"S3DP_HEAVY": "2", "S3DP_FAST_TRIPS": "0", "S3DP_FIRST_FAST_TRIPS": "0", "S3DP_CE_GIVE_UP": "2"},     # none at all, units verify candidates (rounds 3-4)
     # every lane with a frame to give is a giant after its first full trip: frames are adopted while the queue still has work
     {"S3DP_HEAVY": "2", "S3DP_GIANT_AGE": "1", "S3DP_GIANT_IDLE": "1", "S3DP_FAST_MIN": "4"},
-    {"S3DP_HEAVY": "2", "S3DP_GIANT_AGE": "0", "S3DP_PRUNE_UNITS": "0", "S3DP_TAIL_AGE": "2"},
-    # units are groups of consecutive first-mismatch positions (default 4): one position per unit (until round 5), odd sizes, and one group for the whole step
+    {"S3DP_HEAVY": "2", "S3DP_GIANT_AGE": "0", "S3DP_TAIL_AGE": "2"},
+    # units are groups of consecutive first-mismatch positions (default 2 for the single-end ladders, 1 for pairs): one position per unit (until round 5), odd sizes, and one group for the whole step
     {"S3DP_HEAVY": "2", "S3DP_UNIT_GROUP": "1"},
     {"S3DP_HEAVY": "2", "S3DP_UNIT_GROUP": "3", "S3DP_GIANT_AGE": "1", "S3DP_GIANT_IDLE": "1", "S3DP_FAST_MIN": "2"},
     {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8", "S3DP_UNIT_GROUP": "7"},

@@ -70,3 +70,23 @@ def test_paired_dp_records(tmp_path, variant, opts):
     assert len(mine) == len(ref) == 1440
     bad = [(a, b) for a, b in zip(ref, mine) if a != b]
     assert not bad, "%d differing records, first:\n%s\n%s" % (len(bad), bad[0][0], bad[0][1])
+
+
+def test_the_survivor_among_deep_dp_results_with_equal_first_positions_is_pinned():
+    """a pair's deep-DP results are sorted with std::sort by the first end's position alone and the first of every position is kept, as the
+    reference's OutputBuffer::arrayCopyNRemoveDuplicate does -- with more than sixteen results the survivor among equal positions is what libstdc++'s
+    introsort leaves in front.  The golden list was written by this toolchain's libstdc++ (the one the reference harness is built with): a library whose
+    sort permutes differently must show up here, not as a silent change of X0 / X1 / XA in SAM files."""
+    d = os.path.join(GOLDEN, "dp2")
+    inp = open(os.path.join(d, "deep_dedup_input.txt")).read()
+    want = open(os.path.join(d, "deep_dedup_survivors.txt")).read()
+    out = subprocess.run([pair_tool(), "--dedup"], input=inp, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0
+    assert out.stdout == want
+    rows = [tuple(int(x) for x in l.split()) for l in inp.split("\n") if l]
+    got = [tuple(int(x) for x in l.split()) for l in out.stdout.split("\n") if l]
+    assert [p for p, _ in got] == sorted({p for p, _ in rows})                  # one result per position, ascending
+    first = {}
+    for p, t in rows:
+        first.setdefault(p, t)
+    assert any(first[p] != t for p, t in got)                                   # the case does leave the insertion-sort branch: a stable sort would fail it

@@ -13,6 +13,15 @@ using namespace s3host;
 
 int main(int argc, char **argv)
 {
+    if (argc == 2 && std::string(argv[1]) == "--dedup") {
+        // stdin: one deep-DP result per line, "pos1 tag"; stdout: the tags keepFirstResultPerPosition leaves, in its order
+        std::vector<DeepDpHit> hits;
+        unsigned pos; int tag;
+        while (scanf("%u %d", &pos, &tag) == 2) { DeepDpHit h{}; h.pos1 = pos; h.score1 = tag; hits.push_back(h); }
+        keepFirstResultPerPosition(hits);
+        for (const DeepDpHit &h : hits) printf("%u %d\n", h.pos1, h.score1);
+        return 0;
+    }
     if (argc < 7) { fprintf(stderr, "usage: dp_pair_sam <index> <reads1> <reads2> <results> <stats> <out prefix> [-L n] [-h n] [-p] [-B 0|1]\n"); return 1; }
     int maxReadLength = 120, type = 2, bwaLike = 1;
     bool printMDNM = false;

@@ -15,7 +15,7 @@ import json, sys
 try:
     d = json.load(open(sys.argv[1]))
     pk = d["roofline"]["per_kernel"]
-    print("   per kernel ms:", {k: round(v["ms_per_step"], 1) for k, v in pk.items()}, "oracle", d.get("oracle_check", {}).get("bit_exact"))
+    print("   per kernel ms:", {k: round(v["ms_per_step"], 1) for k, v in pk.items()}, "oracle", (d.get("parity") or {}).get("oracle_check_bit_exact"))
 except Exception as e:
     print("   (no json)", e)
 PY
