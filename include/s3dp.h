@@ -71,6 +71,15 @@ size_t s3_index_device_bytes(const s3_index *ix);
  * (S3DP_LT_EXTRA = 0 .. 3 more characters; default 3 = 16-mers, 103 GB, for texts of two gigabases and more, 2 from one gigabase, 0 below): entries hold
  * exactly the state the shorter table plus that many exact steps give, so results do not change -- an item just starts that many rank steps further on */
 int  s3_index_lookup_chars(const s3_index *ix);
+/* FLANK TABLES of check-and-extend (CEKernel's reference: 2bwt-flex/SRA2BWTCheckAndExtend.c:142, BGS-HostAlgnmtAlgo2.cpp:36-176 read the suffix array and then
+ * the packed text per candidate).  The library builds, at upload, one 16-byte record per suffix-array entry -- {text position, the 48 characters next to it} -- in
+ * the order of the forward index (tasks handed over in backward steps) and of the reverse index (forward steps; csrc/s3dp_flank.hip tells how its order is found
+ * without a suffix array of the reverse index): a rejected candidate -- 97 in 100 -- then costs that record instead of two dependent lines.  Same records.
+ * s3_index_flank_tables: 0, 1 (forward index only) or 2 -- S3DP_FLANK, and the device memory that is free (S3DP_FLANK_RESERVE_GB).
+ * s3_index_fetch_flank: inspection aid (tests compare the tables with a suffix sort of the reversed text): entries [first, first + count) of table 0 (forward
+ * index order) or 1 (reverse index order), four words each: position, then 3 x 16 characters MSB first, the adjacent character first. */
+int  s3_index_flank_tables(const s3_index *ix);
+int  s3_index_fetch_flank(s3_index *ix, int table, uint32_t first, uint32_t count, uint32_t *out);
 
 /* One emitted record of the k-mismatch search, in the reference CPU path's emission order
  * (BGS-HostAlgnmtAlgo2.cpp: SA ranges -> SAList via addSAToSAList :1617,1692; check-and-extend hits

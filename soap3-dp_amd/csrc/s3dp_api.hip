@@ -297,6 +297,7 @@ static int indexUploadBody(s3_index *ix, const s3_index_desc *desc, hipStream_t 
     ix->d.sa = sa; ix->d.pac = pac; ix->d.pacWords = pacWords; ix->d.lkt = lkt; ix->d.rlkt = rlkt;
     ix->d.ltSize = desc->lktSize; ix->d.n = n;
     ix->d.ltBack = nullptr; ix->d.ltBi = nullptr; ix->d.ltK = 0;
+    ix->d.flankBack = nullptr; ix->d.flankFwd = nullptr;
     {
         // padded k-mers of the two tables (see DevIndex): text[n-j .. n-1] + 'A' x (K-j) and, for the reverse table, text[j-1 .. 0] + 'A' x (K-j), j = 1 .. K-1
         const int K = desc->lktSize;
@@ -338,6 +339,20 @@ static int indexUploadBody(s3_index *ix, const s3_index_desc *desc, hipStream_t 
         }
     }
     lap("long lookup tables");
+    {
+        // flank tables of check-and-extend (s3dp_flank.hip): 16 B per suffix-array entry and table -- 2 x 49.6 GB at 3.1 G bases, beside 120 GB of index with the
+        // 16-mer tables.  S3DP_FLANK = 0: none, 1: the forward index's only, 2 (default): both; they are built while S3DP_FLANK_RESERVE_GB (default 24) of device
+        // memory stay free for batches and aligners -- a table that does not fit is left out and its tasks are verified from the suffix array and the text.
+        const int which = (int)envSize("S3DP_FLANK", 2);
+        void *fa[2] = {nullptr, nullptr};
+        int nfa = 0;
+        size_t fbytes = 0;
+        const int e = s3::launchFlankTables(ix->d, which > 2 ? 2 : which, envSize("S3DP_FLANK_RESERVE_GB", 24) << 30, fa, &nfa, &fbytes, verbose, s);
+        for (int k = 0; k < nfa; k++) ix->allocs.push_back(fa[k]);
+        ix->bytes += fbytes;
+        if (e != (int)hipSuccess) return fail(S3_EHIP, std::string("flank tables: ") + hipGetErrorString((hipError_t)e));
+    }
+    lap("flank tables");
     // model tables for every read length and mismatch budget (built on the host, see s3dp_model.cpp)
     std::vector<S3Model> host(S3_MAX_READ_LENGTH + 1);
     for (int e = 0; e <= S3_MAX_MISMATCH; e++) {
@@ -363,6 +378,18 @@ extern "C" void s3_index_free(s3_index *ix)
 
 extern "C" size_t s3_index_device_bytes(const s3_index *ix) { return ix ? ix->bytes : 0; }
 extern "C" int s3_index_lookup_chars(const s3_index *ix) { return !ix ? 0 : ix->d.ltK ? ix->d.ltK : ix->d.ltSize; }
+extern "C" int s3_index_flank_tables(const s3_index *ix) { return !ix ? 0 : (ix->d.flankBack ? 1 : 0) + (ix->d.flankFwd ? 1 : 0); }
+
+extern "C" int s3_index_fetch_flank(s3_index *ix, int table, uint32_t first, uint32_t count, uint32_t *out)
+{
+    if (!ix || !out) return fail(S3_EINVAL, "null argument");
+    const uint4 *t = table == 0 ? ix->d.flankBack : table == 1 ? ix->d.flankFwd : nullptr;
+    if (!t) return fail(S3_EINVAL, "s3_index_fetch_flank: the index holds no such table");
+    if ((uint64_t)first + count > (uint64_t)ix->d.n + 1u) return fail(S3_EINVAL, "s3_index_fetch_flank: beyond the table");
+    HIPCHK(hipSetDevice(ix->dev));
+    HIPCHK(hipMemcpy(out, t + first, (size_t)count * sizeof(uint4), hipMemcpyDeviceToHost));
+    return S3_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 
@@ -374,6 +401,7 @@ int s3i::growRecords(s3_batch *b)
     if (cap > kMaxEntries) cap = kMaxEntries;
     int rc;
     if ((rc = bgrow(b, &b->dRecs, cap, 0))) return rc;
+    if ((rc = bgrow(b, &b->dRecAux, cap, 0))) return rc;
     if (b->dHits) { if ((rc = bgrow(b, &b->dHits, cap, 0))) return rc; }
     b->recCap = (uint32_t)cap;
     return S3_OK;
@@ -447,7 +475,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
-    BA(dRecs, recCap); BA(dOrdered, recCap); BA(dOrdValid, recCap + 8); b->ordCap = recCap;     // (+ 8: the long merge / decode kernels read the bytes eight at a time)
+    BA(dRecs, recCap); BA(dRecAux, recCap); BA(dOrdered, recCap); BA(dOrdValid, recCap + 8); b->ordCap = recCap;     // (+ 8: the long merge / decode kernels read the bytes eight at a time)
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, S3_COUNTER_WORDS); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dWasHeavy, (size_t)maxReads + 64); BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
@@ -632,7 +660,6 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         }
     }
     in.unitsPerItem = 1; in.unitBase = 0; in.unitMode = 0; in.unitGroup = 1;
-    in.ceGiveUp = (uint32_t)envSize("S3DP_CE_GIVE_UP", S3_CE_GIVE_UP);
     in.adoptIdle = (uint32_t)envSize("S3DP_ADOPT_IDLE", S3_UNIT_ADOPT_IDLE);
     in.takeMin = (uint32_t)envSize("S3DP_TAKE_MIN", S3_UNIT_TAKE_MIN);
     if (in.takeMin < 1u) in.takeMin = 1u;
@@ -647,7 +674,6 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     in.firstFastTrips = (uint32_t)envSize("S3DP_FIRST_FAST_TRIPS", S3_FIRST_FAST_TRIPS);
     in.firstFastMin = (uint32_t)envSize("S3DP_FIRST_FAST_MIN", S3_FIRST_FAST_MIN);
     if (in.firstFastMin < 1u) in.firstFastMin = 1u;
-    in.ceInlineMax = (uint32_t)envSize("S3DP_CE_INLINE_MAX", 128);
     uint32_t slots = 0;                                                   // entries of the ordered array this pass needs
     unsigned long long counterSnapAll[S3_COUNTER_WORDS] = {}, counterSnap[S3_NUM_COUNTERS] = {};   // per kernel role; summed over the roles
     if (b->counting) {
@@ -702,7 +728,7 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         HIPCHK(hipMemsetAsync(b->dHeavyCount, 0, 4, b->stream));
         HIPCHK(hipMemsetAsync(b->dHeavyFlags, 0, nActive, b->stream));
         SearchOut out{};
-        out.recs = b->dRecs; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
+        out.recs = b->dRecs; out.recAux = b->dRecAux; out.recCap = b->recCap; out.recCount = b->dRecCount; out.itemCounts = b->dItemCounts; out.flags = b->dFlags;
         out.counters = b->counting ? b->dCounters : nullptr;
         out.workHead = b->dWorkHead;
         out.cutDummy = b->dFlags + 2;
@@ -779,7 +805,12 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                 HIPCHK(hipMemcpyAsync(b->dTaskRange + 1, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
                 HIPCHK(mark(b->evCe, b->evCeUsed, true, 3));
                 out.counters = countersOf(3);
-                launchCheckExtend(b->ix->d, in, out, b->dTaskRange, b->stream);
+                // (S3DP_FLANK is read here too: 0 / 1 make ceKernel ignore tables the index holds -- A/B runs and the tests' matrix on one resident index)
+                DevIndex dce = b->ix->d;
+                const size_t useFlank = envSize("S3DP_FLANK", 2);
+                if (useFlank < 2) dce.flankFwd = nullptr;
+                if (useFlank < 1) dce.flankBack = nullptr;
+                launchCheckExtend(dce, in, out, b->dTaskRange, b->stream);
                 HIPCHK(mark(b->evCe, b->evCeUsed, false, 3));
                 HIPCHK(hipMemcpyAsync(b->dTaskRange, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
                 return S3_OK;
@@ -972,6 +1003,7 @@ int s3i::checkFlags(s3_batch *b)
     if (flags & S3_FLAG_STACK_OVERFLOW) return fail(S3_EOVERFLOW, "search stack overflow (internal bound exceeded)");
     if (flags & S3_FLAG_REC_OVERFLOW) return fail(S3_EOVERFLOW, "record buffer overflow: raise S3DP_REC_PER_READ");
     if (flags & S3_FLAG_OCC_OVERFLOW) return fail(S3_EOVERFLOW, "occurrence buffer overflow: raise S3DP_OCC_PER_READ");
+    if (flags & S3_FLAG_FLANK) return fail(S3_EHIP, "check-and-extend: the flank table of the reverse index disagrees with the index (run with S3DP_FLANK=1 and report this)");
     return S3_OK;
 }
 

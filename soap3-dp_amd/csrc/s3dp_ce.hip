@@ -3,6 +3,10 @@
 // search stands in the model) into the record stream, reserve one sequence number per candidate and go on.  This kernel verifies the candidates -- suffix-
 // array value, then the text under the rest of the model against the oriented read, 16 characters per XOR / fold / popcount -- and appends the accepted
 // ones under their reserved numbers, so the record stream keeps the CPU path's order; rejected candidates leave holes the ordering pass skips.
+// Since round 6 a candidate is first looked up in a FLANK TABLE (s3dp_flank.hip): one 16-byte record {text position, the 48 characters next to the matched
+// part} in the order of the index the handing-over step walks -- the forward index for backward steps (recs[].z), the reverse index for forward steps
+// (SearchOut::recAux) -- and nine in ten are rejected from that record alone; survivors go on as before.  A forward task's candidates come in the REVERSE
+// index's order: a survivor finds its place in the forward range (its sequence number) by looking its text position up in the task's <= 32 suffix-array entries.
 // (Round 5 tried the text a second time in OVERLAPPING 64-byte lines -- line k = the 256 characters from 128 k on, so that no window straddles two lines:
 //  1.0 text lines per candidate instead of 1.4 -- and the kernel got SLOWER, 72.4 -> 78.2 ms per ladder: twice the text's bytes halve what the 256 MB
 //  of last-level cache hold of it, and that costs more than the second lines did.  profiles/README_r05.md.)
@@ -23,17 +27,16 @@ using namespace v2;
 // prefix sums.  Accepted candidates are appended to the record stream with one atomic per wave and S3_V2_REC_BLOCK records.  Per candidate: SA
 // value, then per remaining model step the text against the oriented read, 16 characters at a time (XOR, fold, popcount), the step's error
 // window checked as in the stepping kernel (BGS-HostAlgnmtAlgo2.cpp:86-169).
-// COUNT (counters enabled: measurement passes only): besides the tallies, WHERE the rejected candidates are decided (would a table
-// of the 32 characters next to every suffix -- one line per candidate instead of a suffix-array line and then a text line -- settle them?).  Per rejected
-// candidate: the direction of the step it was handed over in (backward: the characters to its LEFT, a table in suffix-array order would hold them; forward:
-// the characters behind the matched part, whose distance from the suffix's start differs from task to task), the mismatches it may still take in that
-// step (0 / 1 / 2 and more), and whether the 32 characters next to the matched part alone exceed them / the rest of that step decides / a later step does:
+// COUNT (counters enabled: measurement passes only): besides the tallies, WHERE the rejected candidates are decided.  Per rejected candidate: the direction
+// of the step it was handed over in (backward: the characters to its LEFT; forward: the characters behind the matched part), the mismatches it may still take
+// in that step (0 / 1 / 2 and more), and whether its flank record alone rejected it (without a table: whether the 32 characters next to the matched part
+// alone would have -- the measurement the tables were built on, 91.7 % on the benchmark) / the rest of that step decides / a later step does:
 // counters[S3_CE_HIST_BASE + (dir * 3 + budget) * 3 + where].
 template <bool COUNT>
 __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, SearchOut out, const uint32_t *taskRange)
 {
     __shared__ uint4 sRec[4][64];                              // per wave: the task records of the batch ...
-    __shared__ uint32_t sStart[4][65], sRead[4][64];           // ... the number of their first candidate; the read a task belongs to
+    __shared__ uint32_t sStart[4][65], sRead[4][64], sAux[4][64];   // ... the number of their first candidate; the read a task belongs to; its range's start in the reverse index
     // ... and the tasks' reads, their searched strand, S words each (launchCheckExtend sizes it; not for reads of more than 256 bases): a candidate's read words
     // come out of LDS.  What the kernel is bound by, next to the lines it fetches, is the number of lines its wave-instructions TOUCH -- the vector cache
     // looks up one line per lane and clock --, and until round 5 a candidate asked for its window word by word: up to nine 4-byte loads from the text and
@@ -87,6 +90,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         if (lane == 63u) sStart[wv][64] = total;
         const uint32_t myRead = task ? (in.active ? in.active[slotOf] : slotOf) : 0u;
         sRead[wv][lane] = myRead;
+        sAux[wv][lane] = task && idx < nRec ? out.recAux[idx] : 0u;
         if (staged && task) {
             const uint4 *src = (const uint4 *)(in.readsT + (size_t)myRead * 2u * S + (size_t)((item % groups) & 1u) * S);
             uint4 *dst = (uint4 *)(myRd + lane * S);
@@ -117,17 +121,55 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
                 const uint32_t *rdL = myRd + lo * S;
                 const S3Case &cs = in.models[Li].cs[casIdx];
-                recX = tr.x; seqK = (tr.y & 0xFFFFFFu) + k;
+                recX = tr.x;
                 acc = occ0;
-                const uint32_t sa = ix.sa[tr.z + k];
-                nSa++;
                 const S3Step st0 = cs.st[s0];
                 const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i0;
+                const bool fwdStep = st0.dir > 0;
+                const uint4 *tab = fwdStep ? ix.flankFwd : ix.flankBack;
+                uint32_t sa = 0, kf = k;                                        // text position of the matched part's start; the candidate's place in the FORWARD range
+                bool flankRejected = false;
+                nSa++;
+                if (tab) {
+                    const uint4 e = tab[(fwdStep ? sAux[wv][lo] : tr.z) + k];
+                    const int pos0 = st0.start + st0.dir * i0;
+                    const uint32_t len0 = (uint32_t)(pos0 < st0.end ? st0.end - pos0 : pos0 - st0.end) + 1u, nAdj = len0 < 48u ? len0 : 48u;
+                    // the read's characters next to the matched part, the adjacent one first (positions before the read's start never count: nAdj <= len0)
+                    auto rword = [&](uint32_t w) -> uint32_t { return w < S ? (staged ? rdL[w] : rd[w]) : 0u; };
+                    auto rwin = [&](int p0) -> uint32_t {
+                        if (p0 <= -16) return 0u;
+                        if (p0 < 0) return rword(0u) >> (2u * (uint32_t)(-p0));
+                        const uint32_t w = (uint32_t)p0 >> 4, sh = ((uint32_t)p0 & 15u) * 2u;
+                        const uint32_t a = rword(w), b = rword(w + 1u);
+                        return sh ? (a << sh) | (b >> (32u - sh)) : a;
+                    };
+                    const uint32_t q0 = fwdStep ? rwin(pos0) : pairRev(rwin(pos0 - 15)), q1 = fwdStep ? rwin(pos0 + 16) : pairRev(rwin(pos0 - 31)),
+                                   q2 = fwdStep ? rwin(pos0 + 32) : pairRev(rwin(pos0 - 47));
+                    auto miss = [](uint32_t a, uint32_t b, uint32_t n) -> int {        // mismatches among the first n <= 16 characters
+                        uint32_t x = a ^ b;
+                        x = (x | (x >> 1)) & 0x55555555u;
+                        if (n < 16u) x &= n ? ~0u << (32u - 2u * n) : 0u;
+                        return __popc(x);
+                    };
+                    const int mmAdj = miss(e.y, q0, nAdj < 16u ? nAdj : 16u) + miss(e.z, q1, nAdj <= 16u ? 0u : nAdj < 32u ? nAdj - 16u : 16u) +
+                                      miss(e.w, q2, nAdj <= 32u ? 0u : nAdj - 32u);
+                    // (only characters inside the text decide here: a window that leaves it is the full comparison's business, with its bounds checks)
+                    const bool inText = fwdStep ? (uint64_t)e.x + nAdj <= (uint64_t)ix.n : e.x >= nAdj;
+                    flankRejected = inText && mmAdj + ins0 > st0.maxErr;
+                    sa = fwdStep ? e.x - (uint32_t)(pos0 - st0.lm0) : e.x;
+                    if (!flankRejected && fwdStep) {
+                        const uint32_t size = sStart[wv][lo + 1u] - sStart[wv][lo];
+                        kf = 0xFFFFFFFFu;
+                        for (uint32_t j = 0; j < size; j++) if (ix.sa[tr.z + j] == sa) { kf = j; break; }
+                        if (kf == 0xFFFFFFFFu) { atomicOr(out.flags, S3_FLAG_FLANK); flankRejected = true; }
+                    }
+                } else sa = ix.sa[tr.z + k];
+                seqK = (tr.y & 0xFFFFFFu) + kf;
                 rp = sa - (uint32_t)leftAlign;                                   // 32-bit wrap, as the reference
                 int t = s0, ii = i0, insCur = ins0;
                 bool rejBound = false;
-                hit = true;
-                while (t < nSteps) {
+                hit = !flankRejected;
+                while (hit && t < nSteps) {
                     const S3Step st = cs.st[t];
                     const int pos = st.start + st.dir * ii;
                     const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end), right = (uint32_t)(pos < st.end ? st.end : pos);
@@ -187,12 +229,14 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 if constexpr (COUNT) {
                     if (!hit) {
                         uint32_t where = 2u;                                     // a later step
-                        if (t == s0) {
+                        if (flankRejected) where = 0u;                           // the flank record alone (48 characters next to the matched part)
+                        else if (t == s0) {
                             where = 1u;                                          // the rest of the first compared step (or the text's end)
                             const int pos = st0.start + st0.dir * i0;
                             const uint32_t left = (uint32_t)(pos < st0.end ? pos : st0.end), right = (uint32_t)(pos < st0.end ? st0.end : pos);
                             const uint32_t len = right - left + 1u, nAdj = len < 32u ? len : 32u;
-                            if (!rejBound && (st0.dir > 0 ? rp + left + nAdj <= ix.n : rp + right < ix.n)) {
+                            // (without a flank table: would the 32 characters next to the matched part alone have decided?  VERDICT r5, item 5)
+                            if (!tab && !rejBound && (st0.dir > 0 ? rp + left + nAdj <= ix.n : rp + right < ix.n)) {
                                 int m2 = 0;
                                 for (uint32_t q = 0; q < nAdj; q++) {
                                     const uint32_t rpos = st0.dir > 0 ? left + q : right - q, tp = rp + rpos;

@@ -33,6 +33,7 @@
 #define S3_FLAG_STACK_OVERFLOW 1u
 #define S3_FLAG_REC_OVERFLOW   2u
 #define S3_FLAG_OCC_OVERFLOW   4u
+#define S3_FLAG_FLANK          8u     // ceKernel: a survivor of a forward task is not in its task's forward range (the flank table of the reverse index and the index disagree)
 
 namespace s3 {
 
@@ -52,6 +53,11 @@ struct DevIndex {
     uint32_t        n;
     // long lookup tables held in HBM (built at upload, s3dp_kernels.hip::launchLongLookup): the state of an item after its lookup step's first
     // ltK = ltSize + 1 or 2 characters -- what the ltSize-mer table plus one / two exact steps give, stored so that the steps are not walked again
+    // FLANK TABLES (round 6; s3dp_flank.hip): per suffix-array entry its text position and the 48 characters NEXT to it, the adjacent one first, 16 per word MSB
+    // first -- flankBack[k]: {SA[k], T[SA[k]-1], T[SA[k]-2], ...} in the order of the forward index, flankFwd[k']: {E, T[E], T[E+1], ...} in the order of the REVERSE
+    // index (E = the text position behind the suffix's first character as the reverse index reads it, i.e. behind the matched part of a forward step).
+    // ceKernel rejects nine candidates in ten from this one 16-byte entry (instead of a suffix-array line and then, dependently, a text line).  nullptr: none.
+    const uint4    *flankBack, *flankFwd;
     const uint2    *ltBack;      // backward lookup steps: {l, r}, indexed by the ltK characters in read order
     const uint4    *ltBi;        // bidirectional lookup steps: {l, r, rev l, rev r}, indexed by the ltK characters REVERSED (order of the reverse index)
     int             ltK;         // 0: none
@@ -87,8 +93,6 @@ struct SearchIn {
     uint32_t        unitGroup;     // second pass: consecutive positions per unit (S3DP_UNIT_GROUP; 1: one unit per position, as until round 5)
     uint32_t        unitBase;      // second pass: unit u counts its records in itemCounts[unitBase + u]
     uint32_t        sStarPacked;   // 3 bits per case: the first step that allows a mismatch (= nSteps: none)
-    uint32_t        ceInlineMax;   // second pass: occurrences a unit verifies itself before it hands the rest of its candidates to ceKernel
-    uint32_t        ceGiveUp;      // second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel (S3_CE_GIVE_UP)
     uint32_t        adoptIdle;   // unit pass: idle lanes a wave needs before its busy lanes give frames away (S3_UNIT_ADOPT_IDLE)
     uint32_t        takeMin;     // unit pass: idle lanes a wave lets gather before they start their next units together (S3_UNIT_TAKE_MIN; 1: at once)
     uint32_t        tailAge;             // unit pass, queue empty: full trips a lane must have spent on its unit before it gives frames away (S3DP_TAIL_AGE)
@@ -100,15 +104,13 @@ struct SearchIn {
 
 #define S3_REC_TASK  (1u << 28)
 #define S3_REC_PASS2 0x80000000u            // in the item word: record written by the second pass (records of a listed read without it are stale)
-// second pass: rejected candidates in a row after which a unit hands its candidates to ceKernel.  0 since the fast trips of round 5: a unit verifies nothing
-// itself -- a lane in check-and-extend moves in full trips only, one trip in five, and sits out the fast ones (10 M reads: 284.3 -> 278.9 ms per step against
-// 2, `young` 23.9 -> 24.6 M reads/s, satellite-heavy 14.2 -> 14.4; round 3 had chosen 2 with every trip a full one)
-#define S3_CE_GIVE_UP 0u
 #define S3_TRUNK_VALID 0x80000000u          // trunkStates[].w: the trunk pass reached this position
 #define S3_REC_EARLY (1u << 29)              // task written inside the exact lookup step (single-suffix range): the rest of that step is verified too
 
 struct SearchOut {
     uint4              *recs;    // {item, seq|kind<<24|nmis<<25, a, b};  S3_REC_TASK set: a check-and-extend task {item, first seq, SA left, size-1 | state<<8}
+    uint32_t           *recAux;  // per record slot, written with a TASK record: the first suffix of the task's range in the REVERSE index (what a task written in a forward
+                                 // step looks its candidates up by in DevIndex::flankFwd; recs[].z stays the forward index's)
     uint32_t            recCap;
     uint32_t           *recCount;
     uint32_t           *itemCounts;
@@ -197,6 +199,7 @@ void launchListedKeys(const uint32_t *slots, uint32_t n, const uint32_t *active,
 void launchListedPlace(const uint32_t *sortedSlots, uint32_t n, uint32_t *heavyList, uint32_t *heavyIndex, hipStream_t s);
 void launchUnitChains(const SearchOut &out, uint32_t unitBase, uint32_t nUnits, hipStream_t s);
 void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &out, const uint32_t *taskRange, hipStream_t s);
+int  launchFlankTables(DevIndex &d, int which, size_t reserveBytes, void **allocs, int *nAllocs, size_t *bytes, bool verbose, hipStream_t s);   // s3dp_flank.hip; returns a hipError_t as int
 int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int
 struct ScatterDyn { const uint32_t *owner, *local; uint32_t base, cap; };          // the counters of adopted frames (SearchOut::dynOwner / dynLocal / dynBase / dynCap)
 void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, uint8_t *valid, const uint8_t *heavyFlags,

@@ -87,6 +87,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     uint32_t ltA = 0, ltB = 0, ltC = 0, ltD = 0;                            // lookup-table keys of the starting item
     bool padded = false;                                                    // the item's lookup range may hold an element that is no occurrence
     uint32_t pendMeta = 0, pendA = 0, pendB = 0;
+    uint32_t pendC = 0;                                                     // of a task written in a forward step: the first suffix of its range in the REVERSE index (SearchOut::recAux)
     // ---- wave-uniform ----
     uint32_t recCur = 0, recEnd = 0;
     bool queueEmpty = false, basePending = false;
@@ -136,6 +137,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         pendMeta = 0x80000000u | seq | S3_REC_TASK | flags;
         pendA = fwdL();
         pendB = (aR - aL) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+        pendC = aL;                                                          // (forward step: the active range is the reverse index's)
         seq += aR - aL + 1u;
         readCand += aR - aL + 1u;
     };
@@ -546,7 +548,10 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                 }
                 if (pendMeta >> 31) {
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(TRUNK ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                    if (recCur + rk < recEnd) {
+                        out.recs[recCur + rk] = make_uint4(TRUNK ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                        if (pendMeta & S3_REC_TASK) out.recAux[recCur + rk] = pendC;
+                    }
                     pendMeta = 0;
                 }
                 recCur += np;

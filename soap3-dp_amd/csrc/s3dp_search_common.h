@@ -31,9 +31,8 @@
 //     lane per read, item and position) starts from those.  Since round 5 a unit is a GROUP of consecutive positions (two by default): the lane walks the
 //     trunk's path through its group -- writing nothing there: those records are the trunk's --, takes the mismatch children at every position and drops the
 //     continuation at the group's last one (s3dp_unit.hip, "GROUPS"): half the unit starts, the same order.
-//   * THE CUT.  The CPU path stops a read at MaxOutputPerRead occurrences.  The lanes of the unit pass verify their candidates themselves (up to a
-//     point: after in.ceGiveUp rejections in a row, or in.ceInlineMax verified occurrences, a unit writes task records like the first pass), book
-//     what they hold for sure in counters the units of their read share (itemAcc per item, the spare word of the trunk states per position), and
+//   * THE CUT.  The CPU path stops a read at MaxOutputPerRead occurrences.  The lanes of the unit pass book the SA-range occurrences
+//     they hold for sure (their check-and-extend candidates go to ceKernel, as the first pass's do) in counters the units of their read share (itemAcc per item, the spare word of the trunk states per position), and
 //     everything in sequence order up to a unit that adds up to MaxOutputPerRead puts the read's cut behind that unit (SearchOut::readCut); a lane
 //     that finds itself behind its read's cut stops.  The merge applies the cut exactly either way.
 //   * THE TAIL.  Once the queue is empty, an idle lane of the unit pass adopts the oldest frame of a busy lane of its wave; the frame's records

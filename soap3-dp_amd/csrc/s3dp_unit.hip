@@ -24,7 +24,7 @@
 //     them.  A unit of ten thousand trips becomes a few hundred trips of a whole wave; the order of the records does not change;
 //   * and since round 5: FAST TRIPS -- a full trip of the state machine is followed by up to seven trips that only step (the pass was bound by vector
 //     issue, two thirds of it the rare paths); GIANTS -- a lane long on its unit gives frames away before the queue is empty; units that verify no
-//     candidates themselves (the kernel is compiled without that machinery when in.ceGiveUp is 0: template parameter CEIN).
+//     candidates themselves (every small range inside a check window is a TASK record for ceKernel).
 //
 // Results are bit-identical to the CPU path: BGS-HostAlgnmtAlgo2.cpp:933-1071
 // (order), :86-169 (check-and-extend), DV-Kernel.cu:437-955 (what the reference's own kernels do per step).
@@ -41,7 +41,7 @@ namespace s3 {
 using namespace v2;
 
 namespace unit {
-enum : uint32_t { U_IDLE = 0, U_STEP = 1, U_LOAD = 2, U_ADOPT = 3, U_POPWAIT = 4, U_CE_SA = 5, U_CE_TEXT = 6, U_RESUME = 7, U_DONE = 8 };
+enum : uint32_t { U_IDLE = 0, U_STEP = 1, U_LOAD = 2, U_ADOPT = 3, U_POPWAIT = 4, U_RESUME = 7, U_DONE = 8 };
 
 }  // namespace unit
 
@@ -50,8 +50,9 @@ using namespace unit;
 // COUNT: with the statistics of s3_batch_enable_counters (rank queries, trips, longest unit ...): ten more registers, measurement runs only
 // (four waves per SIMD = 128 registers.  Five -- 96 registers, 29 dwords of the lane state spilled, 154 KB of LDS per CU -- was tried in round 5:
 //  the unit passes of a ladder 149 -> 187 ms, profiles/README_r05.md)
-// CEIN: units may verify candidates themselves (in.ceGiveUp > 0; the default since the fast trips is 0: the launch takes the kernel without that machinery)
-template <bool UNIFORM, bool COUNT, bool CEIN>
+// (Until round 5 a unit verified its first check-and-extend candidates itself -- two dependent lines per candidate inside a lane that moves in full trips only;
+//  since the fast trips every candidate goes to ceKernel, and round 6 took the machinery out: S3DP_CE_GIVE_UP / S3DP_CE_INLINE_MAX are gone.)
+template <bool UNIFORM, bool COUNT>
 __global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_UNIT_WAVES_PER_SIMD)
 unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 {
@@ -77,13 +78,12 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     const uint32_t U = in.unitsPerItem;
     const uint32_t nSlots = nListed * groups * U;                           // (< 2^31: s3dp_api.hip)
     uint4 *stk = out.unitStack + (size_t)(blockIdx.x * (S3_SEARCH_BLOCK / 64u) + wv) * S3_UNIT_STACK * 64u;     // frame d of lane k: stk[(d % S3_UNIT_STACK) * 64 + k]
-    const uint32_t giveUp = in.ceGiveUp < 0xFFFFu ? in.ceGiveUp : 0xFFFFu, inlineMax = in.ceInlineMax < 0xFFFFu ? in.ceInlineMax : 0xFFFFu;
 
     const unsigned long long tWave0 = COUNT ? wall_clock64() : 0ULL;        // (COUNT) the wave's own duration in 10 ns ticks, summed over the grid: how much of a launch is its tail
     // ---- statistics (COUNT) ----
-    uint32_t nRank = 0, nSaL = 0, nCeL = 0, nCutSkip = 0, nCutMid = 0, unitTrips = 0, maxUnitTrips = 0, nAdopt = 0;
+    uint32_t nRank = 0, nCutSkip = 0, nCutMid = 0, unitTrips = 0, maxUnitTrips = 0, nAdopt = 0;
     unsigned long long laneTrips = 0, waveTrips = 0;
-    uint32_t dCeWave = 0, dCeLane = 0, dStepLane = 0, dBookWave = 0, dPopLane = 0, dFastWave = 0, dFastLane = 0, dParked = 0;     // ... fast trips, their stepping lanes; lanes parked (U_RESUME / U_POPWAIT) at a full trip     // (COUNT) how often the rare paths run, and for how many lanes
+    uint32_t dStepLane = 0, dBookWave = 0, dPopLane = 0, dFastWave = 0, dFastLane = 0, dParked = 0;     // ... fast trips, their stepping lanes; lanes parked (U_RESUME / U_POPWAIT) at a full trip     // (COUNT) how often the rare paths run, and for how many lanes
 
     // ---- per-lane state ----
     uint32_t state = U_IDLE;
@@ -109,14 +109,8 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     bool tosValid = false;                                                  // ... when this is set
     uint32_t aux = 0;                                                       // U_LOAD: the read's number in readsT; U_ADOPT: where the frame lies
     uint32_t loadOff = 0;
-    // check-and-extend by the lane: candidates [ceL + ceK, ceL + ceN) of the suffix array are left; of the current one: suffix-array value, text position
-    // of the read's first character, and (packed) the model step being compared, characters of it done, mismatches so far
-    uint32_t ceL = 0, ceSa = 0, ceRp = 0;
-    uint32_t ceNK = 0;                                                      // ceN | ceK << 8
-    uint32_t ceWhere = 0;                                                   // ceT | ceII << 3 | ceIns << 14 | ceAcc << 17
-    uint32_t ceProg = 0;                                                    // ceOff | ceMm << 16
-    uint32_t ceHist = 0;                                                    // rejected candidates in a row | occurrences verified by the lane << 16
     uint32_t pendMeta = 0, pendA = 0, pendB = 0;
+    uint32_t pendC = 0;                                                     // of a task written in a forward step: the first suffix of its range in the REVERSE index (SearchOut::recAux)
     uint32_t countPending = 0;
     uint32_t age = 0;                                                       // full trips the lane has spent on its unit (a GIANT: more than in.giantAge)
     // ---- wave-uniform ----
@@ -134,17 +128,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         if constexpr (UNIFORM) return (const uint32_t *)&((const S3Model *)shmem)->cs[casIdx].st[k];
         else return (const uint32_t *)&in.models[Li].cs[casIdx].st[k];
     };
-    auto stepAt = [&](int k) -> S3Step {
-        if constexpr (UNIFORM) return ((const S3Model *)shmem)->cs[casIdx].st[k];
-        else return in.models[Li].cs[casIdx].st[k];
-    };
-    auto oword = [&](uint32_t w) -> uint32_t { return w < wl ? ro[w * 64u + lane] : 0u; };
     auto readChar = [&](int pos) -> uint32_t { return (ro[((uint32_t)pos >> 4) * 64u + lane] >> (30u - 2u * ((uint32_t)pos & 15u))) & 3u; };
-    auto readWindow = [&](int p0) -> uint32_t {
-        const uint32_t w = (uint32_t)p0 >> 4, sh = ((uint32_t)p0 & 15u) * 2u;
-        const uint32_t a = oword(w), b2 = oword(w + 1u);
-        return sh ? (a << sh) | (b2 >> (32u - sh)) : a;
-    };
     auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
         pendMeta = 0x80000000u | seq | (kind << 24) | (nmis << 25);
         pendA = a; pendB = b;
@@ -195,11 +179,11 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 const int pos = sc.start() + sc.dir() * i;
                 if ((aR - aL) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd()) {
                     if (groupEnd != 0u && s == (int)sUnit() && ins == 0) { needPop = true; continue; }      // in the trunk's footsteps: the trunk wrote this task and ended here
-                    if (CEIN && (ceHist & 0xFFFFu) < giveUp) { ceL = fwdL(); ceNK = aR - aL + 1u; state = U_CE_SA; return; }      // the lane verifies them itself
                     if (pendMeta >> 31) { state = U_RESUME; return; }
                     pendMeta = 0x80000000u | seq | S3_REC_TASK;
                     pendA = fwdL();
                     pendB = (aR - aL) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
+                    pendC = aL;                                              // (forward step: the active range is the reverse index's)
                     seq += aR - aL + 1u;
                     needPop = true;
                     continue;
@@ -320,7 +304,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 groupEnd = p + 1u != U ? (p + 1u) * in.unitGroup : 0u;
                 i = (int)(p * in.unitGroup);                                                 // (the unit without a mismatch in this step: behind the step's last position, set when the step is known)
                 ins = 0; occ = 0; seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
-                ceHist = 0; countPending = 0; age = 0;
+                countPending = 0; age = 0;
                 if constexpr (COUNT) unitTrips = 0;
                 loadOff = 0;
                 state = U_LOAD;
@@ -397,7 +381,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                     for (uint32_t w = 0; w < wl; w++) ro[w * 64u + lane] = ro[w * 64u + giver];
                     groupEnd = m1.z;
                     seq = 0; total = 0; sp = 0; sb = 0; tosValid = false;
-                    ceHist = 0; countPending = 0; age = 0;
+                    countPending = 0; age = 0;
                     if constexpr (COUNT) { unitTrips = 0; nAdopt++; }
                     state = U_ADOPT;
                 }
@@ -408,7 +392,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 
         // ---------- what does this lane need?  Addresses only: every lane issues the same loads, back to back, with no branch between them (a load
         // inside a branch makes the compiler wait for it at the join); a lane that needs nothing reads a cache-hot dummy ----------
-        uint32_t iL = 0, iR = 0, textLine = 0;
+        uint32_t iL = 0, iR = 0;
         bool needB = false;
         int dir = 0;
         const uint4 *dummy16 = (const uint4 *)ix.pac;
@@ -416,17 +400,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint4 *aP0 = dummy16, *aP1 = dummy16, *aPT = dummy16;
         const uint32_t *aD0 = ix.pac, *aCut = ix.pac;
         if (state == U_STEP) stepAsk(iL, iR, needB, dir, ownLine, aP0, aP1, aD0);
-        else if (CEIN && state == U_CE_TEXT) {
-            const int ceT = (int)(ceWhere & 7u), ceII = (int)((ceWhere >> 3) & 0x7FFu);
-            const S3Step st = stepAt(ceT);
-            const int pos = st.start + st.dir * ceII;
-            const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end);
-            textLine = (ceRp + left + (ceProg & 0xFFFFu)) >> 8;
-            ownLine = (const uint4 *)ix.pac + (size_t)textLine * 4u;
-            if ((ceNK >> 8) + 1u < (ceNK & 0xFFu)) aD0 = ix.sa + ceL + (ceNK >> 8) + 1u;     // the next candidate's suffix-array entry rides along
-        } else if (CEIN && state == U_CE_SA) {
-            aD0 = ix.sa + ceL + (ceNK >> 8);
-        } else if (state == U_LOAD) {
+        else if (state == U_LOAD) {        } else if (state == U_LOAD) {
             const uint4 *src = (const uint4 *)(in.readsT + (size_t)aux * 2u * wpq + (size_t)(subN & 1u) * wpq + loadOff);
             aP0 = src;
             if (wpq - loadOff > 4u) aP1 = src + 1;
@@ -434,10 +408,9 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         } else if (state == U_ADOPT) {
             aP0 = stk + aux;
         }
-        const bool inCe = CEIN && (state == U_CE_SA || state == U_CE_TEXT);
-        const bool running = state == U_STEP || state == U_POPWAIT || inCe || state == U_RESUME;
+        const bool running = state == U_STEP || state == U_POPWAIT || state == U_RESUME;
         const bool wantTos = running && !tosValid && sp > sb;
-        const bool wantCut = wantTos || inCe || state == U_ADOPT;
+        const bool wantCut = wantTos || state == U_ADOPT;
         if (wantTos) aPT = stk + ((sp - 1u) & (S3_UNIT_STACK - 1u)) * 64u + lane;
         if (wantCut) aCut = out.readCut + listed;
         // ---------- issue: the cooperative lines (4 adjacent lanes fetch the 4 x 16 B of one owner's line: the owner's address travels by ds_bpermute,
@@ -543,95 +516,10 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 else { i = sc.len(); doSettle = true; needPop = false; }         // the unit without a mismatch in this step: behind its last position
             }
         }
-        // ---------- check-and-extend by the lane itself (BGS-HostAlgnmtAlgo2.cpp:86-169: per candidate its suffix-array entry, then the text under the rest of the model, one 64-byte line = 256 characters per trip, compared as ceKernel compares) ----------
         if constexpr (COUNT) {
-            const unsigned long long cm = __ballot(CEIN && (state == U_CE_SA || state == U_CE_TEXT));
-            dCeWave += cm ? 1u : 0u;
-            dCeLane += (CEIN && (state == U_CE_SA || state == U_CE_TEXT)) ? 1u : 0u;
             dStepLane += state == U_STEP ? 1u : 0u;
             dPopLane += (doSettle && needPop) || state == U_POPWAIT ? 1u : 0u;
             dParked += state == U_RESUME || state == U_POPWAIT ? 1u : 0u;
-        }
-        if (CEIN && (state == U_CE_SA || state == U_CE_TEXT)) {
-            bool textHere = state == U_CE_TEXT;                               // the line of this trip belongs to the current candidate
-            bool fresh = !textHere;                                           // the current candidate has not been set up yet
-            const uint32_t ceN = ceNK & 0xFFu;
-            uint32_t ceK = ceNK >> 8;
-            const bool haveNext = textHere && ceK + 1u < ceN;                 // ... and the next candidate's entry came along
-            const uint32_t lineHere = textLine;
-            int ceT = (int)(ceWhere & 7u), ceII = (int)((ceWhere >> 3) & 0x7FFu), ceIns = (int)((ceWhere >> 14) & 7u), ceAcc = (int)((ceWhere >> 17) & 0x7Fu);
-            int ceOff = (int)(ceProg & 0xFFFFu), ceMm = (int)(ceProg >> 16);
-            uint32_t ceMiss = ceHist & 0xFFFFu, ceTaken = ceHist >> 16;
-            if (fresh) ceSa = saVal;
-            for (;;) {
-                int verdict = 0;                                              // 1: accepted, -1: rejected, 0: needs a text line
-                if (fresh) {
-                    ceRp = ceSa - (uint32_t)(sc.dir() > 0 ? sc.lm0() : sc.lm0() - i);     // 32-bit wrap, as the reference
-                    ceT = s; ceII = i; ceIns = ins; ceAcc = occ; ceOff = 0; ceMm = 0;
-                    if constexpr (COUNT) nSaL++;
-                    fresh = false;
-                }
-                for (;;) {
-                    const S3Step st = stepAt(ceT);
-                    const int pos = st.start + st.dir * ceII;
-                    const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end), right = (uint32_t)(pos < st.end ? st.end : pos);
-                    const uint32_t len = right - left + 1u;
-                    if (ceOff == 0 && ceRp + left > ix.n) { verdict = -1; break; }          // BGS-HostAlgnmtAlgo2.cpp:122-125
-                    const uint32_t tpos = ceRp + left + (uint32_t)ceOff;
-                    if (!textHere || (tpos >> 8) != lineHere) break;          // that line is not here: next trip
-                    uint32_t todo = len - (uint32_t)ceOff;
-                    const uint32_t inLine = 256u - (tpos & 255u);
-                    if (todo > inLine) todo = inLine;
-                    for (uint32_t o = 0; o < todo; o += 16u) {
-                        const uint32_t c = todo - o > 16u ? 16u : todo - o;
-                        const uint32_t tp = (tpos + o) & 255u, w = tp >> 4, sh = (tp & 15u) * 2u;
-                        const uint32_t t0 = myStage32[w], t1 = w + 1u < 16u ? myStage32[w + 1u] : 0u;
-                        const uint32_t a_ = sh ? (t0 << sh) | (t1 >> (32u - sh)) : t0;
-                        uint32_t x = a_ ^ readWindow((int)(left + (uint32_t)ceOff + o));
-                        x = (x | (x >> 1)) & 0x55555555u;
-                        if (c < 16u) x &= ~0u << (32u - 2u * c);
-                        ceMm += __popc(x);
-                    }
-                    if constexpr (COUNT) nCeL += (todo + 31u) >> 5;
-                    ceOff += (int)todo;
-                    if ((uint32_t)ceOff < len) break;                          // the rest of the step lies in the next line
-                    const int tot = ceMm + ceIns;
-                    if (tot < st.minErr || tot > st.maxErr) { verdict = -1; break; }
-                    ceAcc += tot; ceT++; ceII = 0; ceIns = 0; ceOff = 0; ceMm = 0;
-                    if (ceT >= nSteps) { verdict = 1; break; }
-                }
-                if (verdict == 0) { state = U_CE_TEXT; break; }
-                if (verdict > 0) {
-                    // an occurrence: written under the unit's next sequence number (rejected candidates reserve nothing here)
-                    pendMeta = 0x80000000u | seq | (1u << 24) | ((uint32_t)ceAcc << 25);
-                    pendA = ceRp; pendB = ceRp;
-                    seq++; total++;
-                    countPending++;
-                    // (a unit that has verified in.ceInlineMax occurrences itself has shown what it is worth to its read's cut: from there on its
-                    //  candidates go to ceKernel -- a thousand of them one after the other is what a launch would wait for)
-                    if (ceTaken < 0xFFFFu) ceTaken++;
-                    ceMiss = ceTaken >= inlineMax ? giveUp : 0u;
-                } else if (ceMiss < 0xFFFFu) ceMiss++;
-                ceK++;
-                if (ceK >= ceN) { doSettle = true; needPop = true; break; }    // all candidates seen: the search goes on (settle sets the state)
-                if (ceMiss >= giveUp && !(pendMeta >> 31)) {
-                    // the rest of this range goes to ceKernel as a task (its candidates reserve their sequence numbers, as in the first pass)
-                    pendMeta = 0x80000000u | seq | S3_REC_TASK;
-                    pendA = ceL + ceK;
-                    pendB = (ceN - ceK - 1u) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
-                    seq += ceN - ceK;
-                    doSettle = true; needPop = true;
-                    break;
-                }
-                if (total >= in.maxOut) { state = U_DONE; sp = sb; tosValid = false; break; }
-                if (textHere && haveNext) { ceSa = saVal; fresh = true; textHere = false; continue; }   // set the next one up now; its text comes with the next trip
-                state = U_CE_SA;
-                break;
-            }
-            ceNK = ceN | ceK << 8;
-            ceWhere = (uint32_t)ceT | (uint32_t)ceII << 3 | (uint32_t)ceIns << 14 | (uint32_t)ceAcc << 17;
-            ceProg = (uint32_t)ceOff | (uint32_t)ceMm << 16;
-            ceHist = ceMiss | ceTaken << 16;
         }
         if (doSettle) settle(needPop);
         // ---------- book the occurrences the unit holds for sure, where the other units of its read can see them: per item (itemAcc) and per position
@@ -671,7 +559,10 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 }
                 if (pendMeta >> 31) {
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(cntIdx | S3_REC_PASS2, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                    if (recCur + rk < recEnd) {
+                        out.recs[recCur + rk] = make_uint4(cntIdx | S3_REC_PASS2, pendMeta & 0x7FFFFFFFu, pendA, pendB);
+                        if (pendMeta & S3_REC_TASK) out.recAux[recCur + rk] = pendC;
+                    }
                     pendMeta = 0;
                 }
                 recCur += np;
@@ -745,16 +636,12 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     if constexpr (COUNT) {
         if (out.counters) {
             atomicAdd(&out.counters[0], (unsigned long long)nRank);
-            atomicAdd(&out.counters[2], (unsigned long long)nSaL);
-            atomicAdd(&out.counters[3], (unsigned long long)nCeL);
             atomicAdd(&out.counters[4], (unsigned long long)nCutSkip);
             atomicAdd(&out.counters[5], (unsigned long long)nCutMid);
             atomicAdd(&out.counters[6], laneTrips);
             atomicMax(&out.counters[7], (unsigned long long)maxUnitTrips);
             atomicAdd(&out.counters[8], (unsigned long long)nAdopt);
             if (lane == 0) atomicAdd(&out.counters[9], waveTrips);
-            if (lane == 0) atomicAdd(&out.counters[11], (unsigned long long)dCeWave);
-            atomicAdd(&out.counters[12], (unsigned long long)dCeLane);
             atomicAdd(&out.counters[13], (unsigned long long)dStepLane);
             if (lane == 0) atomicAdd(&out.counters[14], (unsigned long long)dBookWave);
             atomicAdd(&out.counters[15], (unsigned long long)dPopLane);
@@ -828,11 +715,10 @@ int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out,
     uint64_t blocks = ((uint64_t)in.nActive * (uint64_t)in.nCases * 2u * in.unitsPerItem + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
     const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + S3_UNIT_RDY_BYTES + in.wLds * 256u);
-    const bool count = out.counters != nullptr, cein = in.ceGiveUp != 0u;
+    const bool count = out.counters != nullptr;
     using Kern = void (*)(DevIndex, SearchIn, SearchOut);
-    static const Kern kerns[8] = {unitKernel<false, false, false>, unitKernel<false, false, true>, unitKernel<false, true, false>, unitKernel<false, true, true>,
-                                  unitKernel<true, false, false>,  unitKernel<true, false, true>,  unitKernel<true, true, false>,  unitKernel<true, true, true>};
-    const Kern fn = kerns[(in.uniformLen ? 4 : 0) + (count ? 2 : 0) + (cein ? 1 : 0)];
+    static const Kern kerns[4] = {unitKernel<false, false>, unitKernel<false, true>, unitKernel<true, false>, unitKernel<true, true>};
+    const Kern fn = kerns[(in.uniformLen ? 2 : 0) + (count ? 1 : 0)];
     if (lds > 48u * 1024u) {
         const hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

@@ -46,7 +46,7 @@ class KernelStats(C.Structure):
                 ("listedRankQueries", C.c_uint64), ("accepted", C.c_uint64), ("ceRejected", C.c_uint64 * 18)]
 
 
-EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_index_lookup_chars", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
+EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_index_lookup_chars", "s3_index_flank_tables", "s3_index_fetch_flank", "s3_batch_create", "s3_batch_free", "s3_batch_upload",
            "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_batch_fetch_pair_origins", "s3_batch_route_pairs", "s3_batch_no_pair_result", "s3_batch_fetch_routing", "s3_batch_fetch_kept", "s3_dp_new_default_routed", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_dp_single_end", "s3_dp_deep", "s3_dp_new_default", "s3_batch_fetch_alignments", "s3_batch_sync", "s3_batch_last_ce_timing",
            "s3_batch_last_timing", "s3_batch_set_grid", "s3_batch_kernel_stats", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_device_host_node", "s3_last_error", "s3_version", "s3_probe_gather", "s3_probe_copy", "s3_dp_totals",
@@ -316,6 +316,20 @@ class Index:
 
     def device_bytes(self):
         return lib().s3_index_device_bytes(self.h)
+
+    def flank_tables(self):
+        """0, 1 (forward index only) or 2: the flank tables of check-and-extend the upload found room for"""
+        f = lib().s3_index_flank_tables
+        f.argtypes = [C.c_void_p]
+        return int(f(self.h))
+
+    def fetch_flank(self, table, first, count):
+        """entries [first, first + count) of flank table 0 (forward index order) / 1 (reverse index order): uint32 [count, 4] = position, 3 x 16 characters"""
+        out = np.zeros((count, 4), dtype=np.uint32)
+        f = lib().s3_index_fetch_flank
+        f.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p]
+        _chk(f(self.h, int(table), int(first), int(count), out.ctypes.data))
+        return out
 
     def close(self):
         if self.h:

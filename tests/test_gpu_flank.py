@@ -1,0 +1,78 @@
+"""gpu: the flank tables of check-and-extend (csrc/s3dp_flank.hip) against a suffix sort -- flankBack[k] = {SA[k], the 48 characters before SA[k], nearest first},
+flankFwd[k'] = {E, the 48 characters from E on} in the order of the REVERSE index, which the upload finds by walking LF steps of the reverse index along the text
+from anchors.  The expected tables come from numpy: the forward suffix array is the index file's, the reverse index's order from sorting the reversed text."""
+import numpy as np
+import pytest
+
+import s3dp
+from conftest import host_index
+
+pytestmark = pytest.mark.gpu
+
+
+def suffix_array(t):
+    """suffix array of t (uint8 codes 0..3) with the empty suffix first, by prefix doubling"""
+    n = len(t)
+    rank = np.concatenate([t.astype(np.int64) + 1, [0]])
+    sa = np.argsort(rank, kind="stable")
+    h = 1
+    while True:
+        r2 = np.concatenate([rank[h:], np.zeros(h, dtype=np.int64)]) if h <= n else np.zeros(n + 1, dtype=np.int64)
+        key = rank * (n + 2) + r2
+        sa = np.argsort(key, kind="stable")
+        ks = key[sa]
+        newrank = np.zeros(n + 1, dtype=np.int64)
+        newrank[sa] = np.concatenate([[0], np.cumsum(ks[1:] != ks[:-1])])
+        rank = newrank
+        if rank.max() == n:
+            return sa
+        h *= 2
+
+
+def windows(t, starts, step):
+    """[len(starts), 3] uint32: 48 characters from starts in direction step (+1 / -1), 16 per word MSB first; outside the text: 0"""
+    n = len(t)
+    out = np.zeros((len(starts), 3), dtype=np.uint32)
+    for j in range(48):
+        p = starts + step * j
+        ok = (p >= 0) & (p < n)
+        c = np.where(ok, t[np.clip(p, 0, n - 1)], 0).astype(np.uint32)
+        out[:, j // 16] |= c << np.uint32(30 - 2 * (j % 16))
+    return out
+
+
+@pytest.mark.parametrize("name", ["g1", "g6"])
+def test_flank_tables_equal_a_suffix_sort(name):
+    hi = host_index(name)
+    ix = s3dp.Index(hi)
+    assert ix.flank_tables() == 2
+    t = np.asarray(hi.codes, dtype=np.uint8)
+    n = len(t)
+    assert hi.sa_interval == 1 and n == hi.n
+    sa = np.asarray(hi.sa, dtype=np.int64)[: n + 1]
+    back = ix.fetch_flank(0, 0, n + 1)
+    assert (back[:, 0].astype(np.int64) == sa).all()
+    assert (back[1:, 1:] == windows(t, sa[1:] - 1, -1)).all() and (back[0, 1:] == 0).all()
+    # the reverse index orders the occurrences by what lies to their LEFT, read leftwards: entry k' <-> the suffix of the reversed text at rsa[k'],
+    # which ends (in the text) at n - 1 - rsa[k']; E = the position behind it
+    rsa = suffix_array(t[::-1])
+    E = n - rsa
+    fwd = ix.fetch_flank(1, 0, n + 1)
+    assert (fwd[1:, 0].astype(np.int64) == E[1:]).all()
+    assert (fwd[1:, 1:] == windows(t, E[1:], +1)).all()
+    assert (fwd[0] == 0).all()                                                   # the empty suffix: never a candidate
+    ix.close()
+
+
+def test_the_switch_leaves_tables_out(monkeypatch):
+    hi = host_index("g1")
+    for want in (0, 1):
+        monkeypatch.setenv("S3DP_FLANK", str(want))
+        ix = s3dp.Index(hi)
+        assert ix.flank_tables() == want
+        ix.close()
+    monkeypatch.setenv("S3DP_FLANK", "2")
+    monkeypatch.setenv("S3DP_FLANK_RESERVE_GB", "100000")                         # more than any device has: no room for a table
+    ix = s3dp.Index(hi)
+    assert ix.flank_tables() == 0
+    ix.close()

@@ -29,8 +29,8 @@ def test_search_bit_exact_vs_reference_dump_and_oracle(monkeypatch, name, maxlen
     read with more than two candidates goes that way; 2i: the same with whole items as units (S3DP_UNITS=0).  The records must not depend on it."""
     monkeypatch.setenv("S3DP_HEAVY", heavy[0])
     monkeypatch.setenv("S3DP_UNITS", "0" if heavy.endswith("i") else "1")
-    if heavy.endswith("g"):                                 # units never verify candidates themselves / always do
-        monkeypatch.setenv("S3DP_CE_GIVE_UP", "0")
+    if heavy.endswith("g"):                                 # no flank tables: every candidate of ceKernel goes through the suffix array and the text
+        monkeypatch.setenv("S3DP_FLANK", "0")
     if heavy.endswith("p"):                                 # one first-mismatch position per unit (until round 5; the default: groups of two for the single-end ladders, one position for pairs)
         monkeypatch.setenv("S3DP_UNIT_GROUP", "1")
     reads = golden_reads(name)
@@ -68,15 +68,15 @@ KNOBS = [
     {"S3DP_EARLY_CE": "0"},                                  # the exact lookup step is walked to its end, as the CPU path walks it
     {"S3DP_EARLY_CE": "4", "S3DP_EARLY_MIN": "17"},
     {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8"},             # nearly every read is listed by its rank queries
-    {"S3DP_HEAVY": "2", "S3DP_CE_INLINE_MAX": "1"},          # units hand their candidates to ceKernel after the first they verified
-    {"S3DP_HEAVY": "2", "S3DP_CE_INLINE_MAX": "1000000", "S3DP_CE_GIVE_UP": "1000000"},
+    {"S3DP_HEAVY": "2", "S3DP_FLANK": "1"},                  # flank table of the forward index only: tasks of forward steps take the suffix array and the text
+    {"S3DP_HEAVY": "0", "S3DP_FLANK": "0", "S3DP_EARLY_CE": "0"},
     {"S3DP_HEAVY": "2", "S3DP_UNIT_NODES": "0"},             # no adoption of frames: every unit is searched by one lane
     {"S3DP_HEAVY": "2", "S3DP_UNIT_NODES": "300"},           # the counters of adopted frames run out on the way
     {"S3DP_HEAVY": "2", "S3DP_BLOCKS_PER_CU": "1", "S3DP_CE_BLOCKS_PER_CU": "1"},
     # round 5: every trip that leaves a stepping lane is followed by trips that only step (the fixtures never gather the 32 stepping lanes of the default)
     {"S3DP_HEAVY": "2", "S3DP_FAST_MIN": "1", "S3DP_FAST_TRIPS": "3", "S3DP_FIRST_FAST_MIN": "1", "S3DP_FIRST_FAST_TRIPS": "3"},
-    {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8", "S3DP_FAST_MIN": "2", "S3DP_FAST_TRIPS": "15", "S3DP_FIRST_FAST_MIN": "2", "S3DP_FIRST_FAST_TRIPS": "15", "S3DP_CE_GIVE_UP": "2"},
-    {"S3DP_HEAVY": "2", "S3DP_FAST_TRIPS": "0", "S3DP_FIRST_FAST_TRIPS": "0", "S3DP_CE_GIVE_UP": "2"},     # none at all, units verify candidates (rounds 3-4)
+    {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8", "S3DP_FAST_MIN": "2", "S3DP_FAST_TRIPS": "15", "S3DP_FIRST_FAST_MIN": "2", "S3DP_FIRST_FAST_TRIPS": "15"},
+    {"S3DP_HEAVY": "2", "S3DP_FAST_TRIPS": "0", "S3DP_FIRST_FAST_TRIPS": "0"},     # none at all (rounds 3-4)
     # every lane with a frame to give is a giant after its first full trip: frames are adopted while the queue still has work
     {"S3DP_HEAVY": "2", "S3DP_GIANT_AGE": "1", "S3DP_GIANT_IDLE": "1", "S3DP_FAST_MIN": "4"},
     {"S3DP_HEAVY": "2", "S3DP_GIANT_AGE": "0", "S3DP_TAIL_AGE": "2"},
@@ -182,7 +182,7 @@ def test_max_output_truncation(monkeypatch, cap, heavy):
     monkeypatch.setenv("S3DP_HEAVY", heavy[0])
     monkeypatch.setenv("S3DP_UNITS", "0" if heavy.endswith("i") else "1")
     if heavy.endswith("g"):
-        monkeypatch.setenv("S3DP_CE_GIVE_UP", "1000000")
+        monkeypatch.setenv("S3DP_FLANK", "0")
     name, maxlen, mm = "g2", 120, 2
     reads = golden_reads(name)
     q, lens, wpq = s3dp.pack_reads(reads, maxlen)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from rocprofv3 --pmc FETCH_SIZE counter files of `bench.py --steps 1 --warmup 0` runs (one counted ladder + one timed
-ladder: the second half of every search kernel's dispatches is the timed step).  FETCH_SIZE comes in kilobytes (MI355X_MICROARCH.md); 64-byte requests.
+"""profiles/pmc_traffic.json from rocprofv3 --pmc FETCH_SIZE counter files of `bench.py --steps 1 --warmup 0` runs (counted ladders, then one timed
+ladder: the LAST four dispatches of every role -- one per phase of the ladder -- are the timed step).  FETCH_SIZE comes in kilobytes (MI355X_MICROARCH.md); 64-byte requests.
     tools/make_pmc_traffic.py <commit> <repeat_frac>=<counter_collection.csv> ...   > profiles/pmc_traffic.json"""
 import collections
 import csv
@@ -8,13 +8,14 @@ import json
 import sys
 
 KERNELS = ("firstKernel", "unitKernel", "ceKernel")
+PHASES = 4                                   # search passes of the bench ladder (mismatch budgets 1 .. 4)
 
 
 def role_of(name):
     """first / trunk (the two roles of s3::firstKernel: its last template argument) / unit / ce"""
     if "unitKernel" in name:
         return "unit"
-    if "s3::ceKernel(" in name:
+    if "s3::ceKernel" in name:
         return "ce"
     if "firstKernel" in name:
         args = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",") if "<" in name else []
@@ -36,15 +37,13 @@ def fetch_of_last_ladder(path):
         roles.setdefault(ro, collections.OrderedDict()).setdefault(r["Dispatch_Id"], 0.0)
         roles[ro][r["Dispatch_Id"]] += float(r["Counter_Value"])
     out = {}
-    for k, d in per.items():
-        vals = list(d.values())
-        half = vals[len(vals) // 2:]
-        out[k] = {"launches": len(half), "bytes": sum(half) * 1024.0}
     by_role = {}
     for k, d in roles.items():
-        vals = list(d.values())
-        half = vals[len(vals) // 2:]
-        by_role[k] = {"launches": len(half), "bytes": sum(half) * 1024.0}
+        last = list(d.values())[-PHASES:]
+        by_role[k] = {"launches": len(last), "bytes": sum(last) * 1024.0}
+    for k in per:
+        rs = [r for r in by_role if (r in ("first", "trunk")) == (k == "firstKernel") and (r == "unit") == (k == "unitKernel") and (r == "ce") == (k == "ceKernel")]
+        out[k] = {"launches": sum(by_role[r]["launches"] for r in rs), "bytes": sum(by_role[r]["bytes"] for r in rs)}
     return out, by_role
 
 
