@@ -85,12 +85,35 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         const uint32_t total = (uint32_t)__shfl((int)incl, 63);
         if (total == 0) continue;
         __builtin_amdgcn_wave_barrier();
-        sRec[wv][lane] = make_uint4(rec.x, rec.y, rec.z, (rec.w & 0xFFFFFF00u) | (item % groups));     // (low byte: the (case, strand) of the item)
         sStart[wv][lane] = incl - size;
         if (lane == 63u) sStart[wv][64] = total;
         const uint32_t myRead = task ? (in.active ? in.active[slotOf] : slotOf) : 0u;
         sRead[wv][lane] = myRead;
         sAux[wv][lane] = task && idx < nRec ? out.recAux[idx] : 0u;
+        // An item whose lookup range may hold a PADDED table element (DevIndex::padBi: 13-mers the file format's tables count for text positions next to the
+        // text's ends) has a forward and a reverse range that need not hold the same occurrences -- BWTExactModelForward_Lookup2 (BGS-HostAlgnmtAlgo2.cpp:
+        // 349-356) makes their sizes equal by moving one end.  The CPU path verifies the FORWARD range's suffixes; such a task does the same here (bit 7 of
+        // the task's low byte: its candidates are not looked up in the reverse index's table).  Computed as the first pass computes `padded` (s3dp_first.hip).
+        uint32_t paddedBit = 0u;
+        if (task && ix.flankFwd) {
+            const uint32_t sub = item % groups;
+            const int Lr = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[myRead];
+            const S3Step l0 = in.models[Lr].cs[sub >> 1].st[0];
+            if (l0.type != S3_T_BACK_LOOKUP) {
+                const int k0 = ix.ltSize;
+                bool padded = l0.len < k0;
+                if (!padded) {
+                    const uint32_t *src = in.readsT + (size_t)myRead * 2u * S + (size_t)(sub & 1u) * S;
+                    const uint32_t w = (uint32_t)l0.start >> 4, sh = ((uint32_t)l0.start & 15u) * 2u;
+                    const uint32_t a = w < S ? src[w] : 0u, b2 = w + 1u < S ? src[w + 1u] : 0u;
+                    const uint32_t r13 = pairRev(sh ? (a << sh) | (b2 >> (32u - sh)) : a) & ((1u << (2 * k0)) - 1u);
+#pragma unroll
+                    for (int j = 0; j < 24; j++) padded |= r13 == ix.padBi[j];
+                }
+                paddedBit = padded ? 0x80u : 0u;
+            }
+        }
+        sRec[wv][lane] = make_uint4(rec.x, rec.y, rec.z, (rec.w & 0xFFFFFF00u) | (item % groups) | paddedBit);     // (low byte: the (case, strand) of the item; bit 7: see above)
         if (staged && task) {
             const uint4 *src = (const uint4 *)(in.readsT + (size_t)myRead * 2u * S + (size_t)((item % groups) & 1u) * S);
             uint4 *dst = (uint4 *)(myRd + lane * S);
@@ -112,7 +135,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 }
                 const uint4 tr = sRec[wv][lo];
                 const uint32_t k = c - sStart[wv][lo];
-                const uint32_t meta = tr.w >> 8, sub = tr.w & 0xFFu;
+                const uint32_t meta = tr.w >> 8, sub = tr.w & 0x7Fu;
                 const int s0 = (int)(meta & 7u), i0 = (int)((meta >> 3) & 0x7FFu), ins0 = (int)((meta >> 14) & 7u), occ0 = (int)((meta >> 17) & 7u);
                 const uint32_t casIdx = sub >> 1, strand = sub & 1u, rIdx = sRead[wv][lo];
                 const bool early = (tr.y & S3_REC_EARLY) != 0;
@@ -126,7 +149,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 const S3Step st0 = cs.st[s0];
                 const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i0;
                 const bool fwdStep = st0.dir > 0;
-                const uint4 *tab = fwdStep ? ix.flankFwd : ix.flankBack;
+                const uint4 *tab = fwdStep ? ((tr.w & 0x80u) ? nullptr : ix.flankFwd) : ix.flankBack;
                 uint32_t sa = 0, kf = k;                                        // text position of the matched part's start; the candidate's place in the FORWARD range
                 bool flankRejected = false;
                 nSa++;
