@@ -400,7 +400,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint4 *aP0 = dummy16, *aP1 = dummy16, *aPT = dummy16;
         const uint32_t *aD0 = ix.pac, *aCut = ix.pac;
         if (state == U_STEP) stepAsk(iL, iR, needB, dir, ownLine, aP0, aP1, aD0);
-        else if (state == U_LOAD) {        } else if (state == U_LOAD) {
+        else if (state == U_LOAD) {
             const uint4 *src = (const uint4 *)(in.readsT + (size_t)aux * 2u * wpq + (size_t)(subN & 1u) * wpq + loadOff);
             aP0 = src;
             if (wpq - loadOff > 4u) aP1 = src + 1;
