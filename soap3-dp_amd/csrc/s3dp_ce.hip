@@ -24,24 +24,33 @@ using namespace v2;
 // ---- check-and-extend of the task records --------------------------------------------------------------------------------------------------
 // A wave takes 64 records at a time; the candidates of their tasks are numbered through (wave prefix sum of the task sizes, descriptors in LDS) and
 // dealt to the lanes 64 at a time -- one lane per CANDIDATE, whatever the sizes of the tasks (1 .. 256): a lane finds its task by bisection in the
-// prefix sums.  Accepted candidates are appended to the record stream with one atomic per wave and S3_V2_REC_BLOCK records.  Per candidate: SA
-// value, then per remaining model step the text against the oriented read, 16 characters at a time (XOR, fold, popcount), the step's error
-// window checked as in the stepping kernel (BGS-HostAlgnmtAlgo2.cpp:86-169).
+// prefix sums.  TWO PHASES since round 6:
+//   FILTER   every candidate: its flank record (one 16-byte load, no dependent second one) against the read's characters next to the matched part.  Nine in ten
+//            end here.  Survivors -- and the candidates of tasks no table serves -- go into a queue in LDS with all that the second phase needs (seven words),
+//            so that the queue outlives the batch of records it came from;
+//   VERIFY   whenever the queue holds 64 survivors (and once more at the end): suffix-array value (from the flank record; a forward task's survivor finds its
+//            place in the FORWARD range -- its sequence number -- among the task's suffix-array entries), then per remaining model step the text against the
+//            oriented read, 16 characters per XOR / fold / popcount, the step's error window checked as in the stepping kernel (BGS-HostAlgnmtAlgo2.cpp:86-169).
+//            Accepted candidates are appended to the record stream with one atomic per wave and S3_V2_REC_BLOCK records.
+// The first form of the round-6 kernel filtered and verified in one round of 64 candidates: a round then waited for its few survivors' two or three dependent
+// loads, and the kernel got SLOWER than without the tables (64.6 -> 82.8 ms per ladder); the verification has to run on full waves.
 // COUNT (counters enabled: measurement passes only): besides the tallies, WHERE the rejected candidates are decided.  Per rejected candidate: the direction
 // of the step it was handed over in (backward: the characters to its LEFT; forward: the characters behind the matched part), the mismatches it may still take
 // in that step (0 / 1 / 2 and more), and whether its flank record alone rejected it (without a table: whether the 32 characters next to the matched part
 // alone would have -- the measurement the tables were built on, 91.7 % on the benchmark) / the rest of that step decides / a later step does:
 // counters[S3_CE_HIST_BASE + (dir * 3 + budget) * 3 + where].
+#define S3_CE_QUEUE 128u                   // survivors a wave can hold between two verifications (fewer than 64 before a filter round, which adds at most 64)
+#define S3_CE_QWORDS 7u
 template <bool COUNT>
 __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, SearchOut out, const uint32_t *taskRange)
 {
     __shared__ uint4 sRec[4][64];                              // per wave: the task records of the batch ...
     __shared__ uint32_t sStart[4][65], sRead[4][64], sAux[4][64];   // ... the number of their first candidate; the read a task belongs to; its range's start in the reverse index
-    // ... and the tasks' reads, their searched strand, S words each (launchCheckExtend sizes it; not for reads of more than 256 bases): a candidate's read words
-    // come out of LDS.  What the kernel is bound by, next to the lines it fetches, is the number of lines its wave-instructions TOUCH -- the vector cache
-    // looks up one line per lane and clock --, and until round 5 a candidate asked for its window word by word: up to nine 4-byte loads from the text and
-    // nine from the read per model step, 27 load instructions per round of 64 candidates.  Now: the text in two or three aligned 16-byte pieces, the read
-    // from LDS -- 6 to 8.
+    // the survivors' queue: {record's item word, first sequence number | flags, first suffix of the forward range, state << 8 | (case, strand) | size - 1 << 28 ..., read, k, sa}
+    __shared__ uint32_t sQ[4][S3_CE_QWORDS][S3_CE_QUEUE];
+    // ... and the tasks' reads, their searched strand, S words each (launchCheckExtend sizes it; not for reads of more than 256 bases): the filter's read words
+    // come out of LDS (the verification reads them from memory: the line was fetched a moment ago).  What the kernel is bound by, next to the lines it fetches,
+    // is the number of lines its wave-instructions TOUCH -- the vector cache looks up one line per lane and clock --: the text comes in aligned 16-byte pieces.
     extern __shared__ __align__(16) uint32_t sRd[];
     const uint32_t firstRec = taskRange[0];                   // records [firstRec, nRec): what the stepping launches wrote since the last call
     uint32_t nRec = taskRange[1];
@@ -55,6 +64,172 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
     uint32_t nSa = 0, nCe = 0, nAcc = 0;
     uint32_t histW[S3_CE_HIST_SLOTS] = {};                    // (COUNT) wave-uniform
     uint32_t recCur = 0, recEnd = 0;                          // wave-uniform: reserved block [recCur, recEnd)
+    uint32_t qn = 0;                                          // wave-uniform: survivors in the queue
+
+    auto histAdd = [&](uint32_t histIdx) {
+        if constexpr (COUNT) {
+#pragma unroll
+            for (uint32_t k = 0; k < S3_CE_HIST_SLOTS; k++) histW[k] += (uint32_t)__popcll(__ballot(histIdx == k));
+        }
+    };
+    auto histOf = [&](const S3Step &st0, int ins0, uint32_t where) -> uint32_t {
+        const int left0 = st0.maxErr - ins0;
+        return ((st0.dir > 0 ? 1u : 0u) * 3u + (uint32_t)(left0 < 0 ? 0 : left0 > 2 ? 2 : left0)) * 3u + where;
+    };
+
+    // ---- VERIFY: the first `take` survivors of the queue, one per lane ----
+    auto verify = [&](uint32_t take) {
+        bool hit = false;
+        uint32_t rp = 0, recX = 0, seqK = 0, histIdx = 0xFFFFFFFFu;
+        int acc = 0;
+        if (lane < take) {
+            recX = sQ[wv][0][lane];
+            const uint32_t y = sQ[wv][1][lane], fl = sQ[wv][2][lane], w = sQ[wv][3][lane], rIdx = sQ[wv][4][lane], k = sQ[wv][5][lane];
+            uint32_t sa = sQ[wv][6][lane];
+            const uint32_t meta = (w >> 8) & 0xFFFFFu, sub = w & 0x7Fu, size = (w >> 28) + 1u + ((y >> 30) << 4);     // size - 1: four bits in w, two in y (<= 63: larger tasks never use a table)
+            const bool haveSa = (w & 0x80u) != 0u;                                    // the flank record gave the position
+            const int s0 = (int)(meta & 7u), i0 = (int)((meta >> 3) & 0x7FFu), ins0 = (int)((meta >> 14) & 7u), occ0 = (int)((meta >> 17) & 7u);
+            const uint32_t casIdx = sub >> 1, strand = sub & 1u;
+            const bool early = (y & S3_REC_EARLY) != 0;
+            const int Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
+            const int nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
+            const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
+            const S3Case &cs = in.models[Li].cs[casIdx];
+            const S3Step st0 = cs.st[s0];
+            const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i0;
+            acc = occ0;
+            uint32_t kf = k;                                                          // the candidate's place in the FORWARD range
+            hit = true;
+            if (!haveSa) sa = ix.sa[fl + k];
+            else if (st0.dir > 0 && size > 1u) {
+                // a forward task's candidates come in the reverse index's order: the survivor's place among the task's suffix-array entries (all requested at once)
+                kf = 0xFFFFFFFFu;
+                for (uint32_t j0 = 0; j0 < size; j0 += 8u) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; j++) v[j] = j0 + j < size ? ix.sa[fl + j0 + j] : 0u;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; j++) if (j0 + j < size && v[j] == sa) kf = j0 + j;
+                }
+                if (kf == 0xFFFFFFFFu) { atomicOr(out.flags, S3_FLAG_FLANK); hit = false; }
+            }
+            seqK = (y & 0xFFFFFFu) + kf;
+            rp = sa - (uint32_t)leftAlign;                                            // 32-bit wrap, as the reference
+            int t = s0, ii = i0, insCur = ins0;
+            bool rejBound = false;
+            while (hit && t < nSteps) {
+                const S3Step st = cs.st[t];
+                const int pos = st.start + st.dir * ii;
+                const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end), right = (uint32_t)(pos < st.end ? st.end : pos);
+                const uint32_t len = right - left + 1u;
+                if (early && t == s0) {
+                    // what is left of the exact lookup step: the walk this replaces matches real text only
+                    const long long rpS = (long long)sa - (long long)leftAlign;
+                    if (rpS + (long long)left < 0 || rpS + (long long)right >= (long long)ix.n) { hit = false; rejBound = true; break; }
+                }
+                if (rp + left > ix.n) { hit = false; rejBound = true; break; }        // BGS-HostAlgnmtAlgo2.cpp:122-125
+                const uint32_t tpos = rp + left;
+                int mm = 0;
+                // 64 characters at a time: all text and read words of the piece are requested before the first is used
+                for (uint32_t o0 = 0; o0 < len; o0 += 64u) {
+                    const uint32_t piece = len - o0 > 64u ? 64u : len - o0;
+                    const uint32_t tp0 = tpos + o0, tw0 = tp0 >> 4, tsh = (tp0 & 15u) * 2u;
+                    const uint32_t qp0 = left + o0, qw0 = qp0 >> 4, qsh = (qp0 & 15u) * 2u;
+                    uint32_t tw[5], qw[5];
+                    {
+                        // the text words tw0 .. tw0 + 4 out of the aligned 16-byte pieces that hold them (the text ends in a zero tail longer than a piece:
+                        // s3dp_api.hip), the first one at word `off` of the first piece
+                        const uint32_t jmax = (piece + 15u) >> 4, off = tw0 & 3u, lastW = off + jmax;     // lastW <= 7
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 *tc = (const u32x4 *)ix.pac + (tw0 >> 2);
+                        u32x4 c0 = tc[0], c1 = {0u, 0u, 0u, 0u};
+                        if (lastW >= 4u) c1 = tc[1];
+                        asm volatile("" : "+v"(c0), "+v"(c1));                    // (whole pieces: left alone the compiler asks for them word by word again)
+                        const uint32_t W[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                        for (uint32_t j = 0; j < 5; j++) tw[j] = off == 0u ? W[j] : off == 1u ? W[j + 1] : off == 2u ? W[j + 2] : W[j + 3];
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 5; j++) {
+                        const uint32_t need = j * 16u < piece + 16u;                  // word j + the one behind it for the shift
+                        if (!need) tw[j] = 0u;
+                        qw[j] = (need && qw0 + j < S) ? rd[qw0 + j] : 0u;
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        if (j * 16u < piece) {
+                            const uint32_t cch = piece - j * 16u > 16u ? 16u : piece - j * 16u;
+                            const uint32_t a_ = tsh ? (tw[j] << tsh) | (tw[j + 1] >> (32u - tsh)) : tw[j];
+                            const uint32_t b_ = qsh ? (qw[j] << qsh) | (qw[j + 1] >> (32u - qsh)) : qw[j];
+                            uint32_t x = a_ ^ b_;
+                            x = (x | (x >> 1)) & 0x55555555u;
+                            if (cch < 16u) x &= ~0u << (32u - 2u * cch);
+                            mm += __popc(x);
+                        }
+                    }
+                }
+                nCe += (len + 31u) >> 5;
+                const int tot = mm + insCur;
+                if (tot < st.minErr || tot > st.maxErr) { hit = false; break; }
+                acc += tot; t++; ii = 0; insCur = 0;
+            }
+            if constexpr (COUNT) {
+                if (!hit) {
+                    uint32_t where = 2u;                                         // a later step
+                    if (t == s0) {
+                        where = 1u;                                              // the rest of the first compared step (or the text's end)
+                        const int pos = st0.start + st0.dir * i0;
+                        const uint32_t left = (uint32_t)(pos < st0.end ? pos : st0.end), right = (uint32_t)(pos < st0.end ? st0.end : pos);
+                        const uint32_t len = right - left + 1u, nAdj = len < 32u ? len : 32u;
+                        // (a candidate no flank table served: would the 32 characters next to the matched part alone have decided?  VERDICT r5, item 5)
+                        if (!haveSa && !rejBound && (st0.dir > 0 ? rp + left + nAdj <= ix.n : rp + right < ix.n)) {
+                            int m2 = 0;
+                            for (uint32_t q = 0; q < nAdj; q++) {
+                                const uint32_t rpos = st0.dir > 0 ? left + q : right - q, tp = rp + rpos;
+                                const uint32_t tc = (ix.pac[tp >> 4] >> (30u - 2u * (tp & 15u))) & 3u, rc = (rd[rpos >> 4] >> (30u - 2u * (rpos & 15u))) & 3u;
+                                m2 += tc != rc ? 1 : 0;
+                            }
+                            if (m2 + ins0 > st0.maxErr) where = 0u;
+                        }
+                    }
+                    histIdx = histOf(st0, ins0, where);
+                }
+            }
+        }
+        histAdd(histIdx);
+        const unsigned long long hm = __ballot(hit);
+        if (hm) {
+            // accepted candidates go into a block of record slots the wave reserved with one atomic (as the stepping kernel does)
+            const uint32_t np = (uint32_t)__popcll(hm);
+            if (recCur + np > recEnd) {
+                for (uint32_t j = recCur + lane; j < recEnd; j += 64u) out.recs[j] = make_uint4(0xFFFFFFFFu, 0, 0, 0);   // unused tail
+                uint32_t b0 = 0;
+                if (lane == 0) b0 = atomicAdd(out.recCount, S3_V2_REC_BLOCK);
+                b0 = (uint32_t)__shfl((int)b0, 0);
+                recCur = b0; recEnd = b0 + S3_V2_REC_BLOCK;
+                if (recEnd > out.recCap || recEnd < b0) { recEnd = b0 < out.recCap ? out.recCap : b0; if (lane == 0) atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
+            }
+            if (hit) {
+                nAcc++;
+                const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(recX, seqK | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
+            }
+            recCur += np;
+            if (recCur > recEnd) recCur = recEnd;
+        }
+        // what is left of the queue moves to its front
+        __builtin_amdgcn_wave_barrier();
+        uint32_t mv[S3_CE_QWORDS];
+        const bool moves = take + lane < qn;
+#pragma unroll
+        for (uint32_t f = 0; f < S3_CE_QWORDS; f++) mv[f] = moves ? sQ[wv][f][take + lane] : 0u;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t f = 0; f < S3_CE_QWORDS; f++) if (moves) sQ[wv][f][lane] = mv[f];
+        qn -= take;
+        __builtin_amdgcn_wave_barrier();
+    };
+
     for (uint64_t base = (uint64_t)firstRec + (uint64_t)waveId * 64u; base < nRec; base += (uint64_t)nWaves * 64u) {
         const uint64_t idx = base + lane;
         uint4 rec = make_uint4(0xFFFFFFFFu, 0, 0, 0);
@@ -63,8 +238,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         uint32_t item = rec.x & ~S3_REC_PASS2;
         uint32_t slotOf = item / groups;
         if (task && (rec.x & S3_REC_PASS2)) {
-            // second-pass records (units that gave up verifying their candidates themselves) count in unit space:
-            // unit = heavy read * groups * U + item * U + position
+            // second-pass records count in unit space: unit = heavy read * groups * U + item * U + position
             const uint32_t U = in.unitsPerItem;
             if (out.dynCap && item >= out.dynBase) item = out.dynOwner[item - out.dynBase];      // counted by an adopted frame: the unit its chain started from
             const uint32_t unit = item - in.unitBase;
@@ -89,13 +263,14 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         if (lane == 63u) sStart[wv][64] = total;
         const uint32_t myRead = task ? (in.active ? in.active[slotOf] : slotOf) : 0u;
         sRead[wv][lane] = myRead;
-        sAux[wv][lane] = task && idx < nRec ? out.recAux[idx] : 0u;
+        sAux[wv][lane] = task ? out.recAux[idx] : 0u;
         // An item whose lookup range may hold a PADDED table element (DevIndex::padBi: 13-mers the file format's tables count for text positions next to the
         // text's ends) has a forward and a reverse range that need not hold the same occurrences -- BWTExactModelForward_Lookup2 (BGS-HostAlgnmtAlgo2.cpp:
         // 349-356) makes their sizes equal by moving one end.  The CPU path verifies the FORWARD range's suffixes; such a task does the same here (bit 7 of
         // the task's low byte: its candidates are not looked up in the reverse index's table).  Computed as the first pass computes `padded` (s3dp_first.hip).
-        uint32_t paddedBit = 0u;
-        if (task && ix.flankFwd) {
+        // So does a task of more than 64 candidates (the queue's size field; the models' thresholds stop at 32).
+        uint32_t noTableBit = size > 64u ? 0x80u : 0u;
+        if (task && ix.flankFwd && !noTableBit) {
             const uint32_t sub = item % groups;
             const int Lr = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[myRead];
             const S3Step l0 = in.models[Lr].cs[sub >> 1].st[0];
@@ -110,22 +285,23 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
 #pragma unroll
                     for (int j = 0; j < 24; j++) padded |= r13 == ix.padBi[j];
                 }
-                paddedBit = padded ? 0x80u : 0u;
+                noTableBit = padded ? 0x80u : 0u;
             }
         }
-        sRec[wv][lane] = make_uint4(rec.x, rec.y, rec.z, (rec.w & 0xFFFFFF00u) | (item % groups) | paddedBit);     // (low byte: the (case, strand) of the item; bit 7: see above)
+        sRec[wv][lane] = make_uint4(rec.x, rec.y, rec.z, (rec.w & 0xFFFFFF00u) | (item % groups) | noTableBit);     // (low byte: the (case, strand) of the item; bit 7: see above)
         if (staged && task) {
             const uint4 *src = (const uint4 *)(in.readsT + (size_t)myRead * 2u * S + (size_t)((item % groups) & 1u) * S);
             uint4 *dst = (uint4 *)(myRd + lane * S);
             for (uint32_t k = 0; k < S / 4u; k++) dst[k] = src[k];
         }
         __builtin_amdgcn_wave_barrier();
+        // ---- FILTER: 64 candidates per round; a verification whenever the queue holds a wave's worth ----
         for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
+            if (qn >= 64u) verify(64u);
             const uint32_t c = c0 + lane;
-            bool hit = false;
-            uint32_t rp = 0, recX = 0, seqK = 0;
-            int acc = 0;
-            uint32_t histIdx = 0xFFFFFFFFu;                     // (COUNT) where this candidate was rejected
+            bool survives = false;
+            uint32_t q[S3_CE_QWORDS] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            uint32_t histIdx = 0xFFFFFFFFu;
             if (c < total) {
                 // the task this candidate belongs to: the last one that starts at or before c (tasks of size 0 start where the next one starts)
                 uint32_t lo = 0, hi = 63u;
@@ -134,30 +310,24 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                     if (sStart[wv][mid] <= c) lo = mid; else hi = mid - 1u;
                 }
                 const uint4 tr = sRec[wv][lo];
-                const uint32_t k = c - sStart[wv][lo];
+                const uint32_t k = c - sStart[wv][lo], size = sStart[wv][lo + 1u] - sStart[wv][lo];
                 const uint32_t meta = tr.w >> 8, sub = tr.w & 0x7Fu;
-                const int s0 = (int)(meta & 7u), i0 = (int)((meta >> 3) & 0x7FFu), ins0 = (int)((meta >> 14) & 7u), occ0 = (int)((meta >> 17) & 7u);
+                const int s0 = (int)(meta & 7u), i0 = (int)((meta >> 3) & 0x7FFu), ins0 = (int)((meta >> 14) & 7u);
                 const uint32_t casIdx = sub >> 1, strand = sub & 1u, rIdx = sRead[wv][lo];
-                const bool early = (tr.y & S3_REC_EARLY) != 0;
                 const int Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
-                const int nSteps = (int)((in.nStepsPacked >> (3u * casIdx)) & 7u);
-                const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
-                const uint32_t *rdL = myRd + lo * S;
-                const S3Case &cs = in.models[Li].cs[casIdx];
-                recX = tr.x;
-                acc = occ0;
-                const S3Step st0 = cs.st[s0];
-                const int leftAlign = st0.dir > 0 ? st0.lm0 : st0.lm0 - i0;
-                const bool fwdStep = st0.dir > 0;
-                const uint4 *tab = fwdStep ? ((tr.w & 0x80u) ? nullptr : ix.flankFwd) : ix.flankBack;
-                uint32_t sa = 0, kf = k;                                        // text position of the matched part's start; the candidate's place in the FORWARD range
-                bool flankRejected = false;
+                const bool fwdStep = (tr.y & S3_REC_FWD) != 0u;                  // (= the direction of step s0: said by the record, so that the flank record's load does not wait for the model's)
+                const uint4 *tab = (tr.w & 0x80u) ? nullptr : fwdStep ? ix.flankFwd : ix.flankBack;
+                const S3Step st0 = in.models[Li].cs[casIdx].st[s0];
                 nSa++;
+                survives = true;
+                uint32_t sa = 0u;
                 if (tab) {
                     const uint4 e = tab[(fwdStep ? sAux[wv][lo] : tr.z) + k];
                     const int pos0 = st0.start + st0.dir * i0;
                     const uint32_t len0 = (uint32_t)(pos0 < st0.end ? st0.end - pos0 : pos0 - st0.end) + 1u, nAdj = len0 < 48u ? len0 : 48u;
                     // the read's characters next to the matched part, the adjacent one first (positions before the read's start never count: nAdj <= len0)
+                    const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
+                    const uint32_t *rdL = myRd + lo * S;
                     auto rword = [&](uint32_t w) -> uint32_t { return w < S ? (staged ? rdL[w] : rd[w]) : 0u; };
                     auto rwin = [&](int p0) -> uint32_t {
                         if (p0 <= -16) return 0u;
@@ -178,128 +348,27 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                                       miss(e.w, q2, nAdj <= 32u ? 0u : nAdj - 32u);
                     // (only characters inside the text decide here: a window that leaves it is the full comparison's business, with its bounds checks)
                     const bool inText = fwdStep ? (uint64_t)e.x + nAdj <= (uint64_t)ix.n : e.x >= nAdj;
-                    flankRejected = inText && mmAdj + ins0 > st0.maxErr;
+                    survives = !(inText && mmAdj + ins0 > st0.maxErr);
                     sa = fwdStep ? e.x - (uint32_t)(pos0 - st0.lm0) : e.x;
-                    if (!flankRejected && fwdStep) {
-                        const uint32_t size = sStart[wv][lo + 1u] - sStart[wv][lo];
-                        kf = 0xFFFFFFFFu;
-                        for (uint32_t j = 0; j < size; j++) if (ix.sa[tr.z + j] == sa) { kf = j; break; }
-                        if (kf == 0xFFFFFFFFu) { atomicOr(out.flags, S3_FLAG_FLANK); flankRejected = true; }
-                    }
-                } else sa = ix.sa[tr.z + k];
-                seqK = (tr.y & 0xFFFFFFu) + kf;
-                rp = sa - (uint32_t)leftAlign;                                   // 32-bit wrap, as the reference
-                int t = s0, ii = i0, insCur = ins0;
-                bool rejBound = false;
-                hit = !flankRejected;
-                while (hit && t < nSteps) {
-                    const S3Step st = cs.st[t];
-                    const int pos = st.start + st.dir * ii;
-                    const uint32_t left = (uint32_t)(pos < st.end ? pos : st.end), right = (uint32_t)(pos < st.end ? st.end : pos);
-                    const uint32_t len = right - left + 1u;
-                    if (early && t == s0) {
-                        // what is left of the exact lookup step: the walk this replaces matches real text only
-                        const long long rpS = (long long)sa - (long long)leftAlign;
-                        if (rpS + (long long)left < 0 || rpS + (long long)right >= (long long)ix.n) { hit = false; rejBound = true; break; }
-                    }
-                    if (rp + left > ix.n) { hit = false; rejBound = true; break; }                // BGS-HostAlgnmtAlgo2.cpp:122-125
-                    const uint32_t tpos = rp + left;
-                    int mm = 0;
-                    // 128 characters at a time: all text and read words of the piece are requested before the first is used
-                    for (uint32_t o0 = 0; o0 < len; o0 += 128u) {
-                        const uint32_t piece = len - o0 > 128u ? 128u : len - o0;
-                        const uint32_t tp0 = tpos + o0, tw0 = tp0 >> 4, tsh = (tp0 & 15u) * 2u;
-                        const uint32_t qp0 = left + o0, qw0 = qp0 >> 4, qsh = (qp0 & 15u) * 2u;
-                        uint32_t tw[9], qw[9];
-                        {
-                            // the text words tw0 .. tw0 + jmax out of the aligned 16-byte pieces that hold them (the text ends in a zero tail longer than a
-                            // piece: s3dp_api.hip), the first one at word `off` of the first piece
-                            const uint32_t jmax = (piece + 15u) >> 4, off = tw0 & 3u, lastW = off + jmax;     // lastW <= 11
-                            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                            const u32x4 *tc = (const u32x4 *)ix.pac + (tw0 >> 2);
-                            u32x4 c0 = tc[0], c1 = {0u, 0u, 0u, 0u}, c2 = {0u, 0u, 0u, 0u};
-                            if (lastW >= 4u) c1 = tc[1];
-                            if (lastW >= 8u) c2 = tc[2];
-                            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));          // (whole pieces: left alone the compiler asks for them word by word again)
-                            const uint32_t W[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
-#pragma unroll
-                            for (uint32_t j = 0; j < 9; j++) tw[j] = off == 0u ? W[j] : off == 1u ? W[j + 1] : off == 2u ? W[j + 2] : W[j + 3];
-                        }
-#pragma unroll
-                        for (uint32_t j = 0; j < 9; j++) {
-                            const uint32_t need = j * 16u < piece + 16u;              // word j + the one behind it for the shift
-                            if (!need) tw[j] = 0u;
-                            qw[j] = (need && qw0 + j < S) ? (staged ? rdL[qw0 + j] : rd[qw0 + j]) : 0u;
-                        }
-#pragma unroll
-                        for (uint32_t j = 0; j < 8; j++) {
-                            if (j * 16u < piece) {
-                                const uint32_t cch = piece - j * 16u > 16u ? 16u : piece - j * 16u;
-                                const uint32_t a_ = tsh ? (tw[j] << tsh) | (tw[j + 1] >> (32u - tsh)) : tw[j];
-                                const uint32_t b_ = qsh ? (qw[j] << qsh) | (qw[j + 1] >> (32u - qsh)) : qw[j];
-                                uint32_t x = a_ ^ b_;
-                                x = (x | (x >> 1)) & 0x55555555u;
-                                if (cch < 16u) x &= ~0u << (32u - 2u * cch);
-                                mm += __popc(x);
-                            }
-                        }
-                    }
-                    nCe += (len + 31u) >> 5;
-                    const int tot = mm + insCur;
-                    if (tot < st.minErr || tot > st.maxErr) { hit = false; break; }
-                    acc += tot; t++; ii = 0; insCur = 0;
+                    if constexpr (COUNT) { if (!survives) histIdx = histOf(st0, ins0, 0u); }
                 }
-                if constexpr (COUNT) {
-                    if (!hit) {
-                        uint32_t where = 2u;                                     // a later step
-                        if (flankRejected) where = 0u;                           // the flank record alone (48 characters next to the matched part)
-                        else if (t == s0) {
-                            where = 1u;                                          // the rest of the first compared step (or the text's end)
-                            const int pos = st0.start + st0.dir * i0;
-                            const uint32_t left = (uint32_t)(pos < st0.end ? pos : st0.end), right = (uint32_t)(pos < st0.end ? st0.end : pos);
-                            const uint32_t len = right - left + 1u, nAdj = len < 32u ? len : 32u;
-                            // (without a flank table: would the 32 characters next to the matched part alone have decided?  VERDICT r5, item 5)
-                            if (!tab && !rejBound && (st0.dir > 0 ? rp + left + nAdj <= ix.n : rp + right < ix.n)) {
-                                int m2 = 0;
-                                for (uint32_t q = 0; q < nAdj; q++) {
-                                    const uint32_t rpos = st0.dir > 0 ? left + q : right - q, tp = rp + rpos;
-                                    const uint32_t tc = (ix.pac[tp >> 4] >> (30u - 2u * (tp & 15u))) & 3u, rc = (rd[rpos >> 4] >> (30u - 2u * (rpos & 15u))) & 3u;
-                                    m2 += tc != rc ? 1 : 0;
-                                }
-                                if (m2 + ins0 > st0.maxErr) where = 0u;
-                            }
-                        }
-                        const int left0 = st0.maxErr - ins0;
-                        histIdx = ((st0.dir > 0 ? 1u : 0u) * 3u + (uint32_t)(left0 < 0 ? 0 : left0 > 2 ? 2 : left0)) * 3u + where;
-                    }
-                }
+                // (size - 1 <= 63: its low four bits ride in the state word's top, the other two in the sequence word's)
+                q[0] = tr.x; q[1] = (tr.y & 0x3FFFFFFFu) | ((size - 1u) >> 4) << 30; q[2] = tr.z;
+                q[3] = (tr.w & 0x0FFFFF00u) | sub | (tab ? 0x80u : 0u) | ((size - 1u) & 15u) << 28;
+                q[4] = rIdx; q[5] = k; q[6] = sa;
             }
-            if constexpr (COUNT) {
+            histAdd(histIdx);
+            const unsigned long long sm = __ballot(survives);
+            if (survives) {
+                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
 #pragma unroll
-                for (uint32_t k = 0; k < S3_CE_HIST_SLOTS; k++) histW[k] += (uint32_t)__popcll(__ballot(histIdx == k));
+                for (uint32_t f = 0; f < S3_CE_QWORDS; f++) sQ[wv][f][at] = q[f];
             }
-            const unsigned long long hm = __ballot(hit);
-            if (hm) {
-                // accepted candidates go into a block of record slots the wave reserved with one atomic (as the stepping kernel does)
-                const uint32_t np = (uint32_t)__popcll(hm);
-                if (recCur + np > recEnd) {
-                    for (uint32_t j = recCur + lane; j < recEnd; j += 64u) out.recs[j] = make_uint4(0xFFFFFFFFu, 0, 0, 0);   // unused tail
-                    uint32_t b0 = 0;
-                    if (lane == 0) b0 = atomicAdd(out.recCount, S3_V2_REC_BLOCK);
-                    b0 = (uint32_t)__shfl((int)b0, 0);
-                    recCur = b0; recEnd = b0 + S3_V2_REC_BLOCK;
-                    if (recEnd > out.recCap || recEnd < b0) { recEnd = b0 < out.recCap ? out.recCap : b0; if (lane == 0) atomicOr(out.flags, S3_FLAG_REC_OVERFLOW); }
-                }
-                if (hit) {
-                    nAcc++;
-                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-                    if (recCur + rk < recEnd) out.recs[recCur + rk] = make_uint4(recX, seqK | (1u << 24) | ((uint32_t)acc << 25), rp, rp);
-                }
-                recCur += np;
-                if (recCur > recEnd) recCur = recEnd;
-            }
+            qn += (uint32_t)__popcll(sm);
+            __builtin_amdgcn_wave_barrier();
         }
     }
+    while (qn) verify(qn < 64u ? qn : 64u);
     for (uint32_t j = recCur + lane; j < recEnd; j += 64u) out.recs[j] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
     if (out.counters) {
         atomicAdd(&out.counters[2], (unsigned long long)nSa);
@@ -316,15 +385,17 @@ void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &
     if (in.nActive == 0) return;
     // the waves split the task records statically: launch exactly the blocks that are resident at once (a partial second round would run on a
     // third of the chip while the rest idles).  S3DP_CE_BLOCKS_PER_CU overrides the occupancy the runtime reports.
-    static const unsigned blocks = [] {
-        int dev = 0, cus = 256, perCu = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, ceKernel<false>, 256, 16384) != hipSuccess || perCu < 1) perCu = 5;
-        if (const char *e = getenv("S3DP_CE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
-        return (unsigned)(cus * perCu);
-    }();
     const size_t lds = in.wpqLoad >= 4u && in.wpqLoad <= 16u ? (size_t)4u * 64u * in.wpqLoad * 4u : 0u;      // the tasks' reads (ceKernel::sRd)
+    static const unsigned cus = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return (unsigned)n;
+    }();
+    int perCu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, ceKernel<false>, 256, lds) != hipSuccess || perCu < 1) perCu = 4;
+    if (const char *e = getenv("S3DP_CE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
+    const unsigned blocks = cus * (unsigned)perCu;
     if (out.counters) hipLaunchKernelGGL(ceKernel<true>, dim3(blocks), dim3(256), lds, s, ix, in, out, taskRange);
     else hipLaunchKernelGGL(ceKernel<false>, dim3(blocks), dim3(256), lds, s, ix, in, out, taskRange);
 }

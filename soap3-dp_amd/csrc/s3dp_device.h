@@ -105,6 +105,7 @@ struct SearchIn {
 #define S3_REC_TASK  (1u << 28)
 #define S3_REC_PASS2 0x80000000u            // in the item word: record written by the second pass (records of a listed read without it are stale)
 #define S3_TRUNK_VALID 0x80000000u          // trunkStates[].w: the trunk pass reached this position
+#define S3_REC_FWD   (1u << 30)              // task written in a FORWARD step: its candidates are looked up in the reverse index's flank table (recAux)
 #define S3_REC_EARLY (1u << 29)              // task written inside the exact lookup step (single-suffix range): the rest of that step is verified too
 
 struct SearchOut {

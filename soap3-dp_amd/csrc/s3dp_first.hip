@@ -134,7 +134,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     };
     // a small range inside the check window, or a single suffix inside the lookup step: one task record, a sequence number per candidate
     auto task = [&](uint32_t flags) {
-        pendMeta = 0x80000000u | seq | S3_REC_TASK | flags;
+        pendMeta = 0x80000000u | seq | S3_REC_TASK | flags | (sc.dir() > 0 ? S3_REC_FWD : 0u);
         pendA = fwdL();
         pendB = (aR - aL) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
         pendC = aL;                                                          // (forward step: the active range is the reverse index's)

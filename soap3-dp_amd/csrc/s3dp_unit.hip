@@ -180,7 +180,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 if ((aR - aL) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd()) {
                     if (groupEnd != 0u && s == (int)sUnit() && ins == 0) { needPop = true; continue; }      // in the trunk's footsteps: the trunk wrote this task and ended here
                     if (pendMeta >> 31) { state = U_RESUME; return; }
-                    pendMeta = 0x80000000u | seq | S3_REC_TASK;
+                    pendMeta = 0x80000000u | seq | S3_REC_TASK | (sc.dir() > 0 ? S3_REC_FWD : 0u);
                     pendA = fwdL();
                     pendB = (aR - aL) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
                     pendC = aL;                                              // (forward step: the active range is the reverse index's)
