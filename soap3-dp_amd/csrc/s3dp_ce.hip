@@ -45,21 +45,19 @@ template <bool COUNT>
 __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, SearchOut out, const uint32_t *taskRange)
 {
     __shared__ uint4 sRec[4][64];                              // per wave: the task records of the batch ...
-    __shared__ uint32_t sStart[4][65], sRead[4][64], sAux[4][64];   // ... the number of their first candidate; the read a task belongs to; its range's start in the reverse index
+    __shared__ uint32_t sStart[4][65], sRead[4][64];           // ... the number of their first candidate; the read a task belongs to
+    __shared__ uint4 sAux[4][64];                              // ... {its range's start in the reverse index, the read's 48 characters next to the matched part} (SearchOut::recAux)
     // the survivors' queue: {record's item word, first sequence number | flags, first suffix of the forward range, state << 8 | (case, strand) | size - 1 << 28 ..., read, k, sa}
     __shared__ uint32_t sQ[4][S3_CE_QWORDS][S3_CE_QUEUE];
-    // ... and the tasks' reads, their searched strand, S words each (launchCheckExtend sizes it; not for reads of more than 256 bases): the filter's read words
-    // come out of LDS (the verification reads them from memory: the line was fetched a moment ago).  What the kernel is bound by, next to the lines it fetches,
-    // is the number of lines its wave-instructions TOUCH -- the vector cache looks up one line per lane and clock --: the text comes in aligned 16-byte pieces.
-    extern __shared__ __align__(16) uint32_t sRd[];
+    // (Until round 6 the tasks' reads were staged in LDS, one line per task: the filter's read characters now come with the task record, and the verification's
+    //  survivors -- one candidate in ten -- read theirs from memory.  What the kernel is bound by, next to the lines it fetches, is the number of lines its
+    //  wave-instructions TOUCH -- the vector cache looks up one line per lane and clock --: the text comes in aligned 16-byte pieces.)
     const uint32_t firstRec = taskRange[0];                   // records [firstRec, nRec): what the stepping launches wrote since the last call
     uint32_t nRec = taskRange[1];
     if (nRec > out.recCap) nRec = out.recCap;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t groups = (uint32_t)in.nCases * 2u;
     const uint32_t S = in.wpqLoad;
-    const bool staged = S >= 4u && S <= 16u;                   // (S is a power of two)
-    uint32_t *myRd = sRd + (size_t)wv * 64u * S;
     const uint32_t waveId = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t nSa = 0, nCe = 0, nAcc = 0;
     uint32_t histW[S3_CE_HIST_SLOTS] = {};                    // (COUNT) wave-uniform
@@ -263,37 +261,12 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
         if (lane == 63u) sStart[wv][64] = total;
         const uint32_t myRead = task ? (in.active ? in.active[slotOf] : slotOf) : 0u;
         sRead[wv][lane] = myRead;
-        sAux[wv][lane] = task ? out.recAux[idx] : 0u;
-        // An item whose lookup range may hold a PADDED table element (DevIndex::padBi: 13-mers the file format's tables count for text positions next to the
-        // text's ends) has a forward and a reverse range that need not hold the same occurrences -- BWTExactModelForward_Lookup2 (BGS-HostAlgnmtAlgo2.cpp:
-        // 349-356) makes their sizes equal by moving one end.  The CPU path verifies the FORWARD range's suffixes; such a task does the same here (bit 7 of
-        // the task's low byte: its candidates are not looked up in the reverse index's table).  Computed as the first pass computes `padded` (s3dp_first.hip).
+        sAux[wv][lane] = task ? out.recAux[idx] : make_uint4(0u, 0u, 0u, 0u);
+        // A task of an item with a PADDED lookup key (S3_REC_PADDED, lookupPadded in s3dp_search_common.h) verifies the FORWARD range's suffixes, as the CPU
+        // path does: its forward and reverse ranges need not hold the same occurrences (bit 7 of the task's low byte: no table for a forward step's candidates).
         // So does a task of more than 64 candidates (the queue's size field; the models' thresholds stop at 32).
-        uint32_t noTableBit = size > 64u ? 0x80u : 0u;
-        if (task && ix.flankFwd && !noTableBit) {
-            const uint32_t sub = item % groups;
-            const int Lr = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[myRead];
-            const S3Step l0 = in.models[Lr].cs[sub >> 1].st[0];
-            if (l0.type != S3_T_BACK_LOOKUP) {
-                const int k0 = ix.ltSize;
-                bool padded = l0.len < k0;
-                if (!padded) {
-                    const uint32_t *src = in.readsT + (size_t)myRead * 2u * S + (size_t)(sub & 1u) * S;
-                    const uint32_t w = (uint32_t)l0.start >> 4, sh = ((uint32_t)l0.start & 15u) * 2u;
-                    const uint32_t a = w < S ? src[w] : 0u, b2 = w + 1u < S ? src[w + 1u] : 0u;
-                    const uint32_t r13 = pairRev(sh ? (a << sh) | (b2 >> (32u - sh)) : a) & ((1u << (2 * k0)) - 1u);
-#pragma unroll
-                    for (int j = 0; j < 24; j++) padded |= r13 == ix.padBi[j];
-                }
-                noTableBit = padded ? 0x80u : 0u;
-            }
-        }
+        const uint32_t noTableBit = (size > 64u || ((rec.y & S3_REC_PADDED) && (rec.y & S3_REC_FWD))) ? 0x80u : 0u;
         sRec[wv][lane] = make_uint4(rec.x, rec.y, rec.z, (rec.w & 0xFFFFFF00u) | (item % groups) | noTableBit);     // (low byte: the (case, strand) of the item; bit 7: see above)
-        if (staged && task) {
-            const uint4 *src = (const uint4 *)(in.readsT + (size_t)myRead * 2u * S + (size_t)((item % groups) & 1u) * S);
-            uint4 *dst = (uint4 *)(myRd + lane * S);
-            for (uint32_t k = 0; k < S / 4u; k++) dst[k] = src[k];
-        }
         __builtin_amdgcn_wave_barrier();
         // ---- FILTER: 64 candidates per round; a verification whenever the queue holds a wave's worth ----
         for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
@@ -322,22 +295,11 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 survives = true;
                 uint32_t sa = 0u;
                 if (tab) {
-                    const uint4 e = tab[(fwdStep ? sAux[wv][lo] : tr.z) + k];
+                    const uint4 ax = sAux[wv][lo];
+                    const uint4 e = tab[(fwdStep ? ax.x : tr.z) + k];
                     const int pos0 = st0.start + st0.dir * i0;
                     const uint32_t len0 = (uint32_t)(pos0 < st0.end ? st0.end - pos0 : pos0 - st0.end) + 1u, nAdj = len0 < 48u ? len0 : 48u;
-                    // the read's characters next to the matched part, the adjacent one first (positions before the read's start never count: nAdj <= len0)
-                    const uint32_t *rd = in.readsT + (size_t)rIdx * 2u * S + (size_t)strand * S;
-                    const uint32_t *rdL = myRd + lo * S;
-                    auto rword = [&](uint32_t w) -> uint32_t { return w < S ? (staged ? rdL[w] : rd[w]) : 0u; };
-                    auto rwin = [&](int p0) -> uint32_t {
-                        if (p0 <= -16) return 0u;
-                        if (p0 < 0) return rword(0u) >> (2u * (uint32_t)(-p0));
-                        const uint32_t w = (uint32_t)p0 >> 4, sh = ((uint32_t)p0 & 15u) * 2u;
-                        const uint32_t a = rword(w), b = rword(w + 1u);
-                        return sh ? (a << sh) | (b >> (32u - sh)) : a;
-                    };
-                    const uint32_t q0 = fwdStep ? rwin(pos0) : pairRev(rwin(pos0 - 15)), q1 = fwdStep ? rwin(pos0 + 16) : pairRev(rwin(pos0 - 31)),
-                                   q2 = fwdStep ? rwin(pos0 + 32) : pairRev(rwin(pos0 - 47));
+                    const uint32_t q0 = ax.y, q1 = ax.z, q2 = ax.w;                    // the read's characters next to the matched part, the adjacent one first
                     auto miss = [](uint32_t a, uint32_t b, uint32_t n) -> int {        // mismatches among the first n <= 16 characters
                         uint32_t x = a ^ b;
                         x = (x | (x >> 1)) & 0x55555555u;
@@ -385,7 +347,7 @@ void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &
     if (in.nActive == 0) return;
     // the waves split the task records statically: launch exactly the blocks that are resident at once (a partial second round would run on a
     // third of the chip while the rest idles).  S3DP_CE_BLOCKS_PER_CU overrides the occupancy the runtime reports.
-    const size_t lds = in.wpqLoad >= 4u && in.wpqLoad <= 16u ? (size_t)4u * 64u * in.wpqLoad * 4u : 0u;      // the tasks' reads (ceKernel::sRd)
+    const size_t lds = 0;
     static const unsigned cus = [] {
         int dev = 0, n = 256;
         (void)hipGetDevice(&dev);

@@ -105,13 +105,15 @@ struct SearchIn {
 #define S3_REC_TASK  (1u << 28)
 #define S3_REC_PASS2 0x80000000u            // in the item word: record written by the second pass (records of a listed read without it are stale)
 #define S3_TRUNK_VALID 0x80000000u          // trunkStates[].w: the trunk pass reached this position
+#define S3_REC_PADDED (1u << 24)             // task of an item whose lookup range may hold a padded table element: its forward and reverse ranges need not hold the same occurrences
 #define S3_REC_FWD   (1u << 30)              // task written in a FORWARD step: its candidates are looked up in the reverse index's flank table (recAux)
 #define S3_REC_EARLY (1u << 29)              // task written inside the exact lookup step (single-suffix range): the rest of that step is verified too
 
 struct SearchOut {
     uint4              *recs;    // {item, seq|kind<<24|nmis<<25, a, b};  S3_REC_TASK set: a check-and-extend task {item, first seq, SA left, size-1 | state<<8}
-    uint32_t           *recAux;  // per record slot, written with a TASK record: the first suffix of the task's range in the REVERSE index (what a task written in a forward
-                                 // step looks its candidates up by in DevIndex::flankFwd; recs[].z stays the forward index's)
+    uint4              *recAux;  // per record slot, written with a TASK record: {the first suffix of the task's range in the REVERSE index (what a task written in a
+                                 // forward step looks its candidates up by in DevIndex::flankFwd; recs[].z stays the forward index's), the 48 characters of the
+                                 // read NEXT to the matched part, the adjacent one first, 16 per word MSB first}: ceKernel's filter needs nothing else of the read
     uint32_t            recCap;
     uint32_t           *recCount;
     uint32_t           *itemCounts;

@@ -87,7 +87,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     uint32_t ltA = 0, ltB = 0, ltC = 0, ltD = 0;                            // lookup-table keys of the starting item
     bool padded = false;                                                    // the item's lookup range may hold an element that is no occurrence
     uint32_t pendMeta = 0, pendA = 0, pendB = 0;
-    uint32_t pendC = 0;                                                     // of a task written in a forward step: the first suffix of its range in the REVERSE index (SearchOut::recAux)
+    uint32_t pendC = 0, pendQ0 = 0, pendQ1 = 0, pendQ2 = 0;                 // of a task: the first suffix of its range in the REVERSE index, the read's 48 characters next to the matched part (SearchOut::recAux)
     // ---- wave-uniform ----
     uint32_t recCur = 0, recEnd = 0;
     bool queueEmpty = false, basePending = false;
@@ -112,6 +112,11 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint32_t a = oword(w), b2 = oword(w + 1u);
         return sh ? (a << sh) | (b2 >> (32u - sh)) : a;
     };
+    auto readWindowS = [&](int p0) -> uint32_t {              // the same from any p0: characters before the read's start are 0
+        if (p0 <= -16) return 0u;
+        if (p0 < 0) return oword(0u) >> (2u * (uint32_t)(-p0));
+        return readWindow(p0);
+    };
     auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
         pendMeta = 0x80000000u | seq | (kind << 24) | (nmis << 25);
         pendA = a; pendB = b;
@@ -134,7 +139,8 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     };
     // a small range inside the check window, or a single suffix inside the lookup step: one task record, a sequence number per candidate
     auto task = [&](uint32_t flags) {
-        pendMeta = 0x80000000u | seq | S3_REC_TASK | flags | (sc.dir() > 0 ? S3_REC_FWD : 0u);
+        pendMeta = 0x80000000u | seq | S3_REC_TASK | flags | (sc.dir() > 0 ? S3_REC_FWD : 0u) | (padded ? S3_REC_PADDED : 0u);
+        adjacentWindows(sc.start() + sc.dir() * i, sc.dir(), readWindowS, pendQ0, pendQ1, pendQ2);
         pendA = fwdL();
         pendB = (aR - aL) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
         pendC = aL;                                                          // (forward step: the active range is the reverse index's)
@@ -368,23 +374,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;            // <= 13 characters = 26 bits of one window
             const uint32_t padOnes = ll < ix.ltSize ? ((1u << (2 * (ix.ltSize - ll))) - 1u) : 0u;
             const int shPad = 2 * (ix.ltSize - ll);
-            {
-                // does the item's 13-mer belong to the padded ones of the tables it reads?
-                const int k0 = ix.ltSize;
-                const uint32_t m13 = (1u << (2 * k0)) - 1u;
-                padded = st.len < k0;                                        // shorter lookup steps read a whole block of entries: walked
-                if (!padded) {
-                    if (st.type == S3_T_BACK_LOOKUP) {
-                        const uint32_t k13 = (readWindow(st.start - k0 + 1) >> (32 - 2 * k0)) & m13;
-#pragma unroll
-                        for (int j = 0; j < 12; j++) padded |= k13 == ix.padBack[j];
-                    } else {
-                        const uint32_t r13 = pairRev(readWindow(st.start)) & m13;
-#pragma unroll
-                        for (int j = 0; j < 24; j++) padded |= r13 == ix.padBi[j];
-                    }
-                }
-            }
+            padded = lookupPadded(ix, (int)st.type, (int)st.start, (int)st.len, readWindow);
             if (ix.ltK && st.len >= ix.ltK && st.ceThr == 0) {                 // (a lookup step that may switch to check-and-extend on its way -- exact-match models -- is walked)
                 // long table (<= 16 characters): one entry holds the state behind the lookup step's first ltK characters; ltB = ~0 marks the item
                 const int K = ix.ltK;
@@ -550,7 +540,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                     if (recCur + rk < recEnd) {
                         out.recs[recCur + rk] = make_uint4(TRUNK ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
-                        if (pendMeta & S3_REC_TASK) out.recAux[recCur + rk] = pendC;
+                        if (pendMeta & S3_REC_TASK) out.recAux[recCur + rk] = make_uint4(pendC, pendQ0, pendQ1, pendQ2);
                     }
                     pendMeta = 0;
                 }

@@ -56,7 +56,7 @@ struct s3_batch {
     uint32_t fullUniformLen = 0;
     // search / ordering work buffers
     uint4    *dRecs = nullptr, *dOrdered = nullptr;
-    uint32_t *dRecAux = nullptr;                      // SearchOut::recAux: one word per slot of dRecs
+    uint4    *dRecAux = nullptr;                      // SearchOut::recAux: 16 B per slot of dRecs
     uint8_t  *dOrdValid = nullptr;                    // per slot of dOrdered: holds a record (round 4: the holes are no longer written and read as 16-byte entries)
     uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr, *dTaskRange = nullptr;
     unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;

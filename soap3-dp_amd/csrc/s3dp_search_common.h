@@ -104,6 +104,38 @@ __device__ __forceinline__ uint4 rankFromWords(const RankSel &q, uint4 occ, uint
 
 struct Range { uint32_t fl, fr, rl, rr; };
 
+// Does the lookup key of an item belong to the PADDED k-mers of the tables it reads (DevIndex::padBack / padBi: 13-mers the file format's tables count for text
+// positions next to the text's ends)?  Its lookup range may then hold an element that is no occurrence, and its forward and reverse ranges need not hold the
+// same occurrences (BWTExactModelForward_Lookup2, BGS-HostAlgnmtAlgo2.cpp:349-356, makes their sizes equal by moving one end).  st = the case's step 0;
+// window(p) = 16 characters of the item's strand from position p >= 0, MSB first.
+template <class W>
+__device__ __forceinline__ bool lookupPadded(const DevIndex &ix, int stType, int stStart, int stLen, W window)
+{
+    const int k0 = ix.ltSize;
+    if (stLen < k0) return true;                                // shorter lookup steps read a whole block of entries
+    const uint32_t m13 = (1u << (2 * k0)) - 1u;
+    bool padded = false;
+    if (stType == S3_T_BACK_LOOKUP) {
+        const uint32_t k13 = (window(stStart - k0 + 1) >> (32 - 2 * k0)) & m13;
+#pragma unroll
+        for (int j = 0; j < 12; j++) padded |= k13 == ix.padBack[j];
+    } else {
+        const uint32_t r13 = pairRev(window(stStart)) & m13;
+#pragma unroll
+        for (int j = 0; j < 24; j++) padded |= r13 == ix.padBi[j];
+    }
+    return padded;
+}
+
+// the 48 characters of a read next to the matched part of a task (position `pos` = the next one to compare, direction dir), the adjacent one first; windowS(p) =
+// 16 characters from position p, which may be negative (characters before the read's start read as 0: they never count, ceKernel compares inside the step)
+template <class W>
+__device__ __forceinline__ void adjacentWindows(int pos, int dir, W windowS, uint32_t &q0, uint32_t &q1, uint32_t &q2)
+{
+    if (dir > 0) { q0 = windowS(pos); q1 = windowS(pos + 16); q2 = windowS(pos + 32); }
+    else { q0 = pairRev(windowS(pos - 15)); q1 = pairRev(windowS(pos - 31)); q2 = pairRev(windowS(pos - 47)); }
+}
+
 // the model step a lane is in, as the five words of S3Step with the check-and-extend threshold moved into the (unused) type byte
 struct StepC {
     uint32_t w0, w1, w2, w3;

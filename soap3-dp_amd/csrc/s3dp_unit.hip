@@ -94,7 +94,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     int s = 0, i = 0, ins = 0, occ = 0;
     StepC sc = {0, 0, 0, 0};
     int Li = UNIFORM ? (int)in.uniformLen : 0;
-    uint32_t subN = 0;                                                      // item (case * 2 + strand) | number of steps of the case << 8
+    uint32_t subN = 0;                                                      // item (case * 2 + strand) | number of steps of the case << 8 | padded lookup key << 16
     uint32_t listed = 0, unitInRead = 0;
     uint32_t cntIdx = 0, seq = 0, total = 0;
     // GROUPS (round 5).  A unit is the part of an item's search tree whose first mismatch sits in ONE GROUP of in.unitGroup consecutive positions of the first
@@ -110,7 +110,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     uint32_t aux = 0;                                                       // U_LOAD: the read's number in readsT; U_ADOPT: where the frame lies
     uint32_t loadOff = 0;
     uint32_t pendMeta = 0, pendA = 0, pendB = 0;
-    uint32_t pendC = 0;                                                     // of a task written in a forward step: the first suffix of its range in the REVERSE index (SearchOut::recAux)
+    uint32_t pendC = 0, pendQ0 = 0, pendQ1 = 0, pendQ2 = 0;                 // of a task: the first suffix of its range in the REVERSE index, the read's 48 characters next to the matched part (SearchOut::recAux)
     uint32_t countPending = 0;
     uint32_t age = 0;                                                       // full trips the lane has spent on its unit (a GIANT: more than in.giantAge)
     // ---- wave-uniform ----
@@ -122,13 +122,25 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
 
 #define casIdx (((subN) & 0xFFu) >> 1)
 #define subIdx ((subN) & 0xFFu)
-#define nSteps ((int)((subN) >> 8))
+#define nSteps ((int)(((subN) >> 8) & 0xFFu))
+#define itemPadded (((subN) >> 16) & 1u)                       /* the item's lookup key is a padded one (lookupPadded, s3dp_search_common.h): said in its task records */
     auto sUnit = [&]() -> uint32_t { return (in.sStarPacked >> (3u * casIdx)) & 7u; };     // the step the item is cut at (its first step that allows a mismatch)
     auto stepPtr = [&](int k) -> const uint32_t * {
         if constexpr (UNIFORM) return (const uint32_t *)&((const S3Model *)shmem)->cs[casIdx].st[k];
         else return (const uint32_t *)&in.models[Li].cs[casIdx].st[k];
     };
     auto readChar = [&](int pos) -> uint32_t { return (ro[((uint32_t)pos >> 4) * 64u + lane] >> (30u - 2u * ((uint32_t)pos & 15u))) & 3u; };
+    auto oword = [&](uint32_t w) -> uint32_t { return w < wl ? ro[w * 64u + lane] : 0u; };
+    auto readWindow = [&](int p0) -> uint32_t {               // 16 oriented characters from p0 >= 0, first one in the top bits
+        const uint32_t w = (uint32_t)p0 >> 4, sh = ((uint32_t)p0 & 15u) * 2u;
+        const uint32_t a = oword(w), b2 = oword(w + 1u);
+        return sh ? (a << sh) | (b2 >> (32u - sh)) : a;
+    };
+    auto readWindowS = [&](int p0) -> uint32_t {              // the same from any p0: characters before the read's start are 0
+        if (p0 <= -16) return 0u;
+        if (p0 < 0) return oword(0u) >> (2u * (uint32_t)(-p0));
+        return readWindow(p0);
+    };
     auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
         pendMeta = 0x80000000u | seq | (kind << 24) | (nmis << 25);
         pendA = a; pendB = b;
@@ -180,7 +192,8 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                 if ((aR - aL) < (uint32_t)sc.ceThr() && pos >= sc.ceStart() && pos <= sc.ceEnd()) {
                     if (groupEnd != 0u && s == (int)sUnit() && ins == 0) { needPop = true; continue; }      // in the trunk's footsteps: the trunk wrote this task and ended here
                     if (pendMeta >> 31) { state = U_RESUME; return; }
-                    pendMeta = 0x80000000u | seq | S3_REC_TASK | (sc.dir() > 0 ? S3_REC_FWD : 0u);
+                    pendMeta = 0x80000000u | seq | S3_REC_TASK | (sc.dir() > 0 ? S3_REC_FWD : 0u) | (itemPadded ? S3_REC_PADDED : 0u);
+                    adjacentWindows(pos, sc.dir(), readWindowS, pendQ0, pendQ1, pendQ2);
                     pendA = fwdL();
                     pendB = (aR - aL) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
                     pendC = aL;                                              // (forward step: the active range is the reverse index's)
@@ -505,6 +518,10 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             loadOff += 8;
             if constexpr (!UNIFORM) Li = (int)saVal;
             if (loadOff >= wl || loadOff >= wpq) {
+                {
+                    const uint32_t *l0 = stepPtr(0);                                  // the case's lookup step: start (low half of word 0), len (high half of word 2), type (byte 1 of word 3)
+                    if (lookupPadded(ix, (int)(int8_t)((l0[3] >> 8) & 0xFFu), (int)(int16_t)(l0[0] & 0xFFFFu), (int)l0[2] >> 16, readWindow)) subN |= 1u << 16;
+                }
                 loadStepCache();
                 {
                     // the trunk state {l, r, rev l} the step's way round
@@ -561,7 +578,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                     if (recCur + rk < recEnd) {
                         out.recs[recCur + rk] = make_uint4(cntIdx | S3_REC_PASS2, pendMeta & 0x7FFFFFFFu, pendA, pendB);
-                        if (pendMeta & S3_REC_TASK) out.recAux[recCur + rk] = pendC;
+                        if (pendMeta & S3_REC_TASK) out.recAux[recCur + rk] = make_uint4(pendC, pendQ0, pendQ1, pendQ2);
                     }
                     pendMeta = 0;
                 }

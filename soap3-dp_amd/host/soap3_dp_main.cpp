@@ -850,6 +850,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         // (the long lookup tables are sized by the HBM that is free: 16-mers want 103 GB; a run beside another process's allocations may get 15- or 14-mers --
         //  the same records, more rank queries per read)
         printf("[Main] Lookup tables in device memory : %d characters\n", s3_index_lookup_chars(s3_group_index(shared.grp, 0)));
+        printf("[Main] Flank tables of check-and-extend in device memory : %d of 2\n", s3_index_flank_tables(s3_group_index(shared.grp, 0)));
     } else devices = shared.devices;                                           // (later jobs of a list run on the devices the index is on)
     s3_group *grp = shared.grp;
     const int nMembers = (int)devices.size();
