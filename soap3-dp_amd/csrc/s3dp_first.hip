@@ -87,7 +87,8 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     uint32_t ltA = 0, ltB = 0, ltC = 0, ltD = 0;                            // lookup-table keys of the starting item
     bool padded = false;                                                    // the item's lookup range may hold an element that is no occurrence
     uint32_t pendMeta = 0, pendA = 0, pendB = 0;
-    uint32_t pendC = 0, pendQ0 = 0, pendQ1 = 0, pendQ2 = 0;                 // of a task: the first suffix of its range in the REVERSE index, the read's 48 characters next to the matched part (SearchOut::recAux)
+    uint32_t pendC = 0, pendP = 0;                                          // of a task: the first suffix of its range in the REVERSE index; the read position next to the matched part | forward step << 16
+                                                                            // (SearchOut::recAux: the read's 48 characters from there are cut out where the record is written, once per trip)
     // ---- wave-uniform ----
     uint32_t recCur = 0, recEnd = 0;
     bool queueEmpty = false, basePending = false;
@@ -140,7 +141,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     // a small range inside the check window, or a single suffix inside the lookup step: one task record, a sequence number per candidate
     auto task = [&](uint32_t flags) {
         pendMeta = 0x80000000u | seq | S3_REC_TASK | flags | (sc.dir() > 0 ? S3_REC_FWD : 0u) | (padded ? S3_REC_PADDED : 0u);
-        adjacentWindows(sc.start() + sc.dir() * i, sc.dir(), readWindowS, pendQ0, pendQ1, pendQ2);
+        pendP = (uint32_t)(sc.start() + sc.dir() * i) | (sc.dir() > 0 ? 1u << 16 : 0u);
         pendA = fwdL();
         pendB = (aR - aL) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
         pendC = aL;                                                          // (forward step: the active range is the reverse index's)
@@ -540,7 +541,11 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                     if (recCur + rk < recEnd) {
                         out.recs[recCur + rk] = make_uint4(TRUNK ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
-                        if (pendMeta & S3_REC_TASK) out.recAux[recCur + rk] = make_uint4(pendC, pendQ0, pendQ1, pendQ2);
+                        if (pendMeta & S3_REC_TASK) {
+                            uint32_t q0, q1, q2;
+                            adjacentWindows((int)(pendP & 0xFFFFu), (pendP >> 16) ? 1 : -1, readWindowS, q0, q1, q2);
+                            out.recAux[recCur + rk] = make_uint4(pendC, q0, q1, q2);
+                        }
                     }
                     pendMeta = 0;
                 }

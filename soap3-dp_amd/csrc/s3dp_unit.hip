@@ -110,7 +110,8 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
     uint32_t aux = 0;                                                       // U_LOAD: the read's number in readsT; U_ADOPT: where the frame lies
     uint32_t loadOff = 0;
     uint32_t pendMeta = 0, pendA = 0, pendB = 0;
-    uint32_t pendC = 0, pendQ0 = 0, pendQ1 = 0, pendQ2 = 0;                 // of a task: the first suffix of its range in the REVERSE index, the read's 48 characters next to the matched part (SearchOut::recAux)
+    uint32_t pendC = 0, pendP = 0;                                          // of a task: the first suffix of its range in the REVERSE index; the read position next to the matched part | forward step << 16
+                                                                            // (SearchOut::recAux: the read's 48 characters from there are cut out where the record is written, once per trip)
     uint32_t countPending = 0;
     uint32_t age = 0;                                                       // full trips the lane has spent on its unit (a GIANT: more than in.giantAge)
     // ---- wave-uniform ----
@@ -193,7 +194,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                     if (groupEnd != 0u && s == (int)sUnit() && ins == 0) { needPop = true; continue; }      // in the trunk's footsteps: the trunk wrote this task and ended here
                     if (pendMeta >> 31) { state = U_RESUME; return; }
                     pendMeta = 0x80000000u | seq | S3_REC_TASK | (sc.dir() > 0 ? S3_REC_FWD : 0u) | (itemPadded ? S3_REC_PADDED : 0u);
-                    adjacentWindows(pos, sc.dir(), readWindowS, pendQ0, pendQ1, pendQ2);
+                    pendP = (uint32_t)pos | (sc.dir() > 0 ? 1u << 16 : 0u);
                     pendA = fwdL();
                     pendB = (aR - aL) | ((uint32_t)s | (uint32_t)i << 3 | (uint32_t)ins << 14 | (uint32_t)occ << 17) << 8;
                     pendC = aL;                                              // (forward step: the active range is the reverse index's)
@@ -578,7 +579,11 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                     const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                     if (recCur + rk < recEnd) {
                         out.recs[recCur + rk] = make_uint4(cntIdx | S3_REC_PASS2, pendMeta & 0x7FFFFFFFu, pendA, pendB);
-                        if (pendMeta & S3_REC_TASK) out.recAux[recCur + rk] = make_uint4(pendC, pendQ0, pendQ1, pendQ2);
+                        if (pendMeta & S3_REC_TASK) {
+                            uint32_t q0, q1, q2;
+                            adjacentWindows((int)(pendP & 0xFFFFu), (pendP >> 16) ? 1 : -1, readWindowS, q0, q1, q2);
+                            out.recAux[recCur + rk] = make_uint4(pendC, q0, q1, q2);
+                        }
                     }
                     pendMeta = 0;
                 }
