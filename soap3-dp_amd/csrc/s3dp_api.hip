@@ -718,7 +718,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
         //  as much as walking it; s3dp_unit.hip, "GROUPS")
         // Two for the single-end ladders (10 M x 100 bp: unit passes 111.4 -> 93.6 ms), one for the paired ladder and the seeds of the DP stages: the same
         // pairs on the same box took 2.93 s with groups of two and 2.70 s with one position per unit (search kernels 1.36 against 1.19 s; README_r05 9.7)
+        // (round 6: with three and four mismatches a read rarely reaches MaxOutputPerRead -- the cut's coarseness costs nothing there -- and its units are many
+        //  and short: S3DP_UNIT_GROUP_HI positions per unit from three mismatches on)
         in.unitGroup = (uint32_t)envSize("S3DP_UNIT_GROUP", b->unitGroup ? b->unitGroup : 1u);
+        if (modelMm >= 3u && b->unitGroup > 1u) in.unitGroup = (uint32_t)envSize("S3DP_UNIT_GROUP_HI", envSize("S3DP_UNIT_GROUP", S3_UNIT_GROUP_HI));
         if (in.unitGroup < 1u) in.unitGroup = 1u;
         if (ok && longest > 0) unitsPerItem = ((uint32_t)longest + in.unitGroup - 1u) / in.unitGroup + 1u;
     }

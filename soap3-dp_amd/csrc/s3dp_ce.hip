@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) ceKernel(DevIndex ix, SearchIn in, Search
                 const uint32_t k = c - sStart[wv][lo], size = sStart[wv][lo + 1u] - sStart[wv][lo];
                 const uint32_t meta = tr.w >> 8, sub = tr.w & 0x7Fu;
                 const int s0 = (int)(meta & 7u), i0 = (int)((meta >> 3) & 0x7FFu), ins0 = (int)((meta >> 14) & 7u);
-                const uint32_t casIdx = sub >> 1, strand = sub & 1u, rIdx = sRead[wv][lo];
+                const uint32_t casIdx = sub >> 1, rIdx = sRead[wv][lo];
                 const int Li = in.uniformLen ? (int)in.uniformLen : (int)in.readLengths[rIdx];
                 const bool fwdStep = (tr.y & S3_REC_FWD) != 0u;                  // (= the direction of step s0: said by the record, so that the flank record's load does not wait for the model's)
                 const uint4 *tab = (tr.w & 0x80u) ? nullptr : fwdStep ? ix.flankFwd : ix.flankBack;

@@ -23,6 +23,7 @@
 #define S3_UNIT_GIANT_AGE 48u              // full trips on one unit that make a lane a giant whose frames its wave adopts before the queue is empty (S3DP_GIANT_AGE; 0: never)
 #define S3_UNIT_GIANT_IDLE 8u
 #define S3_UNIT_TAIL_AGE 0u
+#define S3_UNIT_GROUP_HI 8u                // ... from three mismatches on (S3DP_UNIT_GROUP_HI)
 #define S3_UNIT_GROUP 2u                   // first-mismatch positions per unit of the second pass (S3DP_UNIT_GROUP)
 #define S3_UNIT_NODE_BLOCK 256u           // sub-unit counters a wave of the unit pass reserves with one atomic
 #define S3_NUM_COUNTERS 40                 // 64-bit tallies of a kernel (SearchOut::counters); [21]: rank queries the first pass spent on reads it then listed; [22..39]: ceKernel's rejection histogram (s3dp_ce.hip)

@@ -85,6 +85,8 @@ KNOBS = [
     {"S3DP_HEAVY": "2", "S3DP_UNIT_GROUP": "3", "S3DP_GIANT_AGE": "1", "S3DP_GIANT_IDLE": "1", "S3DP_FAST_MIN": "2"},
     {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8", "S3DP_UNIT_GROUP": "7"},
     {"S3DP_HEAVY": "2", "S3DP_UNIT_GROUP": "200"},
+    {"S3DP_HEAVY": "2", "S3DP_UNIT_GROUP_HI": "2"},           # the same group size whatever the mismatch budget (until round 6; default: 8 from three mismatches on)
+    {"S3DP_HEAVY": "1", "S3DP_HEAVY_RANK": "8", "S3DP_UNIT_GROUP_HI": "5", "S3DP_FLANK": "1"},
 ]
 
 
