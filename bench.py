@@ -13,6 +13,7 @@ Prints ONE JSON line (rank 0).
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -362,8 +363,83 @@ def write_fastq_pairs(reads2d_np, L, path1, path2):
         rec.tofile(path)
 
 
+def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_sample, exe):
+    """DP parity at the size the DP stages are benchmarked at: pairs drawn from THIS run -- stratified by where the run's records ended
+    (BWT stage / DP stages / no proper pairing) and by what was simulated into them (an indel in one mate: default DP; both mates damaged: deep DP; neither:
+    the new default DP and the too-many-hits routes) -- go through the REFERENCE's own host pipeline on the SAME 3.1 Gbp index files (oracle/_ref/ref_harness:
+    BWT ladder by its CPU twin, routing, the DP engines' packers / seeding / merges / decode / record writers compiled from /root/reference; the two DP
+    kernels behind them are the restatement that tests/test_gpu_dp_reference.py holds bit-identical to the reference's device code) and through the command
+    line again; the three SAM files must hold the same records.  The index's .fmv / .rev.fmv files (the CPU 2BWT's occurrence arrays, which only the
+    reference's host code reads) are written here by HostIndex.write_fmv_files: byte-identical to soap3-dp-builder's (tests/test_builder.py)."""
+    import subprocess
+    from collections import Counter
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.path.exists(harness):
+        return {"skipped": "oracle/_ref/ref_harness is not built"}
+    t_all = time.perf_counter()
+    n_pairs = reads_np.shape[0] // 2
+    rng = np.random.default_rng(8)
+    g, d, u = (in_file.get(k, np.zeros(0, dtype=np.int64)) for k in ("out.gout.1", "out.dpout.1", "out.unpair"))
+    one_indel = tindel[0::2] ^ tindel[1::2]
+    strata = [("bwt_stage", np.setdiff1d(g, np.union1d(d, u))), ("dp_one_mate_with_indel", d[one_indel[d] & ~tboth[d]]), ("dp_both_mates_damaged", d[tboth[d]]),
+              ("dp_neither", d[~tindel[0::2][d] & ~tindel[1::2][d] & ~tboth[d]]), ("no_proper_pairing", u)]
+    per = max(1, n_sample // len(strata))
+    chosen, tags = [], {}
+    for tag, idx in strata:
+        if len(idx) > per:
+            idx = rng.choice(idx, size=per, replace=False)
+        tags[tag] = int(len(idx))
+        chosen.append(np.asarray(idx, dtype=np.int64))
+    sel = np.unique(np.concatenate(chosen))
+    out = {"pairs": int(len(sel)), "strata": tags}
+    if len(sel) == 0:
+        return dict(out, skipped="no pairs to draw from")
+    rows = np.stack([2 * sel, 2 * sel + 1], axis=1).ravel()
+    f1, f2 = os.path.join(work, "s1.fq"), os.path.join(work, "s2.fq")
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for path, rr in ((f1, rows[0::2]), (f2, rows[1::2])):
+        with open(path, "w") as f:
+            for p_, r_ in zip(sel, rr):
+                f.write("@%09d\n%s\n+\n%s\n" % (p_, letters[reads_np[r_]].tobytes().decode(), "I" * L))
+    t0 = time.perf_counter()
+    if not os.path.exists(prefix + ".fmv"):
+        hi.write_fmv_files(prefix)
+    out["fmv_files_s"] = time.perf_counter() - t0
+    ini = os.path.join(ROOT, "soap3-dp_amd", "host", "soap3-dp.ini")
+    opts = ["-L", str(L), "-u", "500", "-v", "1", "-b", "2"]
+    t0 = time.perf_counter()
+    ref = subprocess.run([harness, "sam", ini, "pair", prefix, f1, f2] + opts + ["-o", "ref"], cwd=work, capture_output=True, text=True, timeout=900)
+    out["reference_s"] = time.perf_counter() - t0
+    if ref.returncode != 0:
+        return dict(out, error="ref_harness failed: " + (ref.stdout[-300:] + ref.stderr[-300:]))
+    t0 = time.perf_counter()
+    mine = subprocess.run([exe, "pair", prefix, f1, f2] + opts + ["-o", os.path.join(work, "sub")], capture_output=True, text=True, timeout=900)
+    out["command_line_s"] = time.perf_counter() - t0
+    if mine.returncode != 0:
+        return dict(out, error="soap3-dp pair failed on the sample: " + mine.stderr[-300:])
+    total, differing, files = 0, [], {}
+    for kind in ("gout.1", "dpout.1", "unpair"):
+        def recs(p):
+            return Counter(l for l in open(p).read().split("\n") if l and not l.startswith("@")) if os.path.exists(p) else Counter()
+        a, b_ = recs(os.path.join(work, "ref." + kind)), recs(os.path.join(work, "sub." + kind))
+        files[kind] = {"reference_records": int(sum(a.values())), "records": int(sum(b_.values()))}
+        total += sum(a.values())
+        for l in list((a - b_).elements())[:3] + list((b_ - a).elements())[:3]:
+            differing.append(kind + ": " + l[:160])
+        if a != b_:
+            files[kind]["equal"] = False
+    routes = {k: int(v) for k, v in re.findall(r"(Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|Pairs left without a proper pairing): (\d+)", mine.stdout)}
+    out.update({"records": int(total), "by_file": files, "routes_of_the_sample": routes, "differing_records": differing[:6], "bit_exact": not differing and total > 0,
+                "seconds": time.perf_counter() - t_all,
+                "what": "pairs of this run, stratified by route, through the reference's own host pipeline (oracle/_ref/ref_harness) on the same index files and through the "
+                        "command line again: the records of .gout / .dpout / .unpair as multisets"})
+    if differing:
+        log("DP parity check against the reference pipeline FAILED: %r" % differing[:3])
+    return out
+
+
 def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cli=False, both_frac=0.0, resident=True, index_prefix=None, single_too=False,
-           seed_offset=0, device_no=None, host_threads=None, truth=True):
+           seed_offset=0, device_no=None, host_threads=None, truth=True, dp_check=0):
     """BASELINE.json configs[2] as far as one GPU and the time budget of a default run go: n_pairs 2 x 150 bp pairs on the benchmark genome,
     `pair -u 500 -v 1`, DP stages ON, end to end through the drop-in command line (the DP stages are driven by its host code), plus the resident BWT
     stage of the same pairs through the library with the oracle check on a sample.  Reports pairs/s, the stages' wall and device times, the BWT stage's
@@ -542,7 +618,7 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
             seen = np.zeros(2 * n_pairs, dtype=bool)
             at_truth = np.zeros(2 * n_pairs, dtype=bool)
             mapped = np.zeros(2 * n_pairs, dtype=bool)
-            by_file = {}
+            by_file, in_file = {}, {}
             for name in ("out.gout.1", "out.dpout.1", "out.unpair"):
                 p = os.path.join(work, name)
                 if not os.path.exists(p) or os.path.getsize(p) == 0:
@@ -559,6 +635,7 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
                 seen[row] = True
                 mapped[row] |= isMapped
                 at_truth[row] |= good
+                in_file[name] = np.unique(row // 2)
                 by_file[name] = {"records": int(len(df)), "mates": int(len(prim)), "mates_mapped": int(isMapped.sum()), "mates_at_simulated_place": int(good.sum())}
             both = at_truth[0::2] & at_truth[1::2]
             res["truth_check"] = {"pairs": n_pairs, "mates_reported": int(seen.sum()), "mates_mapped": int(mapped.sum()), "mates_at_simulated_place": int(at_truth.sum()),
@@ -570,6 +647,11 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
                                         "on a genome that is half repeats a mate inside a repeat family has equally good places elsewhere, so this is a rate, "
                                         "not a pass / fail -- all mates must be reported",
                                   "ok": bool(seen.all())}
+            if dp_check > 0:
+                try:
+                    res["dp_oracle_check"] = dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, dp_check, exe)
+                except Exception as e:
+                    res["dp_oracle_check"] = {"error": repr(e)}
             if single_too:
                 # ---- the first mates alone as single reads in the DEFAULT mode (DP stage on; above 120 bases: 100-base seeds verified on the device) -- the
                 # reference's everyday single-end call, which no other leg runs at this size on this genome (58 s for 10 M reads until the end of round 4)
@@ -723,7 +805,8 @@ def extras(s3dp, ix, hi, codes, dev, rank, a):
     res["_index_dir"] = shared
     if a.c3_pairs > 0:
         try:
-            res["c3_pairs"], res["_c3_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs, defer_cli=True, index_prefix=os.path.join(shared, "g.index"), single_too=True)
+            res["c3_pairs"], res["_c3_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs, defer_cli=True, index_prefix=os.path.join(shared, "g.index"), single_too=True,
+                                                     dp_check=a.dp_check)
         except Exception as e:
             res["c3_pairs"] = {"error": repr(e)}
         torch.cuda.empty_cache()
@@ -731,7 +814,7 @@ def extras(s3dp, ix, hi, codes, dev, rank, a):
         # BASELINE.json configs[4] on one GPU: the C3 mixture plus 5 % of the pairs damaged in both mates (deep DP, DV-DPForBothUnalign.cu), command line only
         try:
             res["c5_pairs"], res["_c5_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c5_pairs, defer_cli=True, both_frac=0.05, resident=False,
-                                                      index_prefix=os.path.join(shared, "g.index"))
+                                                      index_prefix=os.path.join(shared, "g.index"), dp_check=a.dp_check)
         except Exception as e:
             res["c5_pairs"] = {"error": repr(e)}
         torch.cuda.empty_cache()
@@ -1477,6 +1560,9 @@ def summary_of(out):
                "dp_isolated_GCUPS": g(ex, "default_dp_half_end", "GCUPS_kernel") if key == "c3_pairs" else None,
                "device_ms": e2e.get("device_ms"), "counts": e2e.get("counts"),
                "both_mates_at_simulated_place": g(leg, "truth_check", "pairs_with_both_mates_at_simulated_place")}
+        dpc = leg.get("dp_oracle_check")
+        if isinstance(dpc, dict):
+            rec["dp_oracle_check"] = {k: dpc.get(k) for k in ("pairs", "records", "bit_exact", "strata", "routes_of_the_sample", "seconds", "error", "skipped") if dpc.get(k) is not None}
         if "per_device" in e2e:
             rec["per_device"] = e2e["per_device"]
         sm[key] = rec
@@ -1484,6 +1570,9 @@ def summary_of(out):
                      (tag, pairs, secs or 0.0, rec["M_pairs_per_s"] or 0.0, rec["loading_s"] or 0.0,
                       ("%.3f" % rec["bwt_stage_frac"]) if rec["bwt_stage_frac"] else "-", ("%.0f" % rec["dp_GCUPS"]) if rec["dp_GCUPS"] else "-",
                       (", %.0f isolated" % rec["dp_isolated_GCUPS"]) if rec["dp_isolated_GCUPS"] else ""))
+        if isinstance(dpc, dict):
+            lines.append("%s DP parity against the reference's own host pipeline on the same index files: %s" % (tag, ("%d pairs by route %r, %d records, bit-exact: %s" % (
+                dpc.get("pairs", 0), dpc.get("strata"), dpc.get("records", 0), dpc.get("bit_exact"))) if "records" in dpc else (dpc.get("error") or dpc.get("skipped"))))
         sd = leg.get("single_default_mode")
         if isinstance(sd, dict) and "M_reads_per_s_reads_in_sam_out" in sd:
             sm[key + "_single_default_mode"] = {"reads": sd["reads"], "M_reads_per_s": sd["M_reads_per_s_reads_in_sam_out"], "wall_s": sd["wall_s"]}
@@ -1622,6 +1711,8 @@ def main():
     ap.add_argument("--c3-pairs", type=int, default=10_000_000, help="extras: BASELINE.json configs[2] -- 2 x 150 bp pairs through the command line with the DP stages on (0: skip)")
     ap.add_argument("--c5-pairs", type=int, default=10_000_000, help="extras: configs[4]'s mixture (5 %% of the pairs damaged in both mates: deep DP) through the command line (0: skip)")
     ap.add_argument("--c4-pairs", type=int, default=10_000_000, help="N > 1: BASELINE.json configs[3] -- pairs PER GPU, every rank's shard through the command line on its own device (0: skip)")
+    ap.add_argument("--dp-check", type=int, default=2048, help="extras: pairs of the C3 / C5 runs, stratified by route, whose records are compared with the reference's own host "
+                                                               "pipeline (oracle/_ref/ref_harness) on the same index files (0: skip)")
     ap.add_argument("--se150-reads", type=int, default=2_000_000, help="extras: 150 bp single-end reads, kernel-only rate (0: skip)")
     ap.add_argument("--exact-rank", type=int, default=1, help="count the reference algorithm's rank queries on this input with one walk-mode device pass")
     ap.add_argument("--robustness", default="young", help="extras: comma-separated repeat models (young, old, satellite-heavy) run at --robustness-reads reads each ('' = none)")

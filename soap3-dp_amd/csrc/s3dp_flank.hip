@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <stdio.h>
+#include <chrono>
 #include "s3dp_device.h"
 #include "s3dp_search_common.h"
 
@@ -135,12 +136,22 @@ int launchFlankTables(DevIndex &d, int which, size_t reserveBytes, void **allocs
         return freeB >= tableBytes + reserveBytes;
     };
     hipError_t e;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[s3dp] flank tables: %-44s %8.3f s\n", what, std::chrono::duration<double>(now - t0).count());
+        t0 = now;
+    };
     if (room()) {
         uint4 *tb = nullptr;
         e = hipMalloc(&tb, tableBytes);
+        lap("allocation (forward index order)");
         if (e == hipSuccess) {
             hipLaunchKernelGGL(flankBackKernel, dim3(8192), dim3(256), 0, s, d, tb);
             if ((e = hipStreamSynchronize(s)) != hipSuccess || (e = hipGetLastError()) != hipSuccess) { (void)hipFree(tb); return (int)e; }
+            lap("forward index order: text windows");
             d.flankBack = tb; allocs[(*nAllocs)++] = tb; *bytes += tableBytes;
         } else (void)hipGetLastError();
     }
@@ -157,12 +168,15 @@ int launchFlankTables(DevIndex &d, int which, size_t reserveBytes, void **allocs
     if (e != hipSuccess) { (void)hipFree(tf); if (anchorRank) (void)hipFree(anchorRank); (void)hipGetLastError(); return e == hipErrorOutOfMemory ? (int)hipSuccess : (int)e; }
     written = (unsigned long long *)(anchorRank + tail);               // [0]: positions written; [1]: the checks' flags
     uint32_t *bad = (uint32_t *)(written + 1);
+    lap("allocation + zeroes (reverse index order)");
     hipLaunchKernelGGL(flankAnchorKernel, dim3((nAnchors + 255u) / 256u), dim3(256), 0, s, d, nAnchors, anchorRank);
+    lap("reverse index order: anchors");
     hipLaunchKernelGGL(flankWalkKernel, dim3((nAnchors + 255u) / 256u), dim3(256), 0, s, d, nAnchors, anchorRank, tf, written, bad);
     unsigned long long res[2] = {0, 0};
     e = hipMemcpyAsync(res, written, 16, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipGetLastError();
+    lap("reverse index order: the walk");
     (void)hipFree(anchorRank);
     if (e != hipSuccess) { (void)hipFree(tf); return (int)e; }
     const uint32_t flags = (uint32_t)res[1];

@@ -190,6 +190,43 @@ def pac_words_from_file(path, n=None):
     return buf.view(">u4").astype(np.uint32)
 
 
+def fmv_words(bwt_words, n, inverse_sa0, cum):
+    """The words of a <prefix>.fmv / .rev.fmv file -- the occurrence arrays of the reference's CPU 2BWT (BWTGenerateOccValueFromBwt, 2bwt-lib/BWTConstruct.c:
+    1037-1247; read back by BWTLoad, BWT.c:196-223): a sample every 256 BWT characters, 16 bits per symbol counted from the last MAJOR sample (every 65,536
+    characters, 32 bits, absolute), two samples per word -- sample 2j in the high half, 2j + 1 in the low half --, the minor words first, then the majors.
+    The product never reads these files (its kernels use the .fmv.gpu layout); they exist so that the REFERENCE's own host code (oracle/_ref/ref_harness) can
+    load an index this builder wrote -- bench.py's DP parity leg at the benchmark's size."""
+    n = int(n)
+    N = (n + 255) // 256 + 1                                       # samples (one at either end)
+    need = (N - 1) * 16
+    w = np.zeros(need, dtype=np.uint32)
+    m = min(len(bwt_words), need)
+    w[:m] = np.asarray(bwt_words[:m], dtype=np.uint32)
+    lut = np.zeros((256, 4), dtype=np.uint32)                      # symbols of a byte's four characters (their order inside the byte is no matter)
+    for v in range(256):
+        for k in range(4):
+            lut[v, (v >> (2 * k)) & 3] += 1
+    b = w.view(np.uint8)
+    cnt = np.zeros((N - 1, 4), dtype=np.uint64)
+    step = 1 << 18                                                 # intervals per piece (64 bytes each)
+    for i0 in range(0, N - 1, step):
+        i1 = min(N - 1, i0 + step)
+        cnt[i0:i1] = lut[b[i0 * 64:i1 * 64]].reshape(i1 - i0, 64, 4).sum(axis=1)
+    absol = np.zeros((N, 4), dtype=np.uint64)
+    np.cumsum(cnt, axis=0, out=absol[1:])
+    n_major = (N + 255) // 256
+    major = absol[0:N:256][:n_major]
+    rel = (absol - major[np.arange(N) // 256]).astype(np.uint32)   # < 65,536: a sample on a major boundary counts from itself
+    W = (N + 1) // 2
+    hi = rel[0::2][:W]
+    lo = rel[1::2]
+    if len(lo) < W:                                                # an odd number of samples: the last word's low half repeats its high half
+        lo = np.concatenate([lo, rel[N - 1:N]])
+    occ = ((hi << np.uint32(16)) | lo).astype(np.uint32)
+    head = np.array([int(inverse_sa0)] + [int(x) for x in cum[1:5]], dtype=np.uint32)
+    return np.concatenate([head, occ.ravel(), major.astype(np.uint32).ravel()])
+
+
 class HostIndex:
     """host arrays of one 2BWT + GPU-2BWT index in the file layouts"""
 
@@ -243,6 +280,12 @@ class HostIndex:
         self.rev_lkt = rev_lkt if shared else np.ascontiguousarray(rev_lkt)
         self.lkt_size = 13
         return self
+
+    def write_fmv_files(self, prefix):
+        """<prefix>.fmv and .rev.fmv beside files written by write_files: the CPU 2BWT's occurrence arrays (fmv_words), which only the reference's own
+        host code reads"""
+        for mid, h in (("", self.fwd), (".rev", self.rev)):
+            fmv_words(h["bwt"], self.n, h["inverseSa0"], h["cum"]).astype("<u4").tofile(prefix + mid + ".fmv")
 
     def write_files(self, prefix, name="chr1", with_lkt=False):
         """Write the reference's index files (<prefix>.bwt .fmv.gpu .rev.bwt .rev.fmv.gpu .sa .pac .ann .amb .tra, optionally .lkt / .rev.lkt)

@@ -49,3 +49,25 @@ def test_builder_chunked_paths(monkeypatch):
     assert (mine.sa == ref.sa).all()
     assert (mine.lkt == ref.lkt).all() and (mine.rev_lkt == ref.rev_lkt).all()
     assert (mine.pac == ref.pac).all()
+
+
+REF_BUILDER = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "soap3-dp-builder")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BUILDER), reason="oracle/_ref/soap3-dp-builder is not built (make -f oracle/ref.mk where /root/reference exists)")
+@pytest.mark.parametrize("name", ["g1", "g2", "g7"])
+def test_fmv_files_equal_the_reference_builders(tmp_path, name):
+    """<prefix>.fmv / .rev.fmv -- the CPU 2BWT's occurrence arrays, which the product never reads but the reference's own host code needs to load an index
+    (bench.py's DP parity leg runs oracle/_ref/ref_harness on the index files of the benchmark genome): byte-identical to what soap3-dp-builder writes."""
+    import shutil
+    import subprocess
+    refdir = os.path.dirname(REF_BUILDER)
+    shutil.copy(os.path.join(GOLDEN, name, "genome.fa"), tmp_path / "g.fa")
+    shutil.copy(os.path.join(refdir, "soap3-dp-builder.ini"), tmp_path / "soap3-dp-builder.ini")
+    subprocess.check_call([REF_BUILDER, "g.fa"], cwd=tmp_path, stdout=subprocess.DEVNULL)
+    hi = host_index(name)
+    hi.write_fmv_files(str(tmp_path / "mine"))
+    for mid in ("", ".rev"):
+        want = open(tmp_path / ("g.fa.index" + mid + ".fmv"), "rb").read()
+        got = open(tmp_path / ("mine" + mid + ".fmv"), "rb").read()
+        assert len(got) == len(want) and got == want
