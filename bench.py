@@ -419,17 +419,35 @@ def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_
         return dict(out, error="soap3-dp pair failed on the sample: " + mine.stderr[-300:])
     total, differing, files = 0, [], {}
     for kind in ("gout.1", "dpout.1", "unpair"):
-        def recs(p):
-            return Counter(l for l in open(p).read().split("\n") if l and not l.startswith("@")) if os.path.exists(p) else Counter()
-        a, b_ = recs(os.path.join(work, "ref." + kind)), recs(os.path.join(work, "sub." + kind))
+        def recs(p, fix_sign=False):
+            if not os.path.exists(p):
+                return Counter()
+            c = Counter()
+            for l in open(p).read().split("\n"):
+                if not l or l.startswith("@"):
+                    continue
+                if fix_sign:
+                    # the reference's record holds positions as 32-bit SIGNED integers (samtools' bam1_core_t.pos): on this benchmark's ONE sequence of 3.1 G
+                    # bases everything beyond 2^31 prints negative (GRCh38's longest chromosome is 0.25 G: the reference never sees such a position).  The
+                    # command line prints the position; for the comparison the reference's negative POS / PNEXT get their 2^32 back.
+                    f = l.split("\t")
+                    for k in (3, 7):
+                        if len(f) > k and f[k].startswith("-"):
+                            f[k] = str(int(f[k]) + (1 << 32))
+                    l = "\t".join(f)
+                c[l] += 1
+            return c
+        a, b_ = recs(os.path.join(work, "ref." + kind), True), recs(os.path.join(work, "sub." + kind))
         files[kind] = {"reference_records": int(sum(a.values())), "records": int(sum(b_.values()))}
         total += sum(a.values())
-        for l in list((a - b_).elements())[:3] + list((b_ - a).elements())[:3]:
-            differing.append(kind + ": " + l[:160])
+        for tag_, l in [("reference only", x) for x in list((a - b_).elements())[:6]] + [("command line only", x) for x in list((b_ - a).elements())[:6]]:
+            differing.append("%s, %s: %s" % (kind, tag_, "\t".join(l.split("\t")[:9] + l.split("\t")[11:])[:400]))
         if a != b_:
             files[kind]["equal"] = False
     routes = {k: int(v) for k, v in re.findall(r"(Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|Pairs left without a proper pairing): (\d+)", mine.stdout)}
-    out.update({"records": int(total), "by_file": files, "routes_of_the_sample": routes, "differing_records": differing[:6], "bit_exact": not differing and total > 0,
+    out["position_note"] = ("the reference prints POS / PNEXT beyond 2^31 as negative numbers (32-bit signed positions; the benchmark genome is ONE sequence of 3.1 G bases): "
+                            "they are compared after adding 2^32")
+    out.update({"records": int(total), "by_file": files, "routes_of_the_sample": routes, "differing_records": differing[:24], "bit_exact": not differing and total > 0,
                 "seconds": time.perf_counter() - t_all,
                 "what": "pairs of this run, stratified by route, through the reference's own host pipeline (oracle/_ref/ref_harness) on the same index files and through the "
                         "command line again: the records of .gout / .dpout / .unpair as multisets"})
