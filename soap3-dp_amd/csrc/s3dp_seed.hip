@@ -11,7 +11,7 @@ using namespace s3i;
 // without a hit once more with one mismatch, every hit turned into an estimated read position, positions of one read and strand merged.
 // Replaces, of the reference: SingleEndSeedingBatch::pack / packSeeds (DV-DPfunctions.cu:1058-1100), single_1_mismatch_alignment2
 // (alignment.cu:1839-1894) + the hit limit of hostKernelSingle (CPUfunctions.cpp:2843-2876: a seed with more than maxHitNum hits is
-// dropped), decodePositions (:1143-1219, sorted by strand, read, position) and singleMerge (:1102-1141, positions closer than
+// dropped), decodePositions (:1143-1219: sorted by read and position, the strands together -- see singleMergeKernel) and singleMerge (:1102-1141, positions closer than
 // DPS_DIVIDE_GAP = 50 collapse into the first).  Everything runs on the device next to the resident reads; the seed batch is an
 // ordinary s3_batch.  Pinned through the reference's own seeding engines in the oracle harness (tests/test_gpu_dp_pipeline.py); also tested against a restatement built on the pinned search oracle.
 // ---------------------------------------------------------------------------------------------
@@ -59,27 +59,36 @@ __global__ void seedKeysKernel(uint32_t nSeeds, const SeedDesc *seeds, const uin
     for (uint32_t k = 0; k < cnt; k++) {
         const uint32_t pos = occPos[src + k], strand = occMeta[src + k] & 0xFFu;
         const uint32_t est = strand == 1u ? pos - d.off : pos + d.len + d.off - readLen;
-        keys[dst + k] = (uint64_t)(d.keyHi | (strand == 2u ? 1u << strandBit : 0u)) << 32 | est;
+        // strandBit 0xFFFFFFFF (the single-end DP): the strand is no part of the order -- (read, position), the strand rides in the lowest bit
+        if (strandBit == 0xFFFFFFFFu) keys[dst + k] = (uint64_t)d.keyHi << 33 | (uint64_t)est << 1 | (strand == 2u ? 1u : 0u);
+        else keys[dst + k] = (uint64_t)(d.keyHi | (strand == 2u ? 1u << strandBit : 0u)) << 32 | est;
     }
 }
 
 // ---- candidate merges on the device --------------------------------------------------------------------------------------------
-// singleMerge (DV-DPfunctions.cu:1102-1141): inside one (strand, read) run of the sorted keys the first position is kept, then every position more than
+// singleMerge (DV-DPfunctions.cu:1102-1141): inside one READ's run of the sorted positions the first position is kept, then every position more than
 // DPS_DIVIDE_GAP = 50 beyond the last KEPT one -- a chain along the run, so the lane that finds itself at the head of a run walks it (runs are a few
 // seeds' worth of hits); a counting walk, a scan, a writing walk.
+// The order is (read, position) with BOTH strands in one run, a kept position keeping its own strand: decodePositions (:1214-1216) sorts by position, by read
+// and then by strand -- but that third pass (MC_RadixSort_8_8, DV-DPfunctions.h:90: ONE round, from the array into the auxiliary array) leaves its result in
+// the buffer that is freed on the next line; what singleMerge walks is the order of the second pass.  Until round 6 this file sorted by (strand, read,
+// position) as the source reads: a read with DP hits on both strands then came as two runs, its result list '+' first instead of by position -- the
+// primary record of such a read differed from the reference's whenever the two strands' best scores tied (found by bench.py's DP parity leg on the
+// benchmark genome, whose repeat families have inverted copies; tests/test_gpu_cli_vs_oracle_scale.py::test_reads_with_dp_hits_on_both_strands).
+// key = read << 33 | position << 1 | (strand == '-')
 __global__ void singleMergeKernel(const uint64_t *keys, uint32_t n, const uint32_t *offsets, uint32_t *counts, s3_seed_candidate *out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t run = keys[i] >> 32;
-    if (i && (keys[i - 1] >> 32) == run) { if (!out) counts[i] = 0; return; }
-    uint32_t prev = (uint32_t)keys[i], kept = 1;
+    const uint64_t run = keys[i] >> 33;
+    if (i && (keys[i - 1] >> 33) == run) { if (!out) counts[i] = 0; return; }
+    uint32_t prev = (uint32_t)(keys[i] >> 1), kept = 1;
     const uint32_t at = out ? offsets[i] : 0u;
-    if (out) out[at] = s3_seed_candidate{(uint32_t)(run & 0x7FFFFFFFu), prev, (uint8_t)((run >> 31) ? 2 : 1), {0, 0, 0}};
-    for (uint32_t k = i + 1; k < n && (keys[k] >> 32) == run; k++) {
-        const uint32_t cur = (uint32_t)keys[k];
+    if (out) out[at] = s3_seed_candidate{(uint32_t)run, prev, (uint8_t)((keys[i] & 1u) ? 2 : 1), {0, 0, 0}};
+    for (uint32_t k = i + 1; k < n && (keys[k] >> 33) == run; k++) {
+        const uint32_t cur = (uint32_t)(keys[k] >> 1);
         if ((uint64_t)prev + 50u < cur) {
-            if (out) out[at + kept] = s3_seed_candidate{(uint32_t)(run & 0x7FFFFFFFu), cur, (uint8_t)((run >> 31) ? 2 : 1), {0, 0, 0}};
+            if (out) out[at + kept] = s3_seed_candidate{(uint32_t)run, cur, (uint8_t)((keys[k] & 1u) ? 2 : 1), {0, 0, 0}};
             kept++; prev = cur;
         }
     }
@@ -423,7 +432,7 @@ extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const ui
     std::vector<uint8_t> status;
     uint64_t *dKeys = nullptr;
     uint32_t nKeys = 0;
-    int rc = seedSearchKeys(reads, seedBatch, seeds, maxHitNum, 31, keys, status, &dKeys, &nKeys);
+    int rc = seedSearchKeys(reads, seedBatch, seeds, maxHitNum, 0xFFFFFFFFu, keys, status, &dKeys, &nKeys);
     if (rc) return rc;
     // singleMerge on the device: count per run head, scan, write; the candidates come over, not the positions
     std::vector<s3_seed_candidate> out;

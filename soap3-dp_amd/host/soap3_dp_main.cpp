@@ -186,8 +186,8 @@ static void parallelFormat(const HostIndex &hix, const SamOptions &so, FILE *out
 }
 
 // ---- single-end DP of a list of reads (DPForUnalignSingle2, DV-DPForSingleReads.cu): seeding in batches of at most 256 Ki seeds, DP at the candidates;
-// `emit` gets one call per run of results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776 -- results arrive in (strand, read, position)
-// order, so a read with hits on both strands comes twice) after OutputBuffer::ready (DV-DPfunctions.h:367-412) with the DP module's type
+// `emit` gets one call per run of results of the same read (DPSOutputThread, DV-DPfunctions.cu:1776 -- results arrive in (read, position) order, both
+// strands of a read in one run: s3dp_seed.hip, singleMergeKernel) after OutputBuffer::ready (DV-DPfunctions.h:367-412) with the DP module's type
 // (all-best + SAM runs it as all-valid, alignment.cu:2563): sorted by position, one result per position; then best-only for -h 3 / 4 --------------
 // parallelOut != NULL: the runs of a batch are handed to `emit` by all host threads at once, each with a writer whose records land in parallelOut in run
 // order; NULL: one call after the other (the writer argument is then a dummy that must not be used).
@@ -523,8 +523,7 @@ static bool pairDpStages(const PairDpCtx &c, const std::vector<s3_pair_result> &
     for (size_t lk = 0; lk < left.size(); lk++) leftSlot[left[lk] >> 1] = (uint32_t)lk;
     std::vector<std::vector<DpHit>> ownLists(2 * left.size());
     auto own = [&](uint32_t r) -> std::vector<DpHit> & { return ownLists[(size_t)2 * leftSlot[r >> 1] + (r & 1u)]; };
-    // a read with DP hits on both strands reaches the reference's store as two entries and breaks its pairing by position in the list
-    // (outputSingleResultForPairEnds :1106-1112 prints an error); here the two runs are one list
+    // (one run per read: a read's DP hits on both strands are one list in position order, as the reference's store holds them)
     if (!singleDpRuns(c.hix, c.so, nullptr, c.b, c.seedBatch, c.dp, lens, todo, c.singlePar, moduleType, [&](SamWriter &, uint32_t k, std::vector<DpHit> &hits) {
             own(k).insert(own(k).end(), hits.begin(), hits.end());
         }, err)) return false;

@@ -83,13 +83,15 @@ def test_seed_candidates_match_restatement(stage, max_hit):
         p, s, _ = oix.decode(hits[int(offs[j]):int(offs[j + 1])])
         for pos, strand in zip(p, s):
             est = (int(pos) - off) if strand == 1 else (int(pos) + sl + off - len(reads[r]))
-            keys.append((int(strand), r, est & 0xFFFFFFFF))
+            keys.append((r, est & 0xFFFFFFFF, int(strand)))
+    # (read, position), the strands together: the reference's third sort pass -- by strand -- leaves its result in a buffer that is freed
+    # (MC_RadixSort_8_8, DV-DPfunctions.h:90; s3dp_seed.hip singleMergeKernel tells the story), so one run per READ is merged, a kept position keeping its strand
     keys.sort()
     want = []
     prev_run, prev = None, 0
-    for strand, r, est in keys:
-        if (strand, r) != prev_run:
-            want.append((r, est, strand)); prev_run = (strand, r); prev = est
+    for r, est, strand in keys:
+        if r != prev_run:
+            want.append((r, est, strand)); prev_run = r; prev = est
         elif prev + 50 < est:
             want.append((r, est, strand)); prev = est
     got = [(int(c["readID"]), int(c["pos"]), int(c["strand"])) for c in cand]
