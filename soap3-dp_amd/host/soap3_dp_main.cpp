@@ -1099,8 +1099,7 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                     const ReadSet &rs = *j->rs;
                     if (j->hadSeedLengths && s3_batch_set_seed_lengths(j->b, nullptr) != S3_OK) fatal(s3_last_error());
                     std::vector<uint8_t> doneFlag(j->cnt, 0);
-                    // a read with DP hits on both strands comes as two runs (two records, as in the reference): its flag may be set by two threads at once,
-                    // to the same value; the count of aligned reads is taken from the flags afterwards
+                    // (one run per read; the count of aligned reads is taken from the flags afterwards)
                     if (!singleDpRuns(hix, so, dpOut, j->b, seedW, dpW, rs.lengths.data(), j->todo, dpPar, alignmentType, [&](SamWriter &w, uint32_t k, std::vector<DpHit> &hits) {
                             w.singleDP(rs, k, hits.data(), hits.size(), dpPar.cutoffThreshold);
                             doneFlag[k] = 1;
