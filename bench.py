@@ -426,6 +426,12 @@ def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_
             for l in open(p).read().split("\n"):
                 if not l or l.startswith("@"):
                     continue
+                f = l.split("\t")
+                if len(f) > 8 and f[8].lstrip("-").isdigit() and abs(int(f[8])) >= 1 << 31:
+                    # (likewise TLEN of two ends more than 2^31 apart -- never a proper pair: both sides are compared as the 32-bit signed number the reference prints)
+                    t = int(f[8]) & 0xFFFFFFFF
+                    f[8] = str(t - (1 << 32) if t >= 1 << 31 else t)
+                    l = "\t".join(f)
                 if fix_sign:
                     # the reference's record holds positions as 32-bit SIGNED integers (samtools' bam1_core_t.pos): on this benchmark's ONE sequence of 3.1 G
                     # bases everything beyond 2^31 prints negative (GRCh38's longest chromosome is 0.25 G: the reference never sees such a position).  The
