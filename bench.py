@@ -412,12 +412,16 @@ def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_
     out["reference_s"] = time.perf_counter() - t0
     if ref.returncode != 0:
         return dict(out, error="ref_harness failed: " + (ref.stdout[-300:] + ref.stderr[-300:]))
+    out["reference_stages"] = [l.replace("[harness] ", "") for l in (ref.stdout + ref.stderr).split("\n") if l.startswith("[harness]") and " DP" in l]
     t0 = time.perf_counter()
-    mine = subprocess.run([exe, "pair", prefix, f1, f2] + opts + ["-o", os.path.join(work, "sub")], capture_output=True, text=True, timeout=900)
+    mine = subprocess.run([exe, "pair", prefix, f1, f2] + opts + ["-o", os.path.join(work, "sub")], capture_output=True, text=True, timeout=900,
+                          env=dict(os.environ, S3DP_VERBOSE="1") if os.environ.get("S3DP_BENCH_DP_VERBOSE") else None)
+    if os.environ.get("S3DP_BENCH_DP_VERBOSE"):
+        out["command_line_stages"] = [l[:300] for l in mine.stderr.split("\n") if "deep DP stage" in l or "default DP call" in l][:40]
     out["command_line_s"] = time.perf_counter() - t0
     if mine.returncode != 0:
         return dict(out, error="soap3-dp pair failed on the sample: " + mine.stderr[-300:])
-    total, differing, files = 0, [], {}
+    total, differing, files, names_differing = 0, [], {}, set()
     for kind in ("gout.1", "dpout.1", "unpair"):
         def recs(p, fix_sign=False):
             if not os.path.exists(p):
@@ -450,10 +454,11 @@ def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_
             differing.append("%s, %s: %s" % (kind, tag_, "\t".join(l.split("\t")[:9] + l.split("\t")[11:])[:400]))
         if a != b_:
             files[kind]["equal"] = False
+            names_differing.update(l.split("\t", 1)[0] for l in list((a - b_).elements()) + list((b_ - a).elements()))
     routes = {k: int(v) for k, v in re.findall(r"(Number of pairs aligned by new default DP|Number of pairs aligned by DP|Number of pairs aligned by deep DP|Pairs left without a proper pairing): (\d+)", mine.stdout)}
     out["position_note"] = ("the reference prints POS / PNEXT beyond 2^31 as negative numbers (32-bit signed positions; the benchmark genome is ONE sequence of 3.1 G bases): "
                             "they are compared after adding 2^32")
-    out.update({"records": int(total), "by_file": files, "routes_of_the_sample": routes, "differing_records": differing[:24], "bit_exact": not differing and total > 0,
+    out.update({"records": int(total), "by_file": files, "routes_of_the_sample": routes, "differing_pairs": len(names_differing), "differing_records": differing[:24], "bit_exact": not differing and total > 0,
                 "seconds": time.perf_counter() - t_all,
                 "what": "pairs of this run, stratified by route, through the reference's own host pipeline (oracle/_ref/ref_harness) on the same index files and through the "
                         "command line again: the records of .gout / .dpout / .unpair as multisets"})
@@ -1586,7 +1591,7 @@ def summary_of(out):
                "both_mates_at_simulated_place": g(leg, "truth_check", "pairs_with_both_mates_at_simulated_place")}
         dpc = leg.get("dp_oracle_check")
         if isinstance(dpc, dict):
-            rec["dp_oracle_check"] = {k: dpc.get(k) for k in ("pairs", "records", "bit_exact", "strata", "routes_of_the_sample", "seconds", "error", "skipped") if dpc.get(k) is not None}
+            rec["dp_oracle_check"] = {k: dpc.get(k) for k in ("pairs", "records", "bit_exact", "differing_pairs", "strata", "routes_of_the_sample", "reference_stages", "seconds", "error", "skipped") if dpc.get(k) is not None}
         if "per_device" in e2e:
             rec["per_device"] = e2e["per_device"]
         sm[key] = rec
@@ -1595,8 +1600,8 @@ def summary_of(out):
                       ("%.3f" % rec["bwt_stage_frac"]) if rec["bwt_stage_frac"] else "-", ("%.0f" % rec["dp_GCUPS"]) if rec["dp_GCUPS"] else "-",
                       (", %.0f isolated" % rec["dp_isolated_GCUPS"]) if rec["dp_isolated_GCUPS"] else ""))
         if isinstance(dpc, dict):
-            lines.append("%s DP parity against the reference's own host pipeline on the same index files: %s" % (tag, ("%d pairs by route %r, %d records, bit-exact: %s" % (
-                dpc.get("pairs", 0), dpc.get("strata"), dpc.get("records", 0), dpc.get("bit_exact"))) if "records" in dpc else (dpc.get("error") or dpc.get("skipped"))))
+            lines.append("%s DP parity against the reference's own host pipeline on the same index files: %s" % (tag, ("%d pairs by route %r, %d records, bit-exact: %s (%d pairs differ)" % (
+                dpc.get("pairs", 0), dpc.get("strata"), dpc.get("records", 0), dpc.get("bit_exact"), dpc.get("differing_pairs", 0))) if "records" in dpc else (dpc.get("error") or dpc.get("skipped"))))
         sd = leg.get("single_default_mode")
         if isinstance(sd, dict) and "M_reads_per_s_reads_in_sam_out" in sd:
             sm[key + "_single_default_mode"] = {"reads": sd["reads"], "M_reads_per_s": sd["M_reads_per_s_reads_in_sam_out"], "wall_s": sd["wall_s"]}
@@ -1682,6 +1687,8 @@ def compact_line(out, full_path=None):
         if isinstance(leg, dict):
             s2[key] = {f: leg.get(f) for f in ("pairs", "seconds", "M_pairs_per_s", "bwt_stage_frac", "dp_GCUPS", "dp_isolated_GCUPS", "device_ms",
                                                "both_mates_at_simulated_place", "dp_oracle_check") if leg.get(f) is not None}
+            if isinstance(s2[key].get("dp_oracle_check"), dict):
+                s2[key]["dp_oracle_check"] = {f: v for f, v in s2[key]["dp_oracle_check"].items() if f in ("pairs", "records", "bit_exact", "differing_pairs", "error", "skipped")}
         else:
             ex = g(out, "extras", key)
             if isinstance(ex, dict):
