@@ -835,7 +835,7 @@ def extras(s3dp, ix, hi, codes, dev, rank, a):
     if a.c3_pairs > 0:
         try:
             res["c3_pairs"], res["_c3_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs, defer_cli=True, index_prefix=os.path.join(shared, "g.index"), single_too=True,
-                                                     dp_check=a.dp_check)
+                                                     dp_check=a.dp_check if a.c5_pairs <= 0 else 0)     # (C5's mixture holds C3's: the DP parity leg runs once, there)
         except Exception as e:
             res["c3_pairs"] = {"error": repr(e)}
         torch.cuda.empty_cache()

@@ -190,7 +190,7 @@ def pac_words_from_file(path, n=None):
     return buf.view(">u4").astype(np.uint32)
 
 
-def fmv_words(bwt_words, n, inverse_sa0, cum):
+def fmv_words(bwt_words, n, inverse_sa0, cum, use_gpu=None):
     """The words of a <prefix>.fmv / .rev.fmv file -- the occurrence arrays of the reference's CPU 2BWT (BWTGenerateOccValueFromBwt, 2bwt-lib/BWTConstruct.c:
     1037-1247; read back by BWTLoad, BWT.c:196-223): a sample every 256 BWT characters, 16 bits per symbol counted from the last MAJOR sample (every 65,536
     characters, 32 bits, absolute), two samples per word -- sample 2j in the high half, 2j + 1 in the low half --, the minor words first, then the majors.
@@ -208,10 +208,25 @@ def fmv_words(bwt_words, n, inverse_sa0, cum):
             lut[v, (v >> (2 * k)) & 3] += 1
     b = w.view(np.uint8)
     cnt = np.zeros((N - 1, 4), dtype=np.uint64)
+    dev = None
+    if use_gpu or (use_gpu is None and N > (1 << 20)):             # (a genome-scale text: the counting on the GPU when there is one -- 30 s of numpy otherwise)
+        try:
+            import torch
+            dev = torch.device("cuda") if torch.cuda.is_available() else None
+        except ImportError:
+            dev = None
     step = 1 << 18                                                 # intervals per piece (64 bytes each)
+    if dev is not None:
+        import torch
+        tl = torch.from_numpy(lut.astype(np.int32)).to(dev)
+        step = 1 << 21
     for i0 in range(0, N - 1, step):
         i1 = min(N - 1, i0 + step)
-        cnt[i0:i1] = lut[b[i0 * 64:i1 * 64]].reshape(i1 - i0, 64, 4).sum(axis=1)
+        if dev is not None:
+            tb = torch.from_numpy(b[i0 * 64:i1 * 64]).to(dev).long()
+            cnt[i0:i1] = tl[tb].reshape(i1 - i0, 64, 4).sum(dim=1).cpu().numpy().astype(np.uint64)
+        else:
+            cnt[i0:i1] = lut[b[i0 * 64:i1 * 64]].reshape(i1 - i0, 64, 4).sum(axis=1)
     absol = np.zeros((N, 4), dtype=np.uint64)
     np.cumsum(cnt, axis=0, out=absol[1:])
     n_major = (N + 255) // 256
