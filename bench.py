@@ -408,16 +408,27 @@ def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_
     ini = os.path.join(ROOT, "soap3-dp_amd", "host", "soap3-dp.ini")
     opts = ["-L", str(L), "-u", "500", "-v", "1", "-b", "2"]
     t0 = time.perf_counter()
-    ref = subprocess.run([harness, "sam", ini, "pair", prefix, f1, f2] + opts + ["-o", "ref"], cwd=work, capture_output=True, text=True, timeout=900)
+    dbg = bool(os.environ.get("S3DP_BENCH_DP_VERBOSE"))              # (a debugging aid: the DP problems and seeding calls of both sides, compared)
+    ref = subprocess.run([harness, "sam", ini, "pair", prefix, f1, f2] + opts + ["-o", "ref"], cwd=work, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, REFDP_DUMP=os.path.join(work, "ref.problems"), REFDP_SEED_DUMP=os.path.join(work, "ref.seeds")) if dbg else None)
     out["reference_s"] = time.perf_counter() - t0
     if ref.returncode != 0:
         return dict(out, error="ref_harness failed: " + (ref.stdout[-300:] + ref.stderr[-300:]))
     out["reference_stages"] = [l.replace("[harness] ", "") for l in (ref.stdout + ref.stderr).split("\n") if l.startswith("[harness]") and " DP" in l]
     t0 = time.perf_counter()
     mine = subprocess.run([exe, "pair", prefix, f1, f2] + opts + ["-o", os.path.join(work, "sub")], capture_output=True, text=True, timeout=900,
-                          env=dict(os.environ, S3DP_VERBOSE="1") if os.environ.get("S3DP_BENCH_DP_VERBOSE") else None)
-    if os.environ.get("S3DP_BENCH_DP_VERBOSE"):
+                          env=dict(os.environ, S3DP_VERBOSE="1", S3DP_DUMP_DP=os.path.join(work, "sub.problems"), S3DP_DP_THREADS="1") if dbg else None)
+    if dbg:
         out["command_line_stages"] = [l[:300] for l in mine.stderr.split("\n") if "deep DP stage" in l or "default DP call" in l][:40]
+        try:
+            out["reference_seeding_calls"] = open(os.path.join(work, "ref.seeds")).read().split("\n")[:12]
+            rp = Counter(l.split(" | ")[0] for l in open(os.path.join(work, "ref.problems")) if l.startswith("P"))
+            mp = Counter(l.split(" | ")[0] for l in open(os.path.join(work, "sub.problems")) if l.startswith("P"))
+            only_r, only_m = list((rp - mp).elements()), list((mp - rp).elements())
+            out["dp_problems"] = {"reference": sum(rp.values()), "command_line": sum(mp.values()), "only_in_reference": len(only_r), "only_in_command_line": len(only_m),
+                                  "examples_only_in_reference": [" ".join(x.split(" ")[:8]) + " " + x.split(" ")[8][:40] + "... " + x.split(" ")[9][:30] + "..." for x in only_r[:6]]}
+        except Exception as e:
+            out["dp_problems"] = {"error": repr(e)}
     out["command_line_s"] = time.perf_counter() - t0
     if mine.returncode != 0:
         return dict(out, error="soap3-dp pair failed on the sample: " + mine.stderr[-300:])

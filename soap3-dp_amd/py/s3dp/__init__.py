@@ -219,7 +219,6 @@ def fmv_words(bwt_words, n, inverse_sa0, cum, use_gpu=None):
     if dev is not None:
         import torch
         tl = torch.from_numpy(lut.astype(np.int32)).to(dev)
-        step = 1 << 21
     for i0 in range(0, N - 1, step):
         i1 = min(N - 1, i0 + step)
         if dev is not None:

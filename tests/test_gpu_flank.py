@@ -82,7 +82,7 @@ def test_fmv_words_counted_on_the_gpu_equal_numpy():
     """s3dp.fmv_words (the CPU 2BWT's occurrence arrays, written for the reference's own host code: bench.py's DP parity leg) counts on the GPU for genome-scale
     texts; the same words as the numpy path (which tests/test_builder.py holds byte-identical to the reference builder's files)"""
     rng = np.random.default_rng(4)
-    n = 40_000_123
+    n = 200_000_123                                              # (several pieces of 2^18 intervals)
     words = rng.integers(0, 1 << 32, size=(n + 15) // 16, dtype=np.uint64).astype(np.uint32)
     words[-1] &= np.uint32(0xFFFFFFFF) << np.uint32(2 * (16 - n % 16))      # the trailing bits of the last word are clear, as in a .bwt file
     cum = [0, 10, 20, 30, n]
