@@ -260,8 +260,9 @@ int  s3_dp_deep(s3_dp *h, s3_batch *b, s3_batch *seedBatch, const uint32_t *read
                 s3_dp_deep_result **results, size_t *nResults, char **cigarPool, uint8_t **tooManyHits);
 
 /* ---- new default DP: pairs with an end the BWT stage aligned to too many places for the default DP ----------------------------------------
- * Replaces newSemiGlobalDP (DV-SemiDP.cu:345; SemiDPWrapper::run2 -> newDefaultDP :237-246): the aligned end's hits are taken as they are
- * (PairEndSeedingBatch::packSeedsOneSide, DV-DPfunctions.cu:2756-2776), only its mate is seeded (S3_STAGE_NEW_DEFAULT_DP), both lists go through the
+ * Replaces newSemiGlobalDP (DV-SemiDP.cu:345; SemiDPWrapper::run2 -> newDefaultDP :237-246): the aligned end's hits are taken as they are and join the
+ * seed positions of BOTH ends (PairEndSeedingEngine's driver, DV-DPfunctions.cu:3056-3079, calls PairEndSeedingBatch::packSeeds ( occ, stage ) :2709-2731,
+ * which packs the seeds of both reads of the pair -- packSeedsOneSide :2733-2776 has no caller; S3_STAGE_NEW_DEFAULT_DP), both lists go through the
  * deep DP's pairing and its two DP rounds (pairEndMerge, PairEndAlignmentEngine), so BOTH ends are aligned by the DP and the results are deep-DP
  * results.  occ: the aligned ends' hits, grouped by pair, pairs ascending (the ReadInputForDP stream).  pairFirstReads / pairFlags (optional
  * outputs): the pairs found in occ and their flags as in s3_dp_deep.  Pinned through the reference's own engines
