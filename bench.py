@@ -429,6 +429,7 @@ def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_
             odd = sorted({x.split(" ")[8] for x in only_r + only_m})
             out["dp_problems_by_read"] = [{"read": r_[:24] + "...", "len": len(r_), "reference": by_read_r.get(r_, 0), "command_line": by_read_m.get(r_, 0),
                                            "shapes_only_in_reference": sorted({" ".join(x.split(" ")[1:8]) for x in only_r if x.split(" ")[8] == r_})[:4]} for r_ in odd[:12]]
+            out["dp_problems_only_in_reference_that_the_command_line_also_submits_once"] = sum(1 for x in only_r if x in mp)
             out["dp_problems"] = {"reference": sum(rp.values()), "command_line": sum(mp.values()), "only_in_reference": len(only_r), "only_in_command_line": len(only_m),
                                   "examples_only_in_reference": [" ".join(x.split(" ")[:8]) + " " + x.split(" ")[8][:40] + "... " + x.split(" ")[9][:30] + "..." for x in only_r[:6]]}
         except Exception as e:
