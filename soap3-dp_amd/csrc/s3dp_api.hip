@@ -60,8 +60,8 @@ hipError_t s3i::scratchAlloc(void **p, size_t bytes, hipStream_t stream)
         }
     } else {
         if ((e = hipMalloc(&got.p, want)) != hipSuccess) {
-            s3i::scratchTrim(dev);                              // the cache may hold what is missing
-            if ((e = hipMalloc(&got.p, want)) != hipSuccess) return e;
+            s3i::scratchTrim(dev);                              // the cache may hold what is missing; then the flank tables give way (s3_index::flankMu)
+            if ((e = s3i::mallocOrRelease(dev, &got.p, want)) != hipSuccess) return e;
         }
         got.bytes = want;
     }
@@ -218,6 +218,52 @@ static int uploadHalf(s3_index *ix, const s3_bwt_desc &h, DevBwt *out, hipStream
 
 static int indexUploadBody(s3_index *ix, const s3_index_desc *desc, hipStream_t s);
 
+// ---- the flank tables give way to batches and aligners (s3_index::flankMu) ----
+static std::mutex g_indexesMu;
+static std::vector<s3_index *> g_indexes;                               // every resident index of the process
+
+bool s3i::releaseFlankTable(int dev)
+{
+    s3_index *owner = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_indexesMu);
+        for (s3_index *ix : g_indexes) if (ix->dev == dev && (ix->d.flankFwd || ix->d.flankBack)) { owner = ix; break; }
+        if (!owner) return false;
+        // (the registry's lock is held to the end: the index cannot be freed under this)
+        std::unique_lock<std::shared_mutex> w(owner->flankMu);
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();                                    // every launch that read the tables was enqueued under the shared lock: done now
+        const void *gone = owner->d.flankFwd ? (const void *)owner->d.flankFwd : (const void *)owner->d.flankBack;
+        const bool wasFwd = owner->d.flankFwd != nullptr;
+        if (wasFwd) owner->d.flankFwd = nullptr; else owner->d.flankBack = nullptr;
+        for (void *&a : owner->allocs) if (a == gone) a = nullptr;
+        (void)hipFree(const_cast<void *>(gone));
+        const size_t bytes = ((size_t)owner->d.n + 1u) * sizeof(uint4);
+        owner->bytes = owner->bytes > bytes ? owner->bytes - bytes : 0;
+        (void)hipSetDevice(cur);
+        fprintf(stderr, "[s3dp] device %d is out of memory: the flank table of check-and-extend in the order of the %s index (%.1f GB) is released; its tasks are verified from "
+                        "the suffix array and the text from here on (same records; S3DP_FLANK, S3DP_FLANK_RESERVE_GB)\n", dev, wasFwd ? "reverse" : "forward", bytes / 1e9);
+    }
+    return true;
+}
+
+hipError_t s3i::mallocOrRelease(int dev, void **q, size_t bytes)
+{
+    // (tests: S3DP_TEST_OOM_EVERY=n makes every n-th allocation of the process find the device full at its first attempt)
+    static const size_t oomEvery = envSize("S3DP_TEST_OOM_EVERY", 0);
+    static std::atomic<size_t> calls{0};
+    bool pretend = oomEvery && (++calls % oomEvery) == 0;
+    for (;;) {
+        const hipError_t e = pretend ? hipErrorOutOfMemory : hipMalloc(q, bytes);
+        pretend = false;
+        if (e != hipErrorOutOfMemory) return e;
+        (void)hipGetLastError();
+        if (!releaseFlankTable(dev)) return e;
+    }
+}
+
 extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index **outp)
 {
     if (!desc || !outp) return fail(S3_EINVAL, "null argument");
@@ -240,6 +286,7 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     const int rc = indexUploadBody(ix, desc, s);
     (void)hipStreamDestroy(s);
     if (rc) { s3_index_free(ix); return rc; }
+    { std::lock_guard<std::mutex> g(g_indexesMu); g_indexes.push_back(ix); }
     *outp = ix;
     return S3_OK;
 }
@@ -370,19 +417,21 @@ static int indexUploadBody(s3_index *ix, const s3_index_desc *desc, hipStream_t 
 extern "C" void s3_index_free(s3_index *ix)
 {
     if (!ix) return;
+    { std::lock_guard<std::mutex> g(g_indexesMu); for (size_t k = 0; k < g_indexes.size(); k++) if (g_indexes[k] == ix) { g_indexes.erase(g_indexes.begin() + k); break; } }
     (void)hipSetDevice(ix->dev);
     s3i::scratchTrim(ix->dev);
-    for (void *p : ix->allocs) (void)hipFree(p);
+    for (void *p : ix->allocs) if (p) (void)hipFree(p);
     delete ix;
 }
 
 extern "C" size_t s3_index_device_bytes(const s3_index *ix) { return ix ? ix->bytes : 0; }
 extern "C" int s3_index_lookup_chars(const s3_index *ix) { return !ix ? 0 : ix->d.ltK ? ix->d.ltK : ix->d.ltSize; }
-extern "C" int s3_index_flank_tables(const s3_index *ix) { return !ix ? 0 : (ix->d.flankBack ? 1 : 0) + (ix->d.flankFwd ? 1 : 0); }
+extern "C" int s3_index_flank_tables(const s3_index *ix) { return !ix ? 0 : (ix->d.flankBack ? 1 : 0) + (ix->d.flankFwd ? 1 : 0); }     // (a table can be released later: s3_index::flankMu)
 
 extern "C" int s3_index_fetch_flank(s3_index *ix, int table, uint32_t first, uint32_t count, uint32_t *out)
 {
     if (!ix || !out) return fail(S3_EINVAL, "null argument");
+    std::shared_lock<std::shared_mutex> r(ix->flankMu);
     const uint4 *t = table == 0 ? ix->d.flankBack : table == 1 ? ix->d.flankFwd : nullptr;
     if (!t) return fail(S3_EINVAL, "s3_index_fetch_flank: the index holds no such table");
     if ((uint64_t)first + count > (uint64_t)ix->d.n + 1u) return fail(S3_EINVAL, "s3_index_fetch_flank: beyond the table");
@@ -809,11 +858,14 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
                 HIPCHK(mark(b->evCe, b->evCeUsed, true, 3));
                 out.counters = countersOf(3);
                 // (S3DP_FLANK is read here too: 0 / 1 make ceKernel ignore tables the index holds -- A/B runs and the tests' matrix on one resident index)
-                DevIndex dce = b->ix->d;
-                const size_t useFlank = envSize("S3DP_FLANK", 2);
-                if (useFlank < 2) dce.flankFwd = nullptr;
-                if (useFlank < 1) dce.flankBack = nullptr;
-                launchCheckExtend(dce, in, out, b->dTaskRange, b->stream);
+                {
+                    std::shared_lock<std::shared_mutex> r(b->ix->flankMu);   // (the tables cannot be released between this copy and the launch; s3_index::flankMu)
+                    DevIndex dce = b->ix->d;
+                    const size_t useFlank = envSize("S3DP_FLANK", 2);
+                    if (useFlank < 2) dce.flankFwd = nullptr;
+                    if (useFlank < 1) dce.flankBack = nullptr;
+                    launchCheckExtend(dce, in, out, b->dTaskRange, b->stream);
+                }
                 HIPCHK(mark(b->evCe, b->evCeUsed, false, 3));
                 HIPCHK(hipMemcpyAsync(b->dTaskRange, b->dRecCount, 4, hipMemcpyDeviceToDevice, b->stream));
                 return S3_OK;

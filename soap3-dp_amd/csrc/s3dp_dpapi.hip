@@ -40,7 +40,7 @@ template <class T>
 static int dalloc(s3_dp *h, T **p, size_t count)
 {
     void *q = nullptr;
-    hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
+    hipError_t e = s3i::mallocOrRelease(h->dev, &q, count * sizeof(T) + 64);    // (an aligner's tables before the flank tables of check-and-extend: s3_index::flankMu)
     if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(dp): ") + hipGetErrorString(e));
     h->allocs.push_back(q);
     *p = (T *)q;

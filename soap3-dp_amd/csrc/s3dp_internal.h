@@ -6,6 +6,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <shared_mutex>
 #include "../../include/s3dp.h"
 #include "s3dp_device.h"
 #include "s3dp_model.h"
@@ -39,6 +40,11 @@ void scratchStreamGone(hipStream_t stream);               // the owner of `strea
 struct s3_index {
     int       dev = 0;
     s3::DevIndex  d{};
+    // The flank tables of check-and-extend (d.flankBack / d.flankFwd, 2 x 16 B per suffix-array entry) are a convenience the device may not have room for once the
+    // batches grow: an allocation of this library that finds the device full releases them -- the reverse index's first -- and tries again (mallocOrRelease);
+    // their tasks then take the suffix array and the text, as all did until round 6.  Launches that read the tables hold this lock shared while they are enqueued;
+    // the release takes it exclusively and waits for the device before it frees.
+    std::shared_mutex flankMu;
     std::vector<void *> allocs;
     S3Model  *models[S3_MAX_MISMATCH + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // device, indexed by read length
     size_t    bytes = 0;
@@ -148,13 +154,17 @@ struct s3_dp {
 };
 
 namespace s3i {
+// hipMalloc; on hipErrorOutOfMemory the flank tables of an index on this device are released one at a time and the allocation is tried again (s3dp_api.hip)
+hipError_t mallocOrRelease(int dev, void **q, size_t bytes);
+bool releaseFlankTable(int dev);
+
 template <class T>
 inline int balloc(s3_batch *b, T **p, size_t count)
 {
     void *q = nullptr;
     size_t bytes = count * sizeof(T);
     if (!bytes) bytes = 16;
-    hipError_t e = hipMalloc(&q, bytes);
+    hipError_t e = mallocOrRelease(b->ix->dev, &q, bytes);
     if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch): ") + hipGetErrorString(e));
     b->allocs.push_back(q);
     *p = (T *)q;
@@ -183,7 +193,7 @@ inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
             if (e0 != hipSuccess) { b->failed = true; return fail(S3_EHIP, std::string("grow (free): ") + hipGetErrorString(e0)); }
             for (auto &a : b->allocs) if (a == (void *)*p) a = nullptr;
             *p = nullptr;
-            e0 = refuse ? hipErrorOutOfMemory : hipMalloc(&q, newCount * sizeof(T));
+            e0 = refuse ? hipErrorOutOfMemory : mallocOrRelease(b->ix->dev, &q, newCount * sizeof(T));
             if (e0 != hipSuccess) {
                 (void)hipGetLastError();
                 b->failed = true;                                     // the old buffer is gone and there is no new one
@@ -201,7 +211,7 @@ inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
         *p = (T *)q;
         return S3_OK;
     }
-    hipError_t e = hipMalloc(&q, newCount * sizeof(T));
+    hipError_t e = mallocOrRelease(b->ix->dev, &q, newCount * sizeof(T));
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(S3_ENOMEM, std::string("hipMalloc(batch grow, ") + std::to_string(newCount * sizeof(T) >> 20) + " MB): " + hipGetErrorString(e)); }
     e = hipMemcpyAsync(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);

@@ -1,6 +1,8 @@
 """gpu: the flank tables of check-and-extend (csrc/s3dp_flank.hip) against a suffix sort -- flankBack[k] = {SA[k], the 48 characters before SA[k], nearest first},
 flankFwd[k'] = {E, the 48 characters from E on} in the order of the REVERSE index, which the upload finds by walking LF steps of the reverse index along the text
 from anchors.  The expected tables come from numpy: the forward suffix array is the index file's, the reverse index's order from sorting the reversed text."""
+import os
+
 import numpy as np
 import pytest
 
@@ -89,3 +91,42 @@ def test_fmv_words_counted_on_the_gpu_equal_numpy():
     a = s3dp.fmv_words(words, n, 12345, cum, use_gpu=False)
     b = s3dp.fmv_words(words, n, 12345, cum, use_gpu=True)
     assert a.dtype == b.dtype and (a == b).all() and len(a) > 5 + n // 128
+
+
+def test_the_tables_give_way_when_the_device_is_full():
+    """An allocation of a batch that finds the device full releases the flank tables one at a time and tries again (a 10 M-read batch of a satellite-heavy genome
+    outgrew the 69 GB beside the 219 GB index: round 6).  S3DP_TEST_OOM_EVERY makes every n-th allocation pretend; the search goes on with fewer tables and the
+    same records.  (Own process: the switch is read once.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, os.path.join(%r, "soap3-dp_amd", "py"))
+import os
+
+import numpy as np
+import s3dp, s3o
+from conftest import host_index, golden_reads
+hi = host_index("g1")
+ix = s3dp.Index(hi)
+assert ix.flank_tables() == 2
+reads = golden_reads("g1")[:800]
+q, lens, wpq = s3dp.pack_reads(reads, 100)
+oix = s3o.Index(host_index=hi)
+want = oix.align_single_allbest(q, lens, wpq, 3, 1000)
+seen = set()
+for rnd in range(4):
+    b = s3dp.Batch(ix, len(reads), wpq)
+    b.upload(q, lens)
+    b.align_single_allbest(3, 1000)
+    got = b.fetch_alignments()
+    assert (got[0] == want[0]).all() and (got[2] == want[2]).all() and all((got[k] == want[k]).all() for k in (3, 4, 5))
+    b.close()
+    seen.add(ix.flank_tables())
+assert ix.flank_tables() == 0 and seen >= {0}, seen
+print("OK", sorted(seen))
+''' % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, S3DP_TEST_OOM_EVERY="7"))
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "is released" in out.stderr
