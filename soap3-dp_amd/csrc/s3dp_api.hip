@@ -255,9 +255,9 @@ hipError_t s3i::mallocOrRelease(int dev, void **q, size_t bytes)
     static const size_t oomEvery = envSize("S3DP_TEST_OOM_EVERY", 0);
     static std::atomic<size_t> calls{0};
     bool pretend = oomEvery && (++calls % oomEvery) == 0;
+    if (pretend) (void)releaseFlankTable(dev);                          // (pretended: a table goes, if there is one, and the allocation is made for real)
     for (;;) {
-        const hipError_t e = pretend ? hipErrorOutOfMemory : hipMalloc(q, bytes);
-        pretend = false;
+        const hipError_t e = hipMalloc(q, bytes);
         if (e != hipErrorOutOfMemory) return e;
         (void)hipGetLastError();
         if (!releaseFlankTable(dev)) return e;
