@@ -363,6 +363,34 @@ def write_fastq_pairs(reads2d_np, L, path1, path2):
         rec.tofile(path)
 
 
+def sam_records(p, fix_sign=False):
+    """the records of a SAM file as a multiset (collections.Counter of lines), headers apart"""
+    from collections import Counter
+    if not os.path.exists(p):
+        return Counter()
+    c = Counter()
+    for l in open(p).read().split("\n"):
+        if not l or l.startswith("@"):
+            continue
+        f = l.split("\t")
+        if len(f) > 8 and f[8].lstrip("-").isdigit() and abs(int(f[8])) >= 1 << 31:
+            # (likewise TLEN of two ends more than 2^31 apart -- never a proper pair: both sides are compared as the 32-bit signed number the reference prints)
+            t = int(f[8]) & 0xFFFFFFFF
+            f[8] = str(t - (1 << 32) if t >= 1 << 31 else t)
+            l = "\t".join(f)
+        if fix_sign:
+            # the reference's record holds positions as 32-bit SIGNED integers (samtools' bam1_core_t.pos): on this benchmark's ONE sequence of 3.1 G
+            # bases everything beyond 2^31 prints negative (GRCh38's longest chromosome is 0.25 G: the reference never sees such a position).  The
+            # command line prints the position; for the comparison the reference's negative POS / PNEXT get their 2^32 back.
+            f = l.split("\t")
+            for k in (3, 7):
+                if len(f) > k and f[k].startswith("-"):
+                    f[k] = str(int(f[k]) + (1 << 32))
+            l = "\t".join(f)
+        c[l] += 1
+    return c
+
+
 def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_sample, exe):
     """DP parity at the size the DP stages are benchmarked at: pairs drawn from THIS run -- stratified by where the run's records ended
     (BWT stage / DP stages / no proper pairing) and by what was simulated into them (an indel in one mate: default DP; both mates damaged: deep DP; neither:
@@ -439,31 +467,7 @@ def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_
         return dict(out, error="soap3-dp pair failed on the sample: " + mine.stderr[-300:])
     total, differing, files, names_differing = 0, [], {}, set()
     for kind in ("gout.1", "dpout.1", "unpair"):
-        def recs(p, fix_sign=False):
-            if not os.path.exists(p):
-                return Counter()
-            c = Counter()
-            for l in open(p).read().split("\n"):
-                if not l or l.startswith("@"):
-                    continue
-                f = l.split("\t")
-                if len(f) > 8 and f[8].lstrip("-").isdigit() and abs(int(f[8])) >= 1 << 31:
-                    # (likewise TLEN of two ends more than 2^31 apart -- never a proper pair: both sides are compared as the 32-bit signed number the reference prints)
-                    t = int(f[8]) & 0xFFFFFFFF
-                    f[8] = str(t - (1 << 32) if t >= 1 << 31 else t)
-                    l = "\t".join(f)
-                if fix_sign:
-                    # the reference's record holds positions as 32-bit SIGNED integers (samtools' bam1_core_t.pos): on this benchmark's ONE sequence of 3.1 G
-                    # bases everything beyond 2^31 prints negative (GRCh38's longest chromosome is 0.25 G: the reference never sees such a position).  The
-                    # command line prints the position; for the comparison the reference's negative POS / PNEXT get their 2^32 back.
-                    f = l.split("\t")
-                    for k in (3, 7):
-                        if len(f) > k and f[k].startswith("-"):
-                            f[k] = str(int(f[k]) + (1 << 32))
-                    l = "\t".join(f)
-                c[l] += 1
-            return c
-        a, b_ = recs(os.path.join(work, "ref." + kind), True), recs(os.path.join(work, "sub." + kind))
+        a, b_ = sam_records(os.path.join(work, "ref." + kind), True), sam_records(os.path.join(work, "sub." + kind))
         files[kind] = {"reference_records": int(sum(a.values())), "records": int(sum(b_.values()))}
         total += sum(a.values())
         for tag_, l in [("reference only", x) for x in list((a - b_).elements())[:6]] + [("command line only", x) for x in list((b_ - a).elements())[:6]]:
@@ -483,8 +487,93 @@ def dp_reference_check(work, prefix, hi, reads_np, L, in_file, tindel, tboth, n_
     return out
 
 
+def single_dp_reference_check(work, prefix, hi, reads_np, L, out_prefix, tindel, tboth, n_sample, exe):
+    """the single-end twin of dp_reference_check: first mates of THIS run as single reads in the default mode (reads above 120 bases: 100-base seeds in the
+    BWT stage, verified over their whole length; what stays unaligned goes through the single-end DP, DV-DPForSingleReads.cu) -- stratified by where the run's
+    records ended (BWT stage / DP stage aligned / DP stage unaligned) and by what was simulated into the read -- through the reference's own host pipeline
+    (oracle/_ref/ref_harness sam ... single) on the same 3.1 Gbp index files and through the command line again: .gout.1 and .dpout.1 must hold the same
+    records."""
+    import io
+    import subprocess
+    import pandas as pd
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.path.exists(harness):
+        return {"skipped": "oracle/_ref/ref_harness is not built"}
+    t_all = time.perf_counter()
+    rng = np.random.default_rng(9)
+    where = {}
+    for kind in ("gout.1", "dpout.1"):
+        p_ = out_prefix + "." + kind
+        if not os.path.exists(p_) or os.path.getsize(p_) == 0:
+            continue
+        cut = subprocess.run("grep -v '^@' %s | cut -f1,2" % p_, shell=True, capture_output=True)
+        if not cut.stdout:
+            continue
+        df = pd.read_csv(io.BytesIO(cut.stdout), sep="\t", header=None, names=["q", "flag"], dtype={"q": np.int64, "flag": np.int64})
+        prim = df[(df.flag & 0x900) == 0]
+        where[kind] = (prim.q.values, (prim.flag.values & 4) != 0)
+    none = (np.zeros(0, dtype=np.int64), np.zeros(0, dtype=bool))
+    gq, _ = where.get("gout.1", none)
+    dq, dun = where.get("dpout.1", none)
+    first_indel = tindel[0::2]
+    dal = dq[~dun]
+    strata = [("bwt_stage", gq), ("dp_read_with_indel", dal[first_indel[dal]]), ("dp_read_damaged", dal[tboth[dal] & ~first_indel[dal]]),
+              ("dp_neither", dal[~first_indel[dal] & ~tboth[dal]]), ("dp_unaligned", dq[dun])]
+    per = max(1, n_sample // len(strata))
+    chosen, tags = [], {}
+    for tag, idx in strata:
+        if len(idx) > per:
+            idx = rng.choice(idx, size=per, replace=False)
+        tags[tag] = int(len(idx))
+        chosen.append(np.asarray(idx, dtype=np.int64))
+    sel = np.unique(np.concatenate(chosen))
+    out = {"reads": int(len(sel)), "strata": tags}
+    if len(sel) == 0:
+        return dict(out, skipped="no reads to draw from")
+    fq = os.path.join(work, "ss.fq")
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(fq, "w") as f:
+        for p_ in sel:
+            f.write("@%09d\n%s\n+\n%s\n" % (p_, letters[reads_np[2 * p_]].tobytes().decode(), "I" * L))
+    t0 = time.perf_counter()
+    if not os.path.exists(prefix + ".fmv"):
+        hi.write_fmv_files(prefix)
+    out["fmv_files_s"] = time.perf_counter() - t0
+    ini = os.path.join(ROOT, "soap3-dp_amd", "host", "soap3-dp.ini")
+    opts = ["-L", str(L), "-b", "2"]
+    t0 = time.perf_counter()
+    ref = subprocess.run([harness, "sam", ini, "single", prefix, fq] + opts + ["-o", "sref"], cwd=work, capture_output=True, text=True, timeout=900)
+    out["reference_s"] = time.perf_counter() - t0
+    if ref.returncode != 0:
+        return dict(out, error="ref_harness failed: " + (ref.stdout[-300:] + ref.stderr[-300:]))
+    out["reference_stages"] = [l.replace("[harness] ", "") for l in (ref.stdout + ref.stderr).split("\n") if l.startswith("[harness]") and " DP" in l]
+    t0 = time.perf_counter()
+    mine = subprocess.run([exe, "single", prefix, fq] + opts + ["-o", os.path.join(work, "ssub")], capture_output=True, text=True, timeout=900)
+    out["command_line_s"] = time.perf_counter() - t0
+    if mine.returncode != 0:
+        return dict(out, error="soap3-dp single failed on the sample: " + mine.stderr[-300:])
+    total, differing, files, names_differing = 0, [], {}, set()
+    for kind in ("gout.1", "dpout.1"):
+        a, b_ = sam_records(os.path.join(work, "sref." + kind), True), sam_records(os.path.join(work, "ssub." + kind))
+        files[kind] = {"reference_records": int(sum(a.values())), "records": int(sum(b_.values()))}
+        total += sum(a.values())
+        for tag_, l in [("reference only", x) for x in list((a - b_).elements())[:6]] + [("command line only", x) for x in list((b_ - a).elements())[:6]]:
+            differing.append("%s, %s: %s" % (kind, tag_, "\t".join(l.split("\t")[:9] + l.split("\t")[11:])[:400]))
+        if a != b_:
+            files[kind]["equal"] = False
+            names_differing.update(l.split("\t", 1)[0] for l in list((a - b_).elements()) + list((b_ - a).elements()))
+    sdp = re.search(r"Number of reads aligned by DP: (\d+)", mine.stdout)
+    out.update({"records": int(total), "by_file": files, "reads_aligned_by_dp_in_the_sample": int(sdp.group(1)) if sdp else None, "differing_reads": len(names_differing),
+                "differing_records": differing[:24], "bit_exact": not differing and total > 0, "seconds": time.perf_counter() - t_all,
+                "what": "first mates of this run as single reads in the default mode, stratified by route, through the reference's own host pipeline "
+                        "(oracle/_ref/ref_harness) on the same index files and through the command line again: the records of .gout / .dpout as multisets"})
+    if differing:
+        log("single-end DP parity check against the reference pipeline FAILED: %r" % differing[:3])
+    return out
+
+
 def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cli=False, both_frac=0.0, resident=True, index_prefix=None, single_too=False,
-           seed_offset=0, device_no=None, host_threads=None, truth=True, dp_check=0):
+           seed_offset=0, device_no=None, host_threads=None, truth=True, dp_check=0, single_dp_check=0):
     """BASELINE.json configs[2] as far as one GPU and the time budget of a default run go: n_pairs 2 x 150 bp pairs on the benchmark genome,
     `pair -u 500 -v 1`, DP stages ON, end to end through the drop-in command line (the DP stages are driven by its host code), plus the resident BWT
     stage of the same pairs through the library with the oracle check on a sample.  Reports pairs/s, the stages' wall and device times, the BWT stage's
@@ -717,6 +806,12 @@ def c3_leg(s3dp, ix, hi, codes, dev, n_pairs, workdir=None, echo=False, defer_cl
                     res["single_default_mode"] = {"reads": n_pairs, "read_len": L, "options": "single -L %d (default mode: BWT stage with 100-base seeds + single-end DP)" % L,
                                                   "wall_s": se_wall, "phases_s": sph, "M_reads_per_s_reads_in_sam_out": n_pairs / max(s_align, sph.get("Read load time", 0.0)) / 1e6,
                                                   "reads_aligned": int(sal.group(1)) if sal else None, "reads_aligned_by_dp": int(sdp.group(1)) if sdp else None}
+                    if single_dp_check > 0:
+                        try:
+                            res["single_default_mode"]["dp_oracle_check"] = single_dp_reference_check(work, prefix, hi, reads_np, L, os.path.join(work, "se"), tindel, tboth,
+                                                                                                      single_dp_check, exe)
+                        except Exception as e:
+                            res["single_default_mode"]["dp_oracle_check"] = {"error": repr(e)}
                 except Exception as e:
                     res["single_default_mode"] = {"error": repr(e)}
         finally:
@@ -851,7 +946,8 @@ def extras(s3dp, ix, hi, codes, dev, rank, a):
     if a.c3_pairs > 0:
         try:
             res["c3_pairs"], res["_c3_cli"] = c3_leg(s3dp, ix, hi, codes, dev, a.c3_pairs, defer_cli=True, index_prefix=os.path.join(shared, "g.index"), single_too=True,
-                                                     dp_check=a.dp_check if a.c5_pairs <= 0 else 0)     # (C5's mixture holds C3's: the DP parity leg runs once, there)
+                                                     dp_check=a.dp_check if a.c5_pairs <= 0 else 0,     # (C5's mixture holds C3's: the DP parity leg runs once, there)
+                                                     single_dp_check=a.dp_check)
         except Exception as e:
             res["c3_pairs"] = {"error": repr(e)}
         torch.cuda.empty_cache()
@@ -1146,7 +1242,8 @@ def measured_peaks(dev, local):
         own = max(own, 2.0 * (1 << 32) / (s3dp.probe_copy(1 << 32, repeats=4, device=local) / 1e3) / 1e9)
     ms, lines = s3dp.probe_gather(int(6e9), blocks=2048, iters=128, ilp=4, loads_per_line=1, device=local)
     return {"copy_GBps": max(best, own), "copy_GBps_own_kernel": own, "copy_GBps_torch_copy": best, "random_Glines_per_s": lines / ms / 1e6,
-            "how": "device-to-device copy, read + write bytes: s3_probe_copy (own kernel, 16 B per lane and access, 4 GiB, best of 3 x 4) and "
+            "how": "device-to-device copy, read + write bytes: s3_probe_copy (own kernels, 16 B per lane and access, the fastest of six shapes -- grid-stride or one "
+                   "workgroup per piece, 1/4/8 loads in flight, non-temporal or ordinary; 4 GiB, best of 3 x 4) and "
                    "torch.Tensor.copy_ (2 GiB, best of 3 x 4); s3_probe_gather over a 6 GB table, 4 independent 64-byte lines in flight per lane"}
 
 
@@ -1622,6 +1719,11 @@ def summary_of(out):
         if isinstance(sd, dict) and "M_reads_per_s_reads_in_sam_out" in sd:
             sm[key + "_single_default_mode"] = {"reads": sd["reads"], "M_reads_per_s": sd["M_reads_per_s_reads_in_sam_out"], "wall_s": sd["wall_s"]}
             lines.append("%s first mates, single -L %d default mode: %.2f M reads/s FASTQ in, SAM out" % (tag, sd["read_len"], sd["M_reads_per_s_reads_in_sam_out"]))
+            sdc = sd.get("dp_oracle_check")
+            if isinstance(sdc, dict):
+                sm[key + "_single_default_mode"]["dp_oracle_check"] = {k: sdc.get(k) for k in ("reads", "records", "bit_exact", "differing_reads", "strata", "error", "skipped") if sdc.get(k) is not None}
+                lines.append("%s first mates, single-end DP parity against the reference's own host pipeline: %s" % (tag, ("%d reads by route %r, %d records, bit-exact: %s (%d reads differ)" % (
+                    sdc.get("reads", 0), sdc.get("strata"), sdc.get("records", 0), sdc.get("bit_exact"), sdc.get("differing_reads", 0))) if "records" in sdc else (sdc.get("error") or sdc.get("skipped"))))
     for model, r in (ex.get("repeat_models") or {}).items():
         if isinstance(r, dict) and "M_reads_per_s" in r:
             sm.setdefault("repeat_models", {})[model] = {"M_reads_per_s": r["M_reads_per_s"], "ms_per_step": r["ms_per_step"]}
@@ -1712,6 +1814,8 @@ def compact_line(out, full_path=None):
     for key in ("repeat_models", "uniform_genome_M_reads_per_s", "streamed_vs_resident", "c3_pairs_single_default_mode"):
         if sm.get(key) is not None:
             s2[key] = sm[key]
+    if isinstance(g(s2, "c3_pairs_single_default_mode", "dp_oracle_check"), dict):
+        s2["c3_pairs_single_default_mode"] = dict(s2["c3_pairs_single_default_mode"], dp_oracle_check={f: v for f, v in s2["c3_pairs_single_default_mode"]["dp_oracle_check"].items() if f != "strata"})
     if isinstance(g(out, "extras", "error"), str):
         s2["extras_error"] = out["extras"]["error"][:160]
     line["summary"] = s2

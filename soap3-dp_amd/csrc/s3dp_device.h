@@ -272,7 +272,8 @@ void launchPairStats(const PairSweepArgs &a, hipStream_t s);
 void launchPairEmit(const PairSweepArgs &a, const uint32_t *xaOffsets, uint32_t xaBase, DevPairXa *xa, hipStream_t s);
 void launchPairGatherXa(uint32_t nPairs, const uint32_t *xaStart, const uint32_t *outOffsets, const DevPairXa *xa, DevPairXa *out, hipStream_t s);
 
-void launchCopyProbe(const uint4 *src, uint4 *dst, size_t n16, hipStream_t s);
+int copyProbeVariants();
+void launchCopyProbe(const uint4 *src, uint4 *dst, size_t n16, int variant, hipStream_t s);
 void launchGatherProbe(const uint4 *table, uint64_t nLines, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,
                        uint32_t *sink, hipStream_t s);
 

@@ -672,24 +672,58 @@ void launchClassify(uint32_t nActive, const uint32_t *totalOcc, const uint32_t *
 // ---------------------------------------------------------------------------------------------
 namespace s3 {
 
-// streaming copy, 16 bytes per lane and load, four independent loads in flight per lane
+// streaming copy, 16 bytes per lane and load, UNROLL independent loads in flight per lane.  Three shapes are
+// tried by s3_probe_copy, which reports the fastest: a grid-stride loop over a fixed grid with non-temporal
+// accesses, the same with ordinary accesses, and one workgroup per contiguous piece (no loop: the grid covers
+// the buffer, the shape of the guide's float4 copy).
 typedef uint32_t s3_v4u __attribute__((ext_vector_type(4)));
+template <int UNROLL, bool NT, bool COVER>
 __global__ void __launch_bounds__(256) copyProbeKernel(const s3_v4u *__restrict__ src, s3_v4u *__restrict__ dst, size_t n16)
 {
+    if (COVER) {
+        const size_t base = (size_t)blockIdx.x * (256 * UNROLL) + threadIdx.x;
+        s3_v4u v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++)
+            if (base + (size_t)k * 256 < n16) v[k] = NT ? __builtin_nontemporal_load(src + base + (size_t)k * 256) : src[base + (size_t)k * 256];
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++)
+            if (base + (size_t)k * 256 < n16) {
+                if (NT) __builtin_nontemporal_store(v[k], dst + base + (size_t)k * 256);
+                else dst[base + (size_t)k * 256] = v[k];
+            }
+        return;
+    }
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const s3_v4u a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        const s3_v4u c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        s3_v4u v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) v[k] = NT ? __builtin_nontemporal_load(src + i + k * stride) : src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) {
+            if (NT) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+            else dst[i + k * stride] = v[k];
+        }
     }
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 
-void launchCopyProbe(const uint4 *src, uint4 *dst, size_t n16, hipStream_t s)
+int copyProbeVariants() { return 6; }
+
+void launchCopyProbe(const uint4 *src, uint4 *dst, size_t n16, int variant, hipStream_t s)
 {
-    hipLaunchKernelGGL(copyProbeKernel, dim3(256 * 16), dim3(256), 0, s, (const s3_v4u *)src, (s3_v4u *)dst, n16);
+    const s3_v4u *a = (const s3_v4u *)src;
+    s3_v4u *b = (s3_v4u *)dst;
+    const dim3 blk(256);
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((copyProbeKernel<4, true, false>), dim3(256 * 16), blk, 0, s, a, b, n16); break;
+    case 1: hipLaunchKernelGGL((copyProbeKernel<4, false, false>), dim3(256 * 16), blk, 0, s, a, b, n16); break;
+    case 2: hipLaunchKernelGGL((copyProbeKernel<8, false, false>), dim3(256 * 8), blk, 0, s, a, b, n16); break;
+    case 3: hipLaunchKernelGGL((copyProbeKernel<1, false, true>), dim3((unsigned)((n16 + 255) / 256)), blk, 0, s, a, b, n16); break;
+    case 4: hipLaunchKernelGGL((copyProbeKernel<4, false, true>), dim3((unsigned)((n16 + 1023) / 1024)), blk, 0, s, a, b, n16); break;
+    default: hipLaunchKernelGGL((copyProbeKernel<4, true, true>), dim3((unsigned)((n16 + 1023) / 1024)), blk, 0, s, a, b, n16); break;
+    }
 }
 
 template <int ILP>
