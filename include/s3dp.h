@@ -173,6 +173,14 @@ int  s3_stream_submit(s3_stream *st, uint32_t n, int useSeedLengths, uint32_t nu
 int  s3_stream_next(s3_stream *st, s3_stream_result *res);
 int  s3_stream_release(s3_stream *st);
 void s3_stream_free(s3_stream *st);
+/* The streams' pinned host staging (the packed reads going in, the results and occurrence lists coming out) comes from a cache of the process: pinning is slow
+ * (0.2-0.4 s per GB) and no kernel of any HIP stream starts while the runtime pins.  s3_host_staging_reserve puts what `depth` slots of s3_stream_create(ix,
+ * maxReads, wordPerQuery, depth) pin into the cache ahead of time, with room for occPerRead occurrences per read in the lists (the soap3-dp executable: 48,
+ * while the index files are read); a slot takes the smallest block that fits and pins a fresh one when none does (a list that outgrows its block); blocks a
+ * stream gives back stay in the cache (up to 4 GB) until s3_host_staging_release.  No counterpart in the reference: its result buffers are pageable
+ * (alignment.cu:1005-1031 copies them back with cudaMemcpy). */
+int  s3_host_staging_reserve(uint32_t maxReads, uint32_t wordPerQuery, int depth, uint32_t occPerRead);
+void s3_host_staging_release(void);
 
 /* ---- several devices -------------------------------------------------------------------------------------------------------------
  * The reference takes ONE device (`-c <id>`, SOAP3-DP.cu:219-220, README.md:523-536).  The path shards by reads, so a group of devices each holds

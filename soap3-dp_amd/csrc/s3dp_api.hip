@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <map>
 #include <mutex>
+#include <thread>
 using namespace s3;
 using namespace s3i;
 
@@ -249,6 +250,38 @@ bool s3i::releaseFlankTable(int dev)
     return true;
 }
 
+namespace {
+struct Retired { std::mutex mu; std::vector<std::pair<int, void *>> list; size_t bytes[64] = {}; } g_retired;
+}
+
+bool s3i::freeRetired(int dev)
+{
+    std::vector<void *> mine;
+    {
+        std::lock_guard<std::mutex> g(g_retired.mu);
+        auto keep = g_retired.list.begin();
+        for (auto &e : g_retired.list) { if (e.first == dev) mine.push_back(e.second); else *keep++ = e; }
+        g_retired.list.erase(keep, g_retired.list.end());
+        if (dev >= 0 && dev < 64) g_retired.bytes[dev] = 0;
+    }
+    for (void *p : mine) (void)hipFree(p);
+    return !mine.empty();
+}
+
+void s3i::retireBuffer(int dev, void *p)
+{
+    if (!p) return;
+    size_t bytes = 0;
+    if (hipMemPtrGetInfo(p, &bytes) != hipSuccess) { (void)hipGetLastError(); bytes = 0; }
+    bool full = false;
+    {
+        std::lock_guard<std::mutex> g(g_retired.mu);
+        g_retired.list.emplace_back(dev, p);
+        if (dev >= 0 && dev < 64) full = (g_retired.bytes[dev] += bytes) > ((size_t)8 << 30);
+    }
+    if (full) (void)freeRetired(dev);
+}
+
 hipError_t s3i::mallocOrRelease(int dev, void **q, size_t bytes)
 {
     // (tests: S3DP_TEST_OOM_EVERY=n makes every n-th allocation of the process find the device full at its first attempt)
@@ -260,6 +293,7 @@ hipError_t s3i::mallocOrRelease(int dev, void **q, size_t bytes)
         const hipError_t e = hipMalloc(q, bytes);
         if (e != hipErrorOutOfMemory) return e;
         (void)hipGetLastError();
+        if (freeRetired(dev)) continue;                                 // (buffers that batches outgrew, kept so that nobody waited for hipFree)
         if (!releaseFlankTable(dev)) return e;
     }
 }
@@ -283,7 +317,11 @@ extern "C" int s3_index_upload(int device, const s3_index_desc *desc, s3_index *
     hipError_t es = hipStreamCreate(&s);
     if (es != hipSuccess) { delete ix; return fail(S3_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(es)); }
     // whatever goes wrong below: the object, its device memory (up to 120 GB with the 16-mer tables) and the stream are released
+    // (the code objects of the library's kernels are loaded meanwhile: s3dp_kernels.hip, preloadKernels; S3DP_PRELOAD_KERNELS=0: at their first launch, as the runtime does)
+    std::thread preload;
+    if (envSize("S3DP_PRELOAD_KERNELS", 1)) preload = std::thread([device] { if (hipSetDevice(device) == hipSuccess) preloadKernels(); (void)hipGetLastError(); });
     const int rc = indexUploadBody(ix, desc, s);
+    if (preload.joinable()) preload.join();
     (void)hipStreamDestroy(s);
     if (rc) { s3_index_free(ix); return rc; }
     { std::lock_guard<std::mutex> g(g_indexesMu); g_indexes.push_back(ix); }
@@ -485,6 +523,16 @@ int s3i::ensureOutLists(s3_batch *b, uint64_t need)
     return S3_OK;
 }
 
+void s3i::noteAlloc(const char *what, size_t bytes, std::chrono::steady_clock::time_point t0)
+{
+    static const bool verbose = getenv("S3DP_VERBOSE") != nullptr;
+    if (!verbose || bytes < (1u << 20)) return;
+    static const auto first = std::chrono::steady_clock::now();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[s3dp] %9.3f s  %s %8.1f MB  %7.2f ms\n", std::chrono::duration<double>(now - first).count(), what, bytes / 1048576.0,
+            std::chrono::duration<double, std::milli>(now - t0).count());
+}
+
 bool s3i::growRefused()
 {
     static std::atomic<long> left{[] { const char *e = getenv("S3DP_TEST_FAIL_GROW"); return e ? atol(e) : 0L; }()};
@@ -571,6 +619,7 @@ extern "C" void s3_batch_free(s3_batch *b)
     (void)hipSetDevice(b->ix->dev);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); s3i::scratchStreamGone(b->stream); }
     for (void *p : b->allocs) (void)hipFree(p);
+    (void)s3i::freeRetired(b->ix->dev);                                // (what this and other batches of the device outgrew: unused since the day it was retired)
     for (auto e : b->evSearch) if (e) (void)hipEventDestroy(e);
     for (auto e : b->evCe) if (e) (void)hipEventDestroy(e);
     for (auto e : b->evTotal) if (e) (void)hipEventDestroy(e);
@@ -649,6 +698,19 @@ extern "C" int s3_batch_enable_counters(s3_batch *b, int on)
     return S3_OK;
 }
 
+// The sort of (64-bit key, 32-bit slot) pairs.  rocPRIM's default Onesweep configuration for this shape on gfx950 (no tuned entry: 256 x 12 items, rank by match)
+// indexes a private array dynamically -- 80 bytes of SCRATCH per lane, and the first launch of a kernel with scratch on a HIP stream makes the runtime
+// reallocate the device's scratch buffer with every queue drained: 60 ms with the device idle, once per slot of a stream of batches (profiles/README_r06.md
+// section 8).  512 x 6 items keeps the array in registers (51 VGPRs, no scratch; compile with -Rpass-analysis=kernel-resource-usage to see).
+using ListedSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<512, 6>, 8,
+                                                                                        rocprim::block_radix_rank_algorithm::match>>;
+static hipError_t sortListed(void *temp, size_t &bytes, const unsigned long long *keysIn, unsigned long long *keysOut, const uint32_t *valsIn, uint32_t *valsOut,
+                             uint32_t n, hipStream_t s)
+{
+    return rocprim::radix_sort_pairs<ListedSortConfig>(temp, bytes, keysIn, keysOut, valsIn, valsOut, n, 0, 64, s);
+}
+
 // slots (nullptr: 0 .. n-1) ordered by the first 32 characters of their reads; the ordered slots are left in b->dOrderVals[1] (s3dp_unit.hip, "LOCALITY")
 int s3i::orderByReadPrefix(s3_batch *b, const uint32_t *slots, uint32_t n, const uint32_t *active, uint32_t stride, uint32_t words)
 {
@@ -663,7 +725,7 @@ int s3i::orderByReadPrefix(s3_batch *b, const uint32_t *slots, uint32_t n, const
         b->orderCap = cap;
     }
     size_t tb = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, b->dOrderKeys[0], b->dOrderKeys[1], b->dOrderVals[0], b->dOrderVals[1], (int)n, 0, 64, b->stream));
+    HIPCHK(sortListed(nullptr, tb, b->dOrderKeys[0], b->dOrderKeys[1], b->dOrderVals[0], b->dOrderVals[1], n, b->stream));
     if (tb + 256 > b->tempBytes) {
         int rc = bgrow(b, &b->dTemp, tb + 256, 0);
         if (rc) { b->tempBytes = 0; return rc; }
@@ -671,7 +733,7 @@ int s3i::orderByReadPrefix(s3_batch *b, const uint32_t *slots, uint32_t n, const
     }
     launchListedKeys(slots, n, active, b->dReadsT, stride, words, b->dOrderKeys[0], b->dOrderVals[0], b->stream);
     tb = b->tempBytes;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b->dTemp, tb, b->dOrderKeys[0], b->dOrderKeys[1], b->dOrderVals[0], b->dOrderVals[1], (int)n, 0, 64, b->stream));
+    HIPCHK(sortListed(b->dTemp, tb, b->dOrderKeys[0], b->dOrderKeys[1], b->dOrderVals[0], b->dOrderVals[1], n, b->stream));
     return S3_OK;
 }
 
@@ -1310,3 +1372,7 @@ extern "C" int s3_probe_gather(int device, size_t tableBytes, uint32_t blocks, u
     return S3_OK;
 }
 
+// this file's code object holds the rocPRIM / hipCUB kernels of the search pass (sums, scans, the sort of the listed reads): an empty kernel to ask for
+// (preloadKernels, s3dp_kernels.hip)
+__global__ void apiPreloadKernel() {}
+void s3::preloadApi() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)apiPreloadKernel); (void)hipGetLastError(); }

@@ -363,3 +363,6 @@ void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &
 }
 
 }  // namespace s3
+
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadCe() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)s3::ceKernel<false>); (void)hipGetLastError(); }

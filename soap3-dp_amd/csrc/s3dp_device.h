@@ -272,6 +272,10 @@ void launchPairStats(const PairSweepArgs &a, hipStream_t s);
 void launchPairEmit(const PairSweepArgs &a, const uint32_t *xaOffsets, uint32_t xaBase, DevPairXa *xa, hipStream_t s);
 void launchPairGatherXa(uint32_t nPairs, const uint32_t *xaStart, const uint32_t *outOffsets, const DevPairXa *xa, DevPairXa *out, hipStream_t s);
 
+// code objects loaded ahead of the first launch (s3dp_kernels.hip: preloadKernels; one function per file that holds kernels)
+void preloadKernels();
+void preloadFirst(); void preloadUnit(); void preloadCe(); void preloadApi(); void preloadLadder(); void preloadFlank(); void preloadPair(); void preloadRoute();
+void preloadSeed(); void preloadDp(); void preloadDpApi();
 int copyProbeVariants();
 void launchCopyProbe(const uint4 *src, uint4 *dst, size_t n16, int variant, hipStream_t s);
 void launchGatherProbe(const uint4 *table, uint64_t nLines, uint32_t blocks, uint32_t itersPerLane, int ilp, int loadsPerLine, int dependent,

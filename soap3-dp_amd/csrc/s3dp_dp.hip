@@ -666,3 +666,6 @@ int launchDp(const DpArgs &a0, hipStream_t s)
 }
 
 }  // namespace s3
+
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadDp() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)s3::dpBacktrackKernel); (void)hipGetLastError(); }

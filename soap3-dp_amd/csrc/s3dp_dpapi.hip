@@ -1016,3 +1016,5 @@ extern "C" int s3_dp_last_timing(s3_dp *h, float *ms)
     return S3_OK;
 }
 
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadDpApi() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)dpCellsKernel); (void)hipGetLastError(); }

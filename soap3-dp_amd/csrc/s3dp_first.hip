@@ -36,7 +36,9 @@ using namespace first;
 // range) ends it for every unit: positions it never reached keep no state.  Its records (tasks for ceKernel) count in the counter of the item's last
 // unit.  With in.unitsPerItem == 1 (no mismatch step to cut the item at: exact-match models; or S3DP_UNITS=0) the lane searches the whole item.
 template <bool UNIFORM, bool COUNT, bool TRUNK>
-__global__ void __launch_bounds__(S3_SEARCH_BLOCK, S3_FIRST_WAVES_PER_SIMD)
+// (the trunk role carries a few registers more than the first pass and is a thirtieth of a ladder's time: it gets the budget of three waves per SIMD instead of
+//  spilling three of them into scratch memory)
+__global__ void __launch_bounds__(S3_SEARCH_BLOCK, TRUNK ? S3_FIRST_WAVES_PER_SIMD - 1 : S3_FIRST_WAVES_PER_SIMD)
 firstKernel(DevIndex ix, SearchIn in, SearchOut out)
 {
     extern __shared__ __align__(16) unsigned char shmem[];
@@ -61,8 +63,9 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     const uint32_t U = TRUNK ? in.unitsPerItem : 1u;
     const bool onTrunk = TRUNK && U > 1u;                                   // the item is cut into units: the lane stays on the trunk
     const uint32_t nSlots = TRUNK ? nListed * groups : in.nActive;
-    uint32_t listed = 0;                                                    // (TRUNK) the lane's read in the list
-    int sStar = 0;                                                          // (TRUNK) the first step of the case that allows a mismatch
+    // (TRUNK) the lane's read in the list and the first step of its case that allows a mismatch are worked out where they are used (`listed`, `sStar` below):
+    // as two more registers per lane they were what pushed the trunk role of this kernel into scratch memory -- 16 bytes per lane, and with them the
+    // reallocation of the device's scratch buffer at the first launch on a stream (s3dp_api.hip, ListedSortConfig)
     uint4 *stk = out.unitStack + (size_t)(blockIdx.x * (S3_SEARCH_BLOCK / 64u) + wv) * S3_UNIT_STACK * 64u;     // frame d of lane k: stk[(d % S3_UNIT_STACK) * 64 + k]
 
     const unsigned long long tWave0 = COUNT ? wall_clock64() : 0ULL;        // (COUNT) the wave's own duration in 10 ns ticks
@@ -94,6 +97,8 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
     bool queueEmpty = false, basePending = false;
     uint32_t pendBase = 0, rdyCount = 0, rdyTaken = 0;
 
+#define listed (slotIdx - ((subN) & 0xFFu) * nListed)
+#define sStar ((int)((in.sStarPacked >> (3u * (((subN) & 0xFFu) >> 1))) & 7u))
 #define casIdx (((subN) & 0xFFu) >> 1)
 #define subIdx ((subN) & 0xFFu)
 #define strand ((subN) & 1u)
@@ -350,9 +355,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                 if constexpr (TRUNK) {
                     // queue order: item first, the read last (slot = item * listed reads + read)
                     const uint32_t sub = slotIdx / nListed, cas = sub >> 1;
-                    listed = slotIdx - sub * nListed;
                     subN = sub | ((in.nStepsPacked >> (3u * cas)) & 7u) << 8;
-                    sStar = (int)((in.sStarPacked >> (3u * cas)) & 7u);
                     cntIdx = in.unitBase + (listed * groups + sub) * U + (U - 1u);
                 }
                 readTotal = 0; readCand = 0; readRank = 0; goHeavy = false;
@@ -606,6 +609,8 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             __builtin_amdgcn_wave_barrier();
         }
     }
+#undef listed
+#undef sStar
 #undef casIdx
 #undef subIdx
 #undef strand
@@ -658,3 +663,6 @@ int launchFirstPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out
 int launchTrunkPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out, unsigned maxBlocks, hipStream_t s) { return launchFirstOrTrunk<true>(ix, in, out, maxBlocks, s); }
 
 }  // namespace s3
+
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadFirst() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)s3::firstKernel<true, false, false>); (void)hipGetLastError(); }

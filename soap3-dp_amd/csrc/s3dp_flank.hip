@@ -192,3 +192,6 @@ int launchFlankTables(DevIndex &d, int which, size_t reserveBytes, void **allocs
 }
 
 }  // namespace s3
+
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadFlank() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)s3::flankBackKernel); (void)hipGetLastError(); }

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <shared_mutex>
 #include "../../include/s3dp.h"
 #include "s3dp_device.h"
@@ -157,6 +158,13 @@ namespace s3i {
 // hipMalloc; on hipErrorOutOfMemory the flank tables of an index on this device are released one at a time and the allocation is tried again (s3dp_api.hip)
 hipError_t mallocOrRelease(int dev, void **q, size_t bytes);
 bool releaseFlankTable(int dev);
+// a buffer that was replaced by a larger one is not freed on the spot -- hipFree waits for EVERY stream of the device, and a batch that grows beside two
+// others in flight stalls all three (the first batches of a streamed run: a third of the device's time idle, profiles/README_r06.md section 8) -- but kept
+// on a list that is freed when a batch is freed, when it passes 8 GB, or when an allocation finds the device full (before a flank table gives way)
+void retireBuffer(int dev, void *p);
+bool freeRetired(int dev);
+// S3DP_VERBOSE: one line per allocation and growth of a batch's buffers -- when (since the first one), how large, how long it took (stderr)
+void noteAlloc(const char *what, size_t bytes, std::chrono::steady_clock::time_point t0);
 
 template <class T>
 inline int balloc(s3_batch *b, T **p, size_t count)
@@ -164,8 +172,10 @@ inline int balloc(s3_batch *b, T **p, size_t count)
     void *q = nullptr;
     size_t bytes = count * sizeof(T);
     if (!bytes) bytes = 16;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = mallocOrRelease(b->ix->dev, &q, bytes);
     if (e != hipSuccess) return fail(S3_ENOMEM, std::string("hipMalloc(batch): ") + hipGetErrorString(e));
+    noteAlloc("alloc", bytes, t0);
     b->allocs.push_back(q);
     *p = (T *)q;
     return S3_OK;
@@ -179,6 +189,7 @@ template <class T>
 inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
 {
     void *q = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if (!keep) {
         // nothing to carry over.  Try to allocate next to the old buffer; when that does not fit (the ordering buffer of a batch of reads from repeat
         // families is tens of gigabytes) the old buffer goes first.
@@ -186,6 +197,7 @@ inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
         if (e0 != hipSuccess) return fail(S3_EHIP, std::string("grow (sync): ") + hipGetErrorString(e0));
         const bool refuse = growRefused();                        // (tests: S3DP_TEST_FAIL_GROW=n makes the n-th growth of the process find the device full)
         e0 = refuse ? hipErrorOutOfMemory : hipMalloc(&q, newCount * sizeof(T));
+        if (e0 == hipErrorOutOfMemory && !refuse && freeRetired(b->ix->dev)) { (void)hipGetLastError(); e0 = hipMalloc(&q, newCount * sizeof(T)); }
         if (e0 != hipSuccess) {
             (void)hipGetLastError();
             q = nullptr;
@@ -207,8 +219,9 @@ inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
         bool placed = false;
         for (auto &a : b->allocs) if (*p && a == (void *)*p) { a = q; placed = true; }
         if (!placed) b->allocs.push_back(q);
-        (void)hipFree(*p);
+        retireBuffer(b->ix->dev, *p);
         *p = (T *)q;
+        noteAlloc("grow", newCount * sizeof(T), t0);
         return S3_OK;
     }
     hipError_t e = mallocOrRelease(b->ix->dev, &q, newCount * sizeof(T));
@@ -217,8 +230,9 @@ inline int bgrow(s3_batch *b, T **p, size_t newCount, size_t keep)
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess) { (void)hipFree(q); return fail(S3_EHIP, std::string("grow copy: ") + hipGetErrorString(e)); }
     for (auto &a : b->allocs) if (a == (void *)*p) a = q;
-    (void)hipFree(*p);
+    retireBuffer(b->ix->dev, *p);
     *p = (T *)q;
+    noteAlloc("grow (kept part copied)", newCount * sizeof(T), t0);
     return S3_OK;
 }
 

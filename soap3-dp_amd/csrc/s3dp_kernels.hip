@@ -742,10 +742,17 @@ __global__ void __launch_bounds__(256) gatherProbeKernel(const uint4 *table, uin
         }
 #pragma unroll
         for (int k = 0; k < ILP; k++) {
-            if (loadsPerLine >= 10) {                                   // 32-byte granules: does the memory system fetch less than 64 B for them?
+            if (loadsPerLine >= 10 && loadsPerLine < 20) {                                   // 32-byte granules: does the memory system fetch less than 64 B for them?
                 const uint4 *p32 = table + (line[k] * 4 + ((x >> 40) & 2));     // one of the two 32-B halves of a random 64-B line
                 v[k] = p32[0];
                 if (loadsPerLine > 11) { uint4 w = p32[1]; v[k].x ^= w.x; v[k].y ^= w.w; }
+                continue;
+            }
+            if (loadsPerLine >= 20) {                                   // 128-byte granules: both 64-B halves of a random 128-B aligned block (21: 256-B)
+                const uint4 *p128 = table + (line[k] & ~(uint64_t)(loadsPerLine > 20 ? 3 : 1)) * 4;
+                v[k] = p128[0];
+                uint4 w = p128[4]; v[k].x ^= w.x; v[k].y ^= w.w;
+                if (loadsPerLine > 20) { uint4 w2 = p128[8], w3 = p128[12]; v[k].z ^= w2.x ^ w3.y; }
                 continue;
             }
             const uint4 *p = table + line[k] * 4;
@@ -769,3 +776,14 @@ void launchGatherProbe(const uint4 *table, uint64_t nLines, uint32_t blocks, uin
 }
 
 }  // namespace s3
+
+// The HIP runtime loads a file's code object when one of its kernels is first launched: 10 to 70 ms each (the files that instantiate rocPRIM sorts are the
+// large ones), with every other thread's launches waiting -- 0.17 s of the first ladder of a process, device idle (profiles/README_r06.md section 8).
+// s3_index_upload runs this on a thread of its own while the index goes up: one kernel per file is asked for its attributes, which loads the file's code object.
+void s3::preloadKernels()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)saExpandKernel);
+    (void)hipGetLastError();
+    preloadFirst(); preloadUnit(); preloadCe(); preloadApi(); preloadLadder(); preloadFlank(); preloadPair(); preloadRoute(); preloadSeed(); preloadDp(); preloadDpApi();
+}

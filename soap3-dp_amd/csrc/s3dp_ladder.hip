@@ -593,6 +593,16 @@ static int ensurePairBuffers(s3_batch *b)
     return S3_OK;
 }
 
+// The segmented sort of the pairs' occurrence keys (64-bit key, 32-bit value).  rocPRIM's default configuration for gfx950 (no tuned entry) spills: 248 VGPRs
+// and 148 bytes of SCRATCH per lane, and the first kernel with scratch on a HIP stream costs a reallocation of the device's scratch buffer with every queue
+// drained (s3dp_api.hip, ListedSortConfig).  256 threads x 8 items: 194 VGPRs, no scratch.
+using PairSortConfig = rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<256, 8>, rocprim::WarpSortConfig<32, 4, 256, 3000, 32, 4, 256>, true>;
+static hipError_t sortSegments(void *temp, size_t &bytes, const uint64_t *keysIn, uint64_t *keysOut, const uint32_t *valsIn, uint32_t *valsOut, uint32_t items,
+                               uint32_t segments, const uint32_t *segBegin, const uint32_t *segEnd, unsigned beginBit, unsigned endBit, hipStream_t s)
+{
+    return rocprim::segmented_radix_sort_pairs<PairSortConfig>(temp, bytes, keysIn, keysOut, valsIn, valsOut, items, segments, segBegin, segEnd, beginBit, endBit, s);
+}
+
 static int ensureSortBuffers(s3_batch *b, size_t items, int segments)
 {
     int rc;
@@ -606,8 +616,7 @@ static int ensureSortBuffers(s3_batch *b, size_t items, int segments)
         b->sortItems = cap;
     }
     size_t tb = 0;
-    HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb, b->dSortKeys[0], b->dSortKeys[1], b->dOccMeta, b->dSortMeta, (int)items, segments,
-                                                       b->dSegBegin, b->dSegEnd, 0, 64, b->stream));
+    HIPCHK(sortSegments(nullptr, tb, b->dSortKeys[0], b->dSortKeys[1], b->dOccMeta, b->dSortMeta, (uint32_t)items, (uint32_t)segments, b->dSegBegin, b->dSegEnd, 0, 64, b->stream));
     if (tb > b->sortTempBytes) {
         const size_t cap = tb + tb / 2 + 256;
         if (b->sortTempBytes == 0) { if ((rc = balloc(b, &b->dSortTemp, cap))) return rc; }
@@ -701,8 +710,8 @@ extern "C" int s3_batch_align_pair(s3_batch *b, uint32_t numMismatch, uint32_t m
             sa.keys = b->dSortKeys[0];
             launchPairSortKeys(sa, b->stream);
             size_t tb = b->sortTempBytes;
-            HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(b->dSortTemp, tb, b->dSortKeys[0], b->dSortKeys[1], b->dOccMeta + regionBase, b->dSortMeta,
-                                                               (int)items, (int)(2 * nA), b->dSegBegin, b->dSegEnd, 0, (int)(32u + sa.idxBits), b->stream));
+            HIPCHK(sortSegments(b->dSortTemp, tb, b->dSortKeys[0], b->dSortKeys[1], b->dOccMeta + regionBase, b->dSortMeta, (uint32_t)items, 2u * nA, b->dSegBegin,
+                                b->dSegEnd, 0, 32u + sa.idxBits, b->stream));
             launchPairSortBack(sa, b->dSortKeys[1], b->dSortMeta, b->stream);
         }
         launchPairSnapshotCounts(nA, active, b->dOccCount, b->dOccCountIn, b->stream);
@@ -844,3 +853,6 @@ extern "C" int s3_batch_fetch_pair_origins(s3_batch *b, uint8_t *fromSaRange, si
     for (uint32_t i = 0; i < total; i++) fromSaRange[i] = (uint8_t)((meta[i] >> 16) & 1u);
     return S3_OK;
 }
+
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadLadder() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)iotaKernel); (void)hipGetLastError(); }

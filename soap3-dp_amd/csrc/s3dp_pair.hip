@@ -466,3 +466,6 @@ void launchPairGatherXa(uint32_t nPairs, const uint32_t *xaStart, const uint32_t
 }
 
 }  // namespace s3
+
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadPair() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)s3::pairExpandKernel); (void)hipGetLastError(); }

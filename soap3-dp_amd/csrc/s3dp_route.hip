@@ -302,3 +302,6 @@ extern "C" int s3_batch_fetch_kept(s3_batch *b, const uint32_t *reads, size_t nR
     *occOut = res;
     return S3_OK;
 }
+
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadRoute() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)routeCountKernel); (void)hipGetLastError(); }

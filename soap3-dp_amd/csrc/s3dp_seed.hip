@@ -478,3 +478,6 @@ extern "C" int s3_seed_candidates(s3_batch *reads, s3_batch *seedBatch, const ui
     if (nSeedsOut) *nSeedsOut = nSeeds;
     return S3_OK;
 }
+
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadSeed() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)seedPackKernel); (void)hipGetLastError(); }

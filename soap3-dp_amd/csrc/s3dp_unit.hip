@@ -778,3 +778,6 @@ void launchUnitChains(const SearchOut &out, uint32_t unitBase, uint32_t nUnits, 
 }
 
 }  // namespace s3
+
+// one kernel of this file's code object, asked for its attributes: the runtime loads a code object at the first use of one of its kernels (preloadKernels, s3dp_kernels.hip)
+void s3::preloadUnit() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, (const void *)s3::unitKernel<true, false>); (void)hipGetLastError(); }

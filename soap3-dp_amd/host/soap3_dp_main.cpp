@@ -834,6 +834,18 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
                     }
             }
         });
+    // single reads with the DP stages off go through a stream of batches (below): the pinned host staging of its slots is made NOW, while the index files are
+    // read -- the runtime starts no kernel while it pins, and three slots pinning their 256 MB of occurrence lists in the first batches of a run kept the
+    // device idle for 0.2 s (S3DP_STAGING_OCC_PER_READ, default 48 entries per read and list; 0: the slots pin what they need when they need it)
+    const int streamDepth = getenv("S3DP_STREAM_DEPTH") && atoi(getenv("S3DP_STREAM_DEPTH")) > 0 ? atoi(getenv("S3DP_STREAM_DEPTH")) : 3;
+    if (!paired && !enableDP && !shared.loaded) {
+        const long occPerRead = getenv("S3DP_STAGING_OCC_PER_READ") ? atol(getenv("S3DP_STAGING_OCC_PER_READ")) : 48;
+        uint32_t w16 = 1;
+        while (w16 < (uint32_t)maxReadLength) w16 *= 2;
+        const uint32_t wpqGuess = w16 / 16 ? w16 / 16 : 1;                          // (words per read as ReadChunker::next packs them)
+        if (occPerRead > 0 && (size_t)chunkReads * (size_t)occPerRead * 8 * (size_t)streamDepth <= ((size_t)3 << 30))
+            preDpThreads.emplace_back([=] { (void)s3_host_staging_reserve(chunkReads, wpqGuess, streamDepth, (uint32_t)occPerRead); });
+    }
     if (!shared.loaded) {
         printf("[Main] loading index into host...\n");
         if (!loadIndex(indexName, hix, err)) return dieJoin(err);
@@ -963,7 +975,6 @@ static int runJob(int argc, char **argv, SharedIndex &shared)
         // three batches in flight (S3DP_STREAM_DEPTH).  The library alone runs 1 Mi-read batches faster six deep (0.85 of the resident rate against 0.75,
         // bench.py's streamed figure); behind the loader and the formatter three are faster (20 M reads, repeat-rich genome: 1.6 s against 2.2; uniform:
         // 0.87 against 1.1 -- profiles/r03_e2e_depth_queues.txt)
-        const int streamDepth = getenv("S3DP_STREAM_DEPTH") && atoi(getenv("S3DP_STREAM_DEPTH")) > 0 ? atoi(getenv("S3DP_STREAM_DEPTH")) : 3;
         if (s3_stream_create(ix, cap, chunk->wpq, streamDepth, &st) != S3_OK) return dieJoin(s3_last_error());
         mark("stream created");
         struct InFlight { std::mutex mu; std::condition_variable cv; std::deque<std::unique_ptr<ReadSet>> q; bool done = false; } fl;

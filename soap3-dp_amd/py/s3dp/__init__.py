@@ -50,7 +50,7 @@ EXPORTS = ["s3_index_upload", "s3_index_free", "s3_index_device_bytes", "s3_inde
            "s3_batch_search", "s3_batch_fetch_hits", "s3_batch_align_single_allbest", "s3_batch_align_single", "s3_batch_set_seed_lengths", "s3_batch_align_pair", "s3_batch_fetch_pairs", "s3_batch_fetch_pair_origins", "s3_batch_route_pairs", "s3_batch_no_pair_result", "s3_batch_fetch_routing", "s3_batch_fetch_kept", "s3_dp_new_default_routed", "s3_dp_stage_parameters", "s3_seed_positions", "s3_dp_half_end", "s3_seed_candidates", "s3_dp_single_end", "s3_dp_deep", "s3_dp_new_default", "s3_batch_fetch_alignments", "s3_batch_sync", "s3_batch_last_ce_timing",
            "s3_batch_last_timing", "s3_batch_set_grid", "s3_batch_kernel_stats", "s3_batch_counters", "s3_batch_enable_counters", "s3_bwt_search", "s3_free", "s3_model_describe",
            "s3_device_count", "s3_device_host_node", "s3_last_error", "s3_version", "s3_probe_gather", "s3_probe_copy", "s3_dp_totals",
-           "s3_stream_create", "s3_stream_acquire", "s3_stream_submit", "s3_stream_next", "s3_stream_release", "s3_stream_free",
+           "s3_stream_create", "s3_stream_acquire", "s3_stream_submit", "s3_stream_next", "s3_stream_release", "s3_stream_free", "s3_host_staging_reserve", "s3_host_staging_release",
            "s3_group_create", "s3_group_size", "s3_group_device", "s3_group_index", "s3_group_member_of_batch", "s3_group_allreduce", "s3_group_free"]
 
 _lib = None
@@ -113,6 +113,19 @@ def probe_gather(table_bytes, blocks=256 * 8, iters=256, ilp=4, loads_per_line=2
     f.argtypes = [C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     _chk(f(device, table_bytes, blocks, iters, ilp, loads_per_line, dependent, repeats, C.byref(ms), C.byref(lines)))
     return ms.value, lines.value
+
+
+def host_staging_reserve(max_reads, word_per_query, depth, occ_per_read):
+    """pinned host blocks for the staging of a stream's slots, made ahead of time (include/s3dp.h: s3_host_staging_reserve)"""
+    f = lib().s3_host_staging_reserve
+    f.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
+    _chk(f(max_reads, word_per_query, depth, occ_per_read))
+
+
+def host_staging_release():
+    f = lib().s3_host_staging_release
+    f.restype = None
+    f()
 
 
 def probe_copy(nbytes, repeats=4, device=0):

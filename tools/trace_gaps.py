@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Device occupancy from a rocprofv3 --kernel-trace csv: how long the device ran at least one kernel, how many kernels ran at once (time-weighted), the
 idle gaps (none running) with the kernels before and after the longest ones, and per kernel name its summed and exclusive share.
-    tools/trace_gaps.py <kernel_trace.csv> [t0_fraction t1_fraction]"""
+    tools/trace_gaps.py <kernel_trace.csv> [t0_fraction t1_fraction]
+    tools/trace_gaps.py <kernel_trace.csv> from <part of a kernel name>      (the window starts at the first kernel of that name)"""
 import csv
 import sys
 import collections
@@ -11,7 +12,10 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-60:]))
 rows.sort()
 lo, hi = rows[0][0], max(r[1] for r in rows)
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[2] == "from":
+    lo = min(r[0] for r in rows if sys.argv[3] in r[2])
+    rows = [r for r in rows if r[1] > lo]
+elif len(sys.argv) > 3:
     span = hi - lo
     lo, hi = lo + int(float(sys.argv[2]) * span), lo + int(float(sys.argv[3]) * span)
     rows = [r for r in rows if r[1] > lo and r[0] < hi]
@@ -43,6 +47,9 @@ gaps.sort(reverse=True)
 print("idle gaps: %d, summed %.3f s; > 100 us: %d summing %.3f s; > 1 ms: %d summing %.3f s" % (
     len(gaps), sum(g[0] for g in gaps) / 1e9, sum(1 for g in gaps if g[0] > 1e5), sum(g[0] for g in gaps if g[0] > 1e5) / 1e9,
     sum(1 for g in gaps if g[0] > 1e6), sum(g[0] for g in gaps if g[0] > 1e6) / 1e9))
+print("the gaps above 1 ms, in time order (offset in the window, length, the kernel that ended before):")
+for g in sorted((g for g in gaps if g[0] > 1e6), key=lambda g: g[1]):
+    print("  at %8.1f ms  %7.2f ms  %s" % ((g[1] - lo) / 1e6, g[0] / 1e6, g[2]))
 after = collections.Counter()
 for g in gaps:
     after[g[2]] += g[0]
