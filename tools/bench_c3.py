@@ -33,9 +33,13 @@ def main():
     else:
         hi = builder.build_host_index(codes.cpu().numpy(), device=dev, verbose=False)
     ix = s3dp.Index(hi, device=0)
-    res = bench.c3_leg(s3dp, ix, hi, codes, dev, a.pairs, workdir=a.workdir, echo=True)
-    print(json.dumps(res))
+    # (the command line runs after this process's own copy of the index is closed: two copies of a 219 GB index do not fit one device)
+    res, cli = bench.c3_leg(s3dp, ix, hi, codes, dev, a.pairs, workdir=a.workdir, echo=True, defer_cli=True)
     ix.close()
+    del codes
+    torch.cuda.empty_cache()
+    res = cli()
+    print(json.dumps(res))
 
 
 if __name__ == "__main__":
