@@ -430,12 +430,12 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         // ---------- issue ----------
         const uint32_t q16 = lane & 3u, q4 = lane >> 2;
         const uint32_t ownLo = (uint32_t)(uintptr_t)ownLine, ownHi = (uint32_t)((uintptr_t)ownLine >> 32);
-        auto quadLine = [&](uint32_t owner) -> const uint4 * {
+        auto quadLine = [&](uint32_t owner) -> uint4 {
             const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownLo);
             const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownHi);
-            return (const uint4 *)(((uintptr_t)hi << 32) | lo) + q16;
+            return loadGlobal16(lo, hi, q16 * 16u);
         };
-        const uint4 va0 = *quadLine(q4), va1 = *quadLine(16u + q4), va2 = *quadLine(32u + q4), va3 = *quadLine(48u + q4);
+        const uint4 va0 = quadLine(q4), va1 = quadLine(16u + q4), va2 = quadLine(32u + q4), va3 = quadLine(48u + q4);
         const uint4 p0 = *aP0, p1 = *aP1, pT = *aPT;
         const uint32_t d0 = *aD0, d1 = *aD1, d2 = *aD2, d3 = *aD3;
         // the queue (wave-uniform branches)
@@ -573,12 +573,12 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (stepping) stepAsk(iL, iR, needB, dir, ownLine, aP0, aP1, aD0);
             const uint32_t q16 = lane & 3u, q4 = lane >> 2;
             const uint32_t ownLo = (uint32_t)(uintptr_t)ownLine, ownHi = (uint32_t)((uintptr_t)ownLine >> 32);
-            auto quadLine = [&](uint32_t owner) -> const uint4 * {
+            auto quadLine = [&](uint32_t owner) -> uint4 {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownLo);
                 const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner * 4u), (int)ownHi);
-                return (const uint4 *)(((uintptr_t)hi << 32) | lo) + q16;
+                return loadGlobal16(lo, hi, q16 * 16u);
             };
-            const uint4 va0 = *quadLine(q4), va1 = *quadLine(16u + q4), va2 = *quadLine(32u + q4), va3 = *quadLine(48u + q4);
+            const uint4 va0 = quadLine(q4), va1 = quadLine(16u + q4), va2 = quadLine(32u + q4), va3 = quadLine(48u + q4);
             const uint4 p0 = *aP0, p1 = *aP1;
             const uint32_t d0 = *aD0;
             stage[(q4) * 4u + q16] = va0;

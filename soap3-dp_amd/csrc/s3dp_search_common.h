@@ -52,6 +52,19 @@ constexpr uint32_t ID_NONE = 0x7FFFFFFFu;
 constexpr uint32_t ID_TEXT = 0x40000000u;                 // cooperative line ids: bit 31 = reverse BWT, ID_TEXT | k = 64-byte line k of the packed text
 constexpr int STACK = 20;
 
+// 16 bytes from an address put together out of two 32-bit halves (the owner's line address travels by ds_bpermute): said to be GLOBAL memory.  A pointer made
+// from integers is a generic one, and the compiler then issues FLAT loads -- which count on the LDS counter too, so the wait for the next ds_bpermute behind the
+// first of the trip's four line loads LOOKED like a wait for that load in the ISA.  Measured (round 6): no difference -- the hardware takes a flat load that turns
+// out to be global off the LDS counter at once -- but the global form needs no 64-bit additions and keeps the trip's waits on the memory counter alone.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// (byteOff < 64 and the address is that of a 64-byte line: the offset is OR-ed into the low half, no 64-bit addition)
+__device__ __forceinline__ uint4 loadGlobal16(uint32_t lo, uint32_t hi, uint32_t byteOff)
+{
+    const unsigned long long a = ((unsigned long long)hi << 32) | (lo | byteOff);
+    const u32x4_t v = *(const __attribute__((address_space(1))) u32x4_t *)a;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 struct Frame { uint32_t fl, fr, rl, meta; };        // rr = rl + (fr - fl);  meta = s | i << 3 | ins << 14 | occ << 17
 
 __device__ __forceinline__ uint64_t hiMask(uint32_t nChars) { return nChars >= 32 ? ~0ULL : (nChars == 0 ? 0ULL : (~0ULL << (64 - 2 * nChars))); }
