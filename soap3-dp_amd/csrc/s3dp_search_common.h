@@ -69,7 +69,18 @@ struct Frame { uint32_t fl, fr, rl, meta; };        // rr = rl + (fr - fl);  met
 
 __device__ __forceinline__ uint64_t hiMask(uint32_t nChars) { return nChars >= 32 ? ~0ULL : (nChars == 0 ? 0ULL : (~0ULL << (64 - 2 * nChars))); }
 __device__ __forceinline__ uint64_t loMask(uint32_t nChars) { return nChars >= 32 ? ~0ULL : ((1ULL << (2 * nChars)) - 1ULL); }
-__device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+// (two levels of selects: the chain c == 0 ? .. : c == 1 ? .. came out of the compiler as three nested branches on the execution mask -- round 6, read in the ISA of the
+//  stepping kernels, which are bound by instruction issue)
+__device__ __forceinline__ uint32_t sel4(const uint4 &v, uint32_t c)
+{
+    const uint32_t lo = (c & 1u) ? v.y : v.x, hi = (c & 1u) ? v.w : v.z;
+    return (c & 2u) ? hi : lo;
+}
+// occurrences of the symbols ABOVE c in a range whose counts of symbols 1, 2, 3 are e1, e2, e3 (what the passive range shrinks by when the step takes symbol c)
+__device__ __forceinline__ uint32_t occAbove(uint32_t c, uint32_t e1, uint32_t e2, uint32_t e3)
+{
+    return (c < 1u ? e1 : 0u) + (c < 2u ? e2 : 0u) + (c < 3u ? e3 : 0u);
+}
 __device__ __forceinline__ uint32_t pairRev(uint32_t x)   // reverse the order of the 16 2-bit characters of a word
 {
     x = __brev(x);
@@ -107,11 +118,13 @@ __device__ __forceinline__ uint4 rankFromWords(const RankSel &q, uint4 occ, uint
     uint32_t c3 = __popc(ba) + __popc(bb);
     uint32_t c2 = __popc(ha ^ ba) + __popc(hb ^ bb);
     uint32_t c1 = __popc(la ^ ba) + __popc(lb ^ bb);
-    if (q.far) { c1 += sub & 0xFFu; c2 += (sub >> 8) & 0xFFu; c3 += (sub >> 16) & 0xFFu; }
+    // (no branch on far / fwd: the precounts are masked, the sign is a factor of a 24-bit multiply-add)
+    const uint32_t pre = q.far ? sub : 0u;
+    c1 += pre & 0xFFu; c2 += (pre >> 8) & 0xFFu; c3 += (pre >> 16) & 0xFFu;
     const uint32_t c0 = q.d - c1 - c2 - c3;
+    const int sg = q.fwd ? 1 : -1;
     uint4 v = occ;
-    if (q.fwd) { v.x += c0; v.y += c1; v.z += c2; v.w += c3; }
-    else { v.x -= c0; v.y -= c1; v.z -= c2; v.w -= c3; }
+    v.x += (uint32_t)__mul24((int)c0, sg); v.y += (uint32_t)__mul24((int)c1, sg); v.z += (uint32_t)__mul24((int)c2, sg); v.w += (uint32_t)__mul24((int)c3, sg);
     return v;
 }
 

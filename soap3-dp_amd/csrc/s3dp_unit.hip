@@ -248,18 +248,23 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         // own line in LDS as words: [0..3] counts, [4..7] half before (reversed), [8..11] half after, [12] / [13] precounts
         const uint32_t offL = (qL.fwd ? 8u : 4u) + (qL.far ? 2u : 0u);
         const uint4 oL = rankFromWords(qL, occA, myStage32[offL], myStage32[offL + 1u], myStage32[12u + (qL.fwd ? 1u : 0u)]);
-        uint4 oR;
-        if (needB) oR = rankFromWords(qR, p0, qR.far ? p1.z : p1.x, qR.far ? p1.w : p1.y, d0);
-        else {
-            const uint32_t offR = (qR.fwd ? 8u : 4u) + (qR.far ? 2u : 0u);
-            oR = rankFromWords(qR, occA, myStage32[offR], myStage32[offR + 1u], myStage32[12u + (qR.fwd ? 1u : 0u)]);
-        }
+        // the right end's rank from ONE body of code whichever line it sits in: the operands are selected, not the results (two bodies in two branches ran one after the
+        // other in nearly every trip)
+        const uint32_t offR = (qR.fwd ? 8u : 4u) + (qR.far ? 2u : 0u);
+        const uint4 occR = make_uint4(needB ? p0.x : occA.x, needB ? p0.y : occA.y, needB ? p0.z : occA.z, needB ? p0.w : occA.w);   // (by component: a select of two structures goes through memory)
+        // (values first, then selects: a select between two members of a structure handed in by reference is a select of addresses, and the structure then lives in
+        //  scratch memory)
+        const uint32_t ownA = myStage32[offR], ownB = myStage32[offR + 1u], ownS = myStage32[12u + (qR.fwd ? 1u : 0u)];
+        const uint32_t p1x = p1.x, p1y = p1.y, p1z = p1.z, p1w = p1.w;
+        const uint32_t farA = qR.far ? p1z : p1x, farB = qR.far ? p1w : p1y;
+        const uint32_t waR = needB ? farA : ownA, wbR = needB ? farB : ownB, subR = needB ? d0 : ownS;
+        const uint4 oR = rankFromWords(qR, occR, waR, wbR, subR);
         if constexpr (COUNT) nRank += 2;
         const int pos = sc.start() + dir * i;
         const uint32_t ch = readChar(pos);
         // child ranges: the active range advances by rank, the passive one shrinks by the occurrences of the larger symbols
         const uint32_t e1 = oR.y - oL.y, e2 = oR.z - oL.z, e3 = oR.w - oL.w;
-        const uint32_t cOc = ch == 0 ? e1 + e2 + e3 : ch == 1 ? e2 + e3 : ch == 2 ? e3 : 0u;
+        const uint32_t cOc = occAbove(ch, e1, e2, e3);
         const uint32_t gAl = sel4(oL, ch) + 1u, gAr = sel4(oR, ch), gPr = pR - cOc;         // the continuation (the read's own character)
         doSettle = true;
         // on the trunk's path (no mismatch yet in the unit's step) at the group's last position, or at the step's last position for a first mismatch: only the
@@ -282,7 +287,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                     if (a3 && kid != 3u) push(oL.w + 1u, oR.w, pR, mKid);
                     if (a2 && kid != 2u) push(oL.z + 1u, oR.z, pR - e3, mKid);
                     if (a1 && kid != 1u) push(oL.y + 1u, oR.y, pR - (e2 + e3), mKid);
-                    const uint32_t kOc = kid == 0u ? e1 + e2 + e3 : kid == 1u ? e2 + e3 : kid == 2u ? e3 : 0u;
+                    const uint32_t kOc = occAbove(kid, e1, e2, e3);
                     aL = sel4(oL, kid) + 1u; aR = sel4(oR, kid); pR = pR - kOc;
                     ins++; i++;
                     taken = true;
