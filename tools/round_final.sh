@@ -1,6 +1,6 @@
 #!/bin/bash
 # the round's closing measurements on one GPU box: the driver's bench line, kernel statistics of the bench ladder under rocprofv3, FETCH_SIZE of the search
-# kernels (-> profiles/pmc_traffic.json).   tools/round_final.sh <outdir> [bench|stats|pmc ...]   (default: all three)
+# kernels (-> profiles/pmc_traffic.json).   tools/round_final.sh <outdir> [bench|stats|pmc ...]   (default: all three; "pmc stats bench" makes the bench line carry the counters of the same box and commit)
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-r05z}; shift; mkdir -p $O
@@ -21,6 +21,8 @@ for w in $WHAT; do
     t=$(find /tmp/prof_stats -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python3 tools/ladder_breakdown.py "$t" > $O/ladder_breakdown.txt 2>&1 && head -30 $O/ladder_breakdown.txt
     rm -rf /tmp/prof_stats ;;
   pmc)
-    S3DP_COMMIT=$(cat .commit 2>/dev/null | head -c 12) tools/ladder_pmc.sh $(basename $O) ;;
+    S3DP_COMMIT=$(cat .commit 2>/dev/null | head -c 12) tools/ladder_pmc.sh $(basename $O)
+    # (a bench stage that follows in the same call reports THIS measurement: roofline.traffic, per_kernel.fetched_bytes, traffic_measured_at_commit)
+    [ -s $O/pmc_traffic.json ] && cp $O/pmc_traffic.json profiles/pmc_traffic.json ;;
   esac
 done
