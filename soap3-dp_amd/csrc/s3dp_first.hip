@@ -57,6 +57,8 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         for (uint32_t k = threadIdx.x; k < sizeof(S3Model) / 4; k += blockDim.x) ((uint32_t *)shmem)[k] = src[k];
         __syncthreads();
     }
+    const uint32_t *padFilter = (const uint32_t *)(shmem + S3_V2_MODEL_BYTES + (S3_SEARCH_BLOCK / 64u) * waveBytes);      // behind the waves' parts (lookupPadded, s3dp_search_common.h)
+    padFilterBuild(ix, (uint32_t *)(shmem + S3_V2_MODEL_BYTES + (S3_SEARCH_BLOCK / 64u) * waveBytes));
 
     const uint32_t groups = (uint32_t)in.nCases * 2u;
     const uint32_t nListed = TRUNK ? *in.slotCount : 0u;
@@ -117,11 +119,6 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint32_t w = (uint32_t)p0 >> 4, sh = ((uint32_t)p0 & 15u) * 2u;
         const uint32_t a = oword(w), b2 = oword(w + 1u);
         return sh ? (a << sh) | (b2 >> (32u - sh)) : a;
-    };
-    auto readWindowS = [&](int p0) -> uint32_t {              // the same from any p0: characters before the read's start are 0
-        if (p0 <= -16) return 0u;
-        if (p0 < 0) return oword(0u) >> (2u * (uint32_t)(-p0));
-        return readWindow(p0);
     };
     auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
         pendMeta = 0x80000000u | seq | (kind << 24) | (nmis << 25);
@@ -383,7 +380,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
             const int ll = ix.ltSize > st.len ? st.len : ix.ltSize;            // <= 13 characters = 26 bits of one window
             const uint32_t padOnes = ll < ix.ltSize ? ((1u << (2 * (ix.ltSize - ll))) - 1u) : 0u;
             const int shPad = 2 * (ix.ltSize - ll);
-            padded = lookupPadded(ix, (int)st.type, (int)st.start, (int)st.len, readWindow);
+            padded = lookupPadded(ix, padFilter, (int)st.type, (int)st.start, (int)st.len, readWindow);
             if (ix.ltK && st.len >= ix.ltK && st.ceThr == 0) {                 // (a lookup step that may switch to check-and-extend on its way -- exact-match models -- is walked)
                 // long table (<= 16 characters): one entry holds the state behind the lookup step's first ltK characters; ltB = ~0 marks the item
                 const int K = ix.ltK;
@@ -551,7 +548,7 @@ firstKernel(DevIndex ix, SearchIn in, SearchOut out)
                         out.recs[recCur + rk] = make_uint4(TRUNK ? cntIdx | S3_REC_PASS2 : cntIdx, pendMeta & 0x7FFFFFFFu, pendA, pendB);
                         if (pendMeta & S3_REC_TASK) {
                             uint32_t q0, q1, q2;
-                            adjacentWindows((int)(pendP & 0xFFFFu), (pendP >> 16) ? 1 : -1, readWindowS, q0, q1, q2);
+                            adjacentWindows((int)(pendP & 0xFFFFu), (pendP >> 16) ? 1 : -1, oword, q0, q1, q2);
                             out.recAux[recCur + rk] = make_uint4(pendC, q0, q1, q2);
                         }
                     }
@@ -645,7 +642,7 @@ static int launchFirstOrTrunk(const DevIndex &ix, const SearchIn &in, const Sear
     if (in.nActive == 0) return (int)hipSuccess;
     uint64_t blocks = ((uint64_t)in.nActive * (TRUNK ? (uint64_t)in.nCases * 2u : 1u) + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
-    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + S3_FIRST_RDY_BYTES + 2u * in.wLds * 256u);
+    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + S3_FIRST_RDY_BYTES + 2u * in.wLds * 256u) + v2::S3_PAD_FILTER_BYTES;
     const bool count = out.counters != nullptr;
     const void *fn = in.uniformLen ? (count ? (const void *)firstKernel<true, true, TRUNK> : (const void *)firstKernel<true, false, TRUNK>)
                                    : (count ? (const void *)firstKernel<false, true, TRUNK> : (const void *)firstKernel<false, false, TRUNK>);

@@ -134,32 +134,63 @@ struct Range { uint32_t fl, fr, rl, rr; };
 // positions next to the text's ends)?  Its lookup range may then hold an element that is no occurrence, and its forward and reverse ranges need not hold the
 // same occurrences (BWTExactModelForward_Lookup2, BGS-HostAlgnmtAlgo2.cpp:349-356, makes their sizes equal by moving one end).  st = the case's step 0;
 // window(p) = 16 characters of the item's strand from position p >= 0, MSB first.
+// (Round 6: the 36 compares run behind a FILTER -- 2,048 bits in LDS, one per value of a key's low 11 bits, set for the keys of both lists by padFilterBuild at the
+//  start of a workgroup.  A key is next to never a padded one, the stepping kernels are bound by instruction issue, and this test runs at the start of every item of
+//  the first pass and of every unit: the lists themselves are walked only when some lane of the wave passes the filter.)
+constexpr uint32_t S3_PAD_FILTER_BYTES = 256u;
+__device__ __forceinline__ void padFilterBuild(const DevIndex &ix, uint32_t *filter)      // by the whole workgroup, before its first item
+{
+    for (uint32_t k = threadIdx.x; k < S3_PAD_FILTER_BYTES / 4u; k += blockDim.x) filter[k] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) { const uint32_t k = ix.padBack[j]; if (k != 0xFFFFFFFFu) filter[(k >> 5) & 63u] |= 1u << (k & 31u); }
+#pragma unroll
+        for (int j = 0; j < 24; j++) { const uint32_t k = ix.padBi[j]; if (k != 0xFFFFFFFFu) filter[(k >> 5) & 63u] |= 1u << (k & 31u); }
+    }
+    __syncthreads();
+}
 template <class W>
-__device__ __forceinline__ bool lookupPadded(const DevIndex &ix, int stType, int stStart, int stLen, W window)
+__device__ __forceinline__ bool lookupPadded(const DevIndex &ix, const uint32_t *filter, int stType, int stStart, int stLen, W window)
 {
     const int k0 = ix.ltSize;
     if (stLen < k0) return true;                                // shorter lookup steps read a whole block of entries
     const uint32_t m13 = (1u << (2 * k0)) - 1u;
+    const bool back = stType == S3_T_BACK_LOOKUP;
+    const uint32_t key = back ? (window(stStart - k0 + 1) >> (32 - 2 * k0)) & m13 : pairRev(window(stStart)) & m13;
     bool padded = false;
-    if (stType == S3_T_BACK_LOOKUP) {
-        const uint32_t k13 = (window(stStart - k0 + 1) >> (32 - 2 * k0)) & m13;
+    if ((filter[(key >> 5) & 63u] >> (key & 31u)) & 1u) {
+        if (back) {
 #pragma unroll
-        for (int j = 0; j < 12; j++) padded |= k13 == ix.padBack[j];
-    } else {
-        const uint32_t r13 = pairRev(window(stStart)) & m13;
+            for (int j = 0; j < 12; j++) padded |= key == ix.padBack[j];
+        } else {
 #pragma unroll
-        for (int j = 0; j < 24; j++) padded |= r13 == ix.padBi[j];
+            for (int j = 0; j < 24; j++) padded |= key == ix.padBi[j];
+        }
     }
     return padded;
 }
 
-// the 48 characters of a read next to the matched part of a task (position `pos` = the next one to compare, direction dir), the adjacent one first; windowS(p) =
-// 16 characters from position p, which may be negative (characters before the read's start read as 0: they never count, ceKernel compares inside the step)
+// the 48 characters of a read next to the matched part of a task (position `pos` = the next one to compare, direction dir), the adjacent one first; word(w) =
+// word w of the item's strand, 16 characters MSB first, 0 for w outside the read (w comes as an unsigned number: the words "before" the read are huge indices) --
+// characters before the read's start read as 0: they never count, ceKernel compares inside the step.
+// (Round 6: the 48 characters are ONE stretch of the read -- [pos, pos + 48) forward, [pos - 47, pos] backward: four words, three funnel shifts, and for a backward step
+//  the three windows reversed and in reverse order.  It used to be three windows cut out one by one in each direction: 250 vector instructions of every full trip that
+//  writes a task record, a quarter of the first pass's full trip.)
 template <class W>
-__device__ __forceinline__ void adjacentWindows(int pos, int dir, W windowS, uint32_t &q0, uint32_t &q1, uint32_t &q2)
+__device__ __forceinline__ void adjacentWindows(int pos, int dir, W word, uint32_t &q0, uint32_t &q1, uint32_t &q2)
 {
-    if (dir > 0) { q0 = windowS(pos); q1 = windowS(pos + 16); q2 = windowS(pos + 32); }
-    else { q0 = pairRev(windowS(pos - 15)); q1 = pairRev(windowS(pos - 31)); q2 = pairRev(windowS(pos - 47)); }
+    const int P = dir > 0 ? pos : pos - 47;                          // first character of the stretch (may be negative)
+    const int wb = P >> 4;                                           // floor(P / 16)
+    const uint32_t sh = ((uint32_t)P & 15u) * 2u;
+    const uint32_t w0 = word((uint32_t)wb), w1 = word((uint32_t)(wb + 1)), w2 = word((uint32_t)(wb + 2)), w3 = word((uint32_t)(wb + 3));
+    // 16 characters from character (P & 15) of {hi, lo}: the pair shifted right by 32 - sh, low half (sh == 0: hi itself)
+    const uint32_t a = sh ? __builtin_amdgcn_alignbit(w0, w1, 32u - sh) : w0;
+    const uint32_t b = sh ? __builtin_amdgcn_alignbit(w1, w2, 32u - sh) : w1;
+    const uint32_t c = sh ? __builtin_amdgcn_alignbit(w2, w3, 32u - sh) : w2;
+    const bool fw = dir > 0;
+    const uint32_t ra = pairRev(a), rb = pairRev(b), rc = pairRev(c);
+    q0 = fw ? a : rc; q1 = fw ? b : rb; q2 = fw ? c : ra;
 }
 
 // the model step a lane is in, as the five words of S3Step with the check-and-extend threshold moved into the (unused) type byte

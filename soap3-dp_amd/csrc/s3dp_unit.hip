@@ -72,6 +72,8 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         for (uint32_t k = threadIdx.x; k < sizeof(S3Model) / 4; k += blockDim.x) ((uint32_t *)shmem)[k] = src[k];
         __syncthreads();
     }
+    const uint32_t *padFilter = (const uint32_t *)(shmem + S3_V2_MODEL_BYTES + (S3_SEARCH_BLOCK / 64u) * waveBytes);      // behind the waves' parts (lookupPadded, s3dp_search_common.h)
+    padFilterBuild(ix, (uint32_t *)(shmem + S3_V2_MODEL_BYTES + (S3_SEARCH_BLOCK / 64u) * waveBytes));
 
     const uint32_t groups = (uint32_t)in.nCases * 2u;
     const uint32_t nListed = *in.slotCount;
@@ -136,11 +138,6 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
         const uint32_t w = (uint32_t)p0 >> 4, sh = ((uint32_t)p0 & 15u) * 2u;
         const uint32_t a = oword(w), b2 = oword(w + 1u);
         return sh ? (a << sh) | (b2 >> (32u - sh)) : a;
-    };
-    auto readWindowS = [&](int p0) -> uint32_t {              // the same from any p0: characters before the read's start are 0
-        if (p0 <= -16) return 0u;
-        if (p0 < 0) return oword(0u) >> (2u * (uint32_t)(-p0));
-        return readWindow(p0);
     };
     auto emit = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t nmis) {
         pendMeta = 0x80000000u | seq | (kind << 24) | (nmis << 25);
@@ -526,7 +523,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
             if (loadOff >= wl || loadOff >= wpq) {
                 {
                     const uint32_t *l0 = stepPtr(0);                                  // the case's lookup step: start (low half of word 0), len (high half of word 2), type (byte 1 of word 3)
-                    if (lookupPadded(ix, (int)(int8_t)((l0[3] >> 8) & 0xFFu), (int)(int16_t)(l0[0] & 0xFFFFu), (int)l0[2] >> 16, readWindow)) subN |= 1u << 16;
+                    if (lookupPadded(ix, padFilter, (int)(int8_t)((l0[3] >> 8) & 0xFFu), (int)(int16_t)(l0[0] & 0xFFFFu), (int)l0[2] >> 16, readWindow)) subN |= 1u << 16;
                 }
                 loadStepCache();
                 {
@@ -586,7 +583,7 @@ unitKernel(DevIndex ix, SearchIn in, SearchOut out)
                         out.recs[recCur + rk] = make_uint4(cntIdx | S3_REC_PASS2, pendMeta & 0x7FFFFFFFu, pendA, pendB);
                         if (pendMeta & S3_REC_TASK) {
                             uint32_t q0, q1, q2;
-                            adjacentWindows((int)(pendP & 0xFFFFu), (pendP >> 16) ? 1 : -1, readWindowS, q0, q1, q2);
+                            adjacentWindows((int)(pendP & 0xFFFFu), (pendP >> 16) ? 1 : -1, oword, q0, q1, q2);
                             out.recAux[recCur + rk] = make_uint4(pendC, q0, q1, q2);
                         }
                     }
@@ -741,7 +738,7 @@ int launchUnitPass(const DevIndex &ix, const SearchIn &in, const SearchOut &out,
     if (in.nActive == 0) return (int)hipSuccess;
     uint64_t blocks = ((uint64_t)in.nActive * (uint64_t)in.nCases * 2u * in.unitsPerItem + S3_SEARCH_BLOCK - 1) / S3_SEARCH_BLOCK;
     if (blocks > maxBlocks) blocks = maxBlocks;
-    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + S3_UNIT_RDY_BYTES + in.wLds * 256u);
+    const size_t lds = S3_V2_MODEL_BYTES + (size_t)(S3_SEARCH_BLOCK / 64) * (4096u + S3_UNIT_RDY_BYTES + in.wLds * 256u) + v2::S3_PAD_FILTER_BYTES;
     const bool count = out.counters != nullptr;
     using Kern = void (*)(DevIndex, SearchIn, SearchOut);
     static const Kern kerns[4] = {unitKernel<false, false>, unitKernel<false, true>, unitKernel<true, false>, unitKernel<true, true>};
