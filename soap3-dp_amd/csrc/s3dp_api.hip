@@ -572,7 +572,7 @@ extern "C" int s3_batch_create(s3_index *ix, uint32_t maxReads, uint32_t wordPer
     int rc;
 #define BA(p, cnt) if ((rc = balloc(b, &b->p, (cnt)))) { s3_batch_free(b); return rc; }
     BA(dQueries, roundUp * wordPerQuery); BA(dLens, roundUp); BA(dSeedLens, roundUp); BA(dReadsT, roundUp * 2 * wordPerQuery + 16);
-    BA(dRecs, recCap); BA(dRecAux, recCap); BA(dOrdered, recCap); BA(dOrdValid, recCap + 8); b->ordCap = recCap;     // (+ 8: the long merge / decode kernels read the bytes eight at a time)
+    BA(dRecs, recCap); BA(dRecAux, recCap); BA(dOrdIdx, recCap); BA(dOrdValid, recCap + 8); b->ordCap = recCap;     // (+ 8: the long merge / decode kernels read the bytes eight at a time)
     BA(dRecCount, 4); BA(dFlags, 4); BA(dCounters, S3_COUNTER_WORDS); BA(dWorkHead, 2); BA(dTaskRange, 4); BA(dSum64, 2);
     BA(dItemCounts, b->maxItems + 1); BA(dItemOffsets, b->maxItems + 1);
     BA(dWasHeavy, (size_t)maxReads + 64); BA(dHeavyFlags, (size_t)maxReads + 64); BA(dHeavyList, (size_t)maxReads + 64); BA(dHeavyCount, 4); BA(dHeavyIndex, (size_t)maxReads + 64);
@@ -1082,10 +1082,10 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     {
         // sequence numbers include the rejected check-and-extend candidates: the ordered array can need more slots than there are records
         if (slots > b->ordCap) {
-            size_t cap = (size_t)slots + slots / 8 + 65536;               // (not doubled: at 16 B per sequence number this is the batch's largest buffer)
+            size_t cap = (size_t)slots + slots / 8 + 65536;               // (not doubled: with its validity bytes, 5 B per sequence number of the pass -- 16 B copies of the records until round 6)
             if (cap > kMaxEntries) cap = kMaxEntries;
             if (slots > cap) return fail(S3_EOVERFLOW, "ordering buffer overflow at the 32-bit limit");
-            int rc = bgrow(b, &b->dOrdered, cap, 0);
+            int rc = bgrow(b, &b->dOrdIdx, cap, 0);
             if (rc) return rc;
             if ((rc = bgrow(b, &b->dOrdValid, cap + 8, 0))) return rc;
             b->ordCap = (uint32_t)cap;
@@ -1094,14 +1094,14 @@ int s3i::searchPass(s3_batch *b, const uint32_t *active, uint32_t nActive, uint3
     // nine in ten sequence numbers belong to rejected check-and-extend candidates: the holes are a zero BYTE each (they used to be 16-byte entries written
     // by a fill pass and read back by merge and decode: 31 GB per ladder of the benchmark, three times)
     if (slots) HIPCHK(hipMemsetAsync(b->dOrdValid, 0, slots, b->stream));
-    launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdered, b->dOrdValid, b->dHeavyFlags, b->dHeavyList, (uint32_t)nCases * 2u, in.unitBase, in.unitsPerItem,
+    launchScatter(b->dRecs, b->dRecCount, b->recCap, b->dItemOffsets, b->dOrdIdx, b->dOrdValid, b->dHeavyFlags, b->dHeavyList, (uint32_t)nCases * 2u, in.unitBase, in.unitsPerItem,
                   b->scatterDyn, b->stream);
     // what the merge / decode kernels need to find a read's slice of the ordered array (kept for the decode calls that follow this pass)
     b->mergeUnitBase = in.unitBase; b->mergeUnitsPerRead = nHeavy ? (uint32_t)nCases * 2u * in.unitsPerItem : 0u;
     // the long-read list of the merge kernels shares the buffer of the heavy list, which the scatter above still reads: a second list
     
     MergeArgs m{};
-    m.nActive = nActive; m.nCases = (uint32_t)nCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered; m.valid = b->dOrdValid;
+    m.nActive = nActive; m.nCases = (uint32_t)nCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordIdx = b->dOrdIdx; m.recs = b->dRecs; m.valid = b->dOrdValid;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     m.longList = b->dLongList; m.longCount = b->dLongCount;
     m.heavyFlags = b->mergeUnitsPerRead ? b->dHeavyFlags : nullptr; m.heavyIndex = b->dHeavyIndex; m.unitBase = b->mergeUnitBase; m.unitsPerRead = b->mergeUnitsPerRead;
@@ -1145,7 +1145,7 @@ extern "C" int s3_batch_search(s3_batch *b, uint32_t numMismatch, uint32_t maxOu
     size_t tb = b->tempBytes;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dKept, b->dHitOffsets, (int)(b->n + 1), b->stream));
     MergeArgs m{};
-    m.nActive = b->n; m.nCases = b->lastNumCases; m.maxOut = maxOutputPerRead; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered; m.valid = b->dOrdValid;
+    m.nActive = b->n; m.nCases = b->lastNumCases; m.maxOut = maxOutputPerRead; m.itemOffsets = b->dItemOffsets; m.ordIdx = b->dOrdIdx; m.recs = b->dRecs; m.valid = b->dOrdValid;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     m.heavyFlags = b->mergeUnitsPerRead ? b->dHeavyFlags : nullptr; m.heavyIndex = b->dHeavyIndex; m.unitBase = b->mergeUnitBase; m.unitsPerRead = b->mergeUnitsPerRead;
     if (!b->dHits) { int rc2 = balloc(b, &b->dHits, b->recCap); if (rc2) return rc2; }

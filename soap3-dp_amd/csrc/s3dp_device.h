@@ -148,7 +148,11 @@ struct DevHit { uint32_t a, b, meta; };       // binary-identical to s3_hit (kin
 struct MergeArgs {
     uint32_t        nActive, nCases, maxOut;
     const uint32_t *itemOffsets;
-    const uint4    *ordered;
+    // (round 6: the ordered array holds the NUMBER of the record that was scattered to a slot, not a copy of it -- 4 B per sequence number of a pass instead of 16: nine
+    //  in ten sequence numbers belong to rejected check-and-extend candidates, and at 16 B each the array was what pushed the flank tables out of HBM on repeat-heavy
+    //  batches; a slot is read only where its validity byte says a record sits)
+    const uint32_t *ordIdx;
+    const uint4    *recs;
     const uint8_t  *valid;        // one byte per slot of `ordered`: 1 = a record was scattered there (the rest: sequence numbers of rejected check-and-extend candidates)
     uint32_t       *keptRecs, *occCounts, *ceCounts, *totalOcc, *withError;
     const uint8_t  *decodeMask;   // optional per-slot state; only slots with state == decodeWant are decoded
@@ -206,7 +210,7 @@ void launchCheckExtend(const DevIndex &ix, const SearchIn &in, const SearchOut &
 int  launchFlankTables(DevIndex &d, int which, size_t reserveBytes, void **allocs, int *nAllocs, size_t *bytes, bool verbose, hipStream_t s);   // s3dp_flank.hip; returns a hipError_t as int
 int  launchLongLookup(DevIndex &d, int extra, uint2 **backOut, uint4 **biOut, hipStream_t s);   // allocates the two tables (hipMalloc), returns a hipError_t as int
 struct ScatterDyn { const uint32_t *owner, *local; uint32_t base, cap; };          // the counters of adopted frames (SearchOut::dynOwner / dynLocal / dynBase / dynCap)
-void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, uint8_t *valid, const uint8_t *heavyFlags,
+void launchScatter(uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint32_t *ordIdx, uint8_t *valid, const uint8_t *heavyFlags,
                    const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, ScatterDyn dyn, hipStream_t s);
 void launchMergeCount(const MergeArgs &a, hipStream_t s);
 void launchMergeFill(const MergeArgs &a, const uint32_t *hitOffsets, DevHit *hits, hipStream_t s);

@@ -62,9 +62,10 @@ struct s3_batch {
     bool longMode = false;          // seed lengths set: the reference's long-read mode
     uint32_t fullUniformLen = 0;
     // search / ordering work buffers
-    uint4    *dRecs = nullptr, *dOrdered = nullptr;
+    uint4    *dRecs = nullptr;
+    uint32_t *dOrdIdx = nullptr;                     // the ordered array: per sequence number of a pass the number of the record scattered there (MergeArgs::ordIdx)
     uint4    *dRecAux = nullptr;                      // SearchOut::recAux: 16 B per slot of dRecs
-    uint8_t  *dOrdValid = nullptr;                    // per slot of dOrdered: holds a record (round 4: the holes are no longer written and read as 16-byte entries)
+    uint8_t  *dOrdValid = nullptr;                    // per slot of dOrdIdx: holds a record (round 4: the holes are no longer written and read as 16-byte entries)
     uint32_t *dRecCount = nullptr, *dFlags = nullptr, *dItemCounts = nullptr, *dItemOffsets = nullptr, *dTaskRange = nullptr;
     unsigned long long *dCounters = nullptr, *dWorkHead = nullptr;
     unsigned long long *dSum64 = nullptr;            // 64-bit total next to a 32-bit scan (sum64Async): a wrapped total must not pass as a small one

@@ -95,7 +95,8 @@ void launchSaExpand(const DevBwt &b, const uint32_t *samples, uint32_t interval,
 // ---------------------------------------------------------------------------------------------
 // ordering: records -> CSR by item (counting scatter; offsets = exclusive scan of itemCounts)
 // ---------------------------------------------------------------------------------------------
-__global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, uint8_t *valid,
+// (the slot gets the record's NUMBER; a record of the second pass is given its item back in place)
+__global__ void scatterKernel(uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint32_t *ordIdx, uint8_t *valid,
                               const uint8_t *heavyFlags, const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, ScatterDyn dyn)
 {
     uint32_t n = *recCount;
@@ -114,13 +115,13 @@ __global__ void scatterKernel(const uint4 *recs, const uint32_t *recCount, uint3
                 at = dyn.owner[at - dyn.base];
             }
             const uint32_t unit = at - unitBase;
-            r.x = heavyList[unit / (groups * unitsPerItem)] * groups + (unit / unitsPerItem) % groups;
+            recs[i].x = heavyList[unit / (groups * unitsPerItem)] * groups + (unit / unitsPerItem) % groups;
             const uint32_t dst = itemOffsets[at] + inChain + (r.y & 0xFFFFFFu);
-            ordered[dst] = r; valid[dst] = 1;
+            ordIdx[dst] = i; valid[dst] = 1;
             continue;
         } else if (heavyFlags[r.x / groups]) continue;                         // stale: the second pass searched this read again
         const uint32_t dst = itemOffsets[at] + (r.y & 0xFFFFFFu);
-        ordered[dst] = r; valid[dst] = 1;
+        ordIdx[dst] = i; valid[dst] = 1;
     }
 }
 
@@ -165,7 +166,7 @@ __global__ void mergeCountKernel(MergeArgs a)
         while (bits && total < a.maxOut) {
             const uint32_t i = w0 + (uint32_t)__ffs((int)bits) - 1u;
             bits &= bits - 1u;
-            const uint4 r = a.ordered[i];
+            const uint4 r = a.recs[a.ordIdx[i]];
             const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
             uint32_t cnt = kind ? 1u : r.w - r.z + 1u;
             if (total + cnt > a.maxOut) cnt = a.maxOut - total;
@@ -248,7 +249,7 @@ __global__ void __launch_bounds__(256) mergeCountLongKernel(MergeArgs a)
             const uint32_t V = tripRecords(cur, tb, beg, end, lane, idx);
             for (uint32_t r0 = 0; r0 < V && total < a.maxOut; r0 += 64u) {
                 const bool valid = r0 + lane < V;
-                const uint4 r = a.ordered[valid ? idx[r0 + lane] : beg];             // (a lane without a record reads a line the wave has)
+                const uint4 r = a.recs[valid ? a.ordIdx[idx[r0 + lane]] : 0u];            // (a lane without a record reads record 0: a hole's slot holds no number)
                 const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
                 // a range is never longer than maxOut can use: clamp before the prefix sum (32-bit)
                 uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;
@@ -288,7 +289,7 @@ __global__ void mergeFillKernel(MergeArgs a, const uint32_t *hitOffsets, DevHit 
     DevHit *dst = hits + hitOffsets[slot];
     for (uint32_t k = 0, i = beg; k < n; i++) {
         if (!a.valid[i]) continue;
-        const uint4 r = a.ordered[i];
+        const uint4 r = a.recs[a.ordIdx[i]];
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
         const uint32_t grp = r.x % groups;
         uint32_t lo = r.z, hi = r.w;
@@ -338,7 +339,7 @@ __global__ void decodeKernel(MergeArgs a, DevIndex ix, const uint32_t *occOffset
         if (have) {
             i = w0 + (uint32_t)__ffs((int)bits) - 1u;
             bits &= bits - 1u;
-            r = a.ordered[i];
+            r = a.recs[a.ordIdx[i]];
         }
         const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
         const uint32_t meta = (((r.x % groups) & 1u) + 1u) | nmis << 8;
@@ -390,7 +391,7 @@ __global__ void __launch_bounds__(256) decodeLongKernel(MergeArgs a, DevIndex ix
           const uint32_t V = tripRecords(cur, tb, beg, end, lane, idx);
           for (uint32_t r0 = 0; r0 < V && total < a.maxOut; r0 += 64u) {
             const bool valid = r0 + lane < V;
-            const uint4 r = a.ordered[valid ? idx[r0 + lane] : beg];
+            const uint4 r = a.recs[valid ? a.ordIdx[idx[r0 + lane]] : 0u];
             const uint32_t kind = (r.y >> 24) & 1u, nmis = (r.y >> 25) & 7u;
             uint32_t cnt = valid ? (kind ? 1u : r.w - r.z + 1u) : 0u;
             if (cnt > a.maxOut) cnt = a.maxOut;
@@ -628,10 +629,10 @@ void launchZeroListedCounts(const uint32_t *heavyList, const uint32_t *heavyCoun
     hipLaunchKernelGGL(zeroListedCountsKernel, dim3(blocks), dim3(256), 0, s, heavyList, heavyCount, groups, itemCounts);
 }
 
-void launchScatter(const uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint4 *ordered, uint8_t *valid, const uint8_t *heavyFlags,
+void launchScatter(uint4 *recs, const uint32_t *recCount, uint32_t recCap, const uint32_t *itemOffsets, uint32_t *ordIdx, uint8_t *valid, const uint8_t *heavyFlags,
                    const uint32_t *heavyList, uint32_t groups, uint32_t unitBase, uint32_t unitsPerItem, ScatterDyn dyn, hipStream_t s)
 {
-    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordered, valid, heavyFlags, heavyList, groups, unitBase, unitsPerItem, dyn);
+    hipLaunchKernelGGL(scatterKernel, dim3(2048), dim3(256), 0, s, recs, recCount, recCap, itemOffsets, ordIdx, valid, heavyFlags, heavyList, groups, unitBase, unitsPerItem, dyn);
 }
 
 void launchMergeCount(const MergeArgs &a, hipStream_t s)

@@ -344,7 +344,7 @@ static int decodeSliced(s3_batch *b, const uint32_t *active, uint32_t nActive, u
         size_t tb = b->tempBytes;
         LCHK(hipcub::DeviceScan::ExclusiveSum(b->dTemp, tb, b->dMasked, b->dOccOffsets, (int)(nActive + 1), st));
         MergeArgs m{};
-        m.nActive = nActive; m.nCases = b->lastNumCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered; m.valid = b->dOrdValid;
+        m.nActive = nActive; m.nCases = b->lastNumCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordIdx = b->dOrdIdx; m.recs = b->dRecs; m.valid = b->dOrdValid;
         m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
         m.decodeMask = dSlice; m.decodeWant = want;
         m.longList = b->dLongList; m.longCount = b->dLongCount;
@@ -411,7 +411,7 @@ int s3i::decodeAndPublish(s3_batch *b, const uint32_t *active, uint32_t nActive,
     hipLaunchKernelGGL(publishKernel, dim3((nActive + 255) / 256), dim3(256), 0, b->stream, nActive, active, b->dState, want, phase, b->dWithError,
                        b->dOccOffsets, base, b->dPhase, b->dFinalWithError, b->dOccStart, b->dOccCount);
     MergeArgs m{};
-    m.nActive = nActive; m.nCases = b->lastNumCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordered = b->dOrdered; m.valid = b->dOrdValid;
+    m.nActive = nActive; m.nCases = b->lastNumCases; m.maxOut = maxOut; m.itemOffsets = b->dItemOffsets; m.ordIdx = b->dOrdIdx; m.recs = b->dRecs; m.valid = b->dOrdValid;
     m.keptRecs = b->dKept; m.occCounts = b->dOccCounts; m.ceCounts = b->dCeCounts; m.totalOcc = b->dTotalOcc; m.withError = b->dWithError;
     m.decodeMask = b->dState; m.decodeWant = want;
     m.longList = b->dLongList; m.longCount = b->dLongCount;                // the list mergeCountKernel of this search pass wrote
