@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--repeat-frac", type=float, default=0.5)
     ap.add_argument("--index-dir", default=None)
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--no-cli", type=int, default=0, help="1: write the reads and the index files and stop (the command line is then run by the caller, e.g. under a profiler as the FIRST run on the files)")
     a = ap.parse_args()
     import torch
     import bench
@@ -38,6 +39,9 @@ def main():
     ix.close()
     del codes
     torch.cuda.empty_cache()
+    if a.no_cli:
+        print(json.dumps({"prepared": a.workdir}))
+        return
     res = cli()
     print(json.dumps(res))
 

@@ -13,6 +13,7 @@ for cfg in "$@"; do
   name=$(echo "$cfg" | tr ',=' '__')
   envs=""; [ "$cfg" != base ] && envs=$(echo "$cfg" | tr ',' ' ')
   for k in 1 2; do
+    sleep ${PAUSE:-6}      # (a process that starts while the last one's 219 GB are still being given back pays for it: tools/exit_fast_probe.sh)
     env $envs timeout 200 $CLI -o /tmp/c3w/outp > $O/${name}_$k.log 2>&1
     echo "$cfg run $k rc=$? $(grep 'Alignment + output' $O/${name}_$k.log) | $(grep 'Device time' $O/${name}_$k.log | head -1 | cut -c1-160)"
   done
